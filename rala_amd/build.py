@@ -1,0 +1,104 @@
+"""In-tree builds of the native pieces (no network, no pip).
+
+* ``build_hip()``   -> rala_amd/csrc/librala_hip.so   (hipcc --offload-arch=gfx950)
+* ``build_host()``  -> rala_amd/host/librala.so + rala_amd/host/rala (C++ host API / CLI)
+* ``build_synth()`` -> rala_amd/synth/libralasynth.so (synthetic input generator)
+* ``build_oracle()``-> oracle/_build/liboracle.so and, where /root/reference exists,
+  oracle/_ref/liboracle_ref.so (test infrastructure; building the checker is not using it)
+
+Every target is rebuilt only when a source is newer than the output.
+"""
+import os
+import shutil
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "rala_amd")
+REFERENCE = "/root/reference"
+
+
+def _stale(out, srcs):
+    if not os.path.exists(out):
+        return True
+    t = os.path.getmtime(out)
+    return any(os.path.getmtime(s) > t for s in srcs if os.path.exists(s))
+
+
+def _run(cmd, cwd=None):
+    res = subprocess.run(cmd, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("build failed: %s\n%s" % (" ".join(cmd), res.stdout))
+    return res.stdout
+
+
+def _glob(d, exts):
+    out = []
+    for base, _, files in os.walk(d):
+        for f in files:
+            if f.endswith(exts):
+                out.append(os.path.join(base, f))
+    return sorted(out)
+
+
+def hipcc():
+    for c in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def build_hip(force=False):
+    d = os.path.join(PKG, "csrc")
+    out = os.path.join(d, "librala_hip.so")
+    srcs = _glob(d, (".hip",))
+    deps = srcs + _glob(d, (".h", ".hpp")) + _glob(os.path.join(ROOT, "include"), (".h",))
+    if force or _stale(out, deps):
+        _run([hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+              "-I" + os.path.join(ROOT, "include"), "-I" + d, "-o", out] + srcs)
+    return out
+
+
+def build_synth(force=False):
+    d = os.path.join(PKG, "synth")
+    out = os.path.join(d, "libralasynth.so")
+    srcs = [os.path.join(d, "synth.cpp")]
+    if force or _stale(out, srcs):
+        _run(["g++", "-O2", "-std=c++14", "-fPIC", "-shared", "-o", out] + srcs)
+    return out
+
+
+def build_host(force=False):
+    d = os.path.join(PKG, "host")
+    srcs = _glob(d, (".cpp",))
+    if not srcs:
+        return None
+    out = os.path.join(d, "librala.so")
+    deps = srcs + _glob(d, (".hpp", ".h")) + _glob(os.path.join(ROOT, "include"), (".h",))
+    lib_srcs = [s for s in srcs if not s.endswith("main.cpp")]
+    if force or _stale(out, deps):
+        hip = build_hip()
+        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I" + os.path.join(ROOT, "include"),
+              "-I" + d, "-o", out] + lib_srcs + [hip, "-Wl,-rpath," + os.path.dirname(hip), "-lz"])
+    exe = os.path.join(d, "rala")
+    main = os.path.join(d, "main.cpp")
+    if os.path.exists(main) and (force or _stale(exe, deps)):
+        _run(["g++", "-O2", "-std=c++17", "-pthread", "-I" + d, "-o", exe, main, out,
+              "-Wl,-rpath," + d, "-Wl,-rpath," + os.path.join(PKG, "csrc")])
+    return out
+
+
+def build_oracle(force=False):
+    d = os.path.join(ROOT, "oracle")
+    if force:
+        _run(["make", "clean"], cwd=d)
+    _run(["make"], cwd=d)
+    out = [os.path.join(d, "_build", "liboracle.so")]
+    if os.path.isdir(os.path.join(REFERENCE, "src")):
+        _run(["make", "ref"], cwd=d)
+        out.append(os.path.join(d, "_ref", "liboracle_ref.so"))
+    return out
+
+
+def build_all(force=False):
+    return {"hip": build_hip(force), "synth": build_synth(force), "host": build_host(force),
+            "oracle": build_oracle(force)}
