@@ -1,0 +1,144 @@
+/*
+ * librala_hip — C ABI of the MI355X (gfx950) implementation of Rala's
+ * data-parallel hot path: pile-o-gram construction / annotation from
+ * PAF/MHAP overlaps, overlap filtering, assembly-graph edge construction and
+ * transitive-edge reduction.
+ *
+ * The reference (rvaser/rala, C++11) has no FFI; these entry points are what
+ * a binding of its hot path would call.  Each one names the reference
+ * interface it replaces (paths relative to the reference root).  All calls
+ * are blocking and are made from one host thread per context, like the
+ * reference's public API (src/graph.hpp:37-117).  Return value: 0 on success,
+ * a negative RALA_HIP_E* code otherwise; rala_hip_last_error() gives the text.
+ * No CPU fallback exists: without a usable HIP device every call fails.
+ *
+ * Data model.  Reads are numbered 0..n_reads-1 in sequence-file order
+ * (src/graph.cpp:255-259).  Overlaps are handed over as a structure of arrays
+ * in file order; a_id/b_id are read numbers (a name that is not in the
+ * sequence file is passed as RALA_HIP_NO_READ: Overlap::transmute returns
+ * false for it, src/overlap.cpp:44-47).  `length` is PAF column 11, or the
+ * larger span for MHAP (src/overlap.cpp:16,29); `strand` is 0 for '+' /
+ * equal rc flags and 1 otherwise (src/overlap.cpp:19,30).
+ */
+#ifndef RALA_HIP_H_
+#define RALA_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RALA_HIP_NO_READ 0xFFFFFFFFu
+
+enum {
+    RALA_HIP_OK = 0,
+    RALA_HIP_EDEVICE = -1,    /* HIP runtime error / no device */
+    RALA_HIP_EINVAL = -2,     /* bad argument or call order */
+    RALA_HIP_ECAPACITY = -3,  /* a fixed-capacity device list overflowed (raise via rala_hip_set_option) */
+    RALA_HIP_EFILTERED = -4,  /* "filtered all sequences" (src/graph.cpp:418-421) */
+    RALA_HIP_ENOMEM = -5
+};
+
+/* rala::OverlapType (src/overlap.hpp:27-33) */
+enum { RALA_HIP_TYPE_X = 0, RALA_HIP_TYPE_A = 1, RALA_HIP_TYPE_B = 2, RALA_HIP_TYPE_AB = 3, RALA_HIP_TYPE_BA = 4 };
+
+enum { RALA_HIP_MEM_HOST = 0, RALA_HIP_MEM_DEVICE = 1 };
+
+typedef struct rala_hip_ctx rala_hip_ctx;
+
+typedef struct rala_hip_overlaps {
+    const uint32_t* a_id;
+    const uint32_t* b_id;
+    const uint32_t* a_begin;
+    const uint32_t* a_end;
+    const uint32_t* b_begin;
+    const uint32_t* b_end;
+    const uint32_t* length;
+    const uint8_t* strand;
+} rala_hip_overlaps;
+
+/* Per-stage device time of the last rala_hip_construct / stage call, in
+ * milliseconds (HIP events on the context's stream), and host time of the
+ * sequential tail. */
+typedef struct rala_hip_timings {
+    float dedupe_ms, bucket_ms, pile_ms, classify_ms, death_ms, finish_ms, tail_host_ms, tr_ms, total_ms;
+    uint32_t pile_launches, death_rounds;
+} rala_hip_timings;
+
+/* ---- context -------------------------------------------------------------- */
+/* Replaces rala::createGraph's resource set-up (src/graph.cpp:184-238: parsers,
+ * thread pool, logger) — here: device selection, one HIP stream, device arenas. */
+int rala_hip_create(int device, rala_hip_ctx** out);
+void rala_hip_destroy(rala_hip_ctx* ctx);
+const char* rala_hip_last_error(const rala_hip_ctx* ctx);
+/* options: "interval_pool_per_read_x1000" (default 1000 = one pit/hill slot per
+ * read on average), "max_lds_read_len" (reads longer than this use the HBM slab path) */
+int rala_hip_set_option(rala_hip_ctx* ctx, const char* key, int64_t value);
+/* the context's hipStream_t, for callers that enqueue their own copies/collectives */
+void* rala_hip_stream(rala_hip_ctx* ctx);
+
+/* ---- inputs ------------------------------------------------------------------ */
+/* Replaces the createPile loop of Graph::initialize (src/graph.cpp:249-264). */
+int rala_hip_set_reads(rala_hip_ctx* ctx, const uint32_t* read_len, uint64_t n_reads);
+/* Replaces the overlap stream of both parser passes (src/graph.cpp:328-382, :443-518):
+ * parsed once, kept as binary SoA in HBM.  mem = RALA_HIP_MEM_HOST copies from host
+ * memory; RALA_HIP_MEM_DEVICE adopts device pointers, which must stay valid. */
+int rala_hip_set_overlaps(rala_hip_ctx* ctx, const rala_hip_overlaps* ovl, uint64_t n, int mem);
+
+/* ---- stages ---------------------------------------------------------------------- */
+/* Graph::initialize (src/graph.cpp:244-425): duplicate removal (:273-307), bound
+ * emission (:311-326), Pile::add_layers for every read (:367-377), then per read
+ * find_valid_region / find_median / find_chimeric_hills / find_chimeric_pits (:387-407).
+ * Returns RALA_HIP_EFILTERED if no read survives. */
+int rala_hip_initialize(rala_hip_ctx* ctx);
+/* Graph::construct after initialize (src/graph.cpp:437-640): second overlap pass with
+ * the in-order containment removal (:443-518), Graph::preprocess for chimeras
+ * (:699-880), optionally Graph::preprocess for repeats with a sensitive overlap set
+ * (:882-1054; pass sens = NULL / n_sens = 0 for none), node and edge construction
+ * (:553-632).  Sensitive overlaps: a = query in untrimmed coordinates, b = target in
+ * TRIMMED coordinates (misc/raven.sh), host memory. */
+int rala_hip_construct(rala_hip_ctx* ctx, const rala_hip_overlaps* sens, uint64_t n_sens);
+/* Graph::remove_transitive_edges on the graph built by rala_hip_construct
+ * (src/graph.cpp:1281-1335).  *n_pairs = its return value. */
+int rala_hip_remove_transitive_edges(rala_hip_ctx* ctx, uint32_t* n_pairs);
+/* The same on a caller-supplied graph (host arrays): edge e and e^1 are
+ * reverse-complement twins (Edge::pair_), out-lists are in edge-id order.
+ * marks[e] = 1 for every edge the reference would mark. */
+int rala_hip_tr_mark(rala_hip_ctx* ctx, uint32_t n_nodes, uint32_t n_edges, const uint32_t* src,
+                     const uint32_t* dst, const uint32_t* len, uint8_t* marks, uint32_t* n_pairs);
+
+/* ---- results (host buffers owned by the caller) --------------------------------------- */
+/* is_valid_overlap_ (src/graph.hpp:168), one byte per overlap */
+int rala_hip_get_valid(rala_hip_ctx* ctx, uint8_t* valid);
+/* Pile::begin/end/median/p10 and liveness (piles_[i] != nullptr) of every read, as they
+ * stand after the last completed stage.  Any pointer may be NULL. */
+int rala_hip_get_piles(rala_hip_ctx* ctx, uint32_t* begin, uint32_t* end, uint16_t* median, uint16_t* p10,
+                       uint8_t* alive);
+/* Pile::data() of one read (src/pile.hpp:53): read_len[read] values.  Contents are
+ * defined for reads that passed find_valid_region. */
+int rala_hip_get_pile_data(rala_hip_ctx* ctx, uint64_t read, uint16_t* data);
+/* Pits / hills / repeat hills of all reads as CSR: offsets[n_reads + 1], then pairs
+ * (first, second) and one aux word per interval (pit: min coverage inside; hill:
+ * spanning-overlap count; repeat hill: bridged flag).  kind: 0 pits, 1 hills, 2 repeat
+ * hills.  Call with pairs = NULL to obtain offsets only. */
+int rala_hip_get_intervals(rala_hip_ctx* ctx, int kind, uint64_t* offsets, uint32_t* pairs, uint32_t* aux);
+/* Overlaps kept for the graph (which = 0) or as internals (which = 1) after construct.
+ * Returns the count through *n; arrays may be NULL to query the count. */
+int rala_hip_get_overlaps(rala_hip_ctx* ctx, int which, uint64_t* n, uint32_t* src_index, uint32_t* a_begin,
+                          uint32_t* a_end, uint32_t* b_begin, uint32_t* b_end, uint32_t* length, uint8_t* type);
+/* Assembly graph: node k belongs to read node_read[k] (k odd = reverse complement);
+ * edges in id order with twin e^1; marks as set by rala_hip_remove_transitive_edges. */
+int rala_hip_get_graph_size(rala_hip_ctx* ctx, uint64_t* n_nodes, uint64_t* n_edges);
+int rala_hip_get_graph(rala_hip_ctx* ctx, uint32_t* node_read, uint32_t* src, uint32_t* dst, uint32_t* len,
+                       uint8_t* marks);
+int rala_hip_get_timings(rala_hip_ctx* ctx, rala_hip_timings* out);
+/* number of reads dropped by find_valid_region (src/graph.cpp:409-424) */
+int rala_hip_get_num_prefiltered(rala_hip_ctx* ctx, uint64_t* n);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* RALA_HIP_H_ */

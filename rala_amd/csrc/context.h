@@ -1,0 +1,118 @@
+// librala_hip context: device arenas + host-side state of one data set.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "geom.h"
+#include "kernels.h"
+#include "rala_hip.h"
+
+namespace rala_hip {
+
+struct HostOvl {
+    uint32_t src;        // index in the input overlap arrays
+    uint32_t a, b;
+    Coords c;
+    uint8_t strand;
+    uint8_t dead;
+};
+
+struct LaunchClass {
+    uint32_t lw;         // LDS elements per array
+    uint32_t first;      // range in the order array
+    uint32_t count;
+    bool in_lds;
+};
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    hipError_t ensure(size_t count) {
+        if (count <= n && p) return hipSuccess;
+        release();
+        if (count == 0) count = 1;
+        hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+        if (e == hipSuccess) n = count;
+        return e;
+    }
+};
+
+}  // namespace rala_hip
+
+struct rala_hip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    hipEvent_t ev[12] = {};
+
+    // options
+    int64_t pool_per_read_x1000 = 1000;
+    int64_t max_lds_read_len = 22000;
+
+    // reads
+    uint64_t n_reads = 0;
+    std::vector<uint32_t> h_read_len;
+    std::vector<uint64_t> h_pile_off;
+    uint64_t pile_elems = 0;
+    rala_hip::DevBuf<uint32_t> d_read_len;
+    rala_hip::DevBuf<uint64_t> d_pile_off;
+    rala_hip::DevBuf<uint16_t> d_pile;
+    rala_hip::DevBuf<uint32_t> d_order;
+    rala_hip::DevBuf<uint16_t> d_slab;
+    std::vector<rala_hip::LaunchClass> classes;
+    uint32_t slab_grid = 0;
+
+    // overlaps
+    uint64_t n_ovl = 0;
+    rala_hip::OvlSoA ovl = {};
+    rala_hip::DevBuf<uint32_t> d_ovl_u32[7];
+    rala_hip::DevBuf<uint8_t> d_ovl_strand;
+    rala_hip::DevBuf<uint8_t> d_valid;
+
+    // bound CSR
+    rala_hip::DevBuf<uint32_t> d_ev_off, d_cursor, d_ev;
+    rala_hip::DevBuf<unsigned char> d_scan_ws;
+
+    // per-read annotation
+    rala_hip::DevBuf<uint32_t> d_begin, d_end, d_iv_slot;
+    rala_hip::DevBuf<uint16_t> d_median, d_p10;
+    rala_hip::DevBuf<uint8_t> d_alive, d_n_pits, d_n_hills;
+    rala_hip::DevBuf<rala_hip::Interval> d_pool;
+    rala_hip::DevBuf<uint32_t> d_small;      // [0] pool_count [1] error [2] changed [3] tr pairs
+    uint32_t pool_cap = 0;
+
+    // pass 2
+    rala_hip::DevBuf<uint8_t> d_cls;
+    rala_hip::DevBuf<uint32_t> d_death[2];
+    rala_hip::DevBuf<uint32_t> d_flag[2], d_pos[2];
+    rala_hip::DevBuf<uint32_t> d_surv_u32[8];
+    rala_hip::DevBuf<uint8_t> d_surv_u8[2];
+
+    // host mirror of the per-read state (valid after initialize / construct)
+    bool initialized = false, constructed = false;
+    uint64_t n_prefiltered = 0;
+    std::vector<uint32_t> h_begin, h_end, h_slot, h_begin0, h_end0;
+    std::vector<uint16_t> h_median, h_p10;
+    std::vector<uint8_t> h_alive, h_n_pits, h_n_hills;
+    std::vector<rala_hip::Interval> h_pool;
+    bool host_state_fresh = false;
+
+    // host tail
+    std::vector<rala_hip::HostOvl> overlaps, internals;
+    std::vector<uint32_t> node_read;
+    std::vector<uint32_t> e_src, e_dst, e_len;
+    std::vector<uint8_t> e_mark;
+
+    rala_hip_timings tm = {};
+};

@@ -1,0 +1,112 @@
+// Kernel argument blocks and launchers of librala_hip (internal header).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rala_hip {
+
+// zero padding in front of a pile inside the LDS image (multiple of 8 so the
+// pile itself starts 16-byte aligned); >= the 847-base slope window
+constexpr uint32_t kPadL = 848;
+
+enum : uint32_t {
+    kErrRegionCapacity = 1u,   // more slope regions / raw intervals than the kernel's LDS lists hold
+    kErrPoolCapacity = 2u,     // interval pool exhausted
+};
+
+// one pit / hill / repeat hill of a read
+struct Interval {
+    uint32_t first, second;
+    uint32_t aux;   // pit: min coverage inside [first, second]; hill: spanning-overlap counter
+};
+
+struct PileArgs {
+    // inputs
+    const uint32_t* read_len;
+    const uint64_t* pile_off;      // element offset of each pile row (rows padded to 8 elements)
+    uint16_t* pile;                // all piles, row after row
+    const uint32_t* ev_off;        // CSR of bound events per read (n_reads + 1)
+    const uint32_t* ev;            // pos << 1 | is_end
+    const uint32_t* order;         // reads of this launch
+    uint32_t n_items;
+    uint32_t lw;                   // uint16 elements per big array (>= kPadL + len + 848, multiple of 8)
+    uint32_t add_to_existing;
+    uint16_t* slab;                // HBM scratch, 3 * lw elements per workgroup (long reads only)
+    // outputs, indexed by read
+    uint32_t* begin;
+    uint32_t* end;
+    uint16_t* median;
+    uint16_t* p10;
+    uint8_t* alive;
+    uint8_t* n_pits;
+    uint8_t* n_hills;
+    uint32_t* iv_slot;             // first pool entry of the read (pits, then hills), ~0u if none
+    Interval* pool;
+    uint32_t* pool_count;
+    uint32_t pool_cap;
+    uint32_t* error;
+};
+
+uint32_t pile_lds_bytes(uint32_t lw);
+uint32_t pile_lw_for(uint32_t read_len);
+void launch_pile_build_annotate(const PileArgs& args, uint32_t grid, bool in_lds, hipStream_t stream);
+
+// ---- overlap-side kernels (overlap_kernels.hip) ------------------------------
+struct OvlSoA {
+    const uint32_t *a_id, *b_id, *a_begin, *a_end, *b_begin, *b_end, *length;
+    const uint8_t* strand;
+    uint64_t n;
+};
+
+struct ReadState {
+    const uint32_t* begin;
+    const uint32_t* end;
+    const uint8_t* alive;
+    const uint8_t* n_pits;
+    const uint8_t* n_hills;
+    const uint32_t* iv_slot;
+    Interval* pool;
+};
+
+// classification byte per overlap
+enum : uint8_t {
+    kClsTypeMask = 0x07,
+    kClsOk = 0x08,         // valid, both piles alive after initialize, trim succeeded
+    kClsKillsA = 0x10,     // live overlap deletes read a (a contained, container not chimeric)
+    kClsKillsB = 0x20,
+    kClsLive = 0x40,       // survived the in-order death scan
+};
+
+void launch_dedupe(const OvlSoA& o, uint32_t n_reads, uint8_t* valid, hipStream_t s);
+void launch_count_bounds(const OvlSoA& o, uint32_t n_reads, uint32_t* counts, hipStream_t s);
+void launch_scatter_bounds(const OvlSoA& o, uint32_t n_reads, uint32_t* cursor, uint32_t* ev, hipStream_t s);
+void launch_classify(const OvlSoA& o, uint32_t n_reads, const uint8_t* valid, const ReadState& rs, uint8_t* cls,
+                     hipStream_t s);
+void launch_death_round(const OvlSoA& o, const uint8_t* cls, const uint32_t* death_old, uint32_t* death_new,
+                        hipStream_t s);
+void launch_death_diff(const uint32_t* a, const uint32_t* b, uint32_t n, uint32_t* changed, hipStream_t s);
+void launch_finish_pass2(const OvlSoA& o, uint8_t* cls, const uint32_t* death, const ReadState& rs,
+                         uint32_t* flag_overlap, uint32_t* flag_internal, hipStream_t s);
+void launch_apply_death(const uint32_t* death, uint8_t* alive, uint32_t n_reads, hipStream_t s);
+
+// survivors gathered into dense arrays (trim re-applied against the pass-1 piles)
+struct Survivors {
+    uint32_t *src, *a_id, *b_id, *a_begin, *a_end, *b_begin, *b_end, *length;
+    uint8_t *strand, *type;
+};
+void launch_gather_survivors(const OvlSoA& o, const uint8_t* cls, const ReadState& rs, const uint32_t* flag,
+                             const uint32_t* pos, const Survivors& out, hipStream_t s);
+
+// ---- scans (scan_kernels.hip) --------------------------------------------------
+// exclusive prefix sum of n uint32 values; out may alias in; out[n] receives the total
+size_t scan_workspace_bytes(uint64_t n);
+void launch_exclusive_scan(const uint32_t* in, uint32_t* out, uint64_t n, void* workspace, hipStream_t s);
+
+// ---- transitive reduction (tr_kernels.hip) ---------------------------------------
+void launch_tr_mark(const uint32_t* row_ptr, const uint32_t* adj_edge, const uint32_t* edge_src,
+                    const uint32_t* edge_dst, const uint32_t* edge_len, uint32_t n_nodes, uint32_t n_edges,
+                    uint8_t* marks, hipStream_t s);
+void launch_tr_count(const uint8_t* marks, uint32_t n_edges, uint32_t* n_pairs, hipStream_t s);
+
+}  // namespace rala_hip

@@ -1,0 +1,247 @@
+// Per-overlap kernels: duplicate removal, bound bucketing (CSR by read),
+// trim/type classification, the in-order containment ("death") scan as a
+// parallel fixed point, hill span counters and survivor gathering.
+//
+// Reference behaviour followed (rvaser/rala src/graph.cpp):
+//   remove_duplicate_overlaps :273-307   store_overlap_bounds :311-326
+//   construct, pass 2         :443-518   (Overlap::trim / ::type in geom.h)
+#include <hip/hip_runtime.h>
+
+#include "device_utils.h"
+#include "geom.h"
+#include "kernels.h"
+
+namespace rala_hip {
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr uint32_t kInf = 0xFFFFFFFFu;
+
+__device__ __forceinline__ bool transmutable(const OvlSoA& o, uint64_t i, uint32_t n_reads) {
+    return o.a_id[i] < n_reads && o.b_id[i] < n_reads;
+}
+
+// One thread per overlap.  Within a maximal run of equal a_id (records whose
+// names do not resolve are skipped and do not break a run), per b_id exactly
+// the last occurrence of the greatest length stays valid; self overlaps are
+// invalid (SURVEY B-T2 closed form of graph.cpp:273-307).
+__global__ __launch_bounds__(kBlock) void dedupe_kernel(OvlSoA o, uint32_t n_reads, uint8_t* __restrict__ valid) {
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= o.n) return;
+    const uint32_t a = o.a_id[i], b = o.b_id[i];
+    if (a >= n_reads || b >= n_reads || a == b) {
+        valid[i] = 0;
+        return;
+    }
+    const uint32_t len = o.length[i];
+    bool ok = true;
+    for (uint64_t j = i; j-- > 0;) {              // earlier members of the run
+        const uint32_t aj = o.a_id[j], bj = o.b_id[j];
+        if (aj >= n_reads || bj >= n_reads) continue;
+        if (aj != a) break;
+        if (bj == b && o.length[j] > len) { ok = false; break; }
+    }
+    if (ok) {
+        for (uint64_t j = i + 1; j < o.n; ++j) {  // later members
+            const uint32_t aj = o.a_id[j], bj = o.b_id[j];
+            if (aj >= n_reads || bj >= n_reads) continue;
+            if (aj != a) break;
+            if (bj == b && o.length[j] >= len) { ok = false; break; }
+        }
+    }
+    valid[i] = ok ? 1 : 0;
+}
+
+// Every resolvable overlap (valid or not) contributes two bounds to each of
+// its reads (graph.cpp:311-326).
+__global__ __launch_bounds__(kBlock) void count_bounds_kernel(OvlSoA o, uint32_t n_reads, uint32_t* counts) {
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= o.n) return;
+    const uint32_t a = o.a_id[i], b = o.b_id[i];
+    if (a >= n_reads || b >= n_reads) return;
+    atomicAdd(&counts[a], 2u);
+    atomicAdd(&counts[b], 2u);
+}
+
+__global__ __launch_bounds__(kBlock) void scatter_bounds_kernel(OvlSoA o, uint32_t n_reads, uint32_t* cursor,
+                                                                uint32_t* __restrict__ ev) {
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= o.n) return;
+    const uint32_t a = o.a_id[i], b = o.b_id[i];
+    if (a >= n_reads || b >= n_reads) return;
+    const uint32_t pa = atomicAdd(&cursor[a], 2u);
+    ev[pa] = (o.a_begin[i] + 15u) << 1;
+    ev[pa + 1] = ((o.a_end[i] - 15u) << 1) | 1u;
+    const uint32_t pb = atomicAdd(&cursor[b], 2u);
+    ev[pb] = (o.b_begin[i] + 15u) << 1;
+    ev[pb + 1] = ((o.b_end[i] - 15u) << 1) | 1u;
+}
+
+__device__ __forceinline__ Coords load_coords(const OvlSoA& o, uint64_t i) {
+    Coords c;
+    c.a_begin = o.a_begin[i]; c.a_end = o.a_end[i];
+    c.b_begin = o.b_begin[i]; c.b_end = o.b_end[i];
+    c.length = o.length[i];
+    return c;
+}
+
+// Static part of construct's second pass: everything about overlap i that does
+// not depend on which piles earlier overlaps deleted.
+__global__ __launch_bounds__(kBlock) void classify_kernel(OvlSoA o, uint32_t n_reads,
+                                                          const uint8_t* __restrict__ valid, ReadState rs,
+                                                          uint8_t* __restrict__ cls) {
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= o.n) return;
+    uint8_t out = 0;
+    if (valid[i]) {
+        const uint32_t a = o.a_id[i], b = o.b_id[i];
+        if (rs.alive[a] && rs.alive[b]) {
+            Coords c = load_coords(o, i);
+            const uint32_t st = o.strand[i];
+            const uint32_t Ba = rs.begin[a], Ea = rs.end[a], Bb = rs.begin[b], Eb = rs.end[b];
+            if (ovl_trim(c, st, Ba, Ea, Bb, Eb)) {
+                const uint32_t t = ovl_type(c, st, Ba, Ea, Bb, Eb);
+                out = (uint8_t)(kClsOk | t);
+                if (t == kTypeB && (rs.n_pits[b] | rs.n_hills[b]) == 0) out |= kClsKillsA;
+                if (t == kTypeA && (rs.n_pits[a] | rs.n_hills[a]) == 0) out |= kClsKillsB;
+            }
+        }
+    }
+    cls[i] = out;
+}
+
+// One Jacobi round of death[r] = min { i : overlap i would delete r and its
+// container is still alive when i is reached }.
+__global__ __launch_bounds__(kBlock) void death_round_kernel(OvlSoA o, const uint8_t* __restrict__ cls,
+                                                             const uint32_t* __restrict__ death_old,
+                                                             uint32_t* death_new) {
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= o.n) return;
+    const uint8_t c = cls[i];
+    if (!(c & (kClsKillsA | kClsKillsB))) return;
+    const uint32_t a = o.a_id[i], b = o.b_id[i];
+    const uint32_t target = (c & kClsKillsA) ? a : b;
+    const uint32_t keeper = (c & kClsKillsA) ? b : a;
+    if (death_old[keeper] > (uint32_t)i) atomicMin(&death_new[target], (uint32_t)i);
+}
+
+__global__ __launch_bounds__(kBlock) void death_diff_kernel(const uint32_t* __restrict__ x,
+                                                            const uint32_t* __restrict__ y, uint32_t n,
+                                                            uint32_t* changed) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    const bool d = i < n && x[i] != y[i];
+    if (__ballot(d) && (threadIdx.x & 63) == 0) atomicOr(changed, 1u);
+}
+
+// Liveness, hill span counters (Pile::check_chimeric_hills, pile.cpp:457-469,
+// including the begin_ double count) and the two survivor flags.
+__global__ __launch_bounds__(kBlock) void finish_pass2_kernel(OvlSoA o, uint8_t* __restrict__ cls,
+                                                              const uint32_t* __restrict__ death, ReadState rs,
+                                                              uint32_t* __restrict__ flag_overlap,
+                                                              uint32_t* __restrict__ flag_internal) {
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= o.n) return;
+    uint8_t c = cls[i];
+    uint32_t f_ov = 0, f_in = 0;
+    if (c & kClsOk) {
+        const uint32_t a = o.a_id[i], b = o.b_id[i];
+        const uint32_t da = death[a], db = death[b];
+        if (da >= (uint32_t)i && db >= (uint32_t)i) {
+            c |= kClsLive;
+            const uint32_t nha = rs.n_hills[a], nhb = rs.n_hills[b];
+            if (nha | nhb) {
+                Coords k = load_coords(o, i);
+                const uint32_t Ba = rs.begin[a], Bb = rs.begin[b];
+                ovl_trim(k, o.strand[i], Ba, rs.end[a], Bb, rs.end[b]);
+                if (nha) {
+                    Interval* h = rs.pool + rs.iv_slot[a] + rs.n_pits[a];
+                    const uint32_t x = Ba + k.a_begin, y = Ba + k.a_end;
+                    for (uint32_t q = 0; q < nha; ++q) {
+                        if (x < h[q].first && y > h[q].second) atomicAdd(&h[q].aux, 1u);
+                    }
+                }
+                if (nhb) {
+                    Interval* h = rs.pool + rs.iv_slot[b] + rs.n_pits[b];
+                    const uint32_t x = Bb + k.b_begin, y = Bb + k.b_end;
+                    for (uint32_t q = 0; q < nhb; ++q) {
+                        if (x < h[q].first && y > h[q].second) atomicAdd(&h[q].aux, 1u);
+                    }
+                }
+            }
+            const bool both_survive = da == kInf && db == kInf;
+            if (both_survive && !(c & (kClsKillsA | kClsKillsB))) {
+                if ((c & kClsTypeMask) == kTypeX) f_in = 1; else f_ov = 1;
+            }
+        }
+        cls[i] = c;
+    }
+    flag_overlap[i] = f_ov;
+    flag_internal[i] = f_in;
+}
+
+__global__ __launch_bounds__(kBlock) void apply_death_kernel(const uint32_t* __restrict__ death, uint8_t* alive,
+                                                             uint32_t n) {
+    const uint32_t r = blockIdx.x * kBlock + threadIdx.x;
+    if (r < n && death[r] != kInf) alive[r] = 0;
+}
+
+__global__ __launch_bounds__(kBlock) void gather_kernel(OvlSoA o, const uint8_t* __restrict__ cls, ReadState rs,
+                                                        const uint32_t* __restrict__ flag,
+                                                        const uint32_t* __restrict__ pos, Survivors out) {
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= o.n || !flag[i]) return;
+    const uint32_t p = pos[i];
+    const uint32_t a = o.a_id[i], b = o.b_id[i];
+    Coords k = load_coords(o, i);
+    const uint32_t st = o.strand[i];
+    ovl_trim(k, st, rs.begin[a], rs.end[a], rs.begin[b], rs.end[b]);
+    out.src[p] = (uint32_t)i;
+    out.a_id[p] = a; out.b_id[p] = b;
+    out.a_begin[p] = k.a_begin; out.a_end[p] = k.a_end;
+    out.b_begin[p] = k.b_begin; out.b_end[p] = k.b_end;
+    out.length[p] = k.length;
+    out.strand[p] = (uint8_t)st;
+    out.type[p] = cls[i] & kClsTypeMask;
+}
+
+inline dim3 grid_for(uint64_t n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); }
+
+}  // namespace
+
+void launch_dedupe(const OvlSoA& o, uint32_t n_reads, uint8_t* valid, hipStream_t s) {
+    if (o.n) hipLaunchKernelGGL(dedupe_kernel, grid_for(o.n), dim3(kBlock), 0, s, o, n_reads, valid);
+}
+void launch_count_bounds(const OvlSoA& o, uint32_t n_reads, uint32_t* counts, hipStream_t s) {
+    if (o.n) hipLaunchKernelGGL(count_bounds_kernel, grid_for(o.n), dim3(kBlock), 0, s, o, n_reads, counts);
+}
+void launch_scatter_bounds(const OvlSoA& o, uint32_t n_reads, uint32_t* cursor, uint32_t* ev, hipStream_t s) {
+    if (o.n) hipLaunchKernelGGL(scatter_bounds_kernel, grid_for(o.n), dim3(kBlock), 0, s, o, n_reads, cursor, ev);
+}
+void launch_classify(const OvlSoA& o, uint32_t n_reads, const uint8_t* valid, const ReadState& rs, uint8_t* cls,
+                     hipStream_t s) {
+    if (o.n) hipLaunchKernelGGL(classify_kernel, grid_for(o.n), dim3(kBlock), 0, s, o, n_reads, valid, rs, cls);
+}
+void launch_death_round(const OvlSoA& o, const uint8_t* cls, const uint32_t* death_old, uint32_t* death_new,
+                        hipStream_t s) {
+    if (o.n) hipLaunchKernelGGL(death_round_kernel, grid_for(o.n), dim3(kBlock), 0, s, o, cls, death_old, death_new);
+}
+void launch_death_diff(const uint32_t* a, const uint32_t* b, uint32_t n, uint32_t* changed, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(death_diff_kernel, grid_for(n), dim3(kBlock), 0, s, a, b, n, changed);
+}
+void launch_finish_pass2(const OvlSoA& o, uint8_t* cls, const uint32_t* death, const ReadState& rs,
+                         uint32_t* flag_overlap, uint32_t* flag_internal, hipStream_t s) {
+    if (o.n) {
+        hipLaunchKernelGGL(finish_pass2_kernel, grid_for(o.n), dim3(kBlock), 0, s, o, cls, death, rs, flag_overlap,
+                           flag_internal);
+    }
+}
+void launch_apply_death(const uint32_t* death, uint8_t* alive, uint32_t n_reads, hipStream_t s) {
+    if (n_reads) hipLaunchKernelGGL(apply_death_kernel, grid_for(n_reads), dim3(kBlock), 0, s, death, alive, n_reads);
+}
+void launch_gather_survivors(const OvlSoA& o, const uint8_t* cls, const ReadState& rs, const uint32_t* flag,
+                             const uint32_t* pos, const Survivors& out, hipStream_t s) {
+    if (o.n) hipLaunchKernelGGL(gather_kernel, grid_for(o.n), dim3(kBlock), 0, s, o, cls, rs, flag, pos, out);
+}
+
+}  // namespace rala_hip

@@ -1,0 +1,561 @@
+// Pile-o-gram construction and annotation on gfx950.
+//
+// One workgroup (256 threads = 4 wavefronts) owns one read.  The read's
+// coverage vector ("pile", one uint16 per base) is built and kept in LDS:
+//   1. bound events of the read (CSR bucket) -> LDS difference array (ds_add)
+//   2. workgroup prefix sum -> uint16 coverage          [Pile::add_layers]
+//   3. first longest run with coverage >= 4             [Pile::find_valid_region]
+//   4. zero outside the run, stream the pile to HBM     [Pile::shrink]
+//   5. median / p10 by two-level LDS radix histogram    [Pile::find_median]
+//   6. window-847 maxima by doubling (packed u16 max)   [Pile::find_slopes]
+//   7. slope flags for q = 1.3 and 1.82 -> ballot bitmasks -> regions
+//   8. region resolution, pits and hills on two lanes   [find_chimeric_pits/hills]
+// Reads too long for LDS use the same code on a per-workgroup HBM slab.
+//
+// Reference behaviour followed: rvaser/rala src/pile.cpp:64-455 (see
+// DESIGN.md for the per-step mapping).  Integer results are bit-exact; the
+// only floating point is IEEE double multiply/compare, compiled with
+// -ffp-contract=off.
+#include <hip/hip_runtime.h>
+
+#include "device_utils.h"
+#include "geom.h"
+#include "kernels.h"
+
+namespace rala_hip {
+
+namespace {
+
+constexpr int kBlock = 256;
+
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
+    u16x2 x = __builtin_bit_cast(u16x2, a), y = __builtin_bit_cast(u16x2, b);
+    u16x2 r = __builtin_elementwise_max(x, y);
+    return __builtin_bit_cast(uint32_t, r);
+}
+
+// ---- slope regions (serial, one lane) --------------------------------------
+struct RegionList {
+    uint32_t* key;    // first << 1 | is_up
+    uint32_t* last;
+    uint32_t n;
+    uint32_t cap;
+    bool overflow;
+};
+
+__device__ __forceinline__ void rl_push(RegionList& R, uint32_t key, uint32_t last) {
+    if (R.n >= R.cap) { R.overflow = true; return; }
+    R.key[R.n] = key;
+    R.last[R.n] = last;
+    ++R.n;
+}
+
+// insertion sort by (key, last); lists are short and nearly sorted
+__device__ void rl_sort(RegionList& R) {
+    for (uint32_t i = 1; i < R.n; ++i) {
+        const uint32_t k = R.key[i], l = R.last[i];
+        uint32_t j = i;
+        while (j > 0 && (R.key[j - 1] > k || (R.key[j - 1] == k && R.last[j - 1] > l))) {
+            R.key[j] = R.key[j - 1];
+            R.last[j] = R.last[j - 1];
+            --j;
+        }
+        R.key[j] = k;
+        R.last[j] = l;
+    }
+}
+
+// pile.cpp:131-256: resolve overlapping neighbours, then narrow (up, down) pairs.
+// d[j] is the coverage at read position j.
+template <class DataPtr>
+__device__ void resolve_and_narrow(RegionList& R, DataPtr d, double q) {
+    if (R.n == 0) return;
+    for (;;) {
+        rl_sort(R);
+        bool changed = false;
+        for (uint32_t i = 0; i + 1 < R.n; ++i) {
+            if (R.last[i] < (R.key[i + 1] >> 1)) continue;
+            if (R.key[i] & 1) {
+                const uint32_t s = R.key[i] >> 1;
+                const uint32_t e = umin(R.last[i], R.last[i + 1]);
+                // flag j in [s, e) with d[j]*q < max d(j, e]; descending sweep
+                int32_t m = d[e];
+                bool open = false;
+                uint32_t lo = 0, hi = 0;
+                for (uint32_t j = e; j-- > s;) {
+                    const uint32_t v = d[j];
+                    if ((double)v * q < (double)m) {
+                        if (open && j + 1 == lo) {
+                            lo = j;
+                        } else {
+                            if (open) rl_push(R, lo << 1 | 1, hi);
+                            open = true;
+                            lo = hi = j;
+                        }
+                    }
+                    m = max(m, (int32_t)v);
+                }
+                if (open) rl_push(R, lo << 1 | 1, hi);
+                R.key[i] = e << 1 | 1;
+            } else {
+                if (R.last[i] == (R.key[i + 1] >> 1)) continue;
+                const uint32_t s = umax(R.key[i] >> 1, R.key[i + 1] >> 1);
+                const uint32_t e = R.last[i];
+                int32_t m = -1;
+                bool open = false;
+                uint32_t lo = 0, hi = 0;
+                for (uint32_t j = s; j <= e; ++j) {
+                    const uint32_t v = d[j];
+                    if (m >= 0 && (double)v * q < (double)m) {
+                        if (open && j == hi + 1) {
+                            hi = j;
+                        } else {
+                            if (open) rl_push(R, lo << 1, hi);
+                            open = true;
+                            lo = hi = j;
+                        }
+                    }
+                    m = max(m, (int32_t)v);
+                }
+                if (open) rl_push(R, lo << 1, hi);
+                R.last[i] = s;
+            }
+            changed = true;
+            break;
+        }
+        if (!changed || R.overflow) break;
+    }
+    for (uint32_t i = 0; i + 1 < R.n; ++i) {
+        if (!(R.key[i] & 1) || (R.key[i + 1] & 1)) continue;
+        const uint32_t b = R.last[i];
+        const uint32_t e = R.key[i + 1] >> 1;
+        if ((uint32_t)(e - b) > kSlopeWindow) continue;
+        uint32_t m = 0;
+        for (uint32_t j = b + 1; j < e; ++j) m = umax(m, d[j]);
+        const uint32_t u_first = R.key[i] >> 1;
+        uint32_t last_ok = u_first;
+        for (uint32_t j = u_first; j <= b; ++j) {
+            if ((double)m > (double)d[j] * q) last_ok = j;
+        }
+        uint32_t first_ok = R.last[i + 1];
+        for (uint32_t j = e; j <= R.last[i + 1]; ++j) {
+            if ((double)m > (double)d[j] * q) { first_ok = j; break; }
+        }
+        R.last[i] = last_ok;
+        R.key[i + 1] = first_ok << 1;
+    }
+}
+
+struct PadView {
+    const uint16_t* p;   // already offset by kPadL
+    __device__ uint32_t operator[](uint32_t j) const { return p[j]; }
+};
+
+// Scratch words (uint32) behind the three big arrays.
+constexpr uint32_t kMaxRegions = 192;   // per slope list (q)
+constexpr uint32_t kMaxRawIv = 64;      // pits / hills before the merge
+constexpr uint32_t SC_TMP = 0;                         // 16 words: scans / reductions (as u64 x 8)
+constexpr uint32_t SC_HIST = SC_TMP + 16;              // 3 x 256 words
+constexpr uint32_t SC_SEL = SC_HIST + 768;             // 8 words
+constexpr uint32_t SC_RCOUNT = SC_SEL + 8;             // 4 words: runs per mask
+constexpr uint32_t SC_RFIRST = SC_RCOUNT + 4;          // 4 x kMaxRegions
+constexpr uint32_t SC_RLAST = SC_RFIRST + 4 * kMaxRegions;
+constexpr uint32_t SC_REG = SC_RLAST + 4 * kMaxRegions;        // 2 lists x (key,last) x kMaxRegions
+constexpr uint32_t SC_IV = SC_REG + 4 * kMaxRegions;           // 2 x (in first,second,out first,second) x kMaxRawIv
+constexpr uint32_t SC_GONE = SC_IV + 8 * kMaxRawIv;            // 2 x kMaxRawIv bytes
+constexpr uint32_t SC_OUT = SC_GONE + (2 * kMaxRawIv) / 4;     // 4 words: n_pits, n_hills, flags
+constexpr uint32_t SC_WORDS = SC_OUT + 4;
+
+}  // namespace
+
+uint32_t pile_lds_bytes(uint32_t lw) { return 3u * lw * 2u + SC_WORDS * 4u; }
+uint32_t pile_lw_for(uint32_t n) { return (kPadL + n + 848u + 7u) & ~7u; }
+
+// kLds: big arrays in LDS (dynamic shared memory) or in a per-workgroup HBM slab.
+template <bool kLds>
+__global__ __launch_bounds__(kBlock) void pile_build_annotate(PileArgs A) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const uint32_t LW = A.lw;
+
+    uint16_t* P;
+    uint32_t* sc;
+    if constexpr (kLds) {
+        P = (uint16_t*)smem;
+        sc = (uint32_t*)(smem + 3u * LW * 2u);
+    } else {
+        P = A.slab + (size_t)blockIdx.x * 3u * LW;
+        sc = (uint32_t*)smem;
+    }
+    uint16_t* MA = P + LW;
+    uint16_t* MB = MA + LW;
+    int32_t* diff = (int32_t*)MA;           // (n + 1) int32 <= 2 * LW uint16
+    uint64_t* tmp64 = (uint64_t*)(sc + SC_TMP);
+    uint32_t* tmp32 = sc + SC_TMP;
+
+    for (uint32_t item = blockIdx.x; item < A.n_items; item += gridDim.x) {
+        const uint32_t r = A.order[item];
+        const uint32_t n = A.read_len[r];
+        const uint16_t* D = P + kPadL;      // D[j] = coverage at position j
+
+        // ---- 0. clear ----------------------------------------------------
+        {
+            uint32_t* P32 = (uint32_t*)P;
+            for (uint32_t j = tid; j < LW / 2; j += kBlock) P32[j] = 0;
+            for (uint32_t j = tid; j <= n; j += kBlock) diff[j] = 0;
+            if (tid < 4) sc[SC_OUT + tid] = 0;
+        }
+        __syncthreads();
+
+        // ---- 1. bound events -> difference array --------------------------
+        {
+            const uint32_t e0 = A.ev_off[r], e1 = A.ev_off[r + 1];
+            for (uint32_t k = e0 + tid; k < e1; k += kBlock) {
+                const uint32_t b = A.ev[k];
+                const uint32_t pos = b >> 1;
+                if (pos <= n) atomicAdd(&diff[pos], (b & 1) ? -1 : 1);
+            }
+        }
+        __syncthreads();
+
+        // ---- 2. prefix sum -> coverage (mod 2^16), chunk per thread ---------
+        const uint32_t C = ((n + kBlock - 1) / kBlock) | 1u;    // odd: conflict-free strides
+        const uint32_t lo = umin(n, (uint32_t)tid * C), hi = umin(n, lo + C);
+        {
+            int32_t s = 0;
+            for (uint32_t j = lo; j < hi; ++j) s += diff[j];
+            int32_t total;
+            int32_t run = block_scan_excl<kBlock>(s, OpAdd(), (int32_t)0, (int32_t*)tmp32, total);
+            uint16_t* Dw = P + kPadL;
+            if (A.add_to_existing) {
+                const uint16_t* old = A.pile + A.pile_off[r];
+                for (uint32_t j = lo; j < hi; ++j) {
+                    run += diff[j];
+                    Dw[j] = (uint16_t)(old[j] + (uint32_t)run);
+                }
+            } else {
+                for (uint32_t j = lo; j < hi; ++j) {
+                    run += diff[j];
+                    Dw[j] = (uint16_t)run;
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- 3. first longest run with coverage >= 4 ------------------------
+        uint32_t B, E;
+        {
+            uint32_t bad = 0;                       // 1 + last position < 4 in my chunk
+            for (uint32_t j = lo; j < hi; ++j) {
+                if (D[j] < kMinCoverage) bad = j + 1;
+            }
+            uint32_t tot;
+            uint32_t rs = block_scan_excl<kBlock>(bad, OpMax(), 0u, tmp32, tot);
+            uint64_t best = 0;                      // (len << 32) | ~start
+            for (uint32_t j = lo; j < hi; ++j) {
+                if (D[j] < kMinCoverage) {
+                    rs = j + 1;
+                } else if (j + 1 == n || D[j + 1] < kMinCoverage) {
+                    const uint64_t cand = ((uint64_t)(j + 1 - rs) << 32) | (uint32_t)(~rs);
+                    if (cand > best) best = cand;
+                }
+            }
+            best = block_reduce<kBlock>(best, OpMax(), (uint64_t)0, tmp64);
+            const uint32_t len = (uint32_t)(best >> 32);
+            B = len ? ~(uint32_t)best : 0;
+            E = B + len;
+        }
+        if (E - B < kMinRegion) {                   // Pile::shrink fails -> pile dropped
+            if (tid == 0) {
+                A.alive[r] = 0;
+                A.begin[r] = 0; A.end[r] = 0; A.median[r] = 0; A.p10[r] = 0;
+                A.n_pits[r] = 0; A.n_hills[r] = 0; A.iv_slot[r] = 0xFFFFFFFFu;
+            }
+            __syncthreads();
+            continue;
+        }
+
+        // ---- 4. zero outside [B, E), stream the pile to HBM -----------------
+        {
+            uint16_t* Dw = P + kPadL;
+            for (uint32_t j = tid; j < B; j += kBlock) Dw[j] = 0;
+            for (uint32_t j = E + tid; j < n; j += kBlock) Dw[j] = 0;
+        }
+        __syncthreads();
+        {
+            uint4* dst = (uint4*)(A.pile + A.pile_off[r]);
+            const uint4* src = (const uint4*)(P + kPadL);
+            const uint32_t nv = (n + 7) / 8;        // pile rows are padded to 8 elements
+            for (uint32_t j = tid; j < nv; j += kBlock) dst[j] = src[j];
+        }
+
+        // ---- 5. order statistics of [B, E) -----------------------------------
+        uint32_t med, p10;
+        {
+            uint32_t* hist = sc + SC_HIST;
+            uint32_t* sel = sc + SC_SEL;
+            for (uint32_t j = tid; j < 768; j += kBlock) hist[j] = 0;
+            __syncthreads();
+            for (uint32_t j = B + tid; j < E; j += kBlock) atomicAdd(&hist[D[j] >> 8], 1u);
+            __syncthreads();
+            const uint32_t m = E - B;
+            const uint32_t k1 = m / 2, k2 = m / 10;
+            if (tid < 64) {
+                // lane owns 4 consecutive bins
+                const uint32_t c0 = hist[4 * tid], c1 = hist[4 * tid + 1], c2 = hist[4 * tid + 2], c3 = hist[4 * tid + 3];
+                const uint32_t incl = wave_scan_incl(c0 + c1 + c2 + c3, OpAdd());
+                uint32_t before = incl - (c0 + c1 + c2 + c3);
+                const uint32_t c[4] = {c0, c1, c2, c3};
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    if (k1 >= before && k1 < before + c[b]) { sel[0] = 4 * tid + b; sel[1] = k1 - before; }
+                    if (k2 >= before && k2 < before + c[b]) { sel[2] = 4 * tid + b; sel[3] = k2 - before; }
+                    before += c[b];
+                }
+            }
+            __syncthreads();
+            const uint32_t h1 = sel[0], h2 = sel[2];
+            for (uint32_t j = B + tid; j < E; j += kBlock) {
+                const uint32_t v = D[j];
+                if ((v >> 8) == h1) atomicAdd(&hist[256 + (v & 255)], 1u);
+                if ((v >> 8) == h2) atomicAdd(&hist[512 + (v & 255)], 1u);
+            }
+            __syncthreads();
+            if (tid < 128) {
+                const int w = tid >> 6, l = tid & 63;
+                const uint32_t* hh = hist + 256 + 256 * w;
+                const uint32_t kk = sel[1 + 2 * w];
+                const uint32_t c0 = hh[4 * l], c1 = hh[4 * l + 1], c2 = hh[4 * l + 2], c3 = hh[4 * l + 3];
+                const uint32_t incl = wave_scan_incl(c0 + c1 + c2 + c3, OpAdd());
+                uint32_t before = incl - (c0 + c1 + c2 + c3);
+                const uint32_t c[4] = {c0, c1, c2, c3};
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    if (kk >= before && kk < before + c[b]) sel[4 + w] = 4 * l + b;
+                    before += c[b];
+                }
+            }
+            __syncthreads();
+            med = (h1 << 8) | sel[4];
+            p10 = (h2 << 8) | sel[5];
+        }
+
+        // ---- 6. window maxima: M512[j] = max P[j .. j+511] by doubling --------
+        {
+            const uint32_t W = LW / 2;              // packed pairs
+            const uint32_t* s32 = (const uint32_t*)P;
+            uint32_t* d32 = (uint32_t*)MA;
+            // s = 1: pair (2j, 2j+1) needs P[2j+2]
+            for (uint32_t j = tid; j < W; j += kBlock) {
+                const uint32_t w0 = s32[j];
+                const uint32_t w1 = (j + 1 < W) ? s32[j + 1] : 0u;
+                d32[j] = pk_max_u16(w0, (w0 >> 16) | (w1 << 16));
+            }
+            __syncthreads();
+            uint32_t* a = (uint32_t*)MA;
+            uint32_t* b = (uint32_t*)MB;
+            for (uint32_t s = 2; s <= 256; s <<= 1) {
+                const uint32_t h = s / 2;
+                for (uint32_t j = tid; j < W; j += kBlock) {
+                    const uint32_t w1 = (j + h < W) ? a[j + h] : 0u;
+                    b[j] = pk_max_u16(a[j], w1);
+                }
+                __syncthreads();
+                uint32_t* t = a; a = b; b = t;
+            }
+            // eight swaps: the result is back in MA, MB is free
+        }
+
+        // ---- 7. slope flags -> bitmasks --------------------------------------
+        const uint32_t nw = (n + 63) / 64;
+        uint64_t* mask = (uint64_t*)MB;             // 4 x nw words: dn1.3, up1.3, dn1.82, up1.82
+        {
+            const uint16_t* M = MA + kPadL;         // M[x] = max D[x .. x+511], x may be negative
+            for (uint32_t i = tid; i < nw * 64; i += kBlock) {
+                bool d13 = false, u13 = false, d182 = false, u182 = false;
+                if (i < n) {
+                    const int32_t v = D[i];
+                    const int32_t lm = max((int32_t)M[(int32_t)i - 847], (int32_t)M[(int32_t)i - 512]);
+                    const int32_t rm = max((int32_t)M[i + 1], (int32_t)M[i + 336]);
+                    const int32_t t13 = (int32_t)((double)v * 1.3);
+                    const int32_t t182 = (int32_t)((double)v * 1.82);
+                    const bool nf = i != 0, nl = i != n - 1;
+                    d13 = nf && lm > t13;  u13 = nl && rm > t13;
+                    d182 = nf && lm > t182; u182 = nl && rm > t182;
+                }
+                const uint64_t b0 = __ballot(d13), b1 = __ballot(u13), b2 = __ballot(d182), b3 = __ballot(u182);
+                if ((tid & 63) == 0) {
+                    const uint32_t w = i >> 6;
+                    mask[w] = b0; mask[nw + w] = b1; mask[2 * nw + w] = b2; mask[3 * nw + w] = b3;
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- 8. runs of set bits -> (first, last); wave w owns mask w ---------
+        {
+            const int w = wave_id(), l = lane_id();
+            const uint64_t* mk = mask + (size_t)w * nw;
+            uint32_t* rf = sc + SC_RFIRST + w * kMaxRegions;
+            uint32_t* rl = sc + SC_RLAST + w * kMaxRegions;
+            uint32_t base_s = 0, base_e = 0;
+            for (uint32_t w0 = 0; w0 < nw; w0 += 64) {
+                const uint32_t x = w0 + l;
+                uint64_t m = 0, starts = 0, ends = 0;
+                if (x < nw) {
+                    m = mk[x];
+                    const uint64_t prev = x > 0 ? (mk[x - 1] >> 63) : 0;
+                    const uint64_t next = x + 1 < nw ? (mk[x + 1] & 1) : 0;
+                    starts = m & ~((m << 1) | prev);
+                    ends = m & ~((m >> 1) | (next << 63));
+                }
+                const uint32_t cs = __popcll(starts), ce = __popcll(ends);
+                const uint32_t is = wave_scan_incl(cs, OpAdd()), ie = wave_scan_incl(ce, OpAdd());
+                uint32_t ps = base_s + is - cs, pe = base_e + ie - ce;
+                while (starts) {
+                    const uint32_t bit = __ffsll((unsigned long long)starts) - 1;
+                    starts &= starts - 1;
+                    if (ps < kMaxRegions) rf[ps] = x * 64 + bit;
+                    ++ps;
+                }
+                while (ends) {
+                    const uint32_t bit = __ffsll((unsigned long long)ends) - 1;
+                    ends &= ends - 1;
+                    if (pe < kMaxRegions) rl[pe] = x * 64 + bit;
+                    ++pe;
+                }
+                base_s += __shfl((int)is, 63, 64);
+                base_e += __shfl((int)ie, 63, 64);
+            }
+            if (l == 0) sc[SC_RCOUNT + w] = base_s;
+        }
+        __syncthreads();
+
+        // ---- 9. resolve + pits (wave 1) / hills (wave 0), one lane each --------
+        if (tid == 0 || tid == 64) {
+            const int which = tid >> 6;                     // 0: q = 1.3 hills, 1: q = 1.82 pits
+            const double q = which ? 1.82 : 1.3;
+            RegionList R;
+            R.key = sc + SC_REG + which * 2 * kMaxRegions;
+            R.last = R.key + kMaxRegions;
+            R.n = 0; R.cap = kMaxRegions; R.overflow = false;
+            const uint32_t nd = sc[SC_RCOUNT + 2 * which], nu = sc[SC_RCOUNT + 2 * which + 1];
+            if (nd + nu > kMaxRegions) R.overflow = true;
+            if (!R.overflow) {
+                const uint32_t* df = sc + SC_RFIRST + (2 * which) * kMaxRegions;
+                const uint32_t* dl = sc + SC_RLAST + (2 * which) * kMaxRegions;
+                const uint32_t* uf = df + kMaxRegions;
+                const uint32_t* ul = dl + kMaxRegions;
+                for (uint32_t k = 0; k < nd; ++k) rl_push(R, df[k] << 1, dl[k]);
+                for (uint32_t k = 0; k < nu; ++k) rl_push(R, uf[k] << 1 | 1, ul[k]);
+                PadView dv{D};
+                resolve_and_narrow(R, dv, q);
+            }
+            uint32_t* ivf = sc + SC_IV + which * 4 * kMaxRawIv;
+            uint32_t* ivs = ivf + kMaxRawIv;
+            uint32_t* of = ivs + kMaxRawIv;
+            uint32_t* os = of + kMaxRawIv;
+            uint8_t* gone = (uint8_t*)(sc + SC_GONE) + which * kMaxRawIv;
+            uint32_t cnt = 0;
+            bool ovf = R.overflow;
+            if (!ovf && R.n) {
+                if (which) {
+                    // pile.cpp:357-363: adjacent (down, up) -> pit
+                    for (uint32_t i = 0; i + 1 < R.n; ++i) {
+                        if (!(R.key[i] & 1) && (R.key[i + 1] & 1)) {
+                            if (cnt >= kMaxRawIv) { ovf = true; break; }
+                            ivf[cnt] = R.key[i] >> 1;
+                            ivs[cnt] = R.last[i + 1];
+                            ++cnt;
+                        }
+                    }
+                } else {
+                    // pile.cpp:411-451: every (up, later down) pair
+                    const double span = (double)(E - B);
+                    const double lo_lim = 0.05 * span + (double)B;
+                    const double hi_lim = 0.95 * span + (double)B;
+                    for (uint32_t i = 0; i + 1 < R.n && !ovf; ++i) {
+                        if (!(R.key[i] & 1)) continue;
+                        const uint32_t u_first = R.key[i] >> 1, u_last = R.last[i];
+                        for (uint32_t j = i + 1; j < R.n; ++j) {
+                            if (R.key[j] & 1) continue;
+                            const uint32_t w_first = R.key[j] >> 1, w_last = R.last[j];
+                            if ((double)u_first < lo_lim || (double)w_last > hi_lim ||
+                                (uint32_t)(w_first - u_last) > 840u) {
+                                continue;
+                            }
+                            const uint32_t pk = (uint32_t)(1.3 * (double)umax(D[u_last], D[w_first]));
+                            bool found = false;
+                            for (uint32_t x = u_last + 1; x < w_first; ++x) {
+                                if (D[x] > pk) { found = true; break; }
+                            }
+                            if (!found) continue;
+                            if (cnt >= kMaxRawIv) { ovf = true; break; }
+                            ivf[cnt] = (uint32_t)(u_first - B) > kHillFuzz ? u_first - kHillFuzz : B;
+                            ivs[cnt] = (uint32_t)(E - w_last) > kHillFuzz ? w_last + kHillFuzz : E;
+                            ++cnt;
+                        }
+                    }
+                }
+                if (!ovf) cnt = interval_merge(ivf, ivs, cnt, gone, of, os);
+            }
+            sc[SC_OUT + which] = ovf ? 0 : cnt;
+            if (ovf) atomicOr(&sc[SC_OUT + 2], 1u);
+        }
+        __syncthreads();
+
+        // ---- 10. publish ------------------------------------------------------
+        if (tid == 0) {
+            const uint32_t nh = sc[SC_OUT + 0], np = sc[SC_OUT + 1];
+            uint32_t err = sc[SC_OUT + 2] ? kErrRegionCapacity : 0;
+            uint32_t slot = 0xFFFFFFFFu;
+            uint32_t wp = np, wh = nh;
+            if (np > 255 || nh > 255) { err |= kErrRegionCapacity; wp = wh = 0; }
+            if (wp + wh) {
+                slot = atomicAdd(A.pool_count, wp + wh);
+                if (slot + wp + wh > A.pool_cap) {
+                    err |= kErrPoolCapacity;
+                    slot = 0xFFFFFFFFu; wp = wh = 0;
+                } else {
+                    const uint32_t* pf = sc + SC_IV + 4 * kMaxRawIv + 2 * kMaxRawIv;   // pits: merged out
+                    const uint32_t* ps = pf + kMaxRawIv;
+                    const uint32_t* hf = sc + SC_IV + 2 * kMaxRawIv;                   // hills: merged out
+                    const uint32_t* hs = hf + kMaxRawIv;
+                    for (uint32_t k = 0; k < wp; ++k) {
+                        uint32_t mn = 0xFFFFu;
+                        for (uint32_t x = pf[k]; x <= ps[k]; ++x) mn = umin(mn, D[x]);
+                        Interval iv; iv.first = pf[k]; iv.second = ps[k]; iv.aux = mn;
+                        A.pool[slot + k] = iv;
+                    }
+                    for (uint32_t k = 0; k < wh; ++k) {
+                        Interval iv; iv.first = hf[k]; iv.second = hs[k]; iv.aux = 0;
+                        A.pool[slot + wp + k] = iv;
+                    }
+                }
+            }
+            A.alive[r] = 1;
+            A.begin[r] = B; A.end[r] = E;
+            A.median[r] = (uint16_t)med; A.p10[r] = (uint16_t)p10;
+            A.n_pits[r] = (uint8_t)wp; A.n_hills[r] = (uint8_t)wh;
+            A.iv_slot[r] = slot;
+            if (err) atomicOr(A.error, err);
+        }
+        __syncthreads();
+    }
+}
+
+void launch_pile_build_annotate(const PileArgs& args, uint32_t grid, bool in_lds, hipStream_t stream) {
+    if (grid == 0) return;
+    if (in_lds) {
+        const uint32_t bytes = pile_lds_bytes(args.lw);
+        hipFuncSetAttribute((const void*)pile_build_annotate<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)bytes);
+        hipLaunchKernelGGL(pile_build_annotate<true>, dim3(grid), dim3(kBlock), bytes, stream, args);
+    } else {
+        hipLaunchKernelGGL(pile_build_annotate<false>, dim3(grid), dim3(kBlock), SC_WORDS * 4u, stream, args);
+    }
+}
+
+}  // namespace rala_hip

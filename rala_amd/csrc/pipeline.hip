@@ -1,0 +1,765 @@
+// librala_hip: C ABI (include/rala_hip.h) and host orchestration of the stages.
+//
+// Device work: duplicate removal, bound bucketing, pile build + annotation,
+// overlap classification, the containment fixed point, hill counters,
+// survivor gathering, transitive-edge marking.  Host work (this file): the
+// short sequential tail of Graph::preprocess on the few per cent of overlaps
+// that survive containment removal (connected components, component medians,
+// iterate-until-stable), node/edge numbering, CSR assembly.
+#include <hip/hip_runtime.h>
+#include <string.h>
+
+#include <algorithm>
+#include <chrono>
+#include <numeric>
+
+#include "context.h"
+
+using namespace rala_hip;
+
+namespace {
+
+#define HIPCHECK(call)                                                                       \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);                    \
+            return e_ == hipErrorOutOfMemory ? RALA_HIP_ENOMEM : RALA_HIP_EDEVICE;           \
+        }                                                                                    \
+    } while (0)
+
+int fail(rala_hip_ctx* ctx, int code, const char* msg) {
+    ctx->err = msg;
+    return code;
+}
+
+ReadState read_state(rala_hip_ctx* ctx) {
+    ReadState rs;
+    rs.begin = ctx->d_begin.p; rs.end = ctx->d_end.p; rs.alive = ctx->d_alive.p;
+    rs.n_pits = ctx->d_n_pits.p; rs.n_hills = ctx->d_n_hills.p; rs.iv_slot = ctx->d_iv_slot.p;
+    rs.pool = ctx->d_pool.p;
+    return rs;
+}
+
+double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// ---- host mirror of the per-read state -------------------------------------------
+int download_read_state(rala_hip_ctx* ctx) {
+    const uint64_t n = ctx->n_reads;
+    ctx->h_begin.resize(n); ctx->h_end.resize(n); ctx->h_median.resize(n); ctx->h_p10.resize(n);
+    ctx->h_alive.resize(n); ctx->h_n_pits.resize(n); ctx->h_n_hills.resize(n); ctx->h_slot.resize(n);
+    hipStream_t s = ctx->stream;
+    HIPCHECK(hipMemcpyAsync(ctx->h_begin.data(), ctx->d_begin.p, n * 4, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipMemcpyAsync(ctx->h_end.data(), ctx->d_end.p, n * 4, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipMemcpyAsync(ctx->h_median.data(), ctx->d_median.p, n * 2, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipMemcpyAsync(ctx->h_p10.data(), ctx->d_p10.p, n * 2, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipMemcpyAsync(ctx->h_alive.data(), ctx->d_alive.p, n, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipMemcpyAsync(ctx->h_n_pits.data(), ctx->d_n_pits.p, n, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipMemcpyAsync(ctx->h_n_hills.data(), ctx->d_n_hills.p, n, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipMemcpyAsync(ctx->h_slot.data(), ctx->d_iv_slot.p, n * 4, hipMemcpyDeviceToHost, s));
+    uint32_t small[4];
+    HIPCHECK(hipMemcpyAsync(small, ctx->d_small.p, sizeof(small), hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipStreamSynchronize(s));
+    const uint32_t used = std::min(small[0], ctx->pool_cap);
+    ctx->h_pool.resize(used);
+    if (used) {
+        HIPCHECK(hipMemcpy(ctx->h_pool.data(), ctx->d_pool.p, (size_t)used * sizeof(Interval), hipMemcpyDeviceToHost));
+    }
+    ctx->host_state_fresh = true;
+    return RALA_HIP_OK;
+}
+
+// ---- launch classes: reads grouped by the LDS image size they need -------------------
+void build_classes(rala_hip_ctx* ctx, std::vector<uint32_t>& order) {
+    const uint64_t n = ctx->n_reads;
+    static const uint32_t kLw[] = {8192, 10240, 12288, 14336, 16384, 20480, 24576};
+    const int n_lds = (int)(sizeof(kLw) / sizeof(kLw[0]));
+    std::vector<std::vector<uint32_t>> bins(n_lds + 1);
+    uint32_t max_long = 0;
+    for (uint64_t r = 0; r < n; ++r) {
+        const uint32_t len = ctx->h_read_len[r];
+        const uint32_t lw = pile_lw_for(len);
+        int k = n_lds;
+        if ((int64_t)len <= ctx->max_lds_read_len) {
+            for (int c = 0; c < n_lds; ++c) {
+                if (lw <= kLw[c]) { k = c; break; }
+            }
+        }
+        bins[k].push_back((uint32_t)r);
+        if (k == n_lds) max_long = std::max(max_long, lw);
+    }
+    ctx->classes.clear();
+    order.clear();
+    // big classes first: their workgroups are the long poles
+    for (int k = n_lds; k >= 0; --k) {
+        if (bins[k].empty()) continue;
+        LaunchClass c;
+        c.in_lds = k < n_lds;
+        c.lw = c.in_lds ? kLw[k] : max_long;
+        c.first = (uint32_t)order.size();
+        c.count = (uint32_t)bins[k].size();
+        // longest first inside a class
+        std::stable_sort(bins[k].begin(), bins[k].end(), [&](uint32_t x, uint32_t y) {
+            return ctx->h_read_len[x] > ctx->h_read_len[y];
+        });
+        order.insert(order.end(), bins[k].begin(), bins[k].end());
+        ctx->classes.push_back(c);
+    }
+}
+
+// ---- host tail helpers (Graph::preprocess, graph.cpp:699-880) --------------------------
+bool host_trim(rala_hip_ctx* ctx, HostOvl& o) {
+    if (!ctx->h_alive[o.a] || !ctx->h_alive[o.b]) return false;
+    return ovl_trim(o.c, o.strand, ctx->h_begin[o.a], ctx->h_end[o.a], ctx->h_begin[o.b], ctx->h_end[o.b]);
+}
+
+uint32_t host_type(rala_hip_ctx* ctx, const HostOvl& o) {
+    return ovl_type(o.c, o.strand, ctx->h_begin[o.a], ctx->h_end[o.a], ctx->h_begin[o.b], ctx->h_end[o.b]);
+}
+
+uint64_t retrim(rala_hip_ctx* ctx, std::vector<HostOvl>& v) {
+    size_t w = 0;
+    for (size_t k = 0; k < v.size(); ++k) {
+        if (!host_trim(ctx, v[k])) continue;
+        if (w != k) v[w] = v[k];
+        ++w;
+    }
+    const uint64_t dropped = v.size() - w;
+    v.resize(w);
+    return dropped;
+}
+
+bool host_shrink(rala_hip_ctx* ctx, uint32_t r, uint32_t b, uint32_t e) {
+    if (b > e || e - b < kMinRegion) return false;
+    ctx->h_begin[r] = b;
+    ctx->h_end[r] = e;
+    return true;
+}
+
+// Pile::break_over_chimeric_hills (pile.cpp:471-498)
+bool break_hills(rala_hip_ctx* ctx, uint32_t r, const Interval* hills, uint32_t n) {
+    const uint32_t B = ctx->h_begin[r], E = ctx->h_end[r];
+    uint32_t b = 0, e = 0, from = B;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (B > hills[i].first || E < hills[i].second) continue;
+        if (hills[i].aux > 3) continue;
+        if ((uint32_t)(hills[i].first - from) > (uint32_t)(e - b)) { b = from; e = hills[i].first; }
+        from = hills[i].second;
+    }
+    if ((uint32_t)(E - from) > (uint32_t)(e - b)) { b = from; e = E; }
+    return host_shrink(ctx, r, b, e);
+}
+
+// Pile::break_over_chimeric_pits (pile.cpp:366-402); a pit is real when some
+// coverage inside it satisfies data*1.84 <= median — monotone in data, so the
+// minimum recorded by the pile kernel decides.  Unreal pits are kept (in place).
+bool break_pits(rala_hip_ctx* ctx, uint32_t r, Interval* pits, uint8_t& n_pits, uint16_t dataset_median) {
+    const uint32_t B = ctx->h_begin[r], E = ctx->h_end[r];
+    uint32_t b = 0, e = 0, from = B;
+    uint32_t w = 0;
+    for (uint32_t k = 0; k < n_pits; ++k) {
+        const Interval it = pits[k];
+        if (B > it.first || E < it.second) continue;
+        if ((double)it.aux * 1.84 <= (double)dataset_median) {
+            if ((uint32_t)(it.first - from) > (uint32_t)(e - b)) { b = from; e = it.first; }
+            from = it.second;
+        } else {
+            pits[w++] = it;
+        }
+    }
+    if ((uint32_t)(E - from) > (uint32_t)(e - b)) { b = from; e = E; }
+    n_pits = (uint8_t)w;
+    return host_shrink(ctx, r, b, e);
+}
+
+struct UnionFind {
+    std::vector<uint32_t> p;
+    explicit UnionFind(size_t n) : p(n) { std::iota(p.begin(), p.end(), 0u); }
+    uint32_t find(uint32_t x) {
+        while (p[x] != x) { p[x] = p[p[x]]; x = p[x]; }
+        return x;
+    }
+    void unite(uint32_t a, uint32_t b) {
+        a = find(a); b = find(b);
+        if (a != b) p[std::max(a, b)] = std::min(a, b);
+    }
+};
+
+// per read: the median of the pile medians of its connected component over the
+// current overlaps (graph.cpp:740-783); reads outside any component get no entry
+void component_medians(rala_hip_ctx* ctx, std::vector<uint32_t>& members, std::vector<uint16_t>& med_of_member) {
+    const uint64_t n = ctx->n_reads;
+    UnionFind uf(n);
+    std::vector<uint8_t> touched(n, 0);
+    for (const HostOvl& o : ctx->overlaps) {
+        uf.unite(o.a, o.b);
+        touched[o.a] = touched[o.b] = 1;
+    }
+    members.clear();
+    for (uint64_t r = 0; r < n; ++r) if (touched[r]) members.push_back((uint32_t)r);
+    // group members by root
+    std::vector<uint32_t> root(members.size());
+    for (size_t k = 0; k < members.size(); ++k) root[k] = uf.find(members[k]);
+    std::vector<uint32_t> idx(members.size());
+    std::iota(idx.begin(), idx.end(), 0u);
+    std::stable_sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) { return root[x] < root[y]; });
+    med_of_member.assign(members.size(), 0);
+    std::vector<uint16_t> m;
+    for (size_t s = 0; s < idx.size();) {
+        size_t t = s;
+        m.clear();
+        while (t < idx.size() && root[idx[t]] == root[idx[s]]) { m.push_back(ctx->h_median[members[idx[t]]]); ++t; }
+        std::nth_element(m.begin(), m.begin() + m.size() / 2, m.end());
+        const uint16_t med = m[m.size() / 2];
+        for (size_t k = s; k < t; ++k) med_of_member[idx[k]] = med;
+        s = t;
+    }
+}
+
+void preprocess_chimeras(rala_hip_ctx* ctx) {
+    const uint64_t n = ctx->n_reads;
+    std::vector<uint8_t> n_pits0(ctx->h_n_pits);     // hills sit behind the initial pits
+    // break over chimeric hills (graph.cpp:704-720)
+    for (uint64_t r = 0; r < n; ++r) {
+        if (!ctx->h_alive[r] || ctx->h_n_hills[r] == 0) continue;
+        const Interval* hills = ctx->h_pool.data() + ctx->h_slot[r] + n_pits0[r];
+        if (!break_hills(ctx, (uint32_t)r, hills, ctx->h_n_hills[r])) ctx->h_alive[r] = 0;
+        ctx->h_n_hills[r] = 0;
+    }
+    retrim(ctx, ctx->overlaps);      // :722-728
+    retrim(ctx, ctx->internals);     // :730-736
+
+    std::vector<uint32_t> members;
+    std::vector<uint16_t> med;
+    for (;;) {                       // :738-829
+        component_medians(ctx, members, med);
+        for (size_t k = 0; k < members.size(); ++k) {
+            const uint32_t r = members[k];
+            if (ctx->h_n_pits[r] == 0) continue;     // no pits: shrink(begin, end) is a no-op
+            Interval* pits = ctx->h_pool.data() + ctx->h_slot[r];
+            if (!break_pits(ctx, r, pits, ctx->h_n_pits[r], med[k])) ctx->h_alive[r] = 0;
+        }
+        const bool changed = retrim(ctx, ctx->overlaps) != 0;
+        size_t w = 0;
+        for (size_t k = 0; k < ctx->internals.size(); ++k) {
+            HostOvl& o = ctx->internals[k];
+            if (!host_trim(ctx, o)) continue;
+            const uint32_t t = host_type(ctx, o);
+            if (t == kTypeAB || t == kTypeBA) { ctx->overlaps.push_back(o); continue; }
+            if (w != k) ctx->internals[w] = o;
+            ++w;
+        }
+        ctx->internals.resize(w);
+        if (!changed) break;
+    }
+
+    // in-order containment removal without the chimera guard (:831-877)
+    auto kill_scan = [&](std::vector<HostOvl>& v) {
+        for (HostOvl& o : v) {
+            if (!ctx->h_alive[o.a] || !ctx->h_alive[o.b]) { o.dead = 1; continue; }
+            const uint32_t t = host_type(ctx, o);
+            if (t == kTypeA) { ctx->h_alive[o.b] = 0; o.dead = 1; }
+            else if (t == kTypeB) { ctx->h_alive[o.a] = 0; o.dead = 1; }
+        }
+    };
+    kill_scan(ctx->overlaps);
+    kill_scan(ctx->internals);
+    auto compact = [&](std::vector<HostOvl>& v, bool check_piles) {
+        size_t w = 0;
+        for (size_t k = 0; k < v.size(); ++k) {
+            if (v[k].dead) continue;
+            if (check_piles && (!ctx->h_alive[v[k].a] || !ctx->h_alive[v[k].b])) continue;
+            if (w != k) v[w] = v[k];
+            ++w;
+        }
+        v.resize(w);
+    };
+    compact(ctx->internals, false);
+    compact(ctx->overlaps, true);
+}
+
+// nodes for the surviving reads, two edges per dovetail overlap (graph.cpp:553-632)
+void build_graph(rala_hip_ctx* ctx) {
+    const uint64_t n = ctx->n_reads;
+    std::vector<uint32_t> read_to_node(n, 0xFFFFFFFFu);
+    ctx->node_read.clear();
+    for (uint64_t r = 0; r < n; ++r) {
+        if (!ctx->h_alive[r]) continue;
+        read_to_node[r] = (uint32_t)ctx->node_read.size();
+        ctx->node_read.push_back((uint32_t)r);
+        ctx->node_read.push_back((uint32_t)r);
+    }
+    ctx->e_src.clear(); ctx->e_dst.clear(); ctx->e_len.clear();
+    for (const HostOvl& o : ctx->overlaps) {
+        const uint32_t Ba = ctx->h_begin[o.a], Ea = ctx->h_end[o.a], Bb = ctx->h_begin[o.b], Eb = ctx->h_end[o.b];
+        const uint32_t t = ovl_type(o.c, o.strand, Ba, Ea, Bb, Eb);
+        EdgePair e;
+        if (!ovl_edges(o.c, o.strand, t, read_to_node[o.a], read_to_node[o.b], Ba, Ea, Bb, Eb, e)) continue;
+        ctx->e_src.push_back(e.src0); ctx->e_dst.push_back(e.dst0); ctx->e_len.push_back(e.len0);
+        ctx->e_src.push_back(e.src1); ctx->e_dst.push_back(e.dst1); ctx->e_len.push_back(e.len1);
+    }
+    ctx->e_mark.assign(ctx->e_src.size(), 0);
+}
+
+int tr_mark_impl(rala_hip_ctx* ctx, uint32_t n_nodes, uint32_t n_edges, const uint32_t* src, const uint32_t* dst,
+                 const uint32_t* len, uint8_t* marks, uint32_t* n_pairs) {
+    *n_pairs = 0;
+    if (n_edges == 0) return RALA_HIP_OK;
+    if (n_edges & 1) return fail(ctx, RALA_HIP_EINVAL, "edges must come in twin pairs (e, e^1)");
+    // CSR with out-lists in edge-id order (suffix_edges_ append order)
+    std::vector<uint32_t> row(n_nodes + 1, 0), adj(n_edges);
+    for (uint32_t e = 0; e < n_edges; ++e) {
+        if (src[e] >= n_nodes || dst[e] >= n_nodes) return fail(ctx, RALA_HIP_EINVAL, "edge endpoint out of range");
+        ++row[src[e] + 1];
+    }
+    for (uint32_t v = 0; v < n_nodes; ++v) row[v + 1] += row[v];
+    {
+        std::vector<uint32_t> cur(row.begin(), row.end() - 1);
+        for (uint32_t e = 0; e < n_edges; ++e) adj[cur[src[e]]++] = e;
+    }
+    DevBuf<uint32_t> d_row, d_adj, d_src, d_dst, d_len;
+    DevBuf<uint8_t> d_marks;
+    HIPCHECK(d_row.ensure(n_nodes + 1)); HIPCHECK(d_adj.ensure(n_edges)); HIPCHECK(d_src.ensure(n_edges));
+    HIPCHECK(d_dst.ensure(n_edges)); HIPCHECK(d_len.ensure(n_edges)); HIPCHECK(d_marks.ensure(n_edges));
+    hipStream_t s = ctx->stream;
+    HIPCHECK(hipMemcpyAsync(d_row.p, row.data(), (size_t)(n_nodes + 1) * 4, hipMemcpyHostToDevice, s));
+    HIPCHECK(hipMemcpyAsync(d_adj.p, adj.data(), (size_t)n_edges * 4, hipMemcpyHostToDevice, s));
+    HIPCHECK(hipMemcpyAsync(d_src.p, src, (size_t)n_edges * 4, hipMemcpyHostToDevice, s));
+    HIPCHECK(hipMemcpyAsync(d_dst.p, dst, (size_t)n_edges * 4, hipMemcpyHostToDevice, s));
+    HIPCHECK(hipMemcpyAsync(d_len.p, len, (size_t)n_edges * 4, hipMemcpyHostToDevice, s));
+    HIPCHECK(hipMemsetAsync(d_marks.p, 0, n_edges, s));
+    HIPCHECK(hipMemsetAsync(ctx->d_small.p + 3, 0, 4, s));
+    HIPCHECK(hipEventRecord(ctx->ev[10], s));
+    launch_tr_mark(d_row.p, d_adj.p, d_src.p, d_dst.p, d_len.p, n_nodes, n_edges, d_marks.p, s);
+    launch_tr_count(d_marks.p, n_edges, ctx->d_small.p + 3, s);
+    HIPCHECK(hipEventRecord(ctx->ev[11], s));
+    HIPCHECK(hipMemcpyAsync(marks, d_marks.p, n_edges, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipMemcpyAsync(n_pairs, ctx->d_small.p + 3, 4, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipStreamSynchronize(s));
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipEventElapsedTime(&ctx->tm.tr_ms, ctx->ev[10], ctx->ev[11]));
+    return RALA_HIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rala_hip_create(int device, rala_hip_ctx** out) {
+    if (!out) return RALA_HIP_EINVAL;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return RALA_HIP_EDEVICE;
+    if (hipSetDevice(device) != hipSuccess) return RALA_HIP_EDEVICE;
+    rala_hip_ctx* ctx = new rala_hip_ctx;
+    ctx->device = device;
+    if (hipStreamCreate(&ctx->stream) != hipSuccess) { delete ctx; return RALA_HIP_EDEVICE; }
+    for (auto& e : ctx->ev) {
+        if (hipEventCreate(&e) != hipSuccess) { delete ctx; return RALA_HIP_EDEVICE; }
+    }
+    if (ctx->d_small.ensure(8) != hipSuccess) { delete ctx; return RALA_HIP_EDEVICE; }
+    *out = ctx;
+    return RALA_HIP_OK;
+}
+
+void rala_hip_destroy(rala_hip_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* rala_hip_last_error(const rala_hip_ctx* ctx) { return ctx ? ctx->err.c_str() : "no context"; }
+
+int rala_hip_set_option(rala_hip_ctx* ctx, const char* key, int64_t value) {
+    if (!ctx || !key) return RALA_HIP_EINVAL;
+    if (!strcmp(key, "interval_pool_per_read_x1000")) { ctx->pool_per_read_x1000 = value; return RALA_HIP_OK; }
+    if (!strcmp(key, "max_lds_read_len")) { ctx->max_lds_read_len = value; return RALA_HIP_OK; }
+    return fail(ctx, RALA_HIP_EINVAL, "unknown option");
+}
+
+void* rala_hip_stream(rala_hip_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int rala_hip_set_reads(rala_hip_ctx* ctx, const uint32_t* read_len, uint64_t n_reads) {
+    if (!ctx || (!read_len && n_reads)) return RALA_HIP_EINVAL;
+    if (n_reads >= 0x7FFFFFFFull) return fail(ctx, RALA_HIP_EINVAL, "too many reads");
+    HIPCHECK(hipSetDevice(ctx->device));
+    ctx->n_reads = n_reads;
+    ctx->h_read_len.assign(read_len, read_len + n_reads);
+    ctx->h_pile_off.resize(n_reads + 1);
+    uint64_t off = 0;
+    for (uint64_t r = 0; r < n_reads; ++r) {
+        ctx->h_pile_off[r] = off;
+        off += ((uint64_t)read_len[r] + 7) & ~7ull;      // rows padded to 16 bytes
+    }
+    ctx->h_pile_off[n_reads] = off;
+    ctx->pile_elems = off;
+    HIPCHECK(ctx->d_read_len.ensure(n_reads + 1));
+    HIPCHECK(ctx->d_pile_off.ensure(n_reads + 1));
+    HIPCHECK(ctx->d_pile.ensure(off + 8));
+    HIPCHECK(hipMemcpy(ctx->d_read_len.p, read_len, n_reads * 4, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(ctx->d_pile_off.p, ctx->h_pile_off.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice));
+    std::vector<uint32_t> order;
+    build_classes(ctx, order);
+    HIPCHECK(ctx->d_order.ensure(n_reads));
+    if (n_reads) HIPCHECK(hipMemcpy(ctx->d_order.p, order.data(), n_reads * 4, hipMemcpyHostToDevice));
+    ctx->slab_grid = 0;
+    for (const LaunchClass& c : ctx->classes) {
+        if (!c.in_lds) {
+            ctx->slab_grid = std::min<uint32_t>(c.count, 512);
+            HIPCHECK(ctx->d_slab.ensure((size_t)ctx->slab_grid * 3 * c.lw));
+        }
+    }
+    HIPCHECK(ctx->d_ev_off.ensure(n_reads + 2)); HIPCHECK(ctx->d_cursor.ensure(n_reads + 2));
+    HIPCHECK(ctx->d_begin.ensure(n_reads)); HIPCHECK(ctx->d_end.ensure(n_reads));
+    HIPCHECK(ctx->d_median.ensure(n_reads)); HIPCHECK(ctx->d_p10.ensure(n_reads));
+    HIPCHECK(ctx->d_alive.ensure(n_reads)); HIPCHECK(ctx->d_n_pits.ensure(n_reads));
+    HIPCHECK(ctx->d_n_hills.ensure(n_reads)); HIPCHECK(ctx->d_iv_slot.ensure(n_reads));
+    HIPCHECK(ctx->d_death[0].ensure(n_reads)); HIPCHECK(ctx->d_death[1].ensure(n_reads));
+    ctx->pool_cap = (uint32_t)std::max<int64_t>(1024, (int64_t)n_reads * ctx->pool_per_read_x1000 / 1000);
+    HIPCHECK(ctx->d_pool.ensure(ctx->pool_cap));
+    ctx->initialized = ctx->constructed = false;
+    return RALA_HIP_OK;
+}
+
+int rala_hip_set_overlaps(rala_hip_ctx* ctx, const rala_hip_overlaps* o, uint64_t n, int mem) {
+    if (!ctx || (!o && n)) return RALA_HIP_EINVAL;
+    if (n >= 0xFFFFFFF0ull / 4) return fail(ctx, RALA_HIP_EINVAL, "too many overlaps for 32-bit bound offsets");
+    HIPCHECK(hipSetDevice(ctx->device));
+    ctx->n_ovl = n;
+    const uint32_t* src[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (n) {
+        src[0] = o->a_id; src[1] = o->b_id; src[2] = o->a_begin; src[3] = o->a_end;
+        src[4] = o->b_begin; src[5] = o->b_end; src[6] = o->length;
+    }
+    const uint32_t* dev[7];
+    const uint8_t* dev_strand;
+    if (mem == RALA_HIP_MEM_DEVICE) {
+        for (int k = 0; k < 7; ++k) dev[k] = src[k];
+        dev_strand = n ? o->strand : nullptr;
+    } else {
+        for (int k = 0; k < 7; ++k) {
+            HIPCHECK(ctx->d_ovl_u32[k].ensure(n));
+            if (n) HIPCHECK(hipMemcpy(ctx->d_ovl_u32[k].p, src[k], n * 4, hipMemcpyHostToDevice));
+            dev[k] = ctx->d_ovl_u32[k].p;
+        }
+        HIPCHECK(ctx->d_ovl_strand.ensure(n));
+        if (n) HIPCHECK(hipMemcpy(ctx->d_ovl_strand.p, o->strand, n, hipMemcpyHostToDevice));
+        dev_strand = ctx->d_ovl_strand.p;
+    }
+    ctx->ovl.a_id = dev[0]; ctx->ovl.b_id = dev[1]; ctx->ovl.a_begin = dev[2]; ctx->ovl.a_end = dev[3];
+    ctx->ovl.b_begin = dev[4]; ctx->ovl.b_end = dev[5]; ctx->ovl.length = dev[6]; ctx->ovl.strand = dev_strand;
+    ctx->ovl.n = n;
+    HIPCHECK(ctx->d_valid.ensure(n));
+    HIPCHECK(ctx->d_ev.ensure(4 * n + 8));
+    HIPCHECK(ctx->d_cls.ensure(n));
+    for (int k = 0; k < 2; ++k) { HIPCHECK(ctx->d_flag[k].ensure(n + 1)); HIPCHECK(ctx->d_pos[k].ensure(n + 2)); }
+    HIPCHECK(ctx->d_scan_ws.ensure(scan_workspace_bytes(std::max<uint64_t>(n, ctx->n_reads) + 2)));
+    ctx->initialized = ctx->constructed = false;
+    return RALA_HIP_OK;
+}
+
+int rala_hip_initialize(rala_hip_ctx* ctx) {
+    if (!ctx) return RALA_HIP_EINVAL;
+    if (ctx->n_reads == 0) return fail(ctx, RALA_HIP_EINVAL, "no reads set");
+    HIPCHECK(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const uint32_t n_reads = (uint32_t)ctx->n_reads;
+    ctx->tm = rala_hip_timings();
+    ctx->overlaps.clear(); ctx->internals.clear();
+    ctx->initialized = ctx->constructed = false;
+
+    HIPCHECK(hipMemsetAsync(ctx->d_small.p, 0, 8 * 4, s));
+    HIPCHECK(hipEventRecord(ctx->ev[0], s));
+    launch_dedupe(ctx->ovl, n_reads, ctx->d_valid.p, s);
+    HIPCHECK(hipEventRecord(ctx->ev[1], s));
+    // bucket bounds by read: count -> exclusive scan -> scatter
+    HIPCHECK(hipMemsetAsync(ctx->d_cursor.p, 0, (size_t)(n_reads + 1) * 4, s));
+    launch_count_bounds(ctx->ovl, n_reads, ctx->d_cursor.p, s);
+    launch_exclusive_scan(ctx->d_cursor.p, ctx->d_ev_off.p, n_reads, ctx->d_scan_ws.p, s);
+    HIPCHECK(hipMemcpyAsync(ctx->d_cursor.p, ctx->d_ev_off.p, (size_t)n_reads * 4, hipMemcpyDeviceToDevice, s));
+    launch_scatter_bounds(ctx->ovl, n_reads, ctx->d_cursor.p, ctx->d_ev.p, s);
+    HIPCHECK(hipEventRecord(ctx->ev[2], s));
+
+    PileArgs a;
+    a.read_len = ctx->d_read_len.p; a.pile_off = ctx->d_pile_off.p; a.pile = ctx->d_pile.p;
+    a.ev_off = ctx->d_ev_off.p; a.ev = ctx->d_ev.p;
+    a.add_to_existing = 0; a.slab = ctx->d_slab.p;
+    a.begin = ctx->d_begin.p; a.end = ctx->d_end.p; a.median = ctx->d_median.p; a.p10 = ctx->d_p10.p;
+    a.alive = ctx->d_alive.p; a.n_pits = ctx->d_n_pits.p; a.n_hills = ctx->d_n_hills.p; a.iv_slot = ctx->d_iv_slot.p;
+    a.pool = ctx->d_pool.p; a.pool_count = ctx->d_small.p; a.pool_cap = ctx->pool_cap; a.error = ctx->d_small.p + 1;
+    for (const LaunchClass& c : ctx->classes) {
+        a.order = ctx->d_order.p + c.first;
+        a.n_items = c.count;
+        a.lw = c.lw;
+        launch_pile_build_annotate(a, c.in_lds ? c.count : ctx->slab_grid, c.in_lds, s);
+        ++ctx->tm.pile_launches;
+    }
+    HIPCHECK(hipEventRecord(ctx->ev[3], s));
+    HIPCHECK(hipGetLastError());
+
+    int rc = download_read_state(ctx);
+    if (rc != RALA_HIP_OK) return rc;
+    uint32_t small[4];
+    HIPCHECK(hipMemcpy(small, ctx->d_small.p, sizeof(small), hipMemcpyDeviceToHost));
+    HIPCHECK(hipEventElapsedTime(&ctx->tm.dedupe_ms, ctx->ev[0], ctx->ev[1]));
+    HIPCHECK(hipEventElapsedTime(&ctx->tm.bucket_ms, ctx->ev[1], ctx->ev[2]));
+    HIPCHECK(hipEventElapsedTime(&ctx->tm.pile_ms, ctx->ev[2], ctx->ev[3]));
+    if (small[1] & kErrRegionCapacity) return fail(ctx, RALA_HIP_ECAPACITY, "slope-region list overflow in the pile kernel");
+    if (small[1] & kErrPoolCapacity) {
+        return fail(ctx, RALA_HIP_ECAPACITY, "interval pool exhausted (raise interval_pool_per_read_x1000)");
+    }
+    ctx->h_begin0 = ctx->h_begin;
+    ctx->h_end0 = ctx->h_end;
+    ctx->n_prefiltered = 0;
+    for (uint64_t r = 0; r < ctx->n_reads; ++r) if (!ctx->h_alive[r]) ++ctx->n_prefiltered;
+    ctx->initialized = true;
+    if (ctx->n_prefiltered == ctx->n_reads) return fail(ctx, RALA_HIP_EFILTERED, "filtered all sequences");
+    return RALA_HIP_OK;
+}
+
+int rala_hip_construct(rala_hip_ctx* ctx, const rala_hip_overlaps* sens, uint64_t n_sens) {
+    if (!ctx) return RALA_HIP_EINVAL;
+    if (!ctx->initialized) return fail(ctx, RALA_HIP_EINVAL, "rala_hip_initialize must succeed first");
+    if (ctx->constructed) return fail(ctx, RALA_HIP_EINVAL, "object already constructed");
+    if (sens != nullptr && n_sens != 0) return fail(ctx, RALA_HIP_EINVAL, "sensitive overlaps: not available yet");
+    HIPCHECK(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const uint32_t n_reads = (uint32_t)ctx->n_reads;
+    const uint64_t N = ctx->n_ovl;
+    const ReadState rs = read_state(ctx);
+
+    // ---- pass 2, static part ----
+    HIPCHECK(hipEventRecord(ctx->ev[4], s));
+    launch_classify(ctx->ovl, n_reads, ctx->d_valid.p, rs, ctx->d_cls.p, s);
+    HIPCHECK(hipEventRecord(ctx->ev[5], s));
+    // ---- in-order containment removal as a fixed point ----
+    int cur = 0;
+    HIPCHECK(hipMemsetAsync(ctx->d_death[0].p, 0xFF, (size_t)n_reads * 4, s));
+    ctx->tm.death_rounds = 0;
+    for (;;) {
+        HIPCHECK(hipMemsetAsync(ctx->d_death[cur ^ 1].p, 0xFF, (size_t)n_reads * 4, s));
+        HIPCHECK(hipMemsetAsync(ctx->d_small.p + 2, 0, 4, s));
+        launch_death_round(ctx->ovl, ctx->d_cls.p, ctx->d_death[cur].p, ctx->d_death[cur ^ 1].p, s);
+        launch_death_diff(ctx->d_death[cur].p, ctx->d_death[cur ^ 1].p, n_reads, ctx->d_small.p + 2, s);
+        uint32_t changed = 0;
+        HIPCHECK(hipMemcpyAsync(&changed, ctx->d_small.p + 2, 4, hipMemcpyDeviceToHost, s));
+        HIPCHECK(hipStreamSynchronize(s));
+        cur ^= 1;
+        ++ctx->tm.death_rounds;
+        if (!changed) break;
+        if (ctx->tm.death_rounds > 100000) return fail(ctx, RALA_HIP_EDEVICE, "containment fixed point did not converge");
+    }
+    HIPCHECK(hipEventRecord(ctx->ev[6], s));
+    // ---- liveness, hill counters, survivors ----
+    launch_finish_pass2(ctx->ovl, ctx->d_cls.p, ctx->d_death[cur].p, rs, ctx->d_flag[0].p, ctx->d_flag[1].p, s);
+    launch_apply_death(ctx->d_death[cur].p, ctx->d_alive.p, n_reads, s);
+    uint32_t n_surv[2] = {0, 0};
+    for (int k = 0; k < 2; ++k) {
+        launch_exclusive_scan(ctx->d_flag[k].p, ctx->d_pos[k].p, N, ctx->d_scan_ws.p, s);
+        HIPCHECK(hipMemcpyAsync(&n_surv[k], ctx->d_pos[k].p + N, 4, hipMemcpyDeviceToHost, s));
+    }
+    HIPCHECK(hipStreamSynchronize(s));
+    std::vector<HostOvl>* lists[2] = {&ctx->overlaps, &ctx->internals};
+    for (int k = 0; k < 2; ++k) {
+        const uint32_t m = n_surv[k];
+        lists[k]->clear();
+        if (m == 0) continue;
+        Survivors sv;
+        for (int f = 0; f < 8; ++f) HIPCHECK(ctx->d_surv_u32[f].ensure(m));
+        for (int f = 0; f < 2; ++f) HIPCHECK(ctx->d_surv_u8[f].ensure(m));
+        sv.src = ctx->d_surv_u32[0].p; sv.a_id = ctx->d_surv_u32[1].p; sv.b_id = ctx->d_surv_u32[2].p;
+        sv.a_begin = ctx->d_surv_u32[3].p; sv.a_end = ctx->d_surv_u32[4].p; sv.b_begin = ctx->d_surv_u32[5].p;
+        sv.b_end = ctx->d_surv_u32[6].p; sv.length = ctx->d_surv_u32[7].p;
+        sv.strand = ctx->d_surv_u8[0].p; sv.type = ctx->d_surv_u8[1].p;
+        // trim in the gather re-derives the coordinates against the pass-1 piles
+        ReadState rs1 = rs;
+        launch_gather_survivors(ctx->ovl, ctx->d_cls.p, rs1, ctx->d_flag[k].p, ctx->d_pos[k].p, sv, s);
+        std::vector<uint32_t> h[8];
+        std::vector<uint8_t> hs(m);
+        for (int f = 0; f < 8; ++f) {
+            h[f].resize(m);
+            HIPCHECK(hipMemcpyAsync(h[f].data(), ctx->d_surv_u32[f].p, (size_t)m * 4, hipMemcpyDeviceToHost, s));
+        }
+        HIPCHECK(hipMemcpyAsync(hs.data(), sv.strand, m, hipMemcpyDeviceToHost, s));
+        HIPCHECK(hipStreamSynchronize(s));
+        lists[k]->resize(m);
+        for (uint32_t i = 0; i < m; ++i) {
+            HostOvl& o = (*lists[k])[i];
+            o.src = h[0][i]; o.a = h[1][i]; o.b = h[2][i];
+            o.c.a_begin = h[3][i]; o.c.a_end = h[4][i]; o.c.b_begin = h[5][i]; o.c.b_end = h[6][i];
+            o.c.length = h[7][i];
+            o.strand = hs[i]; o.dead = 0;
+        }
+    }
+    HIPCHECK(hipEventRecord(ctx->ev[7], s));
+    HIPCHECK(hipGetLastError());
+    // refreshed read state: liveness after the scan, hill counters in the pool
+    int rc = download_read_state(ctx);
+    if (rc != RALA_HIP_OK) return rc;
+    HIPCHECK(hipEventElapsedTime(&ctx->tm.classify_ms, ctx->ev[4], ctx->ev[5]));
+    HIPCHECK(hipEventElapsedTime(&ctx->tm.death_ms, ctx->ev[5], ctx->ev[6]));
+    HIPCHECK(hipEventElapsedTime(&ctx->tm.finish_ms, ctx->ev[6], ctx->ev[7]));
+
+    // ---- sequential tail on the survivors ----
+    const double t0 = now_ms();
+    preprocess_chimeras(ctx);
+    build_graph(ctx);
+    ctx->tm.tail_host_ms = (float)(now_ms() - t0);
+
+    // push the final valid regions / liveness back, re-zero the piles outside them
+    HIPCHECK(hipMemcpyAsync(ctx->d_begin.p, ctx->h_begin.data(), (size_t)n_reads * 4, hipMemcpyHostToDevice, s));
+    HIPCHECK(hipMemcpyAsync(ctx->d_end.p, ctx->h_end.data(), (size_t)n_reads * 4, hipMemcpyHostToDevice, s));
+    HIPCHECK(hipMemcpyAsync(ctx->d_alive.p, ctx->h_alive.data(), (size_t)n_reads, hipMemcpyHostToDevice, s));
+    HIPCHECK(hipStreamSynchronize(s));
+    ctx->constructed = true;
+    return RALA_HIP_OK;
+}
+
+int rala_hip_remove_transitive_edges(rala_hip_ctx* ctx, uint32_t* n_pairs) {
+    if (!ctx || !n_pairs) return RALA_HIP_EINVAL;
+    if (!ctx->constructed) return fail(ctx, RALA_HIP_EINVAL, "rala_hip_construct must succeed first");
+    HIPCHECK(hipSetDevice(ctx->device));
+    const uint32_t ne = (uint32_t)ctx->e_src.size();
+    ctx->e_mark.assign(ne, 0);
+    return tr_mark_impl(ctx, (uint32_t)ctx->node_read.size(), ne, ctx->e_src.data(), ctx->e_dst.data(),
+                        ctx->e_len.data(), ctx->e_mark.data(), n_pairs);
+}
+
+int rala_hip_tr_mark(rala_hip_ctx* ctx, uint32_t n_nodes, uint32_t n_edges, const uint32_t* src,
+                     const uint32_t* dst, const uint32_t* len, uint8_t* marks, uint32_t* n_pairs) {
+    if (!ctx || !n_pairs || (n_edges && (!src || !dst || !len || !marks))) return RALA_HIP_EINVAL;
+    HIPCHECK(hipSetDevice(ctx->device));
+    return tr_mark_impl(ctx, n_nodes, n_edges, src, dst, len, marks, n_pairs);
+}
+
+// ---- results ---------------------------------------------------------------------------
+int rala_hip_get_valid(rala_hip_ctx* ctx, uint8_t* valid) {
+    if (!ctx || !valid) return RALA_HIP_EINVAL;
+    if (!ctx->initialized) return fail(ctx, RALA_HIP_EINVAL, "not initialized");
+    HIPCHECK(hipSetDevice(ctx->device));
+    if (ctx->n_ovl) HIPCHECK(hipMemcpy(valid, ctx->d_valid.p, ctx->n_ovl, hipMemcpyDeviceToHost));
+    return RALA_HIP_OK;
+}
+
+int rala_hip_get_piles(rala_hip_ctx* ctx, uint32_t* begin, uint32_t* end, uint16_t* median, uint16_t* p10,
+                       uint8_t* alive) {
+    if (!ctx) return RALA_HIP_EINVAL;
+    if (!ctx->initialized) return fail(ctx, RALA_HIP_EINVAL, "not initialized");
+    const uint64_t n = ctx->n_reads;
+    for (uint64_t r = 0; r < n; ++r) {
+        const bool a = ctx->h_alive[r];
+        if (begin) begin[r] = a ? ctx->h_begin[r] : 0;
+        if (end) end[r] = a ? ctx->h_end[r] : 0;
+        if (median) median[r] = a ? ctx->h_median[r] : 0;
+        if (p10) p10[r] = a ? ctx->h_p10[r] : 0;
+        if (alive) alive[r] = a;
+    }
+    return RALA_HIP_OK;
+}
+
+int rala_hip_get_pile_data(rala_hip_ctx* ctx, uint64_t read, uint16_t* data) {
+    if (!ctx || !data) return RALA_HIP_EINVAL;
+    if (!ctx->initialized || read >= ctx->n_reads) return fail(ctx, RALA_HIP_EINVAL, "bad read / not initialized");
+    HIPCHECK(hipSetDevice(ctx->device));
+    const uint32_t n = ctx->h_read_len[read];
+    HIPCHECK(hipMemcpy(data, ctx->d_pile.p + ctx->h_pile_off[read], (size_t)n * 2, hipMemcpyDeviceToHost));
+    // Pile::shrink zeroes outside the current valid region (pile.cpp:311-318); the
+    // host tail narrows regions after the pile was written
+    if (ctx->h_alive[read]) {
+        const uint32_t B = ctx->h_begin[read], E = ctx->h_end[read];
+        for (uint32_t j = 0; j < B && j < n; ++j) data[j] = 0;
+        for (uint32_t j = E; j < n; ++j) data[j] = 0;
+    }
+    return RALA_HIP_OK;
+}
+
+int rala_hip_get_intervals(rala_hip_ctx* ctx, int kind, uint64_t* offsets, uint32_t* pairs, uint32_t* aux) {
+    if (!ctx || !offsets) return RALA_HIP_EINVAL;
+    if (!ctx->initialized) return fail(ctx, RALA_HIP_EINVAL, "not initialized");
+    if (kind < 0 || kind > 2) return fail(ctx, RALA_HIP_EINVAL, "bad interval kind");
+    const uint64_t n = ctx->n_reads;
+    uint64_t off = 0;
+    for (uint64_t r = 0; r < n; ++r) {
+        offsets[r] = off;
+        if (!ctx->h_alive[r] || kind == 2) continue;
+        const uint32_t cnt = kind == 0 ? ctx->h_n_pits[r] : ctx->h_n_hills[r];
+        if (cnt == 0) continue;
+        // hills follow the pits found by the pile kernel; the tail only ever drops pits
+        // from the front segment in place, so the initial pit count is what the
+        // device wrote into the pool layout: recover it from the device-side array
+        const Interval* base = ctx->h_pool.data() + ctx->h_slot[r];
+        const Interval* iv = base;
+        if (kind == 1) iv = base + ctx->h_n_pits[r];
+        if (pairs) {
+            for (uint32_t k = 0; k < cnt; ++k) {
+                pairs[2 * (off + k)] = iv[k].first;
+                pairs[2 * (off + k) + 1] = iv[k].second;
+                if (aux) aux[off + k] = iv[k].aux;
+            }
+        }
+        off += cnt;
+    }
+    offsets[n] = off;
+    return RALA_HIP_OK;
+}
+
+int rala_hip_get_overlaps(rala_hip_ctx* ctx, int which, uint64_t* n, uint32_t* src_index, uint32_t* a_begin,
+                          uint32_t* a_end, uint32_t* b_begin, uint32_t* b_end, uint32_t* length, uint8_t* type) {
+    if (!ctx || !n) return RALA_HIP_EINVAL;
+    if (!ctx->constructed) return fail(ctx, RALA_HIP_EINVAL, "not constructed");
+    const std::vector<HostOvl>& v = which == 0 ? ctx->overlaps : ctx->internals;
+    *n = v.size();
+    if (!src_index) return RALA_HIP_OK;
+    for (size_t k = 0; k < v.size(); ++k) {
+        src_index[k] = v[k].src;
+        if (a_begin) a_begin[k] = v[k].c.a_begin;
+        if (a_end) a_end[k] = v[k].c.a_end;
+        if (b_begin) b_begin[k] = v[k].c.b_begin;
+        if (b_end) b_end[k] = v[k].c.b_end;
+        if (length) length[k] = v[k].c.length;
+        if (type) type[k] = (uint8_t)host_type(ctx, v[k]);
+    }
+    return RALA_HIP_OK;
+}
+
+int rala_hip_get_graph_size(rala_hip_ctx* ctx, uint64_t* n_nodes, uint64_t* n_edges) {
+    if (!ctx || !n_nodes || !n_edges) return RALA_HIP_EINVAL;
+    if (!ctx->constructed) return fail(ctx, RALA_HIP_EINVAL, "not constructed");
+    *n_nodes = ctx->node_read.size();
+    *n_edges = ctx->e_src.size();
+    return RALA_HIP_OK;
+}
+
+int rala_hip_get_graph(rala_hip_ctx* ctx, uint32_t* node_read, uint32_t* src, uint32_t* dst, uint32_t* len,
+                       uint8_t* marks) {
+    if (!ctx) return RALA_HIP_EINVAL;
+    if (!ctx->constructed) return fail(ctx, RALA_HIP_EINVAL, "not constructed");
+    if (node_read) memcpy(node_read, ctx->node_read.data(), ctx->node_read.size() * 4);
+    const size_t ne = ctx->e_src.size();
+    if (src) memcpy(src, ctx->e_src.data(), ne * 4);
+    if (dst) memcpy(dst, ctx->e_dst.data(), ne * 4);
+    if (len) memcpy(len, ctx->e_len.data(), ne * 4);
+    if (marks) memcpy(marks, ctx->e_mark.data(), ne);
+    return RALA_HIP_OK;
+}
+
+int rala_hip_get_timings(rala_hip_ctx* ctx, rala_hip_timings* out) {
+    if (!ctx || !out) return RALA_HIP_EINVAL;
+    *out = ctx->tm;
+    out->total_ms = ctx->tm.dedupe_ms + ctx->tm.bucket_ms + ctx->tm.pile_ms + ctx->tm.classify_ms + ctx->tm.death_ms +
+                    ctx->tm.finish_ms + ctx->tm.tail_host_ms + ctx->tm.tr_ms;
+    return RALA_HIP_OK;
+}
+
+int rala_hip_get_num_prefiltered(rala_hip_ctx* ctx, uint64_t* n) {
+    if (!ctx || !n) return RALA_HIP_EINVAL;
+    *n = ctx->n_prefiltered;
+    return RALA_HIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,80 @@
+// Transitive-edge marking on a CSR overlap graph.
+//
+// Reference: rvaser/rala Graph::remove_transitive_edges (src/graph.cpp:1281-1335).
+// For every path a->b->c with an edge a->c present, a->c (the LAST such edge in
+// a's out-list, graph.cpp:1291-1293) and its reverse-complement twin are marked
+// when len(ab)+len(bc) is within 12 % of len(ac) (comparable(), :26-29, FP64).
+// Marked edges keep serving as ab / bc, so the marked set does not depend on
+// the visiting order (SURVEY B-T15): one wavefront-independent thread per
+// edge a->b probes a's out-list for every successor of b.
+#include <hip/hip_runtime.h>
+
+#include "device_utils.h"
+#include "geom.h"
+#include "kernels.h"
+
+namespace rala_hip {
+
+namespace {
+
+constexpr int kBlock = 256;
+
+__global__ __launch_bounds__(kBlock) void tr_mark_kernel(const uint32_t* __restrict__ row_ptr,
+                                                         const uint32_t* __restrict__ adj,
+                                                         const uint32_t* __restrict__ esrc,
+                                                         const uint32_t* __restrict__ edst,
+                                                         const uint32_t* __restrict__ elen, uint32_t n_edges,
+                                                         uint8_t* marks) {
+    const uint32_t e_ab = blockIdx.x * kBlock + threadIdx.x;
+    if (e_ab >= n_edges) return;
+    const uint32_t a = esrc[e_ab], b = edst[e_ab];
+    const uint32_t len_ab = elen[e_ab];
+    const uint32_t a0 = row_ptr[a], a1 = row_ptr[a + 1];
+    const uint32_t b0 = row_ptr[b], b1 = row_ptr[b + 1];
+    for (uint32_t k = b0; k < b1; ++k) {
+        const uint32_t e_bc = adj[k];
+        const uint32_t c = edst[e_bc];
+        // last edge a->c in a's out-list is the candidate
+        uint32_t cand = 0xFFFFFFFFu;
+        for (uint32_t m = a1; m-- > a0;) {
+            const uint32_t e = adj[m];
+            if (edst[e] == c) { cand = e; break; }
+        }
+        if (cand == 0xFFFFFFFFu) continue;
+        const uint32_t sum = len_ab + elen[e_bc];
+        if (comparable((double)sum, (double)elen[cand], 0.12)) {
+            marks[cand] = 1;
+            marks[cand ^ 1u] = 1;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void tr_count_kernel(const uint8_t* __restrict__ marks, uint32_t n_edges,
+                                                          uint32_t* n_pairs) {
+    __shared__ uint32_t tmp[kBlock / 64 + 1];
+    const uint32_t p = blockIdx.x * kBlock + threadIdx.x;     // pair index
+    uint32_t v = 0;
+    if (2 * p + 1 < n_edges) v = marks[2 * p] ? 1u : 0u;
+    v = block_reduce<kBlock>(v, OpAdd(), 0u, tmp);
+    if (threadIdx.x == 0 && v) atomicAdd(n_pairs, v);
+}
+
+}  // namespace
+
+void launch_tr_mark(const uint32_t* row_ptr, const uint32_t* adj_edge, const uint32_t* edge_src,
+                    const uint32_t* edge_dst, const uint32_t* edge_len, uint32_t n_nodes, uint32_t n_edges,
+                    uint8_t* marks, hipStream_t s) {
+    (void)n_nodes;
+    if (n_edges == 0) return;
+    hipLaunchKernelGGL(tr_mark_kernel, dim3((n_edges + kBlock - 1) / kBlock), dim3(kBlock), 0, s, row_ptr, adj_edge,
+                       edge_src, edge_dst, edge_len, n_edges, marks);
+}
+
+void launch_tr_count(const uint8_t* marks, uint32_t n_edges, uint32_t* n_pairs, hipStream_t s) {
+    const uint32_t pairs = n_edges / 2;
+    if (pairs == 0) return;
+    hipLaunchKernelGGL(tr_count_kernel, dim3((pairs + kBlock - 1) / kBlock), dim3(kBlock), 0, s, marks, n_edges,
+                       n_pairs);
+}
+
+}  // namespace rala_hip

@@ -1,0 +1,247 @@
+"""ctypes binding of librala_hip's C ABI (include/rala_hip.h).
+
+Used by the tests and by bench.py.  There is no fallback of any kind: if the shared
+library is missing or no HIP device is usable, construction raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from . import build as _build
+
+TYPE_X, TYPE_A, TYPE_B, TYPE_AB, TYPE_BA = range(5)
+NO_READ = 0xFFFFFFFF
+MEM_HOST, MEM_DEVICE = 0, 1
+
+ERRORS = {0: "OK", -1: "EDEVICE", -2: "EINVAL", -3: "ECAPACITY", -4: "EFILTERED", -5: "ENOMEM"}
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "librala_hip.so")
+
+# every symbol include/rala_hip.h declares
+SYMBOLS = (
+    "rala_hip_create", "rala_hip_destroy", "rala_hip_last_error", "rala_hip_set_option", "rala_hip_stream",
+    "rala_hip_set_reads", "rala_hip_set_overlaps", "rala_hip_initialize", "rala_hip_construct",
+    "rala_hip_remove_transitive_edges", "rala_hip_tr_mark", "rala_hip_get_valid", "rala_hip_get_piles",
+    "rala_hip_get_pile_data", "rala_hip_get_intervals", "rala_hip_get_overlaps", "rala_hip_get_graph_size",
+    "rala_hip_get_graph", "rala_hip_get_timings", "rala_hip_get_num_prefiltered",
+)
+
+
+class OverlapsC(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in
+                ("a_id", "b_id", "a_begin", "a_end", "b_begin", "b_end", "length", "strand")]
+
+
+class Timings(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_float) for n in
+                ("dedupe_ms", "bucket_ms", "pile_ms", "classify_ms", "death_ms", "finish_ms", "tail_host_ms",
+                 "tr_ms", "total_ms")] + [("pile_launches", ctypes.c_uint32), ("death_rounds", ctypes.c_uint32)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+_lib = None
+
+
+def lib(build=True):
+    """Load librala_hip.so (building it in-tree first when sources are newer)."""
+    global _lib
+    if _lib is None:
+        path = LIB_PATH
+        if build:
+            path = _build.build_hip()
+        if not os.path.exists(path):
+            raise RuntimeError("librala_hip.so is missing: run __graft_entry__.build()")
+        L = ctypes.CDLL(path)
+        vp, u64, u32, i32 = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int
+        L.rala_hip_create.argtypes = [i32, ctypes.POINTER(vp)]
+        L.rala_hip_destroy.argtypes = [vp]
+        L.rala_hip_destroy.restype = None
+        L.rala_hip_last_error.argtypes = [vp]
+        L.rala_hip_last_error.restype = ctypes.c_char_p
+        L.rala_hip_set_option.argtypes = [vp, ctypes.c_char_p, ctypes.c_int64]
+        L.rala_hip_stream.argtypes = [vp]
+        L.rala_hip_stream.restype = vp
+        L.rala_hip_set_reads.argtypes = [vp, vp, u64]
+        L.rala_hip_set_overlaps.argtypes = [vp, ctypes.POINTER(OverlapsC), u64, i32]
+        L.rala_hip_initialize.argtypes = [vp]
+        L.rala_hip_construct.argtypes = [vp, ctypes.POINTER(OverlapsC), u64]
+        L.rala_hip_remove_transitive_edges.argtypes = [vp, ctypes.POINTER(u32)]
+        L.rala_hip_tr_mark.argtypes = [vp, u32, u32, vp, vp, vp, vp, ctypes.POINTER(u32)]
+        L.rala_hip_get_valid.argtypes = [vp, vp]
+        L.rala_hip_get_piles.argtypes = [vp, vp, vp, vp, vp, vp]
+        L.rala_hip_get_pile_data.argtypes = [vp, u64, vp]
+        L.rala_hip_get_intervals.argtypes = [vp, i32, vp, vp, vp]
+        L.rala_hip_get_overlaps.argtypes = [vp, i32, ctypes.POINTER(u64), vp, vp, vp, vp, vp, vp, vp]
+        L.rala_hip_get_graph_size.argtypes = [vp, ctypes.POINTER(u64), ctypes.POINTER(u64)]
+        L.rala_hip_get_graph.argtypes = [vp, vp, vp, vp, vp, vp]
+        L.rala_hip_get_timings.argtypes = [vp, ctypes.POINTER(Timings)]
+        L.rala_hip_get_num_prefiltered.argtypes = [vp, ctypes.POINTER(u64)]
+        _lib = L
+    return _lib
+
+
+class RalaHipError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__("librala_hip: %s (%d): %s" % (ERRORS.get(code, "?"), code, text))
+        self.code = code
+
+
+def _soa(ov):
+    """OverlapsC over an object with numpy members a_id … strand (kept alive by the caller)."""
+    c = OverlapsC()
+    for name, _ in OverlapsC._fields_:
+        arr = getattr(ov, name)
+        want = np.uint8 if name == "strand" else np.uint32
+        assert arr.dtype == want and arr.flags["C_CONTIGUOUS"], name
+        setattr(c, name, arr.ctypes.data)
+    return c
+
+
+class Context:
+    """One librala_hip context = one data set on one GPU."""
+
+    def __init__(self, device=0):
+        self.L = lib()
+        h = ctypes.c_void_p()
+        rc = self.L.rala_hip_create(device, ctypes.byref(h))
+        if rc != 0:
+            raise RalaHipError(rc, "no usable HIP device %d" % device)
+        self.h = h
+        self.n_reads = 0
+        self.n_overlaps = 0
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.rala_hip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RalaHipError(rc, self.L.rala_hip_last_error(self.h).decode())
+
+    def set_option(self, key, value):
+        self._check(self.L.rala_hip_set_option(self.h, key.encode(), int(value)))
+
+    def stream(self):
+        return self.L.rala_hip_stream(self.h)
+
+    # ---- inputs ----
+    def set_reads(self, read_len):
+        rl = np.ascontiguousarray(read_len, dtype=np.uint32)
+        self.read_len = rl
+        self.n_reads = int(rl.shape[0])
+        self._check(self.L.rala_hip_set_reads(self.h, rl.ctypes.data, self.n_reads))
+
+    def set_overlaps(self, ov):
+        c = _soa(ov)
+        self.n_overlaps = len(ov)
+        self._check(self.L.rala_hip_set_overlaps(self.h, ctypes.byref(c), self.n_overlaps, MEM_HOST))
+
+    def set_overlaps_device(self, ptrs, n):
+        """ptrs: dict name -> device pointer (int); the memory must outlive the context's use."""
+        c = OverlapsC()
+        for name, _ in OverlapsC._fields_:
+            setattr(c, name, ptrs[name])
+        self.n_overlaps = int(n)
+        self._check(self.L.rala_hip_set_overlaps(self.h, ctypes.byref(c), self.n_overlaps, MEM_DEVICE))
+
+    # ---- stages ----
+    def initialize(self):
+        self._check(self.L.rala_hip_initialize(self.h))
+
+    def construct(self, sens=None):
+        if sens is not None and len(sens):
+            c = _soa(sens)
+            self._check(self.L.rala_hip_construct(self.h, ctypes.byref(c), len(sens)))
+        else:
+            self._check(self.L.rala_hip_construct(self.h, None, 0))
+
+    def remove_transitive_edges(self):
+        n = ctypes.c_uint32(0)
+        self._check(self.L.rala_hip_remove_transitive_edges(self.h, ctypes.byref(n)))
+        return int(n.value)
+
+    def tr_mark(self, n_nodes, src, dst, length):
+        src = np.ascontiguousarray(src, dtype=np.uint32)
+        dst = np.ascontiguousarray(dst, dtype=np.uint32)
+        length = np.ascontiguousarray(length, dtype=np.uint32)
+        marks = np.zeros(len(src), dtype=np.uint8)
+        n = ctypes.c_uint32(0)
+        self._check(self.L.rala_hip_tr_mark(self.h, n_nodes, len(src), src.ctypes.data, dst.ctypes.data,
+                                            length.ctypes.data, marks.ctypes.data, ctypes.byref(n)))
+        return marks, int(n.value)
+
+    # ---- results ----
+    def valid(self):
+        out = np.zeros(self.n_overlaps, dtype=np.uint8)
+        self._check(self.L.rala_hip_get_valid(self.h, out.ctypes.data))
+        return out
+
+    def piles(self):
+        n = self.n_reads
+        d = dict(begin=np.zeros(n, np.uint32), end=np.zeros(n, np.uint32), median=np.zeros(n, np.uint16),
+                 p10=np.zeros(n, np.uint16), alive=np.zeros(n, np.uint8))
+        self._check(self.L.rala_hip_get_piles(self.h, d["begin"].ctypes.data, d["end"].ctypes.data,
+                                              d["median"].ctypes.data, d["p10"].ctypes.data,
+                                              d["alive"].ctypes.data))
+        return d
+
+    def pile_data(self, r):
+        out = np.zeros(int(self.read_len[r]), dtype=np.uint16)
+        self._check(self.L.rala_hip_get_pile_data(self.h, r, out.ctypes.data))
+        return out
+
+    def intervals(self, kind):
+        """(offsets[n+1] uint64, pairs[k,2] uint32, aux[k] uint32)"""
+        offs = np.zeros(self.n_reads + 1, dtype=np.uint64)
+        self._check(self.L.rala_hip_get_intervals(self.h, kind, offs.ctypes.data, None, None))
+        k = int(offs[-1])
+        pairs = np.zeros((k, 2), dtype=np.uint32)
+        aux = np.zeros(k, dtype=np.uint32)
+        if k:
+            self._check(self.L.rala_hip_get_intervals(self.h, kind, offs.ctypes.data, pairs.ctypes.data,
+                                                      aux.ctypes.data))
+        return offs, pairs, aux
+
+    def overlap_list(self, which=0):
+        n = ctypes.c_uint64(0)
+        self._check(self.L.rala_hip_get_overlaps(self.h, which, ctypes.byref(n), *([None] * 7)))
+        m = int(n.value)
+        d = dict(src=np.zeros(m, np.uint32), a_begin=np.zeros(m, np.uint32), a_end=np.zeros(m, np.uint32),
+                 b_begin=np.zeros(m, np.uint32), b_end=np.zeros(m, np.uint32), length=np.zeros(m, np.uint32),
+                 type=np.zeros(m, np.uint8))
+        if m:
+            self._check(self.L.rala_hip_get_overlaps(self.h, which, ctypes.byref(n), *[
+                d[k].ctypes.data for k in ("src", "a_begin", "a_end", "b_begin", "b_end", "length", "type")]))
+        return d
+
+    def graph(self):
+        nn, ne = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        self._check(self.L.rala_hip_get_graph_size(self.h, ctypes.byref(nn), ctypes.byref(ne)))
+        nn, ne = int(nn.value), int(ne.value)
+        d = dict(node_read=np.zeros(nn, np.uint32), src=np.zeros(ne, np.uint32), dst=np.zeros(ne, np.uint32),
+                 len=np.zeros(ne, np.uint32), marked=np.zeros(ne, np.uint8))
+        self._check(self.L.rala_hip_get_graph(self.h, d["node_read"].ctypes.data, d["src"].ctypes.data,
+                                              d["dst"].ctypes.data, d["len"].ctypes.data,
+                                              d["marked"].ctypes.data))
+        return d
+
+    def timings(self):
+        t = Timings()
+        self._check(self.L.rala_hip_get_timings(self.h, ctypes.byref(t)))
+        return t.as_dict()
+
+    def num_prefiltered(self):
+        n = ctypes.c_uint64(0)
+        self._check(self.L.rala_hip_get_num_prefiltered(self.h, ctypes.byref(n)))
+        return int(n.value)

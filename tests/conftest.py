@@ -1,0 +1,29 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def hip_ctx_factory():
+    """Factory of librala_hip contexts; fails loudly when there is no GPU / library."""
+    from rala_amd import hip
+
+    made = []
+
+    def make(device=0):
+        c = hip.Context(device)
+        made.append(c)
+        return c
+
+    yield make
+    for c in made:
+        c.close()

@@ -1,0 +1,25 @@
+"""Parity of the HIP hot path with the oracle, through the C ABI (needs an MI355X)."""
+import numpy as np
+import pytest
+
+from rala_amd.synth import Dataset
+
+import parity
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n,g,seed", [(1000, 200_000, 1), (3000, 600_000, 21), (5000, 1_000_000, 7),
+                                      (2000, 1_200_000, 33)])
+def test_full_path_small(hip_ctx_factory, n, g, seed):
+    ds = Dataset(n, g, seed)
+    st = parity.oracle_stages(ds)
+    ctx = hip_ctx_factory()
+    ctx.set_reads(ds.read_len)
+    ctx.set_overlaps(ds.overlaps)
+    ctx.initialize()
+    parity.check_initialize(ctx, st, ds)
+    ctx.construct()
+    parity.check_construct(ctx, st)
+    parity.check_tr(ctx, st)
+    print(ctx.timings())
