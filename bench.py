@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""Throughput of Rala's hot path on MI355X: overlaps/sec for pile build + filtering +
+graph construction + transitive reduction (BASELINE.json metric), synthetic input of the
+named shape resident in HBM before the timed region.
+
+    python bench.py --gpus 1 --steps K --warmup W [--workload c3|c2|c1]
+
+One step = one pass of the whole hot path over the data set: rala_hip_initialize
+(duplicate removal, bound bucketing, pile build + annotation), rala_hip_construct
+(second overlap pass, containment fixed point, preprocess tail, graph build) and
+rala_hip_remove_transitive_edges.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md)
+
+WORKLOADS = {
+    "c1": "1k reads / 50k overlaps (BASELINE configs[0])",
+    "c2": "100k reads / 5M overlaps (BASELINE configs[1])",
+    "c3": "1M reads / 50M overlaps (BASELINE configs[2])",
+}
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(sample_name="c2"):
+    """Oracle (CPU restatement, one task per pile on a thread pool) on a bounded sample."""
+    from oracle.oracle import Oracle
+    from rala_amd.synth import Dataset
+
+    cores = os.cpu_count() or 1
+    ds = Dataset.config(sample_name)
+    t0 = time.perf_counter()
+    o = Oracle(ds.read_len, ds.overlaps, n_threads=cores)
+    rc = o.construct()
+    n_tr = o.remove_transitive_edges() if rc == 0 else 0
+    dt = time.perf_counter() - t0
+    return {
+        "value": len(ds.overlaps) / dt,
+        "unit": "overlaps/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": "%s synthetic, %d reads / %d overlaps, whole hot path once, %.2f s, %d transitive pairs" % (
+            sample_name, ds.n_reads, len(ds.overlaps), dt, n_tr),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default=os.environ.get("RALA_BENCH_WORKLOAD", "c3"), choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if args.gpus != world:
+        log("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device")
+
+    from rala_amd import hip
+    from rala_amd.synth import Dataset
+
+    t0 = time.perf_counter()
+    ds = Dataset.config(args.workload)
+    n_ovl = len(ds.overlaps)
+    sum_len = int(ds.read_len.astype(np.int64).sum())
+    log("[bench] generated %s: %d reads, %d overlaps in %.1f s" % (args.workload, ds.n_reads, n_ovl,
+                                                                    time.perf_counter() - t0))
+    if world > 1:
+        from rala_amd import multi
+        runner = multi.ShardedRunner(ds, rank, world, local_rank)
+    else:
+        ctx = hip.Context(local_rank)
+        ctx.set_reads(ds.read_len)
+        ctx.set_overlaps(ds.overlaps)          # inputs resident in HBM from here on
+
+        class _Single:
+            def step(self):
+                ctx.initialize()
+                ctx.construct()
+                return ctx.remove_transitive_edges()
+
+            def timings(self):
+                return ctx.timings()
+        runner = _Single()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    n_tr = 0
+    for _ in range(args.warmup):
+        n_tr = runner.step()
+    stage = {}
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        n_tr = runner.step()
+        for k, v in runner.timings().items():
+            stage[k] = stage.get(k, 0.0) + float(v)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        steps = max(1, args.steps)
+        ms = 1000.0 * dt / steps
+        for k in stage:
+            stage[k] /= steps
+        # dominant kernel: pile_build_annotate.  Algorithmic bytes of one step's launches:
+        # 16 B per overlap of bucketed bounds read + 2 B per base of pile written + 40 B per
+        # read of annotations (DESIGN.md "Roofline"); time = HIP events
+        # around those launches on the context's stream.
+        pile_bytes = 16.0 * n_ovl + 2.0 * sum_len + 40.0 * ds.n_reads
+        pile_ms = stage.get("pile_ms", 0.0)
+        achieved = pile_bytes / (pile_ms * 1e-3) / 1e9 if pile_ms > 0 else 0.0
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
+                pm = json.load(f)
+            if pm.get("workload") == args.workload:
+                traffic = pm.get("hbm_bytes_per_step")
+        except Exception:
+            pass
+        out = {
+            "metric": "overlaps/sec (pile build + transitive reduction)",
+            "value": n_ovl * steps / dt,
+            "unit": "overlaps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "u16/u32 (+f64 compares)",
+            "data": "synthetic",
+            "config": {"workload": WORKLOADS[args.workload], "n_reads": ds.n_reads, "n_overlaps": n_ovl,
+                       "sum_read_len": sum_len, "transitive_pairs": int(n_tr)},
+            "roofline": {"bound": "hbm", "kernel": "pile_build_annotate", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "algorithmic_bytes": pile_bytes, "kernel_ms": pile_ms},
+            "stage_ms": stage,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline("c2" if args.workload != "c1" else "c1")
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

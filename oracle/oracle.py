@@ -249,7 +249,8 @@ class Oracle:
     def find_slopes(self, r, q, cap=4096):
         out = np.zeros((cap, 2), dtype=np.uint32)
         n = int(self.L.ora_pile_find_slopes(self.h, r, q, out.ctypes.data, cap))
-        assert n <= cap
+        if n > cap:
+            return self.find_slopes(r, q, cap=n)
         return out[:n].copy()
 
     def interval_merge(self, iv):

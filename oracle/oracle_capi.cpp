@@ -209,7 +209,9 @@ uint64_t ora_get_overlaps(void* p, int which, uint64_t* src, uint32_t* a_begin, 
             a_begin[k] = d.bk.a_begin(v[k].h); a_end[k] = d.bk.a_end(v[k].h);
             b_begin[k] = d.bk.b_begin(v[k].h); b_end[k] = d.bk.b_end(v[k].h);
             length[k] = d.bk.length(v[k].h);
-            type[k] = (uint8_t)d.bk.type(v[k].h);
+            // internals can outlive their piles (graph.cpp:849-867 never re-checks them)
+            const bool live = d.bk.alive(d.bk.a_id(v[k].h)) && d.bk.alive(d.bk.b_id(v[k].h));
+            type[k] = live ? (uint8_t)d.bk.type(v[k].h) : (uint8_t)255;
         }
     }
     return v.size();

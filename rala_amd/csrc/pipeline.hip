@@ -722,7 +722,11 @@ int rala_hip_get_overlaps(rala_hip_ctx* ctx, int which, uint64_t* n, uint32_t* s
         if (b_begin) b_begin[k] = v[k].c.b_begin;
         if (b_end) b_end[k] = v[k].c.b_end;
         if (length) length[k] = v[k].c.length;
-        if (type) type[k] = (uint8_t)host_type(ctx, v[k]);
+        if (type) {
+            // internals can outlive their piles (reference graph.cpp:849-867 never re-checks them)
+            const bool live = ctx->h_alive[v[k].a] && ctx->h_alive[v[k].b];
+            type[k] = live ? (uint8_t)host_type(ctx, v[k]) : (uint8_t)255;
+        }
     }
     return RALA_HIP_OK;
 }
