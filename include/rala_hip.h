@@ -64,7 +64,7 @@ typedef struct rala_hip_overlaps {
  * sequential tail. */
 typedef struct rala_hip_timings {
     float dedupe_ms, bucket_ms, pile_ms, classify_ms, death_ms, finish_ms, tail_host_ms, tr_ms, total_ms;
-    uint32_t pile_launches, death_rounds;
+    uint32_t pile_launches, death_rounds, pile_overflow_reads;
 } rala_hip_timings;
 
 /* ---- context -------------------------------------------------------------- */
@@ -74,7 +74,9 @@ int rala_hip_create(int device, rala_hip_ctx** out);
 void rala_hip_destroy(rala_hip_ctx* ctx);
 const char* rala_hip_last_error(const rala_hip_ctx* ctx);
 /* options: "interval_pool_per_read_x1000" (default 1000 = one pit/hill slot per
- * read on average), "max_lds_read_len" (reads longer than this use the HBM slab path) */
+ * read on average), "max_lds_read_len" (position-space kernel: reads longer than this use
+ * the HBM slab path), "use_run_kernel" (default 1; 0 sends every read through the
+ * position-space kernel), "debug_pile_stop_after" (diagnostics) */
 int rala_hip_set_option(rala_hip_ctx* ctx, const char* key, int64_t value);
 /* the context's hipStream_t, for callers that enqueue their own copies/collectives */
 void* rala_hip_stream(rala_hip_ctx* ctx);

@@ -59,6 +59,8 @@ struct rala_hip_ctx {
     // options
     int64_t pool_per_read_x1000 = 1000;
     int64_t max_lds_read_len = 22000;
+    int64_t debug_pile_stop_after = 99;
+    bool use_run_kernel = true;
 
     // reads
     uint64_t n_reads = 0;
@@ -68,10 +70,9 @@ struct rala_hip_ctx {
     rala_hip::DevBuf<uint32_t> d_read_len;
     rala_hip::DevBuf<uint64_t> d_pile_off;
     rala_hip::DevBuf<uint16_t> d_pile;
-    rala_hip::DevBuf<uint32_t> d_order;
+    rala_hip::DevBuf<uint32_t> d_order, d_overflow;
     rala_hip::DevBuf<uint16_t> d_slab;
     std::vector<rala_hip::LaunchClass> classes;
-    uint32_t slab_grid = 0;
 
     // overlaps
     uint64_t n_ovl = 0;

@@ -195,6 +195,12 @@ __global__ __launch_bounds__(kBlock) void pile_build_annotate(PileArgs A) {
     uint64_t* tmp64 = (uint64_t*)(sc + SC_TMP);
     uint32_t* tmp32 = sc + SC_TMP;
 
+#define RALA_STOP(k)                                   \
+    if (A.stop_after == (k)) {                         \
+        if (tid == 0) A.alive[A.order[item]] = 0;      \
+        __syncthreads();                               \
+        continue;                                      \
+    }
     for (uint32_t item = blockIdx.x; item < A.n_items; item += gridDim.x) {
         const uint32_t r = A.order[item];
         const uint32_t n = A.read_len[r];
@@ -209,6 +215,7 @@ __global__ __launch_bounds__(kBlock) void pile_build_annotate(PileArgs A) {
         }
         __syncthreads();
 
+        RALA_STOP(0)
         // ---- 1. bound events -> difference array --------------------------
         {
             const uint32_t e0 = A.ev_off[r], e1 = A.ev_off[r + 1];
@@ -220,6 +227,7 @@ __global__ __launch_bounds__(kBlock) void pile_build_annotate(PileArgs A) {
         }
         __syncthreads();
 
+        RALA_STOP(1)
         // ---- 2. prefix sum -> coverage (mod 2^16), chunk per thread ---------
         const uint32_t C = ((n + kBlock - 1) / kBlock) | 1u;    // odd: conflict-free strides
         const uint32_t lo = umin(n, (uint32_t)tid * C), hi = umin(n, lo + C);
@@ -244,6 +252,7 @@ __global__ __launch_bounds__(kBlock) void pile_build_annotate(PileArgs A) {
         }
         __syncthreads();
 
+        RALA_STOP(2)
         // ---- 3. first longest run with coverage >= 4 ------------------------
         uint32_t B, E;
         {
@@ -277,6 +286,7 @@ __global__ __launch_bounds__(kBlock) void pile_build_annotate(PileArgs A) {
             continue;
         }
 
+        RALA_STOP(3)
         // ---- 4. zero outside [B, E), stream the pile to HBM -----------------
         {
             uint16_t* Dw = P + kPadL;
@@ -291,6 +301,7 @@ __global__ __launch_bounds__(kBlock) void pile_build_annotate(PileArgs A) {
             for (uint32_t j = tid; j < nv; j += kBlock) dst[j] = src[j];
         }
 
+        RALA_STOP(4)
         // ---- 5. order statistics of [B, E) -----------------------------------
         uint32_t med, p10;
         {
@@ -342,6 +353,7 @@ __global__ __launch_bounds__(kBlock) void pile_build_annotate(PileArgs A) {
             p10 = (h2 << 8) | sel[5];
         }
 
+        RALA_STOP(5)
         // ---- 6. window maxima: M512[j] = max P[j .. j+511] by doubling --------
         {
             const uint32_t W = LW / 2;              // packed pairs
@@ -368,6 +380,7 @@ __global__ __launch_bounds__(kBlock) void pile_build_annotate(PileArgs A) {
             // eight swaps: the result is back in MA, MB is free
         }
 
+        RALA_STOP(6)
         // ---- 7. slope flags -> bitmasks --------------------------------------
         const uint32_t nw = (n + 63) / 64;
         uint64_t* mask = (uint64_t*)MB;             // 4 x nw words: dn1.3, up1.3, dn1.82, up1.82
@@ -394,6 +407,7 @@ __global__ __launch_bounds__(kBlock) void pile_build_annotate(PileArgs A) {
         }
         __syncthreads();
 
+        RALA_STOP(7)
         // ---- 8. runs of set bits -> (first, last); wave w owns mask w ---------
         {
             const int w = wave_id(), l = lane_id();
@@ -433,6 +447,7 @@ __global__ __launch_bounds__(kBlock) void pile_build_annotate(PileArgs A) {
         }
         __syncthreads();
 
+        RALA_STOP(8)
         // ---- 9. resolve + pits (wave 1) / hills (wave 0), one lane each --------
         if (tid == 0 || tid == 64) {
             const int which = tid >> 6;                     // 0: q = 1.3 hills, 1: q = 1.82 pits
@@ -506,6 +521,7 @@ __global__ __launch_bounds__(kBlock) void pile_build_annotate(PileArgs A) {
         }
         __syncthreads();
 
+        RALA_STOP(9)
         // ---- 10. publish ------------------------------------------------------
         if (tid == 0) {
             const uint32_t nh = sc[SC_OUT + 0], np = sc[SC_OUT + 1];

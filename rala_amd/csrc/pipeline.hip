@@ -71,14 +71,13 @@ int download_read_state(rala_hip_ctx* ctx) {
     return RALA_HIP_OK;
 }
 
-// ---- launch classes: reads grouped by the LDS image size they need -------------------
-void build_classes(rala_hip_ctx* ctx, std::vector<uint32_t>& order) {
-    const uint64_t n = ctx->n_reads;
+// ---- launch classes of the position-space kernel: reads grouped by LDS image size ------
+void build_classes(rala_hip_ctx* ctx, const std::vector<uint32_t>& reads, std::vector<uint32_t>& order) {
     static const uint32_t kLw[] = {8192, 10240, 12288, 14336, 16384, 20480, 24576};
     const int n_lds = (int)(sizeof(kLw) / sizeof(kLw[0]));
     std::vector<std::vector<uint32_t>> bins(n_lds + 1);
     uint32_t max_long = 0;
-    for (uint64_t r = 0; r < n; ++r) {
+    for (uint32_t r : reads) {
         const uint32_t len = ctx->h_read_len[r];
         const uint32_t lw = pile_lw_for(len);
         int k = n_lds;
@@ -87,7 +86,7 @@ void build_classes(rala_hip_ctx* ctx, std::vector<uint32_t>& order) {
                 if (lw <= kLw[c]) { k = c; break; }
             }
         }
-        bins[k].push_back((uint32_t)r);
+        bins[k].push_back(r);
         if (k == n_lds) max_long = std::max(max_long, lw);
     }
     ctx->classes.clear();
@@ -100,13 +99,35 @@ void build_classes(rala_hip_ctx* ctx, std::vector<uint32_t>& order) {
         c.lw = c.in_lds ? kLw[k] : max_long;
         c.first = (uint32_t)order.size();
         c.count = (uint32_t)bins[k].size();
-        // longest first inside a class
         std::stable_sort(bins[k].begin(), bins[k].end(), [&](uint32_t x, uint32_t y) {
             return ctx->h_read_len[x] > ctx->h_read_len[y];
         });
         order.insert(order.end(), bins[k].begin(), bins[k].end());
         ctx->classes.push_back(c);
     }
+}
+
+// position-space kernel over `reads` (all of them, or the run kernel's overflow)
+int run_position_kernel(rala_hip_ctx* ctx, PileArgs a, const std::vector<uint32_t>& reads) {
+    if (reads.empty()) return RALA_HIP_OK;
+    std::vector<uint32_t> order;
+    build_classes(ctx, reads, order);
+    HIPCHECK(hipMemcpyAsync(ctx->d_order.p, order.data(), order.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    for (const LaunchClass& c : ctx->classes) {
+        uint32_t grid = c.count;
+        if (!c.in_lds) {
+            grid = std::min<uint32_t>(c.count, 512);
+            HIPCHECK(ctx->d_slab.ensure((size_t)grid * 3 * c.lw));
+        }
+        a.order = ctx->d_order.p + c.first;
+        a.n_items = c.count;
+        a.lw = c.lw;
+        a.slab = ctx->d_slab.p;
+        launch_pile_build_annotate(a, grid, c.in_lds, ctx->stream);
+        ++ctx->tm.pile_launches;
+    }
+    HIPCHECK(hipStreamSynchronize(ctx->stream));      // `order` is pageable host memory
+    return RALA_HIP_OK;
 }
 
 // ---- host tail helpers (Graph::preprocess, graph.cpp:699-880) --------------------------
@@ -379,6 +400,8 @@ int rala_hip_set_option(rala_hip_ctx* ctx, const char* key, int64_t value) {
     if (!ctx || !key) return RALA_HIP_EINVAL;
     if (!strcmp(key, "interval_pool_per_read_x1000")) { ctx->pool_per_read_x1000 = value; return RALA_HIP_OK; }
     if (!strcmp(key, "max_lds_read_len")) { ctx->max_lds_read_len = value; return RALA_HIP_OK; }
+    if (!strcmp(key, "debug_pile_stop_after")) { ctx->debug_pile_stop_after = value; return RALA_HIP_OK; }
+    if (!strcmp(key, "use_run_kernel")) { ctx->use_run_kernel = value != 0; return RALA_HIP_OK; }
     return fail(ctx, RALA_HIP_EINVAL, "unknown option");
 }
 
@@ -403,17 +426,8 @@ int rala_hip_set_reads(rala_hip_ctx* ctx, const uint32_t* read_len, uint64_t n_r
     HIPCHECK(ctx->d_pile.ensure(off + 8));
     HIPCHECK(hipMemcpy(ctx->d_read_len.p, read_len, n_reads * 4, hipMemcpyHostToDevice));
     HIPCHECK(hipMemcpy(ctx->d_pile_off.p, ctx->h_pile_off.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice));
-    std::vector<uint32_t> order;
-    build_classes(ctx, order);
-    HIPCHECK(ctx->d_order.ensure(n_reads));
-    if (n_reads) HIPCHECK(hipMemcpy(ctx->d_order.p, order.data(), n_reads * 4, hipMemcpyHostToDevice));
-    ctx->slab_grid = 0;
-    for (const LaunchClass& c : ctx->classes) {
-        if (!c.in_lds) {
-            ctx->slab_grid = std::min<uint32_t>(c.count, 512);
-            HIPCHECK(ctx->d_slab.ensure((size_t)ctx->slab_grid * 3 * c.lw));
-        }
-    }
+    HIPCHECK(ctx->d_order.ensure(n_reads + 1));
+    HIPCHECK(ctx->d_overflow.ensure(n_reads + 1));
     HIPCHECK(ctx->d_ev_off.ensure(n_reads + 2)); HIPCHECK(ctx->d_cursor.ensure(n_reads + 2));
     HIPCHECK(ctx->d_begin.ensure(n_reads)); HIPCHECK(ctx->d_end.ensure(n_reads));
     HIPCHECK(ctx->d_median.ensure(n_reads)); HIPCHECK(ctx->d_p10.ensure(n_reads));
@@ -489,15 +503,34 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
     a.read_len = ctx->d_read_len.p; a.pile_off = ctx->d_pile_off.p; a.pile = ctx->d_pile.p;
     a.ev_off = ctx->d_ev_off.p; a.ev = ctx->d_ev.p;
     a.add_to_existing = 0; a.slab = ctx->d_slab.p;
+    a.stop_after = (uint32_t)ctx->debug_pile_stop_after;
     a.begin = ctx->d_begin.p; a.end = ctx->d_end.p; a.median = ctx->d_median.p; a.p10 = ctx->d_p10.p;
     a.alive = ctx->d_alive.p; a.n_pits = ctx->d_n_pits.p; a.n_hills = ctx->d_n_hills.p; a.iv_slot = ctx->d_iv_slot.p;
     a.pool = ctx->d_pool.p; a.pool_count = ctx->d_small.p; a.pool_cap = ctx->pool_cap; a.error = ctx->d_small.p + 1;
-    for (const LaunchClass& c : ctx->classes) {
-        a.order = ctx->d_order.p + c.first;
-        a.n_items = c.count;
-        a.lw = c.lw;
-        launch_pile_build_annotate(a, c.in_lds ? c.count : ctx->slab_grid, c.in_lds, s);
+    if (ctx->use_run_kernel) {
+        // run-space kernel for every read; the event-dense ones come back in a list
+        a.order = nullptr;
+        a.n_items = n_reads;
+        a.lw = 0;
+        HIPCHECK(hipMemsetAsync(ctx->d_small.p + 4, 0, 4, s));
+        launch_pile_runs(a, n_reads, ctx->d_overflow.p, ctx->d_small.p + 4, s);
         ++ctx->tm.pile_launches;
+        uint32_t n_over = 0;
+        HIPCHECK(hipMemcpyAsync(&n_over, ctx->d_small.p + 4, 4, hipMemcpyDeviceToHost, s));
+        HIPCHECK(hipStreamSynchronize(s));
+        ctx->tm.pile_overflow_reads = n_over;
+        if (n_over) {
+            std::vector<uint32_t> reads(n_over);
+            HIPCHECK(hipMemcpy(reads.data(), ctx->d_overflow.p, (size_t)n_over * 4, hipMemcpyDeviceToHost));
+            std::sort(reads.begin(), reads.end());
+            const int rc2 = run_position_kernel(ctx, a, reads);
+            if (rc2 != RALA_HIP_OK) return rc2;
+        }
+    } else {
+        std::vector<uint32_t> reads(n_reads);
+        std::iota(reads.begin(), reads.end(), 0u);
+        const int rc2 = run_position_kernel(ctx, a, reads);
+        if (rc2 != RALA_HIP_OK) return rc2;
     }
     HIPCHECK(hipEventRecord(ctx->ev[3], s));
     HIPCHECK(hipGetLastError());

@@ -9,12 +9,16 @@ import parity
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("run_kernel", [1, 0])
 @pytest.mark.parametrize("n,g,seed", [(1000, 200_000, 1), (3000, 600_000, 21), (5000, 1_000_000, 7),
-                                      (2000, 1_200_000, 33)])
-def test_full_path_small(hip_ctx_factory, n, g, seed):
+                                      (2000, 1_200_000, 33), (400, 20_000, 5)])
+def test_full_path_small(hip_ctx_factory, n, g, seed, run_kernel):
+    """run_kernel=1: run-space kernel (+ position-space kernel for event-dense reads);
+    run_kernel=0: every read through the position-space kernel."""
     ds = Dataset(n, g, seed)
     st = parity.oracle_stages(ds)
     ctx = hip_ctx_factory()
+    ctx.set_option("use_run_kernel", run_kernel)
     ctx.set_reads(ds.read_len)
     ctx.set_overlaps(ds.overlaps)
     ctx.initialize()
