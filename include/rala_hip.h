@@ -64,7 +64,7 @@ typedef struct rala_hip_overlaps {
  * sequential tail. */
 typedef struct rala_hip_timings {
     float dedupe_ms, bucket_ms, pile_ms, classify_ms, death_ms, finish_ms, tail_host_ms, tr_ms, total_ms;
-    uint32_t pile_launches, death_rounds, pile_overflow_reads;
+    uint32_t pile_launches, death_rounds, pile_overflow_reads, pile_position_reads;
 } rala_hip_timings;
 
 /* ---- context -------------------------------------------------------------- */

@@ -64,6 +64,7 @@ struct rala_hip_ctx {
 
     // reads
     uint64_t n_reads = 0;
+    uint32_t max_read_len = 0;
     std::vector<uint32_t> h_read_len;
     std::vector<uint64_t> h_pile_off;
     uint64_t pile_elems = 0;

@@ -30,6 +30,7 @@ struct PileArgs {
     const uint32_t* ev;            // pos << 1 | is_end
     const uint32_t* order;         // reads of this launch
     uint32_t n_items;
+    const uint32_t* n_items_dev;   // when non-null the item count is read from device memory
     uint32_t lw;                   // uint16 elements per big array (>= kPadL + len + 848, multiple of 8)
     uint32_t add_to_existing;
     uint32_t stop_after;           // diagnostics: leave the kernel after phase k (99 = run everything)
@@ -53,12 +54,14 @@ uint32_t pile_lds_bytes(uint32_t lw);
 uint32_t pile_lw_for(uint32_t read_len);
 void launch_pile_build_annotate(const PileArgs& args, uint32_t grid, bool in_lds, hipStream_t stream);
 
-// run-space kernel (pile_runs_kernel.hip): one wavefront per read; reads with more than
-// kRunEventCap bound events are appended to overflow_list instead (args.order may be null =
-// identity)
+// run-space kernel (pile_runs_kernel.hip): one wavefront per read; reads with more bound
+// events than the instantiation's cap are appended to overflow_list instead (args.order may
+// be null = identity).  Two instantiations: kRunEventCap (registers-only sort) and
+// kRunEventCapBig.
 constexpr uint32_t kRunEventCap = 512;
-void launch_pile_runs(const PileArgs& args, uint32_t grid, uint32_t* overflow_list, uint32_t* overflow_count,
-                      hipStream_t stream);
+constexpr uint32_t kRunEventCapBig = 2048;
+void launch_pile_runs(const PileArgs& args, uint32_t grid, bool big_cap, uint32_t* overflow_list,
+                      uint32_t* overflow_count, hipStream_t stream);
 
 // ---- overlap-side kernels (overlap_kernels.hip) ------------------------------
 struct OvlSoA {

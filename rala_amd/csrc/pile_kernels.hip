@@ -201,7 +201,8 @@ __global__ __launch_bounds__(kBlock) void pile_build_annotate(PileArgs A) {
         __syncthreads();                               \
         continue;                                      \
     }
-    for (uint32_t item = blockIdx.x; item < A.n_items; item += gridDim.x) {
+    const uint32_t n_items = A.n_items_dev ? *A.n_items_dev : A.n_items;
+    for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
         const uint32_t r = A.order[item];
         const uint32_t n = A.read_len[r];
         const uint16_t* D = P + kPadL;      // D[j] = coverage at position j

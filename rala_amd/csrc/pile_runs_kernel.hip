@@ -1,9 +1,9 @@
 // Pile-o-gram construction and annotation in RUN space, one wavefront per read.
 //
 // A pile is a step function: coverage only changes at bound events.  With the
-// E events of a read sorted (LDS bitonic sort), the prefix sum of +-1 gives
-// R <= E + 1 runs (start, value).  Every per-base loop of the reference then
-// becomes a loop over runs:
+// E events of a read sorted (bitonic sort in registers, cross-lane shuffles),
+// the prefix sum of +-1 gives R <= E + 1 runs (start, value).  Every per-base
+// loop of the reference then becomes a loop over runs:
 //   * Pile::add_layers        sort + wave prefix sum               O(E log^2 E)
 //   * Pile::find_valid_region  streaks of runs with value >= 4      O(R)
 //   * Pile::shrink             zero the runs outside the streak; the pile is
@@ -13,10 +13,13 @@
 //       compared with ONE threshold, so the flagged positions of a run are a
 //       prefix (down) and a suffix (up) of it, bounded by the nearest run to
 //       the left / right whose value exceeds the threshold: O(runs per window)
-//   * region resolution / narrowing / pits / hills: the reference's loops,
-//       reading coverage through a run cursor (one lane; regions are few)
-// Reads with more than kCap events are appended to an overflow list and
-// processed by the position-space kernel (pile_kernels.hip).
+//   * region lists are merged / tested wave-parallel; the reference's serial
+//       resolution, narrowing, pit and hill loops run on one lane only for the
+//       few piles whose regions actually interact, reading coverage through a
+//       run cursor
+// Reads with more than kCap events are appended to an overflow list for the
+// next kernel in the chain (larger kCap, then the position-space kernel of
+// pile_kernels.hip); the chain needs no host synchronisation.
 //
 // Reference behaviour followed: rvaser/rala src/pile.cpp:64-455.
 #include <hip/hip_runtime.h>
@@ -30,7 +33,7 @@ namespace rala_hip {
 namespace {
 
 constexpr uint32_t kNone = 0xFFFFFFFFu;
-constexpr uint32_t kMaxReg = 64;       // regions per slope list
+constexpr uint32_t kMaxReg = 64;       // regions per (q, kind) list
 constexpr uint32_t kMaxRaw = 32;       // pits / hills before the merge
 constexpr uint32_t kIdx = 512;         // entries of the position -> run index
 
@@ -55,7 +58,7 @@ struct RunCursor {
 };
 
 struct RegionList {
-    uint32_t* key;
+    uint32_t* key;      // first << 1 | is_up
     uint32_t* last;
     uint32_t n, cap;
     bool overflow;
@@ -82,29 +85,38 @@ __device__ void rl_sort(RegionList& R) {
     }
 }
 
-// pile.cpp:131-256 (same procedure as pile_kernels.hip, coverage through the cursor)
-__device__ void resolve_and_narrow(RegionList& R, RunCursor& d, double q) {
+// pile.cpp:131-220 (one lane; only reached when two regions overlap).  The
+// reference walks positions; coverage is constant inside a run and a position is
+// never flagged against its own run (v * q >= v), so whole clipped runs are
+// flagged or not together: the walk is over runs.
+__device__ void resolve_serial(RegionList& R, RunCursor& d, double q) {
     if (R.n == 0) return;
+    const uint32_t* rs = d.rs;
+    const uint16_t* rv = d.rv;
     for (;;) {
         rl_sort(R);
         bool changed = false;
         for (uint32_t i = 0; i + 1 < R.n; ++i) {
             if (R.last[i] < (R.key[i + 1] >> 1)) continue;
             if (R.key[i] & 1) {
+                // positions j in [s, e) with d[j] * q < max d(j, e]   (pile.cpp:141-174)
                 const uint32_t s = R.key[i] >> 1;
                 const uint32_t e = umin(R.last[i], R.last[i + 1]);
-                int32_t m = d[e];
+                uint32_t k = d.run_of(e);
+                int32_t m = rv[k];
                 bool open = false;
                 uint32_t lo = 0, hi = 0;
-                for (uint32_t j = e; j-- > s;) {
-                    const uint32_t v = d[j];
+                while (k > 0 && rs[k] > s) {
+                    --k;
+                    const uint32_t v = rv[k];
+                    const uint32_t c_lo = umax(rs[k], s), c_hi = rs[k + 1] - 1;     // clipped run, c_hi < e
                     if ((double)v * q < (double)m) {
-                        if (open && j + 1 == lo) {
-                            lo = j;
+                        if (open && c_hi + 1 == lo) {
+                            lo = c_lo;
                         } else {
                             if (open) rl_push(R, lo << 1 | 1, hi);
                             open = true;
-                            lo = hi = j;
+                            lo = c_lo; hi = c_hi;
                         }
                     }
                     m = max(m, (int32_t)v);
@@ -113,20 +125,24 @@ __device__ void resolve_and_narrow(RegionList& R, RunCursor& d, double q) {
                 R.key[i] = e << 1 | 1;
             } else {
                 if (R.last[i] == (R.key[i + 1] >> 1)) continue;
+                // positions j in (s, e] with d[j] * q < max d[s, j)   (pile.cpp:176-211)
                 const uint32_t s = umax(R.key[i] >> 1, R.key[i + 1] >> 1);
                 const uint32_t e = R.last[i];
-                int32_t m = -1;
+                uint32_t k = d.run_of(s);
+                int32_t m = rv[k];
                 bool open = false;
                 uint32_t lo = 0, hi = 0;
-                for (uint32_t j = s; j <= e; ++j) {
-                    const uint32_t v = d[j];
-                    if (m >= 0 && (double)v * q < (double)m) {
-                        if (open && j == hi + 1) {
-                            hi = j;
+                while (rs[k + 1] <= e) {
+                    ++k;
+                    const uint32_t v = rv[k];
+                    const uint32_t c_lo = rs[k], c_hi = umin(rs[k + 1] - 1, e);
+                    if ((double)v * q < (double)m) {
+                        if (open && c_lo == hi + 1) {
+                            hi = c_hi;
                         } else {
                             if (open) rl_push(R, lo << 1, hi);
                             open = true;
-                            lo = hi = j;
+                            lo = c_lo; hi = c_hi;
                         }
                     }
                     m = max(m, (int32_t)v);
@@ -139,25 +155,111 @@ __device__ void resolve_and_narrow(RegionList& R, RunCursor& d, double q) {
         }
         if (!changed || R.overflow) break;
     }
+}
+
+// max of the coverage over positions [a, b] (a <= b), by runs
+__device__ uint32_t range_max_runs(RunCursor& d, uint32_t a, uint32_t b) {
+    uint32_t k = d.run_of(a);
+    uint32_t m = d.rv[k];
+    while (d.rs[k + 1] <= b) {
+        ++k;
+        m = umax(m, d.rv[k]);
+    }
+    return m;
+}
+
+// pile.cpp:222-256 (one lane; only reached when an up region is followed by a
+// down region within the window), by runs
+__device__ void narrow_serial(RegionList& R, RunCursor& d, double q) {
+    const uint32_t* rs = d.rs;
+    const uint16_t* rv = d.rv;
     for (uint32_t i = 0; i + 1 < R.n; ++i) {
         if (!(R.key[i] & 1) || (R.key[i + 1] & 1)) continue;
         const uint32_t b = R.last[i];
         const uint32_t e = R.key[i + 1] >> 1;
         if ((uint32_t)(e - b) > kSlopeWindow) continue;
-        uint32_t m = 0;
-        for (uint32_t j = b + 1; j < e; ++j) m = umax(m, d[j]);
+        const uint32_t m = (b + 1 < e) ? range_max_runs(d, b + 1, e - 1) : 0u;
         const uint32_t u_first = R.key[i] >> 1;
+        // last j in [u_first, b] with m > d[j] * q
         uint32_t last_ok = u_first;
-        for (uint32_t j = u_first; j <= b; ++j) {
-            if ((double)m > (double)d[j] * q) last_ok = j;
+        {
+            uint32_t k = d.run_of(b);
+            for (;;) {
+                if ((double)m > (double)rv[k] * q) { last_ok = umin(b, rs[k + 1] - 1); break; }
+                if (k == 0 || rs[k] <= u_first) break;
+                --k;
+            }
+            if (last_ok < u_first) last_ok = u_first;
         }
-        uint32_t first_ok = R.last[i + 1];
-        for (uint32_t j = e; j <= R.last[i + 1]; ++j) {
-            if ((double)m > (double)d[j] * q) { first_ok = j; break; }
+        // first j in [e, w_last] with m > d[j] * q
+        const uint32_t w_last = R.last[i + 1];
+        uint32_t first_ok = w_last;
+        {
+            uint32_t k = d.run_of(e);
+            for (;;) {
+                if ((double)m > (double)rv[k] * q) { first_ok = umax(e, rs[k]); break; }
+                if (rs[k + 1] > w_last) break;
+                ++k;
+            }
         }
         R.last[i] = last_ok;
         R.key[i + 1] = first_ok << 1;
     }
+}
+
+// ---- bitonic sort of C * 64 keys held as v[t] = key[t * 64 + lane] ---------------
+template <int C>
+__device__ __forceinline__ void wave_sort_regs(uint32_t (&v)[C], uint32_t lane) {
+    constexpr uint32_t P = (uint32_t)C * 64u;
+#pragma unroll
+    for (uint32_t k = 2; k <= P; k <<= 1) {
+#pragma unroll
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            if (j >= 64) {
+                const uint32_t dt = j >> 6;
+#pragma unroll
+                for (uint32_t t = 0; t < (uint32_t)C; ++t) {
+                    if ((t & dt) == 0) {
+                        const uint32_t e = t * 64u;             // bit k lives in t for k >= 128
+                        const bool asc = (e & k) == 0;
+                        const uint32_t a = v[t], b = v[t | dt];
+                        const bool sw = (a > b) == asc;
+                        v[t] = sw ? b : a;
+                        v[t | dt] = sw ? a : b;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (uint32_t t = 0; t < (uint32_t)C; ++t) {
+                    const uint32_t e = t * 64u + lane;
+                    const uint32_t o = (uint32_t)__shfl_xor((int)v[t], (int)j, 64);
+                    const bool asc = (e & k) == 0;
+                    const bool lower = (lane & j) == 0;
+                    const uint32_t mn = v[t] < o ? v[t] : o, mx = v[t] < o ? o : v[t];
+                    v[t] = (lower == asc) ? mn : mx;
+                }
+            }
+        }
+    }
+}
+
+template <int C>
+__device__ __forceinline__ void load_sort_store(const uint32_t* __restrict__ gev, uint32_t n_ev, uint32_t n,
+                                                uint32_t* ev, uint32_t lane) {
+    uint32_t v[C];
+#pragma unroll
+    for (int t = 0; t < C; ++t) {
+        const uint32_t e = (uint32_t)t * 64u + lane;
+        uint32_t b = kNone;
+        if (e < n_ev) {
+            b = gev[e];
+            if ((b >> 1) > n) b = kNone;        // outside the read (undefined in the reference)
+        }
+        v[t] = b;
+    }
+    wave_sort_regs<C>(v, lane);
+#pragma unroll
+    for (int t = 0; t < C; ++t) ev[(uint32_t)t * 64u + lane] = v[t];
 }
 
 template <uint32_t kCap>
@@ -176,7 +278,8 @@ struct Layout {
     static constexpr uint32_t REG = RC + 4;                     // 2 x (key, last) x 2 * kMaxReg
     static constexpr uint32_t IV = REG + 8 * kMaxReg;           // 2 x 4 x kMaxRaw
     static constexpr uint32_t GONE = IV + 8 * kMaxRaw;          // 2 x kMaxRaw bytes
-    static constexpr uint32_t SEL = GONE + (2 * kMaxRaw) / 4;   // 16 words
+    static constexpr uint32_t CAND = GONE + (2 * kMaxRaw) / 4;  // kMaxRaw hill candidates (i << 16 | j)
+    static constexpr uint32_t SEL = CAND + kMaxRaw;             // 16 words
     static constexpr uint32_t WORDS = SEL + 16;
     static_assert(3 * kArr >= 768, "histograms must fit in arrays D..F");
 };
@@ -193,8 +296,15 @@ __global__ __launch_bounds__(64) void pile_runs_kernel(PileArgs A, uint32_t* ove
     uint16_t* rv = (uint16_t*)(sm + L::RV);
     uint16_t* idx = (uint16_t*)(sm + L::IDX);
     uint32_t* sel = sm + L::SEL;
+    const uint32_t n_items = A.n_items_dev ? *A.n_items_dev : A.n_items;
 
-    for (uint32_t item = blockIdx.x; item < A.n_items; item += gridDim.x) {
+#define RUN_STOP(k)                                                        \
+    if (A.stop_after == (k)) {                                             \
+        if (lane == 0) A.alive[A.order ? A.order[item] : item] = 0;        \
+        wave_sync();                                                       \
+        continue;                                                          \
+    }
+    for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
         const uint32_t r = A.order ? A.order[item] : item;
         const uint32_t n = A.read_len[r];
         const uint32_t e0 = A.ev_off[r];
@@ -204,30 +314,40 @@ __global__ __launch_bounds__(64) void pile_runs_kernel(PileArgs A, uint32_t* ove
             continue;
         }
 
-        // ---- 1. events -> LDS, sorted ascending (value = pos << 1 | is_end) -------
+        // ---- 1. events sorted ascending (value = pos << 1 | is_end) -> LDS ----------
         uint32_t P = 64;
         while (P < n_ev) P <<= 1;
-        for (uint32_t k = lane; k < P; k += 64) {
-            uint32_t b = kNone;
-            if (k < n_ev) {
-                b = A.ev[e0 + k];
-                if ((b >> 1) > n) b = kNone;        // outside the read (undefined in the reference)
-            }
-            ev[k] = b;
-        }
-        wave_sync();
-        for (uint32_t k = 2; k <= P; k <<= 1) {
-            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-                for (uint32_t t = lane; t < P / 2; t += 64) {
-                    const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                    const uint32_t l = i | j;
-                    const uint32_t a = ev[i], b = ev[l];
-                    const bool asc = (i & k) == 0;
-                    if ((a > b) == asc) { ev[i] = b; ev[l] = a; }
+        if (P <= 512) {
+            const uint32_t* gev = A.ev + e0;
+            if (P == 64) load_sort_store<1>(gev, n_ev, n, ev, lane);
+            else if (P == 128) load_sort_store<2>(gev, n_ev, n, ev, lane);
+            else if (P == 256) load_sort_store<4>(gev, n_ev, n, ev, lane);
+            else load_sort_store<8>(gev, n_ev, n, ev, lane);
+            wave_sync();
+        } else {
+            for (uint32_t k = lane; k < P; k += 64) {
+                uint32_t b = kNone;
+                if (k < n_ev) {
+                    b = A.ev[e0 + k];
+                    if ((b >> 1) > n) b = kNone;
                 }
-                wave_sync();
+                ev[k] = b;
+            }
+            wave_sync();
+            for (uint32_t k = 2; k <= P; k <<= 1) {
+                for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                    for (uint32_t t = lane; t < P / 2; t += 64) {
+                        const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                        const uint32_t l = i | j;
+                        const uint32_t a = ev[i], b = ev[l];
+                        const bool asc = (i & k) == 0;
+                        if ((a > b) == asc) { ev[i] = b; ev[l] = a; }
+                    }
+                    wave_sync();
+                }
             }
         }
+        RUN_STOP(21)
 
         // ---- 2. prefix sum of +-1 -> runs (start, value mod 2^16) --------------------
         uint32_t R;
@@ -268,6 +388,7 @@ __global__ __launch_bounds__(64) void pile_runs_kernel(PileArgs A, uint32_t* ove
             }
         }
         wave_sync();
+        RUN_STOP(22)
 
         // ---- 3. first longest streak of runs with value >= 4 ---------------------------
         uint32_t B, E, kB, kE;
@@ -308,6 +429,7 @@ __global__ __launch_bounds__(64) void pile_runs_kernel(PileArgs A, uint32_t* ove
             wave_sync();
             continue;
         }
+        RUN_STOP(23)
 
         // ---- 4. Pile::shrink: zero outside; position index; expand to HBM -----------------
         for (uint32_t k = lane; k < R; k += 64) {
@@ -327,25 +449,39 @@ __global__ __launch_bounds__(64) void pile_runs_kernel(PileArgs A, uint32_t* ove
         }
         wave_sync();
         {
+            // each lane expands 32 consecutive positions (four 16-byte stores)
             uint4* dst = (uint4*)(A.pile + A.pile_off[r]);
             const uint32_t nv = (n + 7) / 8;
-            for (uint32_t g = lane; g < nv; g += 64) {
-                const uint32_t p = g * 8;
-                uint32_t k = idx[p >> shift];
+            const uint32_t nq = (nv + 3) / 4;
+            for (uint32_t g4 = lane; g4 < nq; g4 += 64) {
+                const uint32_t p0 = g4 * 32;
+                uint32_t k = idx[p0 >> shift];
                 uint32_t nxt = rs[k + 1];
-                while (nxt <= p) { ++k; nxt = rs[k + 1]; }
+                while (nxt <= p0) { ++k; nxt = rs[k + 1]; }
                 uint32_t v = rv[k];
-                uint32_t w[4];
 #pragma unroll
-                for (int x = 0; x < 8; ++x) {
-                    const uint32_t q = p + x;
-                    while (nxt <= q && k + 1 < R) { ++k; nxt = rs[k + 1]; v = rv[k]; }
-                    const uint32_t val = q < n ? v : 0u;
-                    if (x & 1) w[x >> 1] |= val << 16; else w[x >> 1] = val;
+                for (uint32_t u = 0; u < 4; ++u) {
+                    const uint32_t p = p0 + u * 8;
+                    if (g4 * 4 + u >= nv) break;
+                    uint32_t w[4];
+                    while (nxt <= p && k + 1 < R) { ++k; nxt = rs[k + 1]; v = rv[k]; }
+                    if (nxt >= p + 8 && p + 8 <= n) {
+                        const uint32_t vv = v | (v << 16);
+                        w[0] = w[1] = w[2] = w[3] = vv;
+                    } else {
+#pragma unroll
+                        for (int x = 0; x < 8; ++x) {
+                            const uint32_t q = p + x;
+                            while (nxt <= q && k + 1 < R) { ++k; nxt = rs[k + 1]; v = rv[k]; }
+                            const uint32_t val = q < n ? v : 0u;
+                            if (x & 1) w[x >> 1] |= val << 16; else w[x >> 1] = val;
+                        }
+                    }
+                    dst[g4 * 4 + u] = make_uint4(w[0], w[1], w[2], w[3]);
                 }
-                dst[g] = make_uint4(w[0], w[1], w[2], w[3]);
             }
         }
+        RUN_STOP(24)
 
         // ---- 5. order statistics over (value, length) of the runs in [kB, kE) --------------
         uint32_t med, p10;
@@ -397,6 +533,7 @@ __global__ __launch_bounds__(64) void pile_runs_kernel(PileArgs A, uint32_t* ove
             p10 = (h2 << 8) | sel[7];
         }
         wave_sync();
+        RUN_STOP(25)
 
         // ---- 6. slope flags per run: a flagged prefix (down) and suffix (up) ----------------
         // down(i), i in run k  <=>  some run j < k with value > t(v_k) reaches into
@@ -411,23 +548,52 @@ __global__ __launch_bounds__(64) void pile_runs_kernel(PileArgs A, uint32_t* ove
             const uint32_t sk = rs[k], ek = rs[k + 1];
             const int32_t t13 = (int32_t)((double)v * 1.3), t182 = (int32_t)((double)v * 1.82);
             uint32_t dl13 = kNone, dl182 = kNone, ur13 = kNone, ur182 = kNone;
-            for (uint32_t j = k; j-- > 0;) {
-                const uint32_t ej = rs[j + 1];
-                if (ej + 846u < sk) break;
-                const int32_t vj = rv[j];
-                if (dl13 == kNone && vj > t13) dl13 = umin(ek - 1, ej + 846u);
-                if (vj > t182) { dl182 = umin(ek - 1, ej + 846u); break; }
+            {
+                bool done = false;
+                for (uint32_t j0 = k; j0 > 0 && !done;) {          // neighbours in batches of 4
+                    uint32_t ej[4];
+                    int32_t vj[4];
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; ++u) {
+                        const uint32_t j = j0 > u ? j0 - 1 - u : 0;
+                        ej[u] = rs[j + 1];
+                        vj[u] = rv[j];
+                    }
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; ++u) {
+                        if (done || j0 <= u) { done = true; break; }
+                        if (ej[u] + 846u < sk) { done = true; break; }
+                        if (dl13 == kNone && vj[u] > t13) dl13 = umin(ek - 1, ej[u] + 846u);
+                        if (vj[u] > t182) { dl182 = umin(ek - 1, ej[u] + 846u); done = true; break; }
+                    }
+                    j0 = j0 > 4 ? j0 - 4 : 0;
+                }
             }
-            for (uint32_t j = k + 1; j < R; ++j) {
-                const uint32_t sj = rs[j];
-                if (sj > ek + 846u) break;
-                const int32_t vj = rv[j];
-                if (ur13 == kNone && vj > t13) ur13 = umax(sk, sj >= 847u ? sj - 847u : 0u);
-                if (vj > t182) { ur182 = umax(sk, sj >= 847u ? sj - 847u : 0u); break; }
+            {
+                bool done = false;
+                for (uint32_t j0 = k + 1; j0 < R && !done; j0 += 4) {
+                    uint32_t sj[4];
+                    int32_t vj[4];
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; ++u) {
+                        const uint32_t j = umin(j0 + u, R - 1);
+                        sj[u] = rs[j];
+                        vj[u] = rv[j];
+                    }
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; ++u) {
+                        if (done || j0 + u >= R) { done = true; break; }
+                        if (sj[u] > ek + 846u) { done = true; break; }
+                        const uint32_t lim = umax(sk, sj[u] >= 847u ? sj[u] - 847u : 0u);
+                        if (ur13 == kNone && vj[u] > t13) ur13 = lim;
+                        if (vj[u] > t182) { ur182 = lim; done = true; break; }
+                    }
+                }
             }
             d13[k] = dl13; u13[k] = ur13; d182[k] = dl182; u182[k] = ur182;
         }
         wave_sync();
+        RUN_STOP(26)
 
         // ---- 7. maximal unions of touching intervals -> regions (first, last) ----------------
 #pragma unroll 1
@@ -473,82 +639,161 @@ __global__ __launch_bounds__(64) void pile_runs_kernel(PileArgs A, uint32_t* ove
             if (lane == 0) sm[L::RC + w] = ns;
         }
         wave_sync();
+        RUN_STOP(27)
 
-        // ---- 8. resolve, pits (q = 1.82), hills (q = 1.3); lanes 0 and 1 -----------------------
-        if (lane < 2) {
-            const uint32_t which = lane;                    // 0: hills, 1: pits
+        // ---- 8. per q: merged region list; resolve / narrow only when regions interact;
+        //         pits (q = 1.82) and hills (q = 1.3) ---------------------------------------------
+        bool any_overflow = false;
+#pragma unroll 1
+        for (uint32_t which = 0; which < 2; ++which) {             // 0: q = 1.3 hills, 1: q = 1.82 pits
             const double q = which ? 1.82 : 1.3;
-            RunCursor dv{rs, rv, idx, shift, 0};
-            RegionList Rg;
-            Rg.key = sm + L::REG + which * 4 * kMaxReg;
-            Rg.last = Rg.key + 2 * kMaxReg;
-            Rg.n = 0; Rg.cap = 2 * kMaxReg; Rg.overflow = false;
             const uint32_t nd = sm[L::RC + 2 * which], nu = sm[L::RC + 2 * which + 1];
-            if (nd > kMaxReg || nu > kMaxReg) Rg.overflow = true;
-            if (!Rg.overflow) {
-                const uint32_t* df = sm + L::RF + (2 * which) * kMaxReg;
-                const uint32_t* dl = sm + L::RL + (2 * which) * kMaxReg;
-                const uint32_t* uf = df + kMaxReg;
-                const uint32_t* ul = dl + kMaxReg;
-                for (uint32_t k = 0; k < nd; ++k) rl_push(Rg, df[k] << 1, dl[k]);
-                for (uint32_t k = 0; k < nu; ++k) rl_push(Rg, uf[k] << 1 | 1, ul[k]);
-                resolve_and_narrow(Rg, dv, q);
-            }
+            uint32_t* key = sm + L::REG + which * 4 * kMaxReg;
+            uint32_t* last = key + 2 * kMaxReg;
             uint32_t* ivf = sm + L::IV + which * 4 * kMaxRaw;
             uint32_t* ivs = ivf + kMaxRaw;
             uint32_t* of = ivs + kMaxRaw;
             uint32_t* os = of + kMaxRaw;
             uint8_t* gone = (uint8_t*)(sm + L::GONE) + which * kMaxRaw;
-            uint32_t cnt = 0;
-            bool ovf = Rg.overflow;
-            if (!ovf && Rg.n) {
-                if (which) {
-                    for (uint32_t i = 0; i + 1 < Rg.n; ++i) {
-                        if (!(Rg.key[i] & 1) && (Rg.key[i + 1] & 1)) {
-                            if (cnt >= kMaxRaw) { ovf = true; break; }
-                            ivf[cnt] = Rg.key[i] >> 1;
-                            ivs[cnt] = Rg.last[i + 1];
-                            ++cnt;
+            if (nd > kMaxReg || nu > kMaxReg) {
+                any_overflow = true;
+                if (lane == 0) sel[8 + which] = 0;
+                continue;
+            }
+            const uint32_t nr = nd + nu;
+            // merge the two sorted lists by rank (keys differ in the low bit, so no ties)
+            {
+                const uint32_t* df = sm + L::RF + (2 * which) * kMaxReg;
+                const uint32_t* dl = sm + L::RL + (2 * which) * kMaxReg;
+                const uint32_t* uf = df + kMaxReg;
+                const uint32_t* ul = dl + kMaxReg;
+                for (uint32_t x = lane; x < nr; x += 64) {
+                    const bool is_up = x >= nd;
+                    const uint32_t a = is_up ? x - nd : x;
+                    const uint32_t kx = is_up ? (uf[a] << 1 | 1u) : (df[a] << 1);
+                    const uint32_t lx = is_up ? ul[a] : dl[a];
+                    uint32_t rank = a;
+                    if (is_up) { for (uint32_t y = 0; y < nd; ++y) rank += (df[y] << 1) < kx; }
+                    else       { for (uint32_t y = 0; y < nu; ++y) rank += (uf[y] << 1 | 1u) < kx; }
+                    key[rank] = kx;
+                    last[rank] = lx;
+                }
+            }
+            wave_sync();
+            // do neighbours overlap (pile.cpp:136,177)?  is an (up, down) pair within the window (:224-231)?
+            bool need_resolve = false, need_narrow = false;
+            for (uint32_t i0 = 0; i0 + 1 < nr; i0 += 64) {
+                const uint32_t i = i0 + lane;
+                bool c1 = false, c2 = false;
+                if (i + 1 < nr) {
+                    const uint32_t ki = key[i], li = last[i], kn = key[i + 1];
+                    c1 = li >= (kn >> 1) && ((ki & 1) || li != (kn >> 1));
+                    c2 = (ki & 1) && !(kn & 1) && (uint32_t)((kn >> 1) - li) <= kSlopeWindow;
+                }
+                need_resolve |= __ballot(c1) != 0;
+                need_narrow |= __ballot(c2) != 0;
+            }
+            uint32_t n_reg = nr;
+            if (need_resolve || need_narrow) {
+                if (lane == 0) {
+                    RunCursor dv{rs, rv, idx, shift, 0};
+                    RegionList Rg;
+                    Rg.key = key; Rg.last = last; Rg.n = nr; Rg.cap = 2 * kMaxReg; Rg.overflow = false;
+                    if (need_resolve) resolve_serial(Rg, dv, q);
+                    if (!Rg.overflow) narrow_serial(Rg, dv, q);
+                    sel[12] = Rg.n;
+                    sel[13] = Rg.overflow ? 1u : 0u;
+                }
+                wave_sync();
+                n_reg = sel[12];
+                if (sel[13]) {
+                    any_overflow = true;
+                    if (lane == 0) sel[8 + which] = 0;
+                    wave_sync();
+                    continue;
+                }
+            }
+            // raw pits: adjacent (down, up) (pile.cpp:357-362); raw hill candidates: every
+            // (up i, later down j) that passes the cheap tests of pile.cpp:415-418
+            uint32_t n_raw = 0;
+            if (which) {
+                for (uint32_t i0 = 0; i0 + 1 < n_reg; i0 += 64) {
+                    const uint32_t i = i0 + lane;
+                    const bool c = i + 1 < n_reg && !(key[i] & 1) && (key[i + 1] & 1);
+                    const uint64_t m = __ballot(c);
+                    if (c) {
+                        const uint32_t p = n_raw + __popcll(m & ((1ull << lane) - 1ull));
+                        if (p < kMaxRaw) { ivf[p] = key[i] >> 1; ivs[p] = last[i + 1]; }
+                    }
+                    n_raw += __popcll(m);
+                }
+            } else {
+                uint32_t* cand = sm + L::CAND;
+                const double span = (double)(E - B);
+                const double lo_lim = 0.05 * span + (double)B;
+                const double hi_lim = 0.95 * span + (double)B;
+                const uint32_t np = n_reg * n_reg;
+                for (uint32_t p0 = 0; p0 < np; p0 += 64) {
+                    const uint32_t p = p0 + lane;
+                    bool c = false;
+                    uint32_t i = 0, j = 0;
+                    if (p < np) {
+                        i = p / n_reg; j = p - i * n_reg;
+                        if (j > i && (key[i] & 1) && !(key[j] & 1)) {
+                            const uint32_t u_first = key[i] >> 1, u_last = last[i];
+                            const uint32_t w_first = key[j] >> 1, w_last = last[j];
+                            c = !((double)u_first < lo_lim || (double)w_last > hi_lim ||
+                                  (uint32_t)(w_first - u_last) > 840u);
                         }
                     }
-                } else {
-                    const double span = (double)(E - B);
-                    const double lo_lim = 0.05 * span + (double)B;
-                    const double hi_lim = 0.95 * span + (double)B;
-                    for (uint32_t i = 0; i + 1 < Rg.n && !ovf; ++i) {
-                        if (!(Rg.key[i] & 1)) continue;
-                        const uint32_t u_first = Rg.key[i] >> 1, u_last = Rg.last[i];
-                        for (uint32_t j = i + 1; j < Rg.n; ++j) {
-                            if (Rg.key[j] & 1) continue;
-                            const uint32_t w_first = Rg.key[j] >> 1, w_last = Rg.last[j];
-                            if ((double)u_first < lo_lim || (double)w_last > hi_lim ||
-                                (uint32_t)(w_first - u_last) > 840u) {
-                                continue;
-                            }
+                    const uint64_t m = __ballot(c);
+                    if (c) {
+                        const uint32_t w = n_raw + __popcll(m & ((1ull << lane) - 1ull));
+                        if (w < kMaxRaw) cand[w] = i << 16 | j;
+                    }
+                    n_raw += __popcll(m);
+                }
+            }
+            if (n_raw > kMaxRaw) {
+                any_overflow = true;
+                if (lane == 0) sel[8 + which] = 0;
+                continue;
+            }
+            if (n_raw) {
+                wave_sync();
+                if (lane == 0) {
+                    uint32_t cnt = n_raw;
+                    if (!which) {
+                        // peak test and fuzz of pile.cpp:421-448, candidates in (i, j) order
+                        RunCursor dv{rs, rv, idx, shift, 0};
+                        const uint32_t* cand = sm + L::CAND;
+                        cnt = 0;
+                        for (uint32_t c = 0; c < n_raw; ++c) {
+                            const uint32_t i = cand[c] >> 16, j = cand[c] & 0xFFFFu;
+                            const uint32_t u_first = key[i] >> 1, u_last = last[i];
+                            const uint32_t w_first = key[j] >> 1, w_last = last[j];
                             const uint32_t pk = (uint32_t)(1.3 * (double)umax(dv[u_last], dv[w_first]));
-                            bool found = false;
-                            for (uint32_t x = u_last + 1; x < w_first; ++x) {
-                                if (dv[x] > pk) { found = true; break; }
-                            }
+                            const bool found = u_last + 1 < w_first && range_max_runs(dv, u_last + 1, w_first - 1) > pk;
                             if (!found) continue;
-                            if (cnt >= kMaxRaw) { ovf = true; break; }
                             ivf[cnt] = (uint32_t)(u_first - B) > kHillFuzz ? u_first - kHillFuzz : B;
                             ivs[cnt] = (uint32_t)(E - w_last) > kHillFuzz ? w_last + kHillFuzz : E;
                             ++cnt;
                         }
                     }
+                    sel[8 + which] = interval_merge(ivf, ivs, cnt, gone, of, os);
                 }
-                if (!ovf) cnt = interval_merge(ivf, ivs, cnt, gone, of, os);
+            } else if (lane == 0) {
+                sel[8 + which] = 0;
             }
-            sel[8 + which] = ovf ? 0 : cnt;
-            sel[10 + which] = ovf ? 1u : 0u;
+            wave_sync();
         }
         wave_sync();
+        RUN_STOP(28)
 
         // ---- 9. publish ----------------------------------------------------------------------------
         if (lane == 0) {
             const uint32_t nh = sel[8], np = sel[9];
-            uint32_t err = (sel[10] | sel[11]) ? kErrRegionCapacity : 0;
+            uint32_t err = any_overflow ? kErrRegionCapacity : 0;
             uint32_t slot = kNone;
             uint32_t wp = err ? 0 : np, wh = err ? 0 : nh;
             if (wp + wh) {
@@ -584,13 +829,19 @@ __global__ __launch_bounds__(64) void pile_runs_kernel(PileArgs A, uint32_t* ove
         }
         wave_sync();
     }
+#undef RUN_STOP
 }
 
-void launch_pile_runs(const PileArgs& args, uint32_t grid, uint32_t* overflow_list, uint32_t* overflow_count,
-                      hipStream_t stream) {
+void launch_pile_runs(const PileArgs& args, uint32_t grid, bool big_cap, uint32_t* overflow_list,
+                      uint32_t* overflow_count, hipStream_t stream) {
     if (grid == 0) return;
-    hipLaunchKernelGGL(pile_runs_kernel<kRunEventCap>, dim3(grid), dim3(64), 0, stream, args, overflow_list,
-                       overflow_count);
+    if (big_cap) {
+        hipLaunchKernelGGL(pile_runs_kernel<kRunEventCapBig>, dim3(grid), dim3(64), 0, stream, args, overflow_list,
+                           overflow_count);
+    } else {
+        hipLaunchKernelGGL(pile_runs_kernel<kRunEventCap>, dim3(grid), dim3(64), 0, stream, args, overflow_list,
+                           overflow_count);
+    }
 }
 
 }  // namespace rala_hip

@@ -413,6 +413,8 @@ int rala_hip_set_reads(rala_hip_ctx* ctx, const uint32_t* read_len, uint64_t n_r
     HIPCHECK(hipSetDevice(ctx->device));
     ctx->n_reads = n_reads;
     ctx->h_read_len.assign(read_len, read_len + n_reads);
+    ctx->max_read_len = 0;
+    for (uint64_t r = 0; r < n_reads; ++r) ctx->max_read_len = std::max(ctx->max_read_len, read_len[r]);
     ctx->h_pile_off.resize(n_reads + 1);
     uint64_t off = 0;
     for (uint64_t r = 0; r < n_reads; ++r) {
@@ -507,25 +509,33 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
     a.begin = ctx->d_begin.p; a.end = ctx->d_end.p; a.median = ctx->d_median.p; a.p10 = ctx->d_p10.p;
     a.alive = ctx->d_alive.p; a.n_pits = ctx->d_n_pits.p; a.n_hills = ctx->d_n_hills.p; a.iv_slot = ctx->d_iv_slot.p;
     a.pool = ctx->d_pool.p; a.pool_count = ctx->d_small.p; a.pool_cap = ctx->pool_cap; a.error = ctx->d_small.p + 1;
+    a.n_items_dev = nullptr;
     if (ctx->use_run_kernel) {
-        // run-space kernel for every read; the event-dense ones come back in a list
+        // Chain without host synchronisation: run-space kernel (cap 512) for every read ->
+        // event-dense reads (list 1) to the cap-2048 instantiation -> what is left (list 2)
+        // to the position-space kernel, sized for the longest read.
+        uint32_t* list1 = ctx->d_overflow.p;
+        uint32_t* list2 = ctx->d_order.p;
+        uint32_t* cnt1 = ctx->d_small.p + 4;
+        uint32_t* cnt2 = ctx->d_small.p + 5;
+        HIPCHECK(hipMemsetAsync(cnt1, 0, 8, s));
         a.order = nullptr;
         a.n_items = n_reads;
         a.lw = 0;
-        HIPCHECK(hipMemsetAsync(ctx->d_small.p + 4, 0, 4, s));
-        launch_pile_runs(a, n_reads, ctx->d_overflow.p, ctx->d_small.p + 4, s);
-        ++ctx->tm.pile_launches;
-        uint32_t n_over = 0;
-        HIPCHECK(hipMemcpyAsync(&n_over, ctx->d_small.p + 4, 4, hipMemcpyDeviceToHost, s));
-        HIPCHECK(hipStreamSynchronize(s));
-        ctx->tm.pile_overflow_reads = n_over;
-        if (n_over) {
-            std::vector<uint32_t> reads(n_over);
-            HIPCHECK(hipMemcpy(reads.data(), ctx->d_overflow.p, (size_t)n_over * 4, hipMemcpyDeviceToHost));
-            std::sort(reads.begin(), reads.end());
-            const int rc2 = run_position_kernel(ctx, a, reads);
-            if (rc2 != RALA_HIP_OK) return rc2;
-        }
+        launch_pile_runs(a, n_reads, false, list1, cnt1, s);
+        a.order = list1;
+        a.n_items_dev = cnt1;
+        launch_pile_runs(a, std::min<uint32_t>(n_reads, 2048), true, list2, cnt2, s);
+        a.order = list2;
+        a.n_items_dev = cnt2;
+        const uint32_t max_len = ctx->max_read_len;
+        const bool in_lds = (int64_t)max_len <= ctx->max_lds_read_len && pile_lw_for(max_len) <= 24576;
+        a.lw = pile_lw_for(max_len);
+        const uint32_t grid = std::min<uint32_t>(n_reads, 256);
+        if (!in_lds) HIPCHECK(ctx->d_slab.ensure((size_t)grid * 3 * a.lw));
+        a.slab = ctx->d_slab.p;
+        launch_pile_build_annotate(a, grid, in_lds, s);
+        ctx->tm.pile_launches = 3;
     } else {
         std::vector<uint32_t> reads(n_reads);
         std::iota(reads.begin(), reads.end(), 0u);
@@ -537,8 +547,10 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
 
     int rc = download_read_state(ctx);
     if (rc != RALA_HIP_OK) return rc;
-    uint32_t small[4];
+    uint32_t small[8];
     HIPCHECK(hipMemcpy(small, ctx->d_small.p, sizeof(small), hipMemcpyDeviceToHost));
+    ctx->tm.pile_overflow_reads = small[4];
+    ctx->tm.pile_position_reads = ctx->use_run_kernel ? small[5] : n_reads;
     HIPCHECK(hipEventElapsedTime(&ctx->tm.dedupe_ms, ctx->ev[0], ctx->ev[1]));
     HIPCHECK(hipEventElapsedTime(&ctx->tm.bucket_ms, ctx->ev[1], ctx->ev[2]));
     HIPCHECK(hipEventElapsedTime(&ctx->tm.pile_ms, ctx->ev[2], ctx->ev[3]));

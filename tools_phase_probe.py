@@ -8,7 +8,7 @@ ds = Dataset.config(wl)
 ctx = hip.Context(0)
 ctx.set_reads(ds.read_len); ctx.set_overlaps(ds.overlaps)
 prev = 0.0
-for k in list(range(0, 10)) + [99]:
+for k in ([int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else list(range(0, 10))) + [99]:
     ctx.set_option("debug_pile_stop_after", k)
     best = 1e9
     for _ in range(3):
