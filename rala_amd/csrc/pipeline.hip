@@ -220,12 +220,16 @@ void component_medians(rala_hip_ctx* ctx, std::vector<uint32_t>& members, std::v
     }
     members.clear();
     for (uint64_t r = 0; r < n; ++r) if (touched[r]) members.push_back((uint32_t)r);
-    // group members by root
+    // group members by root (counting sort on the root id)
     std::vector<uint32_t> root(members.size());
-    for (size_t k = 0; k < members.size(); ++k) root[k] = uf.find(members[k]);
+    std::vector<uint32_t> cnt(n + 1, 0);
+    for (size_t k = 0; k < members.size(); ++k) {
+        root[k] = uf.find(members[k]);
+        ++cnt[root[k] + 1];
+    }
+    for (uint64_t r = 0; r < n; ++r) cnt[r + 1] += cnt[r];
     std::vector<uint32_t> idx(members.size());
-    std::iota(idx.begin(), idx.end(), 0u);
-    std::stable_sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) { return root[x] < root[y]; });
+    for (size_t k = 0; k < members.size(); ++k) idx[cnt[root[k]]++] = (uint32_t)k;
     med_of_member.assign(members.size(), 0);
     std::vector<uint16_t> m;
     for (size_t s = 0; s < idx.size();) {
