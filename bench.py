@@ -70,7 +70,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    force_sharded = os.environ.get("RALA_FORCE_SHARDED") == "1" and "RANK" in os.environ
+    use_dist = world > 1 or force_sharded
+    if use_dist:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -88,7 +90,7 @@ def main():
     sum_len = int(ds.read_len.astype(np.int64).sum())
     log("[bench] generated %s: %d reads, %d overlaps in %.1f s" % (args.workload, ds.n_reads, n_ovl,
                                                                     time.perf_counter() - t0))
-    if world > 1:
+    if use_dist:
         from rala_amd import multi
         runner = multi.ShardedRunner(ds, rank, world, local_rank)
     else:
@@ -107,7 +109,7 @@ def main():
         runner = _Single()
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -123,7 +125,7 @@ def main():
             stage[k] = stage.get(k, 0.0) + float(v)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -172,7 +174,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline("c2" if args.workload != "c1" else "c1")
         print(json.dumps(out), flush=True)
 
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -111,6 +111,28 @@ int rala_hip_remove_transitive_edges(rala_hip_ctx* ctx, uint32_t* n_pairs);
 int rala_hip_tr_mark(rala_hip_ctx* ctx, uint32_t n_nodes, uint32_t n_edges, const uint32_t* src,
                      const uint32_t* dst, const uint32_t* len, uint8_t* marks, uint32_t* n_pairs);
 
+/* ---- multi-GPU building blocks (one process per GPU; the collective itself is the caller's,
+ * e.g. RCCL through torch.distributed).  Reads are partitioned over ranks; rank k holds a
+ * slice of the overlap file cut on a_id-run boundaries. ---------------------------------- */
+/* remove_duplicate_overlaps only (src/graph.cpp:273-307) on this context's overlaps */
+int rala_hip_dedupe(rala_hip_ctx* ctx);
+/* store_overlap_bounds (src/graph.cpp:311-326) as tuples: for overlap i the entries 4i..4i+3 of
+ * the DEVICE buffers reads_dev / bounds_dev (4 * n_overlaps uint32 each, 16-byte aligned)
+ * receive (a, (a_begin+15)<<1), (a, (a_end-15)<<1|1), (b, ...), (b, ...); the read is
+ * RALA_HIP_NO_READ for records that do not resolve.  The caller routes them to the read owners. */
+int rala_hip_emit_bound_tuples(rala_hip_ctx* ctx, uint32_t* reads_dev, uint32_t* bounds_dev);
+/* Feed a context whose reads are the locally owned ones with the tuples it received (read =
+ * LOCAL read number; other values are ignored).  rala_hip_initialize then skips duplicate
+ * removal and builds / annotates the piles from these bounds. */
+int rala_hip_set_bound_tuples(rala_hip_ctx* ctx, const uint32_t* reads, const uint32_t* bounds, uint64_t n, int mem);
+/* Install the result of Graph::initialize computed elsewhere (gathered from the owners) into a
+ * context that holds all reads and overlaps, so that rala_hip_construct can follow.  Host
+ * arrays; interval CSR as returned by rala_hip_get_intervals (kinds 0 and 1). */
+int rala_hip_import_state(rala_hip_ctx* ctx, const uint8_t* valid, const uint32_t* begin, const uint32_t* end,
+                          const uint16_t* median, const uint16_t* p10, const uint8_t* alive,
+                          const uint64_t* pits_off, const uint32_t* pits_pairs, const uint32_t* pits_aux,
+                          const uint64_t* hills_off, const uint32_t* hills_pairs);
+
 /* ---- results (host buffers owned by the caller) --------------------------------------- */
 /* is_valid_overlap_ (src/graph.hpp:168), one byte per overlap */
 int rala_hip_get_valid(rala_hip_ctx* ctx, uint8_t* valid);

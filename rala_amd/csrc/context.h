@@ -81,6 +81,15 @@ struct rala_hip_ctx {
     rala_hip::DevBuf<uint32_t> d_ovl_u32[7];
     rala_hip::DevBuf<uint8_t> d_ovl_strand;
     rala_hip::DevBuf<uint8_t> d_valid;
+    bool valid_ready = false;
+
+    // bound tuples shipped in by the caller instead of overlaps (multi-GPU owners)
+    bool tuple_mode = false;
+    uint64_t n_tuples = 0;
+    const uint32_t* tuple_reads = nullptr;
+    const uint32_t* tuple_bounds = nullptr;
+    rala_hip::DevBuf<uint32_t> d_tuple[2];
+    bool piles_resident = false;
 
     // bound CSR
     rala_hip::DevBuf<uint32_t> d_ev_off, d_cursor, d_ev;

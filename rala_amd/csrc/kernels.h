@@ -92,6 +92,11 @@ enum : uint8_t {
 void launch_dedupe(const OvlSoA& o, uint32_t n_reads, uint8_t* valid, hipStream_t s);
 void launch_count_bounds(const OvlSoA& o, uint32_t n_reads, uint32_t* counts, hipStream_t s);
 void launch_scatter_bounds(const OvlSoA& o, uint32_t n_reads, uint32_t* cursor, uint32_t* ev, hipStream_t s);
+// bound tuples (read, bound) instead of overlaps: multi-GPU owners receive them by all-to-all
+void launch_emit_tuples(const OvlSoA& o, uint32_t n_reads, uint32_t* reads, uint32_t* bounds, hipStream_t s);
+void launch_count_tuples(const uint32_t* reads, uint64_t n, uint32_t n_reads, uint32_t* counts, hipStream_t s);
+void launch_scatter_tuples(const uint32_t* reads, const uint32_t* bounds, uint64_t n, uint32_t n_reads,
+                           uint32_t* cursor, uint32_t* ev, hipStream_t s);
 void launch_classify(const OvlSoA& o, uint32_t n_reads, const uint8_t* valid, const ReadState& rs, uint8_t* cls,
                      hipStream_t s);
 void launch_death_round(const OvlSoA& o, const uint8_t* cls, const uint32_t* death_old, uint32_t* death_new,

@@ -78,6 +78,43 @@ __global__ __launch_bounds__(kBlock) void scatter_bounds_kernel(OvlSoA o, uint32
     ev[pb + 1] = ((o.b_end[i] - 15u) << 1) | 1u;
 }
 
+// Multi-GPU: the four bounds of overlap i as (read, bound) tuples at 4i .. 4i+3; the read
+// is ~0u for records that do not resolve.
+__global__ __launch_bounds__(kBlock) void emit_tuples_kernel(OvlSoA o, uint32_t n_reads, uint32_t* __restrict__ reads,
+                                                             uint32_t* __restrict__ bounds) {
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= o.n) return;
+    const uint32_t a = o.a_id[i], b = o.b_id[i];
+    const bool ok = a < n_reads && b < n_reads;
+    uint4 r, v;
+    r.x = r.y = ok ? a : kInf;
+    r.z = r.w = ok ? b : kInf;
+    v.x = (o.a_begin[i] + 15u) << 1;
+    v.y = ((o.a_end[i] - 15u) << 1) | 1u;
+    v.z = (o.b_begin[i] + 15u) << 1;
+    v.w = ((o.b_end[i] - 15u) << 1) | 1u;
+    ((uint4*)reads)[i] = r;
+    ((uint4*)bounds)[i] = v;
+}
+
+__global__ __launch_bounds__(kBlock) void count_tuples_kernel(const uint32_t* __restrict__ reads, uint64_t n,
+                                                              uint32_t n_reads, uint32_t* counts) {
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t r = reads[i];
+    if (r < n_reads) atomicAdd(&counts[r], 1u);
+}
+
+__global__ __launch_bounds__(kBlock) void scatter_tuples_kernel(const uint32_t* __restrict__ reads,
+                                                                const uint32_t* __restrict__ bounds, uint64_t n,
+                                                                uint32_t n_reads, uint32_t* cursor,
+                                                                uint32_t* __restrict__ ev) {
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t r = reads[i];
+    if (r < n_reads) ev[atomicAdd(&cursor[r], 1u)] = bounds[i];
+}
+
 __device__ __forceinline__ Coords load_coords(const OvlSoA& o, uint64_t i) {
     Coords c;
     c.a_begin = o.a_begin[i]; c.a_end = o.a_end[i];
@@ -217,6 +254,19 @@ void launch_count_bounds(const OvlSoA& o, uint32_t n_reads, uint32_t* counts, hi
 }
 void launch_scatter_bounds(const OvlSoA& o, uint32_t n_reads, uint32_t* cursor, uint32_t* ev, hipStream_t s) {
     if (o.n) hipLaunchKernelGGL(scatter_bounds_kernel, grid_for(o.n), dim3(kBlock), 0, s, o, n_reads, cursor, ev);
+}
+void launch_emit_tuples(const OvlSoA& o, uint32_t n_reads, uint32_t* reads, uint32_t* bounds, hipStream_t s) {
+    if (o.n) hipLaunchKernelGGL(emit_tuples_kernel, grid_for(o.n), dim3(kBlock), 0, s, o, n_reads, reads, bounds);
+}
+void launch_count_tuples(const uint32_t* reads, uint64_t n, uint32_t n_reads, uint32_t* counts, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(count_tuples_kernel, grid_for(n), dim3(kBlock), 0, s, reads, n, n_reads, counts);
+}
+void launch_scatter_tuples(const uint32_t* reads, const uint32_t* bounds, uint64_t n, uint32_t n_reads,
+                           uint32_t* cursor, uint32_t* ev, hipStream_t s) {
+    if (n) {
+        hipLaunchKernelGGL(scatter_tuples_kernel, grid_for(n), dim3(kBlock), 0, s, reads, bounds, n, n_reads, cursor,
+                           ev);
+    }
 }
 void launch_classify(const OvlSoA& o, uint32_t n_reads, const uint8_t* valid, const ReadState& rs, uint8_t* cls,
                      hipStream_t s) {

@@ -429,7 +429,7 @@ int rala_hip_set_reads(rala_hip_ctx* ctx, const uint32_t* read_len, uint64_t n_r
     ctx->pile_elems = off;
     HIPCHECK(ctx->d_read_len.ensure(n_reads + 1));
     HIPCHECK(ctx->d_pile_off.ensure(n_reads + 1));
-    HIPCHECK(ctx->d_pile.ensure(off + 8));
+    ctx->d_pile.release();                       // allocated by rala_hip_initialize (owners only)
     HIPCHECK(hipMemcpy(ctx->d_read_len.p, read_len, n_reads * 4, hipMemcpyHostToDevice));
     HIPCHECK(hipMemcpy(ctx->d_pile_off.p, ctx->h_pile_off.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice));
     HIPCHECK(ctx->d_order.ensure(n_reads + 1));
@@ -474,6 +474,8 @@ int rala_hip_set_overlaps(rala_hip_ctx* ctx, const rala_hip_overlaps* o, uint64_
     ctx->ovl.a_id = dev[0]; ctx->ovl.b_id = dev[1]; ctx->ovl.a_begin = dev[2]; ctx->ovl.a_end = dev[3];
     ctx->ovl.b_begin = dev[4]; ctx->ovl.b_end = dev[5]; ctx->ovl.length = dev[6]; ctx->ovl.strand = dev_strand;
     ctx->ovl.n = n;
+    ctx->tuple_mode = false;
+    ctx->valid_ready = false;
     HIPCHECK(ctx->d_valid.ensure(n));
     HIPCHECK(ctx->d_ev.ensure(4 * n + 8));
     HIPCHECK(ctx->d_cls.ensure(n));
@@ -493,16 +495,26 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
     ctx->overlaps.clear(); ctx->internals.clear();
     ctx->initialized = ctx->constructed = false;
 
+    HIPCHECK(ctx->d_pile.ensure(ctx->pile_elems + 8));
     HIPCHECK(hipMemsetAsync(ctx->d_small.p, 0, 8 * 4, s));
     HIPCHECK(hipEventRecord(ctx->ev[0], s));
-    launch_dedupe(ctx->ovl, n_reads, ctx->d_valid.p, s);
+    if (!ctx->tuple_mode) launch_dedupe(ctx->ovl, n_reads, ctx->d_valid.p, s);
     HIPCHECK(hipEventRecord(ctx->ev[1], s));
     // bucket bounds by read: count -> exclusive scan -> scatter
     HIPCHECK(hipMemsetAsync(ctx->d_cursor.p, 0, (size_t)(n_reads + 1) * 4, s));
-    launch_count_bounds(ctx->ovl, n_reads, ctx->d_cursor.p, s);
+    if (ctx->tuple_mode) {
+        launch_count_tuples(ctx->tuple_reads, ctx->n_tuples, n_reads, ctx->d_cursor.p, s);
+    } else {
+        launch_count_bounds(ctx->ovl, n_reads, ctx->d_cursor.p, s);
+    }
     launch_exclusive_scan(ctx->d_cursor.p, ctx->d_ev_off.p, n_reads, ctx->d_scan_ws.p, s);
     HIPCHECK(hipMemcpyAsync(ctx->d_cursor.p, ctx->d_ev_off.p, (size_t)n_reads * 4, hipMemcpyDeviceToDevice, s));
-    launch_scatter_bounds(ctx->ovl, n_reads, ctx->d_cursor.p, ctx->d_ev.p, s);
+    if (ctx->tuple_mode) {
+        launch_scatter_tuples(ctx->tuple_reads, ctx->tuple_bounds, ctx->n_tuples, n_reads, ctx->d_cursor.p,
+                              ctx->d_ev.p, s);
+    } else {
+        launch_scatter_bounds(ctx->ovl, n_reads, ctx->d_cursor.p, ctx->d_ev.p, s);
+    }
     HIPCHECK(hipEventRecord(ctx->ev[2], s));
 
     PileArgs a;
@@ -567,13 +579,124 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
     ctx->n_prefiltered = 0;
     for (uint64_t r = 0; r < ctx->n_reads; ++r) if (!ctx->h_alive[r]) ++ctx->n_prefiltered;
     ctx->initialized = true;
+    ctx->valid_ready = !ctx->tuple_mode;
+    ctx->piles_resident = true;
     if (ctx->n_prefiltered == ctx->n_reads) return fail(ctx, RALA_HIP_EFILTERED, "filtered all sequences");
+    return RALA_HIP_OK;
+}
+
+int rala_hip_dedupe(rala_hip_ctx* ctx) {
+    if (!ctx) return RALA_HIP_EINVAL;
+    if (ctx->n_reads == 0) return fail(ctx, RALA_HIP_EINVAL, "no reads set");
+    HIPCHECK(hipSetDevice(ctx->device));
+    launch_dedupe(ctx->ovl, (uint32_t)ctx->n_reads, ctx->d_valid.p, ctx->stream);
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    HIPCHECK(hipGetLastError());
+    ctx->valid_ready = true;
+    return RALA_HIP_OK;
+}
+
+int rala_hip_emit_bound_tuples(rala_hip_ctx* ctx, uint32_t* reads_dev, uint32_t* bounds_dev) {
+    if (!ctx || !reads_dev || !bounds_dev) return RALA_HIP_EINVAL;
+    HIPCHECK(hipSetDevice(ctx->device));
+    launch_emit_tuples(ctx->ovl, (uint32_t)ctx->n_reads, reads_dev, bounds_dev, ctx->stream);
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    HIPCHECK(hipGetLastError());
+    return RALA_HIP_OK;
+}
+
+int rala_hip_set_bound_tuples(rala_hip_ctx* ctx, const uint32_t* reads, const uint32_t* bounds, uint64_t n, int mem) {
+    if (!ctx || (n && (!reads || !bounds))) return RALA_HIP_EINVAL;
+    if (ctx->n_reads == 0) return fail(ctx, RALA_HIP_EINVAL, "no reads set");
+    if (n >= 0xFFFFFFF0ull) return fail(ctx, RALA_HIP_EINVAL, "too many tuples");
+    HIPCHECK(hipSetDevice(ctx->device));
+    if (mem == RALA_HIP_MEM_DEVICE) {
+        ctx->tuple_reads = reads;
+        ctx->tuple_bounds = bounds;
+    } else {
+        HIPCHECK(ctx->d_tuple[0].ensure(n));
+        HIPCHECK(ctx->d_tuple[1].ensure(n));
+        if (n) {
+            HIPCHECK(hipMemcpy(ctx->d_tuple[0].p, reads, n * 4, hipMemcpyHostToDevice));
+            HIPCHECK(hipMemcpy(ctx->d_tuple[1].p, bounds, n * 4, hipMemcpyHostToDevice));
+        }
+        ctx->tuple_reads = ctx->d_tuple[0].p;
+        ctx->tuple_bounds = ctx->d_tuple[1].p;
+    }
+    ctx->n_tuples = n;
+    ctx->tuple_mode = true;
+    ctx->n_ovl = 0;
+    ctx->ovl = OvlSoA();
+    HIPCHECK(ctx->d_ev.ensure(n + 8));
+    HIPCHECK(ctx->d_scan_ws.ensure(scan_workspace_bytes(std::max<uint64_t>(n, ctx->n_reads) + 2)));
+    ctx->initialized = ctx->constructed = false;
+    return RALA_HIP_OK;
+}
+
+int rala_hip_import_state(rala_hip_ctx* ctx, const uint8_t* valid, const uint32_t* begin, const uint32_t* end,
+                          const uint16_t* median, const uint16_t* p10, const uint8_t* alive,
+                          const uint64_t* pits_off, const uint32_t* pits_pairs, const uint32_t* pits_aux,
+                          const uint64_t* hills_off, const uint32_t* hills_pairs) {
+    if (!ctx || !begin || !end || !median || !p10 || !alive || !pits_off || !hills_off) return RALA_HIP_EINVAL;
+    if (ctx->n_reads == 0) return fail(ctx, RALA_HIP_EINVAL, "no reads set");
+    if (ctx->n_ovl && !valid) return fail(ctx, RALA_HIP_EINVAL, "valid bits required");
+    HIPCHECK(hipSetDevice(ctx->device));
+    const uint64_t n = ctx->n_reads;
+    ctx->tm = rala_hip_timings();
+    ctx->overlaps.clear(); ctx->internals.clear();
+    std::vector<uint8_t> np(n), nh(n);
+    std::vector<uint32_t> slot(n, 0xFFFFFFFFu);
+    std::vector<Interval> pool;
+    for (uint64_t r = 0; r < n; ++r) {
+        const uint64_t a = pits_off[r + 1] - pits_off[r], b = hills_off[r + 1] - hills_off[r];
+        if (a > 255 || b > 255) return fail(ctx, RALA_HIP_EINVAL, "too many intervals on a read");
+        np[r] = (uint8_t)a; nh[r] = (uint8_t)b;
+        if (a + b == 0) continue;
+        slot[r] = (uint32_t)pool.size();
+        for (uint64_t k = pits_off[r]; k < pits_off[r + 1]; ++k) {
+            Interval iv; iv.first = pits_pairs[2 * k]; iv.second = pits_pairs[2 * k + 1]; iv.aux = pits_aux[k];
+            pool.push_back(iv);
+        }
+        for (uint64_t k = hills_off[r]; k < hills_off[r + 1]; ++k) {
+            Interval iv; iv.first = hills_pairs[2 * k]; iv.second = hills_pairs[2 * k + 1]; iv.aux = 0;
+            pool.push_back(iv);
+        }
+    }
+    if (pool.size() > ctx->pool_cap) {
+        ctx->pool_cap = (uint32_t)pool.size() + 1024;
+        HIPCHECK(ctx->d_pool.ensure(ctx->pool_cap));
+    }
+    const uint32_t used = (uint32_t)pool.size();
+    uint32_t small[8] = {used, 0, 0, 0, 0, 0, 0, 0};
+    HIPCHECK(hipMemcpy(ctx->d_small.p, small, sizeof(small), hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(ctx->d_begin.p, begin, n * 4, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(ctx->d_end.p, end, n * 4, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(ctx->d_median.p, median, n * 2, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(ctx->d_p10.p, p10, n * 2, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(ctx->d_alive.p, alive, n, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(ctx->d_n_pits.p, np.data(), n, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(ctx->d_n_hills.p, nh.data(), n, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(ctx->d_iv_slot.p, slot.data(), n * 4, hipMemcpyHostToDevice));
+    if (used) HIPCHECK(hipMemcpy(ctx->d_pool.p, pool.data(), (size_t)used * sizeof(Interval), hipMemcpyHostToDevice));
+    if (ctx->n_ovl) HIPCHECK(hipMemcpy(ctx->d_valid.p, valid, ctx->n_ovl, hipMemcpyHostToDevice));
+    const int rc = download_read_state(ctx);
+    if (rc != RALA_HIP_OK) return rc;
+    ctx->h_begin0 = ctx->h_begin;
+    ctx->h_end0 = ctx->h_end;
+    ctx->n_prefiltered = 0;
+    for (uint64_t r = 0; r < n; ++r) if (!ctx->h_alive[r]) ++ctx->n_prefiltered;
+    ctx->initialized = true;
+    ctx->valid_ready = true;
+    ctx->constructed = false;
+    ctx->piles_resident = false;
+    if (ctx->n_prefiltered == n) return fail(ctx, RALA_HIP_EFILTERED, "filtered all sequences");
     return RALA_HIP_OK;
 }
 
 int rala_hip_construct(rala_hip_ctx* ctx, const rala_hip_overlaps* sens, uint64_t n_sens) {
     if (!ctx) return RALA_HIP_EINVAL;
     if (!ctx->initialized) return fail(ctx, RALA_HIP_EINVAL, "rala_hip_initialize must succeed first");
+    if (ctx->tuple_mode) return fail(ctx, RALA_HIP_EINVAL, "construct needs the overlaps (tuple-fed context)");
     if (ctx->constructed) return fail(ctx, RALA_HIP_EINVAL, "object already constructed");
     if (sens != nullptr && n_sens != 0) return fail(ctx, RALA_HIP_EINVAL, "sensitive overlaps: not available yet");
     HIPCHECK(hipSetDevice(ctx->device));
@@ -689,7 +812,7 @@ int rala_hip_tr_mark(rala_hip_ctx* ctx, uint32_t n_nodes, uint32_t n_edges, cons
 // ---- results ---------------------------------------------------------------------------
 int rala_hip_get_valid(rala_hip_ctx* ctx, uint8_t* valid) {
     if (!ctx || !valid) return RALA_HIP_EINVAL;
-    if (!ctx->initialized) return fail(ctx, RALA_HIP_EINVAL, "not initialized");
+    if (!ctx->valid_ready) return fail(ctx, RALA_HIP_EINVAL, "run rala_hip_dedupe or rala_hip_initialize first");
     HIPCHECK(hipSetDevice(ctx->device));
     if (ctx->n_ovl) HIPCHECK(hipMemcpy(valid, ctx->d_valid.p, ctx->n_ovl, hipMemcpyDeviceToHost));
     return RALA_HIP_OK;
@@ -714,6 +837,7 @@ int rala_hip_get_piles(rala_hip_ctx* ctx, uint32_t* begin, uint32_t* end, uint16
 int rala_hip_get_pile_data(rala_hip_ctx* ctx, uint64_t read, uint16_t* data) {
     if (!ctx || !data) return RALA_HIP_EINVAL;
     if (!ctx->initialized || read >= ctx->n_reads) return fail(ctx, RALA_HIP_EINVAL, "bad read / not initialized");
+    if (!ctx->piles_resident) return fail(ctx, RALA_HIP_EINVAL, "piles live on the owning rank's context");
     HIPCHECK(hipSetDevice(ctx->device));
     const uint32_t n = ctx->h_read_len[read];
     HIPCHECK(hipMemcpy(data, ctx->d_pile.p + ctx->h_pile_off[read], (size_t)n * 2, hipMemcpyDeviceToHost));

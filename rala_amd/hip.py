@@ -25,6 +25,7 @@ SYMBOLS = (
     "rala_hip_remove_transitive_edges", "rala_hip_tr_mark", "rala_hip_get_valid", "rala_hip_get_piles",
     "rala_hip_get_pile_data", "rala_hip_get_intervals", "rala_hip_get_overlaps", "rala_hip_get_graph_size",
     "rala_hip_get_graph", "rala_hip_get_timings", "rala_hip_get_num_prefiltered",
+    "rala_hip_dedupe", "rala_hip_emit_bound_tuples", "rala_hip_set_bound_tuples", "rala_hip_import_state",
 )
 
 
@@ -81,6 +82,10 @@ def lib(build=True):
         L.rala_hip_get_graph.argtypes = [vp, vp, vp, vp, vp, vp]
         L.rala_hip_get_timings.argtypes = [vp, ctypes.POINTER(Timings)]
         L.rala_hip_get_num_prefiltered.argtypes = [vp, ctypes.POINTER(u64)]
+        L.rala_hip_dedupe.argtypes = [vp]
+        L.rala_hip_emit_bound_tuples.argtypes = [vp, vp, vp]
+        L.rala_hip_set_bound_tuples.argtypes = [vp, vp, vp, u64, i32]
+        L.rala_hip_import_state.argtypes = [vp] + [vp] * 11
         _lib = L
     return _lib
 
@@ -156,6 +161,39 @@ class Context:
             setattr(c, name, ptrs[name])
         self.n_overlaps = int(n)
         self._check(self.L.rala_hip_set_overlaps(self.h, ctypes.byref(c), self.n_overlaps, MEM_DEVICE))
+
+    # ---- multi-GPU building blocks ----
+    def dedupe(self):
+        self._check(self.L.rala_hip_dedupe(self.h))
+
+    def emit_bound_tuples(self, reads_ptr, bounds_ptr):
+        """device pointers of 4 * n_overlaps uint32 each"""
+        self._check(self.L.rala_hip_emit_bound_tuples(self.h, reads_ptr, bounds_ptr))
+
+    def set_bound_tuples_device(self, reads_ptr, bounds_ptr, n):
+        self.n_overlaps = 0
+        self._check(self.L.rala_hip_set_bound_tuples(self.h, reads_ptr, bounds_ptr, int(n), MEM_DEVICE))
+
+    def set_bound_tuples(self, reads, bounds):
+        reads = np.ascontiguousarray(reads, dtype=np.uint32)
+        bounds = np.ascontiguousarray(bounds, dtype=np.uint32)
+        self.n_overlaps = 0
+        self._check(self.L.rala_hip_set_bound_tuples(self.h, reads.ctypes.data, bounds.ctypes.data, len(reads),
+                                                     MEM_HOST))
+
+    def import_state(self, valid, piles, pits, hills):
+        """piles: dict as returned by piles(); pits / hills: (offsets, pairs, aux) as intervals()."""
+        c = np.ascontiguousarray
+        valid = c(valid, dtype=np.uint8)
+        arrs = [valid, c(piles["begin"], dtype=np.uint32), c(piles["end"], dtype=np.uint32),
+                c(piles["median"], dtype=np.uint16), c(piles["p10"], dtype=np.uint16),
+                c(piles["alive"], dtype=np.uint8), c(pits[0], dtype=np.uint64),
+                c(pits[1], dtype=np.uint32).reshape(-1), c(pits[2], dtype=np.uint32),
+                c(hills[0], dtype=np.uint64), c(hills[1], dtype=np.uint32).reshape(-1)]
+        ptrs = [a.ctypes.data if a.size else None for a in arrs]
+        if ptrs[6] is None or ptrs[9] is None:
+            raise ValueError("interval offsets must have n_reads + 1 entries")
+        self._check(self.L.rala_hip_import_state(self.h, *ptrs))
 
     # ---- stages ----
     def initialize(self):
