@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-RALA_FORCE_SHARDED=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --workload c2 --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | tail -4
+timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -30

@@ -119,6 +119,16 @@ struct rala_hip_ctx {
     std::vector<rala_hip::Interval> h_pool;
     bool host_state_fresh = false;
 
+    // sensitive pass (repeat hills)
+    rala_hip::DevBuf<uint16_t> d_dataset_median;
+    rala_hip::DevBuf<uint8_t> d_n_rep;
+    rala_hip::DevBuf<uint32_t> d_rep_slot;
+    rala_hip::DevBuf<rala_hip::Interval> d_rep_pool;
+    std::vector<uint8_t> h_n_rep;
+    std::vector<uint32_t> h_rep_slot;
+    std::vector<rala_hip::Interval> h_rep_pool;
+    bool have_repeats = false;
+
     // host tail
     std::vector<rala_hip::HostOvl> overlaps, internals;
     std::vector<uint32_t> node_read;

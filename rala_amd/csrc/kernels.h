@@ -63,6 +63,33 @@ constexpr uint32_t kRunEventCapBig = 2048;
 void launch_pile_runs(const PileArgs& args, uint32_t grid, bool big_cap, uint32_t* overflow_list,
                       uint32_t* overflow_count, hipStream_t stream);
 
+// sensitive pass (pile_repeats_kernel.hip): mode 1 = add layers on top + median for the
+// targets; mode 2 = repeat hills for the members of connected components
+struct RepeatArgs {
+    const uint32_t* read_len;
+    const uint64_t* pile_off;
+    uint16_t* pile;
+    const uint32_t* ev_off;            // mode 1: CSR of the new bounds per read
+    const uint32_t* ev;
+    const uint32_t* order;
+    uint32_t n_items;
+    uint32_t lw;
+    uint16_t* slab;
+    const uint32_t* begin;             // current valid regions
+    const uint32_t* end;
+    uint16_t* median;                  // mode 1 writes, mode 2 reads
+    uint16_t* p10;
+    const uint16_t* dataset_median;    // mode 2: component median per read
+    uint8_t* n_rep;                    // mode 2 outputs
+    uint32_t* rep_slot;
+    Interval* pool;
+    uint32_t* pool_count;
+    uint32_t pool_cap;
+    uint32_t* error;
+};
+uint32_t repeats_lds_bytes(uint32_t lw);
+void launch_pile_repeats(const RepeatArgs& args, uint32_t grid, bool in_lds, int mode, hipStream_t stream);
+
 // ---- overlap-side kernels (overlap_kernels.hip) ------------------------------
 struct OvlSoA {
     const uint32_t *a_id, *b_id, *a_begin, *a_end, *b_begin, *b_end, *length;

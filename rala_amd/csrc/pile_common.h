@@ -1,0 +1,142 @@
+// Pieces shared by the position-space pile kernels (pile_kernels.hip,
+// pile_repeats_kernel.hip): packed uint16 max, slope-region lists and the
+// reference's region resolution / narrowing (pile.cpp:131-256) over an LDS or
+// HBM image of the pile.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "geom.h"
+
+namespace rala_hip {
+namespace {
+
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
+    u16x2 x = __builtin_bit_cast(u16x2, a), y = __builtin_bit_cast(u16x2, b);
+    u16x2 r = __builtin_elementwise_max(x, y);
+    return __builtin_bit_cast(uint32_t, r);
+}
+
+// ---- slope regions (serial, one lane) --------------------------------------
+struct RegionList {
+    uint32_t* key;    // first << 1 | is_up
+    uint32_t* last;
+    uint32_t n;
+    uint32_t cap;
+    bool overflow;
+};
+
+__device__ __forceinline__ void rl_push(RegionList& R, uint32_t key, uint32_t last) {
+    if (R.n >= R.cap) { R.overflow = true; return; }
+    R.key[R.n] = key;
+    R.last[R.n] = last;
+    ++R.n;
+}
+
+// insertion sort by (key, last); lists are short and nearly sorted
+__device__ void rl_sort(RegionList& R) {
+    for (uint32_t i = 1; i < R.n; ++i) {
+        const uint32_t k = R.key[i], l = R.last[i];
+        uint32_t j = i;
+        while (j > 0 && (R.key[j - 1] > k || (R.key[j - 1] == k && R.last[j - 1] > l))) {
+            R.key[j] = R.key[j - 1];
+            R.last[j] = R.last[j - 1];
+            --j;
+        }
+        R.key[j] = k;
+        R.last[j] = l;
+    }
+}
+
+// pile.cpp:131-256: resolve overlapping neighbours, then narrow (up, down) pairs.
+// d[j] is the coverage at read position j.
+template <class DataPtr>
+__device__ void resolve_and_narrow(RegionList& R, DataPtr d, double q) {
+    if (R.n == 0) return;
+    for (;;) {
+        rl_sort(R);
+        bool changed = false;
+        for (uint32_t i = 0; i + 1 < R.n; ++i) {
+            if (R.last[i] < (R.key[i + 1] >> 1)) continue;
+            if (R.key[i] & 1) {
+                const uint32_t s = R.key[i] >> 1;
+                const uint32_t e = umin(R.last[i], R.last[i + 1]);
+                // flag j in [s, e) with d[j]*q < max d(j, e]; descending sweep
+                int32_t m = d[e];
+                bool open = false;
+                uint32_t lo = 0, hi = 0;
+                for (uint32_t j = e; j-- > s;) {
+                    const uint32_t v = d[j];
+                    if ((double)v * q < (double)m) {
+                        if (open && j + 1 == lo) {
+                            lo = j;
+                        } else {
+                            if (open) rl_push(R, lo << 1 | 1, hi);
+                            open = true;
+                            lo = hi = j;
+                        }
+                    }
+                    m = max(m, (int32_t)v);
+                }
+                if (open) rl_push(R, lo << 1 | 1, hi);
+                R.key[i] = e << 1 | 1;
+            } else {
+                if (R.last[i] == (R.key[i + 1] >> 1)) continue;
+                const uint32_t s = umax(R.key[i] >> 1, R.key[i + 1] >> 1);
+                const uint32_t e = R.last[i];
+                int32_t m = -1;
+                bool open = false;
+                uint32_t lo = 0, hi = 0;
+                for (uint32_t j = s; j <= e; ++j) {
+                    const uint32_t v = d[j];
+                    if (m >= 0 && (double)v * q < (double)m) {
+                        if (open && j == hi + 1) {
+                            hi = j;
+                        } else {
+                            if (open) rl_push(R, lo << 1, hi);
+                            open = true;
+                            lo = hi = j;
+                        }
+                    }
+                    m = max(m, (int32_t)v);
+                }
+                if (open) rl_push(R, lo << 1, hi);
+                R.last[i] = s;
+            }
+            changed = true;
+            break;
+        }
+        if (!changed || R.overflow) break;
+    }
+    for (uint32_t i = 0; i + 1 < R.n; ++i) {
+        if (!(R.key[i] & 1) || (R.key[i + 1] & 1)) continue;
+        const uint32_t b = R.last[i];
+        const uint32_t e = R.key[i + 1] >> 1;
+        if ((uint32_t)(e - b) > kSlopeWindow) continue;
+        uint32_t m = 0;
+        for (uint32_t j = b + 1; j < e; ++j) m = umax(m, d[j]);
+        const uint32_t u_first = R.key[i] >> 1;
+        uint32_t last_ok = u_first;
+        for (uint32_t j = u_first; j <= b; ++j) {
+            if ((double)m > (double)d[j] * q) last_ok = j;
+        }
+        uint32_t first_ok = R.last[i + 1];
+        for (uint32_t j = e; j <= R.last[i + 1]; ++j) {
+            if ((double)m > (double)d[j] * q) { first_ok = j; break; }
+        }
+        R.last[i] = last_ok;
+        R.key[i + 1] = first_ok << 1;
+    }
+}
+
+struct PadView {
+    const uint16_t* p;   // already offset by kPadL
+    __device__ uint32_t operator[](uint32_t j) const { return p[j]; }
+};
+
+
+}  // namespace
+}  // namespace rala_hip

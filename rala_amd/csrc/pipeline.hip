@@ -305,6 +305,173 @@ void preprocess_chimeras(rala_hip_ctx* ctx) {
     compact(ctx->overlaps, true);
 }
 
+// position-space sensitive-pass kernel over `reads`, grouped by LDS image size
+int run_repeats_kernel(rala_hip_ctx* ctx, RepeatArgs a, const std::vector<uint32_t>& reads, int mode) {
+    if (reads.empty()) return RALA_HIP_OK;
+    std::vector<uint32_t> order;
+    build_classes(ctx, reads, order);
+    HIPCHECK(hipMemcpyAsync(ctx->d_order.p, order.data(), order.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    for (const LaunchClass& c : ctx->classes) {
+        uint32_t grid = c.count;
+        if (!c.in_lds) {
+            grid = std::min<uint32_t>(c.count, 512);
+            HIPCHECK(ctx->d_slab.ensure((size_t)grid * 3 * c.lw));
+        }
+        a.order = ctx->d_order.p + c.first;
+        a.n_items = c.count;
+        a.lw = c.lw;
+        a.slab = ctx->d_slab.p;
+        launch_pile_repeats(a, grid, c.in_lds, mode, ctx->stream);
+    }
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    HIPCHECK(hipGetLastError());
+    return RALA_HIP_OK;
+}
+
+// Pile::check_repetitive_hills (pile.cpp:568-592) on host arrays; x, y = b side of the overlap
+void check_repetitive_hills(rala_hip_ctx* ctx, uint32_t r, uint32_t x, uint32_t y) {
+    const uint32_t B = ctx->h_begin[r], E = ctx->h_end[r];
+    Interval* h = ctx->h_rep_pool.data() + ctx->h_rep_slot[r];
+    for (uint32_t i = 0; i < ctx->h_n_rep[r]; ++i) {
+        if (!(x < h[i].second && h[i].first < y)) continue;
+        if ((double)h[i].first < 0.1 * (double)(E - B) + (double)B && (uint32_t)(x - B) < (uint32_t)(E - y)) {
+            if (y >= h[i].second + kHillFuzz) h[i].aux = 1;
+        } else if ((double)h[i].second > 0.9 * (double)(E - B) + (double)B && (uint32_t)(x - B) > (uint32_t)(E - y)) {
+            if (x + kHillFuzz <= h[i].first) h[i].aux = 1;
+        }
+    }
+}
+
+// Pile::is_valid_overlap (pile.cpp:605-630)
+bool is_valid_overlap(rala_hip_ctx* ctx, uint32_t r, uint32_t x, uint32_t y) {
+    const uint32_t B = ctx->h_begin[r], E = ctx->h_end[r];
+    const Interval* h = ctx->h_rep_pool.data() + (ctx->h_n_rep[r] ? ctx->h_rep_slot[r] : 0);
+    for (uint32_t i = 0; i < ctx->h_n_rep[r]; ++i) {
+        if (!(x < h[i].second && h[i].first < y)) continue;
+        if ((double)h[i].first < 0.1 * (double)(E - B) + (double)B) {
+            if (y < h[i].second + kHillFuzz && h[i].aux) return false;
+        } else if ((double)h[i].second > 0.9 * (double)(E - B) + (double)B) {
+            if (x + kHillFuzz > h[i].first && h[i].aux) return false;
+        }
+    }
+    return true;
+}
+
+// Graph::preprocess(overlaps, sensitive path) (graph.cpp:882-1054).  Sensitive records:
+// a = query (original read, untrimmed coordinates), b = target (trimmed read of the -p run).
+int preprocess_repeats(rala_hip_ctx* ctx, const rala_hip_overlaps* sens, uint64_t n_sens) {
+    const uint64_t n = ctx->n_reads;
+    hipStream_t s = ctx->stream;
+    // Overlap::transmute_ (overlap.cpp:84-114): target coordinates shifted by the pile's begin
+    std::vector<HostOvl> sov(n_sens);
+    std::vector<uint32_t> cnt(n + 1, 0);
+    for (uint64_t i = 0; i < n_sens; ++i) {
+        const uint32_t a = sens->a_id[i], b = sens->b_id[i];
+        if (a >= n || b >= n) return fail(ctx, RALA_HIP_EINVAL, "sensitive overlap names must resolve");
+        if (!ctx->h_alive[b]) return fail(ctx, RALA_HIP_EINVAL, "sensitive overlap targets a read that did not survive");
+        HostOvl& o = sov[i];
+        o.src = (uint32_t)i; o.a = a; o.b = b; o.strand = sens->strand[i] ? 1 : 0; o.dead = 0;
+        o.c.a_begin = sens->a_begin[i]; o.c.a_end = sens->a_end[i];
+        o.c.b_begin = sens->b_begin[i] + ctx->h_begin[b];
+        o.c.b_end = sens->b_end[i] + ctx->h_begin[b];
+        o.c.length = sens->length[i];
+        cnt[b + 1] += 2;
+    }
+    // bounds of the targets, no +-15 (graph.cpp:929-933), bucketed by read
+    std::vector<uint32_t> targets;
+    for (uint64_t r = 0; r < n; ++r) {
+        if (cnt[r + 1]) targets.push_back((uint32_t)r);
+        cnt[r + 1] += cnt[r];
+    }
+    std::vector<uint32_t> ev(2 * n_sens + 1), cur(cnt.begin(), cnt.end() - 1);
+    for (const HostOvl& o : sov) {
+        ev[cur[o.b]++] = o.c.b_begin << 1;
+        ev[cur[o.b]++] = (o.c.b_end << 1) | 1u;
+    }
+    HIPCHECK(ctx->d_ev.ensure(2 * n_sens + 8));
+    HIPCHECK(hipMemcpyAsync(ctx->d_ev_off.p, cnt.data(), (n + 1) * 4, hipMemcpyHostToDevice, s));
+    HIPCHECK(hipMemcpyAsync(ctx->d_ev.p, ev.data(), 2 * n_sens * 4, hipMemcpyHostToDevice, s));
+    // current valid regions on the device (the host tail narrowed them)
+    HIPCHECK(hipMemcpyAsync(ctx->d_begin.p, ctx->h_begin.data(), n * 4, hipMemcpyHostToDevice, s));
+    HIPCHECK(hipMemcpyAsync(ctx->d_end.p, ctx->h_end.data(), n * 4, hipMemcpyHostToDevice, s));
+    HIPCHECK(ctx->d_dataset_median.ensure(n));
+    HIPCHECK(ctx->d_n_rep.ensure(n));
+    HIPCHECK(ctx->d_rep_slot.ensure(n));
+    HIPCHECK(ctx->d_rep_pool.ensure(ctx->pool_cap));
+    HIPCHECK(hipMemsetAsync(ctx->d_n_rep.p, 0, n, s));
+    HIPCHECK(hipMemsetAsync(ctx->d_small.p + 6, 0, 8, s));          // [6] rep pool count [7] error
+    HIPCHECK(hipStreamSynchronize(s));
+
+    RepeatArgs a;
+    a.read_len = ctx->d_read_len.p; a.pile_off = ctx->d_pile_off.p; a.pile = ctx->d_pile.p;
+    a.ev_off = ctx->d_ev_off.p; a.ev = ctx->d_ev.p;
+    a.begin = ctx->d_begin.p; a.end = ctx->d_end.p; a.median = ctx->d_median.p; a.p10 = ctx->d_p10.p;
+    a.dataset_median = ctx->d_dataset_median.p; a.n_rep = ctx->d_n_rep.p; a.rep_slot = ctx->d_rep_slot.p;
+    a.pool = ctx->d_rep_pool.p; a.pool_count = ctx->d_small.p + 6; a.pool_cap = ctx->pool_cap;
+    a.error = ctx->d_small.p + 7;
+    a.order = nullptr; a.n_items = 0; a.lw = 0; a.slab = nullptr;
+    // add_layers on top of the coverage + find_median for the targets (graph.cpp:941-969)
+    int rc = run_repeats_kernel(ctx, a, targets, 1);
+    if (rc != RALA_HIP_OK) return rc;
+    HIPCHECK(hipMemcpy(ctx->h_median.data(), ctx->d_median.p, n * 2, hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(ctx->h_p10.data(), ctx->d_p10.p, n * 2, hipMemcpyDeviceToHost));
+    // first trim of the sensitive overlaps (graph.cpp:935-939)
+    {
+        size_t w = 0;
+        for (size_t k = 0; k < sov.size(); ++k) {
+            if (!host_trim(ctx, sov[k])) continue;
+            if (w != k) sov[w] = sov[k];
+            ++w;
+        }
+        sov.resize(w);
+    }
+    // component medians over the primary overlaps -> repeat hills (graph.cpp:971-1026)
+    std::vector<uint32_t> members;
+    std::vector<uint16_t> med;
+    component_medians(ctx, members, med);
+    {
+        std::vector<uint16_t> dm(n, 0);
+        for (size_t k = 0; k < members.size(); ++k) dm[members[k]] = med[k];
+        HIPCHECK(hipMemcpy(ctx->d_dataset_median.p, dm.data(), n * 2, hipMemcpyHostToDevice));
+    }
+    rc = run_repeats_kernel(ctx, a, members, 2);
+    if (rc != RALA_HIP_OK) return rc;
+    uint32_t small[8];
+    HIPCHECK(hipMemcpy(small, ctx->d_small.p, sizeof(small), hipMemcpyDeviceToHost));
+    if (small[7] & kErrRegionCapacity) return fail(ctx, RALA_HIP_ECAPACITY, "slope-region list overflow (repeat hills)");
+    if (small[7] & kErrPoolCapacity) return fail(ctx, RALA_HIP_ECAPACITY, "repeat-hill pool exhausted");
+    ctx->h_n_rep.resize(n); ctx->h_rep_slot.resize(n);
+    HIPCHECK(hipMemcpy(ctx->h_n_rep.data(), ctx->d_n_rep.p, n, hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(ctx->h_rep_slot.data(), ctx->d_rep_slot.p, n * 4, hipMemcpyDeviceToHost));
+    ctx->h_rep_pool.resize(small[6]);
+    if (small[6]) {
+        HIPCHECK(hipMemcpy(ctx->h_rep_pool.data(), ctx->d_rep_pool.p, (size_t)small[6] * sizeof(Interval),
+                           hipMemcpyDeviceToHost));
+    }
+    // sensitive dovetails mark the hills they bridge (graph.cpp:1028-1043)
+    for (HostOvl& o : sov) {
+        if (!host_trim(ctx, o)) continue;
+        const uint32_t t = host_type(ctx, o);
+        if ((t == kTypeAB || t == kTypeBA) && ctx->h_n_rep[o.b]) check_repetitive_hills(ctx, o.b, o.c.b_begin, o.c.b_end);
+    }
+    // overlaps that end inside a bridged edge hill are dropped (graph.cpp:1045-1051)
+    {
+        size_t w = 0;
+        for (size_t k = 0; k < ctx->overlaps.size(); ++k) {
+            const HostOvl& o = ctx->overlaps[k];
+            if (!is_valid_overlap(ctx, o.a, o.c.a_begin, o.c.a_end) ||
+                !is_valid_overlap(ctx, o.b, o.c.b_begin, o.c.b_end)) {
+                continue;
+            }
+            if (w != k) ctx->overlaps[w] = ctx->overlaps[k];
+            ++w;
+        }
+        ctx->overlaps.resize(w);
+    }
+    ctx->have_repeats = true;
+    return RALA_HIP_OK;
+}
+
 // nodes for the surviving reads, two edges per dovetail overlap (graph.cpp:553-632)
 void build_graph(rala_hip_ctx* ctx) {
     const uint64_t n = ctx->n_reads;
@@ -698,7 +865,10 @@ int rala_hip_construct(rala_hip_ctx* ctx, const rala_hip_overlaps* sens, uint64_
     if (!ctx->initialized) return fail(ctx, RALA_HIP_EINVAL, "rala_hip_initialize must succeed first");
     if (ctx->tuple_mode) return fail(ctx, RALA_HIP_EINVAL, "construct needs the overlaps (tuple-fed context)");
     if (ctx->constructed) return fail(ctx, RALA_HIP_EINVAL, "object already constructed");
-    if (sens != nullptr && n_sens != 0) return fail(ctx, RALA_HIP_EINVAL, "sensitive overlaps: not available yet");
+    if (sens != nullptr && n_sens != 0 && !ctx->piles_resident) {
+        return fail(ctx, RALA_HIP_EINVAL, "the sensitive pass needs the piles on this context");
+    }
+    ctx->have_repeats = false;
     HIPCHECK(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     const uint32_t n_reads = (uint32_t)ctx->n_reads;
@@ -780,6 +950,10 @@ int rala_hip_construct(rala_hip_ctx* ctx, const rala_hip_overlaps* sens, uint64_
     // ---- sequential tail on the survivors ----
     const double t0 = now_ms();
     preprocess_chimeras(ctx);
+    if (sens != nullptr && n_sens != 0) {
+        const int rc3 = preprocess_repeats(ctx, sens, n_sens);
+        if (rc3 != RALA_HIP_OK) return rc3;
+    }
     build_graph(ctx);
     ctx->tm.tail_host_ms = (float)(now_ms() - t0);
 
@@ -859,7 +1033,21 @@ int rala_hip_get_intervals(rala_hip_ctx* ctx, int kind, uint64_t* offsets, uint3
     uint64_t off = 0;
     for (uint64_t r = 0; r < n; ++r) {
         offsets[r] = off;
-        if (!ctx->h_alive[r] || kind == 2) continue;
+        if (!ctx->h_alive[r]) continue;
+        if (kind == 2) {
+            if (!ctx->have_repeats || ctx->h_n_rep[r] == 0) continue;
+            const Interval* iv = ctx->h_rep_pool.data() + ctx->h_rep_slot[r];
+            const uint32_t c2 = ctx->h_n_rep[r];
+            if (pairs) {
+                for (uint32_t k = 0; k < c2; ++k) {
+                    pairs[2 * (off + k)] = iv[k].first;
+                    pairs[2 * (off + k) + 1] = iv[k].second;
+                    if (aux) aux[off + k] = iv[k].aux;
+                }
+            }
+            off += c2;
+            continue;
+        }
         const uint32_t cnt = kind == 0 ? ctx->h_n_pits[r] : ctx->h_n_hills[r];
         if (cnt == 0) continue;
         // hills follow the pits found by the pile kernel; the tail only ever drops pits

@@ -82,3 +82,29 @@ def test_tr_mark_standalone(hip_ctx_factory):
         want_pairs = o.remove_transitive_edges()
         gc.same("marks", marks, o.edges()["marked"])
         assert pairs == want_pairs
+
+
+@pytest.mark.parametrize("name", [s for s in gc.SETS if "s_n" in gc.load(s).files])
+def test_hip_sensitive_pass_reproduces_golden(hip_ctx_factory, name):
+    """rala -s: add_layers on top, re-median, repeat hills, bridged flags, overlap filter."""
+    g = gc.load(name)
+    ds = gc.dataset_for(g)
+    sens = ds.sensitive(g["p2f_alive"], g["p2f_begin"], g["p2f_end"])
+    assert len(sens) == int(g["s_n"])
+    ctx = hip_ctx_factory()
+    ctx.set_reads(ds.read_len)
+    ctx.set_overlaps(ds.overlaps)
+    ctx.initialize()
+    ctx.construct(sens)
+    offs, pairs, flags = ctx.intervals(2)
+    gc.same("s_rep_off", offs, g["s_rep_off"])
+    gc.same("s_rep", pairs, g["s_rep"])
+    gc.same("s_rep_flags", flags.astype(np.uint8), g["s_rep_flags"])
+    p = ctx.piles()
+    gc.same("s_median", p["median"], g["s_median"])
+    gc.same("s_p10", p["p10"], g["s_p10"])
+    gc.same("s_ov_src", ctx.overlap_list(0)["src"], g["s_ov_src"].astype(np.uint32))
+    assert ctx.remove_transitive_edges() == int(g["s_n_tr"])
+    gr = ctx.graph()
+    for k in ("src", "dst", "len", "marked"):
+        gc.same("s_edge_" + k, gr[k], g["s_edge_" + k])

@@ -32,3 +32,50 @@ def test_full_path_small(hip_ctx_factory, n, g, seed, run_kernel):
     print(tm)
     if run_kernel and (n, g) == (1500, 12_000):
         assert tm["pile_position_reads"] > 0 and tm["pile_overflow_reads"] >= tm["pile_position_reads"]
+
+
+@pytest.mark.parametrize("n,g,seed", [(5000, 1_000_000, 7), (6000, 1_600_000, 19)])
+def test_sensitive_pass_vs_oracle(hip_ctx_factory, n, g, seed):
+    """Graph::preprocess(overlaps, sensitive path) (reference graph.cpp:882-1054)."""
+    from oracle.oracle import Oracle
+
+    ds = Dataset(n, g, seed)
+    o = Oracle(ds.read_len, ds.overlaps, n_threads=8)
+    assert o.initialize() == 0
+    o.pass2()
+    o.preprocess_chimeras()
+    p = o.piles()
+    sens = ds.sensitive(p["alive"], p["begin"], p["end"])
+    o.preprocess_repeats(sens)
+    want_rep = o.all_intervals(2)
+    want_flags = [o.repeat_flags(r) for r in range(n)]
+    want_flags = np.concatenate(want_flags) if want_flags else np.zeros(0, np.uint8)
+    want_ov = o.overlap_list(0)
+    want_p = o.piles()
+    o.build_graph()
+    want_tr = o.remove_transitive_edges()
+    want_e = o.edges()
+
+    ctx = hip_ctx_factory()
+    ctx.set_reads(ds.read_len)
+    ctx.set_overlaps(ds.overlaps)
+    ctx.initialize()
+    ctx.construct(sens)
+    offs, pairs, flags = ctx.intervals(2)
+    parity.assert_same("rep.offsets", offs, want_rep[0])
+    parity.assert_same("rep.pairs", pairs, want_rep[1])
+    parity.assert_same("rep.flags", flags.astype(np.uint8), want_flags)
+    assert len(pairs) > 0, "the data set should exercise repeat hills"
+    hp = ctx.piles()
+    for k in ("alive", "begin", "end", "median", "p10"):
+        parity.assert_same("piles." + k, hp[k], want_p[k])
+    h = ctx.overlap_list(0)
+    parity.assert_same("ov.src", h["src"], want_ov["src"].astype(np.uint32))
+    assert ctx.remove_transitive_edges() == want_tr
+    gr = ctx.graph()
+    for k in ("src", "dst", "len", "marked"):
+        parity.assert_same("edges." + k, gr[k], want_e[k])
+    # coverage of a few targets after the second add_layers
+    tg = np.unique(sens.b_id)[:16]
+    for r in tg:
+        parity.assert_same("pile_data[%d]" % r, ctx.pile_data(int(r)), o.pile_data(int(r)))
