@@ -1,0 +1,446 @@
+#include "graph.hpp"
+
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <algorithm>
+#include <chrono>
+#include <fstream>
+#include <set>
+
+#include "io.hpp"
+#include "overlap.hpp"
+#include "pile.hpp"
+#include "rala_hip.h"
+#include "sequence.hpp"
+
+namespace rala {
+
+namespace {
+
+struct StageTimer {      // same stage lines as the reference's logger (graph.cpp:246,266,384,...)
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    void operator()() { t0 = std::chrono::steady_clock::now(); }
+    void operator()(const char* msg) {
+        const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        fprintf(stderr, "%s %.6lf s\n", msg, s);
+    }
+};
+
+void check(rala_hip_ctx* ctx, int rc, const char* where) {
+    if (rc == RALA_HIP_OK) return;
+    fprintf(stderr, "[rala::Graph::%s] error: %s!\n", where, rala_hip_last_error(ctx));
+    exit(1);
+}
+
+}  // namespace
+
+std::unique_ptr<Graph> createGraph(const std::string& sequences_path, const std::string& overlaps_path,
+    uint32_t num_threads) {
+    using io::has_suffix;
+    if (!(has_suffix(sequences_path, ".fasta") || has_suffix(sequences_path, ".fa") ||
+          has_suffix(sequences_path, ".fasta.gz") || has_suffix(sequences_path, ".fa.gz") ||
+          has_suffix(sequences_path, ".fastq") || has_suffix(sequences_path, ".fq") ||
+          has_suffix(sequences_path, ".fastq.gz") || has_suffix(sequences_path, ".fq.gz"))) {
+        fprintf(stderr, "[rala::createGraph] error: "
+            "file %s has unsupported format extension (valid extensions: "
+            ".fasta, .fasta.gz, .fa, .fa.gz, .fastq, .fastq.gz, .fq, .fq.gz)!\n", sequences_path.c_str());
+        exit(1);
+    }
+    if (!(has_suffix(overlaps_path, ".mhap") || has_suffix(overlaps_path, ".mhap.gz") ||
+          has_suffix(overlaps_path, ".paf") || has_suffix(overlaps_path, ".paf.gz"))) {
+        fprintf(stderr, "[rala::createGraph] error: "
+            "file %s has unsupported format extension (valid extensions: "
+            ".mhap, .mhap.gz, .paf, .paf.gz)!\n", overlaps_path.c_str());
+        exit(1);
+    }
+    return std::unique_ptr<Graph>(new Graph(sequences_path, overlaps_path, num_threads));
+}
+
+Graph::Graph(const std::string& sequences_path, const std::string& overlaps_path, uint32_t num_threads)
+        : sequences_path_(sequences_path), overlaps_path_(overlaps_path), num_threads_(num_threads), ctx_(nullptr) {
+    if (rala_hip_create(0, &ctx_) != RALA_HIP_OK) {
+        fprintf(stderr, "[rala::Graph::Graph] error: no usable HIP device!\n");
+        exit(1);
+    }
+}
+
+Graph::~Graph() {
+    piles_.clear();
+    if (ctx_) rala_hip_destroy(ctx_);
+}
+
+namespace {
+
+bool read_sequences(const std::string& path, const io::SequenceSink& sink) {
+    if (io::has_suffix(path, ".fastq") || io::has_suffix(path, ".fq") || io::has_suffix(path, ".fastq.gz") ||
+        io::has_suffix(path, ".fq.gz")) {
+        return io::read_fastq(path, sink);
+    }
+    return io::read_fasta(path, sink);
+}
+
+struct Columns {
+    std::vector<uint32_t>&a_id, &b_id, &a_begin, &a_end, &b_begin, &b_end, &length;
+    std::vector<uint8_t>& strand;
+};
+
+// one pass over an overlap file into binary columns (the reference parses twice, graph.cpp:328,443)
+void read_overlaps(const std::string& path, const std::unordered_map<std::string, uint64_t>& name_to_id,
+    const std::vector<uint32_t>& read_len, bool check_target_length, Columns c) {
+    auto push = [&](uint32_t a, uint32_t b, uint32_t ab, uint32_t ae, uint32_t bb, uint32_t be, uint32_t len,
+                    uint32_t strand) {
+        c.a_id.push_back(a); c.b_id.push_back(b);
+        c.a_begin.push_back(ab); c.a_end.push_back(ae);
+        c.b_begin.push_back(bb); c.b_end.push_back(be);
+        c.length.push_back(len); c.strand.push_back((uint8_t)strand);
+    };
+    auto length_error = [](uint64_t id) {
+        fprintf(stderr, "[rala::Overlap::transmute] error: "
+            "unequal lengths in sequence and overlap file for sequence with id %lu!\n", id);
+        exit(1);
+    };
+    bool ok;
+    if (io::has_suffix(path, ".mhap") || io::has_suffix(path, ".mhap.gz")) {
+        ok = io::read_mhap(path, [&](const io::MhapRecord& r) {
+            const uint64_t a = r.a_id - 1, b = r.b_id - 1;
+            const uint32_t ia = a < read_len.size() ? (uint32_t)a : RALA_HIP_NO_READ;
+            const uint32_t ib = b < read_len.size() ? (uint32_t)b : RALA_HIP_NO_READ;
+            if (ia != RALA_HIP_NO_READ && r.a_length != read_len[ia]) length_error(a);
+            if (check_target_length && ib != RALA_HIP_NO_READ && ia != RALA_HIP_NO_READ && r.b_length != read_len[ib]) {
+                length_error(b);
+            }
+            push(ia, ib, r.a_begin, r.a_end, r.b_begin, r.b_end, std::max(r.a_end - r.a_begin, r.b_end - r.b_begin),
+                 r.a_rc == r.b_rc ? 0 : 1);
+        });
+    } else {
+        ok = io::read_paf(path, [&](const io::PafRecord& r) {
+            auto a = name_to_id.find(r.q_name), b = name_to_id.find(r.t_name);
+            const uint32_t ia = a == name_to_id.end() ? RALA_HIP_NO_READ : (uint32_t)a->second;
+            const uint32_t ib = b == name_to_id.end() ? RALA_HIP_NO_READ : (uint32_t)b->second;
+            // Overlap::transmute checks a first and stops at the first unknown name (overlap.cpp:43-78)
+            if (ia != RALA_HIP_NO_READ && r.q_length != read_len[ia]) length_error(ia);
+            if (check_target_length && ia != RALA_HIP_NO_READ && ib != RALA_HIP_NO_READ && r.t_length != read_len[ib]) {
+                length_error(ib);
+            }
+            push(ia, ib, r.q_begin, r.q_end, r.t_begin, r.t_end, r.overlap_length, r.orientation == '+' ? 0 : 1);
+        });
+    }
+    if (!ok) {
+        fprintf(stderr, "[rala::Graph::initialize] error: unable to open file %s!\n", path.c_str());
+        exit(1);
+    }
+}
+
+}  // namespace
+
+// reference src/graph.cpp:244-425
+void Graph::initialize() {
+    StageTimer timer;
+    if (!read_sequences(sequences_path_, [&](const std::string& name, const std::string& data) {
+            name_to_id_[name] = names_.size();
+            names_.push_back(name);
+            read_len_.push_back((uint32_t)data.size());
+        })) {
+        fprintf(stderr, "[rala::Graph::initialize] error: unable to open file %s!\n", sequences_path_.c_str());
+        exit(1);
+    }
+    timer("[rala::Graph::initialize] loaded sequences");
+    timer();
+    check(ctx_, rala_hip_set_reads(ctx_, read_len_.data(), read_len_.size()), "initialize");
+    Columns c = {a_id_, b_id_, a_begin_, a_end_, b_begin_, b_end_, length_, strand_};
+    read_overlaps(overlaps_path_, name_to_id_, read_len_, true, c);
+    rala_hip_overlaps soa = {a_id_.data(), b_id_.data(), a_begin_.data(), a_end_.data(), b_begin_.data(),
+                             b_end_.data(), length_.data(), strand_.data()};
+    check(ctx_, rala_hip_set_overlaps(ctx_, &soa, a_id_.size(), RALA_HIP_MEM_HOST), "initialize");
+    timer("[rala::Graph::initialize] loaded overlaps");
+    timer();
+    const int rc = rala_hip_initialize(ctx_);
+    timer("[rala::Graph::initialize] prefiltered sequences");
+    if (rc == RALA_HIP_EFILTERED) {
+        fprintf(stderr, "[rala::Graph::initialize] error: filtered all sequences!\n");
+        exit(1);
+    }
+    check(ctx_, rc, "initialize");
+    uint64_t num_prefiltered_sequences = 0;
+    rala_hip_get_num_prefiltered(ctx_, &num_prefiltered_sequences);
+    fprintf(stderr, "[rala::Graph::initialize] number of prefiltered sequences = %lu\n", num_prefiltered_sequences);
+}
+
+// reference src/graph.cpp:427-640
+void Graph::construct(const std::string& sensitive_overlaps_path) {
+    if (!piles_.empty()) {
+        fprintf(stderr, "[rala::Graph::construct] warning: object already constructed!\n");
+        return;
+    }
+    initialize();
+
+    StageTimer timer;
+    std::vector<uint32_t> s_cols[7];
+    std::vector<uint8_t> s_strand;
+    rala_hip_overlaps sens = {};
+    uint64_t n_sens = 0;
+    if (!sensitive_overlaps_path.empty()) {
+        if (!(io::has_suffix(sensitive_overlaps_path, ".mhap") || io::has_suffix(sensitive_overlaps_path, ".mhap.gz") ||
+              io::has_suffix(sensitive_overlaps_path, ".paf") || io::has_suffix(sensitive_overlaps_path, ".paf.gz"))) {
+            fprintf(stderr, "[rala::preprocess] error: "
+                "file %s has unsupported format extension (valid extensions: "
+                ".mhap, .mhap.gz, .paf, .paf.gz)!\n", sensitive_overlaps_path.c_str());
+            exit(1);
+        }
+        Columns c = {s_cols[0], s_cols[1], s_cols[2], s_cols[3], s_cols[4], s_cols[5], s_cols[6], s_strand};
+        read_overlaps(sensitive_overlaps_path, name_to_id_, read_len_, false, c);
+        sens.a_id = s_cols[0].data(); sens.b_id = s_cols[1].data(); sens.a_begin = s_cols[2].data();
+        sens.a_end = s_cols[3].data(); sens.b_begin = s_cols[4].data(); sens.b_end = s_cols[5].data();
+        sens.length = s_cols[6].data(); sens.strand = s_strand.data();
+        n_sens = s_cols[0].size();
+    }
+    check(ctx_, rala_hip_construct(ctx_, n_sens ? &sens : nullptr, n_sens), "construct");
+    timer("[rala::Graph::construct] loaded overlaps + [rala::Graph::preprocess]");
+    timer();
+
+    // piles_: views of the surviving reads
+    const uint64_t n = read_len_.size();
+    std::vector<uint32_t> begin(n), end(n);
+    std::vector<uint16_t> median(n), p10(n);
+    std::vector<uint8_t> alive(n);
+    rala_hip_get_piles(ctx_, begin.data(), end.data(), median.data(), p10.data(), alive.data());
+    std::vector<uint64_t> off[3];
+    std::vector<uint32_t> pairs[3], aux[3];
+    for (int kind = 0; kind < 3; ++kind) {
+        off[kind].resize(n + 1);
+        rala_hip_get_intervals(ctx_, kind, off[kind].data(), nullptr, nullptr);
+        pairs[kind].resize(2 * off[kind][n] + 2);
+        aux[kind].resize(off[kind][n] + 1);
+        rala_hip_get_intervals(ctx_, kind, off[kind].data(), pairs[kind].data(), aux[kind].data());
+    }
+    piles_.resize(n);
+    for (uint64_t r = 0; r < n; ++r) {
+        if (!alive[r]) continue;
+        piles_[r] = createPile(r, read_len_[r]);
+        Pile& p = *piles_[r];
+        p.ctx_ = ctx_; p.owns_ctx_ = false; p.ctx_read_ = r; p.computed_ = true;
+        p.begin_ = begin[r]; p.end_ = end[r]; p.median_ = median[r]; p.p10_ = p10[r];
+        for (uint64_t k = off[0][r]; k < off[0][r + 1]; ++k) {
+            p.chimeric_pits_.emplace_back(pairs[0][2 * k], pairs[0][2 * k + 1]);
+            p.chimeric_pit_min_.push_back((uint16_t)aux[0][k]);
+        }
+        for (uint64_t k = off[2][r]; k < off[2][r + 1]; ++k) {
+            p.repeat_hills_.emplace_back(pairs[2][2 * k], pairs[2][2 * k + 1]);
+            p.repeat_hill_coverage_.push_back(aux[2][k] != 0);
+        }
+    }
+
+    // nodes (second pass over the sequences, trimmed) and edges (graph.cpp:527-632)
+    uint64_t n_nodes = 0, n_edges = 0;
+    rala_hip_get_graph_size(ctx_, &n_nodes, &n_edges);
+    std::vector<uint32_t> node_read(n_nodes), src(n_edges), dst(n_edges), len(n_edges);
+    rala_hip_get_graph(ctx_, node_read.data(), src.data(), dst.data(), len.data(), nullptr);
+    std::vector<int64_t> read_to_node(n, -1);
+    for (uint64_t k = 0; k < n_nodes; k += 2) read_to_node[node_read[k]] = (int64_t)k;
+    nodes_.resize(n_nodes);
+    uint64_t seq_id = 0;
+    read_sequences(sequences_path_, [&](const std::string& name, const std::string& data) {
+        const uint64_t i = seq_id++;
+        if (i >= n || read_to_node[i] < 0) return;
+        auto seq = createSequence(name, data);
+        seq->trim(begin[i], end[i]);
+        const uint64_t k = (uint64_t)read_to_node[i];
+        nodes_[k].id = k; nodes_[k].sequence_id = i; nodes_[k].name = name; nodes_[k].data = seq->data();
+        nodes_[k + 1].id = k + 1; nodes_[k + 1].sequence_id = i; nodes_[k + 1].name = name;
+        nodes_[k + 1].data = seq->reverse_complement();
+    });
+    timer("[rala::Graph::construct] loaded sequences");
+    timer();
+    edges_.resize(n_edges);
+    for (uint64_t e = 0; e < n_edges; ++e) {
+        edges_[e].id = e; edges_[e].begin_node = src[e]; edges_[e].end_node = dst[e]; edges_[e].length = len[e];
+        edges_[e].is_marked = false; edges_[e].is_removed = false;
+        nodes_[src[e]].suffix_edges.push_back((uint32_t)e);
+        nodes_[dst[e]].prefix_edges.push_back((uint32_t)e);
+    }
+    timer("[rala::Graph::construct] created assembly graph");
+    fprintf(stderr, "[rala::Graph::construct] number of nodes = %zu\n", nodes_.size());
+    fprintf(stderr, "[rala::Graph::construct] number of edges = %zu\n", edges_.size());
+}
+
+void Graph::not_in_this_build(const char* what) const {
+    fprintf(stderr, "[rala::Graph::%s] note: layout clean-up after transitive reduction is outside this "
+        "build's hot path (SURVEY.md section 8f); graph left unchanged\n", what);
+}
+
+// reference src/graph.cpp:642-697
+void Graph::simplify() {
+    StageTimer timer;
+    const uint32_t num_transitive_edges = remove_transitive_edges();
+    timer("[rala::Graph::simplify]");
+    fprintf(stderr, "[rala::Graph::simplify] number of transitive edges = %u\n", num_transitive_edges);
+    not_in_this_build("simplify");
+}
+
+// reference src/graph.cpp:1281-1335 through rala_hip_tr_mark on the current live edges
+uint32_t Graph::remove_transitive_edges() {
+    // live edges keep their pairing: twins are 2k, 2k + 1 and die together
+    std::vector<uint32_t> ids, src, dst, len;
+    for (uint64_t e = 0; e < edges_.size(); ++e) {
+        if (edges_[e].is_removed) continue;
+        ids.push_back((uint32_t)e);
+        src.push_back(edges_[e].begin_node); dst.push_back(edges_[e].end_node); len.push_back(edges_[e].length);
+    }
+    std::vector<uint8_t> marks(ids.size());
+    uint32_t num_transitive_edges = 0;
+    check(ctx_, rala_hip_tr_mark(ctx_, (uint32_t)nodes_.size(), (uint32_t)ids.size(), src.data(), dst.data(),
+                                 len.data(), marks.data(), &num_transitive_edges), "remove_transitive_edges");
+    for (size_t k = 0; k < ids.size(); ++k) {
+        if (marks[k]) edges_[ids[k]].is_marked = true;
+    }
+    // remove_marked_objects (graph.cpp:2118-2151)
+    for (auto& node : nodes_) {
+        auto drop = [&](std::vector<uint32_t>& v) {
+            v.erase(std::remove_if(v.begin(), v.end(), [&](uint32_t e) { return edges_[e].is_marked; }), v.end());
+        };
+        drop(node.suffix_edges);
+        drop(node.prefix_edges);
+    }
+    for (auto& e : edges_) {
+        if (e.is_marked) { e.is_removed = true; e.is_marked = false; }
+    }
+    return num_transitive_edges;
+}
+
+uint32_t Graph::remove_long_edges() { not_in_this_build("remove_long_edges"); return 0; }
+uint32_t Graph::remove_tips() { not_in_this_build("remove_tips"); return 0; }
+uint32_t Graph::remove_bubbles() { not_in_this_build("remove_bubbles"); return 0; }
+uint32_t Graph::create_unitigs() { not_in_this_build("create_unitigs"); return 0; }
+uint32_t Graph::shrink(uint32_t) { not_in_this_build("shrink"); return 0; }
+
+// reference src/graph.cpp:2042-2082 on the nodes as they stand (no unitigs in this build)
+void Graph::extract_contigs(std::vector<std::unique_ptr<Sequence>>& dst, bool drop_unassembled_sequences) {
+    create_unitigs();
+    uint32_t contig_id = 0;
+    std::vector<uint32_t> contig_length;
+    for (const auto& node : nodes_) {
+        if (node.id & 1) continue;
+        if (drop_unassembled_sequences) continue;      // every node is one read: < 6 reads (graph.cpp:2053)
+        contig_length.push_back((uint32_t)node.data.size());
+        std::string name = "Ctg" + std::to_string(contig_id);
+        name += " RC:i:1";
+        name += " LN:i:" + std::to_string(node.data.size());
+        dst.emplace_back(createSequence(name, node.data));
+        ++contig_id;
+    }
+    fprintf(stderr, "[rala::Graph::extract_contigs] number of contigs = %zu\n", contig_length.size());
+    if (contig_length.empty()) return;
+    std::sort(contig_length.begin(), contig_length.end());
+    fprintf(stderr, "[rala::Graph::extract_contigs] shortest contig length = %u\n", contig_length.front());
+    fprintf(stderr, "[rala::Graph::extract_contigs] median contig length = %u\n",
+        contig_length[contig_length.size() / 2]);
+    fprintf(stderr, "[rala::Graph::extract_contigs] longest contig length = %u\n", contig_length.back());
+}
+
+// reference src/graph.cpp:2084-2116 (the reference iterates an unordered_set; here ascending ids)
+void Graph::extract_nodes(std::vector<std::unique_ptr<Sequence>>& dst) {
+    std::set<uint64_t> node_ids;
+    for (const auto& it : nodes_) {
+        if ((it.id & 1) || (it.suffix_edges.empty() && it.prefix_edges.empty())) continue;
+        node_ids.insert(it.id);
+        for (uint32_t e : it.prefix_edges) node_ids.insert(edges_[e].begin_node & ~1u);
+        for (uint32_t e : it.suffix_edges) node_ids.insert(edges_[e].end_node & ~1u);
+    }
+    for (uint64_t id : node_ids) dst.emplace_back(createSequence(nodes_[id].name, nodes_[id].data));
+    fprintf(stderr, "[rala::Graph::extract_nodes] number of nodes = %zu\n", dst.size());
+}
+
+// reference src/graph.cpp:2153-2179
+void Graph::print_csv(const std::string& path) const {
+    auto graph_file = fopen(path.c_str(), "w");
+    if (!graph_file) return;
+    for (const auto& it : nodes_) {
+        if (!(it.id & 1) || (it.suffix_edges.empty() && it.prefix_edges.empty())) continue;
+        const auto& pair = nodes_[it.id ^ 1];
+        fprintf(graph_file, "%lu LN:i:%u RC:i:%lu,%lu LN:i:%u RC:i:%lu,0,-\n", it.id, (uint32_t)it.data.size(), 1ul,
+            pair.id, (uint32_t)pair.data.size(), 1ul);
+    }
+    for (const auto& it : edges_) {
+        if (it.is_removed) continue;
+        const auto& b = nodes_[it.begin_node];
+        const auto& e = nodes_[it.end_node];
+        fprintf(graph_file, "%lu LN:i:%u RC:i:%lu,%lu LN:i:%u RC:i:%lu,1,%lu %u %lf\n", b.id,
+            (uint32_t)b.data.size(), 1ul, e.id, (uint32_t)e.data.size(), 1ul, it.id, it.length, 0.0);
+    }
+    fclose(graph_file);
+}
+
+// reference src/graph.cpp:2181-2226
+void Graph::print_gfa(const std::string& path) const {
+    auto graph_file = fopen(path.c_str(), "w");
+    if (!graph_file) return;
+    for (const auto& it : nodes_) {
+        if ((it.id & 1) || (it.suffix_edges.empty() && it.prefix_edges.empty())) continue;
+        fprintf(graph_file, "S\t%s\t%s\tLN:i:%zu\tRC:i:%lu\n", it.name.c_str(), it.data.c_str(), it.data.size(), 1ul);
+    }
+    for (const auto& it : edges_) {
+        if (it.is_removed) continue;
+        const auto& b = nodes_[it.begin_node];
+        const auto& e = nodes_[it.end_node];
+        fprintf(graph_file, "L\t%s\t%c\t%s\t%c\t%zuM\n", b.name.c_str(), (b.id & 1) ? '-' : '+', e.name.c_str(),
+            (e.id & 1) ? '-' : '+', b.data.size() - it.length);
+    }
+    fclose(graph_file);
+}
+
+// reference src/graph.cpp:2228-2297
+void Graph::print_json(const std::string& path) const {
+    std::ofstream os(path);
+    os << "{\"nodes\":{";
+    bool is_first = true;
+    std::set<uint64_t> sequence_ids;
+    for (const auto& it : nodes_) {
+        const bool junction = it.suffix_edges.size() > 1 || it.prefix_edges.size() > 1;
+        if ((it.id & 1) || !junction) continue;
+        if (!is_first) os << ",";
+        is_first = false;
+        os << "\"" << it.sequence_id << "\":{\"n\":" << it.id << ",";
+        os << "\"p\":[";
+        sequence_ids.insert(it.sequence_id);
+        for (size_t i = 0; i < it.prefix_edges.size(); ++i) {
+            const auto& other = nodes_[edges_[it.prefix_edges[i]].begin_node];
+            sequence_ids.insert(other.sequence_id);
+            os << "[\"" << other.sequence_id << "\",\"" << other.id << "\"," << (other.id & 1) << ","
+               << other.data.size() - edges_[it.prefix_edges[i]].length << "]";
+            if (i + 1 < it.prefix_edges.size()) os << ",";
+        }
+        os << "],\"s\":[";
+        for (size_t i = 0; i < it.suffix_edges.size(); ++i) {
+            const auto& other = nodes_[edges_[it.suffix_edges[i]].end_node];
+            sequence_ids.insert(other.sequence_id);
+            os << "[\"" << other.sequence_id << "\",\"" << other.id << "\"," << (other.id & 1) << ","
+               << it.data.size() - edges_[it.suffix_edges[i]].length << "]";
+            if (i + 1 < it.suffix_edges.size()) os << ",";
+        }
+        os << "]}";
+    }
+    os << "}";
+    if (sequence_ids.empty()) {
+        os << "}";
+        return;
+    }
+    os << ",\"piles\":{";
+    is_first = true;
+    for (uint64_t id : sequence_ids) {
+        if (piles_[id] == nullptr) continue;
+        if (!is_first) os << ",";
+        is_first = false;
+        os << piles_[id]->to_json();
+    }
+    os << "}}";
+}
+
+void Graph::print_debug(const std::string& prefix) const {
+    if (!prefix.empty()) {
+        print_csv(prefix + ".csv");
+        print_json(prefix + ".json");
+    }
+}
+
+}  // namespace rala

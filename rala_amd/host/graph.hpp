@@ -1,0 +1,97 @@
+/*!
+ * @file graph.hpp
+ *
+ * @brief Graph class (interface of rvaser/rala src/graph.hpp:37-180) on top of librala_hip.
+ *
+ * construct() and remove_transitive_edges() run on the GPU through the C ABI
+ * (include/rala_hip.h).  The layout clean-up after transitive reduction (tips, bubbles,
+ * unitigs, shrink, force-directed layout, long edges; reference src/graph.cpp:1056-1279,
+ * 1337-2040) is outside this build's hot path and reports so when called.
+ */
+
+#pragma once
+
+#include <stdint.h>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+struct rala_hip_ctx;
+
+namespace rala {
+
+class Sequence;
+class Pile;
+class Overlap;
+
+class Graph;
+std::unique_ptr<Graph> createGraph(const std::string& sequences_path, const std::string& overlaps_path,
+    uint32_t num_threads);
+
+class Graph {
+public:
+    ~Graph();
+
+    /*! @brief pile-o-grams, chimera / containment removal, (repeat annotation), graph build */
+    void construct(const std::string& sensitive_overlaps_path);
+    /*! @brief transitive reduction, then the clean-up stages where available */
+    void simplify();
+    uint32_t remove_transitive_edges();
+    uint32_t remove_long_edges();
+    uint32_t remove_tips();
+    uint32_t remove_bubbles();
+    uint32_t create_unitigs();
+    uint32_t shrink(uint32_t epsilon);
+    void extract_contigs(std::vector<std::unique_ptr<Sequence>>& dst, bool drop_unassembled_sequences = true);
+    void extract_nodes(std::vector<std::unique_ptr<Sequence>>& dst);
+    void print_csv(const std::string& path) const;
+    void print_gfa(const std::string& path) const;
+    void print_json(const std::string& path) const;
+    void print_debug(const std::string& prefix) const;
+
+    /*! @brief per-read piles after construct() (nullptr = filtered), as the reference's piles_ */
+    const std::vector<std::unique_ptr<Pile>>& piles() const { return piles_; }
+
+    friend std::unique_ptr<Graph> createGraph(const std::string& sequences_path,
+        const std::string& overlaps_path, uint32_t num_threads);
+
+private:
+    Graph(const std::string& sequences_path, const std::string& overlaps_path, uint32_t num_threads);
+    Graph(const Graph&) = delete;
+    const Graph& operator=(const Graph&) = delete;
+
+    void initialize();
+    void not_in_this_build(const char* what) const;
+
+    struct Node {
+        uint64_t id;
+        uint64_t sequence_id;
+        std::string name;
+        std::string data;
+        std::vector<uint32_t> prefix_edges, suffix_edges;
+    };
+    struct Edge {
+        uint64_t id;
+        uint32_t begin_node, end_node, length;
+        bool is_marked;
+        bool is_removed;
+    };
+
+    std::string sequences_path_, overlaps_path_;
+    uint32_t num_threads_;
+    rala_hip_ctx* ctx_;
+
+    std::unordered_map<std::string, uint64_t> name_to_id_;
+    std::vector<std::string> names_;
+    std::vector<uint32_t> read_len_;
+    std::vector<std::unique_ptr<Pile>> piles_;
+    // overlap columns, parsed once
+    std::vector<uint32_t> a_id_, b_id_, a_begin_, a_end_, b_begin_, b_end_, length_;
+    std::vector<uint8_t> strand_;
+
+    std::vector<Node> nodes_;
+    std::vector<Edge> edges_;
+};
+
+}  // namespace rala
