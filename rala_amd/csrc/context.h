@@ -4,10 +4,12 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <memory>
 #include <string>
 #include <vector>
 
 #include "geom.h"
+#include "host_pool.h"
 #include "kernels.h"
 #include "rala_hip.h"
 
@@ -19,6 +21,7 @@ struct HostOvl {
     Coords c;
     uint8_t strand;
     uint8_t dead;
+    uint8_t type;        // cached Overlap::type, 255 = stale (a pile or the coordinates changed)
 };
 
 struct LaunchClass {
@@ -60,6 +63,8 @@ struct rala_hip_ctx {
     int64_t pool_per_read_x1000 = 1000;
     int64_t max_lds_read_len = 22000;
     int64_t debug_pile_stop_after = 99;
+    int64_t host_threads = 0;                       // 0 = min(hardware threads, 16)
+    std::unique_ptr<rala_hip::HostPool> pool;
     bool use_run_kernel = true;
 
     // reads
@@ -130,6 +135,9 @@ struct rala_hip_ctx {
     bool have_repeats = false;
 
     // host tail
+    std::vector<uint8_t> dirty, ever_dirty;       // reads whose valid region changed (this round / ever)
+    std::vector<uint32_t> dirty_list;
+    rala_hip::DevBuf<uint32_t> d_cc_edges, d_cc_label;
     std::vector<rala_hip::HostOvl> overlaps, internals;
     std::vector<uint32_t> node_read;
     std::vector<uint32_t> e_src, e_dst, e_len;

@@ -150,6 +150,10 @@ void launch_exclusive_scan(const uint32_t* in, uint32_t* out, uint64_t n, void* 
 void launch_tr_mark(const uint32_t* row_ptr, const uint32_t* adj_edge, const uint32_t* edge_src,
                     const uint32_t* edge_dst, const uint32_t* edge_len, uint32_t n_nodes, uint32_t n_edges,
                     uint8_t* marks, hipStream_t s);
+// connected components by min-label hooking + pointer jumping (edges = pairs a, b)
+void launch_cc_init(uint32_t* label, uint32_t n, hipStream_t s);
+void launch_cc_hook(const uint32_t* edges, uint32_t n_edges, uint32_t* label, uint32_t* changed, hipStream_t s);
+void launch_cc_compress(uint32_t* label, uint32_t n, hipStream_t s);
 void launch_tr_count(const uint8_t* marks, uint32_t n_edges, uint32_t* n_pairs, hipStream_t s);
 
 }  // namespace rala_hip

@@ -7,6 +7,8 @@
 // that survive containment removal (connected components, component medians,
 // iterate-until-stable), node/edge numbering, CSR assembly.
 #include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -140,20 +142,46 @@ uint32_t host_type(rala_hip_ctx* ctx, const HostOvl& o) {
     return ovl_type(o.c, o.strand, ctx->h_begin[o.a], ctx->h_end[o.a], ctx->h_begin[o.b], ctx->h_end[o.b]);
 }
 
+// Overlap::trim is idempotent while both valid regions stand still, so only overlaps that
+// touch a read whose region changed since the last pass ("dirty") are recomputed.  Dropped
+// items stay in place with dead = 1 (lists are compacted once, at the end); the pass is
+// data parallel over the host pool.  Returns the number of items dropped.
 uint64_t retrim(rala_hip_ctx* ctx, std::vector<HostOvl>& v) {
-    size_t w = 0;
-    for (size_t k = 0; k < v.size(); ++k) {
-        if (!host_trim(ctx, v[k])) continue;
-        if (w != k) v[w] = v[k];
-        ++w;
-    }
-    const uint64_t dropped = v.size() - w;
-    v.resize(w);
-    return dropped;
+    const uint8_t* dirty = ctx->dirty.data();
+    std::vector<uint64_t> dropped(ctx->pool->size(), 0);
+    ctx->pool->chunks(v.size(), [&](unsigned t, size_t b, size_t e) {
+        uint64_t d = 0;
+        for (size_t k = b; k < e; ++k) {
+            HostOvl& o = v[k];
+            if (o.dead || !(dirty[o.a] | dirty[o.b])) continue;
+            if (!host_trim(ctx, o)) { o.dead = 1; ++d; }
+            else o.type = 255;
+        }
+        dropped[t] = d;
+    });
+    uint64_t total = 0;
+    for (uint64_t d : dropped) total += d;
+    return total;
+}
+
+uint32_t cached_type(rala_hip_ctx* ctx, HostOvl& o) {
+    if (o.type == 255) o.type = (uint8_t)host_type(ctx, o);
+    return o.type;
+}
+
+void mark_dirty(rala_hip_ctx* ctx, uint32_t r) {
+    if (!ctx->dirty[r]) { ctx->dirty[r] = 1; ctx->dirty_list.push_back(r); }
+    ctx->ever_dirty[r] = 1;
+}
+
+void clear_dirty(rala_hip_ctx* ctx) {
+    for (uint32_t r : ctx->dirty_list) ctx->dirty[r] = 0;
+    ctx->dirty_list.clear();
 }
 
 bool host_shrink(rala_hip_ctx* ctx, uint32_t r, uint32_t b, uint32_t e) {
-    if (b > e || e - b < kMinRegion) return false;
+    if (b > e || e - b < kMinRegion) { mark_dirty(ctx, r); return false; }
+    if (ctx->h_begin[r] != b || ctx->h_end[r] != e) mark_dirty(ctx, r);
     ctx->h_begin[r] = b;
     ctx->h_end[r] = e;
     return true;
@@ -195,56 +223,84 @@ bool break_pits(rala_hip_ctx* ctx, uint32_t r, Interval* pits, uint8_t& n_pits, 
     return host_shrink(ctx, r, b, e);
 }
 
-struct UnionFind {
-    std::vector<uint32_t> p;
-    explicit UnionFind(size_t n) : p(n) { std::iota(p.begin(), p.end(), 0u); }
-    uint32_t find(uint32_t x) {
-        while (p[x] != x) { p[x] = p[p[x]]; x = p[x]; }
-        return x;
+// per read: the median of the pile medians of its connected component over the current
+// overlaps (graph.cpp:740-783); components by min-label hooking on the GPU (cc_kernels).
+int component_medians(rala_hip_ctx* ctx, std::vector<uint32_t>& members, std::vector<uint16_t>& med_of_member) {
+    const uint64_t n = ctx->n_reads;
+    const size_t m = ctx->overlaps.size();
+    members.clear();
+    med_of_member.clear();
+    if (m == 0) return RALA_HIP_OK;
+    hipStream_t s = ctx->stream;
+    std::vector<uint32_t> edges(2 * m);
+    std::vector<uint8_t> touched(n, 0);
+    ctx->pool->chunks(m, [&](unsigned, size_t b, size_t e) {
+        for (size_t k = b; k < e; ++k) {
+            const HostOvl& o = ctx->overlaps[k];
+            if (o.dead) { edges[2 * k] = 0; edges[2 * k + 1] = 0; continue; }      // harmless self loop
+            edges[2 * k] = o.a; edges[2 * k + 1] = o.b;
+            touched[o.a] = 1; touched[o.b] = 1;
+        }
+    });
+    HIPCHECK(ctx->d_cc_edges.ensure(2 * m));
+    HIPCHECK(ctx->d_cc_label.ensure(n));
+    HIPCHECK(hipMemcpyAsync(ctx->d_cc_edges.p, edges.data(), 2 * m * 4, hipMemcpyHostToDevice, s));
+    launch_cc_init(ctx->d_cc_label.p, (uint32_t)n, s);
+    for (int round = 0;; ++round) {
+        HIPCHECK(hipMemsetAsync(ctx->d_small.p + 2, 0, 4, s));
+        launch_cc_hook(ctx->d_cc_edges.p, (uint32_t)m, ctx->d_cc_label.p, ctx->d_small.p + 2, s);
+        launch_cc_compress(ctx->d_cc_label.p, (uint32_t)n, s);
+        uint32_t changed = 0;
+        HIPCHECK(hipMemcpyAsync(&changed, ctx->d_small.p + 2, 4, hipMemcpyDeviceToHost, s));
+        HIPCHECK(hipStreamSynchronize(s));
+        if (!changed) break;
+        if (round > 10000) return fail(ctx, RALA_HIP_EDEVICE, "connected components did not converge");
     }
-    void unite(uint32_t a, uint32_t b) {
-        a = find(a); b = find(b);
-        if (a != b) p[std::max(a, b)] = std::min(a, b);
+    std::vector<uint32_t> label(n);
+    HIPCHECK(hipMemcpy(label.data(), ctx->d_cc_label.p, n * 4, hipMemcpyDeviceToHost));
+    // members = reads with at least one overlap; group them by label (counting sort)
+    for (uint64_t r = 0; r < n; ++r) if (touched[r]) members.push_back((uint32_t)r);
+    std::vector<uint32_t> cnt(n + 1, 0);
+    for (uint32_t r : members) ++cnt[label[r] + 1];
+    for (uint64_t r = 0; r < n; ++r) cnt[r + 1] += cnt[r];
+    std::vector<uint32_t> idx(members.size());
+    {
+        std::vector<uint32_t> cur(cnt.begin(), cnt.end() - 1);
+        for (size_t k = 0; k < members.size(); ++k) idx[cur[label[members[k]]]++] = (uint32_t)k;
+    }
+    med_of_member.assign(members.size(), 0);
+    std::vector<uint16_t> mm;
+    for (size_t b0 = 0; b0 < idx.size();) {
+        const uint32_t lab = label[members[idx[b0]]];
+        size_t t = b0;
+        mm.clear();
+        while (t < idx.size() && label[members[idx[t]]] == lab) { mm.push_back(ctx->h_median[members[idx[t]]]); ++t; }
+        std::nth_element(mm.begin(), mm.begin() + mm.size() / 2, mm.end());
+        const uint16_t med = mm[mm.size() / 2];
+        for (size_t k = b0; k < t; ++k) med_of_member[idx[k]] = med;
+        b0 = t;
+    }
+    return RALA_HIP_OK;
+}
+
+struct Trace {
+    bool on;
+    double t;
+    Trace() : on(getenv("RALA_HIP_TRACE") != nullptr), t(now_ms()) {}
+    void operator()(const char* what, size_t k = 0) {
+        if (!on) return;
+        const double u = now_ms();
+        fprintf(stderr, "[trace] %-28s %8.3f ms  (%zu)\n", what, u - t, k);
+        t = u;
     }
 };
 
-// per read: the median of the pile medians of its connected component over the
-// current overlaps (graph.cpp:740-783); reads outside any component get no entry
-void component_medians(rala_hip_ctx* ctx, std::vector<uint32_t>& members, std::vector<uint16_t>& med_of_member) {
+int preprocess_chimeras(rala_hip_ctx* ctx) {
+    Trace tr;
     const uint64_t n = ctx->n_reads;
-    UnionFind uf(n);
-    std::vector<uint8_t> touched(n, 0);
-    for (const HostOvl& o : ctx->overlaps) {
-        uf.unite(o.a, o.b);
-        touched[o.a] = touched[o.b] = 1;
-    }
-    members.clear();
-    for (uint64_t r = 0; r < n; ++r) if (touched[r]) members.push_back((uint32_t)r);
-    // group members by root (counting sort on the root id)
-    std::vector<uint32_t> root(members.size());
-    std::vector<uint32_t> cnt(n + 1, 0);
-    for (size_t k = 0; k < members.size(); ++k) {
-        root[k] = uf.find(members[k]);
-        ++cnt[root[k] + 1];
-    }
-    for (uint64_t r = 0; r < n; ++r) cnt[r + 1] += cnt[r];
-    std::vector<uint32_t> idx(members.size());
-    for (size_t k = 0; k < members.size(); ++k) idx[cnt[root[k]]++] = (uint32_t)k;
-    med_of_member.assign(members.size(), 0);
-    std::vector<uint16_t> m;
-    for (size_t s = 0; s < idx.size();) {
-        size_t t = s;
-        m.clear();
-        while (t < idx.size() && root[idx[t]] == root[idx[s]]) { m.push_back(ctx->h_median[members[idx[t]]]); ++t; }
-        std::nth_element(m.begin(), m.begin() + m.size() / 2, m.end());
-        const uint16_t med = m[m.size() / 2];
-        for (size_t k = s; k < t; ++k) med_of_member[idx[k]] = med;
-        s = t;
-    }
-}
-
-void preprocess_chimeras(rala_hip_ctx* ctx) {
-    const uint64_t n = ctx->n_reads;
+    ctx->dirty.assign(n, 0);
+    ctx->ever_dirty.assign(n, 0);
+    ctx->dirty_list.clear();
     std::vector<uint8_t> n_pits0(ctx->h_n_pits);     // hills sit behind the initial pits
     // break over chimeric hills (graph.cpp:704-720)
     for (uint64_t r = 0; r < n; ++r) {
@@ -253,13 +309,18 @@ void preprocess_chimeras(rala_hip_ctx* ctx) {
         if (!break_hills(ctx, (uint32_t)r, hills, ctx->h_n_hills[r])) ctx->h_alive[r] = 0;
         ctx->h_n_hills[r] = 0;
     }
+    tr("break hills", ctx->dirty_list.size());
     retrim(ctx, ctx->overlaps);      // :722-728
     retrim(ctx, ctx->internals);     // :730-736
+    clear_dirty(ctx);
+    tr("retrim ov+int", ctx->overlaps.size() + ctx->internals.size());
 
     std::vector<uint32_t> members;
     std::vector<uint16_t> med;
     for (;;) {                       // :738-829
-        component_medians(ctx, members, med);
+        const int rc = component_medians(ctx, members, med);
+        if (rc != RALA_HIP_OK) return rc;
+        tr("component medians", members.size());
         for (size_t k = 0; k < members.size(); ++k) {
             const uint32_t r = members[k];
             if (ctx->h_n_pits[r] == 0) continue;     // no pits: shrink(begin, end) is a no-op
@@ -267,30 +328,57 @@ void preprocess_chimeras(rala_hip_ctx* ctx) {
             if (!break_pits(ctx, r, pits, ctx->h_n_pits[r], med[k])) ctx->h_alive[r] = 0;
         }
         const bool changed = retrim(ctx, ctx->overlaps) != 0;
-        size_t w = 0;
-        for (size_t k = 0; k < ctx->internals.size(); ++k) {
-            HostOvl& o = ctx->internals[k];
-            if (!host_trim(ctx, o)) continue;
-            const uint32_t t = host_type(ctx, o);
-            if (t == kTypeAB || t == kTypeBA) { ctx->overlaps.push_back(o); continue; }
-            if (w != k) ctx->internals[w] = o;
-            ++w;
+        // internals whose reads moved: trim again; the ones that became dovetails join the
+        // overlaps, in internals order (graph.cpp:809-824)
+        {
+            const uint8_t* dirty = ctx->dirty.data();
+            std::vector<HostOvl>& in = ctx->internals;
+            std::vector<std::vector<uint32_t>> promoted(ctx->pool->size());
+            ctx->pool->chunks(in.size(), [&](unsigned t, size_t b, size_t e) {
+                for (size_t k = b; k < e; ++k) {
+                    HostOvl& o = in[k];
+                    if (o.dead || !(dirty[o.a] | dirty[o.b])) continue;      // still trimmed and still kX
+                    if (!host_trim(ctx, o)) { o.dead = 1; continue; }
+                    o.type = (uint8_t)host_type(ctx, o);
+                    if (o.type == kTypeAB || o.type == kTypeBA) promoted[t].push_back((uint32_t)k);
+                }
+            });
+            for (const auto& list : promoted) {
+                for (uint32_t k : list) {
+                    ctx->overlaps.push_back(in[k]);
+                    in[k].dead = 1;
+                }
+            }
         }
-        ctx->internals.resize(w);
+        tr("break pits + retrim", ctx->dirty_list.size());
+        clear_dirty(ctx);
         if (!changed) break;
     }
 
-    // in-order containment removal without the chimera guard (:831-877)
+    // in-order containment removal without the chimera guard (:831-877); stale types are
+    // refreshed in parallel first, the scan itself is sequential and cheap
+    auto refresh = [&](std::vector<HostOvl>& v) {
+        ctx->pool->chunks(v.size(), [&](unsigned, size_t b, size_t e) {
+            for (size_t k = b; k < e; ++k) {
+                HostOvl& o = v[k];
+                if (!o.dead && o.type == 255 && ctx->h_alive[o.a] && ctx->h_alive[o.b]) o.type = (uint8_t)host_type(ctx, o);
+            }
+        });
+    };
     auto kill_scan = [&](std::vector<HostOvl>& v) {
         for (HostOvl& o : v) {
+            if (o.dead) continue;
             if (!ctx->h_alive[o.a] || !ctx->h_alive[o.b]) { o.dead = 1; continue; }
-            const uint32_t t = host_type(ctx, o);
+            const uint32_t t = o.type;
             if (t == kTypeA) { ctx->h_alive[o.b] = 0; o.dead = 1; }
             else if (t == kTypeB) { ctx->h_alive[o.a] = 0; o.dead = 1; }
         }
     };
+    refresh(ctx->overlaps);
+    refresh(ctx->internals);
     kill_scan(ctx->overlaps);
     kill_scan(ctx->internals);
+    tr("kill scans");
     auto compact = [&](std::vector<HostOvl>& v, bool check_piles) {
         size_t w = 0;
         for (size_t k = 0; k < v.size(); ++k) {
@@ -303,6 +391,8 @@ void preprocess_chimeras(rala_hip_ctx* ctx) {
     };
     compact(ctx->internals, false);
     compact(ctx->overlaps, true);
+    tr("compact", ctx->overlaps.size());
+    return RALA_HIP_OK;
 }
 
 // position-space sensitive-pass kernel over `reads`, grouped by LDS image size
@@ -375,6 +465,7 @@ int preprocess_repeats(rala_hip_ctx* ctx, const rala_hip_overlaps* sens, uint64_
         o.c.b_begin = sens->b_begin[i] + ctx->h_begin[b];
         o.c.b_end = sens->b_end[i] + ctx->h_begin[b];
         o.c.length = sens->length[i];
+        o.type = 255;
         cnt[b + 1] += 2;
     }
     // bounds of the targets, no +-15 (graph.cpp:929-933), bucketed by read
@@ -428,7 +519,8 @@ int preprocess_repeats(rala_hip_ctx* ctx, const rala_hip_overlaps* sens, uint64_
     // component medians over the primary overlaps -> repeat hills (graph.cpp:971-1026)
     std::vector<uint32_t> members;
     std::vector<uint16_t> med;
-    component_medians(ctx, members, med);
+    rc = component_medians(ctx, members, med);
+    if (rc != RALA_HIP_OK) return rc;
     {
         std::vector<uint16_t> dm(n, 0);
         for (size_t k = 0; k < members.size(); ++k) dm[members[k]] = med[k];
@@ -483,16 +575,39 @@ void build_graph(rala_hip_ctx* ctx) {
         ctx->node_read.push_back((uint32_t)r);
         ctx->node_read.push_back((uint32_t)r);
     }
-    ctx->e_src.clear(); ctx->e_dst.clear(); ctx->e_len.clear();
-    for (const HostOvl& o : ctx->overlaps) {
-        const uint32_t Ba = ctx->h_begin[o.a], Ea = ctx->h_end[o.a], Bb = ctx->h_begin[o.b], Eb = ctx->h_end[o.b];
-        const uint32_t t = ovl_type(o.c, o.strand, Ba, Ea, Bb, Eb);
-        EdgePair e;
-        if (!ovl_edges(o.c, o.strand, t, read_to_node[o.a], read_to_node[o.b], Ba, Ea, Bb, Eb, e)) continue;
-        ctx->e_src.push_back(e.src0); ctx->e_dst.push_back(e.dst0); ctx->e_len.push_back(e.len0);
-        ctx->e_src.push_back(e.src1); ctx->e_dst.push_back(e.dst1); ctx->e_len.push_back(e.len1);
-    }
-    ctx->e_mark.assign(ctx->e_src.size(), 0);
+    const std::vector<HostOvl>& ov = ctx->overlaps;
+    const size_t m = ov.size();
+    std::vector<EdgePair> ep(m);
+    std::vector<uint8_t> has(m, 0);
+    const unsigned T = ctx->pool->size();
+    std::vector<uint64_t> cnt(T + 1, 0);
+    ctx->pool->chunks(m, [&](unsigned t, size_t b, size_t e) {
+        uint64_t c = 0;
+        for (size_t k = b; k < e; ++k) {
+            const HostOvl& o = ov[k];
+            const uint32_t Ba = ctx->h_begin[o.a], Ea = ctx->h_end[o.a], Bb = ctx->h_begin[o.b], Eb = ctx->h_end[o.b];
+            const uint32_t ty = ovl_type(o.c, o.strand, Ba, Ea, Bb, Eb);
+            if (ovl_edges(o.c, o.strand, ty, read_to_node[o.a], read_to_node[o.b], Ba, Ea, Bb, Eb, ep[k])) {
+                has[k] = 1;
+                ++c;
+            }
+        }
+        cnt[t + 1] = c;
+    });
+    for (unsigned t = 0; t < T; ++t) cnt[t + 1] += cnt[t];
+    const uint64_t ne = 2 * cnt[T];
+    ctx->e_src.resize(ne); ctx->e_dst.resize(ne); ctx->e_len.resize(ne);
+    ctx->pool->chunks(m, [&](unsigned t, size_t b, size_t e) {
+        uint64_t w = 2 * (m < 4096 ? 0 : cnt[t]);
+        for (size_t k = b; k < e; ++k) {
+            if (!has[k]) continue;
+            const EdgePair& p = ep[k];
+            ctx->e_src[w] = p.src0; ctx->e_dst[w] = p.dst0; ctx->e_len[w] = p.len0;
+            ctx->e_src[w + 1] = p.src1; ctx->e_dst[w + 1] = p.dst1; ctx->e_len[w + 1] = p.len1;
+            w += 2;
+        }
+    });
+    ctx->e_mark.assign(ne, 0);
 }
 
 int tr_mark_impl(rala_hip_ctx* ctx, uint32_t n_nodes, uint32_t n_edges, const uint32_t* src, const uint32_t* dst,
@@ -552,6 +667,7 @@ int rala_hip_create(int device, rala_hip_ctx** out) {
         if (hipEventCreate(&e) != hipSuccess) { delete ctx; return RALA_HIP_EDEVICE; }
     }
     if (ctx->d_small.ensure(8) != hipSuccess) { delete ctx; return RALA_HIP_EDEVICE; }
+    ctx->pool.reset(new HostPool(std::min(16u, std::max(1u, std::thread::hardware_concurrency()))));
     *out = ctx;
     return RALA_HIP_OK;
 }
@@ -573,6 +689,11 @@ int rala_hip_set_option(rala_hip_ctx* ctx, const char* key, int64_t value) {
     if (!strcmp(key, "max_lds_read_len")) { ctx->max_lds_read_len = value; return RALA_HIP_OK; }
     if (!strcmp(key, "debug_pile_stop_after")) { ctx->debug_pile_stop_after = value; return RALA_HIP_OK; }
     if (!strcmp(key, "use_run_kernel")) { ctx->use_run_kernel = value != 0; return RALA_HIP_OK; }
+    if (!strcmp(key, "host_threads")) {
+        ctx->host_threads = value;
+        ctx->pool.reset(new HostPool((unsigned)std::max<int64_t>(1, std::min<int64_t>(value, 256))));
+        return RALA_HIP_OK;
+    }
     return fail(ctx, RALA_HIP_EINVAL, "unknown option");
 }
 
@@ -922,12 +1043,13 @@ int rala_hip_construct(rala_hip_ctx* ctx, const rala_hip_overlaps* sens, uint64_
         ReadState rs1 = rs;
         launch_gather_survivors(ctx->ovl, ctx->d_cls.p, rs1, ctx->d_flag[k].p, ctx->d_pos[k].p, sv, s);
         std::vector<uint32_t> h[8];
-        std::vector<uint8_t> hs(m);
+        std::vector<uint8_t> hs(m), ht(m);
         for (int f = 0; f < 8; ++f) {
             h[f].resize(m);
             HIPCHECK(hipMemcpyAsync(h[f].data(), ctx->d_surv_u32[f].p, (size_t)m * 4, hipMemcpyDeviceToHost, s));
         }
         HIPCHECK(hipMemcpyAsync(hs.data(), sv.strand, m, hipMemcpyDeviceToHost, s));
+        HIPCHECK(hipMemcpyAsync(ht.data(), sv.type, m, hipMemcpyDeviceToHost, s));
         HIPCHECK(hipStreamSynchronize(s));
         lists[k]->resize(m);
         for (uint32_t i = 0; i < m; ++i) {
@@ -935,7 +1057,7 @@ int rala_hip_construct(rala_hip_ctx* ctx, const rala_hip_overlaps* sens, uint64_
             o.src = h[0][i]; o.a = h[1][i]; o.b = h[2][i];
             o.c.a_begin = h[3][i]; o.c.a_end = h[4][i]; o.c.b_begin = h[5][i]; o.c.b_end = h[6][i];
             o.c.length = h[7][i];
-            o.strand = hs[i]; o.dead = 0;
+            o.strand = hs[i]; o.dead = 0; o.type = ht[i];
         }
     }
     HIPCHECK(hipEventRecord(ctx->ev[7], s));
@@ -949,12 +1071,18 @@ int rala_hip_construct(rala_hip_ctx* ctx, const rala_hip_overlaps* sens, uint64_
 
     // ---- sequential tail on the survivors ----
     const double t0 = now_ms();
-    preprocess_chimeras(ctx);
+    Trace trc;
+    {
+        const int rc4 = preprocess_chimeras(ctx);
+        if (rc4 != RALA_HIP_OK) return rc4;
+    }
     if (sens != nullptr && n_sens != 0) {
         const int rc3 = preprocess_repeats(ctx, sens, n_sens);
         if (rc3 != RALA_HIP_OK) return rc3;
     }
+    trc("preprocess total");
     build_graph(ctx);
+    trc("build_graph", ctx->e_src.size());
     ctx->tm.tail_host_ms = (float)(now_ms() - t0);
 
     // push the final valid regions / liveness back, re-zero the piles outside them

@@ -59,7 +59,53 @@ __global__ __launch_bounds__(kBlock) void tr_count_kernel(const uint8_t* __restr
     if (threadIdx.x == 0 && v) atomicAdd(n_pairs, v);
 }
 
+// ---- connected components (Graph::preprocess, reference graph.cpp:740-773; only the member
+// sets matter: a median per component) -----------------------------------------------------
+__global__ __launch_bounds__(kBlock) void cc_init_kernel(uint32_t* label, uint32_t n) {
+    const uint32_t v = blockIdx.x * kBlock + threadIdx.x;
+    if (v < n) label[v] = v;
+}
+
+__device__ __forceinline__ uint32_t cc_root(const uint32_t* label, uint32_t v) {
+    uint32_t p = label[v];
+    while (p != v) { v = p; p = label[v]; }
+    return v;
+}
+
+// hook the larger root under the smaller one; labels only ever decrease
+__global__ __launch_bounds__(kBlock) void cc_hook_kernel(const uint32_t* __restrict__ edges, uint32_t n_edges,
+                                                         uint32_t* label, uint32_t* changed) {
+    const uint32_t e = blockIdx.x * kBlock + threadIdx.x;
+    if (e >= n_edges) return;
+    const uint32_t ra = cc_root(label, edges[2 * e]), rb = cc_root(label, edges[2 * e + 1]);
+    if (ra == rb) return;
+    const uint32_t hi = ra > rb ? ra : rb, lo = ra > rb ? rb : ra;
+    atomicMin(&label[hi], lo);
+    *changed = 1;
+}
+
+__global__ __launch_bounds__(kBlock) void cc_compress_kernel(uint32_t* label, uint32_t n) {
+    const uint32_t v = blockIdx.x * kBlock + threadIdx.x;
+    if (v >= n) return;
+    uint32_t r = label[v];
+    while (label[r] != r) r = label[r];
+    label[v] = r;
+}
+
 }  // namespace
+
+void launch_cc_init(uint32_t* label, uint32_t n, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(cc_init_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, label, n);
+}
+void launch_cc_hook(const uint32_t* edges, uint32_t n_edges, uint32_t* label, uint32_t* changed, hipStream_t s) {
+    if (n_edges) {
+        hipLaunchKernelGGL(cc_hook_kernel, dim3((n_edges + kBlock - 1) / kBlock), dim3(kBlock), 0, s, edges, n_edges,
+                           label, changed);
+    }
+}
+void launch_cc_compress(uint32_t* label, uint32_t n, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(cc_compress_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, label, n);
+}
 
 void launch_tr_mark(const uint32_t* row_ptr, const uint32_t* adj_edge, const uint32_t* edge_src,
                     const uint32_t* edge_dst, const uint32_t* edge_len, uint32_t n_nodes, uint32_t n_edges,
