@@ -51,6 +51,28 @@ struct DevBuf {
     }
 };
 
+// pinned host staging buffer (fast, truly asynchronous device <-> host copies)
+template <class T>
+struct PinnedBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    ~PinnedBuf() { release(); }
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    hipError_t ensure(size_t count) {
+        if (count <= n && p) return hipSuccess;
+        release();
+        if (count == 0) count = 1;
+        count += count / 4;                 // grow with slack: survivor counts vary little
+        hipError_t e = hipHostMalloc((void**)&p, count * sizeof(T), hipHostMallocDefault);
+        if (e == hipSuccess) n = count;
+        return e;
+    }
+};
+
 }  // namespace rala_hip
 
 struct rala_hip_ctx {
@@ -114,6 +136,9 @@ struct rala_hip_ctx {
     rala_hip::DevBuf<uint32_t> d_flag[2], d_pos[2];
     rala_hip::DevBuf<uint32_t> d_surv_u32[8];
     rala_hip::DevBuf<uint8_t> d_surv_u8[2];
+    rala_hip::PinnedBuf<uint32_t> p_surv_u32[8];
+    rala_hip::PinnedBuf<uint8_t> p_surv_u8[2];
+    std::vector<void*> registered;               // host mirrors pinned with hipHostRegister
 
     // host mirror of the per-read state (valid after initialize / construct)
     bool initialized = false, constructed = false;
@@ -138,7 +163,11 @@ struct rala_hip_ctx {
     std::vector<uint8_t> dirty, ever_dirty;       // reads whose valid region changed (this round / ever)
     std::vector<uint32_t> dirty_list;
     rala_hip::DevBuf<uint32_t> d_cc_edges, d_cc_label;
-    std::vector<rala_hip::HostOvl> overlaps, internals;
+    rala_hip::DevBuf<uint32_t> d_tr[6];
+    rala_hip::DevBuf<uint8_t> d_tr_marks;
+    std::vector<rala_hip::HostOvl> overlaps, internals, scratch_ovl;
+    std::vector<rala_hip::EdgePair> scratch_ep;
+    std::vector<uint8_t> scratch_has;
     std::vector<uint32_t> node_read;
     std::vector<uint32_t> e_src, e_dst, e_len;
     std::vector<uint8_t> e_mark;

@@ -150,6 +150,11 @@ void launch_exclusive_scan(const uint32_t* in, uint32_t* out, uint64_t n, void* 
 void launch_tr_mark(const uint32_t* row_ptr, const uint32_t* adj_edge, const uint32_t* edge_src,
                     const uint32_t* edge_dst, const uint32_t* edge_len, uint32_t n_nodes, uint32_t n_edges,
                     uint8_t* marks, hipStream_t s);
+// out-degree per node (also flags endpoints >= n_nodes) / adjacency fill through a cursor
+void launch_tr_degree(const uint32_t* src, const uint32_t* dst, uint32_t n_nodes, uint32_t n_edges, uint32_t* deg,
+                      uint32_t* bad, hipStream_t s);
+void launch_tr_fill(const uint32_t* src, uint32_t n_nodes, uint32_t n_edges, uint32_t* cursor, uint32_t* adj,
+                    hipStream_t s);
 // connected components by min-label hooking + pointer jumping (edges = pairs a, b)
 void launch_cc_init(uint32_t* label, uint32_t n, hipStream_t s);
 void launch_cc_hook(const uint32_t* edges, uint32_t n_edges, uint32_t* label, uint32_t* changed, hipStream_t s);

@@ -54,23 +54,52 @@ __global__ __launch_bounds__(kBlock) void dedupe_kernel(OvlSoA o, uint32_t n_rea
 }
 
 // Every resolvable overlap (valid or not) contributes two bounds to each of
-// its reads (graph.cpp:311-326).
+// its reads (graph.cpp:311-326).  Overlap files are grouped by query, so the
+// lanes of a wavefront mostly share a_id: one atomic per segment of equal a_id
+// (leader = first lane of the segment, found with a ballot), one per lane for
+// the scattered target side.
+__device__ __forceinline__ uint32_t segment_of(uint32_t key, bool active, uint32_t lane, uint32_t& leader) {
+    // lanes are consecutive overlaps; a segment = maximal run of active lanes with equal key
+    const uint32_t prev = (uint32_t)__shfl_up((int)key, 1, 64);
+    const bool prev_active = __shfl_up((int)active, 1, 64) != 0;
+    const bool head = active && (lane == 0 || !prev_active || prev != key);
+    const uint64_t heads = __ballot(head);
+    const uint64_t act = __ballot(active);
+    // leader: highest head at or below this lane
+    const uint64_t below = heads & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
+    leader = below ? 63u - (uint32_t)__clzll((long long)below) : lane;
+    // segment length (for the leader): up to the next head or the first inactive lane
+    const uint64_t after = (lane == 63) ? 0ull : ((heads | ~act) >> (lane + 1));
+    const uint32_t len = after ? (uint32_t)__ffsll((unsigned long long)after) : (64u - lane);
+    return head ? len : 0u;
+}
+
 __global__ __launch_bounds__(kBlock) void count_bounds_kernel(OvlSoA o, uint32_t n_reads, uint32_t* counts) {
     const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= o.n) return;
-    const uint32_t a = o.a_id[i], b = o.b_id[i];
-    if (a >= n_reads || b >= n_reads) return;
-    atomicAdd(&counts[a], 2u);
-    atomicAdd(&counts[b], 2u);
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t a = kInf, b = kInf;
+    if (i < o.n) { a = o.a_id[i]; b = o.b_id[i]; }
+    const bool ok = a < n_reads && b < n_reads;
+    uint32_t leader;
+    const uint32_t seg = segment_of(a, ok, lane, leader);
+    if (seg) atomicAdd(&counts[a], 2u * seg);
+    if (ok) atomicAdd(&counts[b], 2u);
 }
 
 __global__ __launch_bounds__(kBlock) void scatter_bounds_kernel(OvlSoA o, uint32_t n_reads, uint32_t* cursor,
                                                                 uint32_t* __restrict__ ev) {
     const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= o.n) return;
-    const uint32_t a = o.a_id[i], b = o.b_id[i];
-    if (a >= n_reads || b >= n_reads) return;
-    const uint32_t pa = atomicAdd(&cursor[a], 2u);
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t a = kInf, b = kInf;
+    if (i < o.n) { a = o.a_id[i]; b = o.b_id[i]; }
+    const bool ok = a < n_reads && b < n_reads;
+    uint32_t leader;
+    const uint32_t seg = segment_of(a, ok, lane, leader);
+    uint32_t base = 0;
+    if (seg) base = atomicAdd(&cursor[a], 2u * seg);
+    base = (uint32_t)__shfl((int)base, (int)leader, 64);
+    if (!ok) return;
+    const uint32_t pa = base + 2u * (lane - leader);
     ev[pa] = (o.a_begin[i] + 15u) << 1;
     ev[pa + 1] = ((o.a_end[i] - 15u) << 1) | 1u;
     const uint32_t pb = atomicAdd(&cursor[b], 2u);

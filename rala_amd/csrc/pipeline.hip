@@ -365,29 +365,66 @@ int preprocess_chimeras(rala_hip_ctx* ctx) {
             }
         });
     };
-    auto kill_scan = [&](std::vector<HostOvl>& v) {
-        for (HostOvl& o : v) {
-            if (o.dead) continue;
-            if (!ctx->h_alive[o.a] || !ctx->h_alive[o.b]) { o.dead = 1; continue; }
-            const uint32_t t = o.type;
-            if (t == kTypeA) { ctx->h_alive[o.b] = 0; o.dead = 1; }
-            else if (t == kTypeB) { ctx->h_alive[o.a] = 0; o.dead = 1; }
+    // only containment overlaps (kA / kB) can delete a read: collect them in order (parallel),
+    // walk them sequentially, then drop the items that had lost a read by the time the
+    // reference's loop reached them (parallel; kill_pos = position of the deleting item)
+    std::vector<uint32_t> kill_pos;
+    auto kill_scan = [&](std::vector<HostOvl>& v, bool timed) {
+        std::vector<std::vector<uint32_t>> cand(ctx->pool->size());
+        ctx->pool->chunks(v.size(), [&](unsigned t, size_t b0, size_t e0) {
+            for (size_t k = b0; k < e0; ++k) {
+                const HostOvl& o = v[k];
+                if (!o.dead && (o.type == kTypeA || o.type == kTypeB)) cand[t].push_back((uint32_t)k);
+            }
+        });
+        if (timed) kill_pos.assign(n, 0xFFFFFFFFu);
+        for (const auto& list : cand) {
+            for (uint32_t k : list) {
+                HostOvl& o = v[k];
+                o.dead = 1;
+                if (!ctx->h_alive[o.a] || !ctx->h_alive[o.b]) continue;
+                const uint32_t victim = o.type == kTypeA ? o.b : o.a;
+                ctx->h_alive[victim] = 0;
+                if (timed) kill_pos[victim] = k;
+            }
         }
+        if (!timed) return;       // overlaps: a final sweep drops everything that lost a read
+        ctx->pool->chunks(v.size(), [&](unsigned, size_t b0, size_t e0) {
+            for (size_t k = b0; k < e0; ++k) {
+                HostOvl& o = v[k];
+                if (o.dead) continue;
+                const bool gone_a = !ctx->h_alive[o.a] && (kill_pos[o.a] == 0xFFFFFFFFu || kill_pos[o.a] < k);
+                const bool gone_b = !ctx->h_alive[o.b] && (kill_pos[o.b] == 0xFFFFFFFFu || kill_pos[o.b] < k);
+                if (gone_a || gone_b) o.dead = 1;
+            }
+        });
     };
     refresh(ctx->overlaps);
     refresh(ctx->internals);
-    kill_scan(ctx->overlaps);
-    kill_scan(ctx->internals);
+    kill_scan(ctx->overlaps, false);
+    kill_scan(ctx->internals, true);
     tr("kill scans");
+    // one compaction at the end: what is dead or (overlaps only, :869-877) lost a read goes
     auto compact = [&](std::vector<HostOvl>& v, bool check_piles) {
-        size_t w = 0;
-        for (size_t k = 0; k < v.size(); ++k) {
-            if (v[k].dead) continue;
-            if (check_piles && (!ctx->h_alive[v[k].a] || !ctx->h_alive[v[k].b])) continue;
-            if (w != k) v[w] = v[k];
-            ++w;
-        }
-        v.resize(w);
+        const unsigned T = ctx->pool->size();
+        std::vector<size_t> cnt(T + 1, 0);
+        auto keep = [&](const HostOvl& o) {
+            return !o.dead && !(check_piles && (!ctx->h_alive[o.a] || !ctx->h_alive[o.b]));
+        };
+        const bool single = v.size() < 4096;
+        ctx->pool->chunks(v.size(), [&](unsigned t, size_t b0, size_t e0) {
+            size_t c = 0;
+            for (size_t k = b0; k < e0; ++k) c += keep(v[k]);
+            cnt[t + 1] = c;
+        });
+        for (unsigned t = 0; t < T; ++t) cnt[t + 1] += cnt[t];
+        std::vector<HostOvl>& out = ctx->scratch_ovl;      // capacity survives across calls
+        out.resize(single ? cnt[1] : cnt[T]);
+        ctx->pool->chunks(v.size(), [&](unsigned t, size_t b0, size_t e0) {
+            size_t w = single ? 0 : cnt[t];
+            for (size_t k = b0; k < e0; ++k) if (keep(v[k])) out[w++] = v[k];
+        });
+        v.swap(out);
     };
     compact(ctx->internals, false);
     compact(ctx->overlaps, true);
@@ -577,8 +614,10 @@ void build_graph(rala_hip_ctx* ctx) {
     }
     const std::vector<HostOvl>& ov = ctx->overlaps;
     const size_t m = ov.size();
-    std::vector<EdgePair> ep(m);
-    std::vector<uint8_t> has(m, 0);
+    std::vector<EdgePair>& ep = ctx->scratch_ep;
+    std::vector<uint8_t>& has = ctx->scratch_has;
+    ep.resize(m);
+    has.assign(m, 0);
     const unsigned T = ctx->pool->size();
     std::vector<uint64_t> cnt(T + 1, 0);
     ctx->pool->chunks(m, [&](unsigned t, size_t b, size_t e) {
@@ -615,38 +654,37 @@ int tr_mark_impl(rala_hip_ctx* ctx, uint32_t n_nodes, uint32_t n_edges, const ui
     *n_pairs = 0;
     if (n_edges == 0) return RALA_HIP_OK;
     if (n_edges & 1) return fail(ctx, RALA_HIP_EINVAL, "edges must come in twin pairs (e, e^1)");
-    // CSR with out-lists in edge-id order (suffix_edges_ append order)
-    std::vector<uint32_t> row(n_nodes + 1, 0), adj(n_edges);
-    for (uint32_t e = 0; e < n_edges; ++e) {
-        if (src[e] >= n_nodes || dst[e] >= n_nodes) return fail(ctx, RALA_HIP_EINVAL, "edge endpoint out of range");
-        ++row[src[e] + 1];
-    }
-    for (uint32_t v = 0; v < n_nodes; ++v) row[v + 1] += row[v];
-    {
-        std::vector<uint32_t> cur(row.begin(), row.end() - 1);
-        for (uint32_t e = 0; e < n_edges; ++e) adj[cur[src[e]]++] = e;
-    }
-    DevBuf<uint32_t> d_row, d_adj, d_src, d_dst, d_len;
-    DevBuf<uint8_t> d_marks;
-    HIPCHECK(d_row.ensure(n_nodes + 1)); HIPCHECK(d_adj.ensure(n_edges)); HIPCHECK(d_src.ensure(n_edges));
-    HIPCHECK(d_dst.ensure(n_edges)); HIPCHECK(d_len.ensure(n_edges)); HIPCHECK(d_marks.ensure(n_edges));
     hipStream_t s = ctx->stream;
-    HIPCHECK(hipMemcpyAsync(d_row.p, row.data(), (size_t)(n_nodes + 1) * 4, hipMemcpyHostToDevice, s));
-    HIPCHECK(hipMemcpyAsync(d_adj.p, adj.data(), (size_t)n_edges * 4, hipMemcpyHostToDevice, s));
-    HIPCHECK(hipMemcpyAsync(d_src.p, src, (size_t)n_edges * 4, hipMemcpyHostToDevice, s));
-    HIPCHECK(hipMemcpyAsync(d_dst.p, dst, (size_t)n_edges * 4, hipMemcpyHostToDevice, s));
-    HIPCHECK(hipMemcpyAsync(d_len.p, len, (size_t)n_edges * 4, hipMemcpyHostToDevice, s));
-    HIPCHECK(hipMemsetAsync(d_marks.p, 0, n_edges, s));
-    HIPCHECK(hipMemsetAsync(ctx->d_small.p + 3, 0, 4, s));
+    DevBuf<uint32_t>* B = ctx->d_tr;          // row, cursor, adj, src, dst, len (persistent)
+    HIPCHECK(B[0].ensure(n_nodes + 2)); HIPCHECK(B[1].ensure(n_nodes + 2)); HIPCHECK(B[2].ensure(n_edges));
+    HIPCHECK(B[3].ensure(n_edges)); HIPCHECK(B[4].ensure(n_edges)); HIPCHECK(B[5].ensure(n_edges));
+    HIPCHECK(ctx->d_tr_marks.ensure(n_edges));
+    HIPCHECK(ctx->d_scan_ws.ensure(scan_workspace_bytes((uint64_t)n_nodes + 2)));
+    HIPCHECK(hipMemcpyAsync(B[3].p, src, (size_t)n_edges * 4, hipMemcpyHostToDevice, s));
+    HIPCHECK(hipMemcpyAsync(B[4].p, dst, (size_t)n_edges * 4, hipMemcpyHostToDevice, s));
+    HIPCHECK(hipMemcpyAsync(B[5].p, len, (size_t)n_edges * 4, hipMemcpyHostToDevice, s));
+    HIPCHECK(hipMemsetAsync(ctx->d_tr_marks.p, 0, n_edges, s));
+    HIPCHECK(hipMemsetAsync(ctx->d_small.p + 2, 0, 8, s));           // [2] bad endpoint flag [3] pairs
+    HIPCHECK(hipMemsetAsync(B[1].p, 0, (size_t)(n_nodes + 1) * 4, s));
     HIPCHECK(hipEventRecord(ctx->ev[10], s));
-    launch_tr_mark(d_row.p, d_adj.p, d_src.p, d_dst.p, d_len.p, n_nodes, n_edges, d_marks.p, s);
-    launch_tr_count(d_marks.p, n_edges, ctx->d_small.p + 3, s);
+    // CSR on the device: out-degree count -> scan -> fill.  The fill order is arbitrary; the
+    // candidate a->c is the edge with the highest id, which is the reference's "last one
+    // in suffix_edges_" (graph.cpp:1291-1293, out-lists are in edge-id order there).
+    launch_tr_degree(B[3].p, B[4].p, n_nodes, n_edges, B[1].p, ctx->d_small.p + 2, s);
+    launch_exclusive_scan(B[1].p, B[0].p, n_nodes, ctx->d_scan_ws.p, s);
+    HIPCHECK(hipMemcpyAsync(B[1].p, B[0].p, (size_t)n_nodes * 4, hipMemcpyDeviceToDevice, s));
+    launch_tr_fill(B[3].p, n_nodes, n_edges, B[1].p, B[2].p, s);
+    launch_tr_mark(B[0].p, B[2].p, B[3].p, B[4].p, B[5].p, n_nodes, n_edges, ctx->d_tr_marks.p, s);
+    launch_tr_count(ctx->d_tr_marks.p, n_edges, ctx->d_small.p + 3, s);
     HIPCHECK(hipEventRecord(ctx->ev[11], s));
-    HIPCHECK(hipMemcpyAsync(marks, d_marks.p, n_edges, hipMemcpyDeviceToHost, s));
-    HIPCHECK(hipMemcpyAsync(n_pairs, ctx->d_small.p + 3, 4, hipMemcpyDeviceToHost, s));
+    uint32_t res[2] = {0, 0};
+    HIPCHECK(hipMemcpyAsync(marks, ctx->d_tr_marks.p, n_edges, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipMemcpyAsync(res, ctx->d_small.p + 2, 8, hipMemcpyDeviceToHost, s));
     HIPCHECK(hipStreamSynchronize(s));
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipEventElapsedTime(&ctx->tm.tr_ms, ctx->ev[10], ctx->ev[11]));
+    if (res[0]) return fail(ctx, RALA_HIP_EINVAL, "edge endpoint out of range");
+    *n_pairs = res[1];
     return RALA_HIP_OK;
 }
 
@@ -676,6 +714,8 @@ void rala_hip_destroy(rala_hip_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    for (void* q : ctx->registered) (void)hipHostUnregister(q);
+    ctx->registered.clear();
     for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -728,6 +768,22 @@ int rala_hip_set_reads(rala_hip_ctx* ctx, const uint32_t* read_len, uint64_t n_r
     HIPCHECK(ctx->d_alive.ensure(n_reads)); HIPCHECK(ctx->d_n_pits.ensure(n_reads));
     HIPCHECK(ctx->d_n_hills.ensure(n_reads)); HIPCHECK(ctx->d_iv_slot.ensure(n_reads));
     HIPCHECK(ctx->d_death[0].ensure(n_reads)); HIPCHECK(ctx->d_death[1].ensure(n_reads));
+    // host mirrors of the per-read state: sized once, pinned for fast copies
+    for (void* q : ctx->registered) (void)hipHostUnregister(q);
+    ctx->registered.clear();
+    ctx->h_begin.resize(n_reads); ctx->h_end.resize(n_reads); ctx->h_median.resize(n_reads);
+    ctx->h_p10.resize(n_reads); ctx->h_alive.resize(n_reads); ctx->h_n_pits.resize(n_reads);
+    ctx->h_n_hills.resize(n_reads); ctx->h_slot.resize(n_reads);
+    if (n_reads) {
+        auto pin = [&](void* q, size_t bytes) {
+            if (hipHostRegister(q, bytes, hipHostRegisterDefault) == hipSuccess) ctx->registered.push_back(q);
+            else (void)hipGetLastError();
+        };
+        pin(ctx->h_begin.data(), n_reads * 4); pin(ctx->h_end.data(), n_reads * 4);
+        pin(ctx->h_median.data(), n_reads * 2); pin(ctx->h_p10.data(), n_reads * 2);
+        pin(ctx->h_alive.data(), n_reads); pin(ctx->h_n_pits.data(), n_reads);
+        pin(ctx->h_n_hills.data(), n_reads); pin(ctx->h_slot.data(), n_reads * 4);
+    }
     ctx->pool_cap = (uint32_t)std::max<int64_t>(1024, (int64_t)n_reads * ctx->pool_per_read_x1000 / 1000);
     HIPCHECK(ctx->d_pool.ensure(ctx->pool_cap));
     ctx->initialized = ctx->constructed = false;
@@ -1042,23 +1098,32 @@ int rala_hip_construct(rala_hip_ctx* ctx, const rala_hip_overlaps* sens, uint64_
         // trim in the gather re-derives the coordinates against the pass-1 piles
         ReadState rs1 = rs;
         launch_gather_survivors(ctx->ovl, ctx->d_cls.p, rs1, ctx->d_flag[k].p, ctx->d_pos[k].p, sv, s);
-        std::vector<uint32_t> h[8];
-        std::vector<uint8_t> hs(m), ht(m);
         for (int f = 0; f < 8; ++f) {
-            h[f].resize(m);
-            HIPCHECK(hipMemcpyAsync(h[f].data(), ctx->d_surv_u32[f].p, (size_t)m * 4, hipMemcpyDeviceToHost, s));
+            HIPCHECK(ctx->p_surv_u32[f].ensure(m));
+            HIPCHECK(hipMemcpyAsync(ctx->p_surv_u32[f].p, ctx->d_surv_u32[f].p, (size_t)m * 4, hipMemcpyDeviceToHost, s));
         }
-        HIPCHECK(hipMemcpyAsync(hs.data(), sv.strand, m, hipMemcpyDeviceToHost, s));
-        HIPCHECK(hipMemcpyAsync(ht.data(), sv.type, m, hipMemcpyDeviceToHost, s));
+        for (int f = 0; f < 2; ++f) {
+            HIPCHECK(ctx->p_surv_u8[f].ensure(m));
+            HIPCHECK(hipMemcpyAsync(ctx->p_surv_u8[f].p, ctx->d_surv_u8[f].p, m, hipMemcpyDeviceToHost, s));
+        }
         HIPCHECK(hipStreamSynchronize(s));
+        // promoted internals are appended to the overlaps later: room for them up front
+        lists[k]->reserve(k == 0 ? (size_t)n_surv[0] + n_surv[1] : (size_t)m);
         lists[k]->resize(m);
-        for (uint32_t i = 0; i < m; ++i) {
-            HostOvl& o = (*lists[k])[i];
-            o.src = h[0][i]; o.a = h[1][i]; o.b = h[2][i];
-            o.c.a_begin = h[3][i]; o.c.a_end = h[4][i]; o.c.b_begin = h[5][i]; o.c.b_end = h[6][i];
-            o.c.length = h[7][i];
-            o.strand = hs[i]; o.dead = 0; o.type = ht[i];
-        }
+        std::vector<HostOvl>& dst = *lists[k];
+        uint32_t* hp[8];
+        for (int f = 0; f < 8; ++f) hp[f] = ctx->p_surv_u32[f].p;
+        const uint8_t* hs = ctx->p_surv_u8[0].p;
+        const uint8_t* ht = ctx->p_surv_u8[1].p;
+        ctx->pool->chunks(m, [&](unsigned, size_t b, size_t e) {
+            for (size_t i = b; i < e; ++i) {
+                HostOvl& o = dst[i];
+                o.src = hp[0][i]; o.a = hp[1][i]; o.b = hp[2][i];
+                o.c.a_begin = hp[3][i]; o.c.a_end = hp[4][i]; o.c.b_begin = hp[5][i]; o.c.b_end = hp[6][i];
+                o.c.length = hp[7][i];
+                o.strand = hs[i]; o.dead = 0; o.type = ht[i];
+            }
+        });
     }
     HIPCHECK(hipEventRecord(ctx->ev[7], s));
     HIPCHECK(hipGetLastError());

@@ -23,22 +23,24 @@ __global__ __launch_bounds__(kBlock) void tr_mark_kernel(const uint32_t* __restr
                                                          const uint32_t* __restrict__ adj,
                                                          const uint32_t* __restrict__ esrc,
                                                          const uint32_t* __restrict__ edst,
-                                                         const uint32_t* __restrict__ elen, uint32_t n_edges,
-                                                         uint8_t* marks) {
+                                                         const uint32_t* __restrict__ elen, uint32_t n_nodes,
+                                                         uint32_t n_edges, uint8_t* marks) {
     const uint32_t e_ab = blockIdx.x * kBlock + threadIdx.x;
     if (e_ab >= n_edges) return;
     const uint32_t a = esrc[e_ab], b = edst[e_ab];
+    if (a >= n_nodes || b >= n_nodes) return;          // reported by tr_degree_kernel
     const uint32_t len_ab = elen[e_ab];
     const uint32_t a0 = row_ptr[a], a1 = row_ptr[a + 1];
     const uint32_t b0 = row_ptr[b], b1 = row_ptr[b + 1];
     for (uint32_t k = b0; k < b1; ++k) {
         const uint32_t e_bc = adj[k];
         const uint32_t c = edst[e_bc];
-        // last edge a->c in a's out-list is the candidate
+        // the candidate is the LAST edge a->c of a's out-list = the one with the highest id
+        // (out-lists are in edge-id order in the reference; here the list order is arbitrary)
         uint32_t cand = 0xFFFFFFFFu;
-        for (uint32_t m = a1; m-- > a0;) {
+        for (uint32_t m = a0; m < a1; ++m) {
             const uint32_t e = adj[m];
-            if (edst[e] == c) { cand = e; break; }
+            if (edst[e] == c && (cand == 0xFFFFFFFFu || e > cand)) cand = e;
         }
         if (cand == 0xFFFFFFFFu) continue;
         const uint32_t sum = len_ab + elen[e_bc];
@@ -57,6 +59,25 @@ __global__ __launch_bounds__(kBlock) void tr_count_kernel(const uint8_t* __restr
     if (2 * p + 1 < n_edges) v = marks[2 * p] ? 1u : 0u;
     v = block_reduce<kBlock>(v, OpAdd(), 0u, tmp);
     if (threadIdx.x == 0 && v) atomicAdd(n_pairs, v);
+}
+
+__global__ __launch_bounds__(kBlock) void tr_degree_kernel(const uint32_t* __restrict__ src,
+                                                           const uint32_t* __restrict__ dst, uint32_t n_nodes,
+                                                           uint32_t n_edges, uint32_t* deg, uint32_t* bad) {
+    const uint32_t e = blockIdx.x * kBlock + threadIdx.x;
+    if (e >= n_edges) return;
+    const uint32_t a = src[e], b = dst[e];
+    if (a >= n_nodes || b >= n_nodes) { *bad = 1; return; }
+    atomicAdd(&deg[a], 1u);
+}
+
+__global__ __launch_bounds__(kBlock) void tr_fill_kernel(const uint32_t* __restrict__ src, uint32_t n_nodes,
+                                                         uint32_t n_edges, uint32_t* cursor, uint32_t* adj) {
+    const uint32_t e = blockIdx.x * kBlock + threadIdx.x;
+    if (e >= n_edges) return;
+    const uint32_t a = src[e];
+    if (a >= n_nodes) return;
+    adj[atomicAdd(&cursor[a], 1u)] = e;
 }
 
 // ---- connected components (Graph::preprocess, reference graph.cpp:740-773; only the member
@@ -94,6 +115,20 @@ __global__ __launch_bounds__(kBlock) void cc_compress_kernel(uint32_t* label, ui
 
 }  // namespace
 
+void launch_tr_degree(const uint32_t* src, const uint32_t* dst, uint32_t n_nodes, uint32_t n_edges, uint32_t* deg,
+                      uint32_t* bad, hipStream_t s) {
+    if (n_edges) {
+        hipLaunchKernelGGL(tr_degree_kernel, dim3((n_edges + kBlock - 1) / kBlock), dim3(kBlock), 0, s, src, dst,
+                           n_nodes, n_edges, deg, bad);
+    }
+}
+void launch_tr_fill(const uint32_t* src, uint32_t n_nodes, uint32_t n_edges, uint32_t* cursor, uint32_t* adj,
+                    hipStream_t s) {
+    if (n_edges) {
+        hipLaunchKernelGGL(tr_fill_kernel, dim3((n_edges + kBlock - 1) / kBlock), dim3(kBlock), 0, s, src, n_nodes,
+                           n_edges, cursor, adj);
+    }
+}
 void launch_cc_init(uint32_t* label, uint32_t n, hipStream_t s) {
     if (n) hipLaunchKernelGGL(cc_init_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, label, n);
 }
@@ -110,10 +145,9 @@ void launch_cc_compress(uint32_t* label, uint32_t n, hipStream_t s) {
 void launch_tr_mark(const uint32_t* row_ptr, const uint32_t* adj_edge, const uint32_t* edge_src,
                     const uint32_t* edge_dst, const uint32_t* edge_len, uint32_t n_nodes, uint32_t n_edges,
                     uint8_t* marks, hipStream_t s) {
-    (void)n_nodes;
     if (n_edges == 0) return;
     hipLaunchKernelGGL(tr_mark_kernel, dim3((n_edges + kBlock - 1) / kBlock), dim3(kBlock), 0, s, row_ptr, adj_edge,
-                       edge_src, edge_dst, edge_len, n_edges, marks);
+                       edge_src, edge_dst, edge_len, n_nodes, n_edges, marks);
 }
 
 void launch_tr_count(const uint8_t* marks, uint32_t n_edges, uint32_t* n_pairs, hipStream_t s) {
