@@ -135,7 +135,7 @@ def main():
         ms = 1000.0 * dt / steps
         for k in stage:
             stage[k] /= steps
-        # dominant kernel: pile_build_annotate.  Algorithmic bytes of one step's launches:
+        # dominant kernel: the pile kernel chain (pile_runs_kernel).  Algorithmic bytes of one step's launches:
         # 16 B per overlap of bucketed bounds read + 2 B per base of pile written + 40 B per
         # read of annotations (DESIGN.md "Roofline"); time = HIP events
         # around those launches on the context's stream.
@@ -165,7 +165,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": WORKLOADS[args.workload], "n_reads": ds.n_reads, "n_overlaps": n_ovl,
                        "sum_read_len": sum_len, "transitive_pairs": int(n_tr)},
-            "roofline": {"bound": "hbm", "kernel": "pile_build_annotate", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": "pile_runs_kernel<512|2048> + pile_build_annotate (overflow chain)", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "algorithmic_bytes": pile_bytes, "kernel_ms": pile_ms},
             "stage_ms": stage,

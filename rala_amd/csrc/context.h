@@ -167,7 +167,9 @@ struct rala_hip_ctx {
     rala_hip::DevBuf<uint8_t> d_tr_marks;
     std::vector<rala_hip::HostOvl> overlaps, internals, scratch_ovl;
     std::vector<rala_hip::EdgePair> scratch_ep;
-    std::vector<uint8_t> scratch_has;
+    std::vector<uint8_t> scratch_has, scratch_touched, h_n_pits0;
+    std::vector<uint32_t> scratch_u32a, scratch_u32b, alive_rank, alive_reads;
+    rala_hip::PinnedBuf<uint32_t> p_cc_edges, p_cc_label;
     std::vector<uint32_t> node_read;
     std::vector<uint32_t> e_src, e_dst, e_len;
     std::vector<uint8_t> e_mark;

@@ -435,49 +435,74 @@ __global__ __launch_bounds__(64) void pile_runs_kernel(PileArgs A, uint32_t* ove
         for (uint32_t k = lane; k < R; k += 64) {
             if (k < kB || k >= kE) rv[k] = 0;
         }
-        uint32_t shift = 6;
+        // idx[g] = run that contains position g << shift = number of runs j >= 1 that start at
+        // or before it: histogram of ceil(start / 2^shift) over the runs, then a prefix sum
+        uint32_t shift = 5;
         while ((n >> shift) >= kIdx) ++shift;
-        wave_sync();
-        for (uint32_t m = lane; m <= (n - 1) >> shift; m += 64) {
-            const uint32_t p = m << shift;
-            uint32_t a = 0, b = R - 1;                  // last run with start <= p
-            while (a < b) {
-                const uint32_t mid = (a + b + 1) >> 1;
-                if (rs[mid] <= p) a = mid; else b = mid - 1;
+        const uint32_t ng = ((n - 1) >> shift) + 1;
+        {
+            uint32_t* gcnt = sm + L::D;                 // free until the histograms of step 5
+            for (uint32_t m = lane; m < ng; m += 64) gcnt[m] = 0;
+            wave_sync();
+            const uint32_t round_up = (1u << shift) - 1u;
+            for (uint32_t j = 1 + lane; j < R; j += 64) {
+                const uint32_t g = (rs[j] + round_up) >> shift;
+                if (g < ng) atomicAdd(&gcnt[g], 1u);
             }
-            idx[m] = (uint16_t)a;
+            wave_sync();
+            const uint32_t c = (ng + 63) / 64;
+            const uint32_t lo = umin(ng, lane * c), hi = umin(ng, lo + c);
+            uint32_t sum = 0;
+            for (uint32_t m = lo; m < hi; ++m) sum += gcnt[m];
+            uint32_t run = wave_scan_incl(sum, OpAdd()) - sum;
+            for (uint32_t m = lo; m < hi; ++m) {
+                run += gcnt[m];
+                idx[m] = (uint16_t)run;
+            }
         }
         wave_sync();
         {
-            // each lane expands 32 consecutive positions (four 16-byte stores)
+            // 16 bytes (8 positions) per lane per store, consecutive lanes -> consecutive
+            // addresses (1 KiB per wave instruction); four independent groups per lane and
+            // iteration so that their run look-ups overlap
             uint4* dst = (uint4*)(A.pile + A.pile_off[r]);
             const uint32_t nv = (n + 7) / 8;
-            const uint32_t nq = (nv + 3) / 4;
-            for (uint32_t g4 = lane; g4 < nq; g4 += 64) {
-                const uint32_t p0 = g4 * 32;
-                uint32_t k = idx[p0 >> shift];
-                uint32_t nxt = rs[k + 1];
-                while (nxt <= p0) { ++k; nxt = rs[k + 1]; }
-                uint32_t v = rv[k];
+            for (uint32_t g0 = lane; g0 < nv; g0 += 256) {
+                uint32_t k[4], nxt[4], v[4];
 #pragma unroll
                 for (uint32_t u = 0; u < 4; ++u) {
-                    const uint32_t p = p0 + u * 8;
-                    if (g4 * 4 + u >= nv) break;
+                    const uint32_t g = umin(g0 + 64 * u, nv - 1);
+                    k[u] = idx[(g * 8) >> shift];
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < 4; ++u) nxt[u] = rs[k[u] + 1];
+#pragma unroll
+                for (uint32_t u = 0; u < 4; ++u) {
+                    const uint32_t p = umin(g0 + 64 * u, nv - 1) * 8;
+                    while (nxt[u] <= p) { ++k[u]; nxt[u] = rs[k[u] + 1]; }
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < 4; ++u) v[u] = rv[k[u]];
+#pragma unroll
+                for (uint32_t u = 0; u < 4; ++u) {
+                    const uint32_t g = g0 + 64 * u;
+                    if (g >= nv) break;
+                    const uint32_t p = g * 8;
                     uint32_t w[4];
-                    while (nxt <= p && k + 1 < R) { ++k; nxt = rs[k + 1]; v = rv[k]; }
-                    if (nxt >= p + 8 && p + 8 <= n) {
-                        const uint32_t vv = v | (v << 16);
+                    if (nxt[u] >= p + 8 && p + 8 <= n) {
+                        const uint32_t vv = v[u] | (v[u] << 16);
                         w[0] = w[1] = w[2] = w[3] = vv;
                     } else {
+                        uint32_t kk = k[u], nx = nxt[u], vv = v[u];
 #pragma unroll
                         for (int x = 0; x < 8; ++x) {
                             const uint32_t q = p + x;
-                            while (nxt <= q && k + 1 < R) { ++k; nxt = rs[k + 1]; v = rv[k]; }
-                            const uint32_t val = q < n ? v : 0u;
+                            while (nx <= q && kk + 1 < R) { ++kk; nx = rs[kk + 1]; vv = rv[kk]; }
+                            const uint32_t val = q < n ? vv : 0u;
                             if (x & 1) w[x >> 1] |= val << 16; else w[x >> 1] = val;
                         }
                     }
-                    dst[g4 * 4 + u] = make_uint4(w[0], w[1], w[2], w[3]);
+                    dst[g] = make_uint4(w[0], w[1], w[2], w[3]);
                 }
             }
         }

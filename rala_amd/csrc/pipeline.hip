@@ -169,9 +169,14 @@ uint32_t cached_type(rala_hip_ctx* ctx, HostOvl& o) {
     return o.type;
 }
 
+// flags only (callable from pool threads, one read per thread); collect_dirty() lists them
 void mark_dirty(rala_hip_ctx* ctx, uint32_t r) {
-    if (!ctx->dirty[r]) { ctx->dirty[r] = 1; ctx->dirty_list.push_back(r); }
+    ctx->dirty[r] = 1;
     ctx->ever_dirty[r] = 1;
+}
+
+void collect_dirty(rala_hip_ctx* ctx, const std::vector<uint32_t>& among) {
+    for (uint32_t r : among) if (ctx->dirty[r]) ctx->dirty_list.push_back(r);
 }
 
 void clear_dirty(rala_hip_ctx* ctx) {
@@ -226,55 +231,65 @@ bool break_pits(rala_hip_ctx* ctx, uint32_t r, Interval* pits, uint8_t& n_pits, 
 // per read: the median of the pile medians of its connected component over the current
 // overlaps (graph.cpp:740-783); components by min-label hooking on the GPU (cc_kernels).
 int component_medians(rala_hip_ctx* ctx, std::vector<uint32_t>& members, std::vector<uint16_t>& med_of_member) {
-    const uint64_t n = ctx->n_reads;
     const size_t m = ctx->overlaps.size();
     members.clear();
     med_of_member.clear();
     if (m == 0) return RALA_HIP_OK;
     hipStream_t s = ctx->stream;
-    std::vector<uint32_t> edges(2 * m);
-    std::vector<uint8_t> touched(n, 0);
-    ctx->pool->chunks(m, [&](unsigned, size_t b, size_t e) {
-        for (size_t k = b; k < e; ++k) {
+    // work on the ranks of the reads that were alive after the second pass (about a tenth of all)
+    const std::vector<uint32_t>& rank = ctx->alive_rank;
+    const std::vector<uint32_t>& reads = ctx->alive_reads;
+    const size_t na = reads.size();
+    HIPCHECK(ctx->p_cc_edges.ensure(2 * m));
+    HIPCHECK(ctx->p_cc_label.ensure(na));
+    uint32_t* edges = ctx->p_cc_edges.p;
+    std::vector<uint8_t>& touched = ctx->scratch_touched;
+    touched.assign(na, 0);
+    ctx->pool->chunks(m, [&](unsigned, size_t b0, size_t e0) {
+        for (size_t k = b0; k < e0; ++k) {
             const HostOvl& o = ctx->overlaps[k];
             if (o.dead) { edges[2 * k] = 0; edges[2 * k + 1] = 0; continue; }      // harmless self loop
-            edges[2 * k] = o.a; edges[2 * k + 1] = o.b;
-            touched[o.a] = 1; touched[o.b] = 1;
+            const uint32_t ra = rank[o.a], rb = rank[o.b];
+            edges[2 * k] = ra; edges[2 * k + 1] = rb;
+            touched[ra] = 1; touched[rb] = 1;
         }
     });
     HIPCHECK(ctx->d_cc_edges.ensure(2 * m));
-    HIPCHECK(ctx->d_cc_label.ensure(n));
-    HIPCHECK(hipMemcpyAsync(ctx->d_cc_edges.p, edges.data(), 2 * m * 4, hipMemcpyHostToDevice, s));
-    launch_cc_init(ctx->d_cc_label.p, (uint32_t)n, s);
+    HIPCHECK(ctx->d_cc_label.ensure(na));
+    HIPCHECK(hipMemcpyAsync(ctx->d_cc_edges.p, edges, 2 * m * 4, hipMemcpyHostToDevice, s));
+    launch_cc_init(ctx->d_cc_label.p, (uint32_t)na, s);
     for (int round = 0;; ++round) {
         HIPCHECK(hipMemsetAsync(ctx->d_small.p + 2, 0, 4, s));
-        launch_cc_hook(ctx->d_cc_edges.p, (uint32_t)m, ctx->d_cc_label.p, ctx->d_small.p + 2, s);
-        launch_cc_compress(ctx->d_cc_label.p, (uint32_t)n, s);
+        for (int it = 0; it < 4; ++it) {          // several hook + jump steps per host round trip
+            launch_cc_hook(ctx->d_cc_edges.p, (uint32_t)m, ctx->d_cc_label.p, ctx->d_small.p + 2, s);
+            launch_cc_compress(ctx->d_cc_label.p, (uint32_t)na, s);
+        }
         uint32_t changed = 0;
         HIPCHECK(hipMemcpyAsync(&changed, ctx->d_small.p + 2, 4, hipMemcpyDeviceToHost, s));
         HIPCHECK(hipStreamSynchronize(s));
         if (!changed) break;
         if (round > 10000) return fail(ctx, RALA_HIP_EDEVICE, "connected components did not converge");
     }
-    std::vector<uint32_t> label(n);
-    HIPCHECK(hipMemcpy(label.data(), ctx->d_cc_label.p, n * 4, hipMemcpyDeviceToHost));
-    // members = reads with at least one overlap; group them by label (counting sort)
-    for (uint64_t r = 0; r < n; ++r) if (touched[r]) members.push_back((uint32_t)r);
-    std::vector<uint32_t> cnt(n + 1, 0);
-    for (uint32_t r : members) ++cnt[label[r] + 1];
-    for (uint64_t r = 0; r < n; ++r) cnt[r + 1] += cnt[r];
+    uint32_t* label = ctx->p_cc_label.p;
+    HIPCHECK(hipMemcpyAsync(label, ctx->d_cc_label.p, na * 4, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipStreamSynchronize(s));
+    // members = reads with at least one overlap, in read order; grouped by label (counting sort)
+    std::vector<uint32_t>& mrank = ctx->scratch_u32a;
+    mrank.clear();
+    for (size_t q = 0; q < na; ++q) if (touched[q]) { members.push_back(reads[q]); mrank.push_back((uint32_t)q); }
+    std::vector<uint32_t>& cnt = ctx->scratch_u32b;
+    cnt.assign(na + 1, 0);
+    for (uint32_t q : mrank) ++cnt[label[q] + 1];
+    for (size_t q = 0; q < na; ++q) cnt[q + 1] += cnt[q];
     std::vector<uint32_t> idx(members.size());
-    {
-        std::vector<uint32_t> cur(cnt.begin(), cnt.end() - 1);
-        for (size_t k = 0; k < members.size(); ++k) idx[cur[label[members[k]]]++] = (uint32_t)k;
-    }
+    for (size_t k = 0; k < members.size(); ++k) idx[cnt[label[mrank[k]]]++] = (uint32_t)k;
     med_of_member.assign(members.size(), 0);
     std::vector<uint16_t> mm;
     for (size_t b0 = 0; b0 < idx.size();) {
-        const uint32_t lab = label[members[idx[b0]]];
+        const uint32_t lab = label[mrank[idx[b0]]];
         size_t t = b0;
         mm.clear();
-        while (t < idx.size() && label[members[idx[t]]] == lab) { mm.push_back(ctx->h_median[members[idx[t]]]); ++t; }
+        while (t < idx.size() && label[mrank[idx[t]]] == lab) { mm.push_back(ctx->h_median[members[idx[t]]]); ++t; }
         std::nth_element(mm.begin(), mm.begin() + mm.size() / 2, mm.end());
         const uint16_t med = mm[mm.size() / 2];
         for (size_t k = b0; k < t; ++k) med_of_member[idx[k]] = med;
@@ -301,14 +316,23 @@ int preprocess_chimeras(rala_hip_ctx* ctx) {
     ctx->dirty.assign(n, 0);
     ctx->ever_dirty.assign(n, 0);
     ctx->dirty_list.clear();
-    std::vector<uint8_t> n_pits0(ctx->h_n_pits);     // hills sit behind the initial pits
-    // break over chimeric hills (graph.cpp:704-720)
+    ctx->alive_rank.assign(n, 0xFFFFFFFFu);
+    ctx->alive_reads.clear();
     for (uint64_t r = 0; r < n; ++r) {
-        if (!ctx->h_alive[r] || ctx->h_n_hills[r] == 0) continue;
+        if (!ctx->h_alive[r]) continue;
+        ctx->alive_rank[r] = (uint32_t)ctx->alive_reads.size();
+        ctx->alive_reads.push_back((uint32_t)r);
+    }
+    const std::vector<uint8_t>& n_pits0 = ctx->h_n_pits0;     // hills sit behind the initial pits
+    ctx->h_n_pits0 = ctx->h_n_pits;
+    // break over chimeric hills (graph.cpp:704-720)
+    for (uint32_t r : ctx->alive_reads) {
+        if (ctx->h_n_hills[r] == 0) continue;
         const Interval* hills = ctx->h_pool.data() + ctx->h_slot[r] + n_pits0[r];
         if (!break_hills(ctx, (uint32_t)r, hills, ctx->h_n_hills[r])) ctx->h_alive[r] = 0;
         ctx->h_n_hills[r] = 0;
     }
+    collect_dirty(ctx, ctx->alive_reads);
     tr("break hills", ctx->dirty_list.size());
     retrim(ctx, ctx->overlaps);      // :722-728
     retrim(ctx, ctx->internals);     // :730-736
@@ -321,12 +345,15 @@ int preprocess_chimeras(rala_hip_ctx* ctx) {
         const int rc = component_medians(ctx, members, med);
         if (rc != RALA_HIP_OK) return rc;
         tr("component medians", members.size());
-        for (size_t k = 0; k < members.size(); ++k) {
-            const uint32_t r = members[k];
-            if (ctx->h_n_pits[r] == 0) continue;     // no pits: shrink(begin, end) is a no-op
-            Interval* pits = ctx->h_pool.data() + ctx->h_slot[r];
-            if (!break_pits(ctx, r, pits, ctx->h_n_pits[r], med[k])) ctx->h_alive[r] = 0;
-        }
+        ctx->pool->chunks(members.size(), [&](unsigned, size_t b0, size_t e0) {
+            for (size_t k = b0; k < e0; ++k) {
+                const uint32_t r = members[k];
+                if (ctx->h_n_pits[r] == 0) continue;     // no pits: shrink(begin, end) is a no-op
+                Interval* pits = ctx->h_pool.data() + ctx->h_slot[r];
+                if (!break_pits(ctx, r, pits, ctx->h_n_pits[r], med[k])) ctx->h_alive[r] = 0;
+            }
+        });
+        collect_dirty(ctx, members);
         const bool changed = retrim(ctx, ctx->overlaps) != 0;
         // internals whose reads moved: trim again; the ones that became dovetails join the
         // overlaps, in internals order (graph.cpp:809-824)

@@ -1,6 +1,6 @@
 """Diagnostic: cumulative time of the pile kernel's phases (stop_after sweep) on c2."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rala_amd import hip
 from rala_amd.synth import Dataset
 wl = sys.argv[1] if len(sys.argv) > 1 else "c2"
