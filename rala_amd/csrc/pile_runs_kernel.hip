@@ -33,8 +33,7 @@ namespace rala_hip {
 namespace {
 
 constexpr uint32_t kNone = 0xFFFFFFFFu;
-constexpr uint32_t kMaxReg = 64;       // regions per (q, kind) list
-constexpr uint32_t kMaxRaw = 32;       // pits / hills before the merge
+constexpr uint16_t kNone16 = 0xFFFFu;
 constexpr uint32_t kIdx = 512;         // entries of the position -> run index
 
 __device__ __forceinline__ void wave_sync() { __syncthreads(); }   // workgroup == one wavefront
@@ -264,13 +263,15 @@ __device__ __forceinline__ void load_sort_store(const uint32_t* __restrict__ gev
 
 template <uint32_t kCap>
 struct Layout {
-    static constexpr uint32_t kArr = kCap + 4;                  // words per run-indexed array
-    static constexpr uint32_t A = 0;                            // events (sort) -> down end, q = 1.3
-    static constexpr uint32_t RS = A + kArr;                    // run starts (+ sentinel)
-    static constexpr uint32_t D = RS + kArr;                    // histograms (D..F) -> up start 1.3
-    static constexpr uint32_t E = D + kArr;                     // down end 1.82
-    static constexpr uint32_t F = E + kArr;                     // up start 1.82
-    static constexpr uint32_t RV = F + kArr;                    // run values, uint16 (kArr / 2 words)
+    // list capacities: a read that needs more goes to the next kernel of the chain
+    static constexpr uint32_t kMaxReg = kCap <= 512 ? 32 : 64;   // regions per (q, kind) list
+    static constexpr uint32_t kMaxRaw = kCap <= 512 ? 16 : 32;   // pits / hills before the merge
+    static constexpr uint32_t kArr = kCap + 4;                  // entries per run-indexed array
+    // X: events (sort) -> group counts -> histograms -> the four uint16 interval arrays
+    static constexpr uint32_t X = 0;
+    static constexpr uint32_t kX = 2 * kArr > 768 ? 2 * kArr : 768;
+    static constexpr uint32_t RS = X + kX;                      // run starts (+ sentinel)
+    static constexpr uint32_t RV = RS + kArr;                   // run values, uint16 (kArr / 2 words)
     static constexpr uint32_t IDX = RV + kArr / 2;              // kIdx uint16
     static constexpr uint32_t RF = IDX + kIdx / 2;              // 4 lists x kMaxReg firsts
     static constexpr uint32_t RL = RF + 4 * kMaxReg;            // 4 lists x kMaxReg lasts
@@ -281,7 +282,7 @@ struct Layout {
     static constexpr uint32_t CAND = GONE + (2 * kMaxRaw) / 4;  // kMaxRaw hill candidates (i << 16 | j)
     static constexpr uint32_t SEL = CAND + kMaxRaw;             // 16 words
     static constexpr uint32_t WORDS = SEL + 16;
-    static_assert(3 * kArr >= 768, "histograms must fit in arrays D..F");
+    static_assert(kX >= kCap && kX >= kIdx, "shared region too small");
 };
 
 }  // namespace
@@ -289,9 +290,10 @@ struct Layout {
 template <uint32_t kCap>
 __global__ __launch_bounds__(64) void pile_runs_kernel(PileArgs A, uint32_t* overflow_list, uint32_t* overflow_count) {
     typedef Layout<kCap> L;
+    constexpr uint32_t kMaxReg = L::kMaxReg, kMaxRaw = L::kMaxRaw;
     __shared__ __align__(16) uint32_t sm[L::WORDS];
     const uint32_t lane = threadIdx.x;
-    uint32_t* ev = sm + L::A;
+    uint32_t* ev = sm + L::X;
     uint32_t* rs = sm + L::RS;
     uint16_t* rv = (uint16_t*)(sm + L::RV);
     uint16_t* idx = (uint16_t*)(sm + L::IDX);
@@ -441,7 +443,7 @@ __global__ __launch_bounds__(64) void pile_runs_kernel(PileArgs A, uint32_t* ove
         while ((n >> shift) >= kIdx) ++shift;
         const uint32_t ng = ((n - 1) >> shift) + 1;
         {
-            uint32_t* gcnt = sm + L::D;                 // free until the histograms of step 5
+            uint32_t* gcnt = sm + L::X;                 // the sorted events are no longer needed
             for (uint32_t m = lane; m < ng; m += 64) gcnt[m] = 0;
             wave_sync();
             const uint32_t round_up = (1u << shift) - 1u;
@@ -511,7 +513,7 @@ __global__ __launch_bounds__(64) void pile_runs_kernel(PileArgs A, uint32_t* ove
         // ---- 5. order statistics over (value, length) of the runs in [kB, kE) --------------
         uint32_t med, p10;
         {
-            uint32_t* hist = sm + L::D;
+            uint32_t* hist = sm + L::X;
             for (uint32_t j = lane; j < 768; j += 64) hist[j] = 0;
             wave_sync();
             for (uint32_t k = kB + lane; k < kE; k += 64) atomicAdd(&hist[rv[k] >> 8], rs[k + 1] - rs[k]);
@@ -564,10 +566,12 @@ __global__ __launch_bounds__(64) void pile_runs_kernel(PileArgs A, uint32_t* ove
         // down(i), i in run k  <=>  some run j < k with value > t(v_k) reaches into
         // [i-847, i-1]  <=>  i <= end_j + 846 for the nearest such j;   up(i) likewise
         // with the nearest j > k: i >= start_j - 847.   t(v) = int32(v * q)  (pile.cpp:94)
-        uint32_t* d13 = sm + L::A;
-        uint32_t* u13 = sm + L::D;
-        uint32_t* d182 = sm + L::E;
-        uint32_t* u182 = sm + L::F;
+        // stored as uint16 offsets (<= 846): down = last flagged - run start, up = run end - 1 -
+        // first flagged; kNone16 = nothing flagged
+        uint16_t* d13 = (uint16_t*)(sm + L::X);
+        uint16_t* u13 = d13 + L::kArr;
+        uint16_t* d182 = u13 + L::kArr;
+        uint16_t* u182 = d182 + L::kArr;
         for (uint32_t k = lane; k < R; k += 64) {
             const uint32_t v = rv[k];
             const uint32_t sk = rs[k], ek = rs[k + 1];
@@ -615,7 +619,10 @@ __global__ __launch_bounds__(64) void pile_runs_kernel(PileArgs A, uint32_t* ove
                     }
                 }
             }
-            d13[k] = dl13; u13[k] = ur13; d182[k] = dl182; u182[k] = ur182;
+            d13[k] = dl13 == kNone ? kNone16 : (uint16_t)(dl13 - sk);
+            u13[k] = ur13 == kNone ? kNone16 : (uint16_t)(ek - 1 - ur13);
+            d182[k] = dl182 == kNone ? kNone16 : (uint16_t)(dl182 - sk);
+            u182[k] = ur182 == kNone ? kNone16 : (uint16_t)(ek - 1 - ur182);
         }
         wave_sync();
         RUN_STOP(26)
@@ -623,7 +630,7 @@ __global__ __launch_bounds__(64) void pile_runs_kernel(PileArgs A, uint32_t* ove
         // ---- 7. maximal unions of touching intervals -> regions (first, last) ----------------
 #pragma unroll 1
         for (uint32_t w = 0; w < 4; ++w) {
-            const uint32_t* iv = (w == 0) ? d13 : (w == 1) ? u13 : (w == 2) ? d182 : u182;
+            const uint16_t* iv = (w == 0) ? d13 : (w == 1) ? u13 : (w == 2) ? d182 : u182;
             const bool is_up = w & 1;
             uint32_t* rf = sm + L::RF + w * kMaxReg;
             uint32_t* rl = sm + L::RL + w * kMaxReg;
@@ -632,20 +639,22 @@ __global__ __launch_bounds__(64) void pile_runs_kernel(PileArgs A, uint32_t* ove
                 const uint32_t k = k0 + lane;
                 bool st = false, en = false;
                 uint32_t fv = 0, lv = 0;
-                if (k < R && iv[k] != kNone) {
+                if (k < R && iv[k] != kNone16) {
                     const uint32_t sk = rs[k], ek = rs[k + 1];
                     if (!is_up) {
-                        // interval [sk, iv[k]]
-                        const bool prev_joins = k > 0 && iv[k - 1] != kNone && iv[k - 1] == sk - 1;
-                        const bool next_joins = iv[k] == ek - 1 && k + 1 < R && iv[k + 1] != kNone;
+                        // interval [sk, sk + iv[k]]
+                        const uint32_t last_k = sk + iv[k];
+                        const bool prev_joins = k > 0 && iv[k - 1] != kNone16 && rs[k - 1] + iv[k - 1] == sk - 1;
+                        const bool next_joins = last_k == ek - 1 && k + 1 < R && iv[k + 1] != kNone16;
                         st = !prev_joins; en = !next_joins;
-                        fv = sk; lv = iv[k];
+                        fv = sk; lv = last_k;
                     } else {
-                        // interval [iv[k], ek - 1]
-                        const bool prev_joins = iv[k] == sk && k > 0 && iv[k - 1] != kNone;
-                        const bool next_joins = k + 1 < R && iv[k + 1] != kNone && iv[k + 1] == ek;
+                        // interval [ek - 1 - iv[k], ek - 1]
+                        const uint32_t first_k = ek - 1 - iv[k];
+                        const bool prev_joins = first_k == sk && k > 0 && iv[k - 1] != kNone16;
+                        const bool next_joins = k + 1 < R && iv[k + 1] != kNone16 && rs[k + 2] - 1 - iv[k + 1] == ek;
                         st = !prev_joins; en = !next_joins;
-                        fv = iv[k]; lv = ek - 1;
+                        fv = first_k; lv = ek - 1;
                     }
                 }
                 const uint64_t ms = __ballot(st), me = __ballot(en);
@@ -816,9 +825,15 @@ __global__ __launch_bounds__(64) void pile_runs_kernel(PileArgs A, uint32_t* ove
         RUN_STOP(28)
 
         // ---- 9. publish ----------------------------------------------------------------------------
+        if (any_overflow) {
+            // more regions / raw intervals than this instantiation keeps: hand the read on
+            if (lane == 0) overflow_list[atomicAdd(overflow_count, 1u)] = r;
+            wave_sync();
+            continue;
+        }
         if (lane == 0) {
             const uint32_t nh = sel[8], np = sel[9];
-            uint32_t err = any_overflow ? kErrRegionCapacity : 0;
+            uint32_t err = 0;
             uint32_t slot = kNone;
             uint32_t wp = err ? 0 : np, wh = err ? 0 : nh;
             if (wp + wh) {
