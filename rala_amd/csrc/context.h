@@ -159,6 +159,20 @@ struct rala_hip_ctx {
     std::vector<rala_hip::Interval> h_rep_pool;
     bool have_repeats = false;
 
+    // device-resident tail (tail_kernels.hip)
+    bool use_gpu_tail = true;
+    bool tail_on_device = false;          // results of the last construct live on the device
+    bool host_stale = false;              // host mirrors (lists, graph, read state) need a download
+    bool marks_on_device = false;         // transitive marks of the device graph not fetched yet
+    uint32_t t_n0 = 0, t_n1 = 0, t_rounds = 0, t_n_kept = 0, t_n_nodes = 0, t_n_edges = 0;
+    rala_hip::DevBuf<uint8_t> d_t_state, d_t_round, d_dirty, d_n_pits0, d_touched;
+    rala_hip::DevBuf<uint16_t> d_cmed;
+    rala_hip::DevBuf<uint32_t> d_rank, d_alive_reads, d_t_tmp[2], d_kept_item, d_dovetail, d_epos, d_node_rank,
+        d_node_read, d_e[3], d_t_death[2];
+    rala_hip::PinnedBuf<uint32_t> p_alive_reads;
+    rala_hip::PinnedBuf<uint8_t> p_touched;
+    rala_hip::PinnedBuf<uint16_t> p_cmed;
+
     // host tail
     std::vector<uint8_t> dirty, ever_dirty;       // reads whose valid region changed (this round / ever)
     std::vector<uint32_t> dirty_list;
@@ -168,7 +182,7 @@ struct rala_hip_ctx {
     std::vector<rala_hip::HostOvl> overlaps, internals, scratch_ovl;
     std::vector<rala_hip::EdgePair> scratch_ep;
     std::vector<uint8_t> scratch_has, scratch_touched, h_n_pits0;
-    std::vector<uint32_t> scratch_u32a, scratch_u32b, alive_rank, alive_reads;
+    std::vector<uint32_t> scratch_u32a, scratch_u32b, scratch_u32c, alive_rank, alive_reads;
     rala_hip::PinnedBuf<uint32_t> p_cc_edges, p_cc_label;
     std::vector<uint32_t> node_read;
     std::vector<uint32_t> e_src, e_dst, e_len;

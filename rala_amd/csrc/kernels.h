@@ -141,6 +141,44 @@ struct Survivors {
 void launch_gather_survivors(const OvlSoA& o, const uint8_t* cls, const ReadState& rs, const uint32_t* flag,
                              const uint32_t* pos, const Survivors& out, hipStream_t s);
 
+// ---- preprocess tail on device-resident lists (tail_kernels.hip) -------------------
+struct TailList {               // survivors of the second pass: overlaps first, then internals
+    uint32_t n;
+    uint32_t *src, *a, *b, *a_begin, *a_end, *b_begin, *b_end, *length;
+    uint8_t *strand, *type;
+    uint8_t* state;             // 0 dead, 1 overlap, 2 internal, 3 internal promoted to overlap
+    uint8_t* round;             // round of the promotion
+};
+struct TailReads {
+    uint32_t *begin, *end;
+    uint8_t *alive, *dirty, *n_pits, *n_hills;
+    const uint8_t* n_pits0;     // pit count the pile kernel wrote (hills sit behind those pits)
+    const uint32_t* iv_slot;
+    Interval* pool;
+};
+void launch_break_hills(const TailReads& R, uint32_t n_reads, hipStream_t s);
+void launch_break_pits(const TailReads& R, const uint32_t* alive_reads, const uint8_t* touched, const uint16_t* comp_median,
+                       uint32_t n_alive, hipStream_t s);
+void launch_retrim(const TailList& L, const TailReads& R, uint32_t promote, uint32_t round, uint32_t* dropped,
+                   hipStream_t s);
+void launch_cc_edges(const TailList& L, const uint32_t* rank, uint32_t* edges, uint8_t* touched, hipStream_t s);
+void launch_refresh_types(const TailList& L, const TailReads& R, hipStream_t s);
+void launch_tail_death_round(const TailList& L, const uint8_t* alive, uint32_t which, const uint32_t* death_old,
+                             uint32_t* death_new, hipStream_t s);
+void launch_tail_apply_scan(const TailList& L, const uint8_t* alive, uint32_t which, const uint32_t* death, hipStream_t s);
+void launch_kill_reads(const uint32_t* death, uint8_t* alive, uint32_t n, hipStream_t s);
+void launch_keep_flags(const TailList& L, const uint8_t* alive, uint32_t want_state, uint32_t want_round, uint32_t* flag,
+                       hipStream_t s);
+void launch_u8_to_u32(const uint8_t* in, uint32_t* out, uint32_t n, hipStream_t s);
+void launch_ranks(const uint8_t* alive, const uint32_t* pos, uint32_t* rank, uint32_t* alive_reads, uint32_t n, hipStream_t s);
+void launch_place_kept(const TailList& L, const TailReads& R, const uint32_t* flag, const uint32_t* pos, uint32_t base,
+                       uint32_t* kept_item, uint32_t* dovetail, hipStream_t s);
+void launch_build_edges(const TailList& L, const TailReads& R, const uint32_t* kept_item, const uint32_t* dovetail,
+                        const uint32_t* epos, uint32_t n_kept, const uint32_t* node_rank, uint32_t* e_src, uint32_t* e_dst,
+                        uint32_t* e_len, hipStream_t s);
+void launch_node_reads(const uint8_t* alive, const uint32_t* rank, uint32_t* node_read, uint32_t n, hipStream_t s);
+void launch_init_list_state(uint8_t* state, uint8_t* round, uint32_t n0, uint32_t n, hipStream_t s);
+
 // ---- scans (scan_kernels.hip) --------------------------------------------------
 // exclusive prefix sum of n uint32 values; out may alias in; out[n] receives the total
 size_t scan_workspace_bytes(uint64_t n);

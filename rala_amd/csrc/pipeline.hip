@@ -364,7 +364,8 @@ int preprocess_chimeras(rala_hip_ctx* ctx) {
             ctx->pool->chunks(in.size(), [&](unsigned t, size_t b, size_t e) {
                 for (size_t k = b; k < e; ++k) {
                     HostOvl& o = in[k];
-                    if (o.dead || !(dirty[o.a] | dirty[o.b])) continue;      // still trimmed and still kX
+                    // untouched since it was classified: still trimmed and still kX
+                    if (o.dead || !((dirty[o.a] | dirty[o.b]) || o.type == 255)) continue;
                     if (!host_trim(ctx, o)) { o.dead = 1; continue; }
                     o.type = (uint8_t)host_type(ctx, o);
                     if (o.type == kTypeAB || o.type == kTypeBA) promoted[t].push_back((uint32_t)k);
@@ -676,20 +677,17 @@ void build_graph(rala_hip_ctx* ctx) {
     ctx->e_mark.assign(ne, 0);
 }
 
-int tr_mark_impl(rala_hip_ctx* ctx, uint32_t n_nodes, uint32_t n_edges, const uint32_t* src, const uint32_t* dst,
-                 const uint32_t* len, uint8_t* marks, uint32_t* n_pairs) {
+// transitive-edge marking on device edge arrays; marks stay in ctx->d_tr_marks
+int tr_mark_device(rala_hip_ctx* ctx, uint32_t n_nodes, uint32_t n_edges, const uint32_t* d_src, const uint32_t* d_dst,
+                   const uint32_t* d_len, uint32_t* n_pairs) {
     *n_pairs = 0;
     if (n_edges == 0) return RALA_HIP_OK;
     if (n_edges & 1) return fail(ctx, RALA_HIP_EINVAL, "edges must come in twin pairs (e, e^1)");
     hipStream_t s = ctx->stream;
-    DevBuf<uint32_t>* B = ctx->d_tr;          // row, cursor, adj, src, dst, len (persistent)
+    DevBuf<uint32_t>* B = ctx->d_tr;          // row, cursor, adj (persistent)
     HIPCHECK(B[0].ensure(n_nodes + 2)); HIPCHECK(B[1].ensure(n_nodes + 2)); HIPCHECK(B[2].ensure(n_edges));
-    HIPCHECK(B[3].ensure(n_edges)); HIPCHECK(B[4].ensure(n_edges)); HIPCHECK(B[5].ensure(n_edges));
     HIPCHECK(ctx->d_tr_marks.ensure(n_edges));
     HIPCHECK(ctx->d_scan_ws.ensure(scan_workspace_bytes((uint64_t)n_nodes + 2)));
-    HIPCHECK(hipMemcpyAsync(B[3].p, src, (size_t)n_edges * 4, hipMemcpyHostToDevice, s));
-    HIPCHECK(hipMemcpyAsync(B[4].p, dst, (size_t)n_edges * 4, hipMemcpyHostToDevice, s));
-    HIPCHECK(hipMemcpyAsync(B[5].p, len, (size_t)n_edges * 4, hipMemcpyHostToDevice, s));
     HIPCHECK(hipMemsetAsync(ctx->d_tr_marks.p, 0, n_edges, s));
     HIPCHECK(hipMemsetAsync(ctx->d_small.p + 2, 0, 8, s));           // [2] bad endpoint flag [3] pairs
     HIPCHECK(hipMemsetAsync(B[1].p, 0, (size_t)(n_nodes + 1) * 4, s));
@@ -697,21 +695,271 @@ int tr_mark_impl(rala_hip_ctx* ctx, uint32_t n_nodes, uint32_t n_edges, const ui
     // CSR on the device: out-degree count -> scan -> fill.  The fill order is arbitrary; the
     // candidate a->c is the edge with the highest id, which is the reference's "last one
     // in suffix_edges_" (graph.cpp:1291-1293, out-lists are in edge-id order there).
-    launch_tr_degree(B[3].p, B[4].p, n_nodes, n_edges, B[1].p, ctx->d_small.p + 2, s);
+    launch_tr_degree(d_src, d_dst, n_nodes, n_edges, B[1].p, ctx->d_small.p + 2, s);
     launch_exclusive_scan(B[1].p, B[0].p, n_nodes, ctx->d_scan_ws.p, s);
     HIPCHECK(hipMemcpyAsync(B[1].p, B[0].p, (size_t)n_nodes * 4, hipMemcpyDeviceToDevice, s));
-    launch_tr_fill(B[3].p, n_nodes, n_edges, B[1].p, B[2].p, s);
-    launch_tr_mark(B[0].p, B[2].p, B[3].p, B[4].p, B[5].p, n_nodes, n_edges, ctx->d_tr_marks.p, s);
+    launch_tr_fill(d_src, n_nodes, n_edges, B[1].p, B[2].p, s);
+    launch_tr_mark(B[0].p, B[2].p, d_src, d_dst, d_len, n_nodes, n_edges, ctx->d_tr_marks.p, s);
     launch_tr_count(ctx->d_tr_marks.p, n_edges, ctx->d_small.p + 3, s);
     HIPCHECK(hipEventRecord(ctx->ev[11], s));
     uint32_t res[2] = {0, 0};
-    HIPCHECK(hipMemcpyAsync(marks, ctx->d_tr_marks.p, n_edges, hipMemcpyDeviceToHost, s));
     HIPCHECK(hipMemcpyAsync(res, ctx->d_small.p + 2, 8, hipMemcpyDeviceToHost, s));
     HIPCHECK(hipStreamSynchronize(s));
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipEventElapsedTime(&ctx->tm.tr_ms, ctx->ev[10], ctx->ev[11]));
     if (res[0]) return fail(ctx, RALA_HIP_EINVAL, "edge endpoint out of range");
     *n_pairs = res[1];
+    return RALA_HIP_OK;
+}
+
+int tr_mark_impl(rala_hip_ctx* ctx, uint32_t n_nodes, uint32_t n_edges, const uint32_t* src, const uint32_t* dst,
+                 const uint32_t* len, uint8_t* marks, uint32_t* n_pairs) {
+    *n_pairs = 0;
+    if (n_edges == 0) return RALA_HIP_OK;
+    hipStream_t s = ctx->stream;
+    DevBuf<uint32_t>* B = ctx->d_tr;
+    HIPCHECK(B[3].ensure(n_edges)); HIPCHECK(B[4].ensure(n_edges)); HIPCHECK(B[5].ensure(n_edges));
+    HIPCHECK(hipMemcpyAsync(B[3].p, src, (size_t)n_edges * 4, hipMemcpyHostToDevice, s));
+    HIPCHECK(hipMemcpyAsync(B[4].p, dst, (size_t)n_edges * 4, hipMemcpyHostToDevice, s));
+    HIPCHECK(hipMemcpyAsync(B[5].p, len, (size_t)n_edges * 4, hipMemcpyHostToDevice, s));
+    const int rc = tr_mark_device(ctx, n_nodes, n_edges, B[3].p, B[4].p, B[5].p, n_pairs);
+    if (rc != RALA_HIP_OK) return rc;
+    HIPCHECK(hipMemcpy(marks, ctx->d_tr_marks.p, n_edges, hipMemcpyDeviceToHost));
+    return RALA_HIP_OK;
+}
+
+// ---- preprocess tail on the device (tail_kernels.hip) ---------------------------------------
+TailList tail_list(rala_hip_ctx* ctx) {
+    TailList L;
+    L.n = ctx->t_n0 + ctx->t_n1;
+    L.src = ctx->d_surv_u32[0].p; L.a = ctx->d_surv_u32[1].p; L.b = ctx->d_surv_u32[2].p;
+    L.a_begin = ctx->d_surv_u32[3].p; L.a_end = ctx->d_surv_u32[4].p; L.b_begin = ctx->d_surv_u32[5].p;
+    L.b_end = ctx->d_surv_u32[6].p; L.length = ctx->d_surv_u32[7].p;
+    L.strand = ctx->d_surv_u8[0].p; L.type = ctx->d_surv_u8[1].p;
+    L.state = ctx->d_t_state.p; L.round = ctx->d_t_round.p;
+    return L;
+}
+
+TailReads tail_reads(rala_hip_ctx* ctx) {
+    TailReads R;
+    R.begin = ctx->d_begin.p; R.end = ctx->d_end.p; R.alive = ctx->d_alive.p; R.dirty = ctx->d_dirty.p;
+    R.n_pits = ctx->d_n_pits.p; R.n_hills = ctx->d_n_hills.p; R.n_pits0 = ctx->d_n_pits0.p;
+    R.iv_slot = ctx->d_iv_slot.p; R.pool = ctx->d_pool.p;
+    return R;
+}
+
+// fixed point of the in-order containment removal over one class of items
+int tail_death_scan(rala_hip_ctx* ctx, const TailList& L, uint32_t which, uint32_t** death_out) {
+    hipStream_t s = ctx->stream;
+    const uint32_t n_reads = (uint32_t)ctx->n_reads;
+    int cur = 0;
+    HIPCHECK(hipMemsetAsync(ctx->d_t_death[0].p, 0xFF, (size_t)n_reads * 4, s));
+    for (int round = 0;; ++round) {
+        HIPCHECK(hipMemsetAsync(ctx->d_t_death[cur ^ 1].p, 0xFF, (size_t)n_reads * 4, s));
+        HIPCHECK(hipMemsetAsync(ctx->d_small.p + 2, 0, 4, s));
+        launch_tail_death_round(L, ctx->d_alive.p, which, ctx->d_t_death[cur].p, ctx->d_t_death[cur ^ 1].p, s);
+        launch_death_diff(ctx->d_t_death[cur].p, ctx->d_t_death[cur ^ 1].p, n_reads, ctx->d_small.p + 2, s);
+        uint32_t changed = 0;
+        HIPCHECK(hipMemcpyAsync(&changed, ctx->d_small.p + 2, 4, hipMemcpyDeviceToHost, s));
+        HIPCHECK(hipStreamSynchronize(s));
+        cur ^= 1;
+        if (!changed) break;
+        if (round > 100000) return fail(ctx, RALA_HIP_EDEVICE, "containment fixed point did not converge");
+    }
+    *death_out = ctx->d_t_death[cur].p;
+    return RALA_HIP_OK;
+}
+
+// Graph::preprocess (chimeras) + node/edge build with the survivor lists resident on the device
+int gpu_tail_run(rala_hip_ctx* ctx) {
+    hipStream_t s = ctx->stream;
+    const uint32_t n_reads = (uint32_t)ctx->n_reads;
+    const uint32_t M = ctx->t_n0 + ctx->t_n1;
+    const size_t big = (size_t)std::max<uint64_t>(n_reads, M) + 2;
+    HIPCHECK(ctx->d_t_state.ensure(M)); HIPCHECK(ctx->d_t_round.ensure(M));
+    HIPCHECK(ctx->d_dirty.ensure(n_reads)); HIPCHECK(ctx->d_n_pits0.ensure(n_reads));
+    HIPCHECK(ctx->d_rank.ensure(n_reads)); HIPCHECK(ctx->d_alive_reads.ensure(n_reads));
+    HIPCHECK(ctx->d_t_tmp[0].ensure(big)); HIPCHECK(ctx->d_t_tmp[1].ensure(big));
+    HIPCHECK(ctx->d_kept_item.ensure(M)); HIPCHECK(ctx->d_dovetail.ensure(M + 1)); HIPCHECK(ctx->d_epos.ensure(M + 2));
+    HIPCHECK(ctx->d_node_rank.ensure(n_reads + 2)); HIPCHECK(ctx->d_t_death[0].ensure(n_reads));
+    HIPCHECK(ctx->d_t_death[1].ensure(n_reads));
+    HIPCHECK(ctx->d_scan_ws.ensure(scan_workspace_bytes(big)));
+    if ((uint64_t)M * 258ull >= 0xFFFFFFFFull) return fail(ctx, RALA_HIP_EINVAL, "too many surviving overlaps");
+    const TailList L = tail_list(ctx);
+    const TailReads R = tail_reads(ctx);
+    launch_init_list_state(L.state, L.round, ctx->t_n0, M, s);
+    HIPCHECK(hipMemsetAsync(ctx->d_dirty.p, 0, n_reads, s));
+    HIPCHECK(hipMemcpyAsync(ctx->d_n_pits0.p, ctx->d_n_pits.p, n_reads, hipMemcpyDeviceToDevice, s));
+    // ranks of the reads that survived the second pass (the component graph lives on them)
+    launch_u8_to_u32(ctx->d_alive.p, ctx->d_t_tmp[0].p, n_reads, s);
+    launch_exclusive_scan(ctx->d_t_tmp[0].p, ctx->d_t_tmp[1].p, n_reads, ctx->d_scan_ws.p, s);
+    launch_ranks(ctx->d_alive.p, ctx->d_t_tmp[1].p, ctx->d_rank.p, ctx->d_alive_reads.p, n_reads, s);
+    uint32_t n_alive = 0;
+    HIPCHECK(hipMemcpyAsync(&n_alive, ctx->d_t_tmp[1].p + n_reads, 4, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipStreamSynchronize(s));
+    HIPCHECK(ctx->p_alive_reads.ensure(n_alive)); HIPCHECK(ctx->p_touched.ensure(n_alive));
+    HIPCHECK(ctx->p_cmed.ensure(n_alive)); HIPCHECK(ctx->p_cc_label.ensure(n_alive));
+    HIPCHECK(ctx->d_touched.ensure(n_alive)); HIPCHECK(ctx->d_cmed.ensure(n_alive));
+    HIPCHECK(ctx->d_cc_edges.ensure(2 * (size_t)M)); HIPCHECK(ctx->d_cc_label.ensure(n_alive));
+    HIPCHECK(hipMemcpyAsync(ctx->p_alive_reads.p, ctx->d_alive_reads.p, (size_t)n_alive * 4, hipMemcpyDeviceToHost, s));
+
+    // break over chimeric hills, first re-trim (graph.cpp:704-736; no promotion here)
+    launch_break_hills(R, n_reads, s);
+    launch_retrim(L, R, 0, 0, ctx->d_small.p + 2, s);
+    HIPCHECK(hipMemsetAsync(ctx->d_dirty.p, 0, n_reads, s));
+
+    std::vector<uint32_t>& cnt = ctx->scratch_u32b;
+    std::vector<uint32_t>& mrank = ctx->scratch_u32a;
+    std::vector<uint16_t> mm;
+    uint32_t rounds = 0;
+    for (;; ++rounds) {                                             // graph.cpp:738-829
+        if (rounds >= 255) return fail(ctx, RALA_HIP_EDEVICE, "chimera loop did not settle");
+        // connected components over the live overlaps, labels in rank space
+        HIPCHECK(hipMemsetAsync(ctx->d_touched.p, 0, n_alive, s));
+        launch_cc_edges(L, ctx->d_rank.p, ctx->d_cc_edges.p, ctx->d_touched.p, s);
+        launch_cc_init(ctx->d_cc_label.p, n_alive, s);
+        for (int it = 0;; ++it) {
+            HIPCHECK(hipMemsetAsync(ctx->d_small.p + 2, 0, 4, s));
+            for (int k = 0; k < 4; ++k) {
+                launch_cc_hook(ctx->d_cc_edges.p, M, ctx->d_cc_label.p, ctx->d_small.p + 2, s);
+                launch_cc_compress(ctx->d_cc_label.p, n_alive, s);
+            }
+            uint32_t changed = 0;
+            HIPCHECK(hipMemcpyAsync(&changed, ctx->d_small.p + 2, 4, hipMemcpyDeviceToHost, s));
+            HIPCHECK(hipStreamSynchronize(s));
+            if (!changed) break;
+            if (it > 10000) return fail(ctx, RALA_HIP_EDEVICE, "connected components did not converge");
+        }
+        HIPCHECK(hipMemcpyAsync(ctx->p_cc_label.p, ctx->d_cc_label.p, (size_t)n_alive * 4, hipMemcpyDeviceToHost, s));
+        HIPCHECK(hipMemcpyAsync(ctx->p_touched.p, ctx->d_touched.p, n_alive, hipMemcpyDeviceToHost, s));
+        HIPCHECK(hipStreamSynchronize(s));
+        // median of the pile medians per component (graph.cpp:777-783), host: counting sort by label
+        {
+            const uint32_t* label = ctx->p_cc_label.p;
+            const uint8_t* touched = ctx->p_touched.p;
+            const uint32_t* reads = ctx->p_alive_reads.p;
+            uint16_t* cmed = ctx->p_cmed.p;
+            mrank.clear();
+            for (uint32_t q = 0; q < n_alive; ++q) if (touched[q]) mrank.push_back(q);
+            cnt.assign((size_t)n_alive + 1, 0);
+            for (uint32_t q : mrank) ++cnt[label[q] + 1];
+            for (uint32_t q = 0; q < n_alive; ++q) cnt[q + 1] += cnt[q];
+            std::vector<uint32_t>& idx = ctx->scratch_u32c;
+            idx.resize(mrank.size());
+            for (size_t k = 0; k < mrank.size(); ++k) idx[cnt[label[mrank[k]]]++] = mrank[k];
+            for (size_t b0 = 0; b0 < idx.size();) {
+                const uint32_t lab = label[idx[b0]];
+                size_t t = b0;
+                mm.clear();
+                while (t < idx.size() && label[idx[t]] == lab) { mm.push_back(ctx->h_median[reads[idx[t]]]); ++t; }
+                std::nth_element(mm.begin(), mm.begin() + mm.size() / 2, mm.end());
+                const uint16_t med = mm[mm.size() / 2];
+                for (size_t k = b0; k < t; ++k) cmed[idx[k]] = med;
+                b0 = t;
+            }
+        }
+        HIPCHECK(hipMemcpyAsync(ctx->d_cmed.p, ctx->p_cmed.p, (size_t)n_alive * 2, hipMemcpyHostToDevice, s));
+        launch_break_pits(R, ctx->d_alive_reads.p, ctx->d_touched.p, ctx->d_cmed.p, n_alive, s);
+        HIPCHECK(hipMemsetAsync(ctx->d_small.p + 2, 0, 4, s));
+        launch_retrim(L, R, 1, rounds, ctx->d_small.p + 2, s);
+        HIPCHECK(hipMemsetAsync(ctx->d_dirty.p, 0, n_reads, s));
+        uint32_t dropped = 0;
+        HIPCHECK(hipMemcpyAsync(&dropped, ctx->d_small.p + 2, 4, hipMemcpyDeviceToHost, s));
+        HIPCHECK(hipStreamSynchronize(s));
+        if (!dropped) break;
+    }
+    ctx->t_rounds = rounds + 1;
+
+    // in-order containment removal (graph.cpp:831-877): overlaps (+ promoted), then internals
+    launch_refresh_types(L, R, s);
+    for (uint32_t which = 0; which < 2; ++which) {
+        uint32_t* death = nullptr;
+        const int rc = tail_death_scan(ctx, L, which, &death);
+        if (rc != RALA_HIP_OK) return rc;
+        launch_tail_apply_scan(L, ctx->d_alive.p, which, death, s);
+        launch_kill_reads(death, ctx->d_alive.p, n_reads, s);
+    }
+
+    // the final overlap list: originals in order, then the promoted ones round by round
+    uint32_t n_kept = 0;
+    for (uint32_t seg = 0; seg <= ctx->t_rounds; ++seg) {
+        launch_keep_flags(L, ctx->d_alive.p, seg == 0 ? 1u : 3u, seg == 0 ? 0u : seg - 1, ctx->d_t_tmp[0].p, s);
+        launch_exclusive_scan(ctx->d_t_tmp[0].p, ctx->d_t_tmp[1].p, M, ctx->d_scan_ws.p, s);
+        launch_place_kept(L, R, ctx->d_t_tmp[0].p, ctx->d_t_tmp[1].p, n_kept, ctx->d_kept_item.p, ctx->d_dovetail.p, s);
+        uint32_t c = 0;
+        HIPCHECK(hipMemcpyAsync(&c, ctx->d_t_tmp[1].p + M, 4, hipMemcpyDeviceToHost, s));
+        HIPCHECK(hipStreamSynchronize(s));
+        n_kept += c;
+    }
+    ctx->t_n_kept = n_kept;
+    // nodes: two per surviving read (graph.cpp:553-574)
+    launch_u8_to_u32(ctx->d_alive.p, ctx->d_t_tmp[0].p, n_reads, s);
+    launch_exclusive_scan(ctx->d_t_tmp[0].p, ctx->d_node_rank.p, n_reads, ctx->d_scan_ws.p, s);
+    uint32_t n_final = 0, n_dove = 0;
+    HIPCHECK(hipMemcpyAsync(&n_final, ctx->d_node_rank.p + n_reads, 4, hipMemcpyDeviceToHost, s));
+    // edges: two per dovetail overlap (graph.cpp:576-632)
+    launch_exclusive_scan(ctx->d_dovetail.p, ctx->d_epos.p, n_kept, ctx->d_scan_ws.p, s);
+    HIPCHECK(hipMemcpyAsync(&n_dove, ctx->d_epos.p + n_kept, 4, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipStreamSynchronize(s));
+    ctx->t_n_nodes = 2 * n_final;
+    ctx->t_n_edges = 2 * n_dove;
+    HIPCHECK(ctx->d_node_read.ensure(ctx->t_n_nodes));
+    for (int k = 0; k < 3; ++k) HIPCHECK(ctx->d_e[k].ensure(ctx->t_n_edges));
+    launch_node_reads(ctx->d_alive.p, ctx->d_node_rank.p, ctx->d_node_read.p, n_reads, s);
+    launch_build_edges(L, R, ctx->d_kept_item.p, ctx->d_dovetail.p, ctx->d_epos.p, n_kept, ctx->d_node_rank.p,
+                       ctx->d_e[0].p, ctx->d_e[1].p, ctx->d_e[2].p, s);
+    HIPCHECK(hipStreamSynchronize(s));
+    HIPCHECK(hipGetLastError());
+    ctx->tail_on_device = true;
+    ctx->host_stale = true;
+    return RALA_HIP_OK;
+}
+
+// host mirrors of a device-resident result (lists in the reference's order, graph, read state)
+int materialize_host(rala_hip_ctx* ctx) {
+    if (!ctx->host_stale) return RALA_HIP_OK;
+    hipStream_t s = ctx->stream;
+    int rc = download_read_state(ctx);
+    if (rc != RALA_HIP_OK) return rc;
+    const uint32_t M = ctx->t_n0 + ctx->t_n1;
+    std::vector<uint32_t> h[8];
+    std::vector<uint8_t> strand(M), type(M), state(M);
+    for (int f = 0; f < 8; ++f) {
+        h[f].resize(M);
+        if (M) HIPCHECK(hipMemcpyAsync(h[f].data(), ctx->d_surv_u32[f].p, (size_t)M * 4, hipMemcpyDeviceToHost, s));
+    }
+    std::vector<uint32_t> kept(ctx->t_n_kept);
+    if (M) {
+        HIPCHECK(hipMemcpyAsync(strand.data(), ctx->d_surv_u8[0].p, M, hipMemcpyDeviceToHost, s));
+        HIPCHECK(hipMemcpyAsync(type.data(), ctx->d_surv_u8[1].p, M, hipMemcpyDeviceToHost, s));
+        HIPCHECK(hipMemcpyAsync(state.data(), ctx->d_t_state.p, M, hipMemcpyDeviceToHost, s));
+    }
+    if (ctx->t_n_kept) {
+        HIPCHECK(hipMemcpyAsync(kept.data(), ctx->d_kept_item.p, (size_t)ctx->t_n_kept * 4, hipMemcpyDeviceToHost, s));
+    }
+    ctx->node_read.resize(ctx->t_n_nodes);
+    ctx->e_src.resize(ctx->t_n_edges); ctx->e_dst.resize(ctx->t_n_edges); ctx->e_len.resize(ctx->t_n_edges);
+    if (ctx->t_n_nodes) {
+        HIPCHECK(hipMemcpyAsync(ctx->node_read.data(), ctx->d_node_read.p, (size_t)ctx->t_n_nodes * 4, hipMemcpyDeviceToHost, s));
+    }
+    if (ctx->t_n_edges) {
+        HIPCHECK(hipMemcpyAsync(ctx->e_src.data(), ctx->d_e[0].p, (size_t)ctx->t_n_edges * 4, hipMemcpyDeviceToHost, s));
+        HIPCHECK(hipMemcpyAsync(ctx->e_dst.data(), ctx->d_e[1].p, (size_t)ctx->t_n_edges * 4, hipMemcpyDeviceToHost, s));
+        HIPCHECK(hipMemcpyAsync(ctx->e_len.data(), ctx->d_e[2].p, (size_t)ctx->t_n_edges * 4, hipMemcpyDeviceToHost, s));
+    }
+    HIPCHECK(hipStreamSynchronize(s));
+    ctx->e_mark.assign(ctx->t_n_edges, 0);
+    auto item = [&](uint32_t k) {
+        HostOvl o;
+        o.src = h[0][k]; o.a = h[1][k]; o.b = h[2][k];
+        o.c.a_begin = h[3][k]; o.c.a_end = h[4][k]; o.c.b_begin = h[5][k]; o.c.b_end = h[6][k]; o.c.length = h[7][k];
+        o.strand = strand[k]; o.dead = 0; o.type = type[k];
+        return o;
+    };
+    ctx->overlaps.clear(); ctx->internals.clear();
+    for (uint32_t k : kept) ctx->overlaps.push_back(item(k));
+    for (uint32_t k = ctx->t_n0; k < M; ++k) if (state[k] == 2) ctx->internals.push_back(item(k));
+    ctx->host_stale = false;
     return RALA_HIP_OK;
 }
 
@@ -756,6 +1004,7 @@ int rala_hip_set_option(rala_hip_ctx* ctx, const char* key, int64_t value) {
     if (!strcmp(key, "max_lds_read_len")) { ctx->max_lds_read_len = value; return RALA_HIP_OK; }
     if (!strcmp(key, "debug_pile_stop_after")) { ctx->debug_pile_stop_after = value; return RALA_HIP_OK; }
     if (!strcmp(key, "use_run_kernel")) { ctx->use_run_kernel = value != 0; return RALA_HIP_OK; }
+    if (!strcmp(key, "use_gpu_tail")) { ctx->use_gpu_tail = value != 0; return RALA_HIP_OK; }
     if (!strcmp(key, "host_threads")) {
         ctx->host_threads = value;
         ctx->pool.reset(new HostPool((unsigned)std::max<int64_t>(1, std::min<int64_t>(value, 256))));
@@ -865,6 +1114,7 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
     ctx->tm = rala_hip_timings();
     ctx->overlaps.clear(); ctx->internals.clear();
     ctx->initialized = ctx->constructed = false;
+    ctx->tail_on_device = ctx->host_stale = ctx->marks_on_device = false;
 
     HIPCHECK(ctx->d_pile.ensure(ctx->pile_elems + 8));
     HIPCHECK(hipMemsetAsync(ctx->d_small.p, 0, 8 * 4, s));
@@ -1110,40 +1360,64 @@ int rala_hip_construct(rala_hip_ctx* ctx, const rala_hip_overlaps* sens, uint64_
         HIPCHECK(hipMemcpyAsync(&n_surv[k], ctx->d_pos[k].p + N, 4, hipMemcpyDeviceToHost, s));
     }
     HIPCHECK(hipStreamSynchronize(s));
+    // both survivor lists side by side in one device list: overlaps, then internals
+    const uint32_t M = n_surv[0] + n_surv[1];
+    ctx->t_n0 = n_surv[0]; ctx->t_n1 = n_surv[1];
+    for (int f = 0; f < 8; ++f) HIPCHECK(ctx->d_surv_u32[f].ensure(M));
+    for (int f = 0; f < 2; ++f) HIPCHECK(ctx->d_surv_u8[f].ensure(M));
+    for (int k = 0; k < 2; ++k) {
+        if (n_surv[k] == 0) continue;
+        const uint32_t off = k == 0 ? 0 : n_surv[0];
+        Survivors sv;
+        sv.src = ctx->d_surv_u32[0].p + off; sv.a_id = ctx->d_surv_u32[1].p + off; sv.b_id = ctx->d_surv_u32[2].p + off;
+        sv.a_begin = ctx->d_surv_u32[3].p + off; sv.a_end = ctx->d_surv_u32[4].p + off;
+        sv.b_begin = ctx->d_surv_u32[5].p + off; sv.b_end = ctx->d_surv_u32[6].p + off;
+        sv.length = ctx->d_surv_u32[7].p + off;
+        sv.strand = ctx->d_surv_u8[0].p + off; sv.type = ctx->d_surv_u8[1].p + off;
+        // trim in the gather re-derives the coordinates against the pass-1 piles
+        launch_gather_survivors(ctx->ovl, ctx->d_cls.p, rs, ctx->d_flag[k].p, ctx->d_pos[k].p, sv, s);
+    }
+    HIPCHECK(hipEventRecord(ctx->ev[7], s));
+    HIPCHECK(hipGetLastError());
+    const bool on_device = ctx->use_gpu_tail && !(sens != nullptr && n_sens != 0);
+    ctx->tail_on_device = false;
+    ctx->host_stale = false;
+    if (on_device) {
+        const double t0 = now_ms();
+        const int rc5 = gpu_tail_run(ctx);
+        if (rc5 != RALA_HIP_OK) return rc5;
+        ctx->tm.tail_host_ms = (float)(now_ms() - t0);
+        HIPCHECK(hipEventElapsedTime(&ctx->tm.classify_ms, ctx->ev[4], ctx->ev[5]));
+        HIPCHECK(hipEventElapsedTime(&ctx->tm.death_ms, ctx->ev[5], ctx->ev[6]));
+        HIPCHECK(hipEventElapsedTime(&ctx->tm.finish_ms, ctx->ev[6], ctx->ev[7]));
+        ctx->constructed = true;
+        return RALA_HIP_OK;
+    }
+    // host tail: lists to the host
     std::vector<HostOvl>* lists[2] = {&ctx->overlaps, &ctx->internals};
+    for (int f = 0; f < 8; ++f) {
+        HIPCHECK(ctx->p_surv_u32[f].ensure(M));
+        if (M) HIPCHECK(hipMemcpyAsync(ctx->p_surv_u32[f].p, ctx->d_surv_u32[f].p, (size_t)M * 4, hipMemcpyDeviceToHost, s));
+    }
+    for (int f = 0; f < 2; ++f) {
+        HIPCHECK(ctx->p_surv_u8[f].ensure(M));
+        if (M) HIPCHECK(hipMemcpyAsync(ctx->p_surv_u8[f].p, ctx->d_surv_u8[f].p, M, hipMemcpyDeviceToHost, s));
+    }
+    HIPCHECK(hipStreamSynchronize(s));
     for (int k = 0; k < 2; ++k) {
         const uint32_t m = n_surv[k];
+        const uint32_t off = k == 0 ? 0 : n_surv[0];
         lists[k]->clear();
-        if (m == 0) continue;
-        Survivors sv;
-        for (int f = 0; f < 8; ++f) HIPCHECK(ctx->d_surv_u32[f].ensure(m));
-        for (int f = 0; f < 2; ++f) HIPCHECK(ctx->d_surv_u8[f].ensure(m));
-        sv.src = ctx->d_surv_u32[0].p; sv.a_id = ctx->d_surv_u32[1].p; sv.b_id = ctx->d_surv_u32[2].p;
-        sv.a_begin = ctx->d_surv_u32[3].p; sv.a_end = ctx->d_surv_u32[4].p; sv.b_begin = ctx->d_surv_u32[5].p;
-        sv.b_end = ctx->d_surv_u32[6].p; sv.length = ctx->d_surv_u32[7].p;
-        sv.strand = ctx->d_surv_u8[0].p; sv.type = ctx->d_surv_u8[1].p;
-        // trim in the gather re-derives the coordinates against the pass-1 piles
-        ReadState rs1 = rs;
-        launch_gather_survivors(ctx->ovl, ctx->d_cls.p, rs1, ctx->d_flag[k].p, ctx->d_pos[k].p, sv, s);
-        for (int f = 0; f < 8; ++f) {
-            HIPCHECK(ctx->p_surv_u32[f].ensure(m));
-            HIPCHECK(hipMemcpyAsync(ctx->p_surv_u32[f].p, ctx->d_surv_u32[f].p, (size_t)m * 4, hipMemcpyDeviceToHost, s));
-        }
-        for (int f = 0; f < 2; ++f) {
-            HIPCHECK(ctx->p_surv_u8[f].ensure(m));
-            HIPCHECK(hipMemcpyAsync(ctx->p_surv_u8[f].p, ctx->d_surv_u8[f].p, m, hipMemcpyDeviceToHost, s));
-        }
-        HIPCHECK(hipStreamSynchronize(s));
         // promoted internals are appended to the overlaps later: room for them up front
-        lists[k]->reserve(k == 0 ? (size_t)n_surv[0] + n_surv[1] : (size_t)m);
+        lists[k]->reserve(k == 0 ? (size_t)M : (size_t)m);
         lists[k]->resize(m);
         std::vector<HostOvl>& dst = *lists[k];
         uint32_t* hp[8];
-        for (int f = 0; f < 8; ++f) hp[f] = ctx->p_surv_u32[f].p;
-        const uint8_t* hs = ctx->p_surv_u8[0].p;
-        const uint8_t* ht = ctx->p_surv_u8[1].p;
-        ctx->pool->chunks(m, [&](unsigned, size_t b, size_t e) {
-            for (size_t i = b; i < e; ++i) {
+        for (int f = 0; f < 8; ++f) hp[f] = ctx->p_surv_u32[f].p + off;
+        const uint8_t* hs = ctx->p_surv_u8[0].p + off;
+        const uint8_t* ht = ctx->p_surv_u8[1].p + off;
+        ctx->pool->chunks(m, [&](unsigned, size_t b0, size_t e0) {
+            for (size_t i = b0; i < e0; ++i) {
                 HostOvl& o = dst[i];
                 o.src = hp[0][i]; o.a = hp[1][i]; o.b = hp[2][i];
                 o.c.a_begin = hp[3][i]; o.c.a_end = hp[4][i]; o.c.b_begin = hp[5][i]; o.c.b_end = hp[6][i];
@@ -1152,8 +1426,6 @@ int rala_hip_construct(rala_hip_ctx* ctx, const rala_hip_overlaps* sens, uint64_
             }
         });
     }
-    HIPCHECK(hipEventRecord(ctx->ev[7], s));
-    HIPCHECK(hipGetLastError());
     // refreshed read state: liveness after the scan, hill counters in the pool
     int rc = download_read_state(ctx);
     if (rc != RALA_HIP_OK) return rc;
@@ -1161,7 +1433,7 @@ int rala_hip_construct(rala_hip_ctx* ctx, const rala_hip_overlaps* sens, uint64_
     HIPCHECK(hipEventElapsedTime(&ctx->tm.death_ms, ctx->ev[5], ctx->ev[6]));
     HIPCHECK(hipEventElapsedTime(&ctx->tm.finish_ms, ctx->ev[6], ctx->ev[7]));
 
-    // ---- sequential tail on the survivors ----
+    // ---- tail on the host (cross-check path; also used with sensitive overlaps) ----
     const double t0 = now_ms();
     Trace trc;
     {
@@ -1190,6 +1462,12 @@ int rala_hip_remove_transitive_edges(rala_hip_ctx* ctx, uint32_t* n_pairs) {
     if (!ctx || !n_pairs) return RALA_HIP_EINVAL;
     if (!ctx->constructed) return fail(ctx, RALA_HIP_EINVAL, "rala_hip_construct must succeed first");
     HIPCHECK(hipSetDevice(ctx->device));
+    if (ctx->tail_on_device) {
+        const int rc = tr_mark_device(ctx, ctx->t_n_nodes, ctx->t_n_edges, ctx->d_e[0].p, ctx->d_e[1].p, ctx->d_e[2].p,
+                                      n_pairs);
+        ctx->marks_on_device = rc == RALA_HIP_OK;
+        return rc;
+    }
     const uint32_t ne = (uint32_t)ctx->e_src.size();
     ctx->e_mark.assign(ne, 0);
     return tr_mark_impl(ctx, (uint32_t)ctx->node_read.size(), ne, ctx->e_src.data(), ctx->e_dst.data(),
@@ -1216,6 +1494,7 @@ int rala_hip_get_piles(rala_hip_ctx* ctx, uint32_t* begin, uint32_t* end, uint16
                        uint8_t* alive) {
     if (!ctx) return RALA_HIP_EINVAL;
     if (!ctx->initialized) return fail(ctx, RALA_HIP_EINVAL, "not initialized");
+    { const int rcm = materialize_host(ctx); if (rcm != RALA_HIP_OK) return rcm; }
     const uint64_t n = ctx->n_reads;
     for (uint64_t r = 0; r < n; ++r) {
         const bool a = ctx->h_alive[r];
@@ -1233,6 +1512,7 @@ int rala_hip_get_pile_data(rala_hip_ctx* ctx, uint64_t read, uint16_t* data) {
     if (!ctx->initialized || read >= ctx->n_reads) return fail(ctx, RALA_HIP_EINVAL, "bad read / not initialized");
     if (!ctx->piles_resident) return fail(ctx, RALA_HIP_EINVAL, "piles live on the owning rank's context");
     HIPCHECK(hipSetDevice(ctx->device));
+    { const int rcm = materialize_host(ctx); if (rcm != RALA_HIP_OK) return rcm; }
     const uint32_t n = ctx->h_read_len[read];
     HIPCHECK(hipMemcpy(data, ctx->d_pile.p + ctx->h_pile_off[read], (size_t)n * 2, hipMemcpyDeviceToHost));
     // Pile::shrink zeroes outside the current valid region (pile.cpp:311-318); the
@@ -1249,6 +1529,7 @@ int rala_hip_get_intervals(rala_hip_ctx* ctx, int kind, uint64_t* offsets, uint3
     if (!ctx || !offsets) return RALA_HIP_EINVAL;
     if (!ctx->initialized) return fail(ctx, RALA_HIP_EINVAL, "not initialized");
     if (kind < 0 || kind > 2) return fail(ctx, RALA_HIP_EINVAL, "bad interval kind");
+    { const int rcm = materialize_host(ctx); if (rcm != RALA_HIP_OK) return rcm; }
     const uint64_t n = ctx->n_reads;
     uint64_t off = 0;
     for (uint64_t r = 0; r < n; ++r) {
@@ -1293,6 +1574,7 @@ int rala_hip_get_overlaps(rala_hip_ctx* ctx, int which, uint64_t* n, uint32_t* s
                           uint32_t* a_end, uint32_t* b_begin, uint32_t* b_end, uint32_t* length, uint8_t* type) {
     if (!ctx || !n) return RALA_HIP_EINVAL;
     if (!ctx->constructed) return fail(ctx, RALA_HIP_EINVAL, "not constructed");
+    { const int rcm = materialize_host(ctx); if (rcm != RALA_HIP_OK) return rcm; }
     const std::vector<HostOvl>& v = which == 0 ? ctx->overlaps : ctx->internals;
     *n = v.size();
     if (!src_index) return RALA_HIP_OK;
@@ -1315,6 +1597,11 @@ int rala_hip_get_overlaps(rala_hip_ctx* ctx, int which, uint64_t* n, uint32_t* s
 int rala_hip_get_graph_size(rala_hip_ctx* ctx, uint64_t* n_nodes, uint64_t* n_edges) {
     if (!ctx || !n_nodes || !n_edges) return RALA_HIP_EINVAL;
     if (!ctx->constructed) return fail(ctx, RALA_HIP_EINVAL, "not constructed");
+    if (ctx->tail_on_device) {
+        *n_nodes = ctx->t_n_nodes;
+        *n_edges = ctx->t_n_edges;
+        return RALA_HIP_OK;
+    }
     *n_nodes = ctx->node_read.size();
     *n_edges = ctx->e_src.size();
     return RALA_HIP_OK;
@@ -1324,6 +1611,13 @@ int rala_hip_get_graph(rala_hip_ctx* ctx, uint32_t* node_read, uint32_t* src, ui
                        uint8_t* marks) {
     if (!ctx) return RALA_HIP_EINVAL;
     if (!ctx->constructed) return fail(ctx, RALA_HIP_EINVAL, "not constructed");
+    { const int rcm = materialize_host(ctx); if (rcm != RALA_HIP_OK) return rcm; }
+    if (ctx->marks_on_device) {
+        HIPCHECK(hipSetDevice(ctx->device));
+        ctx->e_mark.resize(ctx->t_n_edges);
+        if (ctx->t_n_edges) HIPCHECK(hipMemcpy(ctx->e_mark.data(), ctx->d_tr_marks.p, ctx->t_n_edges, hipMemcpyDeviceToHost));
+        ctx->marks_on_device = false;
+    }
     if (node_read) memcpy(node_read, ctx->node_read.data(), ctx->node_read.size() * 4);
     const size_t ne = ctx->e_src.size();
     if (src) memcpy(src, ctx->e_src.data(), ne * 4);

@@ -1,0 +1,347 @@
+// Graph::preprocess (chimeras) and graph construction on device-resident survivor lists.
+//
+// After the second overlap pass a few per cent of the overlaps are left (state 1 =
+// "overlaps", state 2 = "internals").  The reference then iterates
+//   break over hills -> re-trim -> { components, component median, break over pits,
+//   re-trim, promote internals that became dovetails } until no overlap dies
+//   -> in-order containment removal -> nodes / edges
+// (src/graph.cpp:699-880, 553-632).  Here every per-item step is a kernel over the
+// list (items are never moved: dead items keep state 0, promoted internals get state 3
+// and the round in which they were promoted, which fixes their place in the reference's
+// list order); the in-order containment removal is the same fixed point as in the second
+// pass; only the per-component medians are computed on the host (from the labels).
+#include <hip/hip_runtime.h>
+
+#include "device_utils.h"
+#include "geom.h"
+#include "kernels.h"
+
+namespace rala_hip {
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr uint32_t kInf = 0xFFFFFFFFu;
+
+inline dim3 grid_for(uint64_t n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); }
+
+// Pile::shrink without the data part (pile.cpp:299-322); marks the read dirty
+__device__ __forceinline__ bool dev_shrink(const TailReads& R, uint32_t r, uint32_t b, uint32_t e) {
+    if (b > e || e - b < kMinRegion) { R.dirty[r] = 1; return false; }
+    if (R.begin[r] != b || R.end[r] != e) R.dirty[r] = 1;
+    R.begin[r] = b;
+    R.end[r] = e;
+    return true;
+}
+
+// Pile::break_over_chimeric_hills (pile.cpp:471-498), one thread per read
+__global__ __launch_bounds__(kBlock) void break_hills_kernel(TailReads R, uint32_t n_reads) {
+    const uint32_t r = blockIdx.x * kBlock + threadIdx.x;
+    if (r >= n_reads || !R.alive[r] || R.n_hills[r] == 0) return;
+    const Interval* hills = R.pool + R.iv_slot[r] + R.n_pits0[r];
+    const uint32_t n = R.n_hills[r];
+    const uint32_t B = R.begin[r], E = R.end[r];
+    uint32_t b = 0, e = 0, from = B;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (B > hills[i].first || E < hills[i].second) continue;
+        if (hills[i].aux > 3) continue;
+        if ((uint32_t)(hills[i].first - from) > (uint32_t)(e - b)) { b = from; e = hills[i].first; }
+        from = hills[i].second;
+    }
+    if ((uint32_t)(E - from) > (uint32_t)(e - b)) { b = from; e = E; }
+    if (!dev_shrink(R, r, b, e)) R.alive[r] = 0;
+    R.n_hills[r] = 0;
+}
+
+// Pile::break_over_chimeric_pits (pile.cpp:366-402) for the reads of a component; the pile
+// kernel recorded the minimum coverage inside each pit (data * 1.84 <= median is monotone)
+__global__ __launch_bounds__(kBlock) void break_pits_kernel(TailReads R, const uint32_t* __restrict__ alive_reads,
+                                                            const uint8_t* __restrict__ touched,
+                                                            const uint16_t* __restrict__ comp_median, uint32_t n_alive) {
+    const uint32_t q = blockIdx.x * kBlock + threadIdx.x;
+    if (q >= n_alive || !touched[q]) return;
+    const uint32_t r = alive_reads[q];
+    if (!R.alive[r] || R.n_pits[r] == 0) return;
+    Interval* pits = R.pool + R.iv_slot[r];
+    const uint32_t n = R.n_pits[r];
+    const double med = (double)comp_median[q];
+    const uint32_t B = R.begin[r], E = R.end[r];
+    uint32_t b = 0, e = 0, from = B, w = 0;
+    for (uint32_t k = 0; k < n; ++k) {
+        const Interval it = pits[k];
+        if (B > it.first || E < it.second) continue;
+        if ((double)it.aux * 1.84 <= med) {
+            if ((uint32_t)(it.first - from) > (uint32_t)(e - b)) { b = from; e = it.first; }
+            from = it.second;
+        } else {
+            pits[w++] = it;
+        }
+    }
+    if ((uint32_t)(E - from) > (uint32_t)(e - b)) { b = from; e = E; }
+    R.n_pits[r] = (uint8_t)w;
+    if (!dev_shrink(R, r, b, e)) R.alive[r] = 0;
+}
+
+__device__ __forceinline__ Coords item_coords(const TailList& L, uint32_t k) {
+    Coords c;
+    c.a_begin = L.a_begin[k]; c.a_end = L.a_end[k]; c.b_begin = L.b_begin[k]; c.b_end = L.b_end[k];
+    c.length = L.length[k];
+    return c;
+}
+
+// Overlap::trim for the items that touch a dirty read (graph.cpp:722-736, 801-824): dropped
+// overlaps are counted (the loop continues while any died), internals that became dovetails
+// are promoted
+__global__ __launch_bounds__(kBlock) void retrim_kernel(TailList L, TailReads R, uint32_t promote, uint32_t round,
+                                                        uint32_t* dropped) {
+    const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
+    if (k >= L.n) return;
+    const uint8_t st = L.state[k];
+    if (st == 0) return;
+    const uint32_t a = L.a[k], b = L.b[k];
+    // untouched items are still trimmed (and internals still kX); an internal whose type went
+    // stale in the first re-trim (no promotion there, graph.cpp:730-736) is looked at again
+    const bool stale_internal = promote && st == 2 && L.type[k] == 255;
+    if (!((R.dirty[a] | R.dirty[b]) || stale_internal)) return;
+    Coords c = item_coords(L, k);
+    const uint32_t strand = L.strand[k];
+    const bool ok = R.alive[a] && R.alive[b] && ovl_trim(c, strand, R.begin[a], R.end[a], R.begin[b], R.end[b]);
+    if (!ok) {
+        L.state[k] = 0;
+        if (st != 2) atomicAdd(dropped, 1u);
+        return;
+    }
+    L.a_begin[k] = c.a_begin; L.a_end[k] = c.a_end; L.b_begin[k] = c.b_begin; L.b_end[k] = c.b_end;
+    L.length[k] = c.length;
+    uint8_t t = 255;
+    if (st == 2 && promote) {
+        t = (uint8_t)ovl_type(c, strand, R.begin[a], R.end[a], R.begin[b], R.end[b]);
+        if (t == kTypeAB || t == kTypeBA) {
+            L.state[k] = 3;
+            L.round[k] = (uint8_t)round;
+        }
+    }
+    L.type[k] = t;
+}
+
+// edges of the component graph in rank space; dead items become self loops
+__global__ __launch_bounds__(kBlock) void cc_edges_kernel(TailList L, const uint32_t* __restrict__ rank,
+                                                          uint32_t* __restrict__ edges, uint8_t* touched) {
+    const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
+    if (k >= L.n) return;
+    const uint8_t st = L.state[k];
+    uint32_t x = 0, y = 0;
+    if (st == 1 || st == 3) {
+        x = rank[L.a[k]]; y = rank[L.b[k]];
+        touched[x] = 1; touched[y] = 1;
+    }
+    edges[2 * k] = x;
+    edges[2 * k + 1] = y;
+}
+
+// stale types (coordinates or a region moved) before the containment scans
+__global__ __launch_bounds__(kBlock) void refresh_types_kernel(TailList L, TailReads R) {
+    const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
+    if (k >= L.n || L.state[k] == 0 || L.type[k] != 255) return;
+    const uint32_t a = L.a[k], b = L.b[k];
+    if (!R.alive[a] || !R.alive[b]) return;
+    const Coords c = item_coords(L, k);
+    L.type[k] = (uint8_t)ovl_type(c, L.strand[k], R.begin[a], R.end[a], R.begin[b], R.end[b]);
+}
+
+// position of an item in the reference's list: overlaps in order, then the promoted
+// internals by (round, index); internals are scanned separately, by index
+__device__ __forceinline__ uint32_t item_key(const TailList& L, uint32_t k, uint8_t st) {
+    return st == 3 ? L.n * (1u + L.round[k]) + k : k;
+}
+
+// In-order containment removal without the chimera guard (graph.cpp:831-866) as the same
+// fixed point as in the second pass.  which = 0: overlaps + promoted, 1: internals.
+__global__ __launch_bounds__(kBlock) void tail_death_round_kernel(TailList L, const uint8_t* __restrict__ alive,
+                                                                  uint32_t which, const uint32_t* __restrict__ death_old,
+                                                                  uint32_t* death_new) {
+    const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
+    if (k >= L.n) return;
+    const uint8_t st = L.state[k];
+    if (which == 0 ? !(st == 1 || st == 3) : st != 2) return;
+    const uint8_t t = L.type[k];
+    if (t != kTypeA && t != kTypeB) return;
+    const uint32_t a = L.a[k], b = L.b[k];
+    if (!alive[a] || !alive[b]) return;
+    const uint32_t target = t == kTypeA ? b : a;
+    const uint32_t keeper = t == kTypeA ? a : b;
+    const uint32_t key = item_key(L, k, st);
+    if (death_old[keeper] > key) atomicMin(&death_new[target], key);
+}
+
+// after a scan: reads with a death index are gone; items of the scanned class are dropped
+// when they are containments (they either deleted a read or had lost one) or, for the
+// internals, when a read was already gone by the time the loop reached them
+__global__ __launch_bounds__(kBlock) void tail_apply_scan_kernel(TailList L, const uint8_t* __restrict__ alive,
+                                                                 uint32_t which, const uint32_t* __restrict__ death) {
+    const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
+    if (k >= L.n) return;
+    const uint8_t st = L.state[k];
+    if (which == 0 ? !(st == 1 || st == 3) : st != 2) return;
+    const uint8_t t = L.type[k];
+    const uint32_t a = L.a[k], b = L.b[k];
+    bool drop = t == kTypeA || t == kTypeB;
+    if (which == 1) {
+        const uint32_t key = k;
+        drop = drop || !alive[a] || !alive[b] || death[a] < key || death[b] < key;
+    }
+    if (drop) L.state[k] = 0;
+}
+
+__global__ __launch_bounds__(kBlock) void kill_reads_kernel(const uint32_t* __restrict__ death, uint8_t* alive, uint32_t n) {
+    const uint32_t r = blockIdx.x * kBlock + threadIdx.x;
+    if (r < n && death[r] != kInf) alive[r] = 0;
+}
+
+// 1 for the items that form the final overlap list, in one of its segments (originals, or
+// the promoted ones of one round)
+__global__ __launch_bounds__(kBlock) void keep_flags_kernel(TailList L, const uint8_t* __restrict__ alive,
+                                                            uint32_t want_state, uint32_t want_round,
+                                                            uint32_t* __restrict__ flag) {
+    const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
+    if (k >= L.n) return;
+    const uint8_t st = L.state[k];
+    bool keep = st == want_state && (st != 3 || L.round[k] == want_round);
+    keep = keep && alive[L.a[k]] && alive[L.b[k]];
+    flag[k] = keep ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(kBlock) void u8_to_u32_kernel(const uint8_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t n) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) out[i] = in[i] ? 1u : 0u;
+}
+
+// rank[r] / alive_reads[rank] from the exclusive scan of the alive flags
+__global__ __launch_bounds__(kBlock) void ranks_kernel(const uint8_t* __restrict__ alive, const uint32_t* __restrict__ pos,
+                                                       uint32_t* __restrict__ rank, uint32_t* __restrict__ alive_reads,
+                                                       uint32_t n) {
+    const uint32_t r = blockIdx.x * kBlock + threadIdx.x;
+    if (r >= n) return;
+    if (alive[r]) {
+        rank[r] = pos[r];
+        if (alive_reads) alive_reads[pos[r]] = r;
+    } else {
+        rank[r] = kInf;
+    }
+}
+
+// final overlap j (kept item k at position base + pos[k]): remember k, and whether it is a
+// dovetail (graph.cpp:594,612)
+__global__ __launch_bounds__(kBlock) void place_kept_kernel(TailList L, TailReads R, const uint32_t* __restrict__ flag,
+                                                            const uint32_t* __restrict__ pos, uint32_t base,
+                                                            uint32_t* __restrict__ kept_item, uint32_t* __restrict__ dovetail) {
+    const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
+    if (k >= L.n || !flag[k]) return;
+    const uint32_t j = base + pos[k];
+    kept_item[j] = k;
+    const uint32_t a = L.a[k], b = L.b[k];
+    const Coords c = item_coords(L, k);
+    const uint32_t t = ovl_type(c, L.strand[k], R.begin[a], R.end[a], R.begin[b], R.end[b]);
+    L.type[k] = (uint8_t)t;
+    dovetail[j] = (t == kTypeAB || t == kTypeBA) ? 1u : 0u;
+}
+
+// two edges per dovetail overlap (graph.cpp:594-629); node = 2 * rank of the read
+__global__ __launch_bounds__(kBlock) void build_edges_kernel(TailList L, TailReads R, const uint32_t* __restrict__ kept_item,
+                                                             const uint32_t* __restrict__ dovetail,
+                                                             const uint32_t* __restrict__ epos, uint32_t n_kept,
+                                                             const uint32_t* __restrict__ node_rank,
+                                                             uint32_t* __restrict__ e_src, uint32_t* __restrict__ e_dst,
+                                                             uint32_t* __restrict__ e_len) {
+    const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
+    if (j >= n_kept || !dovetail[j]) return;
+    const uint32_t k = kept_item[j];
+    const uint32_t a = L.a[k], b = L.b[k];
+    const Coords c = item_coords(L, k);
+    EdgePair e;
+    ovl_edges(c, L.strand[k], L.type[k], 2u * node_rank[a], 2u * node_rank[b], R.begin[a], R.end[a], R.begin[b], R.end[b], e);
+    const uint32_t w = 2u * epos[j];
+    e_src[w] = e.src0; e_dst[w] = e.dst0; e_len[w] = e.len0;
+    e_src[w + 1] = e.src1; e_dst[w + 1] = e.dst1; e_len[w + 1] = e.len1;
+}
+
+__global__ __launch_bounds__(kBlock) void node_reads_kernel(const uint8_t* __restrict__ alive, const uint32_t* __restrict__ rank,
+                                                            uint32_t* __restrict__ node_read, uint32_t n) {
+    const uint32_t r = blockIdx.x * kBlock + threadIdx.x;
+    if (r >= n || !alive[r]) return;
+    node_read[2 * rank[r]] = r;
+    node_read[2 * rank[r] + 1] = r;
+}
+
+__global__ __launch_bounds__(kBlock) void init_list_state_kernel(uint8_t* state, uint8_t* round, uint32_t n0, uint32_t n) {
+    const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
+    if (k >= n) return;
+    state[k] = k < n0 ? 1 : 2;
+    round[k] = 0;
+}
+
+}  // namespace
+
+void launch_break_hills(const TailReads& R, uint32_t n_reads, hipStream_t s) {
+    if (n_reads) hipLaunchKernelGGL(break_hills_kernel, grid_for(n_reads), dim3(kBlock), 0, s, R, n_reads);
+}
+void launch_break_pits(const TailReads& R, const uint32_t* alive_reads, const uint8_t* touched, const uint16_t* comp_median,
+                       uint32_t n_alive, hipStream_t s) {
+    if (n_alive) {
+        hipLaunchKernelGGL(break_pits_kernel, grid_for(n_alive), dim3(kBlock), 0, s, R, alive_reads, touched, comp_median,
+                           n_alive);
+    }
+}
+void launch_retrim(const TailList& L, const TailReads& R, uint32_t promote, uint32_t round, uint32_t* dropped,
+                   hipStream_t s) {
+    if (L.n) hipLaunchKernelGGL(retrim_kernel, grid_for(L.n), dim3(kBlock), 0, s, L, R, promote, round, dropped);
+}
+void launch_cc_edges(const TailList& L, const uint32_t* rank, uint32_t* edges, uint8_t* touched, hipStream_t s) {
+    if (L.n) hipLaunchKernelGGL(cc_edges_kernel, grid_for(L.n), dim3(kBlock), 0, s, L, rank, edges, touched);
+}
+void launch_refresh_types(const TailList& L, const TailReads& R, hipStream_t s) {
+    if (L.n) hipLaunchKernelGGL(refresh_types_kernel, grid_for(L.n), dim3(kBlock), 0, s, L, R);
+}
+void launch_tail_death_round(const TailList& L, const uint8_t* alive, uint32_t which, const uint32_t* death_old,
+                             uint32_t* death_new, hipStream_t s) {
+    if (L.n) {
+        hipLaunchKernelGGL(tail_death_round_kernel, grid_for(L.n), dim3(kBlock), 0, s, L, alive, which, death_old,
+                           death_new);
+    }
+}
+void launch_tail_apply_scan(const TailList& L, const uint8_t* alive, uint32_t which, const uint32_t* death, hipStream_t s) {
+    if (L.n) hipLaunchKernelGGL(tail_apply_scan_kernel, grid_for(L.n), dim3(kBlock), 0, s, L, alive, which, death);
+}
+void launch_kill_reads(const uint32_t* death, uint8_t* alive, uint32_t n, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(kill_reads_kernel, grid_for(n), dim3(kBlock), 0, s, death, alive, n);
+}
+void launch_keep_flags(const TailList& L, const uint8_t* alive, uint32_t want_state, uint32_t want_round, uint32_t* flag,
+                       hipStream_t s) {
+    if (L.n) hipLaunchKernelGGL(keep_flags_kernel, grid_for(L.n), dim3(kBlock), 0, s, L, alive, want_state, want_round, flag);
+}
+void launch_u8_to_u32(const uint8_t* in, uint32_t* out, uint32_t n, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(u8_to_u32_kernel, grid_for(n), dim3(kBlock), 0, s, in, out, n);
+}
+void launch_ranks(const uint8_t* alive, const uint32_t* pos, uint32_t* rank, uint32_t* alive_reads, uint32_t n, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(ranks_kernel, grid_for(n), dim3(kBlock), 0, s, alive, pos, rank, alive_reads, n);
+}
+void launch_place_kept(const TailList& L, const TailReads& R, const uint32_t* flag, const uint32_t* pos, uint32_t base,
+                       uint32_t* kept_item, uint32_t* dovetail, hipStream_t s) {
+    if (L.n) hipLaunchKernelGGL(place_kept_kernel, grid_for(L.n), dim3(kBlock), 0, s, L, R, flag, pos, base, kept_item, dovetail);
+}
+void launch_build_edges(const TailList& L, const TailReads& R, const uint32_t* kept_item, const uint32_t* dovetail,
+                        const uint32_t* epos, uint32_t n_kept, const uint32_t* node_rank, uint32_t* e_src, uint32_t* e_dst,
+                        uint32_t* e_len, hipStream_t s) {
+    if (n_kept) {
+        hipLaunchKernelGGL(build_edges_kernel, grid_for(n_kept), dim3(kBlock), 0, s, L, R, kept_item, dovetail, epos, n_kept,
+                           node_rank, e_src, e_dst, e_len);
+    }
+}
+void launch_node_reads(const uint8_t* alive, const uint32_t* rank, uint32_t* node_read, uint32_t n, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(node_reads_kernel, grid_for(n), dim3(kBlock), 0, s, alive, rank, node_read, n);
+}
+void launch_init_list_state(uint8_t* state, uint8_t* round, uint32_t n0, uint32_t n, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(init_list_state_kernel, grid_for(n), dim3(kBlock), 0, s, state, round, n0, n);
+}
+
+}  // namespace rala_hip

@@ -34,6 +34,21 @@ def test_full_path_small(hip_ctx_factory, n, g, seed, run_kernel):
         assert tm["pile_position_reads"] > 0 and tm["pile_overflow_reads"] >= tm["pile_position_reads"]
 
 
+@pytest.mark.parametrize("n,g,seed", [(3000, 600_000, 21), (2000, 1_200_000, 33), (600, 60_000, 9)])
+def test_host_tail_cross_check(hip_ctx_factory, n, g, seed):
+    """use_gpu_tail = 0: Graph::preprocess on the host (the path the sensitive pass uses)."""
+    ds = Dataset(n, g, seed)
+    st = parity.oracle_stages(ds)
+    ctx = hip_ctx_factory()
+    ctx.set_option("use_gpu_tail", 0)
+    ctx.set_reads(ds.read_len)
+    ctx.set_overlaps(ds.overlaps)
+    ctx.initialize()
+    ctx.construct()
+    parity.check_construct(ctx, st)
+    parity.check_tr(ctx, st)
+
+
 @pytest.mark.parametrize("n,g,seed", [(5000, 1_000_000, 7), (6000, 1_600_000, 19)])
 def test_sensitive_pass_vs_oracle(hip_ctx_factory, n, g, seed):
     """Graph::preprocess(overlaps, sensitive path) (reference graph.cpp:882-1054)."""
