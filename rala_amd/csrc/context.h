@@ -107,7 +107,7 @@ struct rala_hip_ctx {
     rala_hip::OvlSoA ovl = {};
     rala_hip::DevBuf<uint32_t> d_ovl_u32[7];
     rala_hip::DevBuf<uint8_t> d_ovl_strand;
-    rala_hip::DevBuf<uint8_t> d_valid;
+    rala_hip::DevBuf<uint8_t> d_valid, d_suspect;
     bool valid_ready = false;
 
     // bound tuples shipped in by the caller instead of overlaps (multi-GPU owners)

@@ -116,7 +116,8 @@ enum : uint8_t {
     kClsLive = 0x40,       // survived the in-order death scan
 };
 
-void launch_dedupe(const OvlSoA& o, uint32_t n_reads, uint8_t* valid, hipStream_t s);
+// suspect: n_reads bytes of scratch (queries whose runs are not strictly ordered by target)
+void launch_dedupe(const OvlSoA& o, uint32_t n_reads, uint8_t* suspect, uint8_t* valid, hipStream_t s);
 void launch_count_bounds(const OvlSoA& o, uint32_t n_reads, uint32_t* counts, hipStream_t s);
 void launch_scatter_bounds(const OvlSoA& o, uint32_t n_reads, uint32_t* cursor, uint32_t* ev, hipStream_t s);
 // bound tuples (read, bound) instead of overlaps: multi-GPU owners receive them by all-to-all

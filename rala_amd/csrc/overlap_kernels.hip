@@ -26,7 +26,27 @@ __device__ __forceinline__ bool transmutable(const OvlSoA& o, uint64_t i, uint32
 // names do not resolve are skipped and do not break a run), per b_id exactly
 // the last occurrence of the greatest length stays valid; self overlaps are
 // invalid (SURVEY B-T2 closed form of graph.cpp:273-307).
-__global__ __launch_bounds__(kBlock) void dedupe_kernel(OvlSoA o, uint32_t n_reads, uint8_t* __restrict__ valid) {
+// A run whose targets are strictly increasing cannot hold two overlaps of the same pair
+// (the usual case: overlappers emit each query's hits ordered by target).  This pass flags
+// the queries that own a run where that order is broken, or a record that does not resolve;
+// only their overlaps need the full comparison below.
+__global__ __launch_bounds__(kBlock) void dedupe_mark_kernel(OvlSoA o, uint32_t n_reads, uint8_t* __restrict__ suspect) {
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= o.n || i == 0) return;
+    const uint32_t a = o.a_id[i], b = o.b_id[i];
+    const uint32_t pa = o.a_id[i - 1], pb = o.b_id[i - 1];
+    const bool ok = a < n_reads && b < n_reads, pok = pa < n_reads && pb < n_reads;
+    if (ok && pok) {
+        if (pa == a && b <= pb) suspect[a] = 1;
+    } else {
+        // an unresolved record hides the order of its neighbours: flag both queries
+        if (a < n_reads) suspect[a] = 1;
+        if (pa < n_reads) suspect[pa] = 1;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void dedupe_kernel(OvlSoA o, uint32_t n_reads, const uint8_t* __restrict__ suspect,
+                                                        uint8_t* __restrict__ valid) {
     const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= o.n) return;
     const uint32_t a = o.a_id[i], b = o.b_id[i];
@@ -34,20 +54,52 @@ __global__ __launch_bounds__(kBlock) void dedupe_kernel(OvlSoA o, uint32_t n_rea
         valid[i] = 0;
         return;
     }
+    if (!suspect[a]) {          // every run of this query has strictly increasing targets
+        valid[i] = 1;
+        return;
+    }
     const uint32_t len = o.length[i];
     bool ok = true;
-    for (uint64_t j = i; j-- > 0;) {              // earlier members of the run
-        const uint32_t aj = o.a_id[j], bj = o.b_id[j];
-        if (aj >= n_reads || bj >= n_reads) continue;
-        if (aj != a) break;
-        if (bj == b && o.length[j] > len) { ok = false; break; }
+    // neighbours in batches of four: the loads do not depend on the loop exit
+    {
+        bool done = false;
+        for (uint64_t j0 = i; j0 > 0 && !done;) {     // earlier members of the run
+            uint32_t aj[4], bj[4];
+            uint64_t jj[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) {
+                jj[u] = j0 > u ? j0 - 1 - u : 0;
+                aj[u] = o.a_id[jj[u]];
+                bj[u] = o.b_id[jj[u]];
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) {
+                if (done || j0 <= u) { done = true; break; }
+                if (aj[u] >= n_reads || bj[u] >= n_reads) continue;
+                if (aj[u] != a) { done = true; break; }
+                if (bj[u] == b && o.length[jj[u]] > len) { ok = false; done = true; break; }
+            }
+            j0 = j0 > 4 ? j0 - 4 : 0;
+        }
     }
     if (ok) {
-        for (uint64_t j = i + 1; j < o.n; ++j) {  // later members
-            const uint32_t aj = o.a_id[j], bj = o.b_id[j];
-            if (aj >= n_reads || bj >= n_reads) continue;
-            if (aj != a) break;
-            if (bj == b && o.length[j] >= len) { ok = false; break; }
+        bool done = false;
+        for (uint64_t j0 = i + 1; j0 < o.n && !done; j0 += 4) {      // later members
+            uint32_t aj[4], bj[4];
+            uint64_t jj[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) {
+                jj[u] = j0 + u < o.n ? j0 + u : o.n - 1;
+                aj[u] = o.a_id[jj[u]];
+                bj[u] = o.b_id[jj[u]];
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) {
+                if (done || j0 + u >= o.n) { done = true; break; }
+                if (aj[u] >= n_reads || bj[u] >= n_reads) continue;
+                if (aj[u] != a) { done = true; break; }
+                if (bj[u] == b && o.length[jj[u]] >= len) { ok = false; done = true; break; }
+            }
         }
     }
     valid[i] = ok ? 1 : 0;
@@ -275,8 +327,11 @@ inline dim3 grid_for(uint64_t n) { return dim3((unsigned)((n + kBlock - 1) / kBl
 
 }  // namespace
 
-void launch_dedupe(const OvlSoA& o, uint32_t n_reads, uint8_t* valid, hipStream_t s) {
-    if (o.n) hipLaunchKernelGGL(dedupe_kernel, grid_for(o.n), dim3(kBlock), 0, s, o, n_reads, valid);
+void launch_dedupe(const OvlSoA& o, uint32_t n_reads, uint8_t* suspect, uint8_t* valid, hipStream_t s) {
+    if (!o.n) return;
+    (void)hipMemsetAsync(suspect, 0, n_reads, s);
+    hipLaunchKernelGGL(dedupe_mark_kernel, grid_for(o.n), dim3(kBlock), 0, s, o, n_reads, suspect);
+    hipLaunchKernelGGL(dedupe_kernel, grid_for(o.n), dim3(kBlock), 0, s, o, n_reads, (const uint8_t*)suspect, valid);
 }
 void launch_count_bounds(const OvlSoA& o, uint32_t n_reads, uint32_t* counts, hipStream_t s) {
     if (o.n) hipLaunchKernelGGL(count_bounds_kernel, grid_for(o.n), dim3(kBlock), 0, s, o, n_reads, counts);

@@ -1039,6 +1039,7 @@ int rala_hip_set_reads(rala_hip_ctx* ctx, const uint32_t* read_len, uint64_t n_r
     HIPCHECK(ctx->d_order.ensure(n_reads + 1));
     HIPCHECK(ctx->d_overflow.ensure(n_reads + 1));
     HIPCHECK(ctx->d_ev_off.ensure(n_reads + 2)); HIPCHECK(ctx->d_cursor.ensure(n_reads + 2));
+    HIPCHECK(ctx->d_suspect.ensure(n_reads + 1));
     HIPCHECK(ctx->d_begin.ensure(n_reads)); HIPCHECK(ctx->d_end.ensure(n_reads));
     HIPCHECK(ctx->d_median.ensure(n_reads)); HIPCHECK(ctx->d_p10.ensure(n_reads));
     HIPCHECK(ctx->d_alive.ensure(n_reads)); HIPCHECK(ctx->d_n_pits.ensure(n_reads));
@@ -1119,7 +1120,7 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
     HIPCHECK(ctx->d_pile.ensure(ctx->pile_elems + 8));
     HIPCHECK(hipMemsetAsync(ctx->d_small.p, 0, 8 * 4, s));
     HIPCHECK(hipEventRecord(ctx->ev[0], s));
-    if (!ctx->tuple_mode) launch_dedupe(ctx->ovl, n_reads, ctx->d_valid.p, s);
+    if (!ctx->tuple_mode) launch_dedupe(ctx->ovl, n_reads, ctx->d_suspect.p, ctx->d_valid.p, s);
     HIPCHECK(hipEventRecord(ctx->ev[1], s));
     // bucket bounds by read: count -> exclusive scan -> scatter
     HIPCHECK(hipMemsetAsync(ctx->d_cursor.p, 0, (size_t)(n_reads + 1) * 4, s));
@@ -1210,7 +1211,7 @@ int rala_hip_dedupe(rala_hip_ctx* ctx) {
     if (!ctx) return RALA_HIP_EINVAL;
     if (ctx->n_reads == 0) return fail(ctx, RALA_HIP_EINVAL, "no reads set");
     HIPCHECK(hipSetDevice(ctx->device));
-    launch_dedupe(ctx->ovl, (uint32_t)ctx->n_reads, ctx->d_valid.p, ctx->stream);
+    launch_dedupe(ctx->ovl, (uint32_t)ctx->n_reads, ctx->d_suspect.p, ctx->d_valid.p, ctx->stream);
     HIPCHECK(hipStreamSynchronize(ctx->stream));
     HIPCHECK(hipGetLastError());
     ctx->valid_ready = true;
