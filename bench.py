@@ -140,6 +140,8 @@ def main():
         # read of annotations (DESIGN.md "Roofline"); time = HIP events
         # around those launches on the context's stream.
         pile_bytes = 16.0 * n_ovl + 2.0 * sum_len + 40.0 * ds.n_reads
+        if use_dist:
+            pile_bytes /= world     # a rank's launches cover the reads it owns (1 / world of every term)
         pile_ms = stage.get("pile_ms", 0.0)
         achieved = pile_bytes / (pile_ms * 1e-3) / 1e9 if pile_ms > 0 else 0.0
         traffic = None

@@ -121,6 +121,12 @@ int rala_hip_dedupe(rala_hip_ctx* ctx);
  * receive (a, (a_begin+15)<<1), (a, (a_end-15)<<1|1), (b, ...), (b, ...); the read is
  * RALA_HIP_NO_READ for records that do not resolve.  The caller routes them to the read owners. */
 int rala_hip_emit_bound_tuples(rala_hip_ctx* ctx, uint32_t* reads_dev, uint32_t* bounds_dev);
+/* The same tuples grouped by owner rank (owner = read % world, stored read = read / world =
+ * the owner's local read number): the device buffers (4 * n_overlaps uint32 each) receive the
+ * bucket of rank 0, then rank 1, ...; counts[world] (host) receives the bucket sizes.  Records
+ * that do not resolve are left out. */
+int rala_hip_emit_bound_tuples_bucketed(rala_hip_ctx* ctx, uint32_t world, uint32_t* reads_dev, uint32_t* bounds_dev,
+                                        uint64_t* counts);
 /* Feed a context whose reads are the locally owned ones with the tuples it received (read =
  * LOCAL read number; other values are ignored).  rala_hip_initialize then skips duplicate
  * removal and builds / annotates the piles from these bounds. */
@@ -132,6 +138,32 @@ int rala_hip_import_state(rala_hip_ctx* ctx, const uint8_t* valid, const uint32_
                           const uint16_t* median, const uint16_t* p10, const uint8_t* alive,
                           const uint64_t* pits_off, const uint32_t* pits_pairs, const uint32_t* pits_aux,
                           const uint64_t* hills_off, const uint32_t* hills_pairs);
+
+/* Device-resident view of the result of rala_hip_initialize, for device-to-device gathers:
+ * per-read arrays of n_reads entries, the interval pool (12-byte {first, second, aux} records;
+ * a read's pits, then its hills, start at slot[read], or slot == 0xFFFFFFFF) and the validity
+ * bytes.  rala_hip_get_device_state fills the view from a context;
+ * rala_hip_import_state_device installs a (gathered) view into a context that holds all
+ * reads and overlaps, like rala_hip_import_state does from host arrays. */
+typedef struct rala_hip_device_state {
+    const uint32_t* begin;
+    const uint32_t* end;
+    const uint16_t* median;
+    const uint16_t* p10;
+    const uint8_t* alive;
+    const uint8_t* n_pits;
+    const uint8_t* n_hills;
+    const uint32_t* slot;
+    const void* pool;
+    uint64_t pool_count;
+    const uint8_t* valid;       /* may be NULL in a tuple-fed context */
+} rala_hip_device_state;
+int rala_hip_get_device_state(rala_hip_ctx* ctx, rala_hip_device_state* out);
+/* Copy the context's arrays into the caller's device buffers (non-NULL members of dst;
+ * dst->pool_count = capacity of dst->pool in records).  Lets a caller that owns its device
+ * memory (a torch tensor handed to RCCL) avoid aliasing the context's buffers. */
+int rala_hip_copy_device_state(rala_hip_ctx* ctx, const rala_hip_device_state* dst);
+int rala_hip_import_state_device(rala_hip_ctx* ctx, const rala_hip_device_state* in);
 
 /* ---- results (host buffers owned by the caller) --------------------------------------- */
 /* is_valid_overlap_ (src/graph.hpp:168), one byte per overlap */

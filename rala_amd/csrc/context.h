@@ -115,7 +115,7 @@ struct rala_hip_ctx {
     uint64_t n_tuples = 0;
     const uint32_t* tuple_reads = nullptr;
     const uint32_t* tuple_bounds = nullptr;
-    rala_hip::DevBuf<uint32_t> d_tuple[2];
+    rala_hip::DevBuf<uint32_t> d_tuple[2], d_owner_cnt;
     bool piles_resident = false;
 
     // bound CSR

@@ -122,6 +122,8 @@ void launch_count_bounds(const OvlSoA& o, uint32_t n_reads, uint32_t* counts, hi
 void launch_scatter_bounds(const OvlSoA& o, uint32_t n_reads, uint32_t* cursor, uint32_t* ev, hipStream_t s);
 // bound tuples (read, bound) instead of overlaps: multi-GPU owners receive them by all-to-all
 void launch_emit_tuples(const OvlSoA& o, uint32_t n_reads, uint32_t* reads, uint32_t* bounds, hipStream_t s);
+void launch_bucket_tuples(const OvlSoA& o, uint32_t n_reads, uint32_t world, uint32_t pass, uint32_t* counters,
+                          uint32_t* reads, uint32_t* bounds, hipStream_t s);
 void launch_count_tuples(const uint32_t* reads, uint64_t n, uint32_t n_reads, uint32_t* counts, hipStream_t s);
 void launch_scatter_tuples(const uint32_t* reads, const uint32_t* bounds, uint64_t n, uint32_t n_reads,
                            uint32_t* cursor, uint32_t* ev, hipStream_t s);

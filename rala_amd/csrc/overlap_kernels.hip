@@ -178,12 +178,94 @@ __global__ __launch_bounds__(kBlock) void emit_tuples_kernel(OvlSoA o, uint32_t 
     ((uint4*)bounds)[i] = v;
 }
 
+// Multi-GPU: tuples grouped by the owner of the read (read % world; local read = read / world).
+// A workgroup owns a chunk of kBucketChunk consecutive overlaps; wavefronts 0/1 take the
+// query side, 2/3 the target side, every lane emitting the begin and the end bound of its
+// overlap next to each other (so the owner's bucketing sees runs of equal reads).  Bucket
+// sizes are accumulated in LDS: pass 0 adds them to the global per-owner counters, pass 1
+// reserves the chunk's range of every bucket with one atomic per owner and scatters.  The
+// order inside a bucket is irrelevant (coverage is additive).
+constexpr uint32_t kBucketChunk = 2048;
+
+template <class F>
+__device__ __forceinline__ void for_each_owner(uint32_t owner, F f) {
+    // wave-uniform loop over the distinct owners present in the wavefront
+    uint64_t todo = __ballot(owner != kInf);
+    while (todo) {
+        const uint32_t first = (uint32_t)__ffsll((unsigned long long)todo) - 1;
+        const uint32_t p = (uint32_t)__shfl((int)owner, (int)first, 64);
+        const uint64_t m = __ballot(owner == p);
+        f(p, m);
+        todo &= ~m;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void bucket_tuples_kernel(OvlSoA o, uint32_t n_reads, uint32_t world, uint32_t pass,
+                                                               uint32_t* counters, uint32_t* __restrict__ reads,
+                                                               uint32_t* __restrict__ bounds) {
+    static_assert(kBlock == 256, "four wavefronts per workgroup");
+    __shared__ uint32_t s_cnt[64], s_base[64];
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = threadIdx.x >> 6;
+    const bool side_b = wave >= 2;
+    const uint64_t first = (uint64_t)blockIdx.x * kBucketChunk + (wave & 1u) * 64u;
+    if (threadIdx.x < 64) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    auto owner_of = [&](uint64_t i, uint32_t& read) {
+        read = kInf;
+        if (i < o.n) {
+            const uint32_t a = o.a_id[i], b = o.b_id[i];
+            if (a < n_reads && b < n_reads) read = side_b ? b : a;
+        }
+        return read == kInf ? kInf : read % world;
+    };
+    for (uint32_t k = 0; k < kBucketChunk; k += 128) {
+        uint32_t read;
+        const uint32_t owner = owner_of(first + k + lane, read);
+        for_each_owner(owner, [&](uint32_t p, uint64_t m) {
+            if (lane == 0) atomicAdd(&s_cnt[p], 2u * (uint32_t)__popcll(m));
+        });
+    }
+    __syncthreads();
+    if (pass == 0) {
+        if (threadIdx.x < world && s_cnt[threadIdx.x]) atomicAdd(&counters[threadIdx.x], s_cnt[threadIdx.x]);
+        return;
+    }
+    if (threadIdx.x < world) {
+        const uint32_t c = s_cnt[threadIdx.x];
+        s_base[threadIdx.x] = c ? atomicAdd(&counters[threadIdx.x], c) : 0u;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t k = 0; k < kBucketChunk; k += 128) {
+        const uint64_t i = first + k + lane;
+        uint32_t read;
+        const uint32_t owner = owner_of(i, read);
+        for_each_owner(owner, [&](uint32_t p, uint64_t m) {
+            uint32_t off = 0;
+            if (lane == 0) off = atomicAdd(&s_cnt[p], 2u * (uint32_t)__popcll(m));
+            off = (uint32_t)__shfl((int)off, 0, 64);
+            if (owner == p) {
+                const uint32_t w = s_base[p] + off + 2u * (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                const uint32_t lo = side_b ? o.b_begin[i] : o.a_begin[i];
+                const uint32_t hi = side_b ? o.b_end[i] : o.a_end[i];
+                reads[w] = reads[w + 1] = read / world;
+                bounds[w] = (lo + 15u) << 1;
+                bounds[w + 1] = ((hi - 15u) << 1) | 1u;
+            }
+        });
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void count_tuples_kernel(const uint32_t* __restrict__ reads, uint64_t n,
                                                               uint32_t n_reads, uint32_t* counts) {
     const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t r = reads[i];
-    if (r < n_reads) atomicAdd(&counts[r], 1u);
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t r = i < n ? reads[i] : kInf;
+    uint32_t leader;
+    const uint32_t seg = segment_of(r, r < n_reads, lane, leader);
+    if (seg) atomicAdd(&counts[r], seg);
 }
 
 __global__ __launch_bounds__(kBlock) void scatter_tuples_kernel(const uint32_t* __restrict__ reads,
@@ -191,9 +273,14 @@ __global__ __launch_bounds__(kBlock) void scatter_tuples_kernel(const uint32_t* 
                                                                 uint32_t n_reads, uint32_t* cursor,
                                                                 uint32_t* __restrict__ ev) {
     const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t r = reads[i];
-    if (r < n_reads) ev[atomicAdd(&cursor[r], 1u)] = bounds[i];
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t r = i < n ? reads[i] : kInf;
+    uint32_t leader;
+    const uint32_t seg = segment_of(r, r < n_reads, lane, leader);
+    uint32_t base = 0;
+    if (seg) base = atomicAdd(&cursor[r], seg);
+    base = (uint32_t)__shfl((int)base, (int)leader, 64);
+    if (r < n_reads) ev[base + (lane - leader)] = bounds[i];
 }
 
 __device__ __forceinline__ Coords load_coords(const OvlSoA& o, uint64_t i) {
@@ -341,6 +428,13 @@ void launch_scatter_bounds(const OvlSoA& o, uint32_t n_reads, uint32_t* cursor, 
 }
 void launch_emit_tuples(const OvlSoA& o, uint32_t n_reads, uint32_t* reads, uint32_t* bounds, hipStream_t s) {
     if (o.n) hipLaunchKernelGGL(emit_tuples_kernel, grid_for(o.n), dim3(kBlock), 0, s, o, n_reads, reads, bounds);
+}
+void launch_bucket_tuples(const OvlSoA& o, uint32_t n_reads, uint32_t world, uint32_t pass, uint32_t* counters,
+                          uint32_t* reads, uint32_t* bounds, hipStream_t s) {
+    if (o.n) {
+        hipLaunchKernelGGL(bucket_tuples_kernel, dim3((uint32_t)((o.n + kBucketChunk - 1) / kBucketChunk)), dim3(kBlock), 0, s, o, n_reads, world, pass, counters,
+                           reads, bounds);
+    }
 }
 void launch_count_tuples(const uint32_t* reads, uint64_t n, uint32_t n_reads, uint32_t* counts, hipStream_t s) {
     if (n) hipLaunchKernelGGL(count_tuples_kernel, grid_for(n), dim3(kBlock), 0, s, reads, n, n_reads, counts);

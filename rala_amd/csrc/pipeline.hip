@@ -1227,6 +1227,118 @@ int rala_hip_emit_bound_tuples(rala_hip_ctx* ctx, uint32_t* reads_dev, uint32_t*
     return RALA_HIP_OK;
 }
 
+int rala_hip_emit_bound_tuples_bucketed(rala_hip_ctx* ctx, uint32_t world, uint32_t* reads_dev, uint32_t* bounds_dev,
+                                        uint64_t* counts) {
+    if (!ctx || !reads_dev || !bounds_dev || !counts || world == 0 || world > 64) return RALA_HIP_EINVAL;
+    HIPCHECK(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    HIPCHECK(ctx->d_owner_cnt.ensure(2 * 64));
+    uint32_t* cnt = ctx->d_owner_cnt.p;
+    uint32_t* cur = cnt + 64;
+    HIPCHECK(hipMemsetAsync(cnt, 0, 2 * 64 * 4, s));
+    launch_bucket_tuples(ctx->ovl, (uint32_t)ctx->n_reads, world, 0, cnt, reads_dev, bounds_dev, s);
+    uint32_t h[64];
+    HIPCHECK(hipMemcpyAsync(h, cnt, world * 4, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipStreamSynchronize(s));
+    uint32_t off[64];
+    uint32_t acc = 0;
+    for (uint32_t p = 0; p < world; ++p) { off[p] = acc; acc += h[p]; counts[p] = h[p]; }
+    HIPCHECK(hipMemcpyAsync(cur, off, world * 4, hipMemcpyHostToDevice, s));
+    launch_bucket_tuples(ctx->ovl, (uint32_t)ctx->n_reads, world, 1, cur, reads_dev, bounds_dev, s);
+    HIPCHECK(hipStreamSynchronize(s));
+    HIPCHECK(hipGetLastError());
+    return RALA_HIP_OK;
+}
+
+int rala_hip_get_device_state(rala_hip_ctx* ctx, rala_hip_device_state* out) {
+    if (!ctx || !out) return RALA_HIP_EINVAL;
+    if (!ctx->initialized) return fail(ctx, RALA_HIP_EINVAL, "not initialized");
+    out->begin = ctx->d_begin.p; out->end = ctx->d_end.p; out->median = ctx->d_median.p; out->p10 = ctx->d_p10.p;
+    out->alive = ctx->d_alive.p; out->n_pits = ctx->d_n_pits.p; out->n_hills = ctx->d_n_hills.p;
+    out->slot = ctx->d_iv_slot.p; out->pool = ctx->d_pool.p; out->pool_count = ctx->h_pool.size();
+    out->valid = ctx->valid_ready ? ctx->d_valid.p : nullptr;
+    return RALA_HIP_OK;
+}
+
+int rala_hip_copy_device_state(rala_hip_ctx* ctx, const rala_hip_device_state* dst) {
+    if (!ctx || !dst) return RALA_HIP_EINVAL;
+    const bool per_read = dst->begin || dst->end || dst->median || dst->p10 || dst->alive || dst->n_pits ||
+                          dst->n_hills || dst->slot || dst->pool;
+    if (per_read && !ctx->initialized) return fail(ctx, RALA_HIP_EINVAL, "not initialized");
+    HIPCHECK(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const uint64_t n = ctx->n_reads;
+    auto cp = [&](const void* to, const void* from, size_t bytes) -> hipError_t {
+        if (!to || bytes == 0) return hipSuccess;
+        return hipMemcpyAsync(const_cast<void*>(to), from, bytes, hipMemcpyDeviceToDevice, s);
+    };
+    HIPCHECK(cp(dst->begin, ctx->d_begin.p, n * 4));
+    HIPCHECK(cp(dst->end, ctx->d_end.p, n * 4));
+    HIPCHECK(cp(dst->median, ctx->d_median.p, n * 2));
+    HIPCHECK(cp(dst->p10, ctx->d_p10.p, n * 2));
+    HIPCHECK(cp(dst->alive, ctx->d_alive.p, n));
+    HIPCHECK(cp(dst->n_pits, ctx->d_n_pits.p, n));
+    HIPCHECK(cp(dst->n_hills, ctx->d_n_hills.p, n));
+    HIPCHECK(cp(dst->slot, ctx->d_iv_slot.p, n * 4));
+    if (dst->pool) {
+        if (dst->pool_count < ctx->h_pool.size()) return fail(ctx, RALA_HIP_ECAPACITY, "pool buffer too small");
+        HIPCHECK(cp(dst->pool, ctx->d_pool.p, ctx->h_pool.size() * sizeof(Interval)));
+    }
+    if (dst->valid) {
+        if (!ctx->valid_ready) return fail(ctx, RALA_HIP_EINVAL, "no validity bits on this context");
+        HIPCHECK(cp(dst->valid, ctx->d_valid.p, ctx->n_ovl));
+    }
+    HIPCHECK(hipStreamSynchronize(s));
+    return RALA_HIP_OK;
+}
+
+int rala_hip_import_state_device(rala_hip_ctx* ctx, const rala_hip_device_state* in) {
+    if (!ctx || !in || !in->begin || !in->end || !in->median || !in->p10 || !in->alive || !in->n_pits ||
+        !in->n_hills || !in->slot) {
+        return RALA_HIP_EINVAL;
+    }
+    if (ctx->n_reads == 0) return fail(ctx, RALA_HIP_EINVAL, "no reads set");
+    if (ctx->n_ovl && !in->valid) return fail(ctx, RALA_HIP_EINVAL, "valid bits required");
+    if (in->pool_count && !in->pool) return RALA_HIP_EINVAL;
+    HIPCHECK(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const uint64_t n = ctx->n_reads;
+    ctx->tm = rala_hip_timings();
+    ctx->overlaps.clear(); ctx->internals.clear();
+    if (in->pool_count > ctx->pool_cap) {
+        ctx->pool_cap = (uint32_t)in->pool_count + 1024;
+        HIPCHECK(ctx->d_pool.ensure(ctx->pool_cap));
+    }
+    const uint32_t small[8] = {(uint32_t)in->pool_count, 0, 0, 0, 0, 0, 0, 0};
+    HIPCHECK(hipMemcpyAsync(ctx->d_small.p, small, sizeof(small), hipMemcpyHostToDevice, s));
+    HIPCHECK(hipMemcpyAsync(ctx->d_begin.p, in->begin, n * 4, hipMemcpyDeviceToDevice, s));
+    HIPCHECK(hipMemcpyAsync(ctx->d_end.p, in->end, n * 4, hipMemcpyDeviceToDevice, s));
+    HIPCHECK(hipMemcpyAsync(ctx->d_median.p, in->median, n * 2, hipMemcpyDeviceToDevice, s));
+    HIPCHECK(hipMemcpyAsync(ctx->d_p10.p, in->p10, n * 2, hipMemcpyDeviceToDevice, s));
+    HIPCHECK(hipMemcpyAsync(ctx->d_alive.p, in->alive, n, hipMemcpyDeviceToDevice, s));
+    HIPCHECK(hipMemcpyAsync(ctx->d_n_pits.p, in->n_pits, n, hipMemcpyDeviceToDevice, s));
+    HIPCHECK(hipMemcpyAsync(ctx->d_n_hills.p, in->n_hills, n, hipMemcpyDeviceToDevice, s));
+    HIPCHECK(hipMemcpyAsync(ctx->d_iv_slot.p, in->slot, n * 4, hipMemcpyDeviceToDevice, s));
+    if (in->pool_count) {
+        HIPCHECK(hipMemcpyAsync(ctx->d_pool.p, in->pool, (size_t)in->pool_count * sizeof(Interval), hipMemcpyDeviceToDevice, s));
+    }
+    if (ctx->n_ovl) HIPCHECK(hipMemcpyAsync(ctx->d_valid.p, in->valid, ctx->n_ovl, hipMemcpyDeviceToDevice, s));
+    HIPCHECK(hipStreamSynchronize(s));
+    const int rc = download_read_state(ctx);
+    if (rc != RALA_HIP_OK) return rc;
+    ctx->h_begin0 = ctx->h_begin;
+    ctx->h_end0 = ctx->h_end;
+    ctx->n_prefiltered = 0;
+    for (uint64_t r = 0; r < n; ++r) if (!ctx->h_alive[r]) ++ctx->n_prefiltered;
+    ctx->initialized = true;
+    ctx->valid_ready = true;
+    ctx->constructed = false;
+    ctx->piles_resident = false;
+    ctx->tail_on_device = ctx->host_stale = ctx->marks_on_device = false;
+    if (ctx->n_prefiltered == n) return fail(ctx, RALA_HIP_EFILTERED, "filtered all sequences");
+    return RALA_HIP_OK;
+}
+
 int rala_hip_set_bound_tuples(rala_hip_ctx* ctx, const uint32_t* reads, const uint32_t* bounds, uint64_t n, int mem) {
     if (!ctx || (n && (!reads || !bounds))) return RALA_HIP_EINVAL;
     if (ctx->n_reads == 0) return fail(ctx, RALA_HIP_EINVAL, "no reads set");
@@ -1311,6 +1423,7 @@ int rala_hip_import_state(rala_hip_ctx* ctx, const uint8_t* valid, const uint32_
     ctx->valid_ready = true;
     ctx->constructed = false;
     ctx->piles_resident = false;
+    ctx->tail_on_device = ctx->host_stale = ctx->marks_on_device = false;
     if (ctx->n_prefiltered == n) return fail(ctx, RALA_HIP_EFILTERED, "filtered all sequences");
     return RALA_HIP_OK;
 }

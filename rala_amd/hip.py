@@ -26,12 +26,19 @@ SYMBOLS = (
     "rala_hip_get_pile_data", "rala_hip_get_intervals", "rala_hip_get_overlaps", "rala_hip_get_graph_size",
     "rala_hip_get_graph", "rala_hip_get_timings", "rala_hip_get_num_prefiltered",
     "rala_hip_dedupe", "rala_hip_emit_bound_tuples", "rala_hip_set_bound_tuples", "rala_hip_import_state",
+    "rala_hip_emit_bound_tuples_bucketed", "rala_hip_get_device_state", "rala_hip_import_state_device",
+    "rala_hip_copy_device_state",
 )
 
 
 class OverlapsC(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in
                 ("a_id", "b_id", "a_begin", "a_end", "b_begin", "b_end", "length", "strand")]
+
+
+class DeviceState(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in ("begin", "end", "median", "p10", "alive", "n_pits", "n_hills", "slot",
+                                               "pool")] + [("pool_count", ctypes.c_uint64), ("valid", ctypes.c_void_p)]
 
 
 class Timings(ctypes.Structure):
@@ -86,6 +93,10 @@ def lib(build=True):
         L.rala_hip_emit_bound_tuples.argtypes = [vp, vp, vp]
         L.rala_hip_set_bound_tuples.argtypes = [vp, vp, vp, u64, i32]
         L.rala_hip_import_state.argtypes = [vp] + [vp] * 11
+        L.rala_hip_emit_bound_tuples_bucketed.argtypes = [vp, u32, vp, vp, vp]
+        L.rala_hip_get_device_state.argtypes = [vp, ctypes.POINTER(DeviceState)]
+        L.rala_hip_import_state_device.argtypes = [vp, ctypes.POINTER(DeviceState)]
+        L.rala_hip_copy_device_state.argtypes = [vp, ctypes.POINTER(DeviceState)]
         _lib = L
     return _lib
 
@@ -169,6 +180,32 @@ class Context:
     def emit_bound_tuples(self, reads_ptr, bounds_ptr):
         """device pointers of 4 * n_overlaps uint32 each"""
         self._check(self.L.rala_hip_emit_bound_tuples(self.h, reads_ptr, bounds_ptr))
+
+    def emit_bound_tuples_bucketed(self, world, reads_ptr, bounds_ptr):
+        """tuples grouped by owner rank; returns the bucket sizes"""
+        counts = np.zeros(world, dtype=np.uint64)
+        self._check(self.L.rala_hip_emit_bound_tuples_bucketed(self.h, world, reads_ptr, bounds_ptr,
+                                                                  counts.ctypes.data))
+        return counts
+
+    def device_state(self):
+        st = DeviceState()
+        self._check(self.L.rala_hip_get_device_state(self.h, ctypes.byref(st)))
+        return st
+
+    def copy_device_state(self, **ptrs):
+        """device-to-device copy of the named arrays into caller buffers (pointers)"""
+        st = DeviceState()
+        for k, v in ptrs.items():
+            setattr(st, k, v)
+        self._check(self.L.rala_hip_copy_device_state(self.h, ctypes.byref(st)))
+
+    def import_state_device(self, **ptrs):
+        """ptrs: begin, end, median, p10, alive, n_pits, n_hills, slot, pool, pool_count, valid"""
+        st = DeviceState()
+        for k, v in ptrs.items():
+            setattr(st, k, v)
+        self._check(self.L.rala_hip_import_state_device(self.h, ctypes.byref(st)))
 
     def set_bound_tuples_device(self, reads_ptr, bounds_ptr, n):
         self.n_overlaps = 0

@@ -5,17 +5,18 @@ cut into P contiguous slices on a_id-run boundaries (duplicate removal is per ru
 reference graph.cpp:346-350).  Per step:
 
   1. every rank removes duplicates in its slice and turns the slice's overlaps into bound
-     tuples (read, bound)                                   [rala_hip_dedupe / _emit_bound_tuples]
+     tuples (local read, bound) grouped by owner  [rala_hip_dedupe, _emit_bound_tuples_bucketed]
   2. ONE all-to-all(v) ships every tuple to the owner of its read (coverage is additive
      mod 2^16, so arrival order is irrelevant)
   3. owners bucket the tuples and build + annotate their piles   [rala_hip_set_bound_tuples,
      rala_hip_initialize]
-  4. all-gather of the per-read annotations (16 B per read + the few pits / hills) and of the
-     validity bits; every rank installs them                     [rala_hip_import_state]
+  4. all-gather of the per-read annotations (19 B per read, one packed buffer per rank), of the
+     interval pools and of the validity bits, all device to device; every rank installs the
+     result                                        [rala_hip_copy_device_state, _import_state_device]
   5. the remainder (second overlap pass, containment fixed point, preprocess tail, graph,
      transitive reduction) is small and runs replicated on every rank.
 
-The tensor plumbing below (owner split, variable all-to-all, padded all-gather, global
+The tensor plumbing below (variable all-to-all, padded all-gather, packed state layout, global
 re-indexing) is device agnostic so that the CPU test-suite can run it under gloo.
 """
 import numpy as np
@@ -111,6 +112,61 @@ def merge_intervals(counts_parts, flat_parts, n_reads, world, width):
     return offs, flat
 
 
+# packed per-read state of one rank: field arrays of nl entries back to back (nl % 8 == 0)
+STATE_FIELDS = (("begin", 4), ("end", 4), ("slot", 4), ("median", 2), ("p10", 2), ("alive", 1), ("n_pits", 1),
+                ("n_hills", 1))
+_VIEW = {4: torch.int32, 2: torch.int16, 1: torch.uint8}
+NO_SLOT = -1        # 0xFFFFFFFF seen as int32
+POOL_RECORD = 12    # bytes of one {first, second, aux} interval
+
+
+def padded_local(n_reads, world):
+    """entries per rank in the packed state (largest local read count rounded up to 8)"""
+    return (n_local_reads(n_reads, 0, world) + 7) // 8 * 8
+
+
+def state_layout(nl):
+    """byte offset of every field in the packed state, and its total size"""
+    off, o = {}, 0
+    for name, w in STATE_FIELDS:
+        off[name] = o
+        o += w * nl
+    return off, o
+
+
+def all_gather_rows(x, group=None):
+    """x: 1-D tensor of the same length on every rank -> (world, len) tensor"""
+    world = dist.get_world_size(group)
+    out = torch.empty((world, x.numel()), dtype=x.dtype, device=x.device)
+    dist.all_gather(list(out.unbind(0)), x.contiguous(), group=group)
+    return out
+
+
+def unpack_state(rows, nl, n_reads, pool_counts):
+    """rows: (world, bytes) uint8, rank k's packed state in row k.  Returns the global per-read
+    tensors (read j * world + k = entry j of rank k); slots are rebased onto the concatenation
+    of the ranks' interval pools (pool_counts = records per rank)."""
+    world = rows.shape[0]
+    off, _ = state_layout(nl)
+    base = torch.zeros(world, dtype=torch.int64)
+    base[1:] = torch.cumsum(torch.as_tensor(pool_counts, dtype=torch.int64), 0)[:-1]
+    base = base.to(device=rows.device, dtype=torch.int32).view(-1, 1)
+    out = {}
+    for name, w in STATE_FIELDS:
+        f = rows[:, off[name]: off[name] + w * nl].view(_VIEW[w])            # (world, nl)
+        if name == "slot":
+            f = torch.where(f == NO_SLOT, f, f + base)
+        out[name] = f.t().reshape(-1)[:n_reads].contiguous()
+    return out
+
+
+def gather_pools(pool, group=None):
+    """pool: uint8 tensor of this rank's interval records -> (concatenated pools, records per rank)"""
+    parts = all_gather_v(pool, group)
+    counts = [p.numel() // POOL_RECORD for p in parts]
+    return (torch.cat(parts) if parts else pool), counts
+
+
 class ShardedRunner:
     """bench.py's runner for WORLD_SIZE > 1 (one process per GPU)."""
 
@@ -145,62 +201,68 @@ class ShardedRunner:
         self._tm = {}
 
     def step(self):
-        hip, world = self.hip, self.world
+        hip, world, dev = self.hip, self.world, self.dev
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-        # 1. duplicates + tuples of this slice
+        u8 = lambda n: torch.empty(max(int(n), 1), dtype=torch.uint8, device=dev)
+        import time
+        wall = [time.perf_counter()]
+
+        def lap():
+            torch.cuda.synchronize()
+            wall.append(time.perf_counter())
+        # 1. duplicates + owner-grouped tuples of this slice
         self.cs.dedupe()
-        valid_slice = torch.from_numpy(self.cs.valid()).to(self.dev)
-        self.cs.emit_bound_tuples(self.t_reads.data_ptr(), self.t_bounds.data_ptr())
-        n4 = 4 * len(self.slice)
-        reads = self.t_reads[:n4].to(torch.int64) & 0xFFFFFFFF
-        bounds = self.t_bounds[:n4].to(torch.int64) & 0xFFFFFFFF
+        counts = self.cs.emit_bound_tuples_bucketed(world, self.t_reads.data_ptr(), self.t_bounds.data_ptr())
         ev[0].record()
+        lap()
         # 2. one all-to-all to the owners
-        lr, bd, counts = owner_split(reads, bounds, world)
-        lr, _ = all_to_all_v(lr.to(torch.int32), counts, self.group)
-        bd, _ = all_to_all_v(bd.to(torch.int32), counts, self.group)     # bit pattern of the uint32 bound
+        n_send = int(counts.sum())
+        send = torch.from_numpy(counts.astype(np.int64)).to(dev)
+        lr, _ = all_to_all_v(self.t_reads[:n_send], send, self.group)
+        bd, _ = all_to_all_v(self.t_bounds[:n_send], send, self.group)    # bit pattern of the uint32 bound
         ev[1].record()
+        lap()
         # 3. owners build their piles
-        self._keep = (lr, bd)
-        torch.cuda.synchronize()
         self.cl.set_bound_tuples_device(lr.data_ptr(), bd.data_ptr(), lr.numel())
         try:
             self.cl.initialize()
         except hip.RalaHipError as e:
             if e.code != -4:        # every local read filtered is not fatal for the whole job
                 raise
-        p = self.cl.piles()
-        pits = self.cl.intervals(0)
-        hills = self.cl.intervals(1)
         ev[2].record()
-        # 4. all-gather annotations + validity bits, install them
-        def gather_np(a, dtype):
-            t = torch.from_numpy(np.ascontiguousarray(a).astype(dtype, copy=False)).to(self.dev)
-            return [x.cpu().numpy() for x in all_gather_v(t, self.group)]
-
-        n = self.n_reads
-        piles = {k: interleave(gather_np(p[k].astype(np.int64), np.int64), n, world).astype(p[k].dtype)
-                 for k in ("begin", "end", "median", "p10", "alive")}
-        pc = gather_np(np.diff(pits[0].astype(np.int64)), np.int64)
-        pf = gather_np(np.concatenate([pits[1].astype(np.int64), pits[2].astype(np.int64)[:, None]],
-                                      axis=1).reshape(-1), np.int64)
-        hc = gather_np(np.diff(hills[0].astype(np.int64)), np.int64)
-        hf = gather_np(hills[1].astype(np.int64).reshape(-1), np.int64)
-        p_off, p_flat = merge_intervals(pc, pf, n, world, 3)
-        h_off, h_flat = merge_intervals(hc, hf, n, world, 2)
-        valid = np.concatenate([x.cpu().numpy() for x in all_gather_v(valid_slice, self.group)])
-        self.cg.import_state(valid, piles,
-                             (p_off, p_flat[:, :2].astype(np.uint32), p_flat[:, 2].astype(np.uint32)),
-                             (h_off, h_flat.astype(np.uint32), None))
+        lap()
+        # 4. all-gather annotations + interval pools + validity bits (device to device), install them
+        n, nl = self.n_reads, padded_local(self.n_reads, world)
+        off, total = state_layout(nl)
+        packed = u8(total)
+        n_pool = int(self.cl.device_state().pool_count)
+        pool = u8(n_pool * POOL_RECORD)
+        self.cl.copy_device_state(pool=pool.data_ptr(), pool_count=n_pool,
+                                  **{k: packed.data_ptr() + o for k, o in off.items()})
+        vmax = max(self.slice_lens)
+        vbuf = u8(vmax)
+        if len(self.slice):
+            self.cs.copy_device_state(valid=vbuf.data_ptr())
+        rows = all_gather_rows(packed, self.group)
+        pools, pool_counts = gather_pools(pool[: n_pool * POOL_RECORD], self.group)
+        vrows = all_gather_rows(vbuf, self.group)
+        valid = torch.cat([vrows[k, : self.slice_lens[k]] for k in range(world)]) if sum(self.slice_lens) else vbuf
+        st = unpack_state(rows, nl, n, pool_counts)
+        torch.cuda.synchronize()
+        self.cg.import_state_device(pool=pools.data_ptr(), pool_count=sum(pool_counts), valid=valid.data_ptr(),
+                                    **{k: t.data_ptr() for k, t in st.items()})
         ev[3].record()
+        lap()
         # 5. replicated remainder
         self.cg.construct()
         n_tr = self.cg.remove_transitive_edges()
-        torch.cuda.synchronize()
+        lap()
         tl, tg = self.cl.timings(), self.cg.timings()
         self._tm = dict(tg)
         for k in ("dedupe_ms", "bucket_ms", "pile_ms", "pile_launches", "pile_overflow_reads", "pile_position_reads"):
             self._tm[k] = tl[k]
+        for k, name in enumerate(("emit", "exchange", "owner_init", "gather", "remainder")):
+            self._tm["wall_%s_ms" % name] = 1e3 * (wall[k + 1] - wall[k])
         self._tm["exchange_ms"] = ev[0].elapsed_time(ev[1])
         self._tm["gather_ms"] = ev[2].elapsed_time(ev[3])
         return n_tr

@@ -85,3 +85,89 @@ def test_sharded_initialize_matches_oracle(hip_ctx_factory, world, n, g, seed):
     cg.construct()
     parity.check_construct(cg, st)
     parity.check_tr(cg, st)
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+@pytest.mark.parametrize("n,g,seed", [(1000, 200_000, 1), (2000, 1_200_000, 33)])
+def test_sharded_device_path_matches_oracle(hip_ctx_factory, world, n, g, seed):
+    """The path bench.py runs for WORLD_SIZE > 1 (ShardedRunner.step): owner-grouped tuples
+    straight from the kernel, packed per-read state and interval pools gathered device to
+    device, rala_hip_import_state_device."""
+    ds = Dataset(n, g, seed)
+    st = parity.oracle_stages(ds)
+    ov = ds.overlaps
+    cuts = multi.slice_starts(ov.a_id, world)
+    dev = torch.device("cuda", 0)
+    sent, valid_parts = [], []
+    for k in range(world):
+        sl = ov.take(slice(cuts[k], cuts[k + 1]))
+        cs = hip_ctx_factory()
+        cs.set_reads(ds.read_len)
+        cs.set_overlaps(sl)
+        cs.dedupe()
+        t_r = torch.empty(4 * max(1, len(sl)), dtype=torch.int32, device=dev)
+        t_b = torch.empty_like(t_r)
+        counts = cs.emit_bound_tuples_bucketed(world, t_r.data_ptr(), t_b.data_ptr())
+        # the buckets hold exactly the tuples of the unbucketed emission
+        u_r, u_b = torch.empty_like(t_r), torch.empty_like(t_b)
+        cs.emit_bound_tuples(u_r.data_ptr(), u_b.data_ptr())
+        ur = u_r[: 4 * len(sl)].cpu().numpy().view(np.uint32).astype(np.int64)
+        ub = u_b[: 4 * len(sl)].cpu().numpy().view(np.uint32).astype(np.int64)
+        keep = ur != multi.NO_READ
+        off = 0
+        for p in range(world):
+            c = int(counts[p])
+            got = sorted(zip(t_r[off: off + c].cpu().numpy().view(np.uint32).tolist(),
+                             t_b[off: off + c].cpu().numpy().view(np.uint32).tolist()))
+            m = keep & (ur % world == p)
+            assert got == sorted(zip((ur[m] // world).tolist(), ub[m].tolist()))
+            off += c
+        sent.append((t_r, t_b, counts))
+        v = torch.empty(max(1, len(sl)), dtype=torch.uint8, device=dev)
+        if len(sl):
+            cs.copy_device_state(valid=v.data_ptr())
+        valid_parts.append(v[: len(sl)])
+    nl = multi.padded_local(n, world)
+    off_f, total = multi.state_layout(nl)
+    rows = torch.zeros((world, total), dtype=torch.uint8, device=dev)
+    pools = []
+    for k in range(world):
+        lr, bd = [], []
+        for src in range(world):
+            r, b, c = sent[src]
+            o = int(c[:k].sum())
+            lr.append(r[o: o + int(c[k])])
+            bd.append(b[o: o + int(c[k])])
+        lr, bd = torch.cat(lr).contiguous(), torch.cat(bd).contiguous()
+        cl = hip_ctx_factory()
+        cl.set_reads(np.ascontiguousarray(ds.read_len[k::world]))
+        torch.cuda.synchronize()
+        cl.set_bound_tuples_device(lr.data_ptr(), bd.data_ptr(), lr.numel())
+        cl.initialize()
+        n_pool = int(cl.device_state().pool_count)
+        pool = torch.empty(max(1, n_pool * multi.POOL_RECORD), dtype=torch.uint8, device=dev)
+        cl.copy_device_state(pool=pool.data_ptr(), pool_count=n_pool,
+                             **{f: rows[k].data_ptr() + o for f, o in off_f.items()})
+        pools.append(pool[: n_pool * multi.POOL_RECORD])
+    counts = [p.numel() // multi.POOL_RECORD for p in pools]
+    state = multi.unpack_state(rows, nl, n, counts)
+    pool_all = torch.cat(pools)
+    valid = torch.cat(valid_parts)
+    torch.cuda.synchronize()
+    cg = hip_ctx_factory()
+    cg.set_reads(ds.read_len)
+    cg.set_overlaps(ov)
+    cg.import_state_device(pool=pool_all.data_ptr(), pool_count=sum(counts), valid=valid.data_ptr(),
+                           **{f: t.data_ptr() for f, t in state.items()})
+    parity.assert_same("valid", cg.valid(), st["valid"])
+    p = cg.piles()
+    for key in ("begin", "end", "median", "p10", "alive"):
+        parity.assert_same("piles0." + key, p[key], st["piles0"][key])
+    pits, hills = cg.intervals(0), cg.intervals(1)
+    parity.assert_same("pits0.offsets", pits[0], st["pits0"][0])
+    parity.assert_same("pits0.pairs", pits[1], st["pits0"][1])
+    parity.assert_same("hills0.offsets", hills[0], st["hills0"][0])
+    parity.assert_same("hills0.pairs", hills[1], st["hills0"][1])
+    cg.construct()
+    parity.check_construct(cg, st)
+    parity.check_tr(cg, st)

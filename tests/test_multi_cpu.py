@@ -103,3 +103,82 @@ def test_slice_starts_on_run_boundaries():
         assert all(x <= y for x, y in zip(cuts, cuts[1:]))
         for c in cuts[1:-1]:
             assert c == len(a) or c == 0 or a[c] != a[c - 1]
+
+
+def _local_state(rank, world, n_reads, seed):
+    """what an owner rank would hold after initialize: per-read fields + an interval pool"""
+    rng = np.random.default_rng(seed * 100 + rank)
+    n = multi.n_local_reads(n_reads, rank, world)
+    f = {
+        "begin": rng.integers(0, 1 << 20, n).astype(np.uint32), "end": rng.integers(0, 1 << 31, n).astype(np.uint32) * 2,
+        "median": rng.integers(0, 1 << 16, n).astype(np.uint16), "p10": rng.integers(0, 1 << 16, n).astype(np.uint16),
+        "alive": rng.integers(0, 2, n).astype(np.uint8), "n_pits": rng.integers(0, 3, n).astype(np.uint8),
+        "n_hills": rng.integers(0, 3, n).astype(np.uint8),
+    }
+    cnt = f["n_pits"].astype(np.int64) + f["n_hills"]
+    slot = np.full(n, 0xFFFFFFFF, dtype=np.uint32)
+    order = rng.permutation(n)                         # pool order is arbitrary (atomic allocation)
+    pos = 0
+    pool = []
+    for j in order:
+        if cnt[j]:
+            slot[j] = pos
+            for i in range(cnt[j]):
+                pool.append((j * world + rank, i, 7 * i + rank))
+            pos += cnt[j]
+    f["slot"] = slot
+    return f, np.array(pool, dtype=np.uint32).reshape(-1, 3)
+
+
+def _state_worker(rank, world, port, seed, n_reads, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        f, pool = _local_state(rank, world, n_reads, seed)
+        nl = multi.padded_local(n_reads, world)
+        off, total = multi.state_layout(nl)
+        packed = np.zeros(total, dtype=np.uint8)
+        for name, w in multi.STATE_FIELDS:
+            raw = f[name].view(np.uint8)
+            packed[off[name]: off[name] + raw.size] = raw
+        rows = multi.all_gather_rows(torch.from_numpy(packed))
+        pools, counts = multi.gather_pools(torch.from_numpy(pool.reshape(-1).view(np.uint8).copy()))
+        st = multi.unpack_state(rows, nl, n_reads, counts)
+        q.put((rank, {k: v.numpy().tolist() for k, v in st.items()},
+               pools.numpy().view(np.uint32).reshape(-1, 3).tolist(), counts))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_reads", [(2, 37), (3, 41), (2, 1)])
+def test_packed_state_gather(world, n_reads):
+    seed = 5
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_state_worker, args=(r, world, port, seed, n_reads, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    locs = [_local_state(r, world, n_reads, seed) for r in range(world)]
+    for rank, st, pools, counts in res:
+        assert counts == [len(l[1]) for l in locs]
+        for name, w in multi.STATE_FIELDS:
+            if name == "slot":
+                continue
+            want = multi.interleave([l[0][name] for l in locs], n_reads, world)
+            got = np.array(st[name], dtype=np.int64) & ((1 << (8 * w)) - 1)
+            assert got.tolist() == want.astype(np.int64).tolist(), name
+        # every read's intervals are found through its rebased slot, in order
+        for r in range(n_reads):
+            k, j = r % world, r // world
+            cnt = int(locs[k][0]["n_pits"][j]) + int(locs[k][0]["n_hills"][j])
+            s = st["slot"][r]
+            if cnt == 0:
+                assert s == multi.NO_SLOT
+            else:
+                assert [tuple(x) for x in pools[s: s + cnt]] == [(r, i, 7 * i + k) for i in range(cnt)]
