@@ -464,47 +464,87 @@ __global__ __launch_bounds__(64) void pile_runs_kernel(PileArgs A, uint32_t* ove
         }
         wave_sync();
         {
-            // 16 bytes (8 positions) per lane per store, consecutive lanes -> consecutive
-            // addresses (1 KiB per wave instruction); four independent groups per lane and
-            // iteration so that their run look-ups overlap
+            // Expansion, 16 bytes (8 positions) per lane and store, consecutive lanes ->
+            // consecutive addresses (1 KiB per wave instruction).  Per segment of 16384
+            // positions: a bitmap with one bit per position that starts a run, and per
+            // 32-bit word the number of run starts before it; the run of position p is then
+            // pref[w] + popcount(bits up to p) - no searching, and the byte of the bitmap
+            // that belongs to a lane's 8 positions says where (if anywhere) the value changes.
+            constexpr uint32_t kSeg = 16384, kBmWords = kSeg / 32;
+            uint32_t* bm = sm + L::X;                       // the group counts are no longer needed
+            uint16_t* pref = (uint16_t*)(bm + kBmWords);
             uint4* dst = (uint4*)(A.pile + A.pile_off[r]);
             const uint32_t nv = (n + 7) / 8;
-            for (uint32_t g0 = lane; g0 < nv; g0 += 256) {
-                uint32_t k[4], nxt[4], v[4];
-#pragma unroll
-                for (uint32_t u = 0; u < 4; ++u) {
-                    const uint32_t g = umin(g0 + 64 * u, nv - 1);
-                    k[u] = idx[(g * 8) >> shift];
+            if (lane == 0) rv[R] = 0;                       // padding behind the last base (rs[R] = n)
+            uint32_t kbase = 0;                             // run that contains the segment's first position
+            for (uint32_t s0 = 0; s0 < nv * 8; s0 += kSeg) {
+                wave_sync();
+                ((uint4*)bm)[lane] = make_uint4(0, 0, 0, 0);
+                ((uint4*)bm)[lane + 64] = make_uint4(0, 0, 0, 0);
+                wave_sync();
+                for (uint32_t k = 1 + lane; k <= R; k += 64) {
+                    const uint32_t st = rs[k] - s0;         // starts are distinct positions
+                    if (st < kSeg && rs[k] > 0) atomicOr(&bm[st >> 5], 1u << (st & 31));
                 }
+                wave_sync();
+                {
+                    const uint4 a = ((const uint4*)bm)[2 * lane], b = ((const uint4*)bm)[2 * lane + 1];
+                    const uint32_t c[8] = {(uint32_t)__popc(a.x), (uint32_t)__popc(a.y), (uint32_t)__popc(a.z),
+                                           (uint32_t)__popc(a.w), (uint32_t)__popc(b.x), (uint32_t)__popc(b.y),
+                                           (uint32_t)__popc(b.z), (uint32_t)__popc(b.w)};
+                    const uint32_t tot = c[0] + c[1] + c[2] + c[3] + c[4] + c[5] + c[6] + c[7];
+                    const uint32_t incl = wave_scan_incl(tot, OpAdd());
+                    uint32_t run = kbase + incl - tot;
+                    uint32_t pk[4];
 #pragma unroll
-                for (uint32_t u = 0; u < 4; ++u) nxt[u] = rs[k[u] + 1];
-#pragma unroll
-                for (uint32_t u = 0; u < 4; ++u) {
-                    const uint32_t p = umin(g0 + 64 * u, nv - 1) * 8;
-                    while (nxt[u] <= p) { ++k[u]; nxt[u] = rs[k[u] + 1]; }
+                    for (int x = 0; x < 4; ++x) {
+                        const uint32_t lo = run; run += c[2 * x];
+                        const uint32_t hi = run; run += c[2 * x + 1];
+                        pk[x] = lo | (hi << 16);
+                    }
+                    ((uint4*)pref)[lane] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                    kbase += (uint32_t)__shfl((int)incl, 63, 64);
                 }
+                wave_sync();
+                const uint32_t g_lo = s0 / 8, g_hi = umin(nv, (s0 + kSeg) / 8);
+                for (uint32_t g0 = g_lo + lane; g0 < g_hi; g0 += 256) {
+                    uint32_t bits[4], k[4], v[4];
 #pragma unroll
-                for (uint32_t u = 0; u < 4; ++u) v[u] = rv[k[u]];
+                    for (uint32_t u = 0; u < 4; ++u) {
+                        const uint32_t g = umin(g0 + 64 * u, g_hi - 1);
+                        const uint32_t w = (g * 8 - s0) >> 5;
+                        bits[u] = bm[w];
+                        k[u] = pref[w];
+                    }
 #pragma unroll
-                for (uint32_t u = 0; u < 4; ++u) {
-                    const uint32_t g = g0 + 64 * u;
-                    if (g >= nv) break;
-                    const uint32_t p = g * 8;
-                    uint32_t w[4];
-                    if (nxt[u] >= p + 8 && p + 8 <= n) {
+                    for (uint32_t u = 0; u < 4; ++u) {
+                        const uint32_t g = umin(g0 + 64 * u, g_hi - 1);
+                        const uint32_t sh = (g * 8) & 31;
+                        k[u] += (uint32_t)__popc(bits[u] & ((2u << sh) - 1u));
+                        bits[u] = (bits[u] >> (sh + 1)) & 0x7Fu;        // starts at positions 1 .. 7 of the group
+                        v[u] = rv[k[u]];
+                    }
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; ++u) {
+                        const uint32_t g = g0 + 64 * u;
+                        if (g >= g_hi) break;
                         const uint32_t vv = v[u] | (v[u] << 16);
-                        w[0] = w[1] = w[2] = w[3] = vv;
-                    } else {
-                        uint32_t kk = k[u], nx = nxt[u], vv = v[u];
-#pragma unroll
-                        for (int x = 0; x < 8; ++x) {
-                            const uint32_t q = p + x;
-                            while (nx <= q && kk + 1 < R) { ++kk; nx = rs[kk + 1]; vv = rv[kk]; }
-                            const uint32_t val = q < n ? vv : 0u;
-                            if (x & 1) w[x >> 1] |= val << 16; else w[x >> 1] = val;
+                        uint64_t lo = (uint64_t)vv | ((uint64_t)vv << 32), hi = lo;
+                        uint32_t inner = bits[u], kk = k[u];
+                        while (inner) {
+                            const uint32_t x = (uint32_t)__ffs((int)inner);     // position 1 .. 7 inside the group
+                            inner &= inner - 1;
+                            const uint32_t nvv = rv[++kk];
+                            const uint64_t fill = (uint64_t)(nvv | (nvv << 16)) * 0x100000001ull;
+                            const uint64_t mlo = x < 4 ? (~0ull << (16 * x)) : 0ull;
+                            const uint64_t mhi = x < 4 ? ~0ull : (~0ull << (16 * (x - 4)));
+                            lo = (lo & ~mlo) | (fill & mlo);
+                            hi = (hi & ~mhi) | (fill & mhi);
+                        }
+                        if (A.stop_after != 77) {
+                            dst[g] = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
                         }
                     }
-                    dst[g] = make_uint4(w[0], w[1], w[2], w[3]);
                 }
             }
         }
