@@ -167,6 +167,9 @@ struct rala_hip_ctx {
     uint32_t t_n0 = 0, t_n1 = 0, t_rounds = 0, t_n_kept = 0, t_n_nodes = 0, t_n_edges = 0;
     rala_hip::DevBuf<uint8_t> d_t_state, d_t_round, d_dirty, d_n_pits0, d_touched;
     rala_hip::DevBuf<uint16_t> d_cmed;
+    rala_hip::DevBuf<uint64_t> d_med_keys[2];
+    rala_hip::DevBuf<uint8_t> d_med_tmp;
+    rala_hip::DevBuf<uint32_t> d_cc_flags;
     rala_hip::DevBuf<uint32_t> d_rank, d_alive_reads, d_t_tmp[2], d_kept_item, d_dovetail, d_epos, d_node_rank,
         d_node_read, d_e[3], d_t_death[2];
     rala_hip::PinnedBuf<uint32_t> p_alive_reads;

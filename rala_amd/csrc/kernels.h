@@ -200,6 +200,11 @@ void launch_tr_fill(const uint32_t* src, uint32_t n_nodes, uint32_t n_edges, uin
 void launch_cc_init(uint32_t* label, uint32_t n, hipStream_t s);
 void launch_cc_hook(const uint32_t* edges, uint32_t n_edges, uint32_t* label, uint32_t* changed, hipStream_t s);
 void launch_cc_compress(uint32_t* label, uint32_t n, hipStream_t s);
+// median of the pile medians per component (median_kernels.hip); keys / sorted: n_alive uint64 each
+size_t component_median_workspace(uint32_t n);
+hipError_t launch_component_medians(const uint32_t* label, const uint8_t* touched, const uint32_t* alive_reads,
+                                    const uint16_t* median, uint32_t n_alive, uint64_t* keys, uint64_t* sorted, void* tmp,
+                                    size_t tmp_bytes, uint16_t* cmed, hipStream_t s);
 void launch_tr_count(const uint8_t* marks, uint32_t n_edges, uint32_t* n_pairs, hipStream_t s);
 
 }  // namespace rala_hip

@@ -773,6 +773,10 @@ int tail_death_scan(rala_hip_ctx* ctx, const TailList& L, uint32_t which, uint32
 // Graph::preprocess (chimeras) + node/edge build with the survivor lists resident on the device
 int gpu_tail_run(rala_hip_ctx* ctx) {
     hipStream_t s = ctx->stream;
+    Trace trc;
+    auto mark = [&](const char* what, size_t k = 0) {
+        if (trc.on) { (void)hipStreamSynchronize(s); trc(what, k); }
+    };
     const uint32_t n_reads = (uint32_t)ctx->n_reads;
     const uint32_t M = ctx->t_n0 + ctx->t_n1;
     const size_t big = (size_t)std::max<uint64_t>(n_reads, M) + 2;
@@ -797,20 +801,20 @@ int gpu_tail_run(rala_hip_ctx* ctx) {
     uint32_t n_alive = 0;
     HIPCHECK(hipMemcpyAsync(&n_alive, ctx->d_t_tmp[1].p + n_reads, 4, hipMemcpyDeviceToHost, s));
     HIPCHECK(hipStreamSynchronize(s));
-    HIPCHECK(ctx->p_alive_reads.ensure(n_alive)); HIPCHECK(ctx->p_touched.ensure(n_alive));
-    HIPCHECK(ctx->p_cmed.ensure(n_alive)); HIPCHECK(ctx->p_cc_label.ensure(n_alive));
     HIPCHECK(ctx->d_touched.ensure(n_alive)); HIPCHECK(ctx->d_cmed.ensure(n_alive));
     HIPCHECK(ctx->d_cc_edges.ensure(2 * (size_t)M)); HIPCHECK(ctx->d_cc_label.ensure(n_alive));
-    HIPCHECK(hipMemcpyAsync(ctx->p_alive_reads.p, ctx->d_alive_reads.p, (size_t)n_alive * 4, hipMemcpyDeviceToHost, s));
+    HIPCHECK(ctx->d_med_keys[0].ensure(n_alive)); HIPCHECK(ctx->d_med_keys[1].ensure(n_alive));
+    const size_t med_tmp = component_median_workspace(n_alive);
+    HIPCHECK(ctx->d_med_tmp.ensure(med_tmp));
+    HIPCHECK(ctx->d_cc_flags.ensure(8));
+    mark("tail: ranks", n_alive);
 
     // break over chimeric hills, first re-trim (graph.cpp:704-736; no promotion here)
     launch_break_hills(R, n_reads, s);
     launch_retrim(L, R, 0, 0, ctx->d_small.p + 2, s);
     HIPCHECK(hipMemsetAsync(ctx->d_dirty.p, 0, n_reads, s));
+    mark("tail: hills + retrim", M);
 
-    std::vector<uint32_t>& cnt = ctx->scratch_u32b;
-    std::vector<uint32_t>& mrank = ctx->scratch_u32a;
-    std::vector<uint16_t> mm;
     uint32_t rounds = 0;
     for (;; ++rounds) {                                             // graph.cpp:738-829
         if (rounds >= 255) return fail(ctx, RALA_HIP_EDEVICE, "chimera loop did not settle");
@@ -819,46 +823,25 @@ int gpu_tail_run(rala_hip_ctx* ctx) {
         launch_cc_edges(L, ctx->d_rank.p, ctx->d_cc_edges.p, ctx->d_touched.p, s);
         launch_cc_init(ctx->d_cc_label.p, n_alive, s);
         for (int it = 0;; ++it) {
-            HIPCHECK(hipMemsetAsync(ctx->d_small.p + 2, 0, 4, s));
-            for (int k = 0; k < 4; ++k) {
-                launch_cc_hook(ctx->d_cc_edges.p, M, ctx->d_cc_label.p, ctx->d_small.p + 2, s);
+            // four hook + compress rounds per host check; a round that hooked nothing ends it
+            constexpr int kBatch = 4;
+            HIPCHECK(hipMemsetAsync(ctx->d_cc_flags.p, 0, kBatch * 4, s));
+            for (int k = 0; k < kBatch; ++k) {
+                launch_cc_hook(ctx->d_cc_edges.p, M, ctx->d_cc_label.p, ctx->d_cc_flags.p + k, s);
                 launch_cc_compress(ctx->d_cc_label.p, n_alive, s);
             }
-            uint32_t changed = 0;
-            HIPCHECK(hipMemcpyAsync(&changed, ctx->d_small.p + 2, 4, hipMemcpyDeviceToHost, s));
+            uint32_t changed[kBatch];
+            HIPCHECK(hipMemcpyAsync(changed, ctx->d_cc_flags.p, sizeof(changed), hipMemcpyDeviceToHost, s));
             HIPCHECK(hipStreamSynchronize(s));
-            if (!changed) break;
+            if (!changed[kBatch - 1]) break;
             if (it > 10000) return fail(ctx, RALA_HIP_EDEVICE, "connected components did not converge");
         }
-        HIPCHECK(hipMemcpyAsync(ctx->p_cc_label.p, ctx->d_cc_label.p, (size_t)n_alive * 4, hipMemcpyDeviceToHost, s));
-        HIPCHECK(hipMemcpyAsync(ctx->p_touched.p, ctx->d_touched.p, n_alive, hipMemcpyDeviceToHost, s));
-        HIPCHECK(hipStreamSynchronize(s));
-        // median of the pile medians per component (graph.cpp:777-783), host: counting sort by label
-        {
-            const uint32_t* label = ctx->p_cc_label.p;
-            const uint8_t* touched = ctx->p_touched.p;
-            const uint32_t* reads = ctx->p_alive_reads.p;
-            uint16_t* cmed = ctx->p_cmed.p;
-            mrank.clear();
-            for (uint32_t q = 0; q < n_alive; ++q) if (touched[q]) mrank.push_back(q);
-            cnt.assign((size_t)n_alive + 1, 0);
-            for (uint32_t q : mrank) ++cnt[label[q] + 1];
-            for (uint32_t q = 0; q < n_alive; ++q) cnt[q + 1] += cnt[q];
-            std::vector<uint32_t>& idx = ctx->scratch_u32c;
-            idx.resize(mrank.size());
-            for (size_t k = 0; k < mrank.size(); ++k) idx[cnt[label[mrank[k]]]++] = mrank[k];
-            for (size_t b0 = 0; b0 < idx.size();) {
-                const uint32_t lab = label[idx[b0]];
-                size_t t = b0;
-                mm.clear();
-                while (t < idx.size() && label[idx[t]] == lab) { mm.push_back(ctx->h_median[reads[idx[t]]]); ++t; }
-                std::nth_element(mm.begin(), mm.begin() + mm.size() / 2, mm.end());
-                const uint16_t med = mm[mm.size() / 2];
-                for (size_t k = b0; k < t; ++k) cmed[idx[k]] = med;
-                b0 = t;
-            }
-        }
-        HIPCHECK(hipMemcpyAsync(ctx->d_cmed.p, ctx->p_cmed.p, (size_t)n_alive * 2, hipMemcpyHostToDevice, s));
+        mark("tail: components");
+        // median of the pile medians per component (graph.cpp:777-783)
+        HIPCHECK(launch_component_medians(ctx->d_cc_label.p, ctx->d_touched.p, ctx->d_alive_reads.p, ctx->d_median.p, n_alive,
+                                          ctx->d_med_keys[0].p, ctx->d_med_keys[1].p, ctx->d_med_tmp.p, med_tmp,
+                                          ctx->d_cmed.p, s));
+        mark("tail: component medians");
         launch_break_pits(R, ctx->d_alive_reads.p, ctx->d_touched.p, ctx->d_cmed.p, n_alive, s);
         HIPCHECK(hipMemsetAsync(ctx->d_small.p + 2, 0, 4, s));
         launch_retrim(L, R, 1, rounds, ctx->d_small.p + 2, s);
@@ -866,6 +849,7 @@ int gpu_tail_run(rala_hip_ctx* ctx) {
         uint32_t dropped = 0;
         HIPCHECK(hipMemcpyAsync(&dropped, ctx->d_small.p + 2, 4, hipMemcpyDeviceToHost, s));
         HIPCHECK(hipStreamSynchronize(s));
+        mark("tail: pits + retrim", dropped);
         if (!dropped) break;
     }
     ctx->t_rounds = rounds + 1;
@@ -878,6 +862,7 @@ int gpu_tail_run(rala_hip_ctx* ctx) {
         if (rc != RALA_HIP_OK) return rc;
         launch_tail_apply_scan(L, ctx->d_alive.p, which, death, s);
         launch_kill_reads(death, ctx->d_alive.p, n_reads, s);
+        mark("tail: containment scan", which);
     }
 
     // the final overlap list: originals in order, then the promoted ones round by round
@@ -892,6 +877,7 @@ int gpu_tail_run(rala_hip_ctx* ctx) {
         n_kept += c;
     }
     ctx->t_n_kept = n_kept;
+    mark("tail: final list", n_kept);
     // nodes: two per surviving read (graph.cpp:553-574)
     launch_u8_to_u32(ctx->d_alive.p, ctx->d_t_tmp[0].p, n_reads, s);
     launch_exclusive_scan(ctx->d_t_tmp[0].p, ctx->d_node_rank.p, n_reads, ctx->d_scan_ws.p, s);
@@ -910,6 +896,7 @@ int gpu_tail_run(rala_hip_ctx* ctx) {
                        ctx->d_e[0].p, ctx->d_e[1].p, ctx->d_e[2].p, s);
     HIPCHECK(hipStreamSynchronize(s));
     HIPCHECK(hipGetLastError());
+    mark("tail: nodes + edges", ctx->t_n_edges);
     ctx->tail_on_device = true;
     ctx->host_stale = true;
     return RALA_HIP_OK;
