@@ -127,10 +127,14 @@ void launch_bucket_tuples(const OvlSoA& o, uint32_t n_reads, uint32_t world, uin
 void launch_count_tuples(const uint32_t* reads, uint64_t n, uint32_t n_reads, uint32_t* counts, hipStream_t s);
 void launch_scatter_tuples(const uint32_t* reads, const uint32_t* bounds, uint64_t n, uint32_t n_reads,
                            uint32_t* cursor, uint32_t* ev, hipStream_t s);
+// overlaps that would delete a read (contained read, container without pits / hills)
+struct KillList {
+    uint32_t* count;            // device counter, zeroed before classify
+    uint32_t *ovl, *target, *keeper;
+};
 void launch_classify(const OvlSoA& o, uint32_t n_reads, const uint8_t* valid, const ReadState& rs, uint8_t* cls,
-                     hipStream_t s);
-void launch_death_round(const OvlSoA& o, const uint8_t* cls, const uint32_t* death_old, uint32_t* death_new,
-                        hipStream_t s);
+                     const KillList& kl, hipStream_t s);
+void launch_death_round(const KillList& kl, const uint32_t* death_old, uint32_t* death_new, hipStream_t s);
 void launch_death_diff(const uint32_t* a, const uint32_t* b, uint32_t n, uint32_t* changed, hipStream_t s);
 void launch_finish_pass2(const OvlSoA& o, uint8_t* cls, const uint32_t* death, const ReadState& rs,
                          uint32_t* flag_overlap, uint32_t* flag_internal, hipStream_t s);

@@ -293,42 +293,76 @@ __device__ __forceinline__ Coords load_coords(const OvlSoA& o, uint64_t i) {
 
 // Static part of construct's second pass: everything about overlap i that does
 // not depend on which piles earlier overlaps deleted.
+// A workgroup classifies a chunk of kClassifyChunk consecutive overlaps (8 per thread) and
+// appends those that would delete a read to the killer list {overlap, target, keeper}: slots
+// inside the chunk through an LDS counter (one add per wavefront and iteration), one global
+// add per workgroup.  The list order is irrelevant (the fixed point takes minima).
+constexpr uint32_t kClassifyChunk = 2048;
+
 __global__ __launch_bounds__(kBlock) void classify_kernel(OvlSoA o, uint32_t n_reads,
                                                           const uint8_t* __restrict__ valid, ReadState rs,
-                                                          uint8_t* __restrict__ cls) {
-    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= o.n) return;
-    uint8_t out = 0;
-    if (valid[i]) {
-        const uint32_t a = o.a_id[i], b = o.b_id[i];
-        if (rs.alive[a] && rs.alive[b]) {
-            Coords c = load_coords(o, i);
-            const uint32_t st = o.strand[i];
-            const uint32_t Ba = rs.begin[a], Ea = rs.end[a], Bb = rs.begin[b], Eb = rs.end[b];
-            if (ovl_trim(c, st, Ba, Ea, Bb, Eb)) {
-                const uint32_t t = ovl_type(c, st, Ba, Ea, Bb, Eb);
-                out = (uint8_t)(kClsOk | t);
-                if (t == kTypeB && (rs.n_pits[b] | rs.n_hills[b]) == 0) out |= kClsKillsA;
-                if (t == kTypeA && (rs.n_pits[a] | rs.n_hills[a]) == 0) out |= kClsKillsB;
+                                                          uint8_t* __restrict__ cls, KillList kl) {
+    __shared__ uint32_t s_cnt, s_base;
+    constexpr uint32_t kPer = kClassifyChunk / kBlock;
+    const uint32_t lane = threadIdx.x & 63;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    uint32_t slot[kPer];
+    uint8_t res[kPer];
+#pragma unroll
+    for (uint32_t u = 0; u < kPer; ++u) {
+        const uint64_t i = (uint64_t)blockIdx.x * kClassifyChunk + u * kBlock + threadIdx.x;
+        uint8_t out = 0;
+        if (i < o.n && valid[i]) {
+            const uint32_t a = o.a_id[i], b = o.b_id[i];
+            if (rs.alive[a] && rs.alive[b]) {
+                Coords c = load_coords(o, i);
+                const uint32_t st = o.strand[i];
+                const uint32_t Ba = rs.begin[a], Ea = rs.end[a], Bb = rs.begin[b], Eb = rs.end[b];
+                if (ovl_trim(c, st, Ba, Ea, Bb, Eb)) {
+                    const uint32_t t = ovl_type(c, st, Ba, Ea, Bb, Eb);
+                    out = (uint8_t)(kClsOk | t);
+                    if (t == kTypeB && (rs.n_pits[b] | rs.n_hills[b]) == 0) out |= kClsKillsA;
+                    if (t == kTypeA && (rs.n_pits[a] | rs.n_hills[a]) == 0) out |= kClsKillsB;
+                }
             }
         }
+        if (i < o.n) cls[i] = out;
+        res[u] = out;
+        const bool k = (out & (kClsKillsA | kClsKillsB)) != 0;
+        const uint64_t m = __ballot(k);
+        uint32_t base = 0;
+        if (m) {
+            if (lane == 0) base = atomicAdd(&s_cnt, (uint32_t)__popcll(m));
+            base = (uint32_t)__shfl((int)base, 0, 64);
+        }
+        slot[u] = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
     }
-    cls[i] = out;
+    __syncthreads();
+    if (threadIdx.x == 0) s_base = s_cnt ? atomicAdd(kl.count, s_cnt) : 0u;
+    __syncthreads();
+    const uint32_t base = s_base;
+#pragma unroll
+    for (uint32_t u = 0; u < kPer; ++u) {
+        if (!(res[u] & (kClsKillsA | kClsKillsB))) continue;
+        const uint64_t i = (uint64_t)blockIdx.x * kClassifyChunk + u * kBlock + threadIdx.x;
+        const uint32_t a = o.a_id[i], b = o.b_id[i];
+        const uint32_t w = base + slot[u];
+        kl.ovl[w] = (uint32_t)i;
+        kl.target[w] = (res[u] & kClsKillsA) ? a : b;
+        kl.keeper[w] = (res[u] & kClsKillsA) ? b : a;
+    }
 }
 
 // One Jacobi round of death[r] = min { i : overlap i would delete r and its
 // container is still alive when i is reached }.
-__global__ __launch_bounds__(kBlock) void death_round_kernel(OvlSoA o, const uint8_t* __restrict__ cls,
-                                                             const uint32_t* __restrict__ death_old,
+__global__ __launch_bounds__(kBlock) void death_round_kernel(KillList kl, const uint32_t* __restrict__ death_old,
                                                              uint32_t* death_new) {
-    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= o.n) return;
-    const uint8_t c = cls[i];
-    if (!(c & (kClsKillsA | kClsKillsB))) return;
-    const uint32_t a = o.a_id[i], b = o.b_id[i];
-    const uint32_t target = (c & kClsKillsA) ? a : b;
-    const uint32_t keeper = (c & kClsKillsA) ? b : a;
-    if (death_old[keeper] > (uint32_t)i) atomicMin(&death_new[target], (uint32_t)i);
+    const uint32_t n = *kl.count;
+    for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < n; k += gridDim.x * kBlock) {
+        const uint32_t i = kl.ovl[k];
+        if (death_old[kl.keeper[k]] > i) atomicMin(&death_new[kl.target[k]], i);
+    }
 }
 
 __global__ __launch_bounds__(kBlock) void death_diff_kernel(const uint32_t* __restrict__ x,
@@ -336,7 +370,7 @@ __global__ __launch_bounds__(kBlock) void death_diff_kernel(const uint32_t* __re
                                                             uint32_t* changed) {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     const bool d = i < n && x[i] != y[i];
-    if (__ballot(d) && (threadIdx.x & 63) == 0) atomicOr(changed, 1u);
+    if (d) *changed = 1u;       // benign race: every writer stores the same value
 }
 
 // Liveness, hill span counters (Pile::check_chimeric_hills, pile.cpp:457-469,
@@ -447,12 +481,15 @@ void launch_scatter_tuples(const uint32_t* reads, const uint32_t* bounds, uint64
     }
 }
 void launch_classify(const OvlSoA& o, uint32_t n_reads, const uint8_t* valid, const ReadState& rs, uint8_t* cls,
-                     hipStream_t s) {
-    if (o.n) hipLaunchKernelGGL(classify_kernel, grid_for(o.n), dim3(kBlock), 0, s, o, n_reads, valid, rs, cls);
+                     const KillList& kl, hipStream_t s) {
+    if (o.n) {
+        hipLaunchKernelGGL(classify_kernel, dim3((uint32_t)((o.n + kClassifyChunk - 1) / kClassifyChunk)), dim3(kBlock), 0, s,
+                           o, n_reads, valid, rs, cls, kl);
+    }
 }
-void launch_death_round(const OvlSoA& o, const uint8_t* cls, const uint32_t* death_old, uint32_t* death_new,
-                        hipStream_t s) {
-    if (o.n) hipLaunchKernelGGL(death_round_kernel, grid_for(o.n), dim3(kBlock), 0, s, o, cls, death_old, death_new);
+void launch_death_round(const KillList& kl, const uint32_t* death_old, uint32_t* death_new, hipStream_t s) {
+    // the list length lives on the device: a fixed grid strides over it
+    hipLaunchKernelGGL(death_round_kernel, dim3(8192), dim3(kBlock), 0, s, kl, death_old, death_new);
 }
 void launch_death_diff(const uint32_t* a, const uint32_t* b, uint32_t n, uint32_t* changed, hipStream_t s) {
     if (n) hipLaunchKernelGGL(death_diff_kernel, grid_for(n), dim3(kBlock), 0, s, a, b, n, changed);

@@ -754,16 +754,20 @@ int tail_death_scan(rala_hip_ctx* ctx, const TailList& L, uint32_t which, uint32
     const uint32_t n_reads = (uint32_t)ctx->n_reads;
     int cur = 0;
     HIPCHECK(hipMemsetAsync(ctx->d_t_death[0].p, 0xFF, (size_t)n_reads * 4, s));
+    HIPCHECK(ctx->d_cc_flags.ensure(8));
     for (int round = 0;; ++round) {
-        HIPCHECK(hipMemsetAsync(ctx->d_t_death[cur ^ 1].p, 0xFF, (size_t)n_reads * 4, s));
-        HIPCHECK(hipMemsetAsync(ctx->d_small.p + 2, 0, 4, s));
-        launch_tail_death_round(L, ctx->d_alive.p, which, ctx->d_t_death[cur].p, ctx->d_t_death[cur ^ 1].p, s);
-        launch_death_diff(ctx->d_t_death[cur].p, ctx->d_t_death[cur ^ 1].p, n_reads, ctx->d_small.p + 2, s);
-        uint32_t changed = 0;
-        HIPCHECK(hipMemcpyAsync(&changed, ctx->d_small.p + 2, 4, hipMemcpyDeviceToHost, s));
+        constexpr int kBatch = 3;
+        HIPCHECK(hipMemsetAsync(ctx->d_cc_flags.p, 0, kBatch * 4, s));
+        for (int k = 0; k < kBatch; ++k) {
+            HIPCHECK(hipMemsetAsync(ctx->d_t_death[cur ^ 1].p, 0xFF, (size_t)n_reads * 4, s));
+            launch_tail_death_round(L, ctx->d_alive.p, which, ctx->d_t_death[cur].p, ctx->d_t_death[cur ^ 1].p, s);
+            launch_death_diff(ctx->d_t_death[cur].p, ctx->d_t_death[cur ^ 1].p, n_reads, ctx->d_cc_flags.p + k, s);
+            cur ^= 1;
+        }
+        uint32_t changed[kBatch];
+        HIPCHECK(hipMemcpyAsync(changed, ctx->d_cc_flags.p, sizeof(changed), hipMemcpyDeviceToHost, s));
         HIPCHECK(hipStreamSynchronize(s));
-        cur ^= 1;
-        if (!changed) break;
+        if (!changed[kBatch - 1]) break;
         if (round > 100000) return fail(ctx, RALA_HIP_EDEVICE, "containment fixed point did not converge");
     }
     *death_out = ctx->d_t_death[cur].p;
@@ -1431,24 +1435,34 @@ int rala_hip_construct(rala_hip_ctx* ctx, const rala_hip_overlaps* sens, uint64_
     const ReadState rs = read_state(ctx);
 
     // ---- pass 2, static part ----
+    for (int k = 0; k < 3; ++k) HIPCHECK(ctx->d_kill[k].ensure(N));
+    HIPCHECK(ctx->d_kill_count.ensure(4));
+    KillList kl;
+    kl.count = ctx->d_kill_count.p; kl.ovl = ctx->d_kill[0].p; kl.target = ctx->d_kill[1].p; kl.keeper = ctx->d_kill[2].p;
     HIPCHECK(hipEventRecord(ctx->ev[4], s));
-    launch_classify(ctx->ovl, n_reads, ctx->d_valid.p, rs, ctx->d_cls.p, s);
+    HIPCHECK(hipMemsetAsync(kl.count, 0, 4, s));
+    launch_classify(ctx->ovl, n_reads, ctx->d_valid.p, rs, ctx->d_cls.p, kl, s);
     HIPCHECK(hipEventRecord(ctx->ev[5], s));
     // ---- in-order containment removal as a fixed point ----
     int cur = 0;
     HIPCHECK(hipMemsetAsync(ctx->d_death[0].p, 0xFF, (size_t)n_reads * 4, s));
     ctx->tm.death_rounds = 0;
+    HIPCHECK(ctx->d_cc_flags.ensure(8));
     for (;;) {
-        HIPCHECK(hipMemsetAsync(ctx->d_death[cur ^ 1].p, 0xFF, (size_t)n_reads * 4, s));
-        HIPCHECK(hipMemsetAsync(ctx->d_small.p + 2, 0, 4, s));
-        launch_death_round(ctx->ovl, ctx->d_cls.p, ctx->d_death[cur].p, ctx->d_death[cur ^ 1].p, s);
-        launch_death_diff(ctx->d_death[cur].p, ctx->d_death[cur ^ 1].p, n_reads, ctx->d_small.p + 2, s);
-        uint32_t changed = 0;
-        HIPCHECK(hipMemcpyAsync(&changed, ctx->d_small.p + 2, 4, hipMemcpyDeviceToHost, s));
+        // rounds past the fixed point change nothing, so a few are run per host check
+        constexpr int kBatch = 3;
+        HIPCHECK(hipMemsetAsync(ctx->d_cc_flags.p, 0, kBatch * 4, s));
+        for (int k = 0; k < kBatch; ++k) {
+            HIPCHECK(hipMemsetAsync(ctx->d_death[cur ^ 1].p, 0xFF, (size_t)n_reads * 4, s));
+            launch_death_round(kl, ctx->d_death[cur].p, ctx->d_death[cur ^ 1].p, s);
+            launch_death_diff(ctx->d_death[cur].p, ctx->d_death[cur ^ 1].p, n_reads, ctx->d_cc_flags.p + k, s);
+            cur ^= 1;
+            ++ctx->tm.death_rounds;
+        }
+        uint32_t changed[kBatch];
+        HIPCHECK(hipMemcpyAsync(changed, ctx->d_cc_flags.p, sizeof(changed), hipMemcpyDeviceToHost, s));
         HIPCHECK(hipStreamSynchronize(s));
-        cur ^= 1;
-        ++ctx->tm.death_rounds;
-        if (!changed) break;
+        if (!changed[kBatch - 1]) break;
         if (ctx->tm.death_rounds > 100000) return fail(ctx, RALA_HIP_EDEVICE, "containment fixed point did not converge");
     }
     HIPCHECK(hipEventRecord(ctx->ev[6], s));
