@@ -151,12 +151,11 @@ __global__ __launch_bounds__(kBlock) void scatter_bounds_kernel(OvlSoA o, uint32
     if (seg) base = atomicAdd(&cursor[a], 2u * seg);
     base = (uint32_t)__shfl((int)base, (int)leader, 64);
     if (!ok) return;
+    // every cursor starts even (counts are even) and moves in steps of two: 8-byte stores
     const uint32_t pa = base + 2u * (lane - leader);
-    ev[pa] = (o.a_begin[i] + 15u) << 1;
-    ev[pa + 1] = ((o.a_end[i] - 15u) << 1) | 1u;
+    *(uint2*)(ev + pa) = make_uint2((o.a_begin[i] + 15u) << 1, ((o.a_end[i] - 15u) << 1) | 1u);
     const uint32_t pb = atomicAdd(&cursor[b], 2u);
-    ev[pb] = (o.b_begin[i] + 15u) << 1;
-    ev[pb + 1] = ((o.b_end[i] - 15u) << 1) | 1u;
+    *(uint2*)(ev + pb) = make_uint2((o.b_begin[i] + 15u) << 1, ((o.b_end[i] - 15u) << 1) | 1u);
 }
 
 // Multi-GPU: the four bounds of overlap i as (read, bound) tuples at 4i .. 4i+3; the read

@@ -612,7 +612,50 @@ __global__ __launch_bounds__(64) void pile_runs_kernel(PileArgs A, uint32_t* ove
         uint16_t* u13 = d13 + L::kArr;
         uint16_t* d182 = u13 + L::kArr;
         uint16_t* u182 = d182 + L::kArr;
-        for (uint32_t k = lane; k < R; k += 64) {
+        // Most runs have no neighbour within the window that exceeds even the q = 1.3
+        // threshold.  bm8[b] = max of the 8 runs of block b; a conservative run range of the
+        // window comes from the position index; runs whose bound stays below the threshold
+        // get "nothing flagged" right away, the others are compacted into a list so that the
+        // neighbour scans below run with all lanes busy.
+        uint32_t* bm8 = sm + L::RF;
+        uint16_t* surv = (uint16_t*)(bm8 + (L::kArr / 8 + 8));
+        static_assert(L::SEL - L::RF >= (L::kArr / 8 + 8) + L::kArr / 2 + 2, "scratch for the slope filter");
+        for (uint32_t b = lane; b * 8 < R; b += 64) {
+            uint32_t m = 0;
+#pragma unroll
+            for (uint32_t x = 0; x < 8; ++x) m = umax(m, (b * 8 + x) < R ? rv[b * 8 + x] : 0u);
+            bm8[b] = m;
+        }
+        wave_sync();
+        uint32_t n_surv = 0;
+        for (uint32_t k0 = 0; k0 < R; k0 += 64) {
+            const uint32_t k = k0 + lane;
+            bool need = false;
+            if (k < R) {
+                const uint32_t v = rv[k];
+                const uint32_t sk = rs[k], ek = rs[k + 1];
+                const int32_t t13 = (int32_t)((double)v * 1.3);
+                const uint32_t gl = (sk >= 847u ? sk - 847u : 0u) >> shift;
+                const uint32_t gr = ((ek + 846u) >> shift) + 1u;
+                const uint32_t jl = idx[gl];
+                const uint32_t jr = gr < ng ? idx[gr] : R - 1;
+                int32_t ub = 0;
+                for (uint32_t b = jl >> 3; b <= (jr >> 3); b += 4) {
+                    const uint32_t last = jr >> 3;
+                    const int32_t m0 = (int32_t)bm8[b], m1 = (int32_t)bm8[umin(b + 1, last)],
+                                  m2 = (int32_t)bm8[umin(b + 2, last)], m3 = (int32_t)bm8[umin(b + 3, last)];
+                    ub = max(max(ub, m0), max(m1, max(m2, m3)));
+                }
+                need = ub > t13;
+                if (!need) { d13[k] = kNone16; u13[k] = kNone16; d182[k] = kNone16; u182[k] = kNone16; }
+            }
+            const uint64_t m = __ballot(need);
+            if (need) surv[n_surv + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)k;
+            n_surv += (uint32_t)__popcll(m);
+        }
+        wave_sync();
+        for (uint32_t j = lane; j < n_surv; j += 64) {
+            const uint32_t k = surv[j];
             const uint32_t v = rv[k];
             const uint32_t sk = rs[k], ek = rs[k + 1];
             const int32_t t13 = (int32_t)((double)v * 1.3), t182 = (int32_t)((double)v * 1.82);
