@@ -1,7 +1,7 @@
 // Pile-o-gram construction and annotation in RUN space, one wavefront per read.
 //
 // A pile is a step function: coverage only changes at bound events.  With the
-// E events of a read sorted (bitonic sort in registers, cross-lane shuffles),
+// E events of a read sorted (bitonic sort in registers, DPP / cross-lane shuffles, wave_sort.h),
 // the prefix sum of +-1 gives R <= E + 1 runs (start, value).  Every per-base
 // loop of the reference then becomes a loop over runs:
 //   * Pile::add_layers        sort + wave prefix sum               O(E log^2 E)
@@ -27,6 +27,7 @@
 #include "device_utils.h"
 #include "geom.h"
 #include "kernels.h"
+#include "wave_sort.h"
 
 namespace rala_hip {
 
@@ -206,42 +207,6 @@ __device__ void narrow_serial(RegionList& R, RunCursor& d, double q) {
     }
 }
 
-// ---- bitonic sort of C * 64 keys held as v[t] = key[t * 64 + lane] ---------------
-template <int C>
-__device__ __forceinline__ void wave_sort_regs(uint32_t (&v)[C], uint32_t lane) {
-    constexpr uint32_t P = (uint32_t)C * 64u;
-#pragma unroll
-    for (uint32_t k = 2; k <= P; k <<= 1) {
-#pragma unroll
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            if (j >= 64) {
-                const uint32_t dt = j >> 6;
-#pragma unroll
-                for (uint32_t t = 0; t < (uint32_t)C; ++t) {
-                    if ((t & dt) == 0) {
-                        const uint32_t e = t * 64u;             // bit k lives in t for k >= 128
-                        const bool asc = (e & k) == 0;
-                        const uint32_t a = v[t], b = v[t | dt];
-                        const bool sw = (a > b) == asc;
-                        v[t] = sw ? b : a;
-                        v[t | dt] = sw ? a : b;
-                    }
-                }
-            } else {
-#pragma unroll
-                for (uint32_t t = 0; t < (uint32_t)C; ++t) {
-                    const uint32_t e = t * 64u + lane;
-                    const uint32_t o = (uint32_t)__shfl_xor((int)v[t], (int)j, 64);
-                    const bool asc = (e & k) == 0;
-                    const bool lower = (lane & j) == 0;
-                    const uint32_t mn = v[t] < o ? v[t] : o, mx = v[t] < o ? o : v[t];
-                    v[t] = (lower == asc) ? mn : mx;
-                }
-            }
-        }
-    }
-}
-
 template <int C>
 __device__ __forceinline__ void load_sort_store(const uint32_t* __restrict__ gev, uint32_t n_ev, uint32_t n,
                                                 uint32_t* ev, uint32_t lane) {
@@ -256,7 +221,7 @@ __device__ __forceinline__ void load_sort_store(const uint32_t* __restrict__ gev
         }
         v[t] = b;
     }
-    wave_sort_regs<C>(v, lane);
+    wave_sort_dpp<C>(v, lane);
 #pragma unroll
     for (int t = 0; t < C; ++t) ev[(uint32_t)t * 64u + lane] = v[t];
 }
