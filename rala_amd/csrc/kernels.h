@@ -202,7 +202,8 @@ void launch_tr_fill(const uint32_t* src, uint32_t n_nodes, uint32_t n_edges, uin
                     hipStream_t s);
 // connected components by min-label hooking + pointer jumping (edges = pairs a, b)
 void launch_cc_init(uint32_t* label, uint32_t n, hipStream_t s);
-void launch_cc_hook(const uint32_t* edges, uint32_t n_edges, uint32_t* label, uint32_t* changed, hipStream_t s);
+void launch_cc_hook(const uint32_t* edges, uint32_t n_edges, uint32_t sample, uint32_t* label, uint32_t* changed,
+                    hipStream_t s);
 void launch_cc_compress(uint32_t* label, uint32_t n, hipStream_t s);
 // median of the pile medians per component (median_kernels.hip); keys / sorted: n_alive uint64 each
 size_t component_median_workspace(uint32_t n);

@@ -360,7 +360,11 @@ __global__ __launch_bounds__(kBlock) void death_round_kernel(KillList kl, const 
     const uint32_t n = *kl.count;
     for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < n; k += gridDim.x * kBlock) {
         const uint32_t i = kl.ovl[k];
-        if (death_old[kl.keeper[k]] > i) atomicMin(&death_new[kl.target[k]], i);
+        if (death_old[kl.keeper[k]] > i) {
+            // a contained read has one killer per containing overlap: most minima are already there
+            uint32_t* d = &death_new[kl.target[k]];
+            if (__hip_atomic_load(d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > i) atomicMin(d, i);
+        }
     }
 }
 

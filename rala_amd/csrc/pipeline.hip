@@ -261,7 +261,7 @@ int component_medians(rala_hip_ctx* ctx, std::vector<uint32_t>& members, std::ve
     for (int round = 0;; ++round) {
         HIPCHECK(hipMemsetAsync(ctx->d_small.p + 2, 0, 4, s));
         for (int it = 0; it < 4; ++it) {          // several hook + jump steps per host round trip
-            launch_cc_hook(ctx->d_cc_edges.p, (uint32_t)m, ctx->d_cc_label.p, ctx->d_small.p + 2, s);
+            launch_cc_hook(ctx->d_cc_edges.p, (uint32_t)m, 0, ctx->d_cc_label.p, ctx->d_small.p + 2, s);
             launch_cc_compress(ctx->d_cc_label.p, (uint32_t)na, s);
         }
         uint32_t changed = 0;
@@ -826,12 +826,16 @@ int gpu_tail_run(rala_hip_ctx* ctx) {
         HIPCHECK(hipMemsetAsync(ctx->d_touched.p, 0, n_alive, s));
         launch_cc_edges(L, ctx->d_rank.p, ctx->d_cc_edges.p, ctx->d_touched.p, s);
         launch_cc_init(ctx->d_cc_label.p, n_alive, s);
+        for (int k = 0; k < 2; ++k) {                               // sampled rounds, see cc_hook_kernel
+            launch_cc_hook(ctx->d_cc_edges.p, M, 1, ctx->d_cc_label.p, ctx->d_cc_flags.p + 7, s);
+            launch_cc_compress(ctx->d_cc_label.p, n_alive, s);
+        }
         for (int it = 0;; ++it) {
             // four hook + compress rounds per host check; a round that hooked nothing ends it
             constexpr int kBatch = 4;
             HIPCHECK(hipMemsetAsync(ctx->d_cc_flags.p, 0, kBatch * 4, s));
             for (int k = 0; k < kBatch; ++k) {
-                launch_cc_hook(ctx->d_cc_edges.p, M, ctx->d_cc_label.p, ctx->d_cc_flags.p + k, s);
+                launch_cc_hook(ctx->d_cc_edges.p, M, 0, ctx->d_cc_label.p, ctx->d_cc_flags.p + k, s);
                 launch_cc_compress(ctx->d_cc_label.p, n_alive, s);
             }
             uint32_t changed[kBatch];

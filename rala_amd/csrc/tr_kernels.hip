@@ -94,15 +94,28 @@ __device__ __forceinline__ uint32_t cc_root(const uint32_t* label, uint32_t v) {
 }
 
 // hook the larger root under the smaller one; labels only ever decrease
+// sample != 0: only the first two edges of every run of equal first endpoint take part
+// (the list is grouped by query read).  Two such rounds connect most of a large component
+// at the price of two atomics per node; the full rounds that follow then find almost every
+// edge inside one tree already and skip it, instead of hammering a few roots with a million
+// atomic minima.
 __global__ __launch_bounds__(kBlock) void cc_hook_kernel(const uint32_t* __restrict__ edges, uint32_t n_edges,
-                                                         uint32_t* label, uint32_t* changed) {
+                                                         uint32_t sample, uint32_t* label, uint32_t* changed) {
     const uint32_t e = blockIdx.x * kBlock + threadIdx.x;
-    if (e >= n_edges) return;
-    const uint32_t ra = cc_root(label, edges[2 * e]), rb = cc_root(label, edges[2 * e + 1]);
-    if (ra == rb) return;
-    const uint32_t hi = ra > rb ? ra : rb, lo = ra > rb ? rb : ra;
-    atomicMin(&label[hi], lo);
-    *changed = 1;
+    bool hooked = false;
+    if (e < n_edges) {
+        const uint32_t a = edges[2 * e], b = edges[2 * e + 1];
+        if (a != b && (!sample || e < 2 || edges[2 * (e - 2)] != a)) {
+            const uint32_t ra = cc_root(label, a), rb = cc_root(label, b);
+            if (ra != rb) {
+                const uint32_t hi = ra > rb ? ra : rb, lo = ra > rb ? rb : ra;
+                // labels only fall: skip the atomic when an earlier hook already went lower
+                if (__hip_atomic_load(&label[hi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > lo) atomicMin(&label[hi], lo);
+                hooked = true;
+            }
+        }
+    }
+    if (__ballot(hooked) != 0 && (threadIdx.x & 63) == 0) *changed = 1;
 }
 
 __global__ __launch_bounds__(kBlock) void cc_compress_kernel(uint32_t* label, uint32_t n) {
@@ -132,10 +145,11 @@ void launch_tr_fill(const uint32_t* src, uint32_t n_nodes, uint32_t n_edges, uin
 void launch_cc_init(uint32_t* label, uint32_t n, hipStream_t s) {
     if (n) hipLaunchKernelGGL(cc_init_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, label, n);
 }
-void launch_cc_hook(const uint32_t* edges, uint32_t n_edges, uint32_t* label, uint32_t* changed, hipStream_t s) {
+void launch_cc_hook(const uint32_t* edges, uint32_t n_edges, uint32_t sample, uint32_t* label, uint32_t* changed,
+                    hipStream_t s) {
     if (n_edges) {
         hipLaunchKernelGGL(cc_hook_kernel, dim3((n_edges + kBlock - 1) / kBlock), dim3(kBlock), 0, s, edges, n_edges,
-                           label, changed);
+                           sample, label, changed);
     }
 }
 void launch_cc_compress(uint32_t* label, uint32_t n, hipStream_t s) {
