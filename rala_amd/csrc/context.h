@@ -119,7 +119,7 @@ struct rala_hip_ctx {
     bool piles_resident = false;
 
     // bound CSR
-    rala_hip::DevBuf<uint32_t> d_ev_off, d_cursor, d_ev;
+    rala_hip::DevBuf<uint32_t> d_ev_off, d_cursor, d_ev, d_slot_rank[2];
     rala_hip::DevBuf<unsigned char> d_scan_ws;
 
     // per-read annotation

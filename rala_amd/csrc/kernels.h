@@ -118,8 +118,12 @@ enum : uint8_t {
 
 // suspect: n_reads bytes of scratch (queries whose runs are not strictly ordered by target)
 void launch_dedupe(const OvlSoA& o, uint32_t n_reads, uint8_t* suspect, uint8_t* valid, hipStream_t s);
-void launch_count_bounds(const OvlSoA& o, uint32_t n_reads, uint32_t* counts, hipStream_t s);
-void launch_scatter_bounds(const OvlSoA& o, uint32_t n_reads, uint32_t* cursor, uint32_t* ev, hipStream_t s);
+// counts -> (exclusive scan) -> ev_off; rank_a / rank_b: n_overlaps each, slot of the overlap's
+// bounds inside the bucket of read a / read b
+void launch_count_bounds(const OvlSoA& o, uint32_t n_reads, uint32_t* counts, uint32_t* rank_a, uint32_t* rank_b,
+                         hipStream_t s);
+void launch_scatter_bounds(const OvlSoA& o, uint32_t n_reads, const uint32_t* ev_off, const uint32_t* rank_a,
+                           const uint32_t* rank_b, uint32_t* ev, hipStream_t s);
 // bound tuples (read, bound) instead of overlaps: multi-GPU owners receive them by all-to-all
 void launch_emit_tuples(const OvlSoA& o, uint32_t n_reads, uint32_t* reads, uint32_t* bounds, hipStream_t s);
 void launch_bucket_tuples(const OvlSoA& o, uint32_t n_reads, uint32_t world, uint32_t pass, uint32_t* counters,

@@ -126,20 +126,12 @@ __device__ __forceinline__ uint32_t segment_of(uint32_t key, bool active, uint32
     return head ? len : 0u;
 }
 
-__global__ __launch_bounds__(kBlock) void count_bounds_kernel(OvlSoA o, uint32_t n_reads, uint32_t* counts) {
-    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-    const uint32_t lane = threadIdx.x & 63;
-    uint32_t a = kInf, b = kInf;
-    if (i < o.n) { a = o.a_id[i]; b = o.b_id[i]; }
-    const bool ok = a < n_reads && b < n_reads;
-    uint32_t leader;
-    const uint32_t seg = segment_of(a, ok, lane, leader);
-    if (seg) atomicAdd(&counts[a], 2u * seg);
-    if (ok) atomicAdd(&counts[b], 2u);
-}
-
-__global__ __launch_bounds__(kBlock) void scatter_bounds_kernel(OvlSoA o, uint32_t n_reads, uint32_t* cursor,
-                                                                uint32_t* __restrict__ ev) {
+// Counting pass.  The value an atomic add returns is a unique slot inside the read's bucket,
+// so it is kept (rank_a / rank_b, 4 B per overlap and side) and the scatter pass needs no
+// atomics at all.
+__global__ __launch_bounds__(kBlock) void count_bounds_kernel(OvlSoA o, uint32_t n_reads, uint32_t* counts,
+                                                             uint32_t* __restrict__ rank_a,
+                                                             uint32_t* __restrict__ rank_b) {
     const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63;
     uint32_t a = kInf, b = kInf;
@@ -148,13 +140,26 @@ __global__ __launch_bounds__(kBlock) void scatter_bounds_kernel(OvlSoA o, uint32
     uint32_t leader;
     const uint32_t seg = segment_of(a, ok, lane, leader);
     uint32_t base = 0;
-    if (seg) base = atomicAdd(&cursor[a], 2u * seg);
+    if (seg) base = atomicAdd(&counts[a], 2u * seg);
     base = (uint32_t)__shfl((int)base, (int)leader, 64);
     if (!ok) return;
-    // every cursor starts even (counts are even) and moves in steps of two: 8-byte stores
-    const uint32_t pa = base + 2u * (lane - leader);
+    rank_a[i] = base + 2u * (lane - leader);
+    rank_b[i] = atomicAdd(&counts[b], 2u);
+}
+
+__global__ __launch_bounds__(kBlock) void scatter_bounds_kernel(OvlSoA o, uint32_t n_reads,
+                                                                const uint32_t* __restrict__ ev_off,
+                                                                const uint32_t* __restrict__ rank_a,
+                                                                const uint32_t* __restrict__ rank_b,
+                                                                uint32_t* __restrict__ ev) {
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= o.n) return;
+    const uint32_t a = o.a_id[i], b = o.b_id[i];
+    if (a >= n_reads || b >= n_reads) return;
+    // bucket offsets and ranks are even: 8-byte stores
+    const uint32_t pa = ev_off[a] + rank_a[i];
     *(uint2*)(ev + pa) = make_uint2((o.a_begin[i] + 15u) << 1, ((o.a_end[i] - 15u) << 1) | 1u);
-    const uint32_t pb = atomicAdd(&cursor[b], 2u);
+    const uint32_t pb = ev_off[b] + rank_b[i];
     *(uint2*)(ev + pb) = make_uint2((o.b_begin[i] + 15u) << 1, ((o.b_end[i] - 15u) << 1) | 1u);
 }
 
@@ -457,11 +462,15 @@ void launch_dedupe(const OvlSoA& o, uint32_t n_reads, uint8_t* suspect, uint8_t*
     hipLaunchKernelGGL(dedupe_mark_kernel, grid_for(o.n), dim3(kBlock), 0, s, o, n_reads, suspect);
     hipLaunchKernelGGL(dedupe_kernel, grid_for(o.n), dim3(kBlock), 0, s, o, n_reads, (const uint8_t*)suspect, valid);
 }
-void launch_count_bounds(const OvlSoA& o, uint32_t n_reads, uint32_t* counts, hipStream_t s) {
-    if (o.n) hipLaunchKernelGGL(count_bounds_kernel, grid_for(o.n), dim3(kBlock), 0, s, o, n_reads, counts);
+void launch_count_bounds(const OvlSoA& o, uint32_t n_reads, uint32_t* counts, uint32_t* rank_a, uint32_t* rank_b,
+                         hipStream_t s) {
+    if (o.n) hipLaunchKernelGGL(count_bounds_kernel, grid_for(o.n), dim3(kBlock), 0, s, o, n_reads, counts, rank_a, rank_b);
 }
-void launch_scatter_bounds(const OvlSoA& o, uint32_t n_reads, uint32_t* cursor, uint32_t* ev, hipStream_t s) {
-    if (o.n) hipLaunchKernelGGL(scatter_bounds_kernel, grid_for(o.n), dim3(kBlock), 0, s, o, n_reads, cursor, ev);
+void launch_scatter_bounds(const OvlSoA& o, uint32_t n_reads, const uint32_t* ev_off, const uint32_t* rank_a,
+                           const uint32_t* rank_b, uint32_t* ev, hipStream_t s) {
+    if (o.n) {
+        hipLaunchKernelGGL(scatter_bounds_kernel, grid_for(o.n), dim3(kBlock), 0, s, o, n_reads, ev_off, rank_a, rank_b, ev);
+    }
 }
 void launch_emit_tuples(const OvlSoA& o, uint32_t n_reads, uint32_t* reads, uint32_t* bounds, hipStream_t s) {
     if (o.n) hipLaunchKernelGGL(emit_tuples_kernel, grid_for(o.n), dim3(kBlock), 0, s, o, n_reads, reads, bounds);

@@ -1122,15 +1122,16 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
     if (ctx->tuple_mode) {
         launch_count_tuples(ctx->tuple_reads, ctx->n_tuples, n_reads, ctx->d_cursor.p, s);
     } else {
-        launch_count_bounds(ctx->ovl, n_reads, ctx->d_cursor.p, s);
+        HIPCHECK(ctx->d_slot_rank[0].ensure(ctx->n_ovl + 1)); HIPCHECK(ctx->d_slot_rank[1].ensure(ctx->n_ovl + 1));
+        launch_count_bounds(ctx->ovl, n_reads, ctx->d_cursor.p, ctx->d_slot_rank[0].p, ctx->d_slot_rank[1].p, s);
     }
     launch_exclusive_scan(ctx->d_cursor.p, ctx->d_ev_off.p, n_reads, ctx->d_scan_ws.p, s);
-    HIPCHECK(hipMemcpyAsync(ctx->d_cursor.p, ctx->d_ev_off.p, (size_t)n_reads * 4, hipMemcpyDeviceToDevice, s));
     if (ctx->tuple_mode) {
+        HIPCHECK(hipMemcpyAsync(ctx->d_cursor.p, ctx->d_ev_off.p, (size_t)n_reads * 4, hipMemcpyDeviceToDevice, s));
         launch_scatter_tuples(ctx->tuple_reads, ctx->tuple_bounds, ctx->n_tuples, n_reads, ctx->d_cursor.p,
                               ctx->d_ev.p, s);
     } else {
-        launch_scatter_bounds(ctx->ovl, n_reads, ctx->d_cursor.p, ctx->d_ev.p, s);
+        launch_scatter_bounds(ctx->ovl, n_reads, ctx->d_ev_off.p, ctx->d_slot_rank[0].p, ctx->d_slot_rank[1].p, ctx->d_ev.p, s);
     }
     HIPCHECK(hipEventRecord(ctx->ev[2], s));
 
