@@ -133,7 +133,8 @@ struct rala_hip_ctx {
     // pass 2
     rala_hip::DevBuf<uint8_t> d_cls;
     rala_hip::DevBuf<uint32_t> d_death[2];
-    rala_hip::DevBuf<uint32_t> d_flag[2], d_pos[2];
+    rala_hip::DevBuf<uint32_t> d_chunk[4];      // survivors per chunk (overlaps, internals) and their scans
+    rala_hip::DevBuf<uint4> d_rec;              // packed per-read records of the second pass
     rala_hip::DevBuf<uint32_t> d_surv_u32[8];
     rala_hip::DevBuf<uint8_t> d_surv_u8[2];
     rala_hip::PinnedBuf<uint32_t> p_surv_u32[8];

@@ -114,6 +114,7 @@ enum : uint8_t {
     kClsKillsA = 0x10,     // live overlap deletes read a (a contained, container not chimeric)
     kClsKillsB = 0x20,
     kClsLive = 0x40,       // survived the in-order death scan
+    kClsSurvivor = 0x80,   // live, both reads survive, deletes nobody: goes on to preprocess
 };
 
 // suspect: n_reads bytes of scratch (queries whose runs are not strictly ordered by target)
@@ -136,12 +137,15 @@ struct KillList {
     uint32_t* count;            // device counter, zeroed before classify
     uint32_t *ovl, *target, *keeper;
 };
-void launch_classify(const OvlSoA& o, uint32_t n_reads, const uint8_t* valid, const ReadState& rs, uint8_t* cls,
+// per-read record of the second pass: {begin, end, n_pits | n_hills << 8 | alive << 16, pool slot}
+void launch_pack_reads(const ReadState& rs, uint32_t n_reads, uint4* rec, hipStream_t s);
+uint32_t pass2_chunks(uint64_t n_overlaps);     // workgroups (= chunk counters) of finish / gather
+void launch_classify(const OvlSoA& o, uint32_t n_reads, const uint8_t* valid, const uint4* rec, uint8_t* cls,
                      const KillList& kl, hipStream_t s);
 void launch_death_round(const KillList& kl, const uint32_t* death_old, uint32_t* death_new, hipStream_t s);
 void launch_death_diff(const uint32_t* a, const uint32_t* b, uint32_t n, uint32_t* changed, hipStream_t s);
-void launch_finish_pass2(const OvlSoA& o, uint8_t* cls, const uint32_t* death, const ReadState& rs,
-                         uint32_t* flag_overlap, uint32_t* flag_internal, hipStream_t s);
+void launch_finish_pass2(const OvlSoA& o, uint8_t* cls, const uint32_t* death, const uint4* rec, Interval* pool,
+                         uint32_t* chunk_ov, uint32_t* chunk_in, hipStream_t s);
 void launch_apply_death(const uint32_t* death, uint8_t* alive, uint32_t n_reads, hipStream_t s);
 
 // survivors gathered into dense arrays (trim re-applied against the pass-1 piles)
@@ -149,8 +153,8 @@ struct Survivors {
     uint32_t *src, *a_id, *b_id, *a_begin, *a_end, *b_begin, *b_end, *length;
     uint8_t *strand, *type;
 };
-void launch_gather_survivors(const OvlSoA& o, const uint8_t* cls, const ReadState& rs, const uint32_t* flag,
-                             const uint32_t* pos, const Survivors& out, hipStream_t s);
+void launch_gather_survivors(const OvlSoA& o, const uint8_t* cls, const uint4* rec, const uint32_t* chunk_ov_off,
+                             const uint32_t* chunk_in_off, uint32_t n_ov_total, const Survivors& out, hipStream_t s);
 
 // ---- preprocess tail on device-resident lists (tail_kernels.hip) -------------------
 struct TailList {               // survivors of the second pass: overlaps first, then internals

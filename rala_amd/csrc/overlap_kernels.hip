@@ -297,6 +297,18 @@ __device__ __forceinline__ Coords load_coords(const OvlSoA& o, uint64_t i) {
 
 // Static part of construct's second pass: everything about overlap i that does
 // not depend on which piles earlier overlaps deleted.
+// Per-read state of the second pass in one 16-byte record (one random access per read
+// instead of five): begin, end, n_pits | n_hills << 8 | alive << 16, first pool slot.
+__global__ __launch_bounds__(kBlock) void pack_reads_kernel(ReadState rs, uint32_t n, uint4* __restrict__ rec) {
+    const uint32_t r = blockIdx.x * kBlock + threadIdx.x;
+    if (r >= n) return;
+    rec[r] = make_uint4(rs.begin[r], rs.end[r], (uint32_t)rs.n_pits[r] | ((uint32_t)rs.n_hills[r] << 8) |
+                        ((uint32_t)(rs.alive[r] != 0) << 16), rs.iv_slot[r]);
+}
+__device__ __forceinline__ bool rec_alive(const uint4& r) { return (r.z >> 16) & 1u; }
+__device__ __forceinline__ uint32_t rec_pits(const uint4& r) { return r.z & 0xFFu; }
+__device__ __forceinline__ uint32_t rec_hills(const uint4& r) { return (r.z >> 8) & 0xFFu; }
+
 // A workgroup classifies a chunk of kClassifyChunk consecutive overlaps (8 per thread) and
 // appends those that would delete a read to the killer list {overlap, target, keeper}: slots
 // inside the chunk through an LDS counter (one add per wavefront and iteration), one global
@@ -304,7 +316,8 @@ __device__ __forceinline__ Coords load_coords(const OvlSoA& o, uint64_t i) {
 constexpr uint32_t kClassifyChunk = 2048;
 
 __global__ __launch_bounds__(kBlock) void classify_kernel(OvlSoA o, uint32_t n_reads,
-                                                          const uint8_t* __restrict__ valid, ReadState rs,
+                                                          const uint8_t* __restrict__ valid,
+                                                          const uint4* __restrict__ rec,
                                                           uint8_t* __restrict__ cls, KillList kl) {
     __shared__ uint32_t s_cnt, s_base;
     constexpr uint32_t kPer = kClassifyChunk / kBlock;
@@ -319,15 +332,15 @@ __global__ __launch_bounds__(kBlock) void classify_kernel(OvlSoA o, uint32_t n_r
         uint8_t out = 0;
         if (i < o.n && valid[i]) {
             const uint32_t a = o.a_id[i], b = o.b_id[i];
-            if (rs.alive[a] && rs.alive[b]) {
+            const uint4 ra = rec[a], rb = rec[b];
+            if (rec_alive(ra) && rec_alive(rb)) {
                 Coords c = load_coords(o, i);
                 const uint32_t st = o.strand[i];
-                const uint32_t Ba = rs.begin[a], Ea = rs.end[a], Bb = rs.begin[b], Eb = rs.end[b];
-                if (ovl_trim(c, st, Ba, Ea, Bb, Eb)) {
-                    const uint32_t t = ovl_type(c, st, Ba, Ea, Bb, Eb);
+                if (ovl_trim(c, st, ra.x, ra.y, rb.x, rb.y)) {
+                    const uint32_t t = ovl_type(c, st, ra.x, ra.y, rb.x, rb.y);
                     out = (uint8_t)(kClsOk | t);
-                    if (t == kTypeB && (rs.n_pits[b] | rs.n_hills[b]) == 0) out |= kClsKillsA;
-                    if (t == kTypeA && (rs.n_pits[a] | rs.n_hills[a]) == 0) out |= kClsKillsB;
+                    if (t == kTypeB && (rb.z & 0xFFFFu) == 0) out |= kClsKillsA;
+                    if (t == kTypeA && (ra.z & 0xFFFFu) == 0) out |= kClsKillsB;
                 }
             }
         }
@@ -382,49 +395,67 @@ __global__ __launch_bounds__(kBlock) void death_diff_kernel(const uint32_t* __re
 }
 
 // Liveness, hill span counters (Pile::check_chimeric_hills, pile.cpp:457-469,
-// including the begin_ double count) and the two survivor flags.
+// including the begin_ double count) and the survivor bit.  A workgroup owns a chunk of
+// kClassifyChunk consecutive overlaps and reports how many of them survive as overlaps and
+// as internals; the gather kernel below re-derives every survivor's position from the scanned
+// chunk counts and wave ballots, so no per-overlap flag / position arrays exist.
 __global__ __launch_bounds__(kBlock) void finish_pass2_kernel(OvlSoA o, uint8_t* __restrict__ cls,
-                                                              const uint32_t* __restrict__ death, ReadState rs,
-                                                              uint32_t* __restrict__ flag_overlap,
-                                                              uint32_t* __restrict__ flag_internal) {
-    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= o.n) return;
-    uint8_t c = cls[i];
-    uint32_t f_ov = 0, f_in = 0;
-    if (c & kClsOk) {
-        const uint32_t a = o.a_id[i], b = o.b_id[i];
-        const uint32_t da = death[a], db = death[b];
-        if (da >= (uint32_t)i && db >= (uint32_t)i) {
-            c |= kClsLive;
-            const uint32_t nha = rs.n_hills[a], nhb = rs.n_hills[b];
-            if (nha | nhb) {
-                Coords k = load_coords(o, i);
-                const uint32_t Ba = rs.begin[a], Bb = rs.begin[b];
-                ovl_trim(k, o.strand[i], Ba, rs.end[a], Bb, rs.end[b]);
-                if (nha) {
-                    Interval* h = rs.pool + rs.iv_slot[a] + rs.n_pits[a];
-                    const uint32_t x = Ba + k.a_begin, y = Ba + k.a_end;
-                    for (uint32_t q = 0; q < nha; ++q) {
-                        if (x < h[q].first && y > h[q].second) atomicAdd(&h[q].aux, 1u);
+                                                              const uint32_t* __restrict__ death,
+                                                              const uint4* __restrict__ rec, Interval* pool,
+                                                              uint32_t* __restrict__ chunk_ov,
+                                                              uint32_t* __restrict__ chunk_in) {
+    __shared__ uint32_t s_ov, s_in;
+    constexpr uint32_t kPer = kClassifyChunk / kBlock;
+    const uint32_t lane = threadIdx.x & 63;
+    if (threadIdx.x == 0) { s_ov = 0; s_in = 0; }
+    __syncthreads();
+    uint32_t n_ov = 0, n_in = 0;
+#pragma unroll 2
+    for (uint32_t u = 0; u < kPer; ++u) {
+        const uint64_t i = (uint64_t)blockIdx.x * kClassifyChunk + u * kBlock + threadIdx.x;
+        bool f_ov = false, f_in = false;
+        if (i < o.n) {
+            uint8_t c = cls[i];
+            if (c & kClsOk) {
+                const uint32_t a = o.a_id[i], b = o.b_id[i];
+                const uint32_t da = death[a], db = death[b];
+                if (da >= (uint32_t)i && db >= (uint32_t)i) {
+                    c |= kClsLive;
+                    const uint4 ra = rec[a], rb = rec[b];
+                    const uint32_t nha = rec_hills(ra), nhb = rec_hills(rb);
+                    if (nha | nhb) {
+                        Coords k = load_coords(o, i);
+                        ovl_trim(k, o.strand[i], ra.x, ra.y, rb.x, rb.y);
+                        if (nha) {
+                            Interval* h = pool + ra.w + rec_pits(ra);
+                            const uint32_t x = ra.x + k.a_begin, y = ra.x + k.a_end;
+                            for (uint32_t q = 0; q < nha; ++q) {
+                                if (x < h[q].first && y > h[q].second) atomicAdd(&h[q].aux, 1u);
+                            }
+                        }
+                        if (nhb) {
+                            Interval* h = pool + rb.w + rec_pits(rb);
+                            const uint32_t x = rb.x + k.b_begin, y = rb.x + k.b_end;
+                            for (uint32_t q = 0; q < nhb; ++q) {
+                                if (x < h[q].first && y > h[q].second) atomicAdd(&h[q].aux, 1u);
+                            }
+                        }
+                    }
+                    const bool both_survive = da == kInf && db == kInf;
+                    if (both_survive && !(c & (kClsKillsA | kClsKillsB))) {
+                        c |= kClsSurvivor;
+                        if ((c & kClsTypeMask) == kTypeX) f_in = true; else f_ov = true;
                     }
                 }
-                if (nhb) {
-                    Interval* h = rs.pool + rs.iv_slot[b] + rs.n_pits[b];
-                    const uint32_t x = Bb + k.b_begin, y = Bb + k.b_end;
-                    for (uint32_t q = 0; q < nhb; ++q) {
-                        if (x < h[q].first && y > h[q].second) atomicAdd(&h[q].aux, 1u);
-                    }
-                }
-            }
-            const bool both_survive = da == kInf && db == kInf;
-            if (both_survive && !(c & (kClsKillsA | kClsKillsB))) {
-                if ((c & kClsTypeMask) == kTypeX) f_in = 1; else f_ov = 1;
+                cls[i] = c;
             }
         }
-        cls[i] = c;
+        n_ov += (uint32_t)__popcll(__ballot(f_ov));
+        n_in += (uint32_t)__popcll(__ballot(f_in));
     }
-    flag_overlap[i] = f_ov;
-    flag_internal[i] = f_in;
+    if (lane == 0) { atomicAdd(&s_ov, n_ov); atomicAdd(&s_in, n_in); }
+    __syncthreads();
+    if (threadIdx.x == 0) { chunk_ov[blockIdx.x] = s_ov; chunk_in[blockIdx.x] = s_in; }
 }
 
 __global__ __launch_bounds__(kBlock) void apply_death_kernel(const uint32_t* __restrict__ death, uint8_t* alive,
@@ -433,23 +464,58 @@ __global__ __launch_bounds__(kBlock) void apply_death_kernel(const uint32_t* __r
     if (r < n && death[r] != kInf) alive[r] = 0;
 }
 
-__global__ __launch_bounds__(kBlock) void gather_kernel(OvlSoA o, const uint8_t* __restrict__ cls, ReadState rs,
-                                                        const uint32_t* __restrict__ flag,
-                                                        const uint32_t* __restrict__ pos, Survivors out) {
-    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= o.n || !flag[i]) return;
-    const uint32_t p = pos[i];
-    const uint32_t a = o.a_id[i], b = o.b_id[i];
-    Coords k = load_coords(o, i);
-    const uint32_t st = o.strand[i];
-    ovl_trim(k, st, rs.begin[a], rs.end[a], rs.begin[b], rs.end[b]);
-    out.src[p] = (uint32_t)i;
-    out.a_id[p] = a; out.b_id[p] = b;
-    out.a_begin[p] = k.a_begin; out.a_end[p] = k.a_end;
-    out.b_begin[p] = k.b_begin; out.b_end[p] = k.b_end;
-    out.length[p] = k.length;
-    out.strand[p] = (uint8_t)st;
-    out.type[p] = cls[i] & kClsTypeMask;
+// Survivors into dense arrays in file order: overlaps from slot 0, internals from slot
+// n_ov_total (trim re-applied against the pass-1 piles).
+__global__ __launch_bounds__(kBlock) void gather_kernel(OvlSoA o, const uint8_t* __restrict__ cls,
+                                                        const uint4* __restrict__ rec,
+                                                        const uint32_t* __restrict__ chunk_ov_off,
+                                                        const uint32_t* __restrict__ chunk_in_off,
+                                                        uint32_t n_ov_total, Survivors out) {
+    constexpr uint32_t kPer = kClassifyChunk / kBlock;
+    __shared__ uint32_t t_ov[kPer * 4 + 1], t_in[kPer * 4 + 1];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint8_t c[kPer];
+    uint64_t m_ov[kPer], m_in[kPer];
+#pragma unroll
+    for (uint32_t u = 0; u < kPer; ++u) {
+        const uint64_t i = (uint64_t)blockIdx.x * kClassifyChunk + u * kBlock + threadIdx.x;
+        c[u] = i < o.n ? cls[i] : 0;
+        const bool sv = (c[u] & kClsSurvivor) != 0, x = (c[u] & kClsTypeMask) == kTypeX;
+        m_ov[u] = __ballot(sv && !x);
+        m_in[u] = __ballot(sv && x);
+        if (lane == 0) {
+            t_ov[u * 4 + wave] = (uint32_t)__popcll(m_ov[u]);
+            t_in[u * 4 + wave] = (uint32_t)__popcll(m_in[u]);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        uint32_t* t = threadIdx.x ? t_in : t_ov;
+        uint32_t run = threadIdx.x ? n_ov_total + chunk_in_off[blockIdx.x] : chunk_ov_off[blockIdx.x];
+        for (uint32_t q = 0; q < kPer * 4; ++q) { const uint32_t v = t[q]; t[q] = run; run += v; }
+    }
+    __syncthreads();
+    const uint64_t below = (1ull << lane) - 1ull;
+#pragma unroll
+    for (uint32_t u = 0; u < kPer; ++u) {
+        if (!(c[u] & kClsSurvivor)) continue;
+        const uint64_t i = (uint64_t)blockIdx.x * kClassifyChunk + u * kBlock + threadIdx.x;
+        const bool x = (c[u] & kClsTypeMask) == kTypeX;
+        const uint32_t p = x ? t_in[u * 4 + wave] + (uint32_t)__popcll(m_in[u] & below)
+                             : t_ov[u * 4 + wave] + (uint32_t)__popcll(m_ov[u] & below);
+        const uint32_t a = o.a_id[i], b = o.b_id[i];
+        const uint4 ra = rec[a], rb = rec[b];
+        Coords k = load_coords(o, i);
+        const uint32_t st = o.strand[i];
+        ovl_trim(k, st, ra.x, ra.y, rb.x, rb.y);
+        out.src[p] = (uint32_t)i;
+        out.a_id[p] = a; out.b_id[p] = b;
+        out.a_begin[p] = k.a_begin; out.a_end[p] = k.a_end;
+        out.b_begin[p] = k.b_begin; out.b_end[p] = k.b_end;
+        out.length[p] = k.length;
+        out.strand[p] = (uint8_t)st;
+        out.type[p] = c[u] & kClsTypeMask;
+    }
 }
 
 inline dim3 grid_for(uint64_t n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); }
@@ -492,11 +558,15 @@ void launch_scatter_tuples(const uint32_t* reads, const uint32_t* bounds, uint64
                            ev);
     }
 }
-void launch_classify(const OvlSoA& o, uint32_t n_reads, const uint8_t* valid, const ReadState& rs, uint8_t* cls,
+void launch_pack_reads(const ReadState& rs, uint32_t n_reads, uint4* rec, hipStream_t s) {
+    if (n_reads) hipLaunchKernelGGL(pack_reads_kernel, grid_for(n_reads), dim3(kBlock), 0, s, rs, n_reads, rec);
+}
+uint32_t pass2_chunks(uint64_t n_overlaps) { return (uint32_t)((n_overlaps + kClassifyChunk - 1) / kClassifyChunk); }
+void launch_classify(const OvlSoA& o, uint32_t n_reads, const uint8_t* valid, const uint4* rec, uint8_t* cls,
                      const KillList& kl, hipStream_t s) {
     if (o.n) {
         hipLaunchKernelGGL(classify_kernel, dim3((uint32_t)((o.n + kClassifyChunk - 1) / kClassifyChunk)), dim3(kBlock), 0, s,
-                           o, n_reads, valid, rs, cls, kl);
+                           o, n_reads, valid, rec, cls, kl);
     }
 }
 void launch_death_round(const KillList& kl, const uint32_t* death_old, uint32_t* death_new, hipStream_t s) {
@@ -506,19 +576,22 @@ void launch_death_round(const KillList& kl, const uint32_t* death_old, uint32_t*
 void launch_death_diff(const uint32_t* a, const uint32_t* b, uint32_t n, uint32_t* changed, hipStream_t s) {
     if (n) hipLaunchKernelGGL(death_diff_kernel, grid_for(n), dim3(kBlock), 0, s, a, b, n, changed);
 }
-void launch_finish_pass2(const OvlSoA& o, uint8_t* cls, const uint32_t* death, const ReadState& rs,
-                         uint32_t* flag_overlap, uint32_t* flag_internal, hipStream_t s) {
+void launch_finish_pass2(const OvlSoA& o, uint8_t* cls, const uint32_t* death, const uint4* rec, Interval* pool,
+                         uint32_t* chunk_ov, uint32_t* chunk_in, hipStream_t s) {
     if (o.n) {
-        hipLaunchKernelGGL(finish_pass2_kernel, grid_for(o.n), dim3(kBlock), 0, s, o, cls, death, rs, flag_overlap,
-                           flag_internal);
+        hipLaunchKernelGGL(finish_pass2_kernel, dim3(pass2_chunks(o.n)), dim3(kBlock), 0, s, o, cls, death, rec, pool,
+                           chunk_ov, chunk_in);
     }
 }
 void launch_apply_death(const uint32_t* death, uint8_t* alive, uint32_t n_reads, hipStream_t s) {
     if (n_reads) hipLaunchKernelGGL(apply_death_kernel, grid_for(n_reads), dim3(kBlock), 0, s, death, alive, n_reads);
 }
-void launch_gather_survivors(const OvlSoA& o, const uint8_t* cls, const ReadState& rs, const uint32_t* flag,
-                             const uint32_t* pos, const Survivors& out, hipStream_t s) {
-    if (o.n) hipLaunchKernelGGL(gather_kernel, grid_for(o.n), dim3(kBlock), 0, s, o, cls, rs, flag, pos, out);
+void launch_gather_survivors(const OvlSoA& o, const uint8_t* cls, const uint4* rec, const uint32_t* chunk_ov_off,
+                             const uint32_t* chunk_in_off, uint32_t n_ov_total, const Survivors& out, hipStream_t s) {
+    if (o.n) {
+        hipLaunchKernelGGL(gather_kernel, dim3(pass2_chunks(o.n)), dim3(kBlock), 0, s, o, cls, rec, chunk_ov_off,
+                           chunk_in_off, n_ov_total, out);
+    }
 }
 
 }  // namespace rala_hip

@@ -1095,7 +1095,7 @@ int rala_hip_set_overlaps(rala_hip_ctx* ctx, const rala_hip_overlaps* o, uint64_
     HIPCHECK(ctx->d_valid.ensure(n));
     HIPCHECK(ctx->d_ev.ensure(4 * n + 8));
     HIPCHECK(ctx->d_cls.ensure(n));
-    for (int k = 0; k < 2; ++k) { HIPCHECK(ctx->d_flag[k].ensure(n + 1)); HIPCHECK(ctx->d_pos[k].ensure(n + 2)); }
+    for (int k = 0; k < 4; ++k) HIPCHECK(ctx->d_chunk[k].ensure(pass2_chunks(n) + 2));
     HIPCHECK(ctx->d_scan_ws.ensure(scan_workspace_bytes(std::max<uint64_t>(n, ctx->n_reads) + 2)));
     ctx->initialized = ctx->constructed = false;
     return RALA_HIP_OK;
@@ -1446,7 +1446,9 @@ int rala_hip_construct(rala_hip_ctx* ctx, const rala_hip_overlaps* sens, uint64_
     kl.count = ctx->d_kill_count.p; kl.ovl = ctx->d_kill[0].p; kl.target = ctx->d_kill[1].p; kl.keeper = ctx->d_kill[2].p;
     HIPCHECK(hipEventRecord(ctx->ev[4], s));
     HIPCHECK(hipMemsetAsync(kl.count, 0, 4, s));
-    launch_classify(ctx->ovl, n_reads, ctx->d_valid.p, rs, ctx->d_cls.p, kl, s);
+    HIPCHECK(ctx->d_rec.ensure(n_reads));
+    launch_pack_reads(rs, n_reads, ctx->d_rec.p, s);
+    launch_classify(ctx->ovl, n_reads, ctx->d_valid.p, ctx->d_rec.p, ctx->d_cls.p, kl, s);
     HIPCHECK(hipEventRecord(ctx->ev[5], s));
     // ---- in-order containment removal as a fixed point ----
     int cur = 0;
@@ -1472,12 +1474,14 @@ int rala_hip_construct(rala_hip_ctx* ctx, const rala_hip_overlaps* sens, uint64_
     }
     HIPCHECK(hipEventRecord(ctx->ev[6], s));
     // ---- liveness, hill counters, survivors ----
-    launch_finish_pass2(ctx->ovl, ctx->d_cls.p, ctx->d_death[cur].p, rs, ctx->d_flag[0].p, ctx->d_flag[1].p, s);
+    const uint32_t n_chunks = pass2_chunks(N);
+    launch_finish_pass2(ctx->ovl, ctx->d_cls.p, ctx->d_death[cur].p, ctx->d_rec.p, ctx->d_pool.p, ctx->d_chunk[0].p,
+                        ctx->d_chunk[1].p, s);
     launch_apply_death(ctx->d_death[cur].p, ctx->d_alive.p, n_reads, s);
     uint32_t n_surv[2] = {0, 0};
     for (int k = 0; k < 2; ++k) {
-        launch_exclusive_scan(ctx->d_flag[k].p, ctx->d_pos[k].p, N, ctx->d_scan_ws.p, s);
-        HIPCHECK(hipMemcpyAsync(&n_surv[k], ctx->d_pos[k].p + N, 4, hipMemcpyDeviceToHost, s));
+        launch_exclusive_scan(ctx->d_chunk[k].p, ctx->d_chunk[2 + k].p, n_chunks, ctx->d_scan_ws.p, s);
+        HIPCHECK(hipMemcpyAsync(&n_surv[k], ctx->d_chunk[2 + k].p + n_chunks, 4, hipMemcpyDeviceToHost, s));
     }
     HIPCHECK(hipStreamSynchronize(s));
     // both survivor lists side by side in one device list: overlaps, then internals
@@ -1485,17 +1489,15 @@ int rala_hip_construct(rala_hip_ctx* ctx, const rala_hip_overlaps* sens, uint64_
     ctx->t_n0 = n_surv[0]; ctx->t_n1 = n_surv[1];
     for (int f = 0; f < 8; ++f) HIPCHECK(ctx->d_surv_u32[f].ensure(M));
     for (int f = 0; f < 2; ++f) HIPCHECK(ctx->d_surv_u8[f].ensure(M));
-    for (int k = 0; k < 2; ++k) {
-        if (n_surv[k] == 0) continue;
-        const uint32_t off = k == 0 ? 0 : n_surv[0];
+    if (M) {
         Survivors sv;
-        sv.src = ctx->d_surv_u32[0].p + off; sv.a_id = ctx->d_surv_u32[1].p + off; sv.b_id = ctx->d_surv_u32[2].p + off;
-        sv.a_begin = ctx->d_surv_u32[3].p + off; sv.a_end = ctx->d_surv_u32[4].p + off;
-        sv.b_begin = ctx->d_surv_u32[5].p + off; sv.b_end = ctx->d_surv_u32[6].p + off;
-        sv.length = ctx->d_surv_u32[7].p + off;
-        sv.strand = ctx->d_surv_u8[0].p + off; sv.type = ctx->d_surv_u8[1].p + off;
+        sv.src = ctx->d_surv_u32[0].p; sv.a_id = ctx->d_surv_u32[1].p; sv.b_id = ctx->d_surv_u32[2].p;
+        sv.a_begin = ctx->d_surv_u32[3].p; sv.a_end = ctx->d_surv_u32[4].p;
+        sv.b_begin = ctx->d_surv_u32[5].p; sv.b_end = ctx->d_surv_u32[6].p;
+        sv.length = ctx->d_surv_u32[7].p;
+        sv.strand = ctx->d_surv_u8[0].p; sv.type = ctx->d_surv_u8[1].p;
         // trim in the gather re-derives the coordinates against the pass-1 piles
-        launch_gather_survivors(ctx->ovl, ctx->d_cls.p, rs, ctx->d_flag[k].p, ctx->d_pos[k].p, sv, s);
+        launch_gather_survivors(ctx->ovl, ctx->d_cls.p, ctx->d_rec.p, ctx->d_chunk[2].p, ctx->d_chunk[3].p, n_surv[0], sv, s);
     }
     HIPCHECK(hipEventRecord(ctx->ev[7], s));
     HIPCHECK(hipGetLastError());
