@@ -144,11 +144,12 @@ struct rala_hip_ctx {
     // host mirror of the per-read state (valid after initialize / construct)
     bool initialized = false, constructed = false;
     uint64_t n_prefiltered = 0;
-    std::vector<uint32_t> h_begin, h_end, h_slot, h_begin0, h_end0;
+    std::vector<uint32_t> h_begin, h_end, h_slot;
     std::vector<uint16_t> h_median, h_p10;
     std::vector<uint8_t> h_alive, h_n_pits, h_n_hills;
     std::vector<rala_hip::Interval> h_pool;
-    bool host_state_fresh = false;
+    bool host_state_fresh = false;      // host mirrors of the per-read state match the device
+    uint32_t pool_used = 0;             // interval pool records in use
 
     // sensitive pass (repeat hills)
     rala_hip::DevBuf<uint16_t> d_dataset_median;

@@ -192,6 +192,7 @@ void launch_build_edges(const TailList& L, const TailReads& R, const uint32_t* k
                         const uint32_t* epos, uint32_t n_kept, const uint32_t* node_rank, uint32_t* e_src, uint32_t* e_dst,
                         uint32_t* e_len, hipStream_t s);
 void launch_node_reads(const uint8_t* alive, const uint32_t* rank, uint32_t* node_read, uint32_t n, hipStream_t s);
+void launch_count_zero_u8(const uint8_t* x, uint32_t n, uint32_t* out, hipStream_t s);    // *out += #zeros
 void launch_init_list_state(uint8_t* state, uint8_t* round, uint32_t n0, uint32_t n, hipStream_t s);
 
 // ---- scans (scan_kernels.hip) --------------------------------------------------

@@ -65,6 +65,7 @@ int download_read_state(rala_hip_ctx* ctx) {
     HIPCHECK(hipMemcpyAsync(small, ctx->d_small.p, sizeof(small), hipMemcpyDeviceToHost, s));
     HIPCHECK(hipStreamSynchronize(s));
     const uint32_t used = std::min(small[0], ctx->pool_cap);
+    ctx->pool_used = used;
     ctx->h_pool.resize(used);
     if (used) {
         HIPCHECK(hipMemcpy(ctx->h_pool.data(), ctx->d_pool.p, (size_t)used * sizeof(Interval), hipMemcpyDeviceToHost));
@@ -912,7 +913,7 @@ int gpu_tail_run(rala_hip_ctx* ctx) {
 
 // host mirrors of a device-resident result (lists in the reference's order, graph, read state)
 int materialize_host(rala_hip_ctx* ctx) {
-    if (!ctx->host_stale) return RALA_HIP_OK;
+    if (!ctx->host_stale) return ctx->host_state_fresh ? RALA_HIP_OK : download_read_state(ctx);
     hipStream_t s = ctx->stream;
     int rc = download_read_state(ctx);
     if (rc != RALA_HIP_OK) return rc;
@@ -1179,10 +1180,16 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
     HIPCHECK(hipEventRecord(ctx->ev[3], s));
     HIPCHECK(hipGetLastError());
 
-    int rc = download_read_state(ctx);
-    if (rc != RALA_HIP_OK) return rc;
-    uint32_t small[8];
-    HIPCHECK(hipMemcpy(small, ctx->d_small.p, sizeof(small), hipMemcpyDeviceToHost));
+    // the per-read results stay on the device; host mirrors are fetched by the first getter
+    HIPCHECK(ctx->d_cc_flags.ensure(8));
+    HIPCHECK(hipMemsetAsync(ctx->d_cc_flags.p + 6, 0, 4, s));
+    launch_count_zero_u8(ctx->d_alive.p, n_reads, ctx->d_cc_flags.p + 6, s);
+    uint32_t small[8], n_dead = 0;
+    HIPCHECK(hipMemcpyAsync(small, ctx->d_small.p, sizeof(small), hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipMemcpyAsync(&n_dead, ctx->d_cc_flags.p + 6, 4, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipStreamSynchronize(s));
+    ctx->host_state_fresh = false;
+    ctx->pool_used = std::min(small[0], ctx->pool_cap);
     ctx->tm.pile_overflow_reads = small[4];
     ctx->tm.pile_position_reads = ctx->use_run_kernel ? small[5] : n_reads;
     HIPCHECK(hipEventElapsedTime(&ctx->tm.dedupe_ms, ctx->ev[0], ctx->ev[1]));
@@ -1192,10 +1199,7 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
     if (small[1] & kErrPoolCapacity) {
         return fail(ctx, RALA_HIP_ECAPACITY, "interval pool exhausted (raise interval_pool_per_read_x1000)");
     }
-    ctx->h_begin0 = ctx->h_begin;
-    ctx->h_end0 = ctx->h_end;
-    ctx->n_prefiltered = 0;
-    for (uint64_t r = 0; r < ctx->n_reads; ++r) if (!ctx->h_alive[r]) ++ctx->n_prefiltered;
+    ctx->n_prefiltered = n_dead;
     ctx->initialized = true;
     ctx->valid_ready = !ctx->tuple_mode;
     ctx->piles_resident = true;
@@ -1251,7 +1255,7 @@ int rala_hip_get_device_state(rala_hip_ctx* ctx, rala_hip_device_state* out) {
     if (!ctx->initialized) return fail(ctx, RALA_HIP_EINVAL, "not initialized");
     out->begin = ctx->d_begin.p; out->end = ctx->d_end.p; out->median = ctx->d_median.p; out->p10 = ctx->d_p10.p;
     out->alive = ctx->d_alive.p; out->n_pits = ctx->d_n_pits.p; out->n_hills = ctx->d_n_hills.p;
-    out->slot = ctx->d_iv_slot.p; out->pool = ctx->d_pool.p; out->pool_count = ctx->h_pool.size();
+    out->slot = ctx->d_iv_slot.p; out->pool = ctx->d_pool.p; out->pool_count = (size_t)ctx->pool_used;
     out->valid = ctx->valid_ready ? ctx->d_valid.p : nullptr;
     return RALA_HIP_OK;
 }
@@ -1277,8 +1281,8 @@ int rala_hip_copy_device_state(rala_hip_ctx* ctx, const rala_hip_device_state* d
     HIPCHECK(cp(dst->n_hills, ctx->d_n_hills.p, n));
     HIPCHECK(cp(dst->slot, ctx->d_iv_slot.p, n * 4));
     if (dst->pool) {
-        if (dst->pool_count < ctx->h_pool.size()) return fail(ctx, RALA_HIP_ECAPACITY, "pool buffer too small");
-        HIPCHECK(cp(dst->pool, ctx->d_pool.p, ctx->h_pool.size() * sizeof(Interval)));
+        if (dst->pool_count < (size_t)ctx->pool_used) return fail(ctx, RALA_HIP_ECAPACITY, "pool buffer too small");
+        HIPCHECK(cp(dst->pool, ctx->d_pool.p, (size_t)ctx->pool_used * sizeof(Interval)));
     }
     if (dst->valid) {
         if (!ctx->valid_ready) return fail(ctx, RALA_HIP_EINVAL, "no validity bits on this context");
@@ -1322,8 +1326,6 @@ int rala_hip_import_state_device(rala_hip_ctx* ctx, const rala_hip_device_state*
     HIPCHECK(hipStreamSynchronize(s));
     const int rc = download_read_state(ctx);
     if (rc != RALA_HIP_OK) return rc;
-    ctx->h_begin0 = ctx->h_begin;
-    ctx->h_end0 = ctx->h_end;
     ctx->n_prefiltered = 0;
     for (uint64_t r = 0; r < n; ++r) if (!ctx->h_alive[r]) ++ctx->n_prefiltered;
     ctx->initialized = true;
@@ -1411,8 +1413,6 @@ int rala_hip_import_state(rala_hip_ctx* ctx, const uint8_t* valid, const uint32_
     if (ctx->n_ovl) HIPCHECK(hipMemcpy(ctx->d_valid.p, valid, ctx->n_ovl, hipMemcpyHostToDevice));
     const int rc = download_read_state(ctx);
     if (rc != RALA_HIP_OK) return rc;
-    ctx->h_begin0 = ctx->h_begin;
-    ctx->h_end0 = ctx->h_end;
     ctx->n_prefiltered = 0;
     for (uint64_t r = 0; r < n; ++r) if (!ctx->h_alive[r]) ++ctx->n_prefiltered;
     ctx->initialized = true;

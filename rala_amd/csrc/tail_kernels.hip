@@ -344,4 +344,15 @@ void launch_init_list_state(uint8_t* state, uint8_t* round, uint32_t n0, uint32_
     if (n) hipLaunchKernelGGL(init_list_state_kernel, grid_for(n), dim3(kBlock), 0, s, state, round, n0, n);
 }
 
+namespace {
+__global__ __launch_bounds__(256) void count_zero_u8_kernel(const uint8_t* __restrict__ x, uint32_t n, uint32_t* out) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const uint64_t m = __ballot(i < n && x[i] == 0);
+    if (m && (threadIdx.x & 63) == 0) atomicAdd(out, (uint32_t)__popcll(m));
+}
+}  // namespace
+void launch_count_zero_u8(const uint8_t* x, uint32_t n, uint32_t* out, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(count_zero_u8_kernel, dim3((n + 255) / 256), dim3(256), 0, s, x, n, out);
+}
+
 }  // namespace rala_hip
