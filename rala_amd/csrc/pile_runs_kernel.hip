@@ -281,77 +281,150 @@ __global__ __launch_bounds__(64) void pile_runs_kernel(PileArgs A, uint32_t* ove
             continue;
         }
 
-        // ---- 1. events sorted ascending (value = pos << 1 | is_end) -> LDS ----------
-        uint32_t P = 64;
-        while (P < n_ev) P <<= 1;
-        if (P <= 512) {
-            const uint32_t* gev = A.ev + e0;
-            if (P == 64) load_sort_store<1>(gev, n_ev, n, ev, lane);
-            else if (P == 128) load_sort_store<2>(gev, n_ev, n, ev, lane);
-            else if (P == 256) load_sort_store<4>(gev, n_ev, n, ev, lane);
-            else load_sort_store<8>(gev, n_ev, n, ev, lane);
-            wave_sync();
-        } else {
-            for (uint32_t k = lane; k < P; k += 64) {
-                uint32_t b = kNone;
-                if (k < n_ev) {
-                    b = A.ev[e0 + k];
-                    if ((b >> 1) > n) b = kNone;
-                }
-                ev[k] = b;
-            }
-            wave_sync();
-            for (uint32_t k = 2; k <= P; k <<= 1) {
-                for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-                    for (uint32_t t = lane; t < P / 2; t += 64) {
-                        const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                        const uint32_t l = i | j;
-                        const uint32_t a = ev[i], b = ev[l];
-                        const bool asc = (i & k) == 0;
-                        if ((a > b) == asc) { ev[i] = b; ev[l] = a; }
-                    }
-                    wave_sync();
-                }
-            }
-        }
-        RUN_STOP(21)
-
-        // ---- 2. prefix sum of +-1 -> runs (start, value mod 2^16) --------------------
+        // ---- 1 + 2. runs (start, value mod 2^16) ---------------------------------------------
+        // Reads of up to 16384 bases (bitmap = 512 words) need no sort: one bit per position
+        // that carries an event, the number of set bits up to a position is the index of its
+        // run, so every event adds its +-1 straight into its run's slot (LDS atomics) and a
+        // prefix sum over the slots gives the coverage.  Longer reads (and the big
+        // instantiation) sort their events and sweep, as the reference does.
         uint32_t R;
-        {
-            const uint32_t c = P / 64;                   // events per lane, contiguous
-            const uint32_t lo = lane * c;
-            int32_t s = 0;
-            uint32_t nb = 0;
-            for (uint32_t k = lo; k < lo + c; ++k) {
-                const uint32_t b = ev[k];
-                if (b == kNone) break;
-                s += (b & 1) ? -1 : 1;
-                const uint32_t nx = (k + 1 < P) ? ev[k + 1] : kNone;
-                if ((b >> 1) < n && (nx == kNone || (nx >> 1) != (b >> 1))) ++nb;
+        constexpr uint32_t kBitmapBases = 16384;
+        if (kCap == 512 && n <= kBitmapBases) {
+            uint32_t* bm = sm + L::X;
+            uint16_t* pref = (uint16_t*)(bm + kBitmapBases / 32);
+            int32_t* delta = (int32_t*)(sm + L::RF);
+            static_assert(kCap != 512 || L::SEL - L::RF >= L::kArr, "scratch for the per-run sums");
+            ((uint4*)bm)[lane] = make_uint4(0, 0, 0, 0);
+            ((uint4*)bm)[lane + 64] = make_uint4(0, 0, 0, 0);
+            for (uint32_t k = lane; k < n_ev + 2; k += 64) delta[k] = 0;
+            uint32_t evr[kCap / 64];
+#pragma unroll
+            for (uint32_t t = 0; t < kCap / 64; ++t) {
+                const uint32_t e = t * 64 + lane;
+                evr[t] = e < n_ev ? A.ev[e0 + e] : kNone;
             }
-            const int32_t s_incl = wave_scan_incl(s, OpAdd());
-            const uint32_t b_incl = wave_scan_incl(nb, OpAdd());
-            const uint32_t first = ev[0];
-            const uint32_t has_init = (first == kNone || (first >> 1) > 0) ? 1u : 0u;
-            int32_t cov = s_incl - s;
-            uint32_t w = has_init + b_incl - nb;
-            for (uint32_t k = lo; k < lo + c; ++k) {
-                const uint32_t b = ev[k];
-                if (b == kNone) break;
-                cov += (b & 1) ? -1 : 1;
-                const uint32_t nx = (k + 1 < P) ? ev[k + 1] : kNone;
-                if ((b >> 1) < n && (nx == kNone || (nx >> 1) != (b >> 1))) {
-                    rs[w] = b >> 1;
-                    rv[w] = (uint16_t)cov;
-                    ++w;
+            wave_sync();
+#pragma unroll
+            for (uint32_t t = 0; t < kCap / 64; ++t) {
+                if (t * 64 >= n_ev) break;
+                const uint32_t pos = evr[t] >> 1;
+                if (evr[t] != kNone && pos < n) atomicOr(&bm[pos >> 5], 1u << (pos & 31));
+            }
+            if (lane == 0) atomicOr(&bm[0], 1u);             // position 0 always starts a run
+            wave_sync();
+            {
+                const uint4 x = ((const uint4*)bm)[2 * lane], y = ((const uint4*)bm)[2 * lane + 1];
+                const uint32_t c[8] = {(uint32_t)__popc(x.x), (uint32_t)__popc(x.y), (uint32_t)__popc(x.z),
+                                       (uint32_t)__popc(x.w), (uint32_t)__popc(y.x), (uint32_t)__popc(y.y),
+                                       (uint32_t)__popc(y.z), (uint32_t)__popc(y.w)};
+                const uint32_t tot = c[0] + c[1] + c[2] + c[3] + c[4] + c[5] + c[6] + c[7];
+                const uint32_t incl = wave_scan_incl(tot, OpAdd());
+                uint32_t run = incl - tot;
+                uint32_t pk[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t lo = run; run += c[2 * q];
+                    const uint32_t hi = run; run += c[2 * q + 1];
+                    pk[q] = lo | (hi << 16);
+                }
+                ((uint4*)pref)[lane] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                R = (uint32_t)__shfl((int)incl, 63, 64);
+            }
+            wave_sync();
+#pragma unroll
+            for (uint32_t t = 0; t < kCap / 64; ++t) {
+                if (t * 64 >= n_ev) break;
+                const uint32_t pos = evr[t] >> 1;
+                if (evr[t] != kNone && pos < n) {
+                    const uint32_t w = pos >> 5;
+                    const uint32_t k = pref[w] + (uint32_t)__popc(bm[w] & ((2u << (pos & 31)) - 1u)) - 1u;
+                    rs[k] = pos;
+                    atomicAdd(&delta[k], (evr[t] & 1u) ? -1 : 1);
                 }
             }
-            R = has_init + (uint32_t)__shfl((int)b_incl, 63, 64);
-            if (lane == 0) {
-                if (has_init) { rs[0] = 0; rv[0] = 0; }
-                rs[R] = n;
-                rs[R + 1] = n;
+            if (lane == 0) { rs[0] = 0; rs[R] = n; rs[R + 1] = n; }
+            wave_sync();
+            {
+                const uint32_t cc = (R + 63) / 64;
+                const uint32_t lo = umin(R, lane * cc), hi = umin(R, lo + cc);
+                int32_t sum = 0;
+                for (uint32_t k = lo; k < hi; ++k) sum += delta[k];
+                int32_t cov = wave_scan_incl(sum, OpAdd()) - sum;
+                for (uint32_t k = lo; k < hi; ++k) {
+                    cov += delta[k];
+                    rv[k] = (uint16_t)cov;
+                }
+            }
+        } else {
+            // events sorted ascending (value = pos << 1 | is_end) -> LDS
+            uint32_t P = 64;
+            while (P < n_ev) P <<= 1;
+            if (P <= 512) {
+                const uint32_t* gev = A.ev + e0;
+                if (P == 64) load_sort_store<1>(gev, n_ev, n, ev, lane);
+                else if (P == 128) load_sort_store<2>(gev, n_ev, n, ev, lane);
+                else if (P == 256) load_sort_store<4>(gev, n_ev, n, ev, lane);
+                else load_sort_store<8>(gev, n_ev, n, ev, lane);
+                wave_sync();
+            } else {
+                for (uint32_t k = lane; k < P; k += 64) {
+                    uint32_t b = kNone;
+                    if (k < n_ev) {
+                        b = A.ev[e0 + k];
+                        if ((b >> 1) > n) b = kNone;
+                    }
+                    ev[k] = b;
+                }
+                wave_sync();
+                for (uint32_t k = 2; k <= P; k <<= 1) {
+                    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                        for (uint32_t t = lane; t < P / 2; t += 64) {
+                            const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                            const uint32_t l = i | j;
+                            const uint32_t a = ev[i], b = ev[l];
+                            const bool asc = (i & k) == 0;
+                            if ((a > b) == asc) { ev[i] = b; ev[l] = a; }
+                        }
+                        wave_sync();
+                    }
+                }
+            }
+            // prefix sum of +-1 -> runs
+            {
+                const uint32_t c = P / 64;                   // events per lane, contiguous
+                const uint32_t lo = lane * c;
+                int32_t s = 0;
+                uint32_t nb = 0;
+                for (uint32_t k = lo; k < lo + c; ++k) {
+                    const uint32_t b = ev[k];
+                    if (b == kNone) break;
+                    s += (b & 1) ? -1 : 1;
+                    const uint32_t nx = (k + 1 < P) ? ev[k + 1] : kNone;
+                    if ((b >> 1) < n && (nx == kNone || (nx >> 1) != (b >> 1))) ++nb;
+                }
+                const int32_t s_incl = wave_scan_incl(s, OpAdd());
+                const uint32_t b_incl = wave_scan_incl(nb, OpAdd());
+                const uint32_t first = ev[0];
+                const uint32_t has_init = (first == kNone || (first >> 1) > 0) ? 1u : 0u;
+                int32_t cov = s_incl - s;
+                uint32_t w = has_init + b_incl - nb;
+                for (uint32_t k = lo; k < lo + c; ++k) {
+                    const uint32_t b = ev[k];
+                    if (b == kNone) break;
+                    cov += (b & 1) ? -1 : 1;
+                    const uint32_t nx = (k + 1 < P) ? ev[k + 1] : kNone;
+                    if ((b >> 1) < n && (nx == kNone || (nx >> 1) != (b >> 1))) {
+                        rs[w] = b >> 1;
+                        rv[w] = (uint16_t)cov;
+                        ++w;
+                    }
+                }
+                R = has_init + (uint32_t)__shfl((int)b_incl, 63, 64);
+                if (lane == 0) {
+                    if (has_init) { rs[0] = 0; rv[0] = 0; }
+                    rs[R] = n;
+                    rs[R + 1] = n;
+                }
             }
         }
         wave_sync();
