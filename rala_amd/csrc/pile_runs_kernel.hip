@@ -289,7 +289,8 @@ __global__ __launch_bounds__(64) void pile_runs_kernel(PileArgs A, uint32_t* ove
         // instantiation) sort their events and sweep, as the reference does.
         uint32_t R;
         constexpr uint32_t kBitmapBases = 16384;
-        if (kCap == 512 && n <= kBitmapBases) {
+        const bool bitmap_path = kCap == 512 && n <= kBitmapBases;
+        if (bitmap_path) {
             uint32_t* bm = sm + L::X;
             uint16_t* pref = (uint16_t*)(bm + kBitmapBases / 32);
             int32_t* delta = (int32_t*)(sm + L::RF);
@@ -475,12 +476,19 @@ __global__ __launch_bounds__(64) void pile_runs_kernel(PileArgs A, uint32_t* ove
         for (uint32_t k = lane; k < R; k += 64) {
             if (k < kB || k >= kE) rv[k] = 0;
         }
-        // idx[g] = run that contains position g << shift = number of runs j >= 1 that start at
-        // or before it: histogram of ceil(start / 2^shift) over the runs, then a prefix sum
+        // idx[g] = run that contains position g << shift
         uint32_t shift = 5;
         while ((n >> shift) >= kIdx) ++shift;
         const uint32_t ng = ((n - 1) >> shift) + 1;
-        {
+        if (bitmap_path) {
+            // the bitmap of run starts and its per-word prefix are still there (shift == 5:
+            // the position is the first bit of word g)
+            const uint32_t* bm = sm + L::X;
+            const uint16_t* pref = (const uint16_t*)(bm + kBitmapBases / 32);
+            for (uint32_t m = lane; m < ng; m += 64) idx[m] = (uint16_t)(pref[m] + (bm[m] & 1u) - 1u);
+        } else {
+            // number of runs j >= 1 that start at or before it: histogram of
+            // ceil(start / 2^shift) over the runs, then a prefix sum
             uint32_t* gcnt = sm + L::X;                 // the sorted events are no longer needed
             for (uint32_t m = lane; m < ng; m += 64) gcnt[m] = 0;
             wave_sync();
@@ -515,35 +523,43 @@ __global__ __launch_bounds__(64) void pile_runs_kernel(PileArgs A, uint32_t* ove
             const uint32_t nv = (n + 7) / 8;
             if (lane == 0) rv[R] = 0;                       // padding behind the last base (rs[R] = n)
             uint32_t kbase = 0;                             // run that contains the segment's first position
+            const uint32_t bias = bitmap_path ? 0xFFFFFFFFu : 0u;    // bit 0 is set on the bitmap path
             for (uint32_t s0 = 0; s0 < nv * 8; s0 += kSeg) {
-                wave_sync();
-                ((uint4*)bm)[lane] = make_uint4(0, 0, 0, 0);
-                ((uint4*)bm)[lane + 64] = make_uint4(0, 0, 0, 0);
-                wave_sync();
-                for (uint32_t k = 1 + lane; k <= R; k += 64) {
-                    const uint32_t st = rs[k] - s0;         // starts are distinct positions
-                    if (st < kSeg && rs[k] > 0) atomicOr(&bm[st >> 5], 1u << (st & 31));
-                }
-                wave_sync();
-                {
-                    const uint4 a = ((const uint4*)bm)[2 * lane], b = ((const uint4*)bm)[2 * lane + 1];
-                    const uint32_t c[8] = {(uint32_t)__popc(a.x), (uint32_t)__popc(a.y), (uint32_t)__popc(a.z),
-                                           (uint32_t)__popc(a.w), (uint32_t)__popc(b.x), (uint32_t)__popc(b.y),
-                                           (uint32_t)__popc(b.z), (uint32_t)__popc(b.w)};
-                    const uint32_t tot = c[0] + c[1] + c[2] + c[3] + c[4] + c[5] + c[6] + c[7];
-                    const uint32_t incl = wave_scan_incl(tot, OpAdd());
-                    uint32_t run = kbase + incl - tot;
-                    uint32_t pk[4];
-#pragma unroll
-                    for (int x = 0; x < 4; ++x) {
-                        const uint32_t lo = run; run += c[2 * x];
-                        const uint32_t hi = run; run += c[2 * x + 1];
-                        pk[x] = lo | (hi << 16);
+                if (bitmap_path) {
+                    // bitmap and prefix of step 1 are still valid; only the padding behind the
+                    // last base needs its own "run" (never crosses into the next word)
+                    if (lane == 0 && n < kSeg) atomicOr(&bm[n >> 5], 1u << (n & 31));
+                    wave_sync();
+                } else {
+                    wave_sync();
+                    ((uint4*)bm)[lane] = make_uint4(0, 0, 0, 0);
+                    ((uint4*)bm)[lane + 64] = make_uint4(0, 0, 0, 0);
+                    wave_sync();
+                    for (uint32_t k = 1 + lane; k <= R; k += 64) {
+                        const uint32_t st = rs[k] - s0;         // starts are distinct positions
+                        if (st < kSeg && rs[k] > 0) atomicOr(&bm[st >> 5], 1u << (st & 31));
                     }
-                    ((uint4*)pref)[lane] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-                    kbase += (uint32_t)__shfl((int)incl, 63, 64);
+                    wave_sync();
+                    {
+                        const uint4 a = ((const uint4*)bm)[2 * lane], b = ((const uint4*)bm)[2 * lane + 1];
+                        const uint32_t c[8] = {(uint32_t)__popc(a.x), (uint32_t)__popc(a.y), (uint32_t)__popc(a.z),
+                                               (uint32_t)__popc(a.w), (uint32_t)__popc(b.x), (uint32_t)__popc(b.y),
+                                               (uint32_t)__popc(b.z), (uint32_t)__popc(b.w)};
+                        const uint32_t tot = c[0] + c[1] + c[2] + c[3] + c[4] + c[5] + c[6] + c[7];
+                        const uint32_t incl = wave_scan_incl(tot, OpAdd());
+                        uint32_t run = kbase + incl - tot;
+                        uint32_t pk[4];
+#pragma unroll
+                        for (int x = 0; x < 4; ++x) {
+                            const uint32_t lo = run; run += c[2 * x];
+                            const uint32_t hi = run; run += c[2 * x + 1];
+                            pk[x] = lo | (hi << 16);
+                        }
+                        ((uint4*)pref)[lane] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                        kbase += (uint32_t)__shfl((int)incl, 63, 64);
+                    }
+                    wave_sync();
                 }
-                wave_sync();
                 const uint32_t g_lo = s0 / 8, g_hi = umin(nv, (s0 + kSeg) / 8);
                 for (uint32_t g0 = g_lo + lane; g0 < g_hi; g0 += 256) {
                     uint32_t bits[4], k[4], v[4];
@@ -558,7 +574,7 @@ __global__ __launch_bounds__(64) void pile_runs_kernel(PileArgs A, uint32_t* ove
                     for (uint32_t u = 0; u < 4; ++u) {
                         const uint32_t g = umin(g0 + 64 * u, g_hi - 1);
                         const uint32_t sh = (g * 8) & 31;
-                        k[u] += (uint32_t)__popc(bits[u] & ((2u << sh) - 1u));
+                        k[u] += (uint32_t)__popc(bits[u] & ((2u << sh) - 1u)) + bias;
                         bits[u] = (bits[u] >> (sh + 1)) & 0x7Fu;        // starts at positions 1 .. 7 of the group
                         v[u] = rv[k[u]];
                     }

@@ -94,3 +94,35 @@ def test_sensitive_pass_vs_oracle(hip_ctx_factory, n, g, seed):
     tg = np.unique(sens.b_id)[:16]
     for r in tg:
         parity.assert_same("pile_data[%d]" % r, ctx.pile_data(int(r)), o.pile_data(int(r)))
+
+
+class _Scaled:
+    """A synthetic data set with every coordinate and length multiplied by `factor`."""
+
+    def __init__(self, ds, factor):
+        from rala_amd.synth import Overlaps, FIELDS
+
+        ov = ds.overlaps
+        kw = {f: getattr(ov, f) for f in FIELDS}
+        for f in ("a_begin", "a_end", "b_begin", "b_end", "length"):
+            kw[f] = kw[f] * factor
+        self.overlaps = Overlaps(strand=ov.strand, **kw)
+        self.read_len = (ds.read_len * factor).astype(np.uint32)
+        self.n_reads = ds.n_reads
+
+
+@pytest.mark.parametrize("factor", [2, 7])
+def test_long_reads(hip_ctx_factory, factor):
+    """Reads longer than the 16384-base position bitmap (sorted-event path of the run-space
+    kernel) and longer than 65536 bases (run starts beyond 16 bits)."""
+    ds = _Scaled(Dataset(1500, 300_000, 11), factor)
+    assert ds.read_len.max() > (16384 if factor == 2 else 65536)
+    st = parity.oracle_stages(ds)
+    ctx = hip_ctx_factory()
+    ctx.set_reads(ds.read_len)
+    ctx.set_overlaps(ds.overlaps)
+    ctx.initialize()
+    parity.check_initialize(ctx, st, ds)
+    ctx.construct()
+    parity.check_construct(ctx, st)
+    parity.check_tr(ctx, st)
