@@ -79,6 +79,11 @@ def build_host(force=False):
         hip = build_hip()
         _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I" + os.path.join(ROOT, "include"),
               "-I" + d, "-o", out] + lib_srcs + [hip, "-Wl,-rpath," + os.path.dirname(hip), "-lz"])
+    # the clean-up stages alone (no HIP dependency), for the CPU test-suite
+    ag = os.path.join(d, "libassembly_graph.so")
+    ag_srcs = [os.path.join(d, "assembly_graph.cpp"), os.path.join(d, "assembly_graph_capi.cpp")]
+    if force or _stale(ag, ag_srcs + [os.path.join(d, "assembly_graph.hpp")]):
+        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I" + d, "-o", ag] + ag_srcs)
     exe = os.path.join(d, "rala")
     main = os.path.join(d, "main.cpp")
     if os.path.exists(main) and (force or _stale(exe, deps)):

@@ -1,0 +1,431 @@
+#include "assembly_graph.hpp"
+
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <algorithm>
+#include <deque>
+#include <unordered_set>
+
+namespace rala {
+
+void AssemblyGraph::add_sequence_nodes(uint64_t sequence_id, const std::string& name, const std::string& data,
+    const std::string& reverse_complement) {
+    for (int rc = 0; rc < 2; ++rc) {
+        Node n;
+        n.id = nodes_.size();
+        n.name = name;
+        n.data = rc ? reverse_complement : data;
+        n.sequence_ids.assign(1, sequence_id);
+        n.is_first_rc = n.is_last_rc = rc != 0;        // graph.cpp:126-131
+        n.alive = true;
+        nodes_.push_back(std::move(n));
+    }
+}
+
+void AssemblyGraph::add_edge(uint32_t begin_node, uint32_t end_node, uint32_t length) {
+    Edge e;
+    e.id = edges_.size();
+    e.begin_node = begin_node; e.end_node = end_node; e.length = length;
+    e.alive = true;
+    nodes_[begin_node].suffix_edges.push_back((uint32_t)e.id);
+    nodes_[end_node].prefix_edges.push_back((uint32_t)e.id);
+    edges_.push_back(e);
+}
+
+void AssemblyGraph::mark_edge(uint32_t edge_id) {
+    for (uint32_t e : {edge_id, edge_id ^ 1u}) {
+        edges_[e].is_marked = true;
+        marked_edges_.push_back(e);
+    }
+}
+
+// graph.cpp:2118-2151: marked edges leave the adjacency lists (order of the rest kept), nodes
+// that end up isolated go too when asked for
+void AssemblyGraph::remove_marked_objects(bool remove_nodes) {
+    auto drop = [&](std::vector<uint32_t>& v) {
+        v.erase(std::remove_if(v.begin(), v.end(), [&](uint32_t e) { return edges_[e].is_marked; }), v.end());
+    };
+    for (uint32_t e : marked_edges_) {
+        if (!edges_[e].alive) continue;             // marked twice
+        drop(nodes_[edges_[e].begin_node].suffix_edges);
+        drop(nodes_[edges_[e].end_node].prefix_edges);
+    }
+    for (uint32_t e : marked_edges_) {
+        if (!edges_[e].alive) continue;
+        if (remove_nodes) {
+            for (uint32_t v : {edges_[e].begin_node, edges_[e].end_node}) {
+                if (nodes_[v].alive && nodes_[v].outdegree() == 0 && nodes_[v].indegree() == 0) {
+                    nodes_[v] = Node();
+                }
+            }
+        }
+    }
+    for (uint32_t e : marked_edges_) {
+        edges_[e].alive = false;
+        edges_[e].is_marked = false;
+    }
+    marked_edges_.clear();
+}
+
+// graph.cpp:1337-1366.  Edge weights come from the force-directed layout, which this build does
+// not run (it is seeded from std::random_device in the reference): all weights are 0 and
+// nothing qualifies, unless a caller filled Edge::weight.
+uint32_t AssemblyGraph::remove_long_edges() {
+    uint32_t num_long_edges = 0;
+    for (const auto& node : nodes_) {
+        if (!node.alive || node.suffix_edges.size() < 2) continue;
+        for (uint32_t e : node.suffix_edges) {
+            for (uint32_t o : node.suffix_edges) {
+                if (e == o || edges_[e].is_marked || edges_[o].is_marked) continue;
+                if (edges_[e].weight * 2.0 < edges_[o].weight) {
+                    mark_edge(o);
+                    ++num_long_edges;
+                }
+            }
+        }
+    }
+    remove_marked_objects();
+    return num_long_edges;
+}
+
+// graph.cpp:1368-1438
+uint32_t AssemblyGraph::remove_tips() {
+    uint32_t num_tip_edges = 0;
+    const size_t n0 = nodes_.size();
+    std::vector<bool> is_visited(n0, false);
+    for (size_t i = 0; i < n0; ++i) {
+        if (!nodes_[i].alive || is_visited[i] || !nodes_[i].is_tip()) continue;
+        bool is_circular = false;
+        uint32_t num_reads = 0;
+        uint32_t end_node = (uint32_t)i;
+        while (!nodes_[end_node].is_junction()) {
+            num_reads += (uint32_t)nodes_[end_node].sequence_ids.size();
+            is_visited[end_node] = true;
+            is_visited[end_node ^ 1u] = true;
+            if (nodes_[end_node].outdegree() == 0 ||
+                nodes_[edges_[nodes_[end_node].suffix_edges[0]].end_node].is_junction()) {
+                break;
+            }
+            end_node = edges_[nodes_[end_node].suffix_edges[0]].end_node;
+            if (end_node == i) { is_circular = true; break; }
+        }
+        if (is_circular || nodes_[end_node].outdegree() == 0 || num_reads > 5) continue;
+
+        uint32_t num_removed_edges = 0;
+        for (uint32_t e : nodes_[end_node].suffix_edges) {
+            if (nodes_[edges_[e].end_node].indegree() > 1) {
+                mark_edge(e);
+                ++num_removed_edges;
+            }
+        }
+        if (num_removed_edges == nodes_[end_node].suffix_edges.size()) {
+            uint32_t curr = (uint32_t)i;
+            while (curr != end_node) {
+                const uint32_t e = nodes_[curr].suffix_edges[0];
+                mark_edge(e);
+                curr = edges_[e].end_node;
+            }
+        }
+        num_tip_edges += num_removed_edges;
+        remove_marked_objects(true);
+    }
+    return num_tip_edges;
+}
+
+uint32_t AssemblyGraph::find_edge(uint32_t src, uint32_t dst) const {
+    for (uint32_t e : nodes_[src].suffix_edges) {
+        if (edges_[e].end_node == dst) return e;
+    }
+    fprintf(stderr, "[rala::Graph::find_edge] error: missing edge between nodes %u and %u\n", src, dst);
+    exit(1);
+}
+
+uint32_t AssemblyGraph::path_length(const std::vector<uint32_t>& path) const {
+    if (path.empty()) return 0;
+    uint32_t len = nodes_[path.back()].length();
+    for (size_t i = 0; i + 1 < path.size(); ++i) {
+        for (uint32_t e : nodes_[path[i]].suffix_edges) {
+            if (edges_[e].end_node == path[i + 1]) { len += edges_[e].length; break; }
+        }
+    }
+    return len;
+}
+
+// graph.cpp:1636-1702
+void AssemblyGraph::find_removable_edges(std::vector<uint32_t>& dst, const std::vector<uint32_t>& path) const {
+    if (path.empty()) return;
+    int64_t pref = -1;                   // first inner node with several in edges
+    for (size_t i = 1; i + 1 < path.size(); ++i) {
+        if (nodes_[path[i]].indegree() > 1) { pref = (int64_t)i; break; }
+    }
+    int64_t suff = -1;                   // last inner node with several out edges
+    for (size_t i = 1; i + 1 < path.size(); ++i) {
+        if (nodes_[path[i]].outdegree() > 1) suff = (int64_t)i;
+    }
+    auto take = [&](int64_t from, int64_t to) {
+        for (int64_t i = from; i < to; ++i) dst.push_back(find_edge(path[i], path[i + 1]));
+    };
+    const int64_t last = (int64_t)path.size() - 1;
+    if (pref == -1 && suff == -1) { take(0, last); return; }
+    if (pref != -1 && nodes_[path[pref]].outdegree() > 1) return;
+    if (suff != -1 && nodes_[path[suff]].indegree() > 1) return;
+    if (pref == -1) take(suff, last);
+    else if (suff == -1) take(0, pref);
+    else if (suff < pref) take(suff, pref);
+}
+
+// graph.cpp:1440-1613
+uint32_t AssemblyGraph::remove_bubbles() {
+    const size_t n0 = nodes_.size();
+    std::vector<uint32_t> distance(n0, 0);
+    std::vector<int64_t> predecessor(n0, -1);
+    std::vector<uint32_t> visited;
+    std::deque<uint32_t> queue;
+
+    auto extract_path = [&](std::vector<uint32_t>& dst, uint32_t source, uint32_t sink) {
+        uint32_t curr = sink;
+        while (curr != source) {
+            dst.push_back(curr);
+            curr = (uint32_t)predecessor[curr];
+        }
+        dst.push_back(source);
+        std::reverse(dst.begin(), dst.end());
+    };
+    auto inner_junction = [&](const std::vector<uint32_t>& p) {
+        for (size_t i = 1; i + 1 < p.size(); ++i) if (nodes_[p[i]].is_junction()) return true;
+        return false;
+    };
+    auto is_valid_bubble = [&](const std::vector<uint32_t>& path, const std::vector<uint32_t>& other) {
+        if (path.empty() || other.empty()) return false;
+        std::unordered_set<uint32_t> node_set(path.begin(), path.end());
+        node_set.insert(other.begin(), other.end());
+        if (path.size() + other.size() - 2 != node_set.size()) return false;
+        for (uint32_t v : path) if (node_set.count(v ^ 1u)) return false;
+        const uint32_t a = path_length(path), b = path_length(other);
+        if (std::min(a, b) < std::max(a, b) * 0.8) {
+            if (inner_junction(other) || inner_junction(path)) return false;
+        }
+        return true;
+    };
+    auto num_reads = [&](const std::vector<uint32_t>& p) {
+        uint64_t n = 0;
+        for (uint32_t v : p) n += nodes_[v].sequence_ids.size();
+        return n;
+    };
+
+    uint32_t num_bubbles_popped = 0;
+    for (size_t s = 0; s < n0; ++s) {
+        if (!nodes_[s].alive || nodes_[s].outdegree() < 2) continue;
+        const uint32_t source = (uint32_t)s;
+        bool found_sink = false;
+        uint32_t sink = 0, sink_other_predecessor = 0;
+        queue.push_back(source);
+        visited.push_back(source);
+        while (!queue.empty() && !found_sink) {
+            const uint32_t v = queue.front();
+            queue.pop_front();
+            for (uint32_t e : nodes_[v].suffix_edges) {
+                const uint32_t w = edges_[e].end_node;
+                if (w == source) continue;                                   // cycle
+                if (distance[v] + edges_[e].length > 5000000) continue;       // out of reach
+                distance[w] = distance[v] + edges_[e].length;
+                visited.push_back(w);
+                queue.push_back(w);
+                if (predecessor[w] != -1) {
+                    sink = w;
+                    sink_other_predecessor = v;
+                    found_sink = true;
+                    break;
+                }
+                predecessor[w] = v;
+            }
+        }
+        if (found_sink) {
+            std::vector<uint32_t> path, other(1, sink);
+            extract_path(path, source, sink);
+            extract_path(other, source, sink_other_predecessor);
+            if (is_valid_bubble(path, other)) {
+                const uint64_t path_reads = num_reads(path), other_reads = num_reads(other);
+                std::vector<uint32_t> doomed;
+                find_removable_edges(doomed, path_reads > other_reads ? other : path);
+                if (doomed.empty()) {
+                    const uint32_t a = path_length(path), b = path_length(other);
+                    if (std::min(a, b) >= std::max(a, b) * 0.8) {
+                        find_removable_edges(doomed, path_reads > other_reads ? path : other);
+                    }
+                }
+                for (uint32_t e : doomed) mark_edge(e);
+                if (!doomed.empty()) {
+                    remove_marked_objects(true);
+                    ++num_bubbles_popped;
+                }
+            }
+        }
+        queue.clear();
+        for (uint32_t v : visited) {
+            distance[v] = 0;
+            predecessor[v] = -1;
+        }
+        visited.clear();
+    }
+    return num_bubbles_popped;
+}
+
+// graph.cpp:133-170 (Node constructor for unitigs)
+uint32_t AssemblyGraph::append_unitig(uint32_t begin_node, uint32_t end_node) {
+    Node u;
+    u.id = nodes_.size();
+    u.alive = true;
+    u.is_first_rc = nodes_[begin_node].is_first_rc;
+    uint32_t node = begin_node;
+    while (true) {
+        const Edge& edge = edges_[nodes_[node].suffix_edges[0]];
+        u.data += nodes_[node].data.substr(0, edge.length);
+        u.sequence_ids.insert(u.sequence_ids.end(), nodes_[node].sequence_ids.begin(), nodes_[node].sequence_ids.end());
+        u.is_last_rc = nodes_[node].is_last_rc;
+        node = edge.end_node;
+        if (node == end_node) break;
+    }
+    if (begin_node != end_node) {
+        u.data += nodes_[end_node].data;
+        u.sequence_ids.insert(u.sequence_ids.end(), nodes_[end_node].sequence_ids.begin(),
+            nodes_[end_node].sequence_ids.end());
+        u.is_last_rc = nodes_[end_node].is_last_rc;
+    }
+    nodes_.push_back(std::move(u));
+    return (uint32_t)nodes_.size() - 1;
+}
+
+// graph.cpp:1760-1845 (and the same block of shrink, :1934-2012): unitig + complement, the
+// edge that enters the chain and the edge that leaves it are re-created on the unitigs, every
+// edge of the chain is marked
+void AssemblyGraph::splice_unitig(uint32_t begin_node, uint32_t end_node, bool attach) {
+    const uint32_t unitig = append_unitig(begin_node, end_node);
+    const uint32_t complement = append_unitig(end_node ^ 1u, begin_node ^ 1u);
+    auto new_edge = [&](uint32_t from, uint32_t to, uint32_t length) {
+        Edge e;
+        e.id = edges_.size();
+        e.begin_node = from; e.end_node = to; e.length = length;
+        e.alive = true;
+        edges_.push_back(e);
+        return (uint32_t)e.id;
+    };
+    if (attach) {
+        if (nodes_[begin_node].indegree() != 0) {
+            const uint32_t edge = nodes_[begin_node].prefix_edges[0];
+            const uint32_t from = edges_[edge].begin_node, to_c = edges_[edge ^ 1u].end_node;
+            mark_edge(edge);
+            const uint32_t ue = new_edge(from, unitig, edges_[edge].length);
+            const uint32_t uc = new_edge(complement, to_c,
+                edges_[edge ^ 1u].length + nodes_[complement].length() - nodes_[begin_node ^ 1u].length());
+            nodes_[from].suffix_edges.push_back(ue);
+            nodes_[to_c].prefix_edges.push_back(uc);
+            nodes_[unitig].prefix_edges.push_back(ue);
+            nodes_[complement].suffix_edges.push_back(uc);
+        }
+        if (nodes_[end_node].outdegree() != 0) {
+            const uint32_t edge = nodes_[end_node].suffix_edges[0];
+            const uint32_t to = edges_[edge].end_node, from_c = edges_[edge ^ 1u].begin_node;
+            mark_edge(edge);
+            const uint32_t ue = new_edge(unitig, to,
+                edges_[edge].length + nodes_[unitig].length() - nodes_[end_node].length());
+            const uint32_t uc = new_edge(from_c, complement, edges_[edge ^ 1u].length);
+            nodes_[unitig].suffix_edges.push_back(ue);
+            nodes_[complement].prefix_edges.push_back(uc);
+            nodes_[to].prefix_edges.push_back(ue);
+            nodes_[from_c].suffix_edges.push_back(uc);
+        }
+    }
+    uint32_t node = begin_node;
+    while (true) {
+        const uint32_t e = nodes_[node].suffix_edges[0];
+        mark_edge(e);
+        node = edges_[e].end_node;
+        if (node == end_node) break;
+    }
+}
+
+// graph.cpp:1704-1848
+uint32_t AssemblyGraph::create_unitigs() {
+    const size_t n0 = nodes_.size();
+    std::vector<bool> is_visited(n0, false);
+    uint32_t num_unitigs_created = 0;
+    for (size_t i = 0; i < n0; ++i) {
+        if (!nodes_[i].alive || is_visited[i] || nodes_[i].is_junction()) continue;
+        bool is_circular = false;
+        uint32_t begin_node = (uint32_t)i;
+        while (!nodes_[begin_node].is_junction()) {
+            is_visited[begin_node] = true;
+            is_visited[begin_node ^ 1u] = true;
+            if (nodes_[begin_node].indegree() == 0 ||
+                nodes_[edges_[nodes_[begin_node].prefix_edges[0]].begin_node].is_junction()) {
+                break;
+            }
+            begin_node = edges_[nodes_[begin_node].prefix_edges[0]].begin_node;
+            if (begin_node == i) { is_circular = true; break; }
+        }
+        uint32_t end_node = (uint32_t)i;
+        while (!nodes_[end_node].is_junction()) {
+            is_visited[end_node] = true;
+            is_visited[end_node ^ 1u] = true;
+            if (nodes_[end_node].outdegree() == 0 ||
+                nodes_[edges_[nodes_[end_node].suffix_edges[0]].end_node].is_junction()) {
+                break;
+            }
+            end_node = edges_[nodes_[end_node].suffix_edges[0]].end_node;
+            if (end_node == i) { is_circular = true; break; }
+        }
+        if (!is_circular && begin_node == end_node) continue;
+        splice_unitig(begin_node, end_node, begin_node != end_node);
+        ++num_unitigs_created;
+    }
+    remove_marked_objects(true);
+    return num_unitigs_created;
+}
+
+// graph.cpp:1850-2040 (the bookkeeping for the layout's transitive-edge list is not kept)
+uint32_t AssemblyGraph::shrink(uint32_t epsilon) {
+    const size_t n0 = nodes_.size();
+    std::vector<bool> is_visited(n0, false);
+    uint32_t num_unitigs_created = 0;
+    for (size_t i = 0; i < n0; ++i) {
+        if (!nodes_[i].alive || is_visited[i] || nodes_[i].is_junction()) continue;
+        uint32_t extension = 1;
+        bool is_circular = false;
+        uint32_t begin_node = (uint32_t)i;
+        while (!nodes_[begin_node].is_junction()) {
+            is_visited[begin_node] = true;
+            is_visited[begin_node ^ 1u] = true;
+            if (nodes_[begin_node].indegree() == 0 ||
+                nodes_[edges_[nodes_[begin_node].prefix_edges[0]].begin_node].is_junction()) {
+                break;
+            }
+            begin_node = edges_[nodes_[begin_node].prefix_edges[0]].begin_node;
+            ++extension;
+            if (begin_node == i) { is_circular = true; break; }
+        }
+        if (is_circular) continue;
+        uint32_t end_node = (uint32_t)i;
+        while (!nodes_[end_node].is_junction()) {
+            is_visited[end_node] = true;
+            is_visited[end_node ^ 1u] = true;
+            if (nodes_[end_node].outdegree() == 0 ||
+                nodes_[edges_[nodes_[end_node].suffix_edges[0]].end_node].is_junction()) {
+                break;
+            }
+            end_node = edges_[nodes_[end_node].suffix_edges[0]].end_node;
+            ++extension;
+            if (end_node == i) { is_circular = true; break; }
+        }
+        if (is_circular || begin_node == end_node || extension < 2 * epsilon + 2) continue;
+        for (uint32_t k = 0; k < epsilon; ++k) begin_node = edges_[nodes_[begin_node].suffix_edges[0]].end_node;
+        for (uint32_t k = 0; k < epsilon; ++k) end_node = edges_[nodes_[end_node].prefix_edges[0]].begin_node;
+        splice_unitig(begin_node, end_node, true);
+        ++num_unitigs_created;
+    }
+    remove_marked_objects(true);
+    return num_unitigs_created;
+}
+
+}  // namespace rala

@@ -238,93 +238,98 @@ void Graph::construct(const std::string& sensitive_overlaps_path) {
     rala_hip_get_graph(ctx_, node_read.data(), src.data(), dst.data(), len.data(), nullptr);
     std::vector<int64_t> read_to_node(n, -1);
     for (uint64_t k = 0; k < n_nodes; k += 2) read_to_node[node_read[k]] = (int64_t)k;
-    nodes_.resize(n_nodes);
+    // nodes in read order (graph.cpp:553-574): collect the trimmed sequences first
+    std::vector<std::string> node_name(n_nodes / 2), node_data(n_nodes / 2), node_rc(n_nodes / 2);
     uint64_t seq_id = 0;
     read_sequences(sequences_path_, [&](const std::string& name, const std::string& data) {
         const uint64_t i = seq_id++;
         if (i >= n || read_to_node[i] < 0) return;
         auto seq = createSequence(name, data);
         seq->trim(begin[i], end[i]);
-        const uint64_t k = (uint64_t)read_to_node[i];
-        nodes_[k].id = k; nodes_[k].sequence_id = i; nodes_[k].name = name; nodes_[k].data = seq->data();
-        nodes_[k + 1].id = k + 1; nodes_[k + 1].sequence_id = i; nodes_[k + 1].name = name;
-        nodes_[k + 1].data = seq->reverse_complement();
+        const uint64_t k = (uint64_t)read_to_node[i] / 2;
+        node_name[k] = name;
+        node_data[k] = seq->data();
+        node_rc[k] = seq->reverse_complement();
     });
+    for (uint64_t k = 0; k < n_nodes / 2; ++k) {
+        graph_.add_sequence_nodes(node_read[2 * k], node_name[k], node_data[k], node_rc[k]);
+    }
     timer("[rala::Graph::construct] loaded sequences");
     timer();
-    edges_.resize(n_edges);
-    for (uint64_t e = 0; e < n_edges; ++e) {
-        edges_[e].id = e; edges_[e].begin_node = src[e]; edges_[e].end_node = dst[e]; edges_[e].length = len[e];
-        edges_[e].is_marked = false; edges_[e].is_removed = false;
-        nodes_[src[e]].suffix_edges.push_back((uint32_t)e);
-        nodes_[dst[e]].prefix_edges.push_back((uint32_t)e);
-    }
+    for (uint64_t e = 0; e < n_edges; ++e) graph_.add_edge(src[e], dst[e], len[e]);
     timer("[rala::Graph::construct] created assembly graph");
-    fprintf(stderr, "[rala::Graph::construct] number of nodes = %zu\n", nodes_.size());
-    fprintf(stderr, "[rala::Graph::construct] number of edges = %zu\n", edges_.size());
+    fprintf(stderr, "[rala::Graph::construct] number of nodes = %zu\n", graph_.nodes().size());
+    fprintf(stderr, "[rala::Graph::construct] number of edges = %zu\n", graph_.edges().size());
 }
 
-void Graph::not_in_this_build(const char* what) const {
-    fprintf(stderr, "[rala::Graph::%s] note: layout clean-up after transitive reduction is outside this "
-        "build's hot path (SURVEY.md section 8f); graph left unchanged\n", what);
-}
-
-// reference src/graph.cpp:642-697
+// reference src/graph.cpp:642-697 without the five force-directed layout rounds (:667-671:
+// postprocess() is seeded from std::random_device; remove_long_edges() needs its edge weights)
 void Graph::simplify() {
     StageTimer timer;
     const uint32_t num_transitive_edges = remove_transitive_edges();
+    uint32_t num_tips = 0, num_bubbles = 0, num_long_edges = 0;
+    auto tips_and_bubbles = [&]() {
+        while (true) {
+            uint32_t num_changes = remove_tips();
+            num_tips += num_changes;
+            const uint32_t num_changes_part = remove_bubbles();
+            num_bubbles += num_changes_part;
+            num_changes += num_changes_part;
+            if (num_changes == 0) break;
+        }
+    };
+    tips_and_bubbles();
+    shrink(42);
+    for (uint32_t i = 0; i < 5; ++i) {
+        num_long_edges += remove_long_edges();
+        num_tips += remove_tips();
+    }
+    tips_and_bubbles();
     timer("[rala::Graph::simplify]");
     fprintf(stderr, "[rala::Graph::simplify] number of transitive edges = %u\n", num_transitive_edges);
-    not_in_this_build("simplify");
+    fprintf(stderr, "[rala::Graph::simplify] number of tips = %u\n", num_tips);
+    fprintf(stderr, "[rala::Graph::simplify] number of bubbles = %u\n", num_bubbles);
+    fprintf(stderr, "[rala::Graph::simplify] number of long edges = %u\n", num_long_edges);
 }
 
 // reference src/graph.cpp:1281-1335 through rala_hip_tr_mark on the current live edges
 uint32_t Graph::remove_transitive_edges() {
-    // live edges keep their pairing: twins are 2k, 2k + 1 and die together
+    const auto& edges = graph_.edges();
     std::vector<uint32_t> ids, src, dst, len;
-    for (uint64_t e = 0; e < edges_.size(); ++e) {
-        if (edges_[e].is_removed) continue;
+    for (uint64_t e = 0; e < edges.size(); ++e) {
+        if (!edges[e].alive) continue;
         ids.push_back((uint32_t)e);
-        src.push_back(edges_[e].begin_node); dst.push_back(edges_[e].end_node); len.push_back(edges_[e].length);
+        src.push_back(edges[e].begin_node); dst.push_back(edges[e].end_node); len.push_back(edges[e].length);
     }
     std::vector<uint8_t> marks(ids.size());
     uint32_t num_transitive_edges = 0;
-    check(ctx_, rala_hip_tr_mark(ctx_, (uint32_t)nodes_.size(), (uint32_t)ids.size(), src.data(), dst.data(),
+    check(ctx_, rala_hip_tr_mark(ctx_, (uint32_t)graph_.nodes().size(), (uint32_t)ids.size(), src.data(), dst.data(),
                                  len.data(), marks.data(), &num_transitive_edges), "remove_transitive_edges");
+    // marks come in twin pairs (graph.cpp:1306-1309)
     for (size_t k = 0; k < ids.size(); ++k) {
-        if (marks[k]) edges_[ids[k]].is_marked = true;
+        if (marks[k] && !graph_.edges()[ids[k]].is_marked) graph_.mark_edge(ids[k]);
     }
-    // remove_marked_objects (graph.cpp:2118-2151)
-    for (auto& node : nodes_) {
-        auto drop = [&](std::vector<uint32_t>& v) {
-            v.erase(std::remove_if(v.begin(), v.end(), [&](uint32_t e) { return edges_[e].is_marked; }), v.end());
-        };
-        drop(node.suffix_edges);
-        drop(node.prefix_edges);
-    }
-    for (auto& e : edges_) {
-        if (e.is_marked) { e.is_removed = true; e.is_marked = false; }
-    }
+    graph_.remove_marked_objects();
     return num_transitive_edges;
 }
 
-uint32_t Graph::remove_long_edges() { not_in_this_build("remove_long_edges"); return 0; }
-uint32_t Graph::remove_tips() { not_in_this_build("remove_tips"); return 0; }
-uint32_t Graph::remove_bubbles() { not_in_this_build("remove_bubbles"); return 0; }
-uint32_t Graph::create_unitigs() { not_in_this_build("create_unitigs"); return 0; }
-uint32_t Graph::shrink(uint32_t) { not_in_this_build("shrink"); return 0; }
+uint32_t Graph::remove_long_edges() { return graph_.remove_long_edges(); }
+uint32_t Graph::remove_tips() { return graph_.remove_tips(); }
+uint32_t Graph::remove_bubbles() { return graph_.remove_bubbles(); }
+uint32_t Graph::create_unitigs() { return graph_.create_unitigs(); }
+uint32_t Graph::shrink(uint32_t epsilon) { return graph_.shrink(epsilon); }
 
-// reference src/graph.cpp:2042-2082 on the nodes as they stand (no unitigs in this build)
+// reference src/graph.cpp:2042-2082
 void Graph::extract_contigs(std::vector<std::unique_ptr<Sequence>>& dst, bool drop_unassembled_sequences) {
     create_unitigs();
     uint32_t contig_id = 0;
     std::vector<uint32_t> contig_length;
-    for (const auto& node : nodes_) {
-        if (node.id & 1) continue;
-        if (drop_unassembled_sequences) continue;      // every node is one read: < 6 reads (graph.cpp:2053)
-        contig_length.push_back((uint32_t)node.data.size());
+    for (const auto& node : graph_.nodes()) {
+        if (!node.alive || node.is_rc()) continue;
+        if (drop_unassembled_sequences && (node.sequence_ids.size() < 6 || node.length() < 10000)) continue;
+        contig_length.push_back(node.length());
         std::string name = "Ctg" + std::to_string(contig_id);
-        name += " RC:i:1";
+        name += " RC:i:" + std::to_string(node.sequence_ids.size());
         name += " LN:i:" + std::to_string(node.data.size());
         dst.emplace_back(createSequence(name, node.data));
         ++contig_id;
@@ -340,14 +345,16 @@ void Graph::extract_contigs(std::vector<std::unique_ptr<Sequence>>& dst, bool dr
 
 // reference src/graph.cpp:2084-2116 (the reference iterates an unordered_set; here ascending ids)
 void Graph::extract_nodes(std::vector<std::unique_ptr<Sequence>>& dst) {
+    const auto& nodes = graph_.nodes();
+    const auto& edges = graph_.edges();
     std::set<uint64_t> node_ids;
-    for (const auto& it : nodes_) {
-        if ((it.id & 1) || (it.suffix_edges.empty() && it.prefix_edges.empty())) continue;
+    for (const auto& it : nodes) {
+        if (!it.alive || it.is_rc() || (it.outdegree() == 0 && it.indegree() == 0)) continue;
         node_ids.insert(it.id);
-        for (uint32_t e : it.prefix_edges) node_ids.insert(edges_[e].begin_node & ~1u);
-        for (uint32_t e : it.suffix_edges) node_ids.insert(edges_[e].end_node & ~1u);
+        for (uint32_t e : it.prefix_edges) node_ids.insert(edges[e].begin_node & ~1u);
+        for (uint32_t e : it.suffix_edges) node_ids.insert(edges[e].end_node & ~1u);
     }
-    for (uint64_t id : node_ids) dst.emplace_back(createSequence(nodes_[id].name, nodes_[id].data));
+    for (uint64_t id : node_ids) dst.emplace_back(createSequence(nodes[id].name, nodes[id].data));
     fprintf(stderr, "[rala::Graph::extract_nodes] number of nodes = %zu\n", dst.size());
 }
 
@@ -355,18 +362,19 @@ void Graph::extract_nodes(std::vector<std::unique_ptr<Sequence>>& dst) {
 void Graph::print_csv(const std::string& path) const {
     auto graph_file = fopen(path.c_str(), "w");
     if (!graph_file) return;
-    for (const auto& it : nodes_) {
-        if (!(it.id & 1) || (it.suffix_edges.empty() && it.prefix_edges.empty())) continue;
-        const auto& pair = nodes_[it.id ^ 1];
-        fprintf(graph_file, "%lu LN:i:%u RC:i:%lu,%lu LN:i:%u RC:i:%lu,0,-\n", it.id, (uint32_t)it.data.size(), 1ul,
-            pair.id, (uint32_t)pair.data.size(), 1ul);
+    const auto& nodes = graph_.nodes();
+    for (const auto& it : nodes) {
+        if (!it.alive || !it.is_rc() || (it.outdegree() == 0 && it.indegree() == 0)) continue;
+        const auto& pair = nodes[it.id ^ 1];
+        fprintf(graph_file, "%lu LN:i:%u RC:i:%lu,%lu LN:i:%u RC:i:%lu,0,-\n", it.id, it.length(),
+            it.sequence_ids.size(), pair.id, pair.length(), pair.sequence_ids.size());
     }
-    for (const auto& it : edges_) {
-        if (it.is_removed) continue;
-        const auto& b = nodes_[it.begin_node];
-        const auto& e = nodes_[it.end_node];
-        fprintf(graph_file, "%lu LN:i:%u RC:i:%lu,%lu LN:i:%u RC:i:%lu,1,%lu %u %lf\n", b.id,
-            (uint32_t)b.data.size(), 1ul, e.id, (uint32_t)e.data.size(), 1ul, it.id, it.length, 0.0);
+    for (const auto& it : graph_.edges()) {
+        if (!it.alive) continue;
+        const auto& b = nodes[it.begin_node];
+        const auto& e = nodes[it.end_node];
+        fprintf(graph_file, "%lu LN:i:%u RC:i:%lu,%lu LN:i:%u RC:i:%lu,1,%lu %u %lf\n", b.id, b.length(),
+            b.sequence_ids.size(), e.id, e.length(), e.sequence_ids.size(), it.id, it.length, it.weight);
     }
     fclose(graph_file);
 }
@@ -375,16 +383,28 @@ void Graph::print_csv(const std::string& path) const {
 void Graph::print_gfa(const std::string& path) const {
     auto graph_file = fopen(path.c_str(), "w");
     if (!graph_file) return;
-    for (const auto& it : nodes_) {
-        if ((it.id & 1) || (it.suffix_edges.empty() && it.prefix_edges.empty())) continue;
-        fprintf(graph_file, "S\t%s\t%s\tLN:i:%zu\tRC:i:%lu\n", it.name.c_str(), it.data.c_str(), it.data.size(), 1ul);
+    const auto& nodes = graph_.nodes();
+    std::unordered_map<uint64_t, std::string> unitig_name;
+    uint32_t unitig_id = 0;
+    auto name_of = [&](const AssemblyGraph::Node& n) -> const std::string& {
+        return !n.name.empty() ? n.name : unitig_name[n.id];
+    };
+    for (const auto& it : nodes) {
+        if (!it.alive || it.is_rc() || (it.outdegree() == 0 && it.indegree() == 0)) continue;
+        if (it.name.empty()) {
+            const std::string name = "Utg" + std::to_string(unitig_id++);
+            unitig_name[it.id] = name;
+            unitig_name[it.id ^ 1] = name;
+        }
+        fprintf(graph_file, "S\t%s\t%s\tLN:i:%zu\tRC:i:%lu\n", name_of(it).c_str(), it.data.c_str(), it.data.size(),
+            it.sequence_ids.size());
     }
-    for (const auto& it : edges_) {
-        if (it.is_removed) continue;
-        const auto& b = nodes_[it.begin_node];
-        const auto& e = nodes_[it.end_node];
-        fprintf(graph_file, "L\t%s\t%c\t%s\t%c\t%zuM\n", b.name.c_str(), (b.id & 1) ? '-' : '+', e.name.c_str(),
-            (e.id & 1) ? '-' : '+', b.data.size() - it.length);
+    for (const auto& it : graph_.edges()) {
+        if (!it.alive) continue;
+        const auto& b = nodes[it.begin_node];
+        const auto& e = nodes[it.end_node];
+        fprintf(graph_file, "L\t%s\t%c\t%s\t%c\t%zuM\n", name_of(b).c_str(), b.is_rc() ? '-' : '+',
+            name_of(e).c_str(), e.is_rc() ? '-' : '+', b.data.size() - it.length);
     }
     fclose(graph_file);
 }
@@ -394,28 +414,29 @@ void Graph::print_json(const std::string& path) const {
     std::ofstream os(path);
     os << "{\"nodes\":{";
     bool is_first = true;
+    const auto& nodes = graph_.nodes();
+    const auto& edges = graph_.edges();
     std::set<uint64_t> sequence_ids;
-    for (const auto& it : nodes_) {
-        const bool junction = it.suffix_edges.size() > 1 || it.prefix_edges.size() > 1;
-        if ((it.id & 1) || !junction) continue;
+    for (const auto& it : nodes) {
+        if (!it.alive || it.is_rc() || !it.is_junction()) continue;
         if (!is_first) os << ",";
         is_first = false;
-        os << "\"" << it.sequence_id << "\":{\"n\":" << it.id << ",";
+        os << "\"" << it.sequence_ids.front() << "\":{\"n\":" << it.id << ",";
         os << "\"p\":[";
-        sequence_ids.insert(it.sequence_id);
+        sequence_ids.insert(it.sequence_ids.front());
         for (size_t i = 0; i < it.prefix_edges.size(); ++i) {
-            const auto& other = nodes_[edges_[it.prefix_edges[i]].begin_node];
-            sequence_ids.insert(other.sequence_id);
-            os << "[\"" << other.sequence_id << "\",\"" << other.id << "\"," << (other.id & 1) << ","
-               << other.data.size() - edges_[it.prefix_edges[i]].length << "]";
+            const auto& other = nodes[edges[it.prefix_edges[i]].begin_node];
+            sequence_ids.insert(other.sequence_ids.back());
+            os << "[\"" << other.sequence_ids.back() << "\",\"" << other.id << "\"," << other.is_last_rc << ","
+               << other.length() - edges[it.prefix_edges[i]].length << "]";
             if (i + 1 < it.prefix_edges.size()) os << ",";
         }
         os << "],\"s\":[";
         for (size_t i = 0; i < it.suffix_edges.size(); ++i) {
-            const auto& other = nodes_[edges_[it.suffix_edges[i]].end_node];
-            sequence_ids.insert(other.sequence_id);
-            os << "[\"" << other.sequence_id << "\",\"" << other.id << "\"," << (other.id & 1) << ","
-               << it.data.size() - edges_[it.suffix_edges[i]].length << "]";
+            const auto& other = nodes[edges[it.suffix_edges[i]].end_node];
+            sequence_ids.insert(other.sequence_ids.front());
+            os << "[\"" << other.sequence_ids.front() << "\",\"" << other.id << "\"," << other.is_first_rc << ","
+               << it.length() - edges[it.suffix_edges[i]].length << "]";
             if (i + 1 < it.suffix_edges.size()) os << ",";
         }
         os << "]}";

@@ -4,9 +4,10 @@
  * @brief Graph class (interface of rvaser/rala src/graph.hpp:37-180) on top of librala_hip.
  *
  * construct() and remove_transitive_edges() run on the GPU through the C ABI
- * (include/rala_hip.h).  The layout clean-up after transitive reduction (tips, bubbles,
- * unitigs, shrink, force-directed layout, long edges; reference src/graph.cpp:1056-1279,
- * 1337-2040) is outside this build's hot path and reports so when called.
+ * (include/rala_hip.h).  The clean-up after transitive reduction (tips, bubbles, unitigs,
+ * shrink; reference src/graph.cpp:1337-2040) is host code on the small surviving graph
+ * (assembly_graph.hpp).  The force-directed layout (reference :1056-1279, seeded from
+ * std::random_device) is not run: edge weights stay 0 and remove_long_edges() finds nothing.
  */
 
 #pragma once
@@ -16,6 +17,8 @@
 #include <string>
 #include <unordered_map>
 #include <vector>
+
+#include "assembly_graph.hpp"
 
 struct rala_hip_ctx;
 
@@ -62,21 +65,6 @@ private:
     const Graph& operator=(const Graph&) = delete;
 
     void initialize();
-    void not_in_this_build(const char* what) const;
-
-    struct Node {
-        uint64_t id;
-        uint64_t sequence_id;
-        std::string name;
-        std::string data;
-        std::vector<uint32_t> prefix_edges, suffix_edges;
-    };
-    struct Edge {
-        uint64_t id;
-        uint32_t begin_node, end_node, length;
-        bool is_marked;
-        bool is_removed;
-    };
 
     std::string sequences_path_, overlaps_path_;
     uint32_t num_threads_;
@@ -90,8 +78,7 @@ private:
     std::vector<uint32_t> a_id_, b_id_, a_begin_, a_end_, b_begin_, b_end_, length_;
     std::vector<uint8_t> strand_;
 
-    std::vector<Node> nodes_;
-    std::vector<Edge> edges_;
+    AssemblyGraph graph_;
 };
 
 }  // namespace rala

@@ -25,10 +25,57 @@ def _edges_from_csv(path):
     return sorted(out)
 
 
-def test_cli_debug_csv_and_preconstruct(tmp_path):
+def _read_fasta(path):
+    names, seqs = [], []
+    for line in open(path, "rb"):
+        line = line.rstrip(b"\n")
+        if line.startswith(b">"):
+            names.append(line[1:].split()[0])
+            seqs.append(b"")
+        else:
+            seqs[-1] += line
+    return names, seqs
+
+
+def _expected_layout(o, nodes, post, fa):
+    """oracle graph after transitive reduction, with the reads' trimmed sequences, as an oracle
+    layout object"""
+    import layout
+
+    names, seqs = _read_fasta(fa)
+    p = o.piles()
+    g = layout.oracle()
+    for r in nodes[::2]:
+        g.add_node_pair(int(r), names[r], seqs[r][int(p["begin"][r]): int(p["end"][r])])
+    for s_, d_, l_ in zip(post["src"], post["dst"], post["len"]):
+        g.add_edge(s_, d_, l_)
+    for i in np.nonzero(post["marked"])[0]:
+        if i % 2 == 0:
+            g.mark_edge(i)
+    g.remove_marked(False)
+    return g
+
+
+def _simplify(g):
+    """Graph::simplify after the transitive reduction (reference graph.cpp:647-684, no layout)"""
+    def loop():
+        while g.run("tips") + g.run("bubbles"):
+            pass
+    loop()
+    g.run("shrink", 42)
+    for _ in range(5):
+        g.run("long_edges")
+        g.run("tips")
+    loop()
+
+
+@pytest.mark.parametrize("n,genome,seed", [(600, 120_000, 17), (3000, 400_000, 5)])
+def test_cli_layout_to_contigs(tmp_path, n, genome, seed):
+    """rala <reads.fasta> <overlaps.paf>: construct on the GPU, simplify + unitigs on the host;
+    the debug CSV and the contig FASTA against the oracle pipeline + oracle layout."""
     build.build_host()
     exe = os.path.join(build.PKG, "host", "rala")
-    ds = Dataset(600, 120_000, 17)
+    ds = Dataset(n, genome, seed)
     fa = str(tmp_path / "reads.fasta")
     paf = str(tmp_path / "ovl.paf")
     ds.write_fasta(fa)
@@ -40,22 +87,54 @@ def test_cli_debug_csv_and_preconstruct(tmp_path):
     n_tr = o.remove_transitive_edges()
     post = o.edges()
     nodes = o.nodes()
+    want = _expected_layout(o, nodes, post, fa)
+    _simplify(want)
 
-    # full run with debug output: <prefix>.csv holds the graph after transitive reduction
     prefix = str(tmp_path / "dbg")
-    r = subprocess.run([exe, "-u", "-d", prefix, fa, paf], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
-    assert r.returncode == 0, r.stderr
-    assert "number of transitive edges = %d" % n_tr in r.stderr
-    assert "number of nodes = %d" % len(nodes) in r.stderr
-    assert "number of edges = %d" % len(pre["src"]) in r.stderr
+    r = subprocess.run([exe, "-u", "-d", prefix, fa, paf], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    err = r.stderr.decode()
+    assert r.returncode == 0, err
+    assert "number of transitive edges = %d" % n_tr in err
+    assert "number of nodes = %d" % len(nodes) in err
+    assert "number of edges = %d" % len(pre["src"]) in err
+    # <prefix>.csv: the graph after simplify
+    wn, we = want.dump()
     got = _edges_from_csv(prefix + ".csv")
-    keep = post["marked"] == 0
-    want = sorted((int(e), int(post["src"][e]), int(post["dst"][e]), int(post["len"][e]))
-                  for e in np.nonzero(keep)[0])
-    assert got == want
-    # -u prints every forward node as a contig record
-    assert r.stdout.count(">Ctg") == len(nodes) // 2
+    assert got == sorted((int(e), int(we["begin"][e]), int(we["end"][e]), int(we["length"][e]))
+                         for e in np.nonzero(we["alive"])[0])
+    # contigs: every forward node left after create_unitigs (-u keeps the short ones)
+    want.run("unitigs")
+    wn, _ = want.dump()
+    exp = []
+    for k in np.nonzero(wn["alive"])[0]:
+        if k % 2 == 0:
+            data = want.node_data(int(k))
+            exp.append((b">Ctg%d RC:i:%d LN:i:%d" % (len(exp), wn["n_seq"][k], len(data)), data))
+    lines = r.stdout.split(b"\n")
+    got_c = [(lines[i], lines[i + 1]) for i in range(0, len(lines) - 1, 2)]
+    assert got_c == exp
+    assert max(len(d) for _, d in exp) > 0.5 * genome          # most of the genome in one contig
+    # without -u only contigs of >= 6 reads and >= 10 kb remain (graph.cpp:2053-2054)
+    r2 = subprocess.run([exe, fa, paf], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r2.returncode == 0
+    kept = [(h, d) for h, d in exp if int(h.split(b"RC:i:")[1].split()[0]) >= 6 and len(d) >= 10000]
+    lines = r2.stdout.split(b"\n")
+    got_k = [lines[i + 1] for i in range(0, len(lines) - 1, 2)]
+    assert got_k == [d for _, d in kept]
 
+
+def test_cli_preconstruct(tmp_path):
+    build.build_host()
+    exe = os.path.join(build.PKG, "host", "rala")
+    ds = Dataset(600, 120_000, 17)
+    fa = str(tmp_path / "reads.fasta")
+    paf = str(tmp_path / "ovl.paf")
+    ds.write_fasta(fa)
+    ds.write_paf(paf)
+    o = Oracle(ds.read_len, ds.overlaps, n_threads=4)
+    assert o.construct() == 0
+    pre = o.edges()
+    nodes = o.nodes()
     # -p: uncontained reads that still have edges, trimmed to their valid regions
     r = subprocess.run([exe, "-p", fa, paf], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     assert r.returncode == 0, r.stderr

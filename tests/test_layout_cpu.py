@@ -1,0 +1,222 @@
+"""CPU: the clean-up stages after transitive reduction (tips, bubbles, unitigs, shrink; SURVEY.md
+section 8(f) rank 1) - product (index based) against the oracle restatement (pointer based, the
+reference's object model), on graphs the oracle pipeline builds from synthetic data and on
+hand-made shapes."""
+import numpy as np
+import pytest
+
+from rala_amd.synth import Dataset
+
+import layout
+import parity
+
+
+def _random_dna(rng, n):
+    return bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=n))
+
+
+def _both():
+    return layout.product(), layout.oracle()
+
+
+def _from_pipeline(n, g, seed):
+    """graph after construct + transitive reduction from the oracle pipeline, loaded into both"""
+    ds = Dataset(n, g, seed)
+    st = parity.oracle_stages(ds)
+    piles = st["piles2"]
+    rng = np.random.default_rng(seed)
+    graphs = _both()
+    for k, r in enumerate(st["nodes"][::2]):
+        data = _random_dna(rng, int(piles["end"][r] - piles["begin"][r]))
+        for gph in graphs:
+            gph.add_node_pair(int(r), b"read%d" % r, data)
+    e = st["edges"]
+    for gph in graphs:
+        for s, d, l in zip(e["src"], e["dst"], e["len"]):
+            gph.add_edge(s, d, l)
+        for i in np.nonzero(e["marked"])[0]:
+            if i % 2 == 0:                       # marks come in twin pairs
+                gph.mark_edge(i)
+        gph.remove_marked(False)
+    return graphs
+
+
+def _simplify(gph, log):
+    """Graph::simplify (reference graph.cpp:642-697) without the layout rounds"""
+    def loop():
+        while True:
+            t = gph.run("tips")
+            b = gph.run("bubbles")
+            log.append(("loop", t, b))
+            if t + b == 0:
+                break
+    loop()
+    log.append(("shrink", gph.run("shrink", 42)))
+    for _ in range(5):
+        log.append(("round", gph.run("long_edges"), gph.run("tips")))
+    loop()
+    log.append(("unitigs", gph.run("unitigs")))
+
+
+@pytest.mark.parametrize("n,g,seed", [(3000, 600_000, 21), (5000, 1_000_000, 7), (6000, 1_600_000, 19),
+                                      (4000, 400_000, 2)])
+def test_simplify_matches_oracle(n, g, seed):
+    prod, ora = _from_pipeline(n, g, seed)
+    layout.assert_same_graph(prod, ora, "after transitive reduction")
+    la, lb = [], []
+    _simplify(prod, la)
+    _simplify(ora, lb)
+    assert la == lb
+    layout.assert_same_graph(prod, ora, "after simplify")
+    nodes, _ = prod.dump()
+    assert nodes["alive"].sum() > 0
+    assert any(x[0] == "unitigs" and x[1] > 0 for x in la)
+
+
+@pytest.mark.parametrize("op,arg", [("tips", 0), ("bubbles", 0), ("unitigs", 0), ("shrink", 3), ("shrink", 42)])
+@pytest.mark.parametrize("n,g,seed", [(3000, 600_000, 21), (2000, 1_200_000, 33)])
+def test_single_stage_matches_oracle(n, g, seed, op, arg):
+    prod, ora = _from_pipeline(n, g, seed)
+    assert prod.run(op, arg) == ora.run(op, arg)
+    layout.assert_same_graph(prod, ora, op)
+
+
+def _chain(graphs, rng, n_reads, step=3000, length=10000, first_seq=0):
+    """a linear chain of reads, each overlapping the next: nodes 2k (forward), 2k + 1 (reverse)"""
+    base = None
+    for gph in graphs:
+        nodes0 = gph.dump()[0]["alive"].shape[0]
+        edges0 = gph.dump()[1]["alive"].shape[0]
+        r = np.random.default_rng(1234 + first_seq)
+        for k in range(n_reads):
+            gph.add_node_pair(first_seq + k, b"r%d" % (first_seq + k), _random_dna(r, length))
+        for k in range(n_reads - 1):
+            a, b = nodes0 + 2 * k, nodes0 + 2 * (k + 1)
+            gph.add_edge(a, b, step)               # forward strand
+            gph.add_edge(b + 1, a + 1, step)       # its twin on the reverse strand
+        base = (nodes0, edges0)
+    return base
+
+
+def test_hand_made_shapes():
+    rng = np.random.default_rng(0)
+    # 1. plain chain: one unitig pair, 3000 * 11 + 10000 bases
+    graphs = _both()
+    _chain(graphs, rng, 12)
+    for gph in graphs:
+        assert gph.run("unitigs") == 1
+    layout.assert_same_graph(*graphs, "chain")
+    nodes, edges = graphs[0].dump()
+    assert nodes["alive"].sum() == 2 and nodes["length"][nodes["alive"] == 1].tolist() == [43000, 43000]
+    assert nodes["n_seq"][nodes["alive"] == 1].tolist() == [12, 12] and edges["alive"].sum() == 0
+
+    # 2. chain with a short side branch joining back in (a tip): the tip goes, the chain stays
+    graphs = _both()
+    n0, _ = _chain(graphs, rng, 20)
+    t0, _ = _chain(graphs, rng, 3, first_seq=100)
+    for gph in graphs:
+        gph.add_edge(t0 + 4, n0 + 2 * 10, 2500)          # tip end -> chain node 10 (forward)
+        gph.add_edge(n0 + 2 * 10 + 1, t0 + 5, 2500)
+        assert gph.run("tips") == 1
+    layout.assert_same_graph(*graphs, "tip")
+    nodes, _ = graphs[0].dump()
+    assert nodes["alive"][t0: t0 + 6].sum() == 0 and nodes["alive"][n0: n0 + 40].all()
+
+    # 3. a bubble: two parallel paths between chain nodes 5 and 9, the weaker one (fewer reads) goes
+    graphs = _both()
+    n0, _ = _chain(graphs, rng, 16)
+    b0, _ = _chain(graphs, rng, 2, first_seq=200)
+    for gph in graphs:
+        gph.add_edge(n0 + 2 * 5, b0, 3100)
+        gph.add_edge(b0 + 1, n0 + 2 * 5 + 1, 3100)
+        gph.add_edge(b0 + 2, n0 + 2 * 9, 3100)
+        gph.add_edge(n0 + 2 * 9 + 1, b0 + 3, 3100)
+        assert gph.run("bubbles") >= 1
+    layout.assert_same_graph(*graphs, "bubble")
+    nodes, _ = graphs[0].dump()
+    assert nodes["alive"][b0: b0 + 4].sum() == 0
+
+    # 4. shrink: only chains of at least 2 * eps + 2 nodes are contracted, eps nodes stay at each end
+    graphs = _both()
+    _chain(graphs, rng, 30)
+    for gph in graphs:
+        assert gph.run("shrink", 20) == 0
+        assert gph.run("shrink", 5) == 1
+    layout.assert_same_graph(*graphs, "shrink")
+    nodes, _ = graphs[0].dump()
+    assert nodes["alive"].sum() == 2 * (5 + 5 + 1)
+
+
+def _random_graph(graphs, seed):
+    """a noisy assembly graph: a backbone chain, skip edges (transitive-looking shortcuts),
+    short dead-end branches and parallel detours, all with consistent twins"""
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(30, 120))
+    lens = rng.integers(4000, 12000, size=n)
+    for gph in graphs:
+        r = np.random.default_rng(seed)
+        for k in range(n):
+            gph.add_node_pair(k, b"r%d" % k, _random_dna(r, int(lens[k])))
+    edges = []
+    backbone = int(n * 0.7)
+    for k in range(backbone - 1):
+        if rng.random() < 0.03:
+            continue                                  # a gap: two contigs
+        edges.append((k, k + 1, int(rng.integers(500, 3500))))
+    for _ in range(int(rng.integers(0, 8))):          # shortcuts over 2-3 nodes
+        k = int(rng.integers(0, max(1, backbone - 4)))
+        edges.append((k, k + int(rng.integers(2, 4)), int(rng.integers(3000, 3900))))
+    extra = list(range(backbone, n))
+    rng.shuffle(extra)
+    while extra:
+        m = min(len(extra), int(rng.integers(1, 5)))
+        branch, extra = extra[:m], extra[m:]
+        a = int(rng.integers(0, backbone))
+        kind = rng.random()
+        for x, y in zip(branch, branch[1:]):
+            edges.append((x, y, int(rng.integers(500, 3500))))
+        if kind < 0.4:                                # dead end hanging off the backbone
+            edges.append((a, branch[0], int(rng.integers(500, 3500))))
+        elif kind < 0.7:                              # branch that joins the backbone (a tip)
+            edges.append((branch[-1], a, int(rng.integers(500, 3500))))
+        else:                                         # detour around a stretch of the backbone
+            b = min(backbone - 1, a + int(rng.integers(2, 7)))
+            if b > a:
+                edges.append((a, branch[0], int(rng.integers(500, 3500))))
+                edges.append((branch[-1], b, int(rng.integers(500, 3500))))
+    for gph in graphs:
+        for a, b, l in edges:
+            gph.add_edge(2 * a, 2 * b, l)
+            gph.add_edge(2 * b + 1, 2 * a + 1, min(l, int(lens[b]) - 1))
+    return n, len(edges)
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_random_graphs(seed):
+    graphs = _both()
+    _random_graph(graphs, seed)
+    la, lb = [], []
+    _simplify(graphs[0], la)
+    _simplify(graphs[1], lb)
+    assert la == lb
+    layout.assert_same_graph(*graphs, "random graph %d" % seed)
+
+
+def test_random_graphs_exercise_every_stage():
+    tips = bubbles = shrunk = unitigs = 0
+    for seed in range(60):
+        g = layout.product()
+        _random_graph((g,), seed)
+        log = []
+        _simplify(g, log)
+        for x in log:
+            if x[0] == "loop":
+                tips += x[1]
+                bubbles += x[2]
+            elif x[0] == "round":
+                tips += x[2]
+            elif x[0] == "shrink":
+                shrunk += x[1]
+            else:
+                unitigs += x[1]
+    assert tips > 0 and bubbles > 0 and unitigs > 0, (tips, bubbles, shrunk, unitigs)
