@@ -74,16 +74,16 @@ def build_host(force=False):
         return None
     out = os.path.join(d, "librala.so")
     deps = srcs + _glob(d, (".hpp", ".h")) + _glob(os.path.join(ROOT, "include"), (".h",))
-    lib_srcs = [s for s in srcs if not s.endswith("main.cpp")]
+    lib_srcs = [s for s in srcs if not s.endswith("main.cpp") and not s.endswith("_capi.cpp")]
     if force or _stale(out, deps):
         hip = build_hip()
         _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I" + os.path.join(ROOT, "include"),
               "-I" + d, "-o", out] + lib_srcs + [hip, "-Wl,-rpath," + os.path.dirname(hip), "-lz"])
-    # the clean-up stages alone (no HIP dependency), for the CPU test-suite
+    # the clean-up stages and the readers alone (no HIP dependency), for the CPU test-suite
     ag = os.path.join(d, "libassembly_graph.so")
-    ag_srcs = [os.path.join(d, "assembly_graph.cpp"), os.path.join(d, "assembly_graph_capi.cpp")]
-    if force or _stale(ag, ag_srcs + [os.path.join(d, "assembly_graph.hpp")]):
-        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I" + d, "-o", ag] + ag_srcs)
+    ag_srcs = [os.path.join(d, f) for f in ("assembly_graph.cpp", "assembly_graph_capi.cpp", "io.cpp", "io_capi.cpp")]
+    if force or _stale(ag, ag_srcs + [os.path.join(d, "assembly_graph.hpp"), os.path.join(d, "io.hpp")]):
+        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I" + d, "-o", ag] + ag_srcs + ["-lz"])
     exe = os.path.join(d, "rala")
     main = os.path.join(d, "main.cpp")
     if os.path.exists(main) and (force or _stale(exe, deps)):

@@ -1,0 +1,52 @@
+// End-to-end figure of SURVEY.md section 8(d): overlaps/s from PAF text to the transitively
+// reduced graph (multi-threaded ingest -> host-to-device upload -> rala_hip_initialize /
+// _construct / _remove_transitive_edges), sequence loading excluded like in the metric's
+// definition.  Read names are "r<i>" (what rala_amd.synth writes).
+#include <stdint.h>
+#include <stdio.h>
+
+#include <chrono>
+#include <string>
+#include <vector>
+
+#include "io.hpp"
+#include "rala_hip.h"
+
+extern "C" int rala_e2e_from_paf(const char* paf_path, const uint32_t* read_len, uint64_t n_reads, uint32_t num_threads,
+                                 double* ms_parse, double* ms_upload, double* ms_device, uint64_t* n_overlaps,
+                                 uint32_t* n_transitive) {
+    using clock = std::chrono::steady_clock;
+    auto ms = [](clock::time_point a, clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    std::vector<std::string> names(n_reads);
+    for (uint64_t i = 0; i < n_reads; ++i) names[i] = "r" + std::to_string(i);
+    std::vector<uint32_t> len(read_len, read_len + n_reads);
+    rala::io::NameTable table;
+    table.build(names);
+    rala_hip_ctx* ctx = nullptr;
+    if (rala_hip_create(0, &ctx) != RALA_HIP_OK) return -1;
+    int rc = rala_hip_set_reads(ctx, read_len, n_reads);
+    if (rc != RALA_HIP_OK) { rala_hip_destroy(ctx); return rc; }
+
+    const auto t0 = clock::now();
+    rala::io::OverlapColumns c;
+    int64_t bad = -1;
+    if (!rala::io::read_paf_parallel(paf_path, table, len, true, num_threads, c, &bad) || bad >= 0) {
+        rala_hip_destroy(ctx);
+        return -2;
+    }
+    const auto t1 = clock::now();
+    rala_hip_overlaps soa = {c.a_id.data(), c.b_id.data(), c.a_begin.data(), c.a_end.data(), c.b_begin.data(),
+                             c.b_end.data(), c.length.data(), c.strand.data()};
+    rc = rala_hip_set_overlaps(ctx, &soa, c.size(), RALA_HIP_MEM_HOST);
+    const auto t2 = clock::now();
+    if (rc == RALA_HIP_OK) rc = rala_hip_initialize(ctx);
+    if (rc == RALA_HIP_OK) rc = rala_hip_construct(ctx, nullptr, 0);
+    uint32_t n_tr = 0;
+    if (rc == RALA_HIP_OK) rc = rala_hip_remove_transitive_edges(ctx, &n_tr);
+    const auto t3 = clock::now();
+    if (rc != RALA_HIP_OK) fprintf(stderr, "[rala_e2e_from_paf] error: %s\n", rala_hip_last_error(ctx));
+    *ms_parse = ms(t0, t1); *ms_upload = ms(t1, t2); *ms_device = ms(t2, t3);
+    *n_overlaps = c.size(); *n_transitive = n_tr;
+    rala_hip_destroy(ctx);
+    return rc;
+}

@@ -80,14 +80,11 @@ bool read_sequences(const std::string& path, const io::SequenceSink& sink) {
     return io::read_fasta(path, sink);
 }
 
-struct Columns {
-    std::vector<uint32_t>&a_id, &b_id, &a_begin, &a_end, &b_begin, &b_end, &length;
-    std::vector<uint8_t>& strand;
-};
-
-// one pass over an overlap file into binary columns (the reference parses twice, graph.cpp:328,443)
+// one pass over an overlap file into binary columns (the reference parses twice, graph.cpp:328,443);
+// uncompressed PAF goes through the multi-threaded reader
 void read_overlaps(const std::string& path, const std::unordered_map<std::string, uint64_t>& name_to_id,
-    const std::vector<uint32_t>& read_len, bool check_target_length, Columns c) {
+    const io::NameTable& name_table, const std::vector<uint32_t>& read_len, bool check_target_length,
+    uint32_t num_threads, io::OverlapColumns& c) {
     auto push = [&](uint32_t a, uint32_t b, uint32_t ab, uint32_t ae, uint32_t bb, uint32_t be, uint32_t len,
                     uint32_t strand) {
         c.a_id.push_back(a); c.b_id.push_back(b);
@@ -101,7 +98,11 @@ void read_overlaps(const std::string& path, const std::unordered_map<std::string
         exit(1);
     };
     bool ok;
-    if (io::has_suffix(path, ".mhap") || io::has_suffix(path, ".mhap.gz")) {
+    if (io::has_suffix(path, ".paf")) {
+        int64_t bad = -1;
+        ok = io::read_paf_parallel(path, name_table, read_len, check_target_length, num_threads, c, &bad);
+        if (ok && bad >= 0) length_error((uint64_t)bad);
+    } else if (io::has_suffix(path, ".mhap") || io::has_suffix(path, ".mhap.gz")) {
         ok = io::read_mhap(path, [&](const io::MhapRecord& r) {
             const uint64_t a = r.a_id - 1, b = r.b_id - 1;
             const uint32_t ia = a < read_len.size() ? (uint32_t)a : RALA_HIP_NO_READ;
@@ -148,11 +149,12 @@ void Graph::initialize() {
     timer("[rala::Graph::initialize] loaded sequences");
     timer();
     check(ctx_, rala_hip_set_reads(ctx_, read_len_.data(), read_len_.size()), "initialize");
-    Columns c = {a_id_, b_id_, a_begin_, a_end_, b_begin_, b_end_, length_, strand_};
-    read_overlaps(overlaps_path_, name_to_id_, read_len_, true, c);
-    rala_hip_overlaps soa = {a_id_.data(), b_id_.data(), a_begin_.data(), a_end_.data(), b_begin_.data(),
-                             b_end_.data(), length_.data(), strand_.data()};
-    check(ctx_, rala_hip_set_overlaps(ctx_, &soa, a_id_.size(), RALA_HIP_MEM_HOST), "initialize");
+    name_table_.build(names_);
+    read_overlaps(overlaps_path_, name_to_id_, name_table_, read_len_, true, num_threads_, overlaps_);
+    rala_hip_overlaps soa = {overlaps_.a_id.data(), overlaps_.b_id.data(), overlaps_.a_begin.data(),
+                             overlaps_.a_end.data(), overlaps_.b_begin.data(), overlaps_.b_end.data(),
+                             overlaps_.length.data(), overlaps_.strand.data()};
+    check(ctx_, rala_hip_set_overlaps(ctx_, &soa, overlaps_.size(), RALA_HIP_MEM_HOST), "initialize");
     timer("[rala::Graph::initialize] loaded overlaps");
     timer();
     const int rc = rala_hip_initialize(ctx_);
@@ -176,8 +178,7 @@ void Graph::construct(const std::string& sensitive_overlaps_path) {
     initialize();
 
     StageTimer timer;
-    std::vector<uint32_t> s_cols[7];
-    std::vector<uint8_t> s_strand;
+    io::OverlapColumns s_cols;
     rala_hip_overlaps sens = {};
     uint64_t n_sens = 0;
     if (!sensitive_overlaps_path.empty()) {
@@ -188,12 +189,11 @@ void Graph::construct(const std::string& sensitive_overlaps_path) {
                 ".mhap, .mhap.gz, .paf, .paf.gz)!\n", sensitive_overlaps_path.c_str());
             exit(1);
         }
-        Columns c = {s_cols[0], s_cols[1], s_cols[2], s_cols[3], s_cols[4], s_cols[5], s_cols[6], s_strand};
-        read_overlaps(sensitive_overlaps_path, name_to_id_, read_len_, false, c);
-        sens.a_id = s_cols[0].data(); sens.b_id = s_cols[1].data(); sens.a_begin = s_cols[2].data();
-        sens.a_end = s_cols[3].data(); sens.b_begin = s_cols[4].data(); sens.b_end = s_cols[5].data();
-        sens.length = s_cols[6].data(); sens.strand = s_strand.data();
-        n_sens = s_cols[0].size();
+        read_overlaps(sensitive_overlaps_path, name_to_id_, name_table_, read_len_, false, num_threads_, s_cols);
+        sens.a_id = s_cols.a_id.data(); sens.b_id = s_cols.b_id.data(); sens.a_begin = s_cols.a_begin.data();
+        sens.a_end = s_cols.a_end.data(); sens.b_begin = s_cols.b_begin.data(); sens.b_end = s_cols.b_end.data();
+        sens.length = s_cols.length.data(); sens.strand = s_cols.strand.data();
+        n_sens = s_cols.size();
     }
     check(ctx_, rala_hip_construct(ctx_, n_sens ? &sens : nullptr, n_sens), "construct");
     timer("[rala::Graph::construct] loaded overlaps + [rala::Graph::preprocess]");

@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "assembly_graph.hpp"
+#include "io.hpp"
 
 struct rala_hip_ctx;
 
@@ -74,9 +75,8 @@ private:
     std::vector<std::string> names_;
     std::vector<uint32_t> read_len_;
     std::vector<std::unique_ptr<Pile>> piles_;
-    // overlap columns, parsed once
-    std::vector<uint32_t> a_id_, b_id_, a_begin_, a_end_, b_begin_, b_end_, length_;
-    std::vector<uint8_t> strand_;
+    io::NameTable name_table_;
+    io::OverlapColumns overlaps_;       // parsed once
 
     AssemblyGraph graph_;
 };

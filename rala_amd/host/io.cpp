@@ -162,3 +162,186 @@ bool read_mhap(const std::string& path, const std::function<void(const MhapRecor
 
 }  // namespace io
 }  // namespace rala
+
+// ---- multi-threaded PAF ingest -----------------------------------------------------------------
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <thread>
+
+namespace rala {
+namespace io {
+
+namespace {
+
+inline uint64_t hash_bytes(const char* p, size_t n) {
+    uint64_t h = 1469598103934665603ull;
+    for (size_t i = 0; i < n; ++i) { h ^= (unsigned char)p[i]; h *= 1099511628211ull; }
+    return h ^ (h >> 29);
+}
+
+inline const char* parse_u32(const char* p, const char* e, uint32_t& v) {
+    uint64_t x = 0;
+    while (p < e && *p >= '0' && *p <= '9') { x = x * 10 + (uint64_t)(*p - '0'); ++p; }
+    v = (uint32_t)x;
+    return p;
+}
+
+struct Chunk {
+    OverlapColumns cols;
+    int64_t error_read = -1;        // first line of this chunk with a length mismatch
+};
+
+// one line [p, e) (no newline); returns false if it is not a 12-column record
+inline bool parse_paf_line(const char* p, const char* e, const NameTable& names, const std::vector<uint32_t>& read_len,
+                           bool check_target_length, Chunk& c) {
+    const char* f[13];
+    int nf = 0;
+    f[nf++] = p;
+    for (const char* q = p; q < e && nf < 13; ++q) {
+        if (*q == '\t') f[nf++] = q + 1;
+    }
+    if (nf < 12) return false;
+    auto token_end = [&](int k) {                       // names are cut at the first whitespace
+        const char* end = k + 1 < nf ? f[k + 1] - 1 : e;
+        const char* q = f[k];
+        while (q < end && *q != ' ' && *q != '\t') ++q;
+        return q;
+    };
+    uint32_t ql, qb, qe, tl, tb, te, ol;
+    parse_u32(f[1], e, ql); parse_u32(f[2], e, qb); parse_u32(f[3], e, qe);
+    parse_u32(f[6], e, tl); parse_u32(f[7], e, tb); parse_u32(f[8], e, te);
+    parse_u32(f[10], e, ol);
+    const char orientation = f[4] < e && *f[4] != '\t' ? *f[4] : '+';
+    const uint64_t a = names.find(f[0], (size_t)(token_end(0) - f[0]));
+    const uint64_t b = names.find(f[5], (size_t)(token_end(5) - f[5]));
+    const uint32_t ia = a == ~0ull ? 0xFFFFFFFFu : (uint32_t)a;
+    const uint32_t ib = b == ~0ull ? 0xFFFFFFFFu : (uint32_t)b;
+    if (c.error_read < 0) {
+        if (ia != 0xFFFFFFFFu && ql != read_len[ia]) c.error_read = ia;
+        else if (check_target_length && ia != 0xFFFFFFFFu && ib != 0xFFFFFFFFu && tl != read_len[ib]) c.error_read = ib;
+    }
+    c.cols.a_id.push_back(ia); c.cols.b_id.push_back(ib);
+    c.cols.a_begin.push_back(qb); c.cols.a_end.push_back(qe);
+    c.cols.b_begin.push_back(tb); c.cols.b_end.push_back(te);
+    c.cols.length.push_back(ol);
+    c.cols.strand.push_back(orientation == '+' ? 0 : 1);
+    return true;
+}
+
+}  // namespace
+
+void NameTable::build(const std::vector<std::string>& names) {
+    uint64_t cap = 16;
+    while (cap < 2 * names.size() + 2) cap <<= 1;
+    mask_ = cap - 1;
+    slot_.assign(cap, 0);
+    off_.resize(names.size()); len_.resize(names.size());
+    arena_.clear();
+    for (size_t i = 0; i < names.size(); ++i) {
+        off_[i] = (uint32_t)arena_.size();
+        len_[i] = (uint32_t)names[i].size();
+        arena_ += names[i];
+    }
+    // a later duplicate name replaces an earlier one, like unordered_map::operator[] in the
+    // reference (src/graph.cpp:262)
+    for (size_t i = 0; i < names.size(); ++i) {
+        uint64_t h = hash_bytes(names[i].data(), names[i].size()) & mask_;
+        for (;; h = (h + 1) & mask_) {
+            if (slot_[h] == 0) { slot_[h] = i + 1; break; }
+            const uint64_t j = slot_[h] - 1;
+            if (len_[j] == names[i].size() && memcmp(arena_.data() + off_[j], names[i].data(), len_[j]) == 0) {
+                slot_[h] = i + 1;
+                break;
+            }
+        }
+    }
+}
+
+uint64_t NameTable::find(const char* p, size_t n) const {
+    if (slot_.empty()) return ~0ull;
+    for (uint64_t h = hash_bytes(p, n) & mask_;; h = (h + 1) & mask_) {
+        if (slot_[h] == 0) return ~0ull;
+        const uint64_t j = slot_[h] - 1;
+        if (len_[j] == n && memcmp(arena_.data() + off_[j], p, n) == 0) return j;
+    }
+}
+
+bool read_paf_parallel(const std::string& path, const NameTable& names, const std::vector<uint32_t>& read_len,
+    bool check_target_length, uint32_t num_threads, OverlapColumns& out, int64_t* length_error) {
+    if (length_error) *length_error = -1;
+    const int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) return false;
+    struct stat st;
+    if (fstat(fd, &st) != 0) { close(fd); return false; }
+    const size_t size = (size_t)st.st_size;
+    if (size == 0) { close(fd); return true; }
+    void* map = mmap(nullptr, size, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
+    close(fd);
+    if (map == MAP_FAILED) return false;
+    madvise(map, size, MADV_SEQUENTIAL);
+    const char* base = (const char*)map;
+
+    const uint32_t T = (uint32_t)std::max<size_t>(1, std::min<size_t>(std::max(1u, num_threads), size / (1 << 20) + 1));
+    std::vector<Chunk> chunks(T);
+    auto work = [&](uint32_t t) {
+        size_t lo = size * t / T, hi = size * (t + 1) / T;
+        // a chunk owns the lines that start inside it
+        if (t > 0) {
+            const char* nl = (const char*)memchr(base + lo - 1, '\n', size - (lo - 1));
+            lo = nl ? (size_t)(nl - base) + 1 : size;
+        }
+        Chunk& c = chunks[t];
+        const size_t guess = (hi > lo ? hi - lo : 0) / 48 + 16;      // a PAF line is rarely shorter
+        c.cols.a_id.reserve(guess); c.cols.b_id.reserve(guess); c.cols.a_begin.reserve(guess);
+        c.cols.a_end.reserve(guess); c.cols.b_begin.reserve(guess); c.cols.b_end.reserve(guess);
+        c.cols.length.reserve(guess); c.cols.strand.reserve(guess);
+        size_t p = lo;
+        while (p < hi) {
+            const char* nl = (const char*)memchr(base + p, '\n', size - p);
+            size_t e = nl ? (size_t)(nl - base) : size;
+            size_t le = e;
+            if (le > p && base[le - 1] == '\r') --le;
+            if (le > p) parse_paf_line(base + p, base + le, names, read_len, check_target_length, c);
+            p = e + 1;
+        }
+    };
+    std::vector<std::thread> threads;
+    for (uint32_t t = 1; t < T; ++t) threads.emplace_back(work, t);
+    work(0);
+    for (auto& th : threads) th.join();
+    munmap(map, size);
+
+    size_t total = out.size();
+    for (const auto& c : chunks) total += c.cols.size();
+    std::vector<size_t> at(T);
+    size_t run = out.size();
+    for (uint32_t t = 0; t < T; ++t) { at[t] = run; run += chunks[t].cols.size(); }
+    out.a_id.resize(total); out.b_id.resize(total); out.a_begin.resize(total); out.a_end.resize(total);
+    out.b_begin.resize(total); out.b_end.resize(total); out.length.resize(total); out.strand.resize(total);
+    auto gather = [&](uint32_t t) {
+        const OverlapColumns& c = chunks[t].cols;
+        const size_t n = c.size();
+        if (!n) return;
+        memcpy(out.a_id.data() + at[t], c.a_id.data(), n * 4); memcpy(out.b_id.data() + at[t], c.b_id.data(), n * 4);
+        memcpy(out.a_begin.data() + at[t], c.a_begin.data(), n * 4); memcpy(out.a_end.data() + at[t], c.a_end.data(), n * 4);
+        memcpy(out.b_begin.data() + at[t], c.b_begin.data(), n * 4); memcpy(out.b_end.data() + at[t], c.b_end.data(), n * 4);
+        memcpy(out.length.data() + at[t], c.length.data(), n * 4); memcpy(out.strand.data() + at[t], c.strand.data(), n);
+    };
+    threads.clear();
+    for (uint32_t t = 1; t < T; ++t) threads.emplace_back(gather, t);
+    gather(0);
+    for (auto& th : threads) th.join();
+    if (length_error) {
+        for (const auto& c : chunks) {
+            if (c.error_read >= 0) { *length_error = c.error_read; break; }
+        }
+    }
+    return true;
+}
+
+}  // namespace io
+}  // namespace rala

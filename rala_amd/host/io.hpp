@@ -6,6 +6,7 @@
 #include <stdint.h>
 #include <functional>
 #include <string>
+#include <vector>
 
 namespace rala {
 namespace io {
@@ -29,6 +30,36 @@ bool read_paf(const std::string& path, const std::function<void(const PafRecord&
 bool read_mhap(const std::string& path, const std::function<void(const MhapRecord&)>& sink);
 
 bool has_suffix(const std::string& src, const std::string& suffix);
+
+// ---- one-pass, multi-threaded ingest of an uncompressed PAF file into binary columns -------
+// (the reference tokenises every line into a heap Overlap twice,
+// src/graph.cpp:328,443)
+
+// read name -> id, looked up straight from the bytes of the file (no std::string per field)
+class NameTable {
+public:
+    void build(const std::vector<std::string>& names);
+    // id of the name [p, p + n), or ~0ull
+    uint64_t find(const char* p, size_t n) const;
+private:
+    std::vector<uint64_t> slot_;        // name index + 1, 0 = empty
+    std::vector<uint32_t> off_, len_;
+    std::string arena_;
+    uint64_t mask_ = 0;
+};
+
+struct OverlapColumns {
+    std::vector<uint32_t> a_id, b_id, a_begin, a_end, b_begin, b_end, length;
+    std::vector<uint8_t> strand;
+    size_t size() const { return a_id.size(); }
+};
+
+// Appends the records of `path` to `out` in file order.  Ids of unknown names are 0xFFFFFFFF.
+// Same checks as Overlap::transmute (src/overlap.cpp:36-82): a PAF length that differs from
+// the sequence's is fatal - returned as the offending read id in *length_error (the first such
+// line in file order), the caller prints the reference's message.  false = cannot open / map.
+bool read_paf_parallel(const std::string& path, const NameTable& names, const std::vector<uint32_t>& read_len,
+    bool check_target_length, uint32_t num_threads, OverlapColumns& out, int64_t* length_error);
 
 }  // namespace io
 }  // namespace rala
