@@ -126,3 +126,79 @@ def test_long_reads(hip_ctx_factory, factor):
     ctx.construct()
     parity.check_construct(ctx, st)
     parity.check_tr(ctx, st)
+
+
+def _shuffled_with_duplicates(ds, seed):
+    """same data set, but every query's run of overlaps is shuffled and ~3 % of the records are
+    repeated inside their run with other lengths (the general case of remove_duplicate_overlaps,
+    reference graph.cpp:273-307), ~1 % of the target names do not resolve, a few self overlaps"""
+    from rala_amd.synth import Overlaps, FIELDS
+
+    rng = np.random.default_rng(seed)
+    ov = ds.overlaps
+    n = len(ov)
+    dup = np.nonzero(rng.random(n) < 0.03)[0]
+    idx = np.concatenate([np.arange(n), dup, dup[: len(dup) // 3]])
+    run_key = ov.a_id[idx].astype(np.int64)
+    order = np.lexsort((rng.random(len(idx)), run_key))          # group by query, random inside
+    idx = idx[order]
+    kw = {f: getattr(ov, f)[idx].copy() for f in FIELDS}
+    strand = ov.strand[idx].copy()
+    extra = np.arange(len(idx)) >= 0
+    bump = rng.random(len(idx)) < 0.05
+    kw["length"][bump] += rng.integers(0, 3, size=int(bump.sum())).astype(np.uint32)     # ties and near ties
+    bad = rng.random(len(idx)) < 0.01
+    kw["b_id"][bad] = 0xFFFFFFFF
+    selfo = rng.random(len(idx)) < 0.002
+    kw["b_id"][selfo] = kw["a_id"][selfo]
+    kw["b_begin"][selfo] = kw["a_begin"][selfo]; kw["b_end"][selfo] = kw["a_end"][selfo]
+
+    class _D:
+        pass
+    d = _D()
+    d.overlaps = Overlaps(strand=strand, **kw)
+    d.read_len = ds.read_len
+    d.n_reads = ds.n_reads
+    return d
+
+
+@pytest.mark.parametrize("n,g,seed", [(3000, 600_000, 21), (2000, 1_200_000, 33)])
+def test_unordered_runs_duplicates_unresolved(hip_ctx_factory, n, g, seed):
+    ds = _shuffled_with_duplicates(Dataset(n, g, seed), seed)
+    st = parity.oracle_stages(ds)
+    assert st["valid"].sum() < len(st["valid"])                  # duplicates were found
+    ctx = hip_ctx_factory()
+    ctx.set_reads(ds.read_len)
+    ctx.set_overlaps(ds.overlaps)
+    ctx.initialize()
+    parity.check_initialize(ctx, st, ds)
+    ctx.construct()
+    parity.check_construct(ctx, st)
+    parity.check_tr(ctx, st)
+
+
+def test_degenerate_inputs(hip_ctx_factory):
+    from rala_amd import hip
+    from rala_amd.synth import Overlaps, FIELDS
+
+    # no overlaps at all: every read is filtered ("filtered all sequences", graph.cpp:418-421)
+    ctx = hip_ctx_factory()
+    ctx.set_reads(np.array([5000, 7000, 9000], dtype=np.uint32))
+    empty = Overlaps(strand=np.zeros(0, np.uint8), **{f: np.zeros(0, np.uint32) for f in FIELDS})
+    ctx.set_overlaps(empty)
+    with pytest.raises(hip.RalaHipError) as e:
+        ctx.initialize()
+    assert e.value.code == -4
+    # one read, overlaps that only name unknown reads
+    ctx = hip_ctx_factory()
+    ctx.set_reads(np.array([8000], dtype=np.uint32))
+    kw = {f: np.array([0xFFFFFFFF, 0], dtype=np.uint32) if f in ("a_id", "b_id") else np.array([100, 100], dtype=np.uint32)
+          for f in FIELDS}
+    kw["a_end"] = kw["b_end"] = np.array([4000, 4000], dtype=np.uint32)
+    kw["length"] = np.array([3900, 3900], dtype=np.uint32)
+    kw["b_id"] = np.array([0, 0xFFFFFFFF], dtype=np.uint32)
+    ctx.set_overlaps(Overlaps(strand=np.zeros(2, np.uint8), **kw))
+    with pytest.raises(hip.RalaHipError) as e:
+        ctx.initialize()
+    assert e.value.code == -4
+    assert ctx.valid().tolist() == [0, 0]
