@@ -24,6 +24,8 @@
 // Reference behaviour followed: rvaser/rala src/pile.cpp:64-455.
 #include <hip/hip_runtime.h>
 
+#include <stdlib.h>
+
 #include "device_utils.h"
 #include "geom.h"
 #include "kernels.h"
@@ -35,7 +37,6 @@ namespace {
 
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr uint16_t kNone16 = 0xFFFFu;
-constexpr uint32_t kIdx = 512;         // entries of the position -> run index
 
 __device__ __forceinline__ void wave_sync() { __syncthreads(); }   // workgroup == one wavefront
 
@@ -229,12 +230,18 @@ __device__ __forceinline__ void load_sort_store(const uint32_t* __restrict__ gev
 template <uint32_t kCap>
 struct Layout {
     // list capacities: a read that needs more goes to the next kernel of the chain
-    static constexpr uint32_t kMaxReg = kCap <= 512 ? 32 : 64;   // regions per (q, kind) list
-    static constexpr uint32_t kMaxRaw = kCap <= 512 ? 16 : 32;   // pits / hills before the merge
+    static constexpr uint32_t kMaxReg = kCap <= 512 ? 16 : 64;   // regions per (q, kind) list
+    static constexpr uint32_t kMaxRaw = kCap <= 512 ? 8 : 32;    // pits / hills before the merge
     static constexpr uint32_t kArr = kCap + 4;                  // entries per run-indexed array
-    // X: events (sort) -> group counts -> histograms -> the four uint16 interval arrays
+    static constexpr uint32_t kIdx = kCap <= 512 ? 256 : 512;   // entries of the position -> run index
+    // runs that survive the slope filter (k and four uint16 offsets each) + block maxima
+    static constexpr uint32_t kSurv = kCap <= 512 ? 192 : kArr;
+    static constexpr uint32_t kBm8 = kArr / 8 + 8;
+    static constexpr uint32_t kSlopeWords = (5 * kSurv + 1) / 2 + kBm8;
+    // X: events (sort) -> bitmap + prefix -> group counts -> histograms -> slope survivors
     static constexpr uint32_t X = 0;
-    static constexpr uint32_t kX = 2 * kArr > 768 ? 2 * kArr : 768;
+    static constexpr uint32_t kXmin = kCap > 768 ? kCap : 768;
+    static constexpr uint32_t kX = kSlopeWords > kXmin ? kSlopeWords : kXmin;
     static constexpr uint32_t RS = X + kX;                      // run starts (+ sentinel)
     static constexpr uint32_t RV = RS + kArr;                   // run values, uint16 (kArr / 2 words)
     static constexpr uint32_t IDX = RV + kArr / 2;              // kIdx uint16
@@ -247,13 +254,13 @@ struct Layout {
     static constexpr uint32_t CAND = GONE + (2 * kMaxRaw) / 4;  // kMaxRaw hill candidates (i << 16 | j)
     static constexpr uint32_t SEL = CAND + kMaxRaw;             // 16 words
     static constexpr uint32_t WORDS = SEL + 16;
-    static_assert(kX >= kCap && kX >= kIdx, "shared region too small");
+    static_assert(kX >= kCap && kX >= kIdx && kX >= 768, "shared region too small");
 };
 
 }  // namespace
 
 template <uint32_t kCap>
-__global__ __launch_bounds__(64) void pile_runs_kernel(PileArgs A, uint32_t* overflow_list, uint32_t* overflow_count) {
+__global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* overflow_list, uint32_t* overflow_count) {
     typedef Layout<kCap> L;
     constexpr uint32_t kMaxReg = L::kMaxReg, kMaxRaw = L::kMaxRaw;
     __shared__ __align__(16) uint32_t sm[L::WORDS];
@@ -293,11 +300,13 @@ __global__ __launch_bounds__(64) void pile_runs_kernel(PileArgs A, uint32_t* ove
         if (bitmap_path) {
             uint32_t* bm = sm + L::X;
             uint16_t* pref = (uint16_t*)(bm + kBitmapBases / 32);
-            int32_t* delta = (int32_t*)(sm + L::RF);
-            static_assert(kCap != 512 || L::SEL - L::RF >= L::kArr, "scratch for the per-run sums");
+            // per-run sums of +-1, two per word, biased by 0x8000 so that a subtraction never
+            // borrows from the neighbour (at most kCap events meet at one position)
+            uint32_t* delta = sm + L::RF;
+            static_assert(kCap != 512 || L::SEL - L::RF >= L::kArr / 2 + 2, "scratch for the per-run sums");
             ((uint4*)bm)[lane] = make_uint4(0, 0, 0, 0);
             ((uint4*)bm)[lane + 64] = make_uint4(0, 0, 0, 0);
-            for (uint32_t k = lane; k < n_ev + 2; k += 64) delta[k] = 0;
+            for (uint32_t k = lane; 2 * k < n_ev + 3; k += 64) delta[k] = 0x80008000u;
             uint32_t evr[kCap / 64];
 #pragma unroll
             for (uint32_t t = 0; t < kCap / 64; ++t) {
@@ -340,7 +349,8 @@ __global__ __launch_bounds__(64) void pile_runs_kernel(PileArgs A, uint32_t* ove
                     const uint32_t w = pos >> 5;
                     const uint32_t k = pref[w] + (uint32_t)__popc(bm[w] & ((2u << (pos & 31)) - 1u)) - 1u;
                     rs[k] = pos;
-                    atomicAdd(&delta[k], (evr[t] & 1u) ? -1 : 1);
+                    const uint32_t one = 1u << (16u * (k & 1u));
+                    atomicAdd(&delta[k >> 1], (evr[t] & 1u) ? 0u - one : one);
                 }
             }
             if (lane == 0) { rs[0] = 0; rs[R] = n; rs[R + 1] = n; }
@@ -349,10 +359,13 @@ __global__ __launch_bounds__(64) void pile_runs_kernel(PileArgs A, uint32_t* ove
                 const uint32_t cc = (R + 63) / 64;
                 const uint32_t lo = umin(R, lane * cc), hi = umin(R, lo + cc);
                 int32_t sum = 0;
-                for (uint32_t k = lo; k < hi; ++k) sum += delta[k];
+                auto delta_of = [&](uint32_t k) {
+                    return (int32_t)((delta[k >> 1] >> (16u * (k & 1u))) & 0xFFFFu) - 0x8000;
+                };
+                for (uint32_t k = lo; k < hi; ++k) sum += delta_of(k);
                 int32_t cov = wave_scan_incl(sum, OpAdd()) - sum;
                 for (uint32_t k = lo; k < hi; ++k) {
-                    cov += delta[k];
+                    cov += delta_of(k);
                     rv[k] = (uint16_t)cov;
                 }
             }
@@ -478,14 +491,17 @@ __global__ __launch_bounds__(64) void pile_runs_kernel(PileArgs A, uint32_t* ove
         }
         // idx[g] = run that contains position g << shift
         uint32_t shift = 5;
-        while ((n >> shift) >= kIdx) ++shift;
+        while ((n >> shift) >= L::kIdx) ++shift;
         const uint32_t ng = ((n - 1) >> shift) + 1;
         if (bitmap_path) {
-            // the bitmap of run starts and its per-word prefix are still there (shift == 5:
-            // the position is the first bit of word g)
+            // the bitmap of run starts and its per-word prefix are still there; position
+            // m << shift is the first bit of word m << (shift - 5)
             const uint32_t* bm = sm + L::X;
             const uint16_t* pref = (const uint16_t*)(bm + kBitmapBases / 32);
-            for (uint32_t m = lane; m < ng; m += 64) idx[m] = (uint16_t)(pref[m] + (bm[m] & 1u) - 1u);
+            for (uint32_t m = lane; m < ng; m += 64) {
+                const uint32_t w = m << (shift - 5);
+                idx[m] = (uint16_t)(pref[w] + (bm[w] & 1u) - 1u);
+            }
         } else {
             // number of runs j >= 1 that start at or before it: histogram of
             // ceil(start / 2^shift) over the runs, then a prefix sum
@@ -662,18 +678,19 @@ __global__ __launch_bounds__(64) void pile_runs_kernel(PileArgs A, uint32_t* ove
         // with the nearest j > k: i >= start_j - 847.   t(v) = int32(v * q)  (pile.cpp:94)
         // stored as uint16 offsets (<= 846): down = last flagged - run start, up = run end - 1 -
         // first flagged; kNone16 = nothing flagged
-        uint16_t* d13 = (uint16_t*)(sm + L::X);
-        uint16_t* u13 = d13 + L::kArr;
-        uint16_t* d182 = u13 + L::kArr;
-        uint16_t* u182 = d182 + L::kArr;
         // Most runs have no neighbour within the window that exceeds even the q = 1.3
         // threshold.  bm8[b] = max of the 8 runs of block b; a conservative run range of the
-        // window comes from the position index; runs whose bound stays below the threshold
-        // get "nothing flagged" right away, the others are compacted into a list so that the
-        // neighbour scans below run with all lanes busy.
-        uint32_t* bm8 = sm + L::RF;
-        uint16_t* surv = (uint16_t*)(bm8 + (L::kArr / 8 + 8));
-        static_assert(L::SEL - L::RF >= (L::kArr / 8 + 8) + L::kArr / 2 + 2, "scratch for the slope filter");
+        // window comes from the position index; runs whose bound stays below the threshold have
+        // nothing flagged, the others ("survivors") are compacted into a list - their run
+        // index and four offsets are all that is kept - so that the neighbour scans below run
+        // with all lanes busy.
+        constexpr uint32_t kSurv = L::kSurv;
+        uint16_t* surv = (uint16_t*)(sm + L::X);
+        uint16_t* d13 = surv + kSurv;
+        uint16_t* u13 = d13 + kSurv;
+        uint16_t* d182 = u13 + kSurv;
+        uint16_t* u182 = d182 + kSurv;
+        uint32_t* bm8 = sm + L::X + (5 * kSurv + 1) / 2;
         for (uint32_t b = lane; b * 8 < R; b += 64) {
             uint32_t m = 0;
 #pragma unroll
@@ -701,13 +718,21 @@ __global__ __launch_bounds__(64) void pile_runs_kernel(PileArgs A, uint32_t* ove
                     ub = max(max(ub, m0), max(m1, max(m2, m3)));
                 }
                 need = ub > t13;
-                if (!need) { d13[k] = kNone16; u13[k] = kNone16; d182[k] = kNone16; u182[k] = kNone16; }
             }
             const uint64_t m = __ballot(need);
-            if (need) surv[n_surv + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)k;
+            if (need) {
+                const uint32_t w = n_surv + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                if (w < kSurv) surv[w] = (uint16_t)k;
+            }
             n_surv += (uint32_t)__popcll(m);
         }
         wave_sync();
+        if (n_surv > kSurv) {
+            // more flagged runs than this instantiation keeps: hand the read on
+            if (lane == 0) overflow_list[atomicAdd(overflow_count, 1u)] = r;
+            wave_sync();
+            continue;
+        }
         for (uint32_t j = lane; j < n_surv; j += 64) {
             const uint32_t k = surv[j];
             const uint32_t v = rv[k];
@@ -756,10 +781,10 @@ __global__ __launch_bounds__(64) void pile_runs_kernel(PileArgs A, uint32_t* ove
                     }
                 }
             }
-            d13[k] = dl13 == kNone ? kNone16 : (uint16_t)(dl13 - sk);
-            u13[k] = ur13 == kNone ? kNone16 : (uint16_t)(ek - 1 - ur13);
-            d182[k] = dl182 == kNone ? kNone16 : (uint16_t)(dl182 - sk);
-            u182[k] = ur182 == kNone ? kNone16 : (uint16_t)(ek - 1 - ur182);
+            d13[j] = dl13 == kNone ? kNone16 : (uint16_t)(dl13 - sk);
+            u13[j] = ur13 == kNone ? kNone16 : (uint16_t)(ek - 1 - ur13);
+            d182[j] = dl182 == kNone ? kNone16 : (uint16_t)(dl182 - sk);
+            u182[j] = ur182 == kNone ? kNone16 : (uint16_t)(ek - 1 - ur182);
         }
         wave_sync();
         RUN_STOP(26)
@@ -772,24 +797,29 @@ __global__ __launch_bounds__(64) void pile_runs_kernel(PileArgs A, uint32_t* ove
             uint32_t* rf = sm + L::RF + w * kMaxReg;
             uint32_t* rl = sm + L::RL + w * kMaxReg;
             uint32_t ns = 0, ne = 0;
-            for (uint32_t k0 = 0; k0 < R; k0 += 64) {
-                const uint32_t k = k0 + lane;
+            // a run that is not on the survivor list has nothing flagged: neighbours are the
+            // adjacent list entries, if they are the adjacent runs
+            for (uint32_t j0 = 0; j0 < n_surv; j0 += 64) {
+                const uint32_t j = j0 + lane;
                 bool st = false, en = false;
                 uint32_t fv = 0, lv = 0;
-                if (k < R && iv[k] != kNone16) {
+                if (j < n_surv && iv[j] != kNone16) {
+                    const uint32_t k = surv[j];
                     const uint32_t sk = rs[k], ek = rs[k + 1];
+                    const bool has_prev = j > 0 && surv[j - 1] + 1u == k && iv[j - 1] != kNone16;
+                    const bool has_next = j + 1 < n_surv && surv[j + 1] == k + 1u && iv[j + 1] != kNone16;
                     if (!is_up) {
-                        // interval [sk, sk + iv[k]]
-                        const uint32_t last_k = sk + iv[k];
-                        const bool prev_joins = k > 0 && iv[k - 1] != kNone16 && rs[k - 1] + iv[k - 1] == sk - 1;
-                        const bool next_joins = last_k == ek - 1 && k + 1 < R && iv[k + 1] != kNone16;
+                        // interval [sk, sk + iv[j]]
+                        const uint32_t last_k = sk + iv[j];
+                        const bool prev_joins = has_prev && rs[k - 1] + iv[j - 1] == sk - 1;
+                        const bool next_joins = last_k == ek - 1 && has_next;
                         st = !prev_joins; en = !next_joins;
                         fv = sk; lv = last_k;
                     } else {
-                        // interval [ek - 1 - iv[k], ek - 1]
-                        const uint32_t first_k = ek - 1 - iv[k];
-                        const bool prev_joins = first_k == sk && k > 0 && iv[k - 1] != kNone16;
-                        const bool next_joins = k + 1 < R && iv[k + 1] != kNone16 && rs[k + 2] - 1 - iv[k + 1] == ek;
+                        // interval [ek - 1 - iv[j], ek - 1]
+                        const uint32_t first_k = ek - 1 - iv[j];
+                        const bool prev_joins = first_k == sk && has_prev;
+                        const bool next_joins = has_next && rs[k + 2] - 1 - iv[j + 1] == ek;
                         st = !prev_joins; en = !next_joins;
                         fv = first_k; lv = ek - 1;
                     }
@@ -1012,6 +1042,13 @@ __global__ __launch_bounds__(64) void pile_runs_kernel(PileArgs A, uint32_t* ove
 void launch_pile_runs(const PileArgs& args, uint32_t grid, bool big_cap, uint32_t* overflow_list,
                       uint32_t* overflow_count, hipStream_t stream) {
     if (grid == 0) return;
+    // diagnostics: extra dynamic LDS lowers the occupancy (sensitivity experiments)
+    static const uint32_t extra_lds = getenv("RALA_PILE_EXTRA_LDS") ? (uint32_t)atoi(getenv("RALA_PILE_EXTRA_LDS")) : 0u;
+    if (!big_cap && extra_lds) {
+        hipLaunchKernelGGL(pile_runs_kernel<kRunEventCap>, dim3(grid), dim3(64), extra_lds, stream, args, overflow_list,
+                           overflow_count);
+        return;
+    }
     if (big_cap) {
         hipLaunchKernelGGL(pile_runs_kernel<kRunEventCapBig>, dim3(grid), dim3(64), 0, stream, args, overflow_list,
                            overflow_count);
