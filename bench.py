@@ -27,6 +27,7 @@ WORKLOADS = {
     "c1": "1k reads / 50k overlaps (BASELINE configs[0])",
     "c2": "100k reads / 5M overlaps (BASELINE configs[1])",
     "c3": "1M reads / 50M overlaps (BASELINE configs[2])",
+    "c5": "4M reads / 300M overlaps (BASELINE configs[4], primary overlaps only)",
 }
 
 
