@@ -1323,11 +1323,16 @@ int rala_hip_import_state_device(rala_hip_ctx* ctx, const rala_hip_device_state*
         HIPCHECK(hipMemcpyAsync(ctx->d_pool.p, in->pool, (size_t)in->pool_count * sizeof(Interval), hipMemcpyDeviceToDevice, s));
     }
     if (ctx->n_ovl) HIPCHECK(hipMemcpyAsync(ctx->d_valid.p, in->valid, ctx->n_ovl, hipMemcpyDeviceToDevice, s));
+    // host mirrors are fetched by the first getter; only the number of filtered reads is needed now
+    HIPCHECK(ctx->d_cc_flags.ensure(8));
+    HIPCHECK(hipMemsetAsync(ctx->d_cc_flags.p + 6, 0, 4, s));
+    launch_count_zero_u8(ctx->d_alive.p, (uint32_t)n, ctx->d_cc_flags.p + 6, s);
+    uint32_t n_dead = 0;
+    HIPCHECK(hipMemcpyAsync(&n_dead, ctx->d_cc_flags.p + 6, 4, hipMemcpyDeviceToHost, s));
     HIPCHECK(hipStreamSynchronize(s));
-    const int rc = download_read_state(ctx);
-    if (rc != RALA_HIP_OK) return rc;
-    ctx->n_prefiltered = 0;
-    for (uint64_t r = 0; r < n; ++r) if (!ctx->h_alive[r]) ++ctx->n_prefiltered;
+    ctx->host_state_fresh = false;
+    ctx->pool_used = (uint32_t)in->pool_count;
+    ctx->n_prefiltered = n_dead;
     ctx->initialized = true;
     ctx->valid_ready = true;
     ctx->constructed = false;
