@@ -1,0 +1,80 @@
+"""Generates tests/golden/fullsize_<workload>.json: SHA-256 digests of every stage of the ORACLE on a
+full-size BASELINE workload (c2 = 100 k reads / 5 M overlaps, c3 = 1 M reads / 50 M overlaps), so
+that the GPU suite can check the HIP path at full size without running the oracle there.
+
+    python tests/golden/make_fullsize_digests.py c2 [threads]
+
+Needs roughly 2.5 GB (c2) / 30 GB (c3) of host memory."""
+import hashlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+
+from rala_amd.synth import Dataset
+from oracle.oracle import Oracle
+
+SAMPLE = 400          # reads whose whole coverage vector is digested
+
+
+def dg(*arrays):
+    h = hashlib.sha256()
+    for a in arrays:
+        a = np.ascontiguousarray(a)
+        h.update(str(a.dtype).encode()); h.update(str(a.shape).encode()); h.update(a.tobytes())
+    return h.hexdigest()
+
+
+def sample_reads(n_reads, alive):
+    rng = np.random.default_rng(12345)
+    live = np.nonzero(alive)[0]
+    return np.sort(rng.choice(live, size=min(SAMPLE, len(live)), replace=False))
+
+
+def main():
+    wl = sys.argv[1]
+    threads = int(sys.argv[2]) if len(sys.argv) > 2 else (os.cpu_count() or 1)
+    t0 = time.time()
+    ds = Dataset.config(wl)
+    o = Oracle(ds.read_len, ds.overlaps, n_threads=threads)
+    out = {"workload": wl, "n_reads": int(ds.n_reads), "n_overlaps": len(ds.overlaps)}
+    assert o.initialize() == 0
+    p = o.piles()
+    out["valid"] = dg(np.packbits(o.valid()))
+    out["piles0"] = dg(*[p[k] for k in ("begin", "end", "median", "p10", "alive")])
+    pits, hills = o.all_intervals(0), o.all_intervals(1)
+    out["pits0"] = dg(pits[0].astype(np.uint64), pits[1].astype(np.uint32))
+    out["hills0"] = dg(hills[0].astype(np.uint64), hills[1].astype(np.uint32))
+    reads = sample_reads(ds.n_reads, p["alive"])
+    out["data_reads"] = dg(reads.astype(np.int64))
+    out["data0"] = dg(*[np.asarray(o.pile_data(int(r)), dtype=np.uint16) for r in reads])
+    print("[digest] initialize done %.0f s" % (time.time() - t0), file=sys.stderr)
+    o.pass2()
+    o.preprocess_chimeras()
+    p2 = o.piles()
+    out["piles2"] = dg(p2["begin"], p2["end"], p2["alive"])
+    ov, it = o.overlap_list(0), o.overlap_list(1)
+    out["n_overlaps_kept"] = int(len(ov["src"]))
+    out["n_internals_kept"] = int(len(it["src"]))
+    out["ov"] = dg(*[np.asarray(ov[k]).astype(np.uint32) for k in ("src", "a_begin", "a_end", "b_begin", "b_end", "length", "type")])
+    out["int"] = dg(*[np.asarray(it[k]).astype(np.uint32) for k in ("src", "a_begin", "a_end", "b_begin", "b_end", "length", "type")])
+    o.build_graph()
+    out["nodes"] = dg(o.nodes().astype(np.uint32))
+    out["n_tr"] = int(o.remove_transitive_edges())
+    e = o.edges()
+    out["n_edges"] = int(len(e["src"]))
+    out["edges"] = dg(e["src"].astype(np.uint32), e["dst"].astype(np.uint32), e["len"].astype(np.uint32), e["marked"].astype(np.uint8))
+    out["oracle_seconds"] = round(time.time() - t0, 1)
+    path = os.path.join(ROOT, "tests", "golden", "fullsize_%s.json" % wl)
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

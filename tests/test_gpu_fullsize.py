@@ -1,0 +1,150 @@
+"""GPU: the HIP path at the full BASELINE sizes.
+
+* against SHA-256 digests of every oracle stage (tests/golden/fullsize_<workload>.json, made by
+  tests/golden/make_fullsize_digests.py on the CPU) - bit-exactness at 5 M and 50 M overlaps
+  without running the oracle on the GPU box;
+* through size-independent properties: the two independent pile kernels agree, coverage is
+  additive (sum over a read's pile = clipped spans of its overlaps), a second transitive
+  reduction finds nothing, two runs give the same result (atomics do not leak their order)."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from rala_amd.synth import Dataset
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+SAMPLE = 400
+
+
+def dg(*arrays):
+    h = hashlib.sha256()
+    for a in arrays:
+        a = np.ascontiguousarray(a)
+        h.update(str(a.dtype).encode()); h.update(str(a.shape).encode()); h.update(a.tobytes())
+    return h.hexdigest()
+
+
+def sample_reads(alive):
+    rng = np.random.default_rng(12345)
+    live = np.nonzero(alive)[0]
+    return np.sort(rng.choice(live, size=min(SAMPLE, len(live)), replace=False))
+
+
+_DS = {}
+
+
+def dataset(wl):
+    if wl not in _DS:
+        _DS.clear()                 # one big data set at a time
+        _DS[wl] = Dataset.config(wl)
+    return _DS[wl]
+
+
+def run(ctx_factory, ds, **options):
+    ctx = ctx_factory()
+    for k, v in options.items():
+        ctx.set_option(k, v)
+    ctx.set_reads(ds.read_len)
+    ctx.set_overlaps(ds.overlaps)
+    ctx.initialize()
+    return ctx
+
+
+def stage_digests(ctx):
+    out = {}
+    p = ctx.piles()
+    out["valid"] = dg(np.packbits(ctx.valid()))
+    out["piles0"] = dg(*[p[k] for k in ("begin", "end", "median", "p10", "alive")])
+    for kind, name in ((0, "pits0"), (1, "hills0")):
+        offs, pairs, _aux = ctx.intervals(kind)
+        out[name] = dg(offs.astype(np.uint64), pairs.astype(np.uint32))
+    reads = sample_reads(p["alive"])
+    out["data_reads"] = dg(reads.astype(np.int64))
+    out["data0"] = dg(*[np.asarray(ctx.pile_data(int(r)), dtype=np.uint16) for r in reads])
+    ctx.construct()
+    p2 = ctx.piles()
+    out["piles2"] = dg(p2["begin"], p2["end"], p2["alive"])
+    for which, name in ((0, "ov"), (1, "int")):
+        lst = ctx.overlap_list(which)
+        out["n_%s_kept" % ("overlaps" if which == 0 else "internals")] = int(len(lst["src"]))
+        out[name] = dg(*[np.asarray(lst[k]).astype(np.uint32) for k in
+                         ("src", "a_begin", "a_end", "b_begin", "b_end", "length", "type")])
+    out["nodes"] = dg(ctx.graph()["node_read"].astype(np.uint32))
+    out["n_tr"] = int(ctx.remove_transitive_edges())
+    g = ctx.graph()
+    out["n_edges"] = int(len(g["src"]))
+    out["edges"] = dg(g["src"].astype(np.uint32), g["dst"].astype(np.uint32), g["len"].astype(np.uint32),
+                      g["marked"].astype(np.uint8))
+    return out
+
+
+@pytest.mark.parametrize("wl", ["c2", "c3"])
+def test_fullsize_matches_oracle_digests(hip_ctx_factory, wl):
+    path = os.path.join(HERE, "golden", "fullsize_%s.json" % wl)
+    if not os.path.exists(path):
+        pytest.skip("no digest file for %s" % wl)
+    want = json.load(open(path))
+    ds = dataset(wl)
+    assert (ds.n_reads, len(ds.overlaps)) == (want["n_reads"], want["n_overlaps"])
+    got = stage_digests(run(hip_ctx_factory, ds))
+    for k, v in got.items():
+        assert v == want[k], "%s: stage %s differs from the oracle" % (wl, k)
+
+
+@pytest.mark.parametrize("wl", ["c2", "c3"])
+def test_fullsize_properties(hip_ctx_factory, wl):
+    ds = dataset(wl)
+    ov = ds.overlaps
+    ctx = run(hip_ctx_factory, ds)
+    p = ctx.piles()
+    pits, hills = ctx.intervals(0), ctx.intervals(1)
+    reads = sample_reads(p["alive"])[:100]
+    data = {int(r): np.asarray(ctx.pile_data(int(r)), dtype=np.int64) for r in reads}
+
+    # 1. additivity: inside the valid region the pile is the sum of the (shrunk) overlap spans
+    sel = np.isin(ov.a_id, reads) | np.isin(ov.b_id, reads)
+    idx = np.nonzero(sel)[0]
+    for r in reads:
+        r = int(r)
+        B, E = int(p["begin"][r]), int(p["end"][r])
+        total = 0
+        for side_id, sb, se in ((ov.a_id, ov.a_begin, ov.a_end), (ov.b_id, ov.b_begin, ov.b_end)):
+            m = idx[side_id[idx] == r]
+            lo = np.clip(sb[m].astype(np.int64) + 15, B, E)
+            hi = np.clip(se[m].astype(np.int64) - 15, B, E)
+            total += int(np.maximum(hi - lo, 0).sum())
+        assert int(data[r][B:E].sum()) == total, r
+        assert data[r][:B].sum() == 0 and data[r][E:].sum() == 0
+        assert (data[r][B:E] >= 4).all()                 # Pile::find_valid_region
+
+    # 2. the position-space kernel (an independent implementation) agrees
+    other = run(hip_ctx_factory, ds, use_run_kernel=0)
+    q = other.piles()
+    for k in ("begin", "end", "median", "p10", "alive"):
+        assert (p[k] == q[k]).all(), k
+    for mine, theirs in ((pits, other.intervals(0)), (hills, other.intervals(1))):
+        assert (mine[0] == theirs[0]).all() and (mine[1] == theirs[1]).all()
+    for r in reads[:20]:
+        assert (data[int(r)] == np.asarray(other.pile_data(int(r)), dtype=np.int64)).all()
+    del other
+
+    # 3. a second transitive reduction on the reduced graph marks nothing
+    ctx.construct()
+    n_tr = ctx.remove_transitive_edges()
+    g = ctx.graph()
+    assert n_tr > 0 and int(g["marked"].sum()) == 2 * n_tr
+    keep = g["marked"] == 0
+    marks, pairs = ctx.tr_mark(len(g["node_read"]), g["src"][keep], g["dst"][keep], g["len"][keep])
+    assert pairs == 0 and not marks.any()
+
+    # 4. determinism: a second context gives the same graph
+    again = run(hip_ctx_factory, ds)
+    again.construct()
+    assert again.remove_transitive_edges() == n_tr
+    h = again.graph()
+    for k in ("node_read", "src", "dst", "len", "marked"):
+        assert (g[k] == h[k]).all(), k
