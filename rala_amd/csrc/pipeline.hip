@@ -1506,17 +1506,41 @@ int rala_hip_construct(rala_hip_ctx* ctx, const rala_hip_overlaps* sens, uint64_
     }
     HIPCHECK(hipEventRecord(ctx->ev[7], s));
     HIPCHECK(hipGetLastError());
-    const bool on_device = ctx->use_gpu_tail && !(sens != nullptr && n_sens != 0);
+    const bool with_sens = sens != nullptr && n_sens != 0;
     ctx->tail_on_device = false;
     ctx->host_stale = false;
-    if (on_device) {
+    if (ctx->use_gpu_tail) {
         const double t0 = now_ms();
         const int rc5 = gpu_tail_run(ctx);
         if (rc5 != RALA_HIP_OK) return rc5;
-        ctx->tm.tail_host_ms = (float)(now_ms() - t0);
         HIPCHECK(hipEventElapsedTime(&ctx->tm.classify_ms, ctx->ev[4], ctx->ev[5]));
         HIPCHECK(hipEventElapsedTime(&ctx->tm.death_ms, ctx->ev[5], ctx->ev[6]));
         HIPCHECK(hipEventElapsedTime(&ctx->tm.finish_ms, ctx->ev[6], ctx->ev[7]));
+        if (with_sens) {
+            // Graph::preprocess(sensitive overlaps) (graph.cpp:882-1054) works on the lists the
+            // chimera stage leaves: bring them to the host, annotate repeats (kernels + host
+            // orchestration), rebuild the graph from what is left
+            const int rc6 = materialize_host(ctx);
+            if (rc6 != RALA_HIP_OK) return rc6;
+            ctx->tail_on_device = false;
+            ctx->host_stale = false;
+            // rank space of the component search: the reads that are still there
+            ctx->alive_rank.assign(n_reads, 0xFFFFFFFFu);
+            ctx->alive_reads.clear();
+            for (uint32_t r = 0; r < n_reads; ++r) {
+                if (!ctx->h_alive[r]) continue;
+                ctx->alive_rank[r] = (uint32_t)ctx->alive_reads.size();
+                ctx->alive_reads.push_back(r);
+            }
+            const int rc3 = preprocess_repeats(ctx, sens, n_sens);
+            if (rc3 != RALA_HIP_OK) return rc3;
+            build_graph(ctx);
+            HIPCHECK(hipMemcpyAsync(ctx->d_begin.p, ctx->h_begin.data(), (size_t)n_reads * 4, hipMemcpyHostToDevice, s));
+            HIPCHECK(hipMemcpyAsync(ctx->d_end.p, ctx->h_end.data(), (size_t)n_reads * 4, hipMemcpyHostToDevice, s));
+            HIPCHECK(hipMemcpyAsync(ctx->d_alive.p, ctx->h_alive.data(), (size_t)n_reads, hipMemcpyHostToDevice, s));
+            HIPCHECK(hipStreamSynchronize(s));
+        }
+        ctx->tm.tail_host_ms = (float)(now_ms() - t0);
         ctx->constructed = true;
         return RALA_HIP_OK;
     }

@@ -49,9 +49,11 @@ def test_host_tail_cross_check(hip_ctx_factory, n, g, seed):
     parity.check_tr(ctx, st)
 
 
+@pytest.mark.parametrize("gpu_tail", [1, 0])
 @pytest.mark.parametrize("n,g,seed", [(5000, 1_000_000, 7), (6000, 1_600_000, 19)])
-def test_sensitive_pass_vs_oracle(hip_ctx_factory, n, g, seed):
-    """Graph::preprocess(overlaps, sensitive path) (reference graph.cpp:882-1054)."""
+def test_sensitive_pass_vs_oracle(hip_ctx_factory, n, g, seed, gpu_tail):
+    """Graph::preprocess(overlaps, sensitive path) (reference graph.cpp:882-1054), after the
+    chimera stage on the device (default) or on the host."""
     from oracle.oracle import Oracle
 
     ds = Dataset(n, g, seed)
@@ -72,6 +74,7 @@ def test_sensitive_pass_vs_oracle(hip_ctx_factory, n, g, seed):
     want_e = o.edges()
 
     ctx = hip_ctx_factory()
+    ctx.set_option("use_gpu_tail", gpu_tail)
     ctx.set_reads(ds.read_len)
     ctx.set_overlaps(ds.overlaps)
     ctx.initialize()
