@@ -148,6 +148,11 @@ struct rala_hip_ctx {
     std::vector<uint16_t> h_median, h_p10;
     std::vector<uint8_t> h_alive, h_n_pits, h_n_hills;
     std::vector<rala_hip::Interval> h_pool;
+    // pinned staging of small device -> host reads (pipeline.hip: d2h_small / stream_sync)
+    struct StagedCopy { void* dst; size_t offset, bytes; };
+    rala_hip::PinnedBuf<uint32_t> p_stage;
+    std::vector<StagedCopy> stage_pending;
+    size_t stage_used = 0;
     bool host_state_fresh = false;      // host mirrors of the per-read state match the device
     uint32_t pool_used = 0;             // interval pool records in use
 

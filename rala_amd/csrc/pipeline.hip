@@ -35,6 +35,31 @@ int fail(rala_hip_ctx* ctx, int code, const char* msg) {
     return code;
 }
 
+// Small device -> host reads (counters, flags) go through a pinned staging area: an async copy
+// into pageable memory is staged by the runtime and costs tens of microseconds more, and the
+// tail does a dozen of them per call.  d2h_small queues the copy, stream_sync waits for the
+// stream and delivers what was queued.
+hipError_t d2h_small(rala_hip_ctx* ctx, void* dst, const void* src, size_t bytes, hipStream_t s) {
+    if (ctx->p_stage.ensure(256) != hipSuccess || ctx->stage_used + bytes > 256 * sizeof(uint32_t) ||
+        ctx->stage_pending.size() >= 16) {
+        return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s);
+    }
+    char* at = (char*)ctx->p_stage.p + ctx->stage_used;
+    const hipError_t e = hipMemcpyAsync(at, src, bytes, hipMemcpyDeviceToHost, s);
+    if (e != hipSuccess) return e;
+    ctx->stage_pending.push_back({dst, ctx->stage_used, bytes});
+    ctx->stage_used += (bytes + 7) & ~(size_t)7;
+    return hipSuccess;
+}
+
+hipError_t stream_sync(rala_hip_ctx* ctx, hipStream_t s) {
+    const hipError_t e = hipStreamSynchronize(s);
+    for (const auto& c : ctx->stage_pending) memcpy(c.dst, (const char*)ctx->p_stage.p + c.offset, c.bytes);
+    ctx->stage_pending.clear();
+    ctx->stage_used = 0;
+    return e;
+}
+
 ReadState read_state(rala_hip_ctx* ctx) {
     ReadState rs;
     rs.begin = ctx->d_begin.p; rs.end = ctx->d_end.p; rs.alive = ctx->d_alive.p;
@@ -62,8 +87,8 @@ int download_read_state(rala_hip_ctx* ctx) {
     HIPCHECK(hipMemcpyAsync(ctx->h_n_hills.data(), ctx->d_n_hills.p, n, hipMemcpyDeviceToHost, s));
     HIPCHECK(hipMemcpyAsync(ctx->h_slot.data(), ctx->d_iv_slot.p, n * 4, hipMemcpyDeviceToHost, s));
     uint32_t small[4];
-    HIPCHECK(hipMemcpyAsync(small, ctx->d_small.p, sizeof(small), hipMemcpyDeviceToHost, s));
-    HIPCHECK(hipStreamSynchronize(s));
+    HIPCHECK(d2h_small(ctx, small, ctx->d_small.p, sizeof(small), s));
+    HIPCHECK(stream_sync(ctx, s));
     const uint32_t used = std::min(small[0], ctx->pool_cap);
     ctx->pool_used = used;
     ctx->h_pool.resize(used);
@@ -129,7 +154,7 @@ int run_position_kernel(rala_hip_ctx* ctx, PileArgs a, const std::vector<uint32_
         launch_pile_build_annotate(a, grid, c.in_lds, ctx->stream);
         ++ctx->tm.pile_launches;
     }
-    HIPCHECK(hipStreamSynchronize(ctx->stream));      // `order` is pageable host memory
+    HIPCHECK(stream_sync(ctx, ctx->stream));      // `order` is pageable host memory
     return RALA_HIP_OK;
 }
 
@@ -266,14 +291,14 @@ int component_medians(rala_hip_ctx* ctx, std::vector<uint32_t>& members, std::ve
             launch_cc_compress(ctx->d_cc_label.p, (uint32_t)na, s);
         }
         uint32_t changed = 0;
-        HIPCHECK(hipMemcpyAsync(&changed, ctx->d_small.p + 2, 4, hipMemcpyDeviceToHost, s));
-        HIPCHECK(hipStreamSynchronize(s));
+        HIPCHECK(d2h_small(ctx, &changed, ctx->d_small.p + 2, 4, s));
+        HIPCHECK(stream_sync(ctx, s));
         if (!changed) break;
         if (round > 10000) return fail(ctx, RALA_HIP_EDEVICE, "connected components did not converge");
     }
     uint32_t* label = ctx->p_cc_label.p;
     HIPCHECK(hipMemcpyAsync(label, ctx->d_cc_label.p, na * 4, hipMemcpyDeviceToHost, s));
-    HIPCHECK(hipStreamSynchronize(s));
+    HIPCHECK(stream_sync(ctx, s));
     // members = reads with at least one overlap, in read order; grouped by label (counting sort)
     std::vector<uint32_t>& mrank = ctx->scratch_u32a;
     mrank.clear();
@@ -479,7 +504,7 @@ int run_repeats_kernel(rala_hip_ctx* ctx, RepeatArgs a, const std::vector<uint32
         a.slab = ctx->d_slab.p;
         launch_pile_repeats(a, grid, c.in_lds, mode, ctx->stream);
     }
-    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    HIPCHECK(stream_sync(ctx, ctx->stream));
     HIPCHECK(hipGetLastError());
     return RALA_HIP_OK;
 }
@@ -557,7 +582,7 @@ int preprocess_repeats(rala_hip_ctx* ctx, const rala_hip_overlaps* sens, uint64_
     HIPCHECK(ctx->d_rep_pool.ensure(ctx->pool_cap));
     HIPCHECK(hipMemsetAsync(ctx->d_n_rep.p, 0, n, s));
     HIPCHECK(hipMemsetAsync(ctx->d_small.p + 6, 0, 8, s));          // [6] rep pool count [7] error
-    HIPCHECK(hipStreamSynchronize(s));
+    HIPCHECK(stream_sync(ctx, s));
 
     RepeatArgs a;
     a.read_len = ctx->d_read_len.p; a.pile_off = ctx->d_pile_off.p; a.pile = ctx->d_pile.p;
@@ -704,8 +729,8 @@ int tr_mark_device(rala_hip_ctx* ctx, uint32_t n_nodes, uint32_t n_edges, const 
     launch_tr_count(ctx->d_tr_marks.p, n_edges, ctx->d_small.p + 3, s);
     HIPCHECK(hipEventRecord(ctx->ev[11], s));
     uint32_t res[2] = {0, 0};
-    HIPCHECK(hipMemcpyAsync(res, ctx->d_small.p + 2, 8, hipMemcpyDeviceToHost, s));
-    HIPCHECK(hipStreamSynchronize(s));
+    HIPCHECK(d2h_small(ctx, res, ctx->d_small.p + 2, 8, s));
+    HIPCHECK(stream_sync(ctx, s));
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipEventElapsedTime(&ctx->tm.tr_ms, ctx->ev[10], ctx->ev[11]));
     if (res[0]) return fail(ctx, RALA_HIP_EINVAL, "edge endpoint out of range");
@@ -766,8 +791,8 @@ int tail_death_scan(rala_hip_ctx* ctx, const TailList& L, uint32_t which, uint32
             cur ^= 1;
         }
         uint32_t changed[kBatch];
-        HIPCHECK(hipMemcpyAsync(changed, ctx->d_cc_flags.p, sizeof(changed), hipMemcpyDeviceToHost, s));
-        HIPCHECK(hipStreamSynchronize(s));
+        HIPCHECK(d2h_small(ctx, changed, ctx->d_cc_flags.p, sizeof(changed), s));
+        HIPCHECK(stream_sync(ctx, s));
         if (!changed[kBatch - 1]) break;
         if (round > 100000) return fail(ctx, RALA_HIP_EDEVICE, "containment fixed point did not converge");
     }
@@ -780,7 +805,7 @@ int gpu_tail_run(rala_hip_ctx* ctx) {
     hipStream_t s = ctx->stream;
     Trace trc;
     auto mark = [&](const char* what, size_t k = 0) {
-        if (trc.on) { (void)hipStreamSynchronize(s); trc(what, k); }
+        if (trc.on) { (void)stream_sync(ctx, s); trc(what, k); }
     };
     const uint32_t n_reads = (uint32_t)ctx->n_reads;
     const uint32_t M = ctx->t_n0 + ctx->t_n1;
@@ -804,8 +829,8 @@ int gpu_tail_run(rala_hip_ctx* ctx) {
     launch_exclusive_scan(ctx->d_t_tmp[0].p, ctx->d_t_tmp[1].p, n_reads, ctx->d_scan_ws.p, s);
     launch_ranks(ctx->d_alive.p, ctx->d_t_tmp[1].p, ctx->d_rank.p, ctx->d_alive_reads.p, n_reads, s);
     uint32_t n_alive = 0;
-    HIPCHECK(hipMemcpyAsync(&n_alive, ctx->d_t_tmp[1].p + n_reads, 4, hipMemcpyDeviceToHost, s));
-    HIPCHECK(hipStreamSynchronize(s));
+    HIPCHECK(d2h_small(ctx, &n_alive, ctx->d_t_tmp[1].p + n_reads, 4, s));
+    HIPCHECK(stream_sync(ctx, s));
     HIPCHECK(ctx->d_touched.ensure(n_alive)); HIPCHECK(ctx->d_cmed.ensure(n_alive));
     HIPCHECK(ctx->d_cc_edges.ensure(2 * (size_t)M)); HIPCHECK(ctx->d_cc_label.ensure(n_alive));
     HIPCHECK(ctx->d_med_keys[0].ensure(n_alive)); HIPCHECK(ctx->d_med_keys[1].ensure(n_alive));
@@ -840,8 +865,8 @@ int gpu_tail_run(rala_hip_ctx* ctx) {
                 launch_cc_compress(ctx->d_cc_label.p, n_alive, s);
             }
             uint32_t changed[kBatch];
-            HIPCHECK(hipMemcpyAsync(changed, ctx->d_cc_flags.p, sizeof(changed), hipMemcpyDeviceToHost, s));
-            HIPCHECK(hipStreamSynchronize(s));
+            HIPCHECK(d2h_small(ctx, changed, ctx->d_cc_flags.p, sizeof(changed), s));
+            HIPCHECK(stream_sync(ctx, s));
             if (!changed[kBatch - 1]) break;
             if (it > 10000) return fail(ctx, RALA_HIP_EDEVICE, "connected components did not converge");
         }
@@ -856,8 +881,8 @@ int gpu_tail_run(rala_hip_ctx* ctx) {
         launch_retrim(L, R, 1, rounds, ctx->d_small.p + 2, s);
         HIPCHECK(hipMemsetAsync(ctx->d_dirty.p, 0, n_reads, s));
         uint32_t dropped = 0;
-        HIPCHECK(hipMemcpyAsync(&dropped, ctx->d_small.p + 2, 4, hipMemcpyDeviceToHost, s));
-        HIPCHECK(hipStreamSynchronize(s));
+        HIPCHECK(d2h_small(ctx, &dropped, ctx->d_small.p + 2, 4, s));
+        HIPCHECK(stream_sync(ctx, s));
         mark("tail: pits + retrim", dropped);
         if (!dropped) break;
     }
@@ -881,8 +906,8 @@ int gpu_tail_run(rala_hip_ctx* ctx) {
         launch_exclusive_scan(ctx->d_t_tmp[0].p, ctx->d_t_tmp[1].p, M, ctx->d_scan_ws.p, s);
         launch_place_kept(L, R, ctx->d_t_tmp[0].p, ctx->d_t_tmp[1].p, n_kept, ctx->d_kept_item.p, ctx->d_dovetail.p, s);
         uint32_t c = 0;
-        HIPCHECK(hipMemcpyAsync(&c, ctx->d_t_tmp[1].p + M, 4, hipMemcpyDeviceToHost, s));
-        HIPCHECK(hipStreamSynchronize(s));
+        HIPCHECK(d2h_small(ctx, &c, ctx->d_t_tmp[1].p + M, 4, s));
+        HIPCHECK(stream_sync(ctx, s));
         n_kept += c;
     }
     ctx->t_n_kept = n_kept;
@@ -891,11 +916,11 @@ int gpu_tail_run(rala_hip_ctx* ctx) {
     launch_u8_to_u32(ctx->d_alive.p, ctx->d_t_tmp[0].p, n_reads, s);
     launch_exclusive_scan(ctx->d_t_tmp[0].p, ctx->d_node_rank.p, n_reads, ctx->d_scan_ws.p, s);
     uint32_t n_final = 0, n_dove = 0;
-    HIPCHECK(hipMemcpyAsync(&n_final, ctx->d_node_rank.p + n_reads, 4, hipMemcpyDeviceToHost, s));
+    HIPCHECK(d2h_small(ctx, &n_final, ctx->d_node_rank.p + n_reads, 4, s));
     // edges: two per dovetail overlap (graph.cpp:576-632)
     launch_exclusive_scan(ctx->d_dovetail.p, ctx->d_epos.p, n_kept, ctx->d_scan_ws.p, s);
-    HIPCHECK(hipMemcpyAsync(&n_dove, ctx->d_epos.p + n_kept, 4, hipMemcpyDeviceToHost, s));
-    HIPCHECK(hipStreamSynchronize(s));
+    HIPCHECK(d2h_small(ctx, &n_dove, ctx->d_epos.p + n_kept, 4, s));
+    HIPCHECK(stream_sync(ctx, s));
     ctx->t_n_nodes = 2 * n_final;
     ctx->t_n_edges = 2 * n_dove;
     HIPCHECK(ctx->d_node_read.ensure(ctx->t_n_nodes));
@@ -903,7 +928,7 @@ int gpu_tail_run(rala_hip_ctx* ctx) {
     launch_node_reads(ctx->d_alive.p, ctx->d_node_rank.p, ctx->d_node_read.p, n_reads, s);
     launch_build_edges(L, R, ctx->d_kept_item.p, ctx->d_dovetail.p, ctx->d_epos.p, n_kept, ctx->d_node_rank.p,
                        ctx->d_e[0].p, ctx->d_e[1].p, ctx->d_e[2].p, s);
-    HIPCHECK(hipStreamSynchronize(s));
+    HIPCHECK(stream_sync(ctx, s));
     HIPCHECK(hipGetLastError());
     mark("tail: nodes + edges", ctx->t_n_edges);
     ctx->tail_on_device = true;
@@ -943,7 +968,7 @@ int materialize_host(rala_hip_ctx* ctx) {
         HIPCHECK(hipMemcpyAsync(ctx->e_dst.data(), ctx->d_e[1].p, (size_t)ctx->t_n_edges * 4, hipMemcpyDeviceToHost, s));
         HIPCHECK(hipMemcpyAsync(ctx->e_len.data(), ctx->d_e[2].p, (size_t)ctx->t_n_edges * 4, hipMemcpyDeviceToHost, s));
     }
-    HIPCHECK(hipStreamSynchronize(s));
+    HIPCHECK(stream_sync(ctx, s));
     ctx->e_mark.assign(ctx->t_n_edges, 0);
     auto item = [&](uint32_t k) {
         HostOvl o;
@@ -984,7 +1009,7 @@ int rala_hip_create(int device, rala_hip_ctx** out) {
 void rala_hip_destroy(rala_hip_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
+    (void)stream_sync(ctx, ctx->stream);
     for (void* q : ctx->registered) (void)hipHostUnregister(q);
     ctx->registered.clear();
     for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
@@ -1185,9 +1210,9 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
     HIPCHECK(hipMemsetAsync(ctx->d_cc_flags.p + 6, 0, 4, s));
     launch_count_zero_u8(ctx->d_alive.p, n_reads, ctx->d_cc_flags.p + 6, s);
     uint32_t small[8], n_dead = 0;
-    HIPCHECK(hipMemcpyAsync(small, ctx->d_small.p, sizeof(small), hipMemcpyDeviceToHost, s));
-    HIPCHECK(hipMemcpyAsync(&n_dead, ctx->d_cc_flags.p + 6, 4, hipMemcpyDeviceToHost, s));
-    HIPCHECK(hipStreamSynchronize(s));
+    HIPCHECK(d2h_small(ctx, small, ctx->d_small.p, sizeof(small), s));
+    HIPCHECK(d2h_small(ctx, &n_dead, ctx->d_cc_flags.p + 6, 4, s));
+    HIPCHECK(stream_sync(ctx, s));
     ctx->host_state_fresh = false;
     ctx->pool_used = std::min(small[0], ctx->pool_cap);
     ctx->tm.pile_overflow_reads = small[4];
@@ -1212,7 +1237,7 @@ int rala_hip_dedupe(rala_hip_ctx* ctx) {
     if (ctx->n_reads == 0) return fail(ctx, RALA_HIP_EINVAL, "no reads set");
     HIPCHECK(hipSetDevice(ctx->device));
     launch_dedupe(ctx->ovl, (uint32_t)ctx->n_reads, ctx->d_suspect.p, ctx->d_valid.p, ctx->stream);
-    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    HIPCHECK(stream_sync(ctx, ctx->stream));
     HIPCHECK(hipGetLastError());
     ctx->valid_ready = true;
     return RALA_HIP_OK;
@@ -1222,7 +1247,7 @@ int rala_hip_emit_bound_tuples(rala_hip_ctx* ctx, uint32_t* reads_dev, uint32_t*
     if (!ctx || !reads_dev || !bounds_dev) return RALA_HIP_EINVAL;
     HIPCHECK(hipSetDevice(ctx->device));
     launch_emit_tuples(ctx->ovl, (uint32_t)ctx->n_reads, reads_dev, bounds_dev, ctx->stream);
-    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    HIPCHECK(stream_sync(ctx, ctx->stream));
     HIPCHECK(hipGetLastError());
     return RALA_HIP_OK;
 }
@@ -1239,13 +1264,13 @@ int rala_hip_emit_bound_tuples_bucketed(rala_hip_ctx* ctx, uint32_t world, uint3
     launch_bucket_tuples(ctx->ovl, (uint32_t)ctx->n_reads, world, 0, cnt, reads_dev, bounds_dev, s);
     uint32_t h[64];
     HIPCHECK(hipMemcpyAsync(h, cnt, world * 4, hipMemcpyDeviceToHost, s));
-    HIPCHECK(hipStreamSynchronize(s));
+    HIPCHECK(stream_sync(ctx, s));
     uint32_t off[64];
     uint32_t acc = 0;
     for (uint32_t p = 0; p < world; ++p) { off[p] = acc; acc += h[p]; counts[p] = h[p]; }
     HIPCHECK(hipMemcpyAsync(cur, off, world * 4, hipMemcpyHostToDevice, s));
     launch_bucket_tuples(ctx->ovl, (uint32_t)ctx->n_reads, world, 1, cur, reads_dev, bounds_dev, s);
-    HIPCHECK(hipStreamSynchronize(s));
+    HIPCHECK(stream_sync(ctx, s));
     HIPCHECK(hipGetLastError());
     return RALA_HIP_OK;
 }
@@ -1288,7 +1313,7 @@ int rala_hip_copy_device_state(rala_hip_ctx* ctx, const rala_hip_device_state* d
         if (!ctx->valid_ready) return fail(ctx, RALA_HIP_EINVAL, "no validity bits on this context");
         HIPCHECK(cp(dst->valid, ctx->d_valid.p, ctx->n_ovl));
     }
-    HIPCHECK(hipStreamSynchronize(s));
+    HIPCHECK(stream_sync(ctx, s));
     return RALA_HIP_OK;
 }
 
@@ -1328,8 +1353,8 @@ int rala_hip_import_state_device(rala_hip_ctx* ctx, const rala_hip_device_state*
     HIPCHECK(hipMemsetAsync(ctx->d_cc_flags.p + 6, 0, 4, s));
     launch_count_zero_u8(ctx->d_alive.p, (uint32_t)n, ctx->d_cc_flags.p + 6, s);
     uint32_t n_dead = 0;
-    HIPCHECK(hipMemcpyAsync(&n_dead, ctx->d_cc_flags.p + 6, 4, hipMemcpyDeviceToHost, s));
-    HIPCHECK(hipStreamSynchronize(s));
+    HIPCHECK(d2h_small(ctx, &n_dead, ctx->d_cc_flags.p + 6, 4, s));
+    HIPCHECK(stream_sync(ctx, s));
     ctx->host_state_fresh = false;
     ctx->pool_used = (uint32_t)in->pool_count;
     ctx->n_prefiltered = n_dead;
@@ -1472,8 +1497,8 @@ int rala_hip_construct(rala_hip_ctx* ctx, const rala_hip_overlaps* sens, uint64_
             ++ctx->tm.death_rounds;
         }
         uint32_t changed[kBatch];
-        HIPCHECK(hipMemcpyAsync(changed, ctx->d_cc_flags.p, sizeof(changed), hipMemcpyDeviceToHost, s));
-        HIPCHECK(hipStreamSynchronize(s));
+        HIPCHECK(d2h_small(ctx, changed, ctx->d_cc_flags.p, sizeof(changed), s));
+        HIPCHECK(stream_sync(ctx, s));
         if (!changed[kBatch - 1]) break;
         if (ctx->tm.death_rounds > 100000) return fail(ctx, RALA_HIP_EDEVICE, "containment fixed point did not converge");
     }
@@ -1486,9 +1511,9 @@ int rala_hip_construct(rala_hip_ctx* ctx, const rala_hip_overlaps* sens, uint64_
     uint32_t n_surv[2] = {0, 0};
     for (int k = 0; k < 2; ++k) {
         launch_exclusive_scan(ctx->d_chunk[k].p, ctx->d_chunk[2 + k].p, n_chunks, ctx->d_scan_ws.p, s);
-        HIPCHECK(hipMemcpyAsync(&n_surv[k], ctx->d_chunk[2 + k].p + n_chunks, 4, hipMemcpyDeviceToHost, s));
+        HIPCHECK(d2h_small(ctx, &n_surv[k], ctx->d_chunk[2 + k].p + n_chunks, 4, s));
     }
-    HIPCHECK(hipStreamSynchronize(s));
+    HIPCHECK(stream_sync(ctx, s));
     // both survivor lists side by side in one device list: overlaps, then internals
     const uint32_t M = n_surv[0] + n_surv[1];
     ctx->t_n0 = n_surv[0]; ctx->t_n1 = n_surv[1];
@@ -1538,7 +1563,7 @@ int rala_hip_construct(rala_hip_ctx* ctx, const rala_hip_overlaps* sens, uint64_
             HIPCHECK(hipMemcpyAsync(ctx->d_begin.p, ctx->h_begin.data(), (size_t)n_reads * 4, hipMemcpyHostToDevice, s));
             HIPCHECK(hipMemcpyAsync(ctx->d_end.p, ctx->h_end.data(), (size_t)n_reads * 4, hipMemcpyHostToDevice, s));
             HIPCHECK(hipMemcpyAsync(ctx->d_alive.p, ctx->h_alive.data(), (size_t)n_reads, hipMemcpyHostToDevice, s));
-            HIPCHECK(hipStreamSynchronize(s));
+            HIPCHECK(stream_sync(ctx, s));
         }
         ctx->tm.tail_host_ms = (float)(now_ms() - t0);
         ctx->constructed = true;
@@ -1554,7 +1579,7 @@ int rala_hip_construct(rala_hip_ctx* ctx, const rala_hip_overlaps* sens, uint64_
         HIPCHECK(ctx->p_surv_u8[f].ensure(M));
         if (M) HIPCHECK(hipMemcpyAsync(ctx->p_surv_u8[f].p, ctx->d_surv_u8[f].p, M, hipMemcpyDeviceToHost, s));
     }
-    HIPCHECK(hipStreamSynchronize(s));
+    HIPCHECK(stream_sync(ctx, s));
     for (int k = 0; k < 2; ++k) {
         const uint32_t m = n_surv[k];
         const uint32_t off = k == 0 ? 0 : n_surv[0];
@@ -1604,7 +1629,7 @@ int rala_hip_construct(rala_hip_ctx* ctx, const rala_hip_overlaps* sens, uint64_
     HIPCHECK(hipMemcpyAsync(ctx->d_begin.p, ctx->h_begin.data(), (size_t)n_reads * 4, hipMemcpyHostToDevice, s));
     HIPCHECK(hipMemcpyAsync(ctx->d_end.p, ctx->h_end.data(), (size_t)n_reads * 4, hipMemcpyHostToDevice, s));
     HIPCHECK(hipMemcpyAsync(ctx->d_alive.p, ctx->h_alive.data(), (size_t)n_reads, hipMemcpyHostToDevice, s));
-    HIPCHECK(hipStreamSynchronize(s));
+    HIPCHECK(stream_sync(ctx, s));
     ctx->constructed = true;
     return RALA_HIP_OK;
 }
