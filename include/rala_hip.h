@@ -165,6 +165,15 @@ int rala_hip_get_device_state(rala_hip_ctx* ctx, rala_hip_device_state* out);
 int rala_hip_copy_device_state(rala_hip_ctx* ctx, const rala_hip_device_state* dst);
 int rala_hip_import_state_device(rala_hip_ctx* ctx, const rala_hip_device_state* in);
 
+/* Force-directed layout of one connected component, the O(n^2) part of Graph::postprocess
+ * (src/graph.cpp:1132-1226): n points x, y (host, in / out); the attraction partners of point
+ * i are adj[adj_off[i] .. adj_off[i + 1]) (point indices, n = a point fixed at the origin: a
+ * neighbour outside the component); `iterations` steps with step length t, decreased by dt
+ * after every step, spring constant k.  Same arithmetic, in the same order, as the reference's
+ * per-point task. */
+int rala_hip_layout(rala_hip_ctx* ctx, uint32_t n, double* x, double* y, const uint32_t* adj_off, const uint32_t* adj,
+                    uint32_t iterations, double k, double t, double dt);
+
 /* ---- results (host buffers owned by the caller) --------------------------------------- */
 /* is_valid_overlap_ (src/graph.hpp:168), one byte per overlap */
 int rala_hip_get_valid(rala_hip_ctx* ctx, uint8_t* valid);

@@ -12,17 +12,24 @@
 // heap nodes and edges that point at each other, nullable slots in nodes_ / edges_, a set of
 // marked edge ids, shrinkToFit on the adjacency vectors - so that it is structurally
 // independent of the index-based product code (rala_amd/host/assembly_graph.cpp) it checks.
-// The force-directed layout (postprocess, :1056-1279) is seeded from std::random_device in the
-// reference and is not restated; edge weights therefore stay 0.
+// postprocess (:1056-1279), the force-directed layout behind the edge weights, is restated
+// with the two sources of run-to-run variation pinned the way the product pins them: a fixed
+// mt19937 seed instead of std::random_device, and ascending node ids wherever the reference
+// walks an unordered_set (initial points, the repulsion sum, the order of equally large
+// components).
 #pragma once
 
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <math.h>
+
 #include <algorithm>
 #include <deque>
 #include <memory>
+#include <random>
+#include <set>
 #include <string>
 #include <unordered_set>
 #include <vector>
@@ -105,6 +112,7 @@ public:
     std::vector<std::unique_ptr<Node>> nodes_;
     std::vector<std::unique_ptr<Edge>> edges_;
     std::unordered_set<uint32_t> marked_edges_;
+    std::vector<std::pair<uint64_t, uint64_t>> transitive_edges_;
 
     // graph.cpp:553-574: forward and reverse-complement node of one read
     void add_node_pair(uint64_t sequence_id, const std::string& name, const std::string& data, const std::string& rc) {
@@ -131,6 +139,125 @@ public:
         edge->pair->is_marked = true;
         marked_edges_.emplace(edge->id);
         marked_edges_.emplace(edge->pair->id);
+    }
+
+    // graph.cpp:1322-1332
+    void note_transitive_edges() {
+        for (const auto& it : marked_edges_) {
+            if (it & 1) {
+                transitive_edges_.emplace_back((edges_[it]->begin_node->id >> 1) << 1, (edges_[it]->end_node->id >> 1) << 1);
+                transitive_edges_.emplace_back(transitive_edges_.back().second, transitive_edges_.back().first);
+            }
+        }
+        std::sort(transitive_edges_.begin(), transitive_edges_.end());
+    }
+
+    // graph.cpp:1056-1279 (see the header of this file for what is pinned)
+    void postprocess(uint32_t seed) {
+        if (transitive_edges_.empty() == false) {
+            std::vector<std::pair<uint64_t, uint64_t>> tmp = {transitive_edges_[0]};
+            for (uint64_t i = 1; i < transitive_edges_.size(); ++i) {
+                if (nodes_[transitive_edges_[i].first] == nullptr || nodes_[transitive_edges_[i].second] == nullptr) continue;
+                if (transitive_edges_[i].first != transitive_edges_[i].second &&
+                    transitive_edges_[i] != transitive_edges_[i - 1]) {
+                    tmp.emplace_back(transitive_edges_[i]);
+                }
+            }
+            tmp.swap(transitive_edges_);
+        }
+        std::vector<std::set<uint64_t>> components;
+        std::vector<bool> is_visited(nodes_.size(), false);
+        for (uint64_t i = 0; i < nodes_.size(); ++i) {
+            if (nodes_[i] == nullptr || is_visited[i]) continue;
+            components.resize(components.size() + 1);
+            std::deque<uint64_t> que = {i};
+            while (!que.empty()) {
+                uint64_t j = que.front();
+                que.pop_front();
+                if (is_visited[j]) continue;
+                const auto& node = nodes_[j];
+                is_visited[node->id] = true;
+                is_visited[node->pair->id] = true;
+                components.back().emplace((node->id >> 1) << 1);
+                for (const auto& it : node->prefix_edges) que.emplace_back(it->begin_node->id);
+                for (const auto& it : node->suffix_edges) que.emplace_back(it->end_node->id);
+            }
+        }
+        std::sort(components.begin(), components.end(), [](const std::set<uint64_t>& lhs, const std::set<uint64_t>& rhs) {
+            return lhs.size() != rhs.size() ? lhs.size() > rhs.size() : *lhs.begin() < *rhs.begin();
+        });
+        std::mt19937 generator(seed);
+        std::uniform_real_distribution<> distribution(0., 1.);
+        using point = std::pair<double, double>;
+        for (const auto& component : components) {
+            if (component.size() < 6) continue;
+            bool has_junctions = false;
+            for (const auto& it : component) {
+                if (nodes_[it]->is_junction()) {
+                    has_junctions = true;
+                    break;
+                }
+            }
+            if (has_junctions == false) continue;
+            uint32_t num_iterations = 100;
+            double k = sqrt(1. / static_cast<double>(component.size()));
+            double t = 0.1;
+            double dt = t / static_cast<double>(num_iterations + 1);
+            auto add = [](const point& x, const point& y) { return std::make_pair(x.first + y.first, x.second + y.second); };
+            auto substract = [](const point& x, const point& y) { return std::make_pair(x.first - y.first, x.second - y.second); };
+            auto multiply = [](const point& x, double s) { return std::make_pair(x.first * s, x.second * s); };
+            auto norm = [](const point& x) { return sqrt(x.first * x.first + x.second * x.second); };
+            std::vector<point> points(nodes_.size());
+            for (const auto& it : component) {
+                points[it].first = distribution(generator);
+                points[it].second = distribution(generator);
+            }
+            for (uint32_t i = 0; i < num_iterations; ++i) {
+                std::vector<point> displacements(nodes_.size());
+                for (const auto& n : component) {
+                    point displacement = {0., 0.};
+                    for (const auto& m : component) {
+                        if (n == m) continue;
+                        auto delta = substract(points[n], points[m]);
+                        auto distance = norm(delta);
+                        if (distance < 0.01) distance = 0.01;
+                        displacement = add(displacement, multiply(delta, (k * k) / (distance * distance)));
+                    }
+                    auto pull = [&](uint64_t m) {
+                        auto delta = substract(points[n], points[m]);
+                        auto distance = norm(delta);
+                        if (distance < 0.01) distance = 0.01;
+                        displacement = add(displacement, multiply(delta, -1. * distance / k));
+                    };
+                    for (const auto& e : nodes_[n]->prefix_edges) pull((e->begin_node->id >> 1) << 1);
+                    for (const auto& e : nodes_[n]->suffix_edges) pull((e->end_node->id >> 1) << 1);
+                    bool found = false;
+                    for (const auto& e : transitive_edges_) {
+                        if (e.first != n) {
+                            if (found) break;
+                            continue;
+                        }
+                        found = true;
+                        pull(e.second);
+                    }
+                    auto length = norm(displacement);
+                    if (length < 0.01) length = 0.1;
+                    displacements[n] = add(displacements[n], multiply(displacement, t / length));
+                }
+                for (const auto& n : component) points[n] = add(points[n], displacements[n]);
+                t -= dt;
+                ++i;
+            }
+            for (const auto& it : edges_) {
+                if (it == nullptr || it->id & 1) continue;
+                auto n = (it->begin_node->id >> 1) << 1;
+                auto m = (it->end_node->id >> 1) << 1;
+                if (component.find(n) != component.end() && component.find(m) != component.end()) {
+                    it->weight = norm(substract(points[n], points[m]));
+                    it->pair->weight = it->weight;
+                }
+            }
+        }
     }
 
     // graph.cpp:2118-2151
@@ -475,9 +602,10 @@ public:
         return num_unitigs_created;
     }
 
-    // graph.cpp:1850-2040 (transitive_edges_ bookkeeping of the layout left out)
+    // graph.cpp:1850-2040
     uint32_t shrink(uint32_t epsilon) {
         std::vector<bool> is_visited(nodes_.size(), false);
+        std::vector<uint64_t> node_updates(nodes_.size(), 0);
         uint64_t node_id = nodes_.size();
         std::vector<std::unique_ptr<Node>> unitigs;
         uint64_t edge_id = edges_.size();
@@ -515,12 +643,20 @@ public:
             if (is_circular || begin_node == end_node || extension < 2 * epsilon + 2) continue;
             for (uint32_t i = 0; i < epsilon; ++i) begin_node = begin_node->suffix_edges[0]->end_node;
             for (uint32_t i = 0; i < epsilon; ++i) end_node = end_node->prefix_edges[0]->begin_node;
+            for (auto node = begin_node; node != end_node; node = node->suffix_edges[0]->end_node) {
+                node_updates[(node->id >> 1) << 1] = node_id;
+            }
             make_unitig(begin_node, end_node, true, node_id, edge_id, unitigs, unitig_edges);
             ++num_unitigs_created;
         }
         for (uint64_t i = 0; i < unitigs.size(); ++i) nodes_.emplace_back(std::move(unitigs[i]));
         for (uint64_t i = 0; i < unitig_edges.size(); ++i) edges_.emplace_back(std::move(unitig_edges[i]));
         remove_marked_objects(true);
+        for (auto& it : transitive_edges_) {
+            if (node_updates[it.first] != 0) it.first = node_updates[it.first];
+            if (node_updates[it.second] != 0) it.second = node_updates[it.second];
+        }
+        std::sort(transitive_edges_.begin(), transitive_edges_.end());
         return num_unitigs_created;
     }
 };

@@ -35,6 +35,17 @@ void ol_mark_edge(void* h, uint32_t edge) {
     auto* g = (ora_layout::Layout*)h;
     g->mark(g->edges_[edge].get());
 }
+void ol_note_transitive(void* h) { ((ora_layout::Layout*)h)->note_transitive_edges(); }
+void ol_postprocess(void* h, uint32_t seed) { ((ora_layout::Layout*)h)->postprocess(seed); }
+void ol_edge_weights(void* h, double* w) {
+    auto* g = (ora_layout::Layout*)h;
+    for (size_t i = 0; i < g->edges_.size(); ++i) w[i] = g->edges_[i] ? g->edges_[i]->weight : 0.0;
+}
+uint64_t ol_transitive(void* h, uint64_t* pairs) {
+    auto* g = (ora_layout::Layout*)h;
+    if (pairs) for (size_t i = 0; i < g->transitive_edges_.size(); ++i) { pairs[2 * i] = g->transitive_edges_[i].first; pairs[2 * i + 1] = g->transitive_edges_[i].second; }
+    return g->transitive_edges_.size();
+}
 void ol_remove_marked(void* h, int remove_nodes) { ((ora_layout::Layout*)h)->remove_marked_objects(remove_nodes != 0); }
 
 uint32_t ol_run(void* h, int op, uint32_t arg) {

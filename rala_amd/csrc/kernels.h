@@ -221,4 +221,8 @@ hipError_t launch_component_medians(const uint32_t* label, const uint8_t* touche
                                     size_t tmp_bytes, uint16_t* cmed, hipStream_t s);
 void launch_tr_count(const uint8_t* marks, uint32_t n_edges, uint32_t* n_pairs, hipStream_t s);
 
+// ---- force-directed layout step (layout_kernels.hip) -------------------------------------------
+void launch_layout_step(uint32_t n, const double* x, const double* y, double* x_out, double* y_out,
+                        const uint32_t* adj_off, const uint32_t* adj, double k, double t, hipStream_t s);
+
 }  // namespace rala_hip

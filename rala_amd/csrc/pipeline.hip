@@ -1657,6 +1657,34 @@ int rala_hip_tr_mark(rala_hip_ctx* ctx, uint32_t n_nodes, uint32_t n_edges, cons
     return tr_mark_impl(ctx, n_nodes, n_edges, src, dst, len, marks, n_pairs);
 }
 
+int rala_hip_layout(rala_hip_ctx* ctx, uint32_t n, double* x, double* y, const uint32_t* adj_off, const uint32_t* adj,
+                    uint32_t iterations, double k, double t, double dt) {
+    if (!ctx || (n && (!x || !y || !adj_off))) return RALA_HIP_EINVAL;
+    if (n == 0) return RALA_HIP_OK;
+    const uint32_t n_adj = adj_off[n];
+    if (n_adj && !adj) return RALA_HIP_EINVAL;
+    HIPCHECK(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    for (int b = 0; b < 4; ++b) HIPCHECK(ctx->d_layout[b].ensure(n));
+    HIPCHECK(ctx->d_layout_adj[0].ensure(n + 1)); HIPCHECK(ctx->d_layout_adj[1].ensure(n_adj + 1));
+    HIPCHECK(hipMemcpyAsync(ctx->d_layout[0].p, x, (size_t)n * 8, hipMemcpyHostToDevice, s));
+    HIPCHECK(hipMemcpyAsync(ctx->d_layout[1].p, y, (size_t)n * 8, hipMemcpyHostToDevice, s));
+    HIPCHECK(hipMemcpyAsync(ctx->d_layout_adj[0].p, adj_off, (size_t)(n + 1) * 4, hipMemcpyHostToDevice, s));
+    if (n_adj) HIPCHECK(hipMemcpyAsync(ctx->d_layout_adj[1].p, adj, (size_t)n_adj * 4, hipMemcpyHostToDevice, s));
+    int cur = 0;
+    for (uint32_t it = 0; it < iterations; ++it) {
+        launch_layout_step(n, ctx->d_layout[2 * cur].p, ctx->d_layout[2 * cur + 1].p, ctx->d_layout[2 * (cur ^ 1)].p,
+                           ctx->d_layout[2 * (cur ^ 1) + 1].p, ctx->d_layout_adj[0].p, ctx->d_layout_adj[1].p, k, t, s);
+        cur ^= 1;
+        t -= dt;
+    }
+    HIPCHECK(hipMemcpyAsync(x, ctx->d_layout[2 * cur].p, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipMemcpyAsync(y, ctx->d_layout[2 * cur + 1].p, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+    HIPCHECK(stream_sync(ctx, s));
+    HIPCHECK(hipGetLastError());
+    return RALA_HIP_OK;
+}
+
 // ---- results ---------------------------------------------------------------------------
 int rala_hip_get_valid(rala_hip_ctx* ctx, uint8_t* valid) {
     if (!ctx || !valid) return RALA_HIP_EINVAL;

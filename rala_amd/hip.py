@@ -27,7 +27,7 @@ SYMBOLS = (
     "rala_hip_get_graph", "rala_hip_get_timings", "rala_hip_get_num_prefiltered",
     "rala_hip_dedupe", "rala_hip_emit_bound_tuples", "rala_hip_set_bound_tuples", "rala_hip_import_state",
     "rala_hip_emit_bound_tuples_bucketed", "rala_hip_get_device_state", "rala_hip_import_state_device",
-    "rala_hip_copy_device_state",
+    "rala_hip_copy_device_state", "rala_hip_layout",
 )
 
 
@@ -97,6 +97,7 @@ def lib(build=True):
         L.rala_hip_get_device_state.argtypes = [vp, ctypes.POINTER(DeviceState)]
         L.rala_hip_import_state_device.argtypes = [vp, ctypes.POINTER(DeviceState)]
         L.rala_hip_copy_device_state.argtypes = [vp, ctypes.POINTER(DeviceState)]
+        L.rala_hip_layout.argtypes = [vp, u32, vp, vp, vp, vp, u32, ctypes.c_double, ctypes.c_double, ctypes.c_double]
         _lib = L
     return _lib
 
@@ -180,6 +181,14 @@ class Context:
     def emit_bound_tuples(self, reads_ptr, bounds_ptr):
         """device pointers of 4 * n_overlaps uint32 each"""
         self._check(self.L.rala_hip_emit_bound_tuples(self.h, reads_ptr, bounds_ptr))
+
+    def layout(self, x, y, adj_off, adj, iterations, k, t, dt):
+        """force-directed layout steps (rala_hip_layout); x, y float64 arrays updated in place"""
+        assert x.dtype == np.float64 and y.dtype == np.float64 and x.flags.c_contiguous and y.flags.c_contiguous
+        adj_off = np.ascontiguousarray(adj_off, dtype=np.uint32)
+        adj = np.ascontiguousarray(adj, dtype=np.uint32)
+        self._check(self.L.rala_hip_layout(self.h, len(x), x.ctypes.data, y.ctypes.data, adj_off.ctypes.data,
+                                           adj.ctypes.data if len(adj) else None, iterations, k, t, dt))
 
     def emit_bound_tuples_bucketed(self, world, reads_ptr, bounds_ptr):
         """tuples grouped by owner rank; returns the bucket sizes"""

@@ -3,8 +3,11 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <math.h>
+
 #include <algorithm>
 #include <deque>
+#include <random>
 #include <unordered_set>
 
 namespace rala {
@@ -68,9 +71,106 @@ void AssemblyGraph::remove_marked_objects(bool remove_nodes) {
     marked_edges_.clear();
 }
 
-// graph.cpp:1337-1366.  Edge weights come from the force-directed layout, which this build does
-// not run (it is seeded from std::random_device in the reference): all weights are 0 and
-// nothing qualifies, unless a caller filled Edge::weight.
+// graph.cpp:1322-1332
+void AssemblyGraph::note_transitive_edges() {
+    for (uint32_t e : marked_edges_) {
+        if (!(e & 1)) continue;
+        const uint64_t a = (uint64_t)(edges_[e].begin_node >> 1) << 1, b = (uint64_t)(edges_[e].end_node >> 1) << 1;
+        transitive_edges_.emplace_back(a, b);
+        transitive_edges_.emplace_back(b, a);
+    }
+    std::sort(transitive_edges_.begin(), transitive_edges_.end());
+}
+
+// graph.cpp:1056-1279
+int AssemblyGraph::postprocess(const LayoutEngine& engine, uint32_t seed) {
+    // duplicates and pairs that lost a node leave the transitive list (:1060-1073)
+    if (!transitive_edges_.empty()) {
+        std::vector<std::pair<uint64_t, uint64_t>> tmp = {transitive_edges_[0]};
+        for (size_t i = 1; i < transitive_edges_.size(); ++i) {
+            const auto& te = transitive_edges_[i];
+            if (!nodes_[te.first].alive || !nodes_[te.second].alive) continue;
+            if (te.first != te.second && te != transitive_edges_[i - 1]) tmp.push_back(te);
+        }
+        tmp.swap(transitive_edges_);
+    }
+    // connected components over forward-node ids (:1075-1104), largest first; ties by smallest id
+    const size_t n0 = nodes_.size();
+    std::vector<std::vector<uint32_t>> components;
+    {
+        std::vector<bool> is_visited(n0, false);
+        std::deque<uint32_t> que;
+        for (size_t i = 0; i < n0; ++i) {
+            if (!nodes_[i].alive || is_visited[i]) continue;
+            components.emplace_back();
+            que.assign(1, (uint32_t)i);
+            while (!que.empty()) {
+                const uint32_t j = que.front();
+                que.pop_front();
+                if (is_visited[j]) continue;
+                is_visited[j] = true;
+                is_visited[j ^ 1u] = true;
+                components.back().push_back(j & ~1u);
+                for (uint32_t e : nodes_[j].prefix_edges) que.push_back(edges_[e].begin_node);
+                for (uint32_t e : nodes_[j].suffix_edges) que.push_back(edges_[e].end_node);
+            }
+            std::sort(components.back().begin(), components.back().end());
+        }
+    }
+    std::sort(components.begin(), components.end(), [](const std::vector<uint32_t>& a, const std::vector<uint32_t>& b) {
+        return a.size() != b.size() ? a.size() > b.size() : a[0] < b[0];
+    });
+
+    std::mt19937 generator(seed);
+    std::uniform_real_distribution<> distribution(0., 1.);
+    std::vector<int64_t> member_of(n0, -1);
+    for (const auto& component : components) {
+        if (component.size() < 6) continue;
+        bool has_junctions = false;
+        for (uint32_t v : component) if (nodes_[v].is_junction()) { has_junctions = true; break; }
+        if (!has_junctions) continue;
+
+        const uint32_t n = (uint32_t)component.size();
+        const uint32_t num_iterations = 100;
+        const double k = sqrt(1. / static_cast<double>(n));
+        const double t = 0.1;
+        const double dt = t / static_cast<double>(num_iterations + 1);
+        std::vector<double> x(n), y(n);
+        for (uint32_t i = 0; i < n; ++i) {
+            member_of[component[i]] = i;
+            x[i] = distribution(generator);
+            y[i] = distribution(generator);
+        }
+        // attraction partners in the reference's order: prefix edges, suffix edges, transitive
+        // edges; a partner outside the component sits at the origin (points_ is zero there)
+        std::vector<uint32_t> adj_off(n + 1, 0), adj;
+        for (uint32_t i = 0; i < n; ++i) {
+            const uint32_t v = component[i];
+            auto partner = [&](uint64_t m) { adj.push_back(member_of[m] >= 0 ? (uint32_t)member_of[m] : n); };
+            for (uint32_t e : nodes_[v].prefix_edges) partner(edges_[e].begin_node & ~1u);
+            for (uint32_t e : nodes_[v].suffix_edges) partner(edges_[e].end_node & ~1u);
+            auto lo = std::lower_bound(transitive_edges_.begin(), transitive_edges_.end(),
+                std::make_pair((uint64_t)v, (uint64_t)0));
+            for (; lo != transitive_edges_.end() && lo->first == v; ++lo) partner(lo->second);
+            adj_off[i + 1] = (uint32_t)adj.size();
+        }
+        // the reference's loop advances its counter twice per pass (:1132, :1225): 50 steps
+        const int rc = engine(n, x.data(), y.data(), adj_off.data(), adj.data(), num_iterations / 2, k, t, dt);
+        if (rc != 0) return rc;
+        for (auto& e : edges_) {
+            if (!e.alive || (e.id & 1)) continue;
+            const int64_t a = member_of[e.begin_node & ~1u], b = member_of[e.end_node & ~1u];
+            if (a < 0 || b < 0) continue;
+            const double dx = x[a] - x[b], dy = y[a] - y[b];
+            e.weight = sqrt(dx * dx + dy * dy);
+            edges_[e.id ^ 1].weight = e.weight;
+        }
+        for (uint32_t v : component) member_of[v] = -1;
+    }
+    return 0;
+}
+
+// graph.cpp:1337-1366: an out-edge twice as long (in the layout) as a sibling goes
 uint32_t AssemblyGraph::remove_long_edges() {
     uint32_t num_long_edges = 0;
     for (const auto& node : nodes_) {
@@ -384,10 +484,11 @@ uint32_t AssemblyGraph::create_unitigs() {
     return num_unitigs_created;
 }
 
-// graph.cpp:1850-2040 (the bookkeeping for the layout's transitive-edge list is not kept)
+// graph.cpp:1850-2040
 uint32_t AssemblyGraph::shrink(uint32_t epsilon) {
     const size_t n0 = nodes_.size();
     std::vector<bool> is_visited(n0, false);
+    std::vector<uint64_t> node_updates(n0, 0);       // forward-node id -> unitig that swallowed it
     uint32_t num_unitigs_created = 0;
     for (size_t i = 0; i < n0; ++i) {
         if (!nodes_[i].alive || is_visited[i] || nodes_[i].is_junction()) continue;
@@ -421,10 +522,19 @@ uint32_t AssemblyGraph::shrink(uint32_t epsilon) {
         if (is_circular || begin_node == end_node || extension < 2 * epsilon + 2) continue;
         for (uint32_t k = 0; k < epsilon; ++k) begin_node = edges_[nodes_[begin_node].suffix_edges[0]].end_node;
         for (uint32_t k = 0; k < epsilon; ++k) end_node = edges_[nodes_[end_node].prefix_edges[0]].begin_node;
+        // transitive edges follow their nodes into the unitig (:1926-1931; the end node keeps its id)
+        for (uint32_t node = begin_node; node != end_node; node = edges_[nodes_[node].suffix_edges[0]].end_node) {
+            node_updates[node & ~1u] = nodes_.size();
+        }
         splice_unitig(begin_node, end_node, true);
         ++num_unitigs_created;
     }
     remove_marked_objects(true);
+    for (auto& te : transitive_edges_) {
+        if (node_updates[te.first] != 0) te.first = node_updates[te.first];
+        if (node_updates[te.second] != 0) te.second = node_updates[te.second];
+    }
+    std::sort(transitive_edges_.begin(), transitive_edges_.end());
     return num_unitigs_created;
 }
 

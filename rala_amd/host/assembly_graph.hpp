@@ -7,6 +7,12 @@
  * :1615-1702 find_edge / find_removable_edges, :1704-1848 create_unitigs, :1850-2040 shrink,
  * :2118-2151 remove_marked_objects).
  *
+ * postprocess (:1056-1279) is the force-directed layout that gives edges their weights; its
+ * O(n^2) iterations run through a caller-supplied engine (the GPU kernel behind
+ * rala_hip_layout), everything around it - components, initial points, attraction lists - is
+ * here.  The reference seeds it from std::random_device and walks unordered sets; this build
+ * fixes the seed and the orders (ascending node ids), which makes runs reproducible.
+ *
  * Index based: nodes and edges live in two vectors and refer to each other by position;
  * objects are created in pairs (forward, reverse complement), so the twin of object k is k ^ 1.
  * Plain host code - the graphs are small (about 1 % of the overlaps survive to here).
@@ -16,7 +22,9 @@
 
 #include <stdint.h>
 
+#include <functional>
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace rala {
@@ -56,6 +64,18 @@ public:
     void mark_edge(uint32_t edge_id);       // the edge and its twin
     void remove_marked_objects(bool remove_nodes = false);
 
+    /*! @brief after marking transitive edges, before removing them (graph.cpp:1322-1332) */
+    void note_transitive_edges();
+    /*!
+     * @brief one layout of n points: x, y in / out; the attraction partners of point i are
+     * adj[adj_off[i] .. adj_off[i + 1]) (index n = a point fixed at the origin); `iterations`
+     * steps of repulsion k^2 / d^2 from every other point + attraction d / k along the lists,
+     * step length t, t -= dt after every step.  Returns 0 on success.
+     */
+    typedef std::function<int(uint32_t n, double* x, double* y, const uint32_t* adj_off, const uint32_t* adj,
+        uint32_t iterations, double k, double t, double dt)> LayoutEngine;
+    /*! @brief graph.cpp:1056-1279: edge weights from a force-directed layout per component */
+    int postprocess(const LayoutEngine& engine, uint32_t seed = 0);
     uint32_t remove_long_edges();
     uint32_t remove_tips();
     uint32_t remove_bubbles();
@@ -66,6 +86,7 @@ public:
     const std::vector<Edge>& edges() const { return edges_; }
     std::vector<Node>& nodes() { return nodes_; }
     std::vector<Edge>& edges() { return edges_; }
+    const std::vector<std::pair<uint64_t, uint64_t>>& transitive_edges() const { return transitive_edges_; }
 
 private:
     uint32_t find_edge(uint32_t src, uint32_t dst) const;
@@ -80,6 +101,7 @@ private:
     std::vector<Node> nodes_;
     std::vector<Edge> edges_;
     std::vector<uint32_t> marked_edges_;
+    std::vector<std::pair<uint64_t, uint64_t>> transitive_edges_;   // forward-node ids, both directions, sorted
 };
 
 }  // namespace rala

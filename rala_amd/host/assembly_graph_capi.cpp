@@ -30,6 +30,25 @@ void ag_add_edge(void* h, uint32_t begin_node, uint32_t end_node, uint32_t lengt
     ((rala::AssemblyGraph*)h)->add_edge(begin_node, end_node, length);
 }
 void ag_mark_edge(void* h, uint32_t edge) { ((rala::AssemblyGraph*)h)->mark_edge(edge); }
+void ag_note_transitive(void* h) { ((rala::AssemblyGraph*)h)->note_transitive_edges(); }
+// engine: the layout steps (rala_hip_layout through a ctypes callback in the GPU tests)
+typedef int (*ag_layout_fn)(uint32_t n, double* x, double* y, const uint32_t* adj_off, const uint32_t* adj,
+                            uint32_t iterations, double k, double t, double dt);
+int ag_postprocess(void* h, uint32_t seed, ag_layout_fn engine) {
+    return ((rala::AssemblyGraph*)h)->postprocess(
+        [engine](uint32_t n, double* x, double* y, const uint32_t* adj_off, const uint32_t* adj, uint32_t iterations,
+                 double k, double t, double dt) { return engine(n, x, y, adj_off, adj, iterations, k, t, dt); },
+        seed);
+}
+void ag_edge_weights(void* h, double* w) {
+    auto* g = (rala::AssemblyGraph*)h;
+    for (size_t i = 0; i < g->edges().size(); ++i) w[i] = g->edges()[i].alive ? g->edges()[i].weight : 0.0;
+}
+uint64_t ag_transitive(void* h, uint64_t* pairs) {
+    const auto& te = ((rala::AssemblyGraph*)h)->transitive_edges();
+    if (pairs) for (size_t i = 0; i < te.size(); ++i) { pairs[2 * i] = te[i].first; pairs[2 * i + 1] = te[i].second; }
+    return te.size();
+}
 void ag_remove_marked(void* h, int remove_nodes) { ((rala::AssemblyGraph*)h)->remove_marked_objects(remove_nodes != 0); }
 
 // op: 0 remove_tips, 1 remove_bubbles, 2 create_unitigs, 3 shrink(arg), 4 remove_long_edges

@@ -262,8 +262,8 @@ void Graph::construct(const std::string& sensitive_overlaps_path) {
     fprintf(stderr, "[rala::Graph::construct] number of edges = %zu\n", graph_.edges().size());
 }
 
-// reference src/graph.cpp:642-697 without the five force-directed layout rounds (:667-671:
-// postprocess() is seeded from std::random_device; remove_long_edges() needs its edge weights)
+// reference src/graph.cpp:642-697; the layout of postprocess() runs on the GPU with a fixed seed
+// (the reference seeds it from std::random_device, so its long-edge decisions vary run to run)
 void Graph::simplify() {
     StageTimer timer;
     const uint32_t num_transitive_edges = remove_transitive_edges();
@@ -281,6 +281,7 @@ void Graph::simplify() {
     tips_and_bubbles();
     shrink(42);
     for (uint32_t i = 0; i < 5; ++i) {
+        postprocess();
         num_long_edges += remove_long_edges();
         num_tips += remove_tips();
     }
@@ -309,8 +310,20 @@ uint32_t Graph::remove_transitive_edges() {
     for (size_t k = 0; k < ids.size(); ++k) {
         if (marks[k] && !graph_.edges()[ids[k]].is_marked) graph_.mark_edge(ids[k]);
     }
+    graph_.note_transitive_edges();
     graph_.remove_marked_objects();
     return num_transitive_edges;
+}
+
+// reference src/graph.cpp:1056-1279
+void Graph::postprocess() {
+    StageTimer timer;
+    const int rc = graph_.postprocess([&](uint32_t n, double* x, double* y, const uint32_t* adj_off, const uint32_t* adj,
+                                          uint32_t iterations, double k, double t, double dt) {
+        return rala_hip_layout(ctx_, n, x, y, adj_off, adj, iterations, k, t, dt);
+    }, layout_seed_++);
+    check(ctx_, rc, "postprocess");
+    timer("[rala::Graph::postprocess]");
 }
 
 uint32_t Graph::remove_long_edges() { return graph_.remove_long_edges(); }

@@ -6,8 +6,9 @@
  * construct() and remove_transitive_edges() run on the GPU through the C ABI
  * (include/rala_hip.h).  The clean-up after transitive reduction (tips, bubbles, unitigs,
  * shrink; reference src/graph.cpp:1337-2040) is host code on the small surviving graph
- * (assembly_graph.hpp).  The force-directed layout (reference :1056-1279, seeded from
- * std::random_device) is not run: edge weights stay 0 and remove_long_edges() finds nothing.
+ * (assembly_graph.hpp).  The force-directed layout that weighs the edges for
+ * remove_long_edges() (reference :1056-1279) runs its O(n^2) steps on the GPU
+ * (rala_hip_layout) with fixed seeds; the reference seeds it from std::random_device.
  */
 
 #pragma once
@@ -66,6 +67,7 @@ private:
     const Graph& operator=(const Graph&) = delete;
 
     void initialize();
+    void postprocess();
 
     std::string sequences_path_, overlaps_path_;
     uint32_t num_threads_;
@@ -79,6 +81,7 @@ private:
     io::OverlapColumns overlaps_;       // parsed once
 
     AssemblyGraph graph_;
+    uint32_t layout_seed_ = 0;          // one fixed seed per layout round
 };
 
 }  // namespace rala

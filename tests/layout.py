@@ -8,6 +8,55 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OPS = {"tips": 0, "bubbles": 1, "unitigs": 2, "shrink": 3, "long_edges": 4}
+LAYOUT_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_uint32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
+                             ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32), ctypes.c_uint32,
+                             ctypes.c_double, ctypes.c_double, ctypes.c_double)
+
+
+def numpy_engine(x, y, adj_off, adj, iterations, k, t, dt):
+    """The layout steps of Graph::postprocess on the CPU, vectorised over the points but with
+    every point's sums accumulated in ascending partner order (bit-identical to a sequential
+    evaluation): the stand-in for rala_hip_layout in the CPU suite."""
+    n = len(x)
+    for _ in range(iterations):
+        ax = np.zeros(n); ay = np.zeros(n)
+        for m in range(n):
+            dx = x - x[m]; dy = y - y[m]
+            d = np.sqrt(dx * dx + dy * dy)
+            d = np.where(d < 0.01, 0.01, d)
+            s = (k * k) / (d * d)
+            keep = np.arange(n) != m
+            ax = np.where(keep, ax + dx * s, ax)
+            ay = np.where(keep, ay + dy * s, ay)
+        deg = np.diff(adj_off)
+        for j in range(int(deg.max()) if n else 0):
+            has = deg > j
+            idx = np.where(has, adj[np.minimum(adj_off[:-1] + j, len(adj) - 1)] if len(adj) else 0, n)
+            px = np.where(idx < n, x[np.minimum(idx, n - 1)], 0.0)
+            py = np.where(idx < n, y[np.minimum(idx, n - 1)], 0.0)
+            dx = x - px; dy = y - py
+            d = np.sqrt(dx * dx + dy * dy)
+            d = np.where(d < 0.01, 0.01, d)
+            s = -1. * d / k
+            ax = np.where(has, ax + dx * s, ax)
+            ay = np.where(has, ay + dy * s, ay)
+        length = np.sqrt(ax * ax + ay * ay)
+        length = np.where(length < 0.01, 0.1, length)
+        s = t / length
+        x[:] = x + ax * s
+        y[:] = y + ay * s
+        t -= dt
+    return 0
+
+
+def engine_callback(fn):
+    """wraps engine(x, y, adj_off, adj, iterations, k, t, dt) (numpy arrays, x / y in place)"""
+    def raw(n, px, py, poff, padj, iterations, k, t, dt):
+        x = np.ctypeslib.as_array(px, shape=(n,)); y = np.ctypeslib.as_array(py, shape=(n,))
+        off = np.ctypeslib.as_array(poff, shape=(n + 1,)).copy()
+        adj = np.ctypeslib.as_array(padj, shape=(int(off[n]),)).copy() if off[n] else np.zeros(0, np.uint32)
+        return int(fn(x, y, off, adj, iterations, k, t, dt))
+    return LAYOUT_FN(raw)
 _COMP = bytes.maketrans(b"ACGT", b"TGCA")
 
 
@@ -30,6 +79,15 @@ class _Graph:
         f("dump_nodes").argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 10
         f("dump_edges").argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 4
         f("destroy").argtypes = [ctypes.c_void_p]
+        f("note_transitive").argtypes = [ctypes.c_void_p]
+        f("edge_weights").argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        f("transitive").argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        f("transitive").restype = ctypes.c_uint64
+        if prefix == "ag_":
+            f("postprocess").argtypes = [ctypes.c_void_p, ctypes.c_uint32, LAYOUT_FN]
+            f("postprocess").restype = ctypes.c_int
+        else:
+            f("postprocess").argtypes = [ctypes.c_void_p, ctypes.c_uint32]
         f("node_data").argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_char_p, ctypes.c_uint64]
         f("node_data").restype = ctypes.c_uint64
         self.f = f
@@ -51,6 +109,30 @@ class _Graph:
 
     def remove_marked(self, remove_nodes=False):
         self.f("remove_marked")(self.h, int(remove_nodes))
+
+    def note_transitive(self):
+        self.f("note_transitive")(self.h)
+
+    def postprocess(self, seed, engine=None):
+        """force-directed layout -> edge weights; the product needs an engine for the layout steps"""
+        if self.p == "ag_":
+            cb = engine_callback(engine or numpy_engine)
+            assert self.f("postprocess")(self.h, seed, cb) == 0
+        else:
+            self.f("postprocess")(self.h, seed)
+
+    def edge_weights(self):
+        ne = self.dump()[1]["alive"].shape[0]
+        w = np.zeros(ne, dtype=np.float64)
+        self.f("edge_weights")(self.h, w.ctypes.data)
+        return w
+
+    def transitive(self):
+        n = int(self.f("transitive")(self.h, None))
+        out = np.zeros((n, 2), dtype=np.uint64)
+        if n:
+            self.f("transitive")(self.h, out.ctypes.data)
+        return out
 
     def run(self, op, arg=0):
         return int(self.f("run")(self.h, OPS[op], arg))
@@ -90,6 +172,10 @@ def oracle():
 
 def assert_same_graph(a, b, what=""):
     (na, ea), (nb, eb) = a.dump(), b.dump()
+    wa, wb = a.edge_weights(), b.edge_weights()
+    assert wa.shape == wb.shape and (wa == wb).all(), "%s edge weights differ (max %g)" % (what, np.abs(wa - wb).max())
+    ta, tb = a.transitive(), b.transitive()
+    assert ta.shape == tb.shape and (ta == tb).all(), "%s transitive-edge lists differ" % what
     for name, x, y in (("node", na, nb), ("edge", ea, eb)):
         for k in x:
             assert x[k].shape == y[k].shape, "%s %s.%s: %s vs %s" % (what, name, k, x[k].shape, y[k].shape)

@@ -52,18 +52,21 @@ def _expected_layout(o, nodes, post, fa):
     for i in np.nonzero(post["marked"])[0]:
         if i % 2 == 0:
             g.mark_edge(i)
+    g.note_transitive()
     g.remove_marked(False)
     return g
 
 
 def _simplify(g):
-    """Graph::simplify after the transitive reduction (reference graph.cpp:647-684, no layout)"""
+    """Graph::simplify after the transitive reduction (reference graph.cpp:647-684); layout
+    rounds with the seeds 0 .. 4 like rala::Graph"""
     def loop():
         while g.run("tips") + g.run("bubbles"):
             pass
     loop()
     g.run("shrink", 42)
-    for _ in range(5):
+    for seed in range(5):
+        g.postprocess(seed)
         g.run("long_edges")
         g.run("tips")
     loop()

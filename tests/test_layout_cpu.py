@@ -37,12 +37,14 @@ def _from_pipeline(n, g, seed):
         for i in np.nonzero(e["marked"])[0]:
             if i % 2 == 0:                       # marks come in twin pairs
                 gph.mark_edge(i)
+        gph.note_transitive()
         gph.remove_marked(False)
     return graphs
 
 
-def _simplify(gph, log):
-    """Graph::simplify (reference graph.cpp:642-697) without the layout rounds"""
+def _simplify(gph, log, engine=None):
+    """Graph::simplify after the transitive reduction (reference graph.cpp:647-684); the layout
+    rounds take the seeds 0 .. 4 like rala::Graph does"""
     def loop():
         while True:
             t = gph.run("tips")
@@ -52,7 +54,8 @@ def _simplify(gph, log):
                 break
     loop()
     log.append(("shrink", gph.run("shrink", 42)))
-    for _ in range(5):
+    for seed in range(5):
+        gph.postprocess(seed, engine)
         log.append(("round", gph.run("long_edges"), gph.run("tips")))
     loop()
     log.append(("unitigs", gph.run("unitigs")))
@@ -220,3 +223,54 @@ def test_random_graphs_exercise_every_stage():
             else:
                 unitigs += x[1]
     assert tips > 0 and bubbles > 0 and unitigs > 0, (tips, bubbles, shrunk, unitigs)
+
+
+def _tangle(graphs, seed):
+    """chains that cross in shared nodes (repeat-like junctions no tip / bubble rule resolves)
+    plus a few shortcuts that are marked as transitive and removed: a component the layout runs on"""
+    rng = np.random.default_rng(seed)
+    n_chains, length = int(rng.integers(2, 4)), int(rng.integers(8, 16))
+    ids = [[c * length + k for k in range(length)] for c in range(n_chains)]
+    n = n_chains * length
+    for gph in graphs:
+        r = np.random.default_rng(seed)
+        for k in range(n):
+            gph.add_node_pair(k, b"r%d" % k, _random_dna(r, 9000))
+    edges = []
+    for ch in ids:
+        for a, b in zip(ch, ch[1:]):
+            edges.append((a, b, int(rng.integers(1000, 3000))))
+    for c in range(1, n_chains):                       # cross links through the middle
+        edges.append((ids[0][length // 2], ids[c][length // 2 + 1], 2500))
+        edges.append((ids[c][length // 2 - 1], ids[0][length // 2], 2500))
+    shortcuts = []
+    for _ in range(4):
+        c = int(rng.integers(0, n_chains)); k = int(rng.integers(0, length - 3))
+        shortcuts.append(len(edges))
+        edges.append((ids[c][k], ids[c][k + 2], 5000))
+    for gph in graphs:
+        for a, b, l in edges:
+            gph.add_edge(2 * a, 2 * b, l)
+            gph.add_edge(2 * b + 1, 2 * a + 1, l)
+        for e in shortcuts:
+            gph.mark_edge(2 * e)
+        gph.note_transitive()
+        gph.remove_marked(False)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_layout_weights_and_long_edges(seed):
+    """postprocess (force-directed layout, reference graph.cpp:1056-1279) and remove_long_edges:
+    product (layout steps through the numpy stand-in of rala_hip_layout) against the oracle"""
+    graphs = _both()
+    _tangle(graphs, seed)
+    for gph in graphs:
+        gph.postprocess(seed)
+    layout.assert_same_graph(*graphs, "after postprocess")
+    w = graphs[0].edge_weights()
+    assert (w > 0).any()
+    la, lb = [], []
+    _simplify(graphs[0], la)
+    _simplify(graphs[1], lb)
+    assert la == lb
+    layout.assert_same_graph(*graphs, "after simplify")
