@@ -76,7 +76,10 @@ const char* rala_hip_last_error(const rala_hip_ctx* ctx);
 /* options: "interval_pool_per_read_x1000" (default 1000 = one pit/hill slot per
  * read on average), "max_lds_read_len" (position-space kernel: reads longer than this use
  * the HBM slab path), "use_run_kernel" (default 1; 0 sends every read through the
- * position-space kernel), "debug_pile_stop_after" (diagnostics) */
+ * position-space kernel), "use_gpu_tail" (default 1; 0 runs the chimera stage of
+ * Graph::preprocess on the host), "use_fixed_buckets" (default 1; 0 always buckets the bounds
+ * through the exact count / scan / scatter path), "host_threads", "debug_pile_stop_after"
+ * (diagnostics) */
 int rala_hip_set_option(rala_hip_ctx* ctx, const char* key, int64_t value);
 /* the context's hipStream_t, for callers that enqueue their own copies/collectives */
 void* rala_hip_stream(rala_hip_ctx* ctx);

@@ -119,7 +119,7 @@ struct rala_hip_ctx {
     bool piles_resident = false;
 
     // bound CSR
-    rala_hip::DevBuf<uint32_t> d_ev_off, d_cursor, d_ev, d_slot_rank[2];
+    rala_hip::DevBuf<uint32_t> d_ev_off, d_cursor, d_ev, d_slot_rank[2], d_ev_fixed;
     rala_hip::DevBuf<unsigned char> d_scan_ws;
 
     // per-read annotation
@@ -155,6 +155,7 @@ struct rala_hip_ctx {
     rala_hip::PinnedBuf<uint32_t> p_stage;
     std::vector<StagedCopy> stage_pending;
     size_t stage_used = 0;
+    int64_t use_fixed_buckets = 1;        // single-pass bucketing into fixed slots when they fit
     bool host_state_fresh = false;      // host mirrors of the per-read state match the device
     uint32_t pool_used = 0;             // interval pool records in use
 

@@ -28,6 +28,8 @@ struct PileArgs {
     uint16_t* pile;                // all piles, row after row
     const uint32_t* ev_off;        // CSR of bound events per read (n_reads + 1)
     const uint32_t* ev;            // pos << 1 | is_end
+    const uint32_t* ev_cnt;        // non-null: fixed slots instead of the CSR - read r has ev_cnt[r] events
+    uint32_t ev_stride;            //           at ev + r * ev_stride
     const uint32_t* order;         // reads of this launch
     uint32_t n_items;
     const uint32_t* n_items_dev;   // when non-null the item count is read from device memory
@@ -119,6 +121,11 @@ enum : uint8_t {
 
 // suspect: n_reads bytes of scratch (queries whose runs are not strictly ordered by target)
 void launch_dedupe(const OvlSoA& o, uint32_t n_reads, uint8_t* suspect, uint8_t* valid, hipStream_t s);
+// Single-pass bucketing into fixed slots of `stride` events per read: the slot index comes
+// straight from the counting atomic, so there is no scan and no second pass.  *over is set
+// when a read has more events than a slot holds (the caller then falls back to the CSR path).
+void launch_bucket_fixed(const OvlSoA& o, uint32_t n_reads, uint32_t stride, uint32_t* counts, uint32_t* ev_fixed,
+                         uint32_t* over, hipStream_t s);
 // counts -> (exclusive scan) -> ev_off; rank_a / rank_b: n_overlaps each, slot of the overlap's
 // bounds inside the bucket of read a / read b
 void launch_count_bounds(const OvlSoA& o, uint32_t n_reads, uint32_t* counts, uint32_t* rank_a, uint32_t* rank_b,

@@ -126,6 +126,35 @@ __device__ __forceinline__ uint32_t segment_of(uint32_t key, bool active, uint32
     return head ? len : 0u;
 }
 
+// Fixed-slot bucketing: read r owns ev_fixed[r * stride .. + stride); the counting atomic hands
+// out the position inside the slot and the bounds are stored right away (8-byte stores).  The
+// kernel runs at the rate of the random atomics (about 25 G/s on MI355X whatever their scope,
+// tools/atomic_bench.hip); the stores ride along.
+__global__ __launch_bounds__(kBlock) void bucket_fixed_kernel(OvlSoA o, uint32_t n_reads, uint32_t stride,
+                                                             uint32_t* counts, uint32_t* __restrict__ ev_fixed,
+                                                             uint32_t* over) {
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t a = kInf, b = kInf;
+    if (i < o.n) { a = o.a_id[i]; b = o.b_id[i]; }
+    const bool ok = a < n_reads && b < n_reads;
+    uint32_t leader;
+    const uint32_t seg = segment_of(a, ok, lane, leader);
+    uint32_t base = 0;
+    if (seg) base = atomicAdd(&counts[a], 2u * seg);
+    base = (uint32_t)__shfl((int)base, (int)leader, 64);
+    if (!ok) return;
+    const uint32_t pa = base + 2u * (lane - leader);
+    const uint32_t pb = atomicAdd(&counts[b], 2u);
+    if (pa + 2u <= stride) {
+        *(uint2*)(ev_fixed + (size_t)a * stride + pa) = make_uint2((o.a_begin[i] + 15u) << 1, ((o.a_end[i] - 15u) << 1) | 1u);
+    }
+    if (pb + 2u <= stride) {
+        *(uint2*)(ev_fixed + (size_t)b * stride + pb) = make_uint2((o.b_begin[i] + 15u) << 1, ((o.b_end[i] - 15u) << 1) | 1u);
+    }
+    if (pa + 2u > stride || pb + 2u > stride) *over = 1u;
+}
+
 // Counting pass.  The value an atomic add returns is a unique slot inside the read's bucket,
 // so it is kept (rank_a / rank_b, 4 B per overlap and side) and the scatter pass needs no
 // atomics at all.
@@ -527,6 +556,13 @@ void launch_dedupe(const OvlSoA& o, uint32_t n_reads, uint8_t* suspect, uint8_t*
     (void)hipMemsetAsync(suspect, 0, n_reads, s);
     hipLaunchKernelGGL(dedupe_mark_kernel, grid_for(o.n), dim3(kBlock), 0, s, o, n_reads, suspect);
     hipLaunchKernelGGL(dedupe_kernel, grid_for(o.n), dim3(kBlock), 0, s, o, n_reads, (const uint8_t*)suspect, valid);
+}
+void launch_bucket_fixed(const OvlSoA& o, uint32_t n_reads, uint32_t stride, uint32_t* counts, uint32_t* ev_fixed,
+                         uint32_t* over, hipStream_t s) {
+    if (o.n) {
+        hipLaunchKernelGGL(bucket_fixed_kernel, grid_for(o.n), dim3(kBlock), 0, s, o, n_reads, stride, counts, ev_fixed,
+                           over);
+    }
 }
 void launch_count_bounds(const OvlSoA& o, uint32_t n_reads, uint32_t* counts, uint32_t* rank_a, uint32_t* rank_b,
                          hipStream_t s) {

@@ -95,9 +95,10 @@ __global__ __launch_bounds__(kBlock) void pile_build_annotate(PileArgs A) {
         RALA_STOP(0)
         // ---- 1. bound events -> difference array --------------------------
         {
-            const uint32_t e0 = A.ev_off[r], e1 = A.ev_off[r + 1];
-            for (uint32_t k = e0 + tid; k < e1; k += kBlock) {
-                const uint32_t b = A.ev[k];
+            const uint32_t n_ev = A.ev_cnt ? umin(A.ev_cnt[r], A.ev_stride) : A.ev_off[r + 1] - A.ev_off[r];
+            const uint32_t* __restrict__ rev = A.ev_cnt ? A.ev + (size_t)r * A.ev_stride : A.ev + A.ev_off[r];
+            for (uint32_t k = tid; k < n_ev; k += kBlock) {
+                const uint32_t b = rev[k];
                 const uint32_t pos = b >> 1;
                 if (pos <= n) atomicAdd(&diff[pos], (b & 1) ? -1 : 1);
             }

@@ -281,8 +281,8 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
     for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
         const uint32_t r = A.order ? A.order[item] : item;
         const uint32_t n = A.read_len[r];
-        const uint32_t e0 = A.ev_off[r];
-        const uint32_t n_ev = A.ev_off[r + 1] - e0;
+        const uint32_t n_ev = A.ev_cnt ? umin(A.ev_cnt[r], A.ev_stride) : A.ev_off[r + 1] - A.ev_off[r];
+        const uint32_t* __restrict__ rev = A.ev_cnt ? A.ev + (size_t)r * A.ev_stride : A.ev + A.ev_off[r];
         if (n_ev > kCap) {
             if (lane == 0) overflow_list[atomicAdd(overflow_count, 1u)] = r;
             continue;
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
 #pragma unroll
             for (uint32_t t = 0; t < kCap / 64; ++t) {
                 const uint32_t e = t * 64 + lane;
-                evr[t] = e < n_ev ? A.ev[e0 + e] : kNone;
+                evr[t] = e < n_ev ? rev[e] : kNone;
             }
             wave_sync();
 #pragma unroll
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
             uint32_t P = 64;
             while (P < n_ev) P <<= 1;
             if (P <= 512) {
-                const uint32_t* gev = A.ev + e0;
+                const uint32_t* gev = rev;
                 if (P == 64) load_sort_store<1>(gev, n_ev, n, ev, lane);
                 else if (P == 128) load_sort_store<2>(gev, n_ev, n, ev, lane);
                 else if (P == 256) load_sort_store<4>(gev, n_ev, n, ev, lane);
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
                 for (uint32_t k = lane; k < P; k += 64) {
                     uint32_t b = kNone;
                     if (k < n_ev) {
-                        b = A.ev[e0 + k];
+                        b = rev[k];
                         if ((b >> 1) > n) b = kNone;
                     }
                     ev[k] = b;

@@ -1026,6 +1026,7 @@ int rala_hip_set_option(rala_hip_ctx* ctx, const char* key, int64_t value) {
     if (!strcmp(key, "debug_pile_stop_after")) { ctx->debug_pile_stop_after = value; return RALA_HIP_OK; }
     if (!strcmp(key, "use_run_kernel")) { ctx->use_run_kernel = value != 0; return RALA_HIP_OK; }
     if (!strcmp(key, "use_gpu_tail")) { ctx->use_gpu_tail = value != 0; return RALA_HIP_OK; }
+    if (!strcmp(key, "use_fixed_buckets")) { ctx->use_fixed_buckets = value != 0; return RALA_HIP_OK; }
     if (!strcmp(key, "host_threads")) {
         ctx->host_threads = value;
         ctx->pool.reset(new HostPool((unsigned)std::max<int64_t>(1, std::min<int64_t>(value, 256))));
@@ -1143,7 +1144,25 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
     HIPCHECK(hipEventRecord(ctx->ev[0], s));
     if (!ctx->tuple_mode) launch_dedupe(ctx->ovl, n_reads, ctx->d_suspect.p, ctx->d_valid.p, s);
     HIPCHECK(hipEventRecord(ctx->ev[1], s));
-    // bucket bounds by read: count -> exclusive scan -> scatter
+    // bucket bounds by read.  Fast path: one kernel into fixed slots of kRunEventCapBig events per
+    // read (8 KB; 8 GB at a million reads - HBM is 288 GB); the position inside the slot is what the
+    // counting atomic returns, so there is no scan and no second pass over the overlaps.  A read
+    // with more events than a slot (only the position-space kernel could take it) sends the whole
+    // data set through the exact CSR path below.
+    const uint32_t slot = kRunEventCapBig;
+    bool fixed = !ctx->tuple_mode && ctx->use_run_kernel && ctx->use_fixed_buckets &&
+                 (uint64_t)n_reads * slot * 4ull <= (64ull << 30);
+    if (fixed) {
+        HIPCHECK(ctx->d_ev_fixed.ensure((size_t)n_reads * slot + 8));
+        HIPCHECK(ctx->d_cc_flags.ensure(8));
+        HIPCHECK(hipMemsetAsync(ctx->d_cursor.p, 0, (size_t)(n_reads + 1) * 4, s));
+        HIPCHECK(hipMemsetAsync(ctx->d_cc_flags.p + 5, 0, 4, s));
+        launch_bucket_fixed(ctx->ovl, n_reads, slot, ctx->d_cursor.p, ctx->d_ev_fixed.p, ctx->d_cc_flags.p + 5, s);
+        // the overflow flag is read together with the other results at the end of this call; a
+        // set flag repeats the call on the exact path (no host round trip in the common case)
+    }
+    if (!fixed) {
+    // count -> exclusive scan -> scatter
     HIPCHECK(hipMemsetAsync(ctx->d_cursor.p, 0, (size_t)(n_reads + 1) * 4, s));
     if (ctx->tuple_mode) {
         launch_count_tuples(ctx->tuple_reads, ctx->n_tuples, n_reads, ctx->d_cursor.p, s);
@@ -1159,11 +1178,13 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
     } else {
         launch_scatter_bounds(ctx->ovl, n_reads, ctx->d_ev_off.p, ctx->d_slot_rank[0].p, ctx->d_slot_rank[1].p, ctx->d_ev.p, s);
     }
+    }
     HIPCHECK(hipEventRecord(ctx->ev[2], s));
 
     PileArgs a;
     a.read_len = ctx->d_read_len.p; a.pile_off = ctx->d_pile_off.p; a.pile = ctx->d_pile.p;
-    a.ev_off = ctx->d_ev_off.p; a.ev = ctx->d_ev.p;
+    a.ev_off = ctx->d_ev_off.p; a.ev = fixed ? ctx->d_ev_fixed.p : ctx->d_ev.p;
+    a.ev_cnt = fixed ? ctx->d_cursor.p : nullptr; a.ev_stride = slot;
     a.add_to_existing = 0; a.slab = ctx->d_slab.p;
     a.stop_after = (uint32_t)ctx->debug_pile_stop_after;
     a.begin = ctx->d_begin.p; a.end = ctx->d_end.p; a.median = ctx->d_median.p; a.p10 = ctx->d_p10.p;
@@ -1209,10 +1230,19 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
     HIPCHECK(ctx->d_cc_flags.ensure(8));
     HIPCHECK(hipMemsetAsync(ctx->d_cc_flags.p + 6, 0, 4, s));
     launch_count_zero_u8(ctx->d_alive.p, n_reads, ctx->d_cc_flags.p + 6, s);
-    uint32_t small[8], n_dead = 0;
+    uint32_t small[8], n_dead = 0, slot_overflow = 0;
     HIPCHECK(d2h_small(ctx, small, ctx->d_small.p, sizeof(small), s));
     HIPCHECK(d2h_small(ctx, &n_dead, ctx->d_cc_flags.p + 6, 4, s));
+    if (fixed) HIPCHECK(d2h_small(ctx, &slot_overflow, ctx->d_cc_flags.p + 5, 4, s));
     HIPCHECK(stream_sync(ctx, s));
+    if (slot_overflow) {
+        // some read has more events than a fixed slot holds: once more, through the exact path
+        const int64_t keep = ctx->use_fixed_buckets;
+        ctx->use_fixed_buckets = 0;
+        const int rc_again = rala_hip_initialize(ctx);
+        ctx->use_fixed_buckets = keep;
+        return rc_again;
+    }
     ctx->host_state_fresh = false;
     ctx->pool_used = std::min(small[0], ctx->pool_cap);
     ctx->tm.pile_overflow_reads = small[4];
