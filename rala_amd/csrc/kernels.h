@@ -126,6 +126,8 @@ void launch_dedupe(const OvlSoA& o, uint32_t n_reads, uint8_t* suspect, uint8_t*
 // when a read has more events than a slot holds (the caller then falls back to the CSR path).
 void launch_bucket_fixed(const OvlSoA& o, uint32_t n_reads, uint32_t stride, uint32_t* counts, uint32_t* ev_fixed,
                          uint32_t* over, hipStream_t s);
+void launch_bucket_fixed_tuples(const uint32_t* reads, const uint32_t* bounds, uint64_t n, uint32_t n_reads,
+                                uint32_t stride, uint32_t* counts, uint32_t* ev_fixed, uint32_t* over, hipStream_t s);
 // counts -> (exclusive scan) -> ev_off; rank_a / rank_b: n_overlaps each, slot of the overlap's
 // bounds inside the bucket of read a / read b
 void launch_count_bounds(const OvlSoA& o, uint32_t n_reads, uint32_t* counts, uint32_t* rank_a, uint32_t* rank_b,

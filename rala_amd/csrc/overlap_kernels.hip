@@ -291,6 +291,25 @@ __global__ __launch_bounds__(kBlock) void bucket_tuples_kernel(OvlSoA o, uint32_
     }
 }
 
+// fixed-slot bucketing of (read, bound) tuples (multi-GPU owners): as bucket_fixed_kernel
+__global__ __launch_bounds__(kBlock) void bucket_fixed_tuples_kernel(const uint32_t* __restrict__ reads,
+                                                                     const uint32_t* __restrict__ bounds, uint64_t n,
+                                                                     uint32_t n_reads, uint32_t stride, uint32_t* counts,
+                                                                     uint32_t* __restrict__ ev_fixed, uint32_t* over) {
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t r = i < n ? reads[i] : kInf;
+    uint32_t leader;
+    const uint32_t seg = segment_of(r, r < n_reads, lane, leader);
+    uint32_t base = 0;
+    if (seg) base = atomicAdd(&counts[r], seg);
+    base = (uint32_t)__shfl((int)base, (int)leader, 64);
+    if (r >= n_reads) return;
+    const uint32_t p = base + (lane - leader);
+    if (p < stride) ev_fixed[(size_t)r * stride + p] = bounds[i];
+    else *over = 1u;
+}
+
 __global__ __launch_bounds__(kBlock) void count_tuples_kernel(const uint32_t* __restrict__ reads, uint64_t n,
                                                               uint32_t n_reads, uint32_t* counts) {
     const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -562,6 +581,13 @@ void launch_bucket_fixed(const OvlSoA& o, uint32_t n_reads, uint32_t stride, uin
     if (o.n) {
         hipLaunchKernelGGL(bucket_fixed_kernel, grid_for(o.n), dim3(kBlock), 0, s, o, n_reads, stride, counts, ev_fixed,
                            over);
+    }
+}
+void launch_bucket_fixed_tuples(const uint32_t* reads, const uint32_t* bounds, uint64_t n, uint32_t n_reads,
+                                uint32_t stride, uint32_t* counts, uint32_t* ev_fixed, uint32_t* over, hipStream_t s) {
+    if (n) {
+        hipLaunchKernelGGL(bucket_fixed_tuples_kernel, grid_for(n), dim3(kBlock), 0, s, reads, bounds, n, n_reads, stride,
+                           counts, ev_fixed, over);
     }
 }
 void launch_count_bounds(const OvlSoA& o, uint32_t n_reads, uint32_t* counts, uint32_t* rank_a, uint32_t* rank_b,

@@ -1150,14 +1150,18 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
     // with more events than a slot (only the position-space kernel could take it) sends the whole
     // data set through the exact CSR path below.
     const uint32_t slot = kRunEventCapBig;
-    bool fixed = !ctx->tuple_mode && ctx->use_run_kernel && ctx->use_fixed_buckets &&
-                 (uint64_t)n_reads * slot * 4ull <= (64ull << 30);
+    bool fixed = ctx->use_run_kernel && ctx->use_fixed_buckets && (uint64_t)n_reads * slot * 4ull <= (64ull << 30);
     if (fixed) {
         HIPCHECK(ctx->d_ev_fixed.ensure((size_t)n_reads * slot + 8));
         HIPCHECK(ctx->d_cc_flags.ensure(8));
         HIPCHECK(hipMemsetAsync(ctx->d_cursor.p, 0, (size_t)(n_reads + 1) * 4, s));
         HIPCHECK(hipMemsetAsync(ctx->d_cc_flags.p + 5, 0, 4, s));
-        launch_bucket_fixed(ctx->ovl, n_reads, slot, ctx->d_cursor.p, ctx->d_ev_fixed.p, ctx->d_cc_flags.p + 5, s);
+        if (ctx->tuple_mode) {
+            launch_bucket_fixed_tuples(ctx->tuple_reads, ctx->tuple_bounds, ctx->n_tuples, n_reads, slot, ctx->d_cursor.p,
+                                       ctx->d_ev_fixed.p, ctx->d_cc_flags.p + 5, s);
+        } else {
+            launch_bucket_fixed(ctx->ovl, n_reads, slot, ctx->d_cursor.p, ctx->d_ev_fixed.p, ctx->d_cc_flags.p + 5, s);
+        }
         // the overflow flag is read together with the other results at the end of this call; a
         // set flag repeats the call on the exact path (no host round trip in the common case)
     }
