@@ -705,7 +705,7 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
             if (k < R) {
                 const uint32_t v = rv[k];
                 const uint32_t sk = rs[k], ek = rs[k + 1];
-                const int32_t t13 = (int32_t)((double)v * 1.3);
+                const int32_t t13 = (int32_t)(v * 13u / 10u);      // == int32(v * 1.3) for every uint16 v
                 const uint32_t gl = (sk >= 847u ? sk - 847u : 0u) >> shift;
                 const uint32_t gr = ((ek + 846u) >> shift) + 1u;
                 const uint32_t jl = idx[gl];
@@ -737,7 +737,8 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
             const uint32_t k = surv[j];
             const uint32_t v = rv[k];
             const uint32_t sk = rs[k], ek = rs[k + 1];
-            const int32_t t13 = (int32_t)((double)v * 1.3), t182 = (int32_t)((double)v * 1.82);
+            // int32(v * q) of pile.cpp:94 in integers: exact for every 16-bit v (tools/threshold_check.c)
+            const int32_t t13 = (int32_t)(v * 13u / 10u), t182 = (int32_t)(v * 182u / 100u);
             uint32_t dl13 = kNone, dl182 = kNone, ur13 = kNone, ur182 = kNone;
             {
                 bool done = false;
