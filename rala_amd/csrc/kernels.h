@@ -151,7 +151,11 @@ void launch_pack_reads(const ReadState& rs, uint32_t n_reads, uint4* rec, hipStr
 uint32_t pass2_chunks(uint64_t n_overlaps);     // workgroups (= chunk counters) of finish / gather
 void launch_classify(const OvlSoA& o, uint32_t n_reads, const uint8_t* valid, const uint4* rec, uint8_t* cls,
                      const KillList& kl, hipStream_t s);
-void launch_death_round(const KillList& kl, const uint32_t* death_old, uint32_t* death_new, hipStream_t s);
+// containment fixed point on the killer list (overlap_kernels.hip): lo[t] = min(lo[t], i) over a
+// list; one decision round (sure killers -> sure[], undecided ones -> out)
+void launch_death_lower(const KillList& kl, uint32_t* lo, hipStream_t s);
+void launch_death_decide(const KillList& in, const uint32_t* lo, const uint32_t* up, uint32_t* sure, const KillList& out,
+                         hipStream_t s);
 void launch_death_diff(const uint32_t* a, const uint32_t* b, uint32_t n, uint32_t* changed, hipStream_t s);
 void launch_finish_pass2(const OvlSoA& o, uint8_t* cls, const uint32_t* death, const uint4* rec, Interval* pool,
                          uint32_t* chunk_ov, uint32_t* chunk_in, hipStream_t s);

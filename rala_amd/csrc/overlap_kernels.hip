@@ -419,18 +419,63 @@ __global__ __launch_bounds__(kBlock) void classify_kernel(OvlSoA o, uint32_t n_r
     }
 }
 
-// One Jacobi round of death[r] = min { i : overlap i would delete r and its
-// container is still alive when i is reached }.
-__global__ __launch_bounds__(kBlock) void death_round_kernel(KillList kl, const uint32_t* __restrict__ death_old,
-                                                             uint32_t* death_new) {
+// In-order containment removal (graph.cpp:464-483) as a fixed point:
+//     death[r] = min { i : killer i targets r and death[keeper(i)] > i }
+// The map is antitone, so iterating it from "nobody dies" gives lower and upper bounds in turn.
+// With a lower bound lo[] and an upper bound up[] a killer i is decided as soon as
+// lo[keeper] > i (it kills for sure) or up[keeper] <= i (its keeper is gone for sure):
+//   * sure killers feed sure[target] = min i  (an upper bound of death[target]),
+//   * killers that cannot beat sure[target], and the dead ones, leave the list,
+//   * the rest stay undecided and are looked at again with the next, tighter bounds
+//     (lo' = min(sure, undecided), up' = sure).
+// The undecided set shrinks quickly; when it is empty, death = sure.
+
+// lo[target] = min(lo[target], i) over the list (a coherent load skips hopeless atomics)
+__global__ __launch_bounds__(kBlock) void death_lower_kernel(KillList kl, uint32_t* lo) {
     const uint32_t n = *kl.count;
     for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < n; k += gridDim.x * kBlock) {
         const uint32_t i = kl.ovl[k];
-        if (death_old[kl.keeper[k]] > i) {
-            // a contained read has one killer per containing overlap: most minima are already there
-            uint32_t* d = &death_new[kl.target[k]];
-            if (__hip_atomic_load(d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > i) atomicMin(d, i);
+        uint32_t* d = &lo[kl.target[k]];
+        if (__hip_atomic_load(d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > i) atomicMin(d, i);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void death_decide_kernel(KillList in, const uint32_t* __restrict__ lo,
+                                                              const uint32_t* __restrict__ up, uint32_t* sure,
+                                                              KillList out) {
+    __shared__ uint32_t s_cnt, s_base;
+    const uint32_t n = *in.count;
+    const uint32_t lane = threadIdx.x & 63;
+    // grid-stride over chunks of one workgroup so that the append is aggregated per chunk
+    for (uint32_t k0 = blockIdx.x * kBlock; k0 < n; k0 += gridDim.x * kBlock) {
+        if (threadIdx.x == 0) s_cnt = 0;
+        __syncthreads();
+        const uint32_t k = k0 + threadIdx.x;
+        bool keep = false;
+        uint32_t i = 0, t = 0, kp = 0;
+        if (k < n) {
+            i = in.ovl[k]; t = in.target[k]; kp = in.keeper[k];
+            const uint32_t best = __hip_atomic_load(&sure[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (i < best) {
+                if (lo[kp] > i) atomicMin(&sure[t], i);
+                else if (up[kp] > i) keep = true;
+            }
         }
+        const uint64_t m = __ballot(keep);
+        uint32_t slot = 0;
+        if (m) {
+            if (lane == 0) slot = atomicAdd(&s_cnt, (uint32_t)__popcll(m));
+            slot = (uint32_t)__shfl((int)slot, 0, 64);
+        }
+        slot += (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        __syncthreads();
+        if (threadIdx.x == 0) s_base = s_cnt ? atomicAdd(out.count, s_cnt) : 0u;
+        __syncthreads();
+        if (keep) {
+            const uint32_t w = s_base + slot;
+            out.ovl[w] = i; out.target[w] = t; out.keeper[w] = kp;
+        }
+        __syncthreads();
     }
 }
 
@@ -631,9 +676,13 @@ void launch_classify(const OvlSoA& o, uint32_t n_reads, const uint8_t* valid, co
                            o, n_reads, valid, rec, cls, kl);
     }
 }
-void launch_death_round(const KillList& kl, const uint32_t* death_old, uint32_t* death_new, hipStream_t s) {
+void launch_death_lower(const KillList& kl, uint32_t* lo, hipStream_t s) {
     // the list length lives on the device: a fixed grid strides over it
-    hipLaunchKernelGGL(death_round_kernel, dim3(8192), dim3(kBlock), 0, s, kl, death_old, death_new);
+    hipLaunchKernelGGL(death_lower_kernel, dim3(4096), dim3(kBlock), 0, s, kl, lo);
+}
+void launch_death_decide(const KillList& in, const uint32_t* lo, const uint32_t* up, uint32_t* sure, const KillList& out,
+                         hipStream_t s) {
+    hipLaunchKernelGGL(death_decide_kernel, dim3(4096), dim3(kBlock), 0, s, in, lo, up, sure, out);
 }
 void launch_death_diff(const uint32_t* a, const uint32_t* b, uint32_t n, uint32_t* changed, hipStream_t s) {
     if (n) hipLaunchKernelGGL(death_diff_kernel, grid_for(n), dim3(kBlock), 0, s, a, b, n, changed);

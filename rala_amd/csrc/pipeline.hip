@@ -1514,34 +1514,46 @@ int rala_hip_construct(rala_hip_ctx* ctx, const rala_hip_overlaps* sens, uint64_
     launch_pack_reads(rs, n_reads, ctx->d_rec.p, s);
     launch_classify(ctx->ovl, n_reads, ctx->d_valid.p, ctx->d_rec.p, ctx->d_cls.p, kl, s);
     HIPCHECK(hipEventRecord(ctx->ev[5], s));
-    // ---- in-order containment removal as a fixed point ----
-    int cur = 0;
-    HIPCHECK(hipMemsetAsync(ctx->d_death[0].p, 0xFF, (size_t)n_reads * 4, s));
+    // ---- in-order containment removal as a fixed point (death_decide_kernel) ----
+    // d_death[0] = lower bound, d_death[1] = upper bound, d_death_sure = min over sure killers
+    for (int k = 0; k < 3; ++k) HIPCHECK(ctx->d_kill2[k].ensure(N));
+    HIPCHECK(ctx->d_death_sure.ensure(n_reads));
+    KillList klist[2] = {kl, kl};
+    klist[1].count = ctx->d_kill_count.p + 1;
+    klist[1].ovl = ctx->d_kill2[0].p; klist[1].target = ctx->d_kill2[1].p; klist[1].keeper = ctx->d_kill2[2].p;
+    uint32_t* lo = ctx->d_death[0].p;
+    uint32_t* up = ctx->d_death[1].p;
+    uint32_t* sure = ctx->d_death_sure.p;
+    const size_t dbytes = (size_t)n_reads * 4;
+    HIPCHECK(hipMemsetAsync(lo, 0xFF, dbytes, s));
+    HIPCHECK(hipMemsetAsync(up, 0xFF, dbytes, s));
+    HIPCHECK(hipMemsetAsync(sure, 0xFF, dbytes, s));
+    launch_death_lower(klist[0], lo, s);                         // first lower bound: everybody's first killer
     ctx->tm.death_rounds = 0;
-    HIPCHECK(ctx->d_cc_flags.ensure(8));
+    int cur = 0;
     for (;;) {
-        // rounds past the fixed point change nothing, so a few are run per host check
-        constexpr int kBatch = 3;
-        HIPCHECK(hipMemsetAsync(ctx->d_cc_flags.p, 0, kBatch * 4, s));
-        for (int k = 0; k < kBatch; ++k) {
-            HIPCHECK(hipMemsetAsync(ctx->d_death[cur ^ 1].p, 0xFF, (size_t)n_reads * 4, s));
-            launch_death_round(kl, ctx->d_death[cur].p, ctx->d_death[cur ^ 1].p, s);
-            launch_death_diff(ctx->d_death[cur].p, ctx->d_death[cur ^ 1].p, n_reads, ctx->d_cc_flags.p + k, s);
-            cur ^= 1;
-            ++ctx->tm.death_rounds;
-        }
-        uint32_t changed[kBatch];
-        HIPCHECK(d2h_small(ctx, changed, ctx->d_cc_flags.p, sizeof(changed), s));
+        HIPCHECK(hipMemsetAsync(klist[cur ^ 1].count, 0, 4, s));
+        launch_death_decide(klist[cur], lo, up, sure, klist[cur ^ 1], s);
+        uint32_t undecided = 0;
+        HIPCHECK(d2h_small(ctx, &undecided, klist[cur ^ 1].count, 4, s));
         HIPCHECK(stream_sync(ctx, s));
-        if (!changed[kBatch - 1]) break;
+        ++ctx->tm.death_rounds;
+        cur ^= 1;
+        if (getenv("RALA_HIP_TRACE")) fprintf(stderr, "[trace] containment round %d: %u undecided\n", (int)ctx->tm.death_rounds, undecided);
+        if (undecided == 0) break;
         if (ctx->tm.death_rounds > 100000) return fail(ctx, RALA_HIP_EDEVICE, "containment fixed point did not converge");
+        // tighter bounds: up = sure, lo = min(sure, undecided killers)
+        HIPCHECK(hipMemcpyAsync(up, sure, dbytes, hipMemcpyDeviceToDevice, s));
+        HIPCHECK(hipMemcpyAsync(lo, sure, dbytes, hipMemcpyDeviceToDevice, s));
+        launch_death_lower(klist[cur], lo, s);
     }
+    uint32_t* death = sure;
     HIPCHECK(hipEventRecord(ctx->ev[6], s));
     // ---- liveness, hill counters, survivors ----
     const uint32_t n_chunks = pass2_chunks(N);
-    launch_finish_pass2(ctx->ovl, ctx->d_cls.p, ctx->d_death[cur].p, ctx->d_rec.p, ctx->d_pool.p, ctx->d_chunk[0].p,
+    launch_finish_pass2(ctx->ovl, ctx->d_cls.p, death, ctx->d_rec.p, ctx->d_pool.p, ctx->d_chunk[0].p,
                         ctx->d_chunk[1].p, s);
-    launch_apply_death(ctx->d_death[cur].p, ctx->d_alive.p, n_reads, s);
+    launch_apply_death(death, ctx->d_alive.p, n_reads, s);
     uint32_t n_surv[2] = {0, 0};
     for (int k = 0; k < 2; ++k) {
         launch_exclusive_scan(ctx->d_chunk[k].p, ctx->d_chunk[2 + k].p, n_chunks, ctx->d_scan_ws.p, s);
