@@ -158,3 +158,63 @@ def test_cli_rejects_unknown_extension(tmp_path):
     exe = os.path.join(build.PKG, "host", "rala")
     r = subprocess.run([exe, "reads.txt", "ovl.paf"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     assert r.returncode == 1 and "unsupported format extension" in r.stderr
+
+
+def test_cli_other_formats(tmp_path):
+    """MHAP overlaps (reference overlap.cpp:12-20: 1-based ids, strand = a_rc != b_rc, length = the
+    longer span), gzip-compressed inputs and FASTQ reads give the same contigs as FASTA + PAF."""
+    import gzip
+
+    build.build_host()
+    exe = os.path.join(build.PKG, "host", "rala")
+    ds = Dataset(600, 120_000, 17)
+    fa = str(tmp_path / "reads.fasta")
+    paf = str(tmp_path / "ovl.paf")
+    ds.write_fasta(fa)
+    ds.write_paf(paf)
+    want = subprocess.run([exe, "-u", fa, paf], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert want.returncode == 0 and want.stdout.count(b">Ctg") > 0
+
+    # PAF -> MHAP: "a_id b_id error minmers a_rc a_begin a_end a_len b_rc b_begin b_end b_len", ids from 1
+    mhap = str(tmp_path / "ovl.mhap")
+    with open(paf) as src, open(mhap, "w") as dst:
+        for line in src:
+            f = line.split("\t")
+            a, b = int(f[0][1:]) + 1, int(f[5][1:]) + 1
+            rc = 0 if f[4] == "+" else 1
+            assert int(f[10]) == max(int(f[3]) - int(f[2]), int(f[8]) - int(f[7]))       # PAF col 11 = longer span
+            dst.write("%d %d 0.1 42 0 %s %s %s %d %s %s %s\n" % (a, b, f[2], f[3], f[1], rc, f[7], f[8], f[6]))
+    got = subprocess.run([exe, "-u", fa, mhap], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert got.returncode == 0, got.stderr.decode()
+    assert got.stdout == want.stdout
+
+    # gzip: reads and overlaps
+    for path in (fa, paf, mhap):
+        with open(path, "rb") as src, gzip.open(path + ".gz", "wb") as dst:
+            dst.write(src.read())
+    got = subprocess.run([exe, "-u", fa + ".gz", paf + ".gz"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert got.returncode == 0, got.stderr.decode()
+    assert got.stdout == want.stdout
+    got = subprocess.run([exe, "-u", fa + ".gz", mhap + ".gz"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert got.returncode == 0 and got.stdout == want.stdout
+
+    # FASTQ reads (four-line records)
+    fq = str(tmp_path / "reads.fastq")
+    names, seqs = _read_fasta(fa)
+    with open(fq, "wb") as dst:
+        for nm, sq in zip(names, seqs):
+            dst.write(b"@" + nm + b"\n" + sq + b"\n+\n" + b"I" * len(sq) + b"\n")
+    got = subprocess.run([exe, "-u", fq, paf], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert got.returncode == 0, got.stderr.decode()
+    assert got.stdout == want.stdout
+
+    # a PAF whose lengths disagree with the reads is fatal, with the reference's message
+    bad = str(tmp_path / "bad.paf")
+    with open(paf) as src, open(bad, "w") as dst:
+        lines = src.readlines()
+        f = lines[5].split("\t")
+        f[1] = str(int(f[1]) + 1)
+        lines[5] = "\t".join(f)
+        dst.writelines(lines)
+    got = subprocess.run([exe, fa, bad], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert got.returncode == 1 and b"unequal lengths in sequence and overlap file" in got.stderr
