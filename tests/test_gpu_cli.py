@@ -218,3 +218,46 @@ def test_cli_other_formats(tmp_path):
         dst.writelines(lines)
     got = subprocess.run([exe, fa, bad], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert got.returncode == 1 and b"unequal lengths in sequence and overlap file" in got.stderr
+
+
+def test_cli_sensitive_pass(tmp_path):
+    """rala -s <sensitive overlaps>: the two-pass workflow of the reference (main.cpp:76-94) - the
+    second overlap set is relative to the trimmed reads of the first pass."""
+    build.build_host()
+    exe = os.path.join(build.PKG, "host", "rala")
+    n, genome, seed = 6000, 1_600_000, 19
+    ds = Dataset(n, genome, seed)
+    fa = str(tmp_path / "reads.fasta")
+    paf = str(tmp_path / "ovl.paf")
+    sens_paf = str(tmp_path / "sens.paf")
+    ds.write_fasta(fa)
+    ds.write_paf(paf)
+
+    o = Oracle(ds.read_len, ds.overlaps, n_threads=8)
+    assert o.initialize() == 0
+    o.pass2()
+    o.preprocess_chimeras()
+    p = o.piles()
+    sens = ds.sensitive(p["alive"], p["begin"], p["end"])
+    assert len(sens) > 0
+    ds.write_paf(sens_paf, sensitive=True, target_len=(p["end"] - p["begin"]).astype(np.uint32))
+    o.preprocess_repeats(sens)
+    assert len(o.all_intervals(2)[1]) > 0             # the data set has repeat hills
+    o.build_graph()
+    pre = o.edges()
+    n_tr = o.remove_transitive_edges()
+    post = o.edges()
+    nodes = o.nodes()
+    want = _expected_layout(o, nodes, post, fa)
+    _simplify(want)
+    want.run("unitigs")
+    wn, _ = want.dump()
+    exp = [want.node_data(int(k)) for k in np.nonzero(wn["alive"])[0] if k % 2 == 0]
+
+    r = subprocess.run([exe, "-u", "-s", sens_paf, fa, paf], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    err = r.stderr.decode()
+    assert r.returncode == 0, err
+    assert "number of transitive edges = %d" % n_tr in err
+    assert "number of edges = %d" % len(pre["src"]) in err
+    lines = r.stdout.split(b"\n")
+    assert [lines[i + 1] for i in range(0, len(lines) - 1, 2)] == exp
