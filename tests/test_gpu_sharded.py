@@ -171,3 +171,28 @@ def test_sharded_device_path_matches_oracle(hip_ctx_factory, world, n, g, seed):
     cg.construct()
     parity.check_construct(cg, st)
     parity.check_tr(cg, st)
+
+
+def test_sharded_runner_through_rccl_world1(tmp_path):
+    """bench.py's WORLD_SIZE > 1 runner (rala_amd/multi.py ShardedRunner: RCCL all-to-all and
+    all-gathers, device-to-device state import) launched through torch.distributed.run with one
+    rank: same transitive-pair count as the single-context path."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RALA_FORCE_SHARDED="1")
+    base = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--workload", "c2", "--steps", "1",
+            "--warmup", "1", "--no-cpu-baseline"]
+    single = subprocess.run(base, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=root)
+    assert single.returncode == 0, single.stderr.decode()[-2000:]
+    want = json.loads(single.stdout.decode().strip().splitlines()[-1])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", "29547"] + base[1:]
+    sharded = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=root, env=env)
+    assert sharded.returncode == 0, sharded.stderr.decode()[-2000:]
+    got = json.loads(sharded.stdout.decode().strip().splitlines()[-1])
+    assert got["config"]["transitive_pairs"] == want["config"]["transitive_pairs"] > 0
+    assert "exchange_ms" in got["stage_ms"] and "gather_ms" in got["stage_ms"]
