@@ -1,5 +1,5 @@
 """Differential fuzzing of the HIP path against the oracle on random synthetic data sets
-(python tools/fuzz_parity.py [n_cases] [first_seed]); prints one line per case, exits 1 on a
+(python tests/fuzz_parity.py [n_cases] [first_seed]); prints one line per case, exits 1 on a
 mismatch."""
 import os
 import sys
