@@ -307,11 +307,15 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
             ((uint4*)bm)[lane] = make_uint4(0, 0, 0, 0);
             ((uint4*)bm)[lane + 64] = make_uint4(0, 0, 0, 0);
             for (uint32_t k = lane; 2 * k < n_ev + 3; k += 64) delta[k] = 0x80008000u;
+            // all loads first, unconditionally (clamped index), so that they are in flight together:
+            // a load per predicated block would be waited for one by one
             uint32_t evr[kCap / 64];
+            const uint32_t e_last = n_ev ? n_ev - 1 : 0;
+#pragma unroll
+            for (uint32_t t = 0; t < kCap / 64; ++t) evr[t] = rev[umin(t * 64 + lane, e_last)];
 #pragma unroll
             for (uint32_t t = 0; t < kCap / 64; ++t) {
-                const uint32_t e = t * 64 + lane;
-                evr[t] = e < n_ev ? rev[e] : kNone;
+                if (t * 64 + lane >= n_ev) evr[t] = kNone;
             }
             wave_sync();
 #pragma unroll
