@@ -18,10 +18,6 @@ namespace {
 constexpr int kBlock = 256;
 constexpr uint32_t kInf = 0xFFFFFFFFu;
 
-__device__ __forceinline__ bool transmutable(const OvlSoA& o, uint64_t i, uint32_t n_reads) {
-    return o.a_id[i] < n_reads && o.b_id[i] < n_reads;
-}
-
 // One thread per overlap.  Within a maximal run of equal a_id (records whose
 // names do not resolve are skipped and do not break a run), per b_id exactly
 // the last occurrence of the greatest length stays valid; self overlaps are

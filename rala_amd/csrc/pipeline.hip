@@ -190,11 +190,6 @@ uint64_t retrim(rala_hip_ctx* ctx, std::vector<HostOvl>& v) {
     return total;
 }
 
-uint32_t cached_type(rala_hip_ctx* ctx, HostOvl& o) {
-    if (o.type == 255) o.type = (uint8_t)host_type(ctx, o);
-    return o.type;
-}
-
 // flags only (callable from pool threads, one read per thread); collect_dirty() lists them
 void mark_dirty(rala_hip_ctx* ctx, uint32_t r) {
     ctx->dirty[r] = 1;
