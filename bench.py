@@ -192,7 +192,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": WORKLOADS[args.workload], "n_reads": ds.n_reads, "n_overlaps": n_ovl,
                        "sum_read_len": sum_len, "transitive_pairs": int(n_tr)},
-            "roofline": {"bound": "hbm", "kernel": "pile_runs_kernel<512|2048> + pile_build_annotate (overflow chain)", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": "pile_runs_kernel<512|1024|2048> + pile_build_annotate (overflow chain)", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "algorithmic_bytes": pile_bytes, "kernel_ms": pile_ms,
                          # the whole pile stage (dedupe + bucketing + pile kernels)

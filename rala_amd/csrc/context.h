@@ -148,6 +148,7 @@ struct rala_hip_ctx {
     std::vector<uint16_t> h_median, h_p10;
     std::vector<uint8_t> h_alive, h_n_pits, h_n_hills;
     std::vector<rala_hip::Interval> h_pool;
+    rala_hip::DevBuf<uint32_t> d_overflow_mid, d_chain_cnt;      // third overflow list / chain counters
     rala_hip::DevBuf<double> d_layout[4];
     rala_hip::DevBuf<uint32_t> d_layout_adj[2];
     // pinned staging of small device -> host reads (pipeline.hip: d2h_small / stream_sync)

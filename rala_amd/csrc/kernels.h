@@ -58,12 +58,13 @@ void launch_pile_build_annotate(const PileArgs& args, uint32_t grid, bool in_lds
 
 // run-space kernel (pile_runs_kernel.hip): one wavefront per read; reads with more bound
 // events than the instantiation's cap are appended to overflow_list instead (args.order may
-// be null = identity).  Two instantiations: kRunEventCap (registers-only sort) and
-// kRunEventCapBig.
+// be null = identity).  Three instantiations (tier 0, 1, 2): the larger ones keep longer lists in
+// LDS and run at lower occupancy.
 constexpr uint32_t kRunEventCap = 512;
+constexpr uint32_t kRunEventCapMid = 1024;
 constexpr uint32_t kRunEventCapBig = 2048;
-void launch_pile_runs(const PileArgs& args, uint32_t grid, bool big_cap, uint32_t* overflow_list,
-                      uint32_t* overflow_count, hipStream_t stream);
+void launch_pile_runs(const PileArgs& args, uint32_t grid, int tier, uint32_t* overflow_list, uint32_t* overflow_count,
+                      hipStream_t stream);
 
 // sensitive pass (pile_repeats_kernel.hip): mode 1 = add layers on top + median for the
 // targets; mode 2 = repeat hills for the members of connected components

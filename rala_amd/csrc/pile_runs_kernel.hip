@@ -230,12 +230,13 @@ __device__ __forceinline__ void load_sort_store(const uint32_t* __restrict__ gev
 template <uint32_t kCap>
 struct Layout {
     // list capacities: a read that needs more goes to the next kernel of the chain
-    static constexpr uint32_t kMaxReg = kCap <= 512 ? 16 : 64;   // regions per (q, kind) list
-    static constexpr uint32_t kMaxRaw = kCap <= 512 ? 8 : 32;    // pits / hills before the merge
+    // three instantiations: 512 events (almost every read), 1024 (high coverage), 2048 (the rest)
+    static constexpr uint32_t kMaxReg = kCap <= 512 ? 16 : kCap <= 1024 ? 32 : 64;   // regions per (q, kind) list
+    static constexpr uint32_t kMaxRaw = kCap <= 512 ? 8 : kCap <= 1024 ? 16 : 32;    // pits / hills before the merge
     static constexpr uint32_t kArr = kCap + 4;                  // entries per run-indexed array
     static constexpr uint32_t kIdx = kCap <= 512 ? 256 : 512;   // entries of the position -> run index
     // runs that survive the slope filter (k and four uint16 offsets each) + block maxima
-    static constexpr uint32_t kSurv = kCap <= 512 ? 192 : kArr;
+    static constexpr uint32_t kSurv = kCap <= 512 ? 192 : kCap <= 1024 ? 384 : kArr;
     static constexpr uint32_t kBm8 = kArr / 8 + 8;
     static constexpr uint32_t kSlopeWords = (5 * kSurv + 1) / 2 + kBm8;
     // X: events (sort) -> bitmap + prefix -> group counts -> histograms -> slope survivors
@@ -296,14 +297,14 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
         // instantiation) sort their events and sweep, as the reference does.
         uint32_t R;
         constexpr uint32_t kBitmapBases = 16384;
-        const bool bitmap_path = kCap == 512 && n <= kBitmapBases;
+        const bool bitmap_path = kCap <= 1024 && n <= kBitmapBases;
         if (bitmap_path) {
             uint32_t* bm = sm + L::X;
             uint16_t* pref = (uint16_t*)(bm + kBitmapBases / 32);
             // per-run sums of +-1, two per word, biased by 0x8000 so that a subtraction never
             // borrows from the neighbour (at most kCap events meet at one position)
             uint32_t* delta = sm + L::RF;
-            static_assert(kCap != 512 || L::SEL - L::RF >= L::kArr / 2 + 2, "scratch for the per-run sums");
+            static_assert(kCap > 1024 || L::SEL - L::RF >= L::kArr / 2 + 2, "scratch for the per-run sums");
             ((uint4*)bm)[lane] = make_uint4(0, 0, 0, 0);
             ((uint4*)bm)[lane + 64] = make_uint4(0, 0, 0, 0);
             for (uint32_t k = lane; 2 * k < n_ev + 3; k += 64) delta[k] = 0x80008000u;
@@ -1044,21 +1045,19 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
 #undef RUN_STOP
 }
 
-void launch_pile_runs(const PileArgs& args, uint32_t grid, bool big_cap, uint32_t* overflow_list,
-                      uint32_t* overflow_count, hipStream_t stream) {
+void launch_pile_runs(const PileArgs& args, uint32_t grid, int tier, uint32_t* overflow_list, uint32_t* overflow_count,
+                      hipStream_t stream) {
     if (grid == 0) return;
     // diagnostics: extra dynamic LDS lowers the occupancy (sensitivity experiments)
     static const uint32_t extra_lds = getenv("RALA_PILE_EXTRA_LDS") ? (uint32_t)atoi(getenv("RALA_PILE_EXTRA_LDS")) : 0u;
-    if (!big_cap && extra_lds) {
+    if (tier == 0) {
         hipLaunchKernelGGL(pile_runs_kernel<kRunEventCap>, dim3(grid), dim3(64), extra_lds, stream, args, overflow_list,
                            overflow_count);
-        return;
-    }
-    if (big_cap) {
-        hipLaunchKernelGGL(pile_runs_kernel<kRunEventCapBig>, dim3(grid), dim3(64), 0, stream, args, overflow_list,
+    } else if (tier == 1) {
+        hipLaunchKernelGGL(pile_runs_kernel<kRunEventCapMid>, dim3(grid), dim3(64), 0, stream, args, overflow_list,
                            overflow_count);
     } else {
-        hipLaunchKernelGGL(pile_runs_kernel<kRunEventCap>, dim3(grid), dim3(64), 0, stream, args, overflow_list,
+        hipLaunchKernelGGL(pile_runs_kernel<kRunEventCapBig>, dim3(grid), dim3(64), 0, stream, args, overflow_list,
                            overflow_count);
     }
 }
