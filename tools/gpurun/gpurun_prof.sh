@@ -18,7 +18,8 @@ for name in ("fetch", "write"):
         for row in csv.DictReader(open(f)):
             k = row["Kernel_Name"]
             if "pile_runs_kernel" in k or "pile_build_annotate" in k:
-                short = "pile_runs_kernel<512>" if "512" in k else "pile_runs_kernel<2048>" if "2048" in k else "pile_build_annotate"
+                short = ("pile_runs_kernel<512>" if "<512" in k else "pile_runs_kernel<1024>" if "<1024" in k else
+                         "pile_runs_kernel<2048>" if "<2048" in k else "pile_build_annotate")
                 acc[short] += float(row["Counter_Value"]); cnt[short] += 1
     tot[name] = dict(acc)
     print(name, dict(acc), dict(cnt))
