@@ -88,7 +88,8 @@ def test_sharded_initialize_matches_oracle(hip_ctx_factory, world, n, g, seed):
 
 
 @pytest.mark.parametrize("world", [2, 3, 8])
-@pytest.mark.parametrize("n,g,seed", [(1000, 200_000, 1), (2000, 1_200_000, 33)])
+@pytest.mark.parametrize("n,g,seed", [(1000, 200_000, 1), (2000, 1_200_000, 33),
+                                      (1500, 12_000, 3)])      # ~750x: reads beyond a fixed event slot
 def test_sharded_device_path_matches_oracle(hip_ctx_factory, world, n, g, seed):
     """The path bench.py runs for WORLD_SIZE > 1 (ShardedRunner.step): owner-grouped tuples
     straight from the kernel, packed per-read state and interval pools gathered device to
