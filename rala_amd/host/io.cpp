@@ -279,7 +279,7 @@ bool read_paf_parallel(const std::string& path, const NameTable& names, const st
     if (fstat(fd, &st) != 0) { close(fd); return false; }
     const size_t size = (size_t)st.st_size;
     if (size == 0) { close(fd); return true; }
-    void* map = mmap(nullptr, size, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
+    void* map = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);     // pages are touched by the parsing threads
     close(fd);
     if (map == MAP_FAILED) return false;
     madvise(map, size, MADV_SEQUENTIAL);

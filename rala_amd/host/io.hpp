@@ -5,7 +5,9 @@
 
 #include <stdint.h>
 #include <functional>
+#include <memory>
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace rala {
@@ -48,9 +50,22 @@ private:
     uint64_t mask_ = 0;
 };
 
+// allocator whose resize() leaves new elements uninitialised (the readers overwrite all of them;
+// zero-filling 29 bytes per overlap on one thread would cost as much as parsing)
+template <class T>
+struct UninitAllocator : std::allocator<T> {
+    template <class U> struct rebind { typedef UninitAllocator<U> other; };
+    UninitAllocator() = default;
+    template <class U> UninitAllocator(const UninitAllocator<U>&) {}
+    template <class U> void construct(U* p) { ::new ((void*)p) U; }
+    template <class U, class... A> void construct(U* p, A&&... a) { ::new ((void*)p) U(std::forward<A>(a)...); }
+};
+
 struct OverlapColumns {
-    std::vector<uint32_t> a_id, b_id, a_begin, a_end, b_begin, b_end, length;
-    std::vector<uint8_t> strand;
+    typedef std::vector<uint32_t, UninitAllocator<uint32_t>> U32;
+    typedef std::vector<uint8_t, UninitAllocator<uint8_t>> U8;
+    U32 a_id, b_id, a_begin, a_end, b_begin, b_end, length;
+    U8 strand;
     size_t size() const { return a_id.size(); }
 };
 
