@@ -165,7 +165,6 @@ bool read_mhap(const std::string& path, const std::function<void(const MhapRecor
 
 // ---- multi-threaded PAF ingest -----------------------------------------------------------------
 #include <fcntl.h>
-#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -279,30 +278,53 @@ bool read_paf_parallel(const std::string& path, const NameTable& names, const st
     if (fstat(fd, &st) != 0) { close(fd); return false; }
     const size_t size = (size_t)st.st_size;
     if (size == 0) { close(fd); return true; }
-    void* map = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);     // pages are touched by the parsing threads
-    close(fd);
-    if (map == MAP_FAILED) return false;
-    madvise(map, size, MADV_SEQUENTIAL);
-    const char* base = (const char*)map;
 
+    // one chunk of the file per thread, read with pread into the thread's own buffer (page faults
+    // of a shared mapping serialise on the address-space lock when many threads take them)
     const uint32_t T = (uint32_t)std::max<size_t>(1, std::min<size_t>(std::max(1u, num_threads), size / (1 << 20) + 1));
     std::vector<Chunk> chunks(T);
+    std::vector<int> failed(T, 0);
     auto work = [&](uint32_t t) {
-        size_t lo = size * t / T, hi = size * (t + 1) / T;
-        // a chunk owns the lines that start inside it
+        const size_t lo = size * t / T, hi = size * (t + 1) / T;
+        // a chunk owns the lines that start inside [lo, hi); the last of them may end beyond hi
+        const size_t from = lo ? lo - 1 : 0;
+        std::vector<char, UninitAllocator<char>> buf;
+        size_t have = 0, want = (hi - from) + (1 << 16);
+        bool eof = false;
+        auto fill = [&](size_t upto) {
+            upto = std::min(upto, size - from);
+            if (buf.size() < upto) buf.resize(upto);
+            while (have < upto) {
+                const ssize_t n = pread(fd, buf.data() + have, upto - have, (off_t)(from + have));
+                if (n <= 0) { failed[t] = 1; eof = true; return; }
+                have += (size_t)n;
+            }
+            if (from + have >= size) eof = true;
+        };
+        fill(want);
+        if (failed[t]) return;
+        const char* base = buf.data() - from;          // base[x] = byte x of the file
+        size_t p = lo;
         if (t > 0) {
-            const char* nl = (const char*)memchr(base + lo - 1, '\n', size - (lo - 1));
-            lo = nl ? (size_t)(nl - base) + 1 : size;
+            const char* nl = (const char*)memchr(buf.data(), '\n', have);
+            // no newline in the whole chunk: the line belongs to an earlier chunk
+            if (!nl) { if (!eof) { /* a line longer than the chunk + 64 KiB: not a PAF record */ } return; }
+            p = (size_t)(nl - buf.data()) + from + 1;
         }
         Chunk& c = chunks[t];
         const size_t guess = (hi > lo ? hi - lo : 0) / 48 + 16;      // a PAF line is rarely shorter
         c.cols.a_id.reserve(guess); c.cols.b_id.reserve(guess); c.cols.a_begin.reserve(guess);
         c.cols.a_end.reserve(guess); c.cols.b_begin.reserve(guess); c.cols.b_end.reserve(guess);
         c.cols.length.reserve(guess); c.cols.strand.reserve(guess);
-        size_t p = lo;
         while (p < hi) {
-            const char* nl = (const char*)memchr(base + p, '\n', size - p);
-            size_t e = nl ? (size_t)(nl - base) : size;
+            const char* nl = (const char*)memchr(base + p, '\n', from + have - p);
+            while (!nl && !eof) {                      // the line runs past what was read
+                fill(have + (1 << 20));
+                if (failed[t]) return;
+                base = buf.data() - from;
+                nl = (const char*)memchr(base + p, '\n', from + have - p);
+            }
+            const size_t e = nl ? (size_t)(nl - base) : from + have;
             size_t le = e;
             if (le > p && base[le - 1] == '\r') --le;
             if (le > p) parse_paf_line(base + p, base + le, names, read_len, check_target_length, c);
@@ -313,7 +335,8 @@ bool read_paf_parallel(const std::string& path, const NameTable& names, const st
     for (uint32_t t = 1; t < T; ++t) threads.emplace_back(work, t);
     work(0);
     for (auto& th : threads) th.join();
-    munmap(map, size);
+    close(fd);
+    for (uint32_t t = 0; t < T; ++t) if (failed[t]) return false;
 
     size_t total = out.size();
     for (const auto& c : chunks) total += c.cols.size();
