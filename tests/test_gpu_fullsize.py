@@ -54,7 +54,7 @@ def run(ctx_factory, ds, **options):
     return ctx
 
 
-def stage_digests(ctx):
+def stage_digests(ctx, with_data=True):
     out = {}
     p = ctx.piles()
     out["valid"] = dg(np.packbits(ctx.valid()))
@@ -62,9 +62,10 @@ def stage_digests(ctx):
     for kind, name in ((0, "pits0"), (1, "hills0")):
         offs, pairs, _aux = ctx.intervals(kind)
         out[name] = dg(offs.astype(np.uint64), pairs.astype(np.uint32))
-    reads = sample_reads(p["alive"])
-    out["data_reads"] = dg(reads.astype(np.int64))
-    out["data0"] = dg(*[np.asarray(ctx.pile_data(int(r)), dtype=np.uint16) for r in reads])
+    if with_data:
+        reads = sample_reads(p["alive"])
+        out["data_reads"] = dg(reads.astype(np.int64))
+        out["data0"] = dg(*[np.asarray(ctx.pile_data(int(r)), dtype=np.uint16) for r in reads])
     ctx.construct()
     p2 = ctx.piles()
     out["piles2"] = dg(p2["begin"], p2["end"], p2["alive"])
@@ -148,3 +149,20 @@ def test_fullsize_properties(hip_ctx_factory, wl):
     h = again.graph()
     for k in ("node_read", "src", "dst", "len", "marked"):
         assert (g[k] == h[k]).all(), k
+
+
+@pytest.mark.parametrize("wl,world", [("c2", 4), ("c3", 8)])
+def test_fullsize_sharded_decomposition(hip_ctx_factory, wl, world):
+    """The multi-GPU decomposition (ranks played one after the other on this GPU, same C-ABI
+    calls as rala_amd/multi.py) at full size: every stage digest equals the oracle's."""
+    from test_gpu_sharded import simulate_sharded
+
+    path = os.path.join(HERE, "golden", "fullsize_%s.json" % wl)
+    if not os.path.exists(path):
+        pytest.skip("no digest file for %s" % wl)
+    want = json.load(open(path))
+    ds = dataset(wl)
+    cg = simulate_sharded(hip_ctx_factory, ds, world)
+    got = stage_digests(cg, with_data=False)         # the coverage vectors live on the owner ranks
+    for k, v in got.items():
+        assert v == want[k], "%s sharded over %d ranks: stage %s differs from the oracle" % (wl, world, k)

@@ -87,16 +87,13 @@ def test_sharded_initialize_matches_oracle(hip_ctx_factory, world, n, g, seed):
     parity.check_tr(cg, st)
 
 
-@pytest.mark.parametrize("world", [2, 3, 8])
-@pytest.mark.parametrize("n,g,seed", [(1000, 200_000, 1), (2000, 1_200_000, 33),
-                                      (1500, 12_000, 3)])      # ~750x: reads beyond a fixed event slot
-def test_sharded_device_path_matches_oracle(hip_ctx_factory, world, n, g, seed):
-    """The path bench.py runs for WORLD_SIZE > 1 (ShardedRunner.step): owner-grouped tuples
-    straight from the kernel, packed per-read state and interval pools gathered device to
-    device, rala_hip_import_state_device."""
-    ds = Dataset(n, g, seed)
-    st = parity.oracle_stages(ds)
+def simulate_sharded(hip_ctx_factory, ds, world, check_buckets=False):
+    """The path bench.py runs for WORLD_SIZE > 1 (ShardedRunner.step) with the ranks played one
+    after the other on one GPU: owner-grouped tuples straight from the kernel, packed per-read
+    state and interval pools "gathered" device to device, rala_hip_import_state_device.  Returns
+    the context that holds all reads and overlaps, state imported."""
     ov = ds.overlaps
+    n = ds.n_reads
     cuts = multi.slice_starts(ov.a_id, world)
     dev = torch.device("cuda", 0)
     sent, valid_parts = [], []
@@ -109,20 +106,21 @@ def test_sharded_device_path_matches_oracle(hip_ctx_factory, world, n, g, seed):
         t_r = torch.empty(4 * max(1, len(sl)), dtype=torch.int32, device=dev)
         t_b = torch.empty_like(t_r)
         counts = cs.emit_bound_tuples_bucketed(world, t_r.data_ptr(), t_b.data_ptr())
-        # the buckets hold exactly the tuples of the unbucketed emission
-        u_r, u_b = torch.empty_like(t_r), torch.empty_like(t_b)
-        cs.emit_bound_tuples(u_r.data_ptr(), u_b.data_ptr())
-        ur = u_r[: 4 * len(sl)].cpu().numpy().view(np.uint32).astype(np.int64)
-        ub = u_b[: 4 * len(sl)].cpu().numpy().view(np.uint32).astype(np.int64)
-        keep = ur != multi.NO_READ
-        off = 0
-        for p in range(world):
-            c = int(counts[p])
-            got = sorted(zip(t_r[off: off + c].cpu().numpy().view(np.uint32).tolist(),
-                             t_b[off: off + c].cpu().numpy().view(np.uint32).tolist()))
-            m = keep & (ur % world == p)
-            assert got == sorted(zip((ur[m] // world).tolist(), ub[m].tolist()))
-            off += c
+        if check_buckets:
+            # the buckets hold exactly the tuples of the unbucketed emission
+            u_r, u_b = torch.empty_like(t_r), torch.empty_like(t_b)
+            cs.emit_bound_tuples(u_r.data_ptr(), u_b.data_ptr())
+            ur = u_r[: 4 * len(sl)].cpu().numpy().view(np.uint32).astype(np.int64)
+            ub = u_b[: 4 * len(sl)].cpu().numpy().view(np.uint32).astype(np.int64)
+            keep = ur != multi.NO_READ
+            off = 0
+            for p in range(world):
+                c = int(counts[p])
+                got = sorted(zip(t_r[off: off + c].cpu().numpy().view(np.uint32).tolist(),
+                                 t_b[off: off + c].cpu().numpy().view(np.uint32).tolist()))
+                m = keep & (ur % world == p)
+                assert got == sorted(zip((ur[m] // world).tolist(), ub[m].tolist()))
+                off += c
         sent.append((t_r, t_b, counts))
         v = torch.empty(max(1, len(sl)), dtype=torch.uint8, device=dev)
         if len(sl):
@@ -150,6 +148,7 @@ def test_sharded_device_path_matches_oracle(hip_ctx_factory, world, n, g, seed):
         cl.copy_device_state(pool=pool.data_ptr(), pool_count=n_pool,
                              **{f: rows[k].data_ptr() + o for f, o in off_f.items()})
         pools.append(pool[: n_pool * multi.POOL_RECORD])
+        cl.close()
     counts = [p.numel() // multi.POOL_RECORD for p in pools]
     state = multi.unpack_state(rows, nl, n, counts)
     pool_all = torch.cat(pools)
@@ -160,6 +159,16 @@ def test_sharded_device_path_matches_oracle(hip_ctx_factory, world, n, g, seed):
     cg.set_overlaps(ov)
     cg.import_state_device(pool=pool_all.data_ptr(), pool_count=sum(counts), valid=valid.data_ptr(),
                            **{f: t.data_ptr() for f, t in state.items()})
+    return cg
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+@pytest.mark.parametrize("n,g,seed", [(1000, 200_000, 1), (2000, 1_200_000, 33),
+                                      (1500, 12_000, 3)])      # ~750x: reads beyond a fixed event slot
+def test_sharded_device_path_matches_oracle(hip_ctx_factory, world, n, g, seed):
+    ds = Dataset(n, g, seed)
+    st = parity.oracle_stages(ds)
+    cg = simulate_sharded(hip_ctx_factory, ds, world, check_buckets=True)
     parity.assert_same("valid", cg.valid(), st["valid"])
     p = cg.piles()
     for key in ("begin", "end", "median", "p10", "alive"):
