@@ -84,6 +84,12 @@ def build_host(force=False):
     ag_srcs = [os.path.join(d, f) for f in ("assembly_graph.cpp", "assembly_graph_capi.cpp", "io.cpp", "io_capi.cpp")]
     if force or _stale(ag, ag_srcs + [os.path.join(d, "assembly_graph.hpp"), os.path.join(d, "io.hpp")]):
         _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I" + d, "-o", ag] + ag_srcs + ["-lz"])
+    # C entry points over stand-alone Pile / Overlap objects (tests of the class interface)
+    api = os.path.join(d, "librala_api.so")
+    api_src = os.path.join(d, "host_api_capi.cpp")
+    if force or _stale(api, deps):
+        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I" + os.path.join(ROOT, "include"),
+              "-I" + d, "-o", api, api_src, out, "-Wl,-rpath," + d, "-Wl,-rpath," + os.path.join(PKG, "csrc")])
     exe = os.path.join(d, "rala")
     main = os.path.join(d, "main.cpp")
     if os.path.exists(main) and (force or _stale(exe, deps)):

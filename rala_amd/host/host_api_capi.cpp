@@ -1,0 +1,111 @@
+/*!
+ * @file host_api_capi.cpp
+ *
+ * @brief C entry points over stand-alone rala::Pile / rala::Overlap objects, for the tests that
+ * drive the class interface the way the reference's Graph::initialize does (createPile,
+ * add_layers, find_valid_region, find_median, find_chimeric_hills, find_chimeric_pits,
+ * break_over_*, Overlap::transmute / trim / type; reference src/pile.hpp:19-170,
+ * src/overlap.hpp:27-117).  Built into rala_amd/host/librala_api.so; not part of librala.so.
+ */
+
+#include <stdint.h>
+
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "overlap.hpp"
+#include "pile.hpp"
+
+namespace {
+
+struct Handle {
+    std::vector<std::unique_ptr<rala::Pile>> piles;
+    std::unordered_map<std::string, uint64_t> name_to_id;
+    std::vector<uint32_t> length;
+};
+
+std::string read_name(uint64_t r) { return "read_" + std::to_string(r); }
+
+}  // namespace
+
+extern "C" {
+
+void* hp_create(const uint32_t* read_len, uint64_t n) {
+    Handle* h = new Handle();
+    for (uint64_t r = 0; r < n; ++r) {
+        h->piles.emplace_back(rala::createPile(r, read_len[r]));
+        h->name_to_id[read_name(r)] = r;
+        h->length.push_back(read_len[r]);
+    }
+    return h;
+}
+
+void hp_destroy(void* p) { delete (Handle*)p; }
+
+void hp_add_layers(void* p, uint64_t r, const uint32_t* bounds, uint64_t n) {
+    std::vector<uint32_t> b(bounds, bounds + n);
+    ((Handle*)p)->piles[r]->add_layers(b);
+}
+
+int hp_find_valid_region(void* p, uint64_t r) { return ((Handle*)p)->piles[r]->find_valid_region() ? 1 : 0; }
+void hp_find_median(void* p, uint64_t r) { ((Handle*)p)->piles[r]->find_median(); }
+void hp_find_chimeric_hills(void* p, uint64_t r) { ((Handle*)p)->piles[r]->find_chimeric_hills(); }
+void hp_find_chimeric_pits(void* p, uint64_t r) { ((Handle*)p)->piles[r]->find_chimeric_pits(); }
+int hp_break_over_chimeric_pits(void* p, uint64_t r, uint16_t median) {
+    return ((Handle*)p)->piles[r]->break_over_chimeric_pits(median) ? 1 : 0;
+}
+int hp_break_over_chimeric_hills(void* p, uint64_t r) {
+    return ((Handle*)p)->piles[r]->break_over_chimeric_hills() ? 1 : 0;
+}
+int hp_shrink(void* p, uint64_t r, uint32_t begin, uint32_t end) {
+    return ((Handle*)p)->piles[r]->shrink(begin, end) ? 1 : 0;
+}
+/*! @brief Graph::initialize drops a pile whose valid region is too short (graph.cpp:396-399) */
+void hp_reset(void* p, uint64_t r) { ((Handle*)p)->piles[r].reset(); }
+
+/*! @brief out = {alive, begin, end, median, p10, has_chimeric_pit, has_chimeric_hill} */
+void hp_get(void* p, uint64_t r, uint32_t* out) {
+    const auto& pile = ((Handle*)p)->piles[r];
+    for (int i = 0; i < 7; ++i) out[i] = 0;
+    if (pile == nullptr) return;
+    out[0] = 1; out[1] = pile->begin(); out[2] = pile->end(); out[3] = pile->median(); out[4] = pile->p10();
+    out[5] = pile->has_chimeric_pit(); out[6] = pile->has_chimeric_hill();
+}
+
+uint64_t hp_data(void* p, uint64_t r, uint16_t* out) {
+    const auto& pile = ((Handle*)p)->piles[r];
+    if (pile == nullptr) return 0;
+    const std::vector<uint16_t>& d = pile->data();
+    for (size_t i = 0; i < d.size(); ++i) out[i] = d[i];
+    return d.size();
+}
+
+/*!
+ * @brief one PAF record against the current piles: createOverlap, transmute, trim, type.
+ * coords = {a_begin, a_end, b_begin, b_end, length} in / out.  Returns 0 when transmute or
+ * trim drops the overlap.
+ */
+int hp_overlap_trim_type(void* p, uint32_t a, uint32_t b, uint32_t strand, uint32_t* coords, int* type_out) {
+    Handle* h = (Handle*)p;
+    auto o = rala::createOverlap(read_name(a), h->length[a], coords[0], coords[1], strand ? '-' : '+',
+        read_name(b), h->length[b], coords[2], coords[3], coords[4]);
+    if (!o->transmute(h->piles, h->name_to_id)) return 0;
+    if (o->a_id() != a || o->b_id() != b || o->orientation() != strand) return -1;
+    if (!o->trim(h->piles)) return 0;
+    coords[0] = o->a_begin(); coords[1] = o->a_end(); coords[2] = o->b_begin(); coords[3] = o->b_end();
+    coords[4] = o->length();
+    *type_out = (int)o->type(h->piles);
+    return 1;
+}
+
+/*! @brief an MHAP record (1-based ids): the fields createOverlap derives */
+int hp_overlap_from_mhap(uint64_t a_id, uint64_t b_id, uint32_t a_rc, uint32_t a_begin, uint32_t a_end,
+    uint32_t a_length, uint32_t b_rc, uint32_t b_begin, uint32_t b_end, uint32_t b_length, uint32_t* out) {
+    auto o = rala::createOverlap(a_id, b_id, a_rc, a_begin, a_end, a_length, b_rc, b_begin, b_end, b_length);
+    out[0] = o->a_id(); out[1] = o->b_id(); out[2] = o->length(); out[3] = o->orientation();
+    return 0;
+}
+
+}  // extern "C"

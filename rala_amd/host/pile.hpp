@@ -9,6 +9,11 @@
  * once (Graph::initialize order, reference src/graph.cpp:387-407) and each method then
  * publishes its part of the result.  Piles owned by a Graph are views of the Graph's
  * context.  There is no CPU implementation behind these methods.
+ *
+ * add_layers() may be called several times; every call must hold whole overlaps (a begin
+ * bound and its end bound), which is what Graph::store_overlap_bounds produces
+ * (reference src/graph.cpp:311-326).  The reference sweeps each call on its own, so a
+ * call with unmatched bounds gives a different pile there than the union does here.
  */
 
 #pragma once
