@@ -1,6 +1,8 @@
 """Differential fuzzing of the HIP path against the oracle on random synthetic data sets
 (python tests/fuzz_parity.py [n_cases] [first_seed]); prints one line per case, exits 1 on a
-mismatch."""
+mismatch.  Besides size, coverage and plants a case may scale every coordinate (reads beyond the
+position bitmap / beyond 65535 bases), shuffle the runs and add duplicates, unresolved names and
+self overlaps, and run the sensitive pass (-s) on top."""
 import os
 import sys
 
@@ -12,6 +14,8 @@ import numpy as np
 from rala_amd import hip
 from rala_amd.synth import Dataset
 import parity
+from test_gpu_parity import _Scaled, _shuffled_with_duplicates
+from oracle.oracle import Oracle
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 first = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
@@ -25,6 +29,15 @@ for case in range(n_cases):
     plants = int(rng.integers(0, 16))
     try:
         ds = Dataset(n, g, seed, plants)
+        variant = []
+        if rng.random() < 0.25:
+            ds = _shuffled_with_duplicates(ds, seed)
+            variant.append("shuffled")
+        if rng.random() < 0.2:
+            f = int(rng.choice([2, 3, 7]))
+            ds = _Scaled(ds, f)
+            variant.append("x%d" % f)
+        sens_case = hasattr(ds, "sensitive") and rng.random() < 0.3
         st = parity.oracle_stages(ds, n_threads=os.cpu_count() or 8)
         ctx = hip.Context(0)
         ctx.set_option("use_run_kernel", int(rng.random() < 0.85))
@@ -42,12 +55,39 @@ for case in range(n_cases):
             continue
         assert rc == 0, rc
         parity.check_initialize(ctx, st, ds)
-        ctx.construct()
-        parity.check_construct(ctx, st)
-        parity.check_tr(ctx, st)
+        if sens_case:
+            variant.append("sensitive")
+            ctx.set_option("use_gpu_tail", int(rng.random() < 0.7))
+            o = Oracle(ds.read_len, ds.overlaps, n_threads=os.cpu_count() or 8)
+            assert o.initialize() == 0
+            o.pass2()
+            o.preprocess_chimeras()
+            p = o.piles()
+            sens = ds.sensitive(p["alive"], p["begin"], p["end"])
+            o.preprocess_repeats(sens)
+            want_rep, want_ov, want_p = o.all_intervals(2), o.overlap_list(0), o.piles()
+            o.build_graph()
+            want_tr, want_e = o.remove_transitive_edges(), o.edges()
+            ctx.construct(sens)
+            offs, pairs, flags = ctx.intervals(2)
+            parity.assert_same("rep.offsets", offs, want_rep[0])
+            parity.assert_same("rep.pairs", pairs, want_rep[1])
+            hp = ctx.piles()
+            for k in ("alive", "begin", "end", "median", "p10"):
+                parity.assert_same("piles." + k, hp[k], want_p[k])
+            parity.assert_same("ov.src", ctx.overlap_list(0)["src"], want_ov["src"].astype(np.uint32))
+            assert ctx.remove_transitive_edges() == want_tr
+            gr = ctx.graph()
+            for k in ("src", "dst", "len", "marked"):
+                parity.assert_same("edges." + k, gr[k], want_e[k])
+        else:
+            ctx.construct()
+            parity.check_construct(ctx, st)
+            parity.check_tr(ctx, st)
         tm = ctx.timings()
-        print("case %d n=%d g=%d cov=%g plants=%d: ok (%d overlaps, %d kept, overflow %d, position %d)" % (
-            seed, n, g, cov, plants, len(ds.overlaps), len(st["ov"]["src"]), tm["pile_overflow_reads"],
+        print("case %d n=%d g=%d cov=%g plants=%d %s: ok (%d overlaps, %d kept, overflow %d, position %d)" % (
+            seed, n, g, cov, plants, "+".join(variant) or "plain", len(ds.overlaps), len(st["ov"]["src"]),
+            tm["pile_overflow_reads"],
             tm["pile_position_reads"]), flush=True)
         ctx.close()
     except AssertionError as e:
