@@ -61,7 +61,8 @@ typedef struct rala_hip_overlaps {
 
 /* Per-stage device time of the last rala_hip_construct / stage call, in
  * milliseconds (HIP events on the context's stream), and host time of the
- * sequential tail. */
+ * sequential tail.  Duplicate removal runs on a second stream beside the bucketing and the
+ * pile kernels: dedupe_ms is what it adds beyond them (normally 0). */
 typedef struct rala_hip_timings {
     float dedupe_ms, bucket_ms, pile_ms, classify_ms, death_ms, finish_ms, tail_host_ms, tr_ms, total_ms;
     uint32_t pile_launches, death_rounds, pile_overflow_reads, pile_position_reads;

@@ -78,6 +78,7 @@ struct PinnedBuf {
 struct rala_hip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t side = nullptr;         // duplicate removal runs here, beside the bucketing
     std::string err;
     hipEvent_t ev[12] = {};
 

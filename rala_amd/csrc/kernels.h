@@ -117,6 +117,7 @@ enum : uint8_t {
     kClsKillsA = 0x10,     // live overlap deletes read a (a contained, container not chimeric)
     kClsKillsB = 0x20,
     kClsLive = 0x40,       // survived the in-order death scan
+    kClsHills = 0x40,      // between classify and finish only: a or b carries chimeric hills
     kClsSurvivor = 0x80,   // live, both reads survive, deletes nobody: goes on to preprocess
 };
 

@@ -385,6 +385,8 @@ __global__ __launch_bounds__(kBlock) void classify_kernel(OvlSoA o, uint32_t n_r
                     out = (uint8_t)(kClsOk | t);
                     if (t == kTypeB && (rb.z & 0xFFFFu) == 0) out |= kClsKillsA;
                     if (t == kTypeA && (ra.z & 0xFFFFu) == 0) out |= kClsKillsB;
+                    // the finish pass needs the records of a and b only to count hill spans
+                    if (rec_hills(ra) | rec_hills(rb)) out |= kClsHills;
                 }
             }
         }
@@ -508,11 +510,13 @@ __global__ __launch_bounds__(kBlock) void finish_pass2_kernel(OvlSoA o, uint8_t*
             if (c & kClsOk) {
                 const uint32_t a = o.a_id[i], b = o.b_id[i];
                 const uint32_t da = death[a], db = death[b];
+                const bool hills = (c & kClsHills) != 0;
+                c &= (uint8_t)~kClsHills;
                 if (da >= (uint32_t)i && db >= (uint32_t)i) {
                     c |= kClsLive;
-                    const uint4 ra = rec[a], rb = rec[b];
-                    const uint32_t nha = rec_hills(ra), nhb = rec_hills(rb);
-                    if (nha | nhb) {
+                    if (hills) {
+                        const uint4 ra = rec[a], rb = rec[b];
+                        const uint32_t nha = rec_hills(ra), nhb = rec_hills(rb);
                         Coords k = load_coords(o, i);
                         ovl_trim(k, o.strand[i], ra.x, ra.y, rb.x, rb.y);
                         if (nha) {

@@ -992,6 +992,7 @@ int rala_hip_create(int device, rala_hip_ctx** out) {
     rala_hip_ctx* ctx = new rala_hip_ctx;
     ctx->device = device;
     if (hipStreamCreate(&ctx->stream) != hipSuccess) { delete ctx; return RALA_HIP_EDEVICE; }
+    if (hipStreamCreate(&ctx->side) != hipSuccess) { (void)hipStreamDestroy(ctx->stream); delete ctx; return RALA_HIP_EDEVICE; }
     for (auto& e : ctx->ev) {
         if (hipEventCreate(&e) != hipSuccess) { delete ctx; return RALA_HIP_EDEVICE; }
     }
@@ -1008,6 +1009,7 @@ void rala_hip_destroy(rala_hip_ctx* ctx) {
     for (void* q : ctx->registered) (void)hipHostUnregister(q);
     ctx->registered.clear();
     for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
+    if (ctx->side) (void)hipStreamDestroy(ctx->side);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -1137,8 +1139,14 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
     HIPCHECK(ctx->d_pile.ensure(ctx->pile_elems + 8));
     HIPCHECK(hipMemsetAsync(ctx->d_small.p, 0, 8 * 4, s));
     HIPCHECK(hipEventRecord(ctx->ev[0], s));
-    if (!ctx->tuple_mode) launch_dedupe(ctx->ovl, n_reads, ctx->d_suspect.p, ctx->d_valid.p, s);
-    HIPCHECK(hipEventRecord(ctx->ev[1], s));
+    // duplicate removal only feeds the second pass (every resolvable overlap adds its bounds,
+    // valid or not): it runs on a second stream beside the bucketing, which waits on atomics
+    // and leaves the memory system idle; the main stream joins it after the pile kernels
+    if (!ctx->tuple_mode) {
+        HIPCHECK(hipStreamWaitEvent(ctx->side, ctx->ev[0], 0));
+        launch_dedupe(ctx->ovl, n_reads, ctx->d_suspect.p, ctx->d_valid.p, ctx->side);
+    }
+    HIPCHECK(hipEventRecord(ctx->ev[1], ctx->tuple_mode ? s : ctx->side));
     // bucket bounds by read.  Fast path: one kernel into fixed slots of kRunEventCapBig events per
     // read (8 KB; 8 GB at a million reads - HBM is 288 GB); the position inside the slot is what the
     // counting atomic returns, so there is no scan and no second pass over the overlaps.  A read
@@ -1232,6 +1240,7 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
     }
     HIPCHECK(hipEventRecord(ctx->ev[3], s));
     HIPCHECK(hipGetLastError());
+    if (!ctx->tuple_mode) HIPCHECK(hipStreamWaitEvent(s, ctx->ev[1], 0));
 
     // the per-read results stay on the device; host mirrors are fetched by the first getter
     HIPCHECK(ctx->d_cc_flags.ensure(8));
@@ -1254,8 +1263,16 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
     ctx->pool_used = std::min(small[0], ctx->pool_cap);
     ctx->tm.pile_overflow_reads = small[4];
     ctx->tm.pile_position_reads = ctx->use_run_kernel ? small[5] : n_reads;
-    HIPCHECK(hipEventElapsedTime(&ctx->tm.dedupe_ms, ctx->ev[0], ctx->ev[1]));
-    HIPCHECK(hipEventElapsedTime(&ctx->tm.bucket_ms, ctx->ev[1], ctx->ev[2]));
+    // dedupe_ms: what duplicate removal adds to the critical path (it runs beside the bucketing
+    // and the pile kernels; the main stream joins it after them)
+    {
+        float dd = 0, bk = 0, all = 0;
+        HIPCHECK(hipEventElapsedTime(&dd, ctx->ev[0], ctx->ev[1]));
+        HIPCHECK(hipEventElapsedTime(&bk, ctx->tuple_mode ? ctx->ev[1] : ctx->ev[0], ctx->ev[2]));
+        HIPCHECK(hipEventElapsedTime(&all, ctx->ev[0], ctx->ev[3]));
+        ctx->tm.bucket_ms = bk;
+        ctx->tm.dedupe_ms = ctx->tuple_mode ? dd : std::max(0.0f, dd - all);
+    }
     HIPCHECK(hipEventElapsedTime(&ctx->tm.pile_ms, ctx->ev[2], ctx->ev[3]));
     if (small[1] & kErrRegionCapacity) return fail(ctx, RALA_HIP_ECAPACITY, "slope-region list overflow in the pile kernel");
     if (small[1] & kErrPoolCapacity) {
