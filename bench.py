@@ -120,6 +120,8 @@ def main():
         runner = multi.ShardedRunner(ds, rank, world, local_rank)
     else:
         ctx = hip.Context(local_rank)
+        for kv in filter(None, os.environ.get("RALA_BENCH_OPTIONS", "").split(",")):    # diagnostics: key=value,...
+            ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
         ctx.set_reads(ds.read_len)
         ctx.set_overlaps(ds.overlaps)          # inputs resident in HBM from here on
 

@@ -79,6 +79,7 @@ struct rala_hip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t side = nullptr;         // duplicate removal runs here, beside the bucketing
+    bool use_side_stream = true;
     std::string err;
     hipEvent_t ev[12] = {};
 

@@ -227,6 +227,13 @@ __device__ __forceinline__ void load_sort_store(const uint32_t* __restrict__ gev
     for (int t = 0; t < C; ++t) ev[(uint32_t)t * 64u + lane] = v[t];
 }
 
+// (a & mask) | (b & ~mask) in one instruction
+__device__ __forceinline__ uint32_t bitfield_insert(uint32_t mask, uint32_t a, uint32_t b) {
+    uint32_t d;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "v"(mask), "v"(a), "v"(b));
+    return d;
+}
+
 template <uint32_t kCap>
 struct Layout {
     // list capacities: a read that needs more goes to the next kernel of the chain
@@ -254,7 +261,8 @@ struct Layout {
     static constexpr uint32_t GONE = IV + 8 * kMaxRaw;          // 2 x kMaxRaw bytes
     static constexpr uint32_t CAND = GONE + (2 * kMaxRaw) / 4;  // kMaxRaw hill candidates (i << 16 | j)
     static constexpr uint32_t SEL = CAND + kMaxRaw;             // 16 words
-    static constexpr uint32_t WORDS = SEL + 16;
+    static constexpr uint32_t MT = SEL + 16;                    // 14 words: expansion masks, see there
+    static constexpr uint32_t WORDS = MT + 14;
     static_assert(kX >= kCap && kX >= kIdx && kX >= 768, "shared region too small");
 };
 
@@ -279,6 +287,10 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
         wave_sync();                                                       \
         continue;                                                          \
     }
+    // expansion: a 32-bit word holds two positions; when the value changes at position x of a
+    // group of 8, word q takes the new value in the halves at or behind x: all of it for
+    // x - 2q <= 0, the upper half for x - 2q == 1, nothing beyond.  mt[6 + d] is that mask.
+    if (lane < 14) sm[L::MT + lane] = lane <= 6 ? 0xFFFFFFFFu : lane == 7 ? 0xFFFF0000u : 0u;
     for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
         const uint32_t r = A.order ? A.order[item] : item;
         const uint32_t n = A.read_len[r];
@@ -604,20 +616,22 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
                         const uint32_t g = g0 + 64 * u;
                         if (g >= g_hi) break;
                         const uint32_t vv = v[u] | (v[u] << 16);
-                        uint64_t lo = (uint64_t)vv | ((uint64_t)vv << 32), hi = lo;
+                        uint32_t w0 = vv, w1 = vv, w2 = vv, w3 = vv;
                         uint32_t inner = bits[u], kk = k[u];
                         while (inner) {
                             const uint32_t x = (uint32_t)__ffs((int)inner);     // position 1 .. 7 inside the group
                             inner &= inner - 1;
                             const uint32_t nvv = rv[++kk];
-                            const uint64_t fill = (uint64_t)(nvv | (nvv << 16)) * 0x100000001ull;
-                            const uint64_t mlo = x < 4 ? (~0ull << (16 * x)) : 0ull;
-                            const uint64_t mhi = x < 4 ? ~0ull : (~0ull << (16 * (x - 4)));
-                            lo = (lo & ~mlo) | (fill & mlo);
-                            hi = (hi & ~mhi) | (fill & mhi);
+                            const uint32_t f = nvv | (nvv << 16);
+                            const uint32_t* mt = sm + L::MT + x;
+                            const uint32_t m0 = mt[6], m1 = mt[4], m2 = mt[2], m3 = mt[0];
+                            w0 = bitfield_insert(m0, f, w0);
+                            w1 = bitfield_insert(m1, f, w1);
+                            w2 = bitfield_insert(m2, f, w2);
+                            w3 = bitfield_insert(m3, f, w3);
                         }
                         if (A.stop_after != 77) {
-                            dst[g] = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+                            dst[g] = make_uint4(w0, w1, w2, w3);
                         }
                     }
                 }

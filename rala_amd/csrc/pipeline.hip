@@ -1024,6 +1024,7 @@ int rala_hip_set_option(rala_hip_ctx* ctx, const char* key, int64_t value) {
     if (!strcmp(key, "use_run_kernel")) { ctx->use_run_kernel = value != 0; return RALA_HIP_OK; }
     if (!strcmp(key, "use_gpu_tail")) { ctx->use_gpu_tail = value != 0; return RALA_HIP_OK; }
     if (!strcmp(key, "use_fixed_buckets")) { ctx->use_fixed_buckets = value != 0; return RALA_HIP_OK; }
+    if (!strcmp(key, "use_side_stream")) { ctx->use_side_stream = value != 0; return RALA_HIP_OK; }
     if (!strcmp(key, "host_threads")) {
         ctx->host_threads = value;
         ctx->pool.reset(new HostPool((unsigned)std::max<int64_t>(1, std::min<int64_t>(value, 256))));
@@ -1142,11 +1143,14 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
     // duplicate removal only feeds the second pass (every resolvable overlap adds its bounds,
     // valid or not): it runs on a second stream beside the bucketing, which waits on atomics
     // and leaves the memory system idle; the main stream joins it after the pile kernels
-    if (!ctx->tuple_mode) {
+    const bool forked = !ctx->tuple_mode && ctx->use_side_stream;
+    if (forked) {
         HIPCHECK(hipStreamWaitEvent(ctx->side, ctx->ev[0], 0));
         launch_dedupe(ctx->ovl, n_reads, ctx->d_suspect.p, ctx->d_valid.p, ctx->side);
+    } else if (!ctx->tuple_mode) {
+        launch_dedupe(ctx->ovl, n_reads, ctx->d_suspect.p, ctx->d_valid.p, s);
     }
-    HIPCHECK(hipEventRecord(ctx->ev[1], ctx->tuple_mode ? s : ctx->side));
+    HIPCHECK(hipEventRecord(ctx->ev[1], forked ? ctx->side : s));
     // bucket bounds by read.  Fast path: one kernel into fixed slots of kRunEventCapBig events per
     // read (8 KB; 8 GB at a million reads - HBM is 288 GB); the position inside the slot is what the
     // counting atomic returns, so there is no scan and no second pass over the overlaps.  A read
@@ -1240,7 +1244,7 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
     }
     HIPCHECK(hipEventRecord(ctx->ev[3], s));
     HIPCHECK(hipGetLastError());
-    if (!ctx->tuple_mode) HIPCHECK(hipStreamWaitEvent(s, ctx->ev[1], 0));
+    if (forked) HIPCHECK(hipStreamWaitEvent(s, ctx->ev[1], 0));
 
     // the per-read results stay on the device; host mirrors are fetched by the first getter
     HIPCHECK(ctx->d_cc_flags.ensure(8));
@@ -1268,10 +1272,10 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
     {
         float dd = 0, bk = 0, all = 0;
         HIPCHECK(hipEventElapsedTime(&dd, ctx->ev[0], ctx->ev[1]));
-        HIPCHECK(hipEventElapsedTime(&bk, ctx->tuple_mode ? ctx->ev[1] : ctx->ev[0], ctx->ev[2]));
+        HIPCHECK(hipEventElapsedTime(&bk, forked ? ctx->ev[0] : ctx->ev[1], ctx->ev[2]));
         HIPCHECK(hipEventElapsedTime(&all, ctx->ev[0], ctx->ev[3]));
         ctx->tm.bucket_ms = bk;
-        ctx->tm.dedupe_ms = ctx->tuple_mode ? dd : std::max(0.0f, dd - all);
+        ctx->tm.dedupe_ms = forked ? std::max(0.0f, dd - all) : dd;
     }
     HIPCHECK(hipEventElapsedTime(&ctx->tm.pile_ms, ctx->ev[2], ctx->ev[3]));
     if (small[1] & kErrRegionCapacity) return fail(ctx, RALA_HIP_ECAPACITY, "slope-region list overflow in the pile kernel");
