@@ -177,6 +177,8 @@ def main():
                 pm = json.load(f)
             if pm.get("workload") == args.workload:
                 traffic = pm.get("hbm_bytes_per_step")
+                if traffic is not None and use_dist:
+                    traffic /= world       # measured on one GPU over all reads; a rank's launches cover 1 / world
         except Exception:
             pass
         out = {
