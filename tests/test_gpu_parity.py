@@ -205,3 +205,50 @@ def test_degenerate_inputs(hip_ctx_factory):
         ctx.initialize()
     assert e.value.code == -4
     assert ctx.valid().tolist() == [0, 0]
+
+
+@pytest.mark.parametrize("run_kernel,n,g,seed,factor", [(0, 1500, 300_000, 11, 1), (0, 1500, 300_000, 11, 7),
+                                                       (1, 1500, 12_000, 3, 1)])
+def test_position_kernel_slab_path(hip_ctx_factory, run_kernel, n, g, seed, factor):
+    """max_lds_read_len = 0: the position-space kernel keeps its three per-read arrays in HBM
+    slabs instead of LDS (what it does for reads too long for LDS) - every read with
+    use_run_kernel = 0, the reads beyond the 2048-event cap otherwise."""
+    ds = Dataset(n, g, seed)
+    if factor > 1:
+        ds = _Scaled(ds, factor)
+    st = parity.oracle_stages(ds)
+    ctx = hip_ctx_factory()
+    ctx.set_option("use_run_kernel", run_kernel)
+    ctx.set_option("max_lds_read_len", 0)
+    ctx.set_reads(ds.read_len)
+    ctx.set_overlaps(ds.overlaps)
+    ctx.initialize()
+    parity.check_initialize(ctx, st, ds)
+    ctx.construct()
+    parity.check_construct(ctx, st)
+    parity.check_tr(ctx, st)
+    if run_kernel:
+        assert ctx.timings()["pile_position_reads"] > 0
+
+
+def test_interval_pool_exhaustion_is_reported(hip_ctx_factory):
+    """a pit / hill pool that is too small is an error (RALA_HIP_ECAPACITY), not a silent loss;
+    with room the same context then gives the oracle's result"""
+    from rala_amd import hip
+
+    ds = Dataset(40_000, 8_000_000, 13)
+    st = parity.oracle_stages(ds)
+    n_iv = len(st["pits0"][1]) + len(st["hills0"][1])
+    assert n_iv > 1024, "the data set should need more than the floor of the pool"
+    ctx = hip_ctx_factory()
+    ctx.set_option("interval_pool_per_read_x1000", 1)          # 1024 slots (the floor) for 40 k reads
+    ctx.set_reads(ds.read_len)
+    ctx.set_overlaps(ds.overlaps)
+    with pytest.raises(hip.RalaHipError) as e:
+        ctx.initialize()
+    assert e.value.code == -3, (e.value.code, n_iv)
+    ctx2 = hip_ctx_factory()
+    ctx2.set_reads(ds.read_len)
+    ctx2.set_overlaps(ds.overlaps)
+    ctx2.initialize()
+    parity.check_initialize(ctx2, st, ds)
