@@ -252,3 +252,28 @@ def test_interval_pool_exhaustion_is_reported(hip_ctx_factory):
     ctx2.set_overlaps(ds.overlaps)
     ctx2.initialize()
     parity.check_initialize(ctx2, st, ds)
+
+
+def test_device_resident_overlaps_and_prefilter_count(hip_ctx_factory):
+    """rala_hip_set_overlaps(RALA_HIP_MEM_DEVICE): the columns are adopted where they lie in HBM
+    (here torch tensors); num_prefiltered is the reference's "prefiltered sequences" count."""
+    import torch
+    from rala_amd.synth import FIELDS
+
+    ds = Dataset(3000, 600_000, 21)
+    st = parity.oracle_stages(ds)
+    o = st["oracle"]
+    cols = {f: torch.from_numpy(np.ascontiguousarray(getattr(ds.overlaps, f)).astype(np.int64)).to(torch.int32).cuda()
+            for f in FIELDS}
+    cols["strand"] = torch.from_numpy(np.ascontiguousarray(ds.overlaps.strand)).cuda()
+    torch.cuda.synchronize()
+    ctx = hip_ctx_factory()
+    ctx.set_reads(ds.read_len)
+    ctx.set_overlaps_device({k: v.data_ptr() for k, v in cols.items()}, len(ds.overlaps))
+    ctx.initialize()
+    parity.check_initialize(ctx, st, ds)
+    assert ctx.num_prefiltered() == int(o.L.ora_n_prefiltered(o.h))
+    assert ctx.num_prefiltered() == int((st["piles0"]["alive"] == 0).sum())
+    ctx.construct()
+    parity.check_construct(ctx, st)
+    parity.check_tr(ctx, st)
