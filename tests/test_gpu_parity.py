@@ -277,3 +277,38 @@ def test_device_resident_overlaps_and_prefilter_count(hip_ctx_factory):
     ctx.construct()
     parity.check_construct(ctx, st)
     parity.check_tr(ctx, st)
+
+
+def test_call_order_and_argument_errors(hip_ctx_factory):
+    """the C ABI refuses calls out of order the way the reference does ("object already
+    constructed", graph.cpp:431-435) and reports bad arguments instead of acting on them"""
+    from rala_amd import hip
+
+    def code(fn, *a):
+        with pytest.raises(hip.RalaHipError) as e:
+            fn(*a)
+        return e.value.code
+
+    ds = Dataset(1000, 200_000, 1)
+    ctx = hip_ctx_factory()
+    assert code(ctx.initialize) == -2                      # no reads set
+    assert code(ctx.set_option, "no_such_option", 1) == -2
+    ctx.set_reads(ds.read_len)
+    ctx.set_overlaps(ds.overlaps)
+    assert code(ctx.construct) == -2                       # initialize first
+    assert code(ctx.piles) == -2
+    assert code(ctx.intervals, 0) == -2
+    ctx.initialize()
+    assert code(ctx.intervals, 3) == -2                    # no such kind
+    buf = np.zeros(16, dtype=np.uint16)
+    assert ctx.L.rala_hip_get_pile_data(ctx.h, ds.n_reads, buf.ctypes.data) == -2      # read out of range
+    assert code(ctx.remove_transitive_edges) == -2         # construct first
+    assert code(ctx.graph) == -2
+    assert code(ctx.overlap_list, 0) == -2
+    ctx.construct()
+    assert code(ctx.construct) == -2                       # already constructed
+    n = ctx.remove_transitive_edges()
+    # a second initialize starts over on the same context
+    ctx.initialize()
+    ctx.construct()
+    assert ctx.remove_transitive_edges() == n
