@@ -36,15 +36,17 @@ def log(*a):
 
 
 def cpu_baseline(sample_name="c2"):
-    """The CPU path on a bounded sample, all host cores, one task per pile like the reference's
-    thread pool.  kind "reference": the reference's own rala::Pile / rala::Overlap objects
+    """The CPU path on a bounded sample, as many threads as the process may really use, one
+    task per pile like the reference's thread pool.  kind "reference": the reference's own rala::Pile / rala::Overlap objects
     (oracle/_ref, compiled from the reference's pile.cpp / overlap.cpp) under the restated
     Graph orchestration; kind "port": the flat restatement (oracle/_build) when that library
     is not there.  Both are test infrastructure used here only as the measured baseline."""
     from oracle import oracle as ora
     from rala_amd.synth import Dataset
 
-    cores = os.cpu_count() or 1
+    from rala_amd.cpus import effective_cpus
+
+    cores = effective_cpus()        # affinity mask cut by the container's CPU quota (16 on the gpurun boxes)
     ds = Dataset.config(sample_name)
 
     def once(ref):

@@ -165,10 +165,15 @@ bool read_mhap(const std::string& path, const std::function<void(const MhapRecor
 
 // ---- multi-threaded PAF ingest -----------------------------------------------------------------
 #include <fcntl.h>
+#include <stdio.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <new>
 #include <thread>
 
 namespace rala {
@@ -189,10 +194,11 @@ inline const char* parse_u32(const char* p, const char* e, uint32_t& v) {
     return p;
 }
 
-struct Chunk {
+struct alignas(256) Chunk {        // one per thread, appended to on every line: no shared cache lines
     OverlapColumns cols;
     int64_t error_read = -1;        // first line of this chunk with a length mismatch
 };
+
 
 // one line [p, e) (no newline); returns false if it is not a 12-column record
 inline bool parse_paf_line(const char* p, const char* e, const NameTable& names, const std::vector<uint32_t>& read_len,
@@ -269,6 +275,25 @@ uint64_t NameTable::find(const char* p, size_t n) const {
     }
 }
 
+namespace {
+constexpr size_t kHugeBlock = 1u << 20, kHugePage = 2u << 20;
+}
+
+void* allocate_block(size_t bytes) {
+    if (bytes >= kHugeBlock && getenv("RALA_IO_NO_HUGEPAGES") == nullptr) {
+        const size_t rounded = (bytes + kHugePage - 1) & ~(kHugePage - 1);
+        void* p = aligned_alloc(kHugePage, rounded);
+        if (!p) throw std::bad_alloc();
+        (void)madvise(p, rounded, MADV_HUGEPAGE);
+        return p;
+    }
+    void* p = malloc(bytes ? bytes : 1);
+    if (!p) throw std::bad_alloc();
+    return p;
+}
+
+void free_block(void* p, size_t) { free(p); }
+
 bool read_paf_parallel(const std::string& path, const NameTable& names, const std::vector<uint32_t>& read_len,
     bool check_target_length, uint32_t num_threads, OverlapColumns& out, int64_t* length_error) {
     if (length_error) *length_error = -1;
@@ -281,10 +306,16 @@ bool read_paf_parallel(const std::string& path, const NameTable& names, const st
 
     // one chunk of the file per thread, read with pread into the thread's own buffer (page faults
     // of a shared mapping serialise on the address-space lock when many threads take them)
-    const uint32_t T = (uint32_t)std::max<size_t>(1, std::min<size_t>(std::max(1u, num_threads), size / (1 << 20) + 1));
+    // more chunks than threads, handed out through a counter: threads that are descheduled (a
+    // container's CPU quota throttles in bursts) do not hold the others up
+    const uint32_t n_thr = (uint32_t)std::max<size_t>(1, std::min<size_t>(std::max(1u, num_threads), size / (1 << 20) + 1));
+    const uint32_t T = (uint32_t)std::max<size_t>(n_thr, std::min<size_t>((size_t)n_thr * 8, size / (4 << 20) + 1));
+    const auto t_start = std::chrono::steady_clock::now();
     std::vector<Chunk> chunks(T);
     std::vector<int> failed(T, 0);
+    std::vector<double> t_read(T, 0.0), t_parse(T, 0.0);
     auto work = [&](uint32_t t) {
+        const auto w0 = std::chrono::steady_clock::now();
         const size_t lo = size * t / T, hi = size * (t + 1) / T;
         // a chunk owns the lines that start inside [lo, hi); the last of them may end beyond hi
         const size_t from = lo ? lo - 1 : 0;
@@ -303,6 +334,8 @@ bool read_paf_parallel(const std::string& path, const NameTable& names, const st
         };
         fill(want);
         if (failed[t]) return;
+        const auto w1 = std::chrono::steady_clock::now();
+        t_read[t] = std::chrono::duration<double, std::milli>(w1 - w0).count();
         const char* base = buf.data() - from;          // base[x] = byte x of the file
         size_t p = lo;
         if (t > 0) {
@@ -330,13 +363,20 @@ bool read_paf_parallel(const std::string& path, const NameTable& names, const st
             if (le > p) parse_paf_line(base + p, base + le, names, read_len, check_target_length, c);
             p = e + 1;
         }
+        t_parse[t] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w1).count();
+    };
+    std::atomic<uint32_t> next(0);
+    auto pull = [&](auto&& fn) {
+        for (uint32_t t = next.fetch_add(1); t < T; t = next.fetch_add(1)) fn(t);
     };
     std::vector<std::thread> threads;
-    for (uint32_t t = 1; t < T; ++t) threads.emplace_back(work, t);
-    work(0);
+    for (uint32_t k = 1; k < n_thr; ++k) threads.emplace_back([&] { pull(work); });
+    pull(work);
     for (auto& th : threads) th.join();
     close(fd);
     for (uint32_t t = 0; t < T; ++t) if (failed[t]) return false;
+    const bool trace = getenv("RALA_IO_TRACE") != nullptr;
+    const auto t_parsed = std::chrono::steady_clock::now();
 
     size_t total = out.size();
     for (const auto& c : chunks) total += c.cols.size();
@@ -355,13 +395,23 @@ bool read_paf_parallel(const std::string& path, const NameTable& names, const st
         memcpy(out.length.data() + at[t], c.length.data(), n * 4); memcpy(out.strand.data() + at[t], c.strand.data(), n);
     };
     threads.clear();
-    for (uint32_t t = 1; t < T; ++t) threads.emplace_back(gather, t);
-    gather(0);
+    next = 0;
+    for (uint32_t k = 1; k < n_thr; ++k) threads.emplace_back([&] { pull(gather); });
+    pull(gather);
     for (auto& th : threads) th.join();
     if (length_error) {
         for (const auto& c : chunks) {
             if (c.error_read >= 0) { *length_error = c.error_read; break; }
         }
+    }
+    if (trace) {
+        const auto t_done = std::chrono::steady_clock::now();
+        double avg_parse = 0;
+        for (double x : t_parse) avg_parse += x / T;
+        fprintf(stderr, "[io] %u threads, %u chunks: read + parse %.1f ms (slowest chunk: read %.1f ms, parse %.1f ms; mean parse %.1f ms), gather %.1f ms\n", n_thr, T,
+                std::chrono::duration<double, std::milli>(t_parsed - t_start).count(),
+                *std::max_element(t_read.begin(), t_read.end()), *std::max_element(t_parse.begin(), t_parse.end()), avg_parse,
+                std::chrono::duration<double, std::milli>(t_done - t_parsed).count());
     }
     return true;
 }

@@ -52,11 +52,19 @@ private:
 
 // allocator whose resize() leaves new elements uninitialised (the readers overwrite all of them;
 // zero-filling 29 bytes per overlap on one thread would cost as much as parsing)
+// Large blocks are 2 MiB aligned and marked for transparent huge pages: a 50 M-overlap file puts
+// 6 GB of fresh memory behind these vectors - 1.5 M first-touch faults with 4 KiB pages.
+void* allocate_block(size_t bytes);
+void free_block(void* p, size_t bytes);
+
 template <class T>
 struct UninitAllocator : std::allocator<T> {
     template <class U> struct rebind { typedef UninitAllocator<U> other; };
     UninitAllocator() = default;
     template <class U> UninitAllocator(const UninitAllocator<U>&) {}
+    T* allocate(size_t n) { return (T*)allocate_block(n * sizeof(T)); }
+    T* allocate(size_t n, const void*) { return allocate(n); }
+    void deallocate(T* p, size_t n) { free_block(p, n * sizeof(T)); }
     template <class U> void construct(U* p) { ::new ((void*)p) U; }
     template <class U, class... A> void construct(U* p, A&&... a) { ::new ((void*)p) U(std::forward<A>(a)...); }
 };

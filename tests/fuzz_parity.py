@@ -14,6 +14,7 @@ import numpy as np
 from rala_amd import hip
 from rala_amd.synth import Dataset
 import parity
+from rala_amd.cpus import effective_cpus
 from test_gpu_parity import _Scaled, _shuffled_with_duplicates
 from oracle.oracle import Oracle
 
@@ -38,7 +39,7 @@ for case in range(n_cases):
             ds = _Scaled(ds, f)
             variant.append("x%d" % f)
         sens_case = hasattr(ds, "sensitive") and rng.random() < 0.3
-        st = parity.oracle_stages(ds, n_threads=os.cpu_count() or 8)
+        st = parity.oracle_stages(ds, n_threads=effective_cpus())
         ctx = hip.Context(0)
         ctx.set_option("use_run_kernel", int(rng.random() < 0.85))
         ctx.set_option("use_fixed_buckets", int(rng.random() < 0.8))
@@ -58,7 +59,7 @@ for case in range(n_cases):
         if sens_case:
             variant.append("sensitive")
             ctx.set_option("use_gpu_tail", int(rng.random() < 0.7))
-            o = Oracle(ds.read_len, ds.overlaps, n_threads=os.cpu_count() or 8)
+            o = Oracle(ds.read_len, ds.overlaps, n_threads=effective_cpus())
             assert o.initialize() == 0
             o.pass2()
             o.preprocess_chimeras()

@@ -14,7 +14,8 @@ from rala_amd import build
 from rala_amd.synth import Dataset
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "c2"
-threads = int(sys.argv[2]) if len(sys.argv) > 2 else min(64, os.cpu_count() or 1)
+from rala_amd.cpus import effective_cpus
+threads = int(sys.argv[2]) if len(sys.argv) > 2 else effective_cpus()
 build.build_host()
 L = ctypes.CDLL(os.path.join(build.PKG, "host", "librala.so"))
 L.rala_e2e_from_paf.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32] + [ctypes.c_void_p] * 5
