@@ -197,6 +197,10 @@ inline const char* parse_u32(const char* p, const char* e, uint32_t& v) {
 struct alignas(256) Chunk {        // one per thread, appended to on every line: no shared cache lines
     OverlapColumns cols;
     int64_t error_read = -1;        // first line of this chunk with a length mismatch
+    // overlap files are grouped by query: the previous line's query name and its id
+    const char* last_q = nullptr;
+    size_t last_qn = 0;
+    uint64_t last_a = ~0ull;
 };
 
 
@@ -221,7 +225,13 @@ inline bool parse_paf_line(const char* p, const char* e, const NameTable& names,
     parse_u32(f[6], e, tl); parse_u32(f[7], e, tb); parse_u32(f[8], e, te);
     parse_u32(f[10], e, ol);
     const char orientation = f[4] < e && *f[4] != '\t' ? *f[4] : '+';
-    const uint64_t a = names.find(f[0], (size_t)(token_end(0) - f[0]));
+    const size_t qn = (size_t)(token_end(0) - f[0]);
+    if (c.last_q == nullptr || qn != c.last_qn || memcmp(c.last_q, f[0], qn) != 0) {
+        c.last_a = names.find(f[0], qn);
+        c.last_q = f[0];
+        c.last_qn = qn;
+    }
+    const uint64_t a = c.last_a;
     const uint64_t b = names.find(f[5], (size_t)(token_end(5) - f[5]));
     const uint32_t ia = a == ~0ull ? 0xFFFFFFFFu : (uint32_t)a;
     const uint32_t ib = b == ~0ull ? 0xFFFFFFFFu : (uint32_t)b;
@@ -355,6 +365,7 @@ bool read_paf_parallel(const std::string& path, const NameTable& names, const st
                 fill(have + (1 << 20));
                 if (failed[t]) return;
                 base = buf.data() - from;
+                c.last_q = nullptr;                    // the buffer may have moved
                 nl = (const char*)memchr(base + p, '\n', from + have - p);
             }
             const size_t e = nl ? (size_t)(nl - base) : from + have;
