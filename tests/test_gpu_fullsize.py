@@ -166,3 +166,76 @@ def test_fullsize_sharded_decomposition(hip_ctx_factory, wl, world):
     got = stage_digests(cg, with_data=False)         # the coverage vectors live on the owner ranks
     for k, v in got.items():
         assert v == want[k], "%s sharded over %d ranks: stage %s differs from the oracle" % (wl, world, k)
+
+
+@pytest.mark.skipif(os.environ.get("RALA_TEST_C5") != "1", reason="C5 (4 M reads / 300 M overlaps, 125 GB on the GPU, "
+                    "minutes of host time): set RALA_TEST_C5=1")
+def test_c5_properties():
+    """the largest BASELINE configuration on one GPU, one context at a time (a C5 context holds
+    80 GB of piles + 32 GB of bound slots): additivity, agreement of the two pile kernels,
+    idempotent transitive reduction, run-to-run determinism"""
+    from rala_amd import hip
+
+    ds = dataset("c5")
+    ov = ds.overlaps
+
+    def one(**options):
+        ctx = hip.Context(0)
+        try:
+            for k, v in options.items():
+                ctx.set_option(k, v)
+            ctx.set_reads(ds.read_len)
+            ctx.set_overlaps(ov)
+            ctx.initialize()
+            p = ctx.piles()
+            pits, hills = ctx.intervals(0), ctx.intervals(1)
+            reads = sample_reads(p["alive"])[:60]
+            data = {int(r): np.asarray(ctx.pile_data(int(r)), dtype=np.int64) for r in reads}
+            ctx.construct()
+            n_tr = ctx.remove_transitive_edges()
+            g = ctx.graph()
+            res = dict(p=p, pits=pits, hills=hills, reads=reads, data=data, n_tr=n_tr, g=g,
+                       ov=ctx.overlap_list(0), tm=ctx.timings())
+            if not options:
+                keep = g["marked"] == 0
+                marks, pairs = ctx.tr_mark(len(g["node_read"]), g["src"][keep], g["dst"][keep], g["len"][keep])
+                res["second_tr"] = (int(pairs), bool(marks.any()))
+            return res
+        finally:
+            ctx.close()
+
+    a = one()
+    p, reads, data = a["p"], a["reads"], a["data"]
+    assert a["tm"]["pile_overflow_reads"] > 1000           # the 1024-event instantiation is exercised
+    # additivity on the sampled reads
+    sel = np.nonzero(np.isin(ov.a_id, reads) | np.isin(ov.b_id, reads))[0]
+    for r in reads:
+        r = int(r)
+        B, E = int(p["begin"][r]), int(p["end"][r])
+        total = 0
+        for side_id, sb, se in ((ov.a_id, ov.a_begin, ov.a_end), (ov.b_id, ov.b_begin, ov.b_end)):
+            m = sel[side_id[sel] == r]
+            lo = np.clip(sb[m].astype(np.int64) + 15, B, E)
+            hi = np.clip(se[m].astype(np.int64) - 15, B, E)
+            total += int(np.maximum(hi - lo, 0).sum())
+        assert int(data[r][B:E].sum()) == total, r
+        assert data[r][:B].sum() == 0 and data[r][E:].sum() == 0
+    assert a["n_tr"] > 0 and a["second_tr"] == (0, False)
+    assert int(a["g"]["marked"].sum()) == 2 * a["n_tr"]
+
+    def same(x, y, what):
+        for k in ("begin", "end", "median", "p10", "alive"):
+            assert (x["p"][k] == y["p"][k]).all(), (what, k)
+        for name in ("pits", "hills"):
+            assert (x[name][0] == y[name][0]).all() and (x[name][1] == y[name][1]).all(), (what, name)
+        for r in reads[:20]:
+            assert (x["data"][int(r)] == y["data"][int(r)]).all(), (what, int(r))
+        assert x["n_tr"] == y["n_tr"], what
+        for k in ("node_read", "src", "dst", "len", "marked"):
+            assert (x["g"][k] == y["g"][k]).all(), (what, k)
+        for k in ("src", "a_begin", "a_end", "b_begin", "b_end", "length", "type"):
+            assert (np.asarray(x["ov"][k]) == np.asarray(y["ov"][k])).all(), (what, k)
+
+    same(a, one(use_run_kernel=0), "position-space kernel")
+    same(a, one(use_fixed_buckets=0), "exact CSR bucketing")
+    same(a, one(), "second run")
