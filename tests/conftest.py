@@ -12,9 +12,10 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
-@pytest.fixture(scope="session")
+@pytest.fixture
 def hip_ctx_factory():
-    """Factory of librala_hip contexts; fails loudly when there is no GPU / library."""
+    """Factory of librala_hip contexts, destroyed after the test (a C3 context holds ~30 GB of
+    HBM); fails loudly when there is no GPU / library."""
     from rala_amd import hip
 
     made = []
