@@ -1006,6 +1006,7 @@ void rala_hip_destroy(rala_hip_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)stream_sync(ctx, ctx->stream);
+    if (ctx->side) (void)hipStreamSynchronize(ctx->side);
     for (void* q : ctx->registered) (void)hipHostUnregister(q);
     ctx->registered.clear();
     for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
@@ -1039,6 +1040,7 @@ int rala_hip_set_reads(rala_hip_ctx* ctx, const uint32_t* read_len, uint64_t n_r
     if (!ctx || (!read_len && n_reads)) return RALA_HIP_EINVAL;
     if (n_reads >= 0x7FFFFFFFull) return fail(ctx, RALA_HIP_EINVAL, "too many reads");
     HIPCHECK(hipSetDevice(ctx->device));
+    HIPCHECK(hipStreamSynchronize(ctx->side));
     ctx->n_reads = n_reads;
     ctx->h_read_len.assign(read_len, read_len + n_reads);
     ctx->max_read_len = 0;
@@ -1091,6 +1093,7 @@ int rala_hip_set_overlaps(rala_hip_ctx* ctx, const rala_hip_overlaps* o, uint64_
     if (!ctx || (!o && n)) return RALA_HIP_EINVAL;
     if (n >= 0xFFFFFFF0ull / 4) return fail(ctx, RALA_HIP_EINVAL, "too many overlaps for 32-bit bound offsets");
     HIPCHECK(hipSetDevice(ctx->device));
+    HIPCHECK(hipStreamSynchronize(ctx->side));          // a failed call may have left work there
     ctx->n_ovl = n;
     const uint32_t* src[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     if (n) {
