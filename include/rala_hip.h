@@ -80,8 +80,9 @@ const char* rala_hip_last_error(const rala_hip_ctx* ctx);
  * position-space kernel), "use_gpu_tail" (default 1; 0 runs the chimera stage of
  * Graph::preprocess on the host), "use_fixed_buckets" (default 1; 0 always buckets the bounds
  * through the exact count / scan / scatter path), "use_side_stream" (default 1; 0 runs duplicate
- * removal on the main stream before the bucketing), "host_threads", "debug_pile_stop_after"
- * (diagnostics) */
+ * removal on the main stream before the bucketing), "sensitive_in_device_memory" (default 0; 1 = the
+ * sensitive overlaps handed to rala_hip_construct are device pointers), "host_threads",
+ * "debug_pile_stop_after" (diagnostics) */
 int rala_hip_set_option(rala_hip_ctx* ctx, const char* key, int64_t value);
 /* the context's hipStream_t, for callers that enqueue their own copies/collectives */
 void* rala_hip_stream(rala_hip_ctx* ctx);

@@ -165,6 +165,10 @@ struct rala_hip_ctx {
     // sensitive pass (repeat hills)
     rala_hip::DevBuf<uint16_t> d_dataset_median;
     rala_hip::DevBuf<uint8_t> d_n_rep;
+    // sensitive overlaps on the device: columns, transmuted target side, trimmed coordinates, tuples
+    rala_hip::DevBuf<uint32_t> d_sens_col[7], d_sens_tb[2], d_sens_c[5], d_sens_reads, d_sens_bounds;
+    rala_hip::DevBuf<uint8_t> d_sens_strand, d_sens_state;
+    bool sens_in_device = false;        // option "sensitive_in_device_memory"
     rala_hip::DevBuf<uint32_t> d_rep_slot;
     rala_hip::DevBuf<rala_hip::Interval> d_rep_pool;
     std::vector<uint8_t> h_n_rep;

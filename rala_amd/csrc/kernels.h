@@ -100,6 +100,12 @@ struct OvlSoA {
     uint64_t n;
 };
 
+// trimmed coordinates of the sensitive overlaps (second pass, -s) + kept / dropped
+struct SensCoords {
+    uint32_t *a_begin, *a_end, *b_begin, *b_end, *length;
+    uint8_t* state;
+};
+
 struct ReadState {
     const uint32_t* begin;
     const uint32_t* end;
@@ -141,6 +147,15 @@ void launch_emit_tuples(const OvlSoA& o, uint32_t n_reads, uint32_t* reads, uint
 void launch_bucket_tuples(const OvlSoA& o, uint32_t n_reads, uint32_t world, uint32_t pass, uint32_t* counters,
                           uint32_t* reads, uint32_t* bounds, hipStream_t s);
 void launch_count_tuples(const uint32_t* reads, uint64_t n, uint32_t n_reads, uint32_t* counts, hipStream_t s);
+// sensitive overlaps (graph.cpp:882-1054): transmute_ + target bounds as tuples 2i, 2i + 1;
+// first trim; dovetails mark the repeat hills they bridge
+void launch_sens_tuples(const OvlSoA& o, uint32_t n_reads, const uint32_t* begin, const uint8_t* alive, uint32_t* tb_begin,
+                        uint32_t* tb_end, uint32_t* reads, uint32_t* bounds, uint32_t* error, hipStream_t s);
+void launch_sens_trim(const OvlSoA& o, const uint32_t* tb_begin, const uint32_t* tb_end, const uint32_t* begin,
+                      const uint32_t* end, const uint8_t* alive, const SensCoords& out, hipStream_t s);
+void launch_sens_bridge(const OvlSoA& o, const SensCoords& sc, const uint32_t* begin, const uint32_t* end,
+                        const uint8_t* alive, const uint8_t* n_rep, const uint32_t* rep_slot, Interval* rep_pool,
+                        hipStream_t s);
 void launch_scatter_tuples(const uint32_t* reads, const uint32_t* bounds, uint64_t n, uint32_t n_reads,
                            uint32_t* cursor, uint32_t* ev, hipStream_t s);
 // overlaps that would delete a read (contained read, container without pits / hills)

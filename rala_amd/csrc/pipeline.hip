@@ -504,20 +504,6 @@ int run_repeats_kernel(rala_hip_ctx* ctx, RepeatArgs a, const std::vector<uint32
     return RALA_HIP_OK;
 }
 
-// Pile::check_repetitive_hills (pile.cpp:568-592) on host arrays; x, y = b side of the overlap
-void check_repetitive_hills(rala_hip_ctx* ctx, uint32_t r, uint32_t x, uint32_t y) {
-    const uint32_t B = ctx->h_begin[r], E = ctx->h_end[r];
-    Interval* h = ctx->h_rep_pool.data() + ctx->h_rep_slot[r];
-    for (uint32_t i = 0; i < ctx->h_n_rep[r]; ++i) {
-        if (!(x < h[i].second && h[i].first < y)) continue;
-        if ((double)h[i].first < 0.1 * (double)(E - B) + (double)B && (uint32_t)(x - B) < (uint32_t)(E - y)) {
-            if (y >= h[i].second + kHillFuzz) h[i].aux = 1;
-        } else if ((double)h[i].second > 0.9 * (double)(E - B) + (double)B && (uint32_t)(x - B) > (uint32_t)(E - y)) {
-            if (x + kHillFuzz <= h[i].first) h[i].aux = 1;
-        }
-    }
-}
-
 // Pile::is_valid_overlap (pile.cpp:605-630)
 bool is_valid_overlap(rala_hip_ctx* ctx, uint32_t r, uint32_t x, uint32_t y) {
     const uint32_t B = ctx->h_begin[r], E = ctx->h_end[r];
@@ -538,46 +524,65 @@ bool is_valid_overlap(rala_hip_ctx* ctx, uint32_t r, uint32_t x, uint32_t y) {
 int preprocess_repeats(rala_hip_ctx* ctx, const rala_hip_overlaps* sens, uint64_t n_sens) {
     const uint64_t n = ctx->n_reads;
     hipStream_t s = ctx->stream;
-    // Overlap::transmute_ (overlap.cpp:84-114): target coordinates shifted by the pile's begin
-    std::vector<HostOvl> sov(n_sens);
-    std::vector<uint32_t> cnt(n + 1, 0);
-    for (uint64_t i = 0; i < n_sens; ++i) {
-        const uint32_t a = sens->a_id[i], b = sens->b_id[i];
-        if (a >= n || b >= n) return fail(ctx, RALA_HIP_EINVAL, "sensitive overlap names must resolve");
-        if (!ctx->h_alive[b]) return fail(ctx, RALA_HIP_EINVAL, "sensitive overlap targets a read that did not survive");
-        HostOvl& o = sov[i];
-        o.src = (uint32_t)i; o.a = a; o.b = b; o.strand = sens->strand[i] ? 1 : 0; o.dead = 0;
-        o.c.a_begin = sens->a_begin[i]; o.c.a_end = sens->a_end[i];
-        o.c.b_begin = sens->b_begin[i] + ctx->h_begin[b];
-        o.c.b_end = sens->b_end[i] + ctx->h_begin[b];
-        o.c.length = sens->length[i];
-        o.type = 255;
-        cnt[b + 1] += 2;
+    Trace trc;
+    if (n_sens >= 0x7FFFFFF0ull / 2) return fail(ctx, RALA_HIP_EINVAL, "too many sensitive overlaps");
+    // the sensitive overlaps stay on the device from here on: columns as given (uploaded, or
+    // adopted when the caller says they are device memory)
+    OvlSoA so;
+    {
+        const uint32_t* src[7] = {sens->a_id, sens->b_id, sens->a_begin, sens->a_end, sens->b_begin, sens->b_end, sens->length};
+        const uint32_t* dev[7];
+        const uint8_t* dev_strand = sens->strand;
+        for (int k = 0; k < 7; ++k) dev[k] = src[k];
+        if (!ctx->sens_in_device) {
+            for (int k = 0; k < 7; ++k) {
+                HIPCHECK(ctx->d_sens_col[k].ensure(n_sens));
+                HIPCHECK(hipMemcpyAsync(ctx->d_sens_col[k].p, src[k], n_sens * 4, hipMemcpyHostToDevice, s));
+                dev[k] = ctx->d_sens_col[k].p;
+            }
+            HIPCHECK(ctx->d_sens_strand.ensure(n_sens));
+            HIPCHECK(hipMemcpyAsync(ctx->d_sens_strand.p, sens->strand, n_sens, hipMemcpyHostToDevice, s));
+            dev_strand = ctx->d_sens_strand.p;
+        }
+        so.a_id = dev[0]; so.b_id = dev[1]; so.a_begin = dev[2]; so.a_end = dev[3];
+        so.b_begin = dev[4]; so.b_end = dev[5]; so.length = dev[6]; so.strand = dev_strand; so.n = n_sens;
     }
-    // bounds of the targets, no +-15 (graph.cpp:929-933), bucketed by read
-    std::vector<uint32_t> targets;
-    for (uint64_t r = 0; r < n; ++r) {
-        if (cnt[r + 1]) targets.push_back((uint32_t)r);
-        cnt[r + 1] += cnt[r];
-    }
-    std::vector<uint32_t> ev(2 * n_sens + 1), cur(cnt.begin(), cnt.end() - 1);
-    for (const HostOvl& o : sov) {
-        ev[cur[o.b]++] = o.c.b_begin << 1;
-        ev[cur[o.b]++] = (o.c.b_end << 1) | 1u;
-    }
-    HIPCHECK(ctx->d_ev.ensure(2 * n_sens + 8));
-    HIPCHECK(hipMemcpyAsync(ctx->d_ev_off.p, cnt.data(), (n + 1) * 4, hipMemcpyHostToDevice, s));
-    HIPCHECK(hipMemcpyAsync(ctx->d_ev.p, ev.data(), 2 * n_sens * 4, hipMemcpyHostToDevice, s));
-    // current valid regions on the device (the host tail narrowed them)
+    // current valid regions and liveness on the device (a host tail narrowed them on the host)
     HIPCHECK(hipMemcpyAsync(ctx->d_begin.p, ctx->h_begin.data(), n * 4, hipMemcpyHostToDevice, s));
     HIPCHECK(hipMemcpyAsync(ctx->d_end.p, ctx->h_end.data(), n * 4, hipMemcpyHostToDevice, s));
+    HIPCHECK(hipMemcpyAsync(ctx->d_alive.p, ctx->h_alive.data(), n, hipMemcpyHostToDevice, s));
+    // Overlap::transmute_ (overlap.cpp:84-114) + bounds of the targets, no +-15 (graph.cpp:929-933),
+    // bucketed by read: count -> scan -> scatter
+    for (int k = 0; k < 2; ++k) HIPCHECK(ctx->d_sens_tb[k].ensure(n_sens));
+    HIPCHECK(ctx->d_sens_reads.ensure(2 * n_sens + 8));
+    HIPCHECK(ctx->d_sens_bounds.ensure(2 * n_sens + 8));
+    HIPCHECK(ctx->d_ev.ensure(2 * n_sens + 8));
     HIPCHECK(ctx->d_dataset_median.ensure(n));
     HIPCHECK(ctx->d_n_rep.ensure(n));
     HIPCHECK(ctx->d_rep_slot.ensure(n));
     HIPCHECK(ctx->d_rep_pool.ensure(ctx->pool_cap));
     HIPCHECK(hipMemsetAsync(ctx->d_n_rep.p, 0, n, s));
     HIPCHECK(hipMemsetAsync(ctx->d_small.p + 6, 0, 8, s));          // [6] rep pool count [7] error
+    HIPCHECK(hipMemsetAsync(ctx->d_small.p + 2, 0, 4, s));          // [2] bad sensitive record
+    HIPCHECK(hipMemsetAsync(ctx->d_cursor.p, 0, (n + 1) * 4, s));
+    launch_sens_tuples(so, (uint32_t)n, ctx->d_begin.p, ctx->d_alive.p, ctx->d_sens_tb[0].p, ctx->d_sens_tb[1].p,
+                       ctx->d_sens_reads.p, ctx->d_sens_bounds.p, ctx->d_small.p + 2, s);
+    launch_count_tuples(ctx->d_sens_reads.p, 2 * n_sens, (uint32_t)n, ctx->d_cursor.p, s);
+    launch_exclusive_scan(ctx->d_cursor.p, ctx->d_ev_off.p, n, ctx->d_scan_ws.p, s);
+    HIPCHECK(hipMemcpyAsync(ctx->d_cursor.p, ctx->d_ev_off.p, n * 4, hipMemcpyDeviceToDevice, s));
+    launch_scatter_tuples(ctx->d_sens_reads.p, ctx->d_sens_bounds.p, 2 * n_sens, (uint32_t)n, ctx->d_cursor.p, ctx->d_ev.p, s);
+    // the targets: reads that received bounds
+    std::vector<uint32_t> ev_off(n + 1);
+    uint32_t bad = 0;
+    HIPCHECK(hipMemcpyAsync(ev_off.data(), ctx->d_ev_off.p, (n + 1) * 4, hipMemcpyDeviceToHost, s));
+    HIPCHECK(d2h_small(ctx, &bad, ctx->d_small.p + 2, 4, s));
     HIPCHECK(stream_sync(ctx, s));
+    HIPCHECK(hipGetLastError());
+    if (bad & 1u) return fail(ctx, RALA_HIP_EINVAL, "sensitive overlap names must resolve");
+    if (bad & 2u) return fail(ctx, RALA_HIP_EINVAL, "sensitive overlap targets a read that did not survive");
+    std::vector<uint32_t> targets;
+    for (uint64_t r = 0; r < n; ++r) if (ev_off[r + 1] != ev_off[r]) targets.push_back((uint32_t)r);
+    trc("rep: transmute + bucket", targets.size());
 
     RepeatArgs a;
     a.read_len = ctx->d_read_len.p; a.pile_off = ctx->d_pile_off.p; a.pile = ctx->d_pile.p;
@@ -592,16 +597,15 @@ int preprocess_repeats(rala_hip_ctx* ctx, const rala_hip_overlaps* sens, uint64_
     if (rc != RALA_HIP_OK) return rc;
     HIPCHECK(hipMemcpy(ctx->h_median.data(), ctx->d_median.p, n * 2, hipMemcpyDeviceToHost));
     HIPCHECK(hipMemcpy(ctx->h_p10.data(), ctx->d_p10.p, n * 2, hipMemcpyDeviceToHost));
+    trc("rep: add_layers + median", targets.size());
     // first trim of the sensitive overlaps (graph.cpp:935-939)
-    {
-        size_t w = 0;
-        for (size_t k = 0; k < sov.size(); ++k) {
-            if (!host_trim(ctx, sov[k])) continue;
-            if (w != k) sov[w] = sov[k];
-            ++w;
-        }
-        sov.resize(w);
-    }
+    SensCoords sc;
+    for (int k = 0; k < 5; ++k) HIPCHECK(ctx->d_sens_c[k].ensure(n_sens));
+    HIPCHECK(ctx->d_sens_state.ensure(n_sens));
+    sc.a_begin = ctx->d_sens_c[0].p; sc.a_end = ctx->d_sens_c[1].p; sc.b_begin = ctx->d_sens_c[2].p;
+    sc.b_end = ctx->d_sens_c[3].p; sc.length = ctx->d_sens_c[4].p; sc.state = ctx->d_sens_state.p;
+    launch_sens_trim(so, ctx->d_sens_tb[0].p, ctx->d_sens_tb[1].p, ctx->d_begin.p, ctx->d_end.p, ctx->d_alive.p, sc, s);
+    trc("rep: first trim", n_sens);
     // component medians over the primary overlaps -> repeat hills (graph.cpp:971-1026)
     std::vector<uint32_t> members;
     std::vector<uint16_t> med;
@@ -612,12 +616,20 @@ int preprocess_repeats(rala_hip_ctx* ctx, const rala_hip_overlaps* sens, uint64_
         for (size_t k = 0; k < members.size(); ++k) dm[members[k]] = med[k];
         HIPCHECK(hipMemcpy(ctx->d_dataset_median.p, dm.data(), n * 2, hipMemcpyHostToDevice));
     }
+    trc("rep: component medians", members.size());
     rc = run_repeats_kernel(ctx, a, members, 2);
     if (rc != RALA_HIP_OK) return rc;
     uint32_t small[8];
     HIPCHECK(hipMemcpy(small, ctx->d_small.p, sizeof(small), hipMemcpyDeviceToHost));
     if (small[7] & kErrRegionCapacity) return fail(ctx, RALA_HIP_ECAPACITY, "slope-region list overflow (repeat hills)");
     if (small[7] & kErrPoolCapacity) return fail(ctx, RALA_HIP_ECAPACITY, "repeat-hill pool exhausted");
+    trc("rep: repeat hills kernel", small[6]);
+    // sensitive dovetails mark the hills they bridge (graph.cpp:1028-1043)
+    launch_sens_bridge(so, sc, ctx->d_begin.p, ctx->d_end.p, ctx->d_alive.p, ctx->d_n_rep.p, ctx->d_rep_slot.p,
+                       ctx->d_rep_pool.p, s);
+    HIPCHECK(stream_sync(ctx, s));
+    HIPCHECK(hipGetLastError());
+    trc("rep: bridged hills", n_sens);
     ctx->h_n_rep.resize(n); ctx->h_rep_slot.resize(n);
     HIPCHECK(hipMemcpy(ctx->h_n_rep.data(), ctx->d_n_rep.p, n, hipMemcpyDeviceToHost));
     HIPCHECK(hipMemcpy(ctx->h_rep_slot.data(), ctx->d_rep_slot.p, n * 4, hipMemcpyDeviceToHost));
@@ -626,12 +638,7 @@ int preprocess_repeats(rala_hip_ctx* ctx, const rala_hip_overlaps* sens, uint64_
         HIPCHECK(hipMemcpy(ctx->h_rep_pool.data(), ctx->d_rep_pool.p, (size_t)small[6] * sizeof(Interval),
                            hipMemcpyDeviceToHost));
     }
-    // sensitive dovetails mark the hills they bridge (graph.cpp:1028-1043)
-    for (HostOvl& o : sov) {
-        if (!host_trim(ctx, o)) continue;
-        const uint32_t t = host_type(ctx, o);
-        if ((t == kTypeAB || t == kTypeBA) && ctx->h_n_rep[o.b]) check_repetitive_hills(ctx, o.b, o.c.b_begin, o.c.b_end);
-    }
+    trc("rep: download hills", small[6]);
     // overlaps that end inside a bridged edge hill are dropped (graph.cpp:1045-1051)
     {
         size_t w = 0;
@@ -646,6 +653,7 @@ int preprocess_repeats(rala_hip_ctx* ctx, const rala_hip_overlaps* sens, uint64_
         }
         ctx->overlaps.resize(w);
     }
+    trc("rep: filter overlaps", ctx->overlaps.size());
     ctx->have_repeats = true;
     return RALA_HIP_OK;
 }
@@ -1026,6 +1034,7 @@ int rala_hip_set_option(rala_hip_ctx* ctx, const char* key, int64_t value) {
     if (!strcmp(key, "use_gpu_tail")) { ctx->use_gpu_tail = value != 0; return RALA_HIP_OK; }
     if (!strcmp(key, "use_fixed_buckets")) { ctx->use_fixed_buckets = value != 0; return RALA_HIP_OK; }
     if (!strcmp(key, "use_side_stream")) { ctx->use_side_stream = value != 0; return RALA_HIP_OK; }
+    if (!strcmp(key, "sensitive_in_device_memory")) { ctx->sens_in_device = value != 0; return RALA_HIP_OK; }
     if (!strcmp(key, "host_threads")) {
         ctx->host_threads = value;
         ctx->pool.reset(new HostPool((unsigned)std::max<int64_t>(1, std::min<int64_t>(value, 256))));
@@ -1618,8 +1627,10 @@ int rala_hip_construct(rala_hip_ctx* ctx, const rala_hip_overlaps* sens, uint64_
             // Graph::preprocess(sensitive overlaps) (graph.cpp:882-1054) works on the lists the
             // chimera stage leaves: bring them to the host, annotate repeats (kernels + host
             // orchestration), rebuild the graph from what is left
+            Trace trs;
             const int rc6 = materialize_host(ctx);
             if (rc6 != RALA_HIP_OK) return rc6;
+            trs("sens: materialize_host");
             ctx->tail_on_device = false;
             ctx->host_stale = false;
             // rank space of the component search: the reads that are still there
@@ -1630,9 +1641,12 @@ int rala_hip_construct(rala_hip_ctx* ctx, const rala_hip_overlaps* sens, uint64_
                 ctx->alive_rank[r] = (uint32_t)ctx->alive_reads.size();
                 ctx->alive_reads.push_back(r);
             }
+            trs("sens: alive ranks");
             const int rc3 = preprocess_repeats(ctx, sens, n_sens);
             if (rc3 != RALA_HIP_OK) return rc3;
+            trs("sens: preprocess_repeats");
             build_graph(ctx);
+            trs("sens: build_graph");
             HIPCHECK(hipMemcpyAsync(ctx->d_begin.p, ctx->h_begin.data(), (size_t)n_reads * 4, hipMemcpyHostToDevice, s));
             HIPCHECK(hipMemcpyAsync(ctx->d_end.p, ctx->h_end.data(), (size_t)n_reads * 4, hipMemcpyHostToDevice, s));
             HIPCHECK(hipMemcpyAsync(ctx->d_alive.p, ctx->h_alive.data(), (size_t)n_reads, hipMemcpyHostToDevice, s));

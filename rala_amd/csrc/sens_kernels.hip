@@ -1,0 +1,126 @@
+// Per-overlap work of Graph::preprocess(overlaps, sensitive overlaps) (rvaser/rala src/graph.cpp:882-1054):
+// Overlap::transmute_ + bound emission for the second add_layers (:919-934), the first trim
+// (:935-939), and the pass in which sensitive dovetails mark the repeat hills they bridge
+// (:1028-1043, Pile::check_repetitive_hills pile.cpp:568-592).
+#include <hip/hip_runtime.h>
+
+#include "device_utils.h"
+#include "geom.h"
+#include "kernels.h"
+
+namespace rala_hip {
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr uint32_t kInf = 0xFFFFFFFFu;
+
+// Overlap::transmute_ (overlap.cpp:84-114): the target side is given in the coordinates of the
+// trimmed read, so the pile's begin is added; the two bounds of the target side go out as (read,
+// bound) tuples 2i, 2i + 1 - no +-15 here (graph.cpp:929-933).  Records whose names do not
+// resolve or whose target did not survive are an error of the call (bit 0 / bit 1 of *error).
+__global__ __launch_bounds__(kBlock) void sens_tuples_kernel(OvlSoA o, uint32_t n_reads, const uint32_t* __restrict__ begin,
+                                                             const uint8_t* __restrict__ alive,
+                                                             uint32_t* __restrict__ tb_begin, uint32_t* __restrict__ tb_end,
+                                                             uint32_t* __restrict__ reads, uint32_t* __restrict__ bounds,
+                                                             uint32_t* error) {
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= o.n) return;
+    const uint32_t a = o.a_id[i], b = o.b_id[i];
+    uint32_t r = kInf, x = 0, y = 0;
+    if (a >= n_reads || b >= n_reads) {
+        atomicOr(error, 1u);
+    } else if (!alive[b]) {
+        atomicOr(error, 2u);
+    } else {
+        const uint32_t B = begin[b];
+        x = o.b_begin[i] + B;
+        y = o.b_end[i] + B;
+        r = b;
+    }
+    tb_begin[i] = x; tb_end[i] = y;
+    reads[2 * i] = r; reads[2 * i + 1] = r;
+    bounds[2 * i] = x << 1; bounds[2 * i + 1] = (y << 1) | 1u;
+}
+
+// first Overlap::trim of every sensitive overlap (graph.cpp:935-939); state 1 = kept
+__global__ __launch_bounds__(kBlock) void sens_trim_kernel(OvlSoA o, const uint32_t* __restrict__ tb_begin,
+                                                           const uint32_t* __restrict__ tb_end,
+                                                           const uint32_t* __restrict__ begin, const uint32_t* __restrict__ end,
+                                                           const uint8_t* __restrict__ alive, SensCoords out) {
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= o.n) return;
+    const uint32_t a = o.a_id[i], b = o.b_id[i];
+    uint8_t st = 0;
+    if (alive[a] && alive[b]) {
+        Coords c;
+        c.a_begin = o.a_begin[i]; c.a_end = o.a_end[i]; c.b_begin = tb_begin[i]; c.b_end = tb_end[i];
+        c.length = o.length[i];
+        if (ovl_trim(c, o.strand[i], begin[a], end[a], begin[b], end[b])) {
+            st = 1;
+            out.a_begin[i] = c.a_begin; out.a_end[i] = c.a_end; out.b_begin[i] = c.b_begin; out.b_end[i] = c.b_end;
+            out.length[i] = c.length;
+        }
+    }
+    out.state[i] = st;
+}
+
+// graph.cpp:1028-1043: trim once more, and a dovetail marks the repeat hills of its target that
+// it reaches across (Pile::check_repetitive_hills; every writer stores the same 1)
+__global__ __launch_bounds__(kBlock) void sens_bridge_kernel(OvlSoA o, SensCoords sc, const uint32_t* __restrict__ begin,
+                                                             const uint32_t* __restrict__ end,
+                                                             const uint8_t* __restrict__ alive,
+                                                             const uint8_t* __restrict__ n_rep,
+                                                             const uint32_t* __restrict__ rep_slot, Interval* rep_pool) {
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= o.n || !sc.state[i]) return;
+    const uint32_t a = o.a_id[i], b = o.b_id[i];
+    if (!alive[a] || !alive[b]) return;
+    const uint32_t nr = n_rep[b];
+    if (nr == 0) return;                        // nothing to mark; the overlap itself is not kept
+    Coords c;
+    c.a_begin = sc.a_begin[i]; c.a_end = sc.a_end[i]; c.b_begin = sc.b_begin[i]; c.b_end = sc.b_end[i];
+    c.length = sc.length[i];
+    const uint32_t st = o.strand[i];
+    const uint32_t Ba = begin[a], Ea = end[a], B = begin[b], E = end[b];
+    if (!ovl_trim(c, st, Ba, Ea, B, E)) return;
+    const uint32_t t = ovl_type(c, st, Ba, Ea, B, E);
+    if (t != kTypeAB && t != kTypeBA) return;
+    const uint32_t x = c.b_begin, y = c.b_end;
+    Interval* h = rep_pool + rep_slot[b];
+    for (uint32_t k = 0; k < nr; ++k) {
+        const uint32_t hf = h[k].first, hs = h[k].second;
+        if (!(x < hs && hf < y)) continue;
+        if ((double)hf < 0.1 * (double)(E - B) + (double)B && (uint32_t)(x - B) < (uint32_t)(E - y)) {
+            if (y >= hs + kHillFuzz) h[k].aux = 1;
+        } else if ((double)hs > 0.9 * (double)(E - B) + (double)B && (uint32_t)(x - B) > (uint32_t)(E - y)) {
+            if (x + kHillFuzz <= hf) h[k].aux = 1;
+        }
+    }
+}
+
+dim3 grid_for(uint64_t n) { return dim3((uint32_t)((n + kBlock - 1) / kBlock)); }
+
+}  // namespace
+
+void launch_sens_tuples(const OvlSoA& o, uint32_t n_reads, const uint32_t* begin, const uint8_t* alive, uint32_t* tb_begin,
+                        uint32_t* tb_end, uint32_t* reads, uint32_t* bounds, uint32_t* error, hipStream_t s) {
+    if (o.n) {
+        hipLaunchKernelGGL(sens_tuples_kernel, grid_for(o.n), dim3(kBlock), 0, s, o, n_reads, begin, alive, tb_begin, tb_end,
+                           reads, bounds, error);
+    }
+}
+void launch_sens_trim(const OvlSoA& o, const uint32_t* tb_begin, const uint32_t* tb_end, const uint32_t* begin,
+                      const uint32_t* end, const uint8_t* alive, const SensCoords& out, hipStream_t s) {
+    if (o.n) hipLaunchKernelGGL(sens_trim_kernel, grid_for(o.n), dim3(kBlock), 0, s, o, tb_begin, tb_end, begin, end, alive, out);
+}
+void launch_sens_bridge(const OvlSoA& o, const SensCoords& sc, const uint32_t* begin, const uint32_t* end,
+                        const uint8_t* alive, const uint8_t* n_rep, const uint32_t* rep_slot, Interval* rep_pool,
+                        hipStream_t s) {
+    if (o.n) {
+        hipLaunchKernelGGL(sens_bridge_kernel, grid_for(o.n), dim3(kBlock), 0, s, o, sc, begin, end, alive, n_rep, rep_slot,
+                           rep_pool);
+    }
+}
+
+}  // namespace rala_hip
