@@ -139,4 +139,20 @@ struct PadView {
 
 
 }  // namespace
+// hist[bin] += 1 for every active lane, one LDS atomic per distinct bin among the lanes of a
+// wavefront: neighbouring positions of a pile mostly carry the same value, and 64 atomics on one
+// address would be served one after the other.  Called by all lanes of the wavefront.
+__device__ __forceinline__ void hist_add(uint32_t* hist, uint32_t bin, bool active) {
+    const int lane = (int)(threadIdx.x & 63);
+    uint64_t todo = __ballot(active);
+    while (todo) {
+        const int leader = __ffsll((unsigned long long)todo) - 1;
+        const uint32_t lb = (uint32_t)__shfl((int)bin, leader, 64);
+        const uint64_t same = __ballot(active && bin == lb);
+        if (lane == leader) atomicAdd(&hist[lb], (uint32_t)__popcll(same));
+        todo &= ~same;
+    }
+}
+
+
 }  // namespace rala_hip

@@ -187,7 +187,11 @@ __global__ __launch_bounds__(kBlock) void pile_build_annotate(PileArgs A) {
             uint32_t* sel = sc + SC_SEL;
             for (uint32_t j = tid; j < 768; j += kBlock) hist[j] = 0;
             __syncthreads();
-            for (uint32_t j = B + tid; j < E; j += kBlock) atomicAdd(&hist[D[j] >> 8], 1u);
+            for (uint32_t j0 = B; j0 < E; j0 += kBlock) {
+                const uint32_t j = j0 + tid;
+                const bool in = j < E;
+                hist_add(hist, in ? (uint32_t)(D[j] >> 8) : 0u, in);
+            }
             __syncthreads();
             const uint32_t m = E - B;
             const uint32_t k1 = m / 2, k2 = m / 10;
@@ -206,10 +210,12 @@ __global__ __launch_bounds__(kBlock) void pile_build_annotate(PileArgs A) {
             }
             __syncthreads();
             const uint32_t h1 = sel[0], h2 = sel[2];
-            for (uint32_t j = B + tid; j < E; j += kBlock) {
-                const uint32_t v = D[j];
-                if ((v >> 8) == h1) atomicAdd(&hist[256 + (v & 255)], 1u);
-                if ((v >> 8) == h2) atomicAdd(&hist[512 + (v & 255)], 1u);
+            for (uint32_t j0 = B; j0 < E; j0 += kBlock) {
+                const uint32_t j = j0 + tid;
+                const bool in = j < E;
+                const uint32_t v = in ? D[j] : 0u;
+                hist_add(hist + 256, v & 255, in && (v >> 8) == h1);
+                hist_add(hist + 512, v & 255, in && (v >> 8) == h2);
             }
             __syncthreads();
             if (tid < 128) {

@@ -127,10 +127,18 @@ void build_classes(rala_hip_ctx* ctx, const std::vector<uint32_t>& reads, std::v
         c.lw = c.in_lds ? kLw[k] : max_long;
         c.first = (uint32_t)order.size();
         c.count = (uint32_t)bins[k].size();
-        std::stable_sort(bins[k].begin(), bins[k].end(), [&](uint32_t x, uint32_t y) {
-            return ctx->h_read_len[x] > ctx->h_read_len[y];
-        });
-        order.insert(order.end(), bins[k].begin(), bins[k].end());
+        // longest first (only a scheduling matter): counting sort on length / 64
+        {
+            const std::vector<uint32_t>& v = bins[k];
+            uint32_t top = 0;
+            for (uint32_t r : v) top = std::max(top, ctx->h_read_len[r] >> 6);
+            std::vector<uint32_t> at(top + 2, 0);
+            for (uint32_t r : v) ++at[top - (ctx->h_read_len[r] >> 6) + 1];
+            for (uint32_t b = 0; b <= top; ++b) at[b + 1] += at[b];
+            const size_t base = order.size();
+            order.resize(base + v.size());
+            for (uint32_t r : v) order[base + at[top - (ctx->h_read_len[r] >> 6)]++] = r;
+        }
         ctx->classes.push_back(c);
     }
 }
@@ -484,8 +492,10 @@ int preprocess_chimeras(rala_hip_ctx* ctx) {
 // position-space sensitive-pass kernel over `reads`, grouped by LDS image size
 int run_repeats_kernel(rala_hip_ctx* ctx, RepeatArgs a, const std::vector<uint32_t>& reads, int mode) {
     if (reads.empty()) return RALA_HIP_OK;
+    Trace trc;
     std::vector<uint32_t> order;
     build_classes(ctx, reads, order);
+    trc("repeats: classes", reads.size());
     HIPCHECK(hipMemcpyAsync(ctx->d_order.p, order.data(), order.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     for (const LaunchClass& c : ctx->classes) {
         uint32_t grid = c.count;
@@ -501,6 +511,7 @@ int run_repeats_kernel(rala_hip_ctx* ctx, RepeatArgs a, const std::vector<uint32
     }
     HIPCHECK(stream_sync(ctx, ctx->stream));
     HIPCHECK(hipGetLastError());
+    trc("repeats: kernels", ctx->classes.size());
     return RALA_HIP_OK;
 }
 
