@@ -1,5 +1,5 @@
 # what the round-end driver runs, in its order
-T0=$(date +%s.%N); lap() { T1=$(date +%s.%N); echo "[$1: $(echo "$T1 - $T0" | bc) s]"; T0=$T1; }
+T0=$(date +%s); lap() { T1=$(date +%s); echo "[$1: $((T1 - T0)) s]"; T0=$T1; }
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 python -m pytest tests/ -x -q -m gpu 2>&1 | tail -3
