@@ -3,6 +3,8 @@ full-size BASELINE workload (c2 = 100 k reads / 5 M overlaps, c3 = 1 M reads / 5
 that the GPU suite can check the HIP path at full size without running the oracle there.
 
     python tests/golden/make_fullsize_digests.py c2 [threads]
+    python tests/golden/make_fullsize_digests.py c2 [threads] sens      -> fullsize_c2_sens.json: the same
+        after the sensitive pass (-s) with the generator's sensitive overlap set
 
 Needs roughly 2.5 GB (c2) / 30 GB (c3) of host memory."""
 import hashlib
@@ -39,6 +41,7 @@ def sample_reads(n_reads, alive):
 def main():
     wl = sys.argv[1]
     threads = int(sys.argv[2]) if len(sys.argv) > 2 else (os.cpu_count() or 1)
+    with_sens = len(sys.argv) > 3 and sys.argv[3] == "sens"
     t0 = time.time()
     ds = Dataset.config(wl)
     o = Oracle(ds.read_len, ds.overlaps, n_threads=threads)
@@ -63,6 +66,24 @@ def main():
     out["n_internals_kept"] = int(len(it["src"]))
     out["ov"] = dg(*[np.asarray(ov[k]).astype(np.uint32) for k in ("src", "a_begin", "a_end", "b_begin", "b_end", "length", "type")])
     out["int"] = dg(*[np.asarray(it[k]).astype(np.uint32) for k in ("src", "a_begin", "a_end", "b_begin", "b_end", "length", "type")])
+    if with_sens:
+        # Graph::preprocess(overlaps, sensitive overlaps): the set derived from the piles as they are now
+        sens = ds.sensitive(p2["alive"], p2["begin"], p2["end"])
+        out["n_sensitive"] = len(sens)
+        o.preprocess_repeats(sens)
+        rep = o.all_intervals(2)
+        flags = [o.repeat_flags(int(r)) for r in np.nonzero(np.diff(rep[0]))[0]]
+        out["rep"] = dg(rep[0].astype(np.uint64), rep[1].astype(np.uint32),
+                        (np.concatenate(flags) if flags else np.zeros(0, np.uint8)).astype(np.uint8))
+        out["n_repeat_hills"] = int(len(rep[1]))
+        p3 = o.piles()
+        out["piles3"] = dg(*[p3[k] for k in ("begin", "end", "median", "p10", "alive")])
+        targets = np.unique(sens.b_id)[:SAMPLE]
+        out["data3"] = dg(*[np.asarray(o.pile_data(int(r)), dtype=np.uint16) for r in targets])
+        ov = o.overlap_list(0)
+        out["n_overlaps_kept_sens"] = int(len(ov["src"]))
+        out["ov_sens"] = dg(*[np.asarray(ov[k]).astype(np.uint32) for k in ("src", "a_begin", "a_end", "b_begin", "b_end", "length", "type")])
+        print("[digest] sensitive pass done %.0f s" % (time.time() - t0), file=sys.stderr)
     o.build_graph()
     out["nodes"] = dg(o.nodes().astype(np.uint32))
     out["n_tr"] = int(o.remove_transitive_edges())
@@ -70,7 +91,7 @@ def main():
     out["n_edges"] = int(len(e["src"]))
     out["edges"] = dg(e["src"].astype(np.uint32), e["dst"].astype(np.uint32), e["len"].astype(np.uint32), e["marked"].astype(np.uint8))
     out["oracle_seconds"] = round(time.time() - t0, 1)
-    path = os.path.join(ROOT, "tests", "golden", "fullsize_%s.json" % wl)
+    path = os.path.join(ROOT, "tests", "golden", "fullsize_%s%s.json" % (wl, "_sens" if with_sens else ""))
     with open(path, "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps(out))

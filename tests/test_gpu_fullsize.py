@@ -239,3 +239,43 @@ def test_c5_properties():
     same(a, one(use_run_kernel=0), "position-space kernel")
     same(a, one(use_fixed_buckets=0), "exact CSR bucketing")
     same(a, one(), "second run")
+
+
+@pytest.mark.parametrize("wl", ["c2", "c3"])
+def test_fullsize_sensitive_pass_matches_oracle_digests(hip_ctx_factory, wl):
+    """Graph::preprocess with the sensitive overlap set (-s) at full size: repeat hills and their
+    bridged flags, piles (second add_layers + medians), the filtered overlap list, graph and
+    transitive reduction against the oracle's digests (tests/golden/fullsize_<wl>_sens.json)"""
+    path = os.path.join(HERE, "golden", "fullsize_%s_sens.json" % wl)
+    if not os.path.exists(path):
+        pytest.skip("no digest file for %s with the sensitive pass" % wl)
+    want = json.load(open(path))
+    ds = dataset(wl)
+    ctx = run(hip_ctx_factory, ds)
+    ctx.construct()                                          # the chimera stage alone gives the piles ...
+    p2 = ctx.piles()
+    assert dg(p2["begin"], p2["end"], p2["alive"]) == want["piles2"]
+    sens = ds.sensitive(p2["alive"], p2["begin"], p2["end"])     # ... the generator derives the set from
+    assert len(sens) == want["n_sensitive"]
+    ctx.initialize()
+    ctx.construct(sens)
+    got = {}
+    offs, pairs, flags = ctx.intervals(2)
+    got["rep"] = dg(offs.astype(np.uint64), pairs.astype(np.uint32), flags.astype(np.uint8))
+    got["n_repeat_hills"] = int(len(pairs))
+    p3 = ctx.piles()
+    got["piles3"] = dg(*[p3[k] for k in ("begin", "end", "median", "p10", "alive")])
+    targets = np.unique(sens.b_id)[:SAMPLE]
+    got["data3"] = dg(*[np.asarray(ctx.pile_data(int(r)), dtype=np.uint16) for r in targets])
+    ov = ctx.overlap_list(0)
+    got["n_overlaps_kept_sens"] = int(len(ov["src"]))
+    got["ov_sens"] = dg(*[np.asarray(ov[k]).astype(np.uint32) for k in
+                          ("src", "a_begin", "a_end", "b_begin", "b_end", "length", "type")])
+    got["nodes"] = dg(ctx.graph()["node_read"].astype(np.uint32))
+    got["n_tr"] = int(ctx.remove_transitive_edges())
+    g = ctx.graph()
+    got["n_edges"] = int(len(g["src"]))
+    got["edges"] = dg(g["src"].astype(np.uint32), g["dst"].astype(np.uint32), g["len"].astype(np.uint32),
+                      g["marked"].astype(np.uint8))
+    for k, v in got.items():
+        assert v == want[k], "%s: stage %s differs from the oracle" % (wl, k)
