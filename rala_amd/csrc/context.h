@@ -141,7 +141,6 @@ struct rala_hip_ctx {
     rala_hip::DevBuf<uint8_t> d_surv_u8[2];
     rala_hip::PinnedBuf<uint32_t> p_surv_u32[8];
     rala_hip::PinnedBuf<uint8_t> p_surv_u8[2];
-    std::vector<void*> registered;               // host mirrors pinned with hipHostRegister
 
     // host mirror of the per-read state (valid after initialize / construct)
     bool initialized = false, constructed = false;

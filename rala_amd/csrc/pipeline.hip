@@ -1026,8 +1026,6 @@ void rala_hip_destroy(rala_hip_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)stream_sync(ctx, ctx->stream);
     if (ctx->side) (void)hipStreamSynchronize(ctx->side);
-    for (void* q : ctx->registered) (void)hipHostUnregister(q);
-    ctx->registered.clear();
     for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
     if (ctx->side) (void)hipStreamDestroy(ctx->side);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -1087,22 +1085,13 @@ int rala_hip_set_reads(rala_hip_ctx* ctx, const uint32_t* read_len, uint64_t n_r
     HIPCHECK(ctx->d_alive.ensure(n_reads)); HIPCHECK(ctx->d_n_pits.ensure(n_reads));
     HIPCHECK(ctx->d_n_hills.ensure(n_reads)); HIPCHECK(ctx->d_iv_slot.ensure(n_reads));
     HIPCHECK(ctx->d_death[0].ensure(n_reads)); HIPCHECK(ctx->d_death[1].ensure(n_reads));
-    // host mirrors of the per-read state: sized once, pinned for fast copies
-    for (void* q : ctx->registered) (void)hipHostUnregister(q);
-    ctx->registered.clear();
+    // host mirrors of the per-read state.  They are NOT registered with the runtime: registration
+    // pins whole pages, small vectors of different contexts share pages of the heap, and
+    // unregistering one context's vectors then unmapped pages another context's copies still went
+    // to ("Memory access fault by GPU" in a later, unrelated call).
     ctx->h_begin.resize(n_reads); ctx->h_end.resize(n_reads); ctx->h_median.resize(n_reads);
     ctx->h_p10.resize(n_reads); ctx->h_alive.resize(n_reads); ctx->h_n_pits.resize(n_reads);
     ctx->h_n_hills.resize(n_reads); ctx->h_slot.resize(n_reads);
-    if (n_reads) {
-        auto pin = [&](void* q, size_t bytes) {
-            if (hipHostRegister(q, bytes, hipHostRegisterDefault) == hipSuccess) ctx->registered.push_back(q);
-            else (void)hipGetLastError();
-        };
-        pin(ctx->h_begin.data(), n_reads * 4); pin(ctx->h_end.data(), n_reads * 4);
-        pin(ctx->h_median.data(), n_reads * 2); pin(ctx->h_p10.data(), n_reads * 2);
-        pin(ctx->h_alive.data(), n_reads); pin(ctx->h_n_pits.data(), n_reads);
-        pin(ctx->h_n_hills.data(), n_reads); pin(ctx->h_slot.data(), n_reads * 4);
-    }
     ctx->pool_cap = (uint32_t)std::max<int64_t>(1024, (int64_t)n_reads * ctx->pool_per_read_x1000 / 1000);
     HIPCHECK(ctx->d_pool.ensure(ctx->pool_cap));
     ctx->initialized = ctx->constructed = false;
