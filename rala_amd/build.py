@@ -31,6 +31,19 @@ def _run(cmd, cwd=None):
     return res.stdout
 
 
+def _link(cmd_before_out, out, cmd_after_out):
+    """Compile to a private temporary next to `out` and rename it into place: several processes
+    (ranks under torchrun, pytest workers) may find the same stale library at once, and nobody may
+    ever dlopen a half-written file."""
+    tmp = "%s.%d.tmp" % (out, os.getpid())
+    try:
+        _run(cmd_before_out + ["-o", tmp] + cmd_after_out)
+        os.replace(tmp, out)
+    finally:
+        if os.path.exists(tmp):
+            os.unlink(tmp)
+
+
 def _glob(d, exts):
     out = []
     for base, _, files in os.walk(d):
@@ -53,8 +66,8 @@ def build_hip(force=False):
     srcs = _glob(d, (".hip",))
     deps = srcs + _glob(d, (".h", ".hpp")) + _glob(os.path.join(ROOT, "include"), (".h",))
     if force or _stale(out, deps):
-        _run([hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-              "-I" + os.path.join(ROOT, "include"), "-I" + d, "-o", out] + srcs)
+        _link([hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+               "-I" + os.path.join(ROOT, "include"), "-I" + d], out, srcs + ["-ldl"])
     return out
 
 
@@ -63,7 +76,7 @@ def build_synth(force=False):
     out = os.path.join(d, "libralasynth.so")
     srcs = [os.path.join(d, "synth.cpp")]
     if force or _stale(out, srcs):
-        _run(["g++", "-O2", "-std=c++14", "-fPIC", "-shared", "-o", out] + srcs)
+        _link(["g++", "-O2", "-std=c++14", "-fPIC", "-shared"], out, srcs)
     return out
 
 
@@ -74,28 +87,47 @@ def build_host(force=False):
         return None
     out = os.path.join(d, "librala.so")
     deps = srcs + _glob(d, (".hpp", ".h")) + _glob(os.path.join(ROOT, "include"), (".h",))
-    lib_srcs = [s for s in srcs if not s.endswith("main.cpp") and not s.endswith("_capi.cpp")]
+    lib_srcs = [s for s in srcs if not s.endswith("cli.cpp") and not s.endswith("_capi.cpp")]
     if force or _stale(out, deps):
         hip = build_hip()
-        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I" + os.path.join(ROOT, "include"),
-              "-I" + d, "-o", out] + lib_srcs + [hip, "-Wl,-rpath," + os.path.dirname(hip), "-lz"])
+        _link(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I" + os.path.join(ROOT, "include"),
+               "-I" + d], out, lib_srcs + [hip, "-Wl,-rpath," + os.path.dirname(hip), "-lz"])
     # the clean-up stages and the readers alone (no HIP dependency), for the CPU test-suite
     ag = os.path.join(d, "libassembly_graph.so")
     ag_srcs = [os.path.join(d, f) for f in ("assembly_graph.cpp", "assembly_graph_capi.cpp", "io.cpp", "io_capi.cpp")]
     if force or _stale(ag, ag_srcs + [os.path.join(d, "assembly_graph.hpp"), os.path.join(d, "io.hpp")]):
-        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I" + d, "-o", ag] + ag_srcs + ["-lz"])
+        _link(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I" + d], ag, ag_srcs + ["-lz"])
     # C entry points over stand-alone Pile / Overlap objects (tests of the class interface)
     api = os.path.join(d, "librala_api.so")
     api_src = os.path.join(d, "host_api_capi.cpp")
     if force or _stale(api, deps):
-        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I" + os.path.join(ROOT, "include"),
-              "-I" + d, "-o", api, api_src, out, "-Wl,-rpath," + d, "-Wl,-rpath," + os.path.join(PKG, "csrc")])
+        _link(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I" + os.path.join(ROOT, "include"),
+               "-I" + d], api, [api_src, out, "-Wl,-rpath," + d, "-Wl,-rpath," + os.path.join(PKG, "csrc")])
     exe = os.path.join(d, "rala")
-    main = os.path.join(d, "main.cpp")
-    if os.path.exists(main) and (force or _stale(exe, deps)):
-        _run(["g++", "-O2", "-std=c++17", "-pthread", "-I" + d, "-o", exe, main, out,
-              "-Wl,-rpath," + d, "-Wl,-rpath," + os.path.join(PKG, "csrc")])
+    cli = os.path.join(d, "cli.cpp")
+    if force or _stale(exe, deps):
+        _link(["g++", "-O2", "-std=c++17", "-pthread", "-I" + d], exe,
+              [cli, out, "-Wl,-rpath," + d, "-Wl,-rpath," + os.path.join(PKG, "csrc")])
+    build_reference_cli(out, force)
     return out
+
+
+def build_reference_cli(librala, force=False):
+    """Drop-in check of SURVEY 8(b): the reference's own command line, compiled from where it
+    lies (never copied), against this package's headers and librala.so.  Only possible where
+    /root/reference exists; the binary (rala_amd/host/_refcli/rala_ref, git-ignored) travels to
+    the GPU box like the other built files."""
+    src = os.path.join(REFERENCE, "src", "main.cpp")
+    if not os.path.exists(src):
+        return None
+    d = os.path.join(PKG, "host")
+    out_dir = os.path.join(d, "_refcli")
+    os.makedirs(out_dir, exist_ok=True)
+    exe = os.path.join(out_dir, "rala_ref")
+    if force or _stale(exe, [src, librala]):
+        _link(["g++", "-O2", "-std=c++11", "-pthread", "-I" + d], exe,
+              [src, librala, "-Wl,-rpath," + d, "-Wl,-rpath," + os.path.join(PKG, "csrc")])
+    return exe
 
 
 def build_oracle(force=False):

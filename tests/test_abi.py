@@ -56,3 +56,57 @@ def test_product_does_not_touch_the_oracle():
                 if f == "build.py":
                     continue        # builds the checker for the tests; does not load it
                 assert "oracle" not in text.lower(), "%s mentions the oracle" % os.path.join(base, f)
+
+
+def test_reference_cli_compiles_unchanged():
+    """SURVEY 8(b) "must build unchanged": the reference's src/main.cpp, compiled from where it
+    lies, against this package's graph.hpp / sequence.hpp / thread_pool/thread_pool.hpp and
+    linked with librala.so.  Only where /root/reference exists (this container)."""
+    import subprocess
+
+    from rala_amd import build
+
+    if not os.path.exists(os.path.join(build.REFERENCE, "src", "main.cpp")):
+        pytest.skip("no /root/reference here")
+    build.build_host()
+    exe = os.path.join(build.PKG, "host", "_refcli", "rala_ref")
+    assert os.path.exists(exe)
+    r = subprocess.run([exe, "--version"], stdout=subprocess.PIPE)
+    assert r.returncode == 0 and r.stdout.strip() == b"v1.0.0"
+    ours = subprocess.run([os.path.join(build.PKG, "host", "rala"), "--version"], stdout=subprocess.PIPE)
+    assert ours.returncode == 0 and ours.stdout.startswith(b"v1.0.0")
+    # no file of the reference's text lives in the repository
+    assert not os.path.exists(os.path.join(build.PKG, "host", "main.cpp"))
+
+
+def test_thread_pool_header():
+    """the product's thread_pool/thread_pool.hpp (interface of the reference's un-vendored
+    submodule, graph.cpp:235,369): tasks run, futures deliver, the pool joins"""
+    import subprocess
+    import tempfile
+
+    from rala_amd import build
+
+    src = r'''
+#include <stdio.h>
+#include <numeric>
+#include "thread_pool/thread_pool.hpp"
+int main() {
+    auto pool = thread_pool::createThreadPool(4);
+    std::vector<std::future<long>> f;
+    for (long i = 0; i < 1000; ++i) f.emplace_back(pool->submit_task([](long a, long b) { return a * b; }, i, 2L));
+    long s = 0;
+    for (auto& x : f) { x.wait(); s += x.get(); }
+    auto v = pool->submit_task([]() {});
+    v.wait();
+    printf("%ld %u\n", s, pool->num_threads());
+    return 0;
+}
+'''
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.cpp"), "w").write(src)
+        exe = os.path.join(d, "t")
+        subprocess.check_call(["g++", "-std=c++11", "-O1", "-pthread", "-I" + os.path.join(build.PKG, "host"), "-o", exe,
+                               os.path.join(d, "t.cpp")])
+        out = subprocess.check_output([exe]).split()
+    assert out == [b"999000", b"4"]

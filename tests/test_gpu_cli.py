@@ -261,3 +261,30 @@ def test_cli_sensitive_pass(tmp_path):
     assert "number of edges = %d" % len(pre["src"]) in err
     lines = r.stdout.split(b"\n")
     assert [lines[i + 1] for i in range(0, len(lines) - 1, 2)] == exp
+
+
+def test_reference_cli_drop_in(tmp_path):
+    """the reference's own src/main.cpp, compiled unchanged from /root/reference
+    against rala_amd/host's headers (rala_amd/build.py: build_reference_cli; the binary travels to
+    the GPU box), gives the same contigs, debug CSV and -p reads as this package's own driver."""
+    build.build_host()
+    ref = os.path.join(build.PKG, "host", "_refcli", "rala_ref")
+    if not os.path.exists(ref):
+        pytest.skip("reference CLI was not built (no /root/reference where the build ran)")
+    exe = os.path.join(build.PKG, "host", "rala")
+    ds = Dataset(1200, 200_000, 23)
+    fa, paf = str(tmp_path / "reads.fasta"), str(tmp_path / "ovl.paf")
+    ds.write_fasta(fa)
+    ds.write_paf(paf)
+    outs = {}
+    for name, binary in (("ours", exe), ("ref", ref)):
+        prefix = str(tmp_path / ("dbg_" + name))
+        r = subprocess.run([binary, "-u", "-d", prefix, "-t", "4", fa, paf], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 0, r.stderr.decode()
+        p = subprocess.run([binary, "-p", fa, paf], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert p.returncode == 0, p.stderr.decode()
+        outs[name] = (r.stdout, open(prefix + ".csv").read(), open(prefix + ".json").read(), p.stdout)
+    assert outs["ours"][0] == outs["ref"][0] and len(outs["ours"][0]) > 100_000
+    assert outs["ours"][1] == outs["ref"][1]
+    assert outs["ours"][2] == outs["ref"][2]
+    assert outs["ours"][3] == outs["ref"][3] and outs["ours"][3].count(b">") > 10
