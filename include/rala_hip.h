@@ -122,21 +122,23 @@ int rala_hip_tr_mark(rala_hip_ctx* ctx, uint32_t n_nodes, uint32_t n_edges, cons
  * slice of the overlap file cut on a_id-run boundaries. ---------------------------------- */
 /* remove_duplicate_overlaps only (src/graph.cpp:273-307) on this context's overlaps */
 int rala_hip_dedupe(rala_hip_ctx* ctx);
-/* store_overlap_bounds (src/graph.cpp:311-326) as tuples: for overlap i the entries 4i..4i+3 of
- * the DEVICE buffers reads_dev / bounds_dev (4 * n_overlaps uint32 each, 16-byte aligned)
- * receive (a, (a_begin+15)<<1), (a, (a_end-15)<<1|1), (b, ...), (b, ...); the read is
- * RALA_HIP_NO_READ for records that do not resolve.  The caller routes them to the read owners. */
-int rala_hip_emit_bound_tuples(rala_hip_ctx* ctx, uint32_t* reads_dev, uint32_t* bounds_dev);
+/* A bound tuple is 8 bytes: the read in the low 32 bits, the bound ((position << 1) | is_end,
+ * src/graph.cpp:317-324) in the high 32 bits - one element of the ONE all-to-all that ships every
+ * bound to the owner of its read.
+ * store_overlap_bounds (src/graph.cpp:311-326) as tuples: for overlap i the entries 4i..4i+3 of
+ * the DEVICE buffer tuples_dev (4 * n_overlaps tuples, 16-byte aligned) receive
+ * (a, (a_begin+15)<<1), (a, (a_end-15)<<1|1), (b, ...), (b, ...); the read is RALA_HIP_NO_READ
+ * for records that do not resolve.  The caller routes them to the read owners. */
+int rala_hip_emit_bound_tuples(rala_hip_ctx* ctx, uint64_t* tuples_dev);
 /* The same tuples grouped by owner rank (owner = read % world, stored read = read / world =
- * the owner's local read number): the device buffers (4 * n_overlaps uint32 each) receive the
- * bucket of rank 0, then rank 1, ...; counts[world] (host) receives the bucket sizes.  Records
- * that do not resolve are left out. */
-int rala_hip_emit_bound_tuples_bucketed(rala_hip_ctx* ctx, uint32_t world, uint32_t* reads_dev, uint32_t* bounds_dev,
-                                        uint64_t* counts);
+ * the owner's local read number): the device buffer receives the bucket of rank 0, then rank 1,
+ * ...; counts[world] (host) receives the bucket sizes.  Records that do not resolve are left
+ * out. */
+int rala_hip_emit_bound_tuples_bucketed(rala_hip_ctx* ctx, uint32_t world, uint64_t* tuples_dev, uint64_t* counts);
 /* Feed a context whose reads are the locally owned ones with the tuples it received (read =
  * LOCAL read number; other values are ignored).  rala_hip_initialize then skips duplicate
  * removal and builds / annotates the piles from these bounds. */
-int rala_hip_set_bound_tuples(rala_hip_ctx* ctx, const uint32_t* reads, const uint32_t* bounds, uint64_t n, int mem);
+int rala_hip_set_bound_tuples(rala_hip_ctx* ctx, const uint64_t* tuples, uint64_t n, int mem);
 /* Install the result of Graph::initialize computed elsewhere (gathered from the owners) into a
  * context that holds all reads and overlaps, so that rala_hip_construct can follow.  Host
  * arrays; interval CSR as returned by rala_hip_get_intervals (kinds 0 and 1). */

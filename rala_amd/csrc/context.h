@@ -111,13 +111,14 @@ struct rala_hip_ctx {
     rala_hip::DevBuf<uint8_t> d_ovl_strand;
     rala_hip::DevBuf<uint8_t> d_valid, d_suspect;
     bool valid_ready = false;
+    bool inputs_set = false;            // rala_hip_set_overlaps / _set_bound_tuples was called
 
     // bound tuples shipped in by the caller instead of overlaps (multi-GPU owners)
     bool tuple_mode = false;
     uint64_t n_tuples = 0;
-    const uint32_t* tuple_reads = nullptr;
-    const uint32_t* tuple_bounds = nullptr;
-    rala_hip::DevBuf<uint32_t> d_tuple[2], d_owner_cnt;
+    const uint2* tuples = nullptr;      // {x = local read, y = bound}
+    rala_hip::DevBuf<uint2> d_tuple;
+    rala_hip::DevBuf<uint32_t> d_owner_cnt;
     bool piles_resident = false;
 
     // bound CSR
@@ -165,7 +166,8 @@ struct rala_hip_ctx {
     rala_hip::DevBuf<uint16_t> d_dataset_median;
     rala_hip::DevBuf<uint8_t> d_n_rep;
     // sensitive overlaps on the device: columns, transmuted target side, trimmed coordinates, tuples
-    rala_hip::DevBuf<uint32_t> d_sens_col[7], d_sens_tb[2], d_sens_c[5], d_sens_reads, d_sens_bounds;
+    rala_hip::DevBuf<uint32_t> d_sens_col[7], d_sens_tb[2], d_sens_c[5];
+    rala_hip::DevBuf<uint2> d_sens_tuples;
     rala_hip::DevBuf<uint8_t> d_sens_strand, d_sens_state;
     bool sens_in_device = false;        // option "sensitive_in_device_memory"
     rala_hip::DevBuf<uint32_t> d_rep_slot;

@@ -98,6 +98,7 @@ struct OvlSoA {
     const uint32_t *a_id, *b_id, *a_begin, *a_end, *b_begin, *b_end, *length;
     const uint8_t* strand;
     uint64_t n;
+    uint64_t base;      // file position of record 0 (a rank of a sharded run holds a slice of the file)
 };
 
 // trimmed coordinates of the sensitive overlaps (second pass, -s) + kept / dropped
@@ -134,30 +135,31 @@ void launch_dedupe(const OvlSoA& o, uint32_t n_reads, uint8_t* suspect, uint8_t*
 // when a read has more events than a slot holds (the caller then falls back to the CSR path).
 void launch_bucket_fixed(const OvlSoA& o, uint32_t n_reads, uint32_t stride, uint32_t* counts, uint32_t* ev_fixed,
                          uint32_t* over, hipStream_t s);
-void launch_bucket_fixed_tuples(const uint32_t* reads, const uint32_t* bounds, uint64_t n, uint32_t n_reads,
-                                uint32_t stride, uint32_t* counts, uint32_t* ev_fixed, uint32_t* over, hipStream_t s);
+void launch_bucket_fixed_tuples(const uint2* tuples, uint64_t n, uint32_t n_reads, uint32_t stride, uint32_t* counts,
+                                uint32_t* ev_fixed, uint32_t* over, hipStream_t s);
 // counts -> (exclusive scan) -> ev_off; rank_a / rank_b: n_overlaps each, slot of the overlap's
 // bounds inside the bucket of read a / read b
 void launch_count_bounds(const OvlSoA& o, uint32_t n_reads, uint32_t* counts, uint32_t* rank_a, uint32_t* rank_b,
                          hipStream_t s);
 void launch_scatter_bounds(const OvlSoA& o, uint32_t n_reads, const uint32_t* ev_off, const uint32_t* rank_a,
                            const uint32_t* rank_b, uint32_t* ev, hipStream_t s);
-// bound tuples (read, bound) instead of overlaps: multi-GPU owners receive them by all-to-all
-void launch_emit_tuples(const OvlSoA& o, uint32_t n_reads, uint32_t* reads, uint32_t* bounds, hipStream_t s);
+// bound tuples {x = read, y = bound} (8 bytes) instead of overlaps: multi-GPU owners receive them
+// by all-to-all
+void launch_emit_tuples(const OvlSoA& o, uint32_t n_reads, uint2* tuples, hipStream_t s);
 void launch_bucket_tuples(const OvlSoA& o, uint32_t n_reads, uint32_t world, uint32_t pass, uint32_t* counters,
-                          uint32_t* reads, uint32_t* bounds, hipStream_t s);
-void launch_count_tuples(const uint32_t* reads, uint64_t n, uint32_t n_reads, uint32_t* counts, hipStream_t s);
+                          uint2* tuples, hipStream_t s);
+void launch_count_tuples(const uint2* tuples, uint64_t n, uint32_t n_reads, uint32_t* counts, hipStream_t s);
 // sensitive overlaps (graph.cpp:882-1054): transmute_ + target bounds as tuples 2i, 2i + 1;
 // first trim; dovetails mark the repeat hills they bridge
 void launch_sens_tuples(const OvlSoA& o, uint32_t n_reads, const uint32_t* begin, const uint8_t* alive, uint32_t* tb_begin,
-                        uint32_t* tb_end, uint32_t* reads, uint32_t* bounds, uint32_t* error, hipStream_t s);
+                        uint32_t* tb_end, uint2* tuples, uint32_t* error, hipStream_t s);
 void launch_sens_trim(const OvlSoA& o, const uint32_t* tb_begin, const uint32_t* tb_end, const uint32_t* begin,
                       const uint32_t* end, const uint8_t* alive, const SensCoords& out, hipStream_t s);
 void launch_sens_bridge(const OvlSoA& o, const SensCoords& sc, const uint32_t* begin, const uint32_t* end,
                         const uint8_t* alive, const uint8_t* n_rep, const uint32_t* rep_slot, Interval* rep_pool,
                         hipStream_t s);
-void launch_scatter_tuples(const uint32_t* reads, const uint32_t* bounds, uint64_t n, uint32_t n_reads,
-                           uint32_t* cursor, uint32_t* ev, hipStream_t s);
+void launch_scatter_tuples(const uint2* tuples, uint64_t n, uint32_t n_reads, uint32_t* cursor, uint32_t* ev,
+                           hipStream_t s);
 // overlaps that would delete a read (contained read, container without pits / hills)
 struct KillList {
     uint32_t* count;            // device counter, zeroed before classify

@@ -188,23 +188,17 @@ __global__ __launch_bounds__(kBlock) void scatter_bounds_kernel(OvlSoA o, uint32
     *(uint2*)(ev + pb) = make_uint2((o.b_begin[i] + 15u) << 1, ((o.b_end[i] - 15u) << 1) | 1u);
 }
 
-// Multi-GPU: the four bounds of overlap i as (read, bound) tuples at 4i .. 4i+3; the read
+// Multi-GPU: the four bounds of overlap i as 8-byte tuples {read, bound} at 4i .. 4i+3; the read
 // is ~0u for records that do not resolve.
-__global__ __launch_bounds__(kBlock) void emit_tuples_kernel(OvlSoA o, uint32_t n_reads, uint32_t* __restrict__ reads,
-                                                             uint32_t* __restrict__ bounds) {
+__global__ __launch_bounds__(kBlock) void emit_tuples_kernel(OvlSoA o, uint32_t n_reads, uint2* __restrict__ tuples) {
     const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= o.n) return;
     const uint32_t a = o.a_id[i], b = o.b_id[i];
     const bool ok = a < n_reads && b < n_reads;
-    uint4 r, v;
-    r.x = r.y = ok ? a : kInf;
-    r.z = r.w = ok ? b : kInf;
-    v.x = (o.a_begin[i] + 15u) << 1;
-    v.y = ((o.a_end[i] - 15u) << 1) | 1u;
-    v.z = (o.b_begin[i] + 15u) << 1;
-    v.w = ((o.b_end[i] - 15u) << 1) | 1u;
-    ((uint4*)reads)[i] = r;
-    ((uint4*)bounds)[i] = v;
+    const uint32_t ra = ok ? a : kInf, rb = ok ? b : kInf;
+    uint4* out = (uint4*)(tuples + 4 * i);
+    out[0] = make_uint4(ra, (o.a_begin[i] + 15u) << 1, ra, ((o.a_end[i] - 15u) << 1) | 1u);
+    out[1] = make_uint4(rb, (o.b_begin[i] + 15u) << 1, rb, ((o.b_end[i] - 15u) << 1) | 1u);
 }
 
 // Multi-GPU: tuples grouped by the owner of the read (read % world; local read = read / world).
@@ -230,8 +224,7 @@ __device__ __forceinline__ void for_each_owner(uint32_t owner, F f) {
 }
 
 __global__ __launch_bounds__(kBlock) void bucket_tuples_kernel(OvlSoA o, uint32_t n_reads, uint32_t world, uint32_t pass,
-                                                               uint32_t* counters, uint32_t* __restrict__ reads,
-                                                               uint32_t* __restrict__ bounds) {
+                                                               uint32_t* counters, uint2* __restrict__ tuples) {
     static_assert(kBlock == 256, "four wavefronts per workgroup");
     __shared__ uint32_t s_cnt[64], s_base[64];
     const uint32_t lane = threadIdx.x & 63;
@@ -279,22 +272,21 @@ __global__ __launch_bounds__(kBlock) void bucket_tuples_kernel(OvlSoA o, uint32_
                 const uint32_t w = s_base[p] + off + 2u * (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
                 const uint32_t lo = side_b ? o.b_begin[i] : o.a_begin[i];
                 const uint32_t hi = side_b ? o.b_end[i] : o.a_end[i];
-                reads[w] = reads[w + 1] = read / world;
-                bounds[w] = (lo + 15u) << 1;
-                bounds[w + 1] = ((hi - 15u) << 1) | 1u;
+                const uint32_t local = read / world;
+                *(uint4*)(tuples + w) = make_uint4(local, (lo + 15u) << 1, local, ((hi - 15u) << 1) | 1u);
             }
         });
     }
 }
 
 // fixed-slot bucketing of (read, bound) tuples (multi-GPU owners): as bucket_fixed_kernel
-__global__ __launch_bounds__(kBlock) void bucket_fixed_tuples_kernel(const uint32_t* __restrict__ reads,
-                                                                     const uint32_t* __restrict__ bounds, uint64_t n,
+__global__ __launch_bounds__(kBlock) void bucket_fixed_tuples_kernel(const uint2* __restrict__ tuples, uint64_t n,
                                                                      uint32_t n_reads, uint32_t stride, uint32_t* counts,
                                                                      uint32_t* __restrict__ ev_fixed, uint32_t* over) {
     const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t r = i < n ? reads[i] : kInf;
+    const uint2 t = i < n ? tuples[i] : make_uint2(kInf, 0u);
+    const uint32_t r = t.x;
     uint32_t leader;
     const uint32_t seg = segment_of(r, r < n_reads, lane, leader);
     uint32_t base = 0;
@@ -302,33 +294,33 @@ __global__ __launch_bounds__(kBlock) void bucket_fixed_tuples_kernel(const uint3
     base = (uint32_t)__shfl((int)base, (int)leader, 64);
     if (r >= n_reads) return;
     const uint32_t p = base + (lane - leader);
-    if (p < stride) ev_fixed[(size_t)r * stride + p] = bounds[i];
+    if (p < stride) ev_fixed[(size_t)r * stride + p] = t.y;
     else *over = 1u;
 }
 
-__global__ __launch_bounds__(kBlock) void count_tuples_kernel(const uint32_t* __restrict__ reads, uint64_t n,
+__global__ __launch_bounds__(kBlock) void count_tuples_kernel(const uint2* __restrict__ tuples, uint64_t n,
                                                               uint32_t n_reads, uint32_t* counts) {
     const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t r = i < n ? reads[i] : kInf;
+    const uint32_t r = i < n ? tuples[i].x : kInf;
     uint32_t leader;
     const uint32_t seg = segment_of(r, r < n_reads, lane, leader);
     if (seg) atomicAdd(&counts[r], seg);
 }
 
-__global__ __launch_bounds__(kBlock) void scatter_tuples_kernel(const uint32_t* __restrict__ reads,
-                                                                const uint32_t* __restrict__ bounds, uint64_t n,
+__global__ __launch_bounds__(kBlock) void scatter_tuples_kernel(const uint2* __restrict__ tuples, uint64_t n,
                                                                 uint32_t n_reads, uint32_t* cursor,
                                                                 uint32_t* __restrict__ ev) {
     const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t r = i < n ? reads[i] : kInf;
+    const uint2 t = i < n ? tuples[i] : make_uint2(kInf, 0u);
+    const uint32_t r = t.x;
     uint32_t leader;
     const uint32_t seg = segment_of(r, r < n_reads, lane, leader);
     uint32_t base = 0;
     if (seg) base = atomicAdd(&cursor[r], seg);
     base = (uint32_t)__shfl((int)base, (int)leader, 64);
-    if (r < n_reads) ev[base + (lane - leader)] = bounds[i];
+    if (r < n_reads) ev[base + (lane - leader)] = t.y;
 }
 
 __device__ __forceinline__ Coords load_coords(const OvlSoA& o, uint64_t i) {
@@ -411,7 +403,7 @@ __global__ __launch_bounds__(kBlock) void classify_kernel(OvlSoA o, uint32_t n_r
         const uint64_t i = (uint64_t)blockIdx.x * kClassifyChunk + u * kBlock + threadIdx.x;
         const uint32_t a = o.a_id[i], b = o.b_id[i];
         const uint32_t w = base + slot[u];
-        kl.ovl[w] = (uint32_t)i;
+        kl.ovl[w] = (uint32_t)(o.base + i);            // position in the whole file (multi-GPU: slices)
         kl.target[w] = (res[u] & kClsKillsA) ? a : b;
         kl.keeper[w] = (res[u] & kClsKillsA) ? b : a;
     }
@@ -512,7 +504,8 @@ __global__ __launch_bounds__(kBlock) void finish_pass2_kernel(OvlSoA o, uint8_t*
                 const uint32_t da = death[a], db = death[b];
                 const bool hills = (c & kClsHills) != 0;
                 c &= (uint8_t)~kClsHills;
-                if (da >= (uint32_t)i && db >= (uint32_t)i) {
+                const uint32_t at = (uint32_t)(o.base + i);     // position in the whole file
+                if (da >= at && db >= at) {
                     c |= kClsLive;
                     if (hills) {
                         const uint4 ra = rec[a], rb = rec[b];
@@ -601,7 +594,7 @@ __global__ __launch_bounds__(kBlock) void gather_kernel(OvlSoA o, const uint8_t*
         Coords k = load_coords(o, i);
         const uint32_t st = o.strand[i];
         ovl_trim(k, st, ra.x, ra.y, rb.x, rb.y);
-        out.src[p] = (uint32_t)i;
+        out.src[p] = (uint32_t)(o.base + i);
         out.a_id[p] = a; out.b_id[p] = b;
         out.a_begin[p] = k.a_begin; out.a_end[p] = k.a_end;
         out.b_begin[p] = k.b_begin; out.b_end[p] = k.b_end;
@@ -628,10 +621,10 @@ void launch_bucket_fixed(const OvlSoA& o, uint32_t n_reads, uint32_t stride, uin
                            over);
     }
 }
-void launch_bucket_fixed_tuples(const uint32_t* reads, const uint32_t* bounds, uint64_t n, uint32_t n_reads,
+void launch_bucket_fixed_tuples(const uint2* tuples, uint64_t n, uint32_t n_reads,
                                 uint32_t stride, uint32_t* counts, uint32_t* ev_fixed, uint32_t* over, hipStream_t s) {
     if (n) {
-        hipLaunchKernelGGL(bucket_fixed_tuples_kernel, grid_for(n), dim3(kBlock), 0, s, reads, bounds, n, n_reads, stride,
+        hipLaunchKernelGGL(bucket_fixed_tuples_kernel, grid_for(n), dim3(kBlock), 0, s, tuples, n, n_reads, stride,
                            counts, ev_fixed, over);
     }
 }
@@ -645,25 +638,22 @@ void launch_scatter_bounds(const OvlSoA& o, uint32_t n_reads, const uint32_t* ev
         hipLaunchKernelGGL(scatter_bounds_kernel, grid_for(o.n), dim3(kBlock), 0, s, o, n_reads, ev_off, rank_a, rank_b, ev);
     }
 }
-void launch_emit_tuples(const OvlSoA& o, uint32_t n_reads, uint32_t* reads, uint32_t* bounds, hipStream_t s) {
-    if (o.n) hipLaunchKernelGGL(emit_tuples_kernel, grid_for(o.n), dim3(kBlock), 0, s, o, n_reads, reads, bounds);
+void launch_emit_tuples(const OvlSoA& o, uint32_t n_reads, uint2* tuples, hipStream_t s) {
+    if (o.n) hipLaunchKernelGGL(emit_tuples_kernel, grid_for(o.n), dim3(kBlock), 0, s, o, n_reads, tuples);
 }
 void launch_bucket_tuples(const OvlSoA& o, uint32_t n_reads, uint32_t world, uint32_t pass, uint32_t* counters,
-                          uint32_t* reads, uint32_t* bounds, hipStream_t s) {
+                          uint2* tuples, hipStream_t s) {
     if (o.n) {
         hipLaunchKernelGGL(bucket_tuples_kernel, dim3((uint32_t)((o.n + kBucketChunk - 1) / kBucketChunk)), dim3(kBlock), 0, s, o, n_reads, world, pass, counters,
-                           reads, bounds);
+                           tuples);
     }
 }
-void launch_count_tuples(const uint32_t* reads, uint64_t n, uint32_t n_reads, uint32_t* counts, hipStream_t s) {
-    if (n) hipLaunchKernelGGL(count_tuples_kernel, grid_for(n), dim3(kBlock), 0, s, reads, n, n_reads, counts);
+void launch_count_tuples(const uint2* tuples, uint64_t n, uint32_t n_reads, uint32_t* counts, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(count_tuples_kernel, grid_for(n), dim3(kBlock), 0, s, tuples, n, n_reads, counts);
 }
-void launch_scatter_tuples(const uint32_t* reads, const uint32_t* bounds, uint64_t n, uint32_t n_reads,
-                           uint32_t* cursor, uint32_t* ev, hipStream_t s) {
-    if (n) {
-        hipLaunchKernelGGL(scatter_tuples_kernel, grid_for(n), dim3(kBlock), 0, s, reads, bounds, n, n_reads, cursor,
-                           ev);
-    }
+void launch_scatter_tuples(const uint2* tuples, uint64_t n, uint32_t n_reads, uint32_t* cursor, uint32_t* ev,
+                           hipStream_t s) {
+    if (n) hipLaunchKernelGGL(scatter_tuples_kernel, grid_for(n), dim3(kBlock), 0, s, tuples, n, n_reads, cursor, ev);
 }
 void launch_pack_reads(const ReadState& rs, uint32_t n_reads, uint4* rec, hipStream_t s) {
     if (n_reads) hipLaunchKernelGGL(pack_reads_kernel, grid_for(n_reads), dim3(kBlock), 0, s, rs, n_reads, rec);

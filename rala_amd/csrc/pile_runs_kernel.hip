@@ -26,6 +26,8 @@
 
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "device_utils.h"
 #include "geom.h"
 #include "kernels.h"
@@ -38,7 +40,16 @@ namespace {
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr uint16_t kNone16 = 0xFFFFu;
 
-__device__ __forceinline__ void wave_sync() { __syncthreads(); }   // workgroup == one wavefront
+// The workgroup is ONE wavefront.  Its LDS instructions execute in program order, so lanes that
+// exchange data through LDS need no hardware wait - only the compiler must keep the accesses in
+// order.  __syncthreads() would also drain every outstanding global store (s_waitcnt vmcnt(0)
+// in front of each barrier): after the expansion that parks the wave until its whole pile row
+// has reached memory.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 struct RunCursor {
     const uint32_t* rs;     // run starts, rs[R] = n
@@ -266,9 +277,109 @@ struct Layout {
     static_assert(kX >= kCap && kX >= kIdx && kX >= 768, "shared region too small");
 };
 
+
+// Expansion of a pile of up to 16384 positions (2048 groups of 8 = 16 bytes) from the bitmap of
+// run starts: bm (one bit per position that starts a run, bit n set for the padding behind the
+// last base), pref[w] = run starts before word w, rv = run values (rv[R] = 0).
+//
+// A lane owns byte (lane & 3) of bitmap word (group >> 2), so its masks are loop constants.
+// Pass A stores, for every group, the value of the group's first position in all 8 places
+// (no loop, about ten vector instructions per 16-byte store).  A group in which the value
+// changes (a run starts at one of its positions 1..7: about one group in seven) is noted in an
+// LDS list; pass B takes the noted groups 64 at a time, one per lane, walks the changes and
+// stores the group again.  Both stores of such a group go to the L2 within microseconds of
+// each other, HBM sees one write.  The walk used to run inside the store loop, where nearly
+// every iteration had some lane with a change and all 64 lanes paid for it.
+template <class L>
+__device__ __forceinline__ void expand_from_bitmap(uint32_t* sm, const uint16_t* rv, uint16_t* pile, uint64_t row_off,
+                                                   uint32_t nv, uint32_t lane, bool store) {
+    const uint32_t* bm = sm + L::X;
+    const uint16_t* pref = (const uint16_t*)(bm + 512);
+    const uint16_t* rvm1 = rv - 1;                      // indexed by run + 1 (= run starts at or before)
+    uint32_t* list = sm + L::RF;                        // the region lists are not in use yet
+    static_assert(L::SEL - L::RF >= 320, "scratch for the list of groups with a value change");
+    // the row address is the same in every lane: keep it in scalar registers, 32-bit lane offsets
+    // (the builtin returns int: without the casts the low half would be sign-extended over the high one)
+    const uint64_t off = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(row_off >> 32)) << 32) |
+                         (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)row_off);
+    char* base = (char*)(pile + off);
+    const uint32_t sh1 = ((lane & 3u) << 3) + 1u;
+    const uint32_t below = (1u << sh1) - 1u;            // the bits at or before the group's first position
+    const uint32_t w_lane = lane >> 2;
+    uint32_t pend = 0;
+    auto flush = [&]() {
+        wave_sync();
+        for (uint32_t j0 = 0; j0 < pend; j0 += 64) {
+            const uint32_t j = j0 + lane;
+            if (j < pend) {
+                const uint32_t e = list[j];
+                const uint32_t g = e & 2047u;
+                uint32_t kq = (e >> 11) & 2047u;
+                uint32_t inner = e >> 22;
+                const uint32_t v = rvm1[kq];
+                const uint32_t vv = v | (v << 16);
+                uint32_t w0 = vv, w1 = vv, w2 = vv, w3 = vv;
+                do {
+                    const uint32_t x = (uint32_t)__builtin_ctz(inner) + 1u;     // position 1 .. 7 inside the group
+                    inner &= inner - 1;
+                    const uint32_t nvv = rvm1[++kq];
+                    const uint32_t f = nvv | (nvv << 16);
+                    const uint32_t* mt = sm + L::MT + x;
+                    const uint32_t m0 = mt[6], m1 = mt[4], m2 = mt[2], m3 = mt[0];
+                    w0 = bitfield_insert(m0, f, w0);
+                    w1 = bitfield_insert(m1, f, w1);
+                    w2 = bitfield_insert(m2, f, w2);
+                    w3 = bitfield_insert(m3, f, w3);
+                } while (inner);
+                if (store) *(uint4*)(base + g * 16u) = make_uint4(w0, w1, w2, w3);
+            }
+        }
+        wave_sync();
+        pend = 0;
+    };
+    auto chunk = [&](uint32_t g0, auto full_tag) {
+        constexpr bool kFull = decltype(full_tag)::value;
+        uint32_t bits[4], kq[4], v[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4; ++u) {
+            const uint32_t w = (g0 >> 2) + 16u * u + w_lane;        // < 512 for every group below 2048
+            bits[u] = bm[w];
+            kq[u] = pref[w];
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 4; ++u) {
+            kq[u] += (uint32_t)__popc(bits[u] & below);             // bit 0 of the bitmap is set: >= 1
+            v[u] = rvm1[kq[u]];                                     // (beyond the pile: some LDS word)
+        }
+        char* row = base + (size_t)g0 * 16u;
+#pragma unroll
+        for (uint32_t u = 0; u < 4; ++u) {
+            const uint32_t gl = 64u * u + lane;
+            const bool in = kFull || g0 + gl < nv;
+            const uint32_t vv = v[u] | (v[u] << 16);
+            if (in && store) *(uint4*)(row + gl * 16u) = make_uint4(vv, vv, vv, vv);
+            const uint32_t inner = (bits[u] >> sh1) & 0x7Fu;        // run starts at positions 1 .. 7
+            const bool noted = in && inner != 0;
+            const uint64_t m = __builtin_amdgcn_ballot_w64(noted);
+            if (noted) {
+                const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                list[pend + at] = (g0 + gl) | (kq[u] << 11) | (inner << 22);
+            }
+            pend += (uint32_t)__popcll(m);
+        }
+        if (pend >= 64) flush();
+    };
+    uint32_t g0 = 0;
+    for (; g0 + 256 <= nv; g0 += 256) chunk(g0, std::true_type());
+    if (g0 < nv) chunk(g0, std::false_type());
+    if (pend) flush();
+}
+
 }  // namespace
 
-template <uint32_t kCap>
+// kDiag: the diagnostic instantiation honours PileArgs::stop_after (per-phase counter runs,
+// tools/gpurun/gpurun_pmc.sh); the product instantiation carries none of those branches.
+template <uint32_t kCap, bool kDiag>
 __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* overflow_list, uint32_t* overflow_count) {
     typedef Layout<kCap> L;
     constexpr uint32_t kMaxReg = L::kMaxReg, kMaxRaw = L::kMaxRaw;
@@ -282,7 +393,7 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
     const uint32_t n_items = A.n_items_dev ? *A.n_items_dev : A.n_items;
 
 #define RUN_STOP(k)                                                        \
-    if (A.stop_after == (k)) {                                             \
+    if (kDiag && A.stop_after == (k)) {                                    \
         if (lane == 0) A.alive[A.order ? A.order[item] : item] = 0;        \
         wave_sync();                                                       \
         continue;                                                          \
@@ -355,7 +466,7 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
                     pk[q] = lo | (hi << 16);
                 }
                 ((uint4*)pref)[lane] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-                R = (uint32_t)__shfl((int)incl, 63, 64);
+                R = read_lane63(incl);
             }
             wave_sync();
 #pragma unroll
@@ -450,7 +561,7 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
                         ++w;
                     }
                 }
-                R = has_init + (uint32_t)__shfl((int)b_incl, 63, 64);
+                R = has_init + read_lane63(b_incl);
                 if (lane == 0) {
                     if (has_init) { rs[0] = 0; rv[0] = 0; }
                     rs[R] = n;
@@ -469,7 +580,7 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
             uint32_t bad = 0;
             for (uint32_t k = lo; k < hi; ++k) if (rv[k] < kMinCoverage) bad = k + 1;
             uint32_t st = wave_scan_incl(bad, OpMax());
-            st = shfl_up_t(st, 1);
+            st = lane_above(st);
             if (lane == 0) st = 0;
             uint64_t best = 0;
             uint32_t best_kb = 0, best_ke = 0;
@@ -544,7 +655,8 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
         wave_sync();
         {
             // Expansion, 16 bytes (8 positions) per lane and store, consecutive lanes ->
-            // consecutive addresses (1 KiB per wave instruction).  Per segment of 16384
+            // consecutive addresses (1 KiB per wave instruction); reads of up to 16384 positions
+            // go through expand_from_bitmap.  The sorted path, per segment of 16384
             // positions: a bitmap with one bit per position that starts a run, and per
             // 32-bit word the number of run starts before it; the run of position p is then
             // pref[w] + popcount(bits up to p) - no searching, and the byte of the bitmap
@@ -556,14 +668,15 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
             const uint32_t nv = (n + 7) / 8;
             if (lane == 0) rv[R] = 0;                       // padding behind the last base (rs[R] = n)
             uint32_t kbase = 0;                             // run that contains the segment's first position
-            const uint32_t bias = bitmap_path ? 0xFFFFFFFFu : 0u;    // bit 0 is set on the bitmap path
-            for (uint32_t s0 = 0; s0 < nv * 8; s0 += kSeg) {
-                if (bitmap_path) {
-                    // bitmap and prefix of step 1 are still valid; only the padding behind the
-                    // last base needs its own "run" (never crosses into the next word)
-                    if (lane == 0 && n < kSeg) atomicOr(&bm[n >> 5], 1u << (n & 31));
-                    wave_sync();
-                } else {
+            if (bitmap_path) {
+                // bitmap and prefix of step 1 are still valid; only the padding behind the
+                // last base needs its own "run" (never crosses into the next word)
+                if (lane == 0 && n < kSeg) atomicOr(&bm[n >> 5], 1u << (n & 31));
+                wave_sync();
+                expand_from_bitmap<L>(sm, rv, A.pile, A.pile_off[r], nv, lane, !kDiag || A.stop_after != 77);
+            } else
+            for (uint32_t s0 = 0; s0 < nv * 8; s0 += kSeg) {       // sorted path: long reads, many events
+                {
                     wave_sync();
                     ((uint4*)bm)[lane] = make_uint4(0, 0, 0, 0);
                     ((uint4*)bm)[lane + 64] = make_uint4(0, 0, 0, 0);
@@ -589,7 +702,7 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
                             pk[x] = lo | (hi << 16);
                         }
                         ((uint4*)pref)[lane] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-                        kbase += (uint32_t)__shfl((int)incl, 63, 64);
+                        kbase += read_lane63(incl);
                     }
                     wave_sync();
                 }
@@ -607,7 +720,7 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
                     for (uint32_t u = 0; u < 4; ++u) {
                         const uint32_t g = umin(g0 + 64 * u, g_hi - 1);
                         const uint32_t sh = (g * 8) & 31;
-                        k[u] += (uint32_t)__popc(bits[u] & ((2u << sh) - 1u)) + bias;
+                        k[u] += (uint32_t)__popc(bits[u] & ((2u << sh) - 1u));
                         bits[u] = (bits[u] >> (sh + 1)) & 0x7Fu;        // starts at positions 1 .. 7 of the group
                         v[u] = rv[k[u]];
                     }
@@ -630,9 +743,7 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
                             w2 = bitfield_insert(m2, f, w2);
                             w3 = bitfield_insert(m3, f, w3);
                         }
-                        if (A.stop_after != 77) {
-                            dst[g] = make_uint4(w0, w1, w2, w3);
-                        }
+                        if (!kDiag || A.stop_after != 77) dst[g] = make_uint4(w0, w1, w2, w3);
                     }
                 }
             }
@@ -1064,16 +1175,18 @@ void launch_pile_runs(const PileArgs& args, uint32_t grid, int tier, uint32_t* o
     if (grid == 0) return;
     // diagnostics: extra dynamic LDS lowers the occupancy (sensitivity experiments)
     static const uint32_t extra_lds = getenv("RALA_PILE_EXTRA_LDS") ? (uint32_t)atoi(getenv("RALA_PILE_EXTRA_LDS")) : 0u;
-    if (tier == 0) {
-        hipLaunchKernelGGL(pile_runs_kernel<kRunEventCap>, dim3(grid), dim3(64), extra_lds, stream, args, overflow_list,
-                           overflow_count);
-    } else if (tier == 1) {
-        hipLaunchKernelGGL(pile_runs_kernel<kRunEventCapMid>, dim3(grid), dim3(64), 0, stream, args, overflow_list,
-                           overflow_count);
-    } else {
-        hipLaunchKernelGGL(pile_runs_kernel<kRunEventCapBig>, dim3(grid), dim3(64), 0, stream, args, overflow_list,
-                           overflow_count);
-    }
+    const bool diag = args.stop_after != 99;
+#define RALA_LAUNCH_RUNS(cap, lds)                                                                                      \
+    do {                                                                                                                \
+        if (diag) hipLaunchKernelGGL((pile_runs_kernel<cap, true>), dim3(grid), dim3(64), lds, stream, args,            \
+                                     overflow_list, overflow_count);                                                    \
+        else hipLaunchKernelGGL((pile_runs_kernel<cap, false>), dim3(grid), dim3(64), lds, stream, args,                \
+                                overflow_list, overflow_count);                                                         \
+    } while (0)
+    if (tier == 0) RALA_LAUNCH_RUNS(kRunEventCap, extra_lds);
+    else if (tier == 1) RALA_LAUNCH_RUNS(kRunEventCapMid, 0);
+    else RALA_LAUNCH_RUNS(kRunEventCapBig, 0);
+#undef RALA_LAUNCH_RUNS
 }
 
 }  // namespace rala_hip

@@ -21,17 +21,23 @@ using namespace rala_hip;
 
 namespace {
 
+// Every error return drops the staged device -> host copies that were queued but not delivered
+// yet (d2h_small below): their destinations are mostly locals of the function that is returning.
 #define HIPCHECK(call)                                                                       \
     do {                                                                                     \
         hipError_t e_ = (call);                                                              \
         if (e_ != hipSuccess) {                                                              \
             ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);                    \
+            ctx->stage_pending.clear();                                                      \
+            ctx->stage_used = 0;                                                             \
             return e_ == hipErrorOutOfMemory ? RALA_HIP_ENOMEM : RALA_HIP_EDEVICE;           \
         }                                                                                    \
     } while (0)
 
 int fail(rala_hip_ctx* ctx, int code, const char* msg) {
     ctx->err = msg;
+    ctx->stage_pending.clear();
+    ctx->stage_used = 0;
     return code;
 }
 
@@ -54,7 +60,9 @@ hipError_t d2h_small(rala_hip_ctx* ctx, void* dst, const void* src, size_t bytes
 
 hipError_t stream_sync(rala_hip_ctx* ctx, hipStream_t s) {
     const hipError_t e = hipStreamSynchronize(s);
-    for (const auto& c : ctx->stage_pending) memcpy(c.dst, (const char*)ctx->p_stage.p + c.offset, c.bytes);
+    if (e == hipSuccess) {      // a failed wait delivers nothing
+        for (const auto& c : ctx->stage_pending) memcpy(c.dst, (const char*)ctx->p_stage.p + c.offset, c.bytes);
+    }
     ctx->stage_pending.clear();
     ctx->stage_used = 0;
     return e;
@@ -556,7 +564,7 @@ int preprocess_repeats(rala_hip_ctx* ctx, const rala_hip_overlaps* sens, uint64_
             dev_strand = ctx->d_sens_strand.p;
         }
         so.a_id = dev[0]; so.b_id = dev[1]; so.a_begin = dev[2]; so.a_end = dev[3];
-        so.b_begin = dev[4]; so.b_end = dev[5]; so.length = dev[6]; so.strand = dev_strand; so.n = n_sens;
+        so.b_begin = dev[4]; so.b_end = dev[5]; so.length = dev[6]; so.strand = dev_strand; so.n = n_sens; so.base = 0;
     }
     // current valid regions and liveness on the device (a host tail narrowed them on the host)
     HIPCHECK(hipMemcpyAsync(ctx->d_begin.p, ctx->h_begin.data(), n * 4, hipMemcpyHostToDevice, s));
@@ -565,8 +573,7 @@ int preprocess_repeats(rala_hip_ctx* ctx, const rala_hip_overlaps* sens, uint64_
     // Overlap::transmute_ (overlap.cpp:84-114) + bounds of the targets, no +-15 (graph.cpp:929-933),
     // bucketed by read: count -> scan -> scatter
     for (int k = 0; k < 2; ++k) HIPCHECK(ctx->d_sens_tb[k].ensure(n_sens));
-    HIPCHECK(ctx->d_sens_reads.ensure(2 * n_sens + 8));
-    HIPCHECK(ctx->d_sens_bounds.ensure(2 * n_sens + 8));
+    HIPCHECK(ctx->d_sens_tuples.ensure(2 * n_sens + 8));
     HIPCHECK(ctx->d_ev.ensure(2 * n_sens + 8));
     HIPCHECK(ctx->d_dataset_median.ensure(n));
     HIPCHECK(ctx->d_n_rep.ensure(n));
@@ -577,11 +584,11 @@ int preprocess_repeats(rala_hip_ctx* ctx, const rala_hip_overlaps* sens, uint64_
     HIPCHECK(hipMemsetAsync(ctx->d_small.p + 2, 0, 4, s));          // [2] bad sensitive record
     HIPCHECK(hipMemsetAsync(ctx->d_cursor.p, 0, (n + 1) * 4, s));
     launch_sens_tuples(so, (uint32_t)n, ctx->d_begin.p, ctx->d_alive.p, ctx->d_sens_tb[0].p, ctx->d_sens_tb[1].p,
-                       ctx->d_sens_reads.p, ctx->d_sens_bounds.p, ctx->d_small.p + 2, s);
-    launch_count_tuples(ctx->d_sens_reads.p, 2 * n_sens, (uint32_t)n, ctx->d_cursor.p, s);
+                       ctx->d_sens_tuples.p, ctx->d_small.p + 2, s);
+    launch_count_tuples(ctx->d_sens_tuples.p, 2 * n_sens, (uint32_t)n, ctx->d_cursor.p, s);
     launch_exclusive_scan(ctx->d_cursor.p, ctx->d_ev_off.p, n, ctx->d_scan_ws.p, s);
     HIPCHECK(hipMemcpyAsync(ctx->d_cursor.p, ctx->d_ev_off.p, n * 4, hipMemcpyDeviceToDevice, s));
-    launch_scatter_tuples(ctx->d_sens_reads.p, ctx->d_sens_bounds.p, 2 * n_sens, (uint32_t)n, ctx->d_cursor.p, ctx->d_ev.p, s);
+    launch_scatter_tuples(ctx->d_sens_tuples.p, 2 * n_sens, (uint32_t)n, ctx->d_cursor.p, ctx->d_ev.p, s);
     // the targets: reads that received bounds
     std::vector<uint32_t> ev_off(n + 1);
     uint32_t bad = 0;
@@ -1024,7 +1031,8 @@ int rala_hip_create(int device, rala_hip_ctx** out) {
 void rala_hip_destroy(rala_hip_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    (void)stream_sync(ctx, ctx->stream);
+    ctx->stage_pending.clear();             // nobody is waiting for staged copies any more
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->side) (void)hipStreamSynchronize(ctx->side);
     for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
     if (ctx->side) (void)hipStreamDestroy(ctx->side);
@@ -1085,6 +1093,8 @@ int rala_hip_set_reads(rala_hip_ctx* ctx, const uint32_t* read_len, uint64_t n_r
     HIPCHECK(ctx->d_alive.ensure(n_reads)); HIPCHECK(ctx->d_n_pits.ensure(n_reads));
     HIPCHECK(ctx->d_n_hills.ensure(n_reads)); HIPCHECK(ctx->d_iv_slot.ensure(n_reads));
     HIPCHECK(ctx->d_death[0].ensure(n_reads)); HIPCHECK(ctx->d_death[1].ensure(n_reads));
+    // scans run over reads as well as over overlaps / tuples, whichever call comes first
+    HIPCHECK(ctx->d_scan_ws.ensure(scan_workspace_bytes(std::max<uint64_t>(std::max(ctx->n_ovl, ctx->n_tuples), n_reads) + 2)));
     // host mirrors of the per-read state.  They are NOT registered with the runtime: registration
     // pins whole pages, small vectors of different contexts share pages of the heap, and
     // unregistering one context's vectors then unmapped pages another context's copies still went
@@ -1127,7 +1137,9 @@ int rala_hip_set_overlaps(rala_hip_ctx* ctx, const rala_hip_overlaps* o, uint64_
     ctx->ovl.a_id = dev[0]; ctx->ovl.b_id = dev[1]; ctx->ovl.a_begin = dev[2]; ctx->ovl.a_end = dev[3];
     ctx->ovl.b_begin = dev[4]; ctx->ovl.b_end = dev[5]; ctx->ovl.length = dev[6]; ctx->ovl.strand = dev_strand;
     ctx->ovl.n = n;
+    ctx->ovl.base = 0;
     ctx->tuple_mode = false;
+    ctx->inputs_set = true;
     ctx->valid_ready = false;
     HIPCHECK(ctx->d_valid.ensure(n));
     HIPCHECK(ctx->d_ev.ensure(4 * n + 8));
@@ -1141,6 +1153,7 @@ int rala_hip_set_overlaps(rala_hip_ctx* ctx, const rala_hip_overlaps* o, uint64_
 int rala_hip_initialize(rala_hip_ctx* ctx) {
     if (!ctx) return RALA_HIP_EINVAL;
     if (ctx->n_reads == 0) return fail(ctx, RALA_HIP_EINVAL, "no reads set");
+    if (!ctx->inputs_set) return fail(ctx, RALA_HIP_EINVAL, "no overlaps or bound tuples set");
     HIPCHECK(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     const uint32_t n_reads = (uint32_t)ctx->n_reads;
@@ -1176,7 +1189,7 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
         HIPCHECK(hipMemsetAsync(ctx->d_cursor.p, 0, (size_t)(n_reads + 1) * 4, s));
         HIPCHECK(hipMemsetAsync(ctx->d_cc_flags.p + 5, 0, 4, s));
         if (ctx->tuple_mode) {
-            launch_bucket_fixed_tuples(ctx->tuple_reads, ctx->tuple_bounds, ctx->n_tuples, n_reads, slot, ctx->d_cursor.p,
+            launch_bucket_fixed_tuples(ctx->tuples, ctx->n_tuples, n_reads, slot, ctx->d_cursor.p,
                                        ctx->d_ev_fixed.p, ctx->d_cc_flags.p + 5, s);
         } else {
             launch_bucket_fixed(ctx->ovl, n_reads, slot, ctx->d_cursor.p, ctx->d_ev_fixed.p, ctx->d_cc_flags.p + 5, s);
@@ -1188,7 +1201,7 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
     // count -> exclusive scan -> scatter
     HIPCHECK(hipMemsetAsync(ctx->d_cursor.p, 0, (size_t)(n_reads + 1) * 4, s));
     if (ctx->tuple_mode) {
-        launch_count_tuples(ctx->tuple_reads, ctx->n_tuples, n_reads, ctx->d_cursor.p, s);
+        launch_count_tuples(ctx->tuples, ctx->n_tuples, n_reads, ctx->d_cursor.p, s);
     } else {
         HIPCHECK(ctx->d_slot_rank[0].ensure(ctx->n_ovl + 1)); HIPCHECK(ctx->d_slot_rank[1].ensure(ctx->n_ovl + 1));
         launch_count_bounds(ctx->ovl, n_reads, ctx->d_cursor.p, ctx->d_slot_rank[0].p, ctx->d_slot_rank[1].p, s);
@@ -1196,8 +1209,7 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
     launch_exclusive_scan(ctx->d_cursor.p, ctx->d_ev_off.p, n_reads, ctx->d_scan_ws.p, s);
     if (ctx->tuple_mode) {
         HIPCHECK(hipMemcpyAsync(ctx->d_cursor.p, ctx->d_ev_off.p, (size_t)n_reads * 4, hipMemcpyDeviceToDevice, s));
-        launch_scatter_tuples(ctx->tuple_reads, ctx->tuple_bounds, ctx->n_tuples, n_reads, ctx->d_cursor.p,
-                              ctx->d_ev.p, s);
+        launch_scatter_tuples(ctx->tuples, ctx->n_tuples, n_reads, ctx->d_cursor.p, ctx->d_ev.p, s);
     } else {
         launch_scatter_bounds(ctx->ovl, n_reads, ctx->d_ev_off.p, ctx->d_slot_rank[0].p, ctx->d_slot_rank[1].p, ctx->d_ev.p, s);
     }
@@ -1305,6 +1317,7 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
 int rala_hip_dedupe(rala_hip_ctx* ctx) {
     if (!ctx) return RALA_HIP_EINVAL;
     if (ctx->n_reads == 0) return fail(ctx, RALA_HIP_EINVAL, "no reads set");
+    if (!ctx->inputs_set || ctx->tuple_mode) return fail(ctx, RALA_HIP_EINVAL, "no overlaps set");
     HIPCHECK(hipSetDevice(ctx->device));
     launch_dedupe(ctx->ovl, (uint32_t)ctx->n_reads, ctx->d_suspect.p, ctx->d_valid.p, ctx->stream);
     HIPCHECK(stream_sync(ctx, ctx->stream));
@@ -1313,25 +1326,26 @@ int rala_hip_dedupe(rala_hip_ctx* ctx) {
     return RALA_HIP_OK;
 }
 
-int rala_hip_emit_bound_tuples(rala_hip_ctx* ctx, uint32_t* reads_dev, uint32_t* bounds_dev) {
-    if (!ctx || !reads_dev || !bounds_dev) return RALA_HIP_EINVAL;
+int rala_hip_emit_bound_tuples(rala_hip_ctx* ctx, uint64_t* tuples_dev) {
+    if (!ctx || !tuples_dev) return RALA_HIP_EINVAL;
+    if (((uintptr_t)tuples_dev & 15u) != 0) return fail(ctx, RALA_HIP_EINVAL, "tuple buffer must be 16-byte aligned");
     HIPCHECK(hipSetDevice(ctx->device));
-    launch_emit_tuples(ctx->ovl, (uint32_t)ctx->n_reads, reads_dev, bounds_dev, ctx->stream);
+    launch_emit_tuples(ctx->ovl, (uint32_t)ctx->n_reads, (uint2*)tuples_dev, ctx->stream);
     HIPCHECK(stream_sync(ctx, ctx->stream));
     HIPCHECK(hipGetLastError());
     return RALA_HIP_OK;
 }
 
-int rala_hip_emit_bound_tuples_bucketed(rala_hip_ctx* ctx, uint32_t world, uint32_t* reads_dev, uint32_t* bounds_dev,
-                                        uint64_t* counts) {
-    if (!ctx || !reads_dev || !bounds_dev || !counts || world == 0 || world > 64) return RALA_HIP_EINVAL;
+int rala_hip_emit_bound_tuples_bucketed(rala_hip_ctx* ctx, uint32_t world, uint64_t* tuples_dev, uint64_t* counts) {
+    if (!ctx || !tuples_dev || !counts || world == 0 || world > 64) return RALA_HIP_EINVAL;
+    if (((uintptr_t)tuples_dev & 15u) != 0) return fail(ctx, RALA_HIP_EINVAL, "tuple buffer must be 16-byte aligned");
     HIPCHECK(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     HIPCHECK(ctx->d_owner_cnt.ensure(2 * 64));
     uint32_t* cnt = ctx->d_owner_cnt.p;
     uint32_t* cur = cnt + 64;
     HIPCHECK(hipMemsetAsync(cnt, 0, 2 * 64 * 4, s));
-    launch_bucket_tuples(ctx->ovl, (uint32_t)ctx->n_reads, world, 0, cnt, reads_dev, bounds_dev, s);
+    launch_bucket_tuples(ctx->ovl, (uint32_t)ctx->n_reads, world, 0, cnt, (uint2*)tuples_dev, s);
     uint32_t h[64];
     HIPCHECK(hipMemcpyAsync(h, cnt, world * 4, hipMemcpyDeviceToHost, s));
     HIPCHECK(stream_sync(ctx, s));
@@ -1339,7 +1353,7 @@ int rala_hip_emit_bound_tuples_bucketed(rala_hip_ctx* ctx, uint32_t world, uint3
     uint32_t acc = 0;
     for (uint32_t p = 0; p < world; ++p) { off[p] = acc; acc += h[p]; counts[p] = h[p]; }
     HIPCHECK(hipMemcpyAsync(cur, off, world * 4, hipMemcpyHostToDevice, s));
-    launch_bucket_tuples(ctx->ovl, (uint32_t)ctx->n_reads, world, 1, cur, reads_dev, bounds_dev, s);
+    launch_bucket_tuples(ctx->ovl, (uint32_t)ctx->n_reads, world, 1, cur, (uint2*)tuples_dev, s);
     HIPCHECK(stream_sync(ctx, s));
     HIPCHECK(hipGetLastError());
     return RALA_HIP_OK;
@@ -1437,26 +1451,21 @@ int rala_hip_import_state_device(rala_hip_ctx* ctx, const rala_hip_device_state*
     return RALA_HIP_OK;
 }
 
-int rala_hip_set_bound_tuples(rala_hip_ctx* ctx, const uint32_t* reads, const uint32_t* bounds, uint64_t n, int mem) {
-    if (!ctx || (n && (!reads || !bounds))) return RALA_HIP_EINVAL;
+int rala_hip_set_bound_tuples(rala_hip_ctx* ctx, const uint64_t* tuples, uint64_t n, int mem) {
+    if (!ctx || (n && !tuples)) return RALA_HIP_EINVAL;
     if (ctx->n_reads == 0) return fail(ctx, RALA_HIP_EINVAL, "no reads set");
     if (n >= 0xFFFFFFF0ull) return fail(ctx, RALA_HIP_EINVAL, "too many tuples");
     HIPCHECK(hipSetDevice(ctx->device));
     if (mem == RALA_HIP_MEM_DEVICE) {
-        ctx->tuple_reads = reads;
-        ctx->tuple_bounds = bounds;
+        ctx->tuples = (const uint2*)tuples;
     } else {
-        HIPCHECK(ctx->d_tuple[0].ensure(n));
-        HIPCHECK(ctx->d_tuple[1].ensure(n));
-        if (n) {
-            HIPCHECK(hipMemcpy(ctx->d_tuple[0].p, reads, n * 4, hipMemcpyHostToDevice));
-            HIPCHECK(hipMemcpy(ctx->d_tuple[1].p, bounds, n * 4, hipMemcpyHostToDevice));
-        }
-        ctx->tuple_reads = ctx->d_tuple[0].p;
-        ctx->tuple_bounds = ctx->d_tuple[1].p;
+        HIPCHECK(ctx->d_tuple.ensure(n));
+        if (n) HIPCHECK(hipMemcpy(ctx->d_tuple.p, tuples, n * 8, hipMemcpyHostToDevice));
+        ctx->tuples = ctx->d_tuple.p;
     }
     ctx->n_tuples = n;
     ctx->tuple_mode = true;
+    ctx->inputs_set = true;
     ctx->n_ovl = 0;
     ctx->ovl = OvlSoA();
     HIPCHECK(ctx->d_ev.ensure(n + 8));
@@ -1527,7 +1536,7 @@ int rala_hip_import_state(rala_hip_ctx* ctx, const uint8_t* valid, const uint32_
 int rala_hip_construct(rala_hip_ctx* ctx, const rala_hip_overlaps* sens, uint64_t n_sens) {
     if (!ctx) return RALA_HIP_EINVAL;
     if (!ctx->initialized) return fail(ctx, RALA_HIP_EINVAL, "rala_hip_initialize must succeed first");
-    if (ctx->tuple_mode) return fail(ctx, RALA_HIP_EINVAL, "construct needs the overlaps (tuple-fed context)");
+    if (ctx->tuple_mode || !ctx->inputs_set) return fail(ctx, RALA_HIP_EINVAL, "construct needs the overlaps (rala_hip_set_overlaps)");
     if (ctx->constructed) return fail(ctx, RALA_HIP_EINVAL, "object already constructed");
     if (sens != nullptr && n_sens != 0 && !ctx->piles_resident) {
         return fail(ctx, RALA_HIP_EINVAL, "the sensitive pass needs the piles on this context");

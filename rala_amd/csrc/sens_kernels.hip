@@ -22,8 +22,7 @@ constexpr uint32_t kInf = 0xFFFFFFFFu;
 __global__ __launch_bounds__(kBlock) void sens_tuples_kernel(OvlSoA o, uint32_t n_reads, const uint32_t* __restrict__ begin,
                                                              const uint8_t* __restrict__ alive,
                                                              uint32_t* __restrict__ tb_begin, uint32_t* __restrict__ tb_end,
-                                                             uint32_t* __restrict__ reads, uint32_t* __restrict__ bounds,
-                                                             uint32_t* error) {
+                                                             uint2* __restrict__ tuples, uint32_t* error) {
     const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= o.n) return;
     const uint32_t a = o.a_id[i], b = o.b_id[i];
@@ -39,8 +38,7 @@ __global__ __launch_bounds__(kBlock) void sens_tuples_kernel(OvlSoA o, uint32_t 
         r = b;
     }
     tb_begin[i] = x; tb_end[i] = y;
-    reads[2 * i] = r; reads[2 * i + 1] = r;
-    bounds[2 * i] = x << 1; bounds[2 * i + 1] = (y << 1) | 1u;
+    *(uint4*)(tuples + 2 * i) = make_uint4(r, x << 1, r, (y << 1) | 1u);
 }
 
 // first Overlap::trim of every sensitive overlap (graph.cpp:935-939); state 1 = kept
@@ -104,10 +102,10 @@ dim3 grid_for(uint64_t n) { return dim3((uint32_t)((n + kBlock - 1) / kBlock)); 
 }  // namespace
 
 void launch_sens_tuples(const OvlSoA& o, uint32_t n_reads, const uint32_t* begin, const uint8_t* alive, uint32_t* tb_begin,
-                        uint32_t* tb_end, uint32_t* reads, uint32_t* bounds, uint32_t* error, hipStream_t s) {
+                        uint32_t* tb_end, uint2* tuples, uint32_t* error, hipStream_t s) {
     if (o.n) {
         hipLaunchKernelGGL(sens_tuples_kernel, grid_for(o.n), dim3(kBlock), 0, s, o, n_reads, begin, alive, tb_begin, tb_end,
-                           reads, bounds, error);
+                           tuples, error);
     }
 }
 void launch_sens_trim(const OvlSoA& o, const uint32_t* tb_begin, const uint32_t* tb_end, const uint32_t* begin,

@@ -90,10 +90,10 @@ def lib(build=True):
         L.rala_hip_get_timings.argtypes = [vp, ctypes.POINTER(Timings)]
         L.rala_hip_get_num_prefiltered.argtypes = [vp, ctypes.POINTER(u64)]
         L.rala_hip_dedupe.argtypes = [vp]
-        L.rala_hip_emit_bound_tuples.argtypes = [vp, vp, vp]
-        L.rala_hip_set_bound_tuples.argtypes = [vp, vp, vp, u64, i32]
+        L.rala_hip_emit_bound_tuples.argtypes = [vp, vp]
+        L.rala_hip_set_bound_tuples.argtypes = [vp, vp, u64, i32]
         L.rala_hip_import_state.argtypes = [vp] + [vp] * 11
-        L.rala_hip_emit_bound_tuples_bucketed.argtypes = [vp, u32, vp, vp, vp]
+        L.rala_hip_emit_bound_tuples_bucketed.argtypes = [vp, u32, vp, vp]
         L.rala_hip_get_device_state.argtypes = [vp, ctypes.POINTER(DeviceState)]
         L.rala_hip_import_state_device.argtypes = [vp, ctypes.POINTER(DeviceState)]
         L.rala_hip_copy_device_state.argtypes = [vp, ctypes.POINTER(DeviceState)]
@@ -178,9 +178,9 @@ class Context:
     def dedupe(self):
         self._check(self.L.rala_hip_dedupe(self.h))
 
-    def emit_bound_tuples(self, reads_ptr, bounds_ptr):
-        """device pointers of 4 * n_overlaps uint32 each"""
-        self._check(self.L.rala_hip_emit_bound_tuples(self.h, reads_ptr, bounds_ptr))
+    def emit_bound_tuples(self, tuples_ptr):
+        """device pointer of 4 * n_overlaps 8-byte tuples (read | bound << 32), 16-byte aligned"""
+        self._check(self.L.rala_hip_emit_bound_tuples(self.h, tuples_ptr))
 
     def layout(self, x, y, adj_off, adj, iterations, k, t, dt):
         """force-directed layout steps (rala_hip_layout); x, y float64 arrays updated in place"""
@@ -190,11 +190,10 @@ class Context:
         self._check(self.L.rala_hip_layout(self.h, len(x), x.ctypes.data, y.ctypes.data, adj_off.ctypes.data,
                                            adj.ctypes.data if len(adj) else None, iterations, k, t, dt))
 
-    def emit_bound_tuples_bucketed(self, world, reads_ptr, bounds_ptr):
+    def emit_bound_tuples_bucketed(self, world, tuples_ptr):
         """tuples grouped by owner rank; returns the bucket sizes"""
         counts = np.zeros(world, dtype=np.uint64)
-        self._check(self.L.rala_hip_emit_bound_tuples_bucketed(self.h, world, reads_ptr, bounds_ptr,
-                                                                  counts.ctypes.data))
+        self._check(self.L.rala_hip_emit_bound_tuples_bucketed(self.h, world, tuples_ptr, counts.ctypes.data))
         return counts
 
     def device_state(self):
@@ -216,16 +215,15 @@ class Context:
             setattr(st, k, v)
         self._check(self.L.rala_hip_import_state_device(self.h, ctypes.byref(st)))
 
-    def set_bound_tuples_device(self, reads_ptr, bounds_ptr, n):
+    def set_bound_tuples_device(self, tuples_ptr, n):
         self.n_overlaps = 0
-        self._check(self.L.rala_hip_set_bound_tuples(self.h, reads_ptr, bounds_ptr, int(n), MEM_DEVICE))
+        self._check(self.L.rala_hip_set_bound_tuples(self.h, tuples_ptr, int(n), MEM_DEVICE))
 
     def set_bound_tuples(self, reads, bounds):
-        reads = np.ascontiguousarray(reads, dtype=np.uint32)
-        bounds = np.ascontiguousarray(bounds, dtype=np.uint32)
+        """host arrays (local read, bound) -> packed 8-byte tuples"""
+        t = np.ascontiguousarray(reads, dtype=np.uint64) | (np.ascontiguousarray(bounds, dtype=np.uint64) << np.uint64(32))
         self.n_overlaps = 0
-        self._check(self.L.rala_hip_set_bound_tuples(self.h, reads.ctypes.data, bounds.ctypes.data, len(reads),
-                                                     MEM_HOST))
+        self._check(self.L.rala_hip_set_bound_tuples(self.h, t.ctypes.data, len(t), MEM_HOST))
 
     def import_state(self, valid, piles, pits, hills):
         """piles: dict as returned by piles(); pits / hills: (offsets, pairs, aux) as intervals()."""

@@ -81,9 +81,11 @@ bool read_sequences(const std::string& path, const io::SequenceSink& sink) {
 }
 
 // one pass over an overlap file into binary columns (the reference parses twice, graph.cpp:328,443);
-// uncompressed PAF goes through the multi-threaded reader
+// uncompressed PAF goes through the multi-threaded reader.  check_lengths: the primary overlaps go
+// through Overlap::transmute, which compares both lengths with the sequence file
+// (overlap.cpp:54-59,73-78); the sensitive ones through transmute_, which checks nothing (:84-114)
 void read_overlaps(const std::string& path, const std::unordered_map<std::string, uint64_t>& name_to_id,
-    const io::NameTable& name_table, const std::vector<uint32_t>& read_len, bool check_target_length,
+    const io::NameTable& name_table, const std::vector<uint32_t>& read_len, bool check_lengths,
     uint32_t num_threads, io::OverlapColumns& c) {
     auto push = [&](uint32_t a, uint32_t b, uint32_t ab, uint32_t ae, uint32_t bb, uint32_t be, uint32_t len,
                     uint32_t strand) {
@@ -100,15 +102,15 @@ void read_overlaps(const std::string& path, const std::unordered_map<std::string
     bool ok;
     if (io::has_suffix(path, ".paf")) {
         int64_t bad = -1;
-        ok = io::read_paf_parallel(path, name_table, read_len, check_target_length, num_threads, c, &bad);
+        ok = io::read_paf_parallel(path, name_table, read_len, check_lengths, num_threads, c, &bad);
         if (ok && bad >= 0) length_error((uint64_t)bad);
     } else if (io::has_suffix(path, ".mhap") || io::has_suffix(path, ".mhap.gz")) {
         ok = io::read_mhap(path, [&](const io::MhapRecord& r) {
             const uint64_t a = r.a_id - 1, b = r.b_id - 1;
             const uint32_t ia = a < read_len.size() ? (uint32_t)a : RALA_HIP_NO_READ;
             const uint32_t ib = b < read_len.size() ? (uint32_t)b : RALA_HIP_NO_READ;
-            if (ia != RALA_HIP_NO_READ && r.a_length != read_len[ia]) length_error(a);
-            if (check_target_length && ib != RALA_HIP_NO_READ && ia != RALA_HIP_NO_READ && r.b_length != read_len[ib]) {
+            if (check_lengths && ia != RALA_HIP_NO_READ && r.a_length != read_len[ia]) length_error(a);
+            if (check_lengths && ib != RALA_HIP_NO_READ && ia != RALA_HIP_NO_READ && r.b_length != read_len[ib]) {
                 length_error(b);
             }
             push(ia, ib, r.a_begin, r.a_end, r.b_begin, r.b_end, std::max(r.a_end - r.a_begin, r.b_end - r.b_begin),
@@ -120,8 +122,8 @@ void read_overlaps(const std::string& path, const std::unordered_map<std::string
             const uint32_t ia = a == name_to_id.end() ? RALA_HIP_NO_READ : (uint32_t)a->second;
             const uint32_t ib = b == name_to_id.end() ? RALA_HIP_NO_READ : (uint32_t)b->second;
             // Overlap::transmute checks a first and stops at the first unknown name (overlap.cpp:43-78)
-            if (ia != RALA_HIP_NO_READ && r.q_length != read_len[ia]) length_error(ia);
-            if (check_target_length && ia != RALA_HIP_NO_READ && ib != RALA_HIP_NO_READ && r.t_length != read_len[ib]) {
+            if (check_lengths && ia != RALA_HIP_NO_READ && r.q_length != read_len[ia]) length_error(ia);
+            if (check_lengths && ia != RALA_HIP_NO_READ && ib != RALA_HIP_NO_READ && r.t_length != read_len[ib]) {
                 length_error(ib);
             }
             push(ia, ib, r.q_begin, r.q_end, r.t_begin, r.t_end, r.overlap_length, r.orientation == '+' ? 0 : 1);

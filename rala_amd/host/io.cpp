@@ -206,7 +206,7 @@ struct alignas(256) Chunk {        // one per thread, appended to on every line:
 
 // one line [p, e) (no newline); returns false if it is not a 12-column record
 inline bool parse_paf_line(const char* p, const char* e, const NameTable& names, const std::vector<uint32_t>& read_len,
-                           bool check_target_length, Chunk& c) {
+                           bool check_lengths, Chunk& c) {
     const char* f[13];
     int nf = 0;
     f[nf++] = p;
@@ -236,8 +236,8 @@ inline bool parse_paf_line(const char* p, const char* e, const NameTable& names,
     const uint32_t ia = a == ~0ull ? 0xFFFFFFFFu : (uint32_t)a;
     const uint32_t ib = b == ~0ull ? 0xFFFFFFFFu : (uint32_t)b;
     if (c.error_read < 0) {
-        if (ia != 0xFFFFFFFFu && ql != read_len[ia]) c.error_read = ia;
-        else if (check_target_length && ia != 0xFFFFFFFFu && ib != 0xFFFFFFFFu && tl != read_len[ib]) c.error_read = ib;
+        if (check_lengths && ia != 0xFFFFFFFFu && ql != read_len[ia]) c.error_read = ia;
+        else if (check_lengths && ia != 0xFFFFFFFFu && ib != 0xFFFFFFFFu && tl != read_len[ib]) c.error_read = ib;
     }
     c.cols.a_id.push_back(ia); c.cols.b_id.push_back(ib);
     c.cols.a_begin.push_back(qb); c.cols.a_end.push_back(qe);
@@ -305,7 +305,7 @@ void* allocate_block(size_t bytes) {
 void free_block(void* p, size_t) { free(p); }
 
 bool read_paf_parallel(const std::string& path, const NameTable& names, const std::vector<uint32_t>& read_len,
-    bool check_target_length, uint32_t num_threads, OverlapColumns& out, int64_t* length_error) {
+    bool check_lengths, uint32_t num_threads, OverlapColumns& out, int64_t* length_error) {
     if (length_error) *length_error = -1;
     const int fd = open(path.c_str(), O_RDONLY);
     if (fd < 0) return false;
@@ -371,7 +371,7 @@ bool read_paf_parallel(const std::string& path, const NameTable& names, const st
             const size_t e = nl ? (size_t)(nl - base) : from + have;
             size_t le = e;
             if (le > p && base[le - 1] == '\r') --le;
-            if (le > p) parse_paf_line(base + p, base + le, names, read_len, check_target_length, c);
+            if (le > p) parse_paf_line(base + p, base + le, names, read_len, check_lengths, c);
             p = e + 1;
         }
         t_parse[t] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w1).count();

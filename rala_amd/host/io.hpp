@@ -82,7 +82,7 @@ struct OverlapColumns {
 // the sequence's is fatal - returned as the offending read id in *length_error (the first such
 // line in file order), the caller prints the reference's message.  false = cannot open / map.
 bool read_paf_parallel(const std::string& path, const NameTable& names, const std::vector<uint32_t>& read_len,
-    bool check_target_length, uint32_t num_threads, OverlapColumns& out, int64_t* length_error);
+    bool check_lengths, uint32_t num_threads, OverlapColumns& out, int64_t* length_error);
 
 }  // namespace io
 }  // namespace rala

@@ -23,7 +23,7 @@ extern "C" {
 
 // names: n_reads names separated by '\n'.  parallel = 0: io::read_paf + std::unordered_map (the
 // path gzip input takes), 1: io::read_paf_parallel
-void* io_paf_parse(const char* path, const char* names, const uint32_t* read_len, uint64_t n_reads, int check_target,
+void* io_paf_parse(const char* path, const char* names, const uint32_t* read_len, uint64_t n_reads, int check_lengths,
                    uint32_t threads, int parallel) {
     std::vector<std::string> nm;
     const char* p = names;
@@ -37,7 +37,7 @@ void* io_paf_parse(const char* path, const char* names, const uint32_t* read_len
     if (parallel) {
         rala::io::NameTable table;
         table.build(nm);
-        out->ok = rala::io::read_paf_parallel(path, table, len, check_target != 0, threads, out->cols, &out->length_error);
+        out->ok = rala::io::read_paf_parallel(path, table, len, check_lengths != 0, threads, out->cols, &out->length_error);
         return out;
     }
     std::unordered_map<std::string, uint64_t> map;
@@ -48,8 +48,8 @@ void* io_paf_parse(const char* path, const char* names, const uint32_t* read_len
         const uint32_t ia = a == map.end() ? 0xFFFFFFFFu : (uint32_t)a->second;
         const uint32_t ib = b == map.end() ? 0xFFFFFFFFu : (uint32_t)b->second;
         if (out->length_error < 0) {
-            if (ia != 0xFFFFFFFFu && r.q_length != len[ia]) out->length_error = ia;
-            else if (check_target && ia != 0xFFFFFFFFu && ib != 0xFFFFFFFFu && r.t_length != len[ib]) out->length_error = ib;
+            if (check_lengths && ia != 0xFFFFFFFFu && r.q_length != len[ia]) out->length_error = ia;
+            else if (check_lengths && ia != 0xFFFFFFFFu && ib != 0xFFFFFFFFu && r.t_length != len[ib]) out->length_error = ib;
         }
         c.a_id.push_back(ia); c.b_id.push_back(ib);
         c.a_begin.push_back(r.q_begin); c.a_end.push_back(r.q_end);

@@ -5,8 +5,14 @@ that the GPU suite can check the HIP path at full size without running the oracl
     python tests/golden/make_fullsize_digests.py c2 [threads]
     python tests/golden/make_fullsize_digests.py c2 [threads] sens      -> fullsize_c2_sens.json: the same
         after the sensitive pass (-s) with the generator's sensitive overlap set
+    ... flat                                                            -> flat restatement instead
 
-Needs roughly 2.5 GB (c2) / 30 GB (c3) of host memory."""
+The oracle runs on the reference's own rala::Pile / rala::Overlap objects (oracle/_ref, compiled
+from /root/reference/src/pile.cpp and overlap.cpp where they lie) whenever that library is built;
+the JSON records which backend produced it ("backend").  c5x = 200 k reads at C5's 75x coverage
+(BASELINE configs[4] itself, 4 M reads / 300 M overlaps, does not fit this container's memory).
+
+Needs roughly 2.5 GB (c2) / 8 GB (c5x) / 40 GB (c3) of host memory."""
 import hashlib
 import json
 import os
@@ -19,7 +25,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 
 from rala_amd.synth import Dataset
-from oracle.oracle import Oracle
+from oracle.oracle import Oracle, have_ref
 
 SAMPLE = 400          # reads whose whole coverage vector is digested
 
@@ -40,12 +46,13 @@ def sample_reads(n_reads, alive):
 
 def main():
     wl = sys.argv[1]
-    threads = int(sys.argv[2]) if len(sys.argv) > 2 else (os.cpu_count() or 1)
-    with_sens = len(sys.argv) > 3 and sys.argv[3] == "sens"
+    threads = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else (os.cpu_count() or 1)
+    with_sens = "sens" in sys.argv[2:]
+    use_ref = have_ref() and "flat" not in sys.argv[2:]
     t0 = time.time()
     ds = Dataset.config(wl)
-    o = Oracle(ds.read_len, ds.overlaps, n_threads=threads)
-    out = {"workload": wl, "n_reads": int(ds.n_reads), "n_overlaps": len(ds.overlaps)}
+    o = Oracle(ds.read_len, ds.overlaps, n_threads=threads, ref=use_ref)
+    out = {"workload": wl, "backend": o.backend, "n_reads": int(ds.n_reads), "n_overlaps": len(ds.overlaps)}
     assert o.initialize() == 0
     p = o.piles()
     out["valid"] = dg(np.packbits(o.valid()))

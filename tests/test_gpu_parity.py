@@ -294,6 +294,8 @@ def test_call_order_and_argument_errors(hip_ctx_factory):
     assert code(ctx.initialize) == -2                      # no reads set
     assert code(ctx.set_option, "no_such_option", 1) == -2
     ctx.set_reads(ds.read_len)
+    assert code(ctx.initialize) == -2                      # neither overlaps nor bound tuples set
+    assert code(ctx.dedupe) == -2
     ctx.set_overlaps(ds.overlaps)
     assert code(ctx.construct) == -2                       # initialize first
     assert code(ctx.piles) == -2
@@ -312,3 +314,33 @@ def test_call_order_and_argument_errors(hip_ctx_factory):
     ctx.initialize()
     ctx.construct()
     assert ctx.remove_transitive_edges() == n
+
+
+def test_inputs_in_either_order_and_context_reuse(hip_ctx_factory):
+    """overlaps before reads, and a context used again with MORE reads than overlaps (the scan
+    workspace has to follow the larger of the two whichever call comes last)"""
+    from oracle.oracle import Oracle
+
+    ds = Dataset(1500, 300_000, 9)
+    o = Oracle(ds.read_len, ds.overlaps, n_threads=4)
+    o.construct()
+    ctx = hip_ctx_factory()
+    ctx.set_reads(ds.read_len[:10])
+    ctx.set_overlaps(ds.overlaps.take(slice(0, 0)))
+    # now the real inputs, reads last
+    ctx.set_overlaps(ds.overlaps)
+    ctx.set_reads(ds.read_len)
+    ctx.initialize()
+    ctx.construct()
+    want, got = o.piles(), ctx.piles()
+    for k in ("alive", "begin", "end", "median"):
+        assert (got[k] == want[k]).all(), k
+    # many reads, few overlaps (n_reads > n_overlaps)
+    few = ds.overlaps.take(slice(0, 50))
+    big_len = np.concatenate([ds.read_len] * 4)
+    ctx.set_overlaps(few)
+    ctx.set_reads(big_len)
+    try:
+        ctx.initialize()
+    except Exception as e:          # everything filtered is a legitimate outcome here
+        assert getattr(e, "code", 0) == -4
