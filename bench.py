@@ -22,6 +22,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md)
+WRITE_ONLY_GBS = 5100.0 # what a kernel that only writes the same rows reaches (tools/fill_bench.hip)
 
 WORKLOADS = {
     "c1": "1k reads / 50k overlaps (BASELINE configs[0])",
@@ -59,6 +60,14 @@ def cpu_baseline(sample_name="c2"):
     have_ref = os.path.exists(os.path.join(ROOT, "oracle", "_ref", "liboracle_ref.so"))
     dt_port, n_tr = once(False)
     out = {"unit": "overlaps/s", "cores": cores}
+    # one thread, on a smaller sample (a fifth of the reads at the same coverage) so that it stays seconds
+    small = Dataset(ds.n_reads // 5, max(1, int(ds.read_len.astype(np.int64).sum() // 250)), 7) if ds.n_reads >= 5000 else ds
+    t0 = time.perf_counter()
+    o1 = ora.Oracle(small.read_len, small.overlaps, n_threads=1, ref=have_ref)
+    if o1.construct() == 0:
+        o1.remove_transitive_edges()
+    out["value_1_thread"] = len(small.overlaps) / (time.perf_counter() - t0)
+    out["sample_1_thread"] = "%d reads / %d overlaps" % (small.n_reads, len(small.overlaps))
     if have_ref:
         try:
             dt_ref, n_tr_ref = once(True)
@@ -99,14 +108,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     force_sharded = os.environ.get("RALA_FORCE_SHARDED") == "1" and "RANK" in os.environ
     use_dist = world > 1 or force_sharded
+    if args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is %d - launch one process per GPU:\n"
+                         "  python -m torch.distributed.run --nnodes=1 --nproc-per-node %d --master-addr 127.0.0.1 "
+                         "--master-port 29500 bench.py --gpus %d ..." % (args.gpus, world, args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device")
     if use_dist:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    if args.gpus != world:
-        log("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device")
+        # control plane only (the RCCL id, the barrier, the max-over-ranks clock): gloo over loopback.
+        # The data path is RCCL over xGMI, called from C++ on the contexts' streams.
+        dist.init_process_group("gloo")
 
     from rala_amd import hip
     from rala_amd.synth import Dataset
@@ -155,9 +168,8 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        from rala_amd import multi as _m
+        dt = _m.max_over_ranks(dt)
 
     if rank == 0:
         steps = max(1, args.steps)
@@ -178,7 +190,7 @@ def main():
             with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
                 pm = json.load(f)
             if pm.get("workload") == args.workload:
-                traffic = pm.get("hbm_bytes_per_step")
+                traffic = pm.get("hbm_bytes_per_step")      # replayed from the last PMC passes, not measured in this run
                 if traffic is not None and use_dist:
                     traffic /= world       # measured on one GPU over all reads; a rank's launches cover 1 / world
         except Exception:
@@ -200,7 +212,9 @@ def main():
                        "sum_read_len": sum_len, "transitive_pairs": int(n_tr)},
             "roofline": {"bound": "hbm", "kernel": "pile_runs_kernel<512|1024|2048> + pile_build_annotate (overflow chain)", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "algorithmic_bytes": pile_bytes, "kernel_ms": pile_ms,
+                         "traffic": traffic, "traffic_source": "profiles/pmc_latest.json (rocprofv3 --pmc passes of an earlier run of this command; not re-measured here)" if traffic is not None else None,
+                         "frac_of_write_only_rate": achieved / WRITE_ONLY_GBS,
+                         "algorithmic_bytes": pile_bytes, "kernel_ms": pile_ms,
                          # the whole pile stage (dedupe + bucketing + pile kernels)
                          # against B_pile = 56 N_ovl + 2 sum(len) + 40 N_reads
                          "stage": stage_roofline(stage, n_ovl, sum_len, ds.n_reads, world if use_dist else 1)},

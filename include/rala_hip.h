@@ -173,6 +173,58 @@ int rala_hip_get_device_state(rala_hip_ctx* ctx, rala_hip_device_state* out);
 int rala_hip_copy_device_state(rala_hip_ctx* ctx, const rala_hip_device_state* dst);
 int rala_hip_import_state_device(rala_hip_ctx* ctx, const rala_hip_device_state* in);
 
+/* ---- sharded run over the GPUs of one node --------------------------------------------------
+ * The reference fans its per-pile work out over a thread pool (src/graph.cpp:235, :367-377,
+ * :387-407, ...); here reads are partitioned over P GPUs (owner(read) = read % P), the overlap
+ * file is cut into P slices on a_id-run boundaries (rala_hip_mg_slice_cuts), and ONE all-to-all
+ * of 8-byte bound tuples over xGMI ships every bound to the owner of its read.  Everything that
+ * is per overlap (duplicate removal, bound emission, trim / type, liveness, hill counters) runs on
+ * the slice; everything that is per read (piles, annotation) on the owner; the in-order
+ * containment scan is a fixed point whose bounds are all-reduced (min) per round; the survivors
+ * (about 1 % of the overlaps) are all-gathered and the preprocess tail, the graph and the
+ * transitive reduction run replicated on them.
+ *
+ * One rala_hip_mg object per rank.  Ranks are either processes (one per GPU, RCCL: rank 0 obtains
+ * a 128-byte id with rala_hip_mg_unique_id and ships it to the others by any means) or host
+ * threads of one process (RCCL with an id made in that process, or the in-process transport
+ * RALA_HIP_COMM_LOCAL, which also lets several ranks share one device - how the decomposition
+ * is tested on a single GPU).  rala_hip_mg_create and rala_hip_mg_run are collective: every rank
+ * calls them.  After a run, rala_hip_mg_context(mg) holds the replicated result: all getters
+ * of this header work on it, except rala_hip_get_pile_data (the coverage of read r lives on
+ * rank r % P: rala_hip_mg_get_pile_data). */
+enum { RALA_HIP_COMM_RCCL = 0, RALA_HIP_COMM_LOCAL = 1 };
+typedef struct rala_hip_mg rala_hip_mg;
+typedef struct rala_hip_mg_timings {
+    /* wall-clock milliseconds of this rank's last run, by step */
+    float emit_ms, exchange_ms, owner_ms, gather_ms, construct_ms, repeats_ms, tr_ms, total_ms;
+    uint64_t tuples_sent;       /* bound tuples this rank shipped to other ranks */
+} rala_hip_mg_timings;
+int rala_hip_mg_unique_id(void* id128);
+int rala_hip_mg_local_group_create(uint32_t world, void** group);
+void rala_hip_mg_local_group_destroy(void* group);
+/* token: the 128-byte id (RALA_HIP_COMM_RCCL) or the group (RALA_HIP_COMM_LOCAL) */
+int rala_hip_mg_create(int device, uint32_t rank, uint32_t world, int transport, const void* token, rala_hip_mg** out);
+void rala_hip_mg_destroy(rala_hip_mg* mg);
+const char* rala_hip_mg_last_error(const rala_hip_mg* mg);
+/* all read lengths, on every rank (src/graph.cpp:249-264) */
+int rala_hip_mg_set_reads(rala_hip_mg* mg, const uint32_t* read_len, uint64_t n_reads);
+/* cuts[world + 1]: slice k = records cuts[k] .. cuts[k + 1] of the file; a cut never splits a run of
+ * equal a_id, and records that do not resolve do not break a run (src/graph.cpp:343-350) */
+int rala_hip_mg_slice_cuts(const uint32_t* a_id, uint64_t n, uint32_t world, uint64_t* cuts);
+/* this rank's slice; first = file position of its record 0 */
+int rala_hip_mg_set_overlaps(rala_hip_mg* mg, const rala_hip_overlaps* slice, uint64_t n, uint64_t first, int mem);
+/* Graph::construct + remove_transitive_edges (src/graph.cpp:427-640, :1281-1335); sens_slice = this
+ * rank's share of the sensitive overlaps (any contiguous share; NULL / 0 for none) */
+int rala_hip_mg_run(rala_hip_mg* mg, const rala_hip_overlaps* sens_slice, uint64_t n_sens, uint32_t* n_pairs);
+/* the same for n ranks of this process, one host thread per rank, joined before it returns */
+int rala_hip_mg_run_threads(rala_hip_mg** ranks, uint32_t n, const rala_hip_overlaps* sens_slices, const uint64_t* n_sens,
+                            uint32_t* n_pairs);
+rala_hip_ctx* rala_hip_mg_context(rala_hip_mg* mg);
+/* the context of the reads this rank owns (local read j = read j * P + rank): stage timings of the pile kernels */
+rala_hip_ctx* rala_hip_mg_owner_context(rala_hip_mg* mg);
+int rala_hip_mg_get_pile_data(rala_hip_mg* mg, uint64_t read, uint16_t* data);
+int rala_hip_mg_get_timings(rala_hip_mg* mg, rala_hip_mg_timings* out);
+
 /* Force-directed layout of one connected component, the O(n^2) part of Graph::postprocess
  * (src/graph.cpp:1132-1226): n points x, y (host, in / out); the attraction partners of point
  * i are adj[adj_off[i] .. adj_off[i + 1]) (point indices, n = a point fixed at the origin: a

@@ -1,0 +1,373 @@
+// Collectives of the sharded run: RCCL (opened at run time) and the in-process transport.
+// See comm.h.
+#include "comm.h"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>      // types and prototypes only; the library is opened with dlopen
+#include <string.h>
+
+#include <condition_variable>
+#include <mutex>
+
+#include "context.h"        // DevBuf / PinnedBuf
+
+namespace rala_hip {
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// RCCL
+// ---------------------------------------------------------------------------------------------
+struct RcclApi {
+    void* lib = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string err;
+};
+
+RcclApi* rccl_api() {
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, []() {
+        // a copy that is already in the process (PyTorch brings its own) wins: one RCCL per process
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        for (const char* n : names) {
+            api.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+            if (api.lib) break;
+        }
+        for (size_t k = 0; !api.lib && k < sizeof(names) / sizeof(names[0]); ++k) api.lib = dlopen(names[k], RTLD_NOW | RTLD_GLOBAL);
+        if (!api.lib) {
+            api.err = std::string("librccl not found: ") + (dlerror() ? dlerror() : "");
+            return;
+        }
+        bool ok = true;
+        auto sym = [&](const char* name) {
+            void* p = dlsym(api.lib, name);
+            if (!p) { ok = false; api.err = std::string("librccl lacks ") + name; }
+            return p;
+        };
+        api.GetUniqueId = (decltype(api.GetUniqueId))sym("ncclGetUniqueId");
+        api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
+        api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
+        api.AllReduce = (decltype(api.AllReduce))sym("ncclAllReduce");
+        api.AllGather = (decltype(api.AllGather))sym("ncclAllGather");
+        api.Send = (decltype(api.Send))sym("ncclSend");
+        api.Recv = (decltype(api.Recv))sym("ncclRecv");
+        api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
+        api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
+        api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
+        if (!ok) { dlclose(api.lib); api.lib = nullptr; }
+    });
+    return &api;
+}
+
+class RcclComm : public Comm {
+public:
+    RcclComm(uint32_t rank, uint32_t world) { rank_ = rank; world_ = world; }
+    ~RcclComm() override {
+        if (comm_) (void)api_->CommDestroy(comm_);
+    }
+    bool init(const void* id, std::string* err) {
+        api_ = rccl_api();
+        if (!api_->lib) { *err = api_->err; return false; }
+        static_assert(sizeof(ncclUniqueId) == kCommIdBytes, "unique id size");
+        ncclUniqueId uid;
+        memcpy(&uid, id, sizeof(uid));
+        const ncclResult_t r = api_->CommInitRank(&comm_, (int)world_, uid, (int)rank_);
+        if (r != ncclSuccess) { *err = std::string("ncclCommInitRank: ") + api_->GetErrorString(r); comm_ = nullptr; return false; }
+        return true;
+    }
+
+    int host_all_gather(const uint64_t* mine, uint32_t n, uint64_t* all, hipStream_t s) override {
+        const size_t total = (size_t)world_ * n;
+        if (d_small_.ensure(total + n) != hipSuccess || p_small_.ensure(total + n) != hipSuccess) return fail("out of memory");
+        uint64_t* h = p_small_.p;                        // [0, n): mine; [n, n + total): all
+        memcpy(h, mine, (size_t)n * 8);
+        if (hipMemcpyAsync(d_small_.p, h, (size_t)n * 8, hipMemcpyHostToDevice, s) != hipSuccess) return fail("copy");
+        if (!ok(api_->AllGather(d_small_.p, d_small_.p + n, n, ncclUint64, comm_, s), "ncclAllGather")) return -1;
+        if (hipMemcpyAsync(h + n, d_small_.p + n, total * 8, hipMemcpyDeviceToHost, s) != hipSuccess) return fail("copy");
+        if (hipStreamSynchronize(s) != hipSuccess) return fail("hipStreamSynchronize");
+        memcpy(all, h + n, total * 8);
+        return 0;
+    }
+
+    int all_to_all_v(const void* send, const uint64_t* send_counts, void* recv, const uint64_t* recv_counts,
+                     size_t elem_bytes, hipStream_t s) override {
+        size_t so = 0, ro = 0, self_so = 0, self_ro = 0;
+        if (!ok(api_->GroupStart(), "ncclGroupStart")) return -1;
+        for (uint32_t p = 0; p < world_; ++p) {
+            const size_t sb = (size_t)send_counts[p] * elem_bytes, rb = (size_t)recv_counts[p] * elem_bytes;
+            if (p == rank_) {
+                self_so = so; self_ro = ro;
+            } else {
+                if (sb && !ok(api_->Send((const char*)send + so, sb, ncclUint8, (int)p, comm_, s), "ncclSend")) return -1;
+                if (rb && !ok(api_->Recv((char*)recv + ro, rb, ncclUint8, (int)p, comm_, s), "ncclRecv")) return -1;
+            }
+            so += sb; ro += rb;
+        }
+        if (!ok(api_->GroupEnd(), "ncclGroupEnd")) return -1;
+        const size_t mine = (size_t)send_counts[rank_] * elem_bytes;
+        if (mine && hipMemcpyAsync((char*)recv + self_ro, (const char*)send + self_so, mine, hipMemcpyDeviceToDevice, s) != hipSuccess) {
+            return fail("copy of the own part");
+        }
+        return 0;
+    }
+
+    int all_gather(const void* send, void* recv, size_t bytes, hipStream_t s) override {
+        if (bytes == 0) return 0;
+        return ok(api_->AllGather(send, recv, bytes, ncclUint8, comm_, s), "ncclAllGather") ? 0 : -1;
+    }
+
+    int all_gather_v(const void* send, void* recv, const uint64_t* counts, size_t elem_bytes, hipStream_t s) override {
+        const size_t mine = (size_t)counts[rank_] * elem_bytes;
+        size_t ro = 0, self_ro = 0;
+        if (!ok(api_->GroupStart(), "ncclGroupStart")) return -1;
+        for (uint32_t p = 0; p < world_; ++p) {
+            const size_t rb = (size_t)counts[p] * elem_bytes;
+            if (p == rank_) {
+                self_ro = ro;
+            } else {
+                if (mine && !ok(api_->Send(send, mine, ncclUint8, (int)p, comm_, s), "ncclSend")) return -1;
+                if (rb && !ok(api_->Recv((char*)recv + ro, rb, ncclUint8, (int)p, comm_, s), "ncclRecv")) return -1;
+            }
+            ro += rb;
+        }
+        if (!ok(api_->GroupEnd(), "ncclGroupEnd")) return -1;
+        if (mine && (const char*)send != (char*)recv + self_ro &&
+            hipMemcpyAsync((char*)recv + self_ro, send, mine, hipMemcpyDeviceToDevice, s) != hipSuccess) {
+            return fail("copy of the own part");
+        }
+        return 0;
+    }
+
+    int all_reduce_u32(uint32_t* buf, size_t n, ReduceOp op, hipStream_t s) override {
+        if (n == 0) return 0;
+        const ncclRedOp_t r = op == ReduceOp::kSum ? ncclSum : op == ReduceOp::kMin ? ncclMin : ncclMax;
+        return ok(api_->AllReduce(buf, buf, n, ncclUint32, r, comm_, s), "ncclAllReduce") ? 0 : -1;
+    }
+
+    int barrier(hipStream_t s) override {
+        if (d_small_.ensure(8) != hipSuccess) return fail("out of memory");
+        if (!ok(api_->AllReduce(d_small_.p, d_small_.p, 1, ncclUint64, ncclSum, comm_, s), "ncclAllReduce")) return -1;
+        return hipStreamSynchronize(s) == hipSuccess ? 0 : fail("hipStreamSynchronize");
+    }
+
+private:
+    bool ok(ncclResult_t r, const char* what) {
+        if (r == ncclSuccess) return true;
+        err_ = std::string(what) + ": " + api_->GetErrorString(r);
+        return false;
+    }
+    int fail(const char* what) { err_ = what; return -1; }
+
+    RcclApi* api_ = nullptr;
+    ncclComm_t comm_ = nullptr;
+    DevBuf<uint64_t> d_small_;
+    PinnedBuf<uint64_t> p_small_;
+};
+
+// ---------------------------------------------------------------------------------------------
+// ranks as threads of one process
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t kMaxLocalWorld = 64;
+
+struct PeerPointers {
+    const uint32_t* p[kMaxLocalWorld];
+};
+
+__global__ __launch_bounds__(256) void local_reduce_kernel(PeerPointers peers, uint32_t world, size_t n, int op,
+                                                           uint32_t* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    uint32_t v = peers.p[0][i];
+    for (uint32_t k = 1; k < world; ++k) {
+        const uint32_t x = peers.p[k][i];
+        v = op == 0 ? v + x : op == 1 ? (x < v ? x : v) : (x > v ? x : v);
+    }
+    out[i] = v;
+}
+
+}  // namespace
+
+struct LocalGroup {
+    uint32_t world = 1;
+    std::mutex m;
+    std::condition_variable cv;
+    uint32_t arrived = 0;
+    uint64_t generation = 0;
+    std::vector<const void*> ptr;
+    std::vector<std::vector<uint64_t>> counts;
+    std::vector<std::vector<uint64_t>> host;
+    std::vector<int> device;
+
+    void wait() {
+        std::unique_lock<std::mutex> hold(m);
+        const uint64_t g = generation;
+        if (++arrived == world) {
+            arrived = 0;
+            ++generation;
+            cv.notify_all();
+        } else {
+            cv.wait(hold, [&]() { return generation != g; });
+        }
+    }
+};
+
+namespace {
+
+class LocalComm : public Comm {
+public:
+    LocalComm(LocalGroup* g, uint32_t rank, int device) : g_(g), device_(device) {
+        rank_ = rank; world_ = g->world;
+        g->device[rank] = device;
+    }
+
+    int host_all_gather(const uint64_t* mine, uint32_t n, uint64_t* all, hipStream_t) override {
+        g_->host[rank_].assign(mine, mine + n);
+        g_->wait();
+        for (uint32_t p = 0; p < world_; ++p) memcpy(all + (size_t)p * n, g_->host[p].data(), (size_t)n * 8);
+        g_->wait();
+        return 0;
+    }
+
+    int all_to_all_v(const void* send, const uint64_t* send_counts, void* recv, const uint64_t* recv_counts,
+                     size_t elem_bytes, hipStream_t s) override {
+        if (!publish(send, s)) return -1;
+        g_->counts[rank_].assign(send_counts, send_counts + world_);
+        g_->wait();
+        size_t ro = 0;
+        for (uint32_t p = 0; p < world_; ++p) {
+            size_t so = 0;
+            for (uint32_t q = 0; q < rank_; ++q) so += (size_t)g_->counts[p][q] * elem_bytes;
+            const size_t bytes = (size_t)g_->counts[p][rank_] * elem_bytes;
+            if (g_->counts[p][rank_] != recv_counts[p]) { err_ = "all_to_all_v: counts disagree"; bad_ = true; }
+            if (bytes && !bad_ && !copy((char*)recv + ro, (const char*)g_->ptr[p] + so, bytes, p, s)) bad_ = true;
+            ro += (size_t)recv_counts[p] * elem_bytes;
+        }
+        return finish(s);
+    }
+
+    int all_gather(const void* send, void* recv, size_t bytes, hipStream_t s) override {
+        if (!publish(send, s)) return -1;
+        g_->wait();
+        for (uint32_t p = 0; p < world_ && !bad_; ++p) {
+            if (bytes && !copy((char*)recv + (size_t)p * bytes, g_->ptr[p], bytes, p, s)) bad_ = true;
+        }
+        return finish(s);
+    }
+
+    int all_gather_v(const void* send, void* recv, const uint64_t* counts, size_t elem_bytes, hipStream_t s) override {
+        if (!publish(send, s)) return -1;
+        g_->wait();
+        size_t ro = 0;
+        for (uint32_t p = 0; p < world_; ++p) {
+            const size_t bytes = (size_t)counts[p] * elem_bytes;
+            if (bytes && !bad_ && !copy((char*)recv + ro, g_->ptr[p], bytes, p, s)) bad_ = true;
+            ro += bytes;
+        }
+        return finish(s);
+    }
+
+    int all_reduce_u32(uint32_t* buf, size_t n, ReduceOp op, hipStream_t s) override {
+        if (tmp_.ensure(n) != hipSuccess) { err_ = "out of memory"; return -1; }
+        if (!publish(buf, s)) return -1;
+        g_->wait();
+        if (n) {
+            PeerPointers pp;
+            for (uint32_t p = 0; p < world_; ++p) { pp.p[p] = (const uint32_t*)g_->ptr[p]; peer(p); }
+            hipLaunchKernelGGL(local_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, pp, world_, n,
+                               op == ReduceOp::kSum ? 0 : op == ReduceOp::kMin ? 1 : 2, tmp_.p);
+        }
+        if (finish(s) != 0) return -1;          // everybody has read everybody's buffer
+        if (n && hipMemcpyAsync(buf, tmp_.p, n * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) { err_ = "copy"; return -1; }
+        return 0;
+    }
+
+    int barrier(hipStream_t s) override {
+        if (hipStreamSynchronize(s) != hipSuccess) { err_ = "hipStreamSynchronize"; return -1; }
+        g_->wait();
+        return 0;
+    }
+
+private:
+    bool publish(const void* p, hipStream_t s) {
+        (void)hipSetDevice(device_);
+        bad_ = false;
+        // what the peers are about to read must be complete
+        if (hipStreamSynchronize(s) != hipSuccess) { err_ = "hipStreamSynchronize"; bad_ = true; }
+        g_->ptr[rank_] = p;
+        return true;                            // a failed rank still takes part in the rendezvous
+    }
+    void peer(uint32_t p) {
+        const int d = g_->device[p];
+        if (d == device_ || (size_t)d >= peer_on_.size() || peer_on_[d]) return;
+        (void)hipDeviceEnablePeerAccess(d, 0);  // "already enabled" is fine
+        (void)hipGetLastError();
+        peer_on_[d] = true;
+    }
+    bool copy(void* dst, const void* src, size_t bytes, uint32_t from, hipStream_t s) {
+        peer(from);
+        const hipError_t e = g_->device[from] == device_
+                                 ? hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s)
+                                 : hipMemcpyPeerAsync(dst, device_, src, g_->device[from], bytes, s);
+        if (e != hipSuccess) { err_ = std::string("copy between ranks: ") + hipGetErrorString(e); return false; }
+        return true;
+    }
+    int finish(hipStream_t s) {
+        if (hipStreamSynchronize(s) != hipSuccess) { err_ = "hipStreamSynchronize"; bad_ = true; }
+        g_->wait();                             // the peers' buffers may change from here on
+        return bad_ ? -1 : 0;
+    }
+
+    LocalGroup* g_;
+    int device_;
+    bool bad_ = false;
+    std::vector<bool> peer_on_ = std::vector<bool>(64, false);
+    DevBuf<uint32_t> tmp_;
+};
+
+}  // namespace
+
+int rccl_unique_id(void* id, std::string* err) {
+    RcclApi* api = rccl_api();
+    if (!api->lib) { *err = api->err; return -1; }
+    ncclUniqueId uid;
+    const ncclResult_t r = api->GetUniqueId(&uid);
+    if (r != ncclSuccess) { *err = std::string("ncclGetUniqueId: ") + api->GetErrorString(r); return -1; }
+    memcpy(id, &uid, sizeof(uid));
+    return 0;
+}
+
+Comm* create_rccl_comm(uint32_t rank, uint32_t world, const void* id, std::string* err) {
+    RcclComm* c = new RcclComm(rank, world);
+    if (!c->init(id, err)) { delete c; return nullptr; }
+    return c;
+}
+
+LocalGroup* create_local_group(uint32_t world) {
+    if (world == 0 || world > kMaxLocalWorld) return nullptr;
+    LocalGroup* g = new LocalGroup;
+    g->world = world;
+    g->ptr.assign(world, nullptr);
+    g->counts.assign(world, std::vector<uint64_t>());
+    g->host.assign(world, std::vector<uint64_t>());
+    g->device.assign(world, 0);
+    return g;
+}
+
+void destroy_local_group(LocalGroup* g) { delete g; }
+
+Comm* create_local_comm(LocalGroup* g, uint32_t rank, int device, std::string* err) {
+    if (!g || rank >= g->world) { *err = "bad rank / group"; return nullptr; }
+    return new LocalComm(g, rank, device);
+}
+
+}  // namespace rala_hip

@@ -140,6 +140,7 @@ struct rala_hip_ctx {
     rala_hip::DevBuf<uint4> d_rec;              // packed per-read records of the second pass
     rala_hip::DevBuf<uint32_t> d_surv_u32[8];
     rala_hip::DevBuf<uint8_t> d_surv_u8[2];
+    rala_hip::DevBuf<uint8_t> d_list_block[2];  // sharded runs: this slice's packed survivors / all slices'
     rala_hip::PinnedBuf<uint32_t> p_surv_u32[8];
     rala_hip::PinnedBuf<uint8_t> p_surv_u8[2];
 

@@ -187,6 +187,16 @@ struct Survivors {
 };
 void launch_gather_survivors(const OvlSoA& o, const uint8_t* cls, const uint4* rec, const uint32_t* chunk_ov_off,
                              const uint32_t* chunk_in_off, uint32_t n_ov_total, const Survivors& out, hipStream_t s);
+// sharded runs (one slice of the overlap file per rank)
+struct ListBlocks {             // the ranks' packed survivor blocks inside one gathered buffer
+    uint64_t block_off[64];
+    uint32_t n0[64], n1[64];    // overlaps / internals of the rank
+    uint32_t dst0[64], dst1[64];
+    uint32_t world;
+};
+void launch_death_status(const uint32_t* count, uint32_t* status, hipStream_t s);
+void launch_hill_counts(const ReadState& rs, uint32_t n_reads, uint32_t* dense, uint32_t mode, hipStream_t s);
+void launch_unpack_lists(const uint8_t* blocks, const ListBlocks& lb, const Survivors& out, hipStream_t s);
 
 // ---- preprocess tail on device-resident lists (tail_kernels.hip) -------------------
 struct TailList {               // survivors of the second pass: overlaps first, then internals

@@ -604,6 +604,43 @@ __global__ __launch_bounds__(kBlock) void gather_kernel(OvlSoA o, const uint8_t*
     }
 }
 
+// sharded runs: 0xFFFFFFFF - (undecided killers of this rank); the all-reduce (min) leaves the
+// largest list's size
+__global__ void death_status_kernel(const uint32_t* count, uint32_t* status) { *status = 0xFFFFFFFFu - *count; }
+
+// Hill span counters of a sharded run: every rank counted the overlaps of its slice into its own
+// copy of the pool.  mode 0: dense[slot of hill] = counter (pits stay 0 in the pre-zeroed array);
+// mode 1: counters <- dense (after the all-reduce).
+__global__ __launch_bounds__(kBlock) void hill_counts_kernel(ReadState rs, uint32_t n_reads, uint32_t* dense, uint32_t mode) {
+    const uint32_t r = blockIdx.x * kBlock + threadIdx.x;
+    if (r >= n_reads) return;
+    const uint32_t nh = rs.n_hills[r];
+    if (nh == 0 || rs.iv_slot[r] == kInf) return;
+    const uint32_t first = rs.iv_slot[r] + rs.n_pits[r];
+    for (uint32_t q = 0; q < nh; ++q) {
+        if (mode == 0) dense[first + q] = rs.pool[first + q].aux;
+        else rs.pool[first + q].aux = dense[first + q];
+    }
+}
+
+// survivor blocks of all ranks (packed_list_view layout) -> the tail's lists: overlaps of rank
+// 0, 1, ... in front, internals of rank 0, 1, ... behind them (= file order in both)
+__global__ __launch_bounds__(kBlock) void unpack_lists_kernel(const uint8_t* blocks, ListBlocks lb, Survivors out) {
+    const uint32_t p = blockIdx.y;
+    const uint32_t m = lb.n0[p] + lb.n1[p];
+    const uint8_t* block = blocks + lb.block_off[p];
+    const uint32_t* c = (const uint32_t*)block;
+    for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < m; j += gridDim.x * kBlock) {
+        const uint32_t d = j < lb.n0[p] ? lb.dst0[p] + j : lb.dst1[p] + (j - lb.n0[p]);
+        out.src[d] = c[j]; out.a_id[d] = c[(size_t)m + j]; out.b_id[d] = c[2 * (size_t)m + j];
+        out.a_begin[d] = c[3 * (size_t)m + j]; out.a_end[d] = c[4 * (size_t)m + j];
+        out.b_begin[d] = c[5 * (size_t)m + j]; out.b_end[d] = c[6 * (size_t)m + j];
+        out.length[d] = c[7 * (size_t)m + j];
+        out.strand[d] = block[32 * (size_t)m + j];
+        out.type[d] = block[33 * (size_t)m + j];
+    }
+}
+
 inline dim3 grid_for(uint64_t n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); }
 
 }  // namespace
@@ -683,6 +720,19 @@ void launch_finish_pass2(const OvlSoA& o, uint8_t* cls, const uint32_t* death, c
         hipLaunchKernelGGL(finish_pass2_kernel, dim3(pass2_chunks(o.n)), dim3(kBlock), 0, s, o, cls, death, rec, pool,
                            chunk_ov, chunk_in);
     }
+}
+void launch_death_status(const uint32_t* count, uint32_t* status, hipStream_t s) {
+    hipLaunchKernelGGL(death_status_kernel, dim3(1), dim3(1), 0, s, count, status);
+}
+void launch_hill_counts(const ReadState& rs, uint32_t n_reads, uint32_t* dense, uint32_t mode, hipStream_t s) {
+    if (n_reads) hipLaunchKernelGGL(hill_counts_kernel, grid_for(n_reads), dim3(kBlock), 0, s, rs, n_reads, dense, mode);
+}
+void launch_unpack_lists(const uint8_t* blocks, const ListBlocks& lb, const Survivors& out, hipStream_t s) {
+    uint32_t most = 0;
+    for (uint32_t p = 0; p < lb.world; ++p) most = most > lb.n0[p] + lb.n1[p] ? most : lb.n0[p] + lb.n1[p];
+    if (most == 0) return;
+    const uint32_t gx = (most + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(unpack_lists_kernel, dim3(gx < 1024 ? gx : 1024, lb.world), dim3(kBlock), 0, s, blocks, lb, out);
 }
 void launch_apply_death(const uint32_t* death, uint8_t* alive, uint32_t n_reads, hipStream_t s) {
     if (n_reads) hipLaunchKernelGGL(apply_death_kernel, grid_for(n_reads), dim3(kBlock), 0, s, death, alive, n_reads);

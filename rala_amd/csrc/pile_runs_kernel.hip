@@ -613,7 +613,7 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
         }
         RUN_STOP(23)
 
-        // ---- 4. Pile::shrink: zero outside; position index; expand to HBM -----------------
+        // ---- 4. Pile::shrink: zero outside; position index (the expansion to HBM is step 10) --
         for (uint32_t k = lane; k < R; k += 64) {
             if (k < kB || k >= kE) rv[k] = 0;
         }
@@ -653,101 +653,6 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
             }
         }
         wave_sync();
-        {
-            // Expansion, 16 bytes (8 positions) per lane and store, consecutive lanes ->
-            // consecutive addresses (1 KiB per wave instruction); reads of up to 16384 positions
-            // go through expand_from_bitmap.  The sorted path, per segment of 16384
-            // positions: a bitmap with one bit per position that starts a run, and per
-            // 32-bit word the number of run starts before it; the run of position p is then
-            // pref[w] + popcount(bits up to p) - no searching, and the byte of the bitmap
-            // that belongs to a lane's 8 positions says where (if anywhere) the value changes.
-            constexpr uint32_t kSeg = 16384, kBmWords = kSeg / 32;
-            uint32_t* bm = sm + L::X;                       // the group counts are no longer needed
-            uint16_t* pref = (uint16_t*)(bm + kBmWords);
-            uint4* dst = (uint4*)(A.pile + A.pile_off[r]);
-            const uint32_t nv = (n + 7) / 8;
-            if (lane == 0) rv[R] = 0;                       // padding behind the last base (rs[R] = n)
-            uint32_t kbase = 0;                             // run that contains the segment's first position
-            if (bitmap_path) {
-                // bitmap and prefix of step 1 are still valid; only the padding behind the
-                // last base needs its own "run" (never crosses into the next word)
-                if (lane == 0 && n < kSeg) atomicOr(&bm[n >> 5], 1u << (n & 31));
-                wave_sync();
-                expand_from_bitmap<L>(sm, rv, A.pile, A.pile_off[r], nv, lane, !kDiag || A.stop_after != 77);
-            } else
-            for (uint32_t s0 = 0; s0 < nv * 8; s0 += kSeg) {       // sorted path: long reads, many events
-                {
-                    wave_sync();
-                    ((uint4*)bm)[lane] = make_uint4(0, 0, 0, 0);
-                    ((uint4*)bm)[lane + 64] = make_uint4(0, 0, 0, 0);
-                    wave_sync();
-                    for (uint32_t k = 1 + lane; k <= R; k += 64) {
-                        const uint32_t st = rs[k] - s0;         // starts are distinct positions
-                        if (st < kSeg && rs[k] > 0) atomicOr(&bm[st >> 5], 1u << (st & 31));
-                    }
-                    wave_sync();
-                    {
-                        const uint4 a = ((const uint4*)bm)[2 * lane], b = ((const uint4*)bm)[2 * lane + 1];
-                        const uint32_t c[8] = {(uint32_t)__popc(a.x), (uint32_t)__popc(a.y), (uint32_t)__popc(a.z),
-                                               (uint32_t)__popc(a.w), (uint32_t)__popc(b.x), (uint32_t)__popc(b.y),
-                                               (uint32_t)__popc(b.z), (uint32_t)__popc(b.w)};
-                        const uint32_t tot = c[0] + c[1] + c[2] + c[3] + c[4] + c[5] + c[6] + c[7];
-                        const uint32_t incl = wave_scan_incl(tot, OpAdd());
-                        uint32_t run = kbase + incl - tot;
-                        uint32_t pk[4];
-#pragma unroll
-                        for (int x = 0; x < 4; ++x) {
-                            const uint32_t lo = run; run += c[2 * x];
-                            const uint32_t hi = run; run += c[2 * x + 1];
-                            pk[x] = lo | (hi << 16);
-                        }
-                        ((uint4*)pref)[lane] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-                        kbase += read_lane63(incl);
-                    }
-                    wave_sync();
-                }
-                const uint32_t g_lo = s0 / 8, g_hi = umin(nv, (s0 + kSeg) / 8);
-                for (uint32_t g0 = g_lo + lane; g0 < g_hi; g0 += 256) {
-                    uint32_t bits[4], k[4], v[4];
-#pragma unroll
-                    for (uint32_t u = 0; u < 4; ++u) {
-                        const uint32_t g = umin(g0 + 64 * u, g_hi - 1);
-                        const uint32_t w = (g * 8 - s0) >> 5;
-                        bits[u] = bm[w];
-                        k[u] = pref[w];
-                    }
-#pragma unroll
-                    for (uint32_t u = 0; u < 4; ++u) {
-                        const uint32_t g = umin(g0 + 64 * u, g_hi - 1);
-                        const uint32_t sh = (g * 8) & 31;
-                        k[u] += (uint32_t)__popc(bits[u] & ((2u << sh) - 1u));
-                        bits[u] = (bits[u] >> (sh + 1)) & 0x7Fu;        // starts at positions 1 .. 7 of the group
-                        v[u] = rv[k[u]];
-                    }
-#pragma unroll
-                    for (uint32_t u = 0; u < 4; ++u) {
-                        const uint32_t g = g0 + 64 * u;
-                        if (g >= g_hi) break;
-                        const uint32_t vv = v[u] | (v[u] << 16);
-                        uint32_t w0 = vv, w1 = vv, w2 = vv, w3 = vv;
-                        uint32_t inner = bits[u], kk = k[u];
-                        while (inner) {
-                            const uint32_t x = (uint32_t)__ffs((int)inner);     // position 1 .. 7 inside the group
-                            inner &= inner - 1;
-                            const uint32_t nvv = rv[++kk];
-                            const uint32_t f = nvv | (nvv << 16);
-                            const uint32_t* mt = sm + L::MT + x;
-                            const uint32_t m0 = mt[6], m1 = mt[4], m2 = mt[2], m3 = mt[0];
-                            w0 = bitfield_insert(m0, f, w0);
-                            w1 = bitfield_insert(m1, f, w1);
-                            w2 = bitfield_insert(m2, f, w2);
-                            w3 = bitfield_insert(m3, f, w3);
-                        }
-                        if (!kDiag || A.stop_after != 77) dst[g] = make_uint4(w0, w1, w2, w3);
-                    }
-                }
-            }
-        }
         RUN_STOP(24)
 
         // ---- 5. order statistics over (value, length) of the runs in [kB, kE) --------------
@@ -1164,6 +1069,129 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
             A.n_pits[r] = (uint8_t)wp; A.n_hills[r] = (uint8_t)wh;
             A.iv_slot[r] = slot;
             if (err) atomicOr(A.error, err);
+        }
+        wave_sync();
+        {
+            // ---- 10. expansion, LAST: nothing behind it waits for the stores to drain (the
+            // compiler puts s_waitcnt vmcnt(0) in front of LDS traffic that follows global stores;
+            // in the middle of the kernel that parked the wave until the whole row was in memory),
+            // and a read that is handed on to the next kernel of the chain is not written twice.
+            // 16 bytes (8 positions) per lane and store, consecutive lanes ->
+            // consecutive addresses (1 KiB per wave instruction); reads of up to 16384 positions
+            // go through expand_from_bitmap.  The sorted path, per segment of 16384
+            // positions: a bitmap with one bit per position that starts a run, and per
+            // 32-bit word the number of run starts before it; the run of position p is then
+            // pref[w] + popcount(bits up to p) - no searching, and the byte of the bitmap
+            // that belongs to a lane's 8 positions says where (if anywhere) the value changes.
+            constexpr uint32_t kSeg = 16384, kBmWords = kSeg / 32;
+            uint32_t* bm = sm + L::X;                       // the group counts are no longer needed
+            uint16_t* pref = (uint16_t*)(bm + kBmWords);
+            uint4* dst = (uint4*)(A.pile + A.pile_off[r]);
+            const uint32_t nv = (n + 7) / 8;
+            if (lane == 0) rv[R] = 0;                       // padding behind the last base (rs[R] = n)
+            uint32_t kbase = 0;                             // run that contains the segment's first position
+            if (bitmap_path) {
+                // one bit per run start again (the annotation phases used the region), one more for
+                // the padding behind the last base (rs[R] = n), and the run starts before every word
+                ((uint4*)bm)[lane] = make_uint4(0, 0, 0, 0);
+                ((uint4*)bm)[lane + 64] = make_uint4(0, 0, 0, 0);
+                wave_sync();
+                for (uint32_t k = lane; k <= R; k += 64) {
+                    const uint32_t pos = rs[k];
+                    if (pos < kSeg) atomicOr(&bm[pos >> 5], 1u << (pos & 31));
+                }
+                wave_sync();
+                {
+                    const uint4 x = ((const uint4*)bm)[2 * lane], y = ((const uint4*)bm)[2 * lane + 1];
+                    const uint32_t c[8] = {(uint32_t)__popc(x.x), (uint32_t)__popc(x.y), (uint32_t)__popc(x.z),
+                                           (uint32_t)__popc(x.w), (uint32_t)__popc(y.x), (uint32_t)__popc(y.y),
+                                           (uint32_t)__popc(y.z), (uint32_t)__popc(y.w)};
+                    const uint32_t tot = c[0] + c[1] + c[2] + c[3] + c[4] + c[5] + c[6] + c[7];
+                    uint32_t run = wave_scan_incl(tot, OpAdd()) - tot;
+                    uint32_t pk[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const uint32_t lo = run; run += c[2 * q];
+                        const uint32_t hi = run; run += c[2 * q + 1];
+                        pk[q] = lo | (hi << 16);
+                    }
+                    ((uint4*)pref)[lane] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                }
+                wave_sync();
+                expand_from_bitmap<L>(sm, rv, A.pile, A.pile_off[r], nv, lane, !kDiag || A.stop_after != 77);
+            } else
+            for (uint32_t s0 = 0; s0 < nv * 8; s0 += kSeg) {       // sorted path: long reads, many events
+                {
+                    wave_sync();
+                    ((uint4*)bm)[lane] = make_uint4(0, 0, 0, 0);
+                    ((uint4*)bm)[lane + 64] = make_uint4(0, 0, 0, 0);
+                    wave_sync();
+                    for (uint32_t k = 1 + lane; k <= R; k += 64) {
+                        const uint32_t st = rs[k] - s0;         // starts are distinct positions
+                        if (st < kSeg && rs[k] > 0) atomicOr(&bm[st >> 5], 1u << (st & 31));
+                    }
+                    wave_sync();
+                    {
+                        const uint4 a = ((const uint4*)bm)[2 * lane], b = ((const uint4*)bm)[2 * lane + 1];
+                        const uint32_t c[8] = {(uint32_t)__popc(a.x), (uint32_t)__popc(a.y), (uint32_t)__popc(a.z),
+                                               (uint32_t)__popc(a.w), (uint32_t)__popc(b.x), (uint32_t)__popc(b.y),
+                                               (uint32_t)__popc(b.z), (uint32_t)__popc(b.w)};
+                        const uint32_t tot = c[0] + c[1] + c[2] + c[3] + c[4] + c[5] + c[6] + c[7];
+                        const uint32_t incl = wave_scan_incl(tot, OpAdd());
+                        uint32_t run = kbase + incl - tot;
+                        uint32_t pk[4];
+#pragma unroll
+                        for (int x = 0; x < 4; ++x) {
+                            const uint32_t lo = run; run += c[2 * x];
+                            const uint32_t hi = run; run += c[2 * x + 1];
+                            pk[x] = lo | (hi << 16);
+                        }
+                        ((uint4*)pref)[lane] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                        kbase += read_lane63(incl);
+                    }
+                    wave_sync();
+                }
+                const uint32_t g_lo = s0 / 8, g_hi = umin(nv, (s0 + kSeg) / 8);
+                for (uint32_t g0 = g_lo + lane; g0 < g_hi; g0 += 256) {
+                    uint32_t bits[4], k[4], v[4];
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; ++u) {
+                        const uint32_t g = umin(g0 + 64 * u, g_hi - 1);
+                        const uint32_t w = (g * 8 - s0) >> 5;
+                        bits[u] = bm[w];
+                        k[u] = pref[w];
+                    }
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; ++u) {
+                        const uint32_t g = umin(g0 + 64 * u, g_hi - 1);
+                        const uint32_t sh = (g * 8) & 31;
+                        k[u] += (uint32_t)__popc(bits[u] & ((2u << sh) - 1u));
+                        bits[u] = (bits[u] >> (sh + 1)) & 0x7Fu;        // starts at positions 1 .. 7 of the group
+                        v[u] = rv[k[u]];
+                    }
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; ++u) {
+                        const uint32_t g = g0 + 64 * u;
+                        if (g >= g_hi) break;
+                        const uint32_t vv = v[u] | (v[u] << 16);
+                        uint32_t w0 = vv, w1 = vv, w2 = vv, w3 = vv;
+                        uint32_t inner = bits[u], kk = k[u];
+                        while (inner) {
+                            const uint32_t x = (uint32_t)__ffs((int)inner);     // position 1 .. 7 inside the group
+                            inner &= inner - 1;
+                            const uint32_t nvv = rv[++kk];
+                            const uint32_t f = nvv | (nvv << 16);
+                            const uint32_t* mt = sm + L::MT + x;
+                            const uint32_t m0 = mt[6], m1 = mt[4], m2 = mt[2], m3 = mt[0];
+                            w0 = bitfield_insert(m0, f, w0);
+                            w1 = bitfield_insert(m1, f, w1);
+                            w2 = bitfield_insert(m2, f, w2);
+                            w3 = bitfield_insert(m3, f, w3);
+                        }
+                        if (!kDiag || A.stop_after != 77) dst[g] = make_uint4(w0, w1, w2, w3);
+                    }
+                }
+            }
         }
         wave_sync();
     }

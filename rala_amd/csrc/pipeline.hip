@@ -16,8 +16,36 @@
 #include <numeric>
 
 #include "context.h"
+#include "stages.h"
 
 using namespace rala_hip;
+
+// Small device -> host reads (counters, flags) go through a pinned staging area: an async copy
+// into pageable memory is staged by the runtime and costs tens of microseconds more, and the
+// tail does a dozen of them per call.  d2h_small queues the copy, stream_sync waits for the
+// stream and delivers what was queued.
+hipError_t rala_hip::d2h_small(rala_hip_ctx* ctx, void* dst, const void* src, size_t bytes, hipStream_t s) {
+    if (ctx->p_stage.ensure(256) != hipSuccess || ctx->stage_used + bytes > 256 * sizeof(uint32_t) ||
+        ctx->stage_pending.size() >= 16) {
+        return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s);
+    }
+    char* at = (char*)ctx->p_stage.p + ctx->stage_used;
+    const hipError_t e = hipMemcpyAsync(at, src, bytes, hipMemcpyDeviceToHost, s);
+    if (e != hipSuccess) return e;
+    ctx->stage_pending.push_back({dst, ctx->stage_used, bytes});
+    ctx->stage_used += (bytes + 7) & ~(size_t)7;
+    return hipSuccess;
+}
+
+hipError_t rala_hip::stream_sync(rala_hip_ctx* ctx, hipStream_t s) {
+    const hipError_t e = hipStreamSynchronize(s);
+    if (e == hipSuccess) {      // a failed wait delivers nothing
+        for (const auto& c : ctx->stage_pending) memcpy(c.dst, (const char*)ctx->p_stage.p + c.offset, c.bytes);
+    }
+    ctx->stage_pending.clear();
+    ctx->stage_used = 0;
+    return e;
+}
 
 namespace {
 
@@ -39,33 +67,6 @@ int fail(rala_hip_ctx* ctx, int code, const char* msg) {
     ctx->stage_pending.clear();
     ctx->stage_used = 0;
     return code;
-}
-
-// Small device -> host reads (counters, flags) go through a pinned staging area: an async copy
-// into pageable memory is staged by the runtime and costs tens of microseconds more, and the
-// tail does a dozen of them per call.  d2h_small queues the copy, stream_sync waits for the
-// stream and delivers what was queued.
-hipError_t d2h_small(rala_hip_ctx* ctx, void* dst, const void* src, size_t bytes, hipStream_t s) {
-    if (ctx->p_stage.ensure(256) != hipSuccess || ctx->stage_used + bytes > 256 * sizeof(uint32_t) ||
-        ctx->stage_pending.size() >= 16) {
-        return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s);
-    }
-    char* at = (char*)ctx->p_stage.p + ctx->stage_used;
-    const hipError_t e = hipMemcpyAsync(at, src, bytes, hipMemcpyDeviceToHost, s);
-    if (e != hipSuccess) return e;
-    ctx->stage_pending.push_back({dst, ctx->stage_used, bytes});
-    ctx->stage_used += (bytes + 7) & ~(size_t)7;
-    return hipSuccess;
-}
-
-hipError_t stream_sync(rala_hip_ctx* ctx, hipStream_t s) {
-    const hipError_t e = hipStreamSynchronize(s);
-    if (e == hipSuccess) {      // a failed wait delivers nothing
-        for (const auto& c : ctx->stage_pending) memcpy(c.dst, (const char*)ctx->p_stage.p + c.offset, c.bytes);
-    }
-    ctx->stage_pending.clear();
-    ctx->stage_used = 0;
-    return e;
 }
 
 ReadState read_state(rala_hip_ctx* ctx) {
@@ -1005,7 +1006,251 @@ int materialize_host(rala_hip_ctx* ctx) {
     return RALA_HIP_OK;
 }
 
+
+// ---- sharded survivor lists: a rank's survivors travel as one packed block -------------------
+// block of m items: eight uint32 columns (src, a, b, a_begin, a_end, b_begin, b_end, length) of m
+// entries each, then the strand and type bytes; overlaps first, internals behind them
+size_t packed_list_bytes(uint64_t m) { return ((size_t)m * 34 + 15) & ~(size_t)15; }
+
+Survivors packed_list_view(uint8_t* block, uint64_t m) {
+    Survivors sv;
+    uint32_t* c = (uint32_t*)block;
+    sv.src = c; sv.a_id = c + m; sv.b_id = c + 2 * m; sv.a_begin = c + 3 * m; sv.a_end = c + 4 * m;
+    sv.b_begin = c + 5 * m; sv.b_end = c + 6 * m; sv.length = c + 7 * m;
+    sv.strand = block + 32 * m; sv.type = block + 33 * m;
+    return sv;
+}
+
+// Second overlap pass on ctx->ovl (graph.cpp:443-518): static classification, the in-order
+// containment removal as a fixed point, liveness + hill counters, survivors into the tail lists
+// (ctx->d_surv_*, t_n0 overlaps then t_n1 internals).  With a communicator the overlaps are one
+// slice of the file: the bounds of the fixed point are all-reduced (min) per round, the hill
+// counters all-reduced (sum), the survivor lists all-gathered in slice (= file) order.
+int pass2(rala_hip_ctx* ctx, Comm* comm) {
+    hipStream_t s = ctx->stream;
+    const uint32_t n_reads = (uint32_t)ctx->n_reads;
+    const uint64_t N = ctx->n_ovl;
+    const ReadState rs = read_state(ctx);
+    auto comm_fail = [&](const char* what) {
+        ctx->err = std::string(what) + ": " + comm->error();
+        ctx->stage_pending.clear();
+        ctx->stage_used = 0;
+        return RALA_HIP_EDEVICE;
+    };
+
+    // ---- static part ----
+    for (int k = 0; k < 3; ++k) HIPCHECK(ctx->d_kill[k].ensure(N + 1));
+    HIPCHECK(ctx->d_kill_count.ensure(4));
+    KillList kl;
+    kl.count = ctx->d_kill_count.p; kl.ovl = ctx->d_kill[0].p; kl.target = ctx->d_kill[1].p; kl.keeper = ctx->d_kill[2].p;
+    HIPCHECK(hipEventRecord(ctx->ev[4], s));
+    HIPCHECK(hipMemsetAsync(kl.count, 0, 4, s));
+    HIPCHECK(ctx->d_rec.ensure(n_reads));
+    launch_pack_reads(rs, n_reads, ctx->d_rec.p, s);
+    launch_classify(ctx->ovl, n_reads, ctx->d_valid.p, ctx->d_rec.p, ctx->d_cls.p, kl, s);
+    HIPCHECK(hipEventRecord(ctx->ev[5], s));
+
+    // ---- in-order containment removal as a fixed point (death_decide_kernel) ----
+    // one buffer: sure[n_reads] (min over sure killers = upper bound), lo[n_reads] (lower bound),
+    // one status word - so that a sharded run needs ONE all-reduce (min) per round; up[] apart
+    for (int k = 0; k < 3; ++k) HIPCHECK(ctx->d_kill2[k].ensure(N + 1));
+    HIPCHECK(ctx->d_death_sure.ensure(2 * (size_t)n_reads + 8));
+    KillList klist[2] = {kl, kl};
+    klist[1].count = ctx->d_kill_count.p + 1;
+    klist[1].ovl = ctx->d_kill2[0].p; klist[1].target = ctx->d_kill2[1].p; klist[1].keeper = ctx->d_kill2[2].p;
+    uint32_t* sure = ctx->d_death_sure.p;
+    uint32_t* lo = sure + n_reads;
+    uint32_t* status = sure + 2 * (size_t)n_reads;          // 0xFFFFFFFF - undecided killers (min = most)
+    uint32_t* up = ctx->d_death[1].p;
+    const size_t dbytes = (size_t)n_reads * 4;
+    HIPCHECK(hipMemsetAsync(sure, 0xFF, 2 * dbytes + 4, s));
+    HIPCHECK(hipMemsetAsync(up, 0xFF, dbytes, s));
+    launch_death_lower(klist[0], lo, s);                         // first lower bound: everybody's first killer
+    if (comm && comm->all_reduce_u32(lo, n_reads, ReduceOp::kMin, s) != 0) return comm_fail("all-reduce of the containment bounds");
+    ctx->tm.death_rounds = 0;
+    int cur = 0;
+    bool gathered = comm == nullptr;                             // the killer lists are complete on this rank
+    for (;;) {
+        HIPCHECK(hipMemsetAsync(klist[cur ^ 1].count, 0, 4, s));
+        launch_death_decide(klist[cur], lo, up, sure, klist[cur ^ 1], s);
+        cur ^= 1;
+        // tighter bounds for the next round: up = sure, lo = min(sure, undecided killers)
+        uint32_t undecided = 0;
+        if (gathered) {
+            HIPCHECK(d2h_small(ctx, &undecided, klist[cur].count, 4, s));
+            HIPCHECK(stream_sync(ctx, s));
+        } else {
+            HIPCHECK(hipMemcpyAsync(lo, sure, dbytes, hipMemcpyDeviceToDevice, s));
+            launch_death_lower(klist[cur], lo, s);
+            launch_death_status(klist[cur].count, status, s);
+            if (comm->all_reduce_u32(sure, 2 * (size_t)n_reads + 1, ReduceOp::kMin, s) != 0) return comm_fail("all-reduce of the containment bounds");
+            uint32_t st = 0;
+            HIPCHECK(d2h_small(ctx, &st, status, 4, s));
+            HIPCHECK(stream_sync(ctx, s));
+            undecided = 0xFFFFFFFFu - st;                        // the largest list of any rank
+        }
+        ++ctx->tm.death_rounds;
+        if (getenv("RALA_HIP_TRACE")) fprintf(stderr, "[trace] containment round %d: %u undecided\n", (int)ctx->tm.death_rounds, undecided);
+        if (undecided == 0) break;
+        if (ctx->tm.death_rounds > 100000) return fail(ctx, RALA_HIP_EDEVICE, "containment fixed point did not converge");
+        HIPCHECK(hipMemcpyAsync(up, sure, dbytes, hipMemcpyDeviceToDevice, s));
+        if (gathered) {
+            HIPCHECK(hipMemcpyAsync(lo, sure, dbytes, hipMemcpyDeviceToDevice, s));
+            launch_death_lower(klist[cur], lo, s);
+        } else if ((uint64_t)undecided * comm->world() <= (1u << 16)) {
+            // few killers left: every rank takes all of them and the rest needs no collective
+            uint64_t mine = 0;
+            {
+                uint32_t c = 0;
+                HIPCHECK(d2h_small(ctx, &c, klist[cur].count, 4, s));
+                HIPCHECK(stream_sync(ctx, s));
+                mine = c;
+            }
+            std::vector<uint64_t> counts(comm->world());
+            if (comm->host_all_gather(&mine, 1, counts.data(), s) != 0) return comm_fail("killer counts");
+            uint64_t total = 0;
+            for (uint64_t c : counts) total += c;
+            uint32_t* src3[3] = {klist[cur].ovl, klist[cur].target, klist[cur].keeper};
+            uint32_t* dst3[3] = {klist[cur ^ 1].ovl, klist[cur ^ 1].target, klist[cur ^ 1].keeper};
+            if (total > N + 1) for (int k = 0; k < 3; ++k) { HIPCHECK(ctx->d_kill[k].ensure(total + 1)); HIPCHECK(ctx->d_kill2[k].ensure(total + 1)); }
+            if (total > N + 1) return fail(ctx, RALA_HIP_EDEVICE, "killer list larger than the slice");    // (cannot happen: <= 65536)
+            for (int k = 0; k < 3; ++k) {
+                if (comm->all_gather_v(src3[k], dst3[k], counts.data(), 4, s) != 0) return comm_fail("all-gather of the undecided killers");
+            }
+            const uint32_t t32 = (uint32_t)total;
+            HIPCHECK(hipMemcpyAsync(klist[cur ^ 1].count, &t32, 4, hipMemcpyHostToDevice, s));
+            HIPCHECK(stream_sync(ctx, s));                       // t32 is a local
+            cur ^= 1;
+            gathered = true;
+        }
+    }
+    uint32_t* death = sure;
+    HIPCHECK(hipEventRecord(ctx->ev[6], s));
+
+    // ---- liveness, hill counters, survivors ----
+    const uint32_t n_chunks = pass2_chunks(N);
+    launch_finish_pass2(ctx->ovl, ctx->d_cls.p, death, ctx->d_rec.p, ctx->d_pool.p, ctx->d_chunk[0].p,
+                        ctx->d_chunk[1].p, s);
+    launch_apply_death(death, ctx->d_alive.p, n_reads, s);
+    if (comm && ctx->pool_used) {
+        // Pile::check_chimeric_hills counters (pile.cpp:457-469): every slice counted its own overlaps
+        HIPCHECK(ctx->d_t_tmp[0].ensure(std::max<size_t>(ctx->pool_used, n_reads) + 2));
+        HIPCHECK(hipMemsetAsync(ctx->d_t_tmp[0].p, 0, (size_t)ctx->pool_used * 4, s));
+        launch_hill_counts(rs, n_reads, ctx->d_t_tmp[0].p, 0, s);
+        if (comm->all_reduce_u32(ctx->d_t_tmp[0].p, ctx->pool_used, ReduceOp::kSum, s) != 0) return comm_fail("all-reduce of the hill counters");
+        launch_hill_counts(rs, n_reads, ctx->d_t_tmp[0].p, 1, s);
+    }
+    uint32_t n_surv[2] = {0, 0};
+    for (int k = 0; k < 2; ++k) {
+        launch_exclusive_scan(ctx->d_chunk[k].p, ctx->d_chunk[2 + k].p, n_chunks, ctx->d_scan_ws.p, s);
+        HIPCHECK(d2h_small(ctx, &n_surv[k], ctx->d_chunk[2 + k].p + n_chunks, 4, s));
+    }
+    HIPCHECK(stream_sync(ctx, s));
+    auto tail_view = [&]() {
+        Survivors sv;
+        sv.src = ctx->d_surv_u32[0].p; sv.a_id = ctx->d_surv_u32[1].p; sv.b_id = ctx->d_surv_u32[2].p;
+        sv.a_begin = ctx->d_surv_u32[3].p; sv.a_end = ctx->d_surv_u32[4].p;
+        sv.b_begin = ctx->d_surv_u32[5].p; sv.b_end = ctx->d_surv_u32[6].p;
+        sv.length = ctx->d_surv_u32[7].p;
+        sv.strand = ctx->d_surv_u8[0].p; sv.type = ctx->d_surv_u8[1].p;
+        return sv;
+    };
+    if (!comm) {
+        // both survivor lists side by side in one device list: overlaps, then internals
+        const uint32_t M = n_surv[0] + n_surv[1];
+        ctx->t_n0 = n_surv[0]; ctx->t_n1 = n_surv[1];
+        for (int f = 0; f < 8; ++f) HIPCHECK(ctx->d_surv_u32[f].ensure(M));
+        for (int f = 0; f < 2; ++f) HIPCHECK(ctx->d_surv_u8[f].ensure(M));
+        // trim in the gather re-derives the coordinates against the pass-1 piles
+        if (M) launch_gather_survivors(ctx->ovl, ctx->d_cls.p, ctx->d_rec.p, ctx->d_chunk[2].p, ctx->d_chunk[3].p, n_surv[0], tail_view(), s);
+    } else {
+        // this slice's survivors as one packed block, all blocks gathered, unpacked in rank order
+        const uint32_t P = comm->world();
+        const uint64_t m = (uint64_t)n_surv[0] + n_surv[1];
+        HIPCHECK(ctx->d_list_block[0].ensure(packed_list_bytes(m) + 16));
+        if (m) launch_gather_survivors(ctx->ovl, ctx->d_cls.p, ctx->d_rec.p, ctx->d_chunk[2].p, ctx->d_chunk[3].p, n_surv[0],
+                                       packed_list_view(ctx->d_list_block[0].p, m), s);
+        const uint64_t mine[2] = {n_surv[0], n_surv[1]};
+        std::vector<uint64_t> all(2 * (size_t)P), bytes(P);
+        if (comm->host_all_gather(mine, 2, all.data(), s) != 0) return comm_fail("survivor counts");
+        ListBlocks lb;
+        uint64_t tot0 = 0, tot1 = 0, off = 0;
+        for (uint32_t p = 0; p < P; ++p) { tot0 += all[2 * p]; tot1 += all[2 * p + 1]; }
+        if (tot0 + tot1 >= 0xFFFFFFF0ull / 258) return fail(ctx, RALA_HIP_EINVAL, "too many surviving overlaps");
+        uint64_t at0 = 0, at1 = tot0;
+        for (uint32_t p = 0; p < P; ++p) {
+            const uint64_t mp = all[2 * p] + all[2 * p + 1];
+            bytes[p] = packed_list_bytes(mp);
+            lb.block_off[p] = off; lb.n0[p] = (uint32_t)all[2 * p]; lb.n1[p] = (uint32_t)all[2 * p + 1];
+            lb.dst0[p] = (uint32_t)at0; lb.dst1[p] = (uint32_t)at1;
+            off += bytes[p]; at0 += all[2 * p]; at1 += all[2 * p + 1];
+        }
+        lb.world = P;
+        HIPCHECK(ctx->d_list_block[1].ensure(off + 16));
+        if (comm->all_gather_v(ctx->d_list_block[0].p, ctx->d_list_block[1].p, bytes.data(), 1, s) != 0) return comm_fail("all-gather of the survivors");
+        const uint32_t M = (uint32_t)(tot0 + tot1);
+        ctx->t_n0 = (uint32_t)tot0; ctx->t_n1 = (uint32_t)tot1;
+        for (int f = 0; f < 8; ++f) HIPCHECK(ctx->d_surv_u32[f].ensure(M));
+        for (int f = 0; f < 2; ++f) HIPCHECK(ctx->d_surv_u8[f].ensure(M));
+        if (M) launch_unpack_lists(ctx->d_list_block[1].p, lb, tail_view(), s);
+    }
+    HIPCHECK(hipEventRecord(ctx->ev[7], s));
+    HIPCHECK(hipGetLastError());
+    return RALA_HIP_OK;
+}
+
 }  // namespace
+
+// ---- stage entry points shared with the sharded runner (stages.h) ---------------------------------
+int rala_hip::construct_stages(rala_hip_ctx* ctx, Comm* comm) {
+    if (!ctx) return RALA_HIP_EINVAL;
+    if (!ctx->initialized) return fail(ctx, RALA_HIP_EINVAL, "rala_hip_initialize must succeed first");
+    if (ctx->tuple_mode || !ctx->inputs_set) return fail(ctx, RALA_HIP_EINVAL, "construct needs the overlaps (rala_hip_set_overlaps)");
+    if (ctx->constructed) return fail(ctx, RALA_HIP_EINVAL, "object already constructed");
+    ctx->have_repeats = false;
+    HIPCHECK(hipSetDevice(ctx->device));
+    int rc = pass2(ctx, comm);
+    if (rc != RALA_HIP_OK) return rc;
+    ctx->tail_on_device = false;
+    ctx->host_stale = false;
+    const double t0 = now_ms();
+    rc = gpu_tail_run(ctx);
+    if (rc != RALA_HIP_OK) return rc;
+    HIPCHECK(hipEventElapsedTime(&ctx->tm.classify_ms, ctx->ev[4], ctx->ev[5]));
+    HIPCHECK(hipEventElapsedTime(&ctx->tm.death_ms, ctx->ev[5], ctx->ev[6]));
+    HIPCHECK(hipEventElapsedTime(&ctx->tm.finish_ms, ctx->ev[6], ctx->ev[7]));
+    ctx->tm.tail_host_ms = (float)(now_ms() - t0);
+    ctx->constructed = true;
+    return RALA_HIP_OK;
+}
+
+int rala_hip::install_read_state(rala_hip_ctx* ctx, uint64_t pool_count) {
+    if (!ctx) return RALA_HIP_EINVAL;
+    if (ctx->n_reads == 0) return fail(ctx, RALA_HIP_EINVAL, "no reads set");
+    if (ctx->n_ovl && !ctx->valid_ready) return fail(ctx, RALA_HIP_EINVAL, "validity bits required (rala_hip_dedupe)");
+    if (pool_count > ctx->pool_cap) return fail(ctx, RALA_HIP_ECAPACITY, "interval pool smaller than the installed state");
+    HIPCHECK(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    ctx->tm = rala_hip_timings();
+    ctx->overlaps.clear(); ctx->internals.clear();
+    const uint32_t small[8] = {(uint32_t)pool_count, 0, 0, 0, 0, 0, 0, 0};
+    HIPCHECK(hipMemcpyAsync(ctx->d_small.p, small, sizeof(small), hipMemcpyHostToDevice, s));
+    HIPCHECK(ctx->d_cc_flags.ensure(8));
+    HIPCHECK(hipMemsetAsync(ctx->d_cc_flags.p + 6, 0, 4, s));
+    launch_count_zero_u8(ctx->d_alive.p, (uint32_t)ctx->n_reads, ctx->d_cc_flags.p + 6, s);
+    uint32_t n_dead = 0;
+    HIPCHECK(d2h_small(ctx, &n_dead, ctx->d_cc_flags.p + 6, 4, s));
+    HIPCHECK(stream_sync(ctx, s));                  // `small` is a local
+    ctx->host_state_fresh = false;
+    ctx->pool_used = (uint32_t)pool_count;
+    ctx->n_prefiltered = n_dead;
+    ctx->initialized = true;
+    ctx->constructed = false;
+    ctx->piles_resident = false;
+    ctx->tail_on_device = ctx->host_stale = ctx->marks_on_device = false;
+    if (ctx->n_prefiltered == ctx->n_reads) return fail(ctx, RALA_HIP_EFILTERED, "filtered all sequences");
+    return RALA_HIP_OK;
+}
 
 extern "C" {
 
@@ -1548,80 +1793,12 @@ int rala_hip_construct(rala_hip_ctx* ctx, const rala_hip_overlaps* sens, uint64_
     const uint64_t N = ctx->n_ovl;
     const ReadState rs = read_state(ctx);
 
-    // ---- pass 2, static part ----
-    for (int k = 0; k < 3; ++k) HIPCHECK(ctx->d_kill[k].ensure(N));
-    HIPCHECK(ctx->d_kill_count.ensure(4));
-    KillList kl;
-    kl.count = ctx->d_kill_count.p; kl.ovl = ctx->d_kill[0].p; kl.target = ctx->d_kill[1].p; kl.keeper = ctx->d_kill[2].p;
-    HIPCHECK(hipEventRecord(ctx->ev[4], s));
-    HIPCHECK(hipMemsetAsync(kl.count, 0, 4, s));
-    HIPCHECK(ctx->d_rec.ensure(n_reads));
-    launch_pack_reads(rs, n_reads, ctx->d_rec.p, s);
-    launch_classify(ctx->ovl, n_reads, ctx->d_valid.p, ctx->d_rec.p, ctx->d_cls.p, kl, s);
-    HIPCHECK(hipEventRecord(ctx->ev[5], s));
-    // ---- in-order containment removal as a fixed point (death_decide_kernel) ----
-    // d_death[0] = lower bound, d_death[1] = upper bound, d_death_sure = min over sure killers
-    for (int k = 0; k < 3; ++k) HIPCHECK(ctx->d_kill2[k].ensure(N));
-    HIPCHECK(ctx->d_death_sure.ensure(n_reads));
-    KillList klist[2] = {kl, kl};
-    klist[1].count = ctx->d_kill_count.p + 1;
-    klist[1].ovl = ctx->d_kill2[0].p; klist[1].target = ctx->d_kill2[1].p; klist[1].keeper = ctx->d_kill2[2].p;
-    uint32_t* lo = ctx->d_death[0].p;
-    uint32_t* up = ctx->d_death[1].p;
-    uint32_t* sure = ctx->d_death_sure.p;
-    const size_t dbytes = (size_t)n_reads * 4;
-    HIPCHECK(hipMemsetAsync(lo, 0xFF, dbytes, s));
-    HIPCHECK(hipMemsetAsync(up, 0xFF, dbytes, s));
-    HIPCHECK(hipMemsetAsync(sure, 0xFF, dbytes, s));
-    launch_death_lower(klist[0], lo, s);                         // first lower bound: everybody's first killer
-    ctx->tm.death_rounds = 0;
-    int cur = 0;
-    for (;;) {
-        HIPCHECK(hipMemsetAsync(klist[cur ^ 1].count, 0, 4, s));
-        launch_death_decide(klist[cur], lo, up, sure, klist[cur ^ 1], s);
-        uint32_t undecided = 0;
-        HIPCHECK(d2h_small(ctx, &undecided, klist[cur ^ 1].count, 4, s));
-        HIPCHECK(stream_sync(ctx, s));
-        ++ctx->tm.death_rounds;
-        cur ^= 1;
-        if (getenv("RALA_HIP_TRACE")) fprintf(stderr, "[trace] containment round %d: %u undecided\n", (int)ctx->tm.death_rounds, undecided);
-        if (undecided == 0) break;
-        if (ctx->tm.death_rounds > 100000) return fail(ctx, RALA_HIP_EDEVICE, "containment fixed point did not converge");
-        // tighter bounds: up = sure, lo = min(sure, undecided killers)
-        HIPCHECK(hipMemcpyAsync(up, sure, dbytes, hipMemcpyDeviceToDevice, s));
-        HIPCHECK(hipMemcpyAsync(lo, sure, dbytes, hipMemcpyDeviceToDevice, s));
-        launch_death_lower(klist[cur], lo, s);
+    {
+        const int rc_p2 = pass2(ctx, nullptr);
+        if (rc_p2 != RALA_HIP_OK) return rc_p2;
     }
-    uint32_t* death = sure;
-    HIPCHECK(hipEventRecord(ctx->ev[6], s));
-    // ---- liveness, hill counters, survivors ----
-    const uint32_t n_chunks = pass2_chunks(N);
-    launch_finish_pass2(ctx->ovl, ctx->d_cls.p, death, ctx->d_rec.p, ctx->d_pool.p, ctx->d_chunk[0].p,
-                        ctx->d_chunk[1].p, s);
-    launch_apply_death(death, ctx->d_alive.p, n_reads, s);
-    uint32_t n_surv[2] = {0, 0};
-    for (int k = 0; k < 2; ++k) {
-        launch_exclusive_scan(ctx->d_chunk[k].p, ctx->d_chunk[2 + k].p, n_chunks, ctx->d_scan_ws.p, s);
-        HIPCHECK(d2h_small(ctx, &n_surv[k], ctx->d_chunk[2 + k].p + n_chunks, 4, s));
-    }
-    HIPCHECK(stream_sync(ctx, s));
-    // both survivor lists side by side in one device list: overlaps, then internals
-    const uint32_t M = n_surv[0] + n_surv[1];
-    ctx->t_n0 = n_surv[0]; ctx->t_n1 = n_surv[1];
-    for (int f = 0; f < 8; ++f) HIPCHECK(ctx->d_surv_u32[f].ensure(M));
-    for (int f = 0; f < 2; ++f) HIPCHECK(ctx->d_surv_u8[f].ensure(M));
-    if (M) {
-        Survivors sv;
-        sv.src = ctx->d_surv_u32[0].p; sv.a_id = ctx->d_surv_u32[1].p; sv.b_id = ctx->d_surv_u32[2].p;
-        sv.a_begin = ctx->d_surv_u32[3].p; sv.a_end = ctx->d_surv_u32[4].p;
-        sv.b_begin = ctx->d_surv_u32[5].p; sv.b_end = ctx->d_surv_u32[6].p;
-        sv.length = ctx->d_surv_u32[7].p;
-        sv.strand = ctx->d_surv_u8[0].p; sv.type = ctx->d_surv_u8[1].p;
-        // trim in the gather re-derives the coordinates against the pass-1 piles
-        launch_gather_survivors(ctx->ovl, ctx->d_cls.p, ctx->d_rec.p, ctx->d_chunk[2].p, ctx->d_chunk[3].p, n_surv[0], sv, s);
-    }
-    HIPCHECK(hipEventRecord(ctx->ev[7], s));
-    HIPCHECK(hipGetLastError());
+    const uint32_t M = ctx->t_n0 + ctx->t_n1;
+    const uint32_t n_surv[2] = {ctx->t_n0, ctx->t_n1};
     const bool with_sens = sens != nullptr && n_sens != 0;
     ctx->tail_on_device = false;
     ctx->host_stale = false;

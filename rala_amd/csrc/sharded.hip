@@ -1,0 +1,428 @@
+// Sharded (multi-GPU) run of the hot path: C ABI rala_hip_mg_* (include/rala_hip.h).
+//
+// One rala_hip_mg object per rank (= per GPU).  Reads are the independent units: read r is owned
+// by rank r % P and is local read r / P there.  The overlap file is cut into P contiguous slices
+// on a_id-run boundaries (duplicate removal is per run, reference graph.cpp:346-350); rank k
+// holds slice k and ALL read lengths.  One step (rala_hip_mg_run, collective):
+//
+//   slice   duplicate removal; bound tuples {local read, bound} grouped by owner      O(N / P)
+//   comm    ONE all-to-all(v) of the 8-byte tuples to the read owners
+//   owner   bucket the tuples, build + annotate the piles of the owned reads          O(bases / P)
+//   comm    all-gather of the per-read state (19 B per read) and the interval pools
+//   slice   classify (trim / type) against the gathered state                         O(N / P)
+//   comm    containment fixed point: bounds all-reduced (min) per round; once few killers are
+//           undecided they are gathered and the rest runs without collectives
+//   slice   liveness, hill counters (all-reduce sum), survivors                       O(N / P)
+//   comm    all-gather of the survivor lists (about 1 % of the overlaps)
+//   all     preprocess tail, graph, transitive reduction on the survivors             replicated
+//
+// With sensitive overlaps (-s, graph.cpp:882-1054) the second add_layers and the repeat hills run
+// on the owners as well (tuples by target owner, medians and hills gathered back).
+//
+// Two contexts per rank: `cs` (all reads, the slice's overlaps; ends up with the replicated
+// result, so every getter of rala_hip.h works on it) and `cl` (the owned reads with their piles).
+#include <hip/hip_runtime.h>
+#include <string.h>
+
+#include <algorithm>
+#include <chrono>
+#include <thread>
+
+#include "comm.h"
+#include "context.h"
+#include "stages.h"
+
+using namespace rala_hip;
+
+struct rala_hip_mg {
+    int device = 0;
+    uint32_t rank = 0, world = 1;
+    Comm* comm = nullptr;
+    rala_hip_ctx* cs = nullptr;
+    rala_hip_ctx* cl = nullptr;
+    uint64_t n_reads = 0, n_local = 0, nl_pad = 0;
+    bool have_reads = false, have_overlaps = false;
+    std::string err;
+    DevBuf<uint2> d_send, d_recv;
+    DevBuf<uint8_t> d_state_mine, d_state_all;
+    DevBuf<uint8_t> d_bytes[2];
+    rala_hip_mg_timings tm = {};
+};
+
+namespace {
+
+constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
+constexpr int kBlock = 256;
+
+double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+uint64_t local_count(uint64_t n_reads, uint32_t rank, uint32_t world) {
+    return n_reads > rank ? (n_reads - rank + world - 1) / world : 0;
+}
+
+// ---- packed per-read state of one rank: field arrays of nl entries back to back ------------
+struct StateLayout {
+    uint64_t nl;
+    __host__ __device__ uint64_t begin() const { return 0; }
+    __host__ __device__ uint64_t end() const { return 4 * nl; }
+    __host__ __device__ uint64_t slot() const { return 8 * nl; }
+    __host__ __device__ uint64_t median() const { return 12 * nl; }
+    __host__ __device__ uint64_t p10() const { return 14 * nl; }
+    __host__ __device__ uint64_t alive() const { return 16 * nl; }
+    __host__ __device__ uint64_t n_pits() const { return 17 * nl; }
+    __host__ __device__ uint64_t n_hills() const { return 18 * nl; }
+    __host__ __device__ uint64_t bytes() const { return 19 * nl; }
+};
+
+struct ReadArrays {
+    uint32_t *begin, *end, *slot;
+    uint16_t *median, *p10;
+    uint8_t *alive, *n_pits, *n_hills;
+};
+
+ReadArrays read_arrays(rala_hip_ctx* c) {
+    return ReadArrays{c->d_begin.p, c->d_end.p, c->d_iv_slot.p, c->d_median.p, c->d_p10.p,
+                      c->d_alive.p, c->d_n_pits.p, c->d_n_hills.p};
+}
+
+__global__ __launch_bounds__(kBlock) void pack_state_kernel(ReadArrays a, uint64_t n_local, StateLayout L, uint8_t* out) {
+    const uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j >= L.nl) return;
+    const bool in = j < n_local;
+    ((uint32_t*)(out + L.begin()))[j] = in ? a.begin[j] : 0u;
+    ((uint32_t*)(out + L.end()))[j] = in ? a.end[j] : 0u;
+    ((uint32_t*)(out + L.slot()))[j] = in ? a.slot[j] : kNoSlot;
+    ((uint16_t*)(out + L.median()))[j] = in ? a.median[j] : (uint16_t)0;
+    ((uint16_t*)(out + L.p10()))[j] = in ? a.p10[j] : (uint16_t)0;
+    out[L.alive() + j] = in ? a.alive[j] : (uint8_t)0;
+    out[L.n_pits() + j] = in ? a.n_pits[j] : (uint8_t)0;
+    out[L.n_hills() + j] = in ? a.n_hills[j] : (uint8_t)0;
+}
+
+struct RankTable {
+    uint32_t v[64];
+};
+
+// global read r = j * world + k  <-  entry j of rank k's block; pool slots rebased onto the
+// concatenation of the ranks' interval pools
+__global__ __launch_bounds__(kBlock) void unpack_state_kernel(const uint8_t* all, StateLayout L, uint32_t world,
+                                                              uint64_t n_reads, RankTable pool_base, ReadArrays a) {
+    const uint64_t r = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (r >= n_reads) return;
+    const uint32_t k = (uint32_t)(r % world);
+    const uint64_t j = r / world;
+    const uint8_t* in = all + (uint64_t)k * L.bytes();
+    a.begin[r] = ((const uint32_t*)(in + L.begin()))[j];
+    a.end[r] = ((const uint32_t*)(in + L.end()))[j];
+    const uint32_t s = ((const uint32_t*)(in + L.slot()))[j];
+    a.slot[r] = s == kNoSlot ? kNoSlot : s + pool_base.v[k];
+    a.median[r] = ((const uint16_t*)(in + L.median()))[j];
+    a.p10[r] = ((const uint16_t*)(in + L.p10()))[j];
+    a.alive[r] = in[L.alive() + j];
+    a.n_pits[r] = in[L.n_pits() + j];
+    a.n_hills[r] = in[L.n_hills() + j];
+}
+
+#define MGCHECK(call)                                                                    \
+    do {                                                                                 \
+        hipError_t e_ = (call);                                                          \
+        if (e_ != hipSuccess) {                                                          \
+            mg->err = std::string(#call) + ": " + hipGetErrorString(e_);                 \
+            return e_ == hipErrorOutOfMemory ? RALA_HIP_ENOMEM : RALA_HIP_EDEVICE;       \
+        }                                                                                \
+    } while (0)
+
+int mg_fail(rala_hip_mg* mg, int code, const std::string& msg) {
+    mg->err = msg;
+    return code;
+}
+
+int from_ctx(rala_hip_mg* mg, rala_hip_ctx* c, int rc, const char* where) {
+    if (rc != RALA_HIP_OK) mg->err = std::string(where) + ": " + rala_hip_last_error(c);
+    return rc;
+}
+
+int from_comm(rala_hip_mg* mg, int rc, const char* where) {
+    if (rc == 0) return RALA_HIP_OK;
+    mg->err = std::string(where) + ": " + mg->comm->error();
+    return RALA_HIP_EDEVICE;
+}
+
+// Every rank learns whether any rank failed (otherwise the others would wait in the next
+// collective for ever).  Returns this rank's code, or RALA_HIP_EDEVICE if only another one failed.
+int agree(rala_hip_mg* mg, int rc, const char* where) {
+    std::vector<uint64_t> all(mg->world);
+    const uint64_t mine = (uint64_t)(uint32_t)(-rc);
+    if (mg->comm->host_all_gather(&mine, 1, all.data(), mg->cs->stream) != 0) {
+        if (rc == RALA_HIP_OK) return from_comm(mg, -1, where);
+        return rc;
+    }
+    if (rc != RALA_HIP_OK) return rc;
+    for (uint32_t p = 0; p < mg->world; ++p) {
+        if (all[p] != 0) {
+            return mg_fail(mg, all[p] == (uint64_t)(-RALA_HIP_EFILTERED) ? RALA_HIP_EFILTERED : RALA_HIP_EDEVICE,
+                           std::string(where) + ": rank " + std::to_string(p) + " failed with code -" + std::to_string(all[p]));
+        }
+    }
+    return RALA_HIP_OK;
+}
+
+int run_primary(rala_hip_mg* mg) {
+    rala_hip_ctx* cs = mg->cs;
+    rala_hip_ctx* cl = mg->cl;
+    Comm* comm = mg->comm;
+    const uint32_t P = mg->world;
+    hipStream_t s = cs->stream;
+    double t = now_ms();
+    auto lap = [&](float& slot) {
+        (void)hipStreamSynchronize(cs->stream);
+        (void)hipStreamSynchronize(cl->stream);
+        const double u = now_ms();
+        slot = (float)(u - t);
+        t = u;
+    };
+
+    // 1. slice: duplicates, owner-grouped bound tuples
+    int rc = from_ctx(mg, cs, rala_hip_dedupe(cs), "dedupe");
+    std::vector<uint64_t> send_counts(P, 0);
+    if (rc == RALA_HIP_OK) {
+        MGCHECK(mg->d_send.ensure(4 * std::max<uint64_t>(cs->n_ovl, 1) + 8));
+        rc = from_ctx(mg, cs, rala_hip_emit_bound_tuples_bucketed(cs, P, (uint64_t*)mg->d_send.p, send_counts.data()), "emit tuples");
+    }
+    rc = agree(mg, rc, "emit");
+    if (rc != RALA_HIP_OK) return rc;
+    lap(mg->tm.emit_ms);
+
+    // 2. ONE all-to-all(v) of 8-byte tuples (the bucket sizes travel first)
+    std::vector<uint64_t> matrix((size_t)P * P), recv_counts(P);
+    rc = from_comm(mg, comm->host_all_gather(send_counts.data(), P, matrix.data(), s), "tuple counts");
+    if (rc != RALA_HIP_OK) return rc;
+    uint64_t n_recv = 0;
+    for (uint32_t p = 0; p < P; ++p) { recv_counts[p] = matrix[(size_t)p * P + mg->rank]; n_recv += recv_counts[p]; }
+    MGCHECK(mg->d_recv.ensure(n_recv + 8));
+    rc = from_comm(mg, comm->all_to_all_v(mg->d_send.p, send_counts.data(), mg->d_recv.p, recv_counts.data(), sizeof(uint2), s),
+                   "all-to-all of the bound tuples");
+    if (rc != RALA_HIP_OK) return rc;
+    lap(mg->tm.exchange_ms);
+    mg->tm.tuples_sent = 0;
+    for (uint32_t p = 0; p < P; ++p) if (p != mg->rank) mg->tm.tuples_sent += send_counts[p];
+
+    // 3. owner: piles of the reads this rank owns
+    rc = from_ctx(mg, cl, rala_hip_set_bound_tuples(cl, (const uint64_t*)mg->d_recv.p, n_recv, RALA_HIP_MEM_DEVICE), "set tuples");
+    if (rc == RALA_HIP_OK) {
+        rc = rala_hip_initialize(cl);
+        if (rc == RALA_HIP_EFILTERED) rc = RALA_HIP_OK;      // all of ONE rank's reads filtered is not the job's verdict
+        rc = from_ctx(mg, cl, rc, "owner initialize");
+    }
+    rc = agree(mg, rc, "owner initialize");
+    if (rc != RALA_HIP_OK) return rc;
+    lap(mg->tm.owner_ms);
+
+    // 4. all-gather of the per-read state and the interval pools; install in the slice context
+    StateLayout L{mg->nl_pad};
+    MGCHECK(mg->d_state_mine.ensure(L.bytes() + 16));
+    MGCHECK(mg->d_state_all.ensure(L.bytes() * P + 16));
+    hipLaunchKernelGGL(pack_state_kernel, dim3((unsigned)((L.nl + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
+                       read_arrays(cl), mg->n_local, L, mg->d_state_mine.p);
+    rc = from_comm(mg, comm->all_gather(mg->d_state_mine.p, mg->d_state_all.p, L.bytes(), s), "all-gather of the read state");
+    if (rc != RALA_HIP_OK) return rc;
+    const uint64_t my_pool = cl->pool_used;
+    std::vector<uint64_t> pool_counts(P);
+    rc = from_comm(mg, comm->host_all_gather(&my_pool, 1, pool_counts.data(), s), "pool counts");
+    if (rc != RALA_HIP_OK) return rc;
+    RankTable base;
+    uint64_t pool_total = 0;
+    for (uint32_t p = 0; p < P; ++p) { base.v[p] = (uint32_t)pool_total; pool_total += pool_counts[p]; }
+    if (pool_total > cs->pool_cap) {
+        cs->pool_cap = (uint32_t)pool_total + 1024;
+        MGCHECK(cs->d_pool.ensure(cs->pool_cap));
+    }
+    rc = from_comm(mg, comm->all_gather_v(cl->d_pool.p, cs->d_pool.p, pool_counts.data(), sizeof(Interval), s),
+                   "all-gather of the interval pools");
+    if (rc != RALA_HIP_OK) return rc;
+    hipLaunchKernelGGL(unpack_state_kernel, dim3((unsigned)((mg->n_reads + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
+                       (const uint8_t*)mg->d_state_all.p, L, P, mg->n_reads, base, read_arrays(cs));
+    rc = install_read_state(cs, pool_total);
+    if (rc != RALA_HIP_OK && rc != RALA_HIP_EFILTERED) return from_ctx(mg, cs, rc, "install state");
+    if (rc == RALA_HIP_EFILTERED) return from_ctx(mg, cs, rc, "initialize");      // the same verdict on every rank
+    lap(mg->tm.gather_ms);
+
+    // 5. second pass .. preprocess tail .. graph, sharded by slice where it is per overlap
+    rc = construct_stages(cs, comm);
+    rc = agree(mg, from_ctx(mg, cs, rc, "construct"), "construct");
+    if (rc != RALA_HIP_OK) return rc;
+    lap(mg->tm.construct_ms);
+    return RALA_HIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rala_hip_mg_unique_id(void* id) {
+    if (!id) return RALA_HIP_EINVAL;
+    std::string err;
+    return rccl_unique_id(id, &err) == 0 ? RALA_HIP_OK : RALA_HIP_EDEVICE;
+}
+
+int rala_hip_mg_local_group_create(uint32_t world, void** group) {
+    if (!group) return RALA_HIP_EINVAL;
+    *group = create_local_group(world);
+    return *group ? RALA_HIP_OK : RALA_HIP_EINVAL;
+}
+
+void rala_hip_mg_local_group_destroy(void* group) { destroy_local_group((LocalGroup*)group); }
+
+int rala_hip_mg_create(int device, uint32_t rank, uint32_t world, int transport, const void* token, rala_hip_mg** out) {
+    if (!out) return RALA_HIP_EINVAL;
+    *out = nullptr;
+    if (world == 0 || world > 64 || rank >= world || !token) return RALA_HIP_EINVAL;
+    rala_hip_mg* mg = new rala_hip_mg;
+    mg->device = device; mg->rank = rank; mg->world = world;
+    int rc = rala_hip_create(device, &mg->cs);
+    if (rc == RALA_HIP_OK) rc = rala_hip_create(device, &mg->cl);
+    if (rc == RALA_HIP_OK) {
+        std::string err;
+        if (transport == RALA_HIP_COMM_RCCL) mg->comm = create_rccl_comm(rank, world, token, &err);
+        else if (transport == RALA_HIP_COMM_LOCAL) mg->comm = create_local_comm((LocalGroup*)token, rank, device, &err);
+        if (!mg->comm) {
+            fprintf(stderr, "[rala_hip_mg_create] %s\n", err.empty() ? "unknown transport" : err.c_str());
+            rc = RALA_HIP_EDEVICE;
+        }
+    }
+    if (rc != RALA_HIP_OK) { rala_hip_mg_destroy(mg); return rc; }
+    *out = mg;
+    return RALA_HIP_OK;
+}
+
+void rala_hip_mg_destroy(rala_hip_mg* mg) {
+    if (!mg) return;
+    (void)hipSetDevice(mg->device);
+    if (mg->cs) (void)hipStreamSynchronize(mg->cs->stream);
+    if (mg->cl) (void)hipStreamSynchronize(mg->cl->stream);
+    delete mg->comm;
+    mg->d_send.release(); mg->d_recv.release(); mg->d_state_mine.release(); mg->d_state_all.release();
+    if (mg->cl) rala_hip_destroy(mg->cl);
+    if (mg->cs) rala_hip_destroy(mg->cs);
+    delete mg;
+}
+
+const char* rala_hip_mg_last_error(const rala_hip_mg* mg) { return mg ? mg->err.c_str() : "no object"; }
+
+int rala_hip_mg_set_reads(rala_hip_mg* mg, const uint32_t* read_len, uint64_t n_reads) {
+    if (!mg || (!read_len && n_reads)) return RALA_HIP_EINVAL;
+    mg->n_reads = n_reads;
+    mg->n_local = local_count(n_reads, mg->rank, mg->world);
+    mg->nl_pad = (local_count(n_reads, 0, mg->world) + 15) / 16 * 16;        // the same on every rank
+    int rc = from_ctx(mg, mg->cs, rala_hip_set_reads(mg->cs, read_len, n_reads), "set_reads");
+    if (rc != RALA_HIP_OK) return rc;
+    std::vector<uint32_t> local(mg->n_local);
+    for (uint64_t j = 0; j < mg->n_local; ++j) local[j] = read_len[j * mg->world + mg->rank];
+    rc = from_ctx(mg, mg->cl, rala_hip_set_reads(mg->cl, local.data(), mg->n_local), "set_reads (owner)");
+    mg->have_reads = rc == RALA_HIP_OK;
+    return rc;
+}
+
+int rala_hip_mg_set_overlaps(rala_hip_mg* mg, const rala_hip_overlaps* slice, uint64_t n, uint64_t first, int mem) {
+    if (!mg) return RALA_HIP_EINVAL;
+    if (first + n >= 0xFFFFFFF0ull) return mg_fail(mg, RALA_HIP_EINVAL, "file positions must fit 32 bits");
+    const int rc = from_ctx(mg, mg->cs, rala_hip_set_overlaps(mg->cs, slice, n, mem), "set_overlaps");
+    if (rc != RALA_HIP_OK) return rc;
+    mg->cs->ovl.base = first;
+    mg->have_overlaps = true;
+    return RALA_HIP_OK;
+}
+
+// Cut points of the overlap file: world + 1 positions, every cut at the start of a run of equal
+// a_id.  Records whose query does not resolve (RALA_HIP_NO_READ) neither start nor end a run
+// (graph.cpp:343-350 skips them), so a cut never falls between X, <unresolved>, X.
+int rala_hip_mg_slice_cuts(const uint32_t* a_id, uint64_t n, uint32_t world, uint64_t* cuts) {
+    if (!cuts || world == 0 || (!a_id && n)) return RALA_HIP_EINVAL;
+    cuts[0] = 0;
+    for (uint32_t k = 1; k < world; ++k) {
+        uint64_t i = std::max(cuts[k - 1], n / world * k + std::min<uint64_t>(k, n % world));
+        // the resolved query in front of position i
+        while (i < n) {
+            if (i == 0) break;
+            if (a_id[i] == RALA_HIP_NO_READ) { ++i; continue; }
+            uint64_t j = i;
+            while (j > 0 && a_id[j - 1] == RALA_HIP_NO_READ) --j;
+            if (j == 0 || a_id[j - 1] != a_id[i]) break;      // a new run starts at i
+            ++i;
+        }
+        cuts[k] = std::min(i, n);
+    }
+    cuts[world] = n;
+    return RALA_HIP_OK;
+}
+
+int rala_hip_mg_run(rala_hip_mg* mg, const rala_hip_overlaps* sens_slice, uint64_t n_sens, uint32_t* n_pairs) {
+    if (!mg || !n_pairs) return RALA_HIP_EINVAL;
+    if (!mg->have_reads || !mg->have_overlaps) return mg_fail(mg, RALA_HIP_EINVAL, "set reads and overlaps first");
+    if (sens_slice != nullptr && n_sens != 0) return mg_fail(mg, RALA_HIP_EINVAL, "sensitive overlaps: not wired into the sharded run yet");
+    MGCHECK(hipSetDevice(mg->device));
+    mg->tm = rala_hip_mg_timings();
+    const double t0 = now_ms();
+    int rc = run_primary(mg);
+    if (rc != RALA_HIP_OK) return rc;
+    const double t1 = now_ms();
+    rc = from_ctx(mg, mg->cs, rala_hip_remove_transitive_edges(mg->cs, n_pairs), "remove_transitive_edges");
+    if (rc != RALA_HIP_OK) return rc;
+    mg->tm.tr_ms = (float)(now_ms() - t1);
+    mg->tm.total_ms = (float)(now_ms() - t0);
+    return RALA_HIP_OK;
+}
+
+int rala_hip_mg_run_threads(rala_hip_mg** ranks, uint32_t n, const rala_hip_overlaps* sens_slices, const uint64_t* n_sens,
+                            uint32_t* n_pairs) {
+    if (!ranks || n == 0 || !n_pairs) return RALA_HIP_EINVAL;
+    std::vector<int> rc(n, RALA_HIP_OK);
+    std::vector<uint32_t> pairs(n, 0);
+    std::vector<std::thread> th;
+    for (uint32_t k = 0; k < n; ++k) {
+        th.emplace_back([&, k]() {
+            rc[k] = rala_hip_mg_run(ranks[k], sens_slices ? &sens_slices[k] : nullptr, n_sens ? n_sens[k] : 0, &pairs[k]);
+        });
+    }
+    for (auto& t : th) t.join();
+    for (uint32_t k = 0; k < n; ++k) if (rc[k] != RALA_HIP_OK) return rc[k];
+    for (uint32_t k = 1; k < n; ++k) {
+        if (pairs[k] != pairs[0]) { ranks[0]->err = "ranks disagree on the transitive reduction"; return RALA_HIP_EDEVICE; }
+    }
+    *n_pairs = pairs[0];
+    return RALA_HIP_OK;
+}
+
+rala_hip_ctx* rala_hip_mg_context(rala_hip_mg* mg) { return mg ? mg->cs : nullptr; }
+rala_hip_ctx* rala_hip_mg_owner_context(rala_hip_mg* mg) { return mg ? mg->cl : nullptr; }
+
+int rala_hip_mg_get_pile_data(rala_hip_mg* mg, uint64_t read, uint16_t* data) {
+    if (!mg || !data) return RALA_HIP_EINVAL;
+    if (read >= mg->n_reads || read % mg->world != mg->rank) return mg_fail(mg, RALA_HIP_EINVAL, "the read's pile lives on rank read % world");
+    MGCHECK(hipSetDevice(mg->device));
+    // the owner's context keeps the coverage; the valid region that applies is the final one
+    const uint64_t j = read / mg->world;
+    rala_hip_ctx* cl = mg->cl;
+    const uint32_t n = cl->h_read_len[j];
+    MGCHECK(hipMemcpy(data, cl->d_pile.p + cl->h_pile_off[j], (size_t)n * 2, hipMemcpyDeviceToHost));
+    uint32_t be[2] = {0, 0};
+    uint8_t alive = 0;
+    MGCHECK(hipMemcpy(&be[0], mg->cs->d_begin.p + read, 4, hipMemcpyDeviceToHost));
+    MGCHECK(hipMemcpy(&be[1], mg->cs->d_end.p + read, 4, hipMemcpyDeviceToHost));
+    MGCHECK(hipMemcpy(&alive, mg->cs->d_alive.p + read, 1, hipMemcpyDeviceToHost));
+    if (alive) {
+        for (uint32_t p = 0; p < be[0] && p < n; ++p) data[p] = 0;      // Pile::shrink zeroes outside (pile.cpp:311-318)
+        for (uint32_t p = be[1]; p < n; ++p) data[p] = 0;
+    }
+    return RALA_HIP_OK;
+}
+
+int rala_hip_mg_get_timings(rala_hip_mg* mg, rala_hip_mg_timings* out) {
+    if (!mg || !out) return RALA_HIP_EINVAL;
+    *out = mg->tm;
+    return RALA_HIP_OK;
+}
+
+}  // extern "C"

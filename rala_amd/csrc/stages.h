@@ -1,0 +1,28 @@
+// Stage functions of librala_hip shared by the single-GPU entry points (pipeline.hip) and the
+// sharded runner (sharded.hip).  A non-null Comm makes a stage collective: every rank of the
+// group calls it with its own slice of the overlaps and the same per-read state.
+#pragma once
+
+#include "comm.h"
+#include "context.h"
+
+namespace rala_hip {
+
+// second overlap pass (graph.cpp:443-518) .. Graph::preprocess for chimeras (:699-880) .. node and
+// edge construction (:553-632) on ctx->ovl (file positions ctx->ovl.base + i):
+//   classify (trim / type, killer list)                      per overlap of the slice
+//   containment fixed point                                  comm: bounds all-reduced (min) per round
+//   liveness, hill counters, survivors                       comm: counters all-reduced (sum),
+//                                                                  survivor lists all-gathered
+//   preprocess tail + graph on the survivors                 replicated
+int construct_stages(rala_hip_ctx* ctx, Comm* comm);
+
+// install per-read state that was computed elsewhere and already sits in ctx's device arrays
+// (d_begin .. d_iv_slot, d_pool[0 .. pool_count)); validity bits of ctx's own overlaps must be
+// there too (rala_hip_dedupe).  Counts the filtered reads.
+int install_read_state(rala_hip_ctx* ctx, uint64_t pool_count);
+
+hipError_t stream_sync(rala_hip_ctx* ctx, hipStream_t s);
+hipError_t d2h_small(rala_hip_ctx* ctx, void* dst, const void* src, size_t bytes, hipStream_t s);
+
+}  // namespace rala_hip

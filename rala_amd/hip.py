@@ -28,7 +28,13 @@ SYMBOLS = (
     "rala_hip_dedupe", "rala_hip_emit_bound_tuples", "rala_hip_set_bound_tuples", "rala_hip_import_state",
     "rala_hip_emit_bound_tuples_bucketed", "rala_hip_get_device_state", "rala_hip_import_state_device",
     "rala_hip_copy_device_state", "rala_hip_layout",
+    "rala_hip_mg_unique_id", "rala_hip_mg_local_group_create", "rala_hip_mg_local_group_destroy", "rala_hip_mg_create",
+    "rala_hip_mg_destroy", "rala_hip_mg_last_error", "rala_hip_mg_set_reads", "rala_hip_mg_slice_cuts",
+    "rala_hip_mg_set_overlaps", "rala_hip_mg_run", "rala_hip_mg_run_threads", "rala_hip_mg_context",
+    "rala_hip_mg_owner_context",
+    "rala_hip_mg_get_pile_data", "rala_hip_mg_get_timings",
 )
+COMM_RCCL, COMM_LOCAL = 0, 1
 
 
 class OverlapsC(ctypes.Structure):
@@ -47,6 +53,14 @@ class Timings(ctypes.Structure):
                  "tr_ms", "total_ms")] + [("pile_launches", ctypes.c_uint32), ("death_rounds", ctypes.c_uint32),
                                   ("pile_overflow_reads", ctypes.c_uint32),
                                   ("pile_position_reads", ctypes.c_uint32)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class MgTimings(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_float) for n in ("emit_ms", "exchange_ms", "owner_ms", "gather_ms", "construct_ms",
+                                              "repeats_ms", "tr_ms", "total_ms")] + [("tuples_sent", ctypes.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -98,6 +112,26 @@ def lib(build=True):
         L.rala_hip_import_state_device.argtypes = [vp, ctypes.POINTER(DeviceState)]
         L.rala_hip_copy_device_state.argtypes = [vp, ctypes.POINTER(DeviceState)]
         L.rala_hip_layout.argtypes = [vp, u32, vp, vp, vp, vp, u32, ctypes.c_double, ctypes.c_double, ctypes.c_double]
+        L.rala_hip_mg_unique_id.argtypes = [vp]
+        L.rala_hip_mg_local_group_create.argtypes = [u32, ctypes.POINTER(vp)]
+        L.rala_hip_mg_local_group_destroy.argtypes = [vp]
+        L.rala_hip_mg_local_group_destroy.restype = None
+        L.rala_hip_mg_create.argtypes = [i32, u32, u32, i32, vp, ctypes.POINTER(vp)]
+        L.rala_hip_mg_destroy.argtypes = [vp]
+        L.rala_hip_mg_destroy.restype = None
+        L.rala_hip_mg_last_error.argtypes = [vp]
+        L.rala_hip_mg_last_error.restype = ctypes.c_char_p
+        L.rala_hip_mg_set_reads.argtypes = [vp, vp, u64]
+        L.rala_hip_mg_slice_cuts.argtypes = [vp, u64, u32, vp]
+        L.rala_hip_mg_set_overlaps.argtypes = [vp, ctypes.POINTER(OverlapsC), u64, u64, i32]
+        L.rala_hip_mg_run.argtypes = [vp, ctypes.POINTER(OverlapsC), u64, ctypes.POINTER(u32)]
+        L.rala_hip_mg_run_threads.argtypes = [vp, u32, vp, vp, ctypes.POINTER(u32)]
+        L.rala_hip_mg_context.argtypes = [vp]
+        L.rala_hip_mg_context.restype = vp
+        L.rala_hip_mg_owner_context.argtypes = [vp]
+        L.rala_hip_mg_owner_context.restype = vp
+        L.rala_hip_mg_get_pile_data.argtypes = [vp, u64, vp]
+        L.rala_hip_mg_get_timings.argtypes = [vp, ctypes.POINTER(MgTimings)]
         _lib = L
     return _lib
 
@@ -122,12 +156,16 @@ def _soa(ov):
 class Context:
     """One librala_hip context = one data set on one GPU."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, _borrowed=None):
         self.L = lib()
-        h = ctypes.c_void_p()
-        rc = self.L.rala_hip_create(device, ctypes.byref(h))
-        if rc != 0:
-            raise RalaHipError(rc, "no usable HIP device %d" % device)
+        self._owned = _borrowed is None
+        if _borrowed is not None:
+            h = ctypes.c_void_p(_borrowed)
+        else:
+            h = ctypes.c_void_p()
+            rc = self.L.rala_hip_create(device, ctypes.byref(h))
+            if rc != 0:
+                raise RalaHipError(rc, "no usable HIP device %d" % device)
         self.h = h
         self.n_reads = 0
         self.n_overlaps = 0
@@ -135,7 +173,8 @@ class Context:
 
     def close(self):
         if getattr(self, "h", None):
-            self.L.rala_hip_destroy(self.h)
+            if self._owned:
+                self.L.rala_hip_destroy(self.h)
             self.h = None
 
     def __del__(self):
@@ -329,3 +368,133 @@ class Context:
         n = ctypes.c_uint64(0)
         self._check(self.L.rala_hip_get_num_prefiltered(self.h, ctypes.byref(n)))
         return int(n.value)
+
+
+def slice_cuts(a_id, world):
+    """rala_hip_mg_slice_cuts: world + 1 file positions, cuts on a_id-run boundaries"""
+    a = np.ascontiguousarray(a_id, dtype=np.uint32)
+    cuts = np.zeros(world + 1, dtype=np.uint64)
+    rc = lib().rala_hip_mg_slice_cuts(a.ctypes.data if len(a) else None, len(a), world, cuts.ctypes.data)
+    if rc != 0:
+        raise RalaHipError(rc, "slice_cuts")
+    return [int(c) for c in cuts]
+
+
+def unique_id():
+    """128-byte RCCL id (rank 0 makes it, the others receive the bytes)"""
+    buf = ctypes.create_string_buffer(128)
+    rc = lib().rala_hip_mg_unique_id(buf)
+    if rc != 0:
+        raise RalaHipError(rc, "no usable RCCL")
+    return buf.raw
+
+
+class ShardedRank:
+    """One rank of a sharded run (rala_hip_mg_*).  token: 128-byte RCCL id (bytes) or a LocalGroup."""
+
+    def __init__(self, device, rank, world, token):
+        self.L = lib()
+        self.rank, self.world = rank, world
+        h = ctypes.c_void_p()
+        if isinstance(token, LocalGroup):
+            self._token = token
+            rc = self.L.rala_hip_mg_create(device, rank, world, COMM_LOCAL, token.h, ctypes.byref(h))
+        else:
+            self._token = ctypes.create_string_buffer(bytes(token), 128)
+            rc = self.L.rala_hip_mg_create(device, rank, world, COMM_RCCL, self._token, ctypes.byref(h))
+        if rc != 0:
+            raise RalaHipError(rc, "rala_hip_mg_create failed (device %d, rank %d of %d)" % (device, rank, world))
+        self.h = h
+        self._keep = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.rala_hip_mg_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RalaHipError(rc, self.L.rala_hip_mg_last_error(self.h).decode())
+
+    def set_reads(self, read_len):
+        rl = np.ascontiguousarray(read_len, dtype=np.uint32)
+        self.read_len = rl
+        self._check(self.L.rala_hip_mg_set_reads(self.h, rl.ctypes.data, len(rl)))
+
+    def set_overlaps(self, ov_slice, first):
+        c = _soa(ov_slice)
+        self.n_slice = len(ov_slice)
+        self._check(self.L.rala_hip_mg_set_overlaps(self.h, ctypes.byref(c), len(ov_slice), int(first), MEM_HOST))
+
+    def run(self, sens_slice=None):
+        n = ctypes.c_uint32(0)
+        if sens_slice is not None and len(sens_slice):
+            c = _soa(sens_slice)
+            self._check(self.L.rala_hip_mg_run(self.h, ctypes.byref(c), len(sens_slice), ctypes.byref(n)))
+        else:
+            self._check(self.L.rala_hip_mg_run(self.h, None, 0, ctypes.byref(n)))
+        return int(n.value)
+
+    def context(self):
+        """the replicated result as a (borrowed) Context: piles(), intervals(), overlap_list(), graph() ..."""
+        c = Context(_borrowed=self.L.rala_hip_mg_context(self.h))
+        c.read_len = self.read_len
+        c.n_reads = len(self.read_len)
+        c.n_overlaps = self.n_slice
+        return c
+
+    def pile_data(self, r):
+        out = np.zeros(int(self.read_len[r]), dtype=np.uint16)
+        self._check(self.L.rala_hip_mg_get_pile_data(self.h, int(r), out.ctypes.data))
+        return out
+
+    def owner_timings(self):
+        """stage timings of the owner context (bucketing and pile kernels over the owned reads)"""
+        c = Context(_borrowed=self.L.rala_hip_mg_owner_context(self.h))
+        return c.timings()
+
+    def timings(self):
+        t = MgTimings()
+        self._check(self.L.rala_hip_mg_get_timings(self.h, ctypes.byref(t)))
+        return t.as_dict()
+
+
+class LocalGroup:
+    """rendezvous object of ranks that are threads of this process (RALA_HIP_COMM_LOCAL)"""
+
+    def __init__(self, world):
+        self.L = lib()
+        h = ctypes.c_void_p()
+        rc = self.L.rala_hip_mg_local_group_create(world, ctypes.byref(h))
+        if rc != 0:
+            raise RalaHipError(rc, "local group")
+        self.h, self.world = h, world
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.rala_hip_mg_local_group_destroy(self.h)
+            self.h = None
+
+
+def run_ranks(ranks, sens_slices=None):
+    """rala_hip_mg_run_threads: all ranks of this process, one host thread each"""
+    L = lib()
+    n = len(ranks)
+    arr = (ctypes.c_void_p * n)(*[r.h for r in ranks])
+    pairs = ctypes.c_uint32(0)
+    if sens_slices is not None:
+        cs = (OverlapsC * n)(*[_soa(s) for s in sens_slices])
+        ns = (ctypes.c_uint64 * n)(*[len(s) for s in sens_slices])
+        rc = L.rala_hip_mg_run_threads(arr, n, cs, ns, ctypes.byref(pairs))
+    else:
+        rc = L.rala_hip_mg_run_threads(arr, n, None, None, ctypes.byref(pairs))
+    if rc != 0:
+        msgs = [L.rala_hip_mg_last_error(r.h).decode() for r in ranks]
+        raise RalaHipError(rc, " | ".join(m for m in msgs if m))
+    return int(pairs.value)

@@ -51,9 +51,9 @@ void Pile::run_device() {
         computed_ = true;
         return;
     }
-    std::vector<uint32_t> reads(pending_bounds_.size(), 0u);
-    if (rala_hip_set_bound_tuples(ctx_, reads.data(), pending_bounds_.data(), pending_bounds_.size(),
-                                  RALA_HIP_MEM_HOST) != RALA_HIP_OK) {
+    std::vector<uint64_t> tuples(pending_bounds_.size());      // {read 0, bound}
+    for (size_t k = 0; k < tuples.size(); ++k) tuples[k] = (uint64_t)pending_bounds_[k] << 32;
+    if (rala_hip_set_bound_tuples(ctx_, tuples.data(), tuples.size(), RALA_HIP_MEM_HOST) != RALA_HIP_OK) {
         die("run_device", ctx_);
     }
     const int rc = rala_hip_initialize(ctx_);

@@ -17,7 +17,7 @@ CONFIGS = {
     "c2": (100_000, 20_000_000, 2),
     "c3": (1_000_000, 200_000_000, 3),
     "c5": (4_000_000, 533_000_000, 5),
-    # C5's coverage regime (4 M x 10 kb / 533 Mb = 75x) at a size the oracle can hold: parity-test case
+    # C5's coverage regime (4 M x 10 kb / 533 Mb = 75x) at a size a CPU run can hold: parity-test case
     "c5x": (200_000, 26_650_000, 5),
 }
 

@@ -1,11 +1,12 @@
-"""GPU (one device): the multi-GPU decomposition of Graph::initialize, with the P ranks played
-one after the other in a single process (same C-ABI calls and re-indexing as rala_amd/multi.py,
-the collectives replaced by list shuffling), against the oracle."""
+"""GPU (one device): the sharded run (rala_hip_mg_*, rala_amd/csrc/sharded.hip) with its P ranks as
+host threads of this process, all on device 0, exchanging through the in-process transport
+(RALA_HIP_COMM_LOCAL) - the same collectives, kernels and orchestration as over RCCL, which refuses
+two ranks on one device.  Every rank's replicated result against the oracle, stage by stage; and
+the RCCL transport itself with a world of one."""
 import numpy as np
 import pytest
-import torch
 
-from rala_amd import hip, multi
+from rala_amd import hip
 from rala_amd.synth import Dataset
 
 import parity
@@ -13,196 +14,148 @@ import parity
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("world", [2, 3])
-@pytest.mark.parametrize("n,g,seed", [(1000, 200_000, 1), (2000, 1_200_000, 33)])
-def test_sharded_initialize_matches_oracle(hip_ctx_factory, world, n, g, seed):
-    ds = Dataset(n, g, seed)
-    st = parity.oracle_stages(ds)
-    ov = ds.overlaps
-    cuts = multi.slice_starts(ov.a_id, world)
-    dev = torch.device("cuda", 0)
-    sent = []           # sent[k] = (local_read, bound, counts) of rank k
-    valid_parts = []
-    for k in range(world):
-        sl = ov.take(slice(cuts[k], cuts[k + 1]))
-        assert cuts[k] == 0 or ov.a_id[cuts[k]] != ov.a_id[cuts[k] - 1]
-        cs = hip_ctx_factory()
-        cs.set_reads(ds.read_len)
-        cs.set_overlaps(sl)
-        cs.dedupe()
-        valid_parts.append(cs.valid())
-        t_r = torch.empty(4 * max(1, len(sl)), dtype=torch.int32, device=dev)
-        t_b = torch.empty_like(t_r)
-        cs.emit_bound_tuples(t_r.data_ptr(), t_b.data_ptr())
-        reads = t_r[: 4 * len(sl)].to(torch.int64) & 0xFFFFFFFF
-        bounds = t_b[: 4 * len(sl)].to(torch.int64) & 0xFFFFFFFF
-        sent.append(multi.owner_split(reads, bounds, world))
-    parts = {key: [] for key in ("begin", "end", "median", "p10", "alive")}
-    pc, pf, hc, hf = [], [], [], []
-    for k in range(world):
-        # what the all-to-all delivers to owner k
-        lr, bd = [], []
-        for src in range(world):
-            r, b, c = sent[src]
-            off = int(c[:k].sum())
-            lr.append(r[off: off + int(c[k])])
-            bd.append(b[off: off + int(c[k])])
-        lr = torch.cat(lr).to(torch.int32)
-        bd = torch.cat(bd).to(torch.int32)
-        cl = hip_ctx_factory()
-        cl.set_reads(np.ascontiguousarray(ds.read_len[k::world]))
-        cl.set_bound_tuples_device(lr.data_ptr(), bd.data_ptr(), lr.numel())
-        torch.cuda.synchronize()
-        cl.initialize()
-        p = cl.piles()
-        for key in parts:
-            parts[key].append(p[key])
-        pits, hills = cl.intervals(0), cl.intervals(1)
-        pc.append(np.diff(pits[0].astype(np.int64)))
-        pf.append(np.concatenate([pits[1].astype(np.int64), pits[2].astype(np.int64)[:, None]], axis=1).reshape(-1))
-        hc.append(np.diff(hills[0].astype(np.int64)))
-        hf.append(hills[1].astype(np.int64).reshape(-1))
-        # coverage of a few owned reads against the oracle
-        for r, want in list(st["data0"].items())[:40]:
-            if r % world == k:
-                parity.assert_same("pile_data[%d]" % r, cl.pile_data(r // world), want)
-    piles = {key: multi.interleave(parts[key], n, world) for key in parts}
-    p_off, p_flat = multi.merge_intervals(pc, pf, n, world, 3)
-    h_off, h_flat = multi.merge_intervals(hc, hf, n, world, 2)
-    valid = np.concatenate(valid_parts)
-    parity.assert_same("valid", valid, st["valid"])
-    for key in parts:
-        parity.assert_same("piles0." + key, piles[key], st["piles0"][key])
-    parity.assert_same("pits0.offsets", p_off, st["pits0"][0])
-    parity.assert_same("pits0.pairs", p_flat[:, :2], st["pits0"][1])
-    parity.assert_same("hills0.offsets", h_off, st["hills0"][0])
-    parity.assert_same("hills0.pairs", h_flat, st["hills0"][1])
-    cg = hip_ctx_factory()
-    cg.set_reads(ds.read_len)
-    cg.set_overlaps(ov)
-    cg.import_state(valid, piles, (p_off, p_flat[:, :2].astype(np.uint32), p_flat[:, 2].astype(np.uint32)),
-                    (h_off, h_flat.astype(np.uint32), None))
-    cg.construct()
-    parity.check_construct(cg, st)
-    parity.check_tr(cg, st)
+class Sharded:
+    """P ranks on one device; closes everything at the end of the test"""
+
+    def __init__(self, ds, world, device=0, token=None):
+        self.ds, self.world = ds, world
+        self.group = hip.LocalGroup(world) if token is None else None
+        self.ranks = []
+        ov = ds.overlaps
+        self.cuts = hip.slice_cuts(ov.a_id, world)
+        for k in range(world):
+            r = hip.ShardedRank(device, k, world, self.group if token is None else token)
+            self.ranks.append(r)
+            r.set_reads(ds.read_len)
+            r.set_overlaps(ov.take(slice(self.cuts[k], self.cuts[k + 1])), self.cuts[k])
+
+    def run(self, sens=None):
+        if sens is None:
+            return hip.run_ranks(self.ranks)
+        n = len(sens)
+        cut = [n * k // self.world for k in range(self.world + 1)]
+        return hip.run_ranks(self.ranks, [sens.take(slice(cut[k], cut[k + 1])) for k in range(self.world)])
+
+    def close(self):
+        for r in self.ranks:
+            r.close()
+        if self.group:
+            self.group.close()
 
 
-def simulate_sharded(hip_ctx_factory, ds, world, check_buckets=False):
-    """The path bench.py runs for WORLD_SIZE > 1 (ShardedRunner.step) with the ranks played one
-    after the other on one GPU: owner-grouped tuples straight from the kernel, packed per-read
-    state and interval pools "gathered" device to device, rala_hip_import_state_device.  Returns
-    the context that holds all reads and overlaps, state imported."""
-    ov = ds.overlaps
-    n = ds.n_reads
-    cuts = multi.slice_starts(ov.a_id, world)
-    dev = torch.device("cuda", 0)
-    sent, valid_parts = [], []
-    for k in range(world):
-        sl = ov.take(slice(cuts[k], cuts[k + 1]))
-        cs = hip_ctx_factory()
-        cs.set_reads(ds.read_len)
-        cs.set_overlaps(sl)
-        cs.dedupe()
-        t_r = torch.empty(4 * max(1, len(sl)), dtype=torch.int32, device=dev)
-        t_b = torch.empty_like(t_r)
-        counts = cs.emit_bound_tuples_bucketed(world, t_r.data_ptr(), t_b.data_ptr())
-        if check_buckets:
-            # the buckets hold exactly the tuples of the unbucketed emission
-            u_r, u_b = torch.empty_like(t_r), torch.empty_like(t_b)
-            cs.emit_bound_tuples(u_r.data_ptr(), u_b.data_ptr())
-            ur = u_r[: 4 * len(sl)].cpu().numpy().view(np.uint32).astype(np.int64)
-            ub = u_b[: 4 * len(sl)].cpu().numpy().view(np.uint32).astype(np.int64)
-            keep = ur != multi.NO_READ
-            off = 0
-            for p in range(world):
-                c = int(counts[p])
-                got = sorted(zip(t_r[off: off + c].cpu().numpy().view(np.uint32).tolist(),
-                                 t_b[off: off + c].cpu().numpy().view(np.uint32).tolist()))
-                m = keep & (ur % world == p)
-                assert got == sorted(zip((ur[m] // world).tolist(), ub[m].tolist()))
-                off += c
-        sent.append((t_r, t_b, counts))
-        v = torch.empty(max(1, len(sl)), dtype=torch.uint8, device=dev)
-        if len(sl):
-            cs.copy_device_state(valid=v.data_ptr())
-        valid_parts.append(v[: len(sl)])
-    nl = multi.padded_local(n, world)
-    off_f, total = multi.state_layout(nl)
-    rows = torch.zeros((world, total), dtype=torch.uint8, device=dev)
-    pools = []
-    for k in range(world):
-        lr, bd = [], []
-        for src in range(world):
-            r, b, c = sent[src]
-            o = int(c[:k].sum())
-            lr.append(r[o: o + int(c[k])])
-            bd.append(b[o: o + int(c[k])])
-        lr, bd = torch.cat(lr).contiguous(), torch.cat(bd).contiguous()
-        cl = hip_ctx_factory()
-        cl.set_reads(np.ascontiguousarray(ds.read_len[k::world]))
-        torch.cuda.synchronize()
-        cl.set_bound_tuples_device(lr.data_ptr(), bd.data_ptr(), lr.numel())
-        cl.initialize()
-        n_pool = int(cl.device_state().pool_count)
-        pool = torch.empty(max(1, n_pool * multi.POOL_RECORD), dtype=torch.uint8, device=dev)
-        cl.copy_device_state(pool=pool.data_ptr(), pool_count=n_pool,
-                             **{f: rows[k].data_ptr() + o for f, o in off_f.items()})
-        pools.append(pool[: n_pool * multi.POOL_RECORD])
-        cl.close()
-    counts = [p.numel() // multi.POOL_RECORD for p in pools]
-    state = multi.unpack_state(rows, nl, n, counts)
-    pool_all = torch.cat(pools)
-    valid = torch.cat(valid_parts)
-    torch.cuda.synchronize()
-    cg = hip_ctx_factory()
-    cg.set_reads(ds.read_len)
-    cg.set_overlaps(ov)
-    cg.import_state_device(pool=pool_all.data_ptr(), pool_count=sum(counts), valid=valid.data_ptr(),
-                           **{f: t.data_ptr() for f, t in state.items()})
-    return cg
+@pytest.fixture
+def sharded_factory():
+    made = []
+
+    def make(ds, world, **kw):
+        s = Sharded(ds, world, **kw)
+        made.append(s)
+        return s
+    yield make
+    for s in made:
+        s.close()
+
+
+def check_rank(ctx, st, n_tr):
+    """one rank's replicated result against the oracle's stages"""
+    hp = ctx.piles()
+    for k in ("alive", "begin", "end", "median"):
+        parity.assert_same("piles2." + k, hp[k], st["piles2"][k])
+    for which, key in ((0, "ov"), (1, "int")):
+        h, o = ctx.overlap_list(which), st[key]
+        parity.assert_same(key + ".src", h["src"], o["src"].astype(np.uint32))
+        for f in ("a_begin", "a_end", "b_begin", "b_end", "length", "type"):
+            parity.assert_same(key + "." + f, h[f], o[f])
+    g = ctx.graph()
+    parity.assert_same("nodes", g["node_read"], st["nodes"])
+    for f in ("src", "dst", "len", "marked"):
+        parity.assert_same("edges." + f, g[f], st["edges"][f])
+    assert n_tr == st["n_tr"]
 
 
 @pytest.mark.parametrize("world", [2, 3, 8])
-@pytest.mark.parametrize("n,g,seed", [(1000, 200_000, 1), (2000, 1_200_000, 33),
-                                      (1500, 12_000, 3)])      # ~750x: reads beyond a fixed event slot
-def test_sharded_device_path_matches_oracle(hip_ctx_factory, world, n, g, seed):
+@pytest.mark.parametrize("n,g,seed", [(1000, 200_000, 1), (2000, 1_200_000, 33), (3000, 600_000, 21), (600, 60_000, 9)])
+def test_sharded_run_matches_oracle(sharded_factory, world, n, g, seed):
     ds = Dataset(n, g, seed)
     st = parity.oracle_stages(ds)
-    cg = simulate_sharded(hip_ctx_factory, ds, world, check_buckets=True)
-    parity.assert_same("valid", cg.valid(), st["valid"])
-    p = cg.piles()
-    for key in ("begin", "end", "median", "p10", "alive"):
-        parity.assert_same("piles0." + key, p[key], st["piles0"][key])
-    pits, hills = cg.intervals(0), cg.intervals(1)
-    parity.assert_same("pits0.offsets", pits[0], st["pits0"][0])
-    parity.assert_same("pits0.pairs", pits[1], st["pits0"][1])
-    parity.assert_same("hills0.offsets", hills[0], st["hills0"][0])
-    parity.assert_same("hills0.pairs", hills[1], st["hills0"][1])
-    cg.construct()
-    parity.check_construct(cg, st)
-    parity.check_tr(cg, st)
+    sh = sharded_factory(ds, world)
+    n_tr = sh.run()
+    for r in sh.ranks:
+        check_rank(r.context(), st, n_tr)
+    # pits and hills as they stand after the run, hill counters included (summed over the slices)
+    o = st["oracle"]
+    ctx = sh.ranks[world - 1].context()
+    for kind in (0, 1):
+        offs, pairs, aux = ctx.intervals(kind)
+        want = o.all_intervals(kind)
+        parity.assert_same("intervals%d.offsets" % kind, offs, want[0])
+        parity.assert_same("intervals%d.pairs" % kind, pairs, want[1])
+    # the coverage of a read lives on its owner
+    for r, want in list(st["data0"].items())[:30]:
+        if st["piles2"]["alive"][r]:
+            got = sh.ranks[r % world].pile_data(r)
+            B, E = int(st["piles2"]["begin"][r]), int(st["piles2"]["end"][r])
+            exp = np.array(want, copy=True)
+            exp[:B] = 0
+            exp[E:] = 0
+            parity.assert_same("pile_data[%d]" % r, got, exp)
+    tm = sh.ranks[0].timings()
+    assert tm["total_ms"] > 0 and (world == 1 or tm["tuples_sent"] > 0)
+    # a second run on the same objects gives the same answer
+    assert sh.run() == n_tr
+    check_rank(sh.ranks[0].context(), st, n_tr)
 
 
-def test_sharded_runner_through_rccl_world1(tmp_path):
-    """bench.py's WORLD_SIZE > 1 runner (rala_amd/multi.py ShardedRunner: RCCL all-to-all and
-    all-gathers, device-to-device state import) launched through torch.distributed.run with one
-    rank: same transitive-pair count as the single-context path."""
-    import json
-    import os
-    import subprocess
-    import sys
+def test_sharded_unordered_runs_and_unresolved_names(sharded_factory):
+    """runs of equal queries with unresolved records inside them must not be cut (duplicate removal
+    is per run, graph.cpp:343-350): shuffled runs, duplicates, names that do not resolve"""
+    from rala_amd.synth import Overlaps
 
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, RALA_FORCE_SHARDED="1")
-    base = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--workload", "c2", "--steps", "1",
-            "--warmup", "1", "--no-cpu-baseline"]
-    single = subprocess.run(base, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=root)
-    assert single.returncode == 0, single.stderr.decode()[-2000:]
-    want = json.loads(single.stdout.decode().strip().splitlines()[-1])
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
-           "127.0.0.1", "--master-port", "29547"] + base[1:]
-    sharded = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=root, env=env)
-    assert sharded.returncode == 0, sharded.stderr.decode()[-2000:]
-    got = json.loads(sharded.stdout.decode().strip().splitlines()[-1])
-    assert got["config"]["transitive_pairs"] == want["config"]["transitive_pairs"] > 0
-    assert "exchange_ms" in got["stage_ms"] and "gather_ms" in got["stage_ms"]
+    ds = Dataset(1500, 300_000, 4)
+    ov = ds.overlaps
+    rng = np.random.default_rng(7)
+    # duplicate some records right behind their original, knock out some names
+    idx = np.sort(np.concatenate([np.arange(len(ov)), rng.choice(len(ov), size=len(ov) // 20, replace=False)]))
+    ov2 = ov.take(idx)
+    bad = rng.choice(len(ov2), size=len(ov2) // 50, replace=False)
+    a = ov2.a_id.copy(); b = ov2.b_id.copy()
+    a[bad[::2]] = hip.NO_READ
+    b[bad[1::2]] = hip.NO_READ
+    ov2 = Overlaps(a_id=a, b_id=b, a_begin=ov2.a_begin, a_end=ov2.a_end, b_begin=ov2.b_begin, b_end=ov2.b_end,
+                   length=ov2.length, strand=ov2.strand)
+
+    class DS:
+        pass
+    d = DS()
+    d.read_len, d.overlaps, d.n_reads = ds.read_len, ov2, ds.n_reads
+    st = parity.oracle_stages(d)
+    for world in (2, 5):
+        sh = sharded_factory(d, world)
+        # no cut inside a run, unresolved records skipped when looking for the run's query
+        for c in sh.cuts[1:-1]:
+            j = c
+            while j > 0 and a[j - 1] == hip.NO_READ:
+                j -= 1
+            assert c == len(a) or a[c] == hip.NO_READ or j == 0 or a[j - 1] != a[c]
+        n_tr = sh.run()
+        check_rank(sh.ranks[0].context(), st, n_tr)
+        v = np.concatenate([r.context().valid() for r in sh.ranks])
+        parity.assert_same("valid", v, st["valid"])
+
+
+def test_sharded_everything_filtered_is_the_same_error_everywhere(sharded_factory):
+    ds = Dataset(300, 3_000_000, 2, plants=0)     # 1x coverage, no planted stacks: no read has a valid region
+    sh = sharded_factory(ds, 3)
+    with pytest.raises(hip.RalaHipError) as e:
+        sh.run()
+    assert e.value.code == -4
+
+
+def test_sharded_run_through_rccl_world1(sharded_factory):
+    """the RCCL transport (librccl opened at run time): communicator, all-to-all, all-gather(v),
+    all-reduce with one rank - everything but a second GPU"""
+    ds = Dataset(2000, 400_000, 11)
+    st = parity.oracle_stages(ds)
+    sh = sharded_factory(ds, 1, token=hip.unique_id())
+    n_tr = sh.ranks[0].run()
+    check_rank(sh.ranks[0].context(), st, n_tr)
