@@ -194,6 +194,22 @@ struct ListBlocks {             // the ranks' packed survivor blocks inside one 
     uint32_t dst0[64], dst1[64];
     uint32_t world;
 };
+struct RankOffsets {
+    uint32_t v[64];
+};
+// shard_kernels.hip
+void launch_partition_tuples(const uint2* in, uint64_t n, uint32_t world, uint32_t pass, uint32_t* counters, uint2* out,
+                             hipStream_t s);
+void launch_localize_u32(const uint32_t* global, uint64_t n_local, uint32_t world, uint32_t rank, uint32_t* local, hipStream_t s);
+void launch_localize_u16(const uint16_t* global, uint64_t n_local, uint32_t world, uint32_t rank, uint16_t* local, hipStream_t s);
+void launch_localize_u8(const uint8_t* global, uint64_t n_local, uint32_t world, uint32_t rank, uint8_t* local, hipStream_t s);
+void launch_pack_median(const uint16_t* median, const uint16_t* p10, uint64_t n_local, uint64_t nl_pad, uint32_t* out, hipStream_t s);
+void launch_unpack_median(const uint32_t* all, uint32_t world, uint64_t nl_pad, uint64_t n_reads, uint16_t* median, uint16_t* p10,
+                          hipStream_t s);
+void launch_pack_rep(const uint8_t* n_rep, const uint32_t* rep_slot, uint64_t n_local, uint64_t nl_pad, uint64_t* out, hipStream_t s);
+void launch_unpack_rep(const uint64_t* all, uint32_t world, uint64_t nl_pad, uint64_t n_reads, const RankOffsets& pool_base,
+                       uint8_t* n_rep, uint32_t* rep_slot, hipStream_t s);
+void launch_pool_aux(Interval* pool, uint32_t n, uint32_t* dense, uint32_t mode, hipStream_t s);
 void launch_death_status(const uint32_t* count, uint32_t* status, hipStream_t s);
 void launch_hill_counts(const ReadState& rs, uint32_t n_reads, uint32_t* dense, uint32_t mode, hipStream_t s);
 void launch_unpack_lists(const uint8_t* blocks, const ListBlocks& lb, const Survivors& out, hipStream_t s);

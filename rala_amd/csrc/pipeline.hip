@@ -539,141 +539,296 @@ bool is_valid_overlap(rala_hip_ctx* ctx, uint32_t r, uint32_t x, uint32_t y) {
     return true;
 }
 
+int materialize_host(rala_hip_ctx* ctx);
+void build_graph(rala_hip_ctx* ctx);
+
 // Graph::preprocess(overlaps, sensitive path) (graph.cpp:882-1054).  Sensitive records:
 // a = query (original read, untrimmed coordinates), b = target (trimmed read of the -p run).
-int preprocess_repeats(rala_hip_ctx* ctx, const rala_hip_overlaps* sens, uint64_t n_sens) {
-    const uint64_t n = ctx->n_reads;
-    hipStream_t s = ctx->stream;
+//
+// cs holds all reads and the lists the chimera stage left (on the host); cl holds the piles.  On
+// one GPU they are the same context and comm is null.  In a sharded run cs holds this rank's
+// share of the sensitive overlaps and cl the reads this rank owns (local read j = read j * P +
+// rank): the target bounds travel to the owners in ONE all-to-all, the owners add the layers,
+// take the medians and - once the component medians are known everywhere - look for the repeat
+// hills; medians and hills are all-gathered, the hills' bridged flags all-reduced (max).
+int preprocess_repeats(rala_hip_ctx* cs, rala_hip_ctx* cl, Comm* comm, const rala_hip_overlaps* sens, uint64_t n_sens) {
+    rala_hip_ctx* ctx = cs;                               // error reporting (HIPCHECK / fail)
+    const bool sharded = comm != nullptr;
+    const uint32_t P = sharded ? comm->world() : 1u, me = sharded ? comm->rank() : 0u;
+    const uint64_t n = cs->n_reads;                       // all reads
+    const uint64_t nl = cl->n_reads;                      // the reads whose piles are here
+    const uint64_t nl_pad = ((n + P - 1) / P + 15) / 16 * 16;
+    hipStream_t s = cs->stream;
+    hipStream_t sl = cl->stream;
     Trace trc;
+    auto comm_fail = [&](const char* what) {
+        cs->err = std::string(what) + ": " + comm->error();
+        cs->stage_pending.clear();
+        cs->stage_used = 0;
+        return RALA_HIP_EDEVICE;
+    };
     if (n_sens >= 0x7FFFFFF0ull / 2) return fail(ctx, RALA_HIP_EINVAL, "too many sensitive overlaps");
     // the sensitive overlaps stay on the device from here on: columns as given (uploaded, or
     // adopted when the caller says they are device memory)
     OvlSoA so;
     {
-        const uint32_t* src[7] = {sens->a_id, sens->b_id, sens->a_begin, sens->a_end, sens->b_begin, sens->b_end, sens->length};
+        const uint32_t* src[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        const uint8_t* dev_strand = nullptr;
+        if (n_sens) {
+            src[0] = sens->a_id; src[1] = sens->b_id; src[2] = sens->a_begin; src[3] = sens->a_end;
+            src[4] = sens->b_begin; src[5] = sens->b_end; src[6] = sens->length;
+            dev_strand = sens->strand;
+        }
         const uint32_t* dev[7];
-        const uint8_t* dev_strand = sens->strand;
         for (int k = 0; k < 7; ++k) dev[k] = src[k];
-        if (!ctx->sens_in_device) {
+        if (!cs->sens_in_device) {
             for (int k = 0; k < 7; ++k) {
-                HIPCHECK(ctx->d_sens_col[k].ensure(n_sens));
-                HIPCHECK(hipMemcpyAsync(ctx->d_sens_col[k].p, src[k], n_sens * 4, hipMemcpyHostToDevice, s));
-                dev[k] = ctx->d_sens_col[k].p;
+                HIPCHECK(cs->d_sens_col[k].ensure(n_sens));
+                if (n_sens) HIPCHECK(hipMemcpyAsync(cs->d_sens_col[k].p, src[k], n_sens * 4, hipMemcpyHostToDevice, s));
+                dev[k] = cs->d_sens_col[k].p;
             }
-            HIPCHECK(ctx->d_sens_strand.ensure(n_sens));
-            HIPCHECK(hipMemcpyAsync(ctx->d_sens_strand.p, sens->strand, n_sens, hipMemcpyHostToDevice, s));
-            dev_strand = ctx->d_sens_strand.p;
+            HIPCHECK(cs->d_sens_strand.ensure(n_sens));
+            if (n_sens) HIPCHECK(hipMemcpyAsync(cs->d_sens_strand.p, sens->strand, n_sens, hipMemcpyHostToDevice, s));
+            dev_strand = cs->d_sens_strand.p;
         }
         so.a_id = dev[0]; so.b_id = dev[1]; so.a_begin = dev[2]; so.a_end = dev[3];
         so.b_begin = dev[4]; so.b_end = dev[5]; so.length = dev[6]; so.strand = dev_strand; so.n = n_sens; so.base = 0;
     }
     // current valid regions and liveness on the device (a host tail narrowed them on the host)
-    HIPCHECK(hipMemcpyAsync(ctx->d_begin.p, ctx->h_begin.data(), n * 4, hipMemcpyHostToDevice, s));
-    HIPCHECK(hipMemcpyAsync(ctx->d_end.p, ctx->h_end.data(), n * 4, hipMemcpyHostToDevice, s));
-    HIPCHECK(hipMemcpyAsync(ctx->d_alive.p, ctx->h_alive.data(), n, hipMemcpyHostToDevice, s));
-    // Overlap::transmute_ (overlap.cpp:84-114) + bounds of the targets, no +-15 (graph.cpp:929-933),
-    // bucketed by read: count -> scan -> scatter
-    for (int k = 0; k < 2; ++k) HIPCHECK(ctx->d_sens_tb[k].ensure(n_sens));
-    HIPCHECK(ctx->d_sens_tuples.ensure(2 * n_sens + 8));
-    HIPCHECK(ctx->d_ev.ensure(2 * n_sens + 8));
-    HIPCHECK(ctx->d_dataset_median.ensure(n));
-    HIPCHECK(ctx->d_n_rep.ensure(n));
-    HIPCHECK(ctx->d_rep_slot.ensure(n));
-    HIPCHECK(ctx->d_rep_pool.ensure(ctx->pool_cap));
-    HIPCHECK(hipMemsetAsync(ctx->d_n_rep.p, 0, n, s));
-    HIPCHECK(hipMemsetAsync(ctx->d_small.p + 6, 0, 8, s));          // [6] rep pool count [7] error
-    HIPCHECK(hipMemsetAsync(ctx->d_small.p + 2, 0, 4, s));          // [2] bad sensitive record
-    HIPCHECK(hipMemsetAsync(ctx->d_cursor.p, 0, (n + 1) * 4, s));
-    launch_sens_tuples(so, (uint32_t)n, ctx->d_begin.p, ctx->d_alive.p, ctx->d_sens_tb[0].p, ctx->d_sens_tb[1].p,
-                       ctx->d_sens_tuples.p, ctx->d_small.p + 2, s);
-    launch_count_tuples(ctx->d_sens_tuples.p, 2 * n_sens, (uint32_t)n, ctx->d_cursor.p, s);
-    launch_exclusive_scan(ctx->d_cursor.p, ctx->d_ev_off.p, n, ctx->d_scan_ws.p, s);
-    HIPCHECK(hipMemcpyAsync(ctx->d_cursor.p, ctx->d_ev_off.p, n * 4, hipMemcpyDeviceToDevice, s));
-    launch_scatter_tuples(ctx->d_sens_tuples.p, 2 * n_sens, (uint32_t)n, ctx->d_cursor.p, ctx->d_ev.p, s);
-    // the targets: reads that received bounds
-    std::vector<uint32_t> ev_off(n + 1);
+    HIPCHECK(hipMemcpyAsync(cs->d_begin.p, cs->h_begin.data(), n * 4, hipMemcpyHostToDevice, s));
+    HIPCHECK(hipMemcpyAsync(cs->d_end.p, cs->h_end.data(), n * 4, hipMemcpyHostToDevice, s));
+    HIPCHECK(hipMemcpyAsync(cs->d_alive.p, cs->h_alive.data(), n, hipMemcpyHostToDevice, s));
+    // Overlap::transmute_ (overlap.cpp:84-114) + bounds of the targets, no +-15 (graph.cpp:929-933)
+    for (int k = 0; k < 2; ++k) HIPCHECK(cs->d_sens_tb[k].ensure(n_sens));
+    HIPCHECK(cs->d_sens_tuples.ensure(2 * n_sens + 8));
+    HIPCHECK(cs->d_dataset_median.ensure(n));
+    HIPCHECK(cs->d_n_rep.ensure(n));
+    HIPCHECK(cs->d_rep_slot.ensure(n));
+    HIPCHECK(cs->d_rep_pool.ensure(cs->pool_cap));
+    HIPCHECK(hipMemsetAsync(cs->d_n_rep.p, 0, n, s));
+    HIPCHECK(hipMemsetAsync(cs->d_small.p + 6, 0, 8, s));           // [6] rep pool count [7] error
+    HIPCHECK(hipMemsetAsync(cs->d_small.p + 2, 0, 4, s));           // [2] bad sensitive record
+    launch_sens_tuples(so, (uint32_t)n, cs->d_begin.p, cs->d_alive.p, cs->d_sens_tb[0].p, cs->d_sens_tb[1].p,
+                       cs->d_sens_tuples.p, cs->d_small.p + 2, s);
+    const uint2* tuples = cs->d_sens_tuples.p;          // what the pile holder buckets: {its read, bound}
+    uint64_t n_tuples = 2 * n_sens;
+    if (sharded) {
+        // by owner of the target, ONE all-to-all
+        HIPCHECK(cs->d_owner_cnt.ensure(2 * 64));
+        HIPCHECK(cs->d_sens_part.ensure(2 * n_sens + 8));
+        uint32_t* cnt = cs->d_owner_cnt.p;
+        uint32_t* cur = cnt + 64;
+        HIPCHECK(hipMemsetAsync(cnt, 0, 2 * 64 * 4, s));
+        launch_partition_tuples(cs->d_sens_tuples.p, 2 * n_sens, P, 0, cnt, cs->d_sens_part.p, s);
+        uint32_t h[64];
+        HIPCHECK(hipMemcpyAsync(h, cnt, P * 4, hipMemcpyDeviceToHost, s));
+        HIPCHECK(stream_sync(cs, s));
+        uint32_t off[64];
+        std::vector<uint64_t> send_counts(P), matrix((size_t)P * P), recv_counts(P);
+        uint32_t acc = 0;
+        for (uint32_t p = 0; p < P; ++p) { off[p] = acc; acc += h[p]; send_counts[p] = h[p]; }
+        HIPCHECK(hipMemcpyAsync(cur, off, P * 4, hipMemcpyHostToDevice, s));
+        launch_partition_tuples(cs->d_sens_tuples.p, 2 * n_sens, P, 1, cur, cs->d_sens_part.p, s);
+        // a bad record anywhere is everybody's error
+        if (comm->all_reduce_u32(cs->d_small.p + 2, 1, ReduceOp::kMax, s) != 0) return comm_fail("all-reduce of the record check");
+        if (comm->host_all_gather(send_counts.data(), P, matrix.data(), s) != 0) return comm_fail("sensitive tuple counts");
+        n_tuples = 0;
+        for (uint32_t p = 0; p < P; ++p) { recv_counts[p] = matrix[(size_t)p * P + me]; n_tuples += recv_counts[p]; }
+        HIPCHECK(cs->d_sens_recv.ensure(n_tuples + 8));
+        if (comm->all_to_all_v(cs->d_sens_part.p, send_counts.data(), cs->d_sens_recv.p, recv_counts.data(), sizeof(uint2), s) != 0) {
+            return comm_fail("all-to-all of the sensitive bounds");
+        }
+        tuples = cs->d_sens_recv.p;
+        // the owner's copy of the current valid regions (the chimera stage narrowed them everywhere)
+        HIPCHECK(stream_sync(cs, s));
+        launch_localize_u32(cs->d_begin.p, nl, P, me, cl->d_begin.p, sl);
+        launch_localize_u32(cs->d_end.p, nl, P, me, cl->d_end.p, sl);
+        launch_localize_u8(cs->d_alive.p, nl, P, me, cl->d_alive.p, sl);
+    }
     uint32_t bad = 0;
-    HIPCHECK(hipMemcpyAsync(ev_off.data(), ctx->d_ev_off.p, (n + 1) * 4, hipMemcpyDeviceToHost, s));
-    HIPCHECK(d2h_small(ctx, &bad, ctx->d_small.p + 2, 4, s));
-    HIPCHECK(stream_sync(ctx, s));
+    HIPCHECK(d2h_small(cs, &bad, cs->d_small.p + 2, 4, s));
+    HIPCHECK(stream_sync(cs, s));
     HIPCHECK(hipGetLastError());
     if (bad & 1u) return fail(ctx, RALA_HIP_EINVAL, "sensitive overlap names must resolve");
     if (bad & 2u) return fail(ctx, RALA_HIP_EINVAL, "sensitive overlap targets a read that did not survive");
+    // bucketed by read on the pile holder: count -> scan -> scatter
+    HIPCHECK(cl->d_ev.ensure(n_tuples + 8));
+    HIPCHECK(cl->d_scan_ws.ensure(scan_workspace_bytes(std::max<uint64_t>(n_tuples, nl) + 2)));
+    HIPCHECK(cl->d_dataset_median.ensure(nl));
+    HIPCHECK(cl->d_n_rep.ensure(nl));
+    HIPCHECK(cl->d_rep_slot.ensure(nl));
+    HIPCHECK(cl->d_rep_pool.ensure(cl->pool_cap));
+    if (sharded) {
+        HIPCHECK(hipMemsetAsync(cl->d_n_rep.p, 0, nl, sl));
+        HIPCHECK(hipMemsetAsync(cl->d_small.p + 6, 0, 8, sl));
+    }
+    HIPCHECK(hipMemsetAsync(cl->d_cursor.p, 0, (nl + 1) * 4, sl));
+    launch_count_tuples(tuples, n_tuples, (uint32_t)nl, cl->d_cursor.p, sl);
+    launch_exclusive_scan(cl->d_cursor.p, cl->d_ev_off.p, nl, cl->d_scan_ws.p, sl);
+    HIPCHECK(hipMemcpyAsync(cl->d_cursor.p, cl->d_ev_off.p, nl * 4, hipMemcpyDeviceToDevice, sl));
+    launch_scatter_tuples(tuples, n_tuples, (uint32_t)nl, cl->d_cursor.p, cl->d_ev.p, sl);
+    // the targets: reads that received bounds
+    std::vector<uint32_t> ev_off(nl + 1);
+    HIPCHECK(hipMemcpyAsync(ev_off.data(), cl->d_ev_off.p, (nl + 1) * 4, hipMemcpyDeviceToHost, sl));
+    HIPCHECK(stream_sync(cl, sl));
+    HIPCHECK(hipGetLastError());
     std::vector<uint32_t> targets;
-    for (uint64_t r = 0; r < n; ++r) if (ev_off[r + 1] != ev_off[r]) targets.push_back((uint32_t)r);
+    for (uint64_t r = 0; r < nl; ++r) if (ev_off[r + 1] != ev_off[r]) targets.push_back((uint32_t)r);
     trc("rep: transmute + bucket", targets.size());
 
     RepeatArgs a;
-    a.read_len = ctx->d_read_len.p; a.pile_off = ctx->d_pile_off.p; a.pile = ctx->d_pile.p;
-    a.ev_off = ctx->d_ev_off.p; a.ev = ctx->d_ev.p;
-    a.begin = ctx->d_begin.p; a.end = ctx->d_end.p; a.median = ctx->d_median.p; a.p10 = ctx->d_p10.p;
-    a.dataset_median = ctx->d_dataset_median.p; a.n_rep = ctx->d_n_rep.p; a.rep_slot = ctx->d_rep_slot.p;
-    a.pool = ctx->d_rep_pool.p; a.pool_count = ctx->d_small.p + 6; a.pool_cap = ctx->pool_cap;
-    a.error = ctx->d_small.p + 7;
+    a.read_len = cl->d_read_len.p; a.pile_off = cl->d_pile_off.p; a.pile = cl->d_pile.p;
+    a.ev_off = cl->d_ev_off.p; a.ev = cl->d_ev.p;
+    a.begin = cl->d_begin.p; a.end = cl->d_end.p; a.median = cl->d_median.p; a.p10 = cl->d_p10.p;
+    a.dataset_median = cl->d_dataset_median.p; a.n_rep = cl->d_n_rep.p; a.rep_slot = cl->d_rep_slot.p;
+    a.pool = cl->d_rep_pool.p; a.pool_count = cl->d_small.p + 6; a.pool_cap = cl->pool_cap;
+    a.error = cl->d_small.p + 7;
     a.order = nullptr; a.n_items = 0; a.lw = 0; a.slab = nullptr;
     // add_layers on top of the coverage + find_median for the targets (graph.cpp:941-969)
-    int rc = run_repeats_kernel(ctx, a, targets, 1);
-    if (rc != RALA_HIP_OK) return rc;
-    HIPCHECK(hipMemcpy(ctx->h_median.data(), ctx->d_median.p, n * 2, hipMemcpyDeviceToHost));
-    HIPCHECK(hipMemcpy(ctx->h_p10.data(), ctx->d_p10.p, n * 2, hipMemcpyDeviceToHost));
+    int rc = run_repeats_kernel(cl, a, targets, 1);
+    if (rc != RALA_HIP_OK) { if (cl != cs) cs->err = cl->err; return rc; }
+    if (sharded) {
+        // the new medians, everywhere
+        HIPCHECK(cs->d_gather[0].ensure(nl_pad * 4 + 16));
+        HIPCHECK(cs->d_gather[1].ensure(nl_pad * 4 * P + 16));
+        launch_pack_median(cl->d_median.p, cl->d_p10.p, nl, nl_pad, (uint32_t*)cs->d_gather[0].p, s);
+        if (comm->all_gather(cs->d_gather[0].p, cs->d_gather[1].p, nl_pad * 4, s) != 0) return comm_fail("all-gather of the medians");
+        launch_unpack_median((const uint32_t*)cs->d_gather[1].p, P, nl_pad, n, cs->d_median.p, cs->d_p10.p, s);
+    }
+    HIPCHECK(hipMemcpyAsync(cs->h_median.data(), cs->d_median.p, n * 2, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipMemcpyAsync(cs->h_p10.data(), cs->d_p10.p, n * 2, hipMemcpyDeviceToHost, s));
+    HIPCHECK(stream_sync(cs, s));
     trc("rep: add_layers + median", targets.size());
     // first trim of the sensitive overlaps (graph.cpp:935-939)
     SensCoords sc;
-    for (int k = 0; k < 5; ++k) HIPCHECK(ctx->d_sens_c[k].ensure(n_sens));
-    HIPCHECK(ctx->d_sens_state.ensure(n_sens));
-    sc.a_begin = ctx->d_sens_c[0].p; sc.a_end = ctx->d_sens_c[1].p; sc.b_begin = ctx->d_sens_c[2].p;
-    sc.b_end = ctx->d_sens_c[3].p; sc.length = ctx->d_sens_c[4].p; sc.state = ctx->d_sens_state.p;
-    launch_sens_trim(so, ctx->d_sens_tb[0].p, ctx->d_sens_tb[1].p, ctx->d_begin.p, ctx->d_end.p, ctx->d_alive.p, sc, s);
+    for (int k = 0; k < 5; ++k) HIPCHECK(cs->d_sens_c[k].ensure(n_sens));
+    HIPCHECK(cs->d_sens_state.ensure(n_sens));
+    sc.a_begin = cs->d_sens_c[0].p; sc.a_end = cs->d_sens_c[1].p; sc.b_begin = cs->d_sens_c[2].p;
+    sc.b_end = cs->d_sens_c[3].p; sc.length = cs->d_sens_c[4].p; sc.state = cs->d_sens_state.p;
+    launch_sens_trim(so, cs->d_sens_tb[0].p, cs->d_sens_tb[1].p, cs->d_begin.p, cs->d_end.p, cs->d_alive.p, sc, s);
     trc("rep: first trim", n_sens);
     // component medians over the primary overlaps -> repeat hills (graph.cpp:971-1026)
     std::vector<uint32_t> members;
     std::vector<uint16_t> med;
-    rc = component_medians(ctx, members, med);
+    rc = component_medians(cs, members, med);
     if (rc != RALA_HIP_OK) return rc;
     {
         std::vector<uint16_t> dm(n, 0);
         for (size_t k = 0; k < members.size(); ++k) dm[members[k]] = med[k];
-        HIPCHECK(hipMemcpy(ctx->d_dataset_median.p, dm.data(), n * 2, hipMemcpyHostToDevice));
+        HIPCHECK(hipMemcpy(cs->d_dataset_median.p, dm.data(), n * 2, hipMemcpyHostToDevice));
     }
     trc("rep: component medians", members.size());
-    rc = run_repeats_kernel(ctx, a, members, 2);
-    if (rc != RALA_HIP_OK) return rc;
+    if (!sharded) {
+        rc = run_repeats_kernel(cl, a, members, 2);
+        if (rc != RALA_HIP_OK) return rc;
+    } else {
+        launch_localize_u16(cs->d_dataset_median.p, nl, P, me, cl->d_dataset_median.p, sl);
+        std::vector<uint32_t> mine;
+        for (uint32_t r : members) if (r % P == me) mine.push_back(r / P);
+        rc = run_repeats_kernel(cl, a, mine, 2);
+        if (rc != RALA_HIP_OK) { cs->err = cl->err; return rc; }
+    }
     uint32_t small[8];
-    HIPCHECK(hipMemcpy(small, ctx->d_small.p, sizeof(small), hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(small, cl->d_small.p, sizeof(small), hipMemcpyDeviceToHost));
+    uint32_t n_hills = small[6];
+    if (sharded) {
+        // capacity errors are everybody's; then the hills of all owners, slots rebased onto the
+        // concatenation of their pools
+        HIPCHECK(hipMemcpyAsync(cs->d_small.p + 7, &small[7], 4, hipMemcpyHostToDevice, s));
+        if (comm->all_reduce_u32(cs->d_small.p + 7, 1, ReduceOp::kMax, s) != 0) return comm_fail("all-reduce of the kernel status");
+        HIPCHECK(d2h_small(cs, &small[7], cs->d_small.p + 7, 4, s));
+        HIPCHECK(stream_sync(cs, s));
+    }
     if (small[7] & kErrRegionCapacity) return fail(ctx, RALA_HIP_ECAPACITY, "slope-region list overflow (repeat hills)");
     if (small[7] & kErrPoolCapacity) return fail(ctx, RALA_HIP_ECAPACITY, "repeat-hill pool exhausted");
-    trc("rep: repeat hills kernel", small[6]);
+    if (sharded) {
+        const uint64_t mine = std::min<uint32_t>(small[6], cl->pool_cap);
+        std::vector<uint64_t> counts(P);
+        if (comm->host_all_gather(&mine, 1, counts.data(), s) != 0) return comm_fail("repeat-hill counts");
+        RankOffsets base;
+        uint64_t total = 0;
+        for (uint32_t p = 0; p < P; ++p) { base.v[p] = (uint32_t)total; total += counts[p]; }
+        HIPCHECK(cs->d_rep_pool.ensure(total + 1));
+        HIPCHECK(cs->d_gather[0].ensure(nl_pad * 8 + 16));
+        HIPCHECK(cs->d_gather[1].ensure(nl_pad * 8 * P + 16));
+        launch_pack_rep(cl->d_n_rep.p, cl->d_rep_slot.p, nl, nl_pad, (uint64_t*)cs->d_gather[0].p, s);
+        if (comm->all_gather(cs->d_gather[0].p, cs->d_gather[1].p, nl_pad * 8, s) != 0) return comm_fail("all-gather of the repeat hills");
+        launch_unpack_rep((const uint64_t*)cs->d_gather[1].p, P, nl_pad, n, base, cs->d_n_rep.p, cs->d_rep_slot.p, s);
+        if (comm->all_gather_v(cl->d_rep_pool.p, cs->d_rep_pool.p, counts.data(), sizeof(Interval), s) != 0) {
+            return comm_fail("all-gather of the repeat-hill pools");
+        }
+        n_hills = (uint32_t)total;
+    }
+    trc("rep: repeat hills kernel", n_hills);
     // sensitive dovetails mark the hills they bridge (graph.cpp:1028-1043)
-    launch_sens_bridge(so, sc, ctx->d_begin.p, ctx->d_end.p, ctx->d_alive.p, ctx->d_n_rep.p, ctx->d_rep_slot.p,
-                       ctx->d_rep_pool.p, s);
-    HIPCHECK(stream_sync(ctx, s));
+    launch_sens_bridge(so, sc, cs->d_begin.p, cs->d_end.p, cs->d_alive.p, cs->d_n_rep.p, cs->d_rep_slot.p,
+                       cs->d_rep_pool.p, s);
+    if (sharded && n_hills) {
+        HIPCHECK(cs->d_t_tmp[0].ensure(std::max<size_t>(n_hills, n) + 2));
+        launch_pool_aux(cs->d_rep_pool.p, n_hills, cs->d_t_tmp[0].p, 0, s);
+        if (comm->all_reduce_u32(cs->d_t_tmp[0].p, n_hills, ReduceOp::kMax, s) != 0) return comm_fail("all-reduce of the bridged flags");
+        launch_pool_aux(cs->d_rep_pool.p, n_hills, cs->d_t_tmp[0].p, 1, s);
+    }
+    HIPCHECK(stream_sync(cs, s));
     HIPCHECK(hipGetLastError());
     trc("rep: bridged hills", n_sens);
-    ctx->h_n_rep.resize(n); ctx->h_rep_slot.resize(n);
-    HIPCHECK(hipMemcpy(ctx->h_n_rep.data(), ctx->d_n_rep.p, n, hipMemcpyDeviceToHost));
-    HIPCHECK(hipMemcpy(ctx->h_rep_slot.data(), ctx->d_rep_slot.p, n * 4, hipMemcpyDeviceToHost));
-    ctx->h_rep_pool.resize(small[6]);
-    if (small[6]) {
-        HIPCHECK(hipMemcpy(ctx->h_rep_pool.data(), ctx->d_rep_pool.p, (size_t)small[6] * sizeof(Interval),
+    cs->h_n_rep.resize(n); cs->h_rep_slot.resize(n);
+    HIPCHECK(hipMemcpy(cs->h_n_rep.data(), cs->d_n_rep.p, n, hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(cs->h_rep_slot.data(), cs->d_rep_slot.p, n * 4, hipMemcpyDeviceToHost));
+    cs->h_rep_pool.resize(n_hills);
+    if (n_hills) {
+        HIPCHECK(hipMemcpy(cs->h_rep_pool.data(), cs->d_rep_pool.p, (size_t)n_hills * sizeof(Interval),
                            hipMemcpyDeviceToHost));
     }
-    trc("rep: download hills", small[6]);
+    trc("rep: download hills", n_hills);
     // overlaps that end inside a bridged edge hill are dropped (graph.cpp:1045-1051)
     {
         size_t w = 0;
-        for (size_t k = 0; k < ctx->overlaps.size(); ++k) {
-            const HostOvl& o = ctx->overlaps[k];
-            if (!is_valid_overlap(ctx, o.a, o.c.a_begin, o.c.a_end) ||
-                !is_valid_overlap(ctx, o.b, o.c.b_begin, o.c.b_end)) {
+        for (size_t k = 0; k < cs->overlaps.size(); ++k) {
+            const HostOvl& o = cs->overlaps[k];
+            if (!is_valid_overlap(cs, o.a, o.c.a_begin, o.c.a_end) ||
+                !is_valid_overlap(cs, o.b, o.c.b_begin, o.c.b_end)) {
                 continue;
             }
-            if (w != k) ctx->overlaps[w] = ctx->overlaps[k];
+            if (w != k) cs->overlaps[w] = cs->overlaps[k];
             ++w;
         }
-        ctx->overlaps.resize(w);
+        cs->overlaps.resize(w);
     }
-    trc("rep: filter overlaps", ctx->overlaps.size());
-    ctx->have_repeats = true;
+    trc("rep: filter overlaps", cs->overlaps.size());
+    cs->have_repeats = true;
+    return RALA_HIP_OK;
+}
+
+// the sensitive pass behind a device-resident chimera stage: lists to the host, repeats, graph
+int repeats_after_tail(rala_hip_ctx* cs, rala_hip_ctx* cl, Comm* comm, const rala_hip_overlaps* sens, uint64_t n_sens) {
+    rala_hip_ctx* ctx = cs;
+    hipStream_t s = cs->stream;
+    const uint32_t n_reads = (uint32_t)cs->n_reads;
+    Trace trs;
+    const int rc6 = materialize_host(cs);
+    if (rc6 != RALA_HIP_OK) return rc6;
+    trs("sens: materialize_host");
+    cs->tail_on_device = false;
+    cs->host_stale = false;
+    // rank space of the component search: the reads that are still there
+    cs->alive_rank.assign(n_reads, 0xFFFFFFFFu);
+    cs->alive_reads.clear();
+    for (uint32_t r = 0; r < n_reads; ++r) {
+        if (!cs->h_alive[r]) continue;
+        cs->alive_rank[r] = (uint32_t)cs->alive_reads.size();
+        cs->alive_reads.push_back(r);
+    }
+    trs("sens: alive ranks");
+    const int rc3 = preprocess_repeats(cs, cl, comm, sens, n_sens);
+    if (rc3 != RALA_HIP_OK) return rc3;
+    trs("sens: preprocess_repeats");
+    build_graph(cs);
+    trs("sens: build_graph");
+    HIPCHECK(hipMemcpyAsync(cs->d_begin.p, cs->h_begin.data(), (size_t)n_reads * 4, hipMemcpyHostToDevice, s));
+    HIPCHECK(hipMemcpyAsync(cs->d_end.p, cs->h_end.data(), (size_t)n_reads * 4, hipMemcpyHostToDevice, s));
+    HIPCHECK(hipMemcpyAsync(cs->d_alive.p, cs->h_alive.data(), (size_t)n_reads, hipMemcpyHostToDevice, s));
+    HIPCHECK(stream_sync(cs, s));
     return RALA_HIP_OK;
 }
 
@@ -1222,6 +1377,16 @@ int rala_hip::construct_stages(rala_hip_ctx* ctx, Comm* comm) {
     ctx->tm.tail_host_ms = (float)(now_ms() - t0);
     ctx->constructed = true;
     return RALA_HIP_OK;
+}
+
+int rala_hip::repeats_stage(rala_hip_ctx* cs, rala_hip_ctx* cl, Comm* comm, const rala_hip_overlaps* sens, uint64_t n_sens) {
+    if (!cs || !cl) return RALA_HIP_EINVAL;
+    if (!cs->constructed || !cs->tail_on_device) return fail(cs, RALA_HIP_EINVAL, "construct_stages must have run");
+    if (!cl->piles_resident) return fail(cs, RALA_HIP_EINVAL, "the sensitive pass needs the piles on the owner context");
+    const double t0 = now_ms();
+    const int rc = repeats_after_tail(cs, cl, comm, sens, n_sens);
+    cs->tm.tail_host_ms += (float)(now_ms() - t0);
+    return rc;
 }
 
 int rala_hip::install_read_state(rala_hip_ctx* ctx, uint64_t pool_count) {
@@ -1813,30 +1978,8 @@ int rala_hip_construct(rala_hip_ctx* ctx, const rala_hip_overlaps* sens, uint64_
             // Graph::preprocess(sensitive overlaps) (graph.cpp:882-1054) works on the lists the
             // chimera stage leaves: bring them to the host, annotate repeats (kernels + host
             // orchestration), rebuild the graph from what is left
-            Trace trs;
-            const int rc6 = materialize_host(ctx);
+            const int rc6 = repeats_after_tail(ctx, ctx, nullptr, sens, n_sens);
             if (rc6 != RALA_HIP_OK) return rc6;
-            trs("sens: materialize_host");
-            ctx->tail_on_device = false;
-            ctx->host_stale = false;
-            // rank space of the component search: the reads that are still there
-            ctx->alive_rank.assign(n_reads, 0xFFFFFFFFu);
-            ctx->alive_reads.clear();
-            for (uint32_t r = 0; r < n_reads; ++r) {
-                if (!ctx->h_alive[r]) continue;
-                ctx->alive_rank[r] = (uint32_t)ctx->alive_reads.size();
-                ctx->alive_reads.push_back(r);
-            }
-            trs("sens: alive ranks");
-            const int rc3 = preprocess_repeats(ctx, sens, n_sens);
-            if (rc3 != RALA_HIP_OK) return rc3;
-            trs("sens: preprocess_repeats");
-            build_graph(ctx);
-            trs("sens: build_graph");
-            HIPCHECK(hipMemcpyAsync(ctx->d_begin.p, ctx->h_begin.data(), (size_t)n_reads * 4, hipMemcpyHostToDevice, s));
-            HIPCHECK(hipMemcpyAsync(ctx->d_end.p, ctx->h_end.data(), (size_t)n_reads * 4, hipMemcpyHostToDevice, s));
-            HIPCHECK(hipMemcpyAsync(ctx->d_alive.p, ctx->h_alive.data(), (size_t)n_reads, hipMemcpyHostToDevice, s));
-            HIPCHECK(stream_sync(ctx, s));
         }
         ctx->tm.tail_host_ms = (float)(now_ms() - t0);
         ctx->constructed = true;
@@ -1890,7 +2033,7 @@ int rala_hip_construct(rala_hip_ctx* ctx, const rala_hip_overlaps* sens, uint64_
         if (rc4 != RALA_HIP_OK) return rc4;
     }
     if (sens != nullptr && n_sens != 0) {
-        const int rc3 = preprocess_repeats(ctx, sens, n_sens);
+        const int rc3 = preprocess_repeats(ctx, ctx, nullptr, sens, n_sens);
         if (rc3 != RALA_HIP_OK) return rc3;
     }
     trc("preprocess total");
@@ -1904,6 +2047,54 @@ int rala_hip_construct(rala_hip_ctx* ctx, const rala_hip_overlaps* sens, uint64_
     HIPCHECK(hipMemcpyAsync(ctx->d_alive.p, ctx->h_alive.data(), (size_t)n_reads, hipMemcpyHostToDevice, s));
     HIPCHECK(stream_sync(ctx, s));
     ctx->constructed = true;
+    return RALA_HIP_OK;
+}
+
+int rala_hip_find_repetitive_hills(rala_hip_ctx* ctx, uint64_t read, uint16_t dataset_median) {
+    if (!ctx) return RALA_HIP_EINVAL;
+    if (!ctx->initialized || read >= ctx->n_reads) return fail(ctx, RALA_HIP_EINVAL, "bad read / not initialized");
+    if (!ctx->piles_resident) return fail(ctx, RALA_HIP_EINVAL, "the piles live on another context");
+    HIPCHECK(hipSetDevice(ctx->device));
+    { const int rcm = materialize_host(ctx); if (rcm != RALA_HIP_OK) return rcm; }
+    if (!ctx->h_alive[read]) return fail(ctx, RALA_HIP_EINVAL, "the read was filtered");
+    const uint64_t n = ctx->n_reads;
+    hipStream_t s = ctx->stream;
+    HIPCHECK(ctx->d_dataset_median.ensure(n));
+    HIPCHECK(ctx->d_n_rep.ensure(n));
+    HIPCHECK(ctx->d_rep_slot.ensure(n));
+    HIPCHECK(ctx->d_rep_pool.ensure(ctx->pool_cap));
+    if (!ctx->have_repeats) {
+        HIPCHECK(hipMemsetAsync(ctx->d_n_rep.p, 0, n, s));
+        HIPCHECK(hipMemsetAsync(ctx->d_small.p + 6, 0, 8, s));
+        ctx->h_n_rep.assign(n, 0); ctx->h_rep_slot.assign(n, 0); ctx->h_rep_pool.clear();
+    }
+    // the valid region as it stands (the host mirrors are authoritative after a host tail)
+    HIPCHECK(hipMemcpyAsync(ctx->d_begin.p + read, &ctx->h_begin[read], 4, hipMemcpyHostToDevice, s));
+    HIPCHECK(hipMemcpyAsync(ctx->d_end.p + read, &ctx->h_end[read], 4, hipMemcpyHostToDevice, s));
+    HIPCHECK(hipMemcpyAsync(ctx->d_dataset_median.p + read, &dataset_median, 2, hipMemcpyHostToDevice, s));
+    HIPCHECK(hipMemsetAsync(ctx->d_small.p + 7, 0, 4, s));
+    HIPCHECK(stream_sync(ctx, s));
+    RepeatArgs a;
+    a.read_len = ctx->d_read_len.p; a.pile_off = ctx->d_pile_off.p; a.pile = ctx->d_pile.p;
+    a.ev_off = ctx->d_ev_off.p; a.ev = ctx->d_ev.p;
+    a.begin = ctx->d_begin.p; a.end = ctx->d_end.p; a.median = ctx->d_median.p; a.p10 = ctx->d_p10.p;
+    a.dataset_median = ctx->d_dataset_median.p; a.n_rep = ctx->d_n_rep.p; a.rep_slot = ctx->d_rep_slot.p;
+    a.pool = ctx->d_rep_pool.p; a.pool_count = ctx->d_small.p + 6; a.pool_cap = ctx->pool_cap;
+    a.error = ctx->d_small.p + 7;
+    a.order = nullptr; a.n_items = 0; a.lw = 0; a.slab = nullptr;
+    const std::vector<uint32_t> one(1, (uint32_t)read);
+    const int rc = run_repeats_kernel(ctx, a, one, 2);
+    if (rc != RALA_HIP_OK) return rc;
+    uint32_t small[8];
+    HIPCHECK(hipMemcpy(small, ctx->d_small.p, sizeof(small), hipMemcpyDeviceToHost));
+    if (small[7] & kErrRegionCapacity) return fail(ctx, RALA_HIP_ECAPACITY, "slope-region list overflow (repeat hills)");
+    if (small[7] & kErrPoolCapacity) return fail(ctx, RALA_HIP_ECAPACITY, "repeat-hill pool exhausted");
+    ctx->h_n_rep.resize(n); ctx->h_rep_slot.resize(n);
+    HIPCHECK(hipMemcpy(&ctx->h_n_rep[read], ctx->d_n_rep.p + read, 1, hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(&ctx->h_rep_slot[read], ctx->d_rep_slot.p + read, 4, hipMemcpyDeviceToHost));
+    ctx->h_rep_pool.resize(small[6]);
+    if (small[6]) HIPCHECK(hipMemcpy(ctx->h_rep_pool.data(), ctx->d_rep_pool.p, (size_t)small[6] * sizeof(Interval), hipMemcpyDeviceToHost));
+    ctx->have_repeats = true;
     return RALA_HIP_OK;
 }
 

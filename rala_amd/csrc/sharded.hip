@@ -361,12 +361,19 @@ int rala_hip_mg_slice_cuts(const uint32_t* a_id, uint64_t n, uint32_t world, uin
 int rala_hip_mg_run(rala_hip_mg* mg, const rala_hip_overlaps* sens_slice, uint64_t n_sens, uint32_t* n_pairs) {
     if (!mg || !n_pairs) return RALA_HIP_EINVAL;
     if (!mg->have_reads || !mg->have_overlaps) return mg_fail(mg, RALA_HIP_EINVAL, "set reads and overlaps first");
-    if (sens_slice != nullptr && n_sens != 0) return mg_fail(mg, RALA_HIP_EINVAL, "sensitive overlaps: not wired into the sharded run yet");
     MGCHECK(hipSetDevice(mg->device));
     mg->tm = rala_hip_mg_timings();
     const double t0 = now_ms();
     int rc = run_primary(mg);
     if (rc != RALA_HIP_OK) return rc;
+    if (sens_slice != nullptr) {
+        // collective: a rank whose share is empty still takes part (every rank passes a non-null pointer or none does)
+        const double t2 = now_ms();
+        rc = repeats_stage(mg->cs, mg->cl, mg->comm, sens_slice, n_sens);
+        rc = agree(mg, from_ctx(mg, mg->cs, rc, "sensitive pass"), "sensitive pass");
+        if (rc != RALA_HIP_OK) return rc;
+        mg->tm.repeats_ms = (float)(now_ms() - t2);
+    }
     const double t1 = now_ms();
     rc = from_ctx(mg, mg->cs, rala_hip_remove_transitive_edges(mg->cs, n_pairs), "remove_transitive_edges");
     if (rc != RALA_HIP_OK) return rc;

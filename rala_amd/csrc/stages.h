@@ -17,6 +17,11 @@ namespace rala_hip {
 //   preprocess tail + graph on the survivors                 replicated
 int construct_stages(rala_hip_ctx* ctx, Comm* comm);
 
+// Graph::preprocess with the sensitive overlaps (graph.cpp:882-1054) behind construct_stages:
+// cs = the context construct_stages ran on, with this rank's share of the sensitive overlaps;
+// cl = the context that holds the piles (the same one on a single GPU, comm = null)
+int repeats_stage(rala_hip_ctx* cs, rala_hip_ctx* cl, Comm* comm, const rala_hip_overlaps* sens, uint64_t n_sens);
+
 // install per-read state that was computed elsewhere and already sits in ctx's device arrays
 // (d_begin .. d_iv_slot, d_pool[0 .. pool_count)); validity bits of ctx's own overlaps must be
 // there too (rala_hip_dedupe).  Counts the filtered reads.

@@ -27,7 +27,7 @@ SYMBOLS = (
     "rala_hip_get_graph", "rala_hip_get_timings", "rala_hip_get_num_prefiltered",
     "rala_hip_dedupe", "rala_hip_emit_bound_tuples", "rala_hip_set_bound_tuples", "rala_hip_import_state",
     "rala_hip_emit_bound_tuples_bucketed", "rala_hip_get_device_state", "rala_hip_import_state_device",
-    "rala_hip_copy_device_state", "rala_hip_layout",
+    "rala_hip_copy_device_state", "rala_hip_layout", "rala_hip_find_repetitive_hills",
     "rala_hip_mg_unique_id", "rala_hip_mg_local_group_create", "rala_hip_mg_local_group_destroy", "rala_hip_mg_create",
     "rala_hip_mg_destroy", "rala_hip_mg_last_error", "rala_hip_mg_set_reads", "rala_hip_mg_slice_cuts",
     "rala_hip_mg_set_overlaps", "rala_hip_mg_run", "rala_hip_mg_run_threads", "rala_hip_mg_context",
@@ -112,6 +112,7 @@ def lib(build=True):
         L.rala_hip_import_state_device.argtypes = [vp, ctypes.POINTER(DeviceState)]
         L.rala_hip_copy_device_state.argtypes = [vp, ctypes.POINTER(DeviceState)]
         L.rala_hip_layout.argtypes = [vp, u32, vp, vp, vp, vp, u32, ctypes.c_double, ctypes.c_double, ctypes.c_double]
+        L.rala_hip_find_repetitive_hills.argtypes = [vp, u64, ctypes.c_uint16]
         L.rala_hip_mg_unique_id.argtypes = [vp]
         L.rala_hip_mg_local_group_create.argtypes = [u32, ctypes.POINTER(vp)]
         L.rala_hip_mg_local_group_destroy.argtypes = [vp]
@@ -288,6 +289,9 @@ class Context:
             self._check(self.L.rala_hip_construct(self.h, ctypes.byref(c), len(sens)))
         else:
             self._check(self.L.rala_hip_construct(self.h, None, 0))
+
+    def find_repetitive_hills(self, read, dataset_median):
+        self._check(self.L.rala_hip_find_repetitive_hills(self.h, int(read), int(dataset_median)))
 
     def remove_transitive_edges(self):
         n = ctypes.c_uint32(0)

@@ -144,7 +144,7 @@ def test_sharded_unordered_runs_and_unresolved_names(sharded_factory):
 
 
 def test_sharded_everything_filtered_is_the_same_error_everywhere(sharded_factory):
-    ds = Dataset(300, 3_000_000, 2, plants=0)     # 1x coverage, no planted stacks: no read has a valid region
+    ds = Dataset(300, 30_000_000, 2, plants=0)    # 0.1x coverage, no planted stacks: no read has a valid region
     sh = sharded_factory(ds, 3)
     with pytest.raises(hip.RalaHipError) as e:
         sh.run()
@@ -159,3 +159,50 @@ def test_sharded_run_through_rccl_world1(sharded_factory):
     sh = sharded_factory(ds, 1, token=hip.unique_id())
     n_tr = sh.ranks[0].run()
     check_rank(sh.ranks[0].context(), st, n_tr)
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+@pytest.mark.parametrize("n,g,seed", [(5000, 1_000_000, 7), (6000, 1_600_000, 19)])
+def test_sharded_sensitive_pass_matches_oracle(sharded_factory, world, n, g, seed):
+    """Graph::preprocess with the sensitive overlaps (-s, reference graph.cpp:882-1054) in a sharded
+    run: every rank holds a share of the sensitive overlaps, the target bounds go to the read
+    owners in one all-to-all, medians and repeat hills come back by all-gather, bridged flags
+    by all-reduce.  Every rank's result against the oracle."""
+    from oracle.oracle import Oracle
+
+    ds = Dataset(n, g, seed)
+    o = Oracle(ds.read_len, ds.overlaps, n_threads=8)
+    assert o.initialize() == 0
+    o.pass2()
+    o.preprocess_chimeras()
+    p = o.piles()
+    sens = ds.sensitive(p["alive"], p["begin"], p["end"])
+    o.preprocess_repeats(sens)
+    want_rep = o.all_intervals(2)
+    want_flags = np.concatenate([o.repeat_flags(r) for r in range(n)])
+    want_ov = o.overlap_list(0)
+    want_p = o.piles()
+    o.build_graph()
+    want_tr = o.remove_transitive_edges()
+    want_e = o.edges()
+
+    sh = sharded_factory(ds, world)
+    assert sh.run(sens) == want_tr
+    for r in sh.ranks:
+        ctx = r.context()
+        offs, pairs, flags = ctx.intervals(2)
+        parity.assert_same("rep.offsets", offs, want_rep[0])
+        parity.assert_same("rep.pairs", pairs, want_rep[1])
+        parity.assert_same("rep.flags", flags.astype(np.uint8), want_flags)
+        hp = ctx.piles()
+        for k in ("alive", "begin", "end", "median", "p10"):
+            parity.assert_same("piles." + k, hp[k], want_p[k])
+        h = ctx.overlap_list(0)
+        parity.assert_same("ov.src", h["src"], want_ov["src"].astype(np.uint32))
+        gr = ctx.graph()
+        for k in ("src", "dst", "len", "marked"):
+            parity.assert_same("edges." + k, gr[k], want_e[k])
+    assert len(want_rep[1]) > 0
+    # coverage of a few targets after the second add_layers, from their owners
+    for t in np.unique(sens.b_id)[:24]:
+        parity.assert_same("pile_data[%d]" % t, sh.ranks[int(t) % world].pile_data(int(t)), o.pile_data(int(t)))
