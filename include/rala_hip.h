@@ -108,11 +108,13 @@ int rala_hip_initialize(rala_hip_ctx* ctx);
  * (:553-632).  Sensitive overlaps: a = query in untrimmed coordinates, b = target in
  * TRIMMED coordinates (misc/raven.sh), host memory. */
 int rala_hip_construct(rala_hip_ctx* ctx, const rala_hip_overlaps* sens, uint64_t n_sens);
-/* Pile::find_repetitive_hills(dataset_median) of ONE read on its current coverage (src/pile.cpp:500-566):
- * slopes at 1.42, the 0.84 / 0.9 / 0.336 rules; the read's repeat hills (flags cleared) are then
- * what rala_hip_get_intervals(kind 2) reports for it.  The sensitive pass of rala_hip_construct
- * does this for all reads; this entry point serves a stand-alone rala::Pile. */
-int rala_hip_find_repetitive_hills(rala_hip_ctx* ctx, uint64_t read, uint16_t dataset_median);
+/* Pile::find_repetitive_hills(dataset_median) of ONE read on its current coverage (src/pile.cpp:500-566)
+ * with the Pile's members begin_, end_, median_, p10_ as given: slopes at 1.42, the 0.84 / 0.9 / 0.336
+ * rules; the read's repeat hills (flags cleared) are then what rala_hip_get_intervals(kind 2)
+ * reports for it.  The sensitive pass of rala_hip_construct does this for all reads; this entry
+ * point serves a stand-alone rala::Pile. */
+int rala_hip_find_repetitive_hills(rala_hip_ctx* ctx, uint64_t read, uint32_t begin, uint32_t end, uint16_t median,
+                                   uint16_t p10, uint16_t dataset_median);
 /* Graph::remove_transitive_edges on the graph built by rala_hip_construct
  * (src/graph.cpp:1281-1335).  *n_pairs = its return value. */
 int rala_hip_remove_transitive_edges(rala_hip_ctx* ctx, uint32_t* n_pairs);

@@ -2,6 +2,8 @@
 // Backend for oracle_graph.hpp's Driver that runs on the flat restatement.
 #pragma once
 
+#include <string>
+
 #include "oracle_core.hpp"
 
 namespace ora {
@@ -46,6 +48,20 @@ struct FlatBackend {
     std::vector<Iv> find_slopes(uint64_t r, double q) { return ora::find_slopes(piles[r], q); }
     bool has_hill(uint64_t r) const { return piles[r].has_hill(); }
     bool has_chimeric_region(uint64_t r) const { return piles[r].has_chimeric_region(); }
+    // restatement of Pile::to_json (pile.cpp:632-663): "<id>":{"y":[...],"b":..,"e":..,"h":[f,s,...],"m":..,"p10":..}
+    std::string to_json(uint64_t r) const {
+        std::string out = "\"" + std::to_string(r) + "\":{\"y\":[";
+        const std::vector<uint16_t>& d = data(r);
+        for (size_t i = 0; i < d.size(); ++i) { out += std::to_string(d[i]); if (i + 1 < d.size()) out += ","; }
+        out += "],\"b\":" + std::to_string(begin(r)) + ",\"e\":" + std::to_string(end(r)) + ",\"h\":[";
+        const std::vector<Iv>& h = rep_hills(r);
+        for (size_t i = 0; i < h.size(); ++i) {
+            out += std::to_string(h[i].first) + "," + std::to_string(h[i].second);
+            if (i + 1 < h.size()) out += ",";
+        }
+        out += "],\"m\":" + std::to_string(median(r)) + ",\"p10\":" + std::to_string(p10(r)) + "}";
+        return out;
+    }
     bool has_rep_hills(uint64_t r) const { return piles[r].has_rep_hills(); }
     void check_chimeric_hills(uint64_t r, OvlH h) { ora::check_chimeric_hills(piles[r], *h); }
     bool break_over_chimeric_hills(uint64_t r) { return ora::break_over_chimeric_hills(piles[r]); }

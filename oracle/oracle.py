@@ -54,6 +54,7 @@ def _load(path):
         "ora_pile_find_chimeric_hills": (None, [vp, u64]),
         "ora_pile_find_chimeric_pits": (None, [vp, u64]),
         "ora_pile_find_repetitive_hills": (None, [vp, u64, ctypes.c_uint16]),
+        "ora_pile_to_json": (u64, [vp, u64, ctypes.c_char_p, u64]),
         "ora_pile_break_over_chimeric_pits": (i32, [vp, u64, ctypes.c_uint16]),
         "ora_pile_break_over_chimeric_hills": (i32, [vp, u64]),
         "ora_pile_find_slopes": (u64, [vp, u64, ctypes.c_double, vp, u64]),
@@ -239,6 +240,13 @@ class Oracle:
 
     def find_repetitive_hills(self, r, med):
         self.L.ora_pile_find_repetitive_hills(self.h, r, med)
+
+    def to_json(self, r):
+        """Pile::to_json (reference pile.cpp:632-663) of a live read"""
+        n = int(self.L.ora_pile_to_json(self.h, r, None, 0))
+        buf = ctypes.create_string_buffer(n + 1)
+        self.L.ora_pile_to_json(self.h, r, buf, n)
+        return buf.raw[:n].decode()
 
     def break_over_chimeric_pits(self, r, med):
         return bool(self.L.ora_pile_break_over_chimeric_pits(self.h, r, med))

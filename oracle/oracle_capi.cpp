@@ -154,6 +154,15 @@ int ora_pile_find_valid_region(void* p, uint64_t r) { return ((Handle*)p)->d.bk.
 void ora_pile_find_median(void* p, uint64_t r) { ((Handle*)p)->d.bk.find_median(r); }
 void ora_pile_find_chimeric_hills(void* p, uint64_t r) { ((Handle*)p)->d.bk.find_chimeric_hills(r); }
 void ora_pile_find_chimeric_pits(void* p, uint64_t r) { ((Handle*)p)->d.bk.find_chimeric_pits(r); }
+// Pile::to_json; returns the length, copies at most cap bytes
+uint64_t ora_pile_to_json(void* p, uint64_t r, char* out, uint64_t cap) {
+    Handle* h = (Handle*)p;
+    if (!h->d.bk.alive(r)) return 0;
+    const std::string s = h->d.bk.to_json(r);
+    if (out) memcpy(out, s.data(), s.size() < cap ? s.size() : cap);
+    return s.size();
+}
+
 void ora_pile_find_repetitive_hills(void* p, uint64_t r, uint16_t med) {
     ((Handle*)p)->d.bk.find_repetitive_hills(r, med);
 }

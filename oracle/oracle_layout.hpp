@@ -19,6 +19,8 @@
 // components).
 #pragma once
 
+#include <unordered_map>
+
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -658,6 +660,92 @@ public:
         }
         std::sort(transitive_edges_.begin(), transitive_edges_.end());
         return num_unitigs_created;
+    }
+
+    // ---- the on-disk formats (graph.cpp:2153-2297), written to a string ------------------------
+    // print_csv (graph.cpp:2153-2179)
+    std::string print_csv() const {
+        std::string out;
+        char line[512];
+        for (const auto& it : nodes_) {
+            if (it == nullptr || !it->is_rc() || (it->outdegree() == 0 && it->indegree() == 0)) continue;
+            snprintf(line, sizeof(line), "%lu LN:i:%u RC:i:%lu,%lu LN:i:%u RC:i:%lu,0,-\n", it->id, it->length(),
+                     it->sequence_ids.size(), it->pair->id, it->pair->length(), it->pair->sequence_ids.size());
+            out += line;
+        }
+        for (const auto& it : edges_) {
+            if (it == nullptr) continue;
+            snprintf(line, sizeof(line), "%lu LN:i:%u RC:i:%lu,%lu LN:i:%u RC:i:%lu,1,%lu %u %lf\n", it->begin_node->id,
+                     it->begin_node->length(), it->begin_node->sequence_ids.size(), it->end_node->id,
+                     it->end_node->length(), it->end_node->sequence_ids.size(), it->id, it->length, it->weight);
+            out += line;
+        }
+        return out;
+    }
+    // print_gfa (graph.cpp:2181-2226)
+    std::string print_gfa() const {
+        std::string out;
+        std::unordered_map<uint64_t, std::string> unitig_name;
+        uint32_t unitig_id = 0;
+        auto name_of = [&](const Node* n) -> std::string { return !n->name.empty() ? n->name : unitig_name[n->id]; };
+        for (const auto& it : nodes_) {
+            if (it == nullptr || it->is_rc() || (it->outdegree() == 0 && it->indegree() == 0)) continue;
+            if (it->name.empty()) {
+                const std::string u = "Utg" + std::to_string(unitig_id++);
+                unitig_name[it->id] = u;
+                unitig_name[it->pair->id] = u;
+            }
+            out += "S\t" + name_of(it.get()) + "\t" + it->data + "\tLN:i:" + std::to_string(it->data.size()) + "\tRC:i:" +
+                   std::to_string(it->sequence_ids.size()) + "\n";
+        }
+        for (const auto& it : edges_) {
+            if (it == nullptr) continue;
+            out += "L\t" + name_of(nodes_[it->begin_node->id].get()) + "\t" + (it->begin_node->is_rc() ? "-" : "+") + "\t" +
+                   name_of(nodes_[it->end_node->id].get()) + "\t" + (it->end_node->is_rc() ? "-" : "+") + "\t" +
+                   std::to_string(it->begin_node->data.size() - it->length) + "M\n";
+        }
+        return out;
+    }
+    // print_json (graph.cpp:2228-2297); the reference walks an unordered_set of sequence ids for the
+    // piles, here (as in the product) ascending ids; pile_json(id) stands for piles_[id]->to_json()
+    template <class PileJson>
+    std::string print_json(const PileJson& pile_json) const {
+        std::string out = "{\"nodes\":{";
+        bool is_first = true;
+        std::set<uint64_t> sequence_ids;
+        for (const auto& it : nodes_) {
+            if (it == nullptr || it->is_rc() || !it->is_junction()) continue;
+            if (!is_first) out += ",";
+            is_first = false;
+            out += "\"" + std::to_string(it->sequence_ids.front()) + "\":{\"n\":" + std::to_string(it->id) + ",\"p\":[";
+            sequence_ids.insert(it->sequence_ids.front());
+            for (uint32_t i = 0; i < it->prefix_edges.size(); ++i) {
+                const Node* other = it->prefix_edges[i]->begin_node;
+                sequence_ids.insert(other->sequence_ids.back());
+                out += "[\"" + std::to_string(other->sequence_ids.back()) + "\",\"" + std::to_string(other->id) + "\"," +
+                       std::to_string((int)other->is_last_rc) + "," + std::to_string(other->length() - it->prefix_edges[i]->length) + "]";
+                if (i < it->prefix_edges.size() - 1) out += ",";
+            }
+            out += "],\"s\":[";
+            for (uint32_t i = 0; i < it->suffix_edges.size(); ++i) {
+                const Node* other = it->suffix_edges[i]->end_node;
+                sequence_ids.insert(other->sequence_ids.front());
+                out += "[\"" + std::to_string(other->sequence_ids.front()) + "\",\"" + std::to_string(other->id) + "\"," +
+                       std::to_string((int)other->is_first_rc) + "," + std::to_string(it->length() - it->suffix_edges[i]->length) + "]";
+                if (i < it->suffix_edges.size() - 1) out += ",";
+            }
+            out += "]}";
+        }
+        out += "}";
+        if (sequence_ids.empty()) return out + "}";
+        out += ",\"piles\":{";
+        is_first = true;
+        for (uint64_t id : sequence_ids) {
+            if (!is_first) out += ",";
+            is_first = false;
+            out += pile_json(id);
+        }
+        return out + "}}";
     }
 };
 

@@ -99,6 +99,15 @@ void ol_dump_edges(void* h, uint8_t* alive, uint32_t* begin_node, uint32_t* end_
     }
 }
 
+// kind 0 csv, 1 gfa, 2 json (piles as "<id>":{} stand-ins); returns the length, copies at most cap bytes
+uint64_t ol_print(void* h, int kind, char* dst, uint64_t cap) {
+    const ora_layout::Layout* g = (const ora_layout::Layout*)h;
+    const std::string s = kind == 0 ? g->print_csv() : kind == 1 ? g->print_gfa()
+                          : g->print_json([](uint64_t id) { return "\"" + std::to_string(id) + "\":{}"; });
+    if (dst) memcpy(dst, s.data(), s.size() < cap ? s.size() : cap);
+    return s.size();
+}
+
 uint64_t ol_node_data(void* h, uint64_t node, char* dst, uint64_t cap) {
     const auto* n = ((ora_layout::Layout*)h)->nodes_[node].get();
     if (!n) return 0;

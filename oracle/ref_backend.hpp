@@ -89,6 +89,7 @@ struct RefBackend {
         tmp.release();
     }
     bool is_valid_overlap(uint64_t r, uint32_t x, uint32_t y) const { return piles[r]->is_valid_overlap(x, y); }
+    std::string to_json(uint64_t r) const { return piles[r]->to_json(); }          // pile.cpp:632-663
 
     // PAF constructor (overlap.cpp:22-31) followed by the reference's own
     // Overlap::transmute (overlap.cpp:36-82)

@@ -259,9 +259,10 @@ size_t scan_workspace_bytes(uint64_t n);
 void launch_exclusive_scan(const uint32_t* in, uint32_t* out, uint64_t n, void* workspace, hipStream_t s);
 
 // ---- transitive reduction (tr_kernels.hip) ---------------------------------------
+// edges [first_edge, last_edge) act as a->b (all of them, or one rank's share)
 void launch_tr_mark(const uint32_t* row_ptr, const uint32_t* adj_edge, const uint32_t* edge_src,
-                    const uint32_t* edge_dst, const uint32_t* edge_len, uint32_t n_nodes, uint32_t n_edges,
-                    uint8_t* marks, hipStream_t s);
+                    const uint32_t* edge_dst, const uint32_t* edge_len, uint32_t n_nodes, uint32_t first_edge,
+                    uint32_t last_edge, uint8_t* marks, hipStream_t s);
 // out-degree per node (also flags endpoints >= n_nodes) / adjacency fill through a cursor
 void launch_tr_degree(const uint32_t* src, const uint32_t* dst, uint32_t n_nodes, uint32_t n_edges, uint32_t* deg,
                       uint32_t* bad, hipStream_t s);
@@ -277,7 +278,7 @@ size_t component_median_workspace(uint32_t n);
 hipError_t launch_component_medians(const uint32_t* label, const uint8_t* touched, const uint32_t* alive_reads,
                                     const uint16_t* median, uint32_t n_alive, uint64_t* keys, uint64_t* sorted, void* tmp,
                                     size_t tmp_bytes, uint16_t* cmed, hipStream_t s);
-void launch_tr_count(const uint8_t* marks, uint32_t n_edges, uint32_t* n_pairs, hipStream_t s);
+void launch_tr_count(uint8_t* marks, uint32_t n_edges, uint32_t* n_pairs, hipStream_t s);    // also normalises the marks to 0 / 1
 
 // ---- force-directed layout step (layout_kernels.hip) -------------------------------------------
 void launch_layout_step(uint32_t n, const double* x, const double* y, double* x_out, double* y_out,

@@ -882,16 +882,16 @@ void build_graph(rala_hip_ctx* ctx) {
 
 // transitive-edge marking on device edge arrays; marks stay in ctx->d_tr_marks
 int tr_mark_device(rala_hip_ctx* ctx, uint32_t n_nodes, uint32_t n_edges, const uint32_t* d_src, const uint32_t* d_dst,
-                   const uint32_t* d_len, uint32_t* n_pairs) {
+                   const uint32_t* d_len, uint32_t* n_pairs, Comm* comm = nullptr) {
     *n_pairs = 0;
     if (n_edges == 0) return RALA_HIP_OK;
     if (n_edges & 1) return fail(ctx, RALA_HIP_EINVAL, "edges must come in twin pairs (e, e^1)");
     hipStream_t s = ctx->stream;
     DevBuf<uint32_t>* B = ctx->d_tr;          // row, cursor, adj (persistent)
     HIPCHECK(B[0].ensure(n_nodes + 2)); HIPCHECK(B[1].ensure(n_nodes + 2)); HIPCHECK(B[2].ensure(n_edges));
-    HIPCHECK(ctx->d_tr_marks.ensure(n_edges));
+    HIPCHECK(ctx->d_tr_marks.ensure((size_t)n_edges + 8));
     HIPCHECK(ctx->d_scan_ws.ensure(scan_workspace_bytes((uint64_t)n_nodes + 2)));
-    HIPCHECK(hipMemsetAsync(ctx->d_tr_marks.p, 0, n_edges, s));
+    HIPCHECK(hipMemsetAsync(ctx->d_tr_marks.p, 0, ((size_t)n_edges + 7) & ~(size_t)3, s));
     HIPCHECK(hipMemsetAsync(ctx->d_small.p + 2, 0, 8, s));           // [2] bad endpoint flag [3] pairs
     HIPCHECK(hipMemsetAsync(B[1].p, 0, (size_t)(n_nodes + 1) * 4, s));
     HIPCHECK(hipEventRecord(ctx->ev[10], s));
@@ -902,7 +902,18 @@ int tr_mark_device(rala_hip_ctx* ctx, uint32_t n_nodes, uint32_t n_edges, const 
     launch_exclusive_scan(B[1].p, B[0].p, n_nodes, ctx->d_scan_ws.p, s);
     HIPCHECK(hipMemcpyAsync(B[1].p, B[0].p, (size_t)n_nodes * 4, hipMemcpyDeviceToDevice, s));
     launch_tr_fill(d_src, n_nodes, n_edges, B[1].p, B[2].p, s);
-    launch_tr_mark(B[0].p, B[2].p, d_src, d_dst, d_len, n_nodes, n_edges, ctx->d_tr_marks.p, s);
+    if (!comm) {
+        launch_tr_mark(B[0].p, B[2].p, d_src, d_dst, d_len, n_nodes, 0, n_edges, ctx->d_tr_marks.p, s);
+    } else {
+        // every rank probes from its share of the edges a->b; the marks (bytes 0 / 1) are summed
+        const uint64_t P = comm->world(), k = comm->rank();
+        launch_tr_mark(B[0].p, B[2].p, d_src, d_dst, d_len, n_nodes, (uint32_t)(n_edges * k / P), (uint32_t)(n_edges * (k + 1) / P),
+                       ctx->d_tr_marks.p, s);
+        if (comm->all_reduce_u32((uint32_t*)ctx->d_tr_marks.p, ((size_t)n_edges + 3) / 4, ReduceOp::kSum, s) != 0) {
+            ctx->err = std::string("all-reduce of the transitive marks: ") + comm->error();
+            return RALA_HIP_EDEVICE;
+        }
+    }
     launch_tr_count(ctx->d_tr_marks.p, n_edges, ctx->d_small.p + 3, s);
     HIPCHECK(hipEventRecord(ctx->ev[11], s));
     uint32_t res[2] = {0, 0};
@@ -1387,6 +1398,18 @@ int rala_hip::repeats_stage(rala_hip_ctx* cs, rala_hip_ctx* cl, Comm* comm, cons
     const int rc = repeats_after_tail(cs, cl, comm, sens, n_sens);
     cs->tm.tail_host_ms += (float)(now_ms() - t0);
     return rc;
+}
+
+int rala_hip::transitive_stage(rala_hip_ctx* ctx, Comm* comm, uint32_t* n_pairs) {
+    if (!ctx || !n_pairs) return RALA_HIP_EINVAL;
+    if (!ctx->constructed) return fail(ctx, RALA_HIP_EINVAL, "construct must succeed first");
+    HIPCHECK(hipSetDevice(ctx->device));
+    if (ctx->tail_on_device) {
+        const int rc = tr_mark_device(ctx, ctx->t_n_nodes, ctx->t_n_edges, ctx->d_e[0].p, ctx->d_e[1].p, ctx->d_e[2].p, n_pairs, comm);
+        ctx->marks_on_device = rc == RALA_HIP_OK;
+        return rc;
+    }
+    return rala_hip_remove_transitive_edges(ctx, n_pairs);      // (after the sensitive pass the graph is a host graph)
 }
 
 int rala_hip::install_read_state(rala_hip_ctx* ctx, uint64_t pool_count) {
@@ -2050,13 +2073,16 @@ int rala_hip_construct(rala_hip_ctx* ctx, const rala_hip_overlaps* sens, uint64_
     return RALA_HIP_OK;
 }
 
-int rala_hip_find_repetitive_hills(rala_hip_ctx* ctx, uint64_t read, uint16_t dataset_median) {
+int rala_hip_find_repetitive_hills(rala_hip_ctx* ctx, uint64_t read, uint32_t begin, uint32_t end, uint16_t median,
+                                   uint16_t p10, uint16_t dataset_median) {
     if (!ctx) return RALA_HIP_EINVAL;
     if (!ctx->initialized || read >= ctx->n_reads) return fail(ctx, RALA_HIP_EINVAL, "bad read / not initialized");
     if (!ctx->piles_resident) return fail(ctx, RALA_HIP_EINVAL, "the piles live on another context");
     HIPCHECK(hipSetDevice(ctx->device));
     { const int rcm = materialize_host(ctx); if (rcm != RALA_HIP_OK) return rcm; }
     if (!ctx->h_alive[read]) return fail(ctx, RALA_HIP_EINVAL, "the read was filtered");
+    if (begin > end || end > ctx->h_read_len[read]) return fail(ctx, RALA_HIP_EINVAL, "bad valid region");
+    ctx->h_begin[read] = begin; ctx->h_end[read] = end; ctx->h_median[read] = median; ctx->h_p10[read] = p10;
     const uint64_t n = ctx->n_reads;
     hipStream_t s = ctx->stream;
     HIPCHECK(ctx->d_dataset_median.ensure(n));
@@ -2071,6 +2097,8 @@ int rala_hip_find_repetitive_hills(rala_hip_ctx* ctx, uint64_t read, uint16_t da
     // the valid region as it stands (the host mirrors are authoritative after a host tail)
     HIPCHECK(hipMemcpyAsync(ctx->d_begin.p + read, &ctx->h_begin[read], 4, hipMemcpyHostToDevice, s));
     HIPCHECK(hipMemcpyAsync(ctx->d_end.p + read, &ctx->h_end[read], 4, hipMemcpyHostToDevice, s));
+    HIPCHECK(hipMemcpyAsync(ctx->d_median.p + read, &ctx->h_median[read], 2, hipMemcpyHostToDevice, s));
+    HIPCHECK(hipMemcpyAsync(ctx->d_p10.p + read, &ctx->h_p10[read], 2, hipMemcpyHostToDevice, s));
     HIPCHECK(hipMemcpyAsync(ctx->d_dataset_median.p + read, &dataset_median, 2, hipMemcpyHostToDevice, s));
     HIPCHECK(hipMemsetAsync(ctx->d_small.p + 7, 0, 4, s));
     HIPCHECK(stream_sync(ctx, s));

@@ -375,7 +375,7 @@ int rala_hip_mg_run(rala_hip_mg* mg, const rala_hip_overlaps* sens_slice, uint64
         mg->tm.repeats_ms = (float)(now_ms() - t2);
     }
     const double t1 = now_ms();
-    rc = from_ctx(mg, mg->cs, rala_hip_remove_transitive_edges(mg->cs, n_pairs), "remove_transitive_edges");
+    rc = from_ctx(mg, mg->cs, transitive_stage(mg->cs, mg->comm, n_pairs), "remove_transitive_edges");
     if (rc != RALA_HIP_OK) return rc;
     mg->tm.tr_ms = (float)(now_ms() - t1);
     mg->tm.total_ms = (float)(now_ms() - t0);

@@ -22,6 +22,11 @@ int construct_stages(rala_hip_ctx* ctx, Comm* comm);
 // cl = the context that holds the piles (the same one on a single GPU, comm = null)
 int repeats_stage(rala_hip_ctx* cs, rala_hip_ctx* cl, Comm* comm, const rala_hip_overlaps* sens, uint64_t n_sens);
 
+// Graph::remove_transitive_edges (graph.cpp:1281-1335) on the graph construct_stages left on the
+// device; with a communicator every rank probes from its share of the edges and the marks are
+// all-reduced
+int transitive_stage(rala_hip_ctx* ctx, Comm* comm, uint32_t* n_pairs);
+
 // install per-read state that was computed elsewhere and already sits in ctx's device arrays
 // (d_begin .. d_iv_slot, d_pool[0 .. pool_count)); validity bits of ctx's own overlaps must be
 // there too (rala_hip_dedupe).  Counts the filtered reads.

@@ -24,8 +24,9 @@ __global__ __launch_bounds__(kBlock) void tr_mark_kernel(const uint32_t* __restr
                                                          const uint32_t* __restrict__ esrc,
                                                          const uint32_t* __restrict__ edst,
                                                          const uint32_t* __restrict__ elen, uint32_t n_nodes,
-                                                         uint32_t n_edges, uint8_t* marks) {
-    const uint32_t e_ab = blockIdx.x * kBlock + threadIdx.x;
+                                                         uint32_t first_edge, uint32_t n_edges, uint8_t* marks) {
+    // edges [first_edge, n_edges): all of them, or one rank's share of a sharded run
+    const uint32_t e_ab = first_edge + blockIdx.x * kBlock + threadIdx.x;
     if (e_ab >= n_edges) return;
     const uint32_t a = esrc[e_ab], b = edst[e_ab];
     if (a >= n_nodes || b >= n_nodes) return;          // reported by tr_degree_kernel
@@ -51,12 +52,13 @@ __global__ __launch_bounds__(kBlock) void tr_mark_kernel(const uint32_t* __restr
     }
 }
 
-__global__ __launch_bounds__(kBlock) void tr_count_kernel(const uint8_t* __restrict__ marks, uint32_t n_edges,
+__global__ __launch_bounds__(kBlock) void tr_count_kernel(uint8_t* __restrict__ marks, uint32_t n_edges,
                                                           uint32_t* n_pairs) {
     __shared__ uint32_t tmp[kBlock / 64 + 1];
     const uint32_t p = blockIdx.x * kBlock + threadIdx.x;     // pair index
     uint32_t v = 0;
     if (2 * p + 1 < n_edges) v = marks[2 * p] ? 1u : 0u;
+    if (2 * p + 1 < n_edges && v) { marks[2 * p] = 1; marks[2 * p + 1] = 1; }        // (sharded runs summed the ranks' bytes)
     v = block_reduce<kBlock>(v, OpAdd(), 0u, tmp);
     if (threadIdx.x == 0 && v) atomicAdd(n_pairs, v);
 }
@@ -157,14 +159,14 @@ void launch_cc_compress(uint32_t* label, uint32_t n, hipStream_t s) {
 }
 
 void launch_tr_mark(const uint32_t* row_ptr, const uint32_t* adj_edge, const uint32_t* edge_src,
-                    const uint32_t* edge_dst, const uint32_t* edge_len, uint32_t n_nodes, uint32_t n_edges,
-                    uint8_t* marks, hipStream_t s) {
-    if (n_edges == 0) return;
-    hipLaunchKernelGGL(tr_mark_kernel, dim3((n_edges + kBlock - 1) / kBlock), dim3(kBlock), 0, s, row_ptr, adj_edge,
-                       edge_src, edge_dst, edge_len, n_nodes, n_edges, marks);
+                    const uint32_t* edge_dst, const uint32_t* edge_len, uint32_t n_nodes, uint32_t first_edge,
+                    uint32_t last_edge, uint8_t* marks, hipStream_t s) {
+    if (last_edge <= first_edge) return;
+    hipLaunchKernelGGL(tr_mark_kernel, dim3((last_edge - first_edge + kBlock - 1) / kBlock), dim3(kBlock), 0, s, row_ptr,
+                       adj_edge, edge_src, edge_dst, edge_len, n_nodes, first_edge, last_edge, marks);
 }
 
-void launch_tr_count(const uint8_t* marks, uint32_t n_edges, uint32_t* n_pairs, hipStream_t s) {
+void launch_tr_count(uint8_t* marks, uint32_t n_edges, uint32_t* n_pairs, hipStream_t s) {
     const uint32_t pairs = n_edges / 2;
     if (pairs == 0) return;
     hipLaunchKernelGGL(tr_count_kernel, dim3((pairs + kBlock - 1) / kBlock), dim3(kBlock), 0, s, marks, n_edges,

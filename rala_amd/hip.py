@@ -112,7 +112,7 @@ def lib(build=True):
         L.rala_hip_import_state_device.argtypes = [vp, ctypes.POINTER(DeviceState)]
         L.rala_hip_copy_device_state.argtypes = [vp, ctypes.POINTER(DeviceState)]
         L.rala_hip_layout.argtypes = [vp, u32, vp, vp, vp, vp, u32, ctypes.c_double, ctypes.c_double, ctypes.c_double]
-        L.rala_hip_find_repetitive_hills.argtypes = [vp, u64, ctypes.c_uint16]
+        L.rala_hip_find_repetitive_hills.argtypes = [vp, u64, u32, u32, ctypes.c_uint16, ctypes.c_uint16, ctypes.c_uint16]
         L.rala_hip_mg_unique_id.argtypes = [vp]
         L.rala_hip_mg_local_group_create.argtypes = [u32, ctypes.POINTER(vp)]
         L.rala_hip_mg_local_group_destroy.argtypes = [vp]
@@ -290,8 +290,9 @@ class Context:
         else:
             self._check(self.L.rala_hip_construct(self.h, None, 0))
 
-    def find_repetitive_hills(self, read, dataset_median):
-        self._check(self.L.rala_hip_find_repetitive_hills(self.h, int(read), int(dataset_median)))
+    def find_repetitive_hills(self, read, begin, end, median, p10, dataset_median):
+        self._check(self.L.rala_hip_find_repetitive_hills(self.h, int(read), int(begin), int(end), int(median), int(p10),
+                                                          int(dataset_median)))
 
     def remove_transitive_edges(self):
         n = ctypes.c_uint32(0)

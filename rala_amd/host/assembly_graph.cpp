@@ -1,5 +1,11 @@
 #include "assembly_graph.hpp"
 
+#include <ostream>
+
+#include <unordered_map>
+
+#include <set>
+
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -537,5 +543,100 @@ uint32_t AssemblyGraph::shrink(uint32_t epsilon) {
     std::sort(transitive_edges_.begin(), transitive_edges_.end());
     return num_unitigs_created;
 }
+
+// reference src/graph.cpp:2153-2179
+void AssemblyGraph::write_csv(FILE* graph_file) const {
+    const auto& nodes = nodes_;
+    for (const auto& it : nodes) {
+        if (!it.alive || !it.is_rc() || (it.outdegree() == 0 && it.indegree() == 0)) continue;
+        const auto& pair = nodes[it.id ^ 1];
+        fprintf(graph_file, "%lu LN:i:%u RC:i:%lu,%lu LN:i:%u RC:i:%lu,0,-\n", it.id, it.length(),
+            it.sequence_ids.size(), pair.id, pair.length(), pair.sequence_ids.size());
+    }
+    for (const auto& it : edges_) {
+        if (!it.alive) continue;
+        const auto& b = nodes[it.begin_node];
+        const auto& e = nodes[it.end_node];
+        fprintf(graph_file, "%lu LN:i:%u RC:i:%lu,%lu LN:i:%u RC:i:%lu,1,%lu %u %lf\n", b.id, b.length(),
+            b.sequence_ids.size(), e.id, e.length(), e.sequence_ids.size(), it.id, it.length, it.weight);
+    }
+}
+
+// reference src/graph.cpp:2181-2226
+void AssemblyGraph::write_gfa(FILE* graph_file) const {
+    const auto& nodes = nodes_;
+    std::unordered_map<uint64_t, std::string> unitig_name;
+    uint32_t unitig_id = 0;
+    auto name_of = [&](const Node& n) -> const std::string& {
+        return !n.name.empty() ? n.name : unitig_name[n.id];
+    };
+    for (const auto& it : nodes) {
+        if (!it.alive || it.is_rc() || (it.outdegree() == 0 && it.indegree() == 0)) continue;
+        if (it.name.empty()) {
+            const std::string name = "Utg" + std::to_string(unitig_id++);
+            unitig_name[it.id] = name;
+            unitig_name[it.id ^ 1] = name;
+        }
+        fprintf(graph_file, "S\t%s\t%s\tLN:i:%zu\tRC:i:%lu\n", name_of(it).c_str(), it.data.c_str(), it.data.size(),
+            it.sequence_ids.size());
+    }
+    for (const auto& it : edges_) {
+        if (!it.alive) continue;
+        const auto& b = nodes[it.begin_node];
+        const auto& e = nodes[it.end_node];
+        fprintf(graph_file, "L\t%s\t%c\t%s\t%c\t%zuM\n", name_of(b).c_str(), b.is_rc() ? '-' : '+',
+            name_of(e).c_str(), e.is_rc() ? '-' : '+', b.data.size() - it.length);
+    }
+}
+
+// reference src/graph.cpp:2228-2297 (the reference walks an unordered_set of sequence ids for the piles;
+// here ascending ids)
+void AssemblyGraph::write_json(std::ostream& os, const std::function<std::string(uint64_t)>& pile_json) const {
+    os << "{\"nodes\":{";
+    bool is_first = true;
+    const auto& nodes = nodes_;
+    const auto& edges = edges_;
+    std::set<uint64_t> sequence_ids;
+    for (const auto& it : nodes) {
+        if (!it.alive || it.is_rc() || !it.is_junction()) continue;
+        if (!is_first) os << ",";
+        is_first = false;
+        os << "\"" << it.sequence_ids.front() << "\":{\"n\":" << it.id << ",";
+        os << "\"p\":[";
+        sequence_ids.insert(it.sequence_ids.front());
+        for (size_t i = 0; i < it.prefix_edges.size(); ++i) {
+            const auto& other = nodes[edges[it.prefix_edges[i]].begin_node];
+            sequence_ids.insert(other.sequence_ids.back());
+            os << "[\"" << other.sequence_ids.back() << "\",\"" << other.id << "\"," << other.is_last_rc << ","
+               << other.length() - edges[it.prefix_edges[i]].length << "]";
+            if (i + 1 < it.prefix_edges.size()) os << ",";
+        }
+        os << "],\"s\":[";
+        for (size_t i = 0; i < it.suffix_edges.size(); ++i) {
+            const auto& other = nodes[edges[it.suffix_edges[i]].end_node];
+            sequence_ids.insert(other.sequence_ids.front());
+            os << "[\"" << other.sequence_ids.front() << "\",\"" << other.id << "\"," << other.is_first_rc << ","
+               << it.length() - edges[it.suffix_edges[i]].length << "]";
+            if (i + 1 < it.suffix_edges.size()) os << ",";
+        }
+        os << "]}";
+    }
+    os << "}";
+    if (sequence_ids.empty()) {
+        os << "}";
+        return;
+    }
+    os << ",\"piles\":{";
+    is_first = true;
+    for (uint64_t id : sequence_ids) {
+        const std::string js = pile_json(id);
+        if (js.empty()) continue;               // (a filtered read has no pile)
+        if (!is_first) os << ",";
+        is_first = false;
+        os << js;
+    }
+    os << "}}";
+}
+
 
 }  // namespace rala

@@ -21,8 +21,10 @@
 #pragma once
 
 #include <stdint.h>
+#include <stdio.h>
 
 #include <functional>
+#include <ostream>
 #include <string>
 #include <utility>
 #include <vector>
@@ -81,6 +83,12 @@ public:
     uint32_t remove_bubbles();
     uint32_t create_unitigs();
     uint32_t shrink(uint32_t epsilon);
+
+    /*! @brief the on-disk formats of the reference (graph.cpp:2153-2297): debug CSV, GFA, and the
+     *  JSON that misc/plotter.py reads; pile_json(sequence id) supplies Pile::to_json */
+    void write_csv(FILE* to) const;
+    void write_gfa(FILE* to) const;
+    void write_json(std::ostream& os, const std::function<std::string(uint64_t)>& pile_json) const;
 
     const std::vector<Node>& nodes() const { return nodes_; }
     const std::vector<Edge>& edges() const { return edges_; }

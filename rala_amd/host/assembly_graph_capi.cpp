@@ -1,6 +1,9 @@
 // C surface of rala::AssemblyGraph for the CPU test-suite (tests/test_layout_cpu.py): build a
 // graph from arrays, run the clean-up stages, read the result back.  Not part of the product
 // boundary (that is include/rala_hip.h + the rala:: classes).
+#include <stdio.h>
+#include <stdlib.h>
+#include <sstream>
 #include <stdint.h>
 #include <string.h>
 
@@ -98,6 +101,27 @@ void ag_dump_edges(void* h, uint8_t* alive, uint32_t* begin_node, uint32_t* end_
         begin_node[i] = e.alive ? e.begin_node : 0; end_node[i] = e.alive ? e.end_node : 0;
         length[i] = e.alive ? e.length : 0;
     }
+}
+
+// kind 0 csv, 1 gfa, 2 json (piles as "<id>":{} stand-ins); returns the length, copies at most cap bytes
+uint64_t ag_print(void* h, int kind, char* dst, uint64_t cap) {
+    const rala::AssemblyGraph* g = (const rala::AssemblyGraph*)h;
+    std::string s;
+    if (kind == 2) {
+        std::ostringstream os;
+        g->write_json(os, [](uint64_t id) { return "\"" + std::to_string(id) + "\":{}"; });
+        s = os.str();
+    } else {
+        char* buf = nullptr;
+        size_t len = 0;
+        FILE* f = open_memstream(&buf, &len);
+        if (kind == 0) g->write_csv(f); else g->write_gfa(f);
+        fclose(f);
+        s.assign(buf, len);
+        free(buf);
+    }
+    if (dst) memcpy(dst, s.data(), s.size() < cap ? s.size() : cap);
+    return s.size();
 }
 
 uint64_t ag_node_data(void* h, uint64_t node, char* dst, uint64_t cap) {

@@ -7,6 +7,7 @@
 #include <chrono>
 #include <fstream>
 #include <set>
+#include <thread>
 
 #include "io.hpp"
 #include "overlap.hpp"
@@ -59,15 +60,76 @@ std::unique_ptr<Graph> createGraph(const std::string& sequences_path, const std:
 
 Graph::Graph(const std::string& sequences_path, const std::string& overlaps_path, uint32_t num_threads)
         : sequences_path_(sequences_path), overlaps_path_(overlaps_path), num_threads_(num_threads), ctx_(nullptr) {
-    if (rala_hip_create(0, &ctx_) != RALA_HIP_OK) {
-        fprintf(stderr, "[rala::Graph::Graph] error: no usable HIP device!\n");
+    open_devices();
+}
+
+// RALA_GPUS = number of devices (default 1); RALA_GPU_DEVICES = their ordinals, comma separated
+// (default 0, 1, ...); RALA_COMM = rccl (default) | local (in-process transport, also several ranks
+// on one device).  The reference creates its thread pool here (graph.cpp:230-238).
+void Graph::open_devices() {
+    uint32_t n_gpus = 1;
+    if (const char* e = getenv("RALA_GPUS")) n_gpus = (uint32_t)std::max(1, atoi(e));
+    if (n_gpus == 1) {
+        if (rala_hip_create(0, &ctx_) != RALA_HIP_OK) {
+            fprintf(stderr, "[rala::Graph::Graph] error: no usable HIP device!\n");
+            exit(1);
+        }
+        return;
+    }
+    if (n_gpus > 64) {
+        fprintf(stderr, "[rala::Graph::Graph] error: at most 64 devices!\n");
         exit(1);
     }
+    std::vector<int> device(n_gpus);
+    for (uint32_t k = 0; k < n_gpus; ++k) device[k] = (int)k;
+    if (const char* e = getenv("RALA_GPU_DEVICES")) {
+        const char* p = e;
+        for (uint32_t k = 0; k < n_gpus && *p; ++k) {
+            device[k] = atoi(p);
+            while (*p && *p != ',') ++p;
+            if (*p == ',') ++p;
+        }
+    }
+    const char* transport = getenv("RALA_COMM");
+    const bool local = transport != nullptr && std::string(transport) == "local";
+    unsigned char id[128] = {0};
+    if (local) {
+        if (rala_hip_mg_local_group_create(n_gpus, &local_group_) != RALA_HIP_OK) {
+            fprintf(stderr, "[rala::Graph::Graph] error: cannot set up %u ranks!\n", n_gpus);
+            exit(1);
+        }
+    } else if (rala_hip_mg_unique_id(id) != RALA_HIP_OK) {
+        fprintf(stderr, "[rala::Graph::Graph] error: RCCL is not usable (RALA_COMM=local selects the in-process transport)!\n");
+        exit(1);
+    }
+    // joining a communicator is collective: one host thread per rank
+    ranks_.assign(n_gpus, nullptr);
+    std::vector<int> rc(n_gpus, 0);
+    std::vector<std::thread> th;
+    for (uint32_t k = 0; k < n_gpus; ++k) {
+        th.emplace_back([&, k]() {
+            rc[k] = rala_hip_mg_create(device[k], k, n_gpus, local ? RALA_HIP_COMM_LOCAL : RALA_HIP_COMM_RCCL,
+                                       local ? local_group_ : (const void*)id, &ranks_[k]);
+        });
+    }
+    for (auto& t : th) t.join();
+    for (uint32_t k = 0; k < n_gpus; ++k) {
+        if (rc[k] != RALA_HIP_OK) {
+            fprintf(stderr, "[rala::Graph::Graph] error: device %d (rank %u of %u) is not usable!\n", device[k], k, n_gpus);
+            exit(1);
+        }
+    }
+    ctx_ = rala_hip_mg_context(ranks_[0]);
 }
 
 Graph::~Graph() {
     piles_.clear();
-    if (ctx_) rala_hip_destroy(ctx_);
+    if (!ranks_.empty()) {
+        for (rala_hip_mg* r : ranks_) rala_hip_mg_destroy(r);      // (they own ctx_)
+        if (local_group_) rala_hip_mg_local_group_destroy(local_group_);
+    } else if (ctx_) {
+        rala_hip_destroy(ctx_);
+    }
 }
 
 namespace {
@@ -150,9 +212,29 @@ void Graph::initialize() {
     }
     timer("[rala::Graph::initialize] loaded sequences");
     timer();
-    check(ctx_, rala_hip_set_reads(ctx_, read_len_.data(), read_len_.size()), "initialize");
     name_table_.build(names_);
     read_overlaps(overlaps_path_, name_to_id_, name_table_, read_len_, true, num_threads_, overlaps_);
+    if (!ranks_.empty()) {
+        // every rank gets all read lengths and its slice of the overlaps (cut between runs of
+        // equal queries); the stages themselves run in construct(), all ranks together
+        const uint32_t P = (uint32_t)ranks_.size();
+        std::vector<uint64_t> cuts(P + 1);
+        rala_hip_mg_slice_cuts(overlaps_.a_id.data(), overlaps_.size(), P, cuts.data());
+        for (uint32_t k = 0; k < P; ++k) {
+            const uint64_t lo = cuts[k];
+            rala_hip_overlaps sl = {overlaps_.a_id.data() + lo, overlaps_.b_id.data() + lo, overlaps_.a_begin.data() + lo,
+                                    overlaps_.a_end.data() + lo, overlaps_.b_begin.data() + lo, overlaps_.b_end.data() + lo,
+                                    overlaps_.length.data() + lo, overlaps_.strand.data() + lo};
+            if (rala_hip_mg_set_reads(ranks_[k], read_len_.data(), read_len_.size()) != RALA_HIP_OK ||
+                rala_hip_mg_set_overlaps(ranks_[k], &sl, cuts[k + 1] - lo, lo, RALA_HIP_MEM_HOST) != RALA_HIP_OK) {
+                fprintf(stderr, "[rala::Graph::initialize] error: %s!\n", rala_hip_mg_last_error(ranks_[k]));
+                exit(1);
+            }
+        }
+        timer("[rala::Graph::initialize] loaded overlaps");
+        return;
+    }
+    check(ctx_, rala_hip_set_reads(ctx_, read_len_.data(), read_len_.size()), "initialize");
     rala_hip_overlaps soa = {overlaps_.a_id.data(), overlaps_.b_id.data(), overlaps_.a_begin.data(),
                              overlaps_.a_end.data(), overlaps_.b_begin.data(), overlaps_.b_end.data(),
                              overlaps_.length.data(), overlaps_.strand.data()};
@@ -197,7 +279,36 @@ void Graph::construct(const std::string& sensitive_overlaps_path) {
         sens.length = s_cols.length.data(); sens.strand = s_cols.strand.data();
         n_sens = s_cols.size();
     }
-    check(ctx_, rala_hip_construct(ctx_, n_sens ? &sens : nullptr, n_sens), "construct");
+    if (!ranks_.empty()) {
+        // all ranks together: piles on the owners, filtering per slice, tail + graph replicated
+        const uint32_t P = (uint32_t)ranks_.size();
+        std::vector<rala_hip_overlaps> shares(P);
+        std::vector<uint64_t> n_share(P, 0);
+        for (uint32_t k = 0; k < P; ++k) {
+            const uint64_t lo = n_sens * k / P, hi = n_sens * (k + 1) / P;
+            shares[k] = {sens.a_id + lo, sens.b_id + lo, sens.a_begin + lo, sens.a_end + lo, sens.b_begin + lo,
+                         sens.b_end + lo, sens.length + lo, sens.strand + lo};
+            n_share[k] = hi - lo;
+        }
+        uint32_t pairs = 0;
+        const int rc = rala_hip_mg_run_threads(ranks_.data(), P, n_sens ? shares.data() : nullptr, n_sens ? n_share.data() : nullptr,
+                                               &pairs);
+        if (rc == RALA_HIP_EFILTERED) {
+            fprintf(stderr, "[rala::Graph::initialize] error: filtered all sequences!\n");
+            exit(1);
+        }
+        if (rc != RALA_HIP_OK) {
+            for (rala_hip_mg* r : ranks_) {
+                if (rala_hip_mg_last_error(r)[0]) fprintf(stderr, "[rala::Graph::construct] error: %s!\n", rala_hip_mg_last_error(r));
+            }
+            exit(1);
+        }
+        uint64_t num_prefiltered_sequences = 0;
+        rala_hip_get_num_prefiltered(ctx_, &num_prefiltered_sequences);
+        fprintf(stderr, "[rala::Graph::initialize] number of prefiltered sequences = %lu\n", num_prefiltered_sequences);
+    } else {
+        check(ctx_, rala_hip_construct(ctx_, n_sens ? &sens : nullptr, n_sens), "construct");
+    }
     timer("[rala::Graph::construct] loaded overlaps + [rala::Graph::preprocess]");
     timer();
 
@@ -222,6 +333,7 @@ void Graph::construct(const std::string& sensitive_overlaps_path) {
         piles_[r] = createPile(r, read_len_[r]);
         Pile& p = *piles_[r];
         p.ctx_ = ctx_; p.owns_ctx_ = false; p.ctx_read_ = r; p.computed_ = true;
+        if (!ranks_.empty()) p.mg_ = ranks_[r % ranks_.size()];         // the coverage lives on the owner
         p.begin_ = begin[r]; p.end_ = end[r]; p.median_ = median[r]; p.p10_ = p10[r];
         for (uint64_t k = off[0][r]; k < off[0][r + 1]; ++k) {
             p.chimeric_pits_.emplace_back(pairs[0][2 * k], pairs[0][2 * k + 1]);
@@ -373,103 +485,24 @@ void Graph::extract_nodes(std::vector<std::unique_ptr<Sequence>>& dst) {
     fprintf(stderr, "[rala::Graph::extract_nodes] number of nodes = %zu\n", dst.size());
 }
 
-// reference src/graph.cpp:2153-2179
+// reference src/graph.cpp:2153-2297: the writers live in AssemblyGraph (assembly_graph.cpp)
 void Graph::print_csv(const std::string& path) const {
     auto graph_file = fopen(path.c_str(), "w");
     if (!graph_file) return;
-    const auto& nodes = graph_.nodes();
-    for (const auto& it : nodes) {
-        if (!it.alive || !it.is_rc() || (it.outdegree() == 0 && it.indegree() == 0)) continue;
-        const auto& pair = nodes[it.id ^ 1];
-        fprintf(graph_file, "%lu LN:i:%u RC:i:%lu,%lu LN:i:%u RC:i:%lu,0,-\n", it.id, it.length(),
-            it.sequence_ids.size(), pair.id, pair.length(), pair.sequence_ids.size());
-    }
-    for (const auto& it : graph_.edges()) {
-        if (!it.alive) continue;
-        const auto& b = nodes[it.begin_node];
-        const auto& e = nodes[it.end_node];
-        fprintf(graph_file, "%lu LN:i:%u RC:i:%lu,%lu LN:i:%u RC:i:%lu,1,%lu %u %lf\n", b.id, b.length(),
-            b.sequence_ids.size(), e.id, e.length(), e.sequence_ids.size(), it.id, it.length, it.weight);
-    }
+    graph_.write_csv(graph_file);
     fclose(graph_file);
 }
 
-// reference src/graph.cpp:2181-2226
 void Graph::print_gfa(const std::string& path) const {
     auto graph_file = fopen(path.c_str(), "w");
     if (!graph_file) return;
-    const auto& nodes = graph_.nodes();
-    std::unordered_map<uint64_t, std::string> unitig_name;
-    uint32_t unitig_id = 0;
-    auto name_of = [&](const AssemblyGraph::Node& n) -> const std::string& {
-        return !n.name.empty() ? n.name : unitig_name[n.id];
-    };
-    for (const auto& it : nodes) {
-        if (!it.alive || it.is_rc() || (it.outdegree() == 0 && it.indegree() == 0)) continue;
-        if (it.name.empty()) {
-            const std::string name = "Utg" + std::to_string(unitig_id++);
-            unitig_name[it.id] = name;
-            unitig_name[it.id ^ 1] = name;
-        }
-        fprintf(graph_file, "S\t%s\t%s\tLN:i:%zu\tRC:i:%lu\n", name_of(it).c_str(), it.data.c_str(), it.data.size(),
-            it.sequence_ids.size());
-    }
-    for (const auto& it : graph_.edges()) {
-        if (!it.alive) continue;
-        const auto& b = nodes[it.begin_node];
-        const auto& e = nodes[it.end_node];
-        fprintf(graph_file, "L\t%s\t%c\t%s\t%c\t%zuM\n", name_of(b).c_str(), b.is_rc() ? '-' : '+',
-            name_of(e).c_str(), e.is_rc() ? '-' : '+', b.data.size() - it.length);
-    }
+    graph_.write_gfa(graph_file);
     fclose(graph_file);
 }
 
-// reference src/graph.cpp:2228-2297
 void Graph::print_json(const std::string& path) const {
     std::ofstream os(path);
-    os << "{\"nodes\":{";
-    bool is_first = true;
-    const auto& nodes = graph_.nodes();
-    const auto& edges = graph_.edges();
-    std::set<uint64_t> sequence_ids;
-    for (const auto& it : nodes) {
-        if (!it.alive || it.is_rc() || !it.is_junction()) continue;
-        if (!is_first) os << ",";
-        is_first = false;
-        os << "\"" << it.sequence_ids.front() << "\":{\"n\":" << it.id << ",";
-        os << "\"p\":[";
-        sequence_ids.insert(it.sequence_ids.front());
-        for (size_t i = 0; i < it.prefix_edges.size(); ++i) {
-            const auto& other = nodes[edges[it.prefix_edges[i]].begin_node];
-            sequence_ids.insert(other.sequence_ids.back());
-            os << "[\"" << other.sequence_ids.back() << "\",\"" << other.id << "\"," << other.is_last_rc << ","
-               << other.length() - edges[it.prefix_edges[i]].length << "]";
-            if (i + 1 < it.prefix_edges.size()) os << ",";
-        }
-        os << "],\"s\":[";
-        for (size_t i = 0; i < it.suffix_edges.size(); ++i) {
-            const auto& other = nodes[edges[it.suffix_edges[i]].end_node];
-            sequence_ids.insert(other.sequence_ids.front());
-            os << "[\"" << other.sequence_ids.front() << "\",\"" << other.id << "\"," << other.is_first_rc << ","
-               << it.length() - edges[it.suffix_edges[i]].length << "]";
-            if (i + 1 < it.suffix_edges.size()) os << ",";
-        }
-        os << "]}";
-    }
-    os << "}";
-    if (sequence_ids.empty()) {
-        os << "}";
-        return;
-    }
-    os << ",\"piles\":{";
-    is_first = true;
-    for (uint64_t id : sequence_ids) {
-        if (piles_[id] == nullptr) continue;
-        if (!is_first) os << ",";
-        is_first = false;
-        os << piles_[id]->to_json();
-    }
-    os << "}}";
+    graph_.write_json(os, [&](uint64_t id) { return piles_[id] == nullptr ? std::string() : piles_[id]->to_json(); });
 }
 
 void Graph::print_debug(const std::string& prefix) const {

@@ -23,6 +23,7 @@
 #include "io.hpp"
 
 struct rala_hip_ctx;
+struct rala_hip_mg;
 
 namespace rala {
 
@@ -69,9 +70,15 @@ private:
     void initialize();
     void postprocess();
 
+    void open_devices();
+
     std::string sequences_path_, overlaps_path_;
     uint32_t num_threads_;
-    rala_hip_ctx* ctx_;
+    rala_hip_ctx* ctx_;                 // one GPU: the context; several: rank 0's replicated result
+    // several GPUs of this node (RALA_GPUS / rala --gpus): one rank object per device, reads
+    // partitioned over them (include/rala_hip.h, rala_hip_mg_*)
+    std::vector<rala_hip_mg*> ranks_;
+    void* local_group_ = nullptr;
 
     std::unordered_map<std::string, uint64_t> name_to_id_;
     std::vector<std::string> names_;

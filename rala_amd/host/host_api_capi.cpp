@@ -8,6 +8,7 @@
  * src/overlap.hpp:27-117).  Built into rala_amd/host/librala_api.so; not part of librala.so.
  */
 
+#include <string.h>
 #include <stdint.h>
 
 #include <memory>
@@ -61,6 +62,16 @@ int hp_break_over_chimeric_hills(void* p, uint64_t r) {
 }
 int hp_shrink(void* p, uint64_t r, uint32_t begin, uint32_t end) {
     return ((Handle*)p)->piles[r]->shrink(begin, end) ? 1 : 0;
+}
+void hp_find_repetitive_hills(void* p, uint64_t r, uint16_t median) { ((Handle*)p)->piles[r]->find_repetitive_hills(median); }
+int hp_has_repetitive_hills(void* p, uint64_t r) { return ((Handle*)p)->piles[r]->has_repetitive_hills() ? 1 : 0; }
+/*! @brief Pile::to_json; returns the length, copies at most cap bytes */
+uint64_t hp_to_json(void* p, uint64_t r, char* out, uint64_t cap) {
+    const auto& pile = ((Handle*)p)->piles[r];
+    if (pile == nullptr) return 0;
+    const std::string s = pile->to_json();
+    if (out) memcpy(out, s.data(), s.size() < cap ? s.size() : cap);
+    return s.size();
 }
 /*! @brief Graph::initialize drops a pile whose valid region is too short (graph.cpp:396-399) */
 void hp_reset(void* p, uint64_t r) { ((Handle*)p)->piles[r].reset(); }

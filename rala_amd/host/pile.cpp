@@ -84,7 +84,12 @@ void Pile::run_device() {
 const std::vector<uint16_t>& Pile::data() const {
     if (!data_fetched_) {
         data_.assign(length_, 0);
-        if (ctx_ != nullptr && computed_) {
+        if (mg_ != nullptr && computed_) {
+            if (rala_hip_mg_get_pile_data(mg_, ctx_read_, data_.data()) != RALA_HIP_OK) {
+                fprintf(stderr, "[rala::Pile::data] error: %s!\n", rala_hip_mg_last_error(mg_));
+                exit(1);
+            }
+        } else if (ctx_ != nullptr && computed_) {
             if (rala_hip_get_pile_data(ctx_, ctx_read_, data_.data()) != RALA_HIP_OK) die("data", ctx_);
             // Pile::shrink zeroes outside the valid region (reference src/pile.cpp:311-318)
             for (uint32_t i = 0; i < begin_ && i < length_; ++i) data_[i] = 0;
@@ -193,13 +198,24 @@ bool Pile::break_over_chimeric_hills() {
     return shrink(begin, end);
 }
 
-void Pile::find_repetitive_hills(uint16_t) {
-    // repeat hills need find_slopes(1.42) on the device; they are produced by
-    // Graph::construct(sensitive_overlaps_path) through rala_hip_construct
-    if (owns_ctx_ || ctx_ == nullptr) {
-        fprintf(stderr, "[rala::Pile::find_repetitive_hills] error: "
-            "repeat annotation runs inside Graph::construct in this build!\n");
-        exit(1);
+// reference src/pile.cpp:500-566.  Inside Graph::construct the sensitive pass computes the hills of all
+// reads at once; a stand-alone pile asks the device for its own (rala_hip_find_repetitive_hills)
+void Pile::find_repetitive_hills(uint16_t dataset_median) {
+    if (!owns_ctx_ && ctx_ != nullptr) return;       // a Graph's view: already annotated by the Graph
+    run_device();
+    if (ctx_ == nullptr || !dev_alive_) return;
+    if (rala_hip_find_repetitive_hills(ctx_, ctx_read_, begin_, end_, median_, p10_, dataset_median) != RALA_HIP_OK) {
+        die("find_repetitive_hills", ctx_);
+    }
+    uint64_t offs[2] = {0, 0};
+    rala_hip_get_intervals(ctx_, 2, offs, nullptr, nullptr);
+    std::vector<uint32_t> pairs(2 * offs[1] + 2), aux(offs[1] + 1);
+    rala_hip_get_intervals(ctx_, 2, offs, pairs.data(), aux.data());
+    repeat_hills_.clear();
+    repeat_hill_coverage_.clear();
+    for (uint64_t k = 0; k < offs[1]; ++k) {
+        repeat_hills_.emplace_back(pairs[2 * k], pairs[2 * k + 1]);
+        repeat_hill_coverage_.push_back(false);
     }
 }
 

@@ -25,6 +25,7 @@
 #include <vector>
 
 struct rala_hip_ctx;
+struct rala_hip_mg;
 
 namespace rala {
 
@@ -96,6 +97,7 @@ private:
 
     // device side
     rala_hip_ctx* ctx_;         // Graph's context (view) or own one-read context
+    rala_hip_mg* mg_ = nullptr; // multi-GPU Graph: the rank that owns this read's coverage
     bool owns_ctx_;
     uint64_t ctx_read_;         // read number inside ctx_
     std::vector<uint32_t> pending_bounds_;

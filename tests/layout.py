@@ -137,6 +137,17 @@ class _Graph:
     def run(self, op, arg=0):
         return int(self.f("run")(self.h, OPS[op], arg))
 
+    def print(self, kind):
+        """the graph in one of the reference's on-disk formats: 'csv', 'gfa', 'json' (piles as stand-ins)"""
+        k = {"csv": 0, "gfa": 1, "json": 2}[kind]
+        fn = self.f("print")
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_uint64]
+        fn.restype = ctypes.c_uint64
+        n = int(fn(self.h, k, None, 0))
+        buf = ctypes.create_string_buffer(n + 1)
+        fn(self.h, k, buf, n)
+        return buf.raw[:n]
+
     def node_data(self, node):
         n = int(self.f("node_data")(self.h, node, None, 0))
         buf = ctypes.create_string_buffer(n + 1)

@@ -166,17 +166,47 @@ def test_fullsize_properties(hip_ctx_factory, wl):
 
 
 @pytest.mark.parametrize("wl,world", [("c2", 4), ("c3", 8)])
-def test_fullsize_sharded_decomposition(hip_ctx_factory, wl, world):
-    """The multi-GPU decomposition (ranks played one after the other on this GPU, same C-ABI
-    calls as rala_amd/multi.py) at full size: every stage digest equals the oracle's."""
-    from test_gpu_sharded import simulate_sharded
+def test_fullsize_sharded_run(wl, world):
+    """The sharded run (rala_hip_mg_*: slices, owners, collectives through the in-process transport,
+    the ranks as host threads on this one GPU) at full size: every stage digest of every rank's
+    replicated result equals the oracle's."""
+    from test_gpu_sharded import Sharded
 
     want = load_digests(wl)
     ds = dataset(wl)
-    cg = simulate_sharded(hip_ctx_factory, ds, world)
-    got = stage_digests(cg, with_data=False)         # the coverage vectors live on the owner ranks
-    for k, v in got.items():
-        assert v == want[k], "%s sharded over %d ranks: stage %s differs from the oracle" % (wl, world, k)
+    sh = Sharded(ds, world)
+    try:
+        n_tr = sh.run()
+        assert n_tr == want["n_tr"]
+        valid = np.concatenate([r.context().valid() for r in sh.ranks])
+        assert dg(np.packbits(valid)) == want["valid"]
+        for r in (sh.ranks[0], sh.ranks[world - 1]):
+            ctx = r.context()
+            got = {}
+            p2 = ctx.piles()
+            got["piles2"] = dg(p2["begin"], p2["end"], p2["alive"])
+            for which, name in ((0, "ov"), (1, "int")):
+                lst = ctx.overlap_list(which)
+                got["n_%s_kept" % ("overlaps" if which == 0 else "internals")] = int(len(lst["src"]))
+                got[name] = dg(*[np.asarray(lst[k]).astype(np.uint32) for k in
+                                 ("src", "a_begin", "a_end", "b_begin", "b_end", "length", "type")])
+            g = ctx.graph()
+            got["nodes"] = dg(g["node_read"].astype(np.uint32))
+            got["n_edges"] = int(len(g["src"]))
+            got["edges"] = dg(g["src"].astype(np.uint32), g["dst"].astype(np.uint32), g["len"].astype(np.uint32),
+                              g["marked"].astype(np.uint8))
+            for k, v in got.items():
+                assert v == want[k], "%s sharded over %d ranks: stage %s differs from the oracle" % (wl, world, k)
+        # coverage vectors come from their owners: against a single-context run
+        reads = sample_reads(sh.ranks[0].context().piles()["alive"])[:40]
+        single = run(lambda: __import__("rala_amd.hip", fromlist=["Context"]).Context(0), ds)
+        single.construct()
+        for r in reads:
+            assert (sh.ranks[int(r) % world].pile_data(int(r)) == single.pile_data(int(r))).all(), int(r)
+        single.close()
+        print(wl, world, sh.ranks[0].timings())
+    finally:
+        sh.close()
 
 
 @pytest.mark.skipif(os.environ.get("RALA_SKIP_C5") == "1", reason="RALA_SKIP_C5=1")

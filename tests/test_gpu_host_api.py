@@ -41,6 +41,12 @@ def _lib():
     L.hp_overlap_trim_type.argtypes = [P, U32, U32, U32, P, P]
     L.hp_overlap_trim_type.restype = ctypes.c_int
     L.hp_overlap_from_mhap.argtypes = [U64, U64] + [U32] * 8 + [P]
+    L.hp_find_repetitive_hills.argtypes = [P, U64, ctypes.c_uint16]
+    L.hp_find_repetitive_hills.restype = None
+    L.hp_has_repetitive_hills.argtypes = [P, U64]
+    L.hp_has_repetitive_hills.restype = ctypes.c_int
+    L.hp_to_json.argtypes = [P, U64, ctypes.c_char_p, U64]
+    L.hp_to_json.restype = U64
     return L
 
 
@@ -68,6 +74,12 @@ class HostPiles:
         out = np.zeros(int(self.len[r]), dtype=np.uint16)
         n = self.L.hp_data(self.h, r, out.ctypes.data)
         return out[:n]
+
+    def to_json(self, r):
+        n = int(self.L.hp_to_json(self.h, r, None, 0))
+        buf = ctypes.create_string_buffer(n + 1)
+        self.L.hp_to_json(self.h, r, buf, n)
+        return buf.raw[:n].decode()
 
     def trim_type(self, a, b, strand, coords):
         c = np.ascontiguousarray(coords, dtype=np.uint32).copy()
@@ -162,6 +174,24 @@ def test_pile_objects_follow_the_reference_method_by_method(n, g, seed):
             assert (got["begin"], got["end"]) == (int(want["begin"][r]), int(want["end"][r])), r
             assert got["has_hill"] == 0
             assert (hp.data(r) == o.pile_data(r)).all(), r
+
+        # Pile::find_repetitive_hills (pile.cpp:500-566) with the data set median, on the stand-alone
+        # piles; then Pile::to_json (pile.cpp:632-663) - coverage, region, repeat hills, median, p10
+        n_rep = 0
+        for r in np.nonzero(alive)[0][:400]:
+            r = int(r)
+            for m in (med, max(1, med // 2), 1):        # (a data set median of 1 makes every bump a hill)
+                o.find_repetitive_hills(r, m)
+                L.hp_find_repetitive_hills(hp.h, r, m)
+                want_h = o.intervals(r, 2)
+                assert bool(L.hp_has_repetitive_hills(hp.h, r)) == (len(want_h) > 0), (r, m)
+            js = hp.to_json(r)
+            assert js == o.to_json(r), r
+            n_rep += len(want_h) > 0
+            import json as _json
+            d = _json.loads("{" + js + "}")[str(r)]           # what misc/plotter.py reads: y, b, e, h, m, p10
+            assert len(d["y"]) == int(ds.read_len[r]) and d["b"] == hp.get(r)["begin"] and len(d["h"]) == 2 * len(want_h)
+        assert n_rep > 0 or n < 250
 
         # Overlap::transmute / trim / type against the piles as they are now
         ov = ds.overlaps

@@ -76,6 +76,21 @@ def test_simplify_matches_oracle(n, g, seed):
     assert any(x[0] == "unitigs" and x[1] > 0 for x in la)
 
 
+def test_simplify_with_tips_bubbles_and_long_edges():
+    """a 20x data set on which every clean-up stage has work to do (most data sets of the suite
+    are so well covered that tips, bubbles and long edges do not occur): counts equal and > 0"""
+    prod, ora = _from_pipeline(2000, 1_000_000, 3)
+    la, lb = [], []
+    _simplify(prod, la)
+    _simplify(ora, lb)
+    assert la == lb
+    layout.assert_same_graph(prod, ora, "after simplify")
+    tips = sum(x[1] for x in la if x[0] == "loop") + sum(x[2] for x in la if x[0] == "round")
+    bubbles = sum(x[2] for x in la if x[0] == "loop")
+    long_edges = sum(x[1] for x in la if x[0] == "round")
+    assert tips > 0 and bubbles > 0 and long_edges > 0, (tips, bubbles, long_edges)
+
+
 @pytest.mark.parametrize("op,arg", [("tips", 0), ("bubbles", 0), ("unitigs", 0), ("shrink", 3), ("shrink", 42)])
 @pytest.mark.parametrize("n,g,seed", [(3000, 600_000, 21), (2000, 1_200_000, 33)])
 def test_single_stage_matches_oracle(n, g, seed, op, arg):
@@ -274,3 +289,54 @@ def test_layout_weights_and_long_edges(seed):
     _simplify(graphs[1], lb)
     assert la == lb
     layout.assert_same_graph(*graphs, "after simplify")
+
+
+@pytest.mark.parametrize("n,g,seed", [(3000, 600_000, 21), (2000, 1_000_000, 3)])
+def test_on_disk_formats_match_oracle(n, g, seed):
+    """print_csv / print_gfa / print_json (reference graph.cpp:2153-2297) field by field: the product's
+    writers against the restatement, on the graph as built, after the clean-up stages (edge weights
+    from the layout in the CSV) and after create_unitigs (unitig names in the GFA)"""
+    import json
+
+    prod, ora = _from_pipeline(n, g, seed)
+
+    def check(tag):
+        for kind in ("csv", "gfa", "json"):
+            a, b = prod.print(kind), ora.print(kind)
+            assert a == b, "%s %s differs at byte %d" % (tag, kind, next(i for i, (x, y) in enumerate(zip(a, b)) if x != y)
+                                                         if len(a) == len(b) else -1)
+        return prod.print("csv"), prod.print("gfa"), prod.print("json")
+
+    csv, gfa, js = check("as built")
+    nodes, edges = prod.dump()
+    # CSV: one line per reverse-complement node with edges, one per edge: "id LN:i:len RC:i:reads,...,1,eid len weight"
+    lines = csv.decode().splitlines()
+    e_lines = [l for l in lines if l.split(",")[2] == "1"]
+    assert len(e_lines) == int(edges["alive"].sum())
+    eid, length, weight = e_lines[0].split(",")[3].split()
+    assert int(length) == int(edges["length"][int(eid)]) and float(weight) == 0.0
+    # GFA: S lines carry the sequence and LN / RC tags, L lines the overlap length <len(begin) - edge length>M
+    g_lines = gfa.decode().splitlines()
+    s_lines = [l.split("\t") for l in g_lines if l.startswith("S")]
+    l_lines = [l.split("\t") for l in g_lines if l.startswith("L")]
+    assert len(l_lines) == int(edges["alive"].sum()) and all(x[3].startswith("LN:i:") and int(x[3][5:]) == len(x[2]) for x in s_lines)
+    assert all(x[2] in "+-" and x[4] in "+-" and x[5].endswith("M") for x in l_lines)
+    # JSON: what misc/plotter.py walks - nodes{<read>: {n, p: [[read, node, rc, overlap]...], s: [...]}}, piles{}
+    d = json.loads(js)
+    assert set(d) <= {"nodes", "piles"}
+    for key, v in d["nodes"].items():
+        assert set(v) == {"n", "p", "s"} and all(len(x) == 4 for x in v["p"] + v["s"])
+        assert key in d["piles"]
+    # unitigs get names Utg<k> in the GFA (graph.cpp:2190-2196); chains between junctions collapse
+    assert prod.run("unitigs") == ora.run("unitigs")
+    csv1, gfa1, _ = check("after create_unitigs")
+    assert b"\tUtg0\t" in gfa1 and csv1 != csv
+    # layout rounds put weights on the edges (CSV column 3, third field)
+    for gph in (prod, ora):
+        gph.postprocess(0)
+    csv2, _, _ = check("after postprocess")
+    weights = [float(l.split(",")[3].split()[2]) for l in csv2.decode().splitlines() if l.split(",")[2] == "1"]
+    assert weights and (max(weights) > 0 or seed == 21)       # (the 50x data set has nothing to lay out)
+    _simplify(prod, [])
+    _simplify(ora, [])
+    check("after simplify")
