@@ -220,6 +220,16 @@ def main():
                          "stage": stage_roofline(stage, n_ovl, sum_len, ds.n_reads, world if use_dist else 1)},
             "stage_ms": stage,
         }
+        # the second figure of SURVEY 8(d), from PAF text (ingest + upload + device): measured by
+        # tools/e2e_bench.py (it writes a 3 GB file first), replayed here from its last committed run
+        try:
+            with open(os.path.join(ROOT, "profiles", "r02_%s_e2e_from_paf.json" % args.workload)) as f:
+                e2e = json.load(f)
+            out["end_to_end_from_paf"] = {"value": e2e["overlaps_per_s"], "unit": "overlaps/s", "threads": e2e["threads"],
+                                          "ms_parse": e2e["ms_parse"], "ms_upload": e2e["ms_upload"],
+                                          "source": "profiles/r02_%s_e2e_from_paf.json (tools/e2e_bench.py; not re-measured in this run)" % args.workload}
+        except Exception:
+            pass
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline("c2" if args.workload != "c1" else "c1")
         print(json.dumps(out), flush=True)

@@ -170,6 +170,8 @@ bool read_mhap(const std::string& path, const std::function<void(const MhapRecor
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <emmintrin.h>
+
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -182,9 +184,23 @@ namespace io {
 namespace {
 
 inline uint64_t hash_bytes(const char* p, size_t n) {
-    uint64_t h = 1469598103934665603ull;
-    for (size_t i = 0; i < n; ++i) { h ^= (unsigned char)p[i]; h *= 1099511628211ull; }
-    return h ^ (h >> 29);
+    // 8 bytes at a time (names are short: the byte-wise FNV chain cost more than the table probe)
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ (n * 0xFF51AFD7ED558CCDull);
+    while (n >= 8) {
+        uint64_t w;
+        memcpy(&w, p, 8);
+        h = (h ^ w) * 0xC2B2AE3D27D4EB4Full;
+        h ^= h >> 29;
+        p += 8; n -= 8;
+    }
+    if (n) {
+        uint64_t w = 0;
+        memcpy(&w, p, n);
+        h = (h ^ w) * 0xC2B2AE3D27D4EB4Full;
+        h ^= h >> 29;
+    }
+    h *= 0x165667B19E3779F9ull;
+    return h ^ (h >> 32);
 }
 
 inline const char* parse_u32(const char* p, const char* e, uint32_t& v) {
@@ -194,94 +210,175 @@ inline const char* parse_u32(const char* p, const char* e, uint32_t& v) {
     return p;
 }
 
-struct alignas(256) Chunk {        // one per thread, appended to on every line: no shared cache lines
-    OverlapColumns cols;
+// a line whose numbers are parsed and whose names are located, waiting for its table look-ups
+struct PendingLine {
+    const char* q; const char* t;       // name tokens
+    uint32_t qn, tn;
+    uint64_t qh, th;                    // their hashes (qh only when the query differs from the line before)
+    uint32_t ql, qb, qe, tl, tb, te, ol;
+    uint8_t strand;
+    bool new_query;
+};
+
+constexpr int kBatch = 16;
+
+struct alignas(256) Chunk {        // one per piece of the file: no shared cache lines
+    // where this piece's records go in the final columns (its slot is sized by its line count)
+    uint32_t *a_id = nullptr, *b_id = nullptr, *a_begin = nullptr, *a_end = nullptr, *b_begin = nullptr, *b_end = nullptr,
+             *length = nullptr;
+    uint8_t* strand = nullptr;
+    size_t n = 0;                   // records written
     int64_t error_read = -1;        // first line of this chunk with a length mismatch
     // overlap files are grouped by query: the previous line's query name and its id
     const char* last_q = nullptr;
     size_t last_qn = 0;
     uint64_t last_a = ~0ull;
+    PendingLine pend[kBatch];
+    int n_pend = 0;
 };
 
+// the batch's look-ups (their buckets were prefetched while the lines were parsed), in line order
+inline void resolve_batch(const NameTable& names, const std::vector<uint32_t>& read_len, bool check_lengths, Chunk& c) {
+    for (int k = 0; k < c.n_pend; ++k) {
+        const PendingLine& L = c.pend[k];
+        if (L.new_query) c.last_a = names.find(L.q, L.qn, L.qh);
+        const uint64_t a = c.last_a;
+        const uint64_t b = names.find(L.t, L.tn, L.th);
+        const uint32_t ia = a == ~0ull ? 0xFFFFFFFFu : (uint32_t)a;
+        const uint32_t ib = b == ~0ull ? 0xFFFFFFFFu : (uint32_t)b;
+        if (check_lengths && c.error_read < 0) {
+            if (ia != 0xFFFFFFFFu && L.ql != read_len[ia]) c.error_read = ia;
+            else if (ia != 0xFFFFFFFFu && ib != 0xFFFFFFFFu && L.tl != read_len[ib]) c.error_read = ib;
+        }
+        const size_t w = c.n++;
+        c.a_id[w] = ia; c.b_id[w] = ib;
+        c.a_begin[w] = L.qb; c.a_end[w] = L.qe;
+        c.b_begin[w] = L.tb; c.b_end[w] = L.te;
+        c.length[w] = L.ol;
+        c.strand[w] = L.strand;
+    }
+    c.n_pend = 0;
+}
 
-// one line [p, e) (no newline); returns false if it is not a 12-column record
+// decimal digits [p, p + d) -> value; d <= 8, eight readable bytes end at p + d (the caller keeps
+// eight bytes of slack in front of the first line).  All-digit check, then three multiplications
+// (the byte-at-a-time loop with its data-dependent branches was most of a line's cost).
+inline bool digits8(const char* p, uint32_t d, uint32_t& v) {
+    uint64_t w;
+    memcpy(&w, p + d - 8, 8);                           // the number's last digit is the top byte
+    const uint64_t keep = d == 8 ? ~0ull : ~0ull << (8 * (8 - d));
+    w = (w & keep) | (0x3030303030303030ull & ~keep);
+    if ((((w + 0x4646464646464646ull) | (w - 0x3030303030303030ull)) & 0x8080808080808080ull) != 0) return false;
+    w -= 0x3030303030303030ull;
+    w = (w * 10) + (w >> 8);
+    w = (((w & 0x000000FF000000FFull) * 0x000F424000000064ull) + (((w >> 16) & 0x000000FF000000FFull) * 0x0000271000000001ull)) >> 32;
+    v = (uint32_t)w;
+    return true;
+}
+
+inline void field_u32(const char* b, const char* e, uint32_t& v) {
+    // same value as parse_u32: the leading digits of the field
+    const uint32_t d = (uint32_t)(e - b);
+    if (d >= 1 && d <= 8 && digits8(b, d, v)) return;
+    parse_u32(b, e, v);
+}
+
+// one line [p, e) (no newline; at least 8 readable bytes in front of p and 16 behind e); returns
+// false if it is not a 12-column record.  The tabs come from 16-byte compares (SSE2, baseline of
+// x86-64), a name token ends at its first blank, numbers through digits8.
 inline bool parse_paf_line(const char* p, const char* e, const NameTable& names, const std::vector<uint32_t>& read_len,
                            bool check_lengths, Chunk& c) {
-    const char* f[13];
-    int nf = 0;
-    f[nf++] = p;
-    for (const char* q = p; q < e && nf < 13; ++q) {
-        if (*q == '\t') f[nf++] = q + 1;
+    PendingLine& L = c.pend[c.n_pend];
+    const char* tab[12];
+    int nt = 0;
+    {
+        const __m128i tabs = _mm_set1_epi8('\t');
+        for (const char* q = p; q < e && nt < 12; q += 16) {
+            uint32_t m = (uint32_t)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_loadu_si128((const __m128i*)q), tabs));
+            while (m && nt < 12) {
+                const char* at = q + __builtin_ctz(m);
+                if (at >= e) { m = 0; break; }
+                tab[nt++] = at;
+                m &= m - 1;
+            }
+        }
     }
-    if (nf < 12) return false;
-    auto token_end = [&](int k) {                       // names are cut at the first whitespace
-        const char* end = k + 1 < nf ? f[k + 1] - 1 : e;
-        const char* q = f[k];
-        while (q < end && *q != ' ' && *q != '\t') ++q;
-        return q;
+    if (nt < 11) return false;                       // fewer than 12 columns
+    auto name_end = [](const char* b, const char* e2) {
+        const char* sp = (const char*)memchr(b, ' ', (size_t)(e2 - b));
+        return sp ? sp : e2;
     };
-    uint32_t ql, qb, qe, tl, tb, te, ol;
-    parse_u32(f[1], e, ql); parse_u32(f[2], e, qb); parse_u32(f[3], e, qe);
-    parse_u32(f[6], e, tl); parse_u32(f[7], e, tb); parse_u32(f[8], e, te);
-    parse_u32(f[10], e, ol);
-    const char orientation = f[4] < e && *f[4] != '\t' ? *f[4] : '+';
-    const size_t qn = (size_t)(token_end(0) - f[0]);
-    if (c.last_q == nullptr || qn != c.last_qn || memcmp(c.last_q, f[0], qn) != 0) {
-        c.last_a = names.find(f[0], qn);
-        c.last_q = f[0];
-        c.last_qn = qn;
+    L.q = p;
+    L.qn = (uint32_t)(name_end(p, tab[0]) - p);
+    field_u32(tab[0] + 1, tab[1], L.ql);
+    field_u32(tab[1] + 1, tab[2], L.qb);
+    field_u32(tab[2] + 1, tab[3], L.qe);
+    L.strand = (tab[3] + 1 < tab[4] ? tab[3][1] : '+') == '+' ? 0 : 1;
+    L.t = tab[4] + 1;
+    L.tn = (uint32_t)(name_end(L.t, tab[5]) - L.t);
+    field_u32(tab[5] + 1, tab[6], L.tl);
+    field_u32(tab[6] + 1, tab[7], L.tb);
+    field_u32(tab[7] + 1, tab[8], L.te);
+    field_u32(tab[9] + 1, tab[10], L.ol);            // column 11: alignment length
+    L.new_query = c.last_q == nullptr || L.qn != c.last_qn || memcmp(c.last_q, L.q, L.qn) != 0;
+    if (L.new_query) {
+        L.qh = NameTable::hash(L.q, L.qn);
+        names.prefetch(L.qh);
+        c.last_q = L.q;
+        c.last_qn = L.qn;
     }
-    const uint64_t a = c.last_a;
-    const uint64_t b = names.find(f[5], (size_t)(token_end(5) - f[5]));
-    const uint32_t ia = a == ~0ull ? 0xFFFFFFFFu : (uint32_t)a;
-    const uint32_t ib = b == ~0ull ? 0xFFFFFFFFu : (uint32_t)b;
-    if (c.error_read < 0) {
-        if (check_lengths && ia != 0xFFFFFFFFu && ql != read_len[ia]) c.error_read = ia;
-        else if (check_lengths && ia != 0xFFFFFFFFu && ib != 0xFFFFFFFFu && tl != read_len[ib]) c.error_read = ib;
-    }
-    c.cols.a_id.push_back(ia); c.cols.b_id.push_back(ib);
-    c.cols.a_begin.push_back(qb); c.cols.a_end.push_back(qe);
-    c.cols.b_begin.push_back(tb); c.cols.b_end.push_back(te);
-    c.cols.length.push_back(ol);
-    c.cols.strand.push_back(orientation == '+' ? 0 : 1);
+    L.th = NameTable::hash(L.t, L.tn);
+    names.prefetch(L.th);
+    if (++c.n_pend == kBatch) resolve_batch(names, read_len, check_lengths, c);
     return true;
 }
 
 }  // namespace
 
+uint64_t NameTable::hash(const char* p, size_t n) { return hash_bytes(p, n); }
+
+NameTable::~NameTable() {
+    if (bucket_) free_block(bucket_, n_bucket_ * sizeof(Bucket));
+}
+
 void NameTable::build(const std::vector<std::string>& names) {
     uint64_t cap = 16;
     while (cap < 2 * names.size() + 2) cap <<= 1;
     mask_ = cap - 1;
-    slot_.assign(cap, 0);
-    off_.resize(names.size()); len_.resize(names.size());
+    if (bucket_) free_block(bucket_, n_bucket_ * sizeof(Bucket));
+    n_bucket_ = cap;
+    bucket_ = (Bucket*)allocate_block(cap * sizeof(Bucket));
+    memset((void*)bucket_, 0, cap * sizeof(Bucket));
     arena_.clear();
-    for (size_t i = 0; i < names.size(); ++i) {
-        off_[i] = (uint32_t)arena_.size();
-        len_[i] = (uint32_t)names[i].size();
-        arena_ += names[i];
-    }
     // a later duplicate name replaces an earlier one, like unordered_map::operator[] in the
     // reference (src/graph.cpp:262)
     for (size_t i = 0; i < names.size(); ++i) {
-        uint64_t h = hash_bytes(names[i].data(), names[i].size()) & mask_;
-        for (;; h = (h + 1) & mask_) {
-            if (slot_[h] == 0) { slot_[h] = i + 1; break; }
-            const uint64_t j = slot_[h] - 1;
-            if (len_[j] == names[i].size() && memcmp(arena_.data() + off_[j], names[i].data(), len_[j]) == 0) {
-                slot_[h] = i + 1;
+        const std::string& s = names[i];
+        const uint64_t h = hash_bytes(s.data(), s.size());
+        Bucket nb = Bucket();
+        nb.hash32 = (uint32_t)(h >> 32); nb.id1 = (uint32_t)(i + 1); nb.len = (uint32_t)s.size(); nb.off = (uint32_t)arena_.size();
+        memcpy(nb.head, s.data(), std::min<size_t>(16, s.size()));
+        for (uint64_t k = h & mask_;; k = (k + 1) & mask_) {
+            Bucket& b = bucket_[k];
+            if (b.id1 == 0) { arena_ += s; b = nb; break; }
+            if (b.hash32 == nb.hash32 && b.len == nb.len && memcmp(arena_.data() + b.off, s.data(), b.len) == 0) {
+                b.id1 = nb.id1;                  // same name again: the later read takes it
                 break;
             }
         }
     }
 }
 
-uint64_t NameTable::find(const char* p, size_t n) const {
-    if (slot_.empty()) return ~0ull;
-    for (uint64_t h = hash_bytes(p, n) & mask_;; h = (h + 1) & mask_) {
-        if (slot_[h] == 0) return ~0ull;
-        const uint64_t j = slot_[h] - 1;
-        if (len_[j] == n && memcmp(arena_.data() + off_[j], p, n) == 0) return j;
+uint64_t NameTable::find(const char* p, size_t n, uint64_t h) const {
+    if (!bucket_) return ~0ull;
+    const uint32_t h32 = (uint32_t)(h >> 32);
+    for (uint64_t k = h & mask_;; k = (k + 1) & mask_) {
+        const Bucket& b = bucket_[k];
+        if (b.id1 == 0) return ~0ull;
+        if (b.hash32 != h32 || b.len != n) continue;
+        if (n <= 16 ? memcmp(b.head, p, n) == 0 : (memcmp(b.head, p, 16) == 0 && memcmp(arena_.data() + b.off, p, n) == 0)) {
+            return (uint64_t)b.id1 - 1;
+        }
     }
 }
 
@@ -313,116 +410,155 @@ bool read_paf_parallel(const std::string& path, const NameTable& names, const st
     if (fstat(fd, &st) != 0) { close(fd); return false; }
     const size_t size = (size_t)st.st_size;
     if (size == 0) { close(fd); return true; }
-
-    // one chunk of the file per thread, read with pread into the thread's own buffer (page faults
-    // of a shared mapping serialise on the address-space lock when many threads take them)
-    // more chunks than threads, handed out through a counter: threads that are descheduled (a
-    // container's CPU quota throttles in bursts) do not hold the others up
-    const uint32_t n_thr = (uint32_t)std::max<size_t>(1, std::min<size_t>(std::max(1u, num_threads), size / (1 << 20) + 1));
-    const uint32_t T = (uint32_t)std::max<size_t>(n_thr, std::min<size_t>((size_t)n_thr * 8, size / (4 << 20) + 1));
-    const auto t_start = std::chrono::steady_clock::now();
-    std::vector<Chunk> chunks(T);
-    std::vector<int> failed(T, 0);
-    std::vector<double> t_read(T, 0.0), t_parse(T, 0.0);
-    auto work = [&](uint32_t t) {
-        const auto w0 = std::chrono::steady_clock::now();
-        const size_t lo = size * t / T, hi = size * (t + 1) / T;
-        // a chunk owns the lines that start inside [lo, hi); the last of them may end beyond hi
-        const size_t from = lo ? lo - 1 : 0;
-        std::vector<char, UninitAllocator<char>> buf;
-        size_t have = 0, want = (hi - from) + (1 << 16);
-        bool eof = false;
-        auto fill = [&](size_t upto) {
-            upto = std::min(upto, size - from);
-            if (buf.size() < upto) buf.resize(upto);
-            while (have < upto) {
-                const ssize_t n = pread(fd, buf.data() + have, upto - have, (off_t)(from + have));
-                if (n <= 0) { failed[t] = 1; eof = true; return; }
-                have += (size_t)n;
-            }
-            if (from + have >= size) eof = true;
-        };
-        fill(want);
-        if (failed[t]) return;
-        const auto w1 = std::chrono::steady_clock::now();
-        t_read[t] = std::chrono::duration<double, std::milli>(w1 - w0).count();
-        const char* base = buf.data() - from;          // base[x] = byte x of the file
-        size_t p = lo;
-        if (t > 0) {
-            const char* nl = (const char*)memchr(buf.data(), '\n', have);
-            // no newline in the whole chunk: the line belongs to an earlier chunk
-            if (!nl) { if (!eof) { /* a line longer than the chunk + 64 KiB: not a PAF record */ } return; }
-            p = (size_t)(nl - buf.data()) + from + 1;
-        }
-        Chunk& c = chunks[t];
-        const size_t guess = (hi > lo ? hi - lo : 0) / 48 + 16;      // a PAF line is rarely shorter
-        c.cols.a_id.reserve(guess); c.cols.b_id.reserve(guess); c.cols.a_begin.reserve(guess);
-        c.cols.a_end.reserve(guess); c.cols.b_begin.reserve(guess); c.cols.b_end.reserve(guess);
-        c.cols.length.reserve(guess); c.cols.strand.reserve(guess);
-        while (p < hi) {
-            const char* nl = (const char*)memchr(base + p, '\n', from + have - p);
-            while (!nl && !eof) {                      // the line runs past what was read
-                fill(have + (1 << 20));
-                if (failed[t]) return;
-                base = buf.data() - from;
-                c.last_q = nullptr;                    // the buffer may have moved
-                nl = (const char*)memchr(base + p, '\n', from + have - p);
-            }
-            const size_t e = nl ? (size_t)(nl - base) : from + have;
-            size_t le = e;
-            if (le > p && base[le - 1] == '\r') --le;
-            if (le > p) parse_paf_line(base + p, base + le, names, read_len, check_lengths, c);
-            p = e + 1;
-        }
-        t_parse[t] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w1).count();
-    };
-    std::atomic<uint32_t> next(0);
-    auto pull = [&](auto&& fn) {
-        for (uint32_t t = next.fetch_add(1); t < T; t = next.fetch_add(1)) fn(t);
-    };
-    std::vector<std::thread> threads;
-    for (uint32_t k = 1; k < n_thr; ++k) threads.emplace_back([&] { pull(work); });
-    pull(work);
-    for (auto& th : threads) th.join();
-    close(fd);
-    for (uint32_t t = 0; t < T; ++t) if (failed[t]) return false;
     const bool trace = getenv("RALA_IO_TRACE") != nullptr;
-    const auto t_parsed = std::chrono::steady_clock::now();
+    const auto t_start = std::chrono::steady_clock::now();
 
-    size_t total = out.size();
-    for (const auto& c : chunks) total += c.cols.size();
-    std::vector<size_t> at(T);
-    size_t run = out.size();
-    for (uint32_t t = 0; t < T; ++t) { at[t] = run; run += chunks[t].cols.size(); }
-    out.a_id.resize(total); out.b_id.resize(total); out.a_begin.resize(total); out.a_end.resize(total);
-    out.b_begin.resize(total); out.b_end.resize(total); out.length.resize(total); out.strand.resize(total);
-    auto gather = [&](uint32_t t) {
-        const OverlapColumns& c = chunks[t].cols;
-        const size_t n = c.size();
-        if (!n) return;
-        memcpy(out.a_id.data() + at[t], c.a_id.data(), n * 4); memcpy(out.b_id.data() + at[t], c.b_id.data(), n * 4);
-        memcpy(out.a_begin.data() + at[t], c.a_begin.data(), n * 4); memcpy(out.a_end.data() + at[t], c.a_end.data(), n * 4);
-        memcpy(out.b_begin.data() + at[t], c.b_begin.data(), n * 4); memcpy(out.b_end.data() + at[t], c.b_end.data(), n * 4);
-        memcpy(out.length.data() + at[t], c.length.data(), n * 4); memcpy(out.strand.data() + at[t], c.strand.data(), n);
+    // The file is taken in windows (all of it unless it is very large).  A window is cut into
+    // pieces, more pieces than threads, handed out through a counter (threads that are descheduled -
+    // a container's CPU quota throttles in bursts - do not hold the others up).  Two phases:
+    //   1. every piece is read with pread into its own buffer (page faults of a shared mapping
+    //      serialise on the address-space lock) and its lines are counted;
+    //   2. the counts give every piece its slot in the final columns and the pieces are parsed
+    //      straight into it - no per-piece vectors, no gather pass, nothing to free but the text.
+    // A piece owns the lines that START inside it.  Lines that turn out not to be records leave a
+    // gap at the end of the piece's slot; gaps are closed afterwards (they are rare).
+    const uint32_t n_thr = (uint32_t)std::max<size_t>(1, std::min<size_t>(std::max(1u, num_threads), size / (1 << 20) + 1));
+    const size_t kWindow = (size_t)8 << 30;
+    constexpr size_t kFront = 8, kBack = 16;      // slack around the text for the line parser's wide loads
+    std::vector<std::thread> threads;
+    auto run = [&](uint32_t T, auto&& fn) {
+        std::atomic<uint32_t> next(0);
+        auto pull = [&] { for (uint32_t t = next.fetch_add(1); t < T; t = next.fetch_add(1)) fn(t); };
+        threads.clear();
+        for (uint32_t k = 1; k < n_thr; ++k) threads.emplace_back(pull);
+        pull();
+        for (auto& th : threads) th.join();
     };
-    threads.clear();
-    next = 0;
-    for (uint32_t k = 1; k < n_thr; ++k) threads.emplace_back([&] { pull(gather); });
-    pull(gather);
-    for (auto& th : threads) th.join();
-    if (length_error) {
-        for (const auto& c : chunks) {
-            if (c.error_read >= 0) { *length_error = c.error_read; break; }
+    struct Piece {
+        size_t lo = 0, hi = 0;          // file positions this piece owns line starts in
+        size_t from = 0, have = 0;      // the bytes in memory: file positions [from, from + have)
+        std::vector<char, UninitAllocator<char>> raw;
+        size_t first = 0;               // file position of the first owned line (== hi: none)
+        size_t lines = 0;               // upper bound of the records (non-empty lines)
+        bool failed = false;
+    };
+    double ms_read = 0, ms_parse = 0, ms_close = 0;
+    int64_t first_error = -1;
+    for (size_t w_lo = 0; w_lo < size; w_lo += kWindow) {
+        const size_t w_hi = std::min(size, w_lo + kWindow);
+        const size_t w_size = w_hi - w_lo;
+        const uint32_t T = (uint32_t)std::max<size_t>(n_thr, std::min<size_t>((size_t)n_thr * 8, w_size / (4 << 20) + 1));
+        std::vector<Piece> piece(T);
+        std::vector<Chunk> chunks(T);
+        const auto p0 = std::chrono::steady_clock::now();
+        // ---- phase 1: read, find the owned lines, count them
+        run(T, [&](uint32_t t) {
+            Piece& P = piece[t];
+            P.lo = w_lo + w_size * t / T;
+            P.hi = w_lo + w_size * (t + 1) / T;
+            P.from = P.lo ? P.lo - 1 : 0;              // the byte in front tells whether lo starts a line
+            bool eof = false;
+            auto fill = [&](size_t upto) {
+                upto = std::min(upto, size - P.from);
+                if (P.raw.size() < upto + kFront + kBack) {
+                    std::vector<char, UninitAllocator<char>> bigger(upto + kFront + kBack);
+                    if (P.have) memcpy(bigger.data() + kFront, P.raw.data() + kFront, P.have);
+                    P.raw.swap(bigger);
+                    memset(P.raw.data(), 0, kFront);
+                }
+                while (P.have < upto) {
+                    const ssize_t n = pread(fd, P.raw.data() + kFront + P.have, upto - P.have, (off_t)(P.from + P.have));
+                    if (n <= 0) { P.failed = true; eof = true; return; }
+                    P.have += (size_t)n;
+                }
+                if (P.from + P.have >= size) eof = true;
+            };
+            fill((P.hi - P.from) + (1 << 16));
+            if (P.failed) return;
+            const char* text = P.raw.data() + kFront;
+            size_t p = P.lo;
+            if (P.lo > 0) {
+                const char* nl = (const char*)memchr(text, '\n', P.have);
+                // no newline at all: the line belongs to an earlier piece (and is longer than this one)
+                p = nl ? (size_t)(nl - text) + P.from + 1 : P.hi;
+            }
+            P.first = std::min(p, P.hi);
+            // the last owned line may end beyond what was read
+            while (p < P.hi) {
+                const char* base = P.raw.data() + kFront - P.from;
+                const char* nl = (const char*)memchr(base + p, '\n', P.from + P.have - p);
+                if (!nl) {
+                    if (eof) { ++P.lines; break; }
+                    fill(P.have + (1 << 20));
+                    if (P.failed) return;
+                    continue;
+                }
+                const size_t e = (size_t)(nl - base);
+                if (e > p) ++P.lines;
+                p = e + 1;
+            }
+        });
+        for (const Piece& P : piece) if (P.failed) { close(fd); return false; }
+        const auto p1 = std::chrono::steady_clock::now();
+        // ---- slots in the final columns
+        std::vector<size_t> at(T + 1);
+        at[0] = out.size();
+        for (uint32_t t = 0; t < T; ++t) at[t + 1] = at[t] + piece[t].lines;
+        const size_t total = at[T];
+        out.a_id.resize(total); out.b_id.resize(total); out.a_begin.resize(total); out.a_end.resize(total);
+        out.b_begin.resize(total); out.b_end.resize(total); out.length.resize(total); out.strand.resize(total);
+        // ---- phase 2: parse into the slots
+        run(T, [&](uint32_t t) {
+            Piece& P = piece[t];
+            Chunk& c = chunks[t];
+            c.a_id = out.a_id.data() + at[t]; c.b_id = out.b_id.data() + at[t];
+            c.a_begin = out.a_begin.data() + at[t]; c.a_end = out.a_end.data() + at[t];
+            c.b_begin = out.b_begin.data() + at[t]; c.b_end = out.b_end.data() + at[t];
+            c.length = out.length.data() + at[t]; c.strand = out.strand.data() + at[t];
+            const char* base = P.raw.data() + kFront - P.from;
+            const size_t end_of_text = P.from + P.have;
+            size_t p = P.first;
+            while (p < P.hi) {
+                const char* nl = (const char*)memchr(base + p, '\n', end_of_text - p);
+                const size_t e = nl ? (size_t)(nl - base) : end_of_text;
+                size_t le = e;
+                if (le > p && base[le - 1] == '\r') --le;
+                if (le > p) parse_paf_line(base + p, base + le, names, read_len, check_lengths, c);
+                p = e + 1;
+            }
+            resolve_batch(names, read_len, check_lengths, c);
+            std::vector<char, UninitAllocator<char>>().swap(P.raw);      // (freed by the thread that used it)
+        });
+        const auto p2 = std::chrono::steady_clock::now();
+        // ---- close the gaps left by lines that were not records
+        size_t w = at[0];
+        bool gaps = false;
+        for (uint32_t t = 0; t < T; ++t) {
+            const size_t n = chunks[t].n;
+            if (gaps && n) {
+                memmove(out.a_id.data() + w, out.a_id.data() + at[t], n * 4); memmove(out.b_id.data() + w, out.b_id.data() + at[t], n * 4);
+                memmove(out.a_begin.data() + w, out.a_begin.data() + at[t], n * 4); memmove(out.a_end.data() + w, out.a_end.data() + at[t], n * 4);
+                memmove(out.b_begin.data() + w, out.b_begin.data() + at[t], n * 4); memmove(out.b_end.data() + w, out.b_end.data() + at[t], n * 4);
+                memmove(out.length.data() + w, out.length.data() + at[t], n * 4); memmove(out.strand.data() + w, out.strand.data() + at[t], n);
+            }
+            w += n;
+            if (n != piece[t].lines) gaps = true;
+            if (first_error < 0 && chunks[t].error_read >= 0) first_error = chunks[t].error_read;
         }
+        if (w != total) {
+            out.a_id.resize(w); out.b_id.resize(w); out.a_begin.resize(w); out.a_end.resize(w);
+            out.b_begin.resize(w); out.b_end.resize(w); out.length.resize(w); out.strand.resize(w);
+        }
+        const auto p3 = std::chrono::steady_clock::now();
+        ms_read += std::chrono::duration<double, std::milli>(p1 - p0).count();
+        ms_parse += std::chrono::duration<double, std::milli>(p2 - p1).count();
+        ms_close += std::chrono::duration<double, std::milli>(p3 - p2).count();
     }
+    close(fd);
+    if (length_error) *length_error = first_error;
     if (trace) {
-        const auto t_done = std::chrono::steady_clock::now();
-        double avg_parse = 0;
-        for (double x : t_parse) avg_parse += x / T;
-        fprintf(stderr, "[io] %u threads, %u chunks: read + parse %.1f ms (slowest chunk: read %.1f ms, parse %.1f ms; mean parse %.1f ms), gather %.1f ms\n", n_thr, T,
-                std::chrono::duration<double, std::milli>(t_parsed - t_start).count(),
-                *std::max_element(t_read.begin(), t_read.end()), *std::max_element(t_parse.begin(), t_parse.end()), avg_parse,
-                std::chrono::duration<double, std::milli>(t_done - t_parsed).count());
+        fprintf(stderr, "[io] %u threads: read + count %.1f ms, parse %.1f ms, close gaps %.1f ms, total %.1f ms\n", n_thr, ms_read,
+                ms_parse, ms_close, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count());
     }
     return true;
 }

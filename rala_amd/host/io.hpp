@@ -37,17 +37,39 @@ bool has_suffix(const std::string& src, const std::string& suffix);
 // (the reference tokenises every line into a heap Overlap twice,
 // src/graph.cpp:328,443)
 
-// read name -> id, looked up straight from the bytes of the file (no std::string per field)
+// read name -> id, looked up straight from the bytes of the file (no std::string per field).
+// Open addressing over 32-byte buckets: hash, id, length and the first 16 bytes of the name sit
+// in ONE cache line, so a lookup of a name of up to 16 characters is one memory access (a table
+// of a million names does not fit any cache: with separate offset / length / arena arrays every
+// probe was four dependent misses); longer names confirm against the arena.  prefetch() lets a
+// caller start the bucket's load while it parses on (io.cpp: lines are resolved in batches).
 class NameTable {
 public:
     void build(const std::vector<std::string>& names);
-    // id of the name [p, p + n), or ~0ull
-    uint64_t find(const char* p, size_t n) const;
+    static uint64_t hash(const char* p, size_t n);
+    void prefetch(uint64_t h) const { if (bucket_) __builtin_prefetch(&bucket_[h & mask_]); }
+    // id of the name [p, p + n) whose hash is h, or ~0ull
+    uint64_t find(const char* p, size_t n, uint64_t h) const;
+    uint64_t find(const char* p, size_t n) const { return find(p, n, hash(p, n)); }
 private:
-    std::vector<uint64_t> slot_;        // name index + 1, 0 = empty
-    std::vector<uint32_t> off_, len_;
+    struct alignas(32) Bucket {
+        uint32_t hash32;        // high half of the hash
+        uint32_t id1;           // name index + 1, 0 = empty
+        uint32_t len;
+        uint32_t off;           // start of the name in arena_
+        char head[16];          // first min(len, 16) bytes, zero padded
+    };
+    // (2 MiB-aligned block marked for transparent huge pages: a probe of a 64 MB table would
+    // otherwise miss the TLB as well as the caches)
+    Bucket* bucket_ = nullptr;
+    size_t n_bucket_ = 0;
     std::string arena_;
     uint64_t mask_ = 0;
+public:
+    NameTable() = default;
+    ~NameTable();
+    NameTable(const NameTable&) = delete;
+    NameTable& operator=(const NameTable&) = delete;
 };
 
 // allocator whose resize() leaves new elements uninitialised (the readers overwrite all of them;
