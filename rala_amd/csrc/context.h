@@ -184,7 +184,8 @@ struct rala_hip_ctx {
     bool tail_on_device = false;          // results of the last construct live on the device
     bool host_stale = false;              // host mirrors (lists, graph, read state) need a download
     bool marks_on_device = false;         // transitive marks of the device graph not fetched yet
-    uint32_t t_n0 = 0, t_n1 = 0, t_rounds = 0, t_n_kept = 0, t_n_nodes = 0, t_n_edges = 0;
+    uint32_t t_n0 = 0, t_n1 = 0, t_rounds = 0, t_n_kept = 0, t_n_nodes = 0, t_n_edges = 0, t_n_alive = 0;
+    size_t t_med_tmp = 0;                 // bytes of d_med_tmp
     rala_hip::DevBuf<uint8_t> d_t_state, d_t_round, d_dirty, d_n_pits0, d_touched;
     rala_hip::DevBuf<uint16_t> d_cmed;
     rala_hip::DevBuf<uint64_t> d_med_keys[2];

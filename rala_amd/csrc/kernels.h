@@ -229,6 +229,12 @@ struct TailReads {
     const uint32_t* iv_slot;
     Interval* pool;
 };
+// sensitive pass on the device list (sens_kernels.hip)
+void launch_sens_filter(const TailList& L, const uint32_t* begin, const uint32_t* end, const uint8_t* n_rep,
+                        const uint32_t* rep_slot, const Interval* rep_pool, hipStream_t s);
+void launch_finalize_states(const TailList& L, const uint8_t* alive, hipStream_t s);
+void launch_scatter_component_medians(const uint32_t* alive_reads, const uint8_t* touched, const uint16_t* cmed, uint32_t n_alive,
+                                      uint16_t* out, hipStream_t s);
 void launch_break_hills(const TailReads& R, uint32_t n_reads, hipStream_t s);
 void launch_break_pits(const TailReads& R, const uint32_t* alive_reads, const uint8_t* touched, const uint16_t* comp_median,
                        uint32_t n_alive, hipStream_t s);

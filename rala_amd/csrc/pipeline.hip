@@ -541,6 +541,9 @@ bool is_valid_overlap(rala_hip_ctx* ctx, uint32_t r, uint32_t x, uint32_t y) {
 
 int materialize_host(rala_hip_ctx* ctx);
 void build_graph(rala_hip_ctx* ctx);
+TailList tail_list(rala_hip_ctx* ctx);
+int tail_components(rala_hip_ctx* ctx, const TailList& L, uint32_t n_alive);
+int gpu_tail_part_b(rala_hip_ctx* ctx);
 
 // Graph::preprocess(overlaps, sensitive path) (graph.cpp:882-1054).  Sensitive records:
 // a = query (original read, untrimmed coordinates), b = target (trimmed read of the -p run).
@@ -551,7 +554,10 @@ void build_graph(rala_hip_ctx* ctx);
 // rank): the target bounds travel to the owners in ONE all-to-all, the owners add the layers,
 // take the medians and - once the component medians are known everywhere - look for the repeat
 // hills; medians and hills are all-gathered, the hills' bridged flags all-reduced (max).
-int preprocess_repeats(rala_hip_ctx* cs, rala_hip_ctx* cl, Comm* comm, const rala_hip_overlaps* sens, uint64_t n_sens) {
+int preprocess_repeats(rala_hip_ctx* cs, rala_hip_ctx* cl, Comm* comm, const rala_hip_overlaps* sens, uint64_t n_sens,
+                       bool device_lists) {
+    // device_lists: the chimera stage left its lists, valid regions and liveness on the device
+    // (gpu_tail_part_a); components, the final filter and (afterwards) the graph stay there too
     rala_hip_ctx* ctx = cs;                               // error reporting (HIPCHECK / fail)
     const bool sharded = comm != nullptr;
     const uint32_t P = sharded ? comm->world() : 1u, me = sharded ? comm->rank() : 0u;
@@ -594,10 +600,12 @@ int preprocess_repeats(rala_hip_ctx* cs, rala_hip_ctx* cl, Comm* comm, const ral
         so.a_id = dev[0]; so.b_id = dev[1]; so.a_begin = dev[2]; so.a_end = dev[3];
         so.b_begin = dev[4]; so.b_end = dev[5]; so.length = dev[6]; so.strand = dev_strand; so.n = n_sens; so.base = 0;
     }
-    // current valid regions and liveness on the device (a host tail narrowed them on the host)
-    HIPCHECK(hipMemcpyAsync(cs->d_begin.p, cs->h_begin.data(), n * 4, hipMemcpyHostToDevice, s));
-    HIPCHECK(hipMemcpyAsync(cs->d_end.p, cs->h_end.data(), n * 4, hipMemcpyHostToDevice, s));
-    HIPCHECK(hipMemcpyAsync(cs->d_alive.p, cs->h_alive.data(), n, hipMemcpyHostToDevice, s));
+    if (!device_lists) {
+        // current valid regions and liveness on the device (a host tail narrowed them on the host)
+        HIPCHECK(hipMemcpyAsync(cs->d_begin.p, cs->h_begin.data(), n * 4, hipMemcpyHostToDevice, s));
+        HIPCHECK(hipMemcpyAsync(cs->d_end.p, cs->h_end.data(), n * 4, hipMemcpyHostToDevice, s));
+        HIPCHECK(hipMemcpyAsync(cs->d_alive.p, cs->h_alive.data(), n, hipMemcpyHostToDevice, s));
+    }
     // Overlap::transmute_ (overlap.cpp:84-114) + bounds of the targets, no +-15 (graph.cpp:929-933)
     for (int k = 0; k < 2; ++k) HIPCHECK(cs->d_sens_tb[k].ensure(n_sens));
     HIPCHECK(cs->d_sens_tuples.ensure(2 * n_sens + 8));
@@ -695,9 +703,11 @@ int preprocess_repeats(rala_hip_ctx* cs, rala_hip_ctx* cl, Comm* comm, const ral
         if (comm->all_gather(cs->d_gather[0].p, cs->d_gather[1].p, nl_pad * 4, s) != 0) return comm_fail("all-gather of the medians");
         launch_unpack_median((const uint32_t*)cs->d_gather[1].p, P, nl_pad, n, cs->d_median.p, cs->d_p10.p, s);
     }
-    HIPCHECK(hipMemcpyAsync(cs->h_median.data(), cs->d_median.p, n * 2, hipMemcpyDeviceToHost, s));
-    HIPCHECK(hipMemcpyAsync(cs->h_p10.data(), cs->d_p10.p, n * 2, hipMemcpyDeviceToHost, s));
-    HIPCHECK(stream_sync(cs, s));
+    if (!device_lists) {
+        HIPCHECK(hipMemcpyAsync(cs->h_median.data(), cs->d_median.p, n * 2, hipMemcpyDeviceToHost, s));
+        HIPCHECK(hipMemcpyAsync(cs->h_p10.data(), cs->d_p10.p, n * 2, hipMemcpyDeviceToHost, s));
+        HIPCHECK(stream_sync(cs, s));
+    }
     trc("rep: add_layers + median", targets.size());
     // first trim of the sensitive overlaps (graph.cpp:935-939)
     SensCoords sc;
@@ -709,13 +719,28 @@ int preprocess_repeats(rala_hip_ctx* cs, rala_hip_ctx* cl, Comm* comm, const ral
     trc("rep: first trim", n_sens);
     // component medians over the primary overlaps -> repeat hills (graph.cpp:971-1026)
     std::vector<uint32_t> members;
-    std::vector<uint16_t> med;
-    rc = component_medians(cs, members, med);
-    if (rc != RALA_HIP_OK) return rc;
-    {
+    if (!device_lists) {
+        std::vector<uint16_t> med;
+        rc = component_medians(cs, members, med);
+        if (rc != RALA_HIP_OK) return rc;
         std::vector<uint16_t> dm(n, 0);
         for (size_t k = 0; k < members.size(); ++k) dm[members[k]] = med[k];
         HIPCHECK(hipMemcpy(cs->d_dataset_median.p, dm.data(), n * 2, hipMemcpyHostToDevice));
+    } else {
+        // on the device list, in the rank space of the chimera stage (the new medians are in d_median)
+        const TailList L = tail_list(cs);
+        const uint32_t n_alive = cs->t_n_alive;
+        rc = tail_components(cs, L, n_alive);
+        if (rc != RALA_HIP_OK) return rc;
+        HIPCHECK(hipMemsetAsync(cs->d_dataset_median.p, 0, n * 2, s));
+        launch_scatter_component_medians(cs->d_alive_reads.p, cs->d_touched.p, cs->d_cmed.p, n_alive, cs->d_dataset_median.p, s);
+        // the members (reads with an overlap), for the launch classes of the hill kernel
+        HIPCHECK(cs->p_alive_reads.ensure(n_alive + 1));
+        HIPCHECK(cs->p_touched.ensure(n_alive + 1));
+        HIPCHECK(hipMemcpyAsync(cs->p_alive_reads.p, cs->d_alive_reads.p, (size_t)n_alive * 4, hipMemcpyDeviceToHost, s));
+        HIPCHECK(hipMemcpyAsync(cs->p_touched.p, cs->d_touched.p, n_alive, hipMemcpyDeviceToHost, s));
+        HIPCHECK(stream_sync(cs, s));
+        for (uint32_t q = 0; q < n_alive; ++q) if (cs->p_touched.p[q]) members.push_back(cs->p_alive_reads.p[q]);
     }
     trc("rep: component medians", members.size());
     if (!sharded) {
@@ -782,7 +807,9 @@ int preprocess_repeats(rala_hip_ctx* cs, rala_hip_ctx* cl, Comm* comm, const ral
     }
     trc("rep: download hills", n_hills);
     // overlaps that end inside a bridged edge hill are dropped (graph.cpp:1045-1051)
-    {
+    if (device_lists) {
+        launch_sens_filter(tail_list(cs), cs->d_begin.p, cs->d_end.p, cs->d_n_rep.p, cs->d_rep_slot.p, cs->d_rep_pool.p, s);
+    } else {
         size_t w = 0;
         for (size_t k = 0; k < cs->overlaps.size(); ++k) {
             const HostOvl& o = cs->overlaps[k];
@@ -800,34 +827,19 @@ int preprocess_repeats(rala_hip_ctx* cs, rala_hip_ctx* cl, Comm* comm, const ral
     return RALA_HIP_OK;
 }
 
-// the sensitive pass behind a device-resident chimera stage: lists to the host, repeats, graph
+// the sensitive pass behind the device-resident chimera stage (gpu_tail_part_a): repeats, final
+// filter, then the final list and the graph (gpu_tail_part_b) - nothing comes to the host
 int repeats_after_tail(rala_hip_ctx* cs, rala_hip_ctx* cl, Comm* comm, const rala_hip_overlaps* sens, uint64_t n_sens) {
     rala_hip_ctx* ctx = cs;
     hipStream_t s = cs->stream;
-    const uint32_t n_reads = (uint32_t)cs->n_reads;
     Trace trs;
-    const int rc6 = materialize_host(cs);
-    if (rc6 != RALA_HIP_OK) return rc6;
-    trs("sens: materialize_host");
-    cs->tail_on_device = false;
-    cs->host_stale = false;
-    // rank space of the component search: the reads that are still there
-    cs->alive_rank.assign(n_reads, 0xFFFFFFFFu);
-    cs->alive_reads.clear();
-    for (uint32_t r = 0; r < n_reads; ++r) {
-        if (!cs->h_alive[r]) continue;
-        cs->alive_rank[r] = (uint32_t)cs->alive_reads.size();
-        cs->alive_reads.push_back(r);
-    }
-    trs("sens: alive ranks");
-    const int rc3 = preprocess_repeats(cs, cl, comm, sens, n_sens);
+    launch_finalize_states(tail_list(cs), cs->d_alive.p, s);
+    const int rc3 = preprocess_repeats(cs, cl, comm, sens, n_sens, true);
     if (rc3 != RALA_HIP_OK) return rc3;
     trs("sens: preprocess_repeats");
-    build_graph(cs);
-    trs("sens: build_graph");
-    HIPCHECK(hipMemcpyAsync(cs->d_begin.p, cs->h_begin.data(), (size_t)n_reads * 4, hipMemcpyHostToDevice, s));
-    HIPCHECK(hipMemcpyAsync(cs->d_end.p, cs->h_end.data(), (size_t)n_reads * 4, hipMemcpyHostToDevice, s));
-    HIPCHECK(hipMemcpyAsync(cs->d_alive.p, cs->h_alive.data(), (size_t)n_reads, hipMemcpyHostToDevice, s));
+    const int rc4 = gpu_tail_part_b(cs);
+    if (rc4 != RALA_HIP_OK) return rc4;
+    trs("sens: final list + graph");
     HIPCHECK(stream_sync(cs, s));
     return RALA_HIP_OK;
 }
@@ -988,8 +1000,43 @@ int tail_death_scan(rala_hip_ctx* ctx, const TailList& L, uint32_t which, uint32
     return RALA_HIP_OK;
 }
 
-// Graph::preprocess (chimeras) + node/edge build with the survivor lists resident on the device
-int gpu_tail_run(rala_hip_ctx* ctx) {
+// connected components over the live overlaps of the device list (labels in the rank space of
+// d_rank / d_alive_reads) and, per read with an overlap, the median of the pile medians of its
+// component (graph.cpp:740-783): d_touched[rank], d_cmed[rank]
+int tail_components(rala_hip_ctx* ctx, const TailList& L, uint32_t n_alive) {
+    hipStream_t s = ctx->stream;
+    const uint32_t M = L.n;
+    HIPCHECK(hipMemsetAsync(ctx->d_touched.p, 0, n_alive, s));
+    launch_cc_edges(L, ctx->d_rank.p, ctx->d_cc_edges.p, ctx->d_touched.p, s);
+    launch_cc_init(ctx->d_cc_label.p, n_alive, s);
+    for (int k = 0; k < 2; ++k) {                               // sampled rounds, see cc_hook_kernel
+        launch_cc_hook(ctx->d_cc_edges.p, M, 1, ctx->d_cc_label.p, ctx->d_cc_flags.p + 7, s);
+        launch_cc_compress(ctx->d_cc_label.p, n_alive, s);
+    }
+    for (int it = 0;; ++it) {
+        // four hook + compress rounds per host check; a round that hooked nothing ends it
+        constexpr int kBatch = 4;
+        HIPCHECK(hipMemsetAsync(ctx->d_cc_flags.p, 0, kBatch * 4, s));
+        for (int k = 0; k < kBatch; ++k) {
+            launch_cc_hook(ctx->d_cc_edges.p, M, 0, ctx->d_cc_label.p, ctx->d_cc_flags.p + k, s);
+            launch_cc_compress(ctx->d_cc_label.p, n_alive, s);
+        }
+        uint32_t changed[kBatch];
+        HIPCHECK(d2h_small(ctx, changed, ctx->d_cc_flags.p, sizeof(changed), s));
+        HIPCHECK(stream_sync(ctx, s));
+        if (!changed[kBatch - 1]) break;
+        if (it > 10000) return fail(ctx, RALA_HIP_EDEVICE, "connected components did not converge");
+    }
+    // median of the pile medians per component (graph.cpp:777-783)
+    HIPCHECK(launch_component_medians(ctx->d_cc_label.p, ctx->d_touched.p, ctx->d_alive_reads.p, ctx->d_median.p, n_alive,
+                                      ctx->d_med_keys[0].p, ctx->d_med_keys[1].p, ctx->d_med_tmp.p, ctx->t_med_tmp,
+                                      ctx->d_cmed.p, s));
+    return RALA_HIP_OK;
+}
+
+// Graph::preprocess (chimeras) with the survivor lists resident on the device: everything up to
+// and including the in-order containment removal (graph.cpp:699-877)
+int gpu_tail_part_a(rala_hip_ctx* ctx) {
     hipStream_t s = ctx->stream;
     Trace trc;
     auto mark = [&](const char* what, size_t k = 0) {
@@ -1019,11 +1066,12 @@ int gpu_tail_run(rala_hip_ctx* ctx) {
     uint32_t n_alive = 0;
     HIPCHECK(d2h_small(ctx, &n_alive, ctx->d_t_tmp[1].p + n_reads, 4, s));
     HIPCHECK(stream_sync(ctx, s));
+    ctx->t_n_alive = n_alive;
     HIPCHECK(ctx->d_touched.ensure(n_alive)); HIPCHECK(ctx->d_cmed.ensure(n_alive));
     HIPCHECK(ctx->d_cc_edges.ensure(2 * (size_t)M)); HIPCHECK(ctx->d_cc_label.ensure(n_alive));
     HIPCHECK(ctx->d_med_keys[0].ensure(n_alive)); HIPCHECK(ctx->d_med_keys[1].ensure(n_alive));
-    const size_t med_tmp = component_median_workspace(n_alive);
-    HIPCHECK(ctx->d_med_tmp.ensure(med_tmp));
+    ctx->t_med_tmp = component_median_workspace(n_alive);
+    HIPCHECK(ctx->d_med_tmp.ensure(ctx->t_med_tmp));
     HIPCHECK(ctx->d_cc_flags.ensure(8));
     mark("tail: ranks", n_alive);
 
@@ -1036,34 +1084,9 @@ int gpu_tail_run(rala_hip_ctx* ctx) {
     uint32_t rounds = 0;
     for (;; ++rounds) {                                             // graph.cpp:738-829
         if (rounds >= 255) return fail(ctx, RALA_HIP_EDEVICE, "chimera loop did not settle");
-        // connected components over the live overlaps, labels in rank space
-        HIPCHECK(hipMemsetAsync(ctx->d_touched.p, 0, n_alive, s));
-        launch_cc_edges(L, ctx->d_rank.p, ctx->d_cc_edges.p, ctx->d_touched.p, s);
-        launch_cc_init(ctx->d_cc_label.p, n_alive, s);
-        for (int k = 0; k < 2; ++k) {                               // sampled rounds, see cc_hook_kernel
-            launch_cc_hook(ctx->d_cc_edges.p, M, 1, ctx->d_cc_label.p, ctx->d_cc_flags.p + 7, s);
-            launch_cc_compress(ctx->d_cc_label.p, n_alive, s);
-        }
-        for (int it = 0;; ++it) {
-            // four hook + compress rounds per host check; a round that hooked nothing ends it
-            constexpr int kBatch = 4;
-            HIPCHECK(hipMemsetAsync(ctx->d_cc_flags.p, 0, kBatch * 4, s));
-            for (int k = 0; k < kBatch; ++k) {
-                launch_cc_hook(ctx->d_cc_edges.p, M, 0, ctx->d_cc_label.p, ctx->d_cc_flags.p + k, s);
-                launch_cc_compress(ctx->d_cc_label.p, n_alive, s);
-            }
-            uint32_t changed[kBatch];
-            HIPCHECK(d2h_small(ctx, changed, ctx->d_cc_flags.p, sizeof(changed), s));
-            HIPCHECK(stream_sync(ctx, s));
-            if (!changed[kBatch - 1]) break;
-            if (it > 10000) return fail(ctx, RALA_HIP_EDEVICE, "connected components did not converge");
-        }
-        mark("tail: components");
-        // median of the pile medians per component (graph.cpp:777-783)
-        HIPCHECK(launch_component_medians(ctx->d_cc_label.p, ctx->d_touched.p, ctx->d_alive_reads.p, ctx->d_median.p, n_alive,
-                                          ctx->d_med_keys[0].p, ctx->d_med_keys[1].p, ctx->d_med_tmp.p, med_tmp,
-                                          ctx->d_cmed.p, s));
-        mark("tail: component medians");
+        const int rcc = tail_components(ctx, L, n_alive);
+        if (rcc != RALA_HIP_OK) return rcc;
+        mark("tail: components + medians");
         launch_break_pits(R, ctx->d_alive_reads.p, ctx->d_touched.p, ctx->d_cmed.p, n_alive, s);
         HIPCHECK(hipMemsetAsync(ctx->d_small.p + 2, 0, 4, s));
         launch_retrim(L, R, 1, rounds, ctx->d_small.p + 2, s);
@@ -1086,7 +1109,20 @@ int gpu_tail_run(rala_hip_ctx* ctx) {
         launch_kill_reads(death, ctx->d_alive.p, n_reads, s);
         mark("tail: containment scan", which);
     }
+    return RALA_HIP_OK;
+}
 
+// ... the final overlap list, nodes and edges (graph.cpp:553-632, :869-877) from the device list
+int gpu_tail_part_b(rala_hip_ctx* ctx) {
+    hipStream_t s = ctx->stream;
+    Trace trc;
+    auto mark = [&](const char* what, size_t k = 0) {
+        if (trc.on) { (void)stream_sync(ctx, s); trc(what, k); }
+    };
+    const uint32_t n_reads = (uint32_t)ctx->n_reads;
+    const uint32_t M = ctx->t_n0 + ctx->t_n1;
+    const TailList L = tail_list(ctx);
+    const TailReads R = tail_reads(ctx);
     // the final overlap list: originals in order, then the promoted ones round by round
     uint32_t n_kept = 0;
     for (uint32_t seg = 0; seg <= ctx->t_rounds; ++seg) {
@@ -1122,6 +1158,11 @@ int gpu_tail_run(rala_hip_ctx* ctx) {
     ctx->tail_on_device = true;
     ctx->host_stale = true;
     return RALA_HIP_OK;
+}
+
+int gpu_tail_run(rala_hip_ctx* ctx) {
+    const int rc = gpu_tail_part_a(ctx);
+    return rc != RALA_HIP_OK ? rc : gpu_tail_part_b(ctx);
 }
 
 // host mirrors of a device-resident result (lists in the reference's order, graph, read state)
@@ -1368,7 +1409,7 @@ int pass2(rala_hip_ctx* ctx, Comm* comm) {
 }  // namespace
 
 // ---- stage entry points shared with the sharded runner (stages.h) ---------------------------------
-int rala_hip::construct_stages(rala_hip_ctx* ctx, Comm* comm) {
+int rala_hip::construct_stages(rala_hip_ctx* ctx, Comm* comm, bool sensitive_pass_follows) {
     if (!ctx) return RALA_HIP_EINVAL;
     if (!ctx->initialized) return fail(ctx, RALA_HIP_EINVAL, "rala_hip_initialize must succeed first");
     if (ctx->tuple_mode || !ctx->inputs_set) return fail(ctx, RALA_HIP_EINVAL, "construct needs the overlaps (rala_hip_set_overlaps)");
@@ -1380,7 +1421,7 @@ int rala_hip::construct_stages(rala_hip_ctx* ctx, Comm* comm) {
     ctx->tail_on_device = false;
     ctx->host_stale = false;
     const double t0 = now_ms();
-    rc = gpu_tail_run(ctx);
+    rc = sensitive_pass_follows ? gpu_tail_part_a(ctx) : gpu_tail_run(ctx);      // (repeats_stage builds the graph)
     if (rc != RALA_HIP_OK) return rc;
     HIPCHECK(hipEventElapsedTime(&ctx->tm.classify_ms, ctx->ev[4], ctx->ev[5]));
     HIPCHECK(hipEventElapsedTime(&ctx->tm.death_ms, ctx->ev[5], ctx->ev[6]));
@@ -1392,7 +1433,7 @@ int rala_hip::construct_stages(rala_hip_ctx* ctx, Comm* comm) {
 
 int rala_hip::repeats_stage(rala_hip_ctx* cs, rala_hip_ctx* cl, Comm* comm, const rala_hip_overlaps* sens, uint64_t n_sens) {
     if (!cs || !cl) return RALA_HIP_EINVAL;
-    if (!cs->constructed || !cs->tail_on_device) return fail(cs, RALA_HIP_EINVAL, "construct_stages must have run");
+    if (!cs->constructed) return fail(cs, RALA_HIP_EINVAL, "construct_stages must have run");
     if (!cl->piles_resident) return fail(cs, RALA_HIP_EINVAL, "the sensitive pass needs the piles on the owner context");
     const double t0 = now_ms();
     const int rc = repeats_after_tail(cs, cl, comm, sens, n_sens);
@@ -1992,7 +2033,7 @@ int rala_hip_construct(rala_hip_ctx* ctx, const rala_hip_overlaps* sens, uint64_
     ctx->host_stale = false;
     if (ctx->use_gpu_tail) {
         const double t0 = now_ms();
-        const int rc5 = gpu_tail_run(ctx);
+        const int rc5 = with_sens ? gpu_tail_part_a(ctx) : gpu_tail_run(ctx);
         if (rc5 != RALA_HIP_OK) return rc5;
         HIPCHECK(hipEventElapsedTime(&ctx->tm.classify_ms, ctx->ev[4], ctx->ev[5]));
         HIPCHECK(hipEventElapsedTime(&ctx->tm.death_ms, ctx->ev[5], ctx->ev[6]));
@@ -2056,7 +2097,7 @@ int rala_hip_construct(rala_hip_ctx* ctx, const rala_hip_overlaps* sens, uint64_
         if (rc4 != RALA_HIP_OK) return rc4;
     }
     if (sens != nullptr && n_sens != 0) {
-        const int rc3 = preprocess_repeats(ctx, ctx, nullptr, sens, n_sens);
+        const int rc3 = preprocess_repeats(ctx, ctx, nullptr, sens, n_sens, false);
         if (rc3 != RALA_HIP_OK) return rc3;
     }
     trc("preprocess total");

@@ -97,6 +97,57 @@ __global__ __launch_bounds__(kBlock) void sens_bridge_kernel(OvlSoA o, SensCoord
     }
 }
 
+// Pile::is_valid_overlap (pile.cpp:605-630): an overlap that ends inside a bridged repeat hill at
+// the edge of the read is not trusted
+__device__ __forceinline__ bool pile_valid_overlap(uint32_t x, uint32_t y, uint32_t B, uint32_t E, const Interval* h, uint32_t nr) {
+    for (uint32_t k = 0; k < nr; ++k) {
+        const uint32_t hf = h[k].first, hs = h[k].second;
+        if (!(x < hs && hf < y)) continue;
+        if ((double)hf < 0.1 * (double)(E - B) + (double)B) {
+            if (y < hs + kHillFuzz && h[k].aux) return false;
+        } else if ((double)hs > 0.9 * (double)(E - B) + (double)B) {
+            if (x + kHillFuzz > hf && h[k].aux) return false;
+        }
+    }
+    return true;
+}
+
+// graph.cpp:1045-1051 on the device list: overlaps (not internals) that fail on either side leave
+__global__ __launch_bounds__(kBlock) void sens_filter_kernel(TailList L, const uint32_t* __restrict__ begin,
+                                                             const uint32_t* __restrict__ end,
+                                                             const uint8_t* __restrict__ n_rep,
+                                                             const uint32_t* __restrict__ rep_slot,
+                                                             const Interval* __restrict__ rep_pool) {
+    const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
+    if (k >= L.n) return;
+    const uint8_t st = L.state[k];
+    if (st != 1 && st != 3) return;
+    const uint32_t a = L.a[k], b = L.b[k];
+    const uint32_t na = n_rep[a], nb = n_rep[b];
+    if ((na | nb) == 0) return;
+    bool ok = true;
+    if (na) ok = pile_valid_overlap(L.a_begin[k], L.a_end[k], begin[a], end[a], rep_pool + rep_slot[a], na);
+    if (ok && nb) ok = pile_valid_overlap(L.b_begin[k], L.b_end[k], begin[b], end[b], rep_pool + rep_slot[b], nb);
+    if (!ok) L.state[k] = 0;
+}
+
+// the chimera stage is over: overlaps that lost a read are gone (graph.cpp:869-877); internals stay
+__global__ __launch_bounds__(kBlock) void finalize_states_kernel(TailList L, const uint8_t* __restrict__ alive) {
+    const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
+    if (k >= L.n) return;
+    const uint8_t st = L.state[k];
+    if ((st == 1 || st == 3) && !(alive[L.a[k]] && alive[L.b[k]])) L.state[k] = 0;
+}
+
+// component median of every read that has an overlap, by read number (0 elsewhere)
+__global__ __launch_bounds__(kBlock) void scatter_component_medians_kernel(const uint32_t* __restrict__ alive_reads,
+                                                                          const uint8_t* __restrict__ touched,
+                                                                          const uint16_t* __restrict__ cmed, uint32_t n_alive,
+                                                                          uint16_t* __restrict__ out) {
+    const uint32_t q = blockIdx.x * kBlock + threadIdx.x;
+    if (q < n_alive && touched[q]) out[alive_reads[q]] = cmed[q];
+}
+
 dim3 grid_for(uint64_t n) { return dim3((uint32_t)((n + kBlock - 1) / kBlock)); }
 
 }  // namespace
@@ -118,6 +169,21 @@ void launch_sens_bridge(const OvlSoA& o, const SensCoords& sc, const uint32_t* b
     if (o.n) {
         hipLaunchKernelGGL(sens_bridge_kernel, grid_for(o.n), dim3(kBlock), 0, s, o, sc, begin, end, alive, n_rep, rep_slot,
                            rep_pool);
+    }
+}
+
+void launch_sens_filter(const TailList& L, const uint32_t* begin, const uint32_t* end, const uint8_t* n_rep,
+                        const uint32_t* rep_slot, const Interval* rep_pool, hipStream_t s) {
+    if (L.n) hipLaunchKernelGGL(sens_filter_kernel, grid_for(L.n), dim3(kBlock), 0, s, L, begin, end, n_rep, rep_slot, rep_pool);
+}
+void launch_finalize_states(const TailList& L, const uint8_t* alive, hipStream_t s) {
+    if (L.n) hipLaunchKernelGGL(finalize_states_kernel, grid_for(L.n), dim3(kBlock), 0, s, L, alive);
+}
+void launch_scatter_component_medians(const uint32_t* alive_reads, const uint8_t* touched, const uint16_t* cmed, uint32_t n_alive,
+                                      uint16_t* out, hipStream_t s) {
+    if (n_alive) {
+        hipLaunchKernelGGL(scatter_component_medians_kernel, grid_for(n_alive), dim3(kBlock), 0, s, alive_reads, touched, cmed,
+                           n_alive, out);
     }
 }
 

@@ -169,7 +169,7 @@ int agree(rala_hip_mg* mg, int rc, const char* where) {
     return RALA_HIP_OK;
 }
 
-int run_primary(rala_hip_mg* mg) {
+int run_primary(rala_hip_mg* mg, bool with_sens) {
     rala_hip_ctx* cs = mg->cs;
     rala_hip_ctx* cl = mg->cl;
     Comm* comm = mg->comm;
@@ -250,7 +250,7 @@ int run_primary(rala_hip_mg* mg) {
     lap(mg->tm.gather_ms);
 
     // 5. second pass .. preprocess tail .. graph, sharded by slice where it is per overlap
-    rc = construct_stages(cs, comm);
+    rc = construct_stages(cs, comm, with_sens);
     rc = agree(mg, from_ctx(mg, cs, rc, "construct"), "construct");
     if (rc != RALA_HIP_OK) return rc;
     lap(mg->tm.construct_ms);
@@ -364,7 +364,7 @@ int rala_hip_mg_run(rala_hip_mg* mg, const rala_hip_overlaps* sens_slice, uint64
     MGCHECK(hipSetDevice(mg->device));
     mg->tm = rala_hip_mg_timings();
     const double t0 = now_ms();
-    int rc = run_primary(mg);
+    int rc = run_primary(mg, sens_slice != nullptr);
     if (rc != RALA_HIP_OK) return rc;
     if (sens_slice != nullptr) {
         // collective: a rank whose share is empty still takes part (every rank passes a non-null pointer or none does)

@@ -15,7 +15,7 @@ namespace rala_hip {
 //   liveness, hill counters, survivors                       comm: counters all-reduced (sum),
 //                                                                  survivor lists all-gathered
 //   preprocess tail + graph on the survivors                 replicated
-int construct_stages(rala_hip_ctx* ctx, Comm* comm);
+int construct_stages(rala_hip_ctx* ctx, Comm* comm, bool sensitive_pass_follows = false);
 
 // Graph::preprocess with the sensitive overlaps (graph.cpp:882-1054) behind construct_stages:
 // cs = the context construct_stages ran on, with this rank's share of the sensitive overlaps;
