@@ -152,6 +152,11 @@ struct rala_hip_ctx {
     std::vector<uint8_t> h_alive, h_n_pits, h_n_hills;
     std::vector<rala_hip::Interval> h_pool;
     rala_hip::DevBuf<uint32_t> d_overflow_mid, d_chain_cnt;      // third overflow list / chain counters
+    // how initialize left the primary bound events (the sensitive pass reads them again):
+    // fixed slots (d_ev_fixed, counts in d_cursor) or the CSR (d_ev_off, d_ev)
+    bool ev_ready = false, ev_fixed = false;
+    // bounds of the sensitive overlaps by read (CSR), the list of reads of a sensitive-pass launch
+    rala_hip::DevBuf<uint32_t> d_sens_off, d_sens_cur, d_sens_ev, d_sens_list;
     rala_hip::DevBuf<double> d_layout[4];
     rala_hip::DevBuf<uint32_t> d_layout_adj[2];
     // pinned staging of small device -> host reads (pipeline.hip: d2h_small / stream_sync)

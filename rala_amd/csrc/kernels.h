@@ -50,6 +50,16 @@ struct PileArgs {
     uint32_t* pool_count;
     uint32_t pool_cap;
     uint32_t* error;
+    // sensitive pass (launch_pile_sens): begin / end are inputs; mode 1 writes median / p10 and
+    // the row, mode 2 reads them and writes the repeat hills
+    const uint32_t* sens_off = nullptr;        // CSR of the sensitive bounds per read
+    const uint32_t* sens_ev = nullptr;
+    const uint16_t* dataset_median = nullptr;  // mode 2: component median per read
+    uint8_t* n_rep = nullptr;
+    uint32_t* rep_slot = nullptr;
+    Interval* rep_pool = nullptr;
+    uint32_t* rep_pool_count = nullptr;
+    uint32_t rep_pool_cap = 0;
 };
 
 uint32_t pile_lds_bytes(uint32_t lw);
@@ -65,6 +75,10 @@ constexpr uint32_t kRunEventCapMid = 1024;
 constexpr uint32_t kRunEventCapBig = 2048;
 void launch_pile_runs(const PileArgs& args, uint32_t grid, int tier, uint32_t* overflow_list, uint32_t* overflow_count,
                       hipStream_t stream);
+// the sensitive pass in run space (tier 0: cap 512, tier 1: cap 1024; reads of up to 16384 bases); the others are appended to
+// overflow_list for the position-space kernel below
+void launch_pile_sens(const PileArgs& args, uint32_t grid, int tier, int mode, uint32_t* overflow_list,
+                      uint32_t* overflow_count, hipStream_t stream);
 
 // sensitive pass (pile_repeats_kernel.hip): mode 1 = add layers on top + median for the
 // targets; mode 2 = repeat hills for the members of connected components

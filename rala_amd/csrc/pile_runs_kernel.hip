@@ -379,8 +379,22 @@ __device__ __forceinline__ void expand_from_bitmap(uint32_t* sm, const uint16_t*
 
 // kDiag: the diagnostic instantiation honours PileArgs::stop_after (per-phase counter runs,
 // tools/gpurun/gpurun_pmc.sh); the product instantiation carries none of those branches.
-template <uint32_t kCap, bool kDiag>
+//
+// kSens: the second, "sensitive" pass (rala -s; reference graph.cpp:917-1026) in the same run space.
+// The coverage of a read is then the sum over its primary bound events (still in the slots the
+// first pass bucketed them into) and the bounds of the sensitive overlaps that target it
+// (PileArgs::sens_off / sens_ev); the valid region is given (begin / end as the chimera stage
+// left them), so two more bits in the bitmap of run starts make it a whole number of runs.
+//   kSens == 1  Pile::add_layers + Pile::find_median for the targets (pile.cpp:261-297): the
+//               runs, the order statistics, the expansion of the new coverage to HBM
+//   kSens == 2  Pile::find_repetitive_hills (pile.cpp:500-566) for the members of connected
+//               components: slope regions at q = 1.42, every (up, later down) pair tested over
+//               the runs between them, intervalMerge, clamp.  Neither reads nor writes the row.
+// A read that does not fit (events, length, lists) goes to overflow_list and from there to the
+// position-space kernel of pile_repeats_kernel.hip.
+template <uint32_t kCap, bool kDiag, int kSens>
 __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* overflow_list, uint32_t* overflow_count) {
+    static_assert(kSens == 0 || (kCap <= 1024 && !kDiag), "the sensitive pass runs on the bitmap path");
     typedef Layout<kCap> L;
     constexpr uint32_t kMaxReg = L::kMaxReg, kMaxRaw = L::kMaxRaw;
     __shared__ __align__(16) uint32_t sm[L::WORDS];
@@ -405,9 +419,20 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
     for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
         const uint32_t r = A.order ? A.order[item] : item;
         const uint32_t n = A.read_len[r];
-        const uint32_t n_ev = A.ev_cnt ? umin(A.ev_cnt[r], A.ev_stride) : A.ev_off[r + 1] - A.ev_off[r];
+        const uint32_t n_ev_p = A.ev_cnt ? umin(A.ev_cnt[r], A.ev_stride) : A.ev_off[r + 1] - A.ev_off[r];
         const uint32_t* __restrict__ rev = A.ev_cnt ? A.ev + (size_t)r * A.ev_stride : A.ev + A.ev_off[r];
-        if (n_ev > kCap) {
+        uint32_t n_ev = n_ev_p;
+        const uint32_t* __restrict__ sev = nullptr;
+        uint32_t given_b = 0, given_e = 0;
+        if constexpr (kSens != 0) {
+            const uint32_t s0 = A.sens_off[r];
+            sev = A.sens_ev + s0;
+            n_ev += A.sens_off[r + 1] - s0;
+            given_b = A.begin[r];
+            given_e = A.end[r];
+        }
+        // (the two region marks of the sensitive pass may add two runs)
+        if (n_ev > (kSens ? kCap - 2 : kCap) || (kSens != 0 && (n > 16384 || given_e <= given_b))) {
             if (lane == 0) overflow_list[atomicAdd(overflow_count, 1u)] = r;
             continue;
         }
@@ -430,16 +455,25 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
             static_assert(kCap > 1024 || L::SEL - L::RF >= L::kArr / 2 + 2, "scratch for the per-run sums");
             ((uint4*)bm)[lane] = make_uint4(0, 0, 0, 0);
             ((uint4*)bm)[lane + 64] = make_uint4(0, 0, 0, 0);
-            for (uint32_t k = lane; 2 * k < n_ev + 3; k += 64) delta[k] = 0x80008000u;
+            for (uint32_t k = lane; 2 * k < n_ev + 5; k += 64) delta[k] = 0x80008000u;
             // all loads first, unconditionally (clamped index), so that they are in flight together:
             // a load per predicated block would be waited for one by one
             uint32_t evr[kCap / 64];
             const uint32_t e_last = n_ev ? n_ev - 1 : 0;
+            if constexpr (kSens == 0) {
 #pragma unroll
-            for (uint32_t t = 0; t < kCap / 64; ++t) evr[t] = rev[umin(t * 64 + lane, e_last)];
+                for (uint32_t t = 0; t < kCap / 64; ++t) evr[t] = rev[umin(t * 64 + lane, e_last)];
 #pragma unroll
-            for (uint32_t t = 0; t < kCap / 64; ++t) {
-                if (t * 64 + lane >= n_ev) evr[t] = kNone;
+                for (uint32_t t = 0; t < kCap / 64; ++t) {
+                    if (t * 64 + lane >= n_ev) evr[t] = kNone;
+                }
+            } else {
+                // the primary events, then the bounds of the sensitive overlaps
+#pragma unroll
+                for (uint32_t t = 0; t < kCap / 64; ++t) {
+                    const uint32_t i = t * 64 + lane;
+                    evr[t] = i < n_ev_p ? rev[i] : i < n_ev ? sev[i - n_ev_p] : kNone;
+                }
             }
             wave_sync();
 #pragma unroll
@@ -449,6 +483,11 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
                 if (evr[t] != kNone && pos < n) atomicOr(&bm[pos >> 5], 1u << (pos & 31));
             }
             if (lane == 0) atomicOr(&bm[0], 1u);             // position 0 always starts a run
+            if constexpr (kSens != 0) {
+                // the given valid region starts and ends on a run boundary
+                if (lane == 1 && given_b < n) atomicOr(&bm[given_b >> 5], 1u << (given_b & 31));
+                if (lane == 2 && given_e < n) atomicOr(&bm[given_e >> 5], 1u << (given_e & 31));
+            }
             wave_sync();
             {
                 const uint4 x = ((const uint4*)bm)[2 * lane], y = ((const uint4*)bm)[2 * lane + 1];
@@ -482,6 +521,13 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
                 }
             }
             if (lane == 0) { rs[0] = 0; rs[R] = n; rs[R + 1] = n; }
+            if constexpr (kSens != 0) {
+                if ((lane == 1 || lane == 2) && (lane == 1 ? given_b : given_e) < n) {
+                    const uint32_t pos = lane == 1 ? given_b : given_e;
+                    const uint32_t w = pos >> 5;
+                    rs[pref[w] + (uint32_t)__popc(bm[w] & ((2u << (pos & 31)) - 1u)) - 1u] = pos;
+                }
+            }
             wave_sync();
             {
                 const uint32_t cc = (R + 63) / 64;
@@ -574,7 +620,19 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
 
         // ---- 3. first longest streak of runs with value >= 4 ---------------------------
         uint32_t B, E, kB, kE;
-        {
+        if constexpr (kSens != 0) {
+            // the region is given; the marks made it a whole number of runs
+            const uint32_t* bm = sm + L::X;
+            const uint16_t* pref = (const uint16_t*)(bm + kBitmapBases / 32);
+            auto run_at = [&](uint32_t pos) {
+                const uint32_t w = pos >> 5;
+                return pref[w] + (uint32_t)__popc(bm[w] & ((2u << (pos & 31)) - 1u)) - 1u;
+            };
+            B = given_b;
+            E = umin(given_e, n);
+            kB = B < n ? run_at(B) : R;
+            kE = E < n ? run_at(E) : R;
+        } else {
             const uint32_t c = (R + 63) / 64;
             const uint32_t lo = umin(R, lane * c), hi = umin(R, lo + c);
             uint32_t bad = 0;
@@ -602,7 +660,7 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
             kB = len ? sel[0] : 0;
             kE = len ? sel[1] : 0;
         }
-        if (E - B < kMinRegion) {
+        if (kSens == 0 && E - B < kMinRegion) {
             if (lane == 0) {
                 A.alive[r] = 0;
                 A.begin[r] = 0; A.end[r] = 0; A.median[r] = 0; A.p10[r] = 0;
@@ -657,7 +715,10 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
 
         // ---- 5. order statistics over (value, length) of the runs in [kB, kE) --------------
         uint32_t med, p10;
-        {
+        if constexpr (kSens == 2) {
+            med = A.median[r];
+            p10 = A.p10[r];
+        } else {
             uint32_t* hist = sm + L::X;
             for (uint32_t j = lane; j < 768; j += 64) hist[j] = 0;
             wave_sync();
@@ -707,6 +768,9 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
         wave_sync();
         RUN_STOP(25)
 
+        if constexpr (kSens == 1) {
+            if (lane == 0) { A.median[r] = (uint16_t)med; A.p10[r] = (uint16_t)p10; }
+        } else {
         // ---- 6. slope flags per run: a flagged prefix (down) and suffix (up) ----------------
         // down(i), i in run k  <=>  some run j < k with value > t(v_k) reaches into
         // [i-847, i-1]  <=>  i <= end_j + 846 for the nearest such j;   up(i) likewise
@@ -740,7 +804,8 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
             if (k < R) {
                 const uint32_t v = rv[k];
                 const uint32_t sk = rs[k], ek = rs[k + 1];
-                const int32_t t13 = (int32_t)(v * 13u / 10u);      // == int32(v * 1.3) for every uint16 v
+                // == int32(v * 1.3) (sensitive pass: v * 1.42) for every uint16 v
+                const int32_t t13 = kSens == 2 ? (int32_t)(v * 142u / 100u) : (int32_t)(v * 13u / 10u);
                 const uint32_t gl = (sk >= 847u ? sk - 847u : 0u) >> shift;
                 const uint32_t gr = ((ek + 846u) >> shift) + 1u;
                 const uint32_t jl = idx[gl];
@@ -773,7 +838,9 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
             const uint32_t v = rv[k];
             const uint32_t sk = rs[k], ek = rs[k + 1];
             // int32(v * q) of pile.cpp:94 in integers: exact for every 16-bit v (tools/threshold_check.c)
-            const int32_t t13 = (int32_t)(v * 13u / 10u), t182 = (int32_t)(v * 182u / 100u);
+            // (the sensitive pass has one threshold, q = 1.42: both pairs of lists hold the same)
+            const int32_t t13 = kSens == 2 ? (int32_t)(v * 142u / 100u) : (int32_t)(v * 13u / 10u);
+            const int32_t t182 = kSens == 2 ? t13 : (int32_t)(v * 182u / 100u);
             uint32_t dl13 = kNone, dl182 = kNone, ur13 = kNone, ur182 = kNone;
             {
                 bool done = false;
@@ -827,7 +894,7 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
 
         // ---- 7. maximal unions of touching intervals -> regions (first, last) ----------------
 #pragma unroll 1
-        for (uint32_t w = 0; w < 4; ++w) {
+        for (uint32_t w = 0; w < (kSens == 2 ? 2u : 4u); ++w) {
             const uint16_t* iv = (w == 0) ? d13 : (w == 1) ? u13 : (w == 2) ? d182 : u182;
             const bool is_up = w & 1;
             uint32_t* rf = sm + L::RF + w * kMaxReg;
@@ -882,8 +949,8 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
         //         pits (q = 1.82) and hills (q = 1.3) ---------------------------------------------
         bool any_overflow = false;
 #pragma unroll 1
-        for (uint32_t which = 0; which < 2; ++which) {             // 0: q = 1.3 hills, 1: q = 1.82 pits
-            const double q = which ? 1.82 : 1.3;
+        for (uint32_t which = 0; which < (kSens == 2 ? 1u : 2u); ++which) {   // 0: q = 1.3 hills, 1: q = 1.82 pits
+            const double q = kSens == 2 ? 1.42 : which ? 1.82 : 1.3;
             const uint32_t nd = sm[L::RC + 2 * which], nu = sm[L::RC + 2 * which + 1];
             uint32_t* key = sm + L::REG + which * 4 * kMaxReg;
             uint32_t* last = key + 2 * kMaxReg;
@@ -949,6 +1016,70 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
                     wave_sync();
                     continue;
                 }
+            }
+            if constexpr (kSens == 2) {
+                // repeat hills (pile.cpp:500-566): every (up i, later down j) whose centres are
+                // within 0.84 of the region; the positions between them are walked by runs, all
+                // lanes on one pair at a time
+                constexpr uint32_t kMaxRep = 2 * kMaxRaw;            // both halves of the interval scratch
+                uint32_t* rf = sm + L::IV;
+                uint32_t* rsd = rf + kMaxRep;
+                uint32_t dm = A.dataset_median[r];
+                if ((double)med > 1.42 * (double)dm) dm = umax(dm, p10);       // pile.cpp:503-505
+                const uint32_t floor_v = (uint32_t)((double)dm * 1.42);
+                const double lim = 0.84 * (double)(E - B);
+                auto run_at = [&](uint32_t pos) {
+                    uint32_t c = idx[pos >> shift];
+                    while (rs[c + 1] <= pos) ++c;
+                    return c;
+                };
+                uint32_t n_hit = 0;
+                for (uint32_t i = 0; i + 1 < n_reg; ++i) {
+                    const uint32_t ki = key[i];
+                    if (!(ki & 1)) continue;
+                    const uint32_t u_first = ki >> 1, u_last = last[i];
+                    const uint32_t mid_u = (u_first + u_last) / 2;
+                    for (uint32_t j = i + 1; j < n_reg; ++j) {
+                        const uint32_t kj = key[j];
+                        if (kj & 1) continue;
+                        const uint32_t w_first = kj >> 1, w_last = last[j];
+                        const uint32_t mid_w = (w_first + w_last) / 2;
+                        if ((double)(uint32_t)(mid_w - mid_u) > lim) continue;
+                        uint32_t valid = 0, found = 0;
+                        if (u_last + 1 < w_first) {
+                            const uint32_t ka = run_at(u_last), kb = run_at(w_first);
+                            const uint32_t peak = (uint32_t)(1.42 * (double)umax(rv[ka], rv[kb]));
+                            // runs that reach into (u_last, w_first)
+                            for (uint32_t k = ka + lane; k <= kb; k += 64) {
+                                const uint32_t lo = umax(rs[k], u_last + 1), hi = umin(rs[k + 1], w_first);
+                                if (lo < hi) {
+                                    const uint32_t v = rv[k];
+                                    if (v > floor_v) valid += hi - lo;
+                                    found |= v > peak ? 1u : 0u;
+                                }
+                            }
+                            valid = wave_reduce(valid, OpAdd());
+                            found = wave_reduce(found, OpMax());
+                        }
+                        if (found && !((double)valid < 0.9 * (double)(uint32_t)(w_first - u_last))) {
+                            if (n_hit < kMaxRep && lane == 0) {
+                                rf[n_hit] = (uint32_t)((double)u_last - 0.336 * (double)(uint32_t)(u_last - u_first));
+                                rsd[n_hit] = (uint32_t)((double)w_first + 0.336 * (double)(uint32_t)(w_last - w_first));
+                            }
+                            ++n_hit;
+                        }
+                    }
+                }
+                if (n_hit > kMaxRep) {
+                    any_overflow = true;
+                    continue;
+                }
+                wave_sync();
+                if (lane == 0) {
+                    sel[8] = n_hit ? interval_merge(rf, rsd, n_hit, (uint8_t*)(sm + L::GONE), rsd + kMaxRep, rsd + 2 * kMaxRep) : 0u;
+                }
+                wave_sync();
+                continue;
             }
             // raw pits: adjacent (down, up) (pile.cpp:357-362); raw hill candidates: every
             // (up i, later down j) that passes the cheap tests of pile.cpp:415-418
@@ -1034,7 +1165,31 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
             wave_sync();
             continue;
         }
-        if (lane == 0) {
+        if constexpr (kSens == 2) {
+            if (lane == 0) {
+                constexpr uint32_t kMaxRep = 2 * kMaxRaw;
+                const uint32_t* of = sm + L::IV + 2 * kMaxRep;
+                const uint32_t* os = of + kMaxRep;
+                uint32_t cnt = sel[8], slot = kNone;
+                if (cnt) {
+                    slot = atomicAdd(A.rep_pool_count, cnt);
+                    if (slot + cnt > A.rep_pool_cap) {
+                        atomicOr(A.error, kErrPoolCapacity);
+                        slot = kNone; cnt = 0;
+                    } else {
+                        for (uint32_t k = 0; k < cnt; ++k) {
+                            Interval iv;
+                            iv.first = umax(B, of[k]);                  // pile.cpp:560-563
+                            iv.second = umin(E, os[k]);
+                            iv.aux = 0;
+                            A.rep_pool[slot + k] = iv;
+                        }
+                    }
+                }
+                A.n_rep[r] = (uint8_t)cnt;
+                A.rep_slot[r] = slot;
+            }
+        } else if (lane == 0) {
             const uint32_t nh = sel[8], np = sel[9];
             uint32_t err = 0;
             uint32_t slot = kNone;
@@ -1070,8 +1225,9 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
             A.iv_slot[r] = slot;
             if (err) atomicOr(A.error, err);
         }
+        }
         wave_sync();
-        {
+        if constexpr (kSens != 2) {
             // ---- 10. expansion, LAST: nothing behind it waits for the stores to drain (the
             // compiler puts s_waitcnt vmcnt(0) in front of LDS traffic that follows global stores;
             // in the middle of the kernel that parked the wave until the whole row was in memory),
@@ -1206,15 +1362,31 @@ void launch_pile_runs(const PileArgs& args, uint32_t grid, int tier, uint32_t* o
     const bool diag = args.stop_after != 99;
 #define RALA_LAUNCH_RUNS(cap, lds)                                                                                      \
     do {                                                                                                                \
-        if (diag) hipLaunchKernelGGL((pile_runs_kernel<cap, true>), dim3(grid), dim3(64), lds, stream, args,            \
+        if (diag) hipLaunchKernelGGL((pile_runs_kernel<cap, true, 0>), dim3(grid), dim3(64), lds, stream, args,         \
                                      overflow_list, overflow_count);                                                    \
-        else hipLaunchKernelGGL((pile_runs_kernel<cap, false>), dim3(grid), dim3(64), lds, stream, args,                \
+        else hipLaunchKernelGGL((pile_runs_kernel<cap, false, 0>), dim3(grid), dim3(64), lds, stream, args,             \
                                 overflow_list, overflow_count);                                                         \
     } while (0)
     if (tier == 0) RALA_LAUNCH_RUNS(kRunEventCap, extra_lds);
     else if (tier == 1) RALA_LAUNCH_RUNS(kRunEventCapMid, 0);
     else RALA_LAUNCH_RUNS(kRunEventCapBig, 0);
 #undef RALA_LAUNCH_RUNS
+}
+
+void launch_pile_sens(const PileArgs& args, uint32_t grid, int tier, int mode, uint32_t* overflow_list,
+                      uint32_t* overflow_count, hipStream_t stream) {
+    if (grid == 0) return;
+#define RALA_LAUNCH_SENS(cap, m)                                                                                        \
+    hipLaunchKernelGGL((pile_runs_kernel<cap, false, m>), dim3(grid), dim3(64), 0, stream, args, overflow_list,         \
+                       overflow_count)
+    if (tier == 0) {
+        if (mode == 1) RALA_LAUNCH_SENS(kRunEventCap, 1);
+        else RALA_LAUNCH_SENS(kRunEventCap, 2);
+    } else {
+        if (mode == 1) RALA_LAUNCH_SENS(kRunEventCapMid, 1);
+        else RALA_LAUNCH_SENS(kRunEventCapMid, 2);
+    }
+#undef RALA_LAUNCH_SENS
 }
 
 }  // namespace rala_hip

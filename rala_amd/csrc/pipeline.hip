@@ -524,6 +524,42 @@ int run_repeats_kernel(rala_hip_ctx* ctx, RepeatArgs a, const std::vector<uint32
     return RALA_HIP_OK;
 }
 
+// One mode of the sensitive pass over `reads`: the run-space kernel (cap 512, then 1024) reads the
+// primary bound events where initialize left them plus the sensitive bounds of pa.sens_*; what it
+// hands on goes to the position-space kernel.
+int run_sens_pass(rala_hip_ctx* ctx, PileArgs pa, const RepeatArgs& ra, const std::vector<uint32_t>& reads, int mode) {
+    if (reads.empty()) return RALA_HIP_OK;
+    if (!ctx->use_run_kernel || !ctx->ev_ready) return run_repeats_kernel(ctx, ra, reads, mode);
+    hipStream_t s = ctx->stream;
+    Trace trc;
+    const uint32_t count = (uint32_t)reads.size();
+    HIPCHECK(ctx->d_sens_list.ensure(count + 1));
+    HIPCHECK(ctx->d_overflow.ensure(ctx->n_reads + 1));
+    HIPCHECK(ctx->d_overflow_mid.ensure(ctx->n_reads + 1));
+    HIPCHECK(ctx->d_chain_cnt.ensure(4));
+    HIPCHECK(hipMemcpyAsync(ctx->d_sens_list.p, reads.data(), (size_t)count * 4, hipMemcpyHostToDevice, s));
+    HIPCHECK(hipMemsetAsync(ctx->d_chain_cnt.p, 0, 16, s));
+    pa.order = ctx->d_sens_list.p;
+    pa.n_items = count;
+    pa.n_items_dev = nullptr;
+    launch_pile_sens(pa, count, 0, mode, ctx->d_overflow.p, ctx->d_chain_cnt.p, s);
+    pa.order = ctx->d_overflow.p;
+    pa.n_items_dev = ctx->d_chain_cnt.p;
+    launch_pile_sens(pa, std::min<uint32_t>(count, 8192), 1, mode, ctx->d_overflow_mid.p, ctx->d_chain_cnt.p + 1, s);
+    uint32_t cnt[2] = {0, 0};
+    HIPCHECK(d2h_small(ctx, cnt, ctx->d_chain_cnt.p, 8, s));
+    HIPCHECK(stream_sync(ctx, s));
+    HIPCHECK(hipGetLastError());
+    trc(mode == 1 ? "sens pass 1: run space" : "sens pass 2: run space", count);
+    if (cnt[1] == 0) return RALA_HIP_OK;
+    std::vector<uint32_t> rest(cnt[1]);
+    HIPCHECK(hipMemcpy(rest.data(), ctx->d_overflow_mid.p, (size_t)cnt[1] * 4, hipMemcpyDeviceToHost));
+    std::sort(rest.begin(), rest.end());
+    const int rc = run_repeats_kernel(ctx, ra, rest, mode);
+    trc("sens pass: position space", rest.size());
+    return rc;
+}
+
 // Pile::is_valid_overlap (pile.cpp:605-630)
 bool is_valid_overlap(rala_hip_ctx* ctx, uint32_t r, uint32_t x, uint32_t y) {
     const uint32_t B = ctx->h_begin[r], E = ctx->h_end[r];
@@ -660,7 +696,10 @@ int preprocess_repeats(rala_hip_ctx* cs, rala_hip_ctx* cl, Comm* comm, const ral
     if (bad & 1u) return fail(ctx, RALA_HIP_EINVAL, "sensitive overlap names must resolve");
     if (bad & 2u) return fail(ctx, RALA_HIP_EINVAL, "sensitive overlap targets a read that did not survive");
     // bucketed by read on the pile holder: count -> scan -> scatter
-    HIPCHECK(cl->d_ev.ensure(n_tuples + 8));
+    // (buffers of their own: the primary bound events stay where initialize left them)
+    HIPCHECK(cl->d_sens_ev.ensure(n_tuples + 8));
+    HIPCHECK(cl->d_sens_off.ensure(nl + 2));
+    HIPCHECK(cl->d_sens_cur.ensure(nl + 2));
     HIPCHECK(cl->d_scan_ws.ensure(scan_workspace_bytes(std::max<uint64_t>(n_tuples, nl) + 2)));
     HIPCHECK(cl->d_dataset_median.ensure(nl));
     HIPCHECK(cl->d_n_rep.ensure(nl));
@@ -670,14 +709,14 @@ int preprocess_repeats(rala_hip_ctx* cs, rala_hip_ctx* cl, Comm* comm, const ral
         HIPCHECK(hipMemsetAsync(cl->d_n_rep.p, 0, nl, sl));
         HIPCHECK(hipMemsetAsync(cl->d_small.p + 6, 0, 8, sl));
     }
-    HIPCHECK(hipMemsetAsync(cl->d_cursor.p, 0, (nl + 1) * 4, sl));
-    launch_count_tuples(tuples, n_tuples, (uint32_t)nl, cl->d_cursor.p, sl);
-    launch_exclusive_scan(cl->d_cursor.p, cl->d_ev_off.p, nl, cl->d_scan_ws.p, sl);
-    HIPCHECK(hipMemcpyAsync(cl->d_cursor.p, cl->d_ev_off.p, nl * 4, hipMemcpyDeviceToDevice, sl));
-    launch_scatter_tuples(tuples, n_tuples, (uint32_t)nl, cl->d_cursor.p, cl->d_ev.p, sl);
+    HIPCHECK(hipMemsetAsync(cl->d_sens_cur.p, 0, (nl + 1) * 4, sl));
+    launch_count_tuples(tuples, n_tuples, (uint32_t)nl, cl->d_sens_cur.p, sl);
+    launch_exclusive_scan(cl->d_sens_cur.p, cl->d_sens_off.p, nl, cl->d_scan_ws.p, sl);
+    HIPCHECK(hipMemcpyAsync(cl->d_sens_cur.p, cl->d_sens_off.p, nl * 4, hipMemcpyDeviceToDevice, sl));
+    launch_scatter_tuples(tuples, n_tuples, (uint32_t)nl, cl->d_sens_cur.p, cl->d_sens_ev.p, sl);
     // the targets: reads that received bounds
     std::vector<uint32_t> ev_off(nl + 1);
-    HIPCHECK(hipMemcpyAsync(ev_off.data(), cl->d_ev_off.p, (nl + 1) * 4, hipMemcpyDeviceToHost, sl));
+    HIPCHECK(hipMemcpyAsync(ev_off.data(), cl->d_sens_off.p, (nl + 1) * 4, hipMemcpyDeviceToHost, sl));
     HIPCHECK(stream_sync(cl, sl));
     HIPCHECK(hipGetLastError());
     std::vector<uint32_t> targets;
@@ -686,14 +725,26 @@ int preprocess_repeats(rala_hip_ctx* cs, rala_hip_ctx* cl, Comm* comm, const ral
 
     RepeatArgs a;
     a.read_len = cl->d_read_len.p; a.pile_off = cl->d_pile_off.p; a.pile = cl->d_pile.p;
-    a.ev_off = cl->d_ev_off.p; a.ev = cl->d_ev.p;
+    a.ev_off = cl->d_sens_off.p; a.ev = cl->d_sens_ev.p;
     a.begin = cl->d_begin.p; a.end = cl->d_end.p; a.median = cl->d_median.p; a.p10 = cl->d_p10.p;
     a.dataset_median = cl->d_dataset_median.p; a.n_rep = cl->d_n_rep.p; a.rep_slot = cl->d_rep_slot.p;
     a.pool = cl->d_rep_pool.p; a.pool_count = cl->d_small.p + 6; a.pool_cap = cl->pool_cap;
     a.error = cl->d_small.p + 7;
     a.order = nullptr; a.n_items = 0; a.lw = 0; a.slab = nullptr;
+    // the same in run space: the primary events + the sensitive bounds
+    PileArgs pa;
+    memset(&pa, 0, sizeof(pa));
+    pa.read_len = cl->d_read_len.p; pa.pile_off = cl->d_pile_off.p; pa.pile = cl->d_pile.p;
+    pa.ev_off = cl->d_ev_off.p; pa.ev = cl->ev_fixed ? cl->d_ev_fixed.p : cl->d_ev.p;
+    pa.ev_cnt = cl->ev_fixed ? cl->d_cursor.p : nullptr; pa.ev_stride = kRunEventCapBig;
+    pa.stop_after = 99;
+    pa.begin = cl->d_begin.p; pa.end = cl->d_end.p; pa.median = cl->d_median.p; pa.p10 = cl->d_p10.p;
+    pa.error = cl->d_small.p + 7;
+    pa.sens_off = cl->d_sens_off.p; pa.sens_ev = cl->d_sens_ev.p;
+    pa.dataset_median = cl->d_dataset_median.p; pa.n_rep = cl->d_n_rep.p; pa.rep_slot = cl->d_rep_slot.p;
+    pa.rep_pool = cl->d_rep_pool.p; pa.rep_pool_count = cl->d_small.p + 6; pa.rep_pool_cap = cl->pool_cap;
     // add_layers on top of the coverage + find_median for the targets (graph.cpp:941-969)
-    int rc = run_repeats_kernel(cl, a, targets, 1);
+    int rc = run_sens_pass(cl, pa, a, targets, 1);
     if (rc != RALA_HIP_OK) { if (cl != cs) cs->err = cl->err; return rc; }
     if (sharded) {
         // the new medians, everywhere
@@ -744,13 +795,13 @@ int preprocess_repeats(rala_hip_ctx* cs, rala_hip_ctx* cl, Comm* comm, const ral
     }
     trc("rep: component medians", members.size());
     if (!sharded) {
-        rc = run_repeats_kernel(cl, a, members, 2);
+        rc = run_sens_pass(cl, pa, a, members, 2);
         if (rc != RALA_HIP_OK) return rc;
     } else {
         launch_localize_u16(cs->d_dataset_median.p, nl, P, me, cl->d_dataset_median.p, sl);
         std::vector<uint32_t> mine;
         for (uint32_t r : members) if (r % P == me) mine.push_back(r / P);
-        rc = run_repeats_kernel(cl, a, mine, 2);
+        rc = run_sens_pass(cl, pa, a, mine, 2);
         if (rc != RALA_HIP_OK) { cs->err = cl->err; return rc; }
     }
     uint32_t small[8];
@@ -1475,7 +1526,7 @@ int rala_hip::install_read_state(rala_hip_ctx* ctx, uint64_t pool_count) {
     ctx->n_prefiltered = n_dead;
     ctx->initialized = true;
     ctx->constructed = false;
-    ctx->piles_resident = false;
+    ctx->piles_resident = ctx->ev_ready = false;
     ctx->tail_on_device = ctx->host_stale = ctx->marks_on_device = false;
     if (ctx->n_prefiltered == ctx->n_reads) return fail(ctx, RALA_HIP_EFILTERED, "filtered all sequences");
     return RALA_HIP_OK;
@@ -1578,7 +1629,7 @@ int rala_hip_set_reads(rala_hip_ctx* ctx, const uint32_t* read_len, uint64_t n_r
     ctx->h_n_hills.resize(n_reads); ctx->h_slot.resize(n_reads);
     ctx->pool_cap = (uint32_t)std::max<int64_t>(1024, (int64_t)n_reads * ctx->pool_per_read_x1000 / 1000);
     HIPCHECK(ctx->d_pool.ensure(ctx->pool_cap));
-    ctx->initialized = ctx->constructed = false;
+    ctx->initialized = ctx->constructed = ctx->ev_ready = false;
     return RALA_HIP_OK;
 }
 
@@ -1620,7 +1671,7 @@ int rala_hip_set_overlaps(rala_hip_ctx* ctx, const rala_hip_overlaps* o, uint64_
     HIPCHECK(ctx->d_cls.ensure(n));
     for (int k = 0; k < 4; ++k) HIPCHECK(ctx->d_chunk[k].ensure(pass2_chunks(n) + 2));
     HIPCHECK(ctx->d_scan_ws.ensure(scan_workspace_bytes(std::max<uint64_t>(n, ctx->n_reads) + 2)));
-    ctx->initialized = ctx->constructed = false;
+    ctx->initialized = ctx->constructed = ctx->ev_ready = false;
     return RALA_HIP_OK;
 }
 
@@ -1633,7 +1684,7 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
     const uint32_t n_reads = (uint32_t)ctx->n_reads;
     ctx->tm = rala_hip_timings();
     ctx->overlaps.clear(); ctx->internals.clear();
-    ctx->initialized = ctx->constructed = false;
+    ctx->initialized = ctx->constructed = ctx->ev_ready = false;
     ctx->tail_on_device = ctx->host_stale = ctx->marks_on_device = false;
 
     HIPCHECK(ctx->d_pile.ensure(ctx->pile_elems + 8));
@@ -1781,6 +1832,8 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
         return fail(ctx, RALA_HIP_ECAPACITY, "interval pool exhausted (raise interval_pool_per_read_x1000)");
     }
     ctx->n_prefiltered = n_dead;
+    ctx->ev_ready = true;
+    ctx->ev_fixed = fixed;
     ctx->initialized = true;
     ctx->valid_ready = !ctx->tuple_mode;
     ctx->piles_resident = true;
@@ -1919,7 +1972,7 @@ int rala_hip_import_state_device(rala_hip_ctx* ctx, const rala_hip_device_state*
     ctx->initialized = true;
     ctx->valid_ready = true;
     ctx->constructed = false;
-    ctx->piles_resident = false;
+    ctx->piles_resident = ctx->ev_ready = false;
     ctx->tail_on_device = ctx->host_stale = ctx->marks_on_device = false;
     if (ctx->n_prefiltered == n) return fail(ctx, RALA_HIP_EFILTERED, "filtered all sequences");
     return RALA_HIP_OK;
@@ -1944,7 +1997,7 @@ int rala_hip_set_bound_tuples(rala_hip_ctx* ctx, const uint64_t* tuples, uint64_
     ctx->ovl = OvlSoA();
     HIPCHECK(ctx->d_ev.ensure(n + 8));
     HIPCHECK(ctx->d_scan_ws.ensure(scan_workspace_bytes(std::max<uint64_t>(n, ctx->n_reads) + 2)));
-    ctx->initialized = ctx->constructed = false;
+    ctx->initialized = ctx->constructed = ctx->ev_ready = false;
     return RALA_HIP_OK;
 }
 
@@ -2001,7 +2054,7 @@ int rala_hip_import_state(rala_hip_ctx* ctx, const uint8_t* valid, const uint32_
     ctx->initialized = true;
     ctx->valid_ready = true;
     ctx->constructed = false;
-    ctx->piles_resident = false;
+    ctx->piles_resident = ctx->ev_ready = false;
     ctx->tail_on_device = ctx->host_stale = ctx->marks_on_device = false;
     if (ctx->n_prefiltered == n) return fail(ctx, RALA_HIP_EFILTERED, "filtered all sequences");
     return RALA_HIP_OK;
