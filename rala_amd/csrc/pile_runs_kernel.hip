@@ -282,22 +282,27 @@ struct Layout {
 // run starts: bm (one bit per position that starts a run, bit n set for the padding behind the
 // last base), pref[w] = run starts before word w, rv = run values (rv[R] = 0).
 //
-// A lane owns byte (lane & 3) of bitmap word (group >> 2), so its masks are loop constants.
-// Pass A stores, for every group, the value of the group's first position in all 8 places
-// (no loop, about ten vector instructions per 16-byte store).  A group in which the value
-// changes (a run starts at one of its positions 1..7: about one group in seven) is noted in an
-// LDS list; pass B takes the noted groups 64 at a time, one per lane, walks the changes and
-// stores the group again.  Both stores of such a group go to the L2 within microseconds of
-// each other, HBM sees one write.  The walk used to run inside the store loop, where nearly
-// every iteration had some lane with a change and all 64 lanes paid for it.
+// A lane owns byte (lane & 3) of bitmap word (group >> 2), so its masks are loop constants.  For
+// most groups all 8 places hold the value of the group's first position (about ten vector
+// instructions per 16-byte store).  A group in which the value changes (a run starts at one of
+// its positions 1..7: about one group in seven) is noted in an LDS list; the noted groups of a
+// chunk of 256 are then taken one per lane, the changes walked, and the finished 16 bytes put
+// into an LDS table from which the group's own lane fetches them for the store.  Every byte of
+// the row is stored exactly once, by dense 1 KiB wave stores: patching the noted groups with
+// scattered 16-byte stores afterwards (64 different lines per instruction) cost as much as all
+// the dense stores together (C3: 3.6 ms against 4.0 ms, 5.8 ms for both).  The walk used to run
+// inside the store loop, where nearly every iteration had some lane with a change and all 64
+// lanes paid for it.
 template <class L>
 __device__ __forceinline__ void expand_from_bitmap(uint32_t* sm, const uint16_t* rv, uint16_t* pile, uint64_t row_off,
-                                                   uint32_t nv, uint32_t lane, bool store) {
+                                                   uint32_t nv, uint32_t lane, uint32_t store) {
     const uint32_t* bm = sm + L::X;
     const uint16_t* pref = (const uint16_t*)(bm + 512);
     const uint16_t* rvm1 = rv - 1;                      // indexed by run + 1 (= run starts at or before)
     uint32_t* list = sm + L::RF;                        // the region lists are not in use yet
-    static_assert(L::SEL - L::RF >= 320, "scratch for the list of groups with a value change");
+    constexpr uint32_t kTable = (L::RF + 64 + 3) & ~3u; // 16-byte aligned
+    uint4* table = (uint4*)(sm + kTable);               // 64 finished groups
+    static_assert(L::SEL >= kTable + 256, "scratch for the noted groups of a chunk");
     // the row address is the same in every lane: keep it in scalar registers, 32-bit lane offsets
     // (the builtin returns int: without the casts the low half would be sign-extended over the high one)
     const uint64_t off = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(row_off >> 32)) << 32) |
@@ -306,37 +311,6 @@ __device__ __forceinline__ void expand_from_bitmap(uint32_t* sm, const uint16_t*
     const uint32_t sh1 = ((lane & 3u) << 3) + 1u;
     const uint32_t below = (1u << sh1) - 1u;            // the bits at or before the group's first position
     const uint32_t w_lane = lane >> 2;
-    uint32_t pend = 0;
-    auto flush = [&]() {
-        wave_sync();
-        for (uint32_t j0 = 0; j0 < pend; j0 += 64) {
-            const uint32_t j = j0 + lane;
-            if (j < pend) {
-                const uint32_t e = list[j];
-                const uint32_t g = e & 2047u;
-                uint32_t kq = (e >> 11) & 2047u;
-                uint32_t inner = e >> 22;
-                const uint32_t v = rvm1[kq];
-                const uint32_t vv = v | (v << 16);
-                uint32_t w0 = vv, w1 = vv, w2 = vv, w3 = vv;
-                do {
-                    const uint32_t x = (uint32_t)__builtin_ctz(inner) + 1u;     // position 1 .. 7 inside the group
-                    inner &= inner - 1;
-                    const uint32_t nvv = rvm1[++kq];
-                    const uint32_t f = nvv | (nvv << 16);
-                    const uint32_t* mt = sm + L::MT + x;
-                    const uint32_t m0 = mt[6], m1 = mt[4], m2 = mt[2], m3 = mt[0];
-                    w0 = bitfield_insert(m0, f, w0);
-                    w1 = bitfield_insert(m1, f, w1);
-                    w2 = bitfield_insert(m2, f, w2);
-                    w3 = bitfield_insert(m3, f, w3);
-                } while (inner);
-                if (store) *(uint4*)(base + g * 16u) = make_uint4(w0, w1, w2, w3);
-            }
-        }
-        wave_sync();
-        pend = 0;
-    };
     auto chunk = [&](uint32_t g0, auto full_tag) {
         constexpr bool kFull = decltype(full_tag)::value;
         uint32_t bits[4], kq[4], v[4];
@@ -346,33 +320,80 @@ __device__ __forceinline__ void expand_from_bitmap(uint32_t* sm, const uint16_t*
             bits[u] = bm[w];
             kq[u] = pref[w];
         }
+        uint64_t noted[4];
+        uint32_t total = 0;
 #pragma unroll
         for (uint32_t u = 0; u < 4; ++u) {
             kq[u] += (uint32_t)__popc(bits[u] & below);             // bit 0 of the bitmap is set: >= 1
             v[u] = rvm1[kq[u]];                                     // (beyond the pile: some LDS word)
+            bits[u] = (bits[u] >> sh1) & 0x7Fu;                     // run starts at positions 1 .. 7
+            const bool in = kFull || g0 + 64u * u + lane < nv;
+            noted[u] = __builtin_amdgcn_ballot_w64(in && bits[u] != 0);
+            total += (uint32_t)__popcll(noted[u]);
         }
         char* row = base + (size_t)g0 * 16u;
+        // groups u in [ub, ue) of the chunk (at most 64 of them noted): walk, table, store
+        auto emit = [&](auto ub_tag, auto ue_tag) {
+            constexpr uint32_t ub = decltype(ub_tag)::value, ue = decltype(ue_tag)::value;
+            uint32_t slot[4] = {0, 0, 0, 0};
+            uint32_t cnt = 0;
 #pragma unroll
-        for (uint32_t u = 0; u < 4; ++u) {
-            const uint32_t gl = 64u * u + lane;
-            const bool in = kFull || g0 + gl < nv;
-            const uint32_t vv = v[u] | (v[u] << 16);
-            if (in && store) *(uint4*)(row + gl * 16u) = make_uint4(vv, vv, vv, vv);
-            const uint32_t inner = (bits[u] >> sh1) & 0x7Fu;        // run starts at positions 1 .. 7
-            const bool noted = in && inner != 0;
-            const uint64_t m = __builtin_amdgcn_ballot_w64(noted);
-            if (noted) {
-                const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                list[pend + at] = (g0 + gl) | (kq[u] << 11) | (inner << 22);
+            for (uint32_t u = ub; u < ue; ++u) {
+                const uint64_t m = noted[u];
+                slot[u] = cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                if ((m >> lane) & 1u) list[slot[u]] = kq[u] | (bits[u] << 16);
+                cnt += (uint32_t)__popcll(m);
             }
-            pend += (uint32_t)__popcll(m);
+            if (cnt) {
+                wave_sync();
+                if (lane < cnt) {
+                    const uint32_t e = list[lane];
+                    uint32_t k = e & 0xFFFFu;
+                    uint32_t inner = e >> 16;
+                    const uint32_t v0 = rvm1[k];
+                    const uint32_t vv = v0 | (v0 << 16);
+                    uint32_t w0 = vv, w1 = vv, w2 = vv, w3 = vv;
+                    do {
+                        const uint32_t x = (uint32_t)__builtin_ctz(inner) + 1u;     // position 1 .. 7 inside the group
+                        inner &= inner - 1;
+                        const uint32_t nvv = rvm1[++k];
+                        const uint32_t f = nvv | (nvv << 16);
+                        const uint32_t* mt = sm + L::MT + x;
+                        const uint32_t m0 = mt[6], m1 = mt[4], m2 = mt[2], m3 = mt[0];
+                        w0 = bitfield_insert(m0, f, w0);
+                        w1 = bitfield_insert(m1, f, w1);
+                        w2 = bitfield_insert(m2, f, w2);
+                        w3 = bitfield_insert(m3, f, w3);
+                    } while (inner);
+                    table[lane] = make_uint4(w0, w1, w2, w3);
+                }
+                wave_sync();
+            }
+#pragma unroll
+            for (uint32_t u = ub; u < ue; ++u) {
+                const uint32_t gl = 64u * u + lane;
+                const bool in = kFull || g0 + gl < nv;
+                const uint32_t vv = v[u] | (v[u] << 16);
+                uint4 out = make_uint4(vv, vv, vv, vv);
+                if ((noted[u] >> lane) & 1u) out = table[slot[u]];
+                if (in && store) *(uint4*)(row + gl * 16u) = out;
+            }
+            wave_sync();                                // the table is rewritten by the next call
+        };
+        typedef std::integral_constant<uint32_t, 0> I0;
+        typedef std::integral_constant<uint32_t, 1> I1;
+        typedef std::integral_constant<uint32_t, 2> I2;
+        typedef std::integral_constant<uint32_t, 3> I3;
+        typedef std::integral_constant<uint32_t, 4> I4;
+        if (total <= 64) {
+            emit(I0(), I4());
+        } else {
+            emit(I0(), I1()); emit(I1(), I2()); emit(I2(), I3()); emit(I3(), I4());
         }
-        if (pend >= 64) flush();
     };
     uint32_t g0 = 0;
     for (; g0 + 256 <= nv; g0 += 256) chunk(g0, std::true_type());
     if (g0 < nv) chunk(g0, std::false_type());
-    if (pend) flush();
 }
 
 }  // namespace
@@ -406,8 +427,13 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
     uint32_t* sel = sm + L::SEL;
     const uint32_t n_items = A.n_items_dev ? *A.n_items_dev : A.n_items;
 
+    // diagnostics: 77 = everything but the row stores; 100 * m + k = leave after phase k, with
+    // m = 1: no row stores, 2: no patch stores (pass B of the expansion), 3: only those
+    const uint32_t stop_k = A.stop_after >= 100 ? A.stop_after % 100 : A.stop_after;
+    const uint32_t stop_m = A.stop_after >= 100 ? A.stop_after / 100 : 0;
+    const uint32_t row_stores = !kDiag ? 3u : (A.stop_after == 77 || stop_m == 1) ? 0u : stop_m == 2 ? 1u : stop_m == 3 ? 2u : 3u;
 #define RUN_STOP(k)                                                        \
-    if (kDiag && A.stop_after == (k)) {                                    \
+    if (kDiag && stop_k == (k)) {                                          \
         if (lane == 0) A.alive[A.order ? A.order[item] : item] = 0;        \
         wave_sync();                                                       \
         continue;                                                          \
@@ -419,6 +445,7 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
     for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
         const uint32_t r = A.order ? A.order[item] : item;
         const uint32_t n = A.read_len[r];
+        const uint64_t row_off = kSens == 2 ? 0 : A.pile_off[r];
         const uint32_t n_ev_p = A.ev_cnt ? umin(A.ev_cnt[r], A.ev_stride) : A.ev_off[r + 1] - A.ev_off[r];
         const uint32_t* __restrict__ rev = A.ev_cnt ? A.ev + (size_t)r * A.ev_stride : A.ev + A.ev_off[r];
         uint32_t n_ev = n_ev_p;
@@ -671,7 +698,7 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
         }
         RUN_STOP(23)
 
-        // ---- 4. Pile::shrink: zero outside; position index (the expansion to HBM is step 10) --
+        // ---- 4. Pile::shrink: zero outside; position index --------------------------------
         for (uint32_t k = lane; k < R; k += 64) {
             if (k < kB || k >= kE) rv[k] = 0;
         }
@@ -713,7 +740,116 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
         wave_sync();
         RUN_STOP(24)
 
-        // ---- 5. order statistics over (value, length) of the runs in [kB, kE) --------------
+        // ---- 5. expansion to HBM (Pile::add_layers' result after Pile::shrink), EARLY: the 20 KB of
+        // a row take microseconds to drain; issued here they drain behind the annotation phases
+        // instead of holding the wavefront's slot, LDS and registers at the end of the kernel.
+        // Two things keep the compiler from parking the wave on `s_waitcnt vmcnt(0)` in front of
+        // the next phase: every global load of this read is issued before this point (the row
+        // offset at the top, not here) and explicitly waited for, so no load is pending on any
+        // path when the stores start; stores themselves leave nothing to wait for.  (Reads that
+        // are handed on to the next kernel of the chain are written again there; the 4 % of the
+        // reads that allocate pool entries wait for their stores at that returning atomic.)
+        // 16 bytes (8 positions) per lane and store, consecutive lanes -> consecutive addresses
+        // (1 KiB per wave instruction); reads of up to 16384 positions go through
+        // expand_from_bitmap on the bitmap of run starts that built the runs.  The sorted path,
+        // per segment of 16384 positions: a bitmap with one bit per position that starts a run,
+        // and per 32-bit word the number of run starts before it; the run of position p is then
+        // pref[w] + popcount(bits up to p) - no searching, and the byte of the bitmap that
+        // belongs to a lane's 8 positions says where (if anywhere) the value changes.
+        if constexpr (kSens != 2) {
+            __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0), nothing else
+            constexpr uint32_t kSeg = 16384, kBmWords = kSeg / 32;
+            uint32_t* bm = sm + L::X;
+            uint16_t* pref = (uint16_t*)(bm + kBmWords);
+            uint4* dst = (uint4*)(A.pile + row_off);
+            const uint32_t nv = (n + 7) / 8;
+            if (lane == 0) rv[R] = 0;                       // padding behind the last base (rs[R] = n)
+            uint32_t kbase = 0;                             // run that contains the segment's first position
+            if (bitmap_path) {
+                // one more bit for the padding behind the last base: run R, value 0
+                if (lane == 0 && n < kSeg) atomicOr(&bm[n >> 5], 1u << (n & 31));
+                wave_sync();
+                expand_from_bitmap<L>(sm, rv, A.pile, row_off, nv, lane, row_stores);
+            } else
+            for (uint32_t s0 = 0; s0 < nv * 8; s0 += kSeg) {       // sorted path: long reads, many events
+                {
+                    wave_sync();
+                    ((uint4*)bm)[lane] = make_uint4(0, 0, 0, 0);
+                    ((uint4*)bm)[lane + 64] = make_uint4(0, 0, 0, 0);
+                    wave_sync();
+                    for (uint32_t k = 1 + lane; k <= R; k += 64) {
+                        const uint32_t st = rs[k] - s0;         // starts are distinct positions
+                        if (st < kSeg && rs[k] > 0) atomicOr(&bm[st >> 5], 1u << (st & 31));
+                    }
+                    wave_sync();
+                    {
+                        const uint4 a = ((const uint4*)bm)[2 * lane], b = ((const uint4*)bm)[2 * lane + 1];
+                        const uint32_t c[8] = {(uint32_t)__popc(a.x), (uint32_t)__popc(a.y), (uint32_t)__popc(a.z),
+                                               (uint32_t)__popc(a.w), (uint32_t)__popc(b.x), (uint32_t)__popc(b.y),
+                                               (uint32_t)__popc(b.z), (uint32_t)__popc(b.w)};
+                        const uint32_t tot = c[0] + c[1] + c[2] + c[3] + c[4] + c[5] + c[6] + c[7];
+                        const uint32_t incl = wave_scan_incl(tot, OpAdd());
+                        uint32_t run = kbase + incl - tot;
+                        uint32_t pk[4];
+#pragma unroll
+                        for (int x = 0; x < 4; ++x) {
+                            const uint32_t lo = run; run += c[2 * x];
+                            const uint32_t hi = run; run += c[2 * x + 1];
+                            pk[x] = lo | (hi << 16);
+                        }
+                        ((uint4*)pref)[lane] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                        kbase += read_lane63(incl);
+                    }
+                    wave_sync();
+                }
+                const uint32_t g_lo = s0 / 8, g_hi = umin(nv, (s0 + kSeg) / 8);
+                for (uint32_t g0 = g_lo + lane; g0 < g_hi; g0 += 256) {
+                    uint32_t bits[4], k[4], v[4];
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; ++u) {
+                        const uint32_t g = umin(g0 + 64 * u, g_hi - 1);
+                        const uint32_t w = (g * 8 - s0) >> 5;
+                        bits[u] = bm[w];
+                        k[u] = pref[w];
+                    }
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; ++u) {
+                        const uint32_t g = umin(g0 + 64 * u, g_hi - 1);
+                        const uint32_t sh = (g * 8) & 31;
+                        k[u] += (uint32_t)__popc(bits[u] & ((2u << sh) - 1u));
+                        bits[u] = (bits[u] >> (sh + 1)) & 0x7Fu;        // starts at positions 1 .. 7 of the group
+                        v[u] = rv[k[u]];
+                    }
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; ++u) {
+                        const uint32_t g = g0 + 64 * u;
+                        if (g >= g_hi) break;
+                        const uint32_t vv = v[u] | (v[u] << 16);
+                        uint32_t w0 = vv, w1 = vv, w2 = vv, w3 = vv;
+                        uint32_t inner = bits[u], kk = k[u];
+                        while (inner) {
+                            const uint32_t x = (uint32_t)__ffs((int)inner);     // position 1 .. 7 inside the group
+                            inner &= inner - 1;
+                            const uint32_t nvv = rv[++kk];
+                            const uint32_t f = nvv | (nvv << 16);
+                            const uint32_t* mt = sm + L::MT + x;
+                            const uint32_t m0 = mt[6], m1 = mt[4], m2 = mt[2], m3 = mt[0];
+                            w0 = bitfield_insert(m0, f, w0);
+                            w1 = bitfield_insert(m1, f, w1);
+                            w2 = bitfield_insert(m2, f, w2);
+                            w3 = bitfield_insert(m3, f, w3);
+                        }
+                        if (row_stores == 3u) dst[g] = make_uint4(w0, w1, w2, w3);
+                    }
+                }
+            }
+        }
+        wave_sync();
+
+
+        RUN_STOP(31)
+
+        // ---- 6. order statistics over (value, length) of the runs in [kB, kE) --------------
         uint32_t med, p10;
         if constexpr (kSens == 2) {
             med = A.median[r];
@@ -771,7 +907,7 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
         if constexpr (kSens == 1) {
             if (lane == 0) { A.median[r] = (uint16_t)med; A.p10[r] = (uint16_t)p10; }
         } else {
-        // ---- 6. slope flags per run: a flagged prefix (down) and suffix (up) ----------------
+        // ---- 7. slope flags per run: a flagged prefix (down) and suffix (up) ----------------
         // down(i), i in run k  <=>  some run j < k with value > t(v_k) reaches into
         // [i-847, i-1]  <=>  i <= end_j + 846 for the nearest such j;   up(i) likewise
         // with the nearest j > k: i >= start_j - 847.   t(v) = int32(v * q)  (pile.cpp:94)
@@ -892,7 +1028,7 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
         wave_sync();
         RUN_STOP(26)
 
-        // ---- 7. maximal unions of touching intervals -> regions (first, last) ----------------
+        // ---- 8. maximal unions of touching intervals -> regions (first, last) ----------------
 #pragma unroll 1
         for (uint32_t w = 0; w < (kSens == 2 ? 2u : 4u); ++w) {
             const uint16_t* iv = (w == 0) ? d13 : (w == 1) ? u13 : (w == 2) ? d182 : u182;
@@ -945,7 +1081,7 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
         wave_sync();
         RUN_STOP(27)
 
-        // ---- 8. per q: merged region list; resolve / narrow only when regions interact;
+        // ---- 9. per q: merged region list; resolve / narrow only when regions interact;
         //         pits (q = 1.82) and hills (q = 1.3) ---------------------------------------------
         bool any_overflow = false;
 #pragma unroll 1
@@ -1158,7 +1294,7 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
         wave_sync();
         RUN_STOP(28)
 
-        // ---- 9. publish ----------------------------------------------------------------------------
+        // ---- 10. publish ----------------------------------------------------------------------------
         if (any_overflow) {
             // more regions / raw intervals than this instantiation keeps: hand the read on
             if (lane == 0) overflow_list[atomicAdd(overflow_count, 1u)] = r;
@@ -1227,128 +1363,6 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
         }
         }
         wave_sync();
-        if constexpr (kSens != 2) {
-            // ---- 10. expansion, LAST: nothing behind it waits for the stores to drain (the
-            // compiler puts s_waitcnt vmcnt(0) in front of LDS traffic that follows global stores;
-            // in the middle of the kernel that parked the wave until the whole row was in memory),
-            // and a read that is handed on to the next kernel of the chain is not written twice.
-            // 16 bytes (8 positions) per lane and store, consecutive lanes ->
-            // consecutive addresses (1 KiB per wave instruction); reads of up to 16384 positions
-            // go through expand_from_bitmap.  The sorted path, per segment of 16384
-            // positions: a bitmap with one bit per position that starts a run, and per
-            // 32-bit word the number of run starts before it; the run of position p is then
-            // pref[w] + popcount(bits up to p) - no searching, and the byte of the bitmap
-            // that belongs to a lane's 8 positions says where (if anywhere) the value changes.
-            constexpr uint32_t kSeg = 16384, kBmWords = kSeg / 32;
-            uint32_t* bm = sm + L::X;                       // the group counts are no longer needed
-            uint16_t* pref = (uint16_t*)(bm + kBmWords);
-            uint4* dst = (uint4*)(A.pile + A.pile_off[r]);
-            const uint32_t nv = (n + 7) / 8;
-            if (lane == 0) rv[R] = 0;                       // padding behind the last base (rs[R] = n)
-            uint32_t kbase = 0;                             // run that contains the segment's first position
-            if (bitmap_path) {
-                // one bit per run start again (the annotation phases used the region), one more for
-                // the padding behind the last base (rs[R] = n), and the run starts before every word
-                ((uint4*)bm)[lane] = make_uint4(0, 0, 0, 0);
-                ((uint4*)bm)[lane + 64] = make_uint4(0, 0, 0, 0);
-                wave_sync();
-                for (uint32_t k = lane; k <= R; k += 64) {
-                    const uint32_t pos = rs[k];
-                    if (pos < kSeg) atomicOr(&bm[pos >> 5], 1u << (pos & 31));
-                }
-                wave_sync();
-                {
-                    const uint4 x = ((const uint4*)bm)[2 * lane], y = ((const uint4*)bm)[2 * lane + 1];
-                    const uint32_t c[8] = {(uint32_t)__popc(x.x), (uint32_t)__popc(x.y), (uint32_t)__popc(x.z),
-                                           (uint32_t)__popc(x.w), (uint32_t)__popc(y.x), (uint32_t)__popc(y.y),
-                                           (uint32_t)__popc(y.z), (uint32_t)__popc(y.w)};
-                    const uint32_t tot = c[0] + c[1] + c[2] + c[3] + c[4] + c[5] + c[6] + c[7];
-                    uint32_t run = wave_scan_incl(tot, OpAdd()) - tot;
-                    uint32_t pk[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const uint32_t lo = run; run += c[2 * q];
-                        const uint32_t hi = run; run += c[2 * q + 1];
-                        pk[q] = lo | (hi << 16);
-                    }
-                    ((uint4*)pref)[lane] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-                }
-                wave_sync();
-                expand_from_bitmap<L>(sm, rv, A.pile, A.pile_off[r], nv, lane, !kDiag || A.stop_after != 77);
-            } else
-            for (uint32_t s0 = 0; s0 < nv * 8; s0 += kSeg) {       // sorted path: long reads, many events
-                {
-                    wave_sync();
-                    ((uint4*)bm)[lane] = make_uint4(0, 0, 0, 0);
-                    ((uint4*)bm)[lane + 64] = make_uint4(0, 0, 0, 0);
-                    wave_sync();
-                    for (uint32_t k = 1 + lane; k <= R; k += 64) {
-                        const uint32_t st = rs[k] - s0;         // starts are distinct positions
-                        if (st < kSeg && rs[k] > 0) atomicOr(&bm[st >> 5], 1u << (st & 31));
-                    }
-                    wave_sync();
-                    {
-                        const uint4 a = ((const uint4*)bm)[2 * lane], b = ((const uint4*)bm)[2 * lane + 1];
-                        const uint32_t c[8] = {(uint32_t)__popc(a.x), (uint32_t)__popc(a.y), (uint32_t)__popc(a.z),
-                                               (uint32_t)__popc(a.w), (uint32_t)__popc(b.x), (uint32_t)__popc(b.y),
-                                               (uint32_t)__popc(b.z), (uint32_t)__popc(b.w)};
-                        const uint32_t tot = c[0] + c[1] + c[2] + c[3] + c[4] + c[5] + c[6] + c[7];
-                        const uint32_t incl = wave_scan_incl(tot, OpAdd());
-                        uint32_t run = kbase + incl - tot;
-                        uint32_t pk[4];
-#pragma unroll
-                        for (int x = 0; x < 4; ++x) {
-                            const uint32_t lo = run; run += c[2 * x];
-                            const uint32_t hi = run; run += c[2 * x + 1];
-                            pk[x] = lo | (hi << 16);
-                        }
-                        ((uint4*)pref)[lane] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-                        kbase += read_lane63(incl);
-                    }
-                    wave_sync();
-                }
-                const uint32_t g_lo = s0 / 8, g_hi = umin(nv, (s0 + kSeg) / 8);
-                for (uint32_t g0 = g_lo + lane; g0 < g_hi; g0 += 256) {
-                    uint32_t bits[4], k[4], v[4];
-#pragma unroll
-                    for (uint32_t u = 0; u < 4; ++u) {
-                        const uint32_t g = umin(g0 + 64 * u, g_hi - 1);
-                        const uint32_t w = (g * 8 - s0) >> 5;
-                        bits[u] = bm[w];
-                        k[u] = pref[w];
-                    }
-#pragma unroll
-                    for (uint32_t u = 0; u < 4; ++u) {
-                        const uint32_t g = umin(g0 + 64 * u, g_hi - 1);
-                        const uint32_t sh = (g * 8) & 31;
-                        k[u] += (uint32_t)__popc(bits[u] & ((2u << sh) - 1u));
-                        bits[u] = (bits[u] >> (sh + 1)) & 0x7Fu;        // starts at positions 1 .. 7 of the group
-                        v[u] = rv[k[u]];
-                    }
-#pragma unroll
-                    for (uint32_t u = 0; u < 4; ++u) {
-                        const uint32_t g = g0 + 64 * u;
-                        if (g >= g_hi) break;
-                        const uint32_t vv = v[u] | (v[u] << 16);
-                        uint32_t w0 = vv, w1 = vv, w2 = vv, w3 = vv;
-                        uint32_t inner = bits[u], kk = k[u];
-                        while (inner) {
-                            const uint32_t x = (uint32_t)__ffs((int)inner);     // position 1 .. 7 inside the group
-                            inner &= inner - 1;
-                            const uint32_t nvv = rv[++kk];
-                            const uint32_t f = nvv | (nvv << 16);
-                            const uint32_t* mt = sm + L::MT + x;
-                            const uint32_t m0 = mt[6], m1 = mt[4], m2 = mt[2], m3 = mt[0];
-                            w0 = bitfield_insert(m0, f, w0);
-                            w1 = bitfield_insert(m1, f, w1);
-                            w2 = bitfield_insert(m2, f, w2);
-                            w3 = bitfield_insert(m3, f, w3);
-                        }
-                        if (!kDiag || A.stop_after != 77) dst[g] = make_uint4(w0, w1, w2, w3);
-                    }
-                }
-            }
-        }
         wave_sync();
     }
 #undef RUN_STOP
