@@ -444,6 +444,19 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
     if (lane < 14) sm[L::MT + lane] = lane <= 6 ? 0xFFFFFFFFu : lane == 7 ? 0xFFFF0000u : 0u;
     for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
         const uint32_t r = A.order ? A.order[item] : item;
+        // A wavefront's life starts with dependent round trips to memory (arguments -> counts ->
+        // events), and at one read per wavefront nothing of its own overlaps them.  With fixed
+        // slots the address of the events does not depend on anything loaded: the first 256
+        // slot entries (most reads have fewer events) are requested together with the counts;
+        // what lies behind the count is masked when it is known.
+        constexpr uint32_t kEarly = kCap / 64 < 4 ? kCap / 64 : 4;
+        const bool slots = kSens == 0 && kCap <= 1024 && A.ev_cnt != nullptr;
+        uint32_t ev_early[kEarly];
+        if (slots) {
+            const uint32_t* __restrict__ slot = A.ev + (size_t)r * A.ev_stride;
+#pragma unroll
+            for (uint32_t t = 0; t < kEarly; ++t) ev_early[t] = slot[t * 64 + lane];
+        }
         const uint32_t n = A.read_len[r];
         const uint64_t row_off = kSens == 2 ? 0 : A.pile_off[r];
         const uint32_t n_ev_p = A.ev_cnt ? umin(A.ev_cnt[r], A.ev_stride) : A.ev_off[r + 1] - A.ev_off[r];
@@ -488,8 +501,20 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
             uint32_t evr[kCap / 64];
             const uint32_t e_last = n_ev ? n_ev - 1 : 0;
             if constexpr (kSens == 0) {
+                if (slots) {
 #pragma unroll
-                for (uint32_t t = 0; t < kCap / 64; ++t) evr[t] = rev[umin(t * 64 + lane, e_last)];
+                    for (uint32_t t = 0; t < kEarly; ++t) evr[t] = ev_early[t];
+                    if (n_ev > kEarly * 64) {
+#pragma unroll
+                        for (uint32_t t = kEarly; t < kCap / 64; ++t) evr[t] = rev[umin(t * 64 + lane, e_last)];
+                    } else {
+#pragma unroll
+                        for (uint32_t t = kEarly; t < kCap / 64; ++t) evr[t] = kNone;
+                    }
+                } else {
+#pragma unroll
+                    for (uint32_t t = 0; t < kCap / 64; ++t) evr[t] = rev[umin(t * 64 + lane, e_last)];
+                }
 #pragma unroll
                 for (uint32_t t = 0; t < kCap / 64; ++t) {
                     if (t * 64 + lane >= n_ev) evr[t] = kNone;
@@ -516,6 +541,7 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
                 if (lane == 2 && given_e < n) atomicOr(&bm[given_e >> 5], 1u << (given_e & 31));
             }
             wave_sync();
+            RUN_STOP(41)
             {
                 const uint4 x = ((const uint4*)bm)[2 * lane], y = ((const uint4*)bm)[2 * lane + 1];
                 const uint32_t c[8] = {(uint32_t)__popc(x.x), (uint32_t)__popc(x.y), (uint32_t)__popc(x.z),
@@ -535,6 +561,7 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
                 R = read_lane63(incl);
             }
             wave_sync();
+            RUN_STOP(42)
 #pragma unroll
             for (uint32_t t = 0; t < kCap / 64; ++t) {
                 if (t * 64 >= n_ev) break;
@@ -556,6 +583,7 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
                 }
             }
             wave_sync();
+            RUN_STOP(43)
             {
                 const uint32_t cc = (R + 63) / 64;
                 const uint32_t lo = umin(R, lane * cc), hi = umin(R, lo + cc);
@@ -856,12 +884,38 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
             p10 = A.p10[r];
         } else {
             uint32_t* hist = sm + L::X;
+            // coverage below 256 everywhere (the rule): one histogram of 256 bins answers both
+            const uint32_t m = E - B;
+            const uint32_t k1 = m / 2, k2 = m / 10;
+            ((uint4*)hist)[lane] = make_uint4(0, 0, 0, 0);
+            wave_sync();
+            bool big = false;
+            for (uint32_t k = kB + lane; k < kE; k += 64) {
+                const uint32_t v = rv[k];
+                if (v < 256) atomicAdd(&hist[v], rs[k + 1] - rs[k]);
+                else big = true;
+            }
+            const bool any_big = __builtin_amdgcn_ballot_w64(big) != 0;
+            wave_sync();
+            if (!any_big) {
+                const uint4 c4 = ((const uint4*)hist)[lane];
+                const uint32_t c[4] = {c4.x, c4.y, c4.z, c4.w};
+                const uint32_t incl = wave_scan_incl(c[0] + c[1] + c[2] + c[3], OpAdd());
+                uint32_t before = incl - (c[0] + c[1] + c[2] + c[3]);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    if (k1 >= before && k1 < before + c[b]) sel[6] = 4 * lane + b;
+                    if (k2 >= before && k2 < before + c[b]) sel[7] = 4 * lane + b;
+                    before += c[b];
+                }
+                wave_sync();
+                med = sel[6];
+                p10 = sel[7];
+            } else {
             for (uint32_t j = lane; j < 768; j += 64) hist[j] = 0;
             wave_sync();
             for (uint32_t k = kB + lane; k < kE; k += 64) atomicAdd(&hist[rv[k] >> 8], rs[k + 1] - rs[k]);
             wave_sync();
-            const uint32_t m = E - B;
-            const uint32_t k1 = m / 2, k2 = m / 10;
             {
                 const uint32_t c0 = hist[4 * lane], c1 = hist[4 * lane + 1], c2 = hist[4 * lane + 2],
                                c3 = hist[4 * lane + 3];
@@ -900,6 +954,7 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
             wave_sync();
             med = (h1 << 8) | sel[6];
             p10 = (h2 << 8) | sel[7];
+            }
         }
         wave_sync();
         RUN_STOP(25)
@@ -933,6 +988,7 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
             bm8[b] = m;
         }
         wave_sync();
+        RUN_STOP(44)
         uint32_t n_surv = 0;
         for (uint32_t k0 = 0; k0 < R; k0 += 64) {
             const uint32_t k = k0 + lane;
@@ -963,6 +1019,7 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
             n_surv += (uint32_t)__popcll(m);
         }
         wave_sync();
+        RUN_STOP(45)
         if (n_surv > kSurv) {
             // more flagged runs than this instantiation keeps: hand the read on
             if (lane == 0) overflow_list[atomicAdd(overflow_count, 1u)] = r;
