@@ -34,6 +34,22 @@ def test_full_path_small(hip_ctx_factory, n, g, seed, run_kernel):
         assert tm["pile_position_reads"] > 0 and tm["pile_overflow_reads"] >= tm["pile_position_reads"]
 
 
+@pytest.mark.parametrize("n,g,seed", [(3000, 600_000, 21), (400, 20_000, 5), (1500, 12_000, 3)])
+def test_bucketing_variants(hip_ctx_factory, n, g, seed):
+    """The two ways the bounds reach the pile kernel: fixed slots (default; the position inside the
+    slot is what the counting atomic returns) and the exact CSR (count, scan, scatter)."""
+    ds = Dataset(n, g, seed)
+    st = parity.oracle_stages(ds)
+    for opts in ({"use_fixed_buckets": 0}, {}):
+        ctx = hip_ctx_factory()
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        ctx.set_reads(ds.read_len)
+        ctx.set_overlaps(ds.overlaps)
+        ctx.initialize()
+        parity.check_initialize(ctx, st, ds)
+
+
 @pytest.mark.parametrize("n,g,seed", [(3000, 600_000, 21), (2000, 1_200_000, 33), (600, 60_000, 9)])
 def test_host_tail_cross_check(hip_ctx_factory, n, g, seed):
     """use_gpu_tail = 0: Graph::preprocess on the host (the path the sensitive pass uses)."""
