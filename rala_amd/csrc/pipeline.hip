@@ -1328,12 +1328,30 @@ int pass2(rala_hip_ctx* ctx, Comm* comm) {
     ctx->tm.death_rounds = 0;
     int cur = 0;
     bool gathered = comm == nullptr;                             // the killer lists are complete on this rank
+    // Once few killers are left a round costs what the host's look at the counter costs.  A round
+    // over an empty list changes nothing, so the host then enqueues several rounds at a time and
+    // looks once; the list sizes of the rounds it did not look at are logged on the device (for
+    // the round count) and read with the next results.
+    constexpr uint32_t kFewKillers = 1u << 16, kRoundsPerLook = 5, kLogged = 64;
+    constexpr uint32_t kNotSeen = 0xFFFFFFFFu;
+    HIPCHECK(ctx->d_round_log.ensure(kLogged));
+    std::vector<uint32_t> list_size;                             // after every round; kNotSeen = in the log
+    uint32_t unseen = 0, n_logged = 0;
     for (;;) {
         HIPCHECK(hipMemsetAsync(klist[cur ^ 1].count, 0, 4, s));
         launch_death_decide(klist[cur], lo, up, sure, klist[cur ^ 1], s);
         cur ^= 1;
         // tighter bounds for the next round: up = sure, lo = min(sure, undecided killers)
         uint32_t undecided = 0;
+        if (gathered && unseen && n_logged < kLogged) {
+            --unseen;
+            launch_death_status(klist[cur].count, ctx->d_round_log.p + n_logged++, s);
+            list_size.push_back(kNotSeen);
+            HIPCHECK(hipMemcpyAsync(up, sure, dbytes, hipMemcpyDeviceToDevice, s));
+            HIPCHECK(hipMemcpyAsync(lo, sure, dbytes, hipMemcpyDeviceToDevice, s));
+            launch_death_lower(klist[cur], lo, s);
+            continue;
+        }
         if (gathered) {
             HIPCHECK(d2h_small(ctx, &undecided, klist[cur].count, 4, s));
             HIPCHECK(stream_sync(ctx, s));
@@ -1347,14 +1365,15 @@ int pass2(rala_hip_ctx* ctx, Comm* comm) {
             HIPCHECK(stream_sync(ctx, s));
             undecided = 0xFFFFFFFFu - st;                        // the largest list of any rank
         }
-        ++ctx->tm.death_rounds;
-        if (getenv("RALA_HIP_TRACE")) fprintf(stderr, "[trace] containment round %d: %u undecided\n", (int)ctx->tm.death_rounds, undecided);
+        list_size.push_back(undecided);
+        if (getenv("RALA_HIP_TRACE")) fprintf(stderr, "[trace] containment round %d: %u undecided\n", (int)list_size.size(), undecided);
         if (undecided == 0) break;
-        if (ctx->tm.death_rounds > 100000) return fail(ctx, RALA_HIP_EDEVICE, "containment fixed point did not converge");
+        if (list_size.size() > 100000) return fail(ctx, RALA_HIP_EDEVICE, "containment fixed point did not converge");
         HIPCHECK(hipMemcpyAsync(up, sure, dbytes, hipMemcpyDeviceToDevice, s));
         if (gathered) {
             HIPCHECK(hipMemcpyAsync(lo, sure, dbytes, hipMemcpyDeviceToDevice, s));
             launch_death_lower(klist[cur], lo, s);
+            if (undecided <= kFewKillers && ctx->use_round_batches) unseen = kRoundsPerLook;
         } else if ((uint64_t)undecided * comm->world() <= (1u << 16)) {
             // few killers left: every rank takes all of them and the rest needs no collective
             uint64_t mine = 0;
@@ -1403,7 +1422,18 @@ int pass2(rala_hip_ctx* ctx, Comm* comm) {
         launch_exclusive_scan(ctx->d_chunk[k].p, ctx->d_chunk[2 + k].p, n_chunks, ctx->d_scan_ws.p, s);
         HIPCHECK(d2h_small(ctx, &n_surv[k], ctx->d_chunk[2 + k].p + n_chunks, 4, s));
     }
+    uint32_t round_log[64];
+    if (n_logged) HIPCHECK(d2h_small(ctx, round_log, ctx->d_round_log.p, n_logged * 4, s));
     HIPCHECK(stream_sync(ctx, s));
+    {
+        // rounds until the list was empty
+        uint32_t at = 0;
+        ctx->tm.death_rounds = (uint32_t)list_size.size();
+        for (size_t r = 0; r < list_size.size(); ++r) {
+            const uint32_t sz = list_size[r] == kNotSeen ? 0xFFFFFFFFu - round_log[at++] : list_size[r];
+            if (sz == 0) { ctx->tm.death_rounds = (uint32_t)r + 1; break; }
+        }
+    }
     auto tail_view = [&]() {
         Survivors sv;
         sv.src = ctx->d_surv_u32[0].p; sv.a_id = ctx->d_surv_u32[1].p; sv.b_id = ctx->d_surv_u32[2].p;
@@ -1573,6 +1603,7 @@ int rala_hip_set_option(rala_hip_ctx* ctx, const char* key, int64_t value) {
     if (!strcmp(key, "max_lds_read_len")) { ctx->max_lds_read_len = value; return RALA_HIP_OK; }
     if (!strcmp(key, "debug_pile_stop_after")) { ctx->debug_pile_stop_after = value; return RALA_HIP_OK; }
     if (!strcmp(key, "use_run_kernel")) { ctx->use_run_kernel = value != 0; return RALA_HIP_OK; }
+    if (!strcmp(key, "use_round_batches")) { ctx->use_round_batches = value != 0; return RALA_HIP_OK; }
     if (!strcmp(key, "use_gpu_tail")) { ctx->use_gpu_tail = value != 0; return RALA_HIP_OK; }
     if (!strcmp(key, "use_fixed_buckets")) { ctx->use_fixed_buckets = value != 0; return RALA_HIP_OK; }
     if (!strcmp(key, "use_side_stream")) { ctx->use_side_stream = value != 0; return RALA_HIP_OK; }
