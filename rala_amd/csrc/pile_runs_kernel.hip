@@ -993,28 +993,39 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
         for (uint32_t k0 = 0; k0 < R; k0 += 64) {
             const uint32_t k = k0 + lane;
             bool need = false;
+            uint32_t sides = 0;         // bit 0 / 1: something left of the run may exceed t13 / t182; bits 2, 3: right
             if (k < R) {
                 const uint32_t v = rv[k];
                 const uint32_t sk = rs[k], ek = rs[k + 1];
                 // == int32(v * 1.3) (sensitive pass: v * 1.42) for every uint16 v
                 const int32_t t13 = kSens == 2 ? (int32_t)(v * 142u / 100u) : (int32_t)(v * 13u / 10u);
+                const int32_t t182 = kSens == 2 ? t13 : (int32_t)(v * 182u / 100u);
                 const uint32_t gl = (sk >= 847u ? sk - 847u : 0u) >> shift;
                 const uint32_t gr = ((ek + 846u) >> shift) + 1u;
                 const uint32_t jl = idx[gl];
                 const uint32_t jr = gr < ng ? idx[gr] : R - 1;
-                int32_t ub = 0;
-                for (uint32_t b = jl >> 3; b <= (jr >> 3); b += 4) {
+                // bounds for the two sides apart (the run's own block counts for both): the scans
+                // below then stop at the first neighbour above t13 unless one above t182 can exist
+                const uint32_t own = k >> 3;
+                int32_t ub_l = 0, ub_r = 0;
+                for (uint32_t b = jl >> 3; b <= own; b += 4) {
+                    const int32_t m0 = (int32_t)bm8[b], m1 = (int32_t)bm8[umin(b + 1, own)],
+                                  m2 = (int32_t)bm8[umin(b + 2, own)], m3 = (int32_t)bm8[umin(b + 3, own)];
+                    ub_l = max(max(ub_l, m0), max(m1, max(m2, m3)));
+                }
+                for (uint32_t b = own; b <= (jr >> 3); b += 4) {
                     const uint32_t last = jr >> 3;
                     const int32_t m0 = (int32_t)bm8[b], m1 = (int32_t)bm8[umin(b + 1, last)],
                                   m2 = (int32_t)bm8[umin(b + 2, last)], m3 = (int32_t)bm8[umin(b + 3, last)];
-                    ub = max(max(ub, m0), max(m1, max(m2, m3)));
+                    ub_r = max(max(ub_r, m0), max(m1, max(m2, m3)));
                 }
-                need = ub > t13;
+                sides = (ub_l > t13 ? 1u : 0u) | (ub_l > t182 ? 2u : 0u) | (ub_r > t13 ? 4u : 0u) | (ub_r > t182 ? 8u : 0u);
+                need = (sides & 5u) != 0;
             }
             const uint64_t m = __ballot(need);
             if (need) {
                 const uint32_t w = n_surv + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                if (w < kSurv) surv[w] = (uint16_t)k;
+                if (w < kSurv) surv[w] = (uint16_t)(k | sides << 12);
             }
             n_surv += (uint32_t)__popcll(m);
         }
@@ -1026,8 +1037,10 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
             wave_sync();
             continue;
         }
+        static_assert(L::kArr <= 4096, "run index and side flags share 16 bits");
         for (uint32_t j = lane; j < n_surv; j += 64) {
-            const uint32_t k = surv[j];
+            const uint32_t k = surv[j] & 0xFFFu, sides = surv[j] >> 12;
+            surv[j] = (uint16_t)k;
             const uint32_t v = rv[k];
             const uint32_t sk = rs[k], ek = rs[k + 1];
             // int32(v * q) of pile.cpp:94 in integers: exact for every 16-bit v (tools/threshold_check.c)
@@ -1036,7 +1049,7 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
             const int32_t t182 = kSens == 2 ? t13 : (int32_t)(v * 182u / 100u);
             uint32_t dl13 = kNone, dl182 = kNone, ur13 = kNone, ur182 = kNone;
             {
-                bool done = false;
+                bool done = !(sides & 1u);
                 for (uint32_t j0 = k; j0 > 0 && !done;) {          // neighbours in batches of 4
                     uint32_t ej[4];
                     int32_t vj[4];
@@ -1050,14 +1063,17 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
                     for (uint32_t u = 0; u < 4; ++u) {
                         if (done || j0 <= u) { done = true; break; }
                         if (ej[u] + 846u < sk) { done = true; break; }
-                        if (dl13 == kNone && vj[u] > t13) dl13 = umin(ek - 1, ej[u] + 846u);
+                        if (dl13 == kNone && vj[u] > t13) {
+                            dl13 = umin(ek - 1, ej[u] + 846u);
+                            if (!(sides & 2u)) { done = true; break; }
+                        }
                         if (vj[u] > t182) { dl182 = umin(ek - 1, ej[u] + 846u); done = true; break; }
                     }
                     j0 = j0 > 4 ? j0 - 4 : 0;
                 }
             }
             {
-                bool done = false;
+                bool done = !(sides & 4u);
                 for (uint32_t j0 = k + 1; j0 < R && !done; j0 += 4) {
                     uint32_t sj[4];
                     int32_t vj[4];
@@ -1072,7 +1088,10 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
                         if (done || j0 + u >= R) { done = true; break; }
                         if (sj[u] > ek + 846u) { done = true; break; }
                         const uint32_t lim = umax(sk, sj[u] >= 847u ? sj[u] - 847u : 0u);
-                        if (ur13 == kNone && vj[u] > t13) ur13 = lim;
+                        if (ur13 == kNone && vj[u] > t13) {
+                            ur13 = lim;
+                            if (!(sides & 8u)) { done = true; break; }
+                        }
                         if (vj[u] > t182) { ur182 = lim; done = true; break; }
                     }
                 }
