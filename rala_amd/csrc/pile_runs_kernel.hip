@@ -1105,54 +1105,74 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
         RUN_STOP(26)
 
         // ---- 8. maximal unions of touching intervals -> regions (first, last) ----------------
+        // the two thresholds of a kind (down / up) in one pass: they share the run's bounds and
+        // its neighbourhood on the survivor list
 #pragma unroll 1
-        for (uint32_t w = 0; w < (kSens == 2 ? 2u : 4u); ++w) {
-            const uint16_t* iv = (w == 0) ? d13 : (w == 1) ? u13 : (w == 2) ? d182 : u182;
-            const bool is_up = w & 1;
-            uint32_t* rf = sm + L::RF + w * kMaxReg;
-            uint32_t* rl = sm + L::RL + w * kMaxReg;
-            uint32_t ns = 0, ne = 0;
+        for (uint32_t kind = 0; kind < 2; ++kind) {
+            const bool is_up = kind != 0;
+            constexpr uint32_t kThr = kSens == 2 ? 1 : 2;
+            uint32_t ns[2] = {0, 0}, ne[2] = {0, 0};
             // a run that is not on the survivor list has nothing flagged: neighbours are the
             // adjacent list entries, if they are the adjacent runs
             for (uint32_t j0 = 0; j0 < n_surv; j0 += 64) {
                 const uint32_t j = j0 + lane;
-                bool st = false, en = false;
-                uint32_t fv = 0, lv = 0;
-                if (j < n_surv && iv[j] != kNone16) {
-                    const uint32_t k = surv[j];
-                    const uint32_t sk = rs[k], ek = rs[k + 1];
-                    const bool has_prev = j > 0 && surv[j - 1] + 1u == k && iv[j - 1] != kNone16;
-                    const bool has_next = j + 1 < n_surv && surv[j + 1] == k + 1u && iv[j + 1] != kNone16;
-                    if (!is_up) {
-                        // interval [sk, sk + iv[j]]
-                        const uint32_t last_k = sk + iv[j];
-                        const bool prev_joins = has_prev && rs[k - 1] + iv[j - 1] == sk - 1;
-                        const bool next_joins = last_k == ek - 1 && has_next;
-                        st = !prev_joins; en = !next_joins;
-                        fv = sk; lv = last_k;
-                    } else {
-                        // interval [ek - 1 - iv[j], ek - 1]
-                        const uint32_t first_k = ek - 1 - iv[j];
-                        const bool prev_joins = first_k == sk && has_prev;
-                        const bool next_joins = has_next && rs[k + 2] - 1 - iv[j + 1] == ek;
-                        st = !prev_joins; en = !next_joins;
-                        fv = first_k; lv = ek - 1;
+                const bool in = j < n_surv;
+                uint32_t k = 0, sk = 0, ek = 0, s_prev = 0, e_next = 0;
+                bool adj_prev = false, adj_next = false;
+                if (in) {
+                    k = surv[j];
+                    sk = rs[k]; ek = rs[k + 1];
+                    adj_prev = j > 0 && surv[j - 1] + 1u == k;
+                    adj_next = j + 1 < n_surv && surv[j + 1] == k + 1u;
+                    s_prev = adj_prev ? rs[k - 1] : 0u;
+                    e_next = adj_next ? rs[k + 2] : 0u;
+                }
+#pragma unroll
+                for (uint32_t t = 0; t < kThr; ++t) {
+                    const uint32_t w = 2 * t + kind;
+                    const uint16_t* iv = (w == 0) ? d13 : (w == 1) ? u13 : (w == 2) ? d182 : u182;
+                    uint32_t* rf = sm + L::RF + w * kMaxReg;
+                    uint32_t* rl = sm + L::RL + w * kMaxReg;
+                    bool st = false, en = false;
+                    uint32_t fv = 0, lv = 0;
+                    const uint32_t me_iv = in ? iv[j] : kNone16;
+                    if (me_iv != kNone16) {
+                        const bool has_prev = adj_prev && iv[j - 1] != kNone16;
+                        const bool has_next = adj_next && iv[j + 1] != kNone16;
+                        if (!is_up) {
+                            // interval [sk, sk + iv[j]]
+                            const uint32_t last_k = sk + me_iv;
+                            const bool prev_joins = has_prev && s_prev + iv[j - 1] == sk - 1;
+                            const bool next_joins = last_k == ek - 1 && has_next;
+                            st = !prev_joins; en = !next_joins;
+                            fv = sk; lv = last_k;
+                        } else {
+                            // interval [ek - 1 - iv[j], ek - 1]
+                            const uint32_t first_k = ek - 1 - me_iv;
+                            const bool prev_joins = first_k == sk && has_prev;
+                            const bool next_joins = has_next && e_next - 1 - iv[j + 1] == ek;
+                            st = !prev_joins; en = !next_joins;
+                            fv = first_k; lv = ek - 1;
+                        }
                     }
+                    const uint64_t ms = __ballot(st), me = __ballot(en);
+                    const uint64_t below = (1ull << lane) - 1ull;
+                    if (st) {
+                        const uint32_t p = ns[t] + __popcll(ms & below);
+                        if (p < kMaxReg) rf[p] = fv;
+                    }
+                    if (en) {
+                        const uint32_t p = ne[t] + __popcll(me & below);
+                        if (p < kMaxReg) rl[p] = lv;
+                    }
+                    ns[t] += __popcll(ms);
+                    ne[t] += __popcll(me);
                 }
-                const uint64_t ms = __ballot(st), me = __ballot(en);
-                const uint64_t below = (1ull << lane) - 1ull;
-                if (st) {
-                    const uint32_t p = ns + __popcll(ms & below);
-                    if (p < kMaxReg) rf[p] = fv;
-                }
-                if (en) {
-                    const uint32_t p = ne + __popcll(me & below);
-                    if (p < kMaxReg) rl[p] = lv;
-                }
-                ns += __popcll(ms);
-                ne += __popcll(me);
             }
-            if (lane == 0) sm[L::RC + w] = ns;
+            if (lane == 0) {
+                sm[L::RC + kind] = ns[0];
+                if (kThr == 2) sm[L::RC + 2 + kind] = ns[1];
+            }
         }
         wave_sync();
         RUN_STOP(27)
@@ -1173,6 +1193,12 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
             uint8_t* gone = (uint8_t*)(sm + L::GONE) + which * kMaxRaw;
             if (nd > kMaxReg || nu > kMaxReg) {
                 any_overflow = true;
+                if (lane == 0) sel[8 + which] = 0;
+                continue;
+            }
+            if (nd == 0 || nu == 0) {
+                // a pit is a (down, up) pair, a hill an (up, later down) pair, and regions of one
+                // kind do not touch each other: nothing to resolve, nothing to find
                 if (lane == 0) sel[8 + which] = 0;
                 continue;
             }
