@@ -444,19 +444,6 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
     if (lane < 14) sm[L::MT + lane] = lane <= 6 ? 0xFFFFFFFFu : lane == 7 ? 0xFFFF0000u : 0u;
     for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
         const uint32_t r = A.order ? A.order[item] : item;
-        // A wavefront's life starts with dependent round trips to memory (arguments -> counts ->
-        // events), and at one read per wavefront nothing of its own overlaps them.  With fixed
-        // slots the address of the events does not depend on anything loaded: the first 256
-        // slot entries (most reads have fewer events) are requested together with the counts;
-        // what lies behind the count is masked when it is known.
-        constexpr uint32_t kEarly = kCap / 64 < 4 ? kCap / 64 : 4;
-        const bool slots = kSens == 0 && kCap <= 1024 && A.ev_cnt != nullptr;
-        uint32_t ev_early[kEarly];
-        if (slots) {
-            const uint32_t* __restrict__ slot = A.ev + (size_t)r * A.ev_stride;
-#pragma unroll
-            for (uint32_t t = 0; t < kEarly; ++t) ev_early[t] = slot[t * 64 + lane];
-        }
         const uint32_t n = A.read_len[r];
         const uint64_t row_off = kSens == 2 ? 0 : A.pile_off[r];
         const uint32_t n_ev_p = A.ev_cnt ? umin(A.ev_cnt[r], A.ev_stride) : A.ev_off[r + 1] - A.ev_off[r];
@@ -501,20 +488,8 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
             uint32_t evr[kCap / 64];
             const uint32_t e_last = n_ev ? n_ev - 1 : 0;
             if constexpr (kSens == 0) {
-                if (slots) {
 #pragma unroll
-                    for (uint32_t t = 0; t < kEarly; ++t) evr[t] = ev_early[t];
-                    if (n_ev > kEarly * 64) {
-#pragma unroll
-                        for (uint32_t t = kEarly; t < kCap / 64; ++t) evr[t] = rev[umin(t * 64 + lane, e_last)];
-                    } else {
-#pragma unroll
-                        for (uint32_t t = kEarly; t < kCap / 64; ++t) evr[t] = kNone;
-                    }
-                } else {
-#pragma unroll
-                    for (uint32_t t = 0; t < kCap / 64; ++t) evr[t] = rev[umin(t * 64 + lane, e_last)];
-                }
+                for (uint32_t t = 0; t < kCap / 64; ++t) evr[t] = rev[umin(t * 64 + lane, e_last)];
 #pragma unroll
                 for (uint32_t t = 0; t < kCap / 64; ++t) {
                     if (t * 64 + lane >= n_ev) evr[t] = kNone;
