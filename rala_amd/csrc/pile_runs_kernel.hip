@@ -245,6 +245,18 @@ __device__ __forceinline__ uint32_t bitfield_insert(uint32_t mask, uint32_t a, u
     return d;
 }
 
+// 16-byte store to base + off with the base in scalar registers and a 32-bit lane offset.  The
+// compiler prefers a 64-bit address per lane: two more registers per store in flight, and at this
+// kernel's register budget that meant spill reloads inside the store loop - a scratch load is a
+// vector memory operation, and the wait for it is a wait for every row store issued so far.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store16(const char* base, uint32_t off, const uint4& v) {
+    const u32x4 d = {v.x, v.y, v.z, v.w};
+    // (s_nop: a store of more than 8 bytes reads its data registers over the following cycles; the
+    // compiler's hazard recogniser keeps vector writes to them away from its own stores, not from this one)
+    asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" : : "v"(off), "v"(d), "s"(base) : "memory");
+}
+
 template <uint32_t kCap>
 struct Layout {
     // list capacities: a read that needs more goes to the next kernel of the chain
@@ -331,7 +343,6 @@ __device__ __forceinline__ void expand_from_bitmap(uint32_t* sm, const uint16_t*
             noted[u] = __builtin_amdgcn_ballot_w64(in && bits[u] != 0);
             total += (uint32_t)__popcll(noted[u]);
         }
-        char* row = base + (size_t)g0 * 16u;
         // groups u in [ub, ue) of the chunk (at most 64 of them noted): walk, table, store
         auto emit = [&](auto ub_tag, auto ue_tag) {
             constexpr uint32_t ub = decltype(ub_tag)::value, ue = decltype(ue_tag)::value;
@@ -376,7 +387,7 @@ __device__ __forceinline__ void expand_from_bitmap(uint32_t* sm, const uint16_t*
                 const uint32_t vv = v[u] | (v[u] << 16);
                 uint4 out = make_uint4(vv, vv, vv, vv);
                 if ((noted[u] >> lane) & 1u) out = table[slot[u]];
-                if (in && store) *(uint4*)(row + gl * 16u) = out;
+                if (in && store) store16(base, (g0 + gl) * 16u, out);
             }
             wave_sync();                                // the table is rewritten by the next call
         };
