@@ -23,6 +23,17 @@ __global__ __launch_bounds__(64) void row_fill_lane64(uint4* dst, uint32_t row_v
         }
     }
 }
+// each lane owns 2 consecutive 16-byte vectors (32 contiguous bytes): two store instructions whose lanes are 32 bytes apart
+__global__ __launch_bounds__(64) void row_fill_lane32(uint4* dst, uint32_t row_vec, uint32_t n_rows) {
+    for (uint32_t r = blockIdx.x; r < n_rows; r += gridDim.x) {
+        uint4* p = dst + (size_t)r * row_vec;
+        const uint4 v = make_uint4(r, r, r, r);
+        for (uint32_t g = threadIdx.x * 2; g < row_vec; g += 128) {
+#pragma unroll
+            for (uint32_t u = 0; u < 2; ++u) if (g + u < row_vec) p[g + u] = v;
+        }
+    }
+}
 __global__ __launch_bounds__(256) void row_fill256(uint4* dst, uint32_t row_vec, uint32_t n_rows) {
     for (uint32_t r = blockIdx.x; r < n_rows; r += gridDim.x) {
         uint4* p = dst + (size_t)r * row_vec;
@@ -51,6 +62,7 @@ int main() {
     };
     time("row_fill wave/row grid=n_rows", [&] { hipLaunchKernelGGL(row_fill, dim3(n_rows), dim3(64), 0, 0, d, row_vec, n_rows); });
     time("lane owns 64 B, grid=n_rows", [&] { hipLaunchKernelGGL(row_fill_lane64, dim3(n_rows), dim3(64), 0, 0, d, row_vec, n_rows); });
+    time("lane owns 32 B, grid=n_rows", [&] { hipLaunchKernelGGL(row_fill_lane32, dim3(n_rows), dim3(64), 0, 0, d, row_vec, n_rows); });
     time("row_fill wave/row grid=8192", [&] { hipLaunchKernelGGL(row_fill, dim3(8192), dim3(64), 0, 0, d, row_vec, n_rows); });
     time("row_fill wave/row grid=2304", [&] { hipLaunchKernelGGL(row_fill, dim3(2304), dim3(64), 0, 0, d, row_vec, n_rows); });
     time("row_fill 256thr/row grid=n_rows", [&] { hipLaunchKernelGGL(row_fill256, dim3(n_rows), dim3(256), 0, 0, d, row_vec, n_rows); });
