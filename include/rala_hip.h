@@ -82,7 +82,10 @@ const char* rala_hip_last_error(const rala_hip_ctx* ctx);
  * through the exact count / scan / scatter path), "use_side_stream" (default 1; 0 runs duplicate
  * removal on the main stream before the bucketing), "sensitive_in_device_memory" (default 0; 1 = the
  * sensitive overlaps handed to rala_hip_construct are device pointers), "host_threads",
- * "debug_pile_stop_after" (diagnostics) */
+ * "use_round_batches" (default 1; 0 makes the host look at the killer list after every round of the
+ * containment fixed point instead of enqueuing five rounds per look once the list is short),
+ * "debug_pile_stop_after" (diagnostics: leave the run-space pile kernel after phase k, 99 = all;
+ * 100 * m + k: the same without the row stores (m = 1), tools/phase_probe.py) */
 int rala_hip_set_option(rala_hip_ctx* ctx, const char* key, int64_t value);
 /* the context's hipStream_t, for callers that enqueue their own copies/collectives */
 void* rala_hip_stream(rala_hip_ctx* ctx);

@@ -307,7 +307,7 @@ struct Layout {
 // lanes paid for it.
 template <class L>
 __device__ __forceinline__ void expand_from_bitmap(uint32_t* sm, const uint16_t* rv, uint16_t* pile, uint64_t row_off,
-                                                   uint32_t nv, uint32_t lane, uint32_t store) {
+                                                   uint32_t nv, uint32_t lane, bool store) {
     const uint32_t* bm = sm + L::X;
     const uint16_t* pref = (const uint16_t*)(bm + 512);
     const uint16_t* rvm1 = rv - 1;                      // indexed by run + 1 (= run starts at or before)
@@ -438,11 +438,9 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
     uint32_t* sel = sm + L::SEL;
     const uint32_t n_items = A.n_items_dev ? *A.n_items_dev : A.n_items;
 
-    // diagnostics: 77 = everything but the row stores; 100 * m + k = leave after phase k, with
-    // m = 1: no row stores, 2: no patch stores (pass B of the expansion), 3: only those
+    // diagnostics: 77 = everything but the row stores; 100 + k = leave after phase k, without them
     const uint32_t stop_k = A.stop_after >= 100 ? A.stop_after % 100 : A.stop_after;
-    const uint32_t stop_m = A.stop_after >= 100 ? A.stop_after / 100 : 0;
-    const uint32_t row_stores = !kDiag ? 3u : (A.stop_after == 77 || stop_m == 1) ? 0u : stop_m == 2 ? 1u : stop_m == 3 ? 2u : 3u;
+    const bool row_stores = !kDiag || !(A.stop_after == 77 || A.stop_after >= 100);
 #define RUN_STOP(k)                                                        \
     if (kDiag && stop_k == (k)) {                                          \
         if (lane == 0) A.alive[A.order ? A.order[item] : item] = 0;        \
@@ -853,7 +851,7 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
                             w2 = bitfield_insert(m2, f, w2);
                             w3 = bitfield_insert(m3, f, w3);
                         }
-                        if (row_stores == 3u) dst[g] = make_uint4(w0, w1, w2, w3);
+                        if (row_stores) dst[g] = make_uint4(w0, w1, w2, w3);
                     }
                 }
             }
