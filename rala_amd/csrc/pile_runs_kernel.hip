@@ -333,6 +333,7 @@ __device__ __forceinline__ void expand_from_bitmap(uint32_t* sm, const uint16_t*
             kq[u] = pref[w];
         }
         uint64_t noted[4];
+        bool mine[4];               // this lane's bit of noted[u]
         uint32_t total = 0;
 #pragma unroll
         for (uint32_t u = 0; u < 4; ++u) {
@@ -340,7 +341,8 @@ __device__ __forceinline__ void expand_from_bitmap(uint32_t* sm, const uint16_t*
             v[u] = rvm1[kq[u]];                                     // (beyond the pile: some LDS word)
             bits[u] = (bits[u] >> sh1) & 0x7Fu;                     // run starts at positions 1 .. 7
             const bool in = kFull || g0 + 64u * u + lane < nv;
-            noted[u] = __builtin_amdgcn_ballot_w64(in && bits[u] != 0);
+            mine[u] = in && bits[u] != 0;
+            noted[u] = __builtin_amdgcn_ballot_w64(mine[u]);
             total += (uint32_t)__popcll(noted[u]);
         }
         // groups u in [ub, ue) of the chunk (at most 64 of them noted): walk, table, store
@@ -352,7 +354,7 @@ __device__ __forceinline__ void expand_from_bitmap(uint32_t* sm, const uint16_t*
             for (uint32_t u = ub; u < ue; ++u) {
                 const uint64_t m = noted[u];
                 slot[u] = cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                if ((m >> lane) & 1u) list[slot[u]] = kq[u] | (bits[u] << 16);
+                if (mine[u]) list[slot[u]] = kq[u] | (bits[u] << 16);
                 cnt += (uint32_t)__popcll(m);
             }
             if (cnt) {
@@ -386,7 +388,7 @@ __device__ __forceinline__ void expand_from_bitmap(uint32_t* sm, const uint16_t*
                 const bool in = kFull || g0 + gl < nv;
                 const uint32_t vv = v[u] | (v[u] << 16);
                 uint4 out = make_uint4(vv, vv, vv, vv);
-                if ((noted[u] >> lane) & 1u) out = table[slot[u]];
+                if (mine[u]) out = table[slot[u]];
                 if (in && store) store16(base, (g0 + gl) * 16u, out);
             }
             wave_sync();                                // the table is rewritten by the next call
