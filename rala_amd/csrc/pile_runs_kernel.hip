@@ -1,14 +1,16 @@
 // Pile-o-gram construction and annotation in RUN space, one wavefront per read.
 //
-// A pile is a step function: coverage only changes at bound events.  With the
-// E events of a read sorted (bitonic sort in registers, DPP / cross-lane shuffles, wave_sort.h),
-// the prefix sum of +-1 gives R <= E + 1 runs (start, value).  Every per-base
-// loop of the reference then becomes a loop over runs:
-//   * Pile::add_layers        sort + wave prefix sum               O(E log^2 E)
+// A pile is a step function: coverage only changes at bound events.  The E events of a read
+// give R <= E + 1 runs (start, value): through a bitmap of the positions that carry an event
+// (reads of up to 16384 bases: run index = popcount, +-1 per event into its run's slot, prefix
+// sum) or, for longer reads, sorted (bitonic sort in registers, DPP / cross-lane shuffles,
+// wave_sort.h) and swept.  Every per-base loop of the reference then becomes a loop over runs:
+//   * Pile::add_layers        bitmap + popcounts + wave prefix sum   O(E)
 //   * Pile::find_valid_region  streaks of runs with value >= 4      O(R)
 //   * Pile::shrink             zero the runs outside the streak; the pile is
-//                              expanded once, 16 B per lane, straight to HBM
-//   * Pile::find_median        radix select over (value, length)    O(R)
+//                              expanded once, 16 B per lane, straight to HBM, right
+//                              behind the runs so that the stores drain behind the rest
+//   * Pile::find_median        histogram over (value, length)       O(R)
 //   * Pile::find_slopes flags  within a run the window maximum only has to be
 //       compared with ONE threshold, so the flagged positions of a run are a
 //       prefix (down) and a suffix (up) of it, bounded by the nearest run to
