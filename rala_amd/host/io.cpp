@@ -165,8 +165,10 @@ bool read_mhap(const std::string& path, const std::function<void(const MhapRecor
 
 // ---- multi-threaded PAF ingest -----------------------------------------------------------------
 #include <fcntl.h>
+#include <sched.h>
 #include <stdio.h>
 #include <sys/mman.h>
+#include <sys/resource.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -283,6 +285,16 @@ inline void field_u32(const char* b, const char* e, uint32_t& v) {
     parse_u32(b, e, v);
 }
 
+// n bytes equal?  Both ranges may be read 16 bytes beyond their end (the caller's slack).
+inline bool same_bytes(const char* a, const char* b, size_t n) {
+    if (n <= 16) {
+        const __m128i x = _mm_loadu_si128((const __m128i*)a), y = _mm_loadu_si128((const __m128i*)b);
+        const uint32_t eq = (uint32_t)_mm_movemask_epi8(_mm_cmpeq_epi8(x, y));
+        return ((eq | (0xFFFFFFFFu << n)) & 0xFFFFu) == 0xFFFFu;
+    }
+    return memcmp(a, b, n) == 0;
+}
+
 // one line [p, e) (no newline; at least 8 readable bytes in front of p and 16 behind e); returns
 // false if it is not a 12-column record.  The tabs come from 16-byte compares (SSE2, baseline of
 // x86-64), a name token ends at its first blank, numbers through digits8.
@@ -291,10 +303,15 @@ inline bool parse_paf_line(const char* p, const char* e, const NameTable& names,
     PendingLine& L = c.pend[c.n_pend];
     const char* tab[12];
     int nt = 0;
+    bool any_blank = false;                          // a blank somewhere in front of the 6th tab
     {
-        const __m128i tabs = _mm_set1_epi8('\t');
+        const __m128i tabs = _mm_set1_epi8('\t'), blanks = _mm_set1_epi8(' ');
         for (const char* q = p; q < e && nt < 12; q += 16) {
-            uint32_t m = (uint32_t)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_loadu_si128((const __m128i*)q), tabs));
+            const __m128i x = _mm_loadu_si128((const __m128i*)q);
+            uint32_t m = (uint32_t)_mm_movemask_epi8(_mm_cmpeq_epi8(x, tabs));
+            // names end at their first blank: noted while the bytes are in the register, so that the
+            // usual line (no blank in the name columns) needs no second look at them
+            if (nt < 6) any_blank |= _mm_movemask_epi8(_mm_cmpeq_epi8(x, blanks)) != 0;
             while (m && nt < 12) {
                 const char* at = q + __builtin_ctz(m);
                 if (at >= e) { m = 0; break; }
@@ -304,7 +321,8 @@ inline bool parse_paf_line(const char* p, const char* e, const NameTable& names,
         }
     }
     if (nt < 11) return false;                       // fewer than 12 columns
-    auto name_end = [](const char* b, const char* e2) {
+    auto name_end = [&](const char* b, const char* e2) {
+        if (!any_blank) return e2;
         const char* sp = (const char*)memchr(b, ' ', (size_t)(e2 - b));
         return sp ? sp : e2;
     };
@@ -320,7 +338,7 @@ inline bool parse_paf_line(const char* p, const char* e, const NameTable& names,
     field_u32(tab[6] + 1, tab[7], L.tb);
     field_u32(tab[7] + 1, tab[8], L.te);
     field_u32(tab[9] + 1, tab[10], L.ol);            // column 11: alignment length
-    L.new_query = c.last_q == nullptr || L.qn != c.last_qn || memcmp(c.last_q, L.q, L.qn) != 0;
+    L.new_query = c.last_q == nullptr || L.qn != c.last_qn || !same_bytes(c.last_q, L.q, L.qn);
     if (L.new_query) {
         L.qh = NameTable::hash(L.q, L.qn);
         names.prefetch(L.qh);
@@ -384,6 +402,26 @@ uint64_t NameTable::find(const char* p, size_t n, uint64_t h) const {
 
 namespace {
 constexpr size_t kHugeBlock = 1u << 20, kHugePage = 2u << 20;
+
+// the CPUs this process may run on, one per physical core (the lowest-numbered sibling)
+std::vector<int> one_cpu_per_core() {
+    std::vector<int> out;
+    cpu_set_t allowed;
+    if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return out;
+    for (int cpu = 0; cpu < CPU_SETSIZE; ++cpu) {
+        if (!CPU_ISSET(cpu, &allowed)) continue;
+        char path[128];
+        snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", cpu);
+        FILE* f = fopen(path, "r");
+        if (!f) return std::vector<int>();
+        int first = -1;
+        const int got = fscanf(f, "%d", &first);
+        fclose(f);
+        if (got != 1) return std::vector<int>();
+        if (first == cpu) out.push_back(cpu);
+    }
+    return out;
+}
 }
 
 void* allocate_block(size_t bytes) {
@@ -415,29 +453,74 @@ bool read_paf_parallel(const std::string& path, const NameTable& names, const st
 
     // The file is taken in windows (all of it unless it is very large).  A window is cut into
     // pieces, more pieces than threads, handed out through a counter (threads that are descheduled -
-    // a container's CPU quota throttles in bursts - do not hold the others up).  Two phases:
-    //   1. every piece is read with pread into its own buffer (page faults of a shared mapping
-    //      serialise on the address-space lock) and its lines are counted;
+    // a container's CPU quota throttles in bursts - do not hold the others up).  A piece owns the
+    // lines that START inside it.  Two passes over the text, both through a buffer of half a
+    // megabyte per thread that stays in the core's L2 (the text comes out of the page cache twice;
+    // keeping all of it in freshly allocated memory between the passes cost more: 3 GB of pages
+    // to fault in, clear and unmap at C3 - 1.7 s of system time):
+    //   1. the pieces' line starts are counted (a newline followed by something else);
     //   2. the counts give every piece its slot in the final columns and the pieces are parsed
-    //      straight into it - no per-piece vectors, no gather pass, nothing to free but the text.
-    // A piece owns the lines that START inside it.  Lines that turn out not to be records leave a
-    // gap at the end of the piece's slot; gaps are closed afterwards (they are rare).
+    //      straight into it - no per-piece vectors, no gather pass.
+    // Lines that turn out not to be records leave a gap at the end of the piece's slot; gaps are
+    // closed afterwards (they are rare).
     const uint32_t n_thr = (uint32_t)std::max<size_t>(1, std::min<size_t>(std::max(1u, num_threads), size / (1 << 20) + 1));
     const size_t kWindow = (size_t)8 << 30;
     constexpr size_t kFront = 8, kBack = 16;      // slack around the text for the line parser's wide loads
+    constexpr size_t kText = 512 << 10;           // bytes of text per read
     std::vector<std::thread> threads;
+    // The parser threads are pinned, one per physical core, to the FIRST cores the process may use
+    // (RALA_IO_NO_PIN=1: left to the scheduler).  On the two-socket EPYC 9575F boxes 16 threads
+    // spread over both sockets (which is what the scheduler does, and what a spread pinning does)
+    // parse C3 in 535 - 590 ms; on 16 neighbouring cores of one socket in 320 ms: name table and
+    // columns then live in one NUMA node and two L3 slices (tools/gpurun/r2_ingest_threads.sh).
+    const std::vector<int> cores = getenv("RALA_IO_NO_PIN") ? std::vector<int>() : one_cpu_per_core();
+    cpu_set_t before;
+    const bool pinned = cores.size() >= n_thr && n_thr > 1 && sched_getaffinity(0, sizeof(before), &before) == 0;
+    auto pin = [&](uint32_t k) {
+        if (!pinned) return;
+        cpu_set_t one;
+        CPU_ZERO(&one);
+        const char* env_span = getenv("RALA_IO_PIN_SPAN");          // diagnostics: spread over the first <n> cores
+        const size_t span = env_span ? std::min<size_t>(cores.size(), std::max<size_t>(n_thr, (size_t)atoi(env_span))) : n_thr;
+        // several processes of one job (one per GPU) take different groups of cores
+        const char* env_rank = getenv("LOCAL_RANK");
+        const size_t groups = std::max<size_t>(1, cores.size() / span);
+        const size_t first = env_rank ? ((size_t)atoi(env_rank) % groups) * span : 0;
+        CPU_SET(cores[first + (size_t)k * span / n_thr], &one);
+        (void)sched_setaffinity(0, sizeof(one), &one);
+    };
+    typedef std::vector<char, UninitAllocator<char>> Text;
     auto run = [&](uint32_t T, auto&& fn) {
         std::atomic<uint32_t> next(0);
-        auto pull = [&] { for (uint32_t t = next.fetch_add(1); t < T; t = next.fetch_add(1)) fn(t); };
+        auto pull = [&] {
+            Text buf(kFront + kText + kBack);
+            memset(buf.data(), 0, kFront);
+            for (uint32_t t = next.fetch_add(1); t < T; t = next.fetch_add(1)) fn(t, buf);
+        };
         threads.clear();
-        for (uint32_t k = 1; k < n_thr; ++k) threads.emplace_back(pull);
+        for (uint32_t k = 1; k < n_thr; ++k) threads.emplace_back([&, k] { pin(k); pull(); });
+        pin(0);
         pull();
         for (auto& th : threads) th.join();
+        if (pinned) (void)sched_setaffinity(0, sizeof(before), &before);
+    };
+    // file bytes [from, from + n) into buf (behind its front slack); false = read error
+    auto fetch = [&](Text& buf, size_t from, size_t n) {
+        if (buf.size() < kFront + n + kBack) {
+            Text bigger(kFront + n + kBack);
+            memset(bigger.data(), 0, kFront);
+            buf.swap(bigger);
+        }
+        size_t have = 0;
+        while (have < n) {
+            const ssize_t got = pread(fd, buf.data() + kFront + have, n - have, (off_t)(from + have));
+            if (got <= 0) return false;
+            have += (size_t)got;
+        }
+        return true;
     };
     struct Piece {
         size_t lo = 0, hi = 0;          // file positions this piece owns line starts in
-        size_t from = 0, have = 0;      // the bytes in memory: file positions [from, from + have)
-        std::vector<char, UninitAllocator<char>> raw;
         size_t first = 0;               // file position of the first owned line (== hi: none)
         size_t lines = 0;               // upper bound of the records (non-empty lines)
         bool failed = false;
@@ -451,55 +534,44 @@ bool read_paf_parallel(const std::string& path, const NameTable& names, const st
         std::vector<Piece> piece(T);
         std::vector<Chunk> chunks(T);
         const auto p0 = std::chrono::steady_clock::now();
-        // ---- phase 1: read, find the owned lines, count them
-        run(T, [&](uint32_t t) {
+        rusage ru0, ru1, ru2;
+        if (trace) getrusage(RUSAGE_SELF, &ru0);
+        // ---- pass 1: the owned line starts p in [lo, hi): the byte in front is a newline (or p is
+        // the start of the file) and the byte at p is not.  Reads overlap by one byte.
+        run(T, [&](uint32_t t, Text& buf) {
             Piece& P = piece[t];
             P.lo = w_lo + w_size * t / T;
             P.hi = w_lo + w_size * (t + 1) / T;
-            P.from = P.lo ? P.lo - 1 : 0;              // the byte in front tells whether lo starts a line
-            bool eof = false;
-            auto fill = [&](size_t upto) {
-                upto = std::min(upto, size - P.from);
-                if (P.raw.size() < upto + kFront + kBack) {
-                    std::vector<char, UninitAllocator<char>> bigger(upto + kFront + kBack);
-                    if (P.have) memcpy(bigger.data() + kFront, P.raw.data() + kFront, P.have);
-                    P.raw.swap(bigger);
-                    memset(P.raw.data(), 0, kFront);
+            P.first = P.hi;
+            if (P.lo == 0 && P.hi > 0) P.first = 0;
+            size_t a = P.lo ? P.lo - 1 : 0;                  // first byte of the next read
+            bool start_pending = P.lo == 0;                  // position `a` starts a line (known from the byte in front)
+            while (a < P.hi) {
+                const size_t n = std::min(kText, P.hi - a);
+                if (!fetch(buf, a, n)) { P.failed = true; return; }
+                const char* text = buf.data() + kFront;      // text[k] = file byte a + k
+                if (start_pending) {
+                    if (text[0] != '\n') ++P.lines;
+                    start_pending = false;
                 }
-                while (P.have < upto) {
-                    const ssize_t n = pread(fd, P.raw.data() + kFront + P.have, upto - P.have, (off_t)(P.from + P.have));
-                    if (n <= 0) { P.failed = true; eof = true; return; }
-                    P.have += (size_t)n;
+                // newlines at k <= n - 2 start a line at a + k + 1 < hi, whose first byte is in this read
+                for (const char* q = text; n >= 2;) {
+                    const char* nl = (const char*)memchr(q, '\n', (size_t)(text + n - 1 - q));
+                    if (!nl) break;
+                    const size_t p = a + (size_t)(nl - text) + 1;
+                    if (p >= P.lo) {
+                        if (P.first == P.hi) P.first = p;
+                        if (nl[1] != '\n') ++P.lines;
+                    }
+                    q = nl + 1;
                 }
-                if (P.from + P.have >= size) eof = true;
-            };
-            fill((P.hi - P.from) + (1 << 16));
-            if (P.failed) return;
-            const char* text = P.raw.data() + kFront;
-            size_t p = P.lo;
-            if (P.lo > 0) {
-                const char* nl = (const char*)memchr(text, '\n', P.have);
-                // no newline at all: the line belongs to an earlier piece (and is longer than this one)
-                p = nl ? (size_t)(nl - text) + P.from + 1 : P.hi;
-            }
-            P.first = std::min(p, P.hi);
-            // the last owned line may end beyond what was read
-            while (p < P.hi) {
-                const char* base = P.raw.data() + kFront - P.from;
-                const char* nl = (const char*)memchr(base + p, '\n', P.from + P.have - p);
-                if (!nl) {
-                    if (eof) { ++P.lines; break; }
-                    fill(P.have + (1 << 20));
-                    if (P.failed) return;
-                    continue;
-                }
-                const size_t e = (size_t)(nl - base);
-                if (e > p) ++P.lines;
-                p = e + 1;
+                if (a + n >= P.hi) break;
+                a += n - 1;                                  // the last byte again: is it a newline?
             }
         });
         for (const Piece& P : piece) if (P.failed) { close(fd); return false; }
         const auto p1 = std::chrono::steady_clock::now();
+        if (trace) getrusage(RUSAGE_SELF, &ru1);
         // ---- slots in the final columns
         std::vector<size_t> at(T + 1);
         at[0] = out.size();
@@ -507,29 +579,47 @@ bool read_paf_parallel(const std::string& path, const NameTable& names, const st
         const size_t total = at[T];
         out.a_id.resize(total); out.b_id.resize(total); out.a_begin.resize(total); out.a_end.resize(total);
         out.b_begin.resize(total); out.b_end.resize(total); out.length.resize(total); out.strand.resize(total);
-        // ---- phase 2: parse into the slots
-        run(T, [&](uint32_t t) {
+        // ---- pass 2: parse into the slots
+        run(T, [&](uint32_t t, Text& buf) {
             Piece& P = piece[t];
             Chunk& c = chunks[t];
             c.a_id = out.a_id.data() + at[t]; c.b_id = out.b_id.data() + at[t];
             c.a_begin = out.a_begin.data() + at[t]; c.a_end = out.a_end.data() + at[t];
             c.b_begin = out.b_begin.data() + at[t]; c.b_end = out.b_end.data() + at[t];
             c.length = out.length.data() + at[t]; c.strand = out.strand.data() + at[t];
-            const char* base = P.raw.data() + kFront - P.from;
-            const size_t end_of_text = P.from + P.have;
-            size_t p = P.first;
+            size_t p = P.first;                              // start of the next line to parse
+            size_t want = kText;
             while (p < P.hi) {
-                const char* nl = (const char*)memchr(base + p, '\n', end_of_text - p);
-                const size_t e = nl ? (size_t)(nl - base) : end_of_text;
-                size_t le = e;
-                if (le > p && base[le - 1] == '\r') --le;
-                if (le > p) parse_paf_line(base + p, base + le, names, read_len, check_lengths, c);
-                p = e + 1;
+                const size_t n = std::min(want, size - p);
+                if (!fetch(buf, p, n)) { P.failed = true; return; }
+                const char* text = buf.data() + kFront;      // text[k] = file byte p + k
+                // the last complete line of this read ends at `stop`
+                size_t stop = n;
+                if (p + n < size) {
+                    const char* nl = (const char*)memrchr(text, '\n', n);
+                    if (!nl) { want *= 2; continue; }        // a line longer than the read
+                    stop = (size_t)(nl - text);
+                }
+                size_t k = 0;
+                while (k <= stop && k < n && p + k < P.hi) {
+                    const char* nl = (const char*)memchr(text + k, '\n', stop - k);
+                    const size_t e = nl ? (size_t)(nl - text) : stop;
+                    size_t le = e;
+                    if (le > k && text[le - 1] == '\r') --le;
+                    if (le > k) parse_paf_line(text + k, text + le, names, read_len, check_lengths, c);
+                    k = e + 1;
+                }
+                // the pending look-ups and the remembered query name point into this read
+                resolve_batch(names, read_len, check_lengths, c);
+                c.last_q = nullptr;
+                if (p + k >= P.hi || p + n >= size) break;
+                p += stop + 1;
+                want = kText;
             }
-            resolve_batch(names, read_len, check_lengths, c);
-            std::vector<char, UninitAllocator<char>>().swap(P.raw);      // (freed by the thread that used it)
         });
+        for (const Piece& P : piece) if (P.failed) { close(fd); return false; }
         const auto p2 = std::chrono::steady_clock::now();
+        if (trace) getrusage(RUSAGE_SELF, &ru2);
         // ---- close the gaps left by lines that were not records
         size_t w = at[0];
         bool gaps = false;
@@ -550,6 +640,16 @@ bool read_paf_parallel(const std::string& path, const NameTable& names, const st
             out.b_begin.resize(w); out.b_end.resize(w); out.length.resize(w); out.strand.resize(w);
         }
         const auto p3 = std::chrono::steady_clock::now();
+        if (trace) {
+            auto cpu = [](const rusage& a, const rusage& b, bool sys) {
+                const timeval& x = sys ? a.ru_stime : a.ru_utime;
+                const timeval& y = sys ? b.ru_stime : b.ru_utime;
+                return (y.tv_sec - x.tv_sec) * 1e3 + (y.tv_usec - x.tv_usec) * 1e-3;
+            };
+            fprintf(stderr, "[io] cpu time: read + count user %.0f ms sys %.0f ms, parse user %.0f ms sys %.0f ms (page faults %ld + %ld)\n",
+                    cpu(ru0, ru1, false), cpu(ru0, ru1, true), cpu(ru1, ru2, false), cpu(ru1, ru2, true),
+                    ru1.ru_minflt - ru0.ru_minflt, ru2.ru_minflt - ru1.ru_minflt);
+        }
         ms_read += std::chrono::duration<double, std::milli>(p1 - p0).count();
         ms_parse += std::chrono::duration<double, std::milli>(p2 - p1).count();
         ms_close += std::chrono::duration<double, std::milli>(p3 - p2).count();

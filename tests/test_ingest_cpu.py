@@ -88,6 +88,36 @@ def test_awkward_lines(tmp_path):
     assert want["length"].tolist() == [890, 1500, 400, 100, 1993, 6]
 
 
+def test_lines_across_the_reader_s_buffers(tmp_path):
+    """The reader streams the text through half-megabyte buffers: lines that straddle a buffer or a
+    piece of the file, a line longer than a buffer, runs of empty lines at the seams."""
+    rng = np.random.default_rng(3)
+    names, lens = ["r%d" % i for i in range(50)], [1000 + i for i in range(50)]
+    out = []
+    for k in range(60_000):
+        a, b = int(rng.integers(0, 50)), int(rng.integers(0, 50))
+        line = "r%d\t%d\t%d\t%d\t%s\tr%d\t%d\t%d\t%d\t%d\t%d\t255" % (
+            a, lens[a], k % 100, 500 + k % 400, "+-"[k & 1], b, lens[b], k % 90, 480 + k % 300, 400, 450 + k % 50)
+        if k == 20_000:
+            line += "\tzz:Z:" + "x" * 700_000                  # longer than a buffer
+        if k % 7_000 == 0:
+            line += "\tcg:Z:" + "5M" * int(rng.integers(1, 40_000))
+        out.append(line)
+        if rng.random() < 0.001:
+            out.extend([""] * int(rng.integers(1, 5)))           # runs of empty lines
+    path = str(tmp_path / "seams.paf")
+    with open(path, "w") as f:
+        f.write("\n".join(out) + "\n\n")
+    assert os.path.getsize(path) > 3 << 20
+    want, e0 = parse(path, names, lens, 1, False)
+    assert len(want["a_id"]) == 60_000
+    for threads in (1, 2, 3, 5, 8):
+        got, e1 = parse(path, names, lens, threads, True)
+        assert e0 == e1 == -1
+        for f in want:
+            assert (want[f] == got[f]).all(), (threads, f)
+
+
 def test_length_mismatch_is_reported(tmp_path):
     path = str(tmp_path / "bad.paf")
     with open(path, "w") as f:
