@@ -173,6 +173,7 @@ bool read_mhap(const std::string& path, const std::function<void(const MhapRecor
 #include <unistd.h>
 
 #include <emmintrin.h>
+#include <immintrin.h>
 
 #include <algorithm>
 #include <atomic>
@@ -295,31 +296,11 @@ inline bool same_bytes(const char* a, const char* b, size_t n) {
     return memcmp(a, b, n) == 0;
 }
 
-// one line [p, e) (no newline; at least 8 readable bytes in front of p and 16 behind e); returns
-// false if it is not a 12-column record.  The tabs come from 16-byte compares (SSE2, baseline of
-// x86-64), a name token ends at its first blank, numbers through digits8.
-inline bool parse_paf_line(const char* p, const char* e, const NameTable& names, const std::vector<uint32_t>& read_len,
-                           bool check_lengths, Chunk& c) {
+// the fields of a line that starts at p and whose first nt (<= 12) tabs are at tab[]; false if it
+// is not a 12-column record
+inline bool finish_line(const char* p, const char* const* tab, int nt, bool any_blank, const NameTable& names,
+                        const std::vector<uint32_t>& read_len, bool check_lengths, Chunk& c) {
     PendingLine& L = c.pend[c.n_pend];
-    const char* tab[12];
-    int nt = 0;
-    bool any_blank = false;                          // a blank somewhere in front of the 6th tab
-    {
-        const __m128i tabs = _mm_set1_epi8('\t'), blanks = _mm_set1_epi8(' ');
-        for (const char* q = p; q < e && nt < 12; q += 16) {
-            const __m128i x = _mm_loadu_si128((const __m128i*)q);
-            uint32_t m = (uint32_t)_mm_movemask_epi8(_mm_cmpeq_epi8(x, tabs));
-            // names end at their first blank: noted while the bytes are in the register, so that the
-            // usual line (no blank in the name columns) needs no second look at them
-            if (nt < 6) any_blank |= _mm_movemask_epi8(_mm_cmpeq_epi8(x, blanks)) != 0;
-            while (m && nt < 12) {
-                const char* at = q + __builtin_ctz(m);
-                if (at >= e) { m = 0; break; }
-                tab[nt++] = at;
-                m &= m - 1;
-            }
-        }
-    }
     if (nt < 11) return false;                       // fewer than 12 columns
     auto name_end = [&](const char* b, const char* e2) {
         if (!any_blank) return e2;
@@ -350,6 +331,111 @@ inline bool parse_paf_line(const char* p, const char* e, const NameTable& names,
     if (++c.n_pend == kBatch) resolve_batch(names, read_len, check_lengths, c);
     return true;
 }
+
+// one line [p, e) (no newline; at least 8 readable bytes in front of p and 16 behind e); returns
+// false if it is not a 12-column record.  The tabs come from 16-byte compares (SSE2, baseline of
+// x86-64), a name token ends at its first blank, numbers through digits8.
+inline bool parse_paf_line(const char* p, const char* e, const NameTable& names, const std::vector<uint32_t>& read_len,
+                           bool check_lengths, Chunk& c) {
+    const char* tab[12];
+    int nt = 0;
+    bool any_blank = false;                          // a blank somewhere in front of the 6th tab
+    {
+        const __m128i tabs = _mm_set1_epi8('\t'), blanks = _mm_set1_epi8(' ');
+        for (const char* q = p; q < e && nt < 12; q += 16) {
+            const __m128i x = _mm_loadu_si128((const __m128i*)q);
+            uint32_t m = (uint32_t)_mm_movemask_epi8(_mm_cmpeq_epi8(x, tabs));
+            // names end at their first blank: noted while the bytes are in the register, so that the
+            // usual line (no blank in the name columns) needs no second look at them
+            if (nt < 6) any_blank |= _mm_movemask_epi8(_mm_cmpeq_epi8(x, blanks)) != 0;
+            while (m && nt < 12) {
+                const char* at = q + __builtin_ctz(m);
+                if (at >= e) { m = 0; break; }
+                tab[nt++] = at;
+                m &= m - 1;
+            }
+        }
+    }
+    return finish_line(p, tab, nt, any_blank, names, read_len, check_lengths, c);
+}
+
+// Line starts inside text[0, n): positions j >= 1 whose predecessor is a newline; *lines += those
+// that are not newlines themselves, *first_nl = index of the first newline at or below n - 2 (the
+// first line start is behind it), or n if there is none.  64 readable bytes behind the text.
+__attribute__((target("avx512f,avx512bw")))
+void count_line_starts_avx512(const char* text, size_t n, size_t* lines, size_t* first_nl) {
+    const __m512i v_nl = _mm512_set1_epi8('\n');
+    uint64_t carry = 0;
+    size_t count = 0, first = n;
+    for (size_t blk = 0; blk < n; blk += 64) {
+        const uint64_t valid = n - blk < 64 ? (1ull << (n - blk)) - 1 : ~0ull;
+        const uint64_t m = _mm512_cmpeq_epi8_mask(_mm512_loadu_si512((const void*)(text + blk)), v_nl) & valid;
+        const uint64_t starts = ((m << 1) | carry) & valid;
+        count += (size_t)__builtin_popcountll(starts & ~m);
+        if (first == n && starts) first = blk + (size_t)__builtin_ctzll(starts) - 1;
+        carry = m >> 63;
+    }
+    *lines += count;
+    *first_nl = first;
+}
+
+// The same for a whole read of text with 64-byte compares (AVX-512BW, chosen at run time): tabs,
+// newlines and blanks of a block come out of three compares as bit masks, so a line costs one
+// pass over its bytes instead of a newline search plus a tab scan.  Lines [from, ...) that end at
+// or before text[stop] (a newline, or the end of the file) and start below `limit`; returns the
+// offset behind the last line taken.  64 readable bytes behind text[stop] are required.
+__attribute__((target("avx512f,avx512bw")))
+size_t parse_lines_avx512(const char* text, size_t from, size_t stop, size_t limit, bool ends_at_eof,
+                          const NameTable& names, const std::vector<uint32_t>& read_len, bool check_lengths, Chunk& c) {
+    const __m512i v_nl = _mm512_set1_epi8('\n'), v_tab = _mm512_set1_epi8('\t'), v_sp = _mm512_set1_epi8(' ');
+    const char* tab[12];
+    int nt = 0;
+    bool blank = false;
+    size_t line = from;                               // start of the current line
+    if (line >= limit) return line;
+    const size_t end = ends_at_eof ? stop : stop + 1; // bytes [from, end) are looked at
+    for (size_t blk = from & ~(size_t)63; blk < end; blk += 64) {
+        const __m512i x = _mm512_loadu_si512((const void*)(text + blk));
+        uint64_t m_nl = _mm512_cmpeq_epi8_mask(x, v_nl), m_tab = _mm512_cmpeq_epi8_mask(x, v_tab);
+        uint64_t m_sp = _mm512_cmpeq_epi8_mask(x, v_sp);
+        // only bytes [max(from, blk), end)
+        uint64_t valid = ~0ull;
+        if (blk < from) valid &= ~0ull << (from - blk);
+        if (end - blk < 64) valid &= (1ull << (end - blk)) - 1;
+        m_nl &= valid; m_tab &= valid; m_sp &= valid;
+        if (nt < 6) blank |= (line > blk ? m_sp >> (line - blk) : m_sp) != 0;
+        uint64_t ev = m_nl | m_tab;
+        while (ev) {
+            const unsigned b = (unsigned)__builtin_ctzll(ev);
+            ev &= ev - 1;
+            const size_t pos = blk + b;
+            if ((m_tab >> b) & 1) {
+                if (nt < 12) tab[nt++] = text + pos;
+                continue;
+            }
+            // a newline: the line [line, pos)
+            size_t le = pos;
+            if (le > line && text[le - 1] == '\r') --le;
+            if (le > line) {
+                // tabs behind a carriage return cannot exist; tabs are all in front of le
+                finish_line(text + line, tab, nt, blank, names, read_len, check_lengths, c);
+            }
+            line = pos + 1;
+            nt = 0;
+            if (line >= limit) return line;
+            // blanks of the new line in the rest of this block
+            blank = b < 63 && (m_sp >> (b + 1)) != 0;
+        }
+    }
+    if (ends_at_eof && line < end) {                  // the last line has no newline
+        size_t le = end;
+        if (le > line && text[le - 1] == '\r') --le;
+        if (le > line) finish_line(text + line, tab, nt, blank, names, read_len, check_lengths, c);
+        line = end + 1;
+    }
+    return line;
+}
+
 
 }  // namespace
 
@@ -465,7 +551,9 @@ bool read_paf_parallel(const std::string& path, const NameTable& names, const st
     // closed afterwards (they are rare).
     const uint32_t n_thr = (uint32_t)std::max<size_t>(1, std::min<size_t>(std::max(1u, num_threads), size / (1 << 20) + 1));
     const size_t kWindow = (size_t)8 << 30;
-    constexpr size_t kFront = 8, kBack = 16;      // slack around the text for the line parser's wide loads
+    constexpr size_t kFront = 8, kBack = 80;      // slack around the text for the line parser's wide loads
+    // 64-byte compares where the CPU has them (RALA_IO_NO_AVX512=1: the 16-byte path)
+    const bool wide = __builtin_cpu_supports("avx512bw") && getenv("RALA_IO_NO_AVX512") == nullptr;
     constexpr size_t kText = 512 << 10;           // bytes of text per read
     std::vector<std::thread> threads;
     // The parser threads are pinned, one per physical core, to the FIRST cores the process may use
@@ -555,6 +643,11 @@ bool read_paf_parallel(const std::string& path, const NameTable& names, const st
                     start_pending = false;
                 }
                 // newlines at k <= n - 2 start a line at a + k + 1 < hi, whose first byte is in this read
+                if (wide) {
+                    size_t first_nl = n;
+                    count_line_starts_avx512(text, n, &P.lines, &first_nl);
+                    if (first_nl < n && P.first == P.hi) P.first = a + first_nl + 1;
+                } else
                 for (const char* q = text; n >= 2;) {
                     const char* nl = (const char*)memchr(q, '\n', (size_t)(text + n - 1 - q));
                     if (!nl) break;
@@ -601,6 +694,9 @@ bool read_paf_parallel(const std::string& path, const NameTable& names, const st
                     stop = (size_t)(nl - text);
                 }
                 size_t k = 0;
+                if (wide) {
+                    k = parse_lines_avx512(text, 0, stop, P.hi - p, p + n >= size, names, read_len, check_lengths, c);
+                } else
                 while (k <= stop && k < n && p + k < P.hi) {
                     const char* nl = (const char*)memchr(text + k, '\n', stop - k);
                     const size_t e = nl ? (size_t)(nl - text) : stop;

@@ -43,8 +43,16 @@ def parse(path, names, read_len, threads, parallel, check_lengths=True):
         L.io_paf_free(h)
 
 
+@pytest.fixture(params=["widest", "sse2"])
+def tokenizer(request, monkeypatch):
+    """both tokenizers of the parallel reader: 64-byte compares where the CPU has AVX-512BW, 16-byte otherwise"""
+    if request.param == "sse2":
+        monkeypatch.setenv("RALA_IO_NO_AVX512", "1")
+    return request.param
+
+
 @pytest.mark.parametrize("threads", [1, 2, 3, 8, 61])
-def test_parallel_reader_matches_sequential(tmp_path, threads):
+def test_parallel_reader_matches_sequential(tmp_path, threads, tokenizer):
     ds = Dataset(3000, 600_000, 4)
     paf = str(tmp_path / "ovl.paf")
     ds.write_paf(paf)
@@ -61,7 +69,7 @@ def test_parallel_reader_matches_sequential(tmp_path, threads):
     assert (got["strand"] == ds.overlaps.strand).all()
 
 
-def test_awkward_lines(tmp_path):
+def test_awkward_lines(tmp_path, tokenizer):
     lines = [
         "r0\t1000\t10\t900\t+\tr1\t2000\t5\t895\t800\t890\t255",
         "",                                                         # empty line
@@ -88,7 +96,7 @@ def test_awkward_lines(tmp_path):
     assert want["length"].tolist() == [890, 1500, 400, 100, 1993, 6]
 
 
-def test_lines_across_the_reader_s_buffers(tmp_path):
+def test_lines_across_the_reader_s_buffers(tmp_path, tokenizer):
     """The reader streams the text through half-megabyte buffers: lines that straddle a buffer or a
     piece of the file, a line longer than a buffer, runs of empty lines at the seams."""
     rng = np.random.default_rng(3)
@@ -118,7 +126,7 @@ def test_lines_across_the_reader_s_buffers(tmp_path):
             assert (want[f] == got[f]).all(), (threads, f)
 
 
-def test_length_mismatch_is_reported(tmp_path):
+def test_length_mismatch_is_reported(tmp_path, tokenizer):
     path = str(tmp_path / "bad.paf")
     with open(path, "w") as f:
         f.write("r0\t1000\t0\t500\t+\tr1\t2000\t0\t500\t400\t500\t255\n" * 50)
