@@ -321,12 +321,12 @@ inline bool finish_line(const char* p, const char* const* tab, int nt, bool any_
     field_u32(tab[9] + 1, tab[10], L.ol);            // column 11: alignment length
     L.new_query = c.last_q == nullptr || L.qn != c.last_qn || !same_bytes(c.last_q, L.q, L.qn);
     if (L.new_query) {
-        L.qh = NameTable::hash(L.q, L.qn);
+        L.qh = hash_bytes(L.q, L.qn);
         names.prefetch(L.qh);
         c.last_q = L.q;
         c.last_qn = L.qn;
     }
-    L.th = NameTable::hash(L.t, L.tn);
+    L.th = hash_bytes(L.t, L.tn);
     names.prefetch(L.th);
     if (++c.n_pend == kBatch) resolve_batch(names, read_len, check_lengths, c);
     return true;
@@ -441,11 +441,53 @@ size_t parse_lines_avx512(const char* text, size_t from, size_t stop, size_t lim
 
 uint64_t NameTable::hash(const char* p, size_t n) { return hash_bytes(p, n); }
 
+namespace {
+// the CPUs this process may run on, one per physical core (the lowest-numbered sibling)
+std::vector<int> one_cpu_per_core() {
+    std::vector<int> out;
+    cpu_set_t allowed;
+    if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return out;
+    for (int cpu = 0; cpu < CPU_SETSIZE; ++cpu) {
+        if (!CPU_ISSET(cpu, &allowed)) continue;
+        char path[128];
+        snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", cpu);
+        FILE* f = fopen(path, "r");
+        if (!f) return std::vector<int>();
+        int first = -1;
+        const int got = fscanf(f, "%d", &first);
+        fclose(f);
+        if (got != 1) return std::vector<int>();
+        if (first == cpu) out.push_back(cpu);
+    }
+    return out;
+}
+
+// While it lives the calling thread runs on the first physical cores only - where the parser threads
+// will be pinned - so that what it allocates and touches (the name table) lands in their NUMA node.
+struct NearParserCores {
+    cpu_set_t before;
+    bool active = false;
+    NearParserCores() {
+        if (getenv("RALA_IO_NO_PIN")) return;
+        const std::vector<int> cores = one_cpu_per_core();
+        if (cores.size() < 2 || sched_getaffinity(0, sizeof(before), &before) != 0) return;
+        cpu_set_t near;
+        CPU_ZERO(&near);
+        for (size_t k = 0; k < cores.size() && k < 16; ++k) CPU_SET(cores[k], &near);
+        active = sched_setaffinity(0, sizeof(near), &near) == 0;
+    }
+    ~NearParserCores() {
+        if (active) (void)sched_setaffinity(0, sizeof(before), &before);
+    }
+};
+}  // namespace
+
 NameTable::~NameTable() {
     if (bucket_) free_block(bucket_, n_bucket_ * sizeof(Bucket));
 }
 
 void NameTable::build(const std::vector<std::string>& names) {
+    const NearParserCores near;
     uint64_t cap = 16;
     while (cap < 2 * names.size() + 2) cap <<= 1;
     mask_ = cap - 1;
@@ -489,25 +531,6 @@ uint64_t NameTable::find(const char* p, size_t n, uint64_t h) const {
 namespace {
 constexpr size_t kHugeBlock = 1u << 20, kHugePage = 2u << 20;
 
-// the CPUs this process may run on, one per physical core (the lowest-numbered sibling)
-std::vector<int> one_cpu_per_core() {
-    std::vector<int> out;
-    cpu_set_t allowed;
-    if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return out;
-    for (int cpu = 0; cpu < CPU_SETSIZE; ++cpu) {
-        if (!CPU_ISSET(cpu, &allowed)) continue;
-        char path[128];
-        snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", cpu);
-        FILE* f = fopen(path, "r");
-        if (!f) return std::vector<int>();
-        int first = -1;
-        const int got = fscanf(f, "%d", &first);
-        fclose(f);
-        if (got != 1) return std::vector<int>();
-        if (first == cpu) out.push_back(cpu);
-    }
-    return out;
-}
 }
 
 void* allocate_block(size_t bytes) {

@@ -1,3 +1,4 @@
+# ingest on the box's CPU: pin span sweep (16 threads spread over the first <span> cores of socket 0)
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out tools/_bin
 export TMPDIR=/tmp
@@ -9,9 +10,8 @@ from rala_amd.synth import Dataset
 ds = Dataset.config('c3')
 ds.write_paf('/tmp/c3.paf')
 PY
-lscpu | grep -i "numa\|socket" | head -8
-run() { echo "== $*"; env "$@" RALA_IO_TRACE=1 tools/_bin/ingest_probe /tmp/c3.paf 1000000 16 2>&1 | grep "^\[io\]\|empty table" | tail -2; }
+run() { echo "== $*"; env "$@" RALA_IO_TRACE=1 tools/_bin/ingest_probe /tmp/c3.paf 1000000 16 2>&1 | grep "^\[io\] 16" | tail -3; }
 run RALA_IO_PIN_SPAN=16
 run RALA_IO_PIN_SPAN=24
 run RALA_IO_PIN_SPAN=32
-run RALA_IO_PIN_SPAN=48
+run RALA_IO_PIN_SPAN=64
