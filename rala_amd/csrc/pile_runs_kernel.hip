@@ -1190,6 +1190,18 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
                 if (lane == 0) sel[8 + which] = 0;
                 continue;
             }
+            if (kSens == 0 && nd == 1 && nu == 1) {
+                // the usual pile: one up region where the coverage rises at its left end, one down
+                // region at its right end, far apart.  Nothing overlaps or lies within the window
+                // (pile.cpp:136,177,224-231), no (down, up) pair for a pit (:357-362), and the one hill
+                // candidate fails the distance test (:415-418)
+                const uint32_t up_first = sm[L::RF + (2 * which + 1) * kMaxReg], up_last = sm[L::RL + (2 * which + 1) * kMaxReg];
+                const uint32_t down_first = sm[L::RF + (2 * which) * kMaxReg];
+                if (up_first < down_first && down_first > up_last && down_first - up_last > kSlopeWindow) {
+                    if (lane == 0) sel[8 + which] = 0;
+                    continue;
+                }
+            }
             const uint32_t nr = nd + nu;
             // merge the two sorted lists by rank (keys differ in the low bit, so no ties)
             {
