@@ -221,6 +221,101 @@ __device__ void narrow_serial(RegionList& R, RunCursor& d, double q) {
     }
 }
 
+// resolve_serial with all lanes of the wavefront (lists of up to 64 regions; walks of up to 64
+// runs - longer ones, which need an event every 13 bases over a whole window, go to the serial
+// version on lane 0).  One lane sorting a short list by insertion and looking for the first
+// overlapping pair through LDS, every access a round trip, took a fifth of the merge phase.
+//   * sort: every lane ranks its region among all of them (the others' keys are broadcast reads);
+//   * the first pair that overlaps: one ballot;
+//   * the walk over the runs between s and e: one run per lane, the running maximum of the serial
+//     walk is an exclusive prefix maximum in walk order, maximal groups of consecutive flagged
+//     runs come from the ballot of the flags and are appended by their first lanes.
+// Returns false if the list overflowed (the read is handed on).  Uniform control flow.
+__device__ bool resolve_wave(uint32_t* key, uint32_t* last, uint32_t& n, uint32_t cap, const uint32_t* rs,
+                             const uint16_t* rv, const uint16_t* idx, uint32_t shift, double q, uint32_t lane,
+                             uint32_t* word) {
+    auto run_at = [&](uint32_t pos) {
+        uint32_t c = idx[pos >> shift];
+        while (rs[c + 1] <= pos) ++c;
+        return c;
+    };
+    for (;;) {
+        {
+            const uint32_t k_me = lane < n ? key[lane] : 0u, l_me = lane < n ? last[lane] : 0u;
+            uint32_t rank = 0;
+            for (uint32_t y = 0; y < n; ++y) {
+                const uint32_t ky = key[y], ly = last[y];
+                rank += (ky < k_me || (ky == k_me && (ly < l_me || (ly == l_me && y < lane)))) ? 1u : 0u;
+            }
+            wave_sync();
+            if (lane < n) { key[rank] = k_me; last[rank] = l_me; }
+            wave_sync();
+        }
+        bool c = false;
+        if (lane + 1 < n) {
+            const uint32_t ki = key[lane], li = last[lane], kn = key[lane + 1];
+            c = li >= (kn >> 1) && ((ki & 1) || li != (kn >> 1));
+        }
+        const uint64_t pairs = __builtin_amdgcn_ballot_w64(c);
+        if (!pairs) return true;
+        const uint32_t i = (uint32_t)__builtin_ctzll(pairs);
+        const uint32_t ki = key[i], li = last[i], kn = key[i + 1], ln = last[i + 1];
+        const bool up = ki & 1;
+        // positions [s, e]; the serial walk starts at the run of e (up: towards s) or of s (down: towards e)
+        const uint32_t s = up ? ki >> 1 : umax(ki >> 1, kn >> 1);
+        const uint32_t e = up ? umin(li, ln) : li;
+        const uint32_t k_s = run_at(s), k_e = run_at(e);
+        const uint32_t steps = k_e - k_s;                      // runs the walk visits (it never looks at its first run)
+        if (steps > 64) {
+            // (cannot be decided here: the serial version takes the whole list over)
+            uint32_t* flag = word;                               // a scratch word of the caller's
+            if (lane == 0) {
+                RunCursor d{rs, rv, idx, shift, 0};
+                RegionList R;
+                R.key = key; R.last = last; R.n = n; R.cap = cap; R.overflow = false;
+                resolve_serial(R, d, q);
+                flag[0] = R.n | (R.overflow ? 0x80000000u : 0u);
+            }
+            wave_sync();
+            const uint32_t f = flag[0];
+            n = f & 0x7FFFFFFFu;
+            return !(f >> 31);
+        }
+        const uint32_t k_first = up ? k_e : k_s;                  // its value opens the running maximum
+        const bool mine = lane < steps;
+        const uint32_t k = up ? k_e - 1 - lane : k_s + 1 + lane;  // run of this lane in walk order
+        const uint32_t v = mine ? rv[k] : 0u;
+        const uint32_t incl = wave_scan_incl(v, OpMax());
+        uint32_t before = lane_above(incl);
+        if (lane == 0) before = 0;
+        const uint32_t m = umax((uint32_t)rv[k_first], before);
+        const bool f = mine && (double)v * q < (double)m;
+        const uint32_t c_lo = mine ? (up ? umax(rs[k], s) : rs[k]) : 0u;
+        const uint32_t c_hi = mine ? (up ? rs[k + 1] - 1 : umin(rs[k + 1] - 1, e)) : 0u;
+        const uint64_t F = __builtin_amdgcn_ballot_w64(f);
+        const uint64_t starts = F & ~(F << 1);                    // first lane of every group, in walk order
+        const uint32_t groups = (uint32_t)__popcll(starts);
+        if (n + groups > cap) return false;
+        // the group of a first lane ends in front of the next unflagged lane
+        const uint64_t rest = lane < 63 ? ~F >> (lane + 1) : ~0ull;
+        const uint32_t t_end = rest ? lane + (uint32_t)__builtin_ctzll(rest) : 63u;
+        const uint32_t lo_end = (uint32_t)__shfl((int)c_lo, (int)umin(t_end, 63u), 64);
+        const uint32_t hi_end = (uint32_t)__shfl((int)c_hi, (int)umin(t_end, 63u), 64);
+        if ((starts >> lane) & 1) {
+            const uint32_t at = n + (uint32_t)__popcll(starts & ((1ull << lane) - 1ull));
+            // up: the walk goes down, the group's last lane holds its lowest position; down: the other way round
+            key[at] = up ? (lo_end << 1 | 1u) : (c_lo << 1);
+            last[at] = up ? c_hi : hi_end;
+        }
+        if (lane == 0) {
+            if (up) key[i] = e << 1 | 1u;
+            else last[i] = s;
+        }
+        n += groups;
+        wave_sync();
+    }
+}
+
 template <int C>
 __device__ __forceinline__ void load_sort_store(const uint32_t* __restrict__ gev, uint32_t n_ev, uint32_t n,
                                                 uint32_t* ev, uint32_t lane) {
@@ -428,7 +523,11 @@ __device__ __forceinline__ void expand_from_bitmap(uint32_t* sm, const uint16_t*
 //               the runs between them, intervalMerge, clamp.  Neither reads nor writes the row.
 // A read that does not fit (events, length, lists) goes to overflow_list and from there to the
 // position-space kernel of pile_repeats_kernel.hip.
-template <uint32_t kCap, bool kDiag, int kSens>
+// kOne: the launch has one workgroup per item (the first kernel of the chain): no loop over the
+// items, so nothing is hoisted out of one and kept in registers for the whole kernel.  (A zero
+// vector hoisted that way was spilled and reloaded right behind the row stores: a scratch load, and
+// with it a wait for every one of them.)
+template <uint32_t kCap, bool kDiag, int kSens, bool kOne = false>
 __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* overflow_list, uint32_t* overflow_count) {
     static_assert(kSens == 0 || (kCap <= 1024 && !kDiag), "the sensitive pass runs on the bitmap path");
     typedef Layout<kCap> L;
@@ -455,7 +554,7 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
     // group of 8, word q takes the new value in the halves at or behind x: all of it for
     // x - 2q <= 0, the upper half for x - 2q == 1, nothing beyond.  mt[6 + d] is that mask.
     if (lane < 14) sm[L::MT + lane] = lane <= 6 ? 0xFFFFFFFFu : lane == 7 ? 0xFFFF0000u : 0u;
-    for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+    for (uint32_t item = blockIdx.x; item < n_items; item = kOne ? n_items : item + gridDim.x) {
         const uint32_t r = A.order ? A.order[item] : item;
         const uint32_t n = A.read_len[r];
         const uint64_t row_off = kSens == 2 ? 0 : A.pile_off[r];
@@ -1237,11 +1336,15 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
             }
             uint32_t n_reg = nr;
             if (need_resolve || need_narrow) {
+                bool fits = true;
+                uint32_t n_now = nr;
+                constexpr bool kWaveResolve = 2 * kMaxReg <= 64;     // one region per lane
+                if (kWaveResolve && need_resolve) fits = resolve_wave(key, last, n_now, 2 * kMaxReg, rs, rv, idx, shift, q, lane, sel + 14);
                 if (lane == 0) {
                     RunCursor dv{rs, rv, idx, shift, 0};
                     RegionList Rg;
-                    Rg.key = key; Rg.last = last; Rg.n = nr; Rg.cap = 2 * kMaxReg; Rg.overflow = false;
-                    if (need_resolve) resolve_serial(Rg, dv, q);
+                    Rg.key = key; Rg.last = last; Rg.n = n_now; Rg.cap = 2 * kMaxReg; Rg.overflow = !fits;
+                    if (!kWaveResolve && need_resolve) resolve_serial(Rg, dv, q);
                     if (!Rg.overflow) narrow_serial(Rg, dv, q);
                     sel[12] = Rg.n;
                     sel[13] = Rg.overflow ? 1u : 0u;
@@ -1483,7 +1586,12 @@ void launch_pile_runs(const PileArgs& args, uint32_t grid, int tier, uint32_t* o
         else hipLaunchKernelGGL((pile_runs_kernel<cap, false, 0>), dim3(grid), dim3(64), lds, stream, args,             \
                                 overflow_list, overflow_count);                                                         \
     } while (0)
-    if (tier == 0) RALA_LAUNCH_RUNS(kRunEventCap, extra_lds);
+    if (tier == 0 && grid >= args.n_items && !args.n_items_dev) {
+        if (diag) hipLaunchKernelGGL((pile_runs_kernel<kRunEventCap, true, 0, true>), dim3(grid), dim3(64), extra_lds, stream,
+                                     args, overflow_list, overflow_count);
+        else hipLaunchKernelGGL((pile_runs_kernel<kRunEventCap, false, 0, true>), dim3(grid), dim3(64), extra_lds, stream,
+                                args, overflow_list, overflow_count);
+    } else if (tier == 0) RALA_LAUNCH_RUNS(kRunEventCap, extra_lds);
     else if (tier == 1) RALA_LAUNCH_RUNS(kRunEventCapMid, 0);
     else RALA_LAUNCH_RUNS(kRunEventCapBig, 0);
 #undef RALA_LAUNCH_RUNS
