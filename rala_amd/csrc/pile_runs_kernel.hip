@@ -53,8 +53,9 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-struct RunCursor {
-    const uint32_t* rs;     // run starts, rs[R] = n
+template <class RsT>
+struct RunCursorT {
+    const RsT* rs;          // run starts, rs[R] = n (16 bits where no read is longer than 16384 bases)
     const uint16_t* rv;     // run values
     const uint16_t* idx;    // run containing position m << shift
     uint32_t shift;
@@ -70,6 +71,7 @@ struct RunCursor {
     }
     __device__ uint32_t operator[](uint32_t j) { return rv[run_of(j)]; }
 };
+typedef RunCursorT<uint32_t> RunCursor;
 
 struct RegionList {
     uint32_t* key;      // first << 1 | is_up
@@ -103,9 +105,10 @@ __device__ void rl_sort(RegionList& R) {
 // reference walks positions; coverage is constant inside a run and a position is
 // never flagged against its own run (v * q >= v), so whole clipped runs are
 // flagged or not together: the walk is over runs.
-__device__ void resolve_serial(RegionList& R, RunCursor& d, double q) {
+template <class RsT>
+__device__ void resolve_serial(RegionList& R, RunCursorT<RsT>& d, double q) {
     if (R.n == 0) return;
-    const uint32_t* rs = d.rs;
+    const RsT* rs = d.rs;
     const uint16_t* rv = d.rv;
     for (;;) {
         rl_sort(R);
@@ -172,7 +175,8 @@ __device__ void resolve_serial(RegionList& R, RunCursor& d, double q) {
 }
 
 // max of the coverage over positions [a, b] (a <= b), by runs
-__device__ uint32_t range_max_runs(RunCursor& d, uint32_t a, uint32_t b) {
+template <class RsT>
+__device__ uint32_t range_max_runs(RunCursorT<RsT>& d, uint32_t a, uint32_t b) {
     uint32_t k = d.run_of(a);
     uint32_t m = d.rv[k];
     while (d.rs[k + 1] <= b) {
@@ -184,8 +188,9 @@ __device__ uint32_t range_max_runs(RunCursor& d, uint32_t a, uint32_t b) {
 
 // pile.cpp:222-256 (one lane; only reached when an up region is followed by a
 // down region within the window), by runs
-__device__ void narrow_serial(RegionList& R, RunCursor& d, double q) {
-    const uint32_t* rs = d.rs;
+template <class RsT>
+__device__ void narrow_serial(RegionList& R, RunCursorT<RsT>& d, double q) {
+    const RsT* rs = d.rs;
     const uint16_t* rv = d.rv;
     for (uint32_t i = 0; i + 1 < R.n; ++i) {
         if (!(R.key[i] & 1) || (R.key[i + 1] & 1)) continue;
@@ -231,7 +236,8 @@ __device__ void narrow_serial(RegionList& R, RunCursor& d, double q) {
 //     walk is an exclusive prefix maximum in walk order, maximal groups of consecutive flagged
 //     runs come from the ballot of the flags and are appended by their first lanes.
 // Returns false if the list overflowed (the read is handed on).  Uniform control flow.
-__device__ bool resolve_wave(uint32_t* key, uint32_t* last, uint32_t& n, uint32_t cap, const uint32_t* rs,
+template <class RsT>
+__device__ bool resolve_wave(uint32_t* key, uint32_t* last, uint32_t& n, uint32_t cap, const RsT* rs,
                              const uint16_t* rv, const uint16_t* idx, uint32_t shift, double q, uint32_t lane,
                              uint32_t* word) {
     auto run_at = [&](uint32_t pos) {
@@ -270,7 +276,7 @@ __device__ bool resolve_wave(uint32_t* key, uint32_t* last, uint32_t& n, uint32_
             // (cannot be decided here: the serial version takes the whole list over)
             uint32_t* flag = word;                               // a scratch word of the caller's
             if (lane == 0) {
-                RunCursor d{rs, rv, idx, shift, 0};
+                RunCursorT<RsT> d{rs, rv, idx, shift, 0};
                 RegionList R;
                 R.key = key; R.last = last; R.n = n; R.cap = cap; R.overflow = false;
                 resolve_serial(R, d, q);
@@ -335,6 +341,13 @@ __device__ __forceinline__ void load_sort_store(const uint32_t* __restrict__ gev
     for (int t = 0; t < C; ++t) ev[(uint32_t)t * 64u + lane] = v[t];
 }
 
+// A 32-bit word holds two positions; when the value changes at position x (1 .. 7) of a group of
+// 8, word q takes the new value in the halves at or behind x: all of it for x <= 2q, the upper half
+// for x == 2q + 1, nothing beyond.
+__device__ __forceinline__ uint32_t change_mask(uint32_t x, uint32_t q) {
+    return x <= 2 * q ? 0xFFFFFFFFu : x == 2 * q + 1 ? 0xFFFF0000u : 0u;
+}
+
 // (a & mask) | (b & ~mask) in one instruction
 __device__ __forceinline__ uint32_t bitfield_insert(uint32_t mask, uint32_t a, uint32_t b) {
     uint32_t d;
@@ -354,14 +367,19 @@ __device__ __forceinline__ void store16(const char* base, uint32_t off, const ui
     asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" : : "v"(off), "v"(d), "s"(base) : "memory");
 }
 
-template <uint32_t kCap>
+// kShort: the first kernel of the chain takes only reads of up to 16384 bases (the others go to the
+// next one): run starts in 16 bits, no sorted path, lists a little shorter - 6 656 bytes of LDS,
+// six wavefronts per SIMD instead of five.
+template <uint32_t kCap, bool kShort = false>
 struct Layout {
+    typedef typename std::conditional<kShort, uint16_t, uint32_t>::type rs_t;
+    static constexpr bool kShortLayout = kShort;
     // list capacities: a read that needs more goes to the next kernel of the chain
     // three instantiations: 512 events (almost every read), 1024 (high coverage), 2048 (the rest)
-    static constexpr uint32_t kMaxReg = kCap <= 512 ? 16 : kCap <= 1024 ? 32 : 64;   // regions per (q, kind) list
+    static constexpr uint32_t kMaxReg = kShort ? 14 : kCap <= 512 ? 16 : kCap <= 1024 ? 32 : 64;   // regions per (q, kind) list
     static constexpr uint32_t kMaxRaw = kCap <= 512 ? 8 : kCap <= 1024 ? 16 : 32;    // pits / hills before the merge
     static constexpr uint32_t kArr = kCap + 4;                  // entries per run-indexed array
-    static constexpr uint32_t kIdx = kCap <= 512 ? 256 : 512;   // entries of the position -> run index
+    static constexpr uint32_t kIdx = kShort ? 128 : kCap <= 512 ? 256 : 512;   // entries of the position -> run index
     // runs that survive the slope filter (k and four uint16 offsets each) + block maxima
     static constexpr uint32_t kSurv = kCap <= 512 ? 192 : kCap <= 1024 ? 384 : kArr;
     static constexpr uint32_t kBm8 = kArr / 8 + 8;
@@ -371,7 +389,7 @@ struct Layout {
     static constexpr uint32_t kXmin = kCap > 768 ? kCap : 768;
     static constexpr uint32_t kX = kSlopeWords > kXmin ? kSlopeWords : kXmin;
     static constexpr uint32_t RS = X + kX;                      // run starts (+ sentinel)
-    static constexpr uint32_t RV = RS + kArr;                   // run values, uint16 (kArr / 2 words)
+    static constexpr uint32_t RV = RS + (kShort ? kArr / 2 : kArr);   // run values, uint16 (kArr / 2 words)
     static constexpr uint32_t IDX = RV + kArr / 2;              // kIdx uint16
     static constexpr uint32_t RF = IDX + kIdx / 2;              // 4 lists x kMaxReg firsts
     static constexpr uint32_t RL = RF + 4 * kMaxReg;            // 4 lists x kMaxReg lasts
@@ -380,11 +398,17 @@ struct Layout {
     static constexpr uint32_t IV = REG + 8 * kMaxReg;           // 2 x 4 x kMaxRaw
     static constexpr uint32_t GONE = IV + 8 * kMaxRaw;          // 2 x kMaxRaw bytes
     static constexpr uint32_t CAND = GONE + (2 * kMaxRaw) / 4;  // kMaxRaw hill candidates (i << 16 | j)
-    static constexpr uint32_t SEL = CAND + kMaxRaw;             // 16 words
-    static constexpr uint32_t MT = SEL + 16;                    // 14 words: expansion masks, see there
-    static constexpr uint32_t WORDS = MT + 14;
+    static constexpr uint32_t SEL = CAND + kMaxRaw;             // 12 words
+    static constexpr uint32_t WORDS = SEL + 12;
+    // scratch of the expansion: a list of 64 noted groups and a table of 64 finished ones.  The list
+    // takes the position index's place where that is computed behind the expansion (kShort).
+    static constexpr uint32_t XLIST = kShort ? IDX : RF;
+    static constexpr uint32_t XTABLE = ((kShort ? RF : RF + 64) + 3) & ~3u;
     static_assert(kX >= kCap && kX >= kIdx && kX >= 768, "shared region too small");
+    static_assert(kIdx / 2 >= 64 && SEL >= XTABLE + 256, "scratch for the noted groups of a chunk");
+    static_assert(!kShort || WORDS * 4 <= 6656, "six wavefronts per SIMD: 24 workgroups in 160 KB, 512-byte granules");
 };
+
 
 
 // Expansion of a pile of up to 16384 positions (2048 groups of 8 = 16 bytes) from the bitmap of
@@ -408,10 +432,8 @@ __device__ __forceinline__ void expand_from_bitmap(uint32_t* sm, const uint16_t*
     const uint32_t* bm = sm + L::X;
     const uint16_t* pref = (const uint16_t*)(bm + 512);
     const uint16_t* rvm1 = rv - 1;                      // indexed by run + 1 (= run starts at or before)
-    uint32_t* list = sm + L::RF;                        // the region lists are not in use yet
-    constexpr uint32_t kTable = (L::RF + 64 + 3) & ~3u; // 16-byte aligned
-    uint4* table = (uint4*)(sm + kTable);               // 64 finished groups
-    static_assert(L::SEL >= kTable + 256, "scratch for the noted groups of a chunk");
+    uint32_t* list = sm + L::XLIST;                     // the region lists are not in use yet
+    uint4* table = (uint4*)(sm + L::XTABLE);            // 64 finished groups, 16-byte aligned
     // the row address is the same in every lane: keep it in scalar registers, 32-bit lane offsets
     // (the builtin returns int: without the casts the low half would be sign-extended over the high one)
     const uint64_t off = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(row_off >> 32)) << 32) |
@@ -468,12 +490,10 @@ __device__ __forceinline__ void expand_from_bitmap(uint32_t* sm, const uint16_t*
                         inner &= inner - 1;
                         const uint32_t nvv = rvm1[++k];
                         const uint32_t f = nvv | (nvv << 16);
-                        const uint32_t* mt = sm + L::MT + x;
-                        const uint32_t m0 = mt[6], m1 = mt[4], m2 = mt[2], m3 = mt[0];
-                        w0 = bitfield_insert(m0, f, w0);
-                        w1 = bitfield_insert(m1, f, w1);
-                        w2 = bitfield_insert(m2, f, w2);
-                        w3 = bitfield_insert(m3, f, w3);
+                        w0 = bitfield_insert(change_mask(x, 0), f, w0);
+                        w1 = bitfield_insert(change_mask(x, 1), f, w1);
+                        w2 = bitfield_insert(change_mask(x, 2), f, w2);
+                        w3 = bitfield_insert(change_mask(x, 3), f, w3);
                     } while (inner);
                     table[lane] = make_uint4(w0, w1, w2, w3);
                 }
@@ -528,14 +548,17 @@ __device__ __forceinline__ void expand_from_bitmap(uint32_t* sm, const uint16_t*
 // vector hoisted that way was spilled and reloaded right behind the row stores: a scratch load, and
 // with it a wait for every one of them.)
 template <uint32_t kCap, bool kDiag, int kSens, bool kOne = false>
-__global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* overflow_list, uint32_t* overflow_count) {
+__global__ __launch_bounds__(64, kOne ? 6 : 5) void pile_runs_kernel(PileArgs A, uint32_t* overflow_list, uint32_t* overflow_count) {
     static_assert(kSens == 0 || (kCap <= 1024 && !kDiag), "the sensitive pass runs on the bitmap path");
-    typedef Layout<kCap> L;
+    static_assert(!kOne || (kCap <= 512 && kSens == 0), "the short layout belongs to the first kernel of the chain");
+    constexpr bool kShort = kOne;       // reads of up to 16384 bases only, 16-bit run starts, 6 656 bytes of LDS
+    typedef Layout<kCap, kShort> L;
+    typedef typename L::rs_t rs_t;
     constexpr uint32_t kMaxReg = L::kMaxReg, kMaxRaw = L::kMaxRaw;
     __shared__ __align__(16) uint32_t sm[L::WORDS];
     const uint32_t lane = threadIdx.x;
     uint32_t* ev = sm + L::X;
-    uint32_t* rs = sm + L::RS;
+    rs_t* rs = (rs_t*)(sm + L::RS);
     uint16_t* rv = (uint16_t*)(sm + L::RV);
     uint16_t* idx = (uint16_t*)(sm + L::IDX);
     uint32_t* sel = sm + L::SEL;
@@ -550,10 +573,6 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
         wave_sync();                                                       \
         continue;                                                          \
     }
-    // expansion: a 32-bit word holds two positions; when the value changes at position x of a
-    // group of 8, word q takes the new value in the halves at or behind x: all of it for
-    // x - 2q <= 0, the upper half for x - 2q == 1, nothing beyond.  mt[6 + d] is that mask.
-    if (lane < 14) sm[L::MT + lane] = lane <= 6 ? 0xFFFFFFFFu : lane == 7 ? 0xFFFF0000u : 0u;
     for (uint32_t item = blockIdx.x; item < n_items; item = kOne ? n_items : item + gridDim.x) {
         const uint32_t r = A.order ? A.order[item] : item;
         const uint32_t n = A.read_len[r];
@@ -571,7 +590,7 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
             given_e = A.end[r];
         }
         // (the two region marks of the sensitive pass may add two runs)
-        if (n_ev > (kSens ? kCap - 2 : kCap) || (kSens != 0 && (n > 16384 || given_e <= given_b))) {
+        if (n_ev > (kSens ? kCap - 2 : kCap) || (kSens != 0 && (n > 16384 || given_e <= given_b)) || (kShort && n > 16384)) {
             if (lane == 0) overflow_list[atomicAdd(overflow_count, 1u)] = r;
             continue;
         }
@@ -584,7 +603,7 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
         // instantiation) sort their events and sweep, as the reference does.
         uint32_t R;
         constexpr uint32_t kBitmapBases = 16384;
-        const bool bitmap_path = kCap <= 1024 && n <= kBitmapBases;
+        const bool bitmap_path = kShort || (kCap <= 1024 && n <= kBitmapBases);
         if (bitmap_path) {
             uint32_t* bm = sm + L::X;
             uint16_t* pref = (uint16_t*)(bm + kBitmapBases / 32);
@@ -821,15 +840,18 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
         uint32_t shift = 5;
         while ((n >> shift) >= L::kIdx) ++shift;
         const uint32_t ng = ((n - 1) >> shift) + 1;
-        if (bitmap_path) {
-            // the bitmap of run starts and its per-word prefix are still there; position
-            // m << shift is the first bit of word m << (shift - 5)
+        // (from the bitmap of run starts and its per-word prefix, which are still there: position
+        // m << shift is the first bit of word m << (shift - 5))
+        auto index_from_bitmap = [&]() {
             const uint32_t* bm = sm + L::X;
             const uint16_t* pref = (const uint16_t*)(bm + kBitmapBases / 32);
             for (uint32_t m = lane; m < ng; m += 64) {
                 const uint32_t w = m << (shift - 5);
                 idx[m] = (uint16_t)(pref[w] + (bm[w] & 1u) - 1u);
             }
+        };
+        if (bitmap_path) {
+            if (!kShort) index_from_bitmap();       // (short layout: behind the expansion, whose list lies there)
         } else {
             // number of runs j >= 1 that start at or before it: histogram of
             // ceil(start / 2^shift) over the runs, then a prefix sum
@@ -885,6 +907,7 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
                 if (lane == 0 && n < kSeg) atomicOr(&bm[n >> 5], 1u << (n & 31));
                 wave_sync();
                 expand_from_bitmap<L>(sm, rv, A.pile, row_off, nv, lane, row_stores);
+                if (kShort) index_from_bitmap();
             } else
             for (uint32_t s0 = 0; s0 < nv * 8; s0 += kSeg) {       // sorted path: long reads, many events
                 {
@@ -947,12 +970,10 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
                             inner &= inner - 1;
                             const uint32_t nvv = rv[++kk];
                             const uint32_t f = nvv | (nvv << 16);
-                            const uint32_t* mt = sm + L::MT + x;
-                            const uint32_t m0 = mt[6], m1 = mt[4], m2 = mt[2], m3 = mt[0];
-                            w0 = bitfield_insert(m0, f, w0);
-                            w1 = bitfield_insert(m1, f, w1);
-                            w2 = bitfield_insert(m2, f, w2);
-                            w3 = bitfield_insert(m3, f, w3);
+                            w0 = bitfield_insert(change_mask(x, 0), f, w0);
+                            w1 = bitfield_insert(change_mask(x, 1), f, w1);
+                            w2 = bitfield_insert(change_mask(x, 2), f, w2);
+                            w3 = bitfield_insert(change_mask(x, 3), f, w3);
                         }
                         if (row_stores) dst[g] = make_uint4(w0, w1, w2, w3);
                     }
@@ -1339,19 +1360,19 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
                 bool fits = true;
                 uint32_t n_now = nr;
                 constexpr bool kWaveResolve = 2 * kMaxReg <= 64;     // one region per lane
-                if (kWaveResolve && need_resolve) fits = resolve_wave(key, last, n_now, 2 * kMaxReg, rs, rv, idx, shift, q, lane, sel + 14);
+                if (kWaveResolve && need_resolve) fits = resolve_wave(key, last, n_now, 2 * kMaxReg, rs, rv, idx, shift, q, lane, sel + 4);
                 if (lane == 0) {
-                    RunCursor dv{rs, rv, idx, shift, 0};
+                    RunCursorT<rs_t> dv{rs, rv, idx, shift, 0};
                     RegionList Rg;
                     Rg.key = key; Rg.last = last; Rg.n = n_now; Rg.cap = 2 * kMaxReg; Rg.overflow = !fits;
                     if (!kWaveResolve && need_resolve) resolve_serial(Rg, dv, q);
                     if (!Rg.overflow) narrow_serial(Rg, dv, q);
-                    sel[12] = Rg.n;
-                    sel[13] = Rg.overflow ? 1u : 0u;
+                    sel[2] = Rg.n;                       // (the order statistics are done with sel[2 ..])
+                    sel[3] = Rg.overflow ? 1u : 0u;
                 }
                 wave_sync();
-                n_reg = sel[12];
-                if (sel[13]) {
+                n_reg = sel[2];
+                if (sel[3]) {
                     any_overflow = true;
                     if (lane == 0) sel[8 + which] = 0;
                     wave_sync();
@@ -1474,7 +1495,7 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
                     uint32_t cnt = n_raw;
                     if (!which) {
                         // peak test and fuzz of pile.cpp:421-448, candidates in (i, j) order
-                        RunCursor dv{rs, rv, idx, shift, 0};
+                        RunCursorT<rs_t> dv{rs, rv, idx, shift, 0};
                         const uint32_t* cand = sm + L::CAND;
                         cnt = 0;
                         for (uint32_t c = 0; c < n_raw; ++c) {
@@ -1541,7 +1562,7 @@ __global__ __launch_bounds__(64, 5) void pile_runs_kernel(PileArgs A, uint32_t* 
                     err |= kErrPoolCapacity;
                     slot = kNone; wp = wh = 0;
                 } else {
-                    RunCursor dv{rs, rv, idx, shift, 0};
+                    RunCursorT<rs_t> dv{rs, rv, idx, shift, 0};
                     const uint32_t* pf = sm + L::IV + 4 * kMaxRaw + 2 * kMaxRaw;
                     const uint32_t* ps = pf + kMaxRaw;
                     const uint32_t* hf = sm + L::IV + 2 * kMaxRaw;
