@@ -550,7 +550,7 @@ __device__ __forceinline__ void expand_from_bitmap(uint32_t* sm, const uint16_t*
 template <uint32_t kCap, bool kDiag, int kSens, bool kOne = false>
 __global__ __launch_bounds__(64, kOne ? 6 : 5) void pile_runs_kernel(PileArgs A, uint32_t* overflow_list, uint32_t* overflow_count) {
     static_assert(kSens == 0 || (kCap <= 1024 && !kDiag), "the sensitive pass runs on the bitmap path");
-    static_assert(!kOne || (kCap <= 512 && kSens == 0), "the short layout belongs to the first kernel of the chain");
+    static_assert(!kOne || kCap <= 512, "the short layout belongs to the first kernel of a chain");
     constexpr bool kShort = kOne;       // reads of up to 16384 bases only, 16-bit run starts, 6 656 bytes of LDS
     typedef Layout<kCap, kShort> L;
     typedef typename L::rs_t rs_t;
@@ -851,7 +851,8 @@ __global__ __launch_bounds__(64, kOne ? 6 : 5) void pile_runs_kernel(PileArgs A,
             }
         };
         if (bitmap_path) {
-            if (!kShort) index_from_bitmap();       // (short layout: behind the expansion, whose list lies there)
+            // (short layout: behind the expansion, whose list lies there - unless there is no expansion)
+            if (!kShort || kSens == 2) index_from_bitmap();
         } else {
             // number of runs j >= 1 that start at or before it: histogram of
             // ceil(start / 2^shift) over the runs, then a prefix sum
@@ -1624,7 +1625,13 @@ void launch_pile_sens(const PileArgs& args, uint32_t grid, int tier, int mode, u
 #define RALA_LAUNCH_SENS(cap, m)                                                                                        \
     hipLaunchKernelGGL((pile_runs_kernel<cap, false, m>), dim3(grid), dim3(64), 0, stream, args, overflow_list,         \
                        overflow_count)
-    if (tier == 0) {
+    if (tier == 0 && grid >= args.n_items && !args.n_items_dev) {
+        // one workgroup per read: no loop, short layout (the sensitive pass takes reads of up to 16384 bases anyway)
+        if (mode == 1) hipLaunchKernelGGL((pile_runs_kernel<kRunEventCap, false, 1, true>), dim3(grid), dim3(64), 0, stream, args,
+                                          overflow_list, overflow_count);
+        else hipLaunchKernelGGL((pile_runs_kernel<kRunEventCap, false, 2, true>), dim3(grid), dim3(64), 0, stream, args,
+                                overflow_list, overflow_count);
+    } else if (tier == 0) {
         if (mode == 1) RALA_LAUNCH_SENS(kRunEventCap, 1);
         else RALA_LAUNCH_SENS(kRunEventCap, 2);
     } else {
