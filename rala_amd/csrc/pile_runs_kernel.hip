@@ -364,7 +364,7 @@ __device__ __forceinline__ void store16(const char* base, uint32_t off, const ui
     const u32x4 d = {v.x, v.y, v.z, v.w};
     // (s_nop: a store of more than 8 bytes reads its data registers over the following cycles; the
     // compiler's hazard recogniser keeps vector writes to them away from its own stores, not from this one)
-    asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" : : "v"(off), "v"(d), "s"(base) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" : : "v"(off), "v"(d), "s"(base) : "memory");
 }
 
 // kShort: the first kernel of the chain takes only reads of up to 16384 bases (the others go to the
