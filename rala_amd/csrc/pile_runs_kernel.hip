@@ -362,6 +362,9 @@ __device__ __forceinline__ uint32_t bitfield_insert(uint32_t mask, uint32_t a, u
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store16(const char* base, uint32_t off, const uint4& v) {
     const u32x4 d = {v.x, v.y, v.z, v.w};
+    // (nt: the rows are written once and not read again by this stage - as streaming stores they leave the caches
+    // to the events and the annotations: chain 4.70 -> 4.42 ms at C3.  The bucketing's scattered 8-byte stores
+    // are the opposite case: non-temporal they cannot be merged in the cache, 2.4 -> 3.3 ms.)
     // (s_nop: a store of more than 8 bytes reads its data registers over the following cycles; the
     // compiler's hazard recogniser keeps vector writes to them away from its own stores, not from this one)
     asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" : : "v"(off), "v"(d), "s"(base) : "memory");
@@ -976,7 +979,10 @@ __global__ __launch_bounds__(64, kOne ? 6 : 5) void pile_runs_kernel(PileArgs A,
                             w2 = bitfield_insert(change_mask(x, 2), f, w2);
                             w3 = bitfield_insert(change_mask(x, 3), f, w3);
                         }
-                        if (row_stores) dst[g] = make_uint4(w0, w1, w2, w3);
+                        if (row_stores) {
+                            const u32x4 w = {w0, w1, w2, w3};
+                            __builtin_nontemporal_store(w, (u32x4*)&dst[g]);
+                        }
                     }
                 }
             }
