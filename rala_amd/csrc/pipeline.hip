@@ -1722,16 +1722,15 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
     HIPCHECK(hipMemsetAsync(ctx->d_small.p, 0, 8 * 4, s));
     HIPCHECK(hipEventRecord(ctx->ev[0], s));
     // duplicate removal only feeds the second pass (every resolvable overlap adds its bounds,
-    // valid or not): it runs on a second stream beside the bucketing, which waits on atomics
-    // and leaves the memory system idle; the main stream joins it after the pile kernels
+    // valid or not): it runs on a second stream beside the pile kernels (started when the
+    // bucketing is done - beside the bucketing, both reading the same columns while the atomics
+    // queue, the two slowed each other: 0.2 - 0.5 ms per C3 step); the main stream joins it after
+    // the pile kernels
     const bool forked = !ctx->tuple_mode && ctx->use_side_stream;
-    if (forked) {
-        HIPCHECK(hipStreamWaitEvent(ctx->side, ctx->ev[0], 0));
-        launch_dedupe(ctx->ovl, n_reads, ctx->d_suspect.p, ctx->d_valid.p, ctx->side);
-    } else if (!ctx->tuple_mode) {
-        launch_dedupe(ctx->ovl, n_reads, ctx->d_suspect.p, ctx->d_valid.p, s);
+    if (!forked) {
+        if (!ctx->tuple_mode) launch_dedupe(ctx->ovl, n_reads, ctx->d_suspect.p, ctx->d_valid.p, s);
+        HIPCHECK(hipEventRecord(ctx->ev[1], s));
     }
-    HIPCHECK(hipEventRecord(ctx->ev[1], forked ? ctx->side : s));
     // bucket bounds by read.  Fast path: one kernel into fixed slots of kRunEventCapBig events per
     // read (8 KB; 8 GB at a million reads - HBM is 288 GB); the position inside the slot is what the
     // counting atomic returns, so there is no scan and no second pass over the overlaps.  A read
@@ -1771,6 +1770,11 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
     }
     }
     HIPCHECK(hipEventRecord(ctx->ev[2], s));
+    if (forked) {
+        HIPCHECK(hipStreamWaitEvent(ctx->side, ctx->ev[2], 0));
+        launch_dedupe(ctx->ovl, n_reads, ctx->d_suspect.p, ctx->d_valid.p, ctx->side);
+        HIPCHECK(hipEventRecord(ctx->ev[1], ctx->side));
+    }
 
     PileArgs a;
     a.read_len = ctx->d_read_len.p; a.pile_off = ctx->d_pile_off.p; a.pile = ctx->d_pile.p;
