@@ -363,8 +363,9 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store16(const char* base, uint32_t off, const uint4& v) {
     const u32x4 d = {v.x, v.y, v.z, v.w};
     // (nt: the rows are written once and not read again by this stage - as streaming stores they leave the caches
-    // to the events and the annotations: chain 4.70 -> 4.42 ms at C3.  The bucketing's scattered 8-byte stores
-    // are the opposite case: non-temporal they cannot be merged in the cache, 2.4 -> 3.3 ms.)
+    // to the events and the annotations; 1 % at C3, measured inside one gpurun call - boxes differ by more.  The
+    // bucketing's scattered 8-byte stores are the opposite case: non-temporal they cannot be merged in the
+    // cache, 2.4 -> 3.3 ms.)
     // (s_nop: a store of more than 8 bytes reads its data registers over the following cycles; the
     // compiler's hazard recogniser keeps vector writes to them away from its own stores, not from this one)
     asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" : : "v"(off), "v"(d), "s"(base) : "memory");
