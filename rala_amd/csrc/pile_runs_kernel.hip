@@ -362,13 +362,12 @@ __device__ __forceinline__ uint32_t bitfield_insert(uint32_t mask, uint32_t a, u
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store16(const char* base, uint32_t off, const uint4& v) {
     const u32x4 d = {v.x, v.y, v.z, v.w};
-    // (nt: the rows are written once and not read again by this stage - as streaming stores they leave the caches
-    // to the events and the annotations; 1 % at C3, measured inside one gpurun call - boxes differ by more.  The
-    // bucketing's scattered 8-byte stores are the opposite case: non-temporal they cannot be merged in the
-    // cache, 2.4 -> 3.3 ms.)
+    // (Measured and not kept: the `nt` modifier - streaming stores gave 1 % at C3 inside one gpurun call and 3 %
+    // more write traffic at the memory; for the bucketing's scattered 8-byte stores, which need the cache to
+    // merge them, it cost 40 %.)
     // (s_nop: a store of more than 8 bytes reads its data registers over the following cycles; the
     // compiler's hazard recogniser keeps vector writes to them away from its own stores, not from this one)
-    asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" : : "v"(off), "v"(d), "s"(base) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" : : "v"(off), "v"(d), "s"(base) : "memory");
 }
 
 // kShort: the first kernel of the chain takes only reads of up to 16384 bases (the others go to the
@@ -980,10 +979,7 @@ __global__ __launch_bounds__(64, kOne ? 6 : 5) void pile_runs_kernel(PileArgs A,
                             w2 = bitfield_insert(change_mask(x, 2), f, w2);
                             w3 = bitfield_insert(change_mask(x, 3), f, w3);
                         }
-                        if (row_stores) {
-                            const u32x4 w = {w0, w1, w2, w3};
-                            __builtin_nontemporal_store(w, (u32x4*)&dst[g]);
-                        }
+                        if (row_stores) dst[g] = make_uint4(w0, w1, w2, w3);
                     }
                 }
             }
