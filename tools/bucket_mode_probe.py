@@ -9,12 +9,12 @@ from rala_amd.synth import Dataset
 
 ds = Dataset.config(sys.argv[1] if len(sys.argv) > 1 else "c3")
 keep = []
-for k in range(6):
+for k in range(int(sys.argv[2]) if len(sys.argv) > 2 else 6):
     ctx = hip.Context(0)
     ctx.set_reads(ds.read_len)
     ctx.set_overlaps(ds.overlaps)
     t = []
-    for _ in range(4):
+    for _ in range(12):
         ctx.initialize()
         t.append(ctx.timings()["bucket_ms"])
     print("context %d: bucket_ms %s" % (k, " ".join("%.2f" % x for x in t)), flush=True)
