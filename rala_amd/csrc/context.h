@@ -153,7 +153,7 @@ struct rala_hip_ctx {
     std::vector<uint16_t> h_median, h_p10;
     std::vector<uint8_t> h_alive, h_n_pits, h_n_hills;
     std::vector<rala_hip::Interval> h_pool;
-    rala_hip::DevBuf<uint32_t> d_overflow_mid, d_chain_cnt;      // third overflow list / chain counters
+    rala_hip::DevBuf<uint32_t> d_overflow_mid, d_overflow_long, d_chain_cnt;      // more overflow lists / chain counters
     // how initialize left the primary bound events (the sensitive pass reads them again):
     // fixed slots (d_ev_fixed, counts in d_cursor) or the CSR (d_ev_off, d_ev)
     bool ev_ready = false, ev_fixed = false;

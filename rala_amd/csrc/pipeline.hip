@@ -1787,23 +1787,31 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
     a.pool = ctx->d_pool.p; a.pool_count = ctx->d_small.p; a.pool_cap = ctx->pool_cap; a.error = ctx->d_small.p + 1;
     a.n_items_dev = nullptr;
     if (ctx->use_run_kernel) {
-        // Chain without host synchronisation: run-space kernel (cap 512) for every read ->
-        // event-dense reads (list 1) to the cap-1024 instantiation -> (list 2) to the cap-2048
-        // one -> what is left (list 3) to the position-space kernel, sized for the longest read.
+        // Chain without host synchronisation: run-space kernel for every read (cap 512, reads of up
+        // to 16384 bases, six wavefronts per SIMD) -> the longer reads (list 0) to the cap-512
+        // instantiation for any length -> event-dense reads (list 1) to the cap-1024 instantiation
+        // -> (list 2) to the cap-2048 one -> what is left (list 3) to the position-space kernel,
+        // sized for the longest read.
         HIPCHECK(ctx->d_overflow_mid.ensure(n_reads + 1));
+        HIPCHECK(ctx->d_overflow_long.ensure(n_reads + 1));
         HIPCHECK(ctx->d_chain_cnt.ensure(4));
+        uint32_t* list0 = ctx->d_overflow_long.p;
         uint32_t* list1 = ctx->d_overflow.p;
         uint32_t* list2 = ctx->d_overflow_mid.p;
         uint32_t* list3 = ctx->d_order.p;
+        uint32_t* cnt0 = ctx->d_chain_cnt.p + 1;
         uint32_t* cnt1 = ctx->d_small.p + 4;
         uint32_t* cnt2 = ctx->d_chain_cnt.p;
         uint32_t* cnt3 = ctx->d_small.p + 5;
         HIPCHECK(hipMemsetAsync(cnt1, 0, 8, s));
-        HIPCHECK(hipMemsetAsync(cnt2, 0, 4, s));
+        HIPCHECK(hipMemsetAsync(cnt2, 0, 8, s));
         a.order = nullptr;
         a.n_items = n_reads;
         a.lw = 0;
-        launch_pile_runs(a, n_reads, 0, list1, cnt1, s);
+        launch_pile_runs(a, n_reads, 0, list0, cnt0, s);
+        a.order = list0;
+        a.n_items_dev = cnt0;
+        launch_pile_runs(a, std::min<uint32_t>(n_reads, 20480), 0, list1, cnt1, s);
         a.order = list1;
         a.n_items_dev = cnt1;
         launch_pile_runs(a, std::min<uint32_t>(n_reads, 8192), 1, list2, cnt2, s);
@@ -1819,7 +1827,7 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
         if (!in_lds) HIPCHECK(ctx->d_slab.ensure((size_t)grid * 3 * a.lw));
         a.slab = ctx->d_slab.p;
         launch_pile_build_annotate(a, grid, in_lds, s);
-        ctx->tm.pile_launches = 4;
+        ctx->tm.pile_launches = 5;
     } else {
         std::vector<uint32_t> reads(n_reads);
         std::iota(reads.begin(), reads.end(), 0u);
