@@ -73,6 +73,10 @@ void launch_pile_build_annotate(const PileArgs& args, uint32_t grid, bool in_lds
 constexpr uint32_t kRunEventCap = 512;
 constexpr uint32_t kRunEventCapMid = 1024;
 constexpr uint32_t kRunEventCapBig = 2048;
+// length classes of the pile chain: the first kernel's bitmap, the second kernel's (tier 3)
+constexpr uint32_t kPileClassBases[2] = {16384u, 32768u};
+// tier 0: cap 512 (one workgroup per read where the grid allows: reads of up to 16384 bases only),
+// 3: cap 512 for reads of up to 32768 bases, 1: cap 1024, 2: cap 2048
 void launch_pile_runs(const PileArgs& args, uint32_t grid, int tier, uint32_t* overflow_list, uint32_t* overflow_count,
                       hipStream_t stream);
 // the sensitive pass in run space (tier 0: cap 512, tier 1: cap 1024; reads of up to 16384 bases); the others are appended to

@@ -373,8 +373,14 @@ __device__ __forceinline__ void store16(const char* base, uint32_t off, const ui
 // kShort: the first kernel of the chain takes only reads of up to 16384 bases (the others go to the
 // next one): run starts in 16 bits, no sorted path, lists a little shorter - 6 656 bytes of LDS,
 // six wavefronts per SIMD instead of five.
-template <uint32_t kCap, bool kShort = false>
+// kBases: the reads the bitmap of run starts covers (one bit per position + a 16-bit prefix per word);
+// 16384 everywhere but in the chain's second kernel, the short layout for reads of up to 32768 bases
+// (9 728 bytes of LDS, four wavefronts per SIMD).
+template <uint32_t kCap, bool kShort = false, uint32_t kBases_ = 16384>
 struct Layout {
+    static constexpr uint32_t kBases = kBases_;
+    static constexpr uint32_t kBmWords = kBases / 32;
+    static constexpr uint32_t kXbitmap = kBmWords + kBmWords / 2;
     typedef typename std::conditional<kShort, uint16_t, uint32_t>::type rs_t;
     static constexpr bool kShortLayout = kShort;
     // list capacities: a read that needs more goes to the next kernel of the chain
@@ -389,7 +395,7 @@ struct Layout {
     static constexpr uint32_t kSlopeWords = (5 * kSurv + 1) / 2 + kBm8;
     // X: events (sort) -> bitmap + prefix -> group counts -> histograms -> slope survivors
     static constexpr uint32_t X = 0;
-    static constexpr uint32_t kXmin = kCap > 768 ? kCap : 768;
+    static constexpr uint32_t kXmin = kCap > kXbitmap ? kCap : kXbitmap;
     static constexpr uint32_t kX = kSlopeWords > kXmin ? kSlopeWords : kXmin;
     static constexpr uint32_t RS = X + kX;                      // run starts (+ sentinel)
     static constexpr uint32_t RV = RS + (kShort ? kArr / 2 : kArr);   // run values, uint16 (kArr / 2 words)
@@ -409,12 +415,14 @@ struct Layout {
     static constexpr uint32_t XTABLE = ((kShort ? RF : RF + 64) + 3) & ~3u;
     static_assert(kX >= kCap && kX >= kIdx && kX >= 768, "shared region too small");
     static_assert(kIdx / 2 >= 64 && SEL >= XTABLE + 256, "scratch for the noted groups of a chunk");
-    static_assert(!kShort || WORDS * 4 <= 6656, "six wavefronts per SIMD: 24 workgroups in 160 KB, 512-byte granules");
+    static_assert(kBases == 16384 || (kShort && kBases == 32768), "bitmap sizes in use");
+    static_assert(!kShort || kBases != 16384 || WORDS * 4 <= 6656, "six wavefronts per SIMD: 24 workgroups in 160 KB, 512-byte granules");
+    static_assert(!kShort || WORDS * 4 <= 10240, "four wavefronts per SIMD: 16 workgroups in 160 KB");
 };
 
 
 
-// Expansion of a pile of up to 16384 positions (2048 groups of 8 = 16 bytes) from the bitmap of
+// Expansion of a pile of up to L::kBases positions (groups of 8 = 16 bytes) from the bitmap of
 // run starts: bm (one bit per position that starts a run, bit n set for the padding behind the
 // last base), pref[w] = run starts before word w, rv = run values (rv[R] = 0).
 //
@@ -433,7 +441,7 @@ template <class L>
 __device__ __forceinline__ void expand_from_bitmap(uint32_t* sm, const uint16_t* rv, uint16_t* pile, uint64_t row_off,
                                                    uint32_t nv, uint32_t lane, bool store) {
     const uint32_t* bm = sm + L::X;
-    const uint16_t* pref = (const uint16_t*)(bm + 512);
+    const uint16_t* pref = (const uint16_t*)(bm + L::kBmWords);
     const uint16_t* rvm1 = rv - 1;                      // indexed by run + 1 (= run starts at or before)
     uint32_t* list = sm + L::XLIST;                     // the region lists are not in use yet
     uint4* table = (uint4*)(sm + L::XTABLE);            // 64 finished groups, 16-byte aligned
@@ -450,7 +458,7 @@ __device__ __forceinline__ void expand_from_bitmap(uint32_t* sm, const uint16_t*
         uint32_t bits[4], kq[4], v[4];
 #pragma unroll
         for (uint32_t u = 0; u < 4; ++u) {
-            const uint32_t w = (g0 >> 2) + 16u * u + w_lane;        // < 512 for every group below 2048
+            const uint32_t w = (g0 >> 2) + 16u * u + w_lane;        // < kBmWords for every group of the pile
             bits[u] = bm[w];
             kq[u] = pref[w];
         }
@@ -550,12 +558,14 @@ __device__ __forceinline__ void expand_from_bitmap(uint32_t* sm, const uint16_t*
 // items, so nothing is hoisted out of one and kept in registers for the whole kernel.  (A zero
 // vector hoisted that way was spilled and reloaded right behind the row stores: a scratch load, and
 // with it a wait for every one of them.)
-template <uint32_t kCap, bool kDiag, int kSens, bool kOne = false>
-__global__ __launch_bounds__(64, kOne ? 6 : 5) void pile_runs_kernel(PileArgs A, uint32_t* overflow_list, uint32_t* overflow_count) {
+// kBases > 16384: the short layout with a bigger bitmap, for the reads the first kernel handed on.
+template <uint32_t kCap, bool kDiag, int kSens, bool kOne = false, uint32_t kBases = 16384>
+__global__ __launch_bounds__(64, kOne ? 6 : kBases > 16384 ? 4 : 5) void pile_runs_kernel(PileArgs A, uint32_t* overflow_list, uint32_t* overflow_count) {
     static_assert(kSens == 0 || (kCap <= 1024 && !kDiag), "the sensitive pass runs on the bitmap path");
     static_assert(!kOne || kCap <= 512, "the short layout belongs to the first kernel of a chain");
-    constexpr bool kShort = kOne;       // reads of up to 16384 bases only, 16-bit run starts, 6 656 bytes of LDS
-    typedef Layout<kCap, kShort> L;
+    static_assert(kBases == 16384 || (!kOne && kSens == 0), "the bigger bitmap belongs to the chain's second kernel");
+    constexpr bool kShort = kOne || kBases > 16384;     // reads of up to kBases bases only, 16-bit run starts
+    typedef Layout<kCap, kShort, kBases> L;
     typedef typename L::rs_t rs_t;
     constexpr uint32_t kMaxReg = L::kMaxReg, kMaxRaw = L::kMaxRaw;
     __shared__ __align__(16) uint32_t sm[L::WORDS];
@@ -592,8 +602,11 @@ __global__ __launch_bounds__(64, kOne ? 6 : 5) void pile_runs_kernel(PileArgs A,
             given_b = A.begin[r];
             given_e = A.end[r];
         }
+        // the first kernel of the first pass: longer reads start in their own length class's kernel
+        // (pipeline.hip), no hand-over through the list
+        if (kOne && kSens == 0 && n > kBases) continue;
         // (the two region marks of the sensitive pass may add two runs)
-        if (n_ev > (kSens ? kCap - 2 : kCap) || (kSens != 0 && (n > 16384 || given_e <= given_b)) || (kShort && n > 16384)) {
+        if (n_ev > (kSens ? kCap - 2 : kCap) || (kSens != 0 && (n > 16384 || given_e <= given_b)) || (kShort && n > kBases)) {
             if (lane == 0) overflow_list[atomicAdd(overflow_count, 1u)] = r;
             continue;
         }
@@ -605,7 +618,8 @@ __global__ __launch_bounds__(64, kOne ? 6 : 5) void pile_runs_kernel(PileArgs A,
         // prefix sum over the slots gives the coverage.  Longer reads (and the big
         // instantiation) sort their events and sweep, as the reference does.
         uint32_t R;
-        constexpr uint32_t kBitmapBases = 16384;
+        constexpr uint32_t kBitmapBases = kBases;
+        constexpr uint32_t kV = L::kBmWords / 256;      // 16-byte vectors of the bitmap per lane
         const bool bitmap_path = kShort || (kCap <= 1024 && n <= kBitmapBases);
         if (bitmap_path) {
             uint32_t* bm = sm + L::X;
@@ -614,8 +628,8 @@ __global__ __launch_bounds__(64, kOne ? 6 : 5) void pile_runs_kernel(PileArgs A,
             // borrows from the neighbour (at most kCap events meet at one position)
             uint32_t* delta = sm + L::RF;
             static_assert(kCap > 1024 || L::SEL - L::RF >= L::kArr / 2 + 2, "scratch for the per-run sums");
-            ((uint4*)bm)[lane] = make_uint4(0, 0, 0, 0);
-            ((uint4*)bm)[lane + 64] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (uint32_t j = 0; j < kV; ++j) ((uint4*)bm)[lane + 64 * j] = make_uint4(0, 0, 0, 0);
             for (uint32_t k = lane; 2 * k < n_ev + 5; k += 64) delta[k] = 0x80008000u;
             // all loads first, unconditionally (clamped index), so that they are in flight together:
             // a load per predicated block would be waited for one by one
@@ -652,21 +666,28 @@ __global__ __launch_bounds__(64, kOne ? 6 : 5) void pile_runs_kernel(PileArgs A,
             wave_sync();
             RUN_STOP(41)
             {
-                const uint4 x = ((const uint4*)bm)[2 * lane], y = ((const uint4*)bm)[2 * lane + 1];
-                const uint32_t c[8] = {(uint32_t)__popc(x.x), (uint32_t)__popc(x.y), (uint32_t)__popc(x.z),
-                                       (uint32_t)__popc(x.w), (uint32_t)__popc(y.x), (uint32_t)__popc(y.y),
-                                       (uint32_t)__popc(y.z), (uint32_t)__popc(y.w)};
-                const uint32_t tot = c[0] + c[1] + c[2] + c[3] + c[4] + c[5] + c[6] + c[7];
+                // a lane owns 4 * kV consecutive words of the bitmap
+                uint32_t c[4 * kV];
+                uint32_t tot = 0;
+#pragma unroll
+                for (uint32_t j = 0; j < kV; ++j) {
+                    const uint4 x = ((const uint4*)bm)[kV * lane + j];
+                    c[4 * j] = (uint32_t)__popc(x.x); c[4 * j + 1] = (uint32_t)__popc(x.y);
+                    c[4 * j + 2] = (uint32_t)__popc(x.z); c[4 * j + 3] = (uint32_t)__popc(x.w);
+                    tot += c[4 * j] + c[4 * j + 1] + c[4 * j + 2] + c[4 * j + 3];
+                }
                 const uint32_t incl = wave_scan_incl(tot, OpAdd());
                 uint32_t run = incl - tot;
-                uint32_t pk[4];
+                uint32_t pk[2 * kV];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
+                for (uint32_t q = 0; q < 2 * kV; ++q) {
                     const uint32_t lo = run; run += c[2 * q];
                     const uint32_t hi = run; run += c[2 * q + 1];
                     pk[q] = lo | (hi << 16);
                 }
-                ((uint4*)pref)[lane] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+#pragma unroll
+                for (uint32_t j = 0; j < kV / 2; ++j)
+                    ((uint4*)pref)[(kV / 2) * lane + j] = make_uint4(pk[4 * j], pk[4 * j + 1], pk[4 * j + 2], pk[4 * j + 3]);
                 R = read_lane63(incl);
             }
             wave_sync();
@@ -899,7 +920,7 @@ __global__ __launch_bounds__(64, kOne ? 6 : 5) void pile_runs_kernel(PileArgs A,
         // belongs to a lane's 8 positions says where (if anywhere) the value changes.
         if constexpr (kSens != 2) {
             __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0), nothing else
-            constexpr uint32_t kSeg = 16384, kBmWords = kSeg / 32;
+            constexpr uint32_t kSeg = 16384, kBmWords = kSeg / 32;     // (sorted path: segments of the first size)
             uint32_t* bm = sm + L::X;
             uint16_t* pref = (uint16_t*)(bm + kBmWords);
             uint4* dst = (uint4*)(A.pile + row_off);
@@ -908,7 +929,7 @@ __global__ __launch_bounds__(64, kOne ? 6 : 5) void pile_runs_kernel(PileArgs A,
             uint32_t kbase = 0;                             // run that contains the segment's first position
             if (bitmap_path) {
                 // one more bit for the padding behind the last base: run R, value 0
-                if (lane == 0 && n < kSeg) atomicOr(&bm[n >> 5], 1u << (n & 31));
+                if (lane == 0 && n < kBases) atomicOr(&bm[n >> 5], 1u << (n & 31));
                 wave_sync();
                 expand_from_bitmap<L>(sm, rv, A.pile, row_off, nv, lane, row_stores);
                 if (kShort) index_from_bitmap();
@@ -1615,6 +1636,12 @@ void launch_pile_runs(const PileArgs& args, uint32_t grid, int tier, uint32_t* o
         if (diag) hipLaunchKernelGGL((pile_runs_kernel<kRunEventCap, true, 0, true>), dim3(grid), dim3(64), extra_lds, stream,
                                      args, overflow_list, overflow_count);
         else hipLaunchKernelGGL((pile_runs_kernel<kRunEventCap, false, 0, true>), dim3(grid), dim3(64), extra_lds, stream,
+                                args, overflow_list, overflow_count);
+    } else if (tier == 3) {
+        // reads of 16385 .. 32768 bases: the short layout with a bitmap twice the size
+        if (diag) hipLaunchKernelGGL((pile_runs_kernel<kRunEventCap, true, 0, false, 32768>), dim3(grid), dim3(64), 0, stream,
+                                     args, overflow_list, overflow_count);
+        else hipLaunchKernelGGL((pile_runs_kernel<kRunEventCap, false, 0, false, 32768>), dim3(grid), dim3(64), 0, stream,
                                 args, overflow_list, overflow_count);
     } else if (tier == 0) RALA_LAUNCH_RUNS(kRunEventCap, extra_lds);
     else if (tier == 1) RALA_LAUNCH_RUNS(kRunEventCapMid, 0);

@@ -1627,6 +1627,20 @@ int rala_hip_set_reads(rala_hip_ctx* ctx, const uint32_t* read_len, uint64_t n_r
     ctx->h_read_len.assign(read_len, read_len + n_reads);
     ctx->max_read_len = 0;
     for (uint64_t r = 0; r < n_reads; ++r) ctx->max_read_len = std::max(ctx->max_read_len, read_len[r]);
+    {
+        // length classes of the pile chain (kernels.h: kPileClassBases)
+        uint32_t cnt[3] = {0, 0, 0};
+        auto cls = [](uint32_t n) { return n <= kPileClassBases[0] ? 0 : n <= kPileClassBases[1] ? 1 : 2; };
+        for (uint64_t r = 0; r < n_reads; ++r) ++cnt[cls(read_len[r])];
+        for (int c = 0; c < 3; ++c) ctx->n_class[c] = cnt[c];
+        if (cnt[1] + cnt[2]) {
+            std::vector<uint32_t> order(n_reads);
+            uint32_t at[3] = {0, cnt[0], cnt[0] + cnt[1]};
+            for (uint64_t r = 0; r < n_reads; ++r) order[at[cls(read_len[r])]++] = (uint32_t)r;
+            HIPCHECK(ctx->d_class_order.ensure(n_reads));
+            HIPCHECK(hipMemcpy(ctx->d_class_order.p, order.data(), n_reads * 4, hipMemcpyHostToDevice));
+        }
+    }
     ctx->h_pile_off.resize(n_reads + 1);
     uint64_t off = 0;
     for (uint64_t r = 0; r < n_reads; ++r) {
@@ -1787,11 +1801,14 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
     a.pool = ctx->d_pool.p; a.pool_count = ctx->d_small.p; a.pool_cap = ctx->pool_cap; a.error = ctx->d_small.p + 1;
     a.n_items_dev = nullptr;
     if (ctx->use_run_kernel) {
-        // Chain without host synchronisation: run-space kernel for every read (cap 512, reads of up
-        // to 16384 bases, six wavefronts per SIMD) -> the longer reads (list 0) to the cap-512
-        // instantiation for any length -> event-dense reads (list 1) to the cap-1024 instantiation
-        // -> (list 2) to the cap-2048 one -> what is left (list 3) to the position-space kernel,
-        // sized for the longest read.
+        // Chain without host synchronisation.  The reads start by length class (set_reads sorted
+        // them: a hand-over through a list costs one atomic on one counter per read, 1 ms for
+        // 100 000 reads): up to 16384 bases -> run-space kernel, cap 512, six wavefronts per SIMD,
+        // one workgroup per read; up to 32768 -> the same layout with a bitmap twice the size
+        // (four wavefronts); longer ones start list 0.  What does not fit a kernel goes to its
+        // list: event-dense reads of the two first kernels join list 0 -> cap-512 instantiation
+        // for any length -> (list 1) cap 1024 -> (list 2) cap 2048 -> what is left (list 3) to the
+        // position-space kernel, sized for the longest read.
         HIPCHECK(ctx->d_overflow_mid.ensure(n_reads + 1));
         HIPCHECK(ctx->d_overflow_long.ensure(n_reads + 1));
         HIPCHECK(ctx->d_chain_cnt.ensure(4));
@@ -1803,13 +1820,27 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
         uint32_t* cnt1 = ctx->d_small.p + 4;
         uint32_t* cnt2 = ctx->d_chain_cnt.p;
         uint32_t* cnt3 = ctx->d_small.p + 5;
+        const uint32_t n_short = ctx->n_class[0], n_medium = ctx->n_class[1], n_long = ctx->n_class[2];
+        const uint32_t* by_class = n_medium + n_long ? ctx->d_class_order.p : nullptr;
+        // few longer reads: the first kernel goes over all reads without the indirection and leaves
+        // at once for a longer one
+        static const bool force_order = getenv("RALA_PILE_FORCE_ORDER") != nullptr;
+        const bool short_by_list = by_class && (force_order || (uint64_t)(n_medium + n_long) * 8 > n_reads);
         HIPCHECK(hipMemsetAsync(cnt1, 0, 8, s));
         HIPCHECK(hipMemsetAsync(cnt2, 0, 8, s));
-        a.order = nullptr;
-        a.n_items = n_reads;
+        if (n_long) {
+            HIPCHECK(hipMemcpyAsync(list0, by_class + n_short + n_medium, (size_t)n_long * 4, hipMemcpyDeviceToDevice, s));
+            HIPCHECK(hipMemsetD32Async((hipDeviceptr_t)cnt0, (int)n_long, 1, s));
+        }
         a.lw = 0;
-        launch_pile_runs(a, n_reads, 0, list0, cnt0, s);
+        a.order = short_by_list ? by_class : nullptr;
+        a.n_items = short_by_list ? n_short : n_reads;
+        launch_pile_runs(a, a.n_items, 0, list0, cnt0, s);
+        a.order = by_class ? by_class + n_short : nullptr;
+        a.n_items = n_medium;
+        launch_pile_runs(a, std::min<uint32_t>(n_medium, 16384), 3, list0, cnt0, s);
         a.order = list0;
+        a.n_items = n_reads;
         a.n_items_dev = cnt0;
         launch_pile_runs(a, std::min<uint32_t>(n_reads, 20480), 0, list1, cnt1, s);
         a.order = list1;
@@ -1827,7 +1858,7 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
         if (!in_lds) HIPCHECK(ctx->d_slab.ensure((size_t)grid * 3 * a.lw));
         a.slab = ctx->d_slab.p;
         launch_pile_build_annotate(a, grid, in_lds, s);
-        ctx->tm.pile_launches = 5;
+        ctx->tm.pile_launches = 5 + (n_medium ? 1 : 0);
     } else {
         std::vector<uint32_t> reads(n_reads);
         std::iota(reads.begin(), reads.end(), 0u);

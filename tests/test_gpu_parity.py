@@ -135,12 +135,15 @@ class _Scaled:
         self.n_reads = ds.n_reads
 
 
-@pytest.mark.parametrize("factor", [2, 7])
+@pytest.mark.parametrize("factor", [2, 3, 7])
 def test_long_reads(hip_ctx_factory, factor):
-    """Reads longer than the 16384-base position bitmap (sorted-event path of the run-space
-    kernel) and longer than 65536 bases (run starts beyond 16 bits)."""
+    """Reads longer than the first kernel's 16384-base bitmap (the chain's second kernel: 32768),
+    reads on both sides of 32768 (sorted-event path of the any-length kernel) and longer than
+    65536 bases (run starts beyond 16 bits)."""
     ds = _Scaled(Dataset(1500, 300_000, 11), factor)
-    assert ds.read_len.max() > (16384 if factor == 2 else 65536)
+    assert ds.read_len.max() > (16384 if factor == 2 else 32768 if factor == 3 else 65536)
+    if factor == 3:
+        assert ((ds.read_len > 16384) & (ds.read_len <= 32768)).sum() > 100
     st = parity.oracle_stages(ds)
     ctx = hip_ctx_factory()
     ctx.set_reads(ds.read_len)
