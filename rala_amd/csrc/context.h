@@ -79,6 +79,7 @@ struct rala_hip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t side = nullptr;         // duplicate removal runs here, beside the bucketing
+    hipStream_t aux = nullptr;          // the pile chain's small kernels (long and event-dense reads), beside the first one
     bool use_side_stream = true;
     std::string err;
     hipEvent_t ev[12] = {};
@@ -100,6 +101,7 @@ struct rala_hip_ctx {
     // pile chain.  d_class_order lists the reads class by class; empty when every read is in class 0.
     uint32_t n_class[3] = {0, 0, 0};
     rala_hip::DevBuf<uint32_t> d_class_order;
+    rala_hip::DevBuf<uint32_t> d_dense;               // reads with more events than the first kernels take (+ its counter behind)
     std::vector<uint32_t> h_read_len;
     std::vector<uint64_t> h_pile_off;
     uint64_t pile_elems = 0;

@@ -60,6 +60,9 @@ struct PileArgs {
     Interval* rep_pool = nullptr;
     uint32_t* rep_pool_count = nullptr;
     uint32_t rep_pool_cap = 0;
+    // first pass: reads with more than kRunEventCap events are listed beforehand
+    // (launch_pile_dense_list) and start in the cap-1024 kernel; the cap-512 kernels pass them over
+    uint32_t skip_dense = 0;
 };
 
 uint32_t pile_lds_bytes(uint32_t lw);
@@ -76,7 +79,8 @@ constexpr uint32_t kRunEventCapBig = 2048;
 // length classes of the pile chain: the first kernel's bitmap, the second kernel's (tier 3)
 constexpr uint32_t kPileClassBases[2] = {16384u, 32768u};
 // tier 0: cap 512 (one workgroup per read where the grid allows: reads of up to 16384 bases only),
-// 3: cap 512 for reads of up to 32768 bases, 1: cap 1024, 2: cap 2048
+// 3: cap 512 for reads of up to 32768 bases, 4: cap 512 for any length, 1: cap 1024, 2: cap 2048
+void launch_pile_dense_list(const PileArgs& args, uint32_t n_reads, uint32_t* list, uint32_t* count, hipStream_t stream);
 void launch_pile_runs(const PileArgs& args, uint32_t grid, int tier, uint32_t* overflow_list, uint32_t* overflow_count,
                       hipStream_t stream);
 // the sensitive pass in run space (tier 0: cap 512, tier 1: cap 1024; reads of up to 16384 bases); the others are appended to

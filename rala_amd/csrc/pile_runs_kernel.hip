@@ -606,6 +606,7 @@ __global__ __launch_bounds__(64, kOne ? 6 : kBases > 16384 ? 4 : 5) void pile_ru
         // (pipeline.hip), no hand-over through the list
         if (kOne && kSens == 0 && n > kBases) continue;
         // (the two region marks of the sensitive pass may add two runs)
+        if (kSens == 0 && kCap == kRunEventCap && A.skip_dense && n_ev > kCap) continue;   // listed beforehand
         if (n_ev > (kSens ? kCap - 2 : kCap) || (kSens != 0 && (n > 16384 || given_e <= given_b)) || (kShort && n > kBases)) {
             if (lane == 0) overflow_list[atomicAdd(overflow_count, 1u)] = r;
             continue;
@@ -1619,6 +1620,29 @@ __global__ __launch_bounds__(64, kOne ? 6 : kBases > 16384 ? 4 : 5) void pile_ru
 #undef RUN_STOP
 }
 
+// reads with more events than the cap-512 kernels take: listed straight from the bucket counts, so
+// that their (latency-bound) kernels run beside the first kernel and not behind it
+__global__ __launch_bounds__(256) void pile_dense_list_kernel(PileArgs A, uint32_t n_reads, uint32_t* list, uint32_t* count) {
+    const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+    bool dense = false;
+    if (r < n_reads) {
+        const uint32_t n_ev = A.ev_cnt ? umin(A.ev_cnt[r], A.ev_stride) : A.ev_off[r + 1] - A.ev_off[r];
+        dense = n_ev > kRunEventCap;
+    }
+    const uint64_t m = __builtin_amdgcn_ballot_w64(dense);
+    if (m == 0) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(count, (uint32_t)__popcll(m));
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    if (dense) list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = r;
+}
+
+void launch_pile_dense_list(const PileArgs& args, uint32_t n_reads, uint32_t* list, uint32_t* count, hipStream_t stream) {
+    if (n_reads == 0) return;
+    hipLaunchKernelGGL(pile_dense_list_kernel, dim3((n_reads + 255) / 256), dim3(256), 0, stream, args, n_reads, list, count);
+}
+
 void launch_pile_runs(const PileArgs& args, uint32_t grid, int tier, uint32_t* overflow_list, uint32_t* overflow_count,
                       hipStream_t stream) {
     if (grid == 0) return;
@@ -1643,7 +1667,7 @@ void launch_pile_runs(const PileArgs& args, uint32_t grid, int tier, uint32_t* o
                                      args, overflow_list, overflow_count);
         else hipLaunchKernelGGL((pile_runs_kernel<kRunEventCap, false, 0, false, 32768>), dim3(grid), dim3(64), 0, stream,
                                 args, overflow_list, overflow_count);
-    } else if (tier == 0) RALA_LAUNCH_RUNS(kRunEventCap, extra_lds);
+    } else if (tier == 0 || tier == 4) RALA_LAUNCH_RUNS(kRunEventCap, extra_lds);
     else if (tier == 1) RALA_LAUNCH_RUNS(kRunEventCapMid, 0);
     else RALA_LAUNCH_RUNS(kRunEventCapBig, 0);
 #undef RALA_LAUNCH_RUNS

@@ -1574,6 +1574,7 @@ int rala_hip_create(int device, rala_hip_ctx** out) {
     ctx->device = device;
     if (hipStreamCreate(&ctx->stream) != hipSuccess) { delete ctx; return RALA_HIP_EDEVICE; }
     if (hipStreamCreate(&ctx->side) != hipSuccess) { (void)hipStreamDestroy(ctx->stream); delete ctx; return RALA_HIP_EDEVICE; }
+    if (hipStreamCreate(&ctx->aux) != hipSuccess) { delete ctx; return RALA_HIP_EDEVICE; }
     for (auto& e : ctx->ev) {
         if (hipEventCreate(&e) != hipSuccess) { delete ctx; return RALA_HIP_EDEVICE; }
     }
@@ -1589,8 +1590,10 @@ void rala_hip_destroy(rala_hip_ctx* ctx) {
     ctx->stage_pending.clear();             // nobody is waiting for staged copies any more
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->side) (void)hipStreamSynchronize(ctx->side);
+    if (ctx->aux) (void)hipStreamSynchronize(ctx->aux);
     for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
     if (ctx->side) (void)hipStreamDestroy(ctx->side);
+    if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -1623,6 +1626,7 @@ int rala_hip_set_reads(rala_hip_ctx* ctx, const uint32_t* read_len, uint64_t n_r
     if (n_reads >= 0x7FFFFFFFull) return fail(ctx, RALA_HIP_EINVAL, "too many reads");
     HIPCHECK(hipSetDevice(ctx->device));
     HIPCHECK(hipStreamSynchronize(ctx->side));
+    HIPCHECK(hipStreamSynchronize(ctx->aux));
     ctx->n_reads = n_reads;
     ctx->h_read_len.assign(read_len, read_len + n_reads);
     ctx->max_read_len = 0;
@@ -1683,6 +1687,7 @@ int rala_hip_set_overlaps(rala_hip_ctx* ctx, const rala_hip_overlaps* o, uint64_
     if (n >= 0xFFFFFFF0ull / 4) return fail(ctx, RALA_HIP_EINVAL, "too many overlaps for 32-bit bound offsets");
     HIPCHECK(hipSetDevice(ctx->device));
     HIPCHECK(hipStreamSynchronize(ctx->side));          // a failed call may have left work there
+    HIPCHECK(hipStreamSynchronize(ctx->aux));
     ctx->n_ovl = n;
     const uint32_t* src[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     if (n) {
@@ -1801,48 +1806,60 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
     a.pool = ctx->d_pool.p; a.pool_count = ctx->d_small.p; a.pool_cap = ctx->pool_cap; a.error = ctx->d_small.p + 1;
     a.n_items_dev = nullptr;
     if (ctx->use_run_kernel) {
-        // Chain without host synchronisation.  The reads start by length class (set_reads sorted
-        // them: a hand-over through a list costs one atomic on one counter per read, 1 ms for
-        // 100 000 reads): up to 16384 bases -> run-space kernel, cap 512, six wavefronts per SIMD,
-        // one workgroup per read; up to 32768 -> the same layout with a bitmap twice the size
-        // (four wavefronts); longer ones start list 0.  What does not fit a kernel goes to its
-        // list: event-dense reads of the two first kernels join list 0 -> cap-512 instantiation
-        // for any length -> (list 1) cap 1024 -> (list 2) cap 2048 -> what is left (list 3) to the
-        // position-space kernel, sized for the longest read.
+        // Chain without host synchronisation.  Every read starts in the kernel that fits it, known
+        // beforehand: by length class (set_reads sorted them) and by event count (listed from the
+        // bucket counts).  A hand-over through a list behind the first kernel costs one atomic on
+        // one counter per read (1 ms for 100 000 reads) and puts the small, latency-bound kernels
+        // behind the big one (0.2 ms per C3 step); now they run beside it on a stream of their own:
+        //   main  up to 16384 bases, up to 512 events: run-space kernel, six wavefronts per SIMD,
+        //         one workgroup per read
+        //   aux   more than 512 events (dense list) -> cap 1024;  up to 32768 bases -> the short
+        //         layout with a bitmap twice the size (four wavefronts);  longer -> cap 512 for
+        //         any length
+        // What still does not fit its kernel (slope-region lists, event caps) goes to a list: of
+        // the cap-512 kernels (list 1) -> cap 1024, of those (list 2) -> cap 2048 -> what is left
+        // (list 3) to the position-space kernel, sized for the longest read.  These run on the
+        // main stream behind the join, usually over nothing.
         HIPCHECK(ctx->d_overflow_mid.ensure(n_reads + 1));
-        HIPCHECK(ctx->d_overflow_long.ensure(n_reads + 1));
-        HIPCHECK(ctx->d_chain_cnt.ensure(4));
-        uint32_t* list0 = ctx->d_overflow_long.p;
+        HIPCHECK(ctx->d_dense.ensure(n_reads + 1));
+        uint32_t* list_dense = ctx->d_dense.p;
         uint32_t* list1 = ctx->d_overflow.p;
         uint32_t* list2 = ctx->d_overflow_mid.p;
         uint32_t* list3 = ctx->d_order.p;
-        uint32_t* cnt0 = ctx->d_chain_cnt.p + 1;
+        // (all four zeroed with d_small at the top of this call)
+        uint32_t* cnt_dense = ctx->d_small.p + 3;
         uint32_t* cnt1 = ctx->d_small.p + 4;
-        uint32_t* cnt2 = ctx->d_chain_cnt.p;
+        uint32_t* cnt2 = ctx->d_small.p + 2;
         uint32_t* cnt3 = ctx->d_small.p + 5;
         const uint32_t n_short = ctx->n_class[0], n_medium = ctx->n_class[1], n_long = ctx->n_class[2];
         const uint32_t* by_class = n_medium + n_long ? ctx->d_class_order.p : nullptr;
-        // few longer reads: the first kernel goes over all reads without the indirection and leaves
-        // at once for a longer one
+        // few longer reads: the first kernel goes over all reads without the indirection (2 % at C3)
+        // and leaves at once for a longer one
         static const bool force_order = getenv("RALA_PILE_FORCE_ORDER") != nullptr;
         const bool short_by_list = by_class && (force_order || (uint64_t)(n_medium + n_long) * 8 > n_reads);
-        HIPCHECK(hipMemsetAsync(cnt1, 0, 8, s));
-        HIPCHECK(hipMemsetAsync(cnt2, 0, 8, s));
-        if (n_long) {
-            HIPCHECK(hipMemcpyAsync(list0, by_class + n_short + n_medium, (size_t)n_long * 4, hipMemcpyDeviceToDevice, s));
-            HIPCHECK(hipMemsetD32Async((hipDeviceptr_t)cnt0, (int)n_long, 1, s));
-        }
+        static const bool no_aux = getenv("RALA_PILE_NO_AUX") != nullptr;       // measurements: everything on one stream
+        hipStream_t aux = ctx->use_side_stream && !no_aux ? ctx->aux : s;
+        if (aux != s) HIPCHECK(hipStreamWaitEvent(aux, ctx->ev[2], 0));
         a.lw = 0;
-        a.order = short_by_list ? by_class : nullptr;
-        a.n_items = short_by_list ? n_short : n_reads;
-        launch_pile_runs(a, a.n_items, 0, list0, cnt0, s);
+        a.skip_dense = 1;
+        launch_pile_dense_list(a, n_reads, list_dense, cnt_dense, aux);
+        a.order = list_dense;
+        a.n_items = n_reads;
+        a.n_items_dev = cnt_dense;
+        launch_pile_runs(a, std::min<uint32_t>(n_reads, 8192), 1, list2, cnt2, aux);
+        a.n_items_dev = nullptr;
         a.order = by_class ? by_class + n_short : nullptr;
         a.n_items = n_medium;
-        launch_pile_runs(a, std::min<uint32_t>(n_medium, 16384), 3, list0, cnt0, s);
-        a.order = list0;
+        launch_pile_runs(a, std::min<uint32_t>(n_medium, 16384), 3, list1, cnt1, aux);
+        a.order = by_class ? by_class + n_short + n_medium : nullptr;
+        a.n_items = n_long;
+        launch_pile_runs(a, std::min<uint32_t>(n_long, 20480), 4, list1, cnt1, aux);
+        if (aux != s) HIPCHECK(hipEventRecord(ctx->ev[8], aux));
+        a.order = short_by_list ? by_class : nullptr;
+        a.n_items = short_by_list ? n_short : n_reads;
+        launch_pile_runs(a, a.n_items, 0, list1, cnt1, s);
+        if (aux != s) HIPCHECK(hipStreamWaitEvent(s, ctx->ev[8], 0));
         a.n_items = n_reads;
-        a.n_items_dev = cnt0;
-        launch_pile_runs(a, std::min<uint32_t>(n_reads, 20480), 0, list1, cnt1, s);
         a.order = list1;
         a.n_items_dev = cnt1;
         launch_pile_runs(a, std::min<uint32_t>(n_reads, 8192), 1, list2, cnt2, s);
@@ -1858,7 +1875,7 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
         if (!in_lds) HIPCHECK(ctx->d_slab.ensure((size_t)grid * 3 * a.lw));
         a.slab = ctx->d_slab.p;
         launch_pile_build_annotate(a, grid, in_lds, s);
-        ctx->tm.pile_launches = 5 + (n_medium ? 1 : 0);
+        ctx->tm.pile_launches = 5 + (n_medium ? 1 : 0) + (n_long ? 1 : 0);
     } else {
         std::vector<uint32_t> reads(n_reads);
         std::iota(reads.begin(), reads.end(), 0u);
@@ -1888,7 +1905,7 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
     }
     ctx->host_state_fresh = false;
     ctx->pool_used = std::min(small[0], ctx->pool_cap);
-    ctx->tm.pile_overflow_reads = small[4];
+    ctx->tm.pile_overflow_reads = ctx->use_run_kernel ? small[3] + small[4] : 0;      // event-dense + handed on
     ctx->tm.pile_position_reads = ctx->use_run_kernel ? small[5] : n_reads;
     // dedupe_ms: what duplicate removal adds to the critical path (it runs beside the bucketing
     // and the pile kernels; the main stream joins it after them)

@@ -2,7 +2,7 @@
 T0=$(date +%s); lap() { T1=$(date +%s); echo "[$1: $((T1 - T0)) s]"; T0=$T1; }
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-python -m pytest tests/ -x -q -m gpu 2>&1 | tail -3
+python -m pytest tests/ -x -q -m gpu > gpurun_out/driver_pytest.log 2>&1; grep -E "passed|failed|error" gpurun_out/driver_pytest.log | tail -3
 lap "pytest gpu"
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
 lap "smoke"
