@@ -80,7 +80,8 @@ const char* rala_hip_last_error(const rala_hip_ctx* ctx);
  * position-space kernel), "use_gpu_tail" (default 1; 0 runs the chimera stage of
  * Graph::preprocess on the host), "use_fixed_buckets" (default 1; 0 always buckets the bounds
  * through the exact count / scan / scatter path), "use_side_stream" (default 1; 0 runs duplicate
- * removal on the main stream before the bucketing), "sensitive_in_device_memory" (default 0; 1 = the
+ * removal on the main stream before the bucketing and the pile chain's small kernels - event-dense
+ * and longer reads - before its first one instead of beside it), "sensitive_in_device_memory" (default 0; 1 = the
  * sensitive overlaps handed to rala_hip_construct are device pointers), "host_threads",
  * "use_round_batches" (default 1; 0 makes the host look at the killer list after every round of the
  * containment fixed point instead of enqueuing five rounds per look once the list is short),

@@ -97,9 +97,9 @@ struct rala_hip_ctx {
     // reads
     uint64_t n_reads = 0;
     uint32_t max_read_len = 0;
-    // reads by length class (<= 16384, <= 32768, longer): each class has its own first kernel in the
+    // reads by length class (kernels.h: kPileClassBases): each class has its own first kernel in the
     // pile chain.  d_class_order lists the reads class by class; empty when every read is in class 0.
-    uint32_t n_class[3] = {0, 0, 0};
+    uint32_t n_class[rala_hip::kPileClasses] = {};
     rala_hip::DevBuf<uint32_t> d_class_order;
     rala_hip::DevBuf<uint32_t> d_dense;               // reads with more events than the first kernels take (+ its counter behind)
     std::vector<uint32_t> h_read_len;

@@ -76,8 +76,11 @@ void launch_pile_build_annotate(const PileArgs& args, uint32_t grid, bool in_lds
 constexpr uint32_t kRunEventCap = 512;
 constexpr uint32_t kRunEventCapMid = 1024;
 constexpr uint32_t kRunEventCapBig = 2048;
-// length classes of the pile chain: the first kernel's bitmap, the second kernel's (tier 3)
-constexpr uint32_t kPileClassBases[2] = {16384u, 32768u};
+// length classes of the pile chain: the first kernel's bitmap, the second's (tier 3); longer reads
+// take the cap-512 kernel for any length.  (A third bitmap class, up to 65535 bases at two and a
+// half wavefronts per SIMD, was 3 % faster than that kernel on 50 kb reads - not kept.)
+constexpr uint32_t kPileClasses = 3;
+constexpr uint32_t kPileClassBases[kPileClasses - 1] = {16384u, 32768u};
 // tier 0: cap 512 (one workgroup per read where the grid allows: reads of up to 16384 bases only),
 // 3: cap 512 for reads of up to 32768 bases, 4: cap 512 for any length, 1: cap 1024, 2: cap 2048
 void launch_pile_dense_list(const PileArgs& args, uint32_t n_reads, uint32_t* list, uint32_t* count, hipStream_t stream);

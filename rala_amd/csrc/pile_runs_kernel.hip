@@ -415,9 +415,10 @@ struct Layout {
     static constexpr uint32_t XTABLE = ((kShort ? RF : RF + 64) + 3) & ~3u;
     static_assert(kX >= kCap && kX >= kIdx && kX >= 768, "shared region too small");
     static_assert(kIdx / 2 >= 64 && SEL >= XTABLE + 256, "scratch for the noted groups of a chunk");
-    static_assert(kBases == 16384 || (kShort && kBases == 32768), "bitmap sizes in use");
+    static_assert(kBases == 16384 || (kShort && (kBases == 32768 || kBases == 65536)), "bitmap sizes in use");
     static_assert(!kShort || kBases != 16384 || WORDS * 4 <= 6656, "six wavefronts per SIMD: 24 workgroups in 160 KB, 512-byte granules");
-    static_assert(!kShort || WORDS * 4 <= 10240, "four wavefronts per SIMD: 16 workgroups in 160 KB");
+    static_assert(!kShort || kBases > 32768 || WORDS * 4 <= 10240, "four wavefronts per SIMD: 16 workgroups in 160 KB");
+    static_assert(!kShort || WORDS * 4 <= 16384, "ten workgroups in 160 KB");
 };
 
 
@@ -560,11 +561,12 @@ __device__ __forceinline__ void expand_from_bitmap(uint32_t* sm, const uint16_t*
 // with it a wait for every one of them.)
 // kBases > 16384: the short layout with a bigger bitmap, for the reads the first kernel handed on.
 template <uint32_t kCap, bool kDiag, int kSens, bool kOne = false, uint32_t kBases = 16384>
-__global__ __launch_bounds__(64, kOne ? 6 : kBases > 16384 ? 4 : 5) void pile_runs_kernel(PileArgs A, uint32_t* overflow_list, uint32_t* overflow_count) {
+__global__ __launch_bounds__(64, kOne ? 6 : kBases > 32768 ? 2 : kBases > 16384 ? 4 : 5) void pile_runs_kernel(PileArgs A, uint32_t* overflow_list, uint32_t* overflow_count) {
     static_assert(kSens == 0 || (kCap <= 1024 && !kDiag), "the sensitive pass runs on the bitmap path");
     static_assert(!kOne || kCap <= 512, "the short layout belongs to the first kernel of a chain");
     static_assert(kBases == 16384 || (!kOne && kSens == 0), "the bigger bitmap belongs to the chain's second kernel");
     constexpr bool kShort = kOne || kBases > 16384;     // reads of up to kBases bases only, 16-bit run starts
+    constexpr uint32_t kMaxBases = kBases > 65535 ? 65535 : kBases;     // rs[R] = n in 16 bits
     typedef Layout<kCap, kShort, kBases> L;
     typedef typename L::rs_t rs_t;
     constexpr uint32_t kMaxReg = L::kMaxReg, kMaxRaw = L::kMaxRaw;
@@ -604,10 +606,10 @@ __global__ __launch_bounds__(64, kOne ? 6 : kBases > 16384 ? 4 : 5) void pile_ru
         }
         // the first kernel of the first pass: longer reads start in their own length class's kernel
         // (pipeline.hip), no hand-over through the list
-        if (kOne && kSens == 0 && n > kBases) continue;
+        if (kOne && kSens == 0 && n > kMaxBases) continue;
         // (the two region marks of the sensitive pass may add two runs)
         if (kSens == 0 && kCap == kRunEventCap && A.skip_dense && n_ev > kCap) continue;   // listed beforehand
-        if (n_ev > (kSens ? kCap - 2 : kCap) || (kSens != 0 && (n > 16384 || given_e <= given_b)) || (kShort && n > kBases)) {
+        if (n_ev > (kSens ? kCap - 2 : kCap) || (kSens != 0 && (n > 16384 || given_e <= given_b)) || (kShort && n > kMaxBases)) {
             if (lane == 0) overflow_list[atomicAdd(overflow_count, 1u)] = r;
             continue;
         }

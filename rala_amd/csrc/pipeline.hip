@@ -1633,13 +1633,18 @@ int rala_hip_set_reads(rala_hip_ctx* ctx, const uint32_t* read_len, uint64_t n_r
     for (uint64_t r = 0; r < n_reads; ++r) ctx->max_read_len = std::max(ctx->max_read_len, read_len[r]);
     {
         // length classes of the pile chain (kernels.h: kPileClassBases)
-        uint32_t cnt[3] = {0, 0, 0};
-        auto cls = [](uint32_t n) { return n <= kPileClassBases[0] ? 0 : n <= kPileClassBases[1] ? 1 : 2; };
+        uint32_t cnt[kPileClasses] = {};
+        auto cls = [](uint32_t n) {
+            uint32_t c = 0;
+            while (c + 1 < kPileClasses && n > kPileClassBases[c]) ++c;
+            return c;
+        };
         for (uint64_t r = 0; r < n_reads; ++r) ++cnt[cls(read_len[r])];
-        for (int c = 0; c < 3; ++c) ctx->n_class[c] = cnt[c];
-        if (cnt[1] + cnt[2]) {
+        for (uint32_t c = 0; c < kPileClasses; ++c) ctx->n_class[c] = cnt[c];
+        if (cnt[0] != n_reads) {
             std::vector<uint32_t> order(n_reads);
-            uint32_t at[3] = {0, cnt[0], cnt[0] + cnt[1]};
+            uint32_t at[kPileClasses] = {};
+            for (uint32_t c = 1; c < kPileClasses; ++c) at[c] = at[c - 1] + cnt[c - 1];
             for (uint64_t r = 0; r < n_reads; ++r) order[at[cls(read_len[r])]++] = (uint32_t)r;
             HIPCHECK(ctx->d_class_order.ensure(n_reads));
             HIPCHECK(hipMemcpy(ctx->d_class_order.p, order.data(), n_reads * 4, hipMemcpyHostToDevice));
@@ -1814,8 +1819,8 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
         //   main  up to 16384 bases, up to 512 events: run-space kernel, six wavefronts per SIMD,
         //         one workgroup per read
         //   aux   more than 512 events (dense list) -> cap 1024;  up to 32768 bases -> the short
-        //         layout with a bitmap twice the size (four wavefronts);  longer -> cap 512 for
-        //         any length
+        //         layout with a bitmap twice the size (four wavefronts per SIMD, 9 % faster on
+        //         20 kb reads than what follows);  longer -> cap 512 for any length (sorted events)
         // What still does not fit its kernel (slope-region lists, event caps) goes to a list: of
         // the cap-512 kernels (list 1) -> cap 1024, of those (list 2) -> cap 2048 -> what is left
         // (list 3) to the position-space kernel, sized for the longest read.  These run on the
@@ -1832,11 +1837,11 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
         uint32_t* cnt2 = ctx->d_small.p + 2;
         uint32_t* cnt3 = ctx->d_small.p + 5;
         const uint32_t n_short = ctx->n_class[0], n_medium = ctx->n_class[1], n_long = ctx->n_class[2];
-        const uint32_t* by_class = n_medium + n_long ? ctx->d_class_order.p : nullptr;
+        const uint32_t* by_class = n_short != n_reads ? ctx->d_class_order.p : nullptr;
         // few longer reads: the first kernel goes over all reads without the indirection (2 % at C3)
         // and leaves at once for a longer one
         static const bool force_order = getenv("RALA_PILE_FORCE_ORDER") != nullptr;
-        const bool short_by_list = by_class && (force_order || (uint64_t)(n_medium + n_long) * 8 > n_reads);
+        const bool short_by_list = by_class && (force_order || (uint64_t)(n_reads - n_short) * 8 > n_reads);
         static const bool no_aux = getenv("RALA_PILE_NO_AUX") != nullptr;       // measurements: everything on one stream
         hipStream_t aux = ctx->use_side_stream && !no_aux ? ctx->aux : s;
         if (aux != s) HIPCHECK(hipStreamWaitEvent(aux, ctx->ev[2], 0));
@@ -1850,7 +1855,9 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
         a.n_items_dev = nullptr;
         a.order = by_class ? by_class + n_short : nullptr;
         a.n_items = n_medium;
-        launch_pile_runs(a, std::min<uint32_t>(n_medium, 16384), 3, list1, cnt1, aux);
+        // (measurements: RALA_PILE_ANYLEN_FROM=1 sends this class to the any-length kernel, too)
+        static const int anylen_from = getenv("RALA_PILE_ANYLEN_FROM") ? atoi(getenv("RALA_PILE_ANYLEN_FROM")) : 3;
+        launch_pile_runs(a, std::min<uint32_t>(n_medium, 16384), anylen_from <= 1 ? 4 : 3, list1, cnt1, aux);
         a.order = by_class ? by_class + n_short + n_medium : nullptr;
         a.n_items = n_long;
         launch_pile_runs(a, std::min<uint32_t>(n_long, 20480), 4, list1, cnt1, aux);

@@ -135,13 +135,15 @@ class _Scaled:
         self.n_reads = ds.n_reads
 
 
-@pytest.mark.parametrize("factor", [2, 3, 7])
+@pytest.mark.parametrize("factor", [2, 3, 5, 7])
 def test_long_reads(hip_ctx_factory, factor):
-    """Reads longer than the first kernel's 16384-base bitmap (the chain's second kernel: 32768),
-    reads on both sides of 32768 (sorted-event path of the any-length kernel) and longer than
-    65536 bases (run starts beyond 16 bits)."""
+    """Reads longer than the first kernel's 16384-base bitmap (the length classes' own kernels:
+    up to 32768, up to 65535), reads on both sides of 32768, and longer than 65536 bases (run
+    starts beyond 16 bits: sorted-event path of the any-length kernel)."""
     ds = _Scaled(Dataset(1500, 300_000, 11), factor)
-    assert ds.read_len.max() > (16384 if factor == 2 else 32768 if factor == 3 else 65536)
+    assert ds.read_len.max() > {2: 16384, 3: 32768, 5: 32768, 7: 65536}[factor]
+    if factor == 5:
+        assert ((ds.read_len > 32768) & (ds.read_len <= 65535)).sum() > 1000
     if factor == 3:
         assert ((ds.read_len > 16384) & (ds.read_len <= 32768)).sum() > 100
     st = parity.oracle_stages(ds)

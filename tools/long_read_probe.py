@@ -10,7 +10,7 @@ from rala_amd import hip
 from rala_amd.synth import Dataset, Overlaps, FIELDS
 
 ds = Dataset.config("c2")
-for factor in ([int(a) for a in sys.argv[1:]] or [1, 2]):
+for factor in ([int(a) for a in sys.argv[1:]] or [1, 2, 5, 8]):
     ov = ds.overlaps
     kw = {f: getattr(ov, f) for f in FIELDS}
     for f in ("a_begin", "a_end", "b_begin", "b_end", "length"):
