@@ -200,7 +200,9 @@ void launch_classify(const OvlSoA& o, uint32_t n_reads, const uint8_t* valid, co
 void launch_death_lower(const KillList& kl, uint32_t* lo, hipStream_t s);
 void launch_death_decide(const KillList& in, const uint32_t* lo, const uint32_t* up, uint32_t* sure, const KillList& out,
                          hipStream_t s);
-void launch_death_diff(const uint32_t* a, const uint32_t* b, uint32_t n, uint32_t* changed, hipStream_t s);
+// *changed = 1 if the two differ anywhere; `older` is then filled with 0xFFFFFFFF (the next round's output)
+void launch_death_diff(uint32_t* older, const uint32_t* newer, uint32_t n, uint32_t* changed, hipStream_t s);
+void launch_death_tighten(const uint32_t* sure, uint32_t* up, uint32_t* lo, uint32_t n, hipStream_t s);
 void launch_finish_pass2(const OvlSoA& o, uint8_t* cls, const uint32_t* death, const uint4* rec, Interval* pool,
                          uint32_t* chunk_ov, uint32_t* chunk_in, hipStream_t s);
 void launch_apply_death(const uint32_t* death, uint8_t* alive, uint32_t n_reads, hipStream_t s);

@@ -469,12 +469,27 @@ __global__ __launch_bounds__(kBlock) void death_decide_kernel(KillList in, const
     }
 }
 
-__global__ __launch_bounds__(kBlock) void death_diff_kernel(const uint32_t* __restrict__ x,
+// (x is the older of the two: it becomes the next round's output and is reset for it here - one
+// launch instead of a fill per round)
+__global__ __launch_bounds__(kBlock) void death_diff_kernel(uint32_t* __restrict__ x,
                                                             const uint32_t* __restrict__ y, uint32_t n,
                                                             uint32_t* changed) {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    const bool d = i < n && x[i] != y[i];
+    if (i >= n) return;
+    const bool d = x[i] != y[i];
+    x[i] = 0xFFFFFFFFu;
     if (d) *changed = 1u;       // benign race: every writer stores the same value
+}
+
+// bounds for the next round of the containment fixed point: up = lo = sure (one pass instead of
+// two device-to-device copies)
+__global__ __launch_bounds__(kBlock) void death_tighten_kernel(const uint32_t* __restrict__ sure, uint32_t* __restrict__ up,
+                                                               uint32_t* __restrict__ lo, uint32_t n) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t v = sure[i];
+    up[i] = v;
+    lo[i] = v;
 }
 
 // Liveness, hill span counters (Pile::check_chimeric_hills, pile.cpp:457-469,
@@ -711,8 +726,11 @@ void launch_death_decide(const KillList& in, const uint32_t* lo, const uint32_t*
                          hipStream_t s) {
     hipLaunchKernelGGL(death_decide_kernel, dim3(4096), dim3(kBlock), 0, s, in, lo, up, sure, out);
 }
-void launch_death_diff(const uint32_t* a, const uint32_t* b, uint32_t n, uint32_t* changed, hipStream_t s) {
-    if (n) hipLaunchKernelGGL(death_diff_kernel, grid_for(n), dim3(kBlock), 0, s, a, b, n, changed);
+void launch_death_diff(uint32_t* older, const uint32_t* newer, uint32_t n, uint32_t* changed, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(death_diff_kernel, grid_for(n), dim3(kBlock), 0, s, older, newer, n, changed);
+}
+void launch_death_tighten(const uint32_t* sure, uint32_t* up, uint32_t* lo, uint32_t n, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(death_tighten_kernel, grid_for(n), dim3(kBlock), 0, s, sure, up, lo, n);
 }
 void launch_finish_pass2(const OvlSoA& o, uint8_t* cls, const uint32_t* death, const uint4* rec, Interval* pool,
                          uint32_t* chunk_ov, uint32_t* chunk_in, hipStream_t s) {

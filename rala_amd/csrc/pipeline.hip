@@ -1031,12 +1031,13 @@ int tail_death_scan(rala_hip_ctx* ctx, const TailList& L, uint32_t which, uint32
     const uint32_t n_reads = (uint32_t)ctx->n_reads;
     int cur = 0;
     HIPCHECK(hipMemsetAsync(ctx->d_t_death[0].p, 0xFF, (size_t)n_reads * 4, s));
+    HIPCHECK(hipMemsetAsync(ctx->d_t_death[1].p, 0xFF, (size_t)n_reads * 4, s));
     HIPCHECK(ctx->d_cc_flags.ensure(8));
     for (int round = 0;; ++round) {
         constexpr int kBatch = 3;
         HIPCHECK(hipMemsetAsync(ctx->d_cc_flags.p, 0, kBatch * 4, s));
         for (int k = 0; k < kBatch; ++k) {
-            HIPCHECK(hipMemsetAsync(ctx->d_t_death[cur ^ 1].p, 0xFF, (size_t)n_reads * 4, s));
+            // (the round's output buffer is all ones: filled above, then by the diff kernel)
             launch_tail_death_round(L, ctx->d_alive.p, which, ctx->d_t_death[cur].p, ctx->d_t_death[cur ^ 1].p, s);
             launch_death_diff(ctx->d_t_death[cur].p, ctx->d_t_death[cur ^ 1].p, n_reads, ctx->d_cc_flags.p + k, s);
             cur ^= 1;
@@ -1298,11 +1299,13 @@ int pass2(rala_hip_ctx* ctx, Comm* comm) {
 
     // ---- static part ----
     for (int k = 0; k < 3; ++k) HIPCHECK(ctx->d_kill[k].ensure(N + 1));
-    HIPCHECK(ctx->d_kill_count.ensure(4));
+    // the killer lists' counters: a fresh, pre-zeroed one per round of the fixed point
+    constexpr uint32_t kCountRing = 128;
+    HIPCHECK(ctx->d_kill_count.ensure(kCountRing + 4));
     KillList kl;
     kl.count = ctx->d_kill_count.p; kl.ovl = ctx->d_kill[0].p; kl.target = ctx->d_kill[1].p; kl.keeper = ctx->d_kill[2].p;
     HIPCHECK(hipEventRecord(ctx->ev[4], s));
-    HIPCHECK(hipMemsetAsync(kl.count, 0, 4, s));
+    HIPCHECK(hipMemsetAsync(ctx->d_kill_count.p, 0, (kCountRing + 4) * 4, s));
     HIPCHECK(ctx->d_rec.ensure(n_reads));
     launch_pack_reads(rs, n_reads, ctx->d_rec.p, s);
     launch_classify(ctx->ovl, n_reads, ctx->d_valid.p, ctx->d_rec.p, ctx->d_cls.p, kl, s);
@@ -1314,7 +1317,7 @@ int pass2(rala_hip_ctx* ctx, Comm* comm) {
     for (int k = 0; k < 3; ++k) HIPCHECK(ctx->d_kill2[k].ensure(N + 1));
     HIPCHECK(ctx->d_death_sure.ensure(2 * (size_t)n_reads + 8));
     KillList klist[2] = {kl, kl};
-    klist[1].count = ctx->d_kill_count.p + 1;
+    uint32_t next_count = 1;
     klist[1].ovl = ctx->d_kill2[0].p; klist[1].target = ctx->d_kill2[1].p; klist[1].keeper = ctx->d_kill2[2].p;
     uint32_t* sure = ctx->d_death_sure.p;
     uint32_t* lo = sure + n_reads;
@@ -1338,7 +1341,12 @@ int pass2(rala_hip_ctx* ctx, Comm* comm) {
     std::vector<uint32_t> list_size;                             // after every round; kNotSeen = in the log
     uint32_t unseen = 0, n_logged = 0;
     for (;;) {
-        HIPCHECK(hipMemsetAsync(klist[cur ^ 1].count, 0, 4, s));
+        if (next_count < kCountRing) {
+            klist[cur ^ 1].count = ctx->d_kill_count.p + next_count++;
+        } else {
+            klist[cur ^ 1].count = ctx->d_kill_count.p + kCountRing + (cur ^ 1);
+            HIPCHECK(hipMemsetAsync(klist[cur ^ 1].count, 0, 4, s));
+        }
         launch_death_decide(klist[cur], lo, up, sure, klist[cur ^ 1], s);
         cur ^= 1;
         // tighter bounds for the next round: up = sure, lo = min(sure, undecided killers)
@@ -1347,8 +1355,7 @@ int pass2(rala_hip_ctx* ctx, Comm* comm) {
             --unseen;
             launch_death_status(klist[cur].count, ctx->d_round_log.p + n_logged++, s);
             list_size.push_back(kNotSeen);
-            HIPCHECK(hipMemcpyAsync(up, sure, dbytes, hipMemcpyDeviceToDevice, s));
-            HIPCHECK(hipMemcpyAsync(lo, sure, dbytes, hipMemcpyDeviceToDevice, s));
+            launch_death_tighten(sure, up, lo, n_reads, s);
             launch_death_lower(klist[cur], lo, s);
             continue;
         }
@@ -1369,9 +1376,9 @@ int pass2(rala_hip_ctx* ctx, Comm* comm) {
         if (getenv("RALA_HIP_TRACE")) fprintf(stderr, "[trace] containment round %d: %u undecided\n", (int)list_size.size(), undecided);
         if (undecided == 0) break;
         if (list_size.size() > 100000) return fail(ctx, RALA_HIP_EDEVICE, "containment fixed point did not converge");
-        HIPCHECK(hipMemcpyAsync(up, sure, dbytes, hipMemcpyDeviceToDevice, s));
+        if (!gathered) HIPCHECK(hipMemcpyAsync(up, sure, dbytes, hipMemcpyDeviceToDevice, s));
         if (gathered) {
-            HIPCHECK(hipMemcpyAsync(lo, sure, dbytes, hipMemcpyDeviceToDevice, s));
+            launch_death_tighten(sure, up, lo, n_reads, s);
             launch_death_lower(klist[cur], lo, s);
             if (undecided <= kFewKillers && ctx->use_round_batches) unseen = kRoundsPerLook;
         } else if ((uint64_t)undecided * comm->world() <= (1u << 16)) {
@@ -1766,12 +1773,13 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
         HIPCHECK(ctx->d_ev_fixed.ensure((size_t)n_reads * slot + 8));
         HIPCHECK(ctx->d_cc_flags.ensure(8));
         HIPCHECK(hipMemsetAsync(ctx->d_cursor.p, 0, (size_t)(n_reads + 1) * 4, s));
-        HIPCHECK(hipMemsetAsync(ctx->d_cc_flags.p + 5, 0, 4, s));
+        // (the slot-overflow flag and the count of dead reads below live in d_small, zeroed above and
+        // fetched in one copy with the other results)
         if (ctx->tuple_mode) {
             launch_bucket_fixed_tuples(ctx->tuples, ctx->n_tuples, n_reads, slot, ctx->d_cursor.p,
-                                       ctx->d_ev_fixed.p, ctx->d_cc_flags.p + 5, s);
+                                       ctx->d_ev_fixed.p, ctx->d_small.p + 6, s);
         } else {
-            launch_bucket_fixed(ctx->ovl, n_reads, slot, ctx->d_cursor.p, ctx->d_ev_fixed.p, ctx->d_cc_flags.p + 5, s);
+            launch_bucket_fixed(ctx->ovl, n_reads, slot, ctx->d_cursor.p, ctx->d_ev_fixed.p, ctx->d_small.p + 6, s);
         }
         // the overflow flag is read together with the other results at the end of this call; a
         // set flag repeats the call on the exact path (no host round trip in the common case)
@@ -1894,14 +1902,11 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
     if (forked) HIPCHECK(hipStreamWaitEvent(s, ctx->ev[1], 0));
 
     // the per-read results stay on the device; host mirrors are fetched by the first getter
-    HIPCHECK(ctx->d_cc_flags.ensure(8));
-    HIPCHECK(hipMemsetAsync(ctx->d_cc_flags.p + 6, 0, 4, s));
-    launch_count_zero_u8(ctx->d_alive.p, n_reads, ctx->d_cc_flags.p + 6, s);
-    uint32_t small[8], n_dead = 0, slot_overflow = 0;
+    launch_count_zero_u8(ctx->d_alive.p, n_reads, ctx->d_small.p + 7, s);
+    uint32_t small[8];
     HIPCHECK(d2h_small(ctx, small, ctx->d_small.p, sizeof(small), s));
-    HIPCHECK(d2h_small(ctx, &n_dead, ctx->d_cc_flags.p + 6, 4, s));
-    if (fixed) HIPCHECK(d2h_small(ctx, &slot_overflow, ctx->d_cc_flags.p + 5, 4, s));
     HIPCHECK(stream_sync(ctx, s));
+    const uint32_t n_dead = small[7], slot_overflow = fixed ? small[6] : 0;
     if (slot_overflow) {
         // some read has more events than a fixed slot holds: once more, through the exact path
         const int64_t keep = ctx->use_fixed_buckets;
