@@ -564,7 +564,7 @@ template <uint32_t kCap, bool kDiag, int kSens, bool kOne = false, uint32_t kBas
 __global__ __launch_bounds__(64, kOne ? 6 : kBases > 32768 ? 2 : kBases > 16384 ? 4 : 5) void pile_runs_kernel(PileArgs A, uint32_t* overflow_list, uint32_t* overflow_count) {
     static_assert(kSens == 0 || (kCap <= 1024 && !kDiag), "the sensitive pass runs on the bitmap path");
     static_assert(!kOne || kCap <= 512, "the short layout belongs to the first kernel of a chain");
-    static_assert(kBases == 16384 || (!kOne && kSens == 0), "the bigger bitmap belongs to the chain's second kernel");
+    static_assert(kBases == 16384 || !kOne, "the bigger bitmap belongs to the chain's second kernel");
     constexpr bool kShort = kOne || kBases > 16384;     // reads of up to kBases bases only, 16-bit run starts
     constexpr uint32_t kMaxBases = kBases > 65535 ? 65535 : kBases;     // rs[R] = n in 16 bits
     typedef Layout<kCap, kShort, kBases> L;
@@ -609,7 +609,7 @@ __global__ __launch_bounds__(64, kOne ? 6 : kBases > 32768 ? 2 : kBases > 16384 
         if (kOne && kSens == 0 && n > kMaxBases) continue;
         // (the two region marks of the sensitive pass may add two runs)
         if (kSens == 0 && kCap == kRunEventCap && A.skip_dense && n_ev > kCap) continue;   // listed beforehand
-        if (n_ev > (kSens ? kCap - 2 : kCap) || (kSens != 0 && (n > 16384 || given_e <= given_b)) || (kShort && n > kMaxBases)) {
+        if (n_ev > (kSens ? kCap - 2 : kCap) || (kSens != 0 && (n > kMaxBases || given_e <= given_b)) || (kShort && n > kMaxBases)) {
             if (lane == 0) overflow_list[atomicAdd(overflow_count, 1u)] = r;
             continue;
         }
@@ -1686,6 +1686,12 @@ void launch_pile_sens(const PileArgs& args, uint32_t grid, int tier, int mode, u
         if (mode == 1) hipLaunchKernelGGL((pile_runs_kernel<kRunEventCap, false, 1, true>), dim3(grid), dim3(64), 0, stream, args,
                                           overflow_list, overflow_count);
         else hipLaunchKernelGGL((pile_runs_kernel<kRunEventCap, false, 2, true>), dim3(grid), dim3(64), 0, stream, args,
+                                overflow_list, overflow_count);
+    } else if (tier == 3) {
+        // reads of up to 32768 bases: the short layout with the bigger bitmap, as in the first pass
+        if (mode == 1) hipLaunchKernelGGL((pile_runs_kernel<kRunEventCap, false, 1, false, 32768>), dim3(grid), dim3(64), 0, stream,
+                                          args, overflow_list, overflow_count);
+        else hipLaunchKernelGGL((pile_runs_kernel<kRunEventCap, false, 2, false, 32768>), dim3(grid), dim3(64), 0, stream, args,
                                 overflow_list, overflow_count);
     } else if (tier == 0) {
         if (mode == 1) RALA_LAUNCH_SENS(kRunEventCap, 1);

@@ -542,7 +542,18 @@ int run_sens_pass(rala_hip_ctx* ctx, PileArgs pa, const RepeatArgs& ra, const st
     pa.order = ctx->d_sens_list.p;
     pa.n_items = count;
     pa.n_items_dev = nullptr;
-    launch_pile_sens(pa, count, 0, mode, ctx->d_overflow.p, ctx->d_chain_cnt.p, s);
+    // cap 512 / 16384 bases -> (list) cap 512 / 32768 bases, if there are such reads -> (list) cap 1024 /
+    // 16384 bases -> (list) position space
+    const bool longer = ctx->n_class[0] != ctx->n_reads;
+    uint32_t* first_list = longer ? ctx->d_overflow_long.p : ctx->d_overflow.p;
+    if (longer) HIPCHECK(ctx->d_overflow_long.ensure(ctx->n_reads + 1));
+    first_list = longer ? ctx->d_overflow_long.p : ctx->d_overflow.p;
+    launch_pile_sens(pa, count, 0, mode, first_list, ctx->d_chain_cnt.p + (longer ? 2 : 0), s);
+    if (longer) {
+        pa.order = first_list;
+        pa.n_items_dev = ctx->d_chain_cnt.p + 2;
+        launch_pile_sens(pa, std::min<uint32_t>(count, 16384), 3, mode, ctx->d_overflow.p, ctx->d_chain_cnt.p, s);
+    }
     pa.order = ctx->d_overflow.p;
     pa.n_items_dev = ctx->d_chain_cnt.p;
     launch_pile_sens(pa, std::min<uint32_t>(count, 8192), 1, mode, ctx->d_overflow_mid.p, ctx->d_chain_cnt.p + 1, s);

@@ -74,9 +74,13 @@ def test_sensitive_pass_vs_oracle(hip_ctx_factory, n, g, seed, gpu_tail, run_ker
     chimera stage on the device (default) or on the host; the second pass over the piles in run
     space (default: primary bound events + sensitive bounds, two tiers, the rest in position
     space) or all of it in position space."""
+    _check_sensitive(hip_ctx_factory, Dataset(n, g, seed), gpu_tail, run_kernel, expect_hills=g >= 100_000)
+
+
+def _check_sensitive(hip_ctx_factory, ds, gpu_tail, run_kernel, expect_hills):
     from oracle.oracle import Oracle
 
-    ds = Dataset(n, g, seed)
+    n = ds.n_reads
     o = Oracle(ds.read_len, ds.overlaps, n_threads=8)
     assert o.initialize() == 0
     o.pass2()
@@ -104,7 +108,7 @@ def test_sensitive_pass_vs_oracle(hip_ctx_factory, n, g, seed, gpu_tail, run_ker
     parity.assert_same("rep.offsets", offs, want_rep[0])
     parity.assert_same("rep.pairs", pairs, want_rep[1])
     parity.assert_same("rep.flags", flags.astype(np.uint8), want_flags)
-    assert len(pairs) > 0 or g < 100_000, "the data set should exercise repeat hills"
+    assert len(pairs) > 0 or not expect_hills, "the data set should exercise repeat hills"
     hp = ctx.piles()
     for k in ("alive", "begin", "end", "median", "p10"):
         parity.assert_same("piles." + k, hp[k], want_p[k])
@@ -133,6 +137,23 @@ class _Scaled:
         self.overlaps = Overlaps(strand=ov.strand, **kw)
         self.read_len = (ds.read_len * factor).astype(np.uint32)
         self.n_reads = ds.n_reads
+        self.base, self.factor = ds, factor
+
+    def sensitive(self, alive, begin, end):
+        """sensitive overlaps of the base data set against its reads trimmed to [begin, end) / factor, scaled;
+        target coordinates kept inside the trimmed target"""
+        from rala_amd.synth import Overlaps, FIELDS
+
+        f = self.factor
+        begin, end = np.asarray(begin, dtype=np.uint32), np.asarray(end, dtype=np.uint32)
+        sv = self.base.sensitive(alive, begin // f, end // f)
+        kw = {k: np.array(getattr(sv, k), dtype=np.uint32) for k in FIELDS}
+        for k in ("a_begin", "a_end", "b_begin", "b_end", "length"):
+            kw[k] = kw[k] * f
+        span = (end - begin)[kw["b_id"]]
+        kw["b_end"] = np.minimum(kw["b_end"], span)
+        keep = kw["b_begin"] + 200 < kw["b_end"]
+        return Overlaps(strand=np.array(sv.strand, dtype=np.uint8)[keep], **{k: v[keep] for k, v in kw.items()})
 
 
 @pytest.mark.parametrize("factor", [2, 3, 5, 7])
@@ -155,6 +176,35 @@ def test_long_reads(hip_ctx_factory, factor):
     ctx.construct()
     parity.check_construct(ctx, st)
     parity.check_tr(ctx, st)
+
+
+@pytest.mark.parametrize("factor", [1, 2, 4])
+def test_event_dense_reads_of_every_length_class(hip_ctx_factory, factor):
+    """~300x coverage: most reads have more events than the cap-512 kernels take and start in the cap-1024
+    kernel from the list made of the bucket counts, some go on to cap 2048; with the longer length classes
+    beside them on the same stream."""
+    base = Dataset(1200, 40_000, 5)
+    ds = _Scaled(base, factor) if factor > 1 else base
+    st = parity.oracle_stages(ds)
+    ctx = hip_ctx_factory()
+    ctx.set_reads(ds.read_len)
+    ctx.set_overlaps(ds.overlaps)
+    ctx.initialize()
+    tm = ctx.timings()
+    assert tm["pile_overflow_reads"] > 300, tm
+    parity.check_initialize(ctx, st, ds)
+    ctx.construct()
+    parity.check_construct(ctx, st)
+    parity.check_tr(ctx, st)
+
+
+@pytest.mark.parametrize("factor", [2, 3])
+def test_sensitive_pass_long_reads(hip_ctx_factory, factor):
+    """The second pass over the piles on reads beyond 16384 bases: its 32768-base kernel (factor 2), and
+    the position-space kernel behind it for the still longer ones (factor 3)."""
+    ds = _Scaled(Dataset(3000, 600_000, 7), factor)
+    assert (ds.read_len > 16384).sum() > 2000
+    _check_sensitive(hip_ctx_factory, ds, 1, 1, expect_hills=True)
 
 
 def _shuffled_with_duplicates(ds, seed):
