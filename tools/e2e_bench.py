@@ -27,7 +27,14 @@ with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as d:
     size = os.path.getsize(paf)
     print("[e2e] wrote %s: %.2f GB in %.1f s" % (wl, size / 1e9, time.time() - t0), file=sys.stderr)
     best = None
-    for rep in range(3):
+    # RALA_E2E_AB=VAR: alternate runs without and with the environment variable VAR=1 (reader variants), report both
+    ab = os.environ.get("RALA_E2E_AB")
+    for rep in range(8 if ab else 3):
+        if ab:
+            if rep & 1:
+                os.environ[ab] = "1"
+            else:
+                os.environ.pop(ab, None)
         ms = [ctypes.c_double() for _ in range(3)]
         n_ovl, n_tr = ctypes.c_uint64(), ctypes.c_uint32()
         read_len = np.ascontiguousarray(ds.read_len, dtype=np.uint32)
@@ -35,6 +42,9 @@ with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as d:
                                  ctypes.byref(n_ovl), ctypes.byref(n_tr))
         assert rc == 0, rc
         tot = sum(x.value for x in ms)
+        if ab:
+            print("[e2e] %s=%d: parse %.1f ms, upload %.1f ms, device %.1f ms, total %.1f ms = %.1f M overlaps/s" % (
+                ab, rep & 1, ms[0].value, ms[1].value, ms[2].value, tot, n_ovl.value / tot / 1e3), file=sys.stderr)
         if best is None or tot < best["ms_total"]:
             best = {"workload": wl, "paf_bytes": size, "n_overlaps": n_ovl.value, "threads": threads,
                     "ms_parse": ms[0].value, "ms_upload": ms[1].value, "ms_device_first_call": ms[2].value, "ms_total": tot,
