@@ -1076,20 +1076,9 @@ int tail_components(rala_hip_ctx* ctx, const TailList& L, uint32_t n_alive) {
         launch_cc_hook(ctx->d_cc_edges.p, M, 1, ctx->d_cc_label.p, ctx->d_cc_flags.p + 7, s);
         launch_cc_compress(ctx->d_cc_label.p, n_alive, s);
     }
-    for (int it = 0;; ++it) {
-        // four hook + compress rounds per host check; a round that hooked nothing ends it
-        constexpr int kBatch = 4;
-        HIPCHECK(hipMemsetAsync(ctx->d_cc_flags.p, 0, kBatch * 4, s));
-        for (int k = 0; k < kBatch; ++k) {
-            launch_cc_hook(ctx->d_cc_edges.p, M, 0, ctx->d_cc_label.p, ctx->d_cc_flags.p + k, s);
-            launch_cc_compress(ctx->d_cc_label.p, n_alive, s);
-        }
-        uint32_t changed[kBatch];
-        HIPCHECK(d2h_small(ctx, changed, ctx->d_cc_flags.p, sizeof(changed), s));
-        HIPCHECK(stream_sync(ctx, s));
-        if (!changed[kBatch - 1]) break;
-        if (it > 10000) return fail(ctx, RALA_HIP_EDEVICE, "connected components did not converge");
-    }
+    // one launch over all edges finishes the components (cc_hook_kernel unites to the end)
+    launch_cc_hook(ctx->d_cc_edges.p, M, 0, ctx->d_cc_label.p, ctx->d_cc_flags.p + 7, s);
+    launch_cc_compress(ctx->d_cc_label.p, n_alive, s);
     // median of the pile medians per component (graph.cpp:777-783)
     HIPCHECK(launch_component_medians(ctx->d_cc_label.p, ctx->d_touched.p, ctx->d_alive_reads.p, ctx->d_median.p, n_alive,
                                       ctx->d_med_keys[0].p, ctx->d_med_keys[1].p, ctx->d_med_tmp.p, ctx->t_med_tmp,

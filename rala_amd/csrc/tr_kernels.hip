@@ -95,7 +95,7 @@ __device__ __forceinline__ uint32_t cc_root(const uint32_t* label, uint32_t v) {
     return v;
 }
 
-// hook the larger root under the smaller one; labels only ever decrease
+// unite the trees of every edge's endpoints (the larger root under the smaller one; labels only ever decrease)
 // sample != 0: only the first two edges of every run of equal first endpoint take part
 // (the list is grouped by query read).  Two such rounds connect most of a large component
 // at the price of two atomics per node; the full rounds that follow then find almost every
@@ -108,12 +108,24 @@ __global__ __launch_bounds__(kBlock) void cc_hook_kernel(const uint32_t* __restr
     if (e < n_edges) {
         const uint32_t a = edges[2 * e], b = edges[2 * e + 1];
         if (a != b && (!sample || e < 2 || edges[2 * (e - 2)] != a)) {
-            const uint32_t ra = cc_root(label, a), rb = cc_root(label, b);
-            if (ra != rb) {
+            // Lock-free union, to the end: the larger root goes under the smaller one; if it was no
+            // root any more (somebody hooked it under `old` in the meantime) it now points to the
+            // smaller of the two, and what is left to do is the union of those two.  Labels only
+            // fall, so this ends; when the kernel ends every edge of the launch lies inside one
+            // tree - one full launch is enough, no rounds, no look from the host.
+            uint32_t ra = cc_root(label, a), rb = cc_root(label, b);
+            while (ra != rb) {
                 const uint32_t hi = ra > rb ? ra : rb, lo = ra > rb ? rb : ra;
-                // labels only fall: skip the atomic when an earlier hook already went lower
-                if (__hip_atomic_load(&label[hi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > lo) atomicMin(&label[hi], lo);
-                hooked = true;
+                // (a coherent look first: no atomic on a node that is no root any more - a few roots
+                // would otherwise take a million atomic minima)
+                uint32_t old = __hip_atomic_load(&label[hi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (old == hi) {
+                    old = atomicMin(&label[hi], lo);
+                    hooked = true;
+                    if (old == hi) break;
+                }
+                ra = cc_root(label, old < lo ? old : lo);
+                rb = cc_root(label, old < lo ? lo : old);
             }
         }
     }

@@ -138,8 +138,10 @@ class _Scaled:
         self.read_len = (ds.read_len * factor).astype(np.uint32)
         self.n_reads = ds.n_reads
         self.base, self.factor = ds, factor
+        if hasattr(ds, "sensitive"):
+            self.sensitive = self._sensitive
 
-    def sensitive(self, alive, begin, end):
+    def _sensitive(self, alive, begin, end):
         """sensitive overlaps of the base data set against its reads trimmed to [begin, end) / factor, scaled;
         target coordinates kept inside the trimmed target"""
         from rala_amd.synth import Overlaps, FIELDS
