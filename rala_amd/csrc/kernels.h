@@ -197,9 +197,10 @@ void launch_classify(const OvlSoA& o, uint32_t n_reads, const uint8_t* valid, co
                      const KillList& kl, hipStream_t s);
 // containment fixed point on the killer list (overlap_kernels.hip): lo[t] = min(lo[t], i) over a
 // list; one decision round (sure killers -> sure[], undecided ones -> out)
-void launch_death_lower(const KillList& kl, uint32_t* lo, hipStream_t s);
+// (at_most: a bound of the list's length known to the host, sizes the grid; the length itself is on the device)
+void launch_death_lower(const KillList& kl, uint32_t* lo, hipStream_t s, uint64_t at_most = ~0ull);
 void launch_death_decide(const KillList& in, const uint32_t* lo, const uint32_t* up, uint32_t* sure, const KillList& out,
-                         hipStream_t s);
+                         hipStream_t s, uint64_t at_most = ~0ull);
 // *changed = 1 if the two differ anywhere; `older` is then filled with 0xFFFFFFFF (the next round's output)
 void launch_death_diff(uint32_t* older, const uint32_t* newer, uint32_t n, uint32_t* changed, hipStream_t s);
 void launch_death_tighten(const uint32_t* sure, uint32_t* up, uint32_t* lo, uint32_t n, hipStream_t s);

@@ -6,6 +6,7 @@
 //   remove_duplicate_overlaps :273-307   store_overlap_bounds :311-326
 //   construct, pass 2         :443-518   (Overlap::trim / ::type in geom.h)
 #include <hip/hip_runtime.h>
+#include <algorithm>
 
 #include "device_utils.h"
 #include "geom.h"
@@ -718,13 +719,18 @@ void launch_classify(const OvlSoA& o, uint32_t n_reads, const uint8_t* valid, co
                            o, n_reads, valid, rec, cls, kl);
     }
 }
-void launch_death_lower(const KillList& kl, uint32_t* lo, hipStream_t s) {
-    // the list length lives on the device: a fixed grid strides over it
-    hipLaunchKernelGGL(death_lower_kernel, dim3(4096), dim3(kBlock), 0, s, kl, lo);
+// the list length lives on the device: a grid sized for what the host knows of it strides over it
+// (4096 workgroups that find nothing to do still take 20 us to come and go)
+static uint32_t death_grid(uint64_t at_most) {
+    if (at_most >= 4096ull * kBlock) return 4096;
+    return (uint32_t)std::max<uint64_t>(1, (at_most + kBlock - 1) / kBlock);
+}
+void launch_death_lower(const KillList& kl, uint32_t* lo, hipStream_t s, uint64_t at_most) {
+    hipLaunchKernelGGL(death_lower_kernel, dim3(death_grid(at_most)), dim3(kBlock), 0, s, kl, lo);
 }
 void launch_death_decide(const KillList& in, const uint32_t* lo, const uint32_t* up, uint32_t* sure, const KillList& out,
-                         hipStream_t s) {
-    hipLaunchKernelGGL(death_decide_kernel, dim3(4096), dim3(kBlock), 0, s, in, lo, up, sure, out);
+                         hipStream_t s, uint64_t at_most) {
+    hipLaunchKernelGGL(death_decide_kernel, dim3(death_grid(at_most)), dim3(kBlock), 0, s, in, lo, up, sure, out);
 }
 void launch_death_diff(uint32_t* older, const uint32_t* newer, uint32_t n, uint32_t* changed, hipStream_t s) {
     if (n) hipLaunchKernelGGL(death_diff_kernel, grid_for(n), dim3(kBlock), 0, s, older, newer, n, changed);

@@ -1340,6 +1340,7 @@ int pass2(rala_hip_ctx* ctx, Comm* comm) {
     HIPCHECK(ctx->d_round_log.ensure(kLogged));
     std::vector<uint32_t> list_size;                             // after every round; kNotSeen = in the log
     uint32_t unseen = 0, n_logged = 0;
+    uint64_t at_most = ~0ull;                                    // what the host knows of the current list's length
     for (;;) {
         if (next_count < kCountRing) {
             klist[cur ^ 1].count = ctx->d_kill_count.p + next_count++;
@@ -1347,7 +1348,7 @@ int pass2(rala_hip_ctx* ctx, Comm* comm) {
             klist[cur ^ 1].count = ctx->d_kill_count.p + kCountRing + (cur ^ 1);
             HIPCHECK(hipMemsetAsync(klist[cur ^ 1].count, 0, 4, s));
         }
-        launch_death_decide(klist[cur], lo, up, sure, klist[cur ^ 1], s);
+        launch_death_decide(klist[cur], lo, up, sure, klist[cur ^ 1], s, at_most);
         cur ^= 1;
         // tighter bounds for the next round: up = sure, lo = min(sure, undecided killers)
         uint32_t undecided = 0;
@@ -1356,7 +1357,7 @@ int pass2(rala_hip_ctx* ctx, Comm* comm) {
             launch_death_status(klist[cur].count, ctx->d_round_log.p + n_logged++, s);
             list_size.push_back(kNotSeen);
             launch_death_tighten(sure, up, lo, n_reads, s);
-            launch_death_lower(klist[cur], lo, s);
+            launch_death_lower(klist[cur], lo, s, at_most);
             continue;
         }
         if (gathered) {
@@ -1378,8 +1379,9 @@ int pass2(rala_hip_ctx* ctx, Comm* comm) {
         if (list_size.size() > 100000) return fail(ctx, RALA_HIP_EDEVICE, "containment fixed point did not converge");
         if (!gathered) HIPCHECK(hipMemcpyAsync(up, sure, dbytes, hipMemcpyDeviceToDevice, s));
         if (gathered) {
+            at_most = undecided;                                // the lists only shrink from here
             launch_death_tighten(sure, up, lo, n_reads, s);
-            launch_death_lower(klist[cur], lo, s);
+            launch_death_lower(klist[cur], lo, s, at_most);
             if (undecided <= kFewKillers && ctx->use_round_batches) unseen = kRoundsPerLook;
         } else if ((uint64_t)undecided * comm->world() <= (1u << 16)) {
             // few killers left: every rank takes all of them and the rest needs no collective
@@ -1406,6 +1408,7 @@ int pass2(rala_hip_ctx* ctx, Comm* comm) {
             HIPCHECK(stream_sync(ctx, s));                       // t32 is a local
             cur ^= 1;
             gathered = true;
+            at_most = total;
         }
     }
     uint32_t* death = sure;

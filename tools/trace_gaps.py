@@ -5,6 +5,10 @@ kernel's end and the next one's start (any stream) that are longer than 8 us."""
 import csv
 import sys
 
+def short(name):
+    return name.replace("rala_hip::", "").replace("(anonymous namespace)::", "").split("(")[0][-45:]
+
+
 rows = []
 for row in csv.DictReader(open(sys.argv[1])):
     rows.append((int(row["Start_Timestamp"]), int(row["End_Timestamp"]), row["Kernel_Name"]))
@@ -30,6 +34,12 @@ total = busy_end - t0
 print("step: %.1f us from the first kernel's start to the last one's end, %d kernels, busy %.1f us, idle %.1f us in %d gaps"
       % (total / 1e3, len(step), covered / 1e3, (total - covered) / 1e3, len(gaps)))
 for g, at, p, n in sorted(gaps, reverse=True)[:25]:
-    print("  %7.1f us at %8.1f us  after %-45s before %s" % (g / 1e3, at / 1e3, p.split("(")[0][-45:], n.split("(")[0][-45:]))
+    print("  %7.1f us at %8.1f us  after %-45s before %s" % (g / 1e3, at / 1e3, short(p), short(n)))
 small = sum(g for g, _, _, _ in gaps if g < 8000)
 print("gaps below 8 us: %.1f us in all" % (small / 1e3))
+
+# python tools/trace_gaps.py <csv> <substring>: every kernel of the step whose name contains it, in time order
+if len(sys.argv) > 2:
+    for s0, e0, name in step:
+        if sys.argv[2] in name:
+            print("  at %8.1f us  %7.1f us  %s" % ((s0 - t0) / 1e3, (e0 - s0) / 1e3, name.replace("rala_hip::", "").replace("(anonymous namespace)::", "").split("(")[0][-60:]))
