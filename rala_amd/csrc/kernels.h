@@ -300,7 +300,8 @@ void launch_tr_mark(const uint32_t* row_ptr, const uint32_t* adj_edge, const uin
 // out-degree per node (also flags endpoints >= n_nodes) / adjacency fill through a cursor
 void launch_tr_degree(const uint32_t* src, const uint32_t* dst, uint32_t n_nodes, uint32_t n_edges, uint32_t* deg,
                       uint32_t* bad, hipStream_t s);
-void launch_tr_fill(const uint32_t* src, uint32_t n_nodes, uint32_t n_edges, uint32_t* cursor, uint32_t* adj,
+// adj: 2 * n_edges words, {edge, target of the edge} per out-list entry
+void launch_tr_fill(const uint32_t* src, const uint32_t* dst, uint32_t n_nodes, uint32_t n_edges, uint32_t* cursor, uint32_t* adj,
                     hipStream_t s);
 // connected components by min-label hooking + pointer jumping (edges = pairs a, b)
 void launch_cc_init(uint32_t* label, uint32_t n, hipStream_t s);

@@ -962,7 +962,7 @@ int tr_mark_device(rala_hip_ctx* ctx, uint32_t n_nodes, uint32_t n_edges, const 
     if (n_edges & 1) return fail(ctx, RALA_HIP_EINVAL, "edges must come in twin pairs (e, e^1)");
     hipStream_t s = ctx->stream;
     DevBuf<uint32_t>* B = ctx->d_tr;          // row, cursor, adj (persistent)
-    HIPCHECK(B[0].ensure(n_nodes + 2)); HIPCHECK(B[1].ensure(n_nodes + 2)); HIPCHECK(B[2].ensure(n_edges));
+    HIPCHECK(B[0].ensure(n_nodes + 2)); HIPCHECK(B[1].ensure(n_nodes + 2)); HIPCHECK(B[2].ensure(2 * (size_t)n_edges));
     HIPCHECK(ctx->d_tr_marks.ensure((size_t)n_edges + 8));
     HIPCHECK(ctx->d_scan_ws.ensure(scan_workspace_bytes((uint64_t)n_nodes + 2)));
     HIPCHECK(hipMemsetAsync(ctx->d_tr_marks.p, 0, ((size_t)n_edges + 7) & ~(size_t)3, s));
@@ -975,7 +975,7 @@ int tr_mark_device(rala_hip_ctx* ctx, uint32_t n_nodes, uint32_t n_edges, const 
     launch_tr_degree(d_src, d_dst, n_nodes, n_edges, B[1].p, ctx->d_small.p + 2, s);
     launch_exclusive_scan(B[1].p, B[0].p, n_nodes, ctx->d_scan_ws.p, s);
     HIPCHECK(hipMemcpyAsync(B[1].p, B[0].p, (size_t)n_nodes * 4, hipMemcpyDeviceToDevice, s));
-    launch_tr_fill(d_src, n_nodes, n_edges, B[1].p, B[2].p, s);
+    launch_tr_fill(d_src, d_dst, n_nodes, n_edges, B[1].p, B[2].p, s);
     if (!comm) {
         launch_tr_mark(B[0].p, B[2].p, d_src, d_dst, d_len, n_nodes, 0, n_edges, ctx->d_tr_marks.p, s);
     } else {

@@ -20,7 +20,7 @@ namespace {
 constexpr int kBlock = 256;
 
 __global__ __launch_bounds__(kBlock) void tr_mark_kernel(const uint32_t* __restrict__ row_ptr,
-                                                         const uint32_t* __restrict__ adj,
+                                                         const uint2* __restrict__ adj,
                                                          const uint32_t* __restrict__ esrc,
                                                          const uint32_t* __restrict__ edst,
                                                          const uint32_t* __restrict__ elen, uint32_t n_nodes,
@@ -33,18 +33,20 @@ __global__ __launch_bounds__(kBlock) void tr_mark_kernel(const uint32_t* __restr
     const uint32_t len_ab = elen[e_ab];
     const uint32_t a0 = row_ptr[a], a1 = row_ptr[a + 1];
     const uint32_t b0 = row_ptr[b], b1 = row_ptr[b + 1];
+    // (the out-lists hold {edge, its target}: one sequential read per list element instead of a
+    // gather through the edge's target for each)
     for (uint32_t k = b0; k < b1; ++k) {
-        const uint32_t e_bc = adj[k];
-        const uint32_t c = edst[e_bc];
+        const uint2 bc = adj[k];
+        const uint32_t c = bc.y;
         // the candidate is the LAST edge a->c of a's out-list = the one with the highest id
         // (out-lists are in edge-id order in the reference; here the list order is arbitrary)
         uint32_t cand = 0xFFFFFFFFu;
         for (uint32_t m = a0; m < a1; ++m) {
-            const uint32_t e = adj[m];
-            if (edst[e] == c && (cand == 0xFFFFFFFFu || e > cand)) cand = e;
+            const uint2 ac = adj[m];
+            if (ac.y == c && (cand == 0xFFFFFFFFu || ac.x > cand)) cand = ac.x;
         }
         if (cand == 0xFFFFFFFFu) continue;
-        const uint32_t sum = len_ab + elen[e_bc];
+        const uint32_t sum = len_ab + elen[bc.x];
         if (comparable((double)sum, (double)elen[cand], 0.12)) {
             marks[cand] = 1;
             marks[cand ^ 1u] = 1;
@@ -73,13 +75,13 @@ __global__ __launch_bounds__(kBlock) void tr_degree_kernel(const uint32_t* __res
     atomicAdd(&deg[a], 1u);
 }
 
-__global__ __launch_bounds__(kBlock) void tr_fill_kernel(const uint32_t* __restrict__ src, uint32_t n_nodes,
-                                                         uint32_t n_edges, uint32_t* cursor, uint32_t* adj) {
+__global__ __launch_bounds__(kBlock) void tr_fill_kernel(const uint32_t* __restrict__ src, const uint32_t* __restrict__ dst,
+                                                         uint32_t n_nodes, uint32_t n_edges, uint32_t* cursor, uint2* adj) {
     const uint32_t e = blockIdx.x * kBlock + threadIdx.x;
     if (e >= n_edges) return;
     const uint32_t a = src[e];
     if (a >= n_nodes) return;
-    adj[atomicAdd(&cursor[a], 1u)] = e;
+    adj[atomicAdd(&cursor[a], 1u)] = make_uint2(e, dst[e]);
 }
 
 // ---- connected components (Graph::preprocess, reference graph.cpp:740-773; only the member
@@ -149,11 +151,11 @@ void launch_tr_degree(const uint32_t* src, const uint32_t* dst, uint32_t n_nodes
                            n_nodes, n_edges, deg, bad);
     }
 }
-void launch_tr_fill(const uint32_t* src, uint32_t n_nodes, uint32_t n_edges, uint32_t* cursor, uint32_t* adj,
+void launch_tr_fill(const uint32_t* src, const uint32_t* dst, uint32_t n_nodes, uint32_t n_edges, uint32_t* cursor, uint32_t* adj,
                     hipStream_t s) {
     if (n_edges) {
-        hipLaunchKernelGGL(tr_fill_kernel, dim3((n_edges + kBlock - 1) / kBlock), dim3(kBlock), 0, s, src, n_nodes,
-                           n_edges, cursor, adj);
+        hipLaunchKernelGGL(tr_fill_kernel, dim3((n_edges + kBlock - 1) / kBlock), dim3(kBlock), 0, s, src, dst, n_nodes,
+                           n_edges, cursor, (uint2*)adj);
     }
 }
 void launch_cc_init(uint32_t* label, uint32_t n, hipStream_t s) {
@@ -175,7 +177,7 @@ void launch_tr_mark(const uint32_t* row_ptr, const uint32_t* adj_edge, const uin
                     uint32_t last_edge, uint8_t* marks, hipStream_t s) {
     if (last_edge <= first_edge) return;
     hipLaunchKernelGGL(tr_mark_kernel, dim3((last_edge - first_edge + kBlock - 1) / kBlock), dim3(kBlock), 0, s, row_ptr,
-                       adj_edge, edge_src, edge_dst, edge_len, n_nodes, first_edge, last_edge, marks);
+                       (const uint2*)adj_edge, edge_src, edge_dst, edge_len, n_nodes, first_edge, last_edge, marks);
 }
 
 void launch_tr_count(uint8_t* marks, uint32_t n_edges, uint32_t* n_pairs, hipStream_t s) {
