@@ -1921,6 +1921,10 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
     ctx->host_state_fresh = false;
     ctx->pool_used = std::min(small[0], ctx->pool_cap);
     ctx->tm.pile_overflow_reads = ctx->use_run_kernel ? small[3] + small[4] : 0;      // event-dense + handed on
+    if (getenv("RALA_HIP_TRACE")) {
+        fprintf(stderr, "[trace] pile chain: %u reads listed as event-dense, %u handed on by the cap-512 kernels, %u on to cap 2048, %u to position space\n",
+                small[3], small[4], small[2], small[5]);
+    }
     ctx->tm.pile_position_reads = ctx->use_run_kernel ? small[5] : n_reads;
     // dedupe_ms: what duplicate removal adds to the critical path (it runs beside the bucketing
     // and the pile kernels; the main stream joins it after them)
