@@ -193,8 +193,9 @@ struct KillList {
 // per-read record of the second pass: {begin, end, n_pits | n_hills << 8 | alive << 16, pool slot}
 void launch_pack_reads(const ReadState& rs, uint32_t n_reads, uint4* rec, hipStream_t s);
 uint32_t pass2_chunks(uint64_t n_overlaps);     // workgroups (= chunk counters) of finish / gather
+// lo[n_reads], all ones on entry: lo[r] = the first overlap that would delete read r (the fixed point's first lower bound)
 void launch_classify(const OvlSoA& o, uint32_t n_reads, const uint8_t* valid, const uint4* rec, uint8_t* cls,
-                     const KillList& kl, hipStream_t s);
+                     const KillList& kl, uint32_t* lo, hipStream_t s);
 // containment fixed point on the killer list (overlap_kernels.hip): lo[t] = min(lo[t], i) over a
 // list; one decision round (sure killers -> sure[], undecided ones -> out)
 // (at_most: a bound of the list's length known to the host, sizes the grid; the length itself is on the device)

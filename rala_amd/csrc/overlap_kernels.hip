@@ -355,7 +355,7 @@ constexpr uint32_t kClassifyChunk = 2048;
 __global__ __launch_bounds__(kBlock) void classify_kernel(OvlSoA o, uint32_t n_reads,
                                                           const uint8_t* __restrict__ valid,
                                                           const uint4* __restrict__ rec,
-                                                          uint8_t* __restrict__ cls, KillList kl) {
+                                                          uint8_t* __restrict__ cls, KillList kl, uint32_t* lo) {
     __shared__ uint32_t s_cnt, s_base;
     constexpr uint32_t kPer = kClassifyChunk / kBlock;
     const uint32_t lane = threadIdx.x & 63;
@@ -404,9 +404,15 @@ __global__ __launch_bounds__(kBlock) void classify_kernel(OvlSoA o, uint32_t n_r
         const uint64_t i = (uint64_t)blockIdx.x * kClassifyChunk + u * kBlock + threadIdx.x;
         const uint32_t a = o.a_id[i], b = o.b_id[i];
         const uint32_t w = base + slot[u];
-        kl.ovl[w] = (uint32_t)(o.base + i);            // position in the whole file (multi-GPU: slices)
-        kl.target[w] = (res[u] & kClsKillsA) ? a : b;
+        const uint32_t pos = (uint32_t)(o.base + i);   // position in the whole file (multi-GPU: slices)
+        const uint32_t target = (res[u] & kClsKillsA) ? a : b;
+        kl.ovl[w] = pos;
+        kl.target[w] = target;
         kl.keeper[w] = (res[u] & kClsKillsA) ? b : a;
+        // the fixed point's first lower bound, everybody's first killer (death_lower_kernel over the
+        // whole list: 0.13 ms of atomics at C3 - here they run beside this kernel's loads)
+        uint32_t* d = &lo[target];
+        if (__hip_atomic_load(d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > pos) atomicMin(d, pos);
     }
 }
 
@@ -431,6 +437,8 @@ __global__ __launch_bounds__(kBlock) void death_lower_kernel(KillList kl, uint32
     }
 }
 
+// up == nullptr: the first round, every upper bound is still "never" (one random load less for
+// each of the 1.4 M killers of that round at C3)
 __global__ __launch_bounds__(kBlock) void death_decide_kernel(KillList in, const uint32_t* __restrict__ lo,
                                                               const uint32_t* __restrict__ up, uint32_t* sure,
                                                               KillList out) {
@@ -449,7 +457,7 @@ __global__ __launch_bounds__(kBlock) void death_decide_kernel(KillList in, const
             const uint32_t best = __hip_atomic_load(&sure[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (i < best) {
                 if (lo[kp] > i) atomicMin(&sure[t], i);
-                else if (up[kp] > i) keep = true;
+                else if (up == nullptr || up[kp] > i) keep = true;
             }
         }
         const uint64_t m = __ballot(keep);
@@ -713,10 +721,10 @@ void launch_pack_reads(const ReadState& rs, uint32_t n_reads, uint4* rec, hipStr
 }
 uint32_t pass2_chunks(uint64_t n_overlaps) { return (uint32_t)((n_overlaps + kClassifyChunk - 1) / kClassifyChunk); }
 void launch_classify(const OvlSoA& o, uint32_t n_reads, const uint8_t* valid, const uint4* rec, uint8_t* cls,
-                     const KillList& kl, hipStream_t s) {
+                     const KillList& kl, uint32_t* lo, hipStream_t s) {
     if (o.n) {
         hipLaunchKernelGGL(classify_kernel, dim3((uint32_t)((o.n + kClassifyChunk - 1) / kClassifyChunk)), dim3(kBlock), 0, s,
-                           o, n_reads, valid, rec, cls, kl);
+                           o, n_reads, valid, rec, cls, kl, lo);
     }
 }
 // the list length lives on the device: a grid sized for what the host knows of it strides over it

@@ -1307,26 +1307,28 @@ int pass2(rala_hip_ctx* ctx, Comm* comm) {
     HIPCHECK(hipEventRecord(ctx->ev[4], s));
     HIPCHECK(hipMemsetAsync(ctx->d_kill_count.p, 0, (kCountRing + 4) * 4, s));
     HIPCHECK(ctx->d_rec.ensure(n_reads));
+    // one buffer: sure[n_reads] (min over sure killers = upper bound), lo[n_reads] (lower bound),
+    // one status word - so that a sharded run needs ONE all-reduce (min) per round; up[] apart
+    HIPCHECK(ctx->d_death_sure.ensure(2 * (size_t)n_reads + 8));
+    uint32_t* sure = ctx->d_death_sure.p;
+    uint32_t* lo = sure + n_reads;
+    const size_t dbytes = (size_t)n_reads * 4;
+    HIPCHECK(hipMemsetAsync(sure, 0xFF, 2 * dbytes + 4, s));
     launch_pack_reads(rs, n_reads, ctx->d_rec.p, s);
-    launch_classify(ctx->ovl, n_reads, ctx->d_valid.p, ctx->d_rec.p, ctx->d_cls.p, kl, s);
+    launch_classify(ctx->ovl, n_reads, ctx->d_valid.p, ctx->d_rec.p, ctx->d_cls.p, kl, lo, s);
     HIPCHECK(hipEventRecord(ctx->ev[5], s));
 
     // ---- in-order containment removal as a fixed point (death_decide_kernel) ----
-    // one buffer: sure[n_reads] (min over sure killers = upper bound), lo[n_reads] (lower bound),
-    // one status word - so that a sharded run needs ONE all-reduce (min) per round; up[] apart
     for (int k = 0; k < 3; ++k) HIPCHECK(ctx->d_kill2[k].ensure(N + 1));
-    HIPCHECK(ctx->d_death_sure.ensure(2 * (size_t)n_reads + 8));
     KillList klist[2] = {kl, kl};
     uint32_t next_count = 1;
     klist[1].ovl = ctx->d_kill2[0].p; klist[1].target = ctx->d_kill2[1].p; klist[1].keeper = ctx->d_kill2[2].p;
-    uint32_t* sure = ctx->d_death_sure.p;
-    uint32_t* lo = sure + n_reads;
     uint32_t* status = sure + 2 * (size_t)n_reads;          // 0xFFFFFFFF - undecided killers (min = most)
     uint32_t* up = ctx->d_death[1].p;
-    const size_t dbytes = (size_t)n_reads * 4;
-    HIPCHECK(hipMemsetAsync(sure, 0xFF, 2 * dbytes + 4, s));
-    HIPCHECK(hipMemsetAsync(up, 0xFF, dbytes, s));
-    launch_death_lower(klist[0], lo, s);                         // first lower bound: everybody's first killer
+    // (the first lower bound - everybody's first killer - was taken by the classify kernel; the
+    // upper bounds are all "never" in the first round, which is told so instead of reading them, and
+    // written in full before the second)
+    bool first_round = true;
     if (comm && comm->all_reduce_u32(lo, n_reads, ReduceOp::kMin, s) != 0) return comm_fail("all-reduce of the containment bounds");
     ctx->tm.death_rounds = 0;
     int cur = 0;
@@ -1348,7 +1350,8 @@ int pass2(rala_hip_ctx* ctx, Comm* comm) {
             klist[cur ^ 1].count = ctx->d_kill_count.p + kCountRing + (cur ^ 1);
             HIPCHECK(hipMemsetAsync(klist[cur ^ 1].count, 0, 4, s));
         }
-        launch_death_decide(klist[cur], lo, up, sure, klist[cur ^ 1], s, at_most);
+        launch_death_decide(klist[cur], lo, first_round ? nullptr : up, sure, klist[cur ^ 1], s, at_most);
+        first_round = false;
         cur ^= 1;
         // tighter bounds for the next round: up = sure, lo = min(sure, undecided killers)
         uint32_t undecided = 0;
