@@ -40,7 +40,8 @@ def test_bucketing_variants(hip_ctx_factory, n, g, seed):
     slot is what the counting atomic returns) and the exact CSR (count, scan, scatter)."""
     ds = Dataset(n, g, seed)
     st = parity.oracle_stages(ds)
-    for opts in ({"use_fixed_buckets": 0}, {}):
+    # (use_side_stream = 0: duplicate removal and the pile chain's small kernels on the main stream)
+    for opts in ({"use_fixed_buckets": 0}, {}, {"use_side_stream": 0}, {"use_side_stream": 0, "use_fixed_buckets": 0}):
         ctx = hip_ctx_factory()
         for k, v in opts.items():
             ctx.set_option(k, v)
@@ -180,8 +181,9 @@ def test_long_reads(hip_ctx_factory, factor):
     parity.check_tr(ctx, st)
 
 
+@pytest.mark.parametrize("side_stream", [1, 0])
 @pytest.mark.parametrize("factor", [1, 2, 4])
-def test_event_dense_reads_of_every_length_class(hip_ctx_factory, factor):
+def test_event_dense_reads_of_every_length_class(hip_ctx_factory, factor, side_stream):
     """~300x coverage: most reads have more events than the cap-512 kernels take and start in the cap-1024
     kernel from the list made of the bucket counts, some go on to cap 2048; with the longer length classes
     beside them on the same stream."""
@@ -189,6 +191,7 @@ def test_event_dense_reads_of_every_length_class(hip_ctx_factory, factor):
     ds = _Scaled(base, factor) if factor > 1 else base
     st = parity.oracle_stages(ds)
     ctx = hip_ctx_factory()
+    ctx.set_option("use_side_stream", side_stream)
     ctx.set_reads(ds.read_len)
     ctx.set_overlaps(ds.overlaps)
     ctx.initialize()
