@@ -70,9 +70,10 @@ uint32_t pile_lw_for(uint32_t read_len);
 void launch_pile_build_annotate(const PileArgs& args, uint32_t grid, bool in_lds, hipStream_t stream);
 
 // run-space kernel (pile_runs_kernel.hip): one wavefront per read; reads with more bound
-// events than the instantiation's cap are appended to overflow_list instead (args.order may
-// be null = identity).  Three instantiations (tier 0, 1, 2): the larger ones keep longer lists in
-// LDS and run at lower occupancy.
+// events than the instantiation's cap (or, with args.skip_dense, only those whose region lists do
+// not fit) are appended to overflow_list instead (args.order may be null = identity).  Event caps
+// 512 / 1024 / 2048 (tiers 0, 1, 2): the larger ones keep longer lists in LDS and run at lower
+// occupancy; cap 512 comes in three layouts by read length (tiers 0 / 3 / 4, below).
 constexpr uint32_t kRunEventCap = 512;
 constexpr uint32_t kRunEventCapMid = 1024;
 constexpr uint32_t kRunEventCapBig = 2048;

@@ -2,8 +2,8 @@
 //
 // A pile is a step function: coverage only changes at bound events.  The E events of a read
 // give R <= E + 1 runs (start, value): through a bitmap of the positions that carry an event
-// (reads of up to 16384 bases: run index = popcount, +-1 per event into its run's slot, prefix
-// sum) or, for longer reads, sorted (bitonic sort in registers, DPP / cross-lane shuffles,
+// (reads of up to 16384 / 32768 bases: run index = popcount, +-1 per event into its run's slot,
+// prefix sum) or, for longer reads, sorted (bitonic sort in registers, DPP / cross-lane shuffles,
 // wave_sort.h) and swept.  Every per-base loop of the reference then becomes a loop over runs:
 //   * Pile::add_layers        bitmap + popcounts + wave prefix sum   O(E)
 //   * Pile::find_valid_region  streaks of runs with value >= 4      O(R)
@@ -19,7 +19,9 @@
 //       resolution, narrowing, pit and hill loops run on one lane only for the
 //       few piles whose regions actually interact, reading coverage through a
 //       run cursor
-// Reads with more than kCap events are appended to an overflow list for the
+// Every read starts in the instantiation that fits its length class and its event
+// count (pipeline.hip: both are known before the first kernel runs); what still
+// does not fit - region lists, event caps - is appended to an overflow list for the
 // next kernel in the chain (larger kCap, then the position-space kernel of
 // pile_kernels.hip); the chain needs no host synchronisation.
 //
