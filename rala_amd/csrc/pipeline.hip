@@ -1925,6 +1925,9 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
     ctx->pool_used = std::min(small[0], ctx->pool_cap);
     ctx->tm.pile_overflow_reads = ctx->use_run_kernel ? small[3] + small[4] : 0;      // event-dense + handed on
     if (getenv("RALA_HIP_TRACE")) {
+        fprintf(stderr, "[trace] buffers: slots %p counts %p piles %p a_id %p b_id %p b_begin %p\n", (void*)ctx->d_ev_fixed.p,
+                (void*)ctx->d_cursor.p, (void*)ctx->d_pile.p, (const void*)ctx->ovl.a_id, (const void*)ctx->ovl.b_id,
+                (const void*)ctx->ovl.b_begin);
         fprintf(stderr, "[trace] pile chain: %u reads listed as event-dense, %u handed on by the cap-512 kernels, %u on to cap 2048, %u to position space\n",
                 small[3], small[4], small[2], small[5]);
     }

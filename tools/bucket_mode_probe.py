@@ -14,9 +14,13 @@ for k in range(int(sys.argv[2]) if len(sys.argv) > 2 else 6):
     ctx.set_reads(ds.read_len)
     ctx.set_overlaps(ds.overlaps)
     t = []
-    for _ in range(12):
+    for i in range(12):
+        if i == 1:
+            os.environ.pop("RALA_HIP_TRACE", None)
         ctx.initialize()
         t.append(ctx.timings()["bucket_ms"])
+    if os.environ.get("RALA_PROBE_ADDRESSES"):
+        os.environ["RALA_HIP_TRACE"] = "1"          # the next context's first call prints its buffer addresses
     print("context %d: bucket_ms %s" % (k, " ".join("%.2f" % x for x in t)), flush=True)
     if k % 2 == 0:
         keep.append(ctx)          # stays allocated: the next context gets other memory
