@@ -1756,6 +1756,9 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
     ctx->tail_on_device = ctx->host_stale = ctx->marks_on_device = false;
 
     HIPCHECK(ctx->d_pile.ensure(ctx->pile_elems + 8));
+    // (whatever a failed call may have left on the aux stream ends before the counters are reset)
+    HIPCHECK(hipEventRecord(ctx->ev[9], ctx->aux));
+    HIPCHECK(hipStreamWaitEvent(s, ctx->ev[9], 0));
     HIPCHECK(hipMemsetAsync(ctx->d_small.p, 0, 8 * 4, s));
     HIPCHECK(hipEventRecord(ctx->ev[0], s));
     // duplicate removal only feeds the second pass (every resolvable overlap adds its bounds,
