@@ -101,6 +101,7 @@ struct rala_hip_ctx {
     // pile chain.  d_class_order lists the reads class by class; empty when every read is in class 0.
     uint32_t n_class[rala_hip::kPileClasses] = {};
     rala_hip::DevBuf<uint32_t> d_class_order;
+    rala_hip::DevBuf<uint32_t> d_seg_base;            // tail: where each segment of the final overlap list ends
     rala_hip::DevBuf<uint32_t> d_dense;               // reads with more events than the first kernels take (+ its counter behind)
     std::vector<uint32_t> h_read_len;
     std::vector<uint64_t> h_pile_off;

@@ -280,8 +280,9 @@ void launch_keep_flags(const TailList& L, const uint8_t* alive, uint32_t want_st
                        hipStream_t s);
 void launch_u8_to_u32(const uint8_t* in, uint32_t* out, uint32_t n, hipStream_t s);
 void launch_ranks(const uint8_t* alive, const uint32_t* pos, uint32_t* rank, uint32_t* alive_reads, uint32_t n, hipStream_t s);
-void launch_place_kept(const TailList& L, const TailReads& R, const uint32_t* flag, const uint32_t* pos, uint32_t base,
-                       uint32_t* kept_item, uint32_t* dovetail, hipStream_t s);
+// (base_in: device word with the segment's first position, null = 0; *base_out = that + the segment's length)
+void launch_place_kept(const TailList& L, const TailReads& R, const uint32_t* flag, const uint32_t* pos, const uint32_t* base_in,
+                       uint32_t* base_out, uint32_t* kept_item, uint32_t* dovetail, hipStream_t s);
 void launch_build_edges(const TailList& L, const TailReads& R, const uint32_t* kept_item, const uint32_t* dovetail,
                         const uint32_t* epos, uint32_t n_kept, const uint32_t* node_rank, uint32_t* e_src, uint32_t* e_dst,
                         uint32_t* e_len, hipStream_t s);

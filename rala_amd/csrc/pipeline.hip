@@ -1177,14 +1177,16 @@ int gpu_tail_part_b(rala_hip_ctx* ctx) {
     const TailReads R = tail_reads(ctx);
     // the final overlap list: originals in order, then the promoted ones round by round
     uint32_t n_kept = 0;
+    HIPCHECK(ctx->d_seg_base.ensure(ctx->t_rounds + 2));
     for (uint32_t seg = 0; seg <= ctx->t_rounds; ++seg) {
         launch_keep_flags(L, ctx->d_alive.p, seg == 0 ? 1u : 3u, seg == 0 ? 0u : seg - 1, ctx->d_t_tmp[0].p, s);
         launch_exclusive_scan(ctx->d_t_tmp[0].p, ctx->d_t_tmp[1].p, M, ctx->d_scan_ws.p, s);
-        launch_place_kept(L, R, ctx->d_t_tmp[0].p, ctx->d_t_tmp[1].p, n_kept, ctx->d_kept_item.p, ctx->d_dovetail.p, s);
-        uint32_t c = 0;
-        HIPCHECK(d2h_small(ctx, &c, ctx->d_t_tmp[1].p + M, 4, s));
+        launch_place_kept(L, R, ctx->d_t_tmp[0].p, ctx->d_t_tmp[1].p, seg ? ctx->d_seg_base.p + seg - 1 : nullptr,
+                          ctx->d_seg_base.p + seg, ctx->d_kept_item.p, ctx->d_dovetail.p, s);
+    }
+    if (M) {
+        HIPCHECK(d2h_small(ctx, &n_kept, ctx->d_seg_base.p + ctx->t_rounds, 4, s));
         HIPCHECK(stream_sync(ctx, s));
-        n_kept += c;
     }
     ctx->t_n_kept = n_kept;
     mark("tail: final list", n_kept);

@@ -233,9 +233,14 @@ __global__ __launch_bounds__(kBlock) void ranks_kernel(const uint8_t* __restrict
 // final overlap j (kept item k at position base + pos[k]): remember k, and whether it is a
 // dovetail (graph.cpp:594,612)
 __global__ __launch_bounds__(kBlock) void place_kept_kernel(TailList L, TailReads R, const uint32_t* __restrict__ flag,
-                                                            const uint32_t* __restrict__ pos, uint32_t base,
-                                                            uint32_t* __restrict__ kept_item, uint32_t* __restrict__ dovetail) {
+                                                            const uint32_t* __restrict__ pos, const uint32_t* base_in,
+                                                            uint32_t* base_out, uint32_t* __restrict__ kept_item,
+                                                            uint32_t* __restrict__ dovetail) {
+    // the segment's place in the final list comes from (and the next one's goes to) device memory: the
+    // segments follow each other without a look from the host
     const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t base = base_in ? *base_in : 0u;
+    if (k == 0) *base_out = base + pos[L.n];
     if (k >= L.n || !flag[k]) return;
     const uint32_t j = base + pos[k];
     kept_item[j] = k;
@@ -325,9 +330,10 @@ void launch_u8_to_u32(const uint8_t* in, uint32_t* out, uint32_t n, hipStream_t 
 void launch_ranks(const uint8_t* alive, const uint32_t* pos, uint32_t* rank, uint32_t* alive_reads, uint32_t n, hipStream_t s) {
     if (n) hipLaunchKernelGGL(ranks_kernel, grid_for(n), dim3(kBlock), 0, s, alive, pos, rank, alive_reads, n);
 }
-void launch_place_kept(const TailList& L, const TailReads& R, const uint32_t* flag, const uint32_t* pos, uint32_t base,
-                       uint32_t* kept_item, uint32_t* dovetail, hipStream_t s) {
-    if (L.n) hipLaunchKernelGGL(place_kept_kernel, grid_for(L.n), dim3(kBlock), 0, s, L, R, flag, pos, base, kept_item, dovetail);
+void launch_place_kept(const TailList& L, const TailReads& R, const uint32_t* flag, const uint32_t* pos, const uint32_t* base_in,
+                       uint32_t* base_out, uint32_t* kept_item, uint32_t* dovetail, hipStream_t s) {
+    if (L.n) hipLaunchKernelGGL(place_kept_kernel, grid_for(L.n), dim3(kBlock), 0, s, L, R, flag, pos, base_in, base_out, kept_item,
+                                dovetail);
 }
 void launch_build_edges(const TailList& L, const TailReads& R, const uint32_t* kept_item, const uint32_t* dovetail,
                         const uint32_t* epos, uint32_t n_kept, const uint32_t* node_rank, uint32_t* e_src, uint32_t* e_dst,
