@@ -220,12 +220,16 @@ const char* rala_hip_mg_last_error(const rala_hip_mg* mg);
 /* all read lengths, on every rank (src/graph.cpp:249-264) */
 int rala_hip_mg_set_reads(rala_hip_mg* mg, const uint32_t* read_len, uint64_t n_reads);
 /* cuts[world + 1]: slice k = records cuts[k] .. cuts[k + 1] of the file; a cut never splits a run of
- * equal a_id, and records that do not resolve do not break a run (src/graph.cpp:343-350) */
-int rala_hip_mg_slice_cuts(const uint32_t* a_id, uint64_t n, uint32_t world, uint64_t* cuts);
+ * equal a_id, and records that do not resolve (query or target RALA_HIP_NO_READ) do not break a run
+ * (src/graph.cpp:338-350).  b_id may be NULL when every target is known. */
+int rala_hip_mg_slice_cuts(const uint32_t* a_id, const uint32_t* b_id, uint64_t n, uint32_t world, uint64_t* cuts);
 /* this rank's slice; first = file position of its record 0 */
 int rala_hip_mg_set_overlaps(rala_hip_mg* mg, const rala_hip_overlaps* slice, uint64_t n, uint64_t first, int mem);
 /* Graph::construct + remove_transitive_edges (src/graph.cpp:427-640, :1281-1335); sens_slice = this
- * rank's share of the sensitive overlaps (any contiguous share; NULL / 0 for none) */
+ * rank's share of the sensitive overlaps (any contiguous share, n_sens = 0 allowed; NULL on EVERY
+ * rank for a run without them - ranks that disagree get RALA_HIP_EINVAL).  A failure of one rank
+ * alone (out of memory, a device error) aborts the group: every rank's call fails and the rank
+ * objects must be destroyed. */
 int rala_hip_mg_run(rala_hip_mg* mg, const rala_hip_overlaps* sens_slice, uint64_t n_sens, uint32_t* n_pairs);
 /* the same for n ranks of this process, one host thread per rank, joined before it returns */
 int rala_hip_mg_run_threads(rala_hip_mg** ranks, uint32_t n, const rala_hip_overlaps* sens_slices, const uint64_t* n_sens,

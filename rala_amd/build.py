@@ -60,14 +60,42 @@ def hipcc():
     raise RuntimeError("hipcc not found")
 
 
-def build_hip(force=False):
+def build_hip(force=False, jobs=None):
+    """One object per .hip file (rala_amd/_build/*.o, rebuilt when that file or any header is newer),
+    compiled side by side, then linked: editing one kernel file costs one compile, not fourteen."""
+    from concurrent.futures import ThreadPoolExecutor
+
     d = os.path.join(PKG, "csrc")
     out = os.path.join(d, "librala_hip.so")
     srcs = _glob(d, (".hip",))
-    deps = srcs + _glob(d, (".h", ".hpp")) + _glob(os.path.join(ROOT, "include"), (".h",))
-    if force or _stale(out, deps):
-        _link([hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-               "-I" + os.path.join(ROOT, "include"), "-I" + d], out, srcs + ["-ldl"])
+    hdrs = _glob(d, (".h", ".hpp")) + _glob(os.path.join(ROOT, "include"), (".h",))
+    obj_dir = os.path.join(PKG, "_build")
+    os.makedirs(obj_dir, exist_ok=True)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+             "-I" + os.path.join(ROOT, "include"), "-I" + d]
+    cc = hipcc()
+    objs, todo = [], []
+    for src in srcs:
+        obj = os.path.join(obj_dir, os.path.basename(src)[:-4] + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [src] + hdrs):
+            todo.append((src, obj))
+
+    def compile_one(job):
+        src, obj = job
+        tmp = "%s.%d.tmp" % (obj, os.getpid())
+        try:
+            _run([cc] + flags + ["-c", src, "-o", tmp])
+            os.replace(tmp, obj)
+        finally:
+            if os.path.exists(tmp):
+                os.unlink(tmp)
+
+    if todo:
+        with ThreadPoolExecutor(max_workers=jobs or min(8, os.cpu_count() or 1)) as pool:
+            list(pool.map(compile_one, todo))
+    if force or todo or _stale(out, objs):
+        _link([cc, "--offload-arch=gfx950", "-shared", "-fPIC"], out, objs + ["-ldl"])
     return out
 
 

@@ -45,6 +45,10 @@ public:
     // in place over n uint32 values
     virtual int all_reduce_u32(uint32_t* buf, size_t n, ReduceOp op, hipStream_t s) = 0;
     virtual int barrier(hipStream_t s) = 0;
+    // NOT collective: called by a rank that failed between two collectives and will not make the
+    // next one.  Releases the ranks of this process that wait for it (their calls fail from here on);
+    // the group is unusable afterwards.
+    virtual void abort() = 0;
 
 protected:
     uint32_t rank_ = 0, world_ = 1;

@@ -6,6 +6,7 @@
 #include <rccl/rccl.h>      // types and prototypes only; the library is opened with dlopen
 #include <string.h>
 
+#include <atomic>
 #include <condition_variable>
 #include <mutex>
 
@@ -23,6 +24,7 @@ struct RcclApi {
     decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclSend) Send = nullptr;
@@ -57,6 +59,7 @@ RcclApi* rccl_api() {
         api.GetUniqueId = (decltype(api.GetUniqueId))sym("ncclGetUniqueId");
         api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
         api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
+        api.CommAbort = (decltype(api.CommAbort))sym("ncclCommAbort");
         api.AllReduce = (decltype(api.AllReduce))sym("ncclAllReduce");
         api.AllGather = (decltype(api.AllGather))sym("ncclAllGather");
         api.Send = (decltype(api.Send))sym("ncclSend");
@@ -69,25 +72,60 @@ RcclApi* rccl_api() {
     return &api;
 }
 
+class RcclComm;
+
+// the communicators of THIS process by group id: a rank that fails between two collectives aborts
+// the ones of its group that live here (ranks as threads), so that nobody waits for it for ever
+struct RcclRegistry {
+    std::mutex m;
+    std::vector<RcclComm*> comms;
+};
+RcclRegistry& rccl_registry() {
+    static RcclRegistry r;
+    return r;
+}
+
 class RcclComm : public Comm {
 public:
     RcclComm(uint32_t rank, uint32_t world) { rank_ = rank; world_ = world; }
     ~RcclComm() override {
-        if (comm_) (void)api_->CommDestroy(comm_);
+        {
+            RcclRegistry& reg = rccl_registry();
+            std::lock_guard<std::mutex> hold(reg.m);
+            for (size_t k = 0; k < reg.comms.size(); ++k) {
+                if (reg.comms[k] == this) { reg.comms.erase(reg.comms.begin() + k); break; }
+            }
+        }
+        if (comm_) (void)(aborted_ ? api_->CommAbort(comm_) : api_->CommDestroy(comm_));
     }
     bool init(const void* id, std::string* err) {
         api_ = rccl_api();
         if (!api_->lib) { *err = api_->err; return false; }
         static_assert(sizeof(ncclUniqueId) == kCommIdBytes, "unique id size");
-        ncclUniqueId uid;
-        memcpy(&uid, id, sizeof(uid));
-        const ncclResult_t r = api_->CommInitRank(&comm_, (int)world_, uid, (int)rank_);
+        memcpy(&uid_, id, sizeof(uid_));
+        const ncclResult_t r = api_->CommInitRank(&comm_, (int)world_, uid_, (int)rank_);
         if (r != ncclSuccess) { *err = std::string("ncclCommInitRank: ") + api_->GetErrorString(r); comm_ = nullptr; return false; }
+        RcclRegistry& reg = rccl_registry();
+        std::lock_guard<std::mutex> hold(reg.m);
+        reg.comms.push_back(this);
         return true;
+    }
+
+    // Called by a rank that cannot go on.  Its peers inside this process are released from whatever
+    // collective they wait in (their calls fail from here on); peers in other processes are the
+    // launcher's to end when this process exits with an error.
+    void abort() override {
+        RcclRegistry& reg = rccl_registry();
+        std::lock_guard<std::mutex> hold(reg.m);
+        for (RcclComm* c : reg.comms) {
+            if (memcmp(&c->uid_, &uid_, sizeof(uid_)) != 0 || c->aborted_.exchange(true)) continue;
+            if (c != this && c->comm_) { (void)api_->CommAbort(c->comm_); c->comm_ = nullptr; }
+        }
     }
 
     int host_all_gather(const uint64_t* mine, uint32_t n, uint64_t* all, hipStream_t s) override {
         const size_t total = (size_t)world_ * n;
+        if (dead()) return -1;
         if (d_small_.ensure(total + n) != hipSuccess || p_small_.ensure(total + n) != hipSuccess) return fail("out of memory");
         uint64_t* h = p_small_.p;                        // [0, n): mine; [n, n + total): all
         memcpy(h, mine, (size_t)n * 8);
@@ -102,18 +140,20 @@ public:
     int all_to_all_v(const void* send, const uint64_t* send_counts, void* recv, const uint64_t* recv_counts,
                      size_t elem_bytes, hipStream_t s) override {
         size_t so = 0, ro = 0, self_so = 0, self_ro = 0;
+        if (dead()) return -1;
         if (!ok(api_->GroupStart(), "ncclGroupStart")) return -1;
-        for (uint32_t p = 0; p < world_; ++p) {
+        bool good = true;                               // (a group that was opened is always closed)
+        for (uint32_t p = 0; p < world_ && good; ++p) {
             const size_t sb = (size_t)send_counts[p] * elem_bytes, rb = (size_t)recv_counts[p] * elem_bytes;
             if (p == rank_) {
                 self_so = so; self_ro = ro;
             } else {
-                if (sb && !ok(api_->Send((const char*)send + so, sb, ncclUint8, (int)p, comm_, s), "ncclSend")) return -1;
-                if (rb && !ok(api_->Recv((char*)recv + ro, rb, ncclUint8, (int)p, comm_, s), "ncclRecv")) return -1;
+                if (sb) good = ok(api_->Send((const char*)send + so, sb, ncclUint8, (int)p, comm_, s), "ncclSend");
+                if (rb && good) good = ok(api_->Recv((char*)recv + ro, rb, ncclUint8, (int)p, comm_, s), "ncclRecv");
             }
             so += sb; ro += rb;
         }
-        if (!ok(api_->GroupEnd(), "ncclGroupEnd")) return -1;
+        if (!close_group(good)) return -1;
         const size_t mine = (size_t)send_counts[rank_] * elem_bytes;
         if (mine && hipMemcpyAsync((char*)recv + self_ro, (const char*)send + self_so, mine, hipMemcpyDeviceToDevice, s) != hipSuccess) {
             return fail("copy of the own part");
@@ -123,24 +163,27 @@ public:
 
     int all_gather(const void* send, void* recv, size_t bytes, hipStream_t s) override {
         if (bytes == 0) return 0;
+        if (dead()) return -1;
         return ok(api_->AllGather(send, recv, bytes, ncclUint8, comm_, s), "ncclAllGather") ? 0 : -1;
     }
 
     int all_gather_v(const void* send, void* recv, const uint64_t* counts, size_t elem_bytes, hipStream_t s) override {
         const size_t mine = (size_t)counts[rank_] * elem_bytes;
         size_t ro = 0, self_ro = 0;
+        if (dead()) return -1;
         if (!ok(api_->GroupStart(), "ncclGroupStart")) return -1;
-        for (uint32_t p = 0; p < world_; ++p) {
+        bool good = true;
+        for (uint32_t p = 0; p < world_ && good; ++p) {
             const size_t rb = (size_t)counts[p] * elem_bytes;
             if (p == rank_) {
                 self_ro = ro;
             } else {
-                if (mine && !ok(api_->Send(send, mine, ncclUint8, (int)p, comm_, s), "ncclSend")) return -1;
-                if (rb && !ok(api_->Recv((char*)recv + ro, rb, ncclUint8, (int)p, comm_, s), "ncclRecv")) return -1;
+                if (mine) good = ok(api_->Send(send, mine, ncclUint8, (int)p, comm_, s), "ncclSend");
+                if (rb && good) good = ok(api_->Recv((char*)recv + ro, rb, ncclUint8, (int)p, comm_, s), "ncclRecv");
             }
             ro += rb;
         }
-        if (!ok(api_->GroupEnd(), "ncclGroupEnd")) return -1;
+        if (!close_group(good)) return -1;
         if (mine && (const char*)send != (char*)recv + self_ro &&
             hipMemcpyAsync((char*)recv + self_ro, send, mine, hipMemcpyDeviceToDevice, s) != hipSuccess) {
             return fail("copy of the own part");
@@ -150,11 +193,13 @@ public:
 
     int all_reduce_u32(uint32_t* buf, size_t n, ReduceOp op, hipStream_t s) override {
         if (n == 0) return 0;
+        if (dead()) return -1;
         const ncclRedOp_t r = op == ReduceOp::kSum ? ncclSum : op == ReduceOp::kMin ? ncclMin : ncclMax;
         return ok(api_->AllReduce(buf, buf, n, ncclUint32, r, comm_, s), "ncclAllReduce") ? 0 : -1;
     }
 
     int barrier(hipStream_t s) override {
+        if (dead()) return -1;
         if (d_small_.ensure(8) != hipSuccess) return fail("out of memory");
         if (!ok(api_->AllReduce(d_small_.p, d_small_.p, 1, ncclUint64, ncclSum, comm_, s), "ncclAllReduce")) return -1;
         return hipStreamSynchronize(s) == hipSuccess ? 0 : fail("hipStreamSynchronize");
@@ -167,9 +212,23 @@ private:
         return false;
     }
     int fail(const char* what) { err_ = what; return -1; }
+    bool dead() {
+        if (!aborted_.load() && comm_) return false;
+        err_ = "the group was aborted (a rank failed)";
+        return true;
+    }
+    // ncclGroupEnd even when a call inside the group failed: an open group would swallow every later call
+    bool close_group(bool good) {
+        const std::string first = err_;
+        const bool closed = ok(api_->GroupEnd(), "ncclGroupEnd");
+        if (!good) err_ = first;
+        return good && closed;
+    }
 
     RcclApi* api_ = nullptr;
     ncclComm_t comm_ = nullptr;
+    ncclUniqueId uid_ = {};
+    std::atomic<bool> aborted_{false};
     DevBuf<uint64_t> d_small_;
     PinnedBuf<uint64_t> p_small_;
 };
@@ -208,16 +267,26 @@ struct LocalGroup {
     std::vector<std::vector<uint64_t>> host;
     std::vector<int> device;
 
-    void wait() {
+    bool aborted = false;               // under m: a rank gave up; nobody waits for anybody any more
+
+    // false = the group was aborted (the rendezvous did not take place)
+    bool wait() {
         std::unique_lock<std::mutex> hold(m);
+        if (aborted) return false;
         const uint64_t g = generation;
         if (++arrived == world) {
             arrived = 0;
             ++generation;
             cv.notify_all();
         } else {
-            cv.wait(hold, [&]() { return generation != g; });
+            cv.wait(hold, [&]() { return generation != g || aborted; });
         }
+        return !aborted;
+    }
+    void abort() {
+        std::lock_guard<std::mutex> hold(m);
+        aborted = true;
+        cv.notify_all();
     }
 };
 
@@ -230,19 +299,20 @@ public:
         g->device[rank] = device;
     }
 
+    void abort() override { g_->abort(); }
+
     int host_all_gather(const uint64_t* mine, uint32_t n, uint64_t* all, hipStream_t) override {
         g_->host[rank_].assign(mine, mine + n);
-        g_->wait();
+        if (!meet()) return -1;
         for (uint32_t p = 0; p < world_; ++p) memcpy(all + (size_t)p * n, g_->host[p].data(), (size_t)n * 8);
-        g_->wait();
-        return 0;
+        return meet() ? 0 : -1;
     }
 
     int all_to_all_v(const void* send, const uint64_t* send_counts, void* recv, const uint64_t* recv_counts,
                      size_t elem_bytes, hipStream_t s) override {
-        if (!publish(send, s)) return -1;
+        publish(send, s);
         g_->counts[rank_].assign(send_counts, send_counts + world_);
-        g_->wait();
+        if (!meet()) return -1;
         size_t ro = 0;
         for (uint32_t p = 0; p < world_; ++p) {
             size_t so = 0;
@@ -256,8 +326,8 @@ public:
     }
 
     int all_gather(const void* send, void* recv, size_t bytes, hipStream_t s) override {
-        if (!publish(send, s)) return -1;
-        g_->wait();
+        publish(send, s);
+        if (!meet()) return -1;
         for (uint32_t p = 0; p < world_ && !bad_; ++p) {
             if (bytes && !copy((char*)recv + (size_t)p * bytes, g_->ptr[p], bytes, p, s)) bad_ = true;
         }
@@ -265,8 +335,8 @@ public:
     }
 
     int all_gather_v(const void* send, void* recv, const uint64_t* counts, size_t elem_bytes, hipStream_t s) override {
-        if (!publish(send, s)) return -1;
-        g_->wait();
+        publish(send, s);
+        if (!meet()) return -1;
         size_t ro = 0;
         for (uint32_t p = 0; p < world_; ++p) {
             const size_t bytes = (size_t)counts[p] * elem_bytes;
@@ -277,10 +347,11 @@ public:
     }
 
     int all_reduce_u32(uint32_t* buf, size_t n, ReduceOp op, hipStream_t s) override {
-        if (tmp_.ensure(n) != hipSuccess) { err_ = "out of memory"; return -1; }
-        if (!publish(buf, s)) return -1;
-        g_->wait();
-        if (n) {
+        publish(buf, s);
+        // (a rank without room for its result still keeps both appointments: the others read its buffer)
+        if (tmp_.ensure(n) != hipSuccess) { err_ = "out of memory"; bad_ = true; }
+        if (!meet()) return -1;
+        if (n && !bad_) {
             PeerPointers pp;
             for (uint32_t p = 0; p < world_; ++p) { pp.p[p] = (const uint32_t*)g_->ptr[p]; peer(p); }
             hipLaunchKernelGGL(local_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, pp, world_, n,
@@ -292,19 +363,25 @@ public:
     }
 
     int barrier(hipStream_t s) override {
-        if (hipStreamSynchronize(s) != hipSuccess) { err_ = "hipStreamSynchronize"; return -1; }
-        g_->wait();
-        return 0;
+        bad_ = false;
+        if (hipStreamSynchronize(s) != hipSuccess) { err_ = "hipStreamSynchronize"; bad_ = true; }
+        if (!meet()) return -1;
+        return bad_ ? -1 : 0;
     }
 
 private:
-    bool publish(const void* p, hipStream_t s) {
+    bool meet() {
+        if (g_->wait()) return true;
+        err_ = "the group was aborted (a rank failed)";
+        return false;
+    }
+    // a failed rank still takes part in the rendezvous (bad_ is reported at the end of the call)
+    void publish(const void* p, hipStream_t s) {
         (void)hipSetDevice(device_);
         bad_ = false;
         // what the peers are about to read must be complete
         if (hipStreamSynchronize(s) != hipSuccess) { err_ = "hipStreamSynchronize"; bad_ = true; }
         g_->ptr[rank_] = p;
-        return true;                            // a failed rank still takes part in the rendezvous
     }
     void peer(uint32_t p) {
         const int d = g_->device[p];
@@ -323,7 +400,7 @@ private:
     }
     int finish(hipStream_t s) {
         if (hipStreamSynchronize(s) != hipSuccess) { err_ = "hipStreamSynchronize"; bad_ = true; }
-        g_->wait();                             // the peers' buffers may change from here on
+        if (!meet()) return -1;                 // the peers' buffers may change from here on
         return bad_ ? -1 : 0;
     }
 

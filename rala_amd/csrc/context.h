@@ -91,6 +91,7 @@ struct rala_hip_ctx {
     int64_t host_threads = 0;                       // 0 = min(hardware threads, 16)
     std::unique_ptr<rala_hip::HostPool> pool;
     bool use_run_kernel = true;
+    bool debug_fail_construct = false;          // tests: pass 2 fails on this context
     bool use_round_batches = true;              // containment fixed point: several rounds per look at the counter
     rala_hip::DevBuf<uint32_t> d_round_log;     // list sizes after the rounds the host did not look at
 

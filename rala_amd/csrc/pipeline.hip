@@ -84,6 +84,7 @@ double now_ms() {
 // ---- host mirror of the per-read state -------------------------------------------
 int download_read_state(rala_hip_ctx* ctx) {
     const uint64_t n = ctx->n_reads;
+    HIPCHECK(hipSetDevice(ctx->device));        // (getters may be called with another rank's device current)
     ctx->h_begin.resize(n); ctx->h_end.resize(n); ctx->h_median.resize(n); ctx->h_p10.resize(n);
     ctx->h_alive.resize(n); ctx->h_n_pits.resize(n); ctx->h_n_hills.resize(n); ctx->h_slot.resize(n);
     hipStream_t s = ctx->stream;
@@ -1316,6 +1317,8 @@ int pass2(rala_hip_ctx* ctx, Comm* comm) {
     uint32_t* lo = sure + n_reads;
     const size_t dbytes = (size_t)n_reads * 4;
     HIPCHECK(hipMemsetAsync(sure, 0xFF, 2 * dbytes + 4, s));
+    // (tests: a failure that only this rank sees, between two collectives of a sharded run)
+    if (ctx->debug_fail_construct) return fail(ctx, RALA_HIP_EDEVICE, "debug_fail_construct");
     launch_pack_reads(rs, n_reads, ctx->d_rec.p, s);
     launch_classify(ctx->ovl, n_reads, ctx->d_valid.p, ctx->d_rec.p, ctx->d_cls.p, kl, lo, s);
     HIPCHECK(hipEventRecord(ctx->ev[5], s));
@@ -1587,13 +1590,14 @@ int rala_hip_create(int device, rala_hip_ctx** out) {
     if (hipSetDevice(device) != hipSuccess) return RALA_HIP_EDEVICE;
     rala_hip_ctx* ctx = new rala_hip_ctx;
     ctx->device = device;
-    if (hipStreamCreate(&ctx->stream) != hipSuccess) { delete ctx; return RALA_HIP_EDEVICE; }
-    if (hipStreamCreate(&ctx->side) != hipSuccess) { (void)hipStreamDestroy(ctx->stream); delete ctx; return RALA_HIP_EDEVICE; }
-    if (hipStreamCreate(&ctx->aux) != hipSuccess) { delete ctx; return RALA_HIP_EDEVICE; }
-    for (auto& e : ctx->ev) {
-        if (hipEventCreate(&e) != hipSuccess) { delete ctx; return RALA_HIP_EDEVICE; }
+    bool ok = hipStreamCreate(&ctx->stream) == hipSuccess && hipStreamCreate(&ctx->side) == hipSuccess &&
+              hipStreamCreate(&ctx->aux) == hipSuccess;
+    for (auto& e : ctx->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
+    ok = ok && ctx->d_small.ensure(8) == hipSuccess;
+    if (!ok) {                                  // (rala_hip_destroy releases whatever was created)
+        rala_hip_destroy(ctx);
+        return RALA_HIP_EDEVICE;
     }
-    if (ctx->d_small.ensure(8) != hipSuccess) { delete ctx; return RALA_HIP_EDEVICE; }
     ctx->pool.reset(new HostPool(std::min(16u, std::max(1u, std::thread::hardware_concurrency()))));
     *out = ctx;
     return RALA_HIP_OK;
@@ -1622,6 +1626,7 @@ int rala_hip_set_option(rala_hip_ctx* ctx, const char* key, int64_t value) {
     if (!strcmp(key, "debug_pile_stop_after")) { ctx->debug_pile_stop_after = value; return RALA_HIP_OK; }
     if (!strcmp(key, "use_run_kernel")) { ctx->use_run_kernel = value != 0; return RALA_HIP_OK; }
     if (!strcmp(key, "use_round_batches")) { ctx->use_round_batches = value != 0; return RALA_HIP_OK; }
+    if (!strcmp(key, "debug_fail_construct")) { ctx->debug_fail_construct = value != 0; return RALA_HIP_OK; }
     if (!strcmp(key, "use_gpu_tail")) { ctx->use_gpu_tail = value != 0; return RALA_HIP_OK; }
     if (!strcmp(key, "use_fixed_buckets")) { ctx->use_fixed_buckets = value != 0; return RALA_HIP_OK; }
     if (!strcmp(key, "use_side_stream")) { ctx->use_side_stream = value != 0; return RALA_HIP_OK; }

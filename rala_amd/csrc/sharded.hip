@@ -42,6 +42,7 @@ struct rala_hip_mg {
     rala_hip_ctx* cl = nullptr;
     uint64_t n_reads = 0, n_local = 0, nl_pad = 0;
     bool have_reads = false, have_overlaps = false;
+    bool verdict_shared = false;        // the failure this run returns is known to every rank (no abort needed)
     std::string err;
     DevBuf<uint2> d_send, d_recv;
     DevBuf<uint8_t> d_state_mine, d_state_all;
@@ -152,20 +153,30 @@ int from_comm(rala_hip_mg* mg, int rc, const char* where) {
 
 // Every rank learns whether any rank failed (otherwise the others would wait in the next
 // collective for ever).  Returns this rank's code, or RALA_HIP_EDEVICE if only another one failed.
-int agree(rala_hip_mg* mg, int rc, const char* where) {
+// `flag` travels along and must be the same on every rank (with / without sensitive overlaps).
+int agree(rala_hip_mg* mg, int rc, const char* where, uint32_t flag = 0) {
     std::vector<uint64_t> all(mg->world);
-    const uint64_t mine = (uint64_t)(uint32_t)(-rc);
+    const uint64_t mine = (uint64_t)(uint32_t)(-rc) | (uint64_t)flag << 32;
     if (mg->comm->host_all_gather(&mine, 1, all.data(), mg->cs->stream) != 0) {
         if (rc == RALA_HIP_OK) return from_comm(mg, -1, where);
         return rc;
     }
+    mg->verdict_shared = true;          // whatever is returned below, every rank returns a failure too
     if (rc != RALA_HIP_OK) return rc;
     for (uint32_t p = 0; p < mg->world; ++p) {
-        if (all[p] != 0) {
-            return mg_fail(mg, all[p] == (uint64_t)(-RALA_HIP_EFILTERED) ? RALA_HIP_EFILTERED : RALA_HIP_EDEVICE,
-                           std::string(where) + ": rank " + std::to_string(p) + " failed with code -" + std::to_string(all[p]));
+        const uint64_t code = all[p] & 0xFFFFFFFFull;
+        if (code != 0) {
+            return mg_fail(mg, code == (uint64_t)(-RALA_HIP_EFILTERED) ? RALA_HIP_EFILTERED : RALA_HIP_EDEVICE,
+                           std::string(where) + ": rank " + std::to_string(p) + " failed with code -" + std::to_string(code));
         }
     }
+    for (uint32_t p = 0; p < mg->world; ++p) {
+        if ((all[p] >> 32) != flag) {
+            return mg_fail(mg, RALA_HIP_EINVAL, std::string(where) + ": rank " + std::to_string(p) +
+                                                    " disagrees on whether there are sensitive overlaps");
+        }
+    }
+    mg->verdict_shared = false;
     return RALA_HIP_OK;
 }
 
@@ -188,10 +199,10 @@ int run_primary(rala_hip_mg* mg, bool with_sens) {
     int rc = from_ctx(mg, cs, rala_hip_dedupe(cs), "dedupe");
     std::vector<uint64_t> send_counts(P, 0);
     if (rc == RALA_HIP_OK) {
-        MGCHECK(mg->d_send.ensure(4 * std::max<uint64_t>(cs->n_ovl, 1) + 8));
-        rc = from_ctx(mg, cs, rala_hip_emit_bound_tuples_bucketed(cs, P, (uint64_t*)mg->d_send.p, send_counts.data()), "emit tuples");
+        if (mg->d_send.ensure(4 * std::max<uint64_t>(cs->n_ovl, 1) + 8) != hipSuccess) rc = mg_fail(mg, RALA_HIP_ENOMEM, "tuple buffer");
+        else rc = from_ctx(mg, cs, rala_hip_emit_bound_tuples_bucketed(cs, P, (uint64_t*)mg->d_send.p, send_counts.data()), "emit tuples");
     }
-    rc = agree(mg, rc, "emit");
+    rc = agree(mg, rc, "emit", with_sens ? 1u : 0u);
     if (rc != RALA_HIP_OK) return rc;
     lap(mg->tm.emit_ms);
 
@@ -235,6 +246,10 @@ int run_primary(rala_hip_mg* mg, bool with_sens) {
     RankTable base;
     uint64_t pool_total = 0;
     for (uint32_t p = 0; p < P; ++p) { base.v[p] = (uint32_t)pool_total; pool_total += pool_counts[p]; }
+    if (pool_total >= 0xFFFFFFF0ull) {          // (the same sum on every rank)
+        mg->verdict_shared = true;
+        return mg_fail(mg, RALA_HIP_ECAPACITY, "interval pools of all ranks exceed 32-bit slots");
+    }
     if (pool_total > cs->pool_cap) {
         cs->pool_cap = (uint32_t)pool_total + 1024;
         MGCHECK(cs->d_pool.ensure(cs->pool_cap));
@@ -246,12 +261,16 @@ int run_primary(rala_hip_mg* mg, bool with_sens) {
                        (const uint8_t*)mg->d_state_all.p, L, P, mg->n_reads, base, read_arrays(cs));
     rc = install_read_state(cs, pool_total);
     if (rc != RALA_HIP_OK && rc != RALA_HIP_EFILTERED) return from_ctx(mg, cs, rc, "install state");
-    if (rc == RALA_HIP_EFILTERED) return from_ctx(mg, cs, rc, "initialize");      // the same verdict on every rank
+    if (rc == RALA_HIP_EFILTERED) {                 // the same verdict on every rank
+        mg->verdict_shared = true;
+        return from_ctx(mg, cs, rc, "initialize");
+    }
     lap(mg->tm.gather_ms);
 
     // 5. second pass .. preprocess tail .. graph, sharded by slice where it is per overlap
-    rc = construct_stages(cs, comm, with_sens);
-    rc = agree(mg, from_ctx(mg, cs, rc, "construct"), "construct");
+    rc = from_ctx(mg, cs, construct_stages(cs, comm, with_sens), "construct");
+    if (rc != RALA_HIP_OK) return rc;       // (local: the others may be inside one of its collectives - the caller aborts the group)
+    rc = agree(mg, rc, "construct");
     if (rc != RALA_HIP_OK) return rc;
     lap(mg->tm.construct_ms);
     return RALA_HIP_OK;
@@ -336,19 +355,21 @@ int rala_hip_mg_set_overlaps(rala_hip_mg* mg, const rala_hip_overlaps* slice, ui
 }
 
 // Cut points of the overlap file: world + 1 positions, every cut at the start of a run of equal
-// a_id.  Records whose query does not resolve (RALA_HIP_NO_READ) neither start nor end a run
-// (graph.cpp:343-350 skips them), so a cut never falls between X, <unresolved>, X.
-int rala_hip_mg_slice_cuts(const uint32_t* a_id, uint64_t n, uint32_t world, uint64_t* cuts) {
+// a_id.  Records that do not resolve - query OR target unknown (RALA_HIP_NO_READ) - neither start
+// nor end a run (graph.cpp:338-350: a failed transmute skips the record before the run logic
+// sees it), so a cut never falls between X, <unresolved>, X.  b_id may be NULL (targets all known).
+int rala_hip_mg_slice_cuts(const uint32_t* a_id, const uint32_t* b_id, uint64_t n, uint32_t world, uint64_t* cuts) {
     if (!cuts || world == 0 || (!a_id && n)) return RALA_HIP_EINVAL;
+    auto skipped = [&](uint64_t i) { return a_id[i] == RALA_HIP_NO_READ || (b_id && b_id[i] == RALA_HIP_NO_READ); };
     cuts[0] = 0;
     for (uint32_t k = 1; k < world; ++k) {
         uint64_t i = std::max(cuts[k - 1], n / world * k + std::min<uint64_t>(k, n % world));
-        // the resolved query in front of position i
+        // the resolved record in front of position i
         while (i < n) {
             if (i == 0) break;
-            if (a_id[i] == RALA_HIP_NO_READ) { ++i; continue; }
+            if (skipped(i)) { ++i; continue; }
             uint64_t j = i;
-            while (j > 0 && a_id[j - 1] == RALA_HIP_NO_READ) --j;
+            while (j > 0 && skipped(j - 1)) --j;
             if (j == 0 || a_id[j - 1] != a_id[i]) break;      // a new run starts at i
             ++i;
         }
@@ -358,19 +379,21 @@ int rala_hip_mg_slice_cuts(const uint32_t* a_id, uint64_t n, uint32_t world, uin
     return RALA_HIP_OK;
 }
 
-int rala_hip_mg_run(rala_hip_mg* mg, const rala_hip_overlaps* sens_slice, uint64_t n_sens, uint32_t* n_pairs) {
-    if (!mg || !n_pairs) return RALA_HIP_EINVAL;
-    if (!mg->have_reads || !mg->have_overlaps) return mg_fail(mg, RALA_HIP_EINVAL, "set reads and overlaps first");
+namespace {
+
+int run_all(rala_hip_mg* mg, const rala_hip_overlaps* sens_slice, uint64_t n_sens, uint32_t* n_pairs) {
     MGCHECK(hipSetDevice(mg->device));
     mg->tm = rala_hip_mg_timings();
     const double t0 = now_ms();
     int rc = run_primary(mg, sens_slice != nullptr);
     if (rc != RALA_HIP_OK) return rc;
     if (sens_slice != nullptr) {
-        // collective: a rank whose share is empty still takes part (every rank passes a non-null pointer or none does)
+        // collective: a rank whose share is empty still takes part (every rank passes a non-null
+        // pointer or none does; the first agree() of the run checked that)
         const double t2 = now_ms();
-        rc = repeats_stage(mg->cs, mg->cl, mg->comm, sens_slice, n_sens);
-        rc = agree(mg, from_ctx(mg, mg->cs, rc, "sensitive pass"), "sensitive pass");
+        rc = from_ctx(mg, mg->cs, repeats_stage(mg->cs, mg->cl, mg->comm, sens_slice, n_sens), "sensitive pass");
+        if (rc != RALA_HIP_OK) return rc;
+        rc = agree(mg, rc, "sensitive pass");
         if (rc != RALA_HIP_OK) return rc;
         mg->tm.repeats_ms = (float)(now_ms() - t2);
     }
@@ -380,6 +403,21 @@ int rala_hip_mg_run(rala_hip_mg* mg, const rala_hip_overlaps* sens_slice, uint64
     mg->tm.tr_ms = (float)(now_ms() - t1);
     mg->tm.total_ms = (float)(now_ms() - t0);
     return RALA_HIP_OK;
+}
+
+}  // namespace
+
+// A failure every rank knows of (agree(), the all-filtered verdict) just returns.  Any other one is
+// this rank's alone - an allocation, a kernel, a copy - and the next collective of the others
+// would wait for this rank for ever: the group is aborted instead (Comm::abort), every rank's run
+// fails, the rank objects are of no use afterwards.
+int rala_hip_mg_run(rala_hip_mg* mg, const rala_hip_overlaps* sens_slice, uint64_t n_sens, uint32_t* n_pairs) {
+    if (!mg || !n_pairs) return RALA_HIP_EINVAL;
+    if (!mg->have_reads || !mg->have_overlaps) return mg_fail(mg, RALA_HIP_EINVAL, "set reads and overlaps first");
+    mg->verdict_shared = false;
+    const int rc = run_all(mg, sens_slice, n_sens, n_pairs);
+    if (rc != RALA_HIP_OK && !mg->verdict_shared) mg->comm->abort();
+    return rc;
 }
 
 int rala_hip_mg_run_threads(rala_hip_mg** ranks, uint32_t n, const rala_hip_overlaps* sens_slices, const uint64_t* n_sens,
@@ -408,6 +446,11 @@ rala_hip_ctx* rala_hip_mg_owner_context(rala_hip_mg* mg) { return mg ? mg->cl : 
 int rala_hip_mg_get_pile_data(rala_hip_mg* mg, uint64_t read, uint16_t* data) {
     if (!mg || !data) return RALA_HIP_EINVAL;
     if (read >= mg->n_reads || read % mg->world != mg->rank) return mg_fail(mg, RALA_HIP_EINVAL, "the read's pile lives on rank read % world");
+    struct DeviceGuard {                // the caller's current device is the caller's business
+        int before = -1;
+        DeviceGuard() { if (hipGetDevice(&before) != hipSuccess) before = -1; }
+        ~DeviceGuard() { if (before >= 0) (void)hipSetDevice(before); }
+    } guard;
     MGCHECK(hipSetDevice(mg->device));
     // the owner's context keeps the coverage; the valid region that applies is the final one
     const uint64_t j = read / mg->world;

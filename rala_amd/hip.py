@@ -123,7 +123,7 @@ def lib(build=True):
         L.rala_hip_mg_last_error.argtypes = [vp]
         L.rala_hip_mg_last_error.restype = ctypes.c_char_p
         L.rala_hip_mg_set_reads.argtypes = [vp, vp, u64]
-        L.rala_hip_mg_slice_cuts.argtypes = [vp, u64, u32, vp]
+        L.rala_hip_mg_slice_cuts.argtypes = [vp, vp, u64, u32, vp]
         L.rala_hip_mg_set_overlaps.argtypes = [vp, ctypes.POINTER(OverlapsC), u64, u64, i32]
         L.rala_hip_mg_run.argtypes = [vp, ctypes.POINTER(OverlapsC), u64, ctypes.POINTER(u32)]
         L.rala_hip_mg_run_threads.argtypes = [vp, u32, vp, vp, ctypes.POINTER(u32)]
@@ -375,11 +375,14 @@ class Context:
         return int(n.value)
 
 
-def slice_cuts(a_id, world):
-    """rala_hip_mg_slice_cuts: world + 1 file positions, cuts on a_id-run boundaries"""
+def slice_cuts(a_id, world, b_id=None):
+    """rala_hip_mg_slice_cuts: world + 1 file positions, cuts on a_id-run boundaries (records whose
+    query or target is NO_READ do not break a run)"""
     a = np.ascontiguousarray(a_id, dtype=np.uint32)
+    b = None if b_id is None else np.ascontiguousarray(b_id, dtype=np.uint32)
     cuts = np.zeros(world + 1, dtype=np.uint64)
-    rc = lib().rala_hip_mg_slice_cuts(a.ctypes.data if len(a) else None, len(a), world, cuts.ctypes.data)
+    rc = lib().rala_hip_mg_slice_cuts(a.ctypes.data if len(a) else None, b.ctypes.data if b is not None and len(b) else None,
+                                      len(a), world, cuts.ctypes.data)
     if rc != 0:
         raise RalaHipError(rc, "slice_cuts")
     return [int(c) for c in cuts]
@@ -439,7 +442,7 @@ class ShardedRank:
 
     def run(self, sens_slice=None):
         n = ctypes.c_uint32(0)
-        if sens_slice is not None and len(sens_slice):
+        if sens_slice is not None:          # an EMPTY share still takes part in the collective sensitive pass
             c = _soa(sens_slice)
             self._check(self.L.rala_hip_mg_run(self.h, ctypes.byref(c), len(sens_slice), ctypes.byref(n)))
         else:
@@ -493,6 +496,25 @@ def run_ranks(ranks, sens_slices=None):
     n = len(ranks)
     arr = (ctypes.c_void_p * n)(*[r.h for r in ranks])
     pairs = ctypes.c_uint32(0)
+    if sens_slices is not None and any(s is None for s in sens_slices):
+        # (tests) ranks that disagree on whether there is a sensitive pass: one Python thread per rank
+        import threading
+        rcs = [0] * n
+
+        def one(k):
+            try:
+                ranks[k].run(sens_slices[k])
+            except RalaHipError as e:
+                rcs[k] = e
+        th = [threading.Thread(target=one, args=(k,)) for k in range(n)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        bad = [e for e in rcs if e != 0]
+        if bad:
+            raise bad[0]
+        return 0
     if sens_slices is not None:
         cs = (OverlapsC * n)(*[_soa(s) for s in sens_slices])
         ns = (ctypes.c_uint64 * n)(*[len(s) for s in sens_slices])

@@ -146,9 +146,11 @@ private:
 };
 
 int run(const Settings& st) {
-    if (st.gpus > 1) {
+    {
+        // rala::Graph reads it when it opens its devices; st.gpus is the environment's value unless
+        // --gpus was given, which wins (also --gpus 1 over RALA_GPUS=4)
         const std::string n = std::to_string(st.gpus);
-        setenv("RALA_GPUS", n.c_str(), 1);          // rala::Graph reads it when it opens its devices
+        setenv("RALA_GPUS", n.c_str(), 1);
     }
     std::unique_ptr<rala::Graph> graph = rala::createGraph(st.sequences, st.overlaps, st.threads);
     graph->construct(st.sensitive_overlaps);

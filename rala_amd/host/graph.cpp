@@ -219,7 +219,7 @@ void Graph::initialize() {
         // equal queries); the stages themselves run in construct(), all ranks together
         const uint32_t P = (uint32_t)ranks_.size();
         std::vector<uint64_t> cuts(P + 1);
-        rala_hip_mg_slice_cuts(overlaps_.a_id.data(), overlaps_.size(), P, cuts.data());
+        rala_hip_mg_slice_cuts(overlaps_.a_id.data(), overlaps_.b_id.data(), overlaps_.size(), P, cuts.data());
         for (uint32_t k = 0; k < P; ++k) {
             const uint64_t lo = cuts[k];
             rala_hip_overlaps sl = {overlaps_.a_id.data() + lo, overlaps_.b_id.data() + lo, overlaps_.a_begin.data() + lo,

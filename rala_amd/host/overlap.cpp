@@ -31,55 +31,65 @@ std::unique_ptr<Overlap> createOverlap(uint64_t a_id, uint64_t b_id, uint32_t a_
     return o;
 }
 
+namespace {
+
+// One end of a record while it is being resolved: PAF records arrive with names, MHAP records with
+// ids.  The references point into the Overlap that is transmuted.
+struct End {
+    std::string& name;
+    uint64_t& id;
+    uint32_t& length;
+};
+
+// name -> id, once; the name's storage is given back (an id is all the graph needs from here on)
+bool resolve(End e, const std::unordered_map<std::string, uint64_t>& ids) {
+    if (e.name.empty()) return true;
+    const auto hit = ids.find(e.name);
+    if (hit == ids.end()) return false;
+    e.id = hit->second;
+    e.name.clear();
+    e.name.shrink_to_fit();
+    return true;
+}
+
+const Pile* pile_of(const std::vector<std::unique_ptr<Pile>>& piles, uint64_t id) {
+    return id < piles.size() ? piles[id].get() : nullptr;
+}
+
+}  // namespace
+
+// reference src/overlap.cpp:36-82: false = drop the record (unknown name, read filtered out),
+// fatal when the overlap file and the sequence file disagree on a read's length
 bool Overlap::transmute(const std::vector<std::unique_ptr<Pile>>& piles,
     const std::unordered_map<std::string, uint64_t>& name_to_id) {
     if (is_transmuted_) return true;
-    if (!a_name_.empty()) {
-        auto it = name_to_id.find(a_name_);
-        if (it == name_to_id.end()) return false;
-        a_id_ = it->second;
-        std::string().swap(a_name_);
-    }
-    if (a_id_ >= piles.size() || piles[a_id_] == nullptr) return false;
-    if (a_length_ != piles[a_id_]->data().size()) {
-        fprintf(stderr, "[rala::Overlap::transmute] error: "
-            "unequal lengths in sequence and overlap file for sequence with id %lu!\n", a_id_);
-        exit(1);
-    }
-    if (!b_name_.empty()) {
-        auto it = name_to_id.find(b_name_);
-        if (it == name_to_id.end()) return false;
-        b_id_ = it->second;
-        std::string().swap(b_name_);
-    }
-    if (b_id_ >= piles.size() || piles[b_id_] == nullptr) return false;
-    if (b_length_ != piles[b_id_]->data().size()) {
-        fprintf(stderr, "[rala::Overlap::transmute] error: "
-            "unequal lengths in sequence and overlap file for sequence with id %lu!\n", b_id_);
-        exit(1);
+    for (End e : {End{a_name_, a_id_, a_length_}, End{b_name_, b_id_, b_length_}}) {
+        if (!resolve(e, name_to_id)) return false;
+        const Pile* pile = pile_of(piles, e.id);
+        if (pile == nullptr) return false;
+        if (pile->data().size() != e.length) {
+            fprintf(stderr, "[rala::Overlap::transmute] error: "
+                "unequal lengths in sequence and overlap file for sequence with id %lu!\n", e.id);
+            exit(1);
+        }
     }
     is_transmuted_ = true;
     return true;
 }
 
+// reference src/overlap.cpp:84-114 (sensitive overlaps): no length check, the target side moves
+// from valid-region coordinates to read coordinates
 bool Overlap::transmute_(const std::vector<std::unique_ptr<Pile>>& piles,
     const std::unordered_map<std::string, uint64_t>& name_to_id) {
     if (is_transmuted_) return true;
-    if (!a_name_.empty()) {
-        auto it = name_to_id.find(a_name_);
-        if (it == name_to_id.end()) return false;
-        a_id_ = it->second;
-        std::string().swap(a_name_);
-    }
-    if (!b_name_.empty()) {
-        auto it = name_to_id.find(b_name_);
-        if (it == name_to_id.end()) return false;
-        b_id_ = it->second;
-        std::string().swap(b_name_);
-    }
-    b_begin_ += piles[b_id_]->begin();
-    b_end_ += piles[b_id_]->begin();
-    b_length_ = piles[b_id_]->data().size();
+    if (!resolve(End{a_name_, a_id_, a_length_}, name_to_id)) return false;
+    if (!resolve(End{b_name_, b_id_, b_length_}, name_to_id)) return false;
+    const Pile* target = pile_of(piles, b_id_);
+    if (target == nullptr) return false;
+    const uint32_t shift = target->begin();
+    b_begin_ += shift;
+    b_end_ += shift;
+    b_length_ = (uint32_t)target->data().size();
     is_transmuted_ = true;
     return true;
 }

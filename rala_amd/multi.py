@@ -1,4 +1,6 @@
-"""One process per GPU (bench.py under torchrun): Python side of the sharded run.
+"""Python side of the sharded run: one process per GPU (bench.py under torchrun, ShardedRunner) or
+all ranks as host threads of this process (bare `bench.py --gpus N`, ThreadedRunner - what
+`rala --gpus N` does in C++, rala_amd/host/graph.cpp).
 
 The data path is C++ (rala_amd/csrc/sharded.hip: rala_hip_mg_*, RCCL called directly on the
 context's stream).  What is left for Python when every rank is its own process:
@@ -12,6 +14,8 @@ The same two steps run under gloo with world size 2 in the CPU test-suite
 (tests/test_multi_cpu.py); the collectives themselves need GPUs and are covered by the rank
 simulation of tests/test_gpu_sharded.py.
 """
+import threading
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -60,7 +64,7 @@ class ShardedRunner:
         self.hip = hip
         self.rank, self.world = rank, world
         ov = ds.overlaps
-        self.cuts = hip.slice_cuts(ov.a_id, world)
+        self.cuts = hip.slice_cuts(ov.a_id, world, ov.b_id)
         lo, hi = my_slice(self.cuts, rank)
         err = None
         try:
@@ -77,15 +81,7 @@ class ShardedRunner:
 
     def step(self):
         n_tr = self.mg.run()
-        tm = dict(self.mg.timings())
-        tm.update({"owner_" + k: v for k, v in self.mg.owner_timings().items()
-                   if k in ("dedupe_ms", "bucket_ms", "pile_ms", "pile_launches", "pile_overflow_reads", "pile_position_reads")})
-        tm.update({k: v for k, v in self.mg.context().timings().items()
-                   if k in ("classify_ms", "death_ms", "finish_ms", "tail_host_ms", "death_rounds")})
-        tm["pile_ms"] = tm.get("owner_pile_ms", 0.0)
-        tm["bucket_ms"] = tm.get("owner_bucket_ms", 0.0)
-        tm["dedupe_ms"] = 0.0
-        self._tm = tm
+        self._tm = rank_timings(self.mg)
         return n_tr
 
     def timings(self):
@@ -93,3 +89,90 @@ class ShardedRunner:
 
     def close(self):
         self.mg.close()
+
+
+_STAGE_KEYS = ("dedupe_ms", "bucket_ms", "pile_ms", "pile_launches", "pile_overflow_reads", "pile_position_reads")
+_CONSTRUCT_KEYS = ("classify_ms", "death_ms", "finish_ms", "tail_host_ms", "death_rounds")
+
+
+def rank_timings(mg):
+    """one rank's stage timings in the names bench.py's single-GPU line uses"""
+    tm = dict(mg.timings())
+    tm.update({"owner_" + k: v for k, v in mg.owner_timings().items() if k in _STAGE_KEYS})
+    tm.update({k: v for k, v in mg.context().timings().items() if k in _CONSTRUCT_KEYS})
+    tm["pile_ms"] = tm.get("owner_pile_ms", 0.0)
+    tm["bucket_ms"] = tm.get("owner_bucket_ms", 0.0)
+    tm["dedupe_ms"] = 0.0
+    return tm
+
+
+class ThreadedRunner:
+    """All ranks in THIS process, one host thread per rank / GPU (no launcher needed).
+
+    transport "rccl": every rank joins one RCCL communicator (ncclCommInitRank is collective, so
+    the rank objects are created on threads of their own; ctypes releases the GIL inside the
+    call).  transport "local": the in-process transport (peer copies between the devices; also
+    several ranks on one device, devices = [0, 0, ...]).  A step is rala_hip_mg_run_threads."""
+
+    def __init__(self, ds, world, devices=None, transport="rccl"):
+        from . import hip
+
+        self.hip = hip
+        self.world = world
+        self.transport = transport
+        devices = list(devices) if devices is not None else list(range(world))
+        assert len(devices) == world
+        ov = ds.overlaps
+        self.cuts = hip.slice_cuts(ov.a_id, world, ov.b_id)
+        self._group = None
+        if transport == "local":
+            self._group = hip.LocalGroup(world)
+            token = self._group
+        elif transport == "rccl":
+            token = hip.unique_id()
+        else:
+            raise ValueError("transport is 'rccl' or 'local'")
+        self.ranks = [None] * world
+        self._slices = [None] * world
+        errs = [None] * world
+
+        def make(k):
+            try:
+                mg = hip.ShardedRank(devices[k], k, world, token)
+                self.ranks[k] = mg
+                mg.set_reads(ds.read_len)
+                lo, hi = my_slice(self.cuts, k)
+                self._slices[k] = ov.take(slice(lo, hi))
+                mg.set_overlaps(self._slices[k], lo)
+            except Exception as e:      # noqa: BLE001 - reported below, for all ranks together
+                errs[k] = e
+
+        th = [threading.Thread(target=make, args=(k,)) for k in range(world)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        bad = [(k, e) for k, e in enumerate(errs) if e is not None]
+        if bad:
+            self.close()
+            raise RuntimeError("sharded set-up failed: " + "; ".join("rank %d: %s" % (k, e) for k, e in bad))
+        self._tm = {}
+
+    def step(self, sens_slices=None):
+        n_tr = self.hip.run_ranks(self.ranks, sens_slices)
+        per_rank = [rank_timings(mg) for mg in self.ranks]
+        # the slowest rank's figure per stage (the step waits for it)
+        self._tm = {k: max(float(t.get(k, 0.0)) for t in per_rank) for k in per_rank[0]}
+        return n_tr
+
+    def timings(self):
+        return self._tm
+
+    def close(self):
+        for mg in self.ranks:
+            if mg is not None:
+                mg.close()
+        self.ranks = []
+        if self._group is not None:
+            self._group.close()
+            self._group = None

@@ -22,7 +22,7 @@ class Sharded:
         self.group = hip.LocalGroup(world) if token is None else None
         self.ranks = []
         ov = ds.overlaps
-        self.cuts = hip.slice_cuts(ov.a_id, world)
+        self.cuts = hip.slice_cuts(ov.a_id, world, ov.b_id)
         for k in range(world):
             r = hip.ShardedRank(device, k, world, self.group if token is None else token)
             self.ranks.append(r)
@@ -149,6 +149,89 @@ def test_sharded_everything_filtered_is_the_same_error_everywhere(sharded_factor
     with pytest.raises(hip.RalaHipError) as e:
         sh.run()
     assert e.value.code == -4
+
+
+def test_one_ranks_failure_releases_the_others(sharded_factory):
+    """A failure that only ONE rank sees, between two collectives (here: at the start of the second
+    overlap pass, whose first collective the others have already entered), must not leave the others
+    waiting for ever: the failing rank aborts the group and every rank's run returns an error."""
+    import threading
+
+    ds = Dataset(1000, 200_000, 1)
+    sh = sharded_factory(ds, 3)
+    sh.ranks[1].context().set_option("debug_fail_construct", 1)
+    result = {}
+
+    def go():
+        try:
+            sh.run()
+            result["rc"] = "ok"
+        except hip.RalaHipError as e:
+            result["rc"] = str(e)
+
+    t = threading.Thread(target=go, daemon=True)
+    t.start()
+    t.join(120)
+    assert not t.is_alive(), "the surviving ranks hang"
+    assert result["rc"] != "ok"
+    assert "debug_fail_construct" in result["rc"] and "aborted" in result["rc"]
+
+
+def test_ranks_must_agree_on_the_sensitive_pass(sharded_factory):
+    """NULL on one rank and a (possibly empty) share on another is an error on every rank, not a hang;
+    an EMPTY share on some ranks is fine and gives the result of the unsharded run"""
+    ds = Dataset(5000, 1_000_000, 7)
+    ctx = hip.Context(0)
+    ctx.set_reads(ds.read_len)
+    ctx.set_overlaps(ds.overlaps)
+    ctx.initialize()
+    ctx.construct()
+    p = ctx.piles()
+    sens = ds.sensitive(p["alive"], p["begin"], p["end"])
+    ctx.close()
+    one = hip.Context(0)
+    one.set_reads(ds.read_len)
+    one.set_overlaps(ds.overlaps)
+    one.initialize()
+    one.construct(sens)
+    want = one.remove_transitive_edges()
+    want_e = one.graph()
+    one.close()
+    sh = sharded_factory(ds, 3)
+    # every sensitive overlap on rank 0, empty shares on ranks 1 and 2
+    shares = [sens, sens.take(slice(0, 0)), sens.take(slice(0, 0))]
+    assert hip.run_ranks(sh.ranks, shares) == want
+    for r in sh.ranks:
+        g = r.context().graph()
+        for k in ("src", "dst", "len", "marked"):
+            parity.assert_same("edges." + k, g[k], want_e[k])
+    sh2 = sharded_factory(ds, 2)
+    with pytest.raises(hip.RalaHipError) as e:
+        hip.run_ranks(sh2.ranks, [sens, None])
+    assert "sensitive" in str(e.value)
+
+
+def test_threaded_runner_is_the_unsharded_result():
+    """bench.py's bare `--gpus N` path (multi.ThreadedRunner: rank objects created on threads of
+    their own, steps through rala_hip_mg_run_threads), here with the ranks sharing device 0"""
+    from rala_amd import multi
+
+    ds = Dataset(2000, 400_000, 11)
+    st = parity.oracle_stages(ds)
+    r = multi.ThreadedRunner(ds, 4, devices=[0, 0, 0, 0], transport="local")
+    try:
+        for _ in range(2):                       # a second step re-runs everything on the same objects
+            n_tr = r.step()
+            check_rank(r.ranks[0].context(), st, n_tr)
+            check_rank(r.ranks[3].context(), st, n_tr)
+        assert r.timings()["pile_ms"] > 0
+    finally:
+        r.close()
+    one = multi.ThreadedRunner(ds, 1, transport="rccl")     # RCCL joined from a thread, world of one
+    try:
+        check_rank(one.ranks[0].context(), st, one.step())
+    finally:
+        one.close()
 
 
 def test_sharded_run_through_rccl_world1(sharded_factory):

@@ -92,6 +92,12 @@ def test_slice_cuts_edge_cases():
     assert hip.slice_cuts(np.full(10, 3, dtype=np.uint32), 3) == [0, 10, 10, 10]          # one run cannot be cut
     a = np.array([1, NO_READ, 1, NO_READ, NO_READ, 1, 2, 2], dtype=np.uint32)
     assert hip.slice_cuts(a, 2) == [0, 6, 8]            # X, <unresolved>, X stays together
+    # a record whose TARGET does not resolve is skipped before the run logic as well (graph.cpp:338-350):
+    # X b1 | Y <unknown> | X b1 is one run of X
+    a = np.array([1, 1, 1, 2, 1, 1, 3, 3], dtype=np.uint32)
+    b = np.array([5, 6, 7, NO_READ, 5, 8, 9, 9], dtype=np.uint32)
+    assert hip.slice_cuts(a, 2, b) == [0, 6, 8]
+    assert hip.slice_cuts(a, 2) == [0, 4, 8]            # (without the targets the Y record starts a run)
     a = np.arange(16, dtype=np.uint32)
     assert hip.slice_cuts(a, 4) == [0, 4, 8, 12, 16]
     assert hip.slice_cuts(a, 1) == [0, 16]
