@@ -148,6 +148,10 @@ struct rala_hip_ctx {
     rala_hip::DevBuf<uint32_t> d_death[2];
     rala_hip::DevBuf<uint32_t> d_chunk[4];      // survivors per chunk (overlaps, internals) and their scans
     rala_hip::DevBuf<uint4> d_rec;              // packed per-read records of the second pass
+    rala_hip::DevBuf<uint8_t> d_crec;           // compact ones (valid region + flags, 4 or 8 bytes per read)
+    rala_hip::DevBuf<uint8_t> d_fate;           // per read after the containment scan: never dies | has hills << 1
+    rala_hip::DevBuf<uint64_t> d_scan_state;    // tile states of the single-pass scans (scan_pass.h)
+    rala_hip::DevBuf<uint32_t> d_counts;        // small device counters of the second pass and the tail
     rala_hip::DevBuf<uint32_t> d_surv_u32[8];
     rala_hip::DevBuf<uint8_t> d_surv_u8[2];
     rala_hip::DevBuf<uint8_t> d_list_block[2];  // sharded runs: this slice's packed survivors / all slices'
@@ -217,7 +221,7 @@ struct rala_hip_ctx {
     std::vector<uint8_t> dirty, ever_dirty;       // reads whose valid region changed (this round / ever)
     std::vector<uint32_t> dirty_list;
     rala_hip::DevBuf<uint32_t> d_cc_edges, d_cc_label;
-    rala_hip::DevBuf<uint32_t> d_tr[6];
+    rala_hip::DevBuf<uint32_t> d_tr[7];
     rala_hip::DevBuf<uint8_t> d_tr_marks;
     std::vector<rala_hip::HostOvl> overlaps, internals, scratch_ovl;
     std::vector<rala_hip::EdgePair> scratch_ep;

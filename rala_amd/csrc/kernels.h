@@ -143,17 +143,6 @@ struct ReadState {
     Interval* pool;
 };
 
-// classification byte per overlap
-enum : uint8_t {
-    kClsTypeMask = 0x07,
-    kClsOk = 0x08,         // valid, both piles alive after initialize, trim succeeded
-    kClsKillsA = 0x10,     // live overlap deletes read a (a contained, container not chimeric)
-    kClsKillsB = 0x20,
-    kClsLive = 0x40,       // survived the in-order death scan
-    kClsHills = 0x40,      // between classify and finish only: a or b carries chimeric hills
-    kClsSurvivor = 0x80,   // live, both reads survive, deletes nobody: goes on to preprocess
-};
-
 // suspect: n_reads bytes of scratch (queries whose runs are not strictly ordered by target)
 void launch_dedupe(const OvlSoA& o, uint32_t n_reads, uint8_t* suspect, uint8_t* valid, hipStream_t s);
 // Single-pass bucketing into fixed slots of `stride` events per read: the slot index comes
@@ -191,11 +180,16 @@ struct KillList {
     uint32_t* count;            // device counter, zeroed before classify
     uint32_t *ovl, *target, *keeper;
 };
-// per-read record of the second pass: {begin, end, n_pits | n_hills << 8 | alive << 16, pool slot}
-void launch_pack_reads(const ReadState& rs, uint32_t n_reads, uint4* rec, hipStream_t s);
-uint32_t pass2_chunks(uint64_t n_overlaps);     // workgroups (= chunk counters) of finish / gather
-// lo[n_reads], all ones on entry: lo[r] = the first overlap that would delete read r (the fixed point's first lower bound)
-void launch_classify(const OvlSoA& o, uint32_t n_reads, const uint8_t* valid, const uint4* rec, uint8_t* cls,
+// per-read records of the second pass: rec = {begin, end, n_pits | n_hills << 8 | alive << 16, pool slot};
+// crec = valid region + "chimeric" + "has hills" in 4 bytes (small_records: no read longer than 32767
+// bases) or 8; sure[r] = 0 for the reads that are gone already (sure is all ones on entry)
+size_t compact_record_bytes(bool small_records);
+void launch_pack_reads(const ReadState& rs, uint32_t n_reads, uint4* rec, void* crec, bool small_records, uint32_t* sure,
+                       hipStream_t s);
+uint32_t pass2_chunks(uint64_t n_overlaps);     // workgroups (= chunk counters) of survivor_masks / gather
+// lo[n_reads], all ones on entry: lo[r] = the first overlap that would delete read r (the fixed point's
+// first lower bound).  File positions are 1-based in the killer list and in lo / up / sure.
+void launch_classify(const OvlSoA& o, uint32_t n_reads, const uint8_t* valid, const void* crec, bool small_records,
                      const KillList& kl, uint32_t* lo, hipStream_t s);
 // containment fixed point on the killer list (overlap_kernels.hip): lo[t] = min(lo[t], i) over a
 // list; one decision round (sure killers -> sure[], undecided ones -> out)
@@ -206,17 +200,22 @@ void launch_death_decide(const KillList& in, const uint32_t* lo, const uint32_t*
 // *changed = 1 if the two differ anywhere; `older` is then filled with 0xFFFFFFFF (the next round's output)
 void launch_death_diff(uint32_t* older, const uint32_t* newer, uint32_t n, uint32_t* changed, hipStream_t s);
 void launch_death_tighten(const uint32_t* sure, uint32_t* up, uint32_t* lo, uint32_t n, hipStream_t s);
-void launch_finish_pass2(const OvlSoA& o, uint8_t* cls, const uint32_t* death, const uint4* rec, Interval* pool,
-                         uint32_t* chunk_ov, uint32_t* chunk_in, hipStream_t s);
-void launch_apply_death(const uint32_t* death, uint8_t* alive, uint32_t n_reads, hipStream_t s);
+// liveness + hill span counters + who survives (one mask word per 64 overlaps and kind, counts per chunk)
+void launch_survivor_masks(const OvlSoA& o, uint32_t n_reads, const uint8_t* valid, const uint8_t* fate, const uint32_t* death, const void* crec, bool small_records,
+                           const uint4* rec, Interval* pool, uint64_t* mask_ov, uint64_t* mask_in, uint32_t* chunk_ov,
+                           uint32_t* chunk_in, hipStream_t s);
+// alive[r] = 0 where death[r] is set; fate[r] = "never dies" | "has hills" << 1; *n_alive += the reads that are left
+void launch_apply_death(const uint32_t* death, uint8_t* alive, const uint8_t* n_hills, uint8_t* fate, uint32_t n_reads,
+                        uint32_t* n_alive, hipStream_t s);
 
 // survivors gathered into dense arrays (trim re-applied against the pass-1 piles)
 struct Survivors {
     uint32_t *src, *a_id, *b_id, *a_begin, *a_end, *b_begin, *b_end, *length;
     uint8_t *strand, *type;
 };
-void launch_gather_survivors(const OvlSoA& o, const uint8_t* cls, const uint4* rec, const uint32_t* chunk_ov_off,
-                             const uint32_t* chunk_in_off, uint32_t n_ov_total, const Survivors& out, hipStream_t s);
+void launch_gather_survivors(const OvlSoA& o, const uint64_t* mask_ov, const uint64_t* mask_in, const void* crec,
+                             bool small_records, const uint32_t* chunk_ov_off, const uint32_t* chunk_in_off, uint32_t n_ov_total,
+                             const Survivors& out, hipStream_t s);
 // sharded runs (one slice of the overlap file per rank)
 struct ListBlocks {             // the ranks' packed survivor blocks inside one gathered buffer
     uint64_t block_off[64];
@@ -266,10 +265,12 @@ void launch_finalize_states(const TailList& L, const uint8_t* alive, hipStream_t
 void launch_scatter_component_medians(const uint32_t* alive_reads, const uint8_t* touched, const uint16_t* cmed, uint32_t n_alive,
                                       uint16_t* out, hipStream_t s);
 void launch_break_hills(const TailReads& R, uint32_t n_reads, hipStream_t s);
+// gate: a device word; the kernel does nothing when it holds 0 (a round enqueued before the host knows whether
+// the loop goes on); *dropped is set to 1 if an overlap died
 void launch_break_pits(const TailReads& R, const uint32_t* alive_reads, const uint8_t* touched, const uint16_t* comp_median,
-                       uint32_t n_alive, hipStream_t s);
+                       uint32_t n_alive, hipStream_t s, const uint32_t* gate = nullptr);
 void launch_retrim(const TailList& L, const TailReads& R, uint32_t promote, uint32_t round, uint32_t* dropped,
-                   hipStream_t s);
+                   hipStream_t s, const uint32_t* gate = nullptr);
 void launch_cc_edges(const TailList& L, const uint32_t* rank, uint32_t* edges, uint8_t* touched, hipStream_t s);
 void launch_refresh_types(const TailList& L, const TailReads& R, hipStream_t s);
 void launch_tail_death_round(const TailList& L, const uint8_t* alive, uint32_t which, const uint32_t* death_old,
@@ -289,6 +290,20 @@ void launch_build_edges(const TailList& L, const TailReads& R, const uint32_t* k
 void launch_node_reads(const uint8_t* alive, const uint32_t* rank, uint32_t* node_read, uint32_t n, hipStream_t s);
 void launch_count_zero_u8(const uint8_t* x, uint32_t n, uint32_t* out, hipStream_t s);    // *out += #zeros
 void launch_init_list_state(uint8_t* state, uint8_t* round, uint32_t n0, uint32_t n, hipStream_t s);
+// the same + dirty[] = 0, n_pits0[] = n_pits[] in one launch
+void launch_tail_init(const TailList& L, uint32_t n0, const TailReads& R, uint8_t* n_pits0, uint32_t n_reads, hipStream_t s);
+// single-pass scans with producer and consumer inside (scan_pass.h); false = out of tile states
+struct ScanSpace;
+bool launch_rank_pass(const uint8_t* alive, uint32_t* rank, uint32_t* alive_reads, uint32_t n_reads, ScanSpace& space, hipStream_t s);
+bool launch_node_pass(const uint8_t* alive, uint32_t* node_rank, uint32_t* node_read, uint32_t* n_final, uint32_t n_reads,
+                      ScanSpace& space, hipStream_t s);
+// one segment of the final overlap list + its edges; base[0 .. 1] = kept items / dovetails in front of
+// the segment, next[0 .. 1] receives the same for the segment behind it
+bool launch_segment_pass(const TailList& L, const TailReads& R, uint32_t want_state, uint32_t want_round, uint32_t* base,
+                         uint32_t* next, uint32_t* kept_item, const uint32_t* node_rank, uint32_t* e_src, uint32_t* e_dst,
+                         uint32_t* e_len, ScanSpace& space, hipStream_t s);
+// out[i] = in[0] + .. + in[i - 1], out[n] = the sum; copy (may be null) receives out[0 .. n) as well
+bool launch_offsets_pass(const uint32_t* in, uint32_t* out, uint32_t* copy, uint32_t n, ScanSpace& space, hipStream_t s);
 
 // ---- scans (scan_kernels.hip) --------------------------------------------------
 // exclusive prefix sum of n uint32 values; out may alias in; out[n] receives the total

@@ -332,86 +332,180 @@ __device__ __forceinline__ Coords load_coords(const OvlSoA& o, uint64_t i) {
     return c;
 }
 
-// Static part of construct's second pass: everything about overlap i that does
-// not depend on which piles earlier overlaps deleted.
-// Per-read state of the second pass in one 16-byte record (one random access per read
-// instead of five): begin, end, n_pits | n_hills << 8 | alive << 16, first pool slot.
-__global__ __launch_bounds__(kBlock) void pack_reads_kernel(ReadState rs, uint32_t n, uint4* __restrict__ rec) {
+// ---- second overlap pass (graph.cpp:443-518), static part -----------------------------------
+// Per-read state in two tables:
+//   * rec[r]  = {begin, end, n_pits | n_hills << 8 | alive << 16, first pool slot}, 16 bytes - read only by
+//               the few overlaps that touch a read with chimeric hills (their span counters);
+//   * crec[r] = what trim / type / the containment rule need of a read - valid region, "has a chimeric
+//               region" (the container guard of graph.cpp:469-480), "has hills" - in ONE word when no read
+//               is longer than 32767 bases (two otherwise).  Every overlap looks up both of its reads: two
+//               random accesses into a table of 4 MB per million reads, which stays in each XCD's L2; the
+//               16-byte records (16 MB) did not, and every look-up moved a whole line from further out.
+// Positions in the overlap file are 1-based from here on (o.base + i + 1), so that 0 is a death value of
+// its own: "gone before the first overlap" = a read that find_valid_region dropped.
+template <bool kSmall>
+struct CRec;
+template <>
+struct CRec<true> {
+    typedef uint32_t word;
+    static __device__ __forceinline__ word pack(uint32_t b, uint32_t e, bool alive, bool chimeric, bool hills) {
+        return alive ? b | e << 15 | (chimeric ? 1u << 30 : 0u) | (hills ? 1u << 31 : 0u) : 0u;
+    }
+    word w;
+    __device__ __forceinline__ uint32_t begin() const { return w & 0x7FFFu; }
+    __device__ __forceinline__ uint32_t end() const { return (w >> 15) & 0x7FFFu; }
+    __device__ __forceinline__ bool alive() const { return end() != 0; }
+    __device__ __forceinline__ bool chimeric() const { return (w >> 30) & 1u; }
+    __device__ __forceinline__ bool hills() const { return w >> 31; }
+};
+template <>
+struct CRec<false> {
+    typedef uint2 word;
+    static __device__ __forceinline__ word pack(uint32_t b, uint32_t e, bool alive, bool chimeric, bool hills) {
+        return alive ? make_uint2(b, e | (chimeric ? 1u << 30 : 0u) | (hills ? 1u << 31 : 0u)) : make_uint2(0u, 0u);
+    }
+    word w;
+    __device__ __forceinline__ uint32_t begin() const { return w.x; }
+    __device__ __forceinline__ uint32_t end() const { return w.y & 0x3FFFFFFFu; }
+    __device__ __forceinline__ bool alive() const { return end() != 0; }
+    __device__ __forceinline__ bool chimeric() const { return (w.y >> 30) & 1u; }
+    __device__ __forceinline__ bool hills() const { return w.y >> 31; }
+};
+
+constexpr uint32_t kFateSurvives = 1, kFateHills = 2;      // fate[r]: the read outlives the containment scan / has chimeric hills
+
+// one thread per read: both tables, the reads that are gone already (death value 0)
+template <bool kSmall>
+__global__ __launch_bounds__(kBlock) void pack_reads_kernel(ReadState rs, uint32_t n, uint4* __restrict__ rec,
+                                                            typename CRec<kSmall>::word* __restrict__ crec,
+                                                            uint32_t* __restrict__ sure) {
     const uint32_t r = blockIdx.x * kBlock + threadIdx.x;
     if (r >= n) return;
-    rec[r] = make_uint4(rs.begin[r], rs.end[r], (uint32_t)rs.n_pits[r] | ((uint32_t)rs.n_hills[r] << 8) |
-                        ((uint32_t)(rs.alive[r] != 0) << 16), rs.iv_slot[r]);
+    const bool alive = rs.alive[r] != 0;
+    const uint32_t np = rs.n_pits[r], nh = rs.n_hills[r];
+    const uint32_t b = rs.begin[r], e = rs.end[r];
+    rec[r] = make_uint4(b, e, np | (nh << 8) | ((uint32_t)alive << 16), rs.iv_slot[r]);
+    crec[r] = CRec<kSmall>::pack(b, e, alive, (np | nh) != 0, nh != 0);
+    if (!alive) sure[r] = 0u;
 }
-__device__ __forceinline__ bool rec_alive(const uint4& r) { return (r.z >> 16) & 1u; }
 __device__ __forceinline__ uint32_t rec_pits(const uint4& r) { return r.z & 0xFFu; }
 __device__ __forceinline__ uint32_t rec_hills(const uint4& r) { return (r.z >> 8) & 0xFFu; }
 
-// A workgroup classifies a chunk of kClassifyChunk consecutive overlaps (8 per thread) and
-// appends those that would delete a read to the killer list {overlap, target, keeper}: slots
-// inside the chunk through an LDS counter (one add per wavefront and iteration), one global
-// add per workgroup.  The list order is irrelevant (the fixed point takes minima).
+// A workgroup looks at a chunk of kClassifyChunk consecutive overlaps (8 per thread).
 constexpr uint32_t kClassifyChunk = 2048;
 
-__global__ __launch_bounds__(kBlock) void classify_kernel(OvlSoA o, uint32_t n_reads,
-                                                          const uint8_t* __restrict__ valid,
-                                                          const uint4* __restrict__ rec,
-                                                          uint8_t* __restrict__ cls, KillList kl, uint32_t* lo) {
+// trim + type of overlap i against the pass-1 piles; what it would do: 0 nothing, 1 delete a, 2 delete b
+// (graph.cpp:464-483: a contained read goes unless its container has a chimeric region).  false = the
+// overlap is dropped (duplicate, a read gone, trim failed).
+template <bool kSmall>
+__device__ __forceinline__ bool classify_one(const OvlSoA& o, uint64_t i, const CRec<kSmall>& ra, const CRec<kSmall>& rb,
+                                             Coords& c, uint32_t& strand, uint32_t& type, uint32_t& kills) {
+    if (!ra.alive() || !rb.alive()) return false;
+    c = load_coords(o, i);
+    strand = o.strand[i];
+    if (!ovl_trim(c, strand, ra.begin(), ra.end(), rb.begin(), rb.end())) return false;
+    type = ovl_type(c, strand, ra.begin(), ra.end(), rb.begin(), rb.end());
+    kills = type == kTypeB && !rb.chimeric() ? 1u : type == kTypeA && !ra.chimeric() ? 2u : 0u;
+    return true;
+}
+
+// The overlaps that would delete a read go to the killer list {position, target, keeper}: slots inside
+// the chunk through an LDS counter (one add per wavefront and iteration), one global add per workgroup.
+// The list order is irrelevant (the fixed point takes minima).  Nothing else is kept of this pass: who
+// survives is decided once the deaths are known, by the few overlaps whose reads both live
+// (survivor_masks_kernel), which classify themselves again.
+// a column value that is read once: a streaming load that should not displace the per-read tables in the L2
+template <class T>
+__device__ __forceinline__ T stream_load(const T* p) { return __builtin_nontemporal_load(p); }
+
+// trim + type from values that are already in registers (see classify_one)
+template <bool kSmall>
+__device__ __forceinline__ bool classify_loaded(Coords& c, uint32_t strand, const CRec<kSmall>& ra, const CRec<kSmall>& rb,
+                                                uint32_t& type, uint32_t& kills) {
+    if (!ra.alive() || !rb.alive()) return false;
+    if (!ovl_trim(c, strand, ra.begin(), ra.end(), rb.begin(), rb.end())) return false;
+    type = ovl_type(c, strand, ra.begin(), ra.end(), rb.begin(), rb.end());
+    kills = type == kTypeB && !rb.chimeric() ? 1u : type == kTypeA && !ra.chimeric() ? 2u : 0u;
+    return true;
+}
+
+// The loads of an overlap depend on each other (validity -> ids -> the reads' records -> coordinates); taken
+// overlap by overlap, eight per thread, a wavefront spent its life waiting for one round trip after the
+// other (0.9 ms at C3 for 1.5 GB).  Here a thread issues ALL loads of its overlaps that do not depend on
+// data first, unconditionally (columns, at clamped indices), then all record look-ups, and only then
+// computes: two dependent round trips per kPer overlaps instead of four per overlap.
+template <bool kSmall>
+__global__ __launch_bounds__(kBlock) void classify_kernel(OvlSoA o, uint32_t n_reads, const uint8_t* __restrict__ valid,
+                                                          const typename CRec<kSmall>::word* __restrict__ crec,
+                                                          KillList kl, uint32_t* lo) {
     __shared__ uint32_t s_cnt, s_base;
     constexpr uint32_t kPer = kClassifyChunk / kBlock;
+    constexpr uint32_t kHalf = kPer / 2;
     const uint32_t lane = threadIdx.x & 63;
     if (threadIdx.x == 0) s_cnt = 0;
     __syncthreads();
-    uint32_t slot[kPer];
-    uint8_t res[kPer];
+    uint32_t slot[kPer], tgt[kPer], kpr[kPer];
+    uint32_t any = 0;
+    const uint64_t last = o.n - 1;
 #pragma unroll
-    for (uint32_t u = 0; u < kPer; ++u) {
-        const uint64_t i = (uint64_t)blockIdx.x * kClassifyChunk + u * kBlock + threadIdx.x;
-        uint8_t out = 0;
-        if (i < o.n && valid[i]) {
-            const uint32_t a = o.a_id[i], b = o.b_id[i];
-            const uint4 ra = rec[a], rb = rec[b];
-            if (rec_alive(ra) && rec_alive(rb)) {
-                Coords c = load_coords(o, i);
-                const uint32_t st = o.strand[i];
-                if (ovl_trim(c, st, ra.x, ra.y, rb.x, rb.y)) {
-                    const uint32_t t = ovl_type(c, st, ra.x, ra.y, rb.x, rb.y);
-                    out = (uint8_t)(kClsOk | t);
-                    if (t == kTypeB && (rb.z & 0xFFFFu) == 0) out |= kClsKillsA;
-                    if (t == kTypeA && (ra.z & 0xFFFFu) == 0) out |= kClsKillsB;
-                    // the finish pass needs the records of a and b only to count hill spans
-                    if (rec_hills(ra) | rec_hills(rb)) out |= kClsHills;
-                }
+    for (uint32_t h = 0; h < kPer; h += kHalf) {
+        uint32_t a[kHalf], b[kHalf], st[kHalf];
+        Coords c[kHalf];
+        bool ok[kHalf];
+        typename CRec<kSmall>::word wa[kHalf], wb[kHalf];
+#pragma unroll
+        for (uint32_t v = 0; v < kHalf; ++v) {
+            const uint64_t i = (uint64_t)blockIdx.x * kClassifyChunk + (h + v) * kBlock + threadIdx.x;
+            const uint64_t j = i < o.n ? i : last;
+            ok[v] = i < o.n && stream_load(valid + j);
+            a[v] = stream_load(o.a_id + j); b[v] = stream_load(o.b_id + j);
+            c[v].a_begin = stream_load(o.a_begin + j); c[v].a_end = stream_load(o.a_end + j);
+            c[v].b_begin = stream_load(o.b_begin + j); c[v].b_end = stream_load(o.b_end + j);
+            c[v].length = 0;                        // (Overlap::trim sets it; the file's column is not needed here)
+            st[v] = stream_load(o.strand + j);
+        }
+#pragma unroll
+        for (uint32_t v = 0; v < kHalf; ++v) {
+            // (records of unresolved names are never used: valid[] is 0 there)
+            wa[v] = crec[a[v] < n_reads ? a[v] : 0u];
+            wb[v] = crec[b[v] < n_reads ? b[v] : 0u];
+        }
+#pragma unroll
+        for (uint32_t v = 0; v < kHalf; ++v) {
+            const uint32_t u = h + v;
+            uint32_t kills = 0, t = 0;
+            CRec<kSmall> ra, rb;
+            ra.w = wa[v]; rb.w = wb[v];
+            if (!(ok[v] && classify_loaded<kSmall>(c[v], st[v], ra, rb, t, kills))) kills = 0;
+            tgt[u] = kills == 1 ? a[v] : b[v];
+            kpr[u] = kills == 1 ? b[v] : a[v];
+            const uint64_t m = __ballot(kills != 0);
+            uint32_t base = 0;
+            if (m) {
+                if (lane == 0) base = atomicAdd(&s_cnt, (uint32_t)__popcll(m));
+                base = (uint32_t)__shfl((int)base, 0, 64);
             }
+            slot[u] = kills ? base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)) : 0xFFFFFFFFu;
+            any |= kills;
         }
-        if (i < o.n) cls[i] = out;
-        res[u] = out;
-        const bool k = (out & (kClsKillsA | kClsKillsB)) != 0;
-        const uint64_t m = __ballot(k);
-        uint32_t base = 0;
-        if (m) {
-            if (lane == 0) base = atomicAdd(&s_cnt, (uint32_t)__popcll(m));
-            base = (uint32_t)__shfl((int)base, 0, 64);
-        }
-        slot[u] = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
     }
     __syncthreads();
     if (threadIdx.x == 0) s_base = s_cnt ? atomicAdd(kl.count, s_cnt) : 0u;
     __syncthreads();
+    if (!any) return;
     const uint32_t base = s_base;
 #pragma unroll
     for (uint32_t u = 0; u < kPer; ++u) {
-        if (!(res[u] & (kClsKillsA | kClsKillsB))) continue;
+        if (slot[u] == 0xFFFFFFFFu) continue;
         const uint64_t i = (uint64_t)blockIdx.x * kClassifyChunk + u * kBlock + threadIdx.x;
-        const uint32_t a = o.a_id[i], b = o.b_id[i];
         const uint32_t w = base + slot[u];
-        const uint32_t pos = (uint32_t)(o.base + i);   // position in the whole file (multi-GPU: slices)
-        const uint32_t target = (res[u] & kClsKillsA) ? a : b;
+        const uint32_t pos = (uint32_t)(o.base + i) + 1u;  // 1-based position in the whole file (multi-GPU: slices)
         kl.ovl[w] = pos;
-        kl.target[w] = target;
-        kl.keeper[w] = (res[u] & kClsKillsA) ? b : a;
+        kl.target[w] = tgt[u];
+        kl.keeper[w] = kpr[u];
         // the fixed point's first lower bound, everybody's first killer (death_lower_kernel over the
         // whole list: 0.13 ms of atomics at C3 - here they run beside this kernel's loads)
-        uint32_t* d = &lo[target];
+        uint32_t* d = &lo[tgt[u]];
         if (__hip_atomic_load(d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > pos) atomicMin(d, pos);
     }
 }
@@ -445,34 +539,49 @@ __global__ __launch_bounds__(kBlock) void death_decide_kernel(KillList in, const
     __shared__ uint32_t s_cnt, s_base;
     const uint32_t n = *in.count;
     const uint32_t lane = threadIdx.x & 63;
-    // grid-stride over chunks of one workgroup so that the append is aggregated per chunk
-    for (uint32_t k0 = blockIdx.x * kBlock; k0 < n; k0 += gridDim.x * kBlock) {
+    // Grid-stride over chunks of kPer items per thread so that the append is aggregated per chunk: ONE add
+    // to the list's counter per workgroup and chunk (adds to one word cost about 10 ns apiece wherever they
+    // come from - with a chunk of 256 the 12 000 adds of the first round were a third of its time).
+    constexpr uint32_t kPer = 8;
+    for (uint32_t k0 = blockIdx.x * kBlock * kPer; k0 < n; k0 += gridDim.x * kBlock * kPer) {
         if (threadIdx.x == 0) s_cnt = 0;
         __syncthreads();
-        const uint32_t k = k0 + threadIdx.x;
-        bool keep = false;
-        uint32_t i = 0, t = 0, kp = 0;
-        if (k < n) {
-            i = in.ovl[k]; t = in.target[k]; kp = in.keeper[k];
-            const uint32_t best = __hip_atomic_load(&sure[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (i < best) {
-                if (lo[kp] > i) atomicMin(&sure[t], i);
-                else if (up == nullptr || up[kp] > i) keep = true;
+        uint32_t iv[kPer], tv[kPer], kv[kPer], slot[kPer];
+#pragma unroll
+        for (uint32_t u = 0; u < kPer; ++u) {
+            const uint32_t k = k0 + u * kBlock + threadIdx.x;
+            const uint32_t kk = k < n ? k : n - 1;
+            iv[u] = in.ovl[kk]; tv[u] = in.target[kk]; kv[u] = in.keeper[kk];
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < kPer; ++u) {
+            const uint32_t k = k0 + u * kBlock + threadIdx.x;
+            bool keep = false;
+            if (k < n) {
+                const uint32_t i = iv[u], t = tv[u], kp = kv[u];
+                const uint32_t best = __hip_atomic_load(&sure[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (i < best) {
+                    if (lo[kp] > i) atomicMin(&sure[t], i);
+                    else if (up == nullptr || up[kp] > i) keep = true;
+                }
             }
+            const uint64_t m = __ballot(keep);
+            uint32_t base = 0;
+            if (m) {
+                if (lane == 0) base = atomicAdd(&s_cnt, (uint32_t)__popcll(m));
+                base = (uint32_t)__shfl((int)base, 0, 64);
+            }
+            slot[u] = keep ? base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)) : 0xFFFFFFFFu;
         }
-        const uint64_t m = __ballot(keep);
-        uint32_t slot = 0;
-        if (m) {
-            if (lane == 0) slot = atomicAdd(&s_cnt, (uint32_t)__popcll(m));
-            slot = (uint32_t)__shfl((int)slot, 0, 64);
-        }
-        slot += (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
         __syncthreads();
         if (threadIdx.x == 0) s_base = s_cnt ? atomicAdd(out.count, s_cnt) : 0u;
         __syncthreads();
-        if (keep) {
-            const uint32_t w = s_base + slot;
-            out.ovl[w] = i; out.target[w] = t; out.keeper[w] = kp;
+#pragma unroll
+        for (uint32_t u = 0; u < kPer; ++u) {
+            if (slot[u] != 0xFFFFFFFFu) {
+                const uint32_t w = s_base + slot[u];
+                out.ovl[w] = iv[u]; out.target[w] = tv[u]; out.keeper[w] = kv[u];
+            }
         }
         __syncthreads();
     }
@@ -501,130 +610,210 @@ __global__ __launch_bounds__(kBlock) void death_tighten_kernel(const uint32_t* _
     lo[i] = v;
 }
 
-// Liveness, hill span counters (Pile::check_chimeric_hills, pile.cpp:457-469,
-// including the begin_ double count) and the survivor bit.  A workgroup owns a chunk of
-// kClassifyChunk consecutive overlaps and reports how many of them survive as overlaps and
-// as internals; the gather kernel below re-derives every survivor's position from the scanned
-// chunk counts and wave ballots, so no per-overlap flag / position arrays exist.
-__global__ __launch_bounds__(kBlock) void finish_pass2_kernel(OvlSoA o, uint8_t* __restrict__ cls,
-                                                              const uint32_t* __restrict__ death,
-                                                              const uint4* __restrict__ rec, Interval* pool,
-                                                              uint32_t* __restrict__ chunk_ov,
-                                                              uint32_t* __restrict__ chunk_in) {
+// Liveness, hill span counters (Pile::check_chimeric_hills, pile.cpp:457-469, including the begin_
+// double count) and the survivors, once death[] is final.  An overlap at (1-based) position p is live
+// when neither of its reads died before p (death >= p; a read that was gone from the start has death 0).
+// What nearly every overlap needs of that is ONE BYTE per read (fate[]: "never dies", "has hills"; 1 MB
+// per million reads, which does stay in the L2 - random look-ups into the 4-byte death values came from
+// the memory-side cache, a whole line each: 0.5 ms at C3): only an overlap that touches a read with hills
+// and is live (counters), or whose reads BOTH never die (a survivor unless it is a containment that
+// deleted nobody because its container is chimeric - those stay out, graph.cpp:485-514), looks at the
+// death values, loads its coordinates and classifies itself again.  Per 64 overlaps one mask word of the survivors
+// that go on as overlaps and one of those that go on as internals (type kX); per chunk their numbers.
+// (lanes of ONE wavefront exchanging data through LDS: program order is enough for the hardware, the
+// fences keep the compiler from reordering)
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// One overlap in forty needs more than the two bytes, and a wavefront that takes them as they come has
+// such a lane in four iterations out of five: every one of its eight iterations then walks the long path
+// (death values -> records -> coordinates -> hill intervals, one round trip after the other) for one or
+// two lanes - 0.52 ms at C3, whatever the tables' size.  So the candidates of a wavefront's 512 overlaps
+// are noted in LDS first and then worked on side by side, one per lane: the long path once per
+// wavefront instead of eight times.
+template <bool kSmall>
+__global__ __launch_bounds__(kBlock) void survivor_masks_kernel(OvlSoA o, uint32_t n_reads, const uint8_t* __restrict__ valid,
+                                                                const uint8_t* __restrict__ fate,
+                                                                const uint32_t* __restrict__ death,
+                                                                const typename CRec<kSmall>::word* __restrict__ crec,
+                                                                const uint4* __restrict__ rec, Interval* pool,
+                                                                uint64_t* __restrict__ mask_ov, uint64_t* __restrict__ mask_in,
+                                                                uint32_t* __restrict__ chunk_ov,
+                                                                uint32_t* __restrict__ chunk_in) {
+    constexpr uint32_t kPer = kClassifyChunk / kBlock, kWaves = kBlock / 64;
     __shared__ uint32_t s_ov, s_in;
-    constexpr uint32_t kPer = kClassifyChunk / kBlock;
-    const uint32_t lane = threadIdx.x & 63;
+    __shared__ uint16_t s_list[kWaves][kPer * 64];
+    __shared__ unsigned long long s_mask[kWaves][2][kPer];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) { s_ov = 0; s_in = 0; }
+    if (lane < 2 * kPer) s_mask[wave][lane / kPer][lane % kPer] = 0ull;
     __syncthreads();
-    uint32_t n_ov = 0, n_in = 0;
-#pragma unroll 2
+    const uint64_t last = o.n - 1;
+    const uint64_t below = (1ull << lane) - 1ull;
+    // (all independent loads first, then the look-ups that depend on them - see classify_kernel)
+    uint32_t a[kPer], b[kPer];
+    bool ok[kPer];
+#pragma unroll
     for (uint32_t u = 0; u < kPer; ++u) {
         const uint64_t i = (uint64_t)blockIdx.x * kClassifyChunk + u * kBlock + threadIdx.x;
-        bool f_ov = false, f_in = false;
-        if (i < o.n) {
-            uint8_t c = cls[i];
-            if (c & kClsOk) {
-                const uint32_t a = o.a_id[i], b = o.b_id[i];
-                const uint32_t da = death[a], db = death[b];
-                const bool hills = (c & kClsHills) != 0;
-                c &= (uint8_t)~kClsHills;
-                const uint32_t at = (uint32_t)(o.base + i);     // position in the whole file
-                if (da >= at && db >= at) {
-                    c |= kClsLive;
-                    if (hills) {
-                        const uint4 ra = rec[a], rb = rec[b];
-                        const uint32_t nha = rec_hills(ra), nhb = rec_hills(rb);
-                        Coords k = load_coords(o, i);
-                        ovl_trim(k, o.strand[i], ra.x, ra.y, rb.x, rb.y);
-                        if (nha) {
-                            Interval* h = pool + ra.w + rec_pits(ra);
-                            const uint32_t x = ra.x + k.a_begin, y = ra.x + k.a_end;
-                            for (uint32_t q = 0; q < nha; ++q) {
-                                if (x < h[q].first && y > h[q].second) atomicAdd(&h[q].aux, 1u);
-                            }
-                        }
-                        if (nhb) {
-                            Interval* h = pool + rb.w + rec_pits(rb);
-                            const uint32_t x = rb.x + k.b_begin, y = rb.x + k.b_end;
-                            for (uint32_t q = 0; q < nhb; ++q) {
-                                if (x < h[q].first && y > h[q].second) atomicAdd(&h[q].aux, 1u);
-                            }
-                        }
-                    }
-                    const bool both_survive = da == kInf && db == kInf;
-                    if (both_survive && !(c & (kClsKillsA | kClsKillsB))) {
-                        c |= kClsSurvivor;
-                        if ((c & kClsTypeMask) == kTypeX) f_in = true; else f_ov = true;
-                    }
+        const uint64_t j = i < o.n ? i : last;
+        ok[u] = i < o.n && stream_load(valid + j);
+        a[u] = stream_load(o.a_id + j); b[u] = stream_load(o.b_id + j);
+    }
+    uint32_t fa[kPer], fb[kPer];
+#pragma unroll
+    for (uint32_t u = 0; u < kPer; ++u) {
+        fa[u] = fate[a[u] < n_reads ? a[u] : 0u];
+        fb[u] = fate[b[u] < n_reads ? b[u] : 0u];
+    }
+    uint32_t cnt = 0;           // candidates of this wavefront (the same in every lane)
+#pragma unroll
+    for (uint32_t u = 0; u < kPer; ++u) {
+        const bool both = (fa[u] & fb[u] & kFateSurvives) != 0;
+        const bool hills = ((fa[u] | fb[u]) & kFateHills) != 0;
+        const bool cand = ok[u] && (both | hills);
+        const uint64_t m = __ballot(cand);
+        if (cand) s_list[wave][cnt + (uint32_t)__popcll(m & below)] = (uint16_t)(u * 64u + lane);
+        cnt += (uint32_t)__popcll(m);
+    }
+    wave_lds_sync();
+    for (uint32_t k = lane; k < cnt; k += 64) {
+        const uint32_t e = s_list[wave][k];
+        const uint32_t u = e >> 6, l = e & 63u;
+        const uint64_t i = (uint64_t)blockIdx.x * kClassifyChunk + u * kBlock + wave * 64u + l;
+        const uint32_t ia = o.a_id[i], ib = o.b_id[i];
+        const uint32_t da = death[ia], db = death[ib];
+        const uint32_t at = (uint32_t)(o.base + i) + 1u;
+        if (!(da >= at && db >= at)) continue;
+        const bool both = da == kInf && db == kInf;
+        CRec<kSmall> ra, rb;
+        ra.w = crec[ia]; rb.w = crec[ib];
+        Coords c;
+        uint32_t st, t, kills;
+        if (!classify_one<kSmall>(o, i, ra, rb, c, st, t, kills)) continue;
+        if (ra.hills() | rb.hills()) {
+            const uint4 xa = rec[ia], xb = rec[ib];
+            const uint32_t nha = rec_hills(xa), nhb = rec_hills(xb);
+            if (nha) {
+                Interval* h = pool + xa.w + rec_pits(xa);
+                const uint32_t x = xa.x + c.a_begin, y = xa.x + c.a_end;
+                for (uint32_t q = 0; q < nha; ++q) {
+                    if (x < h[q].first && y > h[q].second) atomicAdd(&h[q].aux, 1u);
                 }
-                cls[i] = c;
+            }
+            if (nhb) {
+                Interval* h = pool + xb.w + rec_pits(xb);
+                const uint32_t x = xb.x + c.b_begin, y = xb.x + c.b_end;
+                for (uint32_t q = 0; q < nhb; ++q) {
+                    if (x < h[q].first && y > h[q].second) atomicAdd(&h[q].aux, 1u);
+                }
             }
         }
-        n_ov += (uint32_t)__popcll(__ballot(f_ov));
-        n_in += (uint32_t)__popcll(__ballot(f_in));
+        if (both && !kills) atomicOr(&s_mask[wave][t == kTypeX ? 1 : 0][u], 1ull << l);
     }
+    wave_lds_sync();
+    uint32_t n_ov = 0, n_in = 0;
+    if (lane < kPer) {
+        const uint64_t m_ov = s_mask[wave][0][lane], m_in = s_mask[wave][1][lane];
+        const uint64_t word = (uint64_t)blockIdx.x * (kClassifyChunk / 64) + lane * kWaves + wave;
+        if (word * 64 < o.n) { mask_ov[word] = m_ov; mask_in[word] = m_in; }
+        n_ov = (uint32_t)__popcll(m_ov);
+        n_in = (uint32_t)__popcll(m_in);
+    }
+    n_ov = wave_reduce(n_ov, OpAdd());
+    n_in = wave_reduce(n_in, OpAdd());
     if (lane == 0) { atomicAdd(&s_ov, n_ov); atomicAdd(&s_in, n_in); }
     __syncthreads();
     if (threadIdx.x == 0) { chunk_ov[blockIdx.x] = s_ov; chunk_in[blockIdx.x] = s_in; }
 }
 
+// the reads that the containment scan deleted; the number of reads that are left
 __global__ __launch_bounds__(kBlock) void apply_death_kernel(const uint32_t* __restrict__ death, uint8_t* alive,
-                                                             uint32_t n) {
-    const uint32_t r = blockIdx.x * kBlock + threadIdx.x;
-    if (r < n && death[r] != kInf) alive[r] = 0;
+                                                             const uint8_t* __restrict__ n_hills, uint8_t* __restrict__ fate,
+                                                             uint32_t n, uint32_t* n_alive) {
+    // (few workgroups, one add each: adds to ONE word cost about 10 ns apiece wherever they come from -
+    // one per wavefront of a million reads was 0.18 ms)
+    __shared__ uint32_t tmp[kBlock / 64 + 1];
+    uint32_t mine = 0;
+    for (uint32_t r = blockIdx.x * kBlock + threadIdx.x; r < n; r += gridDim.x * kBlock) {
+        const bool lives = death[r] == kInf;
+        if (!lives) alive[r] = 0;
+        fate[r] = (uint8_t)((lives ? kFateSurvives : 0u) | (n_hills[r] ? kFateHills : 0u));
+        mine += lives ? 1u : 0u;
+    }
+    mine = block_reduce<kBlock>(mine, OpAdd(), 0u, tmp);
+    if (threadIdx.x == 0 && mine) atomicAdd(n_alive, mine);
 }
 
-// Survivors into dense arrays in file order: overlaps from slot 0, internals from slot
-// n_ov_total (trim re-applied against the pass-1 piles).
-__global__ __launch_bounds__(kBlock) void gather_kernel(OvlSoA o, const uint8_t* __restrict__ cls,
-                                                        const uint4* __restrict__ rec,
+// Survivors into dense arrays in file order: overlaps from slot 0, internals from slot n_ov_total (trim
+// re-applied against the pass-1 piles).  The masks say who; a survivor's place comes from the scanned
+// chunk counts and the popcounts of the mask words in front of it.
+template <bool kSmall>
+__global__ __launch_bounds__(kBlock) void gather_kernel(OvlSoA o, const uint64_t* __restrict__ mask_ov,
+                                                        const uint64_t* __restrict__ mask_in,
+                                                        const typename CRec<kSmall>::word* __restrict__ crec,
                                                         const uint32_t* __restrict__ chunk_ov_off,
                                                         const uint32_t* __restrict__ chunk_in_off,
                                                         uint32_t n_ov_total, Survivors out) {
-    constexpr uint32_t kPer = kClassifyChunk / kBlock;
-    __shared__ uint32_t t_ov[kPer * 4 + 1], t_in[kPer * 4 + 1];
+    constexpr uint32_t kPer = kClassifyChunk / kBlock, kWaves = kBlock / 64;
+    __shared__ uint32_t t_ov[kPer * kWaves + 1], t_in[kPer * kWaves + 1];
+    __shared__ unsigned long long s_m[kWaves][2][kPer];
+    __shared__ uint16_t s_list[kWaves][kPer * 64];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint8_t c[kPer];
-    uint64_t m_ov[kPer], m_in[kPer];
-#pragma unroll
-    for (uint32_t u = 0; u < kPer; ++u) {
-        const uint64_t i = (uint64_t)blockIdx.x * kClassifyChunk + u * kBlock + threadIdx.x;
-        c[u] = i < o.n ? cls[i] : 0;
-        const bool sv = (c[u] & kClsSurvivor) != 0, x = (c[u] & kClsTypeMask) == kTypeX;
-        m_ov[u] = __ballot(sv && !x);
-        m_in[u] = __ballot(sv && x);
-        if (lane == 0) {
-            t_ov[u * 4 + wave] = (uint32_t)__popcll(m_ov[u]);
-            t_in[u * 4 + wave] = (uint32_t)__popcll(m_in[u]);
-        }
+    uint64_t any = 0;
+    if (lane < kPer) {
+        const uint64_t word = (uint64_t)blockIdx.x * (kClassifyChunk / 64) + lane * kWaves + wave;
+        const bool in = word * 64 < o.n;
+        const uint64_t mo = in ? mask_ov[word] : 0ull, mi = in ? mask_in[word] : 0ull;
+        s_m[wave][0][lane] = mo; s_m[wave][1][lane] = mi;
+        t_ov[lane * kWaves + wave] = (uint32_t)__popcll(mo);
+        t_in[lane * kWaves + wave] = (uint32_t)__popcll(mi);
+        any = mo | mi;
     }
+    any = __ballot(any != 0);
     __syncthreads();
     if (threadIdx.x < 2) {
         uint32_t* t = threadIdx.x ? t_in : t_ov;
         uint32_t run = threadIdx.x ? n_ov_total + chunk_in_off[blockIdx.x] : chunk_ov_off[blockIdx.x];
-        for (uint32_t q = 0; q < kPer * 4; ++q) { const uint32_t v = t[q]; t[q] = run; run += v; }
+        for (uint32_t q = 0; q < kPer * kWaves; ++q) { const uint32_t v = t[q]; t[q] = run; run += v; }
     }
     __syncthreads();
+    if (!any) return;
+    // the wavefront's survivors side by side, one per lane (see survivor_masks_kernel)
     const uint64_t below = (1ull << lane) - 1ull;
+    uint32_t cnt = 0;
 #pragma unroll
     for (uint32_t u = 0; u < kPer; ++u) {
-        if (!(c[u] & kClsSurvivor)) continue;
-        const uint64_t i = (uint64_t)blockIdx.x * kClassifyChunk + u * kBlock + threadIdx.x;
-        const bool x = (c[u] & kClsTypeMask) == kTypeX;
-        const uint32_t p = x ? t_in[u * 4 + wave] + (uint32_t)__popcll(m_in[u] & below)
-                             : t_ov[u * 4 + wave] + (uint32_t)__popcll(m_ov[u] & below);
+        const uint64_t m = s_m[wave][0][u] | s_m[wave][1][u];
+        if ((m >> lane) & 1ull) s_list[wave][cnt + (uint32_t)__popcll(m & below)] = (uint16_t)(u * 64u + lane);
+        cnt += (uint32_t)__popcll(m);
+    }
+    wave_lds_sync();
+    for (uint32_t k = lane; k < cnt; k += 64) {
+        const uint32_t e = s_list[wave][k];
+        const uint32_t u = e >> 6, l = e & 63u;
+        const uint64_t mo = s_m[wave][0][u], mi = s_m[wave][1][u];
+        const uint64_t before = (1ull << l) - 1ull;
+        const bool is_in = (mi >> l) & 1ull;
+        const uint32_t p = is_in ? t_in[u * kWaves + wave] + (uint32_t)__popcll(mi & before)
+                                 : t_ov[u * kWaves + wave] + (uint32_t)__popcll(mo & before);
+        const uint64_t i = (uint64_t)blockIdx.x * kClassifyChunk + u * kBlock + wave * 64u + l;
         const uint32_t a = o.a_id[i], b = o.b_id[i];
-        const uint4 ra = rec[a], rb = rec[b];
-        Coords k = load_coords(o, i);
-        const uint32_t st = o.strand[i];
-        ovl_trim(k, st, ra.x, ra.y, rb.x, rb.y);
+        CRec<kSmall> ra, rb;
+        ra.w = crec[a]; rb.w = crec[b];
+        Coords c;
+        uint32_t st = 0, t = 0, kills = 0;
+        (void)classify_one<kSmall>(o, i, ra, rb, c, st, t, kills);
         out.src[p] = (uint32_t)(o.base + i);
         out.a_id[p] = a; out.b_id[p] = b;
-        out.a_begin[p] = k.a_begin; out.a_end[p] = k.a_end;
-        out.b_begin[p] = k.b_begin; out.b_end[p] = k.b_end;
-        out.length[p] = k.length;
+        out.a_begin[p] = c.a_begin; out.a_end[p] = c.a_end;
+        out.b_begin[p] = c.b_begin; out.b_end[p] = c.b_end;
+        out.length[p] = c.length;
         out.strand[p] = (uint8_t)st;
-        out.type[p] = c[u] & kClsTypeMask;
+        out.type[p] = (uint8_t)t;
     }
 }
 
@@ -716,29 +905,34 @@ void launch_scatter_tuples(const uint2* tuples, uint64_t n, uint32_t n_reads, ui
                            hipStream_t s) {
     if (n) hipLaunchKernelGGL(scatter_tuples_kernel, grid_for(n), dim3(kBlock), 0, s, tuples, n, n_reads, cursor, ev);
 }
-void launch_pack_reads(const ReadState& rs, uint32_t n_reads, uint4* rec, hipStream_t s) {
-    if (n_reads) hipLaunchKernelGGL(pack_reads_kernel, grid_for(n_reads), dim3(kBlock), 0, s, rs, n_reads, rec);
+size_t compact_record_bytes(bool small_records) { return small_records ? 4 : 8; }
+void launch_pack_reads(const ReadState& rs, uint32_t n_reads, uint4* rec, void* crec, bool small_records, uint32_t* sure,
+                       hipStream_t s) {
+    if (!n_reads) return;
+    if (small_records) hipLaunchKernelGGL(pack_reads_kernel<true>, grid_for(n_reads), dim3(kBlock), 0, s, rs, n_reads, rec, (uint32_t*)crec, sure);
+    else hipLaunchKernelGGL(pack_reads_kernel<false>, grid_for(n_reads), dim3(kBlock), 0, s, rs, n_reads, rec, (uint2*)crec, sure);
 }
 uint32_t pass2_chunks(uint64_t n_overlaps) { return (uint32_t)((n_overlaps + kClassifyChunk - 1) / kClassifyChunk); }
-void launch_classify(const OvlSoA& o, uint32_t n_reads, const uint8_t* valid, const uint4* rec, uint8_t* cls,
+void launch_classify(const OvlSoA& o, uint32_t n_reads, const uint8_t* valid, const void* crec, bool small_records,
                      const KillList& kl, uint32_t* lo, hipStream_t s) {
-    if (o.n) {
-        hipLaunchKernelGGL(classify_kernel, dim3((uint32_t)((o.n + kClassifyChunk - 1) / kClassifyChunk)), dim3(kBlock), 0, s,
-                           o, n_reads, valid, rec, cls, kl, lo);
-    }
+    if (!o.n) return;
+    const dim3 grid(pass2_chunks(o.n));
+    if (small_records) hipLaunchKernelGGL(classify_kernel<true>, grid, dim3(kBlock), 0, s, o, n_reads, valid, (const uint32_t*)crec, kl, lo);
+    else hipLaunchKernelGGL(classify_kernel<false>, grid, dim3(kBlock), 0, s, o, n_reads, valid, (const uint2*)crec, kl, lo);
 }
 // the list length lives on the device: a grid sized for what the host knows of it strides over it
 // (4096 workgroups that find nothing to do still take 20 us to come and go)
-static uint32_t death_grid(uint64_t at_most) {
-    if (at_most >= 4096ull * kBlock) return 4096;
-    return (uint32_t)std::max<uint64_t>(1, (at_most + kBlock - 1) / kBlock);
+static uint32_t death_grid(uint64_t at_most, uint32_t per_thread = 1) {
+    const uint64_t per_block = (uint64_t)kBlock * per_thread;
+    if (at_most >= 4096ull * per_block) return 4096;
+    return (uint32_t)std::max<uint64_t>(1, (at_most + per_block - 1) / per_block);
 }
 void launch_death_lower(const KillList& kl, uint32_t* lo, hipStream_t s, uint64_t at_most) {
     hipLaunchKernelGGL(death_lower_kernel, dim3(death_grid(at_most)), dim3(kBlock), 0, s, kl, lo);
 }
 void launch_death_decide(const KillList& in, const uint32_t* lo, const uint32_t* up, uint32_t* sure, const KillList& out,
                          hipStream_t s, uint64_t at_most) {
-    hipLaunchKernelGGL(death_decide_kernel, dim3(death_grid(at_most)), dim3(kBlock), 0, s, in, lo, up, sure, out);
+    hipLaunchKernelGGL(death_decide_kernel, dim3(death_grid(at_most, 8)), dim3(kBlock), 0, s, in, lo, up, sure, out);
 }
 void launch_death_diff(uint32_t* older, const uint32_t* newer, uint32_t n, uint32_t* changed, hipStream_t s) {
     if (n) hipLaunchKernelGGL(death_diff_kernel, grid_for(n), dim3(kBlock), 0, s, older, newer, n, changed);
@@ -746,11 +940,17 @@ void launch_death_diff(uint32_t* older, const uint32_t* newer, uint32_t n, uint3
 void launch_death_tighten(const uint32_t* sure, uint32_t* up, uint32_t* lo, uint32_t n, hipStream_t s) {
     if (n) hipLaunchKernelGGL(death_tighten_kernel, grid_for(n), dim3(kBlock), 0, s, sure, up, lo, n);
 }
-void launch_finish_pass2(const OvlSoA& o, uint8_t* cls, const uint32_t* death, const uint4* rec, Interval* pool,
-                         uint32_t* chunk_ov, uint32_t* chunk_in, hipStream_t s) {
-    if (o.n) {
-        hipLaunchKernelGGL(finish_pass2_kernel, dim3(pass2_chunks(o.n)), dim3(kBlock), 0, s, o, cls, death, rec, pool,
-                           chunk_ov, chunk_in);
+void launch_survivor_masks(const OvlSoA& o, uint32_t n_reads, const uint8_t* valid, const uint8_t* fate, const uint32_t* death, const void* crec, bool small_records,
+                           const uint4* rec, Interval* pool, uint64_t* mask_ov, uint64_t* mask_in, uint32_t* chunk_ov,
+                           uint32_t* chunk_in, hipStream_t s) {
+    if (!o.n) return;
+    const dim3 grid(pass2_chunks(o.n));
+    if (small_records) {
+        hipLaunchKernelGGL(survivor_masks_kernel<true>, grid, dim3(kBlock), 0, s, o, n_reads, valid, fate, death, (const uint32_t*)crec, rec, pool,
+                           mask_ov, mask_in, chunk_ov, chunk_in);
+    } else {
+        hipLaunchKernelGGL(survivor_masks_kernel<false>, grid, dim3(kBlock), 0, s, o, n_reads, valid, fate, death, (const uint2*)crec, rec, pool,
+                           mask_ov, mask_in, chunk_ov, chunk_in);
     }
 }
 void launch_death_status(const uint32_t* count, uint32_t* status, hipStream_t s) {
@@ -766,13 +966,23 @@ void launch_unpack_lists(const uint8_t* blocks, const ListBlocks& lb, const Surv
     const uint32_t gx = (most + kBlock - 1) / kBlock;
     hipLaunchKernelGGL(unpack_lists_kernel, dim3(gx < 1024 ? gx : 1024, lb.world), dim3(kBlock), 0, s, blocks, lb, out);
 }
-void launch_apply_death(const uint32_t* death, uint8_t* alive, uint32_t n_reads, hipStream_t s) {
-    if (n_reads) hipLaunchKernelGGL(apply_death_kernel, grid_for(n_reads), dim3(kBlock), 0, s, death, alive, n_reads);
+void launch_apply_death(const uint32_t* death, uint8_t* alive, const uint8_t* n_hills, uint8_t* fate, uint32_t n_reads,
+                        uint32_t* n_alive, hipStream_t s) {
+    if (n_reads) {
+        const uint32_t blocks = std::min<uint32_t>(256, (n_reads + kBlock - 1) / kBlock);
+        hipLaunchKernelGGL(apply_death_kernel, dim3(blocks), dim3(kBlock), 0, s, death, alive, n_hills, fate, n_reads, n_alive);
+    }
 }
-void launch_gather_survivors(const OvlSoA& o, const uint8_t* cls, const uint4* rec, const uint32_t* chunk_ov_off,
-                             const uint32_t* chunk_in_off, uint32_t n_ov_total, const Survivors& out, hipStream_t s) {
-    if (o.n) {
-        hipLaunchKernelGGL(gather_kernel, dim3(pass2_chunks(o.n)), dim3(kBlock), 0, s, o, cls, rec, chunk_ov_off,
+void launch_gather_survivors(const OvlSoA& o, const uint64_t* mask_ov, const uint64_t* mask_in, const void* crec,
+                             bool small_records, const uint32_t* chunk_ov_off, const uint32_t* chunk_in_off, uint32_t n_ov_total,
+                             const Survivors& out, hipStream_t s) {
+    if (!o.n) return;
+    const dim3 grid(pass2_chunks(o.n));
+    if (small_records) {
+        hipLaunchKernelGGL(gather_kernel<true>, grid, dim3(kBlock), 0, s, o, mask_ov, mask_in, (const uint32_t*)crec, chunk_ov_off,
+                           chunk_in_off, n_ov_total, out);
+    } else {
+        hipLaunchKernelGGL(gather_kernel<false>, grid, dim3(kBlock), 0, s, o, mask_ov, mask_in, (const uint2*)crec, chunk_ov_off,
                            chunk_in_off, n_ov_total, out);
     }
 }

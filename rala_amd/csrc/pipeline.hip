@@ -16,6 +16,7 @@
 #include <numeric>
 
 #include "context.h"
+#include "scan_pass.h"
 #include "stages.h"
 
 using namespace rala_hip;
@@ -956,6 +957,8 @@ void build_graph(rala_hip_ctx* ctx) {
 }
 
 // transitive-edge marking on device edge arrays; marks stay in ctx->d_tr_marks
+int scan_space(rala_hip_ctx* ctx, uint32_t scans, uint64_t items, ScanSpace& sp);
+
 int tr_mark_device(rala_hip_ctx* ctx, uint32_t n_nodes, uint32_t n_edges, const uint32_t* d_src, const uint32_t* d_dst,
                    const uint32_t* d_len, uint32_t* n_pairs, Comm* comm = nullptr) {
     *n_pairs = 0;
@@ -973,10 +976,16 @@ int tr_mark_device(rala_hip_ctx* ctx, uint32_t n_nodes, uint32_t n_edges, const 
     // CSR on the device: out-degree count -> scan -> fill.  The fill order is arbitrary; the
     // candidate a->c is the edge with the highest id, which is the reference's "last one
     // in suffix_edges_" (graph.cpp:1291-1293, out-lists are in edge-id order there).
+    ScanSpace sp;
+    {
+        const int rc = scan_space(ctx, 1, n_nodes, sp);
+        if (rc != RALA_HIP_OK) return rc;
+    }
     launch_tr_degree(d_src, d_dst, n_nodes, n_edges, B[1].p, ctx->d_small.p + 2, s);
-    launch_exclusive_scan(B[1].p, B[0].p, n_nodes, ctx->d_scan_ws.p, s);
-    HIPCHECK(hipMemcpyAsync(B[1].p, B[0].p, (size_t)n_nodes * 4, hipMemcpyDeviceToDevice, s));
-    launch_tr_fill(d_src, d_dst, n_nodes, n_edges, B[1].p, B[2].p, s);
+    // row offsets (and the fill cursors, a second copy of them) from the out-degrees: one launch
+    HIPCHECK(B[3 + 3].ensure(n_nodes + 2));
+    if (!launch_offsets_pass(B[1].p, B[0].p, B[6].p, n_nodes, sp, s)) return fail(ctx, RALA_HIP_EDEVICE, "scan space");
+    launch_tr_fill(d_src, d_dst, n_nodes, n_edges, B[6].p, B[2].p, s);
     if (!comm) {
         launch_tr_mark(B[0].p, B[2].p, d_src, d_dst, d_len, n_nodes, 0, n_edges, ctx->d_tr_marks.p, s);
     } else {
@@ -1037,6 +1046,19 @@ TailReads tail_reads(rala_hip_ctx* ctx) {
     return R;
 }
 
+// tile states for the single-pass scans of one stage (scan_pass.h): `scans` scans of up to `items` items;
+// cleared (with the ticket counter behind them) by one fill
+int scan_space(rala_hip_ctx* ctx, uint32_t scans, uint64_t items, ScanSpace& sp) {
+    const size_t words = (size_t)scans * (scan_tiles_for(items) + 2) + 2;
+    HIPCHECK(ctx->d_scan_state.ensure(words));
+    sp.state = ctx->d_scan_state.p;
+    sp.words = words - 2;
+    sp.used = 0;
+    sp.ticket = (uint32_t*)(ctx->d_scan_state.p + words - 2);
+    HIPCHECK(hipMemsetAsync(ctx->d_scan_state.p, 0, words * 8, ctx->stream));
+    return RALA_HIP_OK;
+}
+
 // fixed point of the in-order containment removal over one class of items
 int tail_death_scan(rala_hip_ctx* ctx, const TailList& L, uint32_t which, uint32_t** death_out) {
     hipStream_t s = ctx->stream;
@@ -1046,18 +1068,21 @@ int tail_death_scan(rala_hip_ctx* ctx, const TailList& L, uint32_t which, uint32
     HIPCHECK(hipMemsetAsync(ctx->d_t_death[1].p, 0xFF, (size_t)n_reads * 4, s));
     HIPCHECK(ctx->d_cc_flags.ensure(8));
     for (int round = 0;; ++round) {
-        constexpr int kBatch = 3;
-        HIPCHECK(hipMemsetAsync(ctx->d_cc_flags.p, 0, kBatch * 4, s));
-        for (int k = 0; k < kBatch; ++k) {
+        // A round over a converged pair of bounds changes nothing, so several are enqueued per look from the
+        // host: six at first (what C3 needs; a look costs what four rounds cost), three from then on.
+        constexpr int kMost = 6;
+        const int batch = round == 0 ? kMost : 3;
+        HIPCHECK(hipMemsetAsync(ctx->d_cc_flags.p, 0, kMost * 4, s));
+        for (int k = 0; k < batch; ++k) {
             // (the round's output buffer is all ones: filled above, then by the diff kernel)
             launch_tail_death_round(L, ctx->d_alive.p, which, ctx->d_t_death[cur].p, ctx->d_t_death[cur ^ 1].p, s);
             launch_death_diff(ctx->d_t_death[cur].p, ctx->d_t_death[cur ^ 1].p, n_reads, ctx->d_cc_flags.p + k, s);
             cur ^= 1;
         }
-        uint32_t changed[kBatch];
+        uint32_t changed[kMost];
         HIPCHECK(d2h_small(ctx, changed, ctx->d_cc_flags.p, sizeof(changed), s));
         HIPCHECK(stream_sync(ctx, s));
-        if (!changed[kBatch - 1]) break;
+        if (!changed[batch - 1]) break;
         if (round > 100000) return fail(ctx, RALA_HIP_EDEVICE, "containment fixed point did not converge");
     }
     *death_out = ctx->d_t_death[cur].p;
@@ -1097,60 +1122,70 @@ int gpu_tail_part_a(rala_hip_ctx* ctx) {
     };
     const uint32_t n_reads = (uint32_t)ctx->n_reads;
     const uint32_t M = ctx->t_n0 + ctx->t_n1;
+    // (how many reads are alive came back with the survivor counts of the second pass: no look from the host here)
+    const uint32_t n_alive = ctx->t_n_alive;
     const size_t big = (size_t)std::max<uint64_t>(n_reads, M) + 2;
     HIPCHECK(ctx->d_t_state.ensure(M)); HIPCHECK(ctx->d_t_round.ensure(M));
     HIPCHECK(ctx->d_dirty.ensure(n_reads)); HIPCHECK(ctx->d_n_pits0.ensure(n_reads));
     HIPCHECK(ctx->d_rank.ensure(n_reads)); HIPCHECK(ctx->d_alive_reads.ensure(n_reads));
-    HIPCHECK(ctx->d_t_tmp[0].ensure(big)); HIPCHECK(ctx->d_t_tmp[1].ensure(big));
-    HIPCHECK(ctx->d_kept_item.ensure(M)); HIPCHECK(ctx->d_dovetail.ensure(M + 1)); HIPCHECK(ctx->d_epos.ensure(M + 2));
+    HIPCHECK(ctx->d_kept_item.ensure(M));
     HIPCHECK(ctx->d_node_rank.ensure(n_reads + 2)); HIPCHECK(ctx->d_t_death[0].ensure(n_reads));
     HIPCHECK(ctx->d_t_death[1].ensure(n_reads));
-    HIPCHECK(ctx->d_scan_ws.ensure(scan_workspace_bytes(big)));
-    if ((uint64_t)M * 258ull >= 0xFFFFFFFFull) return fail(ctx, RALA_HIP_EINVAL, "too many surviving overlaps");
-    const TailList L = tail_list(ctx);
-    const TailReads R = tail_reads(ctx);
-    launch_init_list_state(L.state, L.round, ctx->t_n0, M, s);
-    HIPCHECK(hipMemsetAsync(ctx->d_dirty.p, 0, n_reads, s));
-    HIPCHECK(hipMemcpyAsync(ctx->d_n_pits0.p, ctx->d_n_pits.p, n_reads, hipMemcpyDeviceToDevice, s));
-    // ranks of the reads that survived the second pass (the component graph lives on them)
-    launch_u8_to_u32(ctx->d_alive.p, ctx->d_t_tmp[0].p, n_reads, s);
-    launch_exclusive_scan(ctx->d_t_tmp[0].p, ctx->d_t_tmp[1].p, n_reads, ctx->d_scan_ws.p, s);
-    launch_ranks(ctx->d_alive.p, ctx->d_t_tmp[1].p, ctx->d_rank.p, ctx->d_alive_reads.p, n_reads, s);
-    uint32_t n_alive = 0;
-    HIPCHECK(d2h_small(ctx, &n_alive, ctx->d_t_tmp[1].p + n_reads, 4, s));
-    HIPCHECK(stream_sync(ctx, s));
-    ctx->t_n_alive = n_alive;
     HIPCHECK(ctx->d_touched.ensure(n_alive)); HIPCHECK(ctx->d_cmed.ensure(n_alive));
     HIPCHECK(ctx->d_cc_edges.ensure(2 * (size_t)M)); HIPCHECK(ctx->d_cc_label.ensure(n_alive));
     HIPCHECK(ctx->d_med_keys[0].ensure(n_alive)); HIPCHECK(ctx->d_med_keys[1].ensure(n_alive));
     ctx->t_med_tmp = component_median_workspace(n_alive);
     HIPCHECK(ctx->d_med_tmp.ensure(ctx->t_med_tmp));
     HIPCHECK(ctx->d_cc_flags.ensure(8));
+    (void)big;
+    if ((uint64_t)M * 258ull >= 0xFFFFFFFFull) return fail(ctx, RALA_HIP_EINVAL, "too many surviving overlaps");
+    const TailList L = tail_list(ctx);
+    const TailReads R = tail_reads(ctx);
+    ScanSpace sp;
+    {
+        const int rc = scan_space(ctx, 1, n_reads, sp);
+        if (rc != RALA_HIP_OK) return rc;
+    }
+    launch_tail_init(L, ctx->t_n0, R, ctx->d_n_pits0.p, n_reads, s);
+    // ranks of the reads that survived the second pass (the component graph lives on them)
+    if (!launch_rank_pass(ctx->d_alive.p, ctx->d_rank.p, ctx->d_alive_reads.p, n_reads, sp, s)) return fail(ctx, RALA_HIP_EDEVICE, "scan space");
     mark("tail: ranks", n_alive);
 
     // break over chimeric hills, first re-trim (graph.cpp:704-736; no promotion here)
+    HIPCHECK(ctx->d_counts.ensure(16));
+    uint32_t* dropped = ctx->d_counts.p + 4;                        // one word per round of a batch
     launch_break_hills(R, n_reads, s);
-    launch_retrim(L, R, 0, 0, ctx->d_small.p + 2, s);
+    launch_retrim(L, R, 0, 0, dropped, s);
     HIPCHECK(hipMemsetAsync(ctx->d_dirty.p, 0, n_reads, s));
     mark("tail: hills + retrim", M);
 
+    // graph.cpp:738-829: components, component medians, break over pits, re-trim - while an overlap died
+    // in the round.  Hardly a data set is done after one round, and a look from the host costs a third of
+    // one: two rounds are enqueued before the host looks, the second one gated on the device by the first
+    // one's count (a round behind the reference's last would see the internals that round promoted as
+    // overlaps - it must not act), then one at a time.
     uint32_t rounds = 0;
-    for (;; ++rounds) {                                             // graph.cpp:738-829
-        if (rounds >= 255) return fail(ctx, RALA_HIP_EDEVICE, "chimera loop did not settle");
-        const int rcc = tail_components(ctx, L, n_alive);
-        if (rcc != RALA_HIP_OK) return rcc;
-        mark("tail: components + medians");
-        launch_break_pits(R, ctx->d_alive_reads.p, ctx->d_touched.p, ctx->d_cmed.p, n_alive, s);
-        HIPCHECK(hipMemsetAsync(ctx->d_small.p + 2, 0, 4, s));
-        launch_retrim(L, R, 1, rounds, ctx->d_small.p + 2, s);
-        HIPCHECK(hipMemsetAsync(ctx->d_dirty.p, 0, n_reads, s));
-        uint32_t dropped = 0;
-        HIPCHECK(d2h_small(ctx, &dropped, ctx->d_small.p + 2, 4, s));
+    for (;;) {
+        const uint32_t batch = rounds == 0 ? 2u : 1u;
+        HIPCHECK(hipMemsetAsync(dropped, 0, 2 * 4, s));
+        for (uint32_t k = 0; k < batch; ++k) {
+            if (rounds + k >= 255) return fail(ctx, RALA_HIP_EDEVICE, "chimera loop did not settle");
+            const uint32_t* gate = k ? dropped + k - 1 : nullptr;
+            const int rcc = tail_components(ctx, L, n_alive);
+            if (rcc != RALA_HIP_OK) return rcc;
+            launch_break_pits(R, ctx->d_alive_reads.p, ctx->d_touched.p, ctx->d_cmed.p, n_alive, s, gate);
+            launch_retrim(L, R, 1, rounds + k, dropped + k, s, gate);
+            HIPCHECK(hipMemsetAsync(ctx->d_dirty.p, 0, n_reads, s));
+        }
+        uint32_t d[2] = {0, 0};
+        HIPCHECK(d2h_small(ctx, d, dropped, sizeof(d), s));
         HIPCHECK(stream_sync(ctx, s));
-        mark("tail: pits + retrim", dropped);
-        if (!dropped) break;
+        mark("tail: pits + retrim", d[0] + d[1]);
+        if (!d[0]) { rounds += 1; break; }                     // (a second round of the batch did nothing)
+        rounds += batch;
+        if (!d[batch - 1]) break;
     }
-    ctx->t_rounds = rounds + 1;
+    ctx->t_rounds = rounds;
 
     // in-order containment removal (graph.cpp:831-877): overlaps (+ promoted), then internals
     launch_refresh_types(L, R, s);
@@ -1176,40 +1211,41 @@ int gpu_tail_part_b(rala_hip_ctx* ctx) {
     const uint32_t M = ctx->t_n0 + ctx->t_n1;
     const TailList L = tail_list(ctx);
     const TailReads R = tail_reads(ctx);
-    // the final overlap list: originals in order, then the promoted ones round by round
-    uint32_t n_kept = 0;
-    HIPCHECK(ctx->d_seg_base.ensure(ctx->t_rounds + 2));
-    for (uint32_t seg = 0; seg <= ctx->t_rounds; ++seg) {
-        launch_keep_flags(L, ctx->d_alive.p, seg == 0 ? 1u : 3u, seg == 0 ? 0u : seg - 1, ctx->d_t_tmp[0].p, s);
-        launch_exclusive_scan(ctx->d_t_tmp[0].p, ctx->d_t_tmp[1].p, M, ctx->d_scan_ws.p, s);
-        launch_place_kept(L, R, ctx->d_t_tmp[0].p, ctx->d_t_tmp[1].p, seg ? ctx->d_seg_base.p + seg - 1 : nullptr,
-                          ctx->d_seg_base.p + seg, ctx->d_kept_item.p, ctx->d_dovetail.p, s);
+    const uint32_t n_seg = ctx->t_rounds + 1;
+    // sized by what the host knows: at most t_n_alive reads are left, at most M overlaps kept, all dovetails
+    HIPCHECK(ctx->d_seg_base.ensure(2 * (size_t)n_seg + 4));
+    HIPCHECK(ctx->d_node_read.ensure(2 * (size_t)ctx->t_n_alive + 2));
+    for (int k = 0; k < 3; ++k) HIPCHECK(ctx->d_e[k].ensure(2 * (size_t)M + 2));
+    HIPCHECK(ctx->d_counts.ensure(16));
+    ScanSpace sp;
+    {
+        const int rc = scan_space(ctx, n_seg + 1, std::max<uint64_t>(n_reads, M), sp);
+        if (rc != RALA_HIP_OK) return rc;
     }
-    if (M) {
-        HIPCHECK(d2h_small(ctx, &n_kept, ctx->d_seg_base.p + ctx->t_rounds, 4, s));
-        HIPCHECK(stream_sync(ctx, s));
-    }
-    ctx->t_n_kept = n_kept;
-    mark("tail: final list", n_kept);
+    HIPCHECK(hipMemsetAsync(ctx->d_seg_base.p, 0, (2 * (size_t)n_seg + 4) * 4, s));
+    HIPCHECK(hipMemsetAsync(ctx->d_counts.p + 8, 0, 4, s));
     // nodes: two per surviving read (graph.cpp:553-574)
-    launch_u8_to_u32(ctx->d_alive.p, ctx->d_t_tmp[0].p, n_reads, s);
-    launch_exclusive_scan(ctx->d_t_tmp[0].p, ctx->d_node_rank.p, n_reads, ctx->d_scan_ws.p, s);
-    uint32_t n_final = 0, n_dove = 0;
-    HIPCHECK(d2h_small(ctx, &n_final, ctx->d_node_rank.p + n_reads, 4, s));
-    // edges: two per dovetail overlap (graph.cpp:576-632)
-    launch_exclusive_scan(ctx->d_dovetail.p, ctx->d_epos.p, n_kept, ctx->d_scan_ws.p, s);
-    HIPCHECK(d2h_small(ctx, &n_dove, ctx->d_epos.p + n_kept, 4, s));
-    HIPCHECK(stream_sync(ctx, s));
-    ctx->t_n_nodes = 2 * n_final;
-    ctx->t_n_edges = 2 * n_dove;
-    HIPCHECK(ctx->d_node_read.ensure(ctx->t_n_nodes));
-    for (int k = 0; k < 3; ++k) HIPCHECK(ctx->d_e[k].ensure(ctx->t_n_edges));
-    launch_node_reads(ctx->d_alive.p, ctx->d_node_rank.p, ctx->d_node_read.p, n_reads, s);
-    launch_build_edges(L, R, ctx->d_kept_item.p, ctx->d_dovetail.p, ctx->d_epos.p, n_kept, ctx->d_node_rank.p,
-                       ctx->d_e[0].p, ctx->d_e[1].p, ctx->d_e[2].p, s);
+    if (!launch_node_pass(ctx->d_alive.p, ctx->d_node_rank.p, ctx->d_node_read.p, ctx->d_counts.p + 8, n_reads, sp, s)) {
+        return fail(ctx, RALA_HIP_EDEVICE, "scan space");
+    }
+    // the final overlap list: originals in order, then the promoted ones round by round; the two edges of
+    // every dovetail (graph.cpp:576-632) with it
+    for (uint32_t seg = 0; seg < n_seg; ++seg) {
+        if (!launch_segment_pass(L, R, seg == 0 ? 1u : 3u, seg == 0 ? 0u : seg - 1, ctx->d_seg_base.p + 2 * seg,
+                                 ctx->d_seg_base.p + 2 * (seg + 1), ctx->d_kept_item.p, ctx->d_node_rank.p, ctx->d_e[0].p,
+                                 ctx->d_e[1].p, ctx->d_e[2].p, sp, s)) {
+            return fail(ctx, RALA_HIP_EDEVICE, "scan space");
+        }
+    }
+    uint32_t totals[2] = {0, 0}, n_final = 0;
+    HIPCHECK(d2h_small(ctx, totals, ctx->d_seg_base.p + 2 * n_seg, 8, s));
+    HIPCHECK(d2h_small(ctx, &n_final, ctx->d_counts.p + 8, 4, s));
     HIPCHECK(stream_sync(ctx, s));
     HIPCHECK(hipGetLastError());
-    mark("tail: nodes + edges", ctx->t_n_edges);
+    ctx->t_n_kept = totals[0];
+    ctx->t_n_nodes = 2 * n_final;
+    ctx->t_n_edges = 2 * totals[1];
+    mark("tail: final list, nodes, edges", ctx->t_n_edges);
     ctx->tail_on_device = true;
     ctx->host_stale = true;
     return RALA_HIP_OK;
@@ -1310,6 +1346,11 @@ int pass2(rala_hip_ctx* ctx, Comm* comm) {
     HIPCHECK(hipEventRecord(ctx->ev[4], s));
     HIPCHECK(hipMemsetAsync(ctx->d_kill_count.p, 0, (kCountRing + 4) * 4, s));
     HIPCHECK(ctx->d_rec.ensure(n_reads));
+    // compact per-read records (valid region + two flags): 4 bytes when no read is longer than 32767 bases
+    const bool small_rec = ctx->max_read_len <= 32767u;
+    HIPCHECK(ctx->d_crec.ensure((size_t)n_reads * compact_record_bytes(small_rec) + 16));
+    HIPCHECK(ctx->d_counts.ensure(16));
+    HIPCHECK(hipMemsetAsync(ctx->d_counts.p, 0, 16 * 4, s));
     // one buffer: sure[n_reads] (min over sure killers = upper bound), lo[n_reads] (lower bound),
     // one status word - so that a sharded run needs ONE all-reduce (min) per round; up[] apart
     HIPCHECK(ctx->d_death_sure.ensure(2 * (size_t)n_reads + 8));
@@ -1319,8 +1360,8 @@ int pass2(rala_hip_ctx* ctx, Comm* comm) {
     HIPCHECK(hipMemsetAsync(sure, 0xFF, 2 * dbytes + 4, s));
     // (tests: a failure that only this rank sees, between two collectives of a sharded run)
     if (ctx->debug_fail_construct) return fail(ctx, RALA_HIP_EDEVICE, "debug_fail_construct");
-    launch_pack_reads(rs, n_reads, ctx->d_rec.p, s);
-    launch_classify(ctx->ovl, n_reads, ctx->d_valid.p, ctx->d_rec.p, ctx->d_cls.p, kl, lo, s);
+    launch_pack_reads(rs, n_reads, ctx->d_rec.p, ctx->d_crec.p, small_rec, sure, s);
+    launch_classify(ctx->ovl, n_reads, ctx->d_valid.p, ctx->d_crec.p, small_rec, kl, lo, s);
     HIPCHECK(hipEventRecord(ctx->ev[5], s));
 
     // ---- in-order containment removal as a fixed point (death_decide_kernel) ----
@@ -1424,9 +1465,14 @@ int pass2(rala_hip_ctx* ctx, Comm* comm) {
 
     // ---- liveness, hill counters, survivors ----
     const uint32_t n_chunks = pass2_chunks(N);
-    launch_finish_pass2(ctx->ovl, ctx->d_cls.p, death, ctx->d_rec.p, ctx->d_pool.p, ctx->d_chunk[0].p,
-                        ctx->d_chunk[1].p, s);
-    launch_apply_death(death, ctx->d_alive.p, n_reads, s);
+    const size_t mask_words = (size_t)((N + 63) / 64);
+    HIPCHECK(ctx->d_cls.ensure(2 * 8 * mask_words + 16));
+    uint64_t* mask_ov = (uint64_t*)ctx->d_cls.p;
+    uint64_t* mask_in = mask_ov + mask_words;
+    HIPCHECK(ctx->d_fate.ensure(n_reads));
+    launch_apply_death(death, ctx->d_alive.p, ctx->d_n_hills.p, ctx->d_fate.p, n_reads, ctx->d_counts.p + 0, s);
+    launch_survivor_masks(ctx->ovl, n_reads, ctx->d_valid.p, ctx->d_fate.p, death, ctx->d_crec.p, small_rec, ctx->d_rec.p,
+                          ctx->d_pool.p, mask_ov, mask_in, ctx->d_chunk[0].p, ctx->d_chunk[1].p, s);
     if (comm && ctx->pool_used) {
         // Pile::check_chimeric_hills counters (pile.cpp:457-469): every slice counted its own overlaps
         HIPCHECK(ctx->d_t_tmp[0].ensure(std::max<size_t>(ctx->pool_used, n_reads) + 2));
@@ -1442,7 +1488,10 @@ int pass2(rala_hip_ctx* ctx, Comm* comm) {
     }
     uint32_t round_log[64];
     if (n_logged) HIPCHECK(d2h_small(ctx, round_log, ctx->d_round_log.p, n_logged * 4, s));
+    uint32_t n_alive_now = 0;
+    HIPCHECK(d2h_small(ctx, &n_alive_now, ctx->d_counts.p + 0, 4, s));
     HIPCHECK(stream_sync(ctx, s));
+    ctx->t_n_alive = n_alive_now;           // the reads that survived the second pass (the tail's rank space)
     {
         // rounds until the list was empty
         uint32_t at = 0;
@@ -1468,13 +1517,13 @@ int pass2(rala_hip_ctx* ctx, Comm* comm) {
         for (int f = 0; f < 8; ++f) HIPCHECK(ctx->d_surv_u32[f].ensure(M));
         for (int f = 0; f < 2; ++f) HIPCHECK(ctx->d_surv_u8[f].ensure(M));
         // trim in the gather re-derives the coordinates against the pass-1 piles
-        if (M) launch_gather_survivors(ctx->ovl, ctx->d_cls.p, ctx->d_rec.p, ctx->d_chunk[2].p, ctx->d_chunk[3].p, n_surv[0], tail_view(), s);
+        if (M) launch_gather_survivors(ctx->ovl, mask_ov, mask_in, ctx->d_crec.p, small_rec, ctx->d_chunk[2].p, ctx->d_chunk[3].p, n_surv[0], tail_view(), s);
     } else {
         // this slice's survivors as one packed block, all blocks gathered, unpacked in rank order
         const uint32_t P = comm->world();
         const uint64_t m = (uint64_t)n_surv[0] + n_surv[1];
         HIPCHECK(ctx->d_list_block[0].ensure(packed_list_bytes(m) + 16));
-        if (m) launch_gather_survivors(ctx->ovl, ctx->d_cls.p, ctx->d_rec.p, ctx->d_chunk[2].p, ctx->d_chunk[3].p, n_surv[0],
+        if (m) launch_gather_survivors(ctx->ovl, mask_ov, mask_in, ctx->d_crec.p, small_rec, ctx->d_chunk[2].p, ctx->d_chunk[3].p, n_surv[0],
                                        packed_list_view(ctx->d_list_block[0].p, m), s);
         const uint64_t mine[2] = {n_surv[0], n_surv[1]};
         std::vector<uint64_t> all(2 * (size_t)P), bytes(P);
@@ -1743,7 +1792,7 @@ int rala_hip_set_overlaps(rala_hip_ctx* ctx, const rala_hip_overlaps* o, uint64_
     ctx->valid_ready = false;
     HIPCHECK(ctx->d_valid.ensure(n));
     HIPCHECK(ctx->d_ev.ensure(4 * n + 8));
-    HIPCHECK(ctx->d_cls.ensure(n));
+    HIPCHECK(ctx->d_cls.ensure(n / 4 + 64));        // survivor masks of the second pass: two bits per overlap
     for (int k = 0; k < 4; ++k) HIPCHECK(ctx->d_chunk[k].ensure(pass2_chunks(n) + 2));
     HIPCHECK(ctx->d_scan_ws.ensure(scan_workspace_bytes(std::max<uint64_t>(n, ctx->n_reads) + 2)));
     ctx->initialized = ctx->constructed = ctx->ev_ready = false;

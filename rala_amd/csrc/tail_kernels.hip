@@ -15,6 +15,7 @@
 #include "device_utils.h"
 #include "geom.h"
 #include "kernels.h"
+#include "scan_pass.h"
 
 namespace rala_hip {
 
@@ -55,9 +56,13 @@ __global__ __launch_bounds__(kBlock) void break_hills_kernel(TailReads R, uint32
 
 // Pile::break_over_chimeric_pits (pile.cpp:366-402) for the reads of a component; the pile
 // kernel recorded the minimum coverage inside each pit (data * 1.84 <= median is monotone)
+// gate (may be null): the count of overlaps the round before dropped - a round enqueued ahead of the host's
+// look at that count does nothing when it was zero (the reference's loop has ended there, graph.cpp:826-828)
 __global__ __launch_bounds__(kBlock) void break_pits_kernel(TailReads R, const uint32_t* __restrict__ alive_reads,
                                                             const uint8_t* __restrict__ touched,
-                                                            const uint16_t* __restrict__ comp_median, uint32_t n_alive) {
+                                                            const uint16_t* __restrict__ comp_median, uint32_t n_alive,
+                                                            const uint32_t* gate) {
+    if (gate && *gate == 0) return;
     const uint32_t q = blockIdx.x * kBlock + threadIdx.x;
     if (q >= n_alive || !touched[q]) return;
     const uint32_t r = alive_reads[q];
@@ -93,35 +98,44 @@ __device__ __forceinline__ Coords item_coords(const TailList& L, uint32_t k) {
 // overlaps are counted (the loop continues while any died), internals that became dovetails
 // are promoted
 __global__ __launch_bounds__(kBlock) void retrim_kernel(TailList L, TailReads R, uint32_t promote, uint32_t round,
-                                                        uint32_t* dropped) {
+                                                        uint32_t* dropped, const uint32_t* gate) {
+    if (gate && *gate == 0) return;
     const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
-    if (k >= L.n) return;
-    const uint8_t st = L.state[k];
-    if (st == 0) return;
-    const uint32_t a = L.a[k], b = L.b[k];
-    // untouched items are still trimmed (and internals still kX); an internal whose type went
-    // stale in the first re-trim (no promotion there, graph.cpp:730-736) is looked at again
-    const bool stale_internal = promote && st == 2 && L.type[k] == 255;
-    if (!((R.dirty[a] | R.dirty[b]) || stale_internal)) return;
-    Coords c = item_coords(L, k);
-    const uint32_t strand = L.strand[k];
-    const bool ok = R.alive[a] && R.alive[b] && ovl_trim(c, strand, R.begin[a], R.end[a], R.begin[b], R.end[b]);
-    if (!ok) {
-        L.state[k] = 0;
-        if (st != 2) atomicAdd(dropped, 1u);
-        return;
-    }
-    L.a_begin[k] = c.a_begin; L.a_end[k] = c.a_end; L.b_begin[k] = c.b_begin; L.b_end[k] = c.b_end;
-    L.length[k] = c.length;
-    uint8_t t = 255;
-    if (st == 2 && promote) {
-        t = (uint8_t)ovl_type(c, strand, R.begin[a], R.end[a], R.begin[b], R.end[b]);
-        if (t == kTypeAB || t == kTypeBA) {
-            L.state[k] = 3;
-            L.round[k] = (uint8_t)round;
+    bool died = false;
+    if (k < L.n) {
+        const uint8_t st = L.state[k];
+        if (st != 0) {
+            const uint32_t a = L.a[k], b = L.b[k];
+            // untouched items are still trimmed (and internals still kX); an internal whose type went
+            // stale in the first re-trim (no promotion there, graph.cpp:730-736) is looked at again
+            const bool stale_internal = promote && st == 2 && L.type[k] == 255;
+            if ((R.dirty[a] | R.dirty[b]) || stale_internal) {
+                Coords c = item_coords(L, k);
+                const uint32_t strand = L.strand[k];
+                const bool ok = R.alive[a] && R.alive[b] && ovl_trim(c, strand, R.begin[a], R.end[a], R.begin[b], R.end[b]);
+                if (!ok) {
+                    L.state[k] = 0;
+                    died = st != 2;
+                } else {
+                    L.a_begin[k] = c.a_begin; L.a_end[k] = c.a_end; L.b_begin[k] = c.b_begin; L.b_end[k] = c.b_end;
+                    L.length[k] = c.length;
+                    uint8_t t = 255;
+                    if (st == 2 && promote) {
+                        t = (uint8_t)ovl_type(c, strand, R.begin[a], R.end[a], R.begin[b], R.end[b]);
+                        if (t == kTypeAB || t == kTypeBA) {
+                            L.state[k] = 3;
+                            L.round[k] = (uint8_t)round;
+                        }
+                    }
+                    L.type[k] = t;
+                }
+            }
         }
     }
-    L.type[k] = t;
+    // *dropped != 0 is all the loop asks (graph.cpp:826: "while any overlap died").  A hundred thousand
+    // dropped overlaps adding one by one to the same word took 150 us of the first round at C3 - adds to
+    // one word cost about 10 ns apiece; a plain store of the same value from whoever saw one costs nothing.
+    if (__ballot(died) != 0 && (threadIdx.x & 63) == 0) *dropped = 1u;
 }
 
 // edges of the component graph in rank space; dead items become self loops
@@ -278,6 +292,112 @@ __global__ __launch_bounds__(kBlock) void node_reads_kernel(const uint8_t* __res
     node_read[2 * rank[r] + 1] = r;
 }
 
+// start of the tail: list states, nothing dirty, the pit counts the pile kernel wrote (one launch for
+// what used to be a kernel, a fill and a copy)
+__global__ __launch_bounds__(kBlock) void tail_init_kernel(uint8_t* state, uint8_t* round, uint32_t n0, uint32_t m,
+                                                           uint8_t* dirty, uint8_t* n_pits0, const uint8_t* n_pits,
+                                                           uint32_t n_reads) {
+    const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
+    if (k < m) {
+        state[k] = k < n0 ? 1 : 2;
+        round[k] = 0;
+    }
+    if (k < n_reads) {
+        dirty[k] = 0;
+        n_pits0[k] = n_pits[k];
+    }
+}
+
+// ---- scans with their producers and consumers inside (scan_pass.h) ---------------------------------
+// rank[r] / alive_reads[rank] of the reads that are alive (the component graph lives on ranks)
+struct RankPass {
+    const uint8_t* alive;
+    uint32_t* rank;
+    uint32_t* alive_reads;
+    __device__ uint64_t value(uint32_t r) const { return alive[r] ? 1ull : 0ull; }
+    __device__ void place(uint32_t r, uint64_t v, uint64_t before) const {
+        rank[r] = v ? (uint32_t)before : kInf;
+        if (v) alive_reads[(uint32_t)before] = r;
+    }
+    __device__ void total(uint64_t) const {}
+};
+
+// nodes: two per surviving read, in read order (graph.cpp:553-574); *n_final = surviving reads
+struct NodePass {
+    const uint8_t* alive;
+    uint32_t* node_rank;
+    uint32_t* node_read;
+    uint32_t* n_final;
+    __device__ uint64_t value(uint32_t r) const { return alive[r] ? 1ull : 0ull; }
+    __device__ void place(uint32_t r, uint64_t v, uint64_t before) const {
+        node_rank[r] = (uint32_t)before;
+        if (v) {
+            node_read[2 * (uint32_t)before] = r;
+            node_read[2 * (uint32_t)before + 1] = r;
+        }
+    }
+    __device__ void total(uint64_t sum) const { *n_final = (uint32_t)sum; }
+};
+
+// One segment of the final overlap list (the originals, or the internals promoted in one round; list
+// order = the reference's, graph.cpp:813-823) AND its edges: an item that is kept knows its place among
+// the kept ones and, if it is a dovetail, among the dovetails (two counters in one scan: low 31 bits
+// kept, high bits dovetails), so the two edges of graph.cpp:576-632 are written by the same launch.
+// base[0 .. 1] = kept items / dovetails of the segments in front; updated for the next segment.
+struct SegmentPass {
+    TailList L;
+    TailReads R;
+    uint32_t want_state, want_round;
+    uint32_t* base;
+    uint32_t* kept_item;
+    const uint32_t* node_rank;
+    uint32_t *e_src, *e_dst, *e_len;
+    __device__ uint64_t value(uint32_t k) const {
+        const uint8_t st = L.state[k];
+        if (st != want_state || (st == 3 && L.round[k] != want_round)) return 0ull;
+        const uint32_t a = L.a[k], b = L.b[k];
+        if (!R.alive[a] || !R.alive[b]) return 0ull;
+        const Coords c = item_coords(L, k);
+        const uint32_t t = ovl_type(c, L.strand[k], R.begin[a], R.end[a], R.begin[b], R.end[b]);
+        L.type[k] = (uint8_t)t;
+        return 1ull | ((t == kTypeAB || t == kTypeBA) ? 1ull << 31 : 0ull);
+    }
+    __device__ void place(uint32_t k, uint64_t v, uint64_t before) const {
+        if (!v) return;
+        const uint32_t kept_before = base[0] + (uint32_t)(before & 0x7FFFFFFFull);
+        kept_item[kept_before] = k;
+        if (!(v >> 31)) return;
+        const uint32_t w = 2u * (base[1] + (uint32_t)(before >> 31));
+        const uint32_t a = L.a[k], b = L.b[k];
+        const Coords c = item_coords(L, k);
+        EdgePair e;
+        ovl_edges(c, L.strand[k], L.type[k], 2u * node_rank[a], 2u * node_rank[b], R.begin[a], R.end[a], R.begin[b], R.end[b], e);
+        e_src[w] = e.src0; e_dst[w] = e.dst0; e_len[w] = e.len0;
+        e_src[w + 1] = e.src1; e_dst[w + 1] = e.dst1; e_len[w + 1] = e.len1;
+    }
+    // (runs in the last tile, after every other tile has read base[] for its own items?  No: other tiles may
+    // still be placing.  The next segment's base is therefore written to next[], not over base[].)
+    uint32_t* next;
+    __device__ void total(uint64_t sum) const {
+        next[0] = base[0] + (uint32_t)(sum & 0x7FFFFFFFull);
+        next[1] = base[1] + (uint32_t)(sum >> 31);
+    }
+};
+
+// exclusive scan of plain values (row offsets of a CSR from its row lengths); out[n] = the sum
+struct OffsetsPass {
+    const uint32_t* in;
+    uint32_t* out;
+    uint32_t* copy;         // a second copy of the offsets (a fill cursor), may be null
+    uint32_t n;
+    __device__ uint64_t value(uint32_t i) const { return in[i]; }
+    __device__ void place(uint32_t i, uint64_t, uint64_t before) const {
+        out[i] = (uint32_t)before;
+        if (copy) copy[i] = (uint32_t)before;
+    }
+    __device__ void total(uint64_t sum) const { out[n] = (uint32_t)sum; }
+};
+
 __global__ __launch_bounds__(kBlock) void init_list_state_kernel(uint8_t* state, uint8_t* round, uint32_t n0, uint32_t n) {
     const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
     if (k >= n) return;
@@ -291,15 +411,15 @@ void launch_break_hills(const TailReads& R, uint32_t n_reads, hipStream_t s) {
     if (n_reads) hipLaunchKernelGGL(break_hills_kernel, grid_for(n_reads), dim3(kBlock), 0, s, R, n_reads);
 }
 void launch_break_pits(const TailReads& R, const uint32_t* alive_reads, const uint8_t* touched, const uint16_t* comp_median,
-                       uint32_t n_alive, hipStream_t s) {
+                       uint32_t n_alive, hipStream_t s, const uint32_t* gate) {
     if (n_alive) {
         hipLaunchKernelGGL(break_pits_kernel, grid_for(n_alive), dim3(kBlock), 0, s, R, alive_reads, touched, comp_median,
-                           n_alive);
+                           n_alive, gate);
     }
 }
 void launch_retrim(const TailList& L, const TailReads& R, uint32_t promote, uint32_t round, uint32_t* dropped,
-                   hipStream_t s) {
-    if (L.n) hipLaunchKernelGGL(retrim_kernel, grid_for(L.n), dim3(kBlock), 0, s, L, R, promote, round, dropped);
+                   hipStream_t s, const uint32_t* gate) {
+    if (L.n) hipLaunchKernelGGL(retrim_kernel, grid_for(L.n), dim3(kBlock), 0, s, L, R, promote, round, dropped, gate);
 }
 void launch_cc_edges(const TailList& L, const uint32_t* rank, uint32_t* edges, uint8_t* touched, hipStream_t s) {
     if (L.n) hipLaunchKernelGGL(cc_edges_kernel, grid_for(L.n), dim3(kBlock), 0, s, L, rank, edges, touched);
@@ -348,6 +468,28 @@ void launch_node_reads(const uint8_t* alive, const uint32_t* rank, uint32_t* nod
 }
 void launch_init_list_state(uint8_t* state, uint8_t* round, uint32_t n0, uint32_t n, hipStream_t s) {
     if (n) hipLaunchKernelGGL(init_list_state_kernel, grid_for(n), dim3(kBlock), 0, s, state, round, n0, n);
+}
+void launch_tail_init(const TailList& L, uint32_t n0, const TailReads& R, uint8_t* n_pits0, uint32_t n_reads, hipStream_t s) {
+    const uint32_t n = L.n > n_reads ? L.n : n_reads;
+    if (n) hipLaunchKernelGGL(tail_init_kernel, grid_for(n), dim3(kBlock), 0, s, L.state, L.round, n0, L.n, R.dirty, n_pits0, R.n_pits, n_reads);
+}
+bool launch_rank_pass(const uint8_t* alive, uint32_t* rank, uint32_t* alive_reads, uint32_t n_reads, ScanSpace& space, hipStream_t s) {
+    return launch_scan_pass(n_reads, RankPass{alive, rank, alive_reads}, space, s);
+}
+bool launch_node_pass(const uint8_t* alive, uint32_t* node_rank, uint32_t* node_read, uint32_t* n_final, uint32_t n_reads,
+                      ScanSpace& space, hipStream_t s) {
+    return launch_scan_pass(n_reads, NodePass{alive, node_rank, node_read, n_final}, space, s);
+}
+bool launch_segment_pass(const TailList& L, const TailReads& R, uint32_t want_state, uint32_t want_round, uint32_t* base,
+                         uint32_t* next, uint32_t* kept_item, const uint32_t* node_rank, uint32_t* e_src, uint32_t* e_dst,
+                         uint32_t* e_len, ScanSpace& space, hipStream_t s) {
+    SegmentPass f;
+    f.L = L; f.R = R; f.want_state = want_state; f.want_round = want_round; f.base = base; f.kept_item = kept_item;
+    f.node_rank = node_rank; f.e_src = e_src; f.e_dst = e_dst; f.e_len = e_len; f.next = next;
+    return launch_scan_pass(L.n, f, space, s);
+}
+bool launch_offsets_pass(const uint32_t* in, uint32_t* out, uint32_t* copy, uint32_t n, ScanSpace& space, hipStream_t s) {
+    return launch_scan_pass(n, OffsetsPass{in, out, copy, n}, space, s);
 }
 
 namespace {

@@ -56,11 +56,12 @@ __global__ __launch_bounds__(kBlock) void tr_mark_kernel(const uint32_t* __restr
 
 __global__ __launch_bounds__(kBlock) void tr_count_kernel(uint8_t* __restrict__ marks, uint32_t n_edges,
                                                           uint32_t* n_pairs) {
+    // (few workgroups, one add each: adds to one word cost about 10 ns apiece)
     __shared__ uint32_t tmp[kBlock / 64 + 1];
-    const uint32_t p = blockIdx.x * kBlock + threadIdx.x;     // pair index
     uint32_t v = 0;
-    if (2 * p + 1 < n_edges) v = marks[2 * p] ? 1u : 0u;
-    if (2 * p + 1 < n_edges && v) { marks[2 * p] = 1; marks[2 * p + 1] = 1; }        // (sharded runs summed the ranks' bytes)
+    for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; 2 * p + 1 < n_edges; p += gridDim.x * kBlock) {      // pair index
+        if (marks[2 * p]) { marks[2 * p] = 1; marks[2 * p + 1] = 1; ++v; }        // (sharded runs summed the ranks' bytes)
+    }
     v = block_reduce<kBlock>(v, OpAdd(), 0u, tmp);
     if (threadIdx.x == 0 && v) atomicAdd(n_pairs, v);
 }
@@ -183,8 +184,8 @@ void launch_tr_mark(const uint32_t* row_ptr, const uint32_t* adj_edge, const uin
 void launch_tr_count(uint8_t* marks, uint32_t n_edges, uint32_t* n_pairs, hipStream_t s) {
     const uint32_t pairs = n_edges / 2;
     if (pairs == 0) return;
-    hipLaunchKernelGGL(tr_count_kernel, dim3((pairs + kBlock - 1) / kBlock), dim3(kBlock), 0, s, marks, n_edges,
-                       n_pairs);
+    const uint32_t blocks = (pairs + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(tr_count_kernel, dim3(blocks < 128 ? blocks : 128), dim3(kBlock), 0, s, marks, n_edges, n_pairs);
 }
 
 }  // namespace rala_hip

@@ -43,3 +43,11 @@ if len(sys.argv) > 2:
     for s0, e0, name in step:
         if sys.argv[2] in name:
             print("  at %8.1f us  %7.1f us  %s" % ((s0 - t0) / 1e3, (e0 - s0) / 1e3, name.replace("rala_hip::", "").replace("(anonymous namespace)::", "").split("(")[0][-60:]))
+
+# python tools/trace_gaps.py <csv> ALL: the whole step in time order with the gap in front of every kernel
+if len(sys.argv) > 2 and sys.argv[2] == "ALL":
+    end = step[0][0]
+    for s0, e0, name in step:
+        print("  at %8.1f us  gap %6.1f  dur %7.1f  %s" % ((s0 - t0) / 1e3, (s0 - end) / 1e3, (e0 - s0) / 1e3,
+                                                          name.replace("rala_hip::", "").replace("(anonymous namespace)::", "").split("(")[0][-60:]))
+        end = max(end, e0)
