@@ -357,6 +357,13 @@ __device__ __forceinline__ uint32_t bitfield_insert(uint32_t mask, uint32_t a, u
     return d;
 }
 
+// index of the lowest set bit, 0xFFFFFFFF for zero (v_ffbl_b32's own answer: no select around it)
+__device__ __forceinline__ uint32_t ffbl_or_minus1(uint32_t v) {
+    uint32_t d;
+    asm("v_ffbl_b32 %0, %1" : "=v"(d) : "v"(v));
+    return d;
+}
+
 // 16-byte store to base + off with the base in scalar registers and a 32-bit lane offset.  The
 // compiler prefers a 64-bit address per lane: two more registers per store in flight, and at this
 // kernel's register budget that meant spill reloads inside the store loop - a scratch load is a
@@ -416,7 +423,7 @@ struct Layout {
     static constexpr uint32_t XLIST = kShort ? IDX : RF;
     static constexpr uint32_t XTABLE = ((kShort ? RF : RF + 64) + 3) & ~3u;
     static_assert(kX >= kCap && kX >= kIdx && kX >= 768, "shared region too small");
-    static_assert(kIdx / 2 >= 64 && SEL >= XTABLE + 256, "scratch for the noted groups of a chunk");
+    static_assert(kIdx / 2 >= 64 && SEL >= XTABLE + 32, "scratch of the expansion: 64 noted groups, 8 masks");
     static_assert(kBases == 16384 || (kShort && (kBases == 32768 || kBases == 65536)), "bitmap sizes in use");
     static_assert(!kShort || kBases != 16384 || WORDS * 4 <= 6656, "six wavefronts per SIMD: 24 workgroups in 160 KB, 512-byte granules");
     static_assert(!kShort || kBases > 32768 || WORDS * 4 <= 10240, "four wavefronts per SIMD: 16 workgroups in 160 KB");
@@ -429,17 +436,17 @@ struct Layout {
 // run starts: bm (one bit per position that starts a run, bit n set for the padding behind the
 // last base), pref[w] = run starts before word w, rv = run values (rv[R] = 0).
 //
-// A lane owns byte (lane & 3) of bitmap word (group >> 2), so its masks are loop constants.  For
-// most groups all 8 places hold the value of the group's first position (about ten vector
-// instructions per 16-byte store).  A group in which the value changes (a run starts at one of
-// its positions 1..7: about one group in seven) is noted in an LDS list; the noted groups of a
-// chunk of 256 are then taken one per lane, the changes walked, and the finished 16 bytes put
-// into an LDS table from which the group's own lane fetches them for the store.  Every byte of
-// the row is stored exactly once, by dense 1 KiB wave stores: patching the noted groups with
-// scattered 16-byte stores afterwards (64 different lines per instruction) cost as much as all
-// the dense stores together (C3: 3.6 ms against 4.0 ms, 5.8 ms for both).  The walk used to run
-// inside the store loop, where nearly every iteration had some lane with a change and all 64
-// lanes paid for it.
+// A lane owns byte (lane & 3) of bitmap word (group >> 2), so its masks are loop constants.  Six
+// groups in seven hold one value in all 8 places, nearly all of the rest two (one run starts inside,
+// at place x = 1 .. 7): both are ONE code path - the value at the group's first place, the next run's
+// value, and a 16-byte mask "places at or behind x" fetched from an eight-entry LDS table (x = 0: no
+// place), four bit-field inserts.  Only a group in which two or more runs start (one in a hundred) is
+// noted in an LDS list; the noted groups are walked one per lane, once per read, and stored from
+// there - a dozen scattered 16-byte stores per read, where patching EVERY changed group that way
+// (one in seven) once cost as much as all the dense stores together.  Every byte of the row is
+// stored exactly once.  (Before: every changed group went through the list, a walk and a table of
+// finished groups, once per chunk of 256 groups - 700 of the expansion's 900 vector instructions
+// per read.)
 template <class L>
 __device__ __forceinline__ void expand_from_bitmap(uint32_t* sm, const uint16_t* rv, uint16_t* pile, uint64_t row_off,
                                                    uint32_t nv, uint32_t lane, bool store) {
@@ -447,97 +454,90 @@ __device__ __forceinline__ void expand_from_bitmap(uint32_t* sm, const uint16_t*
     const uint16_t* pref = (const uint16_t*)(bm + L::kBmWords);
     const uint16_t* rvm1 = rv - 1;                      // indexed by run + 1 (= run starts at or before)
     uint32_t* list = sm + L::XLIST;                     // the region lists are not in use yet
-    uint4* table = (uint4*)(sm + L::XTABLE);            // 64 finished groups, 16-byte aligned
+    uint4* masks = (uint4*)(sm + L::XTABLE);            // 8 entries, 16-byte aligned
     // the row address is the same in every lane: keep it in scalar registers, 32-bit lane offsets
     // (the builtin returns int: without the casts the low half would be sign-extended over the high one)
     const uint64_t off = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(row_off >> 32)) << 32) |
                          (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)row_off);
     char* base = (char*)(pile + off);
+    if (lane < 8) {
+        // word q holds places 2q and 2q + 1: all ones when x <= 2q, the upper half when x == 2q + 1
+        masks[lane] = lane == 0 ? make_uint4(0, 0, 0, 0)
+                                : make_uint4(change_mask(lane, 0), change_mask(lane, 1), change_mask(lane, 2), change_mask(lane, 3));
+    }
+    wave_sync();
     const uint32_t sh1 = ((lane & 3u) << 3) + 1u;
     const uint32_t below = (1u << sh1) - 1u;            // the bits at or before the group's first position
     const uint32_t w_lane = lane >> 2;
+    uint32_t cnt = 0;                                   // noted groups (the same in every lane)
+    // the noted groups, one per lane: walk the changes, store
+    auto flush = [&]() {
+        wave_sync();
+        if (lane < cnt) {
+            const uint32_t e = list[lane];
+            uint32_t k = e & 0xFFFu;
+            uint32_t inner = (e >> 12) & 0x7Fu;
+            const uint32_t g = e >> 19;
+            const uint32_t v0 = rvm1[k];
+            const uint32_t vv = v0 | (v0 << 16);
+            uint32_t w0 = vv, w1 = vv, w2 = vv, w3 = vv;
+            do {
+                const uint32_t x = (uint32_t)__builtin_ctz(inner) + 1u;     // position 1 .. 7 inside the group
+                inner &= inner - 1;
+                const uint32_t nvv = rvm1[++k];
+                const uint32_t f = nvv | (nvv << 16);
+                w0 = bitfield_insert(change_mask(x, 0), f, w0);
+                w1 = bitfield_insert(change_mask(x, 1), f, w1);
+                w2 = bitfield_insert(change_mask(x, 2), f, w2);
+                w3 = bitfield_insert(change_mask(x, 3), f, w3);
+            } while (inner);
+            if (store) store16(base, g * 16u, make_uint4(w0, w1, w2, w3));
+        }
+        wave_sync();
+        cnt = 0;
+    };
+    static_assert(L::kArr <= 4096 && L::kBases <= 65536, "noted group = run (12 bits) | starts (7) | group (13)");
     auto chunk = [&](uint32_t g0, auto full_tag) {
         constexpr bool kFull = decltype(full_tag)::value;
-        uint32_t bits[4], kq[4], v[4];
+        uint32_t bits[4], kq[4];
 #pragma unroll
         for (uint32_t u = 0; u < 4; ++u) {
             const uint32_t w = (g0 >> 2) + 16u * u + w_lane;        // < kBmWords for every group of the pile
             bits[u] = bm[w];
             kq[u] = pref[w];
         }
-        uint64_t noted[4];
-        bool mine[4];               // this lane's bit of noted[u]
-        uint32_t total = 0;
 #pragma unroll
         for (uint32_t u = 0; u < 4; ++u) {
-            kq[u] += (uint32_t)__popc(bits[u] & below);             // bit 0 of the bitmap is set: >= 1
-            v[u] = rvm1[kq[u]];                                     // (beyond the pile: some LDS word)
-            bits[u] = (bits[u] >> sh1) & 0x7Fu;                     // run starts at positions 1 .. 7
-            const bool in = kFull || g0 + 64u * u + lane < nv;
-            mine[u] = in && bits[u] != 0;
-            noted[u] = __builtin_amdgcn_ballot_w64(mine[u]);
-            total += (uint32_t)__popcll(noted[u]);
-        }
-        // groups u in [ub, ue) of the chunk (at most 64 of them noted): walk, table, store
-        auto emit = [&](auto ub_tag, auto ue_tag) {
-            constexpr uint32_t ub = decltype(ub_tag)::value, ue = decltype(ue_tag)::value;
-            uint32_t slot[4] = {0, 0, 0, 0};
-            uint32_t cnt = 0;
-#pragma unroll
-            for (uint32_t u = ub; u < ue; ++u) {
-                const uint64_t m = noted[u];
-                slot[u] = cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                if (mine[u]) list[slot[u]] = kq[u] | (bits[u] << 16);
-                cnt += (uint32_t)__popcll(m);
-            }
-            if (cnt) {
-                wave_sync();
-                if (lane < cnt) {
-                    const uint32_t e = list[lane];
-                    uint32_t k = e & 0xFFFFu;
-                    uint32_t inner = e >> 16;
-                    const uint32_t v0 = rvm1[k];
-                    const uint32_t vv = v0 | (v0 << 16);
-                    uint32_t w0 = vv, w1 = vv, w2 = vv, w3 = vv;
-                    do {
-                        const uint32_t x = (uint32_t)__builtin_ctz(inner) + 1u;     // position 1 .. 7 inside the group
-                        inner &= inner - 1;
-                        const uint32_t nvv = rvm1[++k];
-                        const uint32_t f = nvv | (nvv << 16);
-                        w0 = bitfield_insert(change_mask(x, 0), f, w0);
-                        w1 = bitfield_insert(change_mask(x, 1), f, w1);
-                        w2 = bitfield_insert(change_mask(x, 2), f, w2);
-                        w3 = bitfield_insert(change_mask(x, 3), f, w3);
-                    } while (inner);
-                    table[lane] = make_uint4(w0, w1, w2, w3);
+            const uint32_t k = kq[u] + (uint32_t)__popc(bits[u] & below);      // bit 0 of the bitmap is set: >= 1
+            const uint32_t v0 = rvm1[k], v1 = rvm1[k + 1];                     // (beyond the pile: some LDS word)
+            const uint32_t b7 = (bits[u] >> sh1) & 0x7Fu;                      // run starts at positions 1 .. 7
+            const uint32_t gl = 64u * u + lane;
+            const bool in = kFull || g0 + gl < nv;
+            const bool multi = in && (b7 & (b7 - 1u)) != 0;
+            // x = place of the (first) run start inside, 0 = none: find-first-bit gives -1 for none
+            const uint32_t x = ffbl_or_minus1(b7) + 1u;
+            const uint4 m = masks[x];
+            const uint32_t f0 = v0 | (v0 << 16), f1 = v1 | (v1 << 16);
+            const uint4 out = make_uint4(bitfield_insert(m.x, f1, f0), bitfield_insert(m.y, f1, f0),
+                                         bitfield_insert(m.z, f1, f0), bitfield_insert(m.w, f1, f0));
+            const uint64_t noted = __builtin_amdgcn_ballot_w64(multi);
+            if (noted) {
+                const uint32_t more = (uint32_t)__popcll(noted);
+                if (cnt + more > 64u) flush();
+                if (multi) {
+                    const uint32_t slot = cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(noted >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)noted, 0u));
+                    list[slot] = k | (b7 << 12) | ((g0 + gl) << 19);
                 }
-                wave_sync();
+                cnt += more;
             }
-#pragma unroll
-            for (uint32_t u = ub; u < ue; ++u) {
-                const uint32_t gl = 64u * u + lane;
-                const bool in = kFull || g0 + gl < nv;
-                const uint32_t vv = v[u] | (v[u] << 16);
-                uint4 out = make_uint4(vv, vv, vv, vv);
-                if (mine[u]) out = table[slot[u]];
-                if (in && store) store16(base, (g0 + gl) * 16u, out);
-            }
-            wave_sync();                                // the table is rewritten by the next call
-        };
-        typedef std::integral_constant<uint32_t, 0> I0;
-        typedef std::integral_constant<uint32_t, 1> I1;
-        typedef std::integral_constant<uint32_t, 2> I2;
-        typedef std::integral_constant<uint32_t, 3> I3;
-        typedef std::integral_constant<uint32_t, 4> I4;
-        if (total <= 64) {
-            emit(I0(), I4());
-        } else {
-            emit(I0(), I1()); emit(I1(), I2()); emit(I2(), I3()); emit(I3(), I4());
+            if (in && !multi && store) store16(base, (g0 + gl) * 16u, out);
         }
     };
     uint32_t g0 = 0;
     for (; g0 + 256 <= nv; g0 += 256) chunk(g0, std::true_type());
     if (g0 < nv) chunk(g0, std::false_type());
+    if (cnt) flush();
+    wave_sync();                                        // the list and the masks lie where others follow
 }
 
 }  // namespace
@@ -573,7 +573,6 @@ __global__ __launch_bounds__(64, kOne ? 6 : kBases > 32768 ? 2 : kBases > 16384 
     typedef typename L::rs_t rs_t;
     constexpr uint32_t kMaxReg = L::kMaxReg, kMaxRaw = L::kMaxRaw;
     __shared__ __align__(16) uint32_t sm[L::WORDS];
-    const uint32_t lane = threadIdx.x;
     uint32_t* ev = sm + L::X;
     rs_t* rs = (rs_t*)(sm + L::RS);
     uint16_t* rv = (uint16_t*)(sm + L::RV);
@@ -590,7 +589,22 @@ __global__ __launch_bounds__(64, kOne ? 6 : kBases > 32768 ? 2 : kBases > 16384 
         wave_sync();                                                       \
         continue;                                                          \
     }
-    for (uint32_t item = blockIdx.x; item < n_items; item = kOne ? n_items : item + gridDim.x) {
+    // Workgroup i runs on XCD i % 8.  A grid smaller than the number of items (a multiple of 8) gives every
+    // XCD one contiguous eighth of the items (tools/fill_bench3.hip: rows written side by side by one XCD
+    // stream out at 6.2 TB/s instead of 5.2 TB/s - in a fill kernel; this kernel does not notice).
+    uint32_t item_first = blockIdx.x, item_end = n_items, item_step = gridDim.x;
+    if (kOne && gridDim.x % 8u == 0 && gridDim.x < n_items) {
+        const uint32_t per = (n_items + 7u) / 8u, xcd = blockIdx.x % 8u;
+        item_first = xcd * per + blockIdx.x / 8u;
+        item_end = umin(n_items, (xcd + 1u) * per);
+        item_step = gridDim.x / 8u;
+    }
+    for (uint32_t item = item_first; item < item_end; item += item_step) {
+        // (The lane id is made opaque once per item: what is derived from it is then no loop invariant.  The
+        // compiler used to hoist such values out of the loop and keep them in registers for the whole kernel -
+        // 96 VGPRs and spills with a loop over items, 70 without one.)
+        uint32_t lane;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(lane) : "v"(threadIdx.x));
         const uint32_t r = A.order ? A.order[item] : item;
         const uint32_t n = A.read_len[r];
         const uint64_t row_off = kSens == 2 ? 0 : A.pile_off[r];
@@ -1661,9 +1675,16 @@ void launch_pile_runs(const PileArgs& args, uint32_t grid, int tier, uint32_t* o
                                 overflow_list, overflow_count);                                                         \
     } while (0)
     if (tier == 0 && grid >= args.n_items && !args.n_items_dev) {
-        if (diag) hipLaunchKernelGGL((pile_runs_kernel<kRunEventCap, true, 0, true>), dim3(grid), dim3(64), extra_lds, stream,
+        // the first kernel of the chain: one workgroup per item.  (Measured and not kept, RALA_PILE_PERSIST=<grid>:
+        // persistent wavefronts, each looping over a share of the items - 6144 of them, what the chip holds at
+        // once, take 6.5 ms where a million short-lived ones take 4.8; 12288: 5.4 ms.  A wavefront that goes on
+        // to its next item waits for that item's first loads alone; a fresh workgroup's start overlaps with the
+        // others' work.  The SQ counters' 74 % slot occupancy is not the dispatcher's doing.)
+        static const uint32_t persist = getenv("RALA_PILE_PERSIST") ? (uint32_t)atoi(getenv("RALA_PILE_PERSIST")) : 0u;
+        const uint32_t g = persist && persist < grid ? persist / 8u * 8u : grid;
+        if (diag) hipLaunchKernelGGL((pile_runs_kernel<kRunEventCap, true, 0, true>), dim3(g), dim3(64), extra_lds, stream,
                                      args, overflow_list, overflow_count);
-        else hipLaunchKernelGGL((pile_runs_kernel<kRunEventCap, false, 0, true>), dim3(grid), dim3(64), extra_lds, stream,
+        else hipLaunchKernelGGL((pile_runs_kernel<kRunEventCap, false, 0, true>), dim3(g), dim3(64), extra_lds, stream,
                                 args, overflow_list, overflow_count);
     } else if (tier == 3) {
         // reads of 16385 .. 32768 bases: the short layout with a bitmap twice the size
