@@ -339,3 +339,68 @@ def test_cli_several_ranks_give_the_single_gpu_result(tmp_path, gpus):
     a = subprocess.run([exe, "-p", fa, paf], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     b = subprocess.run([exe, "-p", "--gpus", str(gpus), fa, paf], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=many)
     assert a.returncode == 0 and b.returncode == 0 and a.stdout == b.stdout
+
+
+@pytest.mark.skipif(os.environ.get("RALA_SKIP_C5") == "1", reason="RALA_SKIP_C5=1")
+def test_cli_c5x_eight_ranks_sensitive_to_contigs(tmp_path):
+    """BASELINE configs[4]'s shape at the size an oracle can hold: c5x (200 k reads at 75x, 15 M overlaps) through
+    `rala -s <sensitive.paf> --gpus 8` - sharded construct with the sensitive pass, transitive reduction, simplify
+    with the layout kernel, unitigs, contig FASTA - against the oracle pipeline (reference Pile / Overlap objects
+    where built) + the oracle layout.  The eight ranks share this box's one GPU (in-process transport)."""
+    import time
+
+    build.build_host()
+    exe = os.path.join(build.PKG, "host", "rala")
+    ds = Dataset.config("c5x")
+    fa, paf, sens_paf = str(tmp_path / "reads.fasta"), str(tmp_path / "ovl.paf"), str(tmp_path / "sens.paf")
+    t0 = time.time()
+    ds.write_fasta(fa)
+    ds.write_paf(paf)
+    from rala_amd.cpus import effective_cpus
+    o = Oracle(ds.read_len, ds.overlaps, n_threads=effective_cpus())
+    assert o.initialize() == 0
+    o.pass2()
+    o.preprocess_chimeras()
+    p = o.piles()
+    sens = ds.sensitive(p["alive"], p["begin"], p["end"])
+    assert len(sens) > 100_000
+    ds.write_paf(sens_paf, sensitive=True, target_len=(p["end"] - p["begin"]).astype(np.uint32))
+    o.preprocess_repeats(sens)
+    o.build_graph()
+    pre = o.edges()
+    n_tr = o.remove_transitive_edges()
+    post = o.edges()
+    nodes = o.nodes()
+    want = _expected_layout(o, nodes, post, fa)
+    n_tips, n_bubbles, n_long = _simplify(want)
+    t1 = time.time()
+
+    env = dict(os.environ, RALA_COMM="local", RALA_GPU_DEVICES=",".join(["0"] * 8))
+    prefix = str(tmp_path / "dbg")
+    r = subprocess.run([exe, "-u", "-d", prefix, "-s", sens_paf, "--gpus", "8", "-t", str(effective_cpus()), fa, paf],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+    err = r.stderr.decode()
+    assert r.returncode == 0, err[-3000:]
+    print("c5x: oracle %.0f s, rala --gpus 8 %.0f s; %d nodes, %d edges, %d transitive, %d tips, %d bubbles, %d long edges" % (
+        t1 - t0, time.time() - t1, len(nodes), len(pre["src"]), n_tr, n_tips, n_bubbles, n_long))
+    assert "number of transitive edges = %d" % n_tr in err
+    assert "number of tips = %d" % n_tips in err
+    assert "number of bubbles = %d" % n_bubbles in err
+    assert "number of long edges = %d" % n_long in err
+    assert "number of nodes = %d" % len(nodes) in err
+    assert "number of edges = %d" % len(pre["src"]) in err
+    wn, we = want.dump()
+    got = _edges_from_csv(prefix + ".csv")
+    assert got == sorted((int(e), int(we["begin"][e]), int(we["end"][e]), int(we["length"][e]))
+                         for e in np.nonzero(we["alive"])[0])
+    want.run("unitigs")
+    wn, _ = want.dump()
+    exp = []
+    for k in np.nonzero(wn["alive"])[0]:
+        if k % 2 == 0:
+            data = want.node_data(int(k))
+            exp.append((b">Ctg%d RC:i:%d LN:i:%d" % (len(exp), wn["n_seq"][k], len(data)), data))
+    lines = r.stdout.split(b"\n")
+    got_c = [(lines[i], lines[i + 1]) for i in range(0, len(lines) - 1, 2)]
+    assert got_c == exp
+    assert sum(len(d) for _, d in exp) > 10_000_000        # tens of megabases of contigs out of a 26.65 Mb genome

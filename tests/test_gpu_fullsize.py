@@ -282,6 +282,114 @@ def test_c5_properties():
     same(a, one(), "second run")
 
 
+def _sens_result(ctx, n_tr=None):
+    """everything the sensitive pass leaves behind, as digests; n_tr: what the (sharded) run returned, or
+    None to run the transitive reduction here"""
+    out = {}
+    offs, pairs, flags = ctx.intervals(2)
+    out["rep"] = dg(offs.astype(np.uint64), pairs.astype(np.uint32), flags.astype(np.uint8))
+    out["n_repeat_hills"] = int(len(pairs))
+    p3 = ctx.piles()
+    out["piles3"] = dg(*[p3[k] for k in ("begin", "end", "median", "p10", "alive")])
+    ov = ctx.overlap_list(0)
+    out["n_overlaps_kept_sens"] = int(len(ov["src"]))
+    out["ov_sens"] = dg(*[np.asarray(ov[k]).astype(np.uint32) for k in
+                          ("src", "a_begin", "a_end", "b_begin", "b_end", "length", "type")])
+    out["n_tr"] = int(ctx.remove_transitive_edges()) if n_tr is None else int(n_tr)
+    g = ctx.graph()
+    out["nodes"] = dg(g["node_read"].astype(np.uint32))
+    out["n_edges"] = int(len(g["src"]))
+    out["edges"] = dg(g["src"].astype(np.uint32), g["dst"].astype(np.uint32), g["len"].astype(np.uint32),
+                      g["marked"].astype(np.uint8))
+    return out, p3
+
+
+@pytest.mark.skipif(os.environ.get("RALA_SKIP_C5") == "1", reason="RALA_SKIP_C5=1")
+def test_c5_sensitive_pass_and_sharded_run():
+    """BASELINE configs[4] as far as one GPU goes: `-s` at 4 M reads / 300 M overlaps (the sensitive set derived
+    from the HIP piles, as the two-pass workflow of the reference derives it from the first pass), and the
+    sharded runner over 8 ranks at that size (in-process transport, all ranks on this GPU), primary and `-s`.
+    No oracle can hold C5 here: the checks are the second add_layers' additivity on sampled targets, the
+    run-space against the position-space kernels, run-to-run determinism, and every rank of the sharded run
+    against the single-context result."""
+    from rala_amd import hip
+    from test_gpu_sharded import Sharded
+
+    ds = dataset("c5")
+    ov = ds.overlaps
+    world = 8
+
+    def single(sens=None, keep=None, **options):
+        ctx = hip.Context(0)
+        try:
+            for k, v in options.items():
+                ctx.set_option(k, v)
+            ctx.set_reads(ds.read_len)
+            ctx.set_overlaps(ov)
+            ctx.initialize()
+            if sens is None:
+                ctx.construct()
+                p2 = ctx.piles()
+                return p2, None, None
+            before = {int(t): np.asarray(ctx.pile_data(int(t)), dtype=np.int64) for t in keep} if keep is not None else None
+            ctx.construct(sens)
+            res, p3 = _sens_result(ctx)
+            after = {int(t): np.asarray(ctx.pile_data(int(t)), dtype=np.int64) for t in keep} if keep is not None else None
+            return res, p3, (before, after)
+        finally:
+            ctx.close()
+
+    # the chimera stage alone gives the piles the generator derives the sensitive set from
+    p2, _, _ = single()
+    sens = ds.sensitive(p2["alive"], p2["begin"], p2["end"])
+    assert len(sens) > 10_000_000, len(sens)
+    targets = np.unique(sens.b_id)
+    rng = np.random.default_rng(7)
+    sample = np.sort(rng.choice(targets, size=48, replace=False))
+
+    want, p3, (before, after) = single(sens, keep=sample)
+    assert want["n_repeat_hills"] > 0 and want["n_tr"] > 0
+    # Pile::add_layers of the sensitive bounds (graph.cpp:929-947: target side only, no +-15, shifted by the
+    # target's valid-region begin) on top of the first pass' coverage: what a sampled target gained inside
+    # its valid region is the clipped spans of the sensitive overlaps that hit it
+    sel = np.nonzero(np.isin(sens.b_id, sample))[0]
+    for t in sample:
+        t = int(t)
+        B, E = int(p2["begin"][t]), int(p2["end"][t])
+        m = sel[sens.b_id[sel] == t]
+        lo = np.clip(sens.b_begin[m].astype(np.int64) + B, B, E)
+        hi = np.clip(sens.b_end[m].astype(np.int64) + B, B, E)
+        gained = int(np.maximum(hi - lo, 0).sum())
+        assert int(after[t][B:E].sum()) - int(before[t][B:E].sum()) == gained, t
+        assert after[t][:B].sum() == 0 and after[t][E:].sum() == 0
+
+    # the position-space kernels (pile_kernels.hip, pile_repeats_kernel.hip) agree with the run-space ones
+    other, _, (_, after_pos) = single(sens, keep=sample[:12], use_run_kernel=0)
+    assert other == want, {k: (other[k], want[k]) for k in want if other[k] != want[k]}
+    for t in sample[:12]:
+        assert (after_pos[int(t)] == after[int(t)]).all(), int(t)
+    # determinism
+    again, _, _ = single(sens)
+    assert again == want
+
+    # the sharded runner at this size: 8 ranks, primary pass and -s, every rank's replicated result
+    sh = Sharded(ds, world)
+    try:
+        n = len(sens)
+        cut = [n * k // world for k in range(world + 1)]
+        shares = [sens.take(slice(cut[k], cut[k + 1])) for k in range(world)]
+        n_tr = hip.run_ranks(sh.ranks, shares)
+        assert n_tr == want["n_tr"]
+        for r in (sh.ranks[0], sh.ranks[3], sh.ranks[world - 1]):
+            got, _ = _sens_result(r.context(), n_tr)
+            assert got == want, {k: (got[k], want[k]) for k in want if got[k] != want[k]}
+        for t in sample[:16]:
+            assert (np.asarray(sh.ranks[int(t) % world].pile_data(int(t)), dtype=np.int64) == after[int(t)]).all(), int(t)
+        print("c5 sharded over", world, "ranks:", sh.ranks[0].timings())
+    finally:
+        sh.close()
+
+
 @pytest.mark.parametrize("wl", ["c2", "c5x", "c3"])
 def test_fullsize_sensitive_pass_matches_oracle_digests(hip_ctx_factory, wl):
     """Graph::preprocess with the sensitive overlap set (-s) at full size: repeat hills and their
