@@ -151,27 +151,32 @@ int from_comm(rala_hip_mg* mg, int rc, const char* where) {
     return RALA_HIP_EDEVICE;
 }
 
-// Every rank learns whether any rank failed (otherwise the others would wait in the next
-// collective for ever).  Returns this rank's code, or RALA_HIP_EDEVICE if only another one failed.
-// `flag` travels along and must be the same on every rank (with / without sensitive overlaps).
-int agree(rala_hip_mg* mg, int rc, const char* where, uint32_t flag = 0) {
-    std::vector<uint64_t> all(mg->world);
-    const uint64_t mine = (uint64_t)(uint32_t)(-rc) | (uint64_t)flag << 32;
-    if (mg->comm->host_all_gather(&mine, 1, all.data(), mg->cs->stream) != 0) {
+// Every rank learns whether any rank failed (otherwise the others would wait in the next collective for
+// ever) - riding on a host exchange the step needs anyway: every rank contributes `n` words of its own
+// behind a status word {code of its failure | flag << 32}; `flag` must be the same on every rank (with /
+// without sensitive overlaps).  all = world * (n + 1) words.  Returns this rank's code, or
+// RALA_HIP_EDEVICE if only another one failed.
+int agree_with(rala_hip_mg* mg, int rc, const char* where, uint32_t flag, const uint64_t* mine, uint32_t n,
+               std::vector<uint64_t>& all) {
+    std::vector<uint64_t> out(n + 1);
+    out[0] = (uint64_t)(uint32_t)(-rc) | (uint64_t)flag << 32;
+    for (uint32_t k = 0; k < n; ++k) out[k + 1] = mine ? mine[k] : 0;
+    all.assign((size_t)mg->world * (n + 1), 0);
+    if (mg->comm->host_all_gather(out.data(), n + 1, all.data(), mg->cs->stream) != 0) {
         if (rc == RALA_HIP_OK) return from_comm(mg, -1, where);
         return rc;
     }
     mg->verdict_shared = true;          // whatever is returned below, every rank returns a failure too
     if (rc != RALA_HIP_OK) return rc;
     for (uint32_t p = 0; p < mg->world; ++p) {
-        const uint64_t code = all[p] & 0xFFFFFFFFull;
+        const uint64_t code = all[(size_t)p * (n + 1)] & 0xFFFFFFFFull;
         if (code != 0) {
             return mg_fail(mg, code == (uint64_t)(-RALA_HIP_EFILTERED) ? RALA_HIP_EFILTERED : RALA_HIP_EDEVICE,
                            std::string(where) + ": rank " + std::to_string(p) + " failed with code -" + std::to_string(code));
         }
     }
     for (uint32_t p = 0; p < mg->world; ++p) {
-        if ((all[p] >> 32) != flag) {
+        if ((all[(size_t)p * (n + 1)] >> 32) != flag) {
             return mg_fail(mg, RALA_HIP_EINVAL, std::string(where) + ": rank " + std::to_string(p) +
                                                     " disagrees on whether there are sensitive overlaps");
         }
@@ -194,6 +199,7 @@ int run_primary(rala_hip_mg* mg, bool with_sens) {
         slot = (float)(u - t);
         t = u;
     };
+    std::vector<uint64_t> all;
 
     // 1. slice: duplicates, owner-grouped bound tuples
     int rc = from_ctx(mg, cs, rala_hip_dedupe(cs), "dedupe");
@@ -202,16 +208,15 @@ int run_primary(rala_hip_mg* mg, bool with_sens) {
         if (mg->d_send.ensure(4 * std::max<uint64_t>(cs->n_ovl, 1) + 8) != hipSuccess) rc = mg_fail(mg, RALA_HIP_ENOMEM, "tuple buffer");
         else rc = from_ctx(mg, cs, rala_hip_emit_bound_tuples_bucketed(cs, P, (uint64_t*)mg->d_send.p, send_counts.data()), "emit tuples");
     }
-    rc = agree(mg, rc, "emit", with_sens ? 1u : 0u);
+    // (the bucket sizes travel with the status: one host exchange)
+    rc = agree_with(mg, rc, "emit", with_sens ? 1u : 0u, send_counts.data(), P, all);
     if (rc != RALA_HIP_OK) return rc;
     lap(mg->tm.emit_ms);
 
-    // 2. ONE all-to-all(v) of 8-byte tuples (the bucket sizes travel first)
-    std::vector<uint64_t> matrix((size_t)P * P), recv_counts(P);
-    rc = from_comm(mg, comm->host_all_gather(send_counts.data(), P, matrix.data(), s), "tuple counts");
-    if (rc != RALA_HIP_OK) return rc;
+    // 2. ONE all-to-all(v) of 8-byte tuples
+    std::vector<uint64_t> recv_counts(P);
     uint64_t n_recv = 0;
-    for (uint32_t p = 0; p < P; ++p) { recv_counts[p] = matrix[(size_t)p * P + mg->rank]; n_recv += recv_counts[p]; }
+    for (uint32_t p = 0; p < P; ++p) { recv_counts[p] = all[(size_t)p * (P + 1) + 1 + mg->rank]; n_recv += recv_counts[p]; }
     MGCHECK(mg->d_recv.ensure(n_recv + 8));
     rc = from_comm(mg, comm->all_to_all_v(mg->d_send.p, send_counts.data(), mg->d_recv.p, recv_counts.data(), sizeof(uint2), s),
                    "all-to-all of the bound tuples");
@@ -227,7 +232,9 @@ int run_primary(rala_hip_mg* mg, bool with_sens) {
         if (rc == RALA_HIP_EFILTERED) rc = RALA_HIP_OK;      // all of ONE rank's reads filtered is not the job's verdict
         rc = from_ctx(mg, cl, rc, "owner initialize");
     }
-    rc = agree(mg, rc, "owner initialize");
+    // (the interval pools' sizes travel with the status)
+    const uint64_t my_pool = rc == RALA_HIP_OK ? cl->pool_used : 0;
+    rc = agree_with(mg, rc, "owner initialize", 0, &my_pool, 1, all);
     if (rc != RALA_HIP_OK) return rc;
     lap(mg->tm.owner_ms);
 
@@ -239,13 +246,14 @@ int run_primary(rala_hip_mg* mg, bool with_sens) {
                        read_arrays(cl), mg->n_local, L, mg->d_state_mine.p);
     rc = from_comm(mg, comm->all_gather(mg->d_state_mine.p, mg->d_state_all.p, L.bytes(), s), "all-gather of the read state");
     if (rc != RALA_HIP_OK) return rc;
-    const uint64_t my_pool = cl->pool_used;
     std::vector<uint64_t> pool_counts(P);
-    rc = from_comm(mg, comm->host_all_gather(&my_pool, 1, pool_counts.data(), s), "pool counts");
-    if (rc != RALA_HIP_OK) return rc;
     RankTable base;
     uint64_t pool_total = 0;
-    for (uint32_t p = 0; p < P; ++p) { base.v[p] = (uint32_t)pool_total; pool_total += pool_counts[p]; }
+    for (uint32_t p = 0; p < P; ++p) {
+        pool_counts[p] = all[(size_t)p * 2 + 1];
+        base.v[p] = (uint32_t)pool_total;
+        pool_total += pool_counts[p];
+    }
     if (pool_total >= 0xFFFFFFF0ull) {          // (the same sum on every rank)
         mg->verdict_shared = true;
         return mg_fail(mg, RALA_HIP_ECAPACITY, "interval pools of all ranks exceed 32-bit slots");
@@ -267,10 +275,9 @@ int run_primary(rala_hip_mg* mg, bool with_sens) {
     }
     lap(mg->tm.gather_ms);
 
-    // 5. second pass .. preprocess tail .. graph, sharded by slice where it is per overlap
+    // 5. second pass .. preprocess tail .. graph, sharded by slice where it is per overlap.  (No status
+    // exchange behind it: a rank that fails in there aborts the group, the caller sees to that.)
     rc = from_ctx(mg, cs, construct_stages(cs, comm, with_sens), "construct");
-    if (rc != RALA_HIP_OK) return rc;       // (local: the others may be inside one of its collectives - the caller aborts the group)
-    rc = agree(mg, rc, "construct");
     if (rc != RALA_HIP_OK) return rc;
     lap(mg->tm.construct_ms);
     return RALA_HIP_OK;
@@ -392,8 +399,6 @@ int run_all(rala_hip_mg* mg, const rala_hip_overlaps* sens_slice, uint64_t n_sen
         // pointer or none does; the first agree() of the run checked that)
         const double t2 = now_ms();
         rc = from_ctx(mg, mg->cs, repeats_stage(mg->cs, mg->cl, mg->comm, sens_slice, n_sens), "sensitive pass");
-        if (rc != RALA_HIP_OK) return rc;
-        rc = agree(mg, rc, "sensitive pass");
         if (rc != RALA_HIP_OK) return rc;
         mg->tm.repeats_ms = (float)(now_ms() - t2);
     }
