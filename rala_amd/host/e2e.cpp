@@ -30,7 +30,12 @@ extern "C" int rala_e2e_from_paf(const char* paf_path, const uint32_t* read_len,
     const auto t0 = clock::now();
     rala::io::OverlapColumns c;
     int64_t bad = -1;
-    if (!rala::io::read_paf_parallel(paf_path, table, len, true, num_threads, c, &bad) || bad >= 0) {
+    const std::string path(paf_path);
+    // (a gzip-compressed file: one thread inflates, the others parse)
+    const bool ok = rala::io::has_suffix(path, ".gz")
+                        ? rala::io::read_overlaps_streamed(path, false, table, len, true, num_threads, c, &bad)
+                        : rala::io::read_paf_parallel(path, table, len, true, num_threads, c, &bad);
+    if (!ok || bad >= 0) {
         rala_hip_destroy(ctx);
         return -2;
     }

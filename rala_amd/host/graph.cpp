@@ -162,22 +162,14 @@ void read_overlaps(const std::string& path, const std::unordered_map<std::string
         exit(1);
     };
     bool ok;
+    int64_t bad = -1;
     if (io::has_suffix(path, ".paf")) {
-        int64_t bad = -1;
         ok = io::read_paf_parallel(path, name_table, read_len, check_lengths, num_threads, c, &bad);
-        if (ok && bad >= 0) length_error((uint64_t)bad);
+    } else if (io::has_suffix(path, ".paf.gz")) {
+        // one thread inflates, the others parse (io.cpp)
+        ok = io::read_overlaps_streamed(path, false, name_table, read_len, check_lengths, std::max(2u, num_threads), c, &bad);
     } else if (io::has_suffix(path, ".mhap") || io::has_suffix(path, ".mhap.gz")) {
-        ok = io::read_mhap(path, [&](const io::MhapRecord& r) {
-            const uint64_t a = r.a_id - 1, b = r.b_id - 1;
-            const uint32_t ia = a < read_len.size() ? (uint32_t)a : RALA_HIP_NO_READ;
-            const uint32_t ib = b < read_len.size() ? (uint32_t)b : RALA_HIP_NO_READ;
-            if (check_lengths && ia != RALA_HIP_NO_READ && r.a_length != read_len[ia]) length_error(a);
-            if (check_lengths && ib != RALA_HIP_NO_READ && ia != RALA_HIP_NO_READ && r.b_length != read_len[ib]) {
-                length_error(b);
-            }
-            push(ia, ib, r.a_begin, r.a_end, r.b_begin, r.b_end, std::max(r.a_end - r.a_begin, r.b_end - r.b_begin),
-                 r.a_rc == r.b_rc ? 0 : 1);
-        });
+        ok = io::read_overlaps_streamed(path, true, name_table, read_len, check_lengths, std::max(2u, num_threads), c, &bad);
     } else {
         ok = io::read_paf(path, [&](const io::PafRecord& r) {
             auto a = name_to_id.find(r.q_name), b = name_to_id.find(r.t_name);
@@ -191,6 +183,7 @@ void read_overlaps(const std::string& path, const std::unordered_map<std::string
             push(ia, ib, r.q_begin, r.q_end, r.t_begin, r.t_end, r.overlap_length, r.orientation == '+' ? 0 : 1);
         });
     }
+    if (ok && bad >= 0) length_error((uint64_t)bad);
     if (!ok) {
         fprintf(stderr, "[rala::Graph::initialize] error: unable to open file %s!\n", path.c_str());
         exit(1);

@@ -178,6 +178,10 @@ bool read_mhap(const std::string& path, const std::function<void(const MhapRecor
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <memory>
+#include <mutex>
 #include <new>
 #include <thread>
 
@@ -778,6 +782,223 @@ bool read_paf_parallel(const std::string& path, const NameTable& names, const st
     if (trace) {
         fprintf(stderr, "[io] %u threads: read + count %.1f ms, parse %.1f ms, close gaps %.1f ms, total %.1f ms\n", n_thr, ms_read,
                 ms_parse, ms_close, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count());
+    }
+    return true;
+}
+
+// ---- compressed PAF, and MHAP: one inflating thread, the others parse --------------------------------
+// A gzip stream can only be inflated front to back.  One thread does that (zlib; it also reads plain
+// files), cutting the text into blocks of a few megabytes that end with a line; the other threads take the
+// blocks as they come, count their lines, parse them with the same tokenizer as read_paf_parallel into
+// columns of their own, and the blocks' columns are copied into the final ones in file order.  The file's
+// rate is then the inflater's (about half a gigabyte of text per second) instead of inflater + parser on one
+// thread.  (BGZF files could be inflated block-parallel; not done.)
+namespace {
+
+// one MHAP line [p, e): "a_id b_id error minmers a_rc a_begin a_end a_len b_rc b_begin b_end b_len", blank
+// separated, ids from 1 (reference src/overlap.cpp:12-20); false if it has fewer than 12 columns
+inline bool parse_mhap_line(const char* p, const char* e, const std::vector<uint32_t>& read_len, bool check_lengths, Chunk& c) {
+    const char* f[13];
+    int nf = 0;
+    f[nf++] = p;
+    for (const char* q = p; q < e && nf < 13;) {
+        const char* sp = (const char*)memchr(q, ' ', (size_t)(e - q));
+        if (!sp) break;
+        f[nf++] = sp + 1;
+        q = sp + 1;
+    }
+    if (nf < 12) return false;
+    auto end_of = [&](int k) { return k + 1 < nf ? f[k + 1] - 1 : e; };
+    auto num = [&](int k) { uint32_t v; field_u32(f[k], end_of(k), v); return v; };
+    uint64_t ida = 0, idb = 0;
+    for (const char* q = f[0]; q < end_of(0) && *q >= '0' && *q <= '9'; ++q) ida = ida * 10 + (uint64_t)(*q - '0');
+    for (const char* q = f[1]; q < end_of(1) && *q >= '0' && *q <= '9'; ++q) idb = idb * 10 + (uint64_t)(*q - '0');
+    const uint64_t a = ida - 1, b = idb - 1;
+    const uint32_t ia = a < read_len.size() ? (uint32_t)a : 0xFFFFFFFFu;
+    const uint32_t ib = b < read_len.size() ? (uint32_t)b : 0xFFFFFFFFu;
+    const uint32_t a_rc = num(4), ab = num(5), ae = num(6), al = num(7), b_rc = num(8), bb = num(9), be = num(10), bl = num(11);
+    if (check_lengths && c.error_read < 0) {
+        if (ia != 0xFFFFFFFFu && al != read_len[ia]) c.error_read = ia;
+        else if (ia != 0xFFFFFFFFu && ib != 0xFFFFFFFFu && bl != read_len[ib]) c.error_read = ib;
+    }
+    const size_t w = c.n++;
+    c.a_id[w] = ia; c.b_id[w] = ib;
+    c.a_begin[w] = ab; c.a_end[w] = ae; c.b_begin[w] = bb; c.b_end[w] = be;
+    c.length[w] = std::max(ae - ab, be - bb);
+    c.strand[w] = a_rc == b_rc ? 0 : 1;
+    return true;
+}
+
+struct TextBlock {
+    std::vector<char, UninitAllocator<char>> text;      // kFront slack, n bytes of whole lines, kBack slack
+    size_t n = 0;
+    size_t index = 0;
+};
+
+struct BlockColumns {
+    OverlapColumns cols;
+    size_t n = 0;
+    int64_t error_read = -1;
+};
+
+}  // namespace
+
+bool read_overlaps_streamed(const std::string& path, bool mhap, const NameTable& names, const std::vector<uint32_t>& read_len,
+    bool check_lengths, uint32_t num_threads, OverlapColumns& out, int64_t* length_error) {
+    if (length_error) *length_error = -1;
+    gzFile in = gzopen(path.c_str(), "rb");
+    if (!in) return false;
+    gzbuffer(in, 1 << 20);
+    constexpr size_t kFront = 8, kBack = 80, kBlockText = 4 << 20;
+    const uint32_t n_parsers = std::max(1u, num_threads > 1 ? num_threads - 1 : 1u);
+    const bool wide = !mhap && __builtin_cpu_supports("avx512bw") && getenv("RALA_IO_NO_AVX512") == nullptr;
+
+    std::mutex m;
+    std::condition_variable cv_block, cv_room;
+    std::deque<std::unique_ptr<TextBlock>> queue;
+    const size_t max_queued = 2 * (size_t)n_parsers + 2;
+    bool done = false, failed = false;
+    std::vector<std::unique_ptr<BlockColumns>> results;         // by block index (under m when resized)
+
+    auto parse_block = [&](TextBlock& tb) {
+        std::unique_ptr<BlockColumns> res(new BlockColumns);
+        const char* text = tb.text.data() + kFront;
+        const size_t n = tb.n;
+        size_t lines = 0;
+        for (const char* q = text; q < text + n;) {             // an upper bound of the records
+            const char* nl = (const char*)memchr(q, '\n', (size_t)(text + n - q));
+            ++lines;
+            if (!nl) break;
+            q = nl + 1;
+        }
+        OverlapColumns& c = res->cols;
+        c.a_id.resize(lines); c.b_id.resize(lines); c.a_begin.resize(lines); c.a_end.resize(lines);
+        c.b_begin.resize(lines); c.b_end.resize(lines); c.length.resize(lines); c.strand.resize(lines);
+        std::unique_ptr<Chunk> ck(new Chunk);
+        ck->a_id = c.a_id.data(); ck->b_id = c.b_id.data(); ck->a_begin = c.a_begin.data(); ck->a_end = c.a_end.data();
+        ck->b_begin = c.b_begin.data(); ck->b_end = c.b_end.data(); ck->length = c.length.data(); ck->strand = c.strand.data();
+        if (wide) {
+            (void)parse_lines_avx512(text, 0, n, n, true, names, read_len, check_lengths, *ck);
+        } else {
+            size_t k = 0;
+            while (k < n) {
+                const char* nl = (const char*)memchr(text + k, '\n', n - k);
+                const size_t e = nl ? (size_t)(nl - text) : n;
+                size_t le = e;
+                if (le > k && text[le - 1] == '\r') --le;
+                if (le > k) {
+                    if (mhap) parse_mhap_line(text + k, text + le, read_len, check_lengths, *ck);
+                    else parse_paf_line(text + k, text + le, names, read_len, check_lengths, *ck);
+                }
+                k = e + 1;
+            }
+        }
+        if (!mhap) resolve_batch(names, read_len, check_lengths, *ck);
+        res->n = ck->n;
+        res->error_read = ck->error_read;
+        return res;
+    };
+
+    std::vector<std::thread> parsers;
+    for (uint32_t k = 0; k < n_parsers; ++k) {
+        parsers.emplace_back([&] {
+            for (;;) {
+                std::unique_ptr<TextBlock> tb;
+                {
+                    std::unique_lock<std::mutex> hold(m);
+                    cv_block.wait(hold, [&] { return !queue.empty() || done; });
+                    if (queue.empty()) return;
+                    tb = std::move(queue.front());
+                    queue.pop_front();
+                }
+                cv_room.notify_one();
+                std::unique_ptr<BlockColumns> res = parse_block(*tb);
+                std::lock_guard<std::mutex> hold(m);
+                if (results.size() <= tb->index) results.resize(tb->index + 1);
+                results[tb->index] = std::move(res);
+            }
+        });
+    }
+
+    // this thread inflates: blocks end with a line; what follows the last newline opens the next block
+    std::vector<char> carry;
+    size_t n_blocks = 0;
+    for (bool eof = false; !eof;) {
+        std::unique_ptr<TextBlock> tb(new TextBlock);
+        const size_t target = carry.size() + kBlockText;        // (a line longer than a block grows the next one)
+        tb->text.resize(kFront + target + kBack);
+        memset(tb->text.data(), 0, kFront);
+        char* text = tb->text.data() + kFront;
+        memcpy(text, carry.data(), carry.size());
+        size_t have = carry.size();
+        carry.clear();
+        while (have < target) {
+            const int got = gzread(in, text + have, (unsigned)std::min<size_t>(target - have, (size_t)1 << 20));
+            if (got < 0) { failed = true; eof = true; break; }
+            if (got == 0) { eof = true; break; }
+            have += (size_t)got;
+        }
+        size_t n = have;
+        if (!eof) {
+            const char* nl = (const char*)memrchr(text, '\n', have);
+            if (!nl) {                                          // no line ends in here: all of it opens the next block
+                carry.assign(text, text + have);
+                continue;
+            }
+            n = (size_t)(nl - text) + 1;
+            carry.assign(text + n, text + have);
+        }
+        if (n == 0) continue;
+        memset(text + n, 0, kBack);
+        tb->n = n;
+        tb->index = n_blocks++;
+        {
+            std::unique_lock<std::mutex> hold(m);
+            cv_room.wait(hold, [&] { return queue.size() < max_queued; });
+            queue.push_back(std::move(tb));
+        }
+        cv_block.notify_one();
+    }
+    {
+        std::lock_guard<std::mutex> hold(m);
+        done = true;
+    }
+    cv_block.notify_all();
+    for (auto& t : parsers) t.join();
+    gzclose(in);
+    if (failed) return false;
+
+    // the blocks' columns into the final ones, in file order
+    std::vector<size_t> at(n_blocks + 1);
+    at[0] = out.size();
+    for (size_t b = 0; b < n_blocks; ++b) at[b + 1] = at[b] + (results.size() > b && results[b] ? results[b]->n : 0);
+    const size_t total = at[n_blocks];
+    out.a_id.resize(total); out.b_id.resize(total); out.a_begin.resize(total); out.a_end.resize(total);
+    out.b_begin.resize(total); out.b_end.resize(total); out.length.resize(total); out.strand.resize(total);
+    for (size_t b = 0; b < n_blocks; ++b) {                     // the first mismatching line in file order
+        if (results.size() > b && results[b] && results[b]->error_read >= 0) {
+            if (length_error) *length_error = results[b]->error_read;
+            break;
+        }
+    }
+    {
+        std::atomic<size_t> next(0);
+        auto copy = [&] {
+            for (size_t b = next.fetch_add(1); b < n_blocks; b = next.fetch_add(1)) {
+                if (results.size() <= b || !results[b]) continue;
+                const BlockColumns& r = *results[b];
+                const size_t w = at[b], n = r.n;
+                memcpy(out.a_id.data() + w, r.cols.a_id.data(), n * 4); memcpy(out.b_id.data() + w, r.cols.b_id.data(), n * 4);
+                memcpy(out.a_begin.data() + w, r.cols.a_begin.data(), n * 4); memcpy(out.a_end.data() + w, r.cols.a_end.data(), n * 4);
+                memcpy(out.b_begin.data() + w, r.cols.b_begin.data(), n * 4); memcpy(out.b_end.data() + w, r.cols.b_end.data(), n * 4);
+                memcpy(out.length.data() + w, r.cols.length.data(), n * 4); memcpy(out.strand.data() + w, r.cols.strand.data(), n);
+                results[b].reset();
+            }
+        };
+        std::vector<std::thread> th;
+        for (uint32_t k = 1; k < n_parsers; ++k) th.emplace_back(copy);
+        copy();
+        for (auto& t : th) t.join();
     }
     return true;
 }

@@ -106,5 +106,12 @@ struct OverlapColumns {
 bool read_paf_parallel(const std::string& path, const NameTable& names, const std::vector<uint32_t>& read_len,
     bool check_lengths, uint32_t num_threads, OverlapColumns& out, int64_t* length_error);
 
+// The same result for a gzip-compressed (or plain) PAF file, or an MHAP file (mhap = true: blank-separated
+// columns, 1-based ids, reference src/overlap.cpp:12-20; `names` is not used then): ONE thread inflates -
+// a gzip stream cannot be cut - and hands blocks of whole lines to the others, which parse them with the
+// tokenizer of read_paf_parallel.
+bool read_overlaps_streamed(const std::string& path, bool mhap, const NameTable& names, const std::vector<uint32_t>& read_len,
+    bool check_lengths, uint32_t num_threads, OverlapColumns& out, int64_t* length_error);
+
 }  // namespace io
 }  // namespace rala

@@ -3,6 +3,8 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <algorithm>
+
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -21,8 +23,9 @@ struct Parsed {
 
 extern "C" {
 
-// names: n_reads names separated by '\n'.  parallel = 0: io::read_paf + std::unordered_map (the
-// path gzip input takes), 1: io::read_paf_parallel
+// names: n_reads names separated by '\n'.  parallel = 0: io::read_paf + std::unordered_map (the line-by-line
+// reader), 1: io::read_paf_parallel, 2: io::read_overlaps_streamed (PAF, plain or gzip), 3: the same for
+// MHAP, 4: io::read_mhap line by line
 void* io_paf_parse(const char* path, const char* names, const uint32_t* read_len, uint64_t n_reads, int check_lengths,
                    uint32_t threads, int parallel) {
     std::vector<std::string> nm;
@@ -34,10 +37,27 @@ void* io_paf_parse(const char* path, const char* names, const uint32_t* read_len
     }
     std::vector<uint32_t> len(read_len, read_len + n_reads);
     auto* out = new Parsed();
-    if (parallel) {
+    if (parallel == 1 || parallel == 2 || parallel == 3) {
         rala::io::NameTable table;
         table.build(nm);
-        out->ok = rala::io::read_paf_parallel(path, table, len, check_lengths != 0, threads, out->cols, &out->length_error);
+        if (parallel == 1) out->ok = rala::io::read_paf_parallel(path, table, len, check_lengths != 0, threads, out->cols, &out->length_error);
+        else out->ok = rala::io::read_overlaps_streamed(path, parallel == 3, table, len, check_lengths != 0, threads, out->cols, &out->length_error);
+        return out;
+    }
+    if (parallel == 4) {
+        auto& c = out->cols;
+        out->ok = rala::io::read_mhap(path, [&](const rala::io::MhapRecord& r) {
+            const uint64_t a = r.a_id - 1, b = r.b_id - 1;
+            const uint32_t ia = a < len.size() ? (uint32_t)a : 0xFFFFFFFFu, ib = b < len.size() ? (uint32_t)b : 0xFFFFFFFFu;
+            if (out->length_error < 0) {
+                if (check_lengths && ia != 0xFFFFFFFFu && r.a_length != len[ia]) out->length_error = ia;
+                else if (check_lengths && ia != 0xFFFFFFFFu && ib != 0xFFFFFFFFu && r.b_length != len[ib]) out->length_error = ib;
+            }
+            c.a_id.push_back(ia); c.b_id.push_back(ib);
+            c.a_begin.push_back(r.a_begin); c.a_end.push_back(r.a_end);
+            c.b_begin.push_back(r.b_begin); c.b_end.push_back(r.b_end);
+            c.length.push_back(std::max(r.a_end - r.a_begin, r.b_end - r.b_begin)); c.strand.push_back(r.a_rc == r.b_rc ? 0 : 1);
+        });
         return out;
     }
     std::unordered_map<std::string, uint64_t> map;

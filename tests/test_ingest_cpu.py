@@ -141,3 +141,89 @@ def test_length_mismatch_is_reported(tmp_path, tokenizer):
         _, seq = parse(path, ["r0", "r1"], [1000, 2000], 1, False, check_lengths=False)
         _, par = parse(path, ["r0", "r1"], [1000, 2000], threads, True, check_lengths=False)
         assert seq == par == -1
+
+
+def _to_mhap(paf, mhap):
+    """PAF -> MHAP: "a_id b_id error minmers a_rc a_begin a_end a_len b_rc b_begin b_end b_len", ids from 1"""
+    with open(paf) as src, open(mhap, "w") as dst:
+        for line in src:
+            f = line.split("\t")
+            if len(f) < 12:
+                dst.write(line)
+                continue
+            a, b = int(f[0][1:]) + 1, int(f[5][1:]) + 1
+            dst.write("%d %d 0.1 42 0 %s %s %s %d %s %s %s\n" % (a, b, f[2], f[3], f[1], 0 if f[4] == "+" else 1, f[7], f[8], f[6]))
+
+
+@pytest.mark.parametrize("threads", [1, 2, 4, 9])
+def test_streamed_reader_gzip_and_mhap(tmp_path, threads, tokenizer):
+    """compressed PAF and MHAP go through one inflating thread + parser threads (io::read_overlaps_streamed):
+    the same columns as the line-by-line readers, whatever the thread count; blocks of 4 MB are cut at lines"""
+    import gzip
+    import shutil
+
+    ds = Dataset(6000, 1_000_000, 4)            # 18 MB of PAF: several blocks
+    paf = str(tmp_path / "ovl.paf")
+    ds.write_paf(paf)
+    assert os.path.getsize(paf) > 9 << 20
+    names = ["r%d" % i for i in range(ds.n_reads)]
+    want, e0 = parse(paf, names, ds.read_len, 1, 0)
+    gz = paf + ".gz"
+    with open(paf, "rb") as src, gzip.open(gz, "wb", compresslevel=1) as dst:
+        shutil.copyfileobj(src, dst)
+    for path in (paf, gz):
+        got, e1 = parse(path, names, ds.read_len, threads, 2)
+        assert e0 == e1 == -1
+        for f in want:
+            assert (want[f] == got[f]).all(), (path, f)
+    mhap = str(tmp_path / "ovl.mhap")
+    _to_mhap(paf, mhap)
+    with open(mhap, "rb") as src, gzip.open(mhap + ".gz", "wb", compresslevel=1) as dst:
+        shutil.copyfileobj(src, dst)
+    seq, e2 = parse(mhap, names, ds.read_len, 1, 4)
+    for path in (mhap, mhap + ".gz"):
+        got, e3 = parse(path, names, ds.read_len, threads, 3)
+        assert e2 == e3 == -1
+        for f in seq:
+            assert (seq[f] == got[f]).all(), (path, f)
+    # MHAP carries no alignment length: the longer span (overlap.cpp:18)
+    for f in ("a_id", "b_id", "a_begin", "a_end", "b_begin", "b_end"):
+        assert (seq[f] == want[f]).all(), f
+    assert (seq["strand"] == want["strand"]).all()
+    assert (seq["length"] == np.maximum(want["a_end"] - want["a_begin"], want["b_end"] - want["b_begin"])).all()
+
+
+def test_streamed_reader_awkward_input(tmp_path, tokenizer):
+    """empty lines, short lines, CR LF, a missing last newline, a line longer than a block, length mismatches"""
+    import gzip
+
+    names, lens = ["r0", "r1", "r2"], [1000, 2000, 3000]
+    lines = [
+        "r0\t1000\t10\t900\t+\tr1\t2000\t5\t895\t800\t890\t255",
+        "",
+        "r1 comment\t2000\t0\t1500\t-\tr2\t3000\t100\t1600\t1400\t1500\t255\ttp:A:S\tzz:Z:" + "y" * (5 << 20),
+        "rX\t500\t0\t400\t+\tr0\t1000\t0\t400\t300\t400\t60",
+        "short\tline",
+        "r2\t3000\t7\t2000\t+\tr0\t1000\t1\t999\t900\t1993\t255\r",
+        "r0\t1000\t1\t2\t-\tr2\t3000\t3\t4\t5\t6\t7",
+    ]
+    path = str(tmp_path / "odd.paf.gz")
+    with gzip.open(path, "wt") as f:
+        f.write("\n".join(lines))
+    want, e0 = parse(path, names, lens, 1, 0)
+    for threads in (1, 3):
+        got, e1 = parse(path, names, lens, threads, 2)
+        assert e0 == e1 == -1
+        for f in want:
+            assert want[f].tolist() == got[f].tolist(), (threads, f)
+    assert want["a_id"].tolist() == [0, 1, 0xFFFFFFFF, 2, 0]
+    bad = str(tmp_path / "bad.mhap")
+    with open(bad, "w") as f:
+        f.write("1 2 0.1 42 0 0 500 1000 0 0 500 2000\n" * 30)
+        f.write("2 1 0.1 42 0 0 500 2000 1 0 500 1001\n")     # target length wrong: read 0
+        f.write("1 2 0.1 42 0 0 500 999 0 0 500 2000\n")
+    for mode, threads in ((4, 1), (3, 1), (3, 4)):
+        _, e = parse(bad, names, lens, threads, mode)
+        assert e == 0
+        _, e = parse(bad, names, lens, threads, mode, check_lengths=False)
+        assert e == -1

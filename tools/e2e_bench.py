@@ -1,5 +1,6 @@
 """End-to-end overlaps/s from PAF text (second figure): multi-threaded
-ingest + upload + the whole device path.  python tools/e2e_bench.py [c2|c3] [threads]"""
+ingest + upload + the whole device path.  python tools/e2e_bench.py [c2|c3] [threads]
+RALA_E2E_GZIP=1: the same from a gzip-compressed file (gzip -1; one thread inflates, the others parse)."""
 import ctypes
 import json
 import os
@@ -26,6 +27,12 @@ with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as d:
     ds.write_paf(paf)
     size = os.path.getsize(paf)
     print("[e2e] wrote %s: %.2f GB in %.1f s" % (wl, size / 1e9, time.time() - t0), file=sys.stderr)
+    if os.environ.get("RALA_E2E_GZIP") == "1":
+        import subprocess
+        t0 = time.time()
+        subprocess.run(["gzip", "-1", paf], check=True)
+        paf += ".gz"
+        print("[e2e] gzip -1: %.2f GB in %.1f s" % (os.path.getsize(paf) / 1e9, time.time() - t0), file=sys.stderr)
     best = None
     # RALA_E2E_AB=VAR: alternate runs without and with the environment variable VAR=1 (reader variants), report both
     ab = os.environ.get("RALA_E2E_AB")
