@@ -95,7 +95,8 @@ def build_hip(force=False, jobs=None):
         with ThreadPoolExecutor(max_workers=jobs or min(8, os.cpu_count() or 1)) as pool:
             list(pool.map(compile_one, todo))
     if force or todo or _stale(out, objs):
-        _link([cc, "--offload-arch=gfx950", "-shared", "-fPIC"], out, objs + ["-ldl"])
+        # (-z defs: a launcher that is declared but not defined must fail here, not at dlopen on the GPU box)
+        _link([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-z,defs"], out, objs + ["-ldl", "-lpthread"])
     return out
 
 

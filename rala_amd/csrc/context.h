@@ -77,6 +77,7 @@ struct PinnedBuf {
 
 struct rala_hip_ctx {
     int device = 0;
+    uint32_t n_compute_units = 256;
     hipStream_t stream = nullptr;
     hipStream_t side = nullptr;         // duplicate removal runs here, beside the bucketing
     hipStream_t aux = nullptr;          // the pile chain's small kernels (long and event-dense reads), beside the first one

@@ -277,20 +277,8 @@ void launch_tail_death_round(const TailList& L, const uint8_t* alive, uint32_t w
                              uint32_t* death_new, hipStream_t s);
 void launch_tail_apply_scan(const TailList& L, const uint8_t* alive, uint32_t which, const uint32_t* death, hipStream_t s);
 void launch_kill_reads(const uint32_t* death, uint8_t* alive, uint32_t n, hipStream_t s);
-void launch_keep_flags(const TailList& L, const uint8_t* alive, uint32_t want_state, uint32_t want_round, uint32_t* flag,
-                       hipStream_t s);
-void launch_u8_to_u32(const uint8_t* in, uint32_t* out, uint32_t n, hipStream_t s);
-void launch_ranks(const uint8_t* alive, const uint32_t* pos, uint32_t* rank, uint32_t* alive_reads, uint32_t n, hipStream_t s);
-// (base_in: device word with the segment's first position, null = 0; *base_out = that + the segment's length)
-void launch_place_kept(const TailList& L, const TailReads& R, const uint32_t* flag, const uint32_t* pos, const uint32_t* base_in,
-                       uint32_t* base_out, uint32_t* kept_item, uint32_t* dovetail, hipStream_t s);
-void launch_build_edges(const TailList& L, const TailReads& R, const uint32_t* kept_item, const uint32_t* dovetail,
-                        const uint32_t* epos, uint32_t n_kept, const uint32_t* node_rank, uint32_t* e_src, uint32_t* e_dst,
-                        uint32_t* e_len, hipStream_t s);
-void launch_node_reads(const uint8_t* alive, const uint32_t* rank, uint32_t* node_read, uint32_t n, hipStream_t s);
 void launch_count_zero_u8(const uint8_t* x, uint32_t n, uint32_t* out, hipStream_t s);    // *out += #zeros
-void launch_init_list_state(uint8_t* state, uint8_t* round, uint32_t n0, uint32_t n, hipStream_t s);
-// the same + dirty[] = 0, n_pits0[] = n_pits[] in one launch
+// list states (the first n0 items are overlaps, the rest internals), dirty[] = 0, n_pits0[] = n_pits[] in one launch
 void launch_tail_init(const TailList& L, uint32_t n0, const TailReads& R, uint8_t* n_pits0, uint32_t n_reads, hipStream_t s);
 // single-pass scans with producer and consumer inside (scan_pass.h); false = out of tile states
 struct ScanSpace;

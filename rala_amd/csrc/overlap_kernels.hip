@@ -628,6 +628,12 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// (Measured, tools/gpurun/r3_probe_masks.sh at C3: the three columns alone stream in 0.11 ms, the two fate
+// bytes add 0.22 ms, the candidates 0.11 ms.  The target's byte is a random access that misses the vector
+// L1; a ONE-bit table "never dies or has hills" in LDS - 125 KB per million reads, one workgroup of 1024
+// threads per compute unit - takes nine look-ups in ten off the memory path and came out at the same
+// 0.43 ms, persistent or not: sixteen wavefronts per compute unit hide less than the thirty-two of this
+// kernel.  Not kept.)
 // One overlap in forty needs more than the two bytes, and a wavefront that takes them as they come has
 // such a lane in four iterations out of five: every one of its eight iterations then walks the long path
 // (death values -> records -> coordinates -> hill intervals, one round trip after the other) for one or
@@ -642,7 +648,7 @@ __global__ __launch_bounds__(kBlock) void survivor_masks_kernel(OvlSoA o, uint32
                                                                 const uint4* __restrict__ rec, Interval* pool,
                                                                 uint64_t* __restrict__ mask_ov, uint64_t* __restrict__ mask_in,
                                                                 uint32_t* __restrict__ chunk_ov,
-                                                                uint32_t* __restrict__ chunk_in) {
+                                                                uint32_t* __restrict__ chunk_in, uint32_t probe) {
     constexpr uint32_t kPer = kClassifyChunk / kBlock, kWaves = kBlock / 64;
     __shared__ uint32_t s_ov, s_in;
     __shared__ uint16_t s_list[kWaves][kPer * 64];
@@ -666,8 +672,8 @@ __global__ __launch_bounds__(kBlock) void survivor_masks_kernel(OvlSoA o, uint32
     uint32_t fa[kPer], fb[kPer];
 #pragma unroll
     for (uint32_t u = 0; u < kPer; ++u) {
-        fa[u] = fate[a[u] < n_reads ? a[u] : 0u];
-        fb[u] = fate[b[u] < n_reads ? b[u] : 0u];
+        fa[u] = probe & 2u ? a[u] & 3u : fate[a[u] < n_reads ? a[u] : 0u];
+        fb[u] = probe & 2u ? b[u] & 3u : fate[b[u] < n_reads ? b[u] : 0u];
     }
     uint32_t cnt = 0;           // candidates of this wavefront (the same in every lane)
 #pragma unroll
@@ -680,6 +686,7 @@ __global__ __launch_bounds__(kBlock) void survivor_masks_kernel(OvlSoA o, uint32
         cnt += (uint32_t)__popcll(m);
     }
     wave_lds_sync();
+    if (probe & 1u) cnt = 0;
     for (uint32_t k = lane; k < cnt; k += 64) {
         const uint32_t e = s_list[wave][k];
         const uint32_t u = e >> 6, l = e & 63u;
@@ -946,11 +953,12 @@ void launch_survivor_masks(const OvlSoA& o, uint32_t n_reads, const uint8_t* val
     if (!o.n) return;
     const dim3 grid(pass2_chunks(o.n));
     if (small_records) {
+        static const uint32_t probe = getenv("RALA_MASKS_PROBE") ? (uint32_t)atoi(getenv("RALA_MASKS_PROBE")) : 0u;   // measurements only
         hipLaunchKernelGGL(survivor_masks_kernel<true>, grid, dim3(kBlock), 0, s, o, n_reads, valid, fate, death, (const uint32_t*)crec, rec, pool,
-                           mask_ov, mask_in, chunk_ov, chunk_in);
+                           mask_ov, mask_in, chunk_ov, chunk_in, probe);
     } else {
         hipLaunchKernelGGL(survivor_masks_kernel<false>, grid, dim3(kBlock), 0, s, o, n_reads, valid, fate, death, (const uint2*)crec, rec, pool,
-                           mask_ov, mask_in, chunk_ov, chunk_in);
+                           mask_ov, mask_in, chunk_ov, chunk_in, 0u);
     }
 }
 void launch_death_status(const uint32_t* count, uint32_t* status, hipStream_t s) {

@@ -1639,6 +1639,12 @@ int rala_hip_create(int device, rala_hip_ctx** out) {
     if (hipSetDevice(device) != hipSuccess) return RALA_HIP_EDEVICE;
     rala_hip_ctx* ctx = new rala_hip_ctx;
     ctx->device = device;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) {
+            ctx->n_compute_units = (uint32_t)prop.multiProcessorCount;
+        }
+    }
     bool ok = hipStreamCreate(&ctx->stream) == hipSuccess && hipStreamCreate(&ctx->side) == hipSuccess &&
               hipStreamCreate(&ctx->aux) == hipSuccess;
     for (auto& e : ctx->ev) ok = ok && hipEventCreate(&e) == hipSuccess;

@@ -212,86 +212,6 @@ __global__ __launch_bounds__(kBlock) void kill_reads_kernel(const uint32_t* __re
     if (r < n && death[r] != kInf) alive[r] = 0;
 }
 
-// 1 for the items that form the final overlap list, in one of its segments (originals, or
-// the promoted ones of one round)
-__global__ __launch_bounds__(kBlock) void keep_flags_kernel(TailList L, const uint8_t* __restrict__ alive,
-                                                            uint32_t want_state, uint32_t want_round,
-                                                            uint32_t* __restrict__ flag) {
-    const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
-    if (k >= L.n) return;
-    const uint8_t st = L.state[k];
-    bool keep = st == want_state && (st != 3 || L.round[k] == want_round);
-    keep = keep && alive[L.a[k]] && alive[L.b[k]];
-    flag[k] = keep ? 1u : 0u;
-}
-
-__global__ __launch_bounds__(kBlock) void u8_to_u32_kernel(const uint8_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t n) {
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i < n) out[i] = in[i] ? 1u : 0u;
-}
-
-// rank[r] / alive_reads[rank] from the exclusive scan of the alive flags
-__global__ __launch_bounds__(kBlock) void ranks_kernel(const uint8_t* __restrict__ alive, const uint32_t* __restrict__ pos,
-                                                       uint32_t* __restrict__ rank, uint32_t* __restrict__ alive_reads,
-                                                       uint32_t n) {
-    const uint32_t r = blockIdx.x * kBlock + threadIdx.x;
-    if (r >= n) return;
-    if (alive[r]) {
-        rank[r] = pos[r];
-        if (alive_reads) alive_reads[pos[r]] = r;
-    } else {
-        rank[r] = kInf;
-    }
-}
-
-// final overlap j (kept item k at position base + pos[k]): remember k, and whether it is a
-// dovetail (graph.cpp:594,612)
-__global__ __launch_bounds__(kBlock) void place_kept_kernel(TailList L, TailReads R, const uint32_t* __restrict__ flag,
-                                                            const uint32_t* __restrict__ pos, const uint32_t* base_in,
-                                                            uint32_t* base_out, uint32_t* __restrict__ kept_item,
-                                                            uint32_t* __restrict__ dovetail) {
-    // the segment's place in the final list comes from (and the next one's goes to) device memory: the
-    // segments follow each other without a look from the host
-    const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
-    const uint32_t base = base_in ? *base_in : 0u;
-    if (k == 0) *base_out = base + pos[L.n];
-    if (k >= L.n || !flag[k]) return;
-    const uint32_t j = base + pos[k];
-    kept_item[j] = k;
-    const uint32_t a = L.a[k], b = L.b[k];
-    const Coords c = item_coords(L, k);
-    const uint32_t t = ovl_type(c, L.strand[k], R.begin[a], R.end[a], R.begin[b], R.end[b]);
-    L.type[k] = (uint8_t)t;
-    dovetail[j] = (t == kTypeAB || t == kTypeBA) ? 1u : 0u;
-}
-
-// two edges per dovetail overlap (graph.cpp:594-629); node = 2 * rank of the read
-__global__ __launch_bounds__(kBlock) void build_edges_kernel(TailList L, TailReads R, const uint32_t* __restrict__ kept_item,
-                                                             const uint32_t* __restrict__ dovetail,
-                                                             const uint32_t* __restrict__ epos, uint32_t n_kept,
-                                                             const uint32_t* __restrict__ node_rank,
-                                                             uint32_t* __restrict__ e_src, uint32_t* __restrict__ e_dst,
-                                                             uint32_t* __restrict__ e_len) {
-    const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
-    if (j >= n_kept || !dovetail[j]) return;
-    const uint32_t k = kept_item[j];
-    const uint32_t a = L.a[k], b = L.b[k];
-    const Coords c = item_coords(L, k);
-    EdgePair e;
-    ovl_edges(c, L.strand[k], L.type[k], 2u * node_rank[a], 2u * node_rank[b], R.begin[a], R.end[a], R.begin[b], R.end[b], e);
-    const uint32_t w = 2u * epos[j];
-    e_src[w] = e.src0; e_dst[w] = e.dst0; e_len[w] = e.len0;
-    e_src[w + 1] = e.src1; e_dst[w + 1] = e.dst1; e_len[w + 1] = e.len1;
-}
-
-__global__ __launch_bounds__(kBlock) void node_reads_kernel(const uint8_t* __restrict__ alive, const uint32_t* __restrict__ rank,
-                                                            uint32_t* __restrict__ node_read, uint32_t n) {
-    const uint32_t r = blockIdx.x * kBlock + threadIdx.x;
-    if (r >= n || !alive[r]) return;
-    node_read[2 * rank[r]] = r;
-    node_read[2 * rank[r] + 1] = r;
-}
-
 // start of the tail: list states, nothing dirty, the pit counts the pile kernel wrote (one launch for
 // what used to be a kernel, a fill and a copy)
 __global__ __launch_bounds__(kBlock) void tail_init_kernel(uint8_t* state, uint8_t* round, uint32_t n0, uint32_t m,
@@ -398,12 +318,6 @@ struct OffsetsPass {
     __device__ void total(uint64_t sum) const { out[n] = (uint32_t)sum; }
 };
 
-__global__ __launch_bounds__(kBlock) void init_list_state_kernel(uint8_t* state, uint8_t* round, uint32_t n0, uint32_t n) {
-    const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
-    if (k >= n) return;
-    state[k] = k < n0 ? 1 : 2;
-    round[k] = 0;
-}
 
 }  // namespace
 
@@ -439,35 +353,6 @@ void launch_tail_apply_scan(const TailList& L, const uint8_t* alive, uint32_t wh
 }
 void launch_kill_reads(const uint32_t* death, uint8_t* alive, uint32_t n, hipStream_t s) {
     if (n) hipLaunchKernelGGL(kill_reads_kernel, grid_for(n), dim3(kBlock), 0, s, death, alive, n);
-}
-void launch_keep_flags(const TailList& L, const uint8_t* alive, uint32_t want_state, uint32_t want_round, uint32_t* flag,
-                       hipStream_t s) {
-    if (L.n) hipLaunchKernelGGL(keep_flags_kernel, grid_for(L.n), dim3(kBlock), 0, s, L, alive, want_state, want_round, flag);
-}
-void launch_u8_to_u32(const uint8_t* in, uint32_t* out, uint32_t n, hipStream_t s) {
-    if (n) hipLaunchKernelGGL(u8_to_u32_kernel, grid_for(n), dim3(kBlock), 0, s, in, out, n);
-}
-void launch_ranks(const uint8_t* alive, const uint32_t* pos, uint32_t* rank, uint32_t* alive_reads, uint32_t n, hipStream_t s) {
-    if (n) hipLaunchKernelGGL(ranks_kernel, grid_for(n), dim3(kBlock), 0, s, alive, pos, rank, alive_reads, n);
-}
-void launch_place_kept(const TailList& L, const TailReads& R, const uint32_t* flag, const uint32_t* pos, const uint32_t* base_in,
-                       uint32_t* base_out, uint32_t* kept_item, uint32_t* dovetail, hipStream_t s) {
-    if (L.n) hipLaunchKernelGGL(place_kept_kernel, grid_for(L.n), dim3(kBlock), 0, s, L, R, flag, pos, base_in, base_out, kept_item,
-                                dovetail);
-}
-void launch_build_edges(const TailList& L, const TailReads& R, const uint32_t* kept_item, const uint32_t* dovetail,
-                        const uint32_t* epos, uint32_t n_kept, const uint32_t* node_rank, uint32_t* e_src, uint32_t* e_dst,
-                        uint32_t* e_len, hipStream_t s) {
-    if (n_kept) {
-        hipLaunchKernelGGL(build_edges_kernel, grid_for(n_kept), dim3(kBlock), 0, s, L, R, kept_item, dovetail, epos, n_kept,
-                           node_rank, e_src, e_dst, e_len);
-    }
-}
-void launch_node_reads(const uint8_t* alive, const uint32_t* rank, uint32_t* node_read, uint32_t n, hipStream_t s) {
-    if (n) hipLaunchKernelGGL(node_reads_kernel, grid_for(n), dim3(kBlock), 0, s, alive, rank, node_read, n);
-}
-void launch_init_list_state(uint8_t* state, uint8_t* round, uint32_t n0, uint32_t n, hipStream_t s) {
-    if (n) hipLaunchKernelGGL(init_list_state_kernel, grid_for(n), dim3(kBlock), 0, s, state, round, n0, n);
 }
 void launch_tail_init(const TailList& L, uint32_t n0, const TailReads& R, uint8_t* n_pits0, uint32_t n_reads, hipStream_t s) {
     const uint32_t n = L.n > n_reads ? L.n : n_reads;
