@@ -1,0 +1,373 @@
+// Bound events by read WITHOUT a memory-side atomic per overlap: the target side is partitioned.
+//
+// Graph::initialize pushes four bounds per overlap to the lists of its two reads (reference
+// src/graph.cpp:311-326).  The query side is cheap: overlap files are grouped by query, so the lanes of a
+// wavefront mostly share the query and one counting atomic serves a whole segment of them.  The target
+// side is a scatter by read id, and the single-pass kernel (bucket_fixed_kernel, overlap_kernels.hip) pays
+// one memory-side atomic and one 32-byte partial write per overlap for it: 21 G/s of each at C3, 0.10 of
+// the HBM peak for the 40 bytes it moves (profiles/r03_c3_pmc_bucket_fixed.json).  Here the target side
+// goes through two partitioning passes whose writes are whole lines, and the events land in an exact CSR
+// (ev_off / ev) that every pile kernel already reads:
+//
+//   l1_count      tiles of the overlap file: LDS histogram of target >> 12, one global add per (tile,
+//                 partition); query-side event counts per read (one add per wavefront segment)
+//   l1_prefix     partition bases; the table of partition-aligned tiles for level 2 (one workgroup)
+//   l1_scatter    the tile's target records {target & 4095, begin, end} (8 bytes) sorted by partition in
+//                 LDS, copied out partition by partition: consecutive lanes write consecutive records
+//   l2_count / l2_prefix / l2_scatter   the same inside every partition of 4096 reads: groups of 256 reads
+//   final_count   one workgroup per group: target-side events per read (LDS histogram) -> event counts
+//   (scan)        event counts -> ev_off
+//   final_write   one workgroup per group: the group's records at places handed out by LDS counters -
+//                 8-byte stores inside a window of 200 KB that the L2 merges into whole lines
+//   query_side    one thread per overlap, as in the single-pass kernel: segment base from one atomic
+//
+// The order of a read's events is irrelevant (Pile::add_layers sorts them; the run-space kernel does not
+// even need that), so the result equals the other bucketing paths' as a multiset per read.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "device_utils.h"
+#include "geom.h"
+#include "kernels.h"
+#include "scan_pass.h"
+
+namespace rala_hip {
+
+namespace {
+
+constexpr uint32_t kInf = 0xFFFFFFFFu;
+constexpr uint32_t kTile = 4096;                // records per workgroup
+constexpr uint32_t kBlockP = 512;
+constexpr uint32_t kPer = kTile / kBlockP;
+constexpr uint32_t kL1Shift = 12;               // 4096 reads per level-1 partition
+constexpr uint32_t kL1Reads = 1u << kL1Shift;
+constexpr uint32_t kGroupShift = 7;             // 128 reads per final group
+constexpr uint32_t kGroupReads = 1u << kGroupShift;
+constexpr uint32_t kGroupsPerPart = kL1Reads / kGroupReads;
+constexpr uint32_t kCoordBits = 26;
+constexpr uint32_t kCoordMax = (1u << kCoordBits) - 1u;
+
+__device__ __forceinline__ uint64_t pack_record(uint32_t b, uint32_t begin, uint32_t end) {
+    // coordinates beyond 2^26 lie outside every read this path takes (pipeline.hip) and stay outside
+    return (uint64_t)(b & (kL1Reads - 1u)) << 52 | (uint64_t)(begin < kCoordMax ? begin : kCoordMax) << kCoordBits |
+           (uint64_t)(end < kCoordMax ? end : kCoordMax);
+}
+__device__ __forceinline__ uint32_t rec_key(uint64_t r) { return (uint32_t)(r >> 52); }
+__device__ __forceinline__ uint2 rec_events(uint64_t r) {
+    const uint32_t begin = (uint32_t)(r >> kCoordBits) & kCoordMax, end = (uint32_t)r & kCoordMax;
+    return make_uint2((begin + 15u) << 1, ((end - 15u) << 1) | 1u);         // graph.cpp:317-324
+}
+
+// lanes are consecutive overlaps; a segment = maximal run of active lanes with equal key.  Returns the
+// segment's length in its first lane (0 elsewhere), `leader` = first lane of this lane's segment.
+__device__ __forceinline__ uint32_t segment_of(uint32_t key, bool active, uint32_t lane, uint32_t& leader) {
+    const uint32_t prev = (uint32_t)__shfl_up((int)key, 1, 64);
+    const bool prev_active = __shfl_up((int)active, 1, 64) != 0;
+    const bool head = active && (lane == 0 || !prev_active || prev != key);
+    const uint64_t heads = __ballot(head);
+    const uint64_t act = __ballot(active);
+    const uint64_t below = heads & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
+    leader = below ? 63u - (uint32_t)__clzll((long long)below) : lane;
+    const uint64_t after = (lane == 63) ? 0ull : ((heads | ~act) >> (lane + 1));
+    const uint32_t len = after ? (uint32_t)__ffsll((unsigned long long)after) : (64u - lane);
+    return head ? len : 0u;
+}
+
+// ---- level 1: target >> 12 ------------------------------------------------------------------------
+// + acount[a] = resolvable overlaps of query a (its query-side events / 2)
+__global__ __launch_bounds__(kBlockP) void l1_count_kernel(OvlSoA o, uint32_t n_reads, uint32_t n_part, uint32_t* part_count,
+                                                           uint32_t* acount) {
+    extern __shared__ uint32_t s_hist[];
+    for (uint32_t p = threadIdx.x; p < n_part; p += kBlockP) s_hist[p] = 0;
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t last = o.n - 1;
+#pragma unroll
+    for (uint32_t u = 0; u < kPer; ++u) {
+        const uint64_t i = (uint64_t)blockIdx.x * kTile + u * kBlockP + threadIdx.x;
+        const uint64_t j = i < o.n ? i : last;
+        const uint32_t a = o.a_id[j], b = o.b_id[j];
+        const bool ok = i < o.n && a < n_reads && b < n_reads;
+        if (ok) atomicAdd(&s_hist[b >> kL1Shift], 1u);
+        uint32_t leader;
+        const uint32_t seg = segment_of(a, ok, lane, leader);
+        if (seg) atomicAdd(&acount[a], seg);
+    }
+    __syncthreads();
+    for (uint32_t p = threadIdx.x; p < n_part; p += kBlockP) {
+        const uint32_t c = s_hist[p];
+        if (c) atomicAdd(&part_count[p], c);
+    }
+}
+
+// base[0 .. n] = exclusive prefix of count[0 .. n), cursor = base.  With tiles != null also the table of
+// tiles that do not cross a range: tile t covers records tile_lo[t] .. of range tile_range[t]; *n_tiles.
+__global__ __launch_bounds__(1024) void prefix_kernel(const uint32_t* __restrict__ count, uint32_t n, uint32_t* __restrict__ base,
+                                                      uint32_t* __restrict__ cursor, uint32_t* __restrict__ tile_range,
+                                                      uint32_t* __restrict__ tile_lo, uint32_t* n_tiles) {
+    __shared__ uint32_t tmp[1024 / 64 + 1];
+    uint32_t carry = 0, tile_carry = 0;
+    for (uint32_t p0 = 0; p0 < n; p0 += 1024) {
+        const uint32_t p = p0 + threadIdx.x;
+        const uint32_t v = p < n ? count[p] : 0u;
+        uint32_t tot;
+        const uint32_t ex = block_scan_excl<1024>(v, OpAdd(), 0u, tmp, tot);
+        if (p < n) { base[p] = carry + ex; cursor[p] = carry + ex; }
+        if (tile_range) {
+            const uint32_t tiles = (v + kTile - 1) / kTile;
+            uint32_t ttot;
+            const uint32_t tex = block_scan_excl<1024>(tiles, OpAdd(), 0u, tmp, ttot);
+            for (uint32_t k = 0; k < tiles; ++k) {
+                tile_range[tile_carry + tex + k] = p;
+                tile_lo[tile_carry + tex + k] = carry + ex + k * kTile;
+            }
+            tile_carry += ttot;
+        }
+        carry += tot;
+    }
+    if (threadIdx.x == 0) {
+        base[n] = carry;
+        if (n_tiles) *n_tiles = tile_carry;
+    }
+}
+
+// dynamic LDS: stage[kTile] (8 B), bin_of[kTile] (2 B), hist / off / gbase [n_bins] (4 B each)
+struct StageLds {
+    uint64_t* stage;
+    uint16_t* bin_of;
+    uint32_t *hist, *off, *gbase;
+    __device__ StageLds(unsigned char* base, uint32_t n_bins) {
+        stage = (uint64_t*)base;
+        bin_of = (uint16_t*)(stage + kTile);
+        hist = (uint32_t*)(bin_of + kTile);
+        off = hist + n_bins;
+        gbase = off + n_bins;
+    }
+};
+inline size_t stage_lds_bytes(uint32_t n_bins) { return (size_t)kTile * 10 + (size_t)n_bins * 12 + 16; }
+
+// The records of one tile, each with its bin and whether it counts: ranks inside the bins (LDS adds), the
+// bins' places in the staging area (scan) and in the output (one global add per bin with records), the
+// records sorted by bin in LDS, then copied out - consecutive lanes, consecutive addresses.
+__device__ __forceinline__ void stage_and_copy(StageLds& L, uint32_t n_bins, const uint64_t* rec, const uint32_t* bin, const bool* in,
+                                               uint32_t* cursor, uint64_t* __restrict__ out, uint32_t* tmp) {
+    for (uint32_t p = threadIdx.x; p < n_bins; p += kBlockP) L.hist[p] = 0;
+    __syncthreads();
+    uint32_t rank[kPer];
+#pragma unroll
+    for (uint32_t u = 0; u < kPer; ++u) rank[u] = in[u] ? atomicAdd(&L.hist[bin[u]], 1u) : 0u;
+    __syncthreads();
+    uint32_t carry = 0;
+    for (uint32_t p0 = 0; p0 < n_bins; p0 += kBlockP) {
+        const uint32_t p = p0 + threadIdx.x;
+        const uint32_t c = p < n_bins ? L.hist[p] : 0u;
+        uint32_t tot;
+        const uint32_t ex = block_scan_excl<(int)kBlockP>(c, OpAdd(), 0u, tmp, tot);
+        if (p < n_bins) {
+            L.off[p] = carry + ex;
+            L.gbase[p] = c ? atomicAdd(&cursor[p], c) : 0u;
+        }
+        carry += tot;
+    }
+    __syncthreads();
+    const uint32_t total = carry;
+#pragma unroll
+    for (uint32_t u = 0; u < kPer; ++u) {
+        if (in[u]) {
+            const uint32_t at = L.off[bin[u]] + rank[u];
+            L.stage[at] = rec[u];
+            L.bin_of[at] = (uint16_t)bin[u];
+        }
+    }
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < total; j += kBlockP) {
+        const uint32_t p = L.bin_of[j];
+        out[L.gbase[p] + (j - L.off[p])] = L.stage[j];
+    }
+}
+
+__global__ __launch_bounds__(kBlockP) void l1_scatter_kernel(OvlSoA o, uint32_t n_reads, uint32_t n_part, uint32_t* part_cursor,
+                                                             uint64_t* __restrict__ rec1) {
+    extern __shared__ __align__(16) unsigned char s_raw[];
+    __shared__ uint32_t tmp[kBlockP / 64 + 1];
+    StageLds L(s_raw, n_part);
+    uint64_t rec[kPer];
+    uint32_t bin[kPer];
+    bool in[kPer];
+    const uint64_t last = o.n - 1;
+#pragma unroll
+    for (uint32_t u = 0; u < kPer; ++u) {
+        const uint64_t i = (uint64_t)blockIdx.x * kTile + u * kBlockP + threadIdx.x;
+        const uint64_t j = i < o.n ? i : last;
+        const uint32_t a = o.a_id[j], b = o.b_id[j];
+        in[u] = i < o.n && a < n_reads && b < n_reads;
+        rec[u] = pack_record(b, o.b_begin[j], o.b_end[j]);
+        bin[u] = in[u] ? b >> kL1Shift : 0u;
+    }
+    stage_and_copy(L, n_part, rec, bin, in, part_cursor, rec1, tmp);
+}
+
+// ---- level 2: inside every partition, groups of 256 reads; tiles that do not cross a partition -------
+__global__ __launch_bounds__(kBlockP) void l2_count_kernel(const uint64_t* __restrict__ rec1, const uint32_t* __restrict__ part_base,
+                                                           const uint32_t* __restrict__ tile_part, const uint32_t* __restrict__ tile_lo,
+                                                           const uint32_t* __restrict__ n_tiles, uint32_t* group_count) {
+    __shared__ uint32_t s_hist[kGroupsPerPart];
+    if (blockIdx.x >= *n_tiles) return;
+    const uint32_t part = tile_part[blockIdx.x], lo = tile_lo[blockIdx.x];
+    const uint32_t hi = umin(lo + kTile, part_base[part + 1]);
+    if (threadIdx.x < kGroupsPerPart) s_hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t j = lo + threadIdx.x; j < hi; j += kBlockP) atomicAdd(&s_hist[rec_key(rec1[j]) >> kGroupShift], 1u);
+    __syncthreads();
+    if (threadIdx.x < kGroupsPerPart && s_hist[threadIdx.x]) atomicAdd(&group_count[part * kGroupsPerPart + threadIdx.x], s_hist[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(kBlockP) void l2_scatter_kernel(const uint64_t* __restrict__ rec1, const uint32_t* __restrict__ part_base,
+                                                             const uint32_t* __restrict__ tile_part, const uint32_t* __restrict__ tile_lo,
+                                                             const uint32_t* __restrict__ n_tiles, uint32_t* group_cursor,
+                                                             uint64_t* __restrict__ rec2) {
+    extern __shared__ __align__(16) unsigned char s_raw[];
+    __shared__ uint32_t tmp[kBlockP / 64 + 1];
+    if (blockIdx.x >= *n_tiles) return;
+    StageLds L(s_raw, kGroupsPerPart);
+    const uint32_t part = tile_part[blockIdx.x], lo = tile_lo[blockIdx.x];
+    const uint32_t hi = umin(lo + kTile, part_base[part + 1]);
+    uint64_t rec[kPer];
+    uint32_t bin[kPer];
+    bool in[kPer];
+#pragma unroll
+    for (uint32_t u = 0; u < kPer; ++u) {
+        const uint32_t j = lo + u * kBlockP + threadIdx.x;
+        in[u] = j < hi;
+        rec[u] = in[u] ? rec1[j] : 0ull;
+        bin[u] = rec_key(rec[u]) >> kGroupShift;
+    }
+    stage_and_copy(L, kGroupsPerPart, rec, bin, in, group_cursor + part * kGroupsPerPart, rec2, tmp);
+}
+
+// ---- final: one workgroup per 256 reads -------------------------------------------------------------------
+constexpr uint32_t kBlockF = 256;
+__global__ __launch_bounds__(kBlockF) void final_count_kernel(const uint64_t* __restrict__ rec2, const uint32_t* __restrict__ group_base,
+                                                              uint32_t n_reads, const uint32_t* __restrict__ acount,
+                                                              uint32_t* __restrict__ ecount) {
+    __shared__ uint32_t s_cnt[kGroupReads];
+    const uint32_t g = blockIdx.x;
+    if (threadIdx.x < kGroupReads) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t lo = group_base[g], hi = group_base[g + 1];
+    for (uint32_t j = lo + threadIdx.x; j < hi; j += kBlockF) atomicAdd(&s_cnt[rec_key(rec2[j]) & (kGroupReads - 1u)], 1u);
+    __syncthreads();
+    const uint32_t r = g * kGroupReads + threadIdx.x;
+    if (threadIdx.x < kGroupReads && r < n_reads) ecount[r] = 2u * (acount[r] + s_cnt[threadIdx.x]);
+}
+
+// target side: the group's records, tile by tile, sorted by read in LDS (as bound pairs) and copied out to the
+// reads' rows behind their query-side events: consecutive lanes write consecutive pairs of one read.
+// (Each record stored straight from the lane that read it - an 8-byte store to one of 12 000 places in a
+// window of 200 KB - took 0.75 ms at C3: one request per lane, whatever the L2 merges afterwards.)
+__global__ __launch_bounds__(kBlockP) void final_write_kernel(const uint64_t* __restrict__ rec2, const uint32_t* __restrict__ group_base,
+                                                              uint32_t n_reads, const uint32_t* __restrict__ acount,
+                                                              const uint32_t* __restrict__ ev_off, uint32_t* __restrict__ ev) {
+    extern __shared__ __align__(16) unsigned char s_raw[];
+    __shared__ uint32_t tmp[kBlockP / 64 + 1];
+    __shared__ uint32_t s_cursor[kGroupReads];          // next free PAIR of every read's row
+    StageLds L(s_raw, kGroupReads);
+    const uint32_t g = blockIdx.x;
+    if (threadIdx.x < kGroupReads) {
+        const uint32_t r = g * kGroupReads + threadIdx.x;
+        s_cursor[threadIdx.x] = r < n_reads ? ev_off[r] / 2u + acount[r] : 0u;      // (rows start at even offsets)
+    }
+    __syncthreads();
+    const uint32_t lo = group_base[g], hi = group_base[g + 1];
+    for (uint32_t j0 = lo; j0 < hi; j0 += kTile) {
+        uint64_t pair[kPer];
+        uint32_t bin[kPer];
+        bool in[kPer];
+#pragma unroll
+        for (uint32_t u = 0; u < kPer; ++u) {
+            const uint32_t j = j0 + u * kBlockP + threadIdx.x;
+            in[u] = j < hi;
+            const uint64_t rec = in[u] ? rec2[j] : 0ull;
+            const uint2 e = rec_events(rec);
+            pair[u] = (uint64_t)e.x | (uint64_t)e.y << 32;
+            bin[u] = rec_key(rec) & (kGroupReads - 1u);
+        }
+        stage_and_copy(L, kGroupReads, pair, bin, in, s_cursor, (uint64_t*)ev, tmp);
+        __syncthreads();
+    }
+}
+
+// query side: one thread per overlap; the lanes of a wavefront that share the query take their places from
+// ONE atomic (the file is grouped by query).  written[] counts what a read has handed out so far.
+__global__ __launch_bounds__(256) void query_side_kernel(OvlSoA o, uint32_t n_reads, const uint32_t* __restrict__ ev_off,
+                                                         uint32_t* written, uint32_t* __restrict__ ev) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t a = kInf, b = kInf;
+    if (i < o.n) { a = o.a_id[i]; b = o.b_id[i]; }
+    const bool ok = a < n_reads && b < n_reads;
+    uint32_t leader;
+    const uint32_t seg = segment_of(a, ok, lane, leader);
+    uint32_t base = 0;
+    if (seg) base = ev_off[a] + atomicAdd(&written[a], 2u * seg);
+    base = (uint32_t)__shfl((int)base, (int)leader, 64);
+    if (!ok) return;
+    *(uint2*)(ev + base + 2u * (lane - leader)) = make_uint2((o.a_begin[i] + 15u) << 1, ((o.a_end[i] - 15u) << 1) | 1u);
+}
+
+}  // namespace
+
+size_t partition_records_needed(uint64_t n_overlaps) { return (size_t)n_overlaps + 8; }
+uint32_t partition_count(uint32_t n_reads) { return (n_reads + kL1Reads - 1) / kL1Reads; }
+uint32_t partition_group_slots(uint32_t n_reads) { return partition_count(n_reads) * kGroupsPerPart + 2; }
+size_t partition_tile_slots(uint32_t n_reads, uint64_t n_overlaps) { return (size_t)(n_overlaps / kTile) + partition_count(n_reads) + 4; }
+bool partition_path_fits(uint32_t n_reads, uint32_t max_read_len, uint64_t n_overlaps) {
+    // coordinates in 26 bits; level-1 histograms in LDS next to the staging area; positions in 32 bits
+    return max_read_len < kCoordMax - 32u && stage_lds_bytes(partition_count(n_reads)) <= 60u * 1024u &&
+           4ull * n_overlaps < 0xFFFFFFF0ull && n_reads > 0 && n_overlaps > 0;
+}
+
+// Buffers (device): acount, ecount, written: n_reads + 2 words each; part: 3 * (n_part + 2) words (counts,
+// bases, cursors); group: 3 * partition_group_slots(n_reads) (counts, bases, cursors); tiles: 2 *
+// partition_tile_slots words + 1 (partition, first record of every level-2 tile; their number); rec1, rec2:
+// partition_records_needed records; ev_off: n_reads + 2; ev: 4 * n_overlaps + 8.  scan: tile states for one
+// scan over n_reads.
+hipError_t launch_bucket_partitioned(const OvlSoA& o, uint32_t n_reads, uint32_t* acount, uint32_t* ecount, uint32_t* written,
+                                     uint32_t* part, uint32_t* group, uint32_t* tiles, uint64_t* rec1, uint64_t* rec2,
+                                     uint32_t* ev_off, uint32_t* ev, ScanSpace& scan, hipStream_t s) {
+    const uint32_t n_part = partition_count(n_reads);
+    const uint32_t n_groups = (n_reads + kGroupReads - 1) / kGroupReads;
+    const uint32_t group_slots = partition_group_slots(n_reads);
+    const size_t tile_slots = partition_tile_slots(n_reads, o.n);
+    uint32_t *part_count = part, *part_base = part + (n_part + 2), *part_cursor = part + 2 * (n_part + 2);
+    uint32_t *group_count = group, *group_base = group + group_slots, *group_cursor = group + 2 * (size_t)group_slots;
+    uint32_t *tile_part = tiles, *tile_lo = tiles + tile_slots, *n_tiles = tiles + 2 * tile_slots;
+    hipError_t e = hipMemsetAsync(acount, 0, (size_t)n_reads * 4, s);
+    if (e == hipSuccess) e = hipMemsetAsync(written, 0, (size_t)n_reads * 4, s);
+    if (e == hipSuccess) e = hipMemsetAsync(part_count, 0, (size_t)(n_part + 2) * 4, s);
+    if (e == hipSuccess) e = hipMemsetAsync(group_count, 0, (size_t)group_slots * 4, s);
+    if (e != hipSuccess) return e;
+    const uint32_t tiles1 = (uint32_t)((o.n + kTile - 1) / kTile);
+    hipLaunchKernelGGL(l1_count_kernel, dim3(tiles1), dim3(kBlockP), (size_t)n_part * 4, s, o, n_reads, n_part, part_count, acount);
+    hipLaunchKernelGGL(prefix_kernel, dim3(1), dim3(1024), 0, s, (const uint32_t*)part_count, n_part, part_base, part_cursor, tile_part,
+                       tile_lo, n_tiles);
+    hipLaunchKernelGGL(l1_scatter_kernel, dim3(tiles1), dim3(kBlockP), stage_lds_bytes(n_part), s, o, n_reads, n_part, part_cursor, rec1);
+    const uint32_t tiles2 = (uint32_t)(o.n / kTile) + n_part + 1;       // at least as many as the table holds
+    hipLaunchKernelGGL(l2_count_kernel, dim3(tiles2), dim3(kBlockP), 0, s, (const uint64_t*)rec1, (const uint32_t*)part_base,
+                       (const uint32_t*)tile_part, (const uint32_t*)tile_lo, (const uint32_t*)n_tiles, group_count);
+    hipLaunchKernelGGL(prefix_kernel, dim3(1), dim3(1024), 0, s, (const uint32_t*)group_count, n_part * kGroupsPerPart, group_base,
+                       group_cursor, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr);
+    hipLaunchKernelGGL(l2_scatter_kernel, dim3(tiles2), dim3(kBlockP), stage_lds_bytes(kGroupsPerPart), s, (const uint64_t*)rec1,
+                       (const uint32_t*)part_base, (const uint32_t*)tile_part, (const uint32_t*)tile_lo, (const uint32_t*)n_tiles,
+                       group_cursor, rec2);
+    hipLaunchKernelGGL(final_count_kernel, dim3(n_groups), dim3(kBlockF), 0, s, (const uint64_t*)rec2, (const uint32_t*)group_base, n_reads,
+                       (const uint32_t*)acount, ecount);
+    if (!launch_offsets_pass(ecount, ev_off, nullptr, n_reads, scan, s)) return hipErrorOutOfMemory;
+    hipLaunchKernelGGL(final_write_kernel, dim3(n_groups), dim3(kBlockP), stage_lds_bytes(kGroupReads), s, (const uint64_t*)rec2,
+                       (const uint32_t*)group_base, n_reads, (const uint32_t*)acount, (const uint32_t*)ev_off, ev);
+    hipLaunchKernelGGL(query_side_kernel, dim3((uint32_t)((o.n + 255) / 256)), dim3(256), 0, s, o, n_reads, (const uint32_t*)ev_off, written, ev);
+    return hipGetLastError();
+}
+
+}  // namespace rala_hip

@@ -180,6 +180,9 @@ struct rala_hip_ctx {
     std::vector<StagedCopy> stage_pending;
     size_t stage_used = 0;
     int64_t use_fixed_buckets = 1;        // single-pass bucketing into fixed slots when they fit
+    bool use_partitioned_buckets = true;  // target side through partitioning passes (bucket_kernels.hip) where the input suits
+    rala_hip::DevBuf<uint32_t> d_bk_u32[3], d_bk_part, d_bk_group, d_bk_tiles;     // per-read counts; partition / group bases; level-2 tiles
+    rala_hip::DevBuf<uint64_t> d_bk_rec[2];                            // target records after level 1 / level 2
     bool host_state_fresh = false;      // host mirrors of the per-read state match the device
     uint32_t pool_used = 0;             // interval pool records in use
 

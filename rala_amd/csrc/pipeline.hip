@@ -1684,6 +1684,7 @@ int rala_hip_set_option(rala_hip_ctx* ctx, const char* key, int64_t value) {
     if (!strcmp(key, "debug_fail_construct")) { ctx->debug_fail_construct = value != 0; return RALA_HIP_OK; }
     if (!strcmp(key, "use_gpu_tail")) { ctx->use_gpu_tail = value != 0; return RALA_HIP_OK; }
     if (!strcmp(key, "use_fixed_buckets")) { ctx->use_fixed_buckets = value != 0; return RALA_HIP_OK; }
+    if (!strcmp(key, "use_partitioned_buckets")) { ctx->use_partitioned_buckets = value != 0; return RALA_HIP_OK; }
     if (!strcmp(key, "use_side_stream")) { ctx->use_side_stream = value != 0; return RALA_HIP_OK; }
     if (!strcmp(key, "sensitive_in_device_memory")) { ctx->sens_in_device = value != 0; return RALA_HIP_OK; }
     if (!strcmp(key, "host_threads")) {
@@ -1839,7 +1840,27 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
     // with more events than a slot (only the position-space kernel could take it) sends the whole
     // data set through the exact CSR path below.
     const uint32_t slot = kRunEventCapBig;
-    bool fixed = ctx->use_run_kernel && ctx->use_fixed_buckets && (uint64_t)n_reads * slot * 4ull <= (64ull << 30);
+    // Partitioned path (bucket_kernels.hip): the target side through two partitioning passes instead of one
+    // memory-side atomic and one partial write per overlap; ends in the exact CSR.  Needs the overlaps
+    // (not tuples), coordinates below 2^26 and enough overlaps per partition for the passes to pay.
+    const bool partitioned = !ctx->tuple_mode && ctx->use_run_kernel && ctx->use_fixed_buckets && ctx->use_partitioned_buckets &&
+                             partition_path_fits(n_reads, ctx->max_read_len, ctx->n_ovl);
+    bool fixed = !partitioned && ctx->use_run_kernel && ctx->use_fixed_buckets && (uint64_t)n_reads * slot * 4ull <= (64ull << 30);
+    if (partitioned) {
+        for (int k = 0; k < 3; ++k) HIPCHECK(ctx->d_bk_u32[k].ensure(n_reads + 2));
+        HIPCHECK(ctx->d_bk_part.ensure(3 * (size_t)(partition_count(n_reads) + 2)));
+        HIPCHECK(ctx->d_bk_group.ensure(3 * (size_t)partition_group_slots(n_reads)));
+        HIPCHECK(ctx->d_bk_tiles.ensure(2 * partition_tile_slots(n_reads, ctx->n_ovl) + 2));
+        for (int k = 0; k < 2; ++k) HIPCHECK(ctx->d_bk_rec[k].ensure(partition_records_needed(ctx->n_ovl)));
+        ScanSpace sp;
+        {
+            const int rc = scan_space(ctx, 1, n_reads, sp);
+            if (rc != RALA_HIP_OK) return rc;
+        }
+        HIPCHECK(launch_bucket_partitioned(ctx->ovl, n_reads, ctx->d_bk_u32[0].p, ctx->d_bk_u32[1].p, ctx->d_bk_u32[2].p,
+                                           ctx->d_bk_part.p, ctx->d_bk_group.p, ctx->d_bk_tiles.p, ctx->d_bk_rec[0].p,
+                                           ctx->d_bk_rec[1].p, ctx->d_ev_off.p, ctx->d_ev.p, sp, s));
+    }
     if (fixed) {
         HIPCHECK(ctx->d_ev_fixed.ensure((size_t)n_reads * slot + 8));
         HIPCHECK(ctx->d_cc_flags.ensure(8));
@@ -1855,7 +1876,7 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
         // the overflow flag is read together with the other results at the end of this call; a
         // set flag repeats the call on the exact path (no host round trip in the common case)
     }
-    if (!fixed) {
+    if (!fixed && !partitioned) {
     // count -> exclusive scan -> scatter
     HIPCHECK(hipMemsetAsync(ctx->d_cursor.p, 0, (size_t)(n_reads + 1) * 4, s));
     if (ctx->tuple_mode) {

@@ -43,6 +43,7 @@ for case in range(n_cases):
         ctx = hip.Context(0)
         ctx.set_option("use_run_kernel", int(rng.random() < 0.85))
         ctx.set_option("use_fixed_buckets", int(rng.random() < 0.8))
+        ctx.set_option("use_partitioned_buckets", int(rng.random() < 0.7))
         ctx.set_option("use_round_batches", int(rng.random() < 0.7))
         ctx.set_option("use_side_stream", int(rng.random() < 0.8))
         ctx.set_reads(ds.read_len)

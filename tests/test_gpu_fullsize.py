@@ -278,6 +278,7 @@ def test_c5_properties():
 
     same(a, one(use_run_kernel=0), "position-space kernel")
     same(a, one(use_fixed_buckets=0), "exact CSR bucketing")
+    same(a, one(use_partitioned_buckets=0), "single-pass bucketing into fixed slots")
     same(a, one(use_round_batches=0), "every containment round looked at by the host")
     same(a, one(), "second run")
 

@@ -36,12 +36,14 @@ def test_full_path_small(hip_ctx_factory, n, g, seed, run_kernel):
 
 @pytest.mark.parametrize("n,g,seed", [(3000, 600_000, 21), (400, 20_000, 5), (1500, 12_000, 3)])
 def test_bucketing_variants(hip_ctx_factory, n, g, seed):
-    """The two ways the bounds reach the pile kernel: fixed slots (default; the position inside the
-    slot is what the counting atomic returns) and the exact CSR (count, scan, scatter)."""
+    """The ways the bounds reach the pile kernel: the target side partitioned into an exact CSR (default,
+    bucket_kernels.hip), fixed slots (the position inside the slot is what the counting atomic returns) and
+    the exact CSR through count, scan, scatter."""
     ds = Dataset(n, g, seed)
     st = parity.oracle_stages(ds)
     # (use_side_stream = 0: duplicate removal and the pile chain's small kernels on the main stream)
-    for opts in ({"use_fixed_buckets": 0}, {}, {"use_side_stream": 0}, {"use_side_stream": 0, "use_fixed_buckets": 0}):
+    for opts in ({"use_fixed_buckets": 0}, {}, {"use_partitioned_buckets": 0}, {"use_side_stream": 0},
+                 {"use_side_stream": 0, "use_partitioned_buckets": 0}, {"use_side_stream": 0, "use_fixed_buckets": 0}):
         ctx = hip_ctx_factory()
         for k, v in opts.items():
             ctx.set_option(k, v)
