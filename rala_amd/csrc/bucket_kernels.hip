@@ -9,17 +9,25 @@
 // goes through two partitioning passes whose writes are whole lines, and the events land in an exact CSR
 // (ev_off / ev) that every pile kernel already reads:
 //
-//   l1_count      tiles of the overlap file: LDS histogram of target >> 12, one global add per (tile,
-//                 partition); query-side event counts per read (one add per wavefront segment)
-//   l1_prefix     partition bases; the table of partition-aligned tiles for level 2 (one workgroup)
-//   l1_scatter    the tile's target records {target & 4095, begin, end} (8 bytes) sorted by partition in
-//                 LDS, copied out partition by partition: consecutive lanes write consecutive records
-//   l2_count / l2_prefix / l2_scatter   the same inside every partition of 4096 reads: groups of 256 reads
+//   count         target-side records per group of 128 reads: one persistent workgroup per compute unit keeps a
+//                 histogram of ALL groups in LDS (31 KB per million reads) over its share of the file
+//   layout        one scan over the groups: where every group's records go at level 2, and with that every
+//                 partition's (32 groups) at level 1; the table of level-2 tiles, none of which crosses a
+//                 partition (one workgroup)
+//   l1_scatter    the tile's target records {target & 4095, begin, end} (8 bytes) sorted by partition in LDS,
+//                 copied out partition by partition - consecutive lanes write consecutive records; one global
+//                 add per (tile, partition) reserves the place.  Also the query-side event counts per read
+//                 (one add per wavefront segment).
+//   l2_scatter    the same inside every partition of 4096 reads: groups of 128 reads
 //   final_count   one workgroup per group: target-side events per read (LDS histogram) -> event counts
 //   (scan)        event counts -> ev_off
 //   final_write   one workgroup per group: the group's records at places handed out by LDS counters -
 //                 8-byte stores inside a window of 200 KB that the L2 merges into whole lines
 //   query_side    one thread per overlap, as in the single-pass kernel: segment base from one atomic
+//
+// Sizes are counted, not guessed: files that name every pair once, query = the lower id, make a read a target
+// in proportion to its id - the first groups of the file hold next to nothing, the last ones twice the
+// average.
 //
 // The order of a read's events is irrelevant (Pile::add_layers sorts them; the run-space kernel does not
 // even need that), so the result equals the other bucketing paths' as a multiset per read.
@@ -75,61 +83,76 @@ __device__ __forceinline__ uint32_t segment_of(uint32_t key, bool active, uint32
 }
 
 // ---- level 1: target >> 12 ------------------------------------------------------------------------
-// + acount[a] = resolvable overlaps of query a (its query-side events / 2)
-__global__ __launch_bounds__(kBlockP) void l1_count_kernel(OvlSoA o, uint32_t n_reads, uint32_t n_part, uint32_t* part_count,
-                                                           uint32_t* acount) {
+constexpr uint32_t kBlockC = 1024;
+__global__ __launch_bounds__(kBlockC) void group_count_kernel(OvlSoA o, uint32_t n_reads, uint32_t n_groups, uint32_t* group_count) {
     extern __shared__ uint32_t s_hist[];
-    for (uint32_t p = threadIdx.x; p < n_part; p += kBlockP) s_hist[p] = 0;
+    for (uint32_t g = threadIdx.x; g < n_groups; g += kBlockC) s_hist[g] = 0;
     __syncthreads();
-    const uint32_t lane = threadIdx.x & 63;
+    // this workgroup's share of the file: whole chunks of kBlockC * 4 overlaps, interleaved with the others'
+    constexpr uint32_t kC = 4;
     const uint64_t last = o.n - 1;
+    for (uint64_t i0 = (uint64_t)blockIdx.x * kBlockC * kC; i0 < o.n; i0 += (uint64_t)gridDim.x * kBlockC * kC) {
+        uint32_t a[kC], b[kC];
 #pragma unroll
-    for (uint32_t u = 0; u < kPer; ++u) {
-        const uint64_t i = (uint64_t)blockIdx.x * kTile + u * kBlockP + threadIdx.x;
-        const uint64_t j = i < o.n ? i : last;
-        const uint32_t a = o.a_id[j], b = o.b_id[j];
-        const bool ok = i < o.n && a < n_reads && b < n_reads;
-        if (ok) atomicAdd(&s_hist[b >> kL1Shift], 1u);
-        uint32_t leader;
-        const uint32_t seg = segment_of(a, ok, lane, leader);
-        if (seg) atomicAdd(&acount[a], seg);
+        for (uint32_t u = 0; u < kC; ++u) {
+            const uint64_t i = i0 + u * kBlockC + threadIdx.x;
+            const uint64_t j = i < o.n ? i : last;
+            a[u] = i < o.n ? __builtin_nontemporal_load(o.a_id + j) : kInf;
+            b[u] = __builtin_nontemporal_load(o.b_id + j);
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < kC; ++u) {
+            if (a[u] < n_reads && b[u] < n_reads) atomicAdd(&s_hist[b[u] >> kGroupShift], 1u);
+        }
     }
     __syncthreads();
-    for (uint32_t p = threadIdx.x; p < n_part; p += kBlockP) {
-        const uint32_t c = s_hist[p];
-        if (c) atomicAdd(&part_count[p], c);
+    for (uint32_t g = threadIdx.x; g < n_groups; g += kBlockC) {
+        const uint32_t c = s_hist[g];
+        if (c) atomicAdd(&group_count[g], c);
     }
 }
 
-// base[0 .. n] = exclusive prefix of count[0 .. n), cursor = base.  With tiles != null also the table of
-// tiles that do not cross a range: tile t covers records tile_lo[t] .. of range tile_range[t]; *n_tiles.
-__global__ __launch_bounds__(1024) void prefix_kernel(const uint32_t* __restrict__ count, uint32_t n, uint32_t* __restrict__ base,
-                                                      uint32_t* __restrict__ cursor, uint32_t* __restrict__ tile_range,
-                                                      uint32_t* __restrict__ tile_lo, uint32_t* n_tiles) {
+// From the groups' counts (n_groups of them, padded with empty ones to n_part * kGroupsPerPart): group_base[0 ..
+// n] and group_cursor = exclusive prefix; part_cursor[p] = group_base[p * kGroupsPerPart] (a partition's records
+// lie where its groups' will); the table of level-2 tiles - tile t covers records tile_lo[t] .. tile_hi[t] of
+// partition tile_part[t], *n_tiles of them.  One workgroup.
+__global__ __launch_bounds__(1024) void layout_kernel(const uint32_t* __restrict__ group_count, uint32_t n_part,
+                                                      uint32_t* __restrict__ group_base, uint32_t* __restrict__ group_cursor,
+                                                      uint32_t* __restrict__ part_cursor, uint32_t* __restrict__ tile_part,
+                                                      uint32_t* __restrict__ tile_lo, uint32_t* __restrict__ tile_hi, uint32_t* n_tiles) {
     __shared__ uint32_t tmp[1024 / 64 + 1];
-    uint32_t carry = 0, tile_carry = 0;
-    for (uint32_t p0 = 0; p0 < n; p0 += 1024) {
-        const uint32_t p = p0 + threadIdx.x;
-        const uint32_t v = p < n ? count[p] : 0u;
+    const uint32_t n = n_part * kGroupsPerPart;
+    uint32_t carry = 0;
+    for (uint32_t g0 = 0; g0 < n; g0 += 1024) {
+        const uint32_t g = g0 + threadIdx.x;
+        const uint32_t c = g < n ? group_count[g] : 0u;
         uint32_t tot;
-        const uint32_t ex = block_scan_excl<1024>(v, OpAdd(), 0u, tmp, tot);
-        if (p < n) { base[p] = carry + ex; cursor[p] = carry + ex; }
-        if (tile_range) {
-            const uint32_t tiles = (v + kTile - 1) / kTile;
-            uint32_t ttot;
-            const uint32_t tex = block_scan_excl<1024>(tiles, OpAdd(), 0u, tmp, ttot);
-            for (uint32_t k = 0; k < tiles; ++k) {
-                tile_range[tile_carry + tex + k] = p;
-                tile_lo[tile_carry + tex + k] = carry + ex + k * kTile;
-            }
-            tile_carry += ttot;
+        const uint32_t ex = block_scan_excl<1024>(c, OpAdd(), 0u, tmp, tot);
+        if (g < n) {
+            group_base[g] = carry + ex;
+            group_cursor[g] = carry + ex;
+            if (g % kGroupsPerPart == 0) part_cursor[g / kGroupsPerPart] = carry + ex;
         }
         carry += tot;
     }
-    if (threadIdx.x == 0) {
-        base[n] = carry;
-        if (n_tiles) *n_tiles = tile_carry;
+    if (threadIdx.x == 0) group_base[n] = carry;
+    __syncthreads();
+    uint32_t tile_carry = 0;
+    for (uint32_t p0 = 0; p0 < n_part; p0 += 1024) {
+        const uint32_t p = p0 + threadIdx.x;
+        const uint32_t lo = p < n_part ? group_base[p * kGroupsPerPart] : 0u;
+        const uint32_t hi = p < n_part ? group_base[(p + 1u) * kGroupsPerPart] : 0u;
+        const uint32_t tiles = (hi - lo + kTile - 1) / kTile;
+        uint32_t ttot;
+        const uint32_t tex = block_scan_excl<1024>(tiles, OpAdd(), 0u, tmp, ttot);
+        for (uint32_t k = 0; k < tiles; ++k) {
+            tile_part[tile_carry + tex + k] = p;
+            tile_lo[tile_carry + tex + k] = lo + k * kTile;
+            tile_hi[tile_carry + tex + k] = umin(hi, lo + (k + 1u) * kTile);
+        }
+        tile_carry += ttot;
     }
+    if (threadIdx.x == 0) *n_tiles = tile_carry;
 }
 
 // dynamic LDS: stage[kTile] (8 B), bin_of[kTile] (2 B), hist / off / gbase [n_bins] (4 B each)
@@ -148,8 +171,8 @@ struct StageLds {
 inline size_t stage_lds_bytes(uint32_t n_bins) { return (size_t)kTile * 10 + (size_t)n_bins * 12 + 16; }
 
 // The records of one tile, each with its bin and whether it counts: ranks inside the bins (LDS adds), the
-// bins' places in the staging area (scan) and in the output (one global add per bin with records), the
-// records sorted by bin in LDS, then copied out - consecutive lanes, consecutive addresses.
+// bins' places in the staging area (scan) and in the output (one add per bin with records), the records
+// sorted by bin in LDS, then copied out - consecutive lanes, consecutive addresses.
 __device__ __forceinline__ void stage_and_copy(StageLds& L, uint32_t n_bins, const uint64_t* rec, const uint32_t* bin, const bool* in,
                                                uint32_t* cursor, uint64_t* __restrict__ out, uint32_t* tmp) {
     for (uint32_t p = threadIdx.x; p < n_bins; p += kBlockP) L.hist[p] = 0;
@@ -187,14 +210,16 @@ __device__ __forceinline__ void stage_and_copy(StageLds& L, uint32_t n_bins, con
     }
 }
 
+// + acount[a] = resolvable overlaps of query a (its query-side events / 2)
 __global__ __launch_bounds__(kBlockP) void l1_scatter_kernel(OvlSoA o, uint32_t n_reads, uint32_t n_part, uint32_t* part_cursor,
-                                                             uint64_t* __restrict__ rec1) {
+                                                             uint64_t* __restrict__ rec1, uint32_t* acount) {
     extern __shared__ __align__(16) unsigned char s_raw[];
     __shared__ uint32_t tmp[kBlockP / 64 + 1];
     StageLds L(s_raw, n_part);
     uint64_t rec[kPer];
     uint32_t bin[kPer];
     bool in[kPer];
+    const uint32_t lane = threadIdx.x & 63;
     const uint64_t last = o.n - 1;
 #pragma unroll
     for (uint32_t u = 0; u < kPer; ++u) {
@@ -204,35 +229,23 @@ __global__ __launch_bounds__(kBlockP) void l1_scatter_kernel(OvlSoA o, uint32_t 
         in[u] = i < o.n && a < n_reads && b < n_reads;
         rec[u] = pack_record(b, o.b_begin[j], o.b_end[j]);
         bin[u] = in[u] ? b >> kL1Shift : 0u;
+        uint32_t leader;
+        const uint32_t seg = segment_of(a, in[u], lane, leader);
+        if (seg) atomicAdd(&acount[a], seg);
     }
     stage_and_copy(L, n_part, rec, bin, in, part_cursor, rec1, tmp);
 }
 
-// ---- level 2: inside every partition, groups of 256 reads; tiles that do not cross a partition -------
-__global__ __launch_bounds__(kBlockP) void l2_count_kernel(const uint64_t* __restrict__ rec1, const uint32_t* __restrict__ part_base,
-                                                           const uint32_t* __restrict__ tile_part, const uint32_t* __restrict__ tile_lo,
-                                                           const uint32_t* __restrict__ n_tiles, uint32_t* group_count) {
-    __shared__ uint32_t s_hist[kGroupsPerPart];
-    if (blockIdx.x >= *n_tiles) return;
-    const uint32_t part = tile_part[blockIdx.x], lo = tile_lo[blockIdx.x];
-    const uint32_t hi = umin(lo + kTile, part_base[part + 1]);
-    if (threadIdx.x < kGroupsPerPart) s_hist[threadIdx.x] = 0;
-    __syncthreads();
-    for (uint32_t j = lo + threadIdx.x; j < hi; j += kBlockP) atomicAdd(&s_hist[rec_key(rec1[j]) >> kGroupShift], 1u);
-    __syncthreads();
-    if (threadIdx.x < kGroupsPerPart && s_hist[threadIdx.x]) atomicAdd(&group_count[part * kGroupsPerPart + threadIdx.x], s_hist[threadIdx.x]);
-}
-
-__global__ __launch_bounds__(kBlockP) void l2_scatter_kernel(const uint64_t* __restrict__ rec1, const uint32_t* __restrict__ part_base,
-                                                             const uint32_t* __restrict__ tile_part, const uint32_t* __restrict__ tile_lo,
+// ---- level 2: inside every partition, groups of 128 reads; tiles that do not cross a partition -------
+__global__ __launch_bounds__(kBlockP) void l2_scatter_kernel(const uint64_t* __restrict__ rec1, const uint32_t* __restrict__ tile_part,
+                                                             const uint32_t* __restrict__ tile_lo, const uint32_t* __restrict__ tile_hi,
                                                              const uint32_t* __restrict__ n_tiles, uint32_t* group_cursor,
                                                              uint64_t* __restrict__ rec2) {
     extern __shared__ __align__(16) unsigned char s_raw[];
     __shared__ uint32_t tmp[kBlockP / 64 + 1];
     if (blockIdx.x >= *n_tiles) return;
     StageLds L(s_raw, kGroupsPerPart);
-    const uint32_t part = tile_part[blockIdx.x], lo = tile_lo[blockIdx.x];
-    const uint32_t hi = umin(lo + kTile, part_base[part + 1]);
+    const uint32_t part = tile_part[blockIdx.x], lo = tile_lo[blockIdx.x], hi = tile_hi[blockIdx.x];
     uint64_t rec[kPer];
     uint32_t bin[kPer];
     bool in[kPer];
@@ -318,49 +331,54 @@ __global__ __launch_bounds__(256) void query_side_kernel(OvlSoA o, uint32_t n_re
 
 }  // namespace
 
-size_t partition_records_needed(uint64_t n_overlaps) { return (size_t)n_overlaps + 8; }
 uint32_t partition_count(uint32_t n_reads) { return (n_reads + kL1Reads - 1) / kL1Reads; }
 uint32_t partition_group_slots(uint32_t n_reads) { return partition_count(n_reads) * kGroupsPerPart + 2; }
+size_t partition_records_needed(uint32_t, uint64_t n_overlaps) { return (size_t)n_overlaps + 64; }
 size_t partition_tile_slots(uint32_t n_reads, uint64_t n_overlaps) { return (size_t)(n_overlaps / kTile) + partition_count(n_reads) + 4; }
 bool partition_path_fits(uint32_t n_reads, uint32_t max_read_len, uint64_t n_overlaps) {
-    // coordinates in 26 bits; level-1 histograms in LDS next to the staging area; positions in 32 bits
-    return max_read_len < kCoordMax - 32u && stage_lds_bytes(partition_count(n_reads)) <= 60u * 1024u &&
-           4ull * n_overlaps < 0xFFFFFFF0ull && n_reads > 0 && n_overlaps > 0;
+    // coordinates in 26 bits; the histogram of all groups in the LDS of one workgroup; level-1 histograms next to
+    // the staging area; positions in 32 bits; enough overlaps per partition for whole-line copies
+    if (n_reads == 0 || n_overlaps == 0) return false;
+    const uint64_t n_part = partition_count(n_reads);
+    return max_read_len < kCoordMax - 32u && n_part * kGroupsPerPart * 4u <= 150u * 1024u &&
+           stage_lds_bytes((uint32_t)n_part) <= 60u * 1024u && 4ull * n_overlaps < 0xFFFFFFF0ull && n_overlaps / n_part >= 512;
 }
 
-// Buffers (device): acount, ecount, written: n_reads + 2 words each; part: 3 * (n_part + 2) words (counts,
-// bases, cursors); group: 3 * partition_group_slots(n_reads) (counts, bases, cursors); tiles: 2 *
-// partition_tile_slots words + 1 (partition, first record of every level-2 tile; their number); rec1, rec2:
-// partition_records_needed records; ev_off: n_reads + 2; ev: 4 * n_overlaps + 8.  scan: tile states for one
-// scan over n_reads.
+// Buffers (device): acount, ecount, written: n_reads + 2 words each; part_cursor: n_part + 2 words; group: 3 *
+// partition_group_slots(n_reads) words (counts, bases, cursors); tiles: 3 * partition_tile_slots words + 1; rec1,
+// rec2: partition_records_needed records; ev_off: n_reads + 2; ev: 4 * n_overlaps + 8.  scan: tile states for one
+// scan over n_reads.  workgroups: compute units of the device (the counting kernel's persistent workgroups).
 hipError_t launch_bucket_partitioned(const OvlSoA& o, uint32_t n_reads, uint32_t* acount, uint32_t* ecount, uint32_t* written,
-                                     uint32_t* part, uint32_t* group, uint32_t* tiles, uint64_t* rec1, uint64_t* rec2,
-                                     uint32_t* ev_off, uint32_t* ev, ScanSpace& scan, hipStream_t s) {
+                                     uint32_t* part_cursor, uint32_t* group, uint32_t* tiles, uint64_t* rec1, uint64_t* rec2,
+                                     uint32_t* ev_off, uint32_t* ev, uint32_t workgroups, ScanSpace& scan, hipStream_t s) {
     const uint32_t n_part = partition_count(n_reads);
     const uint32_t n_groups = (n_reads + kGroupReads - 1) / kGroupReads;
     const uint32_t group_slots = partition_group_slots(n_reads);
     const size_t tile_slots = partition_tile_slots(n_reads, o.n);
-    uint32_t *part_count = part, *part_base = part + (n_part + 2), *part_cursor = part + 2 * (n_part + 2);
     uint32_t *group_count = group, *group_base = group + group_slots, *group_cursor = group + 2 * (size_t)group_slots;
-    uint32_t *tile_part = tiles, *tile_lo = tiles + tile_slots, *n_tiles = tiles + 2 * tile_slots;
+    uint32_t *tile_part = tiles, *tile_lo = tiles + tile_slots, *tile_hi = tiles + 2 * tile_slots, *n_tiles = tiles + 3 * tile_slots;
     hipError_t e = hipMemsetAsync(acount, 0, (size_t)n_reads * 4, s);
     if (e == hipSuccess) e = hipMemsetAsync(written, 0, (size_t)n_reads * 4, s);
-    if (e == hipSuccess) e = hipMemsetAsync(part_count, 0, (size_t)(n_part + 2) * 4, s);
     if (e == hipSuccess) e = hipMemsetAsync(group_count, 0, (size_t)group_slots * 4, s);
     if (e != hipSuccess) return e;
+    const size_t lds_count = (size_t)n_part * kGroupsPerPart * 4;
+    static size_t asked_count = 64 * 1024;
+    if (lds_count > asked_count) {
+        e = hipFuncSetAttribute((const void*)group_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_count);
+        if (e != hipSuccess) return e;
+        asked_count = lds_count;
+    }
+    const uint32_t chunks = (uint32_t)((o.n + kBlockC * 4 - 1) / (kBlockC * 4));
+    hipLaunchKernelGGL(group_count_kernel, dim3(std::min<uint32_t>(workgroups ? workgroups : 256u, chunks)), dim3(kBlockC), lds_count, s, o,
+                       n_reads, n_part * kGroupsPerPart, group_count);
+    hipLaunchKernelGGL(layout_kernel, dim3(1), dim3(1024), 0, s, (const uint32_t*)group_count, n_part, group_base, group_cursor, part_cursor,
+                       tile_part, tile_lo, tile_hi, n_tiles);
     const uint32_t tiles1 = (uint32_t)((o.n + kTile - 1) / kTile);
-    hipLaunchKernelGGL(l1_count_kernel, dim3(tiles1), dim3(kBlockP), (size_t)n_part * 4, s, o, n_reads, n_part, part_count, acount);
-    hipLaunchKernelGGL(prefix_kernel, dim3(1), dim3(1024), 0, s, (const uint32_t*)part_count, n_part, part_base, part_cursor, tile_part,
-                       tile_lo, n_tiles);
-    hipLaunchKernelGGL(l1_scatter_kernel, dim3(tiles1), dim3(kBlockP), stage_lds_bytes(n_part), s, o, n_reads, n_part, part_cursor, rec1);
-    const uint32_t tiles2 = (uint32_t)(o.n / kTile) + n_part + 1;       // at least as many as the table holds
-    hipLaunchKernelGGL(l2_count_kernel, dim3(tiles2), dim3(kBlockP), 0, s, (const uint64_t*)rec1, (const uint32_t*)part_base,
-                       (const uint32_t*)tile_part, (const uint32_t*)tile_lo, (const uint32_t*)n_tiles, group_count);
-    hipLaunchKernelGGL(prefix_kernel, dim3(1), dim3(1024), 0, s, (const uint32_t*)group_count, n_part * kGroupsPerPart, group_base,
-                       group_cursor, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr);
+    hipLaunchKernelGGL(l1_scatter_kernel, dim3(tiles1), dim3(kBlockP), stage_lds_bytes(n_part), s, o, n_reads, n_part, part_cursor, rec1, acount);
+    const uint32_t tiles2 = (uint32_t)(tile_slots - 4);                 // at least as many as the table can hold
     hipLaunchKernelGGL(l2_scatter_kernel, dim3(tiles2), dim3(kBlockP), stage_lds_bytes(kGroupsPerPart), s, (const uint64_t*)rec1,
-                       (const uint32_t*)part_base, (const uint32_t*)tile_part, (const uint32_t*)tile_lo, (const uint32_t*)n_tiles,
-                       group_cursor, rec2);
+                       (const uint32_t*)tile_part, (const uint32_t*)tile_lo, (const uint32_t*)tile_hi, (const uint32_t*)n_tiles, group_cursor,
+                       rec2);
     hipLaunchKernelGGL(final_count_kernel, dim3(n_groups), dim3(kBlockF), 0, s, (const uint64_t*)rec2, (const uint32_t*)group_base, n_reads,
                        (const uint32_t*)acount, ecount);
     if (!launch_offsets_pass(ecount, ev_off, nullptr, n_reads, scan, s)) return hipErrorOutOfMemory;

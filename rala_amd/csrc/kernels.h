@@ -294,15 +294,15 @@ bool launch_segment_pass(const TailList& L, const TailReads& R, uint32_t want_st
 bool launch_offsets_pass(const uint32_t* in, uint32_t* out, uint32_t* copy, uint32_t n, ScanSpace& space, hipStream_t s);
 
 // ---- partitioned bucketing (bucket_kernels.hip) ------------------------------------------------
-size_t partition_records_needed(uint64_t n_overlaps);
+size_t partition_records_needed(uint32_t n_reads, uint64_t n_overlaps);
 uint32_t partition_count(uint32_t n_reads);
 uint32_t partition_group_slots(uint32_t n_reads);
 size_t partition_tile_slots(uint32_t n_reads, uint64_t n_overlaps);
 bool partition_path_fits(uint32_t n_reads, uint32_t max_read_len, uint64_t n_overlaps);
 // bound events of all reads as an exact CSR (ev_off[n_reads + 1], ev); buffer sizes: bucket_kernels.hip
 hipError_t launch_bucket_partitioned(const OvlSoA& o, uint32_t n_reads, uint32_t* acount, uint32_t* ecount, uint32_t* written,
-                                     uint32_t* part, uint32_t* group, uint32_t* tiles, uint64_t* rec1, uint64_t* rec2,
-                                     uint32_t* ev_off, uint32_t* ev, ScanSpace& scan, hipStream_t s);
+                                     uint32_t* part_cursor, uint32_t* group, uint32_t* tiles, uint64_t* rec1, uint64_t* rec2,
+                                     uint32_t* ev_off, uint32_t* ev, uint32_t workgroups, ScanSpace& scan, hipStream_t s);
 
 // ---- scans (scan_kernels.hip) --------------------------------------------------
 // exclusive prefix sum of n uint32 values; out may alias in; out[n] receives the total

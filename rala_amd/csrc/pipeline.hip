@@ -1842,16 +1842,17 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
     const uint32_t slot = kRunEventCapBig;
     // Partitioned path (bucket_kernels.hip): the target side through two partitioning passes instead of one
     // memory-side atomic and one partial write per overlap; ends in the exact CSR.  Needs the overlaps
-    // (not tuples), coordinates below 2^26 and enough overlaps per partition for the passes to pay.
+    // (not tuples), coordinates below 2^26, enough overlaps per partition for the passes to pay, few enough
+    // reads for a histogram of their groups of 128 to fit the LDS (9 M).
     const bool partitioned = !ctx->tuple_mode && ctx->use_run_kernel && ctx->use_fixed_buckets && ctx->use_partitioned_buckets &&
                              partition_path_fits(n_reads, ctx->max_read_len, ctx->n_ovl);
     bool fixed = !partitioned && ctx->use_run_kernel && ctx->use_fixed_buckets && (uint64_t)n_reads * slot * 4ull <= (64ull << 30);
     if (partitioned) {
         for (int k = 0; k < 3; ++k) HIPCHECK(ctx->d_bk_u32[k].ensure(n_reads + 2));
-        HIPCHECK(ctx->d_bk_part.ensure(3 * (size_t)(partition_count(n_reads) + 2)));
+        HIPCHECK(ctx->d_bk_part.ensure(partition_count(n_reads) + 2));
         HIPCHECK(ctx->d_bk_group.ensure(3 * (size_t)partition_group_slots(n_reads)));
-        HIPCHECK(ctx->d_bk_tiles.ensure(2 * partition_tile_slots(n_reads, ctx->n_ovl) + 2));
-        for (int k = 0; k < 2; ++k) HIPCHECK(ctx->d_bk_rec[k].ensure(partition_records_needed(ctx->n_ovl)));
+        HIPCHECK(ctx->d_bk_tiles.ensure(3 * partition_tile_slots(n_reads, ctx->n_ovl) + 2));
+        for (int k = 0; k < 2; ++k) HIPCHECK(ctx->d_bk_rec[k].ensure(partition_records_needed(n_reads, ctx->n_ovl)));
         ScanSpace sp;
         {
             const int rc = scan_space(ctx, 1, n_reads, sp);
@@ -1859,7 +1860,7 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
         }
         HIPCHECK(launch_bucket_partitioned(ctx->ovl, n_reads, ctx->d_bk_u32[0].p, ctx->d_bk_u32[1].p, ctx->d_bk_u32[2].p,
                                            ctx->d_bk_part.p, ctx->d_bk_group.p, ctx->d_bk_tiles.p, ctx->d_bk_rec[0].p,
-                                           ctx->d_bk_rec[1].p, ctx->d_ev_off.p, ctx->d_ev.p, sp, s));
+                                           ctx->d_bk_rec[1].p, ctx->d_ev_off.p, ctx->d_ev.p, ctx->n_compute_units, sp, s));
     }
     if (fixed) {
         HIPCHECK(ctx->d_ev_fixed.ensure((size_t)n_reads * slot + 8));
