@@ -347,19 +347,22 @@ bool partition_path_fits(uint32_t n_reads, uint32_t max_read_len, uint64_t n_ove
 // Buffers (device): acount, ecount, written: n_reads + 2 words each; part_cursor: n_part + 2 words; group: 3 *
 // partition_group_slots(n_reads) words (counts, bases, cursors); tiles: 3 * partition_tile_slots words + 1; rec1,
 // rec2: partition_records_needed records; ev_off: n_reads + 2; ev: 4 * n_overlaps + 8.  scan: tile states for one
-// scan over n_reads.  workgroups: compute units of the device (the counting kernel's persistent workgroups).
+// scan over n_reads (cleared by `fills`, which is launched here).  workgroups: compute units of the device (the counting kernel's persistent workgroups).
 hipError_t launch_bucket_partitioned(const OvlSoA& o, uint32_t n_reads, uint32_t* acount, uint32_t* ecount, uint32_t* written,
                                      uint32_t* part_cursor, uint32_t* group, uint32_t* tiles, uint64_t* rec1, uint64_t* rec2,
-                                     uint32_t* ev_off, uint32_t* ev, uint32_t workgroups, ScanSpace& scan, hipStream_t s) {
+                                     uint32_t* ev_off, uint32_t* ev, uint32_t workgroups, ScanSpace& scan, FillList& fills,
+                                     hipStream_t s) {
     const uint32_t n_part = partition_count(n_reads);
     const uint32_t n_groups = (n_reads + kGroupReads - 1) / kGroupReads;
     const uint32_t group_slots = partition_group_slots(n_reads);
     const size_t tile_slots = partition_tile_slots(n_reads, o.n);
     uint32_t *group_count = group, *group_base = group + group_slots, *group_cursor = group + 2 * (size_t)group_slots;
     uint32_t *tile_part = tiles, *tile_lo = tiles + tile_slots, *tile_hi = tiles + 2 * tile_slots, *n_tiles = tiles + 3 * tile_slots;
-    hipError_t e = hipMemsetAsync(acount, 0, (size_t)n_reads * 4, s);
-    if (e == hipSuccess) e = hipMemsetAsync(written, 0, (size_t)n_reads * 4, s);
-    if (e == hipSuccess) e = hipMemsetAsync(group_count, 0, (size_t)group_slots * 4, s);
+    // (with whatever the caller wants cleared at this point, the scan's tile states among it)
+    fills.add(acount, 0, (size_t)n_reads * 4);
+    fills.add(written, 0, (size_t)n_reads * 4);
+    fills.add(group_count, 0, (size_t)group_slots * 4);
+    hipError_t e = fills.launch(s);
     if (e != hipSuccess) return e;
     const size_t lds_count = (size_t)n_part * kGroupsPerPart * 4;
     static size_t asked_count = 64 * 1024;

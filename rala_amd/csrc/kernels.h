@@ -273,13 +273,17 @@ void launch_retrim(const TailList& L, const TailReads& R, uint32_t promote, uint
                    hipStream_t s, const uint32_t* gate = nullptr);
 void launch_cc_edges(const TailList& L, const uint32_t* rank, uint32_t* edges, uint8_t* touched, hipStream_t s);
 void launch_refresh_types(const TailList& L, const TailReads& R, hipStream_t s);
-void launch_tail_death_round(const TailList& L, const uint8_t* alive, uint32_t which, const uint32_t* death_old,
-                             uint32_t* death_new, hipStream_t s);
-void launch_tail_apply_scan(const TailList& L, const uint8_t* alive, uint32_t which, const uint32_t* death, hipStream_t s);
-void launch_kill_reads(const uint32_t* death, uint8_t* alive, uint32_t n, hipStream_t s);
+// both in-order containment scans of the tail (graph.cpp:831-877) without a look from the host (tail_kernels.hip).  lists:
+// six arrays of L.n words (killers, conditional killers); zeroed5: five zeroed words ([0] is set when a fixed point did
+// not settle); work: four arrays of n_reads words, uninitialised; base2: 2 * n_reads words, all ones, and mark2: 2 * n_reads
+// bytes, zero (tail_init)
+void launch_tail_contain(const TailList& L, uint8_t* alive, uint32_t* const lists[6], uint32_t* zeroed5, uint32_t* const work[4],
+                         uint32_t* base2, uint8_t* mark2, uint32_t n_reads, hipStream_t s);
 void launch_count_zero_u8(const uint8_t* x, uint32_t n, uint32_t* out, hipStream_t s);    // *out += #zeros
-// list states (the first n0 items are overlaps, the rest internals), dirty[] = 0, n_pits0[] = n_pits[] in one launch
-void launch_tail_init(const TailList& L, uint32_t n0, const TailReads& R, uint8_t* n_pits0, uint32_t n_reads, hipStream_t s);
+// list states (the first n0 items are overlaps, the rest internals), dirty[] = 0, n_pits0[] = n_pits[], base2[0 .. 2 n_reads) =
+// all ones, mark2[0 .. 2 n_reads) = 0, zero6[0 .. 5] = 0 in one launch
+void launch_tail_init(const TailList& L, uint32_t n0, const TailReads& R, uint8_t* n_pits0, uint32_t n_reads, uint32_t* base2,
+                      uint8_t* mark2, uint32_t* zero6, hipStream_t s);
 // single-pass scans with producer and consumer inside (scan_pass.h); false = out of tile states
 struct ScanSpace;
 bool launch_rank_pass(const uint8_t* alive, uint32_t* rank, uint32_t* alive_reads, uint32_t n_reads, ScanSpace& space, hipStream_t s);
@@ -293,6 +297,19 @@ bool launch_segment_pass(const TailList& L, const TailReads& R, uint32_t want_st
 // out[i] = in[0] + .. + in[i - 1], out[n] = the sum; copy (may be null) receives out[0 .. n) as well
 bool launch_offsets_pass(const uint32_t* in, uint32_t* out, uint32_t* copy, uint32_t n, ScanSpace& space, hipStream_t s);
 
+// ---- fills (fill_kernels.hip) -------------------------------------------------------------------
+// What a stage has to clear, cleared in one launch: add(pointer, byte value, bytes) ..., then launch(stream).
+struct FillList {
+    static constexpr uint32_t kMost = 8;
+    void* ptr[kMost];
+    size_t bytes[kMost];
+    uint8_t value[kMost];
+    uint32_t n = 0;
+    bool overflow = false;
+    void add(void* p, int byte, size_t n_bytes);
+    hipError_t launch(hipStream_t s);       // (more than kMost entries: hipErrorInvalidValue)
+};
+
 // ---- partitioned bucketing (bucket_kernels.hip) ------------------------------------------------
 size_t partition_records_needed(uint32_t n_reads, uint64_t n_overlaps);
 uint32_t partition_count(uint32_t n_reads);
@@ -302,7 +319,7 @@ bool partition_path_fits(uint32_t n_reads, uint32_t max_read_len, uint64_t n_ove
 // bound events of all reads as an exact CSR (ev_off[n_reads + 1], ev); buffer sizes: bucket_kernels.hip
 hipError_t launch_bucket_partitioned(const OvlSoA& o, uint32_t n_reads, uint32_t* acount, uint32_t* ecount, uint32_t* written,
                                      uint32_t* part_cursor, uint32_t* group, uint32_t* tiles, uint64_t* rec1, uint64_t* rec2,
-                                     uint32_t* ev_off, uint32_t* ev, uint32_t workgroups, ScanSpace& scan, hipStream_t s);
+                                     uint32_t* ev_off, uint32_t* ev, uint32_t workgroups, ScanSpace& scan, FillList& fills, hipStream_t s);
 
 // ---- scans (scan_kernels.hip) --------------------------------------------------
 // exclusive prefix sum of n uint32 values; out may alias in; out[n] receives the total

@@ -591,7 +591,7 @@ bool is_valid_overlap(rala_hip_ctx* ctx, uint32_t r, uint32_t x, uint32_t y) {
 int materialize_host(rala_hip_ctx* ctx);
 void build_graph(rala_hip_ctx* ctx);
 TailList tail_list(rala_hip_ctx* ctx);
-int tail_components(rala_hip_ctx* ctx, const TailList& L, uint32_t n_alive);
+int tail_components(rala_hip_ctx* ctx, const TailList& L, uint32_t n_alive, bool touched_cleared = false);
 int gpu_tail_part_b(rala_hip_ctx* ctx);
 
 // Graph::preprocess(overlaps, sensitive path) (graph.cpp:882-1054).  Sensitive records:
@@ -957,7 +957,7 @@ void build_graph(rala_hip_ctx* ctx) {
 }
 
 // transitive-edge marking on device edge arrays; marks stay in ctx->d_tr_marks
-int scan_space(rala_hip_ctx* ctx, uint32_t scans, uint64_t items, ScanSpace& sp);
+int scan_space(rala_hip_ctx* ctx, uint32_t scans, uint64_t items, ScanSpace& sp, FillList* fills = nullptr);
 
 int tr_mark_device(rala_hip_ctx* ctx, uint32_t n_nodes, uint32_t n_edges, const uint32_t* d_src, const uint32_t* d_dst,
                    const uint32_t* d_len, uint32_t* n_pairs, Comm* comm = nullptr) {
@@ -969,18 +969,20 @@ int tr_mark_device(rala_hip_ctx* ctx, uint32_t n_nodes, uint32_t n_edges, const 
     HIPCHECK(B[0].ensure(n_nodes + 2)); HIPCHECK(B[1].ensure(n_nodes + 2)); HIPCHECK(B[2].ensure(2 * (size_t)n_edges));
     HIPCHECK(ctx->d_tr_marks.ensure((size_t)n_edges + 8));
     HIPCHECK(ctx->d_scan_ws.ensure(scan_workspace_bytes((uint64_t)n_nodes + 2)));
-    HIPCHECK(hipMemsetAsync(ctx->d_tr_marks.p, 0, ((size_t)n_edges + 7) & ~(size_t)3, s));
-    HIPCHECK(hipMemsetAsync(ctx->d_small.p + 2, 0, 8, s));           // [2] bad endpoint flag [3] pairs
-    HIPCHECK(hipMemsetAsync(B[1].p, 0, (size_t)(n_nodes + 1) * 4, s));
     HIPCHECK(hipEventRecord(ctx->ev[10], s));
+    FillList fills;
+    fills.add(ctx->d_tr_marks.p, 0, ((size_t)n_edges + 7) & ~(size_t)3);
+    fills.add(ctx->d_small.p + 2, 0, 8);                             // [2] bad endpoint flag [3] pairs
+    fills.add(B[1].p, 0, (size_t)(n_nodes + 1) * 4);
     // CSR on the device: out-degree count -> scan -> fill.  The fill order is arbitrary; the
     // candidate a->c is the edge with the highest id, which is the reference's "last one
     // in suffix_edges_" (graph.cpp:1291-1293, out-lists are in edge-id order there).
     ScanSpace sp;
     {
-        const int rc = scan_space(ctx, 1, n_nodes, sp);
+        const int rc = scan_space(ctx, 1, n_nodes, sp, &fills);
         if (rc != RALA_HIP_OK) return rc;
     }
+    HIPCHECK(fills.launch(s));
     launch_tr_degree(d_src, d_dst, n_nodes, n_edges, B[1].p, ctx->d_small.p + 2, s);
     // row offsets (and the fill cursors, a second copy of them) from the out-degrees: one launch
     HIPCHECK(B[3 + 3].ensure(n_nodes + 2));
@@ -1047,55 +1049,27 @@ TailReads tail_reads(rala_hip_ctx* ctx) {
 }
 
 // tile states for the single-pass scans of one stage (scan_pass.h): `scans` scans of up to `items` items;
-// cleared (with the ticket counter behind them) by one fill
-int scan_space(rala_hip_ctx* ctx, uint32_t scans, uint64_t items, ScanSpace& sp) {
+// cleared (with the ticket counter behind them) by one fill - the caller's list of fills if it has one
+int scan_space(rala_hip_ctx* ctx, uint32_t scans, uint64_t items, ScanSpace& sp, FillList* fills) {
     const size_t words = (size_t)scans * (scan_tiles_for(items) + 2) + 2;
     HIPCHECK(ctx->d_scan_state.ensure(words));
     sp.state = ctx->d_scan_state.p;
     sp.words = words - 2;
     sp.used = 0;
     sp.ticket = (uint32_t*)(ctx->d_scan_state.p + words - 2);
-    HIPCHECK(hipMemsetAsync(ctx->d_scan_state.p, 0, words * 8, ctx->stream));
-    return RALA_HIP_OK;
-}
-
-// fixed point of the in-order containment removal over one class of items
-int tail_death_scan(rala_hip_ctx* ctx, const TailList& L, uint32_t which, uint32_t** death_out) {
-    hipStream_t s = ctx->stream;
-    const uint32_t n_reads = (uint32_t)ctx->n_reads;
-    int cur = 0;
-    HIPCHECK(hipMemsetAsync(ctx->d_t_death[0].p, 0xFF, (size_t)n_reads * 4, s));
-    HIPCHECK(hipMemsetAsync(ctx->d_t_death[1].p, 0xFF, (size_t)n_reads * 4, s));
-    HIPCHECK(ctx->d_cc_flags.ensure(8));
-    for (int round = 0;; ++round) {
-        // A round over a converged pair of bounds changes nothing, so several are enqueued per look from the
-        // host: six at first (what C3 needs; a look costs what four rounds cost), three from then on.
-        constexpr int kMost = 6;
-        const int batch = round == 0 ? kMost : 3;
-        HIPCHECK(hipMemsetAsync(ctx->d_cc_flags.p, 0, kMost * 4, s));
-        for (int k = 0; k < batch; ++k) {
-            // (the round's output buffer is all ones: filled above, then by the diff kernel)
-            launch_tail_death_round(L, ctx->d_alive.p, which, ctx->d_t_death[cur].p, ctx->d_t_death[cur ^ 1].p, s);
-            launch_death_diff(ctx->d_t_death[cur].p, ctx->d_t_death[cur ^ 1].p, n_reads, ctx->d_cc_flags.p + k, s);
-            cur ^= 1;
-        }
-        uint32_t changed[kMost];
-        HIPCHECK(d2h_small(ctx, changed, ctx->d_cc_flags.p, sizeof(changed), s));
-        HIPCHECK(stream_sync(ctx, s));
-        if (!changed[batch - 1]) break;
-        if (round > 100000) return fail(ctx, RALA_HIP_EDEVICE, "containment fixed point did not converge");
-    }
-    *death_out = ctx->d_t_death[cur].p;
+    if (fills) fills->add(ctx->d_scan_state.p, 0, words * 8);
+    else HIPCHECK(hipMemsetAsync(ctx->d_scan_state.p, 0, words * 8, ctx->stream));
     return RALA_HIP_OK;
 }
 
 // connected components over the live overlaps of the device list (labels in the rank space of
 // d_rank / d_alive_reads) and, per read with an overlap, the median of the pile medians of its
 // component (graph.cpp:740-783): d_touched[rank], d_cmed[rank]
-int tail_components(rala_hip_ctx* ctx, const TailList& L, uint32_t n_alive) {
+// (touched_cleared: the caller's fill has zeroed d_touched)
+int tail_components(rala_hip_ctx* ctx, const TailList& L, uint32_t n_alive, bool touched_cleared) {
     hipStream_t s = ctx->stream;
     const uint32_t M = L.n;
-    HIPCHECK(hipMemsetAsync(ctx->d_touched.p, 0, n_alive, s));
+    if (!touched_cleared) HIPCHECK(hipMemsetAsync(ctx->d_touched.p, 0, n_alive, s));
     launch_cc_edges(L, ctx->d_rank.p, ctx->d_cc_edges.p, ctx->d_touched.p, s);
     launch_cc_init(ctx->d_cc_label.p, n_alive, s);
     for (int k = 0; k < 2; ++k) {                               // sampled rounds, see cc_hook_kernel
@@ -1143,20 +1117,28 @@ int gpu_tail_part_a(rala_hip_ctx* ctx) {
     const TailReads R = tail_reads(ctx);
     ScanSpace sp;
     {
-        const int rc = scan_space(ctx, 1, n_reads, sp);
+        FillList fills;
+        const int rc = scan_space(ctx, 1, n_reads, sp, &fills);
         if (rc != RALA_HIP_OK) return rc;
+        HIPCHECK(fills.launch(s));
     }
-    launch_tail_init(L, ctx->t_n0, R, ctx->d_n_pits0.p, n_reads, s);
+    // (d_counts: [4 .. 5] overlaps dropped per round of a batch, [8] reads left, [9] a containment scan that did not settle,
+    // [10 .. 13] the scans' killer counts - launch_tail_contain)
+    HIPCHECK(ctx->d_counts.ensure(32));
+    for (int k = 0; k < 2; ++k) HIPCHECK(ctx->d_t_work[k].ensure(n_reads));
+    HIPCHECK(ctx->d_t_fin.ensure(2 * (size_t)n_reads));
+    HIPCHECK(ctx->d_t_mark.ensure(2 * (size_t)n_reads));
+    for (int k = 0; k < 3; ++k) { HIPCHECK(ctx->d_kill[k].ensure((size_t)M + 1)); HIPCHECK(ctx->d_kill2[k].ensure((size_t)M + 1)); }
+    launch_tail_init(L, ctx->t_n0, R, ctx->d_n_pits0.p, n_reads, ctx->d_t_fin.p, ctx->d_t_mark.p, ctx->d_counts.p + 9, s);
     // ranks of the reads that survived the second pass (the component graph lives on them)
     if (!launch_rank_pass(ctx->d_alive.p, ctx->d_rank.p, ctx->d_alive_reads.p, n_reads, sp, s)) return fail(ctx, RALA_HIP_EDEVICE, "scan space");
     mark("tail: ranks", n_alive);
 
     // break over chimeric hills, first re-trim (graph.cpp:704-736; no promotion here)
-    HIPCHECK(ctx->d_counts.ensure(16));
+    HIPCHECK(ctx->d_counts.ensure(32));
     uint32_t* dropped = ctx->d_counts.p + 4;                        // one word per round of a batch
     launch_break_hills(R, n_reads, s);
     launch_retrim(L, R, 0, 0, dropped, s);
-    HIPCHECK(hipMemsetAsync(ctx->d_dirty.p, 0, n_reads, s));
     mark("tail: hills + retrim", M);
 
     // graph.cpp:738-829: components, component medians, break over pits, re-trim - while an overlap died
@@ -1167,15 +1149,19 @@ int gpu_tail_part_a(rala_hip_ctx* ctx) {
     uint32_t rounds = 0;
     for (;;) {
         const uint32_t batch = rounds == 0 ? 2u : 1u;
-        HIPCHECK(hipMemsetAsync(dropped, 0, 2 * 4, s));
         for (uint32_t k = 0; k < batch; ++k) {
             if (rounds + k >= 255) return fail(ctx, RALA_HIP_EDEVICE, "chimera loop did not settle");
             const uint32_t* gate = k ? dropped + k - 1 : nullptr;
-            const int rcc = tail_components(ctx, L, n_alive);
+            // one fill: the dirt the last re-trim has dealt with, the components' marks, the batch's verdicts
+            FillList fills;
+            fills.add(ctx->d_dirty.p, 0, n_reads);
+            fills.add(ctx->d_touched.p, 0, n_alive);
+            if (k == 0) fills.add(dropped, 0, 2 * 4);
+            HIPCHECK(fills.launch(s));
+            const int rcc = tail_components(ctx, L, n_alive, true);
             if (rcc != RALA_HIP_OK) return rcc;
             launch_break_pits(R, ctx->d_alive_reads.p, ctx->d_touched.p, ctx->d_cmed.p, n_alive, s, gate);
             launch_retrim(L, R, 1, rounds + k, dropped + k, s, gate);
-            HIPCHECK(hipMemsetAsync(ctx->d_dirty.p, 0, n_reads, s));
         }
         uint32_t d[2] = {0, 0};
         HIPCHECK(d2h_small(ctx, d, dropped, sizeof(d), s));
@@ -1189,14 +1175,13 @@ int gpu_tail_part_a(rala_hip_ctx* ctx) {
 
     // in-order containment removal (graph.cpp:831-877): overlaps (+ promoted), then internals
     launch_refresh_types(L, R, s);
-    for (uint32_t which = 0; which < 2; ++which) {
-        uint32_t* death = nullptr;
-        const int rc = tail_death_scan(ctx, L, which, &death);
-        if (rc != RALA_HIP_OK) return rc;
-        launch_tail_apply_scan(L, ctx->d_alive.p, which, death, s);
-        launch_kill_reads(death, ctx->d_alive.p, n_reads, s);
-        mark("tail: containment scan", which);
+    {
+        uint32_t* const work[4] = {ctx->d_t_death[0].p, ctx->d_t_death[1].p, ctx->d_t_work[0].p, ctx->d_t_work[1].p};
+        uint32_t* const lists[6] = {ctx->d_kill[0].p, ctx->d_kill[1].p, ctx->d_kill[2].p, ctx->d_kill2[0].p, ctx->d_kill2[1].p,
+                                    ctx->d_kill2[2].p};
+        launch_tail_contain(L, ctx->d_alive.p, lists, ctx->d_counts.p + 9, work, ctx->d_t_fin.p, ctx->d_t_mark.p, n_reads, s);
     }
+    mark("tail: containment scans", M);
     return RALA_HIP_OK;
 }
 
@@ -1216,14 +1201,16 @@ int gpu_tail_part_b(rala_hip_ctx* ctx) {
     HIPCHECK(ctx->d_seg_base.ensure(2 * (size_t)n_seg + 4));
     HIPCHECK(ctx->d_node_read.ensure(2 * (size_t)ctx->t_n_alive + 2));
     for (int k = 0; k < 3; ++k) HIPCHECK(ctx->d_e[k].ensure(2 * (size_t)M + 2));
-    HIPCHECK(ctx->d_counts.ensure(16));
+    HIPCHECK(ctx->d_counts.ensure(32));
     ScanSpace sp;
     {
-        const int rc = scan_space(ctx, n_seg + 1, std::max<uint64_t>(n_reads, M), sp);
+        FillList fills;
+        const int rc = scan_space(ctx, n_seg + 1, std::max<uint64_t>(n_reads, M), sp, &fills);
         if (rc != RALA_HIP_OK) return rc;
+        fills.add(ctx->d_seg_base.p, 0, (2 * (size_t)n_seg + 4) * 4);
+        fills.add(ctx->d_counts.p + 8, 0, 4);
+        HIPCHECK(fills.launch(s));
     }
-    HIPCHECK(hipMemsetAsync(ctx->d_seg_base.p, 0, (2 * (size_t)n_seg + 4) * 4, s));
-    HIPCHECK(hipMemsetAsync(ctx->d_counts.p + 8, 0, 4, s));
     // nodes: two per surviving read (graph.cpp:553-574)
     if (!launch_node_pass(ctx->d_alive.p, ctx->d_node_rank.p, ctx->d_node_read.p, ctx->d_counts.p + 8, n_reads, sp, s)) {
         return fail(ctx, RALA_HIP_EDEVICE, "scan space");
@@ -1237,11 +1224,19 @@ int gpu_tail_part_b(rala_hip_ctx* ctx) {
             return fail(ctx, RALA_HIP_EDEVICE, "scan space");
         }
     }
-    uint32_t totals[2] = {0, 0}, n_final = 0;
+    uint32_t totals[2] = {0, 0}, left[2] = {0, 0};
     HIPCHECK(d2h_small(ctx, totals, ctx->d_seg_base.p + 2 * n_seg, 8, s));
-    HIPCHECK(d2h_small(ctx, &n_final, ctx->d_counts.p + 8, 4, s));
+    HIPCHECK(d2h_small(ctx, left, ctx->d_counts.p + 8, 8, s));
     HIPCHECK(stream_sync(ctx, s));
     HIPCHECK(hipGetLastError());
+    if (getenv("RALA_HIP_TRACE")) {
+        uint32_t kc[4] = {0, 0, 0, 0};
+        HIPCHECK(hipMemcpy(kc, ctx->d_counts.p + 10, 16, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[trace] tail containment killers: %u (%u conditional) among the overlaps, %u (%u) among the internals, of %u items\n",
+                kc[0], kc[2], kc[1], kc[3], M);
+    }
+    if (left[1]) return fail(ctx, RALA_HIP_EDEVICE, "containment fixed point did not converge");
+    const uint32_t n_final = left[0];
     ctx->t_n_kept = totals[0];
     ctx->t_n_nodes = 2 * n_final;
     ctx->t_n_edges = 2 * totals[1];
@@ -1344,20 +1339,24 @@ int pass2(rala_hip_ctx* ctx, Comm* comm) {
     KillList kl;
     kl.count = ctx->d_kill_count.p; kl.ovl = ctx->d_kill[0].p; kl.target = ctx->d_kill[1].p; kl.keeper = ctx->d_kill[2].p;
     HIPCHECK(hipEventRecord(ctx->ev[4], s));
-    HIPCHECK(hipMemsetAsync(ctx->d_kill_count.p, 0, (kCountRing + 4) * 4, s));
     HIPCHECK(ctx->d_rec.ensure(n_reads));
     // compact per-read records (valid region + two flags): 4 bytes when no read is longer than 32767 bases
     const bool small_rec = ctx->max_read_len <= 32767u;
     HIPCHECK(ctx->d_crec.ensure((size_t)n_reads * compact_record_bytes(small_rec) + 16));
-    HIPCHECK(ctx->d_counts.ensure(16));
-    HIPCHECK(hipMemsetAsync(ctx->d_counts.p, 0, 16 * 4, s));
+    HIPCHECK(ctx->d_counts.ensure(32));
     // one buffer: sure[n_reads] (min over sure killers = upper bound), lo[n_reads] (lower bound),
     // one status word - so that a sharded run needs ONE all-reduce (min) per round; up[] apart
     HIPCHECK(ctx->d_death_sure.ensure(2 * (size_t)n_reads + 8));
     uint32_t* sure = ctx->d_death_sure.p;
     uint32_t* lo = sure + n_reads;
     const size_t dbytes = (size_t)n_reads * 4;
-    HIPCHECK(hipMemsetAsync(sure, 0xFF, 2 * dbytes + 4, s));
+    {
+        FillList fills;
+        fills.add(ctx->d_kill_count.p, 0, (kCountRing + 4) * 4);
+        fills.add(ctx->d_counts.p, 0, 16 * 4);
+        fills.add(sure, 0xFF, 2 * dbytes + 4);
+        HIPCHECK(fills.launch(s));
+    }
     // (tests: a failure that only this rank sees, between two collectives of a sharded run)
     if (ctx->debug_fail_construct) return fail(ctx, RALA_HIP_EDEVICE, "debug_fail_construct");
     launch_pack_reads(rs, n_reads, ctx->d_rec.p, ctx->d_crec.p, small_rec, sure, s);
@@ -1822,8 +1821,10 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
     // (whatever a failed call may have left on the aux stream ends before the counters are reset)
     HIPCHECK(hipEventRecord(ctx->ev[9], ctx->aux));
     HIPCHECK(hipStreamWaitEvent(s, ctx->ev[9], 0));
-    HIPCHECK(hipMemsetAsync(ctx->d_small.p, 0, 8 * 4, s));
     HIPCHECK(hipEventRecord(ctx->ev[0], s));
+    // the call's counters and what the bucketing wants cleared: one fill (fill_kernels.hip)
+    FillList fills;
+    fills.add(ctx->d_small.p, 0, 8 * 4);
     // duplicate removal only feeds the second pass (every resolvable overlap adds its bounds,
     // valid or not): it runs on a second stream beside the pile kernels (started when the
     // bucketing is done - beside the bucketing, both reading the same columns while the atomics
@@ -1855,17 +1856,18 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
         for (int k = 0; k < 2; ++k) HIPCHECK(ctx->d_bk_rec[k].ensure(partition_records_needed(n_reads, ctx->n_ovl)));
         ScanSpace sp;
         {
-            const int rc = scan_space(ctx, 1, n_reads, sp);
+            const int rc = scan_space(ctx, 1, n_reads, sp, &fills);
             if (rc != RALA_HIP_OK) return rc;
         }
         HIPCHECK(launch_bucket_partitioned(ctx->ovl, n_reads, ctx->d_bk_u32[0].p, ctx->d_bk_u32[1].p, ctx->d_bk_u32[2].p,
                                            ctx->d_bk_part.p, ctx->d_bk_group.p, ctx->d_bk_tiles.p, ctx->d_bk_rec[0].p,
-                                           ctx->d_bk_rec[1].p, ctx->d_ev_off.p, ctx->d_ev.p, ctx->n_compute_units, sp, s));
+                                           ctx->d_bk_rec[1].p, ctx->d_ev_off.p, ctx->d_ev.p, ctx->n_compute_units, sp, fills, s));
     }
     if (fixed) {
         HIPCHECK(ctx->d_ev_fixed.ensure((size_t)n_reads * slot + 8));
         HIPCHECK(ctx->d_cc_flags.ensure(8));
-        HIPCHECK(hipMemsetAsync(ctx->d_cursor.p, 0, (size_t)(n_reads + 1) * 4, s));
+        fills.add(ctx->d_cursor.p, 0, (size_t)(n_reads + 1) * 4);
+        HIPCHECK(fills.launch(s));
         // (the slot-overflow flag and the count of dead reads below live in d_small, zeroed above and
         // fetched in one copy with the other results)
         if (ctx->tuple_mode) {
@@ -1879,7 +1881,8 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
     }
     if (!fixed && !partitioned) {
     // count -> exclusive scan -> scatter
-    HIPCHECK(hipMemsetAsync(ctx->d_cursor.p, 0, (size_t)(n_reads + 1) * 4, s));
+    fills.add(ctx->d_cursor.p, 0, (size_t)(n_reads + 1) * 4);
+    HIPCHECK(fills.launch(s));
     if (ctx->tuple_mode) {
         launch_count_tuples(ctx->tuples, ctx->n_tuples, n_reads, ctx->d_cursor.p, s);
     } else {

@@ -12,6 +12,8 @@
 // pass; only the per-component medians are computed on the host (from the labels).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "device_utils.h"
 #include "geom.h"
 #include "kernels.h"
@@ -169,55 +171,307 @@ __device__ __forceinline__ uint32_t item_key(const TailList& L, uint32_t k, uint
     return st == 3 ? L.n * (1u + L.round[k]) + k : k;
 }
 
-// In-order containment removal without the chimera guard (graph.cpp:831-866) as the same
-// fixed point as in the second pass.  which = 0: overlaps + promoted, 1: internals.
-__global__ __launch_bounds__(kBlock) void tail_death_round_kernel(TailList L, const uint8_t* __restrict__ alive,
-                                                                  uint32_t which, const uint32_t* __restrict__ death_old,
-                                                                  uint32_t* death_new) {
-    const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
-    if (k >= L.n) return;
-    const uint8_t st = L.state[k];
-    if (which == 0 ? !(st == 1 || st == 3) : st != 2) return;
-    const uint8_t t = L.type[k];
-    if (t != kTypeA && t != kTypeB) return;
-    const uint32_t a = L.a[k], b = L.b[k];
-    if (!alive[a] || !alive[b]) return;
-    const uint32_t target = t == kTypeA ? b : a;
-    const uint32_t keeper = t == kTypeA ? a : b;
-    const uint32_t key = item_key(L, k, st);
-    if (death_old[keeper] > key) atomicMin(&death_new[target], key);
+// In-order containment removal without the chimera guard (graph.cpp:831-866), both scans (the overlaps
+// with the promoted internals, then the internals), without a look from the host.  It is the same fixed
+// point as in the second pass - an item that contains a read deletes it unless its own container was
+// deleted earlier in the list:
+//     X_r[t] = min { key : killer (key, t, keeper) with X_(r-1)[keeper] > key },   X_0 = "never",
+// until X_r = X_(r-1) - but by now only the containments that the re-trimming created are left (C3: 27 k +
+// 96 k killers among 1.26 M items), and nearly all of them have a keeper that no killer targets: what they
+// do does not depend on the round.  So:
+//   collect   the killers {key, target, keeper} of both classes (first class from the front of the list,
+//             second from its end) and a mark per targeted read;
+//   reduce    (per class) a killer whose keeper is no target goes into base[target] = min key, for good;
+//             the others - the conditional ones, a few thousand - are listed again;
+//   rounds    (per class) ONE workgroup iterates over the conditional killers, its entries in registers,
+//             workgroup barriers between the rounds, X_r in work[r % 4]: round r compares X_(r-1) with
+//             X_(r-2), proposes into X_r and resets the targets in the array of X_(r+1) (last read a round
+//             ago) to base[] - one barrier per round; then base[] = what settled;
+//   apply     drops the containments of both classes and the internals behind a death, kill the reads.
+// The second scan sees the first one's deaths as base0[] (a read is gone when alive[] = 0 or base0[] is
+// set): alive[] itself changes in the last kernel only.  (Before: per round a kernel over all items and one
+// over all reads, twelve rounds, a look from the host and two fills of 4 MB per scan.)
+// Values that other wavefronts write with atomics are read past the vector cache.
+struct TailKillers {
+    uint32_t *key, *target, *keeper;            // all killers: class 0 at [0, count[0]), class 1 at (n - 1 - count[1], n - 1]
+    uint32_t *c_key, *c_target, *c_keeper;      // the conditional ones of the class at hand, from the front
+    uint32_t* count;                            // [0], [1] killers per class; [2], [3] conditional killers per class
+    uint32_t* error;                            // set when a fixed point did not settle
+    uint8_t* mark[2];                           // per class: the read is the target of a killer
+    uint32_t* base[2];                          // per class: all ones at the start, the read's death at the end
+};
+
+__device__ __forceinline__ uint32_t ld_past_l1(const uint32_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_past_l1(uint32_t* p, uint32_t v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// after a scan: reads with a death index are gone; items of the scanned class are dropped
-// when they are containments (they either deleted a read or had lost one) or, for the
-// internals, when a read was already gone by the time the loop reached them
-__global__ __launch_bounds__(kBlock) void tail_apply_scan_kernel(TailList L, const uint8_t* __restrict__ alive,
-                                                                 uint32_t which, const uint32_t* __restrict__ death) {
+constexpr int kContainBlock = 1024;
+constexpr uint32_t kCollectPer = 4;             // items per thread of the collecting kernel
+
+// Append to a list from a whole workgroup with ONE add to the list's counter (adds to one word cost about
+// 10 ns apiece wherever they come from).  Call from all threads; slot = place in the list or kInf.
+// s_cnt / s_base: LDS words of the caller, s_cnt zeroed and synchronised before the first note().
+struct BlockAppend {
+    uint32_t* s_cnt;
+    uint32_t* s_base;
+    __device__ uint32_t note(bool mine) const {               // place inside the workgroup's batch
+        const uint32_t lane = threadIdx.x & 63u;
+        const uint64_t m = __ballot(mine);
+        uint32_t base = 0;
+        if (m) {
+            const uint32_t leader = (uint32_t)__ffsll((long long)m) - 1u;
+            if (lane == leader) base = atomicAdd(s_cnt, (uint32_t)__popcll(m));
+            base = (uint32_t)__shfl((int)base, (int)leader);
+        }
+        return mine ? base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)) : kInf;
+    }
+    __device__ void reserve(uint32_t* counter) const {        // all threads; afterwards *s_base is the batch's start
+        __syncthreads();
+        if (threadIdx.x == 0) *s_base = *s_cnt ? atomicAdd(counter, *s_cnt) : 0u;
+        __syncthreads();
+    }
+};
+
+__global__ __launch_bounds__(kContainBlock) void tail_contain_collect_kernel(TailList L, const uint8_t* __restrict__ alive, TailKillers K) {
+    __shared__ uint32_t s_cnt[2], s_base[2];
+    if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const BlockAppend app[2] = {{&s_cnt[0], &s_base[0]}, {&s_cnt[1], &s_base[1]}};
+    uint32_t key[kCollectPer], target[kCollectPer], keeper[kCollectPer], slot[kCollectPer], cls[kCollectPer];
+#pragma unroll
+    for (uint32_t u = 0; u < kCollectPer; ++u) {
+        const uint32_t k = (blockIdx.x * kCollectPer + u) * kContainBlock + threadIdx.x;
+        bool killer = false;
+        cls[u] = 0; key[u] = 0; target[u] = 0; keeper[u] = 0;
+        if (k < L.n) {
+            const uint8_t st = L.state[k], t = L.type[k];
+            if (st != 0 && (t == kTypeA || t == kTypeB)) {
+                const uint32_t a = L.a[k], b = L.b[k];
+                if (alive[a] && alive[b]) {
+                    killer = true;
+                    cls[u] = st == 2 ? 1u : 0u;
+                    target[u] = t == kTypeA ? b : a;
+                    keeper[u] = t == kTypeA ? a : b;
+                    key[u] = cls[u] ? k : item_key(L, k, st);
+                }
+            }
+        }
+        const uint32_t s0 = app[0].note(killer && cls[u] == 0), s1 = app[1].note(killer && cls[u] == 1);
+        slot[u] = killer ? (cls[u] ? s1 : s0) : kInf;
+    }
+    app[0].reserve(&K.count[0]);
+    app[1].reserve(&K.count[1]);
+#pragma unroll
+    for (uint32_t u = 0; u < kCollectPer; ++u) {
+        if (slot[u] == kInf) continue;
+        const uint32_t at = cls[u] ? L.n - 1u - (s_base[1] + slot[u]) : s_base[0] + slot[u];
+        K.key[at] = key[u]; K.target[at] = target[u]; K.keeper[at] = keeper[u];
+        K.mark[cls[u]][target[u]] = 1;
+    }
+}
+
+// a read is out of the second scan when it was gone before the scans or the first scan deleted it
+__device__ __forceinline__ bool gone_before_second_scan(const uint8_t* alive, const uint32_t* base0, uint32_t r) {
+    return !alive[r] || base0[r] != kInf;
+}
+
+template <int kClass>
+__global__ __launch_bounds__(kBlock) void tail_contain_reduce_kernel(TailKillers K, uint32_t n_items, const uint8_t* __restrict__ alive) {
+    __shared__ uint32_t s_cnt, s_base;
+    const BlockAppend app = {&s_cnt, &s_base};
+    const uint32_t n = K.count[kClass];
+    uint32_t* base = K.base[kClass];
+    for (uint32_t i0 = blockIdx.x * kBlock; i0 < n; i0 += gridDim.x * kBlock) {
+        if (threadIdx.x == 0) s_cnt = 0;
+        __syncthreads();
+        const uint32_t i = i0 + threadIdx.x;
+        bool conditional = false;
+        uint32_t key = 0, target = 0, keeper = 0;
+        if (i < n) {
+            const uint32_t at = kClass ? n_items - 1u - i : i;
+            key = K.key[at]; target = K.target[at]; keeper = K.keeper[at];
+            const bool ok = kClass == 0 || !(gone_before_second_scan(alive, K.base[0], target) ||
+                                             gone_before_second_scan(alive, K.base[0], keeper));
+            if (ok) {
+                if (K.mark[kClass][keeper]) conditional = true;
+                else if (ld_past_l1(base + target) > key) atomicMin(base + target, key);
+            }
+        }
+        const uint32_t slot = app.note(conditional);
+        app.reserve(&K.count[2 + kClass]);
+        if (conditional) {
+            const uint32_t w = s_base + slot;
+            K.c_key[w] = key; K.c_target[w] = target; K.c_keeper[w] = keeper;
+        }
+        __syncthreads();
+    }
+}
+
+// Up to kLdsEntries conditional killers: X lives in LDS.  A target's slot is the smallest index among the
+// entries that target it (found through one of the work arrays: three trips to memory before the rounds,
+// none in them); a keeper that no conditional killer targets is a constant, base[keeper].  Two arrays and
+// three workgroup barriers per round: reset X_r to base, propose, compare with X_(r-1).
+// (With X in global memory - values other wavefronts write must be read past the vector cache, which on
+// this device means from the memory side - a round took 20 us; 2 500 conditional killers at C3, 7 rounds.)
+constexpr uint32_t kLdsEntries = 7168;
+
+template <int kClass>
+__global__ __launch_bounds__(kContainBlock) void tail_contain_rounds_kernel(TailKillers K, uint32_t* w0, uint32_t* w1, uint32_t* w2,
+                                                                            uint32_t* w3) {
+    const uint32_t n = K.count[2 + kClass];
+    if (n == 0) return;
+    uint32_t* base = K.base[kClass];
+    const uint32_t tid = threadIdx.x;
+    if (n <= kLdsEntries) {
+        constexpr uint32_t kPer = kLdsEntries / kContainBlock;      // 7 entries per thread, in registers
+        __shared__ uint32_t x[2][kLdsEntries];
+        uint32_t ek[kPer], et[kPer], ep[kPer], eb[kPer], st[kPer], sp[kPer], bp[kPer];
+#pragma unroll
+        for (uint32_t u = 0; u < kPer; ++u) {
+            const uint32_t i = tid + u * kContainBlock;
+            const uint32_t at = i < n ? i : 0u;                     // (an absent entry: a copy of entry 0 that never proposes)
+            ek[u] = i < n ? K.c_key[at] : kInf;
+            et[u] = K.c_target[at]; ep[u] = K.c_keeper[at];
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < kPer; ++u) { eb[u] = base[et[u]]; bp[u] = base[ep[u]]; }
+        uint32_t* map = w0;
+#pragma unroll
+        for (uint32_t u = 0; u < kPer; ++u) { st_past_l1(map + et[u], kInf); st_past_l1(map + ep[u], kInf); }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t u = 0; u < kPer; ++u) if (ek[u] != kInf) atomicMin(map + et[u], tid + u * kContainBlock);
+        __syncthreads();
+#pragma unroll
+        for (uint32_t u = 0; u < kPer; ++u) { st[u] = ld_past_l1(map + et[u]); sp[u] = ld_past_l1(map + ep[u]); }
+#pragma unroll
+        for (uint32_t u = 0; u < kPer; ++u) x[0][st[u]] = eb[u];
+        __syncthreads();
+        uint32_t cur = 1;
+        for (uint32_t r = 1;; ++r, cur ^= 1u) {
+            uint32_t* xc = x[cur];
+            const uint32_t* xp = x[cur ^ 1u];
+#pragma unroll
+            for (uint32_t u = 0; u < kPer; ++u) xc[st[u]] = eb[u];
+            __syncthreads();
+#pragma unroll
+            for (uint32_t u = 0; u < kPer; ++u) {
+                const uint32_t vk = sp[u] == kInf ? bp[u] : xp[sp[u]];
+                if (vk > ek[u] && ek[u] != kInf) atomicMin(&xc[st[u]], ek[u]);
+            }
+            __syncthreads();
+            bool moved = false;
+#pragma unroll
+            for (uint32_t u = 0; u < kPer; ++u) moved = moved || xc[st[u]] != xp[st[u]];
+            if (!__syncthreads_or(moved ? 1 : 0)) break;             // X_r = X_(r-1): settled
+            if (r > n + 8u) {                                         // (every round settles at least one read)
+                if (tid == 0) *K.error = 1u;
+                return;
+            }
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < kPer; ++u) base[et[u]] = x[cur][st[u]];
+        return;
+    }
+    // more conditional killers than the LDS holds: X in work[r % 4]: round r compares X_(r-1) with X_(r-2), proposes
+    // into X_r and resets the targets in the array of X_(r+1) (last read a round ago) - one barrier per round
+    constexpr uint32_t kPer = 8;
+    uint32_t* const work[4] = {w0, w1, w2, w3};
+    uint32_t ek[kPer], et[kPer], ep[kPer], eb[kPer];
+    auto load = [&](uint32_t i0) {                // entries i0 + u * block; eb = base[target]; absent ones: copies of entry 0, key "never"
+#pragma unroll
+        for (uint32_t u = 0; u < kPer; ++u) {
+            const uint32_t i = i0 + u * kContainBlock;
+            const uint32_t at = i < n ? i : 0u;
+            ek[u] = i < n ? K.c_key[at] : kInf;
+            et[u] = K.c_target[at]; ep[u] = K.c_keeper[at];
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < kPer; ++u) eb[u] = base[et[u]];
+    };
+    for (uint32_t i0 = tid; i0 < n; i0 += kPer * kContainBlock) {
+        load(i0);
+#pragma unroll
+        for (uint32_t u = 0; u < kPer; ++u) {
+            const uint32_t bp = base[ep[u]];
+            for (int w = 0; w < 4; ++w) { st_past_l1(work[w] + et[u], eb[u]); st_past_l1(work[w] + ep[u], bp); }
+        }
+    }
+    __syncthreads();
+    uint32_t r = 1;
+    for (;; ++r) {
+        const uint32_t* prev2 = work[(r + 2) & 3];      // X_(r-2)
+        const uint32_t* prev = work[(r + 3) & 3];       // X_(r-1)
+        uint32_t* cur = work[r & 3];                    // X_r
+        uint32_t* next = work[(r + 1) & 3];             // X_(r+1): reset here
+        bool moved = false;
+        for (uint32_t i0 = tid; i0 < n; i0 += kPer * kContainBlock) {
+            load(i0);
+            uint32_t vk[kPer], v1[kPer], v2[kPer];
+#pragma unroll
+            for (uint32_t u = 0; u < kPer; ++u) { vk[u] = ld_past_l1(prev + ep[u]); v1[u] = ld_past_l1(prev + et[u]); v2[u] = ld_past_l1(prev2 + et[u]); }
+#pragma unroll
+            for (uint32_t u = 0; u < kPer; ++u) {
+                moved = moved || (r >= 2 && v1[u] != v2[u]);
+                if (vk[u] > ek[u] && ek[u] != kInf) atomicMin(cur + et[u], ek[u]);
+                st_past_l1(next + et[u], eb[u]);
+            }
+        }
+        if (!__syncthreads_or((r < 2 || moved) ? 1 : 0)) break;      // X_(r-1) = X_(r-2): settled (and X_r is the same again)
+        if (r > n + 8u) {
+            if (tid == 0) *K.error = 1u;
+            return;
+        }
+    }
+    const uint32_t* settled = work[(r + 3) & 3];
+    for (uint32_t i0 = tid; i0 < n; i0 += kPer * kContainBlock) {
+        load(i0);
+#pragma unroll
+        for (uint32_t u = 0; u < kPer; ++u) base[et[u]] = ld_past_l1(settled + et[u]);
+    }
+}
+
+// after the scans: the containments of both classes are dropped (they either deleted a read or had lost
+// one), and the internals that the loop reached when one of their reads was already gone
+__global__ __launch_bounds__(kBlock) void tail_contain_apply_kernel(TailList L, const uint8_t* __restrict__ alive,
+                                                                    const uint32_t* __restrict__ base0,
+                                                                    const uint32_t* __restrict__ base1) {
     const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
     if (k >= L.n) return;
     const uint8_t st = L.state[k];
-    if (which == 0 ? !(st == 1 || st == 3) : st != 2) return;
+    if (st == 0) return;
     const uint8_t t = L.type[k];
-    const uint32_t a = L.a[k], b = L.b[k];
     bool drop = t == kTypeA || t == kTypeB;
-    if (which == 1) {
-        const uint32_t key = k;
-        drop = drop || !alive[a] || !alive[b] || death[a] < key || death[b] < key;
+    if (st == 2 && !drop) {
+        const uint32_t a = L.a[k], b = L.b[k];
+        drop = gone_before_second_scan(alive, base0, a) || gone_before_second_scan(alive, base0, b) || base1[a] < k || base1[b] < k;
     }
     if (drop) L.state[k] = 0;
 }
 
-__global__ __launch_bounds__(kBlock) void kill_reads_kernel(const uint32_t* __restrict__ death, uint8_t* alive, uint32_t n) {
-    const uint32_t r = blockIdx.x * kBlock + threadIdx.x;
-    if (r < n && death[r] != kInf) alive[r] = 0;
+// ... and then the reads the scans deleted
+__global__ __launch_bounds__(kBlock) void tail_contain_kill_kernel(TailKillers K, uint32_t n_items, uint8_t* alive) {
+    const uint32_t n0 = K.count[0], n1 = K.count[1];
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n0 + n1; i += gridDim.x * kBlock) {
+        const uint32_t target = K.target[i < n0 ? i : n_items - 1u - (i - n0)];
+        if (K.base[0][target] != kInf || K.base[1][target] != kInf) alive[target] = 0;
+    }
 }
 
 // start of the tail: list states, nothing dirty, the pit counts the pile kernel wrote (one launch for
 // what used to be a kernel, a fill and a copy)
 __global__ __launch_bounds__(kBlock) void tail_init_kernel(uint8_t* state, uint8_t* round, uint32_t n0, uint32_t m,
                                                            uint8_t* dirty, uint8_t* n_pits0, const uint8_t* n_pits,
-                                                           uint32_t n_reads) {
+                                                           uint32_t n_reads, uint32_t* base2, uint8_t* mark2, uint32_t* zero6) {
     const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
+    if (k < 6) zero6[k] = 0;
+    if (k < n_reads) {
+        base2[k] = kInf; base2[n_reads + k] = kInf;
+        mark2[k] = 0; mark2[n_reads + k] = 0;
+    }
     if (k < m) {
         state[k] = k < n0 ? 1 : 2;
         round[k] = 0;
@@ -341,22 +595,31 @@ void launch_cc_edges(const TailList& L, const uint32_t* rank, uint32_t* edges, u
 void launch_refresh_types(const TailList& L, const TailReads& R, hipStream_t s) {
     if (L.n) hipLaunchKernelGGL(refresh_types_kernel, grid_for(L.n), dim3(kBlock), 0, s, L, R);
 }
-void launch_tail_death_round(const TailList& L, const uint8_t* alive, uint32_t which, const uint32_t* death_old,
-                             uint32_t* death_new, hipStream_t s) {
-    if (L.n) {
-        hipLaunchKernelGGL(tail_death_round_kernel, grid_for(L.n), dim3(kBlock), 0, s, L, alive, which, death_old,
-                           death_new);
-    }
+void launch_tail_contain(const TailList& L, uint8_t* alive, uint32_t* const lists[6], uint32_t* zeroed5, uint32_t* const work[4],
+                         uint32_t* base2, uint8_t* mark2, uint32_t n_reads, hipStream_t s) {
+    if (!L.n) return;
+    TailKillers K;
+    K.key = lists[0]; K.target = lists[1]; K.keeper = lists[2];
+    K.c_key = lists[3]; K.c_target = lists[4]; K.c_keeper = lists[5];
+    K.error = zeroed5; K.count = zeroed5 + 1;
+    K.mark[0] = mark2; K.mark[1] = mark2 + n_reads;
+    K.base[0] = base2; K.base[1] = base2 + n_reads;
+    const uint32_t per_block = kCollectPer * kContainBlock;
+    hipLaunchKernelGGL(tail_contain_collect_kernel, dim3((L.n + per_block - 1) / per_block), dim3(kContainBlock), 0, s, L,
+                       (const uint8_t*)alive, K);
+    hipLaunchKernelGGL(tail_contain_reduce_kernel<0>, dim3(128), dim3(kBlock), 0, s, K, L.n, (const uint8_t*)alive);
+    hipLaunchKernelGGL(tail_contain_rounds_kernel<0>, dim3(1), dim3(kContainBlock), 0, s, K, work[0], work[1], work[2], work[3]);
+    hipLaunchKernelGGL(tail_contain_reduce_kernel<1>, dim3(128), dim3(kBlock), 0, s, K, L.n, (const uint8_t*)alive);
+    hipLaunchKernelGGL(tail_contain_rounds_kernel<1>, dim3(1), dim3(kContainBlock), 0, s, K, work[0], work[1], work[2], work[3]);
+    hipLaunchKernelGGL(tail_contain_apply_kernel, grid_for(L.n), dim3(kBlock), 0, s, L, (const uint8_t*)alive,
+                       (const uint32_t*)K.base[0], (const uint32_t*)K.base[1]);
+    hipLaunchKernelGGL(tail_contain_kill_kernel, dim3(128), dim3(kBlock), 0, s, K, L.n, alive);
 }
-void launch_tail_apply_scan(const TailList& L, const uint8_t* alive, uint32_t which, const uint32_t* death, hipStream_t s) {
-    if (L.n) hipLaunchKernelGGL(tail_apply_scan_kernel, grid_for(L.n), dim3(kBlock), 0, s, L, alive, which, death);
-}
-void launch_kill_reads(const uint32_t* death, uint8_t* alive, uint32_t n, hipStream_t s) {
-    if (n) hipLaunchKernelGGL(kill_reads_kernel, grid_for(n), dim3(kBlock), 0, s, death, alive, n);
-}
-void launch_tail_init(const TailList& L, uint32_t n0, const TailReads& R, uint8_t* n_pits0, uint32_t n_reads, hipStream_t s) {
-    const uint32_t n = L.n > n_reads ? L.n : n_reads;
-    if (n) hipLaunchKernelGGL(tail_init_kernel, grid_for(n), dim3(kBlock), 0, s, L.state, L.round, n0, L.n, R.dirty, n_pits0, R.n_pits, n_reads);
+void launch_tail_init(const TailList& L, uint32_t n0, const TailReads& R, uint8_t* n_pits0, uint32_t n_reads, uint32_t* base2,
+                      uint8_t* mark2, uint32_t* zero6, hipStream_t s) {
+    const uint32_t n = std::max<uint32_t>(std::max<uint32_t>(L.n, n_reads), 6u);
+    hipLaunchKernelGGL(tail_init_kernel, grid_for(n), dim3(kBlock), 0, s, L.state, L.round, n0, L.n, R.dirty, n_pits0, R.n_pits, n_reads,
+                       base2, mark2, zero6);
 }
 bool launch_rank_pass(const uint8_t* alive, uint32_t* rank, uint32_t* alive_reads, uint32_t n_reads, ScanSpace& space, hipStream_t s) {
     return launch_scan_pass(n_reads, RankPass{alive, rank, alive_reads}, space, s);
