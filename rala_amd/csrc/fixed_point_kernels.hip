@@ -1,0 +1,206 @@
+// The end of an in-order containment removal (graph.cpp:464-483, :831-866) written as a fixed point.
+//
+// Given: base[r] - the death of read r as far as it is decided for good (all ones: "never") - and a list of
+// CONDITIONAL killers {key, target, keeper}: killer i deletes its target at position key_i unless its
+// keeper was deleted before that position.  Wanted: the one X with
+//     X[t] = min( base[t], min { key_i : target_i = t, X[keeper_i] > key_i } ).
+// The map is antitone, so X_r = F(X_(r-1)) from X_0 = base gives upper and lower bounds in turn and settles
+// (by induction over the keys: what happens below a position is exact after as many rounds as the longest
+// chain of killers below it).  Both callers - the second overlap pass after its first two rounds, the tail's
+// two scans - arrive here with a few thousand conditional killers and need five to seven rounds: ONE
+// workgroup does them, with workgroup barriers between the rounds, instead of four launches and (every few
+// rounds) a look from the host per round.
+//
+// Up to kLdsEntries killers: X lives in LDS.  A target's slot is the smallest index among the entries that
+// target it, found through map[] (one word per read, all ones between calls) by two small kernels in front of
+// the rounds: fixed_point_assign_kernel (atomic minimum of the entry index per target) and
+// fixed_point_prepare_kernel, which gathers for every entry what the rounds need of it - key, the slots of
+// target and keeper, base[] of both - into packed arrays.  (The one workgroup doing those gathers itself
+// took 130 us for 11 k entries: values written with atomics are read from the memory side, and one compute
+// unit has only so many requests in flight.)  A keeper that no listed killer targets is a constant,
+// base[keeper].  Longer lists: X in four work arrays in global memory, 20 us per round instead of 2.
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+
+namespace rala_hip {
+
+namespace {
+
+constexpr uint32_t kInf = 0xFFFFFFFFu;
+constexpr int kFinishBlock = 1024;
+constexpr uint32_t kFinishPer = 12;                                  // entries a thread keeps in registers
+constexpr uint32_t kLdsEntries = kFinishPer * kFinishBlock;          // 12 288: three arrays of that many words = 144 KB
+
+__device__ __forceinline__ uint32_t ld_past_l1(const uint32_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_past_l1(uint32_t* p, uint32_t v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+constexpr int kPrepBlock = 256;
+constexpr uint32_t kPrepGroups = 48;
+
+__global__ __launch_bounds__(kPrepBlock) void fixed_point_assign_kernel(FixedPointList list, uint32_t* map) {
+    const uint32_t n = *list.count;
+    if (n > kLdsEntries) return;
+    for (uint32_t i = blockIdx.x * kPrepBlock + threadIdx.x; i < n; i += gridDim.x * kPrepBlock) atomicMin(map + list.target[i], i);
+}
+
+// pack: six arrays of kLdsEntries words: key, slot of the target, slot of the keeper (all ones: none), base[keeper],
+// base[target], target
+__global__ __launch_bounds__(kPrepBlock) void fixed_point_prepare_kernel(FixedPointList list, const uint32_t* __restrict__ map,
+                                                                         const uint32_t* __restrict__ base, uint32_t* __restrict__ pack) {
+    const uint32_t n = *list.count;
+    if (n > kLdsEntries) return;
+    for (uint32_t i = blockIdx.x * kPrepBlock + threadIdx.x; i < n; i += gridDim.x * kPrepBlock) {
+        const uint32_t t = list.target[i], kp = list.keeper[i];
+        pack[i] = list.key[i];
+        pack[kLdsEntries + i] = map[t];
+        pack[2 * kLdsEntries + i] = map[kp];
+        pack[3 * kLdsEntries + i] = base[kp];
+        pack[4 * kLdsEntries + i] = base[t];
+        pack[5 * kLdsEntries + i] = t;
+    }
+}
+
+__global__ __launch_bounds__(kFinishBlock) void fixed_point_finish_kernel(FixedPointList list, uint32_t* base, uint32_t* map,
+                                                                          const uint32_t* __restrict__ pack, uint32_t* w0, uint32_t* w1,
+                                                                          uint32_t* w2, uint32_t* w3, uint32_t* error,
+                                                                          uint32_t* rounds_out) {
+    extern __shared__ uint32_t lds[];
+    const uint32_t n = *list.count;
+    const uint32_t tid = threadIdx.x;
+    if (n == 0) {
+        if (rounds_out && tid == 0) *rounds_out = 0;
+        return;
+    }
+    uint32_t r = 1;
+    if (n <= kLdsEntries) {
+        constexpr uint32_t kPer = kFinishPer;
+        uint32_t* xb = lds;                         // base per slot
+        uint32_t* x0 = lds + kLdsEntries;           // X of the even rounds; the odd ones' behind it
+        for (uint32_t k = tid; k < n; k += kFinishBlock) { xb[k] = kInf; x0[k] = kInf; x0[kLdsEntries + k] = kInf; }
+        __syncthreads();
+        uint32_t ek[kPer], st[kPer], sp[kPer], bp[kPer];
+#pragma unroll
+        for (uint32_t u = 0; u < kPer; ++u) {
+            const uint32_t i = tid + u * kFinishBlock;
+            const uint32_t at = i < n ? i : 0u;                     // (an absent entry: a copy of entry 0 that never proposes)
+            ek[u] = i < n ? pack[at] : kInf;
+            st[u] = pack[kLdsEntries + at]; sp[u] = pack[2 * kLdsEntries + at]; bp[u] = pack[3 * kLdsEntries + at];
+            const uint32_t bt = pack[4 * kLdsEntries + at];
+            xb[st[u]] = bt; x0[st[u]] = bt;
+        }
+        __syncthreads();
+        uint32_t cur = 1;
+        for (;; ++r, cur ^= 1u) {
+            uint32_t* xc = x0 + cur * kLdsEntries;
+            const uint32_t* xp = x0 + (cur ^ 1u) * kLdsEntries;
+            for (uint32_t k = tid; k < n; k += kFinishBlock) xc[k] = xb[k];
+            __syncthreads();
+#pragma unroll
+            for (uint32_t u = 0; u < kPer; ++u) {
+                const uint32_t vk = sp[u] == kInf ? bp[u] : xp[sp[u]];
+                if (vk > ek[u] && ek[u] != kInf) atomicMin(&xc[st[u]], ek[u]);
+            }
+            __syncthreads();
+            bool moved = false;
+            for (uint32_t k = tid; k < n; k += kFinishBlock) moved = moved || xc[k] != xp[k];
+            if (!__syncthreads_or(moved ? 1 : 0)) break;             // X_r = X_(r-1): settled
+            if (r > n + 8u) {                                         // (every round settles at least one read)
+                if (tid == 0) *error = 1u;
+                break;
+            }
+        }
+        // the deaths; map[] all ones again
+        for (uint32_t i = tid; i < n; i += kFinishBlock) {
+            const uint32_t t = pack[5 * kLdsEntries + i];
+            base[t] = x0[cur * kLdsEntries + pack[kLdsEntries + i]];
+            map[t] = kInf;
+        }
+        if (rounds_out && tid == 0) *rounds_out = r;
+        return;
+    }
+    // more killers than the LDS holds: X_r in work[r % 4]: round r compares X_(r-1) with X_(r-2), proposes into X_r
+    // and resets the targets in the array of X_(r+1) (last read a round ago) - one barrier per round
+    constexpr uint32_t kPer = 8;
+    uint32_t* const work[4] = {w0, w1, w2, w3};
+    uint32_t ek[kPer], et[kPer], ep[kPer], eb[kPer];
+    auto load = [&](uint32_t i0) {                // entries i0 + u * block; absent ones: copies of entry 0, key "never"
+#pragma unroll
+        for (uint32_t u = 0; u < kPer; ++u) {
+            const uint32_t i = i0 + u * kFinishBlock;
+            const uint32_t at = i < n ? i : 0u;
+            ek[u] = i < n ? list.key[at] : kInf;
+            et[u] = list.target[at]; ep[u] = list.keeper[at];
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < kPer; ++u) eb[u] = base[et[u]];
+    };
+    for (uint32_t i0 = tid; i0 < n; i0 += kPer * kFinishBlock) {
+        load(i0);
+#pragma unroll
+        for (uint32_t u = 0; u < kPer; ++u) {
+            const uint32_t bp = base[ep[u]];
+            for (int w = 0; w < 4; ++w) { st_past_l1(work[w] + et[u], eb[u]); st_past_l1(work[w] + ep[u], bp); }
+        }
+    }
+    __syncthreads();
+    for (;; ++r) {
+        const uint32_t* prev2 = work[(r + 2) & 3];      // X_(r-2)
+        const uint32_t* prev = work[(r + 3) & 3];       // X_(r-1)
+        uint32_t* cur = work[r & 3];                    // X_r
+        uint32_t* next = work[(r + 1) & 3];             // X_(r+1): reset here
+        bool moved = false;
+        for (uint32_t i0 = tid; i0 < n; i0 += kPer * kFinishBlock) {
+            load(i0);
+            uint32_t vk[kPer], v1[kPer], v2[kPer];
+#pragma unroll
+            for (uint32_t u = 0; u < kPer; ++u) { vk[u] = ld_past_l1(prev + ep[u]); v1[u] = ld_past_l1(prev + et[u]); v2[u] = ld_past_l1(prev2 + et[u]); }
+#pragma unroll
+            for (uint32_t u = 0; u < kPer; ++u) {
+                moved = moved || (r >= 2 && v1[u] != v2[u]);
+                if (vk[u] > ek[u] && ek[u] != kInf) atomicMin(cur + et[u], ek[u]);
+                st_past_l1(next + et[u], eb[u]);
+            }
+        }
+        if (!__syncthreads_or((r < 2 || moved) ? 1 : 0)) break;      // X_(r-1) = X_(r-2): settled (and X_r is the same again)
+        if (r > n + 8u) {
+            if (tid == 0) *error = 1u;
+            return;
+        }
+    }
+    const uint32_t* settled = work[(r + 3) & 3];
+    for (uint32_t i0 = tid; i0 < n; i0 += kPer * kFinishBlock) {
+        load(i0);
+#pragma unroll
+        for (uint32_t u = 0; u < kPer; ++u) base[et[u]] = ld_past_l1(settled + et[u]);
+    }
+    if (rounds_out && tid == 0) *rounds_out = r - 1;
+}
+
+}  // namespace
+
+size_t fixed_point_pack_words() { return 6 * (size_t)kLdsEntries; }
+
+hipError_t launch_fixed_point_finish(const FixedPointList& list, uint32_t* base, uint32_t* map, uint32_t* pack, uint32_t* const work[4],
+                                     uint32_t* error, uint32_t* rounds_out, hipStream_t s) {
+    constexpr size_t lds_bytes = 3 * (size_t)kLdsEntries * 4;
+    static bool asked = false;
+    if (!asked) {
+        const hipError_t e = hipFuncSetAttribute((const void*)fixed_point_finish_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 (int)lds_bytes);
+        if (e != hipSuccess) return e;
+        asked = true;
+    }
+    hipLaunchKernelGGL(fixed_point_assign_kernel, dim3(kPrepGroups), dim3(kPrepBlock), 0, s, list, map);
+    hipLaunchKernelGGL(fixed_point_prepare_kernel, dim3(kPrepGroups), dim3(kPrepBlock), 0, s, list, (const uint32_t*)map,
+                       (const uint32_t*)base, pack);
+    hipLaunchKernelGGL(fixed_point_finish_kernel, dim3(1), dim3(kFinishBlock), lds_bytes, s, list, base, map, (const uint32_t*)pack,
+                       work[0], work[1], work[2], work[3], error, rounds_out);
+    return hipGetLastError();
+}
+
+}  // namespace rala_hip

@@ -1129,7 +1129,9 @@ int gpu_tail_part_a(rala_hip_ctx* ctx) {
     HIPCHECK(ctx->d_t_fin.ensure(2 * (size_t)n_reads));
     HIPCHECK(ctx->d_t_mark.ensure(2 * (size_t)n_reads));
     for (int k = 0; k < 3; ++k) { HIPCHECK(ctx->d_kill[k].ensure((size_t)M + 1)); HIPCHECK(ctx->d_kill2[k].ensure((size_t)M + 1)); }
-    launch_tail_init(L, ctx->t_n0, R, ctx->d_n_pits0.p, n_reads, ctx->d_t_fin.p, ctx->d_t_mark.p, ctx->d_counts.p + 9, s);
+    HIPCHECK(ctx->d_fp_map.ensure(n_reads));
+    HIPCHECK(ctx->d_fp_pack.ensure(fixed_point_pack_words()));
+    launch_tail_init(L, ctx->t_n0, R, ctx->d_n_pits0.p, n_reads, ctx->d_t_fin.p, ctx->d_t_mark.p, ctx->d_fp_map.p, ctx->d_counts.p + 9, s);
     // ranks of the reads that survived the second pass (the component graph lives on them)
     if (!launch_rank_pass(ctx->d_alive.p, ctx->d_rank.p, ctx->d_alive_reads.p, n_reads, sp, s)) return fail(ctx, RALA_HIP_EDEVICE, "scan space");
     mark("tail: ranks", n_alive);
@@ -1179,7 +1181,8 @@ int gpu_tail_part_a(rala_hip_ctx* ctx) {
         uint32_t* const work[4] = {ctx->d_t_death[0].p, ctx->d_t_death[1].p, ctx->d_t_work[0].p, ctx->d_t_work[1].p};
         uint32_t* const lists[6] = {ctx->d_kill[0].p, ctx->d_kill[1].p, ctx->d_kill[2].p, ctx->d_kill2[0].p, ctx->d_kill2[1].p,
                                     ctx->d_kill2[2].p};
-        launch_tail_contain(L, ctx->d_alive.p, lists, ctx->d_counts.p + 9, work, ctx->d_t_fin.p, ctx->d_t_mark.p, n_reads, s);
+        HIPCHECK(launch_tail_contain(L, ctx->d_alive.p, lists, ctx->d_counts.p + 9, work, ctx->d_t_fin.p, ctx->d_t_mark.p, ctx->d_fp_map.p,
+                                     ctx->d_fp_pack.p, n_reads, s));
     }
     mark("tail: containment scans", M);
     return RALA_HIP_OK;
@@ -1347,6 +1350,8 @@ int pass2(rala_hip_ctx* ctx, Comm* comm) {
     // one buffer: sure[n_reads] (min over sure killers = upper bound), lo[n_reads] (lower bound),
     // one status word - so that a sharded run needs ONE all-reduce (min) per round; up[] apart
     HIPCHECK(ctx->d_death_sure.ensure(2 * (size_t)n_reads + 8));
+    HIPCHECK(ctx->d_fp_map.ensure(n_reads));
+    HIPCHECK(ctx->d_fp_pack.ensure(fixed_point_pack_words()));
     uint32_t* sure = ctx->d_death_sure.p;
     uint32_t* lo = sure + n_reads;
     const size_t dbytes = (size_t)n_reads * 4;
@@ -1355,6 +1360,7 @@ int pass2(rala_hip_ctx* ctx, Comm* comm) {
         fills.add(ctx->d_kill_count.p, 0, (kCountRing + 4) * 4);
         fills.add(ctx->d_counts.p, 0, 16 * 4);
         fills.add(sure, 0xFF, 2 * dbytes + 4);
+        fills.add(ctx->d_fp_map.p, 0xFF, dbytes);               // (launch_fixed_point_finish leaves it that way; here for good measure)
         HIPCHECK(fills.launch(s));
     }
     // (tests: a failure that only this rank sees, between two collectives of a sharded run)
@@ -1386,7 +1392,13 @@ int pass2(rala_hip_ctx* ctx, Comm* comm) {
     constexpr uint32_t kNotSeen = 0xFFFFFFFFu;
     HIPCHECK(ctx->d_round_log.ensure(kLogged));
     std::vector<uint32_t> list_size;                             // after every round; kNotSeen = in the log
-    uint32_t unseen = 0, n_logged = 0;
+    // (one GPU: the first round is not looked at - nobody is done after one round; after the second the host
+    // looks, and a list that is short by then - C3: 1.09 M undecided after the first round, 11 k after the
+    // second - is finished by ONE workgroup with the bounds in LDS (fixed_point_kernels.hip): no more launches
+    // per round, no more looks.  Before: six more rounds of four launches, two more looks.)
+    uint32_t unseen = gathered && ctx->use_round_batches ? 1u : 0u, n_logged = 0;
+    constexpr uint32_t kFinishAtMost = 1u << 16;                 // (beyond the LDS' 12 288 the finishing kernel is slow, not wrong)
+    bool finished_on_device = false;
     uint64_t at_most = ~0ull;                                    // what the host knows of the current list's length
     for (;;) {
         if (next_count < kCountRing) {
@@ -1426,6 +1438,17 @@ int pass2(rala_hip_ctx* ctx, Comm* comm) {
         if (undecided == 0) break;
         if (list_size.size() > 100000) return fail(ctx, RALA_HIP_EDEVICE, "containment fixed point did not converge");
         if (!gathered) HIPCHECK(hipMemcpyAsync(up, sure, dbytes, hipMemcpyDeviceToDevice, s));
+        if (gathered && ctx->use_round_batches && undecided <= kFinishAtMost) {
+            // what is still undecided against sure[] as the deaths decided for good; up[], lo[] are free now
+            HIPCHECK(ctx->d_death[0].ensure(n_reads));
+            HIPCHECK(ctx->d_t_work[0].ensure(n_reads));
+            uint32_t* const work[4] = {up, lo, ctx->d_death[0].p, ctx->d_t_work[0].p};
+            const FixedPointList rest = {klist[cur].ovl, klist[cur].target, klist[cur].keeper, klist[cur].count};
+            HIPCHECK(launch_fixed_point_finish(rest, sure, ctx->d_fp_map.p, ctx->d_fp_pack.p, work, ctx->d_counts.p + 1,
+                                               ctx->d_counts.p + 2, s));
+            finished_on_device = true;
+            break;
+        }
         if (gathered) {
             at_most = undecided;                                // the lists only shrink from here
             launch_death_tighten(sure, up, lo, n_reads, s);
@@ -1487,11 +1510,14 @@ int pass2(rala_hip_ctx* ctx, Comm* comm) {
     }
     uint32_t round_log[64];
     if (n_logged) HIPCHECK(d2h_small(ctx, round_log, ctx->d_round_log.p, n_logged * 4, s));
-    uint32_t n_alive_now = 0;
-    HIPCHECK(d2h_small(ctx, &n_alive_now, ctx->d_counts.p + 0, 4, s));
+    uint32_t counts3[3] = {0, 0, 0};         // reads alive, the finishing kernel's verdict and rounds
+    HIPCHECK(d2h_small(ctx, counts3, ctx->d_counts.p + 0, 12, s));
     HIPCHECK(stream_sync(ctx, s));
-    ctx->t_n_alive = n_alive_now;           // the reads that survived the second pass (the tail's rank space)
-    {
+    if (counts3[1]) return fail(ctx, RALA_HIP_EDEVICE, "containment fixed point did not converge");
+    ctx->t_n_alive = counts3[0];            // the reads that survived the second pass (the tail's rank space)
+    if (finished_on_device) {
+        ctx->tm.death_rounds = (uint32_t)list_size.size() + counts3[2];
+    } else {
         // rounds until the list was empty
         uint32_t at = 0;
         ctx->tm.death_rounds = (uint32_t)list_size.size();

@@ -183,10 +183,8 @@ __device__ __forceinline__ uint32_t item_key(const TailList& L, uint32_t k, uint
 //             second from its end) and a mark per targeted read;
 //   reduce    (per class) a killer whose keeper is no target goes into base[target] = min key, for good;
 //             the others - the conditional ones, a few thousand - are listed again;
-//   rounds    (per class) ONE workgroup iterates over the conditional killers, its entries in registers,
-//             workgroup barriers between the rounds, X_r in work[r % 4]: round r compares X_(r-1) with
-//             X_(r-2), proposes into X_r and resets the targets in the array of X_(r+1) (last read a round
-//             ago) to base[] - one barrier per round; then base[] = what settled;
+//   rounds    (per class) ONE workgroup iterates over the conditional killers (fixed_point_kernels.hip);
+//             then base[] = what settled;
 //   apply     drops the containments of both classes and the internals behind a death, kill the reads.
 // The second scan sees the first one's deaths as base0[] (a read is gone when alive[] = 0 or base0[] is
 // set): alive[] itself changes in the last kernel only.  (Before: per round a kernel over all items and one
@@ -204,10 +202,6 @@ struct TailKillers {
 __device__ __forceinline__ uint32_t ld_past_l1(const uint32_t* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void st_past_l1(uint32_t* p, uint32_t v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 constexpr int kContainBlock = 1024;
 constexpr uint32_t kCollectPer = 4;             // items per thread of the collecting kernel
 
@@ -310,130 +304,6 @@ __global__ __launch_bounds__(kBlock) void tail_contain_reduce_kernel(TailKillers
     }
 }
 
-// Up to kLdsEntries conditional killers: X lives in LDS.  A target's slot is the smallest index among the
-// entries that target it (found through one of the work arrays: three trips to memory before the rounds,
-// none in them); a keeper that no conditional killer targets is a constant, base[keeper].  Two arrays and
-// three workgroup barriers per round: reset X_r to base, propose, compare with X_(r-1).
-// (With X in global memory - values other wavefronts write must be read past the vector cache, which on
-// this device means from the memory side - a round took 20 us; 2 500 conditional killers at C3, 7 rounds.)
-constexpr uint32_t kLdsEntries = 7168;
-
-template <int kClass>
-__global__ __launch_bounds__(kContainBlock) void tail_contain_rounds_kernel(TailKillers K, uint32_t* w0, uint32_t* w1, uint32_t* w2,
-                                                                            uint32_t* w3) {
-    const uint32_t n = K.count[2 + kClass];
-    if (n == 0) return;
-    uint32_t* base = K.base[kClass];
-    const uint32_t tid = threadIdx.x;
-    if (n <= kLdsEntries) {
-        constexpr uint32_t kPer = kLdsEntries / kContainBlock;      // 7 entries per thread, in registers
-        __shared__ uint32_t x[2][kLdsEntries];
-        uint32_t ek[kPer], et[kPer], ep[kPer], eb[kPer], st[kPer], sp[kPer], bp[kPer];
-#pragma unroll
-        for (uint32_t u = 0; u < kPer; ++u) {
-            const uint32_t i = tid + u * kContainBlock;
-            const uint32_t at = i < n ? i : 0u;                     // (an absent entry: a copy of entry 0 that never proposes)
-            ek[u] = i < n ? K.c_key[at] : kInf;
-            et[u] = K.c_target[at]; ep[u] = K.c_keeper[at];
-        }
-#pragma unroll
-        for (uint32_t u = 0; u < kPer; ++u) { eb[u] = base[et[u]]; bp[u] = base[ep[u]]; }
-        uint32_t* map = w0;
-#pragma unroll
-        for (uint32_t u = 0; u < kPer; ++u) { st_past_l1(map + et[u], kInf); st_past_l1(map + ep[u], kInf); }
-        __syncthreads();
-#pragma unroll
-        for (uint32_t u = 0; u < kPer; ++u) if (ek[u] != kInf) atomicMin(map + et[u], tid + u * kContainBlock);
-        __syncthreads();
-#pragma unroll
-        for (uint32_t u = 0; u < kPer; ++u) { st[u] = ld_past_l1(map + et[u]); sp[u] = ld_past_l1(map + ep[u]); }
-#pragma unroll
-        for (uint32_t u = 0; u < kPer; ++u) x[0][st[u]] = eb[u];
-        __syncthreads();
-        uint32_t cur = 1;
-        for (uint32_t r = 1;; ++r, cur ^= 1u) {
-            uint32_t* xc = x[cur];
-            const uint32_t* xp = x[cur ^ 1u];
-#pragma unroll
-            for (uint32_t u = 0; u < kPer; ++u) xc[st[u]] = eb[u];
-            __syncthreads();
-#pragma unroll
-            for (uint32_t u = 0; u < kPer; ++u) {
-                const uint32_t vk = sp[u] == kInf ? bp[u] : xp[sp[u]];
-                if (vk > ek[u] && ek[u] != kInf) atomicMin(&xc[st[u]], ek[u]);
-            }
-            __syncthreads();
-            bool moved = false;
-#pragma unroll
-            for (uint32_t u = 0; u < kPer; ++u) moved = moved || xc[st[u]] != xp[st[u]];
-            if (!__syncthreads_or(moved ? 1 : 0)) break;             // X_r = X_(r-1): settled
-            if (r > n + 8u) {                                         // (every round settles at least one read)
-                if (tid == 0) *K.error = 1u;
-                return;
-            }
-        }
-#pragma unroll
-        for (uint32_t u = 0; u < kPer; ++u) base[et[u]] = x[cur][st[u]];
-        return;
-    }
-    // more conditional killers than the LDS holds: X in work[r % 4]: round r compares X_(r-1) with X_(r-2), proposes
-    // into X_r and resets the targets in the array of X_(r+1) (last read a round ago) - one barrier per round
-    constexpr uint32_t kPer = 8;
-    uint32_t* const work[4] = {w0, w1, w2, w3};
-    uint32_t ek[kPer], et[kPer], ep[kPer], eb[kPer];
-    auto load = [&](uint32_t i0) {                // entries i0 + u * block; eb = base[target]; absent ones: copies of entry 0, key "never"
-#pragma unroll
-        for (uint32_t u = 0; u < kPer; ++u) {
-            const uint32_t i = i0 + u * kContainBlock;
-            const uint32_t at = i < n ? i : 0u;
-            ek[u] = i < n ? K.c_key[at] : kInf;
-            et[u] = K.c_target[at]; ep[u] = K.c_keeper[at];
-        }
-#pragma unroll
-        for (uint32_t u = 0; u < kPer; ++u) eb[u] = base[et[u]];
-    };
-    for (uint32_t i0 = tid; i0 < n; i0 += kPer * kContainBlock) {
-        load(i0);
-#pragma unroll
-        for (uint32_t u = 0; u < kPer; ++u) {
-            const uint32_t bp = base[ep[u]];
-            for (int w = 0; w < 4; ++w) { st_past_l1(work[w] + et[u], eb[u]); st_past_l1(work[w] + ep[u], bp); }
-        }
-    }
-    __syncthreads();
-    uint32_t r = 1;
-    for (;; ++r) {
-        const uint32_t* prev2 = work[(r + 2) & 3];      // X_(r-2)
-        const uint32_t* prev = work[(r + 3) & 3];       // X_(r-1)
-        uint32_t* cur = work[r & 3];                    // X_r
-        uint32_t* next = work[(r + 1) & 3];             // X_(r+1): reset here
-        bool moved = false;
-        for (uint32_t i0 = tid; i0 < n; i0 += kPer * kContainBlock) {
-            load(i0);
-            uint32_t vk[kPer], v1[kPer], v2[kPer];
-#pragma unroll
-            for (uint32_t u = 0; u < kPer; ++u) { vk[u] = ld_past_l1(prev + ep[u]); v1[u] = ld_past_l1(prev + et[u]); v2[u] = ld_past_l1(prev2 + et[u]); }
-#pragma unroll
-            for (uint32_t u = 0; u < kPer; ++u) {
-                moved = moved || (r >= 2 && v1[u] != v2[u]);
-                if (vk[u] > ek[u] && ek[u] != kInf) atomicMin(cur + et[u], ek[u]);
-                st_past_l1(next + et[u], eb[u]);
-            }
-        }
-        if (!__syncthreads_or((r < 2 || moved) ? 1 : 0)) break;      // X_(r-1) = X_(r-2): settled (and X_r is the same again)
-        if (r > n + 8u) {
-            if (tid == 0) *K.error = 1u;
-            return;
-        }
-    }
-    const uint32_t* settled = work[(r + 3) & 3];
-    for (uint32_t i0 = tid; i0 < n; i0 += kPer * kContainBlock) {
-        load(i0);
-#pragma unroll
-        for (uint32_t u = 0; u < kPer; ++u) base[et[u]] = ld_past_l1(settled + et[u]);
-    }
-}
-
 // after the scans: the containments of both classes are dropped (they either deleted a read or had lost
 // one), and the internals that the loop reached when one of their reads was already gone
 __global__ __launch_bounds__(kBlock) void tail_contain_apply_kernel(TailList L, const uint8_t* __restrict__ alive,
@@ -465,11 +335,11 @@ __global__ __launch_bounds__(kBlock) void tail_contain_kill_kernel(TailKillers K
 // what used to be a kernel, a fill and a copy)
 __global__ __launch_bounds__(kBlock) void tail_init_kernel(uint8_t* state, uint8_t* round, uint32_t n0, uint32_t m,
                                                            uint8_t* dirty, uint8_t* n_pits0, const uint8_t* n_pits,
-                                                           uint32_t n_reads, uint32_t* base2, uint8_t* mark2, uint32_t* zero6) {
+                                                           uint32_t n_reads, uint32_t* base2, uint8_t* mark2, uint32_t* map, uint32_t* zero6) {
     const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
     if (k < 6) zero6[k] = 0;
     if (k < n_reads) {
-        base2[k] = kInf; base2[n_reads + k] = kInf;
+        base2[k] = kInf; base2[n_reads + k] = kInf; map[k] = kInf;
         mark2[k] = 0; mark2[n_reads + k] = 0;
     }
     if (k < m) {
@@ -595,9 +465,9 @@ void launch_cc_edges(const TailList& L, const uint32_t* rank, uint32_t* edges, u
 void launch_refresh_types(const TailList& L, const TailReads& R, hipStream_t s) {
     if (L.n) hipLaunchKernelGGL(refresh_types_kernel, grid_for(L.n), dim3(kBlock), 0, s, L, R);
 }
-void launch_tail_contain(const TailList& L, uint8_t* alive, uint32_t* const lists[6], uint32_t* zeroed5, uint32_t* const work[4],
-                         uint32_t* base2, uint8_t* mark2, uint32_t n_reads, hipStream_t s) {
-    if (!L.n) return;
+hipError_t launch_tail_contain(const TailList& L, uint8_t* alive, uint32_t* const lists[6], uint32_t* zeroed5, uint32_t* const work[4],
+                               uint32_t* base2, uint8_t* mark2, uint32_t* map, uint32_t* pack, uint32_t n_reads, hipStream_t s) {
+    if (!L.n) return hipSuccess;
     TailKillers K;
     K.key = lists[0]; K.target = lists[1]; K.keeper = lists[2];
     K.c_key = lists[3]; K.c_target = lists[4]; K.c_keeper = lists[5];
@@ -607,19 +477,23 @@ void launch_tail_contain(const TailList& L, uint8_t* alive, uint32_t* const list
     const uint32_t per_block = kCollectPer * kContainBlock;
     hipLaunchKernelGGL(tail_contain_collect_kernel, dim3((L.n + per_block - 1) / per_block), dim3(kContainBlock), 0, s, L,
                        (const uint8_t*)alive, K);
-    hipLaunchKernelGGL(tail_contain_reduce_kernel<0>, dim3(128), dim3(kBlock), 0, s, K, L.n, (const uint8_t*)alive);
-    hipLaunchKernelGGL(tail_contain_rounds_kernel<0>, dim3(1), dim3(kContainBlock), 0, s, K, work[0], work[1], work[2], work[3]);
-    hipLaunchKernelGGL(tail_contain_reduce_kernel<1>, dim3(128), dim3(kBlock), 0, s, K, L.n, (const uint8_t*)alive);
-    hipLaunchKernelGGL(tail_contain_rounds_kernel<1>, dim3(1), dim3(kContainBlock), 0, s, K, work[0], work[1], work[2], work[3]);
+    for (int c = 0; c < 2; ++c) {
+        if (c == 0) hipLaunchKernelGGL(tail_contain_reduce_kernel<0>, dim3(128), dim3(kBlock), 0, s, K, L.n, (const uint8_t*)alive);
+        else hipLaunchKernelGGL(tail_contain_reduce_kernel<1>, dim3(128), dim3(kBlock), 0, s, K, L.n, (const uint8_t*)alive);
+        const FixedPointList conditional = {K.c_key, K.c_target, K.c_keeper, K.count + 2 + c};
+        const hipError_t e = launch_fixed_point_finish(conditional, K.base[c], map, pack, work, K.error, nullptr, s);
+        if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL(tail_contain_apply_kernel, grid_for(L.n), dim3(kBlock), 0, s, L, (const uint8_t*)alive,
                        (const uint32_t*)K.base[0], (const uint32_t*)K.base[1]);
     hipLaunchKernelGGL(tail_contain_kill_kernel, dim3(128), dim3(kBlock), 0, s, K, L.n, alive);
+    return hipGetLastError();
 }
 void launch_tail_init(const TailList& L, uint32_t n0, const TailReads& R, uint8_t* n_pits0, uint32_t n_reads, uint32_t* base2,
-                      uint8_t* mark2, uint32_t* zero6, hipStream_t s) {
+                      uint8_t* mark2, uint32_t* map, uint32_t* zero6, hipStream_t s) {
     const uint32_t n = std::max<uint32_t>(std::max<uint32_t>(L.n, n_reads), 6u);
     hipLaunchKernelGGL(tail_init_kernel, grid_for(n), dim3(kBlock), 0, s, L.state, L.round, n0, L.n, R.dirty, n_pits0, R.n_pits, n_reads,
-                       base2, mark2, zero6);
+                       base2, mark2, map, zero6);
 }
 bool launch_rank_pass(const uint8_t* alive, uint32_t* rank, uint32_t* alive_reads, uint32_t n_reads, ScanSpace& space, hipStream_t s) {
     return launch_scan_pass(n_reads, RankPass{alive, rank, alive_reads}, space, s);
