@@ -409,23 +409,31 @@ struct Layout {
     static constexpr uint32_t RS = X + kX;                      // run starts (+ sentinel)
     static constexpr uint32_t RV = RS + (kShort ? kArr / 2 : kArr);   // run values, uint16 (kArr / 2 words)
     static constexpr uint32_t IDX = RV + kArr / 2;              // kIdx uint16
-    static constexpr uint32_t RF = IDX + kIdx / 2;              // 4 lists x kMaxReg firsts
+    // The short layout (seven wavefronts per SIMD: 5 632 B) keeps the lists of the last phases inside X, which is
+    // free by then: the region lists behind the slope survivors (written while those are read), the merged
+    // regions and the interval scratch at its start (written when the survivors are done with); the per-run
+    // sums of the first phase in the place of the run values they become.  What is left behind the position
+    // index: the expansion's mask table and the scratch words.
+    static constexpr uint32_t XT = ((IDX + kIdx / 2) + 3) & ~3u;   // (short layout) 32 words: 8 masks of the expansion
+    static constexpr uint32_t RF = kShort ? X + kSlopeWords : IDX + kIdx / 2;   // 4 lists x kMaxReg firsts
     static constexpr uint32_t RL = RF + 4 * kMaxReg;            // 4 lists x kMaxReg lasts
     static constexpr uint32_t RC = RL + 4 * kMaxReg;            // 4 counts
-    static constexpr uint32_t REG = RC + 4;                     // 2 x (key, last) x 2 * kMaxReg
+    static constexpr uint32_t REG = kShort ? X : RC + 4;        // 2 x (key, last) x 2 * kMaxReg
     static constexpr uint32_t IV = REG + 8 * kMaxReg;           // 2 x 4 x kMaxRaw
     static constexpr uint32_t GONE = IV + 8 * kMaxRaw;          // 2 x kMaxRaw bytes
     static constexpr uint32_t CAND = GONE + (2 * kMaxRaw) / 4;  // kMaxRaw hill candidates (i << 16 | j)
-    static constexpr uint32_t SEL = CAND + kMaxRaw;             // 12 words
+    static constexpr uint32_t SEL = kShort ? XT + 32 : CAND + kMaxRaw;   // 12 words
     static constexpr uint32_t WORDS = SEL + 12;
-    // scratch of the expansion: a list of 64 noted groups and a table of 64 finished ones.  The list
-    // takes the position index's place where that is computed behind the expansion (kShort).
+    static constexpr uint32_t DELTA = kShort ? RV : RF;         // per-run sums of +-1 (first phase), two per word
+    static_assert(!kShort || (RC + 4 <= X + kX && CAND + kMaxRaw <= X + kSlopeWords), "the last phases' lists inside X");
+    // scratch of the expansion: a list of 64 noted groups and a table of 8 masks.  The list takes the position
+    // index's place where that is computed behind the expansion (kShort).
     static constexpr uint32_t XLIST = kShort ? IDX : RF;
-    static constexpr uint32_t XTABLE = ((kShort ? RF : RF + 64) + 3) & ~3u;
+    static constexpr uint32_t XTABLE = kShort ? XT : ((RF + 64) + 3) & ~3u;
     static_assert(kX >= kCap && kX >= kIdx && kX >= 768, "shared region too small");
     static_assert(kIdx / 2 >= 64 && SEL >= XTABLE + 32, "scratch of the expansion: 64 noted groups, 8 masks");
     static_assert(kBases == 16384 || (kShort && (kBases == 32768 || kBases == 65536)), "bitmap sizes in use");
-    static_assert(!kShort || kBases != 16384 || WORDS * 4 <= 6656, "six wavefronts per SIMD: 24 workgroups in 160 KB, 512-byte granules");
+    static_assert(!kShort || kBases != 16384 || WORDS * 4 <= 5632, "seven wavefronts per SIMD: 28 workgroups in 160 KB, 512-byte granules");
     static_assert(!kShort || kBases > 32768 || WORDS * 4 <= 10240, "four wavefronts per SIMD: 16 workgroups in 160 KB");
     static_assert(!kShort || WORDS * 4 <= 16384, "ten workgroups in 160 KB");
 };
@@ -563,7 +571,7 @@ __device__ __forceinline__ void expand_from_bitmap(uint32_t* sm, const uint16_t*
 // with it a wait for every one of them.)
 // kBases > 16384: the short layout with a bigger bitmap, for the reads the first kernel handed on.
 template <uint32_t kCap, bool kDiag, int kSens, bool kOne = false, uint32_t kBases = 16384>
-__global__ __launch_bounds__(64, kOne ? 6 : kBases > 32768 ? 2 : kBases > 16384 ? 4 : 5) void pile_runs_kernel(PileArgs A, uint32_t* overflow_list, uint32_t* overflow_count) {
+__global__ __launch_bounds__(64, kOne ? 7 : kBases > 32768 ? 2 : kBases > 16384 ? 4 : 5) void pile_runs_kernel(PileArgs A, uint32_t* overflow_list, uint32_t* overflow_count) {
     static_assert(kSens == 0 || (kCap <= 1024 && !kDiag), "the sensitive pass runs on the bitmap path");
     static_assert(!kOne || kCap <= 512, "the short layout belongs to the first kernel of a chain");
     static_assert(kBases == 16384 || !kOne, "the bigger bitmap belongs to the chain's second kernel");
@@ -645,8 +653,9 @@ __global__ __launch_bounds__(64, kOne ? 6 : kBases > 32768 ? 2 : kBases > 16384 
             uint16_t* pref = (uint16_t*)(bm + kBitmapBases / 32);
             // per-run sums of +-1, two per word, biased by 0x8000 so that a subtraction never
             // borrows from the neighbour (at most kCap events meet at one position)
-            uint32_t* delta = sm + L::RF;
-            static_assert(kCap > 1024 || L::SEL - L::RF >= L::kArr / 2 + 2, "scratch for the per-run sums");
+            // (short layout: in the place of the run values: run k's sum is the 16 bits that rv[k] takes)
+            uint32_t* delta = sm + L::DELTA;
+            static_assert(kCap > 1024 || kShort || L::SEL - L::RF >= L::kArr / 2 + 2, "scratch for the per-run sums");
 #pragma unroll
             for (uint32_t j = 0; j < kV; ++j) ((uint4*)bm)[lane + 64 * j] = make_uint4(0, 0, 0, 0);
             for (uint32_t k = lane; 2 * k < n_ev + 5; k += 64) delta[k] = 0x80008000u;
@@ -1025,7 +1034,6 @@ __global__ __launch_bounds__(64, kOne ? 6 : kBases > 32768 ? 2 : kBases > 16384 
             }
         }
         wave_sync();
-
 
         RUN_STOP(31)
 
