@@ -632,7 +632,7 @@ __global__ __launch_bounds__(64, kOne ? 7 : kBases > 32768 ? 2 : kBases > 16384 
         // (pipeline.hip), no hand-over through the list
         if (kOne && kSens == 0 && n > kMaxBases) continue;
         // (the two region marks of the sensitive pass may add two runs)
-        if (kSens == 0 && kCap == kRunEventCap && A.skip_dense && n_ev > kCap) continue;   // listed beforehand
+        if (kSens == 0 && kCap <= kRunEventCap && A.skip_dense && n_ev > kRunEventCap) continue;   // listed beforehand
         if (n_ev > (kSens ? kCap - 2 : kCap) || (kSens != 0 && (n > kMaxBases || given_e <= given_b)) || (kShort && n > kMaxBases)) {
             if (lane == 0) overflow_list[atomicAdd(overflow_count, 1u)] = r;
             continue;
