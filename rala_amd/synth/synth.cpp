@@ -111,6 +111,18 @@ void generate(Synth& S, uint64_t n_reads, uint64_t genome, uint64_t seed, uint32
         int64_t sum = 0;
         for (int k = 0; k < 12; ++k) sum += (int64_t)(rng.next() >> 48);
         int64_t L = 10000 + (1500 * (sum - 393210)) / 65536;
+        if (plants & 16) {
+            // heavy tail (what nanopore runs look like, not Appendix E's bell): 3 kb + an exponential with a mean of
+            // 7 kb, one read in fifty another 30 - 90 kb on top: all length classes of the pile chain in one data set.
+            // -ln(u / 2^53) in integers, the same on every machine: ln 2 per halving, linear inside the last octave
+            // (-ln x ~ 2 ln 2 (1 - x) on [1/2, 1): close enough for a length).  e = 7000 * 1.024 * (-ln ..)
+            uint64_t u = (rng.next() >> 11) | 1ull;              // 53 bits, never zero
+            int64_t e = 0;
+            while (u < (1ull << 52)) { u <<= 1; e += 4968; }      // 7000 * 1.024 * ln 2
+            e += (int64_t)(((1ull << 53) - u) >> 43) * 4968 * 2 / 1024;
+            L = 3000 + e * 1000 / 1024;
+            if (rng.chance_permille(20)) L += rng.range(30000, 90000);
+        }
         if (L < 3000) L = 3000;
         if ((uint64_t)L + 16 > genome) L = (int64_t)genome / 2;
         S.read_len[i] = (uint32_t)L;
@@ -267,7 +279,7 @@ void generate(Synth& S, uint64_t n_reads, uint64_t genome, uint64_t seed, uint32
 
 extern "C" {
 
-// plants: bit0 chimeras, bit1 adapters, bit2 repeats, bit3 stacks (15 = all)
+// plants: bit0 chimeras, bit1 adapters, bit2 repeats, bit3 stacks (15 = all); bit4: heavy-tailed read lengths
 void* synth_create(uint64_t n_reads, uint64_t genome_len, uint64_t seed, uint32_t plants) {
     Synth* s = new Synth;
     generate(*s, n_reads, genome_len, seed, plants);

@@ -34,6 +34,26 @@ def test_full_path_small(hip_ctx_factory, n, g, seed, run_kernel):
         assert tm["pile_position_reads"] > 0 and tm["pile_overflow_reads"] >= tm["pile_position_reads"]
 
 
+@pytest.mark.parametrize("run_kernel", [1, 0])
+@pytest.mark.parametrize("n,g,seed", [(3000, 3_000_000, 77), (6000, 2_500_000, 78)])
+def test_heavy_tailed_read_lengths(hip_ctx_factory, n, g, seed, run_kernel):
+    """Read lengths with a heavy tail (3 kb + exponential, some reads 30 - 90 kb longer: up to 105 kb) instead of the
+    bell of the named configurations: every length class of the pile chain (16 384 / 32 768 / 65 535 bases and
+    beyond), the 8-byte per-read records of the second pass, coverage from 11x to 27x."""
+    ds = Dataset(n, g, seed, plants=31)
+    assert (ds.read_len > 65535).sum() > 0 and (ds.read_len > 32768).sum() > 20 and (ds.read_len <= 16384).sum() > n // 2
+    st = parity.oracle_stages(ds)
+    ctx = hip_ctx_factory()
+    ctx.set_option("use_run_kernel", run_kernel)
+    ctx.set_reads(ds.read_len)
+    ctx.set_overlaps(ds.overlaps)
+    ctx.initialize()
+    parity.check_initialize(ctx, st, ds)
+    ctx.construct()
+    parity.check_construct(ctx, st)
+    parity.check_tr(ctx, st)
+
+
 @pytest.mark.parametrize("n,g,seed", [(3000, 600_000, 21), (400, 20_000, 5), (1500, 12_000, 3)])
 def test_bucketing_variants(hip_ctx_factory, n, g, seed):
     """The ways the bounds reach the pile kernel: the target side partitioned into an exact CSR (default,

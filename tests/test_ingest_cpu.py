@@ -227,3 +227,72 @@ def test_streamed_reader_awkward_input(tmp_path, tokenizer):
         assert e == 0
         _, e = parse(bad, names, lens, threads, mode, check_lengths=False)
         assert e == -1
+
+
+def _minimap2_like(tmp_path, n_lines=4000, seed=11):
+    """A PAF shaped like `minimap2 -x ava-ont reads.fq reads.fq` output: read names as sequencers write them, the
+    twelve mandatory columns, then minimap2's tags in its order (tp cm s1 [s2] dv rl, sometimes cg); self hits,
+    both orders of a pair, repeated pairs, secondary hits, mapping quality 0.  Returns (path, names, lengths, want)
+    with `want` parsed here in Python (tab split, name = the query / target column as it stands)."""
+    rng = np.random.default_rng(seed)
+    n = 60
+    names = []
+    for i in range(n):
+        kind = i % 3
+        if kind == 0:      # nanopore: a UUID
+            h = "%032x" % int(rng.integers(0, 2 ** 62))
+            names.append("%s-%s-%s-%s-%s" % (h[:8], h[8:12], h[12:16], h[16:20], h[20:32]))
+        elif kind == 1:    # pacbio: movie/zmw/ccs
+            names.append("m54238_180901_011437/%d/ccs" % int(rng.integers(4_000_000, 5_000_000)))
+        else:              # illumina-ish / SRA
+            names.append("SRR%d.%d" % (7_000_000 + i, int(rng.integers(1, 10 ** 6))))
+    lens = [int(x) for x in rng.integers(3000, 40000, n)]
+    want = {f: [] for f in FIELDS + ("strand",)}
+    lines = []
+    for k in range(n_lines):
+        a = int(rng.integers(0, n))
+        b = a if k % 97 == 0 else int(rng.integers(0, n))          # self hits
+        span = int(rng.integers(500, min(lens[a], lens[b])))
+        qb = int(rng.integers(0, lens[a] - span + 1)); qe = qb + span
+        tb = int(rng.integers(0, lens[b] - span + 1)); te = tb + span - int(rng.integers(0, 20))
+        strand = "+-"[int(rng.integers(0, 2))]
+        alen = max(qe - qb, te - tb) + int(rng.integers(0, 50))
+        match = int(alen * 0.85)
+        mapq = 0 if k % 13 == 0 else int(rng.integers(1, 61))
+        tags = ["tp:A:%s" % ("S" if k % 11 == 0 else "P"), "cm:i:%d" % int(rng.integers(5, 900)),
+                "s1:i:%d" % int(rng.integers(50, 9000))]
+        if k % 5:
+            tags.append("s2:i:%d" % int(rng.integers(0, 5000)))
+        tags += ["dv:f:%.4f" % float(rng.random() * 0.2), "rl:i:%d" % int(rng.integers(0, 3000))]
+        if k % 17 == 0:
+            tags.append("cg:Z:" + "".join("%d%s" % (int(rng.integers(1, 400)), "MID"[int(rng.integers(0, 3))])
+                                          for _ in range(int(rng.integers(1, 300)))))
+        lines.append("\t".join([names[a], str(lens[a]), str(qb), str(qe), strand, names[b], str(lens[b]), str(tb), str(te),
+                                str(match), str(alen), str(mapq)] + tags))
+        if k % 401 == 0:
+            lines.append(lines[-1])                                  # the same hit twice
+        reps = 2 if k % 401 == 0 else 1
+        for _ in range(reps):
+            for f, v in zip(FIELDS, (a, b, qb, qe, tb, te, alen)):
+                want[f].append(v)
+            want["strand"].append(1 if strand == "-" else 0)
+    path = str(tmp_path / "ava.paf")
+    with open(path, "w") as f:
+        f.write("\n".join(lines) + "\n")
+    return path, names, lens, want
+
+
+@pytest.mark.parametrize("threads", [1, 5])
+def test_minimap2_shaped_paf(tmp_path, threads, tokenizer):
+    """every reader (line by line, parallel, streamed plain and gzip) against a parse done here in Python"""
+    import gzip
+    import shutil
+
+    path, names, lens, want = _minimap2_like(tmp_path)
+    with open(path, "rb") as src, gzip.open(path + ".gz", "wb", compresslevel=6) as dst:
+        shutil.copyfileobj(src, dst)
+    for p, mode in ((path, 0), (path, 1), (path, 2), (path + ".gz", 0), (path + ".gz", 2)):
+        got, e = parse(p, names, lens, threads, mode)
+        assert e == -1, (p, mode)
+        for f in want:
+            assert got[f].tolist() == want[f], (p, mode, f)
