@@ -18,7 +18,11 @@
 // target and keeper, base[] of both - into packed arrays.  (The one workgroup doing those gathers itself
 // took 130 us for 11 k entries: values written with atomics are read from the memory side, and one compute
 // unit has only so many requests in flight.)  A keeper that no listed killer targets is a constant,
-// base[keeper].  Longer lists: X in four work arrays in global memory, 20 us per round instead of 2.
+// base[keeper].  Longer lists (C5: 73 k undecided killers after the second round of the second pass, 17 k conditional
+// ones in the tail): fixed_point_wide_kernel - X in four work arrays in global memory, a few workgroups that are
+// resident together, a barrier between them per round.  What other wavefronts write with atomics is then read past
+// the vector cache, on this device from the memory side: 20 - 30 us per round instead of 2, whatever the list's
+// length (one workgroup alone took 160 us per round for 24 k entries).
 #include <hip/hip_runtime.h>
 
 #include "kernels.h"
@@ -66,8 +70,7 @@ __global__ __launch_bounds__(kPrepBlock) void fixed_point_prepare_kernel(FixedPo
 }
 
 __global__ __launch_bounds__(kFinishBlock) void fixed_point_finish_kernel(FixedPointList list, uint32_t* base, uint32_t* map,
-                                                                          const uint32_t* __restrict__ pack, uint32_t* w0, uint32_t* w1,
-                                                                          uint32_t* w2, uint32_t* w3, uint32_t* error,
+                                                                          const uint32_t* __restrict__ pack, uint32_t* error,
                                                                           uint32_t* rounds_out) {
     extern __shared__ uint32_t lds[];
     const uint32_t n = *list.count;
@@ -76,8 +79,9 @@ __global__ __launch_bounds__(kFinishBlock) void fixed_point_finish_kernel(FixedP
         if (rounds_out && tid == 0) *rounds_out = 0;
         return;
     }
+    if (n > kLdsEntries) return;                  // (fixed_point_wide_kernel's)
     uint32_t r = 1;
-    if (n <= kLdsEntries) {
+    {
         constexpr uint32_t kPer = kFinishPer;
         uint32_t* xb = lds;                         // base per slot
         uint32_t* x0 = lds + kLdsEntries;           // X of the even rounds; the odd ones' behind it
@@ -123,15 +127,54 @@ __global__ __launch_bounds__(kFinishBlock) void fixed_point_finish_kernel(FixedP
         if (rounds_out && tid == 0) *rounds_out = r;
         return;
     }
-    // more killers than the LDS holds: X_r in work[r % 4]: round r compares X_(r-1) with X_(r-2), proposes into X_r
-    // and resets the targets in the array of X_(r+1) (last read a round ago) - one barrier per round
-    constexpr uint32_t kPer = 8;
+}
+
+// Barrier between the workgroups of a small grid that is resident as a whole.  sync[0] counts arrivals (zero at the
+// launch), `phase` the barriers of this launch.  false: somebody gave up waiting (a workgroup that never got a
+// compute unit) - everybody leaves; the host sees *error.
+constexpr uint32_t kWideGroups = 32;
+// (Everything the workgroups tell each other goes through memory-side atomics, stores and loads: what has to be
+// complete before the arrival is this wavefront's own requests - a wait for its counters, not a fence, which on
+// this device writes the L2 back and invalidates it: 40 us per round with fences.)
+__device__ __forceinline__ bool grid_barrier(uint32_t* sync, uint32_t& phase, uint32_t groups) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    ++phase;
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t spins = 0;
+        while (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < phase * groups) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1u << 23) || __hip_atomic_load(sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                __hip_atomic_store(sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    return ld_past_l1(sync + 1) == 0;
+}
+
+// More killers than the LDS holds: X_r in work[r % 4]: round r compares X_(r-1) with X_(r-2), proposes into X_r and
+// resets the targets in the array of X_(r+1) (last read a round ago) - one barrier per round.  sync: eight zeroed
+// words ([0] arrivals, [1] "give up", [4 .. 6] "a value moved" per round % 3).
+__global__ __launch_bounds__(kFinishBlock) void fixed_point_wide_kernel(FixedPointList list, uint32_t* base, uint32_t* w0, uint32_t* w1,
+                                                                        uint32_t* w2, uint32_t* w3, uint32_t* sync, uint32_t* error,
+                                                                        uint32_t* rounds_out) {
+    const uint32_t n = *list.count;
+    if (n <= kLdsEntries) return;                 // (fixed_point_finish_kernel's)
+    constexpr uint32_t kPer = 4;
+    const uint32_t groups = gridDim.x;
+    const uint32_t stride = groups * kFinishBlock;
+    const uint32_t gtid = blockIdx.x * kFinishBlock + threadIdx.x;
     uint32_t* const work[4] = {w0, w1, w2, w3};
+    uint32_t* const flag = sync + 4;
+    uint32_t phase = 0;
     uint32_t ek[kPer], et[kPer], ep[kPer], eb[kPer];
-    auto load = [&](uint32_t i0) {                // entries i0 + u * block; absent ones: copies of entry 0, key "never"
+    auto load = [&](uint32_t i0) {                // entries i0 + u * stride; absent ones: copies of entry 0 with the key "never"
 #pragma unroll
         for (uint32_t u = 0; u < kPer; ++u) {
-            const uint32_t i = i0 + u * kFinishBlock;
+            const uint32_t i = i0 + u * stride;
             const uint32_t at = i < n ? i : 0u;
             ek[u] = i < n ? list.key[at] : kInf;
             et[u] = list.target[at]; ep[u] = list.keeper[at];
@@ -139,7 +182,7 @@ __global__ __launch_bounds__(kFinishBlock) void fixed_point_finish_kernel(FixedP
 #pragma unroll
         for (uint32_t u = 0; u < kPer; ++u) eb[u] = base[et[u]];
     };
-    for (uint32_t i0 = tid; i0 < n; i0 += kPer * kFinishBlock) {
+    for (uint32_t i0 = gtid; i0 < n; i0 += kPer * stride) {
         load(i0);
 #pragma unroll
         for (uint32_t u = 0; u < kPer; ++u) {
@@ -147,15 +190,19 @@ __global__ __launch_bounds__(kFinishBlock) void fixed_point_finish_kernel(FixedP
             for (int w = 0; w < 4; ++w) { st_past_l1(work[w] + et[u], eb[u]); st_past_l1(work[w] + ep[u], bp); }
         }
     }
-    __syncthreads();
+    if (!grid_barrier(sync, phase, groups)) { if (gtid == 0) *error = 2u; return; }
+    // (up to 131 072 entries stay in registers over the rounds: one trip to memory less per round)
+    const bool resident = n <= kPer * stride;
+    if (resident) load(gtid);
+    uint32_t r = 1;
     for (;; ++r) {
         const uint32_t* prev2 = work[(r + 2) & 3];      // X_(r-2)
         const uint32_t* prev = work[(r + 3) & 3];       // X_(r-1)
         uint32_t* cur = work[r & 3];                    // X_r
         uint32_t* next = work[(r + 1) & 3];             // X_(r+1): reset here
         bool moved = false;
-        for (uint32_t i0 = tid; i0 < n; i0 += kPer * kFinishBlock) {
-            load(i0);
+        for (uint32_t i0 = gtid; i0 < n; i0 += kPer * stride) {
+            if (!resident) load(i0);
             uint32_t vk[kPer], v1[kPer], v2[kPer];
 #pragma unroll
             for (uint32_t u = 0; u < kPer; ++u) { vk[u] = ld_past_l1(prev + ep[u]); v1[u] = ld_past_l1(prev + et[u]); v2[u] = ld_past_l1(prev2 + et[u]); }
@@ -166,19 +213,24 @@ __global__ __launch_bounds__(kFinishBlock) void fixed_point_finish_kernel(FixedP
                 st_past_l1(next + et[u], eb[u]);
             }
         }
-        if (!__syncthreads_or((r < 2 || moved) ? 1 : 0)) break;      // X_(r-1) = X_(r-2): settled (and X_r is the same again)
-        if (r > n + 8u) {
-            if (tid == 0) *error = 1u;
+        if (r >= 2 && __syncthreads_or(moved ? 1 : 0) && threadIdx.x == 0) {
+            __hip_atomic_store(flag + r % 3u, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (gtid == 0) __hip_atomic_store(flag + (r + 1u) % 3u, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!grid_barrier(sync, phase, groups)) { if (gtid == 0) *error = 2u; return; }
+        if (r >= 2 && ld_past_l1(flag + r % 3u) == 0) break;     // X_(r-1) = X_(r-2): settled (and X_r is the same again)
+        if (r > n + 8u) {                                         // (every round settles at least one read)
+            if (gtid == 0) *error = 1u;
             return;
         }
     }
     const uint32_t* settled = work[(r + 3) & 3];
-    for (uint32_t i0 = tid; i0 < n; i0 += kPer * kFinishBlock) {
-        load(i0);
+    for (uint32_t i0 = gtid; i0 < n; i0 += kPer * stride) {
+        if (!resident) load(i0);
 #pragma unroll
         for (uint32_t u = 0; u < kPer; ++u) base[et[u]] = ld_past_l1(settled + et[u]);
     }
-    if (rounds_out && tid == 0) *rounds_out = r - 1;
+    if (rounds_out && gtid == 0) *rounds_out = r - 1;
 }
 
 }  // namespace
@@ -186,7 +238,7 @@ __global__ __launch_bounds__(kFinishBlock) void fixed_point_finish_kernel(FixedP
 size_t fixed_point_pack_words() { return 6 * (size_t)kLdsEntries; }
 
 hipError_t launch_fixed_point_finish(const FixedPointList& list, uint32_t* base, uint32_t* map, uint32_t* pack, uint32_t* const work[4],
-                                     uint32_t* error, uint32_t* rounds_out, hipStream_t s) {
+                                     uint32_t* sync8, uint32_t* error, uint32_t* rounds_out, hipStream_t s) {
     constexpr size_t lds_bytes = 3 * (size_t)kLdsEntries * 4;
     static bool asked = false;
     if (!asked) {
@@ -195,11 +247,14 @@ hipError_t launch_fixed_point_finish(const FixedPointList& list, uint32_t* base,
         if (e != hipSuccess) return e;
         asked = true;
     }
+    // (the list's length is on the device: every kernel looks at it and the ones it is not meant for leave at once)
     hipLaunchKernelGGL(fixed_point_assign_kernel, dim3(kPrepGroups), dim3(kPrepBlock), 0, s, list, map);
     hipLaunchKernelGGL(fixed_point_prepare_kernel, dim3(kPrepGroups), dim3(kPrepBlock), 0, s, list, (const uint32_t*)map,
                        (const uint32_t*)base, pack);
     hipLaunchKernelGGL(fixed_point_finish_kernel, dim3(1), dim3(kFinishBlock), lds_bytes, s, list, base, map, (const uint32_t*)pack,
-                       work[0], work[1], work[2], work[3], error, rounds_out);
+                       error, rounds_out);
+    hipLaunchKernelGGL(fixed_point_wide_kernel, dim3(kWideGroups), dim3(kFinishBlock), 0, s, list, base, work[0], work[1], work[2],
+                       work[3], sync8, error, rounds_out);
     return hipGetLastError();
 }
 

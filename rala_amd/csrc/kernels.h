@@ -274,16 +274,15 @@ void launch_retrim(const TailList& L, const TailReads& R, uint32_t promote, uint
 void launch_cc_edges(const TailList& L, const uint32_t* rank, uint32_t* edges, uint8_t* touched, hipStream_t s);
 void launch_refresh_types(const TailList& L, const TailReads& R, hipStream_t s);
 // both in-order containment scans of the tail (graph.cpp:831-877) without a look from the host (tail_kernels.hip).  lists:
-// six arrays of L.n words (killers, conditional killers); zeroed5: five zeroed words ([0] is set when a fixed point did
-// not settle); work: four arrays of n_reads words, uninitialised; base2: 2 * n_reads words, all ones, and mark2: 2 * n_reads
+// six arrays of L.n words (killers, conditional killers); zeroed21: 21 zeroed words ([0] is set when a fixed point failed); work: four arrays of n_reads words, uninitialised; base2: 2 * n_reads words, all ones, and mark2: 2 * n_reads
 // bytes, zero (tail_init); map, pack: launch_fixed_point_finish's
-hipError_t launch_tail_contain(const TailList& L, uint8_t* alive, uint32_t* const lists[6], uint32_t* zeroed5, uint32_t* const work[4],
+hipError_t launch_tail_contain(const TailList& L, uint8_t* alive, uint32_t* const lists[6], uint32_t* zeroed21, uint32_t* const work[4],
                                uint32_t* base2, uint8_t* mark2, uint32_t* map, uint32_t* pack, uint32_t n_reads, hipStream_t s);
 void launch_count_zero_u8(const uint8_t* x, uint32_t n, uint32_t* out, hipStream_t s);    // *out += #zeros
 // list states (the first n0 items are overlaps, the rest internals), dirty[] = 0, n_pits0[] = n_pits[], base2[0 .. 2 n_reads) =
-// all ones, mark2[0 .. 2 n_reads) = 0, map[0 .. n_reads) = all ones, zero6[0 .. 5] = 0 in one launch
+// all ones, mark2[0 .. 2 n_reads) = 0, map[0 .. n_reads) = all ones, zero22[0 .. 21] = 0 in one launch
 void launch_tail_init(const TailList& L, uint32_t n0, const TailReads& R, uint8_t* n_pits0, uint32_t n_reads, uint32_t* base2,
-                      uint8_t* mark2, uint32_t* map, uint32_t* zero6, hipStream_t s);
+                      uint8_t* mark2, uint32_t* map, uint32_t* zero22, hipStream_t s);
 // single-pass scans with producer and consumer inside (scan_pass.h); false = out of tile states
 struct ScanSpace;
 bool launch_rank_pass(const uint8_t* alive, uint32_t* rank, uint32_t* alive_reads, uint32_t n_reads, ScanSpace& space, hipStream_t s);
@@ -300,15 +299,16 @@ bool launch_offsets_pass(const uint32_t* in, uint32_t* out, uint32_t* copy, uint
 // ---- the end of a containment fixed point (fixed_point_kernels.hip) ------------------------------------
 // conditional killers {key, target, keeper} (*count of them, on the device); base: the deaths decided for good (all ones:
 // never), receives the deaths; map: one word per read, all ones, left all ones; pack: fixed_point_pack_words() words of
-// scratch; work: four arrays of as many words as there are reads, uninitialised; *error is set to 1 when the rounds do not
-// settle; *rounds_out (may be null) receives their number
+// scratch; work: four arrays of as many words as there are reads, uninitialised; sync8: eight zeroed words (one set per
+// call); *error is set when the rounds do not settle (1) or the workgroups of a long list's kernel cannot meet (2);
+// *rounds_out (may be null) receives the number of rounds
 struct FixedPointList {
     const uint32_t *key, *target, *keeper;
     const uint32_t* count;
 };
 size_t fixed_point_pack_words();
 hipError_t launch_fixed_point_finish(const FixedPointList& list, uint32_t* base, uint32_t* map, uint32_t* pack, uint32_t* const work[4],
-                                     uint32_t* error, uint32_t* rounds_out, hipStream_t s);
+                                     uint32_t* sync8, uint32_t* error, uint32_t* rounds_out, hipStream_t s);
 
 // ---- fills (fill_kernels.hip) -------------------------------------------------------------------
 // What a stage has to clear, cleared in one launch: add(pointer, byte value, bytes) ..., then launch(stream).

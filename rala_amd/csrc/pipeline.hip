@@ -1122,9 +1122,9 @@ int gpu_tail_part_a(rala_hip_ctx* ctx) {
         if (rc != RALA_HIP_OK) return rc;
         HIPCHECK(fills.launch(s));
     }
-    // (d_counts: [4 .. 5] overlaps dropped per round of a batch, [8] reads left, [9] a containment scan that did not settle,
-    // [10 .. 13] the scans' killer counts - launch_tail_contain)
-    HIPCHECK(ctx->d_counts.ensure(32));
+    // (d_counts: [4 .. 5] overlaps dropped per round of a batch, [8] reads left, [9] a containment scan that failed,
+    // [10 .. 13] the scans' killer counts, [14 .. 29] their barriers - launch_tail_contain; [32 .. 39] the second pass's)
+    HIPCHECK(ctx->d_counts.ensure(48));
     for (int k = 0; k < 2; ++k) HIPCHECK(ctx->d_t_work[k].ensure(n_reads));
     HIPCHECK(ctx->d_t_fin.ensure(2 * (size_t)n_reads));
     HIPCHECK(ctx->d_t_mark.ensure(2 * (size_t)n_reads));
@@ -1137,7 +1137,7 @@ int gpu_tail_part_a(rala_hip_ctx* ctx) {
     mark("tail: ranks", n_alive);
 
     // break over chimeric hills, first re-trim (graph.cpp:704-736; no promotion here)
-    HIPCHECK(ctx->d_counts.ensure(32));
+    HIPCHECK(ctx->d_counts.ensure(48));
     uint32_t* dropped = ctx->d_counts.p + 4;                        // one word per round of a batch
     launch_break_hills(R, n_reads, s);
     launch_retrim(L, R, 0, 0, dropped, s);
@@ -1204,7 +1204,7 @@ int gpu_tail_part_b(rala_hip_ctx* ctx) {
     HIPCHECK(ctx->d_seg_base.ensure(2 * (size_t)n_seg + 4));
     HIPCHECK(ctx->d_node_read.ensure(2 * (size_t)ctx->t_n_alive + 2));
     for (int k = 0; k < 3; ++k) HIPCHECK(ctx->d_e[k].ensure(2 * (size_t)M + 2));
-    HIPCHECK(ctx->d_counts.ensure(32));
+    HIPCHECK(ctx->d_counts.ensure(48));
     ScanSpace sp;
     {
         FillList fills;
@@ -1238,7 +1238,10 @@ int gpu_tail_part_b(rala_hip_ctx* ctx) {
         fprintf(stderr, "[trace] tail containment killers: %u (%u conditional) among the overlaps, %u (%u) among the internals, of %u items\n",
                 kc[0], kc[2], kc[1], kc[3], M);
     }
-    if (left[1]) return fail(ctx, RALA_HIP_EDEVICE, "containment fixed point did not converge");
+    if (left[1]) {
+        return fail(ctx, RALA_HIP_EDEVICE, left[1] == 1 ? "containment fixed point did not converge"
+                                                        : "containment fixed point: the workgroups could not meet");
+    }
     const uint32_t n_final = left[0];
     ctx->t_n_kept = totals[0];
     ctx->t_n_nodes = 2 * n_final;
@@ -1346,7 +1349,7 @@ int pass2(rala_hip_ctx* ctx, Comm* comm) {
     // compact per-read records (valid region + two flags): 4 bytes when no read is longer than 32767 bases
     const bool small_rec = ctx->max_read_len <= 32767u;
     HIPCHECK(ctx->d_crec.ensure((size_t)n_reads * compact_record_bytes(small_rec) + 16));
-    HIPCHECK(ctx->d_counts.ensure(32));
+    HIPCHECK(ctx->d_counts.ensure(48));
     // one buffer: sure[n_reads] (min over sure killers = upper bound), lo[n_reads] (lower bound),
     // one status word - so that a sharded run needs ONE all-reduce (min) per round; up[] apart
     HIPCHECK(ctx->d_death_sure.ensure(2 * (size_t)n_reads + 8));
@@ -1358,7 +1361,7 @@ int pass2(rala_hip_ctx* ctx, Comm* comm) {
     {
         FillList fills;
         fills.add(ctx->d_kill_count.p, 0, (kCountRing + 4) * 4);
-        fills.add(ctx->d_counts.p, 0, 16 * 4);
+        fills.add(ctx->d_counts.p, 0, 48 * 4);
         fills.add(sure, 0xFF, 2 * dbytes + 4);
         fills.add(ctx->d_fp_map.p, 0xFF, dbytes);               // (launch_fixed_point_finish leaves it that way; here for good measure)
         HIPCHECK(fills.launch(s));
@@ -1397,7 +1400,7 @@ int pass2(rala_hip_ctx* ctx, Comm* comm) {
     // second - is finished by ONE workgroup with the bounds in LDS (fixed_point_kernels.hip): no more launches
     // per round, no more looks.  Before: six more rounds of four launches, two more looks.)
     uint32_t unseen = gathered && ctx->use_round_batches ? 1u : 0u, n_logged = 0;
-    constexpr uint32_t kFinishAtMost = 1u << 16;                 // (beyond the LDS' 12 288 the finishing kernel is slow, not wrong)
+    constexpr uint32_t kFinishAtMost = 1u << 20;                 // (beyond that a round over the whole list by all compute units pays)
     bool finished_on_device = false;
     uint64_t at_most = ~0ull;                                    // what the host knows of the current list's length
     for (;;) {
@@ -1444,8 +1447,8 @@ int pass2(rala_hip_ctx* ctx, Comm* comm) {
             HIPCHECK(ctx->d_t_work[0].ensure(n_reads));
             uint32_t* const work[4] = {up, lo, ctx->d_death[0].p, ctx->d_t_work[0].p};
             const FixedPointList rest = {klist[cur].ovl, klist[cur].target, klist[cur].keeper, klist[cur].count};
-            HIPCHECK(launch_fixed_point_finish(rest, sure, ctx->d_fp_map.p, ctx->d_fp_pack.p, work, ctx->d_counts.p + 1,
-                                               ctx->d_counts.p + 2, s));
+            HIPCHECK(launch_fixed_point_finish(rest, sure, ctx->d_fp_map.p, ctx->d_fp_pack.p, work, ctx->d_counts.p + 32,
+                                               ctx->d_counts.p + 1, ctx->d_counts.p + 2, s));
             finished_on_device = true;
             break;
         }
@@ -1513,7 +1516,10 @@ int pass2(rala_hip_ctx* ctx, Comm* comm) {
     uint32_t counts3[3] = {0, 0, 0};         // reads alive, the finishing kernel's verdict and rounds
     HIPCHECK(d2h_small(ctx, counts3, ctx->d_counts.p + 0, 12, s));
     HIPCHECK(stream_sync(ctx, s));
-    if (counts3[1]) return fail(ctx, RALA_HIP_EDEVICE, "containment fixed point did not converge");
+    if (counts3[1]) {
+        return fail(ctx, RALA_HIP_EDEVICE, counts3[1] == 1 ? "containment fixed point did not converge"
+                                                           : "containment fixed point: the workgroups could not meet");
+    }
     ctx->t_n_alive = counts3[0];            // the reads that survived the second pass (the tail's rank space)
     if (finished_on_device) {
         ctx->tm.death_rounds = (uint32_t)list_size.size() + counts3[2];

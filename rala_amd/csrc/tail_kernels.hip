@@ -335,9 +335,9 @@ __global__ __launch_bounds__(kBlock) void tail_contain_kill_kernel(TailKillers K
 // what used to be a kernel, a fill and a copy)
 __global__ __launch_bounds__(kBlock) void tail_init_kernel(uint8_t* state, uint8_t* round, uint32_t n0, uint32_t m,
                                                            uint8_t* dirty, uint8_t* n_pits0, const uint8_t* n_pits,
-                                                           uint32_t n_reads, uint32_t* base2, uint8_t* mark2, uint32_t* map, uint32_t* zero6) {
+                                                           uint32_t n_reads, uint32_t* base2, uint8_t* mark2, uint32_t* map, uint32_t* zero22) {
     const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
-    if (k < 6) zero6[k] = 0;
+    if (k < 22) zero22[k] = 0;
     if (k < n_reads) {
         base2[k] = kInf; base2[n_reads + k] = kInf; map[k] = kInf;
         mark2[k] = 0; mark2[n_reads + k] = 0;
@@ -465,13 +465,13 @@ void launch_cc_edges(const TailList& L, const uint32_t* rank, uint32_t* edges, u
 void launch_refresh_types(const TailList& L, const TailReads& R, hipStream_t s) {
     if (L.n) hipLaunchKernelGGL(refresh_types_kernel, grid_for(L.n), dim3(kBlock), 0, s, L, R);
 }
-hipError_t launch_tail_contain(const TailList& L, uint8_t* alive, uint32_t* const lists[6], uint32_t* zeroed5, uint32_t* const work[4],
+hipError_t launch_tail_contain(const TailList& L, uint8_t* alive, uint32_t* const lists[6], uint32_t* zeroed21, uint32_t* const work[4],
                                uint32_t* base2, uint8_t* mark2, uint32_t* map, uint32_t* pack, uint32_t n_reads, hipStream_t s) {
     if (!L.n) return hipSuccess;
     TailKillers K;
     K.key = lists[0]; K.target = lists[1]; K.keeper = lists[2];
     K.c_key = lists[3]; K.c_target = lists[4]; K.c_keeper = lists[5];
-    K.error = zeroed5; K.count = zeroed5 + 1;
+    K.error = zeroed21; K.count = zeroed21 + 1;
     K.mark[0] = mark2; K.mark[1] = mark2 + n_reads;
     K.base[0] = base2; K.base[1] = base2 + n_reads;
     const uint32_t per_block = kCollectPer * kContainBlock;
@@ -481,7 +481,7 @@ hipError_t launch_tail_contain(const TailList& L, uint8_t* alive, uint32_t* cons
         if (c == 0) hipLaunchKernelGGL(tail_contain_reduce_kernel<0>, dim3(128), dim3(kBlock), 0, s, K, L.n, (const uint8_t*)alive);
         else hipLaunchKernelGGL(tail_contain_reduce_kernel<1>, dim3(128), dim3(kBlock), 0, s, K, L.n, (const uint8_t*)alive);
         const FixedPointList conditional = {K.c_key, K.c_target, K.c_keeper, K.count + 2 + c};
-        const hipError_t e = launch_fixed_point_finish(conditional, K.base[c], map, pack, work, K.error, nullptr, s);
+        const hipError_t e = launch_fixed_point_finish(conditional, K.base[c], map, pack, work, zeroed21 + 5 + 8 * c, K.error, nullptr, s);
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(tail_contain_apply_kernel, grid_for(L.n), dim3(kBlock), 0, s, L, (const uint8_t*)alive,
@@ -490,10 +490,10 @@ hipError_t launch_tail_contain(const TailList& L, uint8_t* alive, uint32_t* cons
     return hipGetLastError();
 }
 void launch_tail_init(const TailList& L, uint32_t n0, const TailReads& R, uint8_t* n_pits0, uint32_t n_reads, uint32_t* base2,
-                      uint8_t* mark2, uint32_t* map, uint32_t* zero6, hipStream_t s) {
-    const uint32_t n = std::max<uint32_t>(std::max<uint32_t>(L.n, n_reads), 6u);
+                      uint8_t* mark2, uint32_t* map, uint32_t* zero22, hipStream_t s) {
+    const uint32_t n = std::max<uint32_t>(std::max<uint32_t>(L.n, n_reads), 22u);
     hipLaunchKernelGGL(tail_init_kernel, grid_for(n), dim3(kBlock), 0, s, L.state, L.round, n0, L.n, R.dirty, n_pits0, R.n_pits, n_reads,
-                       base2, mark2, map, zero6);
+                       base2, mark2, map, zero22);
 }
 bool launch_rank_pass(const uint8_t* alive, uint32_t* rank, uint32_t* alive_reads, uint32_t n_reads, ScanSpace& space, hipStream_t s) {
     return launch_scan_pass(n_reads, RankPass{alive, rank, alive_reads}, space, s);
