@@ -83,8 +83,10 @@ const char* rala_hip_last_error(const rala_hip_ctx* ctx);
  * removal on the main stream before the bucketing and the pile chain's small kernels - event-dense
  * and longer reads - before its first one instead of beside it), "sensitive_in_device_memory" (default 0; 1 = the
  * sensitive overlaps handed to rala_hip_construct are device pointers), "host_threads",
- * "use_round_batches" (default 1; 0 makes the host look at the killer list after every round of the
- * containment fixed point instead of enqueuing five rounds per look once the list is short),
+ * "use_round_batches" (default 1: the containment fixed point of the second pass is finished on the device after two
+ * rounds; 0 makes the host look at the killer list after every round), "use_partitioned_buckets" (default 1; 0 buckets the
+ * target side through fixed slots), "debug_fp_lds_limit" (tests: containment fixed points with more killers than this
+ * take the kernel for lists that do not fit the LDS),
  * "debug_pile_stop_after" (diagnostics: leave the run-space pile kernel after phase k, 99 = all;
  * 100 * m + k: the same without the row stores (m = 1), tools/phase_probe.py) */
 int rala_hip_set_option(rala_hip_ctx* ctx, const char* key, int64_t value);

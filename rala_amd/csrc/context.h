@@ -93,6 +93,7 @@ struct rala_hip_ctx {
     std::unique_ptr<rala_hip::HostPool> pool;
     bool use_run_kernel = true;
     bool debug_fail_construct = false;          // tests: pass 2 fails on this context
+    uint32_t debug_fp_lds_limit = 0xFFFFFFFFu;  // tests: containment fixed points with more killers than this take the long lists' kernel
     bool use_round_batches = true;              // containment fixed point: several rounds per look at the counter
     rala_hip::DevBuf<uint32_t> d_round_log;     // list sizes after the rounds the host did not look at
 

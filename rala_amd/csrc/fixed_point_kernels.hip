@@ -25,6 +25,8 @@
 // length (one workgroup alone took 160 us per round for 24 k entries).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "kernels.h"
 
 namespace rala_hip {
@@ -48,7 +50,7 @@ constexpr uint32_t kPrepGroups = 48;
 
 __global__ __launch_bounds__(kPrepBlock) void fixed_point_assign_kernel(FixedPointList list, uint32_t* map) {
     const uint32_t n = *list.count;
-    if (n > kLdsEntries) return;
+    if (n > list.lds_limit) return;
     for (uint32_t i = blockIdx.x * kPrepBlock + threadIdx.x; i < n; i += gridDim.x * kPrepBlock) atomicMin(map + list.target[i], i);
 }
 
@@ -57,7 +59,7 @@ __global__ __launch_bounds__(kPrepBlock) void fixed_point_assign_kernel(FixedPoi
 __global__ __launch_bounds__(kPrepBlock) void fixed_point_prepare_kernel(FixedPointList list, const uint32_t* __restrict__ map,
                                                                          const uint32_t* __restrict__ base, uint32_t* __restrict__ pack) {
     const uint32_t n = *list.count;
-    if (n > kLdsEntries) return;
+    if (n > list.lds_limit) return;
     for (uint32_t i = blockIdx.x * kPrepBlock + threadIdx.x; i < n; i += gridDim.x * kPrepBlock) {
         const uint32_t t = list.target[i], kp = list.keeper[i];
         pack[i] = list.key[i];
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(kFinishBlock) void fixed_point_finish_kernel(FixedP
         if (rounds_out && tid == 0) *rounds_out = 0;
         return;
     }
-    if (n > kLdsEntries) return;                  // (fixed_point_wide_kernel's)
+    if (n > list.lds_limit) return;                  // (fixed_point_wide_kernel's)
     uint32_t r = 1;
     {
         constexpr uint32_t kPer = kFinishPer;
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(kFinishBlock) void fixed_point_wide_kernel(FixedPoi
                                                                         uint32_t* w2, uint32_t* w3, uint32_t* sync, uint32_t* error,
                                                                         uint32_t* rounds_out) {
     const uint32_t n = *list.count;
-    if (n <= kLdsEntries) return;                 // (fixed_point_finish_kernel's)
+    if (n <= list.lds_limit) return;                 // (fixed_point_finish_kernel's)
     constexpr uint32_t kPer = 4;
     const uint32_t groups = gridDim.x;
     const uint32_t stride = groups * kFinishBlock;
@@ -237,8 +239,10 @@ __global__ __launch_bounds__(kFinishBlock) void fixed_point_wide_kernel(FixedPoi
 
 size_t fixed_point_pack_words() { return 6 * (size_t)kLdsEntries; }
 
-hipError_t launch_fixed_point_finish(const FixedPointList& list, uint32_t* base, uint32_t* map, uint32_t* pack, uint32_t* const work[4],
+hipError_t launch_fixed_point_finish(const FixedPointList& list_in, uint32_t* base, uint32_t* map, uint32_t* pack, uint32_t* const work[4],
                                      uint32_t* sync8, uint32_t* error, uint32_t* rounds_out, hipStream_t s) {
+    FixedPointList list = list_in;
+    list.lds_limit = std::min<uint32_t>(list_in.lds_limit, kLdsEntries);
     constexpr size_t lds_bytes = 3 * (size_t)kLdsEntries * 4;
     static bool asked = false;
     if (!asked) {

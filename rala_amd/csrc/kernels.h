@@ -277,7 +277,7 @@ void launch_refresh_types(const TailList& L, const TailReads& R, hipStream_t s);
 // six arrays of L.n words (killers, conditional killers); zeroed21: 21 zeroed words ([0] is set when a fixed point failed); work: four arrays of n_reads words, uninitialised; base2: 2 * n_reads words, all ones, and mark2: 2 * n_reads
 // bytes, zero (tail_init); map, pack: launch_fixed_point_finish's
 hipError_t launch_tail_contain(const TailList& L, uint8_t* alive, uint32_t* const lists[6], uint32_t* zeroed21, uint32_t* const work[4],
-                               uint32_t* base2, uint8_t* mark2, uint32_t* map, uint32_t* pack, uint32_t n_reads, hipStream_t s);
+                               uint32_t* base2, uint8_t* mark2, uint32_t* map, uint32_t* pack, uint32_t n_reads, uint32_t lds_limit, hipStream_t s);
 void launch_count_zero_u8(const uint8_t* x, uint32_t n, uint32_t* out, hipStream_t s);    // *out += #zeros
 // list states (the first n0 items are overlaps, the rest internals), dirty[] = 0, n_pits0[] = n_pits[], base2[0 .. 2 n_reads) =
 // all ones, mark2[0 .. 2 n_reads) = 0, map[0 .. n_reads) = all ones, zero22[0 .. 21] = 0 in one launch
@@ -305,6 +305,7 @@ bool launch_offsets_pass(const uint32_t* in, uint32_t* out, uint32_t* copy, uint
 struct FixedPointList {
     const uint32_t *key, *target, *keeper;
     const uint32_t* count;
+    uint32_t lds_limit = 0xFFFFFFFFu;       // tests: lists longer than this take the long lists' kernel (at most what the LDS holds)
 };
 size_t fixed_point_pack_words();
 hipError_t launch_fixed_point_finish(const FixedPointList& list, uint32_t* base, uint32_t* map, uint32_t* pack, uint32_t* const work[4],

@@ -1182,7 +1182,7 @@ int gpu_tail_part_a(rala_hip_ctx* ctx) {
         uint32_t* const lists[6] = {ctx->d_kill[0].p, ctx->d_kill[1].p, ctx->d_kill[2].p, ctx->d_kill2[0].p, ctx->d_kill2[1].p,
                                     ctx->d_kill2[2].p};
         HIPCHECK(launch_tail_contain(L, ctx->d_alive.p, lists, ctx->d_counts.p + 9, work, ctx->d_t_fin.p, ctx->d_t_mark.p, ctx->d_fp_map.p,
-                                     ctx->d_fp_pack.p, n_reads, s));
+                                     ctx->d_fp_pack.p, n_reads, ctx->debug_fp_lds_limit, s));
     }
     mark("tail: containment scans", M);
     return RALA_HIP_OK;
@@ -1446,7 +1446,7 @@ int pass2(rala_hip_ctx* ctx, Comm* comm) {
             HIPCHECK(ctx->d_death[0].ensure(n_reads));
             HIPCHECK(ctx->d_t_work[0].ensure(n_reads));
             uint32_t* const work[4] = {up, lo, ctx->d_death[0].p, ctx->d_t_work[0].p};
-            const FixedPointList rest = {klist[cur].ovl, klist[cur].target, klist[cur].keeper, klist[cur].count};
+            const FixedPointList rest = {klist[cur].ovl, klist[cur].target, klist[cur].keeper, klist[cur].count, ctx->debug_fp_lds_limit};
             HIPCHECK(launch_fixed_point_finish(rest, sure, ctx->d_fp_map.p, ctx->d_fp_pack.p, work, ctx->d_counts.p + 32,
                                                ctx->d_counts.p + 1, ctx->d_counts.p + 2, s));
             finished_on_device = true;
@@ -1712,6 +1712,7 @@ int rala_hip_set_option(rala_hip_ctx* ctx, const char* key, int64_t value) {
     if (!strcmp(key, "debug_pile_stop_after")) { ctx->debug_pile_stop_after = value; return RALA_HIP_OK; }
     if (!strcmp(key, "use_run_kernel")) { ctx->use_run_kernel = value != 0; return RALA_HIP_OK; }
     if (!strcmp(key, "use_round_batches")) { ctx->use_round_batches = value != 0; return RALA_HIP_OK; }
+    if (!strcmp(key, "debug_fp_lds_limit")) { ctx->debug_fp_lds_limit = (uint32_t)std::max<int64_t>(0, value); return RALA_HIP_OK; }
     if (!strcmp(key, "debug_fail_construct")) { ctx->debug_fail_construct = value != 0; return RALA_HIP_OK; }
     if (!strcmp(key, "use_gpu_tail")) { ctx->use_gpu_tail = value != 0; return RALA_HIP_OK; }
     if (!strcmp(key, "use_fixed_buckets")) { ctx->use_fixed_buckets = value != 0; return RALA_HIP_OK; }

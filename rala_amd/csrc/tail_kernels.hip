@@ -466,7 +466,7 @@ void launch_refresh_types(const TailList& L, const TailReads& R, hipStream_t s) 
     if (L.n) hipLaunchKernelGGL(refresh_types_kernel, grid_for(L.n), dim3(kBlock), 0, s, L, R);
 }
 hipError_t launch_tail_contain(const TailList& L, uint8_t* alive, uint32_t* const lists[6], uint32_t* zeroed21, uint32_t* const work[4],
-                               uint32_t* base2, uint8_t* mark2, uint32_t* map, uint32_t* pack, uint32_t n_reads, hipStream_t s) {
+                               uint32_t* base2, uint8_t* mark2, uint32_t* map, uint32_t* pack, uint32_t n_reads, uint32_t lds_limit, hipStream_t s) {
     if (!L.n) return hipSuccess;
     TailKillers K;
     K.key = lists[0]; K.target = lists[1]; K.keeper = lists[2];
@@ -480,7 +480,7 @@ hipError_t launch_tail_contain(const TailList& L, uint8_t* alive, uint32_t* cons
     for (int c = 0; c < 2; ++c) {
         if (c == 0) hipLaunchKernelGGL(tail_contain_reduce_kernel<0>, dim3(128), dim3(kBlock), 0, s, K, L.n, (const uint8_t*)alive);
         else hipLaunchKernelGGL(tail_contain_reduce_kernel<1>, dim3(128), dim3(kBlock), 0, s, K, L.n, (const uint8_t*)alive);
-        const FixedPointList conditional = {K.c_key, K.c_target, K.c_keeper, K.count + 2 + c};
+        const FixedPointList conditional = {K.c_key, K.c_target, K.c_keeper, K.count + 2 + c, lds_limit};
         const hipError_t e = launch_fixed_point_finish(conditional, K.base[c], map, pack, work, zeroed21 + 5 + 8 * c, K.error, nullptr, s);
         if (e != hipSuccess) return e;
     }

@@ -73,6 +73,25 @@ def test_bucketing_variants(hip_ctx_factory, n, g, seed):
         parity.check_initialize(ctx, st, ds)
 
 
+@pytest.mark.parametrize("n,g,seed", [(3000, 600_000, 21), (5000, 1_000_000, 7), (600, 60_000, 9), (40_000, 8_000_000, 13)])
+@pytest.mark.parametrize("opts", [{"debug_fp_lds_limit": 0}, {"debug_fp_lds_limit": 40}, {"use_round_batches": 0}])
+def test_containment_fixed_point_variants(hip_ctx_factory, n, g, seed, opts):
+    """The ends of the containment fixed points (second pass, the tail's two scans; fixed_point_kernels.hip): every list
+    through the kernel for long lists (resident workgroups, a barrier per round; C5 takes it), a mix of both kernels,
+    and the host's loop of one look per round."""
+    ds = Dataset(n, g, seed)
+    st = parity.oracle_stages(ds)
+    ctx = hip_ctx_factory()
+    for k, v in opts.items():
+        ctx.set_option(k, v)
+    ctx.set_reads(ds.read_len)
+    ctx.set_overlaps(ds.overlaps)
+    ctx.initialize()
+    ctx.construct()
+    parity.check_construct(ctx, st)
+    parity.check_tr(ctx, st)
+
+
 @pytest.mark.parametrize("n,g,seed", [(3000, 600_000, 21), (2000, 1_200_000, 33), (600, 60_000, 9)])
 def test_host_tail_cross_check(hip_ctx_factory, n, g, seed):
     """use_gpu_tail = 0: Graph::preprocess on the host (the path the sensitive pass uses)."""
