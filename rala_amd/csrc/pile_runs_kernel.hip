@@ -380,8 +380,8 @@ __device__ __forceinline__ void store16(const char* base, uint32_t off, const ui
 }
 
 // kShort: the first kernel of the chain takes only reads of up to 16384 bases (the others go to the
-// next one): run starts in 16 bits, no sorted path, lists a little shorter - 6 656 bytes of LDS,
-// six wavefronts per SIMD instead of five.
+// next one): run starts in 16 bits, no sorted path, lists a little shorter, the last phases' lists inside the
+// region of the first phases' bitmap - 5 568 bytes of LDS, seven wavefronts per SIMD instead of five.
 // kBases: the reads the bitmap of run starts covers (one bit per position + a 16-bit prefix per word);
 // 16384 everywhere but in the chain's second kernel, the short layout for reads of up to 32768 bases
 // (9 728 bytes of LDS, four wavefronts per SIMD).

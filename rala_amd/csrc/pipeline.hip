@@ -1953,7 +1953,7 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
         // bucket counts).  A hand-over through a list behind the first kernel costs one atomic on
         // one counter per read (1 ms for 100 000 reads) and puts the small, latency-bound kernels
         // behind the big one (0.2 ms per C3 step); now they run beside it on a stream of their own:
-        //   main  up to 16384 bases, up to 512 events: run-space kernel, six wavefronts per SIMD,
+        //   main  up to 16384 bases, up to 512 events: run-space kernel, seven wavefronts per SIMD,
         //         one workgroup per read
         //   aux   more than 512 events (dense list) -> cap 1024;  up to 32768 bases -> the short
         //         layout with a bitmap twice the size (four wavefronts per SIMD, 9 % faster on
