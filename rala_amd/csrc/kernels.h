@@ -295,6 +295,9 @@ bool launch_segment_pass(const TailList& L, const TailReads& R, uint32_t want_st
                          uint32_t* e_len, ScanSpace& space, hipStream_t s);
 // out[i] = in[0] + .. + in[i - 1], out[n] = the sum; copy (may be null) receives out[0 .. n) as well
 bool launch_offsets_pass(const uint32_t* in, uint32_t* out, uint32_t* copy, uint32_t n, ScanSpace& space, hipStream_t s);
+// two of them side by side (sums below 2^31): out0[n], out1[n] and totals[0 .. 1] = the sums
+bool launch_pair_offsets_pass(const uint32_t* in0, const uint32_t* in1, uint32_t* out0, uint32_t* out1, uint32_t* totals, uint32_t n,
+                              ScanSpace& space, hipStream_t s);
 
 // ---- the end of a containment fixed point (fixed_point_kernels.hip) ------------------------------------
 // conditional killers {key, target, keeper} (*count of them, on the device); base: the deaths decided for good (all ones:

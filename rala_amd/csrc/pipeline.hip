@@ -1358,8 +1358,11 @@ int pass2(rala_hip_ctx* ctx, Comm* comm) {
     uint32_t* sure = ctx->d_death_sure.p;
     uint32_t* lo = sure + n_reads;
     const size_t dbytes = (size_t)n_reads * 4;
+    ScanSpace chunk_scan;
     {
         FillList fills;
+        const int rc = scan_space(ctx, 1, pass2_chunks(N), chunk_scan, &fills);
+        if (rc != RALA_HIP_OK) return rc;
         fills.add(ctx->d_kill_count.p, 0, (kCountRing + 4) * 4);
         fills.add(ctx->d_counts.p, 0, 48 * 4);
         fills.add(sure, 0xFF, 2 * dbytes + 4);
@@ -1395,12 +1398,13 @@ int pass2(rala_hip_ctx* ctx, Comm* comm) {
     constexpr uint32_t kNotSeen = 0xFFFFFFFFu;
     HIPCHECK(ctx->d_round_log.ensure(kLogged));
     std::vector<uint32_t> list_size;                             // after every round; kNotSeen = in the log
-    // (one GPU: the first round is not looked at - nobody is done after one round; after the second the host
-    // looks, and a list that is short by then - C3: 1.09 M undecided after the first round, 11 k after the
-    // second - is finished by ONE workgroup with the bounds in LDS (fixed_point_kernels.hip): no more launches
-    // per round, no more looks.  Before: six more rounds of four launches, two more looks.)
-    uint32_t unseen = gathered && ctx->use_round_batches ? 1u : 0u, n_logged = 0;
-    constexpr uint32_t kFinishAtMost = 1u << 20;                 // (beyond that a round over the whole list by all compute units pays)
+    // (one GPU: two rounds without a look from the host - C3: 1.09 M undecided after the first, 11 k after the
+    // second - and what is left is finished on the device (fixed_point_kernels.hip: one workgroup with the bounds
+    // in LDS, or a few resident workgroups for a long list): no more launches per round, no looks.  Before: six
+    // more rounds of four launches, three looks.)
+    const bool blind = comm == nullptr && ctx->use_round_batches;
+    uint32_t unseen = blind ? 1u : 0u, n_logged = 0;
+    constexpr uint32_t kFinishAtMost = 1u << 20;
     bool finished_on_device = false;
     uint64_t at_most = ~0ull;                                    // what the host knows of the current list's length
     for (;;) {
@@ -1413,6 +1417,23 @@ int pass2(rala_hip_ctx* ctx, Comm* comm) {
         launch_death_decide(klist[cur], lo, first_round ? nullptr : up, sure, klist[cur ^ 1], s, at_most);
         first_round = false;
         cur ^= 1;
+        auto finish_on_device = [&]() -> int {
+            // what is still undecided against sure[] as the deaths decided for good; up[], lo[] are free now
+            HIPCHECK(ctx->d_death[0].ensure(n_reads));
+            HIPCHECK(ctx->d_t_work[0].ensure(n_reads));
+            uint32_t* const work[4] = {up, lo, ctx->d_death[0].p, ctx->d_t_work[0].p};
+            const FixedPointList rest = {klist[cur].ovl, klist[cur].target, klist[cur].keeper, klist[cur].count, ctx->debug_fp_lds_limit};
+            HIPCHECK(launch_fixed_point_finish(rest, sure, ctx->d_fp_map.p, ctx->d_fp_pack.p, work, ctx->d_counts.p + 32,
+                                               ctx->d_counts.p + 1, ctx->d_counts.p + 2, s));
+            finished_on_device = true;
+            return (int)RALA_HIP_OK;
+        };
+        if (blind && list_size.size() == 1) {                   // the second round is done
+            list_size.push_back(kNotSeen);
+            const int rc = finish_on_device();
+            if (rc != RALA_HIP_OK) return rc;
+            break;
+        }
         // tighter bounds for the next round: up = sure, lo = min(sure, undecided killers)
         uint32_t undecided = 0;
         if (gathered && unseen && n_logged < kLogged) {
@@ -1442,14 +1463,9 @@ int pass2(rala_hip_ctx* ctx, Comm* comm) {
         if (list_size.size() > 100000) return fail(ctx, RALA_HIP_EDEVICE, "containment fixed point did not converge");
         if (!gathered) HIPCHECK(hipMemcpyAsync(up, sure, dbytes, hipMemcpyDeviceToDevice, s));
         if (gathered && ctx->use_round_batches && undecided <= kFinishAtMost) {
-            // what is still undecided against sure[] as the deaths decided for good; up[], lo[] are free now
-            HIPCHECK(ctx->d_death[0].ensure(n_reads));
-            HIPCHECK(ctx->d_t_work[0].ensure(n_reads));
-            uint32_t* const work[4] = {up, lo, ctx->d_death[0].p, ctx->d_t_work[0].p};
-            const FixedPointList rest = {klist[cur].ovl, klist[cur].target, klist[cur].keeper, klist[cur].count, ctx->debug_fp_lds_limit};
-            HIPCHECK(launch_fixed_point_finish(rest, sure, ctx->d_fp_map.p, ctx->d_fp_pack.p, work, ctx->d_counts.p + 32,
-                                               ctx->d_counts.p + 1, ctx->d_counts.p + 2, s));
-            finished_on_device = true;
+            // (sharded run: the ranks hold the same gathered list and the same bounds)
+            const int rc = finish_on_device();
+            if (rc != RALA_HIP_OK) return rc;
             break;
         }
         if (gathered) {
@@ -1506,16 +1522,18 @@ int pass2(rala_hip_ctx* ctx, Comm* comm) {
         if (comm->all_reduce_u32(ctx->d_t_tmp[0].p, ctx->pool_used, ReduceOp::kSum, s) != 0) return comm_fail("all-reduce of the hill counters");
         launch_hill_counts(rs, n_reads, ctx->d_t_tmp[0].p, 1, s);
     }
-    uint32_t n_surv[2] = {0, 0};
-    for (int k = 0; k < 2; ++k) {
-        launch_exclusive_scan(ctx->d_chunk[k].p, ctx->d_chunk[2 + k].p, n_chunks, ctx->d_scan_ws.p, s);
-        HIPCHECK(d2h_small(ctx, &n_surv[k], ctx->d_chunk[2 + k].p + n_chunks, 4, s));
+    // the chunks' places in the two survivor lists: one scan; its sums come back with the other counts
+    if (!launch_pair_offsets_pass(ctx->d_chunk[0].p, ctx->d_chunk[1].p, ctx->d_chunk[2].p, ctx->d_chunk[3].p, ctx->d_counts.p + 6,
+                                  n_chunks, chunk_scan, s)) {
+        return fail(ctx, RALA_HIP_EDEVICE, "scan space");
     }
     uint32_t round_log[64];
     if (n_logged) HIPCHECK(d2h_small(ctx, round_log, ctx->d_round_log.p, n_logged * 4, s));
-    uint32_t counts3[3] = {0, 0, 0};         // reads alive, the finishing kernel's verdict and rounds
-    HIPCHECK(d2h_small(ctx, counts3, ctx->d_counts.p + 0, 12, s));
+    uint32_t counts8[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // [0] reads alive, [1] the finishing kernel's verdict, [2] its rounds, [6 .. 7] survivors
+    HIPCHECK(d2h_small(ctx, counts8, ctx->d_counts.p + 0, 32, s));
     HIPCHECK(stream_sync(ctx, s));
+    const uint32_t n_surv[2] = {counts8[6], counts8[7]};
+    const uint32_t* counts3 = counts8;
     if (counts3[1]) {
         return fail(ctx, RALA_HIP_EDEVICE, counts3[1] == 1 ? "containment fixed point did not converge"
                                                            : "containment fixed point: the workgroups could not meet");

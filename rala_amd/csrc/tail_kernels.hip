@@ -442,6 +442,22 @@ struct OffsetsPass {
     __device__ void total(uint64_t sum) const { out[n] = (uint32_t)sum; }
 };
 
+// two exclusive scans side by side (the second pass' chunk counts of surviving overlaps and internals: both below 2^31);
+// out[n] = the sums, which also go to totals[0 .. 1]
+struct PairOffsetsPass {
+    const uint32_t *in0, *in1;
+    uint32_t *out0, *out1, *totals;
+    uint32_t n;
+    __device__ uint64_t value(uint32_t i) const { return (uint64_t)in0[i] | (uint64_t)in1[i] << 32; }
+    __device__ void place(uint32_t i, uint64_t, uint64_t before) const {
+        out0[i] = (uint32_t)before;
+        out1[i] = (uint32_t)(before >> 32);
+    }
+    __device__ void total(uint64_t sum) const {
+        out0[n] = totals[0] = (uint32_t)sum;
+        out1[n] = totals[1] = (uint32_t)(sum >> 32);
+    }
+};
 
 }  // namespace
 
@@ -509,6 +525,10 @@ bool launch_segment_pass(const TailList& L, const TailReads& R, uint32_t want_st
     f.L = L; f.R = R; f.want_state = want_state; f.want_round = want_round; f.base = base; f.kept_item = kept_item;
     f.node_rank = node_rank; f.e_src = e_src; f.e_dst = e_dst; f.e_len = e_len; f.next = next;
     return launch_scan_pass(L.n, f, space, s);
+}
+bool launch_pair_offsets_pass(const uint32_t* in0, const uint32_t* in1, uint32_t* out0, uint32_t* out1, uint32_t* totals, uint32_t n,
+                              ScanSpace& space, hipStream_t s) {
+    return launch_scan_pass(n, PairOffsetsPass{in0, in1, out0, out1, totals, n}, space, s);
 }
 bool launch_offsets_pass(const uint32_t* in, uint32_t* out, uint32_t* copy, uint32_t n, ScanSpace& space, hipStream_t s) {
     return launch_scan_pass(n, OffsetsPass{in, out, copy, n}, space, s);
