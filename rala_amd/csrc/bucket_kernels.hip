@@ -365,11 +365,9 @@ hipError_t launch_bucket_partitioned(const OvlSoA& o, uint32_t n_reads, uint32_t
     hipError_t e = fills.launch(s);
     if (e != hipSuccess) return e;
     const size_t lds_count = (size_t)n_part * kGroupsPerPart * 4;
-    static size_t asked_count = 64 * 1024;
-    if (lds_count > asked_count) {
+    if (lds_count > 64 * 1024) {        // (per launch: the attribute belongs to the function on the current device)
         e = hipFuncSetAttribute((const void*)group_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_count);
         if (e != hipSuccess) return e;
-        asked_count = lds_count;
     }
     const uint32_t chunks = (uint32_t)((o.n + kBlockC * 4 - 1) / (kBlockC * 4));
     hipLaunchKernelGGL(group_count_kernel, dim3(std::min<uint32_t>(workgroups ? workgroups : 256u, chunks)), dim3(kBlockC), lds_count, s, o,

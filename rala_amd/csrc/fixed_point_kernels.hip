@@ -244,12 +244,12 @@ hipError_t launch_fixed_point_finish(const FixedPointList& list_in, uint32_t* ba
     FixedPointList list = list_in;
     list.lds_limit = std::min<uint32_t>(list_in.lds_limit, kLdsEntries);
     constexpr size_t lds_bytes = 3 * (size_t)kLdsEntries * 4;
-    static bool asked = false;
-    if (!asked) {
+    // (every time: the attribute belongs to the function on the CURRENT device, and the ranks of a sharded run are threads
+    // of one process on different devices)
+    {
         const hipError_t e = hipFuncSetAttribute((const void*)fixed_point_finish_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                  (int)lds_bytes);
         if (e != hipSuccess) return e;
-        asked = true;
     }
     // (the list's length is on the device: every kernel looks at it and the ones it is not meant for leave at once)
     hipLaunchKernelGGL(fixed_point_assign_kernel, dim3(kPrepGroups), dim3(kPrepBlock), 0, s, list, map);

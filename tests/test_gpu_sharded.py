@@ -106,6 +106,20 @@ def test_sharded_run_matches_oracle(sharded_factory, world, n, g, seed):
     check_rank(sh.ranks[0].context(), st, n_tr)
 
 
+@pytest.mark.parametrize("limit", [0, 40])
+def test_sharded_run_fixed_points_through_the_long_lists_kernel(sharded_factory, limit):
+    """the gathered end of the second pass' fixed point and the tail's scans on every rank through the kernel for lists
+    that do not fit the LDS (resident workgroups, a barrier per round): three ranks on one GPU, each with its own"""
+    ds = Dataset(3000, 600_000, 21)
+    st = parity.oracle_stages(ds)
+    sh = sharded_factory(ds, 3)
+    for r in sh.ranks:
+        r.context().set_option("debug_fp_lds_limit", limit)
+    n_tr = sh.run()
+    for r in sh.ranks:
+        check_rank(r.context(), st, n_tr)
+
+
 def test_sharded_unordered_runs_and_unresolved_names(sharded_factory):
     """runs of equal queries with unresolved records inside them must not be cut (duplicate removal
     is per run, graph.cpp:343-350): shuffled runs, duplicates, names that do not resolve"""
