@@ -259,40 +259,72 @@ __global__ __launch_bounds__(kBlockP) void l2_scatter_kernel(const uint64_t* __r
     stage_and_copy(L, kGroupsPerPart, rec, bin, in, group_cursor + part * kGroupsPerPart, rec2, tmp);
 }
 
-// ---- final: one workgroup per 256 reads -------------------------------------------------------------------
-constexpr uint32_t kBlockF = 256;
-__global__ __launch_bounds__(kBlockF) void final_count_kernel(const uint64_t* __restrict__ rec2, const uint32_t* __restrict__ group_base,
-                                                              uint32_t n_reads, const uint32_t* __restrict__ acount,
-                                                              uint32_t* __restrict__ ecount) {
-    __shared__ uint32_t s_cnt[kGroupReads];
-    const uint32_t g = blockIdx.x;
-    if (threadIdx.x < kGroupReads) s_cnt[threadIdx.x] = 0;
-    __syncthreads();
-    const uint32_t lo = group_base[g], hi = group_base[g + 1];
-    for (uint32_t j = lo + threadIdx.x; j < hi; j += kBlockF) atomicAdd(&s_cnt[rec_key(rec2[j]) & (kGroupReads - 1u)], 1u);
-    __syncthreads();
-    const uint32_t r = g * kGroupReads + threadIdx.x;
-    if (threadIdx.x < kGroupReads && r < n_reads) ecount[r] = 2u * (acount[r] + s_cnt[threadIdx.x]);
+// ---- final: one workgroup per group of 128 reads -------------------------------------------------------
+// Where a group's events start follows from what is known once the first scatter is done - the group's records
+// (its target side, group_base[]) and its reads' query-side counts (acount[]): two small kernels add those up
+// (group_query_sum_kernel, group_event_base_kernel) and the final kernel does the rest per group - the events per
+// read (the group's records, counted in LDS), the reads' row offsets (a scan over 128 values), the rows.  (Before:
+// a counting kernel over all records, a device-wide scan of the per-read counts, then the writing kernel - the
+// records came from memory twice; now the second pass over a group's 50 KB of records finds them in the L2.)
+__global__ __launch_bounds__(kGroupReads) void group_query_sum_kernel(const uint32_t* __restrict__ acount, uint32_t n_reads,
+                                                                      uint32_t* __restrict__ qsum) {
+    __shared__ uint32_t tmp[kGroupReads / 64 + 1];
+    const uint32_t r = blockIdx.x * kGroupReads + threadIdx.x;
+    const uint32_t v = block_reduce<(int)kGroupReads>(r < n_reads ? acount[r] : 0u, OpAdd(), 0u, tmp);
+    if (threadIdx.x == 0) qsum[blockIdx.x] = v;
+}
+
+// pair_base[g] = bound PAIRS in front of group g's rows (exclusive prefix of query-side + target-side pairs), [n] = all
+__global__ __launch_bounds__(1024) void group_event_base_kernel(const uint32_t* __restrict__ qsum, const uint32_t* __restrict__ group_base,
+                                                                uint32_t n_groups, uint32_t* __restrict__ pair_base) {
+    __shared__ uint32_t tmp[1024 / 64 + 1];
+    uint32_t carry = 0;
+    for (uint32_t g0 = 0; g0 < n_groups; g0 += 1024) {
+        const uint32_t g = g0 + threadIdx.x;
+        const uint32_t c = g < n_groups ? qsum[g] + (group_base[g + 1] - group_base[g]) : 0u;
+        uint32_t tot;
+        const uint32_t ex = block_scan_excl<1024>(c, OpAdd(), 0u, tmp, tot);
+        if (g < n_groups) pair_base[g] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) pair_base[n_groups] = carry;
 }
 
 // target side: the group's records, tile by tile, sorted by read in LDS (as bound pairs) and copied out to the
 // reads' rows behind their query-side events: consecutive lanes write consecutive pairs of one read.
 // (Each record stored straight from the lane that read it - an 8-byte store to one of 12 000 places in a
 // window of 200 KB - took 0.75 ms at C3: one request per lane, whatever the L2 merges afterwards.)
-__global__ __launch_bounds__(kBlockP) void final_write_kernel(const uint64_t* __restrict__ rec2, const uint32_t* __restrict__ group_base,
-                                                              uint32_t n_reads, const uint32_t* __restrict__ acount,
-                                                              const uint32_t* __restrict__ ev_off, uint32_t* __restrict__ ev) {
+__global__ __launch_bounds__(kBlockP) void final_kernel(const uint64_t* __restrict__ rec2, const uint32_t* __restrict__ group_base,
+                                                        const uint32_t* __restrict__ pair_base, uint32_t n_reads,
+                                                        const uint32_t* __restrict__ acount, uint32_t* __restrict__ ev_off,
+                                                        uint32_t* __restrict__ ev) {
     extern __shared__ __align__(16) unsigned char s_raw[];
     __shared__ uint32_t tmp[kBlockP / 64 + 1];
     __shared__ uint32_t s_cursor[kGroupReads];          // next free PAIR of every read's row
+    __shared__ uint32_t s_cnt[kGroupReads];
+    static_assert(kGroupReads <= kBlockP, "one thread per read of the group");
     StageLds L(s_raw, kGroupReads);
     const uint32_t g = blockIdx.x;
-    if (threadIdx.x < kGroupReads) {
-        const uint32_t r = g * kGroupReads + threadIdx.x;
-        s_cursor[threadIdx.x] = r < n_reads ? ev_off[r] / 2u + acount[r] : 0u;      // (rows start at even offsets)
-    }
+    if (threadIdx.x < kGroupReads) s_cnt[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t lo = group_base[g], hi = group_base[g + 1];
+    for (uint32_t j = lo + threadIdx.x; j < hi; j += kBlockP) atomicAdd(&s_cnt[rec_key(rec2[j]) & (kGroupReads - 1u)], 1u);
+    __syncthreads();
+    {
+        // the reads' rows: query-side pairs, then target-side pairs; offsets in events (two per pair)
+        const uint32_t r = g * kGroupReads + threadIdx.x;
+        const bool mine = threadIdx.x < kGroupReads && r < n_reads;
+        const uint32_t q = mine ? acount[r] : 0u;
+        const uint32_t pairs = mine ? q + s_cnt[threadIdx.x] : 0u;
+        uint32_t tot;
+        const uint32_t before = pair_base[g] + block_scan_excl<(int)kBlockP>(pairs, OpAdd(), 0u, tmp, tot);
+        if (mine) {
+            ev_off[r] = 2u * before;
+            s_cursor[threadIdx.x] = before + q;
+            if (r == n_reads - 1u) ev_off[n_reads] = 2u * (before + pairs);
+        }
+    }
+    __syncthreads();
     for (uint32_t j0 = lo; j0 < hi; j0 += kTile) {
         uint64_t pair[kPer];
         uint32_t bin[kPer];
@@ -344,14 +376,13 @@ bool partition_path_fits(uint32_t n_reads, uint32_t max_read_len, uint64_t n_ove
            stage_lds_bytes((uint32_t)n_part) <= 60u * 1024u && 4ull * n_overlaps < 0xFFFFFFF0ull && n_overlaps / n_part >= 512;
 }
 
-// Buffers (device): acount, ecount, written: n_reads + 2 words each; part_cursor: n_part + 2 words; group: 3 *
+// Buffers (device): acount, written: n_reads + 2 words each; part_cursor: n_part + 2 words; group: 3 *
 // partition_group_slots(n_reads) words (counts, bases, cursors); tiles: 3 * partition_tile_slots words + 1; rec1,
-// rec2: partition_records_needed records; ev_off: n_reads + 2; ev: 4 * n_overlaps + 8.  scan: tile states for one
-// scan over n_reads (cleared by `fills`, which is launched here).  workgroups: compute units of the device (the counting kernel's persistent workgroups).
-hipError_t launch_bucket_partitioned(const OvlSoA& o, uint32_t n_reads, uint32_t* acount, uint32_t* ecount, uint32_t* written,
+// rec2: partition_records_needed records; ev_off: n_reads + 2; ev: 4 * n_overlaps + 8.  fills: launched here, with
+// what the caller has put in.  workgroups: compute units of the device (the counting kernel's persistent workgroups).
+hipError_t launch_bucket_partitioned(const OvlSoA& o, uint32_t n_reads, uint32_t* acount, uint32_t* written,
                                      uint32_t* part_cursor, uint32_t* group, uint32_t* tiles, uint64_t* rec1, uint64_t* rec2,
-                                     uint32_t* ev_off, uint32_t* ev, uint32_t workgroups, ScanSpace& scan, FillList& fills,
-                                     hipStream_t s) {
+                                     uint32_t* ev_off, uint32_t* ev, uint32_t workgroups, FillList& fills, hipStream_t s) {
     const uint32_t n_part = partition_count(n_reads);
     const uint32_t n_groups = (n_reads + kGroupReads - 1) / kGroupReads;
     const uint32_t group_slots = partition_group_slots(n_reads);
@@ -380,11 +411,13 @@ hipError_t launch_bucket_partitioned(const OvlSoA& o, uint32_t n_reads, uint32_t
     hipLaunchKernelGGL(l2_scatter_kernel, dim3(tiles2), dim3(kBlockP), stage_lds_bytes(kGroupsPerPart), s, (const uint64_t*)rec1,
                        (const uint32_t*)tile_part, (const uint32_t*)tile_lo, (const uint32_t*)tile_hi, (const uint32_t*)n_tiles, group_cursor,
                        rec2);
-    hipLaunchKernelGGL(final_count_kernel, dim3(n_groups), dim3(kBlockF), 0, s, (const uint64_t*)rec2, (const uint32_t*)group_base, n_reads,
-                       (const uint32_t*)acount, ecount);
-    if (!launch_offsets_pass(ecount, ev_off, nullptr, n_reads, scan, s)) return hipErrorOutOfMemory;
-    hipLaunchKernelGGL(final_write_kernel, dim3(n_groups), dim3(kBlockP), stage_lds_bytes(kGroupReads), s, (const uint64_t*)rec2,
-                       (const uint32_t*)group_base, n_reads, (const uint32_t*)acount, (const uint32_t*)ev_off, ev);
+    // (the groups' counts and cursors have served: their places take the query-side sums and the groups' first pairs)
+    uint32_t *qsum = group_count, *pair_base = group_cursor;
+    hipLaunchKernelGGL(group_query_sum_kernel, dim3(n_groups), dim3(kGroupReads), 0, s, (const uint32_t*)acount, n_reads, qsum);
+    hipLaunchKernelGGL(group_event_base_kernel, dim3(1), dim3(1024), 0, s, (const uint32_t*)qsum, (const uint32_t*)group_base, n_groups,
+                       pair_base);
+    hipLaunchKernelGGL(final_kernel, dim3(n_groups), dim3(kBlockP), stage_lds_bytes(kGroupReads), s, (const uint64_t*)rec2,
+                       (const uint32_t*)group_base, (const uint32_t*)pair_base, n_reads, (const uint32_t*)acount, ev_off, ev);
     hipLaunchKernelGGL(query_side_kernel, dim3((uint32_t)((o.n + 255) / 256)), dim3(256), 0, s, o, n_reads, (const uint32_t*)ev_off, written, ev);
     return hipGetLastError();
 }

@@ -334,9 +334,9 @@ uint32_t partition_group_slots(uint32_t n_reads);
 size_t partition_tile_slots(uint32_t n_reads, uint64_t n_overlaps);
 bool partition_path_fits(uint32_t n_reads, uint32_t max_read_len, uint64_t n_overlaps);
 // bound events of all reads as an exact CSR (ev_off[n_reads + 1], ev); buffer sizes: bucket_kernels.hip
-hipError_t launch_bucket_partitioned(const OvlSoA& o, uint32_t n_reads, uint32_t* acount, uint32_t* ecount, uint32_t* written,
+hipError_t launch_bucket_partitioned(const OvlSoA& o, uint32_t n_reads, uint32_t* acount, uint32_t* written,
                                      uint32_t* part_cursor, uint32_t* group, uint32_t* tiles, uint64_t* rec1, uint64_t* rec2,
-                                     uint32_t* ev_off, uint32_t* ev, uint32_t workgroups, ScanSpace& scan, FillList& fills, hipStream_t s);
+                                     uint32_t* ev_off, uint32_t* ev, uint32_t workgroups, FillList& fills, hipStream_t s);
 
 // ---- scans (scan_kernels.hip) --------------------------------------------------
 // exclusive prefix sum of n uint32 values; out may alias in; out[n] receives the total

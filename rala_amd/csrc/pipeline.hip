@@ -1905,14 +1905,9 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
         HIPCHECK(ctx->d_bk_group.ensure(3 * (size_t)partition_group_slots(n_reads)));
         HIPCHECK(ctx->d_bk_tiles.ensure(3 * partition_tile_slots(n_reads, ctx->n_ovl) + 2));
         for (int k = 0; k < 2; ++k) HIPCHECK(ctx->d_bk_rec[k].ensure(partition_records_needed(n_reads, ctx->n_ovl)));
-        ScanSpace sp;
-        {
-            const int rc = scan_space(ctx, 1, n_reads, sp, &fills);
-            if (rc != RALA_HIP_OK) return rc;
-        }
-        HIPCHECK(launch_bucket_partitioned(ctx->ovl, n_reads, ctx->d_bk_u32[0].p, ctx->d_bk_u32[1].p, ctx->d_bk_u32[2].p,
+        HIPCHECK(launch_bucket_partitioned(ctx->ovl, n_reads, ctx->d_bk_u32[0].p, ctx->d_bk_u32[2].p,
                                            ctx->d_bk_part.p, ctx->d_bk_group.p, ctx->d_bk_tiles.p, ctx->d_bk_rec[0].p,
-                                           ctx->d_bk_rec[1].p, ctx->d_ev_off.p, ctx->d_ev.p, ctx->n_compute_units, sp, fills, s));
+                                           ctx->d_bk_rec[1].p, ctx->d_ev_off.p, ctx->d_ev.p, ctx->n_compute_units, fills, s));
     }
     if (fixed) {
         HIPCHECK(ctx->d_ev_fixed.ensure((size_t)n_reads * slot + 8));
