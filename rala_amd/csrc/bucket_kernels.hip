@@ -84,12 +84,15 @@ __device__ __forceinline__ uint32_t segment_of(uint32_t key, bool active, uint32
 
 // ---- level 1: target >> 12 ------------------------------------------------------------------------
 constexpr uint32_t kBlockC = 1024;
+constexpr uint32_t kCountPer = 8;
 __global__ __launch_bounds__(kBlockC) void group_count_kernel(OvlSoA o, uint32_t n_reads, uint32_t n_groups, uint32_t* group_count) {
     extern __shared__ uint32_t s_hist[];
     for (uint32_t g = threadIdx.x; g < n_groups; g += kBlockC) s_hist[g] = 0;
     __syncthreads();
-    // this workgroup's share of the file: whole chunks of kBlockC * 4 overlaps, interleaved with the others'
-    constexpr uint32_t kC = 4;
+    // this workgroup's share of the file: whole chunks of kBlockC * kC overlaps, interleaved with the others'
+    // (the loads in flight are what sets this kernel's rate: 4 per thread and one workgroup per compute unit ran at
+    // 3 TB/s)
+    constexpr uint32_t kC = kCountPer;
     const uint64_t last = o.n - 1;
     for (uint64_t i0 = (uint64_t)blockIdx.x * kBlockC * kC; i0 < o.n; i0 += (uint64_t)gridDim.x * kBlockC * kC) {
         uint32_t a[kC], b[kC];
@@ -400,8 +403,10 @@ hipError_t launch_bucket_partitioned(const OvlSoA& o, uint32_t n_reads, uint32_t
         e = hipFuncSetAttribute((const void*)group_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_count);
         if (e != hipSuccess) return e;
     }
-    const uint32_t chunks = (uint32_t)((o.n + kBlockC * 4 - 1) / (kBlockC * 4));
-    hipLaunchKernelGGL(group_count_kernel, dim3(std::min<uint32_t>(workgroups ? workgroups : 256u, chunks)), dim3(kBlockC), lds_count, s, o,
+    const uint32_t chunks = (uint32_t)((o.n + kBlockC * kCountPer - 1) / (kBlockC * kCountPer));
+    // (two workgroups per compute unit where their histograms fit side by side)
+    const uint32_t count_groups = (workgroups ? workgroups : 256u) * (2 * lds_count <= 150u * 1024u ? 2u : 1u);
+    hipLaunchKernelGGL(group_count_kernel, dim3(std::min<uint32_t>(count_groups, chunks)), dim3(kBlockC), lds_count, s, o,
                        n_reads, n_part * kGroupsPerPart, group_count);
     hipLaunchKernelGGL(layout_kernel, dim3(1), dim3(1024), 0, s, (const uint32_t*)group_count, n_part, group_base, group_cursor, part_cursor,
                        tile_part, tile_lo, tile_hi, n_tiles);
