@@ -352,8 +352,9 @@ __global__ __launch_bounds__(256) void query_side_kernel(OvlSoA o, uint32_t n_re
                                                          uint32_t* written, uint32_t* __restrict__ ev) {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63;
-    uint32_t a = kInf, b = kInf;
-    if (i < o.n) { a = o.a_id[i]; b = o.b_id[i]; }
+    uint32_t a = kInf, b = kInf, begin = 0, end = 0;
+    // (the coordinates with the ids, not behind the add's round trip)
+    if (i < o.n) { a = o.a_id[i]; b = o.b_id[i]; begin = __builtin_nontemporal_load(o.a_begin + i); end = __builtin_nontemporal_load(o.a_end + i); }
     const bool ok = a < n_reads && b < n_reads;
     uint32_t leader;
     const uint32_t seg = segment_of(a, ok, lane, leader);
@@ -361,7 +362,7 @@ __global__ __launch_bounds__(256) void query_side_kernel(OvlSoA o, uint32_t n_re
     if (seg) base = ev_off[a] + atomicAdd(&written[a], 2u * seg);
     base = (uint32_t)__shfl((int)base, (int)leader, 64);
     if (!ok) return;
-    *(uint2*)(ev + base + 2u * (lane - leader)) = make_uint2((o.a_begin[i] + 15u) << 1, ((o.a_end[i] - 15u) << 1) | 1u);
+    *(uint2*)(ev + base + 2u * (lane - leader)) = make_uint2((begin + 15u) << 1, ((end - 15u) << 1) | 1u);
 }
 
 }  // namespace
