@@ -199,7 +199,9 @@ void launch_death_decide(const KillList& in, const uint32_t* lo, const uint32_t*
                          hipStream_t s, uint64_t at_most = ~0ull);
 // *changed = 1 if the two differ anywhere; `older` is then filled with 0xFFFFFFFF (the next round's output)
 void launch_death_diff(uint32_t* older, const uint32_t* newer, uint32_t n, uint32_t* changed, hipStream_t s);
-void launch_death_tighten(const uint32_t* sure, uint32_t* up, uint32_t* lo, uint32_t n, hipStream_t s);
+// (count, status: launch_death_status in the same launch)
+void launch_death_tighten(const uint32_t* sure, uint32_t* up, uint32_t* lo, uint32_t n, hipStream_t s, const uint32_t* count = nullptr,
+                          uint32_t* status = nullptr);
 // liveness + hill span counters + who survives (one mask word per 64 overlaps and kind, counts per chunk)
 void launch_survivor_masks(const OvlSoA& o, uint32_t n_reads, const uint8_t* valid, const uint8_t* fate, const uint32_t* death, const void* crec, bool small_records,
                            const uint4* rec, Interval* pool, uint64_t* mask_ov, uint64_t* mask_in, uint32_t* chunk_ov,
@@ -271,12 +273,15 @@ void launch_break_pits(const TailReads& R, const uint32_t* alive_reads, const ui
                        uint32_t n_alive, hipStream_t s, const uint32_t* gate = nullptr);
 void launch_retrim(const TailList& L, const TailReads& R, uint32_t promote, uint32_t round, uint32_t* dropped,
                    hipStream_t s, const uint32_t* gate = nullptr);
-void launch_cc_edges(const TailList& L, const uint32_t* rank, uint32_t* edges, uint8_t* touched, hipStream_t s);
+// (+ label[v] = v for v < n_labels: the components' start)
+void launch_cc_edges(const TailList& L, const uint32_t* rank, uint32_t* edges, uint8_t* touched, uint32_t* label, uint32_t n_labels,
+                     hipStream_t s);
 void launch_refresh_types(const TailList& L, const TailReads& R, hipStream_t s);
-// both in-order containment scans of the tail (graph.cpp:831-877) without a look from the host (tail_kernels.hip).  lists:
+// both in-order containment scans of the tail (graph.cpp:831-877) without a look from the host (tail_kernels.hip), stale
+// types refreshed on the way (launch_refresh_types' work).  lists:
 // six arrays of L.n words (killers, conditional killers); zeroed21: 21 zeroed words ([0] is set when a fixed point failed); work: four arrays of n_reads words, uninitialised; base2: 2 * n_reads words, all ones, and mark2: 2 * n_reads
 // bytes, zero (tail_init); map, pack: launch_fixed_point_finish's
-hipError_t launch_tail_contain(const TailList& L, uint8_t* alive, uint32_t* const lists[6], uint32_t* zeroed21, uint32_t* const work[4],
+hipError_t launch_tail_contain(const TailList& L, const TailReads& R, uint8_t* alive, uint32_t* const lists[6], uint32_t* zeroed21, uint32_t* const work[4],
                                uint32_t* base2, uint8_t* mark2, uint32_t* map, uint32_t* pack, uint32_t n_reads, uint32_t lds_limit, hipStream_t s);
 void launch_count_zero_u8(const uint8_t* x, uint32_t n, uint32_t* out, hipStream_t s);    // *out += #zeros
 // list states (the first n0 items are overlaps, the rest internals), dirty[] = 0, n_pits0[] = n_pits[], base2[0 .. 2 n_reads) =
@@ -359,11 +364,14 @@ void launch_cc_init(uint32_t* label, uint32_t n, hipStream_t s);
 void launch_cc_hook(const uint32_t* edges, uint32_t n_edges, uint32_t sample, uint32_t* label, uint32_t* changed,
                     hipStream_t s);
 void launch_cc_compress(uint32_t* label, uint32_t n, hipStream_t s);
+// the last compression of a component search and the sort keys of the component medians (median_kernels.hip) in one launch
+void launch_cc_compress_keys(uint32_t* label, uint32_t n, const uint8_t* touched, const uint32_t* reads, const uint16_t* median,
+                             uint64_t* keys, hipStream_t s);
 // median of the pile medians per component (median_kernels.hip); keys / sorted: n_alive uint64 each
 size_t component_median_workspace(uint32_t n);
 hipError_t launch_component_medians(const uint32_t* label, const uint8_t* touched, const uint32_t* alive_reads,
                                     const uint16_t* median, uint32_t n_alive, uint64_t* keys, uint64_t* sorted, void* tmp,
-                                    size_t tmp_bytes, uint16_t* cmed, hipStream_t s);
+                                    size_t tmp_bytes, uint16_t* cmed, hipStream_t s, bool keys_ready = false);
 void launch_tr_count(uint8_t* marks, uint32_t n_edges, uint32_t* n_pairs, hipStream_t s);    // also normalises the marks to 0 / 1
 
 // ---- force-directed layout step (layout_kernels.hip) -------------------------------------------

@@ -60,10 +60,10 @@ size_t component_median_workspace(uint32_t n) {
 
 hipError_t launch_component_medians(const uint32_t* label, const uint8_t* touched, const uint32_t* alive_reads,
                                     const uint16_t* median, uint32_t n_alive, uint64_t* keys, uint64_t* sorted, void* tmp,
-                                    size_t tmp_bytes, uint16_t* cmed, hipStream_t s) {
+                                    size_t tmp_bytes, uint16_t* cmed, hipStream_t s, bool keys_ready) {
     if (n_alive == 0) return hipSuccess;
     const dim3 grid((n_alive + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(median_keys_kernel, grid, dim3(kBlock), 0, s, label, touched, alive_reads, median, n_alive, keys);
+    if (!keys_ready) hipLaunchKernelGGL(median_keys_kernel, grid, dim3(kBlock), 0, s, label, touched, alive_reads, median, n_alive, keys);
     const hipError_t e = rocprim::radix_sort_keys(tmp, tmp_bytes, (const uint64_t*)keys, sorted, (size_t)n_alive, 0u,
                                                   kKeyBits, s);
     if (e != hipSuccess) return e;

@@ -601,9 +601,12 @@ __global__ __launch_bounds__(kBlock) void death_diff_kernel(uint32_t* __restrict
 
 // bounds for the next round of the containment fixed point: up = lo = sure (one pass instead of
 // two device-to-device copies)
+// (+ the list's length for the round count, when the host does not look at it: *status = all ones - *count)
 __global__ __launch_bounds__(kBlock) void death_tighten_kernel(const uint32_t* __restrict__ sure, uint32_t* __restrict__ up,
-                                                               uint32_t* __restrict__ lo, uint32_t n) {
+                                                               uint32_t* __restrict__ lo, uint32_t n, const uint32_t* count,
+                                                               uint32_t* status) {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i == 0 && status) *status = 0xFFFFFFFFu - *count;
     if (i >= n) return;
     const uint32_t v = sure[i];
     up[i] = v;
@@ -954,8 +957,9 @@ void launch_death_decide(const KillList& in, const uint32_t* lo, const uint32_t*
 void launch_death_diff(uint32_t* older, const uint32_t* newer, uint32_t n, uint32_t* changed, hipStream_t s) {
     if (n) hipLaunchKernelGGL(death_diff_kernel, grid_for(n), dim3(kBlock), 0, s, older, newer, n, changed);
 }
-void launch_death_tighten(const uint32_t* sure, uint32_t* up, uint32_t* lo, uint32_t n, hipStream_t s) {
-    if (n) hipLaunchKernelGGL(death_tighten_kernel, grid_for(n), dim3(kBlock), 0, s, sure, up, lo, n);
+void launch_death_tighten(const uint32_t* sure, uint32_t* up, uint32_t* lo, uint32_t n, hipStream_t s, const uint32_t* count,
+                          uint32_t* status) {
+    if (n) hipLaunchKernelGGL(death_tighten_kernel, grid_for(n), dim3(kBlock), 0, s, sure, up, lo, n, count, status);
 }
 void launch_survivor_masks(const OvlSoA& o, uint32_t n_reads, const uint8_t* valid, const uint8_t* fate, const uint32_t* death, const void* crec, bool small_records,
                            const uint4* rec, Interval* pool, uint64_t* mask_ov, uint64_t* mask_in, uint32_t* chunk_ov,

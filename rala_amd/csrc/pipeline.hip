@@ -1070,19 +1070,20 @@ int tail_components(rala_hip_ctx* ctx, const TailList& L, uint32_t n_alive, bool
     hipStream_t s = ctx->stream;
     const uint32_t M = L.n;
     if (!touched_cleared) HIPCHECK(hipMemsetAsync(ctx->d_touched.p, 0, n_alive, s));
-    launch_cc_edges(L, ctx->d_rank.p, ctx->d_cc_edges.p, ctx->d_touched.p, s);
-    launch_cc_init(ctx->d_cc_label.p, n_alive, s);
+    launch_cc_edges(L, ctx->d_rank.p, ctx->d_cc_edges.p, ctx->d_touched.p, ctx->d_cc_label.p, n_alive, s);
     for (int k = 0; k < 2; ++k) {                               // sampled rounds, see cc_hook_kernel
         launch_cc_hook(ctx->d_cc_edges.p, M, 1, ctx->d_cc_label.p, ctx->d_cc_flags.p + 7, s);
         launch_cc_compress(ctx->d_cc_label.p, n_alive, s);
     }
-    // one launch over all edges finishes the components (cc_hook_kernel unites to the end)
+    // one launch over all edges finishes the components (cc_hook_kernel unites to the end); the last compression
+    // writes the sort keys of the component medians with the labels
     launch_cc_hook(ctx->d_cc_edges.p, M, 0, ctx->d_cc_label.p, ctx->d_cc_flags.p + 7, s);
-    launch_cc_compress(ctx->d_cc_label.p, n_alive, s);
+    launch_cc_compress_keys(ctx->d_cc_label.p, n_alive, ctx->d_touched.p, ctx->d_alive_reads.p, ctx->d_median.p,
+                            ctx->d_med_keys[0].p, s);
     // median of the pile medians per component (graph.cpp:777-783)
     HIPCHECK(launch_component_medians(ctx->d_cc_label.p, ctx->d_touched.p, ctx->d_alive_reads.p, ctx->d_median.p, n_alive,
                                       ctx->d_med_keys[0].p, ctx->d_med_keys[1].p, ctx->d_med_tmp.p, ctx->t_med_tmp,
-                                      ctx->d_cmed.p, s));
+                                      ctx->d_cmed.p, s, true));
     return RALA_HIP_OK;
 }
 
@@ -1176,12 +1177,11 @@ int gpu_tail_part_a(rala_hip_ctx* ctx) {
     ctx->t_rounds = rounds;
 
     // in-order containment removal (graph.cpp:831-877): overlaps (+ promoted), then internals
-    launch_refresh_types(L, R, s);
     {
         uint32_t* const work[4] = {ctx->d_t_death[0].p, ctx->d_t_death[1].p, ctx->d_t_work[0].p, ctx->d_t_work[1].p};
         uint32_t* const lists[6] = {ctx->d_kill[0].p, ctx->d_kill[1].p, ctx->d_kill[2].p, ctx->d_kill2[0].p, ctx->d_kill2[1].p,
                                     ctx->d_kill2[2].p};
-        HIPCHECK(launch_tail_contain(L, ctx->d_alive.p, lists, ctx->d_counts.p + 9, work, ctx->d_t_fin.p, ctx->d_t_mark.p, ctx->d_fp_map.p,
+        HIPCHECK(launch_tail_contain(L, R, ctx->d_alive.p, lists, ctx->d_counts.p + 9, work, ctx->d_t_fin.p, ctx->d_t_mark.p, ctx->d_fp_map.p,
                                      ctx->d_fp_pack.p, n_reads, ctx->debug_fp_lds_limit, s));
     }
     mark("tail: containment scans", M);
@@ -1438,9 +1438,8 @@ int pass2(rala_hip_ctx* ctx, Comm* comm) {
         uint32_t undecided = 0;
         if (gathered && unseen && n_logged < kLogged) {
             --unseen;
-            launch_death_status(klist[cur].count, ctx->d_round_log.p + n_logged++, s);
             list_size.push_back(kNotSeen);
-            launch_death_tighten(sure, up, lo, n_reads, s);
+            launch_death_tighten(sure, up, lo, n_reads, s, klist[cur].count, ctx->d_round_log.p + n_logged++);
             launch_death_lower(klist[cur], lo, s, at_most);
             continue;
         }

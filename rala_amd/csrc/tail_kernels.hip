@@ -140,10 +140,13 @@ __global__ __launch_bounds__(kBlock) void retrim_kernel(TailList L, TailReads R,
     if (__ballot(died) != 0 && (threadIdx.x & 63) == 0) *dropped = 1u;
 }
 
-// edges of the component graph in rank space; dead items become self loops
+// edges of the component graph in rank space; dead items become self loops; every read its own component
+// (label[v] = v, v < n_labels: the start of the hooking rounds)
 __global__ __launch_bounds__(kBlock) void cc_edges_kernel(TailList L, const uint32_t* __restrict__ rank,
-                                                          uint32_t* __restrict__ edges, uint8_t* touched) {
+                                                          uint32_t* __restrict__ edges, uint8_t* touched,
+                                                          uint32_t* __restrict__ label, uint32_t n_labels) {
     const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
+    if (k < n_labels) label[k] = k;
     if (k >= L.n) return;
     const uint8_t st = L.state[k];
     uint32_t x = 0, y = 0;
@@ -229,7 +232,9 @@ struct BlockAppend {
     }
 };
 
-__global__ __launch_bounds__(kContainBlock) void tail_contain_collect_kernel(TailList L, const uint8_t* __restrict__ alive, TailKillers K) {
+// (types that went stale when coordinates or a region moved are refreshed on the way - refresh_types_kernel's work)
+__global__ __launch_bounds__(kContainBlock) void tail_contain_collect_kernel(TailList L, TailReads R, const uint8_t* __restrict__ alive,
+                                                                             TailKillers K) {
     __shared__ uint32_t s_cnt[2], s_base[2];
     if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
     __syncthreads();
@@ -241,7 +246,16 @@ __global__ __launch_bounds__(kContainBlock) void tail_contain_collect_kernel(Tai
         bool killer = false;
         cls[u] = 0; key[u] = 0; target[u] = 0; keeper[u] = 0;
         if (k < L.n) {
-            const uint8_t st = L.state[k], t = L.type[k];
+            const uint8_t st = L.state[k];
+            uint8_t t = L.type[k];
+            if (st != 0 && t == 255) {
+                const uint32_t a = L.a[k], b = L.b[k];
+                if (alive[a] && alive[b]) {
+                    const Coords c = item_coords(L, k);
+                    t = (uint8_t)ovl_type(c, L.strand[k], R.begin[a], R.end[a], R.begin[b], R.end[b]);
+                    L.type[k] = t;
+                }
+            }
             if (st != 0 && (t == kTypeA || t == kTypeB)) {
                 const uint32_t a = L.a[k], b = L.b[k];
                 if (alive[a] && alive[b]) {
@@ -475,13 +489,15 @@ void launch_retrim(const TailList& L, const TailReads& R, uint32_t promote, uint
                    hipStream_t s, const uint32_t* gate) {
     if (L.n) hipLaunchKernelGGL(retrim_kernel, grid_for(L.n), dim3(kBlock), 0, s, L, R, promote, round, dropped, gate);
 }
-void launch_cc_edges(const TailList& L, const uint32_t* rank, uint32_t* edges, uint8_t* touched, hipStream_t s) {
-    if (L.n) hipLaunchKernelGGL(cc_edges_kernel, grid_for(L.n), dim3(kBlock), 0, s, L, rank, edges, touched);
+void launch_cc_edges(const TailList& L, const uint32_t* rank, uint32_t* edges, uint8_t* touched, uint32_t* label, uint32_t n_labels,
+                     hipStream_t s) {
+    const uint32_t n = std::max<uint32_t>(L.n, n_labels);
+    if (n) hipLaunchKernelGGL(cc_edges_kernel, grid_for(n), dim3(kBlock), 0, s, L, rank, edges, touched, label, n_labels);
 }
 void launch_refresh_types(const TailList& L, const TailReads& R, hipStream_t s) {
     if (L.n) hipLaunchKernelGGL(refresh_types_kernel, grid_for(L.n), dim3(kBlock), 0, s, L, R);
 }
-hipError_t launch_tail_contain(const TailList& L, uint8_t* alive, uint32_t* const lists[6], uint32_t* zeroed21, uint32_t* const work[4],
+hipError_t launch_tail_contain(const TailList& L, const TailReads& R, uint8_t* alive, uint32_t* const lists[6], uint32_t* zeroed21, uint32_t* const work[4],
                                uint32_t* base2, uint8_t* mark2, uint32_t* map, uint32_t* pack, uint32_t n_reads, uint32_t lds_limit, hipStream_t s) {
     if (!L.n) return hipSuccess;
     TailKillers K;
@@ -491,7 +507,7 @@ hipError_t launch_tail_contain(const TailList& L, uint8_t* alive, uint32_t* cons
     K.mark[0] = mark2; K.mark[1] = mark2 + n_reads;
     K.base[0] = base2; K.base[1] = base2 + n_reads;
     const uint32_t per_block = kCollectPer * kContainBlock;
-    hipLaunchKernelGGL(tail_contain_collect_kernel, dim3((L.n + per_block - 1) / per_block), dim3(kContainBlock), 0, s, L,
+    hipLaunchKernelGGL(tail_contain_collect_kernel, dim3((L.n + per_block - 1) / per_block), dim3(kContainBlock), 0, s, L, R,
                        (const uint8_t*)alive, K);
     for (int c = 0; c < 2; ++c) {
         if (c == 0) hipLaunchKernelGGL(tail_contain_reduce_kernel<0>, dim3(128), dim3(kBlock), 0, s, K, L.n, (const uint8_t*)alive);

@@ -167,7 +167,25 @@ __global__ __launch_bounds__(kBlock) void cc_compress_kernel(uint32_t* label, ui
     label[v] = r;
 }
 
+// ... and, behind the last round, the sort key of the read's component median: label << 16 | pile median (all ones
+// for a read without an overlap) - median_kernels.hip
+__global__ __launch_bounds__(kBlock) void cc_compress_keys_kernel(uint32_t* label, uint32_t n, const uint8_t* __restrict__ touched,
+                                                                  const uint32_t* __restrict__ reads,
+                                                                  const uint16_t* __restrict__ median, uint64_t* __restrict__ keys) {
+    const uint32_t v = blockIdx.x * kBlock + threadIdx.x;
+    if (v >= n) return;
+    uint32_t r = label[v];
+    while (label[r] != r) r = label[r];
+    label[v] = r;
+    keys[v] = touched[v] ? ((uint64_t)r << 16) | median[reads[v]] : ~0ull;
+}
+
 }  // namespace
+
+void launch_cc_compress_keys(uint32_t* label, uint32_t n, const uint8_t* touched, const uint32_t* reads, const uint16_t* median,
+                             uint64_t* keys, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(cc_compress_keys_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, label, n, touched, reads, median, keys);
+}
 
 void launch_tr_degree(const uint32_t* src, const uint32_t* dst, uint32_t n_nodes, uint32_t n_edges, uint32_t* deg,
                       uint32_t* bad, hipStream_t s) {

@@ -27,7 +27,7 @@ for case in range(n_cases):
     n = int(rng.integers(300, 5000))
     cov = float(rng.choice([8, 20, 35, 60, 110]))
     g = int(max(30_000, n * 10_000 / cov))
-    plants = int(rng.integers(0, 16))
+    plants = int(rng.integers(0, 16)) | (16 if rng.random() < 0.2 else 0)      # + heavy-tailed read lengths
     try:
         ds = Dataset(n, g, seed, plants)
         variant = []
@@ -46,6 +46,8 @@ for case in range(n_cases):
         ctx.set_option("use_partitioned_buckets", int(rng.random() < 0.7))
         ctx.set_option("use_round_batches", int(rng.random() < 0.7))
         ctx.set_option("use_side_stream", int(rng.random() < 0.8))
+        if rng.random() < 0.4:      # the containment fixed points' long lists' kernel / a mix of both
+            ctx.set_option("debug_fp_lds_limit", int(rng.choice([0, 7, 100])))
         ctx.set_reads(ds.read_len)
         ctx.set_overlaps(ds.overlaps)
         try:
