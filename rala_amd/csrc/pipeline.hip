@@ -1221,16 +1221,18 @@ int gpu_tail_part_b(rala_hip_ctx* ctx) {
     // the final overlap list: originals in order, then the promoted ones round by round; the two edges of
     // every dovetail (graph.cpp:576-632) with it
     for (uint32_t seg = 0; seg < n_seg; ++seg) {
+        // (the last segment's sums - the totals - go next to the other counts the host fetches: d_counts[6 .. 7])
         if (!launch_segment_pass(L, R, seg == 0 ? 1u : 3u, seg == 0 ? 0u : seg - 1, ctx->d_seg_base.p + 2 * seg,
-                                 ctx->d_seg_base.p + 2 * (seg + 1), ctx->d_kept_item.p, ctx->d_node_rank.p, ctx->d_e[0].p,
+                                 seg + 1 == n_seg ? ctx->d_counts.p + 6 : ctx->d_seg_base.p + 2 * (seg + 1), ctx->d_kept_item.p,
+                                 ctx->d_node_rank.p, ctx->d_e[0].p,
                                  ctx->d_e[1].p, ctx->d_e[2].p, sp, s)) {
             return fail(ctx, RALA_HIP_EDEVICE, "scan space");
         }
     }
-    uint32_t totals[2] = {0, 0}, left[2] = {0, 0};
-    HIPCHECK(d2h_small(ctx, totals, ctx->d_seg_base.p + 2 * n_seg, 8, s));
-    HIPCHECK(d2h_small(ctx, left, ctx->d_counts.p + 8, 8, s));
+    uint32_t four[4] = {0, 0, 0, 0};         // kept items, dovetails, reads left, a containment scan that failed
+    HIPCHECK(d2h_small(ctx, four, ctx->d_counts.p + 6, 16, s));
     HIPCHECK(stream_sync(ctx, s));
+    const uint32_t totals[2] = {four[0], four[1]}, left[2] = {four[2], four[3]};
     HIPCHECK(hipGetLastError());
     if (getenv("RALA_HIP_TRACE")) {
         uint32_t kc[4] = {0, 0, 0, 0};
@@ -1527,7 +1529,7 @@ int pass2(rala_hip_ctx* ctx, Comm* comm) {
         return fail(ctx, RALA_HIP_EDEVICE, "scan space");
     }
     uint32_t round_log[64];
-    if (n_logged) HIPCHECK(d2h_small(ctx, round_log, ctx->d_round_log.p, n_logged * 4, s));
+    if (n_logged && !finished_on_device) HIPCHECK(d2h_small(ctx, round_log, ctx->d_round_log.p, n_logged * 4, s));
     uint32_t counts8[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // [0] reads alive, [1] the finishing kernel's verdict, [2] its rounds, [6 .. 7] survivors
     HIPCHECK(d2h_small(ctx, counts8, ctx->d_counts.p + 0, 32, s));
     HIPCHECK(stream_sync(ctx, s));
