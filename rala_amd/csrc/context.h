@@ -212,7 +212,6 @@ struct rala_hip_ctx {
     size_t t_med_tmp = 0;                 // bytes of d_med_tmp
     rala_hip::DevBuf<uint8_t> d_t_state, d_t_round, d_dirty, d_n_pits0, d_touched;
     rala_hip::DevBuf<uint16_t> d_cmed;
-    rala_hip::DevBuf<uint64_t> d_med_keys[2];
     rala_hip::DevBuf<uint8_t> d_med_tmp;
     rala_hip::DevBuf<uint32_t> d_cc_flags;
     rala_hip::DevBuf<uint32_t> d_kill[3], d_kill2[3], d_kill_count, d_death_sure;

@@ -364,14 +364,16 @@ void launch_cc_init(uint32_t* label, uint32_t n, hipStream_t s);
 void launch_cc_hook(const uint32_t* edges, uint32_t n_edges, uint32_t sample, uint32_t* label, uint32_t* changed,
                     hipStream_t s);
 void launch_cc_compress(uint32_t* label, uint32_t n, hipStream_t s);
-// the last compression of a component search and the sort keys of the component medians (median_kernels.hip) in one launch
-void launch_cc_compress_keys(uint32_t* label, uint32_t n, const uint8_t* touched, const uint32_t* reads, const uint16_t* median,
-                             uint64_t* keys, hipStream_t s);
-// median of the pile medians per component (median_kernels.hip); keys / sorted: n_alive uint64 each
+// the last compression of a component search with the components' sizes (reads with an overlap) for the component medians
+void launch_cc_compress_count(uint32_t* label, uint32_t n, const uint8_t* touched, uint32_t* size, hipStream_t s);
+// component medians (median_kernels.hip): tmp = component_median_workspace(n) bytes; before a search component_median_clear
+// puts what has to be zero into the caller's fill; launch_cc_compress_count(.., component_median_sizes(tmp, n), ..) ends the
+// search; then launch_component_medians: cmed[q] for every read q with an overlap
 size_t component_median_workspace(uint32_t n);
+void component_median_clear(void* tmp, uint32_t n, FillList& fills);
+uint32_t* component_median_sizes(void* tmp, uint32_t n);
 hipError_t launch_component_medians(const uint32_t* label, const uint8_t* touched, const uint32_t* alive_reads,
-                                    const uint16_t* median, uint32_t n_alive, uint64_t* keys, uint64_t* sorted, void* tmp,
-                                    size_t tmp_bytes, uint16_t* cmed, hipStream_t s, bool keys_ready = false);
+                                    const uint16_t* median, uint32_t n_alive, void* tmp, uint16_t* cmed, hipStream_t s);
 void launch_tr_count(uint8_t* marks, uint32_t n_edges, uint32_t* n_pairs, hipStream_t s);    // also normalises the marks to 0 / 1
 
 // ---- force-directed layout step (layout_kernels.hip) -------------------------------------------

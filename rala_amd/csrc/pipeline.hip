@@ -1069,21 +1069,24 @@ int scan_space(rala_hip_ctx* ctx, uint32_t scans, uint64_t items, ScanSpace& sp,
 int tail_components(rala_hip_ctx* ctx, const TailList& L, uint32_t n_alive, bool touched_cleared) {
     hipStream_t s = ctx->stream;
     const uint32_t M = L.n;
-    if (!touched_cleared) HIPCHECK(hipMemsetAsync(ctx->d_touched.p, 0, n_alive, s));
+    if (!touched_cleared) {
+        FillList fills;
+        fills.add(ctx->d_touched.p, 0, n_alive);
+        component_median_clear(ctx->d_med_tmp.p, n_alive, fills);
+        HIPCHECK(fills.launch(s));
+    }
     launch_cc_edges(L, ctx->d_rank.p, ctx->d_cc_edges.p, ctx->d_touched.p, ctx->d_cc_label.p, n_alive, s);
     for (int k = 0; k < 2; ++k) {                               // sampled rounds, see cc_hook_kernel
         launch_cc_hook(ctx->d_cc_edges.p, M, 1, ctx->d_cc_label.p, ctx->d_cc_flags.p + 7, s);
         launch_cc_compress(ctx->d_cc_label.p, n_alive, s);
     }
     // one launch over all edges finishes the components (cc_hook_kernel unites to the end); the last compression
-    // writes the sort keys of the component medians with the labels
+    // counts the components' reads with an overlap
     launch_cc_hook(ctx->d_cc_edges.p, M, 0, ctx->d_cc_label.p, ctx->d_cc_flags.p + 7, s);
-    launch_cc_compress_keys(ctx->d_cc_label.p, n_alive, ctx->d_touched.p, ctx->d_alive_reads.p, ctx->d_median.p,
-                            ctx->d_med_keys[0].p, s);
+    launch_cc_compress_count(ctx->d_cc_label.p, n_alive, ctx->d_touched.p, component_median_sizes(ctx->d_med_tmp.p, n_alive), s);
     // median of the pile medians per component (graph.cpp:777-783)
     HIPCHECK(launch_component_medians(ctx->d_cc_label.p, ctx->d_touched.p, ctx->d_alive_reads.p, ctx->d_median.p, n_alive,
-                                      ctx->d_med_keys[0].p, ctx->d_med_keys[1].p, ctx->d_med_tmp.p, ctx->t_med_tmp,
-                                      ctx->d_cmed.p, s, true));
+                                      ctx->d_med_tmp.p, ctx->d_cmed.p, s));
     return RALA_HIP_OK;
 }
 
@@ -1108,7 +1111,6 @@ int gpu_tail_part_a(rala_hip_ctx* ctx) {
     HIPCHECK(ctx->d_t_death[1].ensure(n_reads));
     HIPCHECK(ctx->d_touched.ensure(n_alive)); HIPCHECK(ctx->d_cmed.ensure(n_alive));
     HIPCHECK(ctx->d_cc_edges.ensure(2 * (size_t)M)); HIPCHECK(ctx->d_cc_label.ensure(n_alive));
-    HIPCHECK(ctx->d_med_keys[0].ensure(n_alive)); HIPCHECK(ctx->d_med_keys[1].ensure(n_alive));
     ctx->t_med_tmp = component_median_workspace(n_alive);
     HIPCHECK(ctx->d_med_tmp.ensure(ctx->t_med_tmp));
     HIPCHECK(ctx->d_cc_flags.ensure(8));
@@ -1159,6 +1161,7 @@ int gpu_tail_part_a(rala_hip_ctx* ctx) {
             FillList fills;
             fills.add(ctx->d_dirty.p, 0, n_reads);
             fills.add(ctx->d_touched.p, 0, n_alive);
+            component_median_clear(ctx->d_med_tmp.p, n_alive, fills);
             if (k == 0) fills.add(dropped, 0, 2 * 4);
             HIPCHECK(fills.launch(s));
             const int rcc = tail_components(ctx, L, n_alive, true);

@@ -167,24 +167,44 @@ __global__ __launch_bounds__(kBlock) void cc_compress_kernel(uint32_t* label, ui
     label[v] = r;
 }
 
-// ... and, behind the last round, the sort key of the read's component median: label << 16 | pile median (all ones
-// for a read without an overlap) - median_kernels.hip
-__global__ __launch_bounds__(kBlock) void cc_compress_keys_kernel(uint32_t* label, uint32_t n, const uint8_t* __restrict__ touched,
-                                                                  const uint32_t* __restrict__ reads,
-                                                                  const uint16_t* __restrict__ median, uint64_t* __restrict__ keys) {
+// ... and, behind the last round, the components' sizes in reads with an overlap (median_kernels.hip): one add per
+// WORKGROUP for the label its first such read has (an overlap graph is one big component and a few small ones: nearly
+// all reads share it, and adds to one word take about 10 ns apiece), one apiece for the others
+__global__ __launch_bounds__(kBlock) void cc_compress_count_kernel(uint32_t* label, uint32_t n, const uint8_t* __restrict__ touched,
+                                                                   uint32_t* size) {
+    __shared__ uint32_t s_label[kBlock / 64], s_any[kBlock / 64], s_cnt[kBlock / 64];
     const uint32_t v = blockIdx.x * kBlock + threadIdx.x;
-    if (v >= n) return;
-    uint32_t r = label[v];
-    while (label[r] != r) r = label[r];
-    label[v] = r;
-    keys[v] = touched[v] ? ((uint64_t)r << 16) | median[reads[v]] : ~0ull;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t r = 0;
+    if (v < n) {
+        r = label[v];
+        while (label[r] != r) r = label[r];
+        label[v] = r;
+    }
+    const bool t = v < n && touched[v];
+    const uint64_t m = __ballot(t);
+    const uint32_t first = (uint32_t)__shfl((int)r, m ? __ffsll((long long)m) - 1 : 0);
+    if (lane == 0) { s_any[wave] = m != 0; s_label[wave] = first; }
+    __syncthreads();
+    uint32_t shared = 0xFFFFFFFFu;
+    for (int w = kBlock / 64 - 1; w >= 0; --w) if (s_any[w]) shared = s_label[w];
+    if (shared == 0xFFFFFFFFu) return;
+    const bool same = t && r == shared;
+    const uint64_t ms = __ballot(same);
+    if (lane == 0) s_cnt[wave] = (uint32_t)__popcll(ms);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t c = 0;
+        for (int w = 0; w < kBlock / 64; ++w) c += s_cnt[w];
+        atomicAdd(&size[shared], c);
+    }
+    if (t && !same) atomicAdd(&size[r], 1u);
 }
 
 }  // namespace
 
-void launch_cc_compress_keys(uint32_t* label, uint32_t n, const uint8_t* touched, const uint32_t* reads, const uint16_t* median,
-                             uint64_t* keys, hipStream_t s) {
-    if (n) hipLaunchKernelGGL(cc_compress_keys_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, label, n, touched, reads, median, keys);
+void launch_cc_compress_count(uint32_t* label, uint32_t n, const uint8_t* touched, uint32_t* size, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(cc_compress_count_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, label, n, touched, size);
 }
 
 void launch_tr_degree(const uint32_t* src, const uint32_t* dst, uint32_t n_nodes, uint32_t n_edges, uint32_t* deg,
