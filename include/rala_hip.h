@@ -86,7 +86,8 @@ const char* rala_hip_last_error(const rala_hip_ctx* ctx);
  * "use_round_batches" (default 1: the containment fixed point of the second pass is finished on the device after two
  * rounds; 0 makes the host look at the killer list after every round), "use_partitioned_buckets" (default 1; 0 buckets the
  * target side through fixed slots), "debug_fp_lds_limit" (tests: containment fixed points with more killers than this
- * take the kernel for lists that do not fit the LDS),
+ * take the kernel for lists that do not fit the LDS), "use_bound_records" (default 1; sharded runs: 0 ships two bound tuples
+ * per overlap side instead of one bound record),
  * "debug_pile_stop_after" (diagnostics: leave the run-space pile kernel after phase k, 99 = all;
  * 100 * m + k: the same without the row stores (m = 1), tools/phase_probe.py) */
 int rala_hip_set_option(rala_hip_ctx* ctx, const char* key, int64_t value);
@@ -152,6 +153,16 @@ int rala_hip_emit_bound_tuples_bucketed(rala_hip_ctx* ctx, uint32_t world, uint6
  * LOCAL read number; other values are ignored).  rala_hip_initialize then skips duplicate
  * removal and builds / annotates the piles from these bounds. */
 int rala_hip_set_bound_tuples(rala_hip_ctx* ctx, const uint64_t* tuples, uint64_t n, int mem);
+/* Bound records: both bounds of one overlap side in ONE 8-byte element - local read (22 bits, as above) << 42 | begin (21
+ * bits) << 21 | end (21 bits), the raw coordinates of src/graph.cpp:317-324 (the +-15 is applied by the owner);
+ * coordinates of 2^21 - 1 and more are stored as 2^21 - 1 (outside every read the format is used for).  Half the bytes
+ * of the all-to-all, and the owner buckets them through the partitioned path (csrc/bucket_kernels.hip).
+ * rala_hip_bound_records_fit: 1 if every read is shorter than 2^21 - 32 bases and a rank owns fewer than 2^22 reads.
+ * _emit_: as rala_hip_emit_bound_tuples_bucketed, one record per overlap side (2 * n_overlaps at most).
+ * _set_: as rala_hip_set_bound_tuples. */
+int rala_hip_bound_records_fit(const rala_hip_ctx* ctx, uint32_t world);
+int rala_hip_emit_bound_records_bucketed(rala_hip_ctx* ctx, uint32_t world, uint64_t* records_dev, uint64_t* counts);
+int rala_hip_set_bound_records(rala_hip_ctx* ctx, const uint64_t* records, uint64_t n, int mem);
 /* Install the result of Graph::initialize computed elsewhere (gathered from the owners) into a
  * context that holds all reads and overlaps, so that rala_hip_construct can follow.  Host
  * arrays; interval CSR as returned by rala_hip_get_intervals (kinds 0 and 1). */

@@ -239,6 +239,56 @@ __global__ __launch_bounds__(kBlockP) void l1_scatter_kernel(OvlSoA o, uint32_t 
     stage_and_copy(L, n_part, rec, bin, in, part_cursor, rec1, tmp);
 }
 
+// ---- the same two kernels for an owner rank's input: bound records {local read : 22 | begin : 21 | end : 21}, both sides
+// of every overlap as records of their own (overlap_kernels.hip: bound_record) -------------------------------
+__device__ __forceinline__ uint32_t bound_record_read(uint64_t r) { return (uint32_t)(r >> (2 * kBoundRecordCoordBits)); }
+
+__global__ __launch_bounds__(kBlockC) void group_count_records_kernel(const uint64_t* __restrict__ records, uint64_t n, uint32_t n_reads,
+                                                                      uint32_t n_groups, uint32_t* group_count) {
+    extern __shared__ uint32_t s_hist[];
+    for (uint32_t g = threadIdx.x; g < n_groups; g += kBlockC) s_hist[g] = 0;
+    __syncthreads();
+    constexpr uint32_t kC = kCountPer;
+    for (uint64_t i0 = (uint64_t)blockIdx.x * kBlockC * kC; i0 < n; i0 += (uint64_t)gridDim.x * kBlockC * kC) {
+        uint32_t key[kC];
+#pragma unroll
+        for (uint32_t u = 0; u < kC; ++u) {
+            const uint64_t i = i0 + u * kBlockC + threadIdx.x;
+            key[u] = i < n ? bound_record_read(__builtin_nontemporal_load(records + i)) : kInf;
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < kC; ++u) {
+            if (key[u] < n_reads) atomicAdd(&s_hist[key[u] >> kGroupShift], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t g = threadIdx.x; g < n_groups; g += kBlockC) {
+        const uint32_t c = s_hist[g];
+        if (c) atomicAdd(&group_count[g], c);
+    }
+}
+
+__global__ __launch_bounds__(kBlockP) void l1_scatter_records_kernel(const uint64_t* __restrict__ records, uint64_t n, uint32_t n_reads,
+                                                                     uint32_t n_part, uint32_t* part_cursor, uint64_t* __restrict__ rec1) {
+    extern __shared__ __align__(16) unsigned char s_raw[];
+    __shared__ uint32_t tmp[kBlockP / 64 + 1];
+    StageLds L(s_raw, n_part);
+    uint64_t rec[kPer];
+    uint32_t bin[kPer];
+    bool in[kPer];
+    constexpr uint32_t kMask = (1u << kBoundRecordCoordBits) - 1u;
+#pragma unroll
+    for (uint32_t u = 0; u < kPer; ++u) {
+        const uint64_t i = (uint64_t)blockIdx.x * kTile + u * kBlockP + threadIdx.x;
+        const uint64_t r = i < n ? __builtin_nontemporal_load(records + i) : ~0ull;
+        const uint32_t key = bound_record_read(r);
+        in[u] = i < n && key < n_reads;
+        rec[u] = pack_record(key, (uint32_t)(r >> kBoundRecordCoordBits) & kMask, (uint32_t)r & kMask);
+        bin[u] = in[u] ? key >> kL1Shift : 0u;
+    }
+    stage_and_copy(L, n_part, rec, bin, in, part_cursor, rec1, tmp);
+}
+
 // ---- level 2: inside every partition, groups of 128 reads; tiles that do not cross a partition -------
 __global__ __launch_bounds__(kBlockP) void l2_scatter_kernel(const uint64_t* __restrict__ rec1, const uint32_t* __restrict__ tile_part,
                                                              const uint32_t* __restrict__ tile_lo, const uint32_t* __restrict__ tile_hi,
@@ -384,48 +434,106 @@ bool partition_path_fits(uint32_t n_reads, uint32_t max_read_len, uint64_t n_ove
 // partition_group_slots(n_reads) words (counts, bases, cursors); tiles: 3 * partition_tile_slots words + 1; rec1,
 // rec2: partition_records_needed records; ev_off: n_reads + 2; ev: 4 * n_overlaps + 8.  fills: launched here, with
 // what the caller has put in.  workgroups: compute units of the device (the counting kernel's persistent workgroups).
+namespace {
+struct PartitionBuffers {
+    uint32_t n_part, n_groups, group_slots;
+    size_t tile_slots;
+    uint32_t *group_count, *group_base, *group_cursor, *tile_part, *tile_lo, *tile_hi, *n_tiles;
+    PartitionBuffers(uint32_t n_reads, uint64_t n_records, uint32_t* group, uint32_t* tiles) {
+        n_part = partition_count(n_reads);
+        n_groups = (n_reads + kGroupReads - 1) / kGroupReads;
+        group_slots = partition_group_slots(n_reads);
+        tile_slots = partition_tile_slots(n_reads, n_records);
+        group_count = group; group_base = group + group_slots; group_cursor = group + 2 * (size_t)group_slots;
+        tile_part = tiles; tile_lo = tiles + tile_slots; tile_hi = tiles + 2 * tile_slots; n_tiles = tiles + 3 * tile_slots;
+    }
+};
+
+hipError_t count_attribute(size_t lds_count) {
+    if (lds_count > 64 * 1024) {        // (per launch: the attribute belongs to the function on the current device)
+        hipError_t e = hipFuncSetAttribute((const void*)group_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_count);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)group_count_records_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_count);
+        return e;
+    }
+    return hipSuccess;
+}
+
+// level 2 and the rows from the level-1 records
+void launch_partition_rest(const PartitionBuffers& B, uint32_t n_reads, const uint32_t* acount, const uint64_t* rec1, uint64_t* rec2,
+                           uint32_t* ev_off, uint32_t* ev, hipStream_t s) {
+    const uint32_t tiles2 = (uint32_t)(B.tile_slots - 4);               // at least as many as the table can hold
+    hipLaunchKernelGGL(l2_scatter_kernel, dim3(tiles2), dim3(kBlockP), stage_lds_bytes(kGroupsPerPart), s, rec1,
+                       (const uint32_t*)B.tile_part, (const uint32_t*)B.tile_lo, (const uint32_t*)B.tile_hi, (const uint32_t*)B.n_tiles,
+                       B.group_cursor, rec2);
+    // (the groups' counts and cursors have served: their places take the query-side sums and the groups' first pairs)
+    uint32_t *qsum = B.group_count, *pair_base = B.group_cursor;
+    hipLaunchKernelGGL(group_query_sum_kernel, dim3(B.n_groups), dim3(kGroupReads), 0, s, acount, n_reads, qsum);
+    hipLaunchKernelGGL(group_event_base_kernel, dim3(1), dim3(1024), 0, s, (const uint32_t*)qsum, (const uint32_t*)B.group_base, B.n_groups,
+                       pair_base);
+    hipLaunchKernelGGL(final_kernel, dim3(B.n_groups), dim3(kBlockP), stage_lds_bytes(kGroupReads), s, (const uint64_t*)rec2,
+                       (const uint32_t*)B.group_base, (const uint32_t*)pair_base, n_reads, acount, ev_off, ev);
+}
+}  // namespace
+
 hipError_t launch_bucket_partitioned(const OvlSoA& o, uint32_t n_reads, uint32_t* acount, uint32_t* written,
                                      uint32_t* part_cursor, uint32_t* group, uint32_t* tiles, uint64_t* rec1, uint64_t* rec2,
                                      uint32_t* ev_off, uint32_t* ev, uint32_t workgroups, FillList& fills, hipStream_t s) {
-    const uint32_t n_part = partition_count(n_reads);
-    const uint32_t n_groups = (n_reads + kGroupReads - 1) / kGroupReads;
-    const uint32_t group_slots = partition_group_slots(n_reads);
-    const size_t tile_slots = partition_tile_slots(n_reads, o.n);
-    uint32_t *group_count = group, *group_base = group + group_slots, *group_cursor = group + 2 * (size_t)group_slots;
-    uint32_t *tile_part = tiles, *tile_lo = tiles + tile_slots, *tile_hi = tiles + 2 * tile_slots, *n_tiles = tiles + 3 * tile_slots;
-    // (with whatever the caller wants cleared at this point, the scan's tile states among it)
+    const PartitionBuffers B(n_reads, o.n, group, tiles);
+    // (with whatever the caller wants cleared at this point)
     fills.add(acount, 0, (size_t)n_reads * 4);
     fills.add(written, 0, (size_t)n_reads * 4);
-    fills.add(group_count, 0, (size_t)group_slots * 4);
+    fills.add(B.group_count, 0, (size_t)B.group_slots * 4);
     hipError_t e = fills.launch(s);
     if (e != hipSuccess) return e;
-    const size_t lds_count = (size_t)n_part * kGroupsPerPart * 4;
-    if (lds_count > 64 * 1024) {        // (per launch: the attribute belongs to the function on the current device)
-        e = hipFuncSetAttribute((const void*)group_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_count);
-        if (e != hipSuccess) return e;
-    }
+    const size_t lds_count = (size_t)B.n_part * kGroupsPerPart * 4;
+    e = count_attribute(lds_count);
+    if (e != hipSuccess) return e;
     const uint32_t chunks = (uint32_t)((o.n + kBlockC * kCountPer - 1) / (kBlockC * kCountPer));
     // (two workgroups per compute unit where their histograms fit side by side)
     const uint32_t count_groups = (workgroups ? workgroups : 256u) * (2 * lds_count <= 150u * 1024u ? 2u : 1u);
     hipLaunchKernelGGL(group_count_kernel, dim3(std::min<uint32_t>(count_groups, chunks)), dim3(kBlockC), lds_count, s, o,
-                       n_reads, n_part * kGroupsPerPart, group_count);
-    hipLaunchKernelGGL(layout_kernel, dim3(1), dim3(1024), 0, s, (const uint32_t*)group_count, n_part, group_base, group_cursor, part_cursor,
-                       tile_part, tile_lo, tile_hi, n_tiles);
+                       n_reads, B.n_part * kGroupsPerPart, B.group_count);
+    hipLaunchKernelGGL(layout_kernel, dim3(1), dim3(1024), 0, s, (const uint32_t*)B.group_count, B.n_part, B.group_base, B.group_cursor,
+                       part_cursor, B.tile_part, B.tile_lo, B.tile_hi, B.n_tiles);
     const uint32_t tiles1 = (uint32_t)((o.n + kTile - 1) / kTile);
-    hipLaunchKernelGGL(l1_scatter_kernel, dim3(tiles1), dim3(kBlockP), stage_lds_bytes(n_part), s, o, n_reads, n_part, part_cursor, rec1, acount);
-    const uint32_t tiles2 = (uint32_t)(tile_slots - 4);                 // at least as many as the table can hold
-    hipLaunchKernelGGL(l2_scatter_kernel, dim3(tiles2), dim3(kBlockP), stage_lds_bytes(kGroupsPerPart), s, (const uint64_t*)rec1,
-                       (const uint32_t*)tile_part, (const uint32_t*)tile_lo, (const uint32_t*)tile_hi, (const uint32_t*)n_tiles, group_cursor,
-                       rec2);
-    // (the groups' counts and cursors have served: their places take the query-side sums and the groups' first pairs)
-    uint32_t *qsum = group_count, *pair_base = group_cursor;
-    hipLaunchKernelGGL(group_query_sum_kernel, dim3(n_groups), dim3(kGroupReads), 0, s, (const uint32_t*)acount, n_reads, qsum);
-    hipLaunchKernelGGL(group_event_base_kernel, dim3(1), dim3(1024), 0, s, (const uint32_t*)qsum, (const uint32_t*)group_base, n_groups,
-                       pair_base);
-    hipLaunchKernelGGL(final_kernel, dim3(n_groups), dim3(kBlockP), stage_lds_bytes(kGroupReads), s, (const uint64_t*)rec2,
-                       (const uint32_t*)group_base, (const uint32_t*)pair_base, n_reads, (const uint32_t*)acount, ev_off, ev);
+    hipLaunchKernelGGL(l1_scatter_kernel, dim3(tiles1), dim3(kBlockP), stage_lds_bytes(B.n_part), s, o, n_reads, B.n_part, part_cursor, rec1,
+                       acount);
+    launch_partition_rest(B, n_reads, acount, rec1, rec2, ev_off, ev, s);
     hipLaunchKernelGGL(query_side_kernel, dim3((uint32_t)((o.n + 255) / 256)), dim3(256), 0, s, o, n_reads, (const uint32_t*)ev_off, written, ev);
     return hipGetLastError();
+}
+
+// An owner rank's bound records (both sides of every overlap that touches one of its reads) into the same CSR.  zero_counts:
+// n_reads + 2 zeroed words (cleared here, through `fills`): no query side apart from the records.
+hipError_t launch_bucket_partitioned_records(const uint64_t* records, uint64_t n, uint32_t n_reads, uint32_t* zero_counts,
+                                             uint32_t* part_cursor, uint32_t* group, uint32_t* tiles, uint64_t* rec1, uint64_t* rec2,
+                                             uint32_t* ev_off, uint32_t* ev, uint32_t workgroups, FillList& fills, hipStream_t s) {
+    const PartitionBuffers B(n_reads, n, group, tiles);
+    fills.add(zero_counts, 0, (size_t)n_reads * 4);
+    fills.add(B.group_count, 0, (size_t)B.group_slots * 4);
+    hipError_t e = fills.launch(s);
+    if (e != hipSuccess) return e;
+    const size_t lds_count = (size_t)B.n_part * kGroupsPerPart * 4;
+    e = count_attribute(lds_count);
+    if (e != hipSuccess) return e;
+    const uint32_t chunks = (uint32_t)((n + kBlockC * kCountPer - 1) / (kBlockC * kCountPer));
+    const uint32_t count_groups = (workgroups ? workgroups : 256u) * (2 * lds_count <= 150u * 1024u ? 2u : 1u);
+    hipLaunchKernelGGL(group_count_records_kernel, dim3(std::min<uint32_t>(count_groups, std::max<uint32_t>(chunks, 1u))), dim3(kBlockC),
+                       lds_count, s, records, n, n_reads, B.n_part * kGroupsPerPart, B.group_count);
+    hipLaunchKernelGGL(layout_kernel, dim3(1), dim3(1024), 0, s, (const uint32_t*)B.group_count, B.n_part, B.group_base, B.group_cursor,
+                       part_cursor, B.tile_part, B.tile_lo, B.tile_hi, B.n_tiles);
+    const uint32_t tiles1 = (uint32_t)((n + kTile - 1) / kTile);
+    if (tiles1) {
+        hipLaunchKernelGGL(l1_scatter_records_kernel, dim3(tiles1), dim3(kBlockP), stage_lds_bytes(B.n_part), s, records, n, n_reads,
+                           B.n_part, part_cursor, rec1);
+    }
+    launch_partition_rest(B, n_reads, zero_counts, rec1, rec2, ev_off, ev, s);
+    return hipGetLastError();
+}
+
+// (n_records: an owner's records - two per overlap that stays on the rank)
+bool partition_path_fits_records(uint32_t n_reads, uint32_t max_read_len, uint64_t n_records) {
+    return max_read_len < (1u << kBoundRecordCoordBits) - 32u && partition_path_fits(n_reads, max_read_len, (n_records + 1) / 2);
 }
 
 }  // namespace rala_hip

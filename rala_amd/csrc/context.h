@@ -94,6 +94,7 @@ struct rala_hip_ctx {
     bool use_run_kernel = true;
     bool debug_fail_construct = false;          // tests: pass 2 fails on this context
     uint32_t debug_fp_lds_limit = 0xFFFFFFFFu;  // tests: containment fixed points with more killers than this take the long lists' kernel
+    bool use_bound_records = true;              // sharded runs: 8-byte bound records instead of two tuples per overlap side where they fit
     bool use_round_batches = true;              // containment fixed point: several rounds per look at the counter
     rala_hip::DevBuf<uint32_t> d_round_log;     // list sizes after the rounds the host did not look at
 
@@ -129,6 +130,9 @@ struct rala_hip_ctx {
     bool tuple_mode = false;
     uint64_t n_tuples = 0;
     const uint2* tuples = nullptr;      // {x = local read, y = bound}
+    const uint64_t* records = nullptr;  // bound records instead (rala_hip_set_bound_records): n_records of them
+    uint64_t n_records = 0;
+    rala_hip::DevBuf<uint64_t> d_record;
     rala_hip::DevBuf<uint2> d_tuple;
     rala_hip::DevBuf<uint32_t> d_owner_cnt;
     bool piles_resident = false;

@@ -161,8 +161,11 @@ void launch_scatter_bounds(const OvlSoA& o, uint32_t n_reads, const uint32_t* ev
 // bound tuples {x = read, y = bound} (8 bytes) instead of overlaps: multi-GPU owners receive them
 // by all-to-all
 void launch_emit_tuples(const OvlSoA& o, uint32_t n_reads, uint2* tuples, hipStream_t s);
+// records: one bound record {local read : 22 | begin : 21 | end : 21} per overlap side instead of two tuples
 void launch_bucket_tuples(const OvlSoA& o, uint32_t n_reads, uint32_t world, uint32_t pass, uint32_t* counters,
-                          uint2* tuples, hipStream_t s);
+                          uint2* tuples, hipStream_t s, bool records = false);
+void launch_records_to_tuples(const uint64_t* records, uint64_t n, uint2* tuples, hipStream_t s);
+constexpr uint32_t kBoundRecordCoordBits = 21, kBoundRecordReadBits = 22;
 void launch_count_tuples(const uint2* tuples, uint64_t n, uint32_t n_reads, uint32_t* counts, hipStream_t s);
 // sensitive overlaps (graph.cpp:882-1054): transmute_ + target bounds as tuples 2i, 2i + 1;
 // first trim; dovetails mark the repeat hills they bridge
@@ -342,6 +345,11 @@ bool partition_path_fits(uint32_t n_reads, uint32_t max_read_len, uint64_t n_ove
 hipError_t launch_bucket_partitioned(const OvlSoA& o, uint32_t n_reads, uint32_t* acount, uint32_t* written,
                                      uint32_t* part_cursor, uint32_t* group, uint32_t* tiles, uint64_t* rec1, uint64_t* rec2,
                                      uint32_t* ev_off, uint32_t* ev, uint32_t workgroups, FillList& fills, hipStream_t s);
+// the same from an owner rank's bound records (launch_bucket_tuples(.., records = true)): zero_counts = n_reads + 2 words
+bool partition_path_fits_records(uint32_t n_reads, uint32_t max_read_len, uint64_t n_records);
+hipError_t launch_bucket_partitioned_records(const uint64_t* records, uint64_t n, uint32_t n_reads, uint32_t* zero_counts,
+                                             uint32_t* part_cursor, uint32_t* group, uint32_t* tiles, uint64_t* rec1, uint64_t* rec2,
+                                             uint32_t* ev_off, uint32_t* ev, uint32_t workgroups, FillList& fills, hipStream_t s);
 
 // ---- scans (scan_kernels.hip) --------------------------------------------------
 // exclusive prefix sum of n uint32 values; out may alias in; out[n] receives the total

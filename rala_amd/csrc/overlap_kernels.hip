@@ -224,8 +224,19 @@ __device__ __forceinline__ void for_each_owner(uint32_t owner, F f) {
     }
 }
 
+// kRecords: ONE 8-byte element per overlap side instead of two - a bound record {local read : 22 | begin : 21 | end : 21}
+// (the raw coordinates, what lies beyond 2^21 - 2 stays there: outside every read this format is used for)
+constexpr uint32_t kRecordCoordBits = 21;
+constexpr uint32_t kRecordCoordMax = (1u << kRecordCoordBits) - 1u;
+__device__ __forceinline__ uint64_t bound_record(uint32_t local, uint32_t begin, uint32_t end) {
+    return (uint64_t)local << (2 * kRecordCoordBits) | (uint64_t)(begin < kRecordCoordMax ? begin : kRecordCoordMax) << kRecordCoordBits |
+           (uint64_t)(end < kRecordCoordMax ? end : kRecordCoordMax);
+}
+
+template <bool kRecords>
 __global__ __launch_bounds__(kBlock) void bucket_tuples_kernel(OvlSoA o, uint32_t n_reads, uint32_t world, uint32_t pass,
                                                                uint32_t* counters, uint2* __restrict__ tuples) {
+    constexpr uint32_t kEach = kRecords ? 1u : 2u;                 // elements per overlap side
     static_assert(kBlock == 256, "four wavefronts per workgroup");
     __shared__ uint32_t s_cnt[64], s_base[64];
     const uint32_t lane = threadIdx.x & 63;
@@ -246,7 +257,7 @@ __global__ __launch_bounds__(kBlock) void bucket_tuples_kernel(OvlSoA o, uint32_
         uint32_t read;
         const uint32_t owner = owner_of(first + k + lane, read);
         for_each_owner(owner, [&](uint32_t p, uint64_t m) {
-            if (lane == 0) atomicAdd(&s_cnt[p], 2u * (uint32_t)__popcll(m));
+            if (lane == 0) atomicAdd(&s_cnt[p], kEach * (uint32_t)__popcll(m));
         });
     }
     __syncthreads();
@@ -267,14 +278,15 @@ __global__ __launch_bounds__(kBlock) void bucket_tuples_kernel(OvlSoA o, uint32_
         const uint32_t owner = owner_of(i, read);
         for_each_owner(owner, [&](uint32_t p, uint64_t m) {
             uint32_t off = 0;
-            if (lane == 0) off = atomicAdd(&s_cnt[p], 2u * (uint32_t)__popcll(m));
+            if (lane == 0) off = atomicAdd(&s_cnt[p], kEach * (uint32_t)__popcll(m));
             off = (uint32_t)__shfl((int)off, 0, 64);
             if (owner == p) {
-                const uint32_t w = s_base[p] + off + 2u * (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                const uint32_t w = s_base[p] + off + kEach * (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
                 const uint32_t lo = side_b ? o.b_begin[i] : o.a_begin[i];
                 const uint32_t hi = side_b ? o.b_end[i] : o.a_end[i];
                 const uint32_t local = read / world;
-                *(uint4*)(tuples + w) = make_uint4(local, (lo + 15u) << 1, local, ((hi - 15u) << 1) | 1u);
+                if (kRecords) *(uint64_t*)(tuples + w) = bound_record(local, lo, hi);
+                else *(uint4*)(tuples + w) = make_uint4(local, (lo + 15u) << 1, local, ((hi - 15u) << 1) | 1u);
             }
         });
     }
@@ -912,11 +924,25 @@ void launch_emit_tuples(const OvlSoA& o, uint32_t n_reads, uint2* tuples, hipStr
     if (o.n) hipLaunchKernelGGL(emit_tuples_kernel, grid_for(o.n), dim3(kBlock), 0, s, o, n_reads, tuples);
 }
 void launch_bucket_tuples(const OvlSoA& o, uint32_t n_reads, uint32_t world, uint32_t pass, uint32_t* counters,
-                          uint2* tuples, hipStream_t s) {
-    if (o.n) {
-        hipLaunchKernelGGL(bucket_tuples_kernel, dim3((uint32_t)((o.n + kBucketChunk - 1) / kBucketChunk)), dim3(kBlock), 0, s, o, n_reads, world, pass, counters,
-                           tuples);
-    }
+                          uint2* tuples, hipStream_t s, bool records) {
+    if (!o.n) return;
+    const dim3 grid((uint32_t)((o.n + kBucketChunk - 1) / kBucketChunk));
+    if (records) hipLaunchKernelGGL(bucket_tuples_kernel<true>, grid, dim3(kBlock), 0, s, o, n_reads, world, pass, counters, tuples);
+    else hipLaunchKernelGGL(bucket_tuples_kernel<false>, grid, dim3(kBlock), 0, s, o, n_reads, world, pass, counters, tuples);
+}
+
+// a bound record as its two tuples (owners whose input does not suit the partitioned bucketing)
+__global__ __launch_bounds__(kBlock) void records_to_tuples_kernel(const uint64_t* __restrict__ records, uint64_t n,
+                                                                   uint2* __restrict__ tuples) {
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t r = records[i];
+    const uint32_t local = (uint32_t)(r >> (2 * kRecordCoordBits));
+    const uint32_t lo = (uint32_t)(r >> kRecordCoordBits) & kRecordCoordMax, hi = (uint32_t)r & kRecordCoordMax;
+    *(uint4*)(tuples + 2 * i) = make_uint4(local, (lo + 15u) << 1, local, ((hi - 15u) << 1) | 1u);
+}
+void launch_records_to_tuples(const uint64_t* records, uint64_t n, uint2* tuples, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(records_to_tuples_kernel, grid_for(n), dim3(kBlock), 0, s, records, n, tuples);
 }
 void launch_count_tuples(const uint2* tuples, uint64_t n, uint32_t n_reads, uint32_t* counts, hipStream_t s) {
     if (n) hipLaunchKernelGGL(count_tuples_kernel, grid_for(n), dim3(kBlock), 0, s, tuples, n, n_reads, counts);

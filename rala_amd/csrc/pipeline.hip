@@ -1734,6 +1734,7 @@ int rala_hip_set_option(rala_hip_ctx* ctx, const char* key, int64_t value) {
     if (!strcmp(key, "debug_pile_stop_after")) { ctx->debug_pile_stop_after = value; return RALA_HIP_OK; }
     if (!strcmp(key, "use_run_kernel")) { ctx->use_run_kernel = value != 0; return RALA_HIP_OK; }
     if (!strcmp(key, "use_round_batches")) { ctx->use_round_batches = value != 0; return RALA_HIP_OK; }
+    if (!strcmp(key, "use_bound_records")) { ctx->use_bound_records = value != 0; return RALA_HIP_OK; }
     if (!strcmp(key, "debug_fp_lds_limit")) { ctx->debug_fp_lds_limit = (uint32_t)std::max<int64_t>(0, value); return RALA_HIP_OK; }
     if (!strcmp(key, "debug_fail_construct")) { ctx->debug_fail_construct = value != 0; return RALA_HIP_OK; }
     if (!strcmp(key, "use_gpu_tail")) { ctx->use_gpu_tail = value != 0; return RALA_HIP_OK; }
@@ -1900,18 +1901,36 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
     // memory-side atomic and one partial write per overlap; ends in the exact CSR.  Needs the overlaps
     // (not tuples), coordinates below 2^26, enough overlaps per partition for the passes to pay, few enough
     // reads for a histogram of their groups of 128 to fit the LDS (9 M).
-    const bool partitioned = !ctx->tuple_mode && ctx->use_run_kernel && ctx->use_fixed_buckets && ctx->use_partitioned_buckets &&
-                             partition_path_fits(n_reads, ctx->max_read_len, ctx->n_ovl);
+    const bool partition_allowed = ctx->use_run_kernel && ctx->use_fixed_buckets && ctx->use_partitioned_buckets;
+    // (an owner rank's bound records: the same path from level 1 on, both sides as records; input that does not suit it
+    // is turned into tuples)
+    const bool from_records = ctx->tuple_mode && ctx->records != nullptr && partition_allowed &&
+                              partition_path_fits_records(n_reads, ctx->max_read_len, ctx->n_records);
+    if (ctx->tuple_mode && ctx->records != nullptr && !from_records) {
+        HIPCHECK(ctx->d_tuple.ensure(2 * ctx->n_records + 8));
+        launch_records_to_tuples(ctx->records, ctx->n_records, ctx->d_tuple.p, s);
+        ctx->tuples = ctx->d_tuple.p;
+        ctx->n_tuples = 2 * ctx->n_records;
+    }
+    const bool partitioned = from_records || (!ctx->tuple_mode && partition_allowed &&
+                                              partition_path_fits(n_reads, ctx->max_read_len, ctx->n_ovl));
     bool fixed = !partitioned && ctx->use_run_kernel && ctx->use_fixed_buckets && (uint64_t)n_reads * slot * 4ull <= (64ull << 30);
     if (partitioned) {
+        const uint64_t n_rec = from_records ? ctx->n_records : ctx->n_ovl;
         for (int k = 0; k < 3; ++k) HIPCHECK(ctx->d_bk_u32[k].ensure(n_reads + 2));
         HIPCHECK(ctx->d_bk_part.ensure(partition_count(n_reads) + 2));
         HIPCHECK(ctx->d_bk_group.ensure(3 * (size_t)partition_group_slots(n_reads)));
-        HIPCHECK(ctx->d_bk_tiles.ensure(3 * partition_tile_slots(n_reads, ctx->n_ovl) + 2));
-        for (int k = 0; k < 2; ++k) HIPCHECK(ctx->d_bk_rec[k].ensure(partition_records_needed(n_reads, ctx->n_ovl)));
-        HIPCHECK(launch_bucket_partitioned(ctx->ovl, n_reads, ctx->d_bk_u32[0].p, ctx->d_bk_u32[2].p,
-                                           ctx->d_bk_part.p, ctx->d_bk_group.p, ctx->d_bk_tiles.p, ctx->d_bk_rec[0].p,
-                                           ctx->d_bk_rec[1].p, ctx->d_ev_off.p, ctx->d_ev.p, ctx->n_compute_units, fills, s));
+        HIPCHECK(ctx->d_bk_tiles.ensure(3 * partition_tile_slots(n_reads, n_rec) + 2));
+        for (int k = 0; k < 2; ++k) HIPCHECK(ctx->d_bk_rec[k].ensure(partition_records_needed(n_reads, n_rec)));
+        if (from_records) {
+            HIPCHECK(launch_bucket_partitioned_records(ctx->records, ctx->n_records, n_reads, ctx->d_bk_u32[0].p, ctx->d_bk_part.p,
+                                                       ctx->d_bk_group.p, ctx->d_bk_tiles.p, ctx->d_bk_rec[0].p, ctx->d_bk_rec[1].p,
+                                                       ctx->d_ev_off.p, ctx->d_ev.p, ctx->n_compute_units, fills, s));
+        } else {
+            HIPCHECK(launch_bucket_partitioned(ctx->ovl, n_reads, ctx->d_bk_u32[0].p, ctx->d_bk_u32[2].p,
+                                               ctx->d_bk_part.p, ctx->d_bk_group.p, ctx->d_bk_tiles.p, ctx->d_bk_rec[0].p,
+                                               ctx->d_bk_rec[1].p, ctx->d_ev_off.p, ctx->d_ev.p, ctx->n_compute_units, fills, s));
+        }
     }
     if (fixed) {
         HIPCHECK(ctx->d_ev_fixed.ensure((size_t)n_reads * slot + 8));
@@ -2119,7 +2138,24 @@ int rala_hip_emit_bound_tuples(rala_hip_ctx* ctx, uint64_t* tuples_dev) {
     return RALA_HIP_OK;
 }
 
+namespace {
+int emit_bucketed(rala_hip_ctx* ctx, uint32_t world, uint64_t* tuples_dev, uint64_t* counts, bool records);
+}
 int rala_hip_emit_bound_tuples_bucketed(rala_hip_ctx* ctx, uint32_t world, uint64_t* tuples_dev, uint64_t* counts) {
+    return emit_bucketed(ctx, world, tuples_dev, counts, false);
+}
+int rala_hip_bound_records_fit(const rala_hip_ctx* ctx, uint32_t world) {
+    if (!ctx || world == 0) return 0;
+    const uint64_t local = (ctx->n_reads + world - 1) / world;
+    return ctx->max_read_len < (1u << kBoundRecordCoordBits) - 32u && local < (1ull << kBoundRecordReadBits) ? 1 : 0;
+}
+int rala_hip_emit_bound_records_bucketed(rala_hip_ctx* ctx, uint32_t world, uint64_t* records_dev, uint64_t* counts) {
+    if (!ctx) return RALA_HIP_EINVAL;
+    if (!rala_hip_bound_records_fit(ctx, world)) return fail(ctx, RALA_HIP_EINVAL, "reads too long or too many for bound records");
+    return emit_bucketed(ctx, world, records_dev, counts, true);
+}
+namespace {
+int emit_bucketed(rala_hip_ctx* ctx, uint32_t world, uint64_t* tuples_dev, uint64_t* counts, bool records) {
     if (!ctx || !tuples_dev || !counts || world == 0 || world > 64) return RALA_HIP_EINVAL;
     if (((uintptr_t)tuples_dev & 15u) != 0) return fail(ctx, RALA_HIP_EINVAL, "tuple buffer must be 16-byte aligned");
     HIPCHECK(hipSetDevice(ctx->device));
@@ -2128,7 +2164,7 @@ int rala_hip_emit_bound_tuples_bucketed(rala_hip_ctx* ctx, uint32_t world, uint6
     uint32_t* cnt = ctx->d_owner_cnt.p;
     uint32_t* cur = cnt + 64;
     HIPCHECK(hipMemsetAsync(cnt, 0, 2 * 64 * 4, s));
-    launch_bucket_tuples(ctx->ovl, (uint32_t)ctx->n_reads, world, 0, cnt, (uint2*)tuples_dev, s);
+    launch_bucket_tuples(ctx->ovl, (uint32_t)ctx->n_reads, world, 0, cnt, (uint2*)tuples_dev, s, records);
     uint32_t h[64];
     HIPCHECK(hipMemcpyAsync(h, cnt, world * 4, hipMemcpyDeviceToHost, s));
     HIPCHECK(stream_sync(ctx, s));
@@ -2136,11 +2172,12 @@ int rala_hip_emit_bound_tuples_bucketed(rala_hip_ctx* ctx, uint32_t world, uint6
     uint32_t acc = 0;
     for (uint32_t p = 0; p < world; ++p) { off[p] = acc; acc += h[p]; counts[p] = h[p]; }
     HIPCHECK(hipMemcpyAsync(cur, off, world * 4, hipMemcpyHostToDevice, s));
-    launch_bucket_tuples(ctx->ovl, (uint32_t)ctx->n_reads, world, 1, cur, (uint2*)tuples_dev, s);
+    launch_bucket_tuples(ctx->ovl, (uint32_t)ctx->n_reads, world, 1, cur, (uint2*)tuples_dev, s, records);
     HIPCHECK(stream_sync(ctx, s));
     HIPCHECK(hipGetLastError());
     return RALA_HIP_OK;
 }
+}  // namespace
 
 int rala_hip_get_device_state(rala_hip_ctx* ctx, rala_hip_device_state* out) {
     if (!ctx || !out) return RALA_HIP_EINVAL;
@@ -2247,12 +2284,41 @@ int rala_hip_set_bound_tuples(rala_hip_ctx* ctx, const uint64_t* tuples, uint64_
         ctx->tuples = ctx->d_tuple.p;
     }
     ctx->n_tuples = n;
+    ctx->records = nullptr;
+    ctx->n_records = 0;
     ctx->tuple_mode = true;
     ctx->inputs_set = true;
     ctx->n_ovl = 0;
     ctx->ovl = OvlSoA();
     HIPCHECK(ctx->d_ev.ensure(n + 8));
     HIPCHECK(ctx->d_scan_ws.ensure(scan_workspace_bytes(std::max<uint64_t>(n, ctx->n_reads) + 2)));
+    ctx->initialized = ctx->constructed = ctx->ev_ready = false;
+    return RALA_HIP_OK;
+}
+
+int rala_hip_set_bound_records(rala_hip_ctx* ctx, const uint64_t* records, uint64_t n, int mem) {
+    if (!ctx || (n && !records)) return RALA_HIP_EINVAL;
+    if (ctx->n_reads == 0) return fail(ctx, RALA_HIP_EINVAL, "no reads set");
+    if (n >= 0x7FFFFFF0ull) return fail(ctx, RALA_HIP_EINVAL, "too many records");
+    if (!rala_hip_bound_records_fit(ctx, 1)) return fail(ctx, RALA_HIP_EINVAL, "reads too long or too many for bound records");
+    HIPCHECK(hipSetDevice(ctx->device));
+    if (mem == RALA_HIP_MEM_DEVICE) {
+        ctx->records = records;
+    } else {
+        HIPCHECK(ctx->d_record.ensure(n + 8));
+        if (n) HIPCHECK(hipMemcpy(ctx->d_record.p, records, n * 8, hipMemcpyHostToDevice));
+        ctx->records = ctx->d_record.p;
+    }
+    if (!ctx->records) { HIPCHECK(ctx->d_record.ensure(8)); ctx->records = ctx->d_record.p; }   // (an empty share)
+    ctx->n_records = n;
+    ctx->tuples = nullptr;
+    ctx->n_tuples = 2 * n;              // (what the tuple paths would see)
+    ctx->tuple_mode = true;
+    ctx->inputs_set = true;
+    ctx->n_ovl = 0;
+    ctx->ovl = OvlSoA();
+    HIPCHECK(ctx->d_ev.ensure(2 * n + 8));
+    HIPCHECK(ctx->d_scan_ws.ensure(scan_workspace_bytes(std::max<uint64_t>(2 * n, ctx->n_reads) + 2)));
     ctx->initialized = ctx->constructed = ctx->ev_ready = false;
     return RALA_HIP_OK;
 }

@@ -201,15 +201,19 @@ int run_primary(rala_hip_mg* mg, bool with_sens) {
     };
     std::vector<uint64_t> all;
 
-    // 1. slice: duplicates, owner-grouped bound tuples
+    // 1. slice: duplicates, owner-grouped bounds - as bound records {local read, begin, end} (8 bytes per overlap side)
+    // where the reads are short and few enough for the format (rala_hip_bound_records_fit: the same answer on every
+    // rank, checked with the status word), as tuples {local read, bound} (two per side) otherwise
+    const bool records = cs->use_bound_records && rala_hip_bound_records_fit(cs, P) != 0;
     int rc = from_ctx(mg, cs, rala_hip_dedupe(cs), "dedupe");
     std::vector<uint64_t> send_counts(P, 0);
     if (rc == RALA_HIP_OK) {
         if (mg->d_send.ensure(4 * std::max<uint64_t>(cs->n_ovl, 1) + 8) != hipSuccess) rc = mg_fail(mg, RALA_HIP_ENOMEM, "tuple buffer");
+        else if (records) rc = from_ctx(mg, cs, rala_hip_emit_bound_records_bucketed(cs, P, (uint64_t*)mg->d_send.p, send_counts.data()), "emit records");
         else rc = from_ctx(mg, cs, rala_hip_emit_bound_tuples_bucketed(cs, P, (uint64_t*)mg->d_send.p, send_counts.data()), "emit tuples");
     }
     // (the bucket sizes travel with the status: one host exchange)
-    rc = agree_with(mg, rc, "emit", with_sens ? 1u : 0u, send_counts.data(), P, all);
+    rc = agree_with(mg, rc, "emit", (with_sens ? 1u : 0u) | (records ? 2u : 0u), send_counts.data(), P, all);
     if (rc != RALA_HIP_OK) return rc;
     lap(mg->tm.emit_ms);
 
@@ -226,7 +230,9 @@ int run_primary(rala_hip_mg* mg, bool with_sens) {
     for (uint32_t p = 0; p < P; ++p) if (p != mg->rank) mg->tm.tuples_sent += send_counts[p];
 
     // 3. owner: piles of the reads this rank owns
-    rc = from_ctx(mg, cl, rala_hip_set_bound_tuples(cl, (const uint64_t*)mg->d_recv.p, n_recv, RALA_HIP_MEM_DEVICE), "set tuples");
+    rc = from_ctx(mg, cl, records ? rala_hip_set_bound_records(cl, (const uint64_t*)mg->d_recv.p, n_recv, RALA_HIP_MEM_DEVICE)
+                                  : rala_hip_set_bound_tuples(cl, (const uint64_t*)mg->d_recv.p, n_recv, RALA_HIP_MEM_DEVICE),
+                  "set tuples");
     if (rc == RALA_HIP_OK) {
         rc = rala_hip_initialize(cl);
         if (rc == RALA_HIP_EFILTERED) rc = RALA_HIP_OK;      // all of ONE rank's reads filtered is not the job's verdict

@@ -27,6 +27,7 @@ SYMBOLS = (
     "rala_hip_get_graph", "rala_hip_get_timings", "rala_hip_get_num_prefiltered",
     "rala_hip_dedupe", "rala_hip_emit_bound_tuples", "rala_hip_set_bound_tuples", "rala_hip_import_state",
     "rala_hip_emit_bound_tuples_bucketed", "rala_hip_get_device_state", "rala_hip_import_state_device",
+    "rala_hip_bound_records_fit", "rala_hip_emit_bound_records_bucketed", "rala_hip_set_bound_records",
     "rala_hip_copy_device_state", "rala_hip_layout", "rala_hip_find_repetitive_hills",
     "rala_hip_mg_unique_id", "rala_hip_mg_local_group_create", "rala_hip_mg_local_group_destroy", "rala_hip_mg_create",
     "rala_hip_mg_destroy", "rala_hip_mg_last_error", "rala_hip_mg_set_reads", "rala_hip_mg_slice_cuts",

@@ -106,6 +106,27 @@ def test_sharded_run_matches_oracle(sharded_factory, world, n, g, seed):
     check_rank(sh.ranks[0].context(), st, n_tr)
 
 
+@pytest.mark.parametrize("n,g,seed,factor", [(3000, 600_000, 21, 1), (600, 60_000, 9, 1), (400, 80_000, 5, 230)])
+def test_sharded_run_bound_tuples_instead_of_records(sharded_factory, n, g, seed, factor):
+    """The bounds travel as 8-byte records {local read, begin, end} where the reads are shorter than 2^21 - 32 bases
+    (the default, every other test here); this is the older format - two tuples {local read, bound} per overlap side,
+    bucketed by the owners' single-pass kernel - by option, and by itself for reads of 2.3 M bases."""
+    from test_gpu_parity import _Scaled
+
+    ds = Dataset(n, g, seed)
+    if factor > 1:
+        ds = _Scaled(ds, factor)
+        assert int(ds.read_len.max()) > (1 << 21)
+    st = parity.oracle_stages(ds)
+    sh = sharded_factory(ds, 3)
+    if factor == 1:
+        for r in sh.ranks:
+            r.context().set_option("use_bound_records", 0)
+    n_tr = sh.run()
+    for r in sh.ranks:
+        check_rank(r.context(), st, n_tr)
+
+
 @pytest.mark.parametrize("limit", [0, 40])
 def test_sharded_run_fixed_points_through_the_long_lists_kernel(sharded_factory, limit):
     """the gathered end of the second pass' fixed point and the tail's scans on every rank through the kernel for lists
