@@ -296,3 +296,68 @@ def test_minimap2_shaped_paf(tmp_path, threads, tokenizer):
         assert e == -1, (p, mode)
         for f in want:
             assert got[f].tolist() == want[f], (p, mode, f)
+
+
+def _write_bgzf(src_path, dst_path, block=60000, level=1):
+    """what `bgzip` writes: gzip members of at most 64 KB with their compressed size in a 'BC' extra field, then the
+    empty end-of-file block (SAM specification, section 4.1)"""
+    import struct
+    import zlib
+
+    def member(data):
+        c = zlib.compressobj(level, zlib.DEFLATED, -15)
+        body = c.compress(data) + c.flush()
+        total = 18 + len(body) + 8
+        return (b"\x1f\x8b\x08\x04" + b"\x00" * 4 + b"\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, total - 1) +
+                body + struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data)))
+
+    with open(src_path, "rb") as src, open(dst_path, "wb") as dst:
+        while True:
+            data = src.read(block)
+            if not data:
+                break
+            dst.write(member(data))
+        dst.write(member(b""))
+
+
+@pytest.mark.parametrize("threads", [1, 2, 7, 16])
+def test_bgzf_is_inflated_by_several_threads(tmp_path, threads, tokenizer):
+    """a bgzip'ed PAF / MHAP (blocks inflated in parallel, given out in file order) = the plain file; a block whose
+    checksum is wrong and a file that ends inside a block are errors"""
+    import gzip
+
+    ds = Dataset(3000, 600_000, 6)
+    names = ["r%d" % i for i in range(ds.n_reads)]
+    paf = str(tmp_path / "ovl.paf")
+    ds.write_paf(paf)
+    want, e0 = parse(paf, names, ds.read_len, 1, 0)
+    bg = paf + ".gz"
+    _write_bgzf(paf, bg, block=int(np.random.default_rng(threads).integers(500, 65000)))
+    with gzip.open(bg, "rb") as f:                       # (a valid multi-member gzip file for anybody else)
+        assert len(f.read()) == os.path.getsize(paf)
+    got, e1 = parse(bg, names, ds.read_len, threads, 2)
+    assert e0 == e1 == -1
+    for f in want:
+        assert (want[f] == got[f]).all(), f
+    mhap = str(tmp_path / "ovl.mhap")
+    _to_mhap(paf, mhap)
+    _write_bgzf(mhap, mhap + ".gz")
+    seq, _ = parse(mhap, names, ds.read_len, 1, 4)
+    got, _ = parse(mhap + ".gz", names, ds.read_len, threads, 3)
+    for f in seq:
+        assert (seq[f] == got[f]).all(), f
+    # a flipped byte in the middle of a block: the checksum (or the deflate stream) fails
+    raw = bytearray(open(bg, "rb").read())
+    raw[len(raw) // 2] ^= 0x55
+    bad = str(tmp_path / "bad.paf.gz")
+    open(bad, "wb").write(bytes(raw))
+    L = _lib()
+    rl = np.ascontiguousarray(ds.read_len, dtype=np.uint32)
+    h = L.io_paf_parse(bad.encode(), "\n".join(names).encode(), rl.ctypes.data, len(names), 1, threads, 2)
+    assert not L.io_paf_ok(h)
+    L.io_paf_free(h)
+    cut = str(tmp_path / "cut.paf.gz")
+    open(cut, "wb").write(bytes(open(bg, "rb").read()[:os.path.getsize(bg) * 2 // 3]))
+    h = L.io_paf_parse(cut.encode(), "\n".join(names).encode(), rl.ctypes.data, len(names), 1, threads, 2)
+    assert not L.io_paf_ok(h)
+    L.io_paf_free(h)

@@ -1,6 +1,7 @@
 """End-to-end overlaps/s from PAF text (second figure): multi-threaded
 ingest + upload + the whole device path.  python tools/e2e_bench.py [c2|c3] [threads]
-RALA_E2E_GZIP=1: the same from a gzip-compressed file (gzip -1; one thread inflates, the others parse)."""
+RALA_E2E_GZIP=1: the same from a gzip-compressed file (gzip -1; one thread inflates, the others parse);
+RALA_E2E_GZIP=bgzf: from a BGZF file (what bgzip writes: blocks inflated by several threads)."""
 import ctypes
 import json
 import os
@@ -33,6 +34,30 @@ with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as d:
         subprocess.run(["gzip", "-1", paf], check=True)
         paf += ".gz"
         print("[e2e] gzip -1: %.2f GB in %.1f s" % (os.path.getsize(paf) / 1e9, time.time() - t0), file=sys.stderr)
+    elif os.environ.get("RALA_E2E_GZIP") == "bgzf":
+        # what bgzip writes: gzip members of 64 KB with their size in a "BC" extra field (inflated by several threads)
+        import struct
+        import zlib
+        from concurrent.futures import ThreadPoolExecutor
+
+        def member(data):
+            c = zlib.compressobj(1, zlib.DEFLATED, -15)
+            body = c.compress(data) + c.flush()
+            return (b"\x1f\x8b\x08\x04" + b"\x00" * 4 + b"\x00\xff" + struct.pack("<H", 6) + b"BC" +
+                    struct.pack("<HH", 2, 18 + len(body) + 8 - 1) + body + struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data)))
+
+        t0 = time.time()
+        with open(paf, "rb") as src, open(paf + ".gz", "wb") as dst, ThreadPoolExecutor(threads) as pool:
+            while True:
+                chunks = [c for c in (src.read(65280) for _ in range(4096)) if c]
+                if not chunks:
+                    break
+                for m in pool.map(member, chunks):
+                    dst.write(m)
+            dst.write(member(b""))
+        os.remove(paf)
+        paf += ".gz"
+        print("[e2e] bgzf: %.2f GB in %.1f s" % (os.path.getsize(paf) / 1e9, time.time() - t0), file=sys.stderr)
     best = None
     # RALA_E2E_AB=VAR: alternate runs without and with the environment variable VAR=1 (reader variants), report both
     ab = os.environ.get("RALA_E2E_AB")
