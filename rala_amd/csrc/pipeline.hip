@@ -1343,7 +1343,9 @@ int pass2(rala_hip_ctx* ctx, Comm* comm) {
     };
 
     // ---- static part ----
-    for (int k = 0; k < 3; ++k) HIPCHECK(ctx->d_kill[k].ensure(N + 1));
+    // (a sharded run gathers up to 65 536 undecided killers of ALL ranks on every rank: room for them whatever the slice's size)
+    const uint64_t kill_room = comm ? std::max<uint64_t>(N + 1, (1u << 16) + 1) : N + 1;
+    for (int k = 0; k < 3; ++k) HIPCHECK(ctx->d_kill[k].ensure(kill_room));
     // the killer lists' counters: a fresh, pre-zeroed one per round of the fixed point
     constexpr uint32_t kCountRing = 128;
     HIPCHECK(ctx->d_kill_count.ensure(kCountRing + 4));
@@ -1381,7 +1383,7 @@ int pass2(rala_hip_ctx* ctx, Comm* comm) {
     HIPCHECK(hipEventRecord(ctx->ev[5], s));
 
     // ---- in-order containment removal as a fixed point (death_decide_kernel) ----
-    for (int k = 0; k < 3; ++k) HIPCHECK(ctx->d_kill2[k].ensure(N + 1));
+    for (int k = 0; k < 3; ++k) HIPCHECK(ctx->d_kill2[k].ensure(kill_room));
     KillList klist[2] = {kl, kl};
     uint32_t next_count = 1;
     klist[1].ovl = ctx->d_kill2[0].p; klist[1].target = ctx->d_kill2[1].p; klist[1].keeper = ctx->d_kill2[2].p;
@@ -1492,8 +1494,7 @@ int pass2(rala_hip_ctx* ctx, Comm* comm) {
             for (uint64_t c : counts) total += c;
             uint32_t* src3[3] = {klist[cur].ovl, klist[cur].target, klist[cur].keeper};
             uint32_t* dst3[3] = {klist[cur ^ 1].ovl, klist[cur ^ 1].target, klist[cur ^ 1].keeper};
-            if (total > N + 1) for (int k = 0; k < 3; ++k) { HIPCHECK(ctx->d_kill[k].ensure(total + 1)); HIPCHECK(ctx->d_kill2[k].ensure(total + 1)); }
-            if (total > N + 1) return fail(ctx, RALA_HIP_EDEVICE, "killer list larger than the slice");    // (cannot happen: <= 65536)
+            if (total > kill_room) return fail(ctx, RALA_HIP_EDEVICE, "more undecided killers than there is room for");   // (cannot happen: <= 65536)
             for (int k = 0; k < 3; ++k) {
                 if (comm->all_gather_v(src3[k], dst3[k], counts.data(), 4, s) != 0) return comm_fail("all-gather of the undecided killers");
             }
