@@ -24,7 +24,7 @@ bad = 0
 for case in range(n_cases):
     seed = first + case
     rng = np.random.default_rng(seed)
-    n = int(rng.integers(300, 5000))
+    n = int(rng.integers(300, 5000)) * int(os.environ.get("RALA_FUZZ_SCALE", "1"))      # (RALA_FUZZ_SCALE=10: several partitions of the bucketing, tens of tiles)
     cov = float(rng.choice([8, 20, 35, 60, 110]))
     g = int(max(30_000, n * 10_000 / cov))
     plants = int(rng.integers(0, 16)) | (16 if rng.random() < 0.2 else 0)      # + heavy-tailed read lengths
