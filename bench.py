@@ -158,11 +158,10 @@ def main():
     if launched and args.gpus != world_env:
         raise SystemExit("bench.py: --gpus %d but the launcher started %d processes (WORLD_SIZE)" % (args.gpus, world_env))
     world = world_env if use_dist else args.gpus
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device")
     devices = [int(x) for x in args.devices.split(",") if x.strip() != ""] or list(range(world))
+    rccl_failed = None
     if use_threads:
-        have = torch.cuda.device_count()
+        have = torch.cuda.device_count()            # (does not initialise the GPU: a child process may still be started)
         if len(devices) != world:
             raise SystemExit("bench.py: --devices names %d devices for %d ranks" % (len(devices), world))
         if args.transport == "rccl" and (len(set(devices)) != world or max(devices) >= have):
@@ -171,6 +170,30 @@ def main():
                              % (world, world, have))
         if max(devices) >= have:
             raise SystemExit("bench.py: device %d does not exist (%d visible)" % (max(devices), have))
+        # RCCL with more than one rank has never run on the boxes this was built on (one GPU each).  A bare
+        # `bench.py --gpus N` therefore tries it in a CHILD process first and, should that fail or hang, runs the same
+        # ranks over the in-process transport (peer copies between the devices) - and says so in the line.
+        try_child = args.transport == "rccl" and "RALA_BENCH_CHILD" not in os.environ and \
+            (world > 1 or os.environ.get("RALA_BENCH_TEST_CHILD") == "1") and os.environ.get("RALA_BENCH_NO_FALLBACK") != "1"
+        if try_child:
+            import subprocess
+            limit = int(os.environ.get("RALA_BENCH_CHILD_TIMEOUT", "900"))
+            try:
+                r = subprocess.run([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=dict(os.environ, RALA_BENCH_CHILD="1"),
+                                   stdout=subprocess.PIPE, timeout=limit)
+                lines = [x for x in r.stdout.decode(errors="replace").splitlines() if x.startswith("{")]
+                if r.returncode == 0 and lines:
+                    print(lines[-1], flush=True)
+                    return
+                rccl_failed = "exit code %d" % r.returncode
+            except subprocess.TimeoutExpired:
+                rccl_failed = "no result within %d s" % limit
+            log("[bench] the RCCL run failed (%s): the same ranks over the in-process transport" % rccl_failed)
+            args.transport = "local"
+        if os.environ.get("RALA_BENCH_FAKE_RCCL_FAILURE") == "1" and "RALA_BENCH_CHILD" in os.environ and args.transport == "rccl":
+            raise SystemExit(3)                     # (tests: the child of the paragraph above fails)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device")
     if use_dist:
         import torch.distributed as dist
         if local_rank >= torch.cuda.device_count():
@@ -198,6 +221,8 @@ def main():
         from rala_amd import multi
         runner = multi.ThreadedRunner(ds, world, devices, args.transport)
         mode = "ranks as host threads of one process, %s" % ("RCCL" if args.transport == "rccl" else "in-process transport (peer copies)")
+        if rccl_failed:
+            mode += " - the RCCL run failed: " + rccl_failed
     else:
         ctx = hip.Context(local_rank)
         for kv in filter(None, os.environ.get("RALA_BENCH_OPTIONS", "").split(",")):    # diagnostics: key=value,...

@@ -55,3 +55,19 @@ def test_bench_end_to_end_figure_is_measured():
     e2e = line["end_to_end_from_paf"]
     assert e2e["value"] > 0 and "measured in this run" in e2e["source"]
     assert e2e["transitive_pairs"] == line["config"]["transitive_pairs"]
+
+
+def test_rccl_attempt_in_a_child_and_the_fallback():
+    """A bare `--gpus N` tries RCCL in a child process first (more than one RCCL rank has never run where this was
+    built); a child that fails sends the same ranks through the in-process transport, and the line says so.  Here with
+    a world of one (RALA_FORCE_SHARDED), the child forced by RALA_BENCH_TEST_CHILD."""
+    common = ("--workload", "c1", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-e2e")
+    ok = bench(*common, env={"RALA_FORCE_SHARDED": "1", "RALA_BENCH_TEST_CHILD": "1"})
+    assert ok.returncode == 0, ok.stderr[-2000:]
+    a = json.loads(ok.stdout.strip().splitlines()[-1])
+    assert "RCCL" in a["config"]["ranks"] and "failed" not in a["config"]["ranks"]
+    bad = bench(*common, env={"RALA_FORCE_SHARDED": "1", "RALA_BENCH_TEST_CHILD": "1", "RALA_BENCH_FAKE_RCCL_FAILURE": "1"})
+    assert bad.returncode == 0, bad.stderr[-2000:]
+    b = json.loads(bad.stdout.strip().splitlines()[-1])
+    assert "in-process transport" in b["config"]["ranks"] and "the RCCL run failed: exit code 3" in b["config"]["ranks"]
+    assert b["config"]["transitive_pairs"] == a["config"]["transitive_pairs"]
