@@ -19,10 +19,11 @@
 //                 add per (tile, partition) reserves the place.  Also the query-side event counts per read
 //                 (one add per wavefront segment).
 //   l2_scatter    the same inside every partition of 4096 reads: groups of 128 reads
-//   final_count   one workgroup per group: target-side events per read (LDS histogram) -> event counts
-//   (scan)        event counts -> ev_off
-//   final_write   one workgroup per group: the group's records at places handed out by LDS counters -
-//                 8-byte stores inside a window of 200 KB that the L2 merges into whole lines
+//   group sums    query-side pairs per group of 128 reads (acount[] from l1_scatter) and, with the groups' record counts,
+//                 where every group's rows start (two small kernels)
+//   final         one workgroup per group: target-side events per read (LDS histogram), the reads' row offsets (scan over
+//                 128 values) -> ev_off, then the group's records at places handed out by LDS counters - 8-byte stores
+//                 inside a window of 200 KB that the L2 merges into whole lines
 //   query_side    one thread per overlap, as in the single-pass kernel: segment base from one atomic
 //
 // Sizes are counted, not guessed: files that name every pair once, query = the lower id, make a read a target
