@@ -1,12 +1,12 @@
 ROOT=$GRAFT_REPO_ROOT
 mkdir -p $ROOT/gpurun_out/pmc
 cd /tmp && export TMPDIR=/tmp
-STOPS=22,23,24,25,26,27,28,99
+STOPS=141,142,143,122,123,124,131,125,144,145,126,127,128,77
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY --output-format csv -d $ROOT/gpurun_out/pmc/p3 -- python3 $ROOT/tools/pile_once.py c2 $STOPS > $ROOT/gpurun_out/pmc/p3.log 2>&1
 cd $ROOT
 python3 - <<'PY'
 import csv, glob, collections, os
-stops = [22,23,24,25,26,27,28,99]
+stops = [141,142,143,122,123,124,131,125,144,145,126,127,128,77]
 for f in glob.glob("gpurun_out/pmc/p3/*/*counter_collection.csv"):
     per = collections.defaultdict(dict)
     for row in csv.DictReader(open(f)):
