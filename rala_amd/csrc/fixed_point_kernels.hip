@@ -19,7 +19,7 @@
 // took 130 us for 11 k entries: values written with atomics are read from the memory side, and one compute
 // unit has only so many requests in flight.)  A keeper that no listed killer targets is a constant,
 // base[keeper].  Longer lists (C5: 73 k undecided killers after the second round of the second pass, 17 k conditional
-// ones in the tail): all workgroups of the rounds kernel (finish_wide) - X in four work arrays in global memory, a few workgroups that are
+// ones in the tail): fixed_point_wide_kernel - X in four work arrays in global memory, a few workgroups that are
 // resident together, a barrier between them per round.  What other wavefronts write with atomics is then read past
 // the vector cache, on this device from the memory side: 20 - 30 us per round instead of 2, whatever the list's
 // length (one workgroup alone took 160 us per round for 24 k entries).
@@ -231,17 +231,21 @@ __device__ __forceinline__ void finish_wide(const FixedPointList& list, uint32_t
     if (rounds_out && gtid == 0) *rounds_out = r - 1;
 }
 
-// the rounds: a list that fits the LDS is the first workgroup's alone (the others leave), a longer one everybody's
-__global__ __launch_bounds__(kFinishBlock) void fixed_point_rounds_kernel(FixedPointList list, uint32_t* base, uint32_t* map,
-                                                                          const uint32_t* __restrict__ pack, uint32_t* w0, uint32_t* w1,
-                                                                          uint32_t* w2, uint32_t* w3, uint32_t* sync, uint32_t* error,
+// The rounds: a list that fits the LDS is one workgroup's, a longer one the resident workgroups'.  Two kernels, both
+// launched (the list's length is on the device; the one it is not meant for leaves at once): the second needs no LDS, and a
+// kernel that asked for 144 KB of it for every workgroup would need a compute unit per workgroup - eight ranks sharing a GPU
+// (the tests do that) would then need every compute unit of the device at the same time to get through their barriers.
+__global__ __launch_bounds__(kFinishBlock) void fixed_point_finish_kernel(FixedPointList list, uint32_t* base, uint32_t* map,
+                                                                          const uint32_t* __restrict__ pack, uint32_t* error,
                                                                           uint32_t* rounds_out) {
     extern __shared__ uint32_t lds[];
-    if (*list.count <= list.lds_limit) {
-        if (blockIdx.x == 0) finish_in_lds(lds, list, base, map, pack, error, rounds_out);
-    } else {
-        finish_wide(list, base, w0, w1, w2, w3, sync, error, rounds_out);
-    }
+    if (*list.count <= list.lds_limit) finish_in_lds(lds, list, base, map, pack, error, rounds_out);
+}
+
+__global__ __launch_bounds__(kFinishBlock) void fixed_point_wide_kernel(FixedPointList list, uint32_t* base, uint32_t* w0, uint32_t* w1,
+                                                                        uint32_t* w2, uint32_t* w3, uint32_t* sync, uint32_t* error,
+                                                                        uint32_t* rounds_out) {
+    if (*list.count > list.lds_limit) finish_wide(list, base, w0, w1, w2, w3, sync, error, rounds_out);
 }
 
 }  // namespace
@@ -256,7 +260,7 @@ hipError_t launch_fixed_point_finish(const FixedPointList& list_in, uint32_t* ba
     // (every time: the attribute belongs to the function on the CURRENT device, and the ranks of a sharded run are threads
     // of one process on different devices)
     {
-        const hipError_t e = hipFuncSetAttribute((const void*)fixed_point_rounds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+        const hipError_t e = hipFuncSetAttribute((const void*)fixed_point_finish_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                  (int)lds_bytes);
         if (e != hipSuccess) return e;
     }
@@ -264,8 +268,10 @@ hipError_t launch_fixed_point_finish(const FixedPointList& list_in, uint32_t* ba
     hipLaunchKernelGGL(fixed_point_assign_kernel, dim3(kPrepGroups), dim3(kPrepBlock), 0, s, list, map);
     hipLaunchKernelGGL(fixed_point_prepare_kernel, dim3(kPrepGroups), dim3(kPrepBlock), 0, s, list, (const uint32_t*)map,
                        (const uint32_t*)base, pack);
-    hipLaunchKernelGGL(fixed_point_rounds_kernel, dim3(kWideGroups), dim3(kFinishBlock), lds_bytes, s, list, base, map,
-                       (const uint32_t*)pack, work[0], work[1], work[2], work[3], sync8, error, rounds_out);
+    hipLaunchKernelGGL(fixed_point_finish_kernel, dim3(1), dim3(kFinishBlock), lds_bytes, s, list, base, map, (const uint32_t*)pack,
+                       error, rounds_out);
+    hipLaunchKernelGGL(fixed_point_wide_kernel, dim3(kWideGroups), dim3(kFinishBlock), 0, s, list, base, work[0], work[1], work[2],
+                       work[3], sync8, error, rounds_out);
     return hipGetLastError();
 }
 
