@@ -792,7 +792,7 @@ bool read_paf_parallel(const std::string& path, const NameTable& names, const st
 // blocks as they come, count their lines, parse them with the same tokenizer as read_paf_parallel into
 // columns of their own, and the blocks' columns are copied into the final ones in file order.  The file's
 // rate is then the inflater's (about half a gigabyte of text per second) instead of inflater + parser on one
-// thread.  (BGZF files could be inflated block-parallel; not done.)
+// thread.  A BGZF file (bgzip) is made of blocks that can be inflated side by side: BgzfSource below.
 namespace {
 
 // one MHAP line [p, e): "a_id b_id error minmers a_rc a_begin a_end a_len b_rc b_begin b_end b_len", blank
