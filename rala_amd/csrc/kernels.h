@@ -165,6 +165,7 @@ void launch_emit_tuples(const OvlSoA& o, uint32_t n_reads, uint2* tuples, hipStr
 void launch_bucket_tuples(const OvlSoA& o, uint32_t n_reads, uint32_t world, uint32_t pass, uint32_t* counters,
                           uint2* tuples, hipStream_t s, bool records = false);
 void launch_records_to_tuples(const uint64_t* records, uint64_t n, uint2* tuples, hipStream_t s);
+void launch_owner_offsets(const uint32_t* count, uint32_t world, uint32_t* cursor, hipStream_t s);
 constexpr uint32_t kBoundRecordCoordBits = 21, kBoundRecordReadBits = 22;
 void launch_count_tuples(const uint2* tuples, uint64_t n, uint32_t n_reads, uint32_t* counts, hipStream_t s);
 // sensitive overlaps (graph.cpp:882-1054): transmute_ + target bounds as tuples 2i, 2i + 1;

@@ -923,6 +923,14 @@ void launch_scatter_bounds(const OvlSoA& o, uint32_t n_reads, const uint32_t* ev
 void launch_emit_tuples(const OvlSoA& o, uint32_t n_reads, uint2* tuples, hipStream_t s) {
     if (o.n) hipLaunchKernelGGL(emit_tuples_kernel, grid_for(o.n), dim3(kBlock), 0, s, o, n_reads, tuples);
 }
+// the owners' buckets side by side: cursor[p] = what lies in front of bucket p (between the two passes of bucket_tuples_kernel)
+__global__ void owner_offsets_kernel(const uint32_t* __restrict__ count, uint32_t world, uint32_t* __restrict__ cursor) {
+    uint32_t acc = 0;
+    for (uint32_t p = 0; p < world; ++p) { cursor[p] = acc; acc += count[p]; }
+}
+void launch_owner_offsets(const uint32_t* count, uint32_t world, uint32_t* cursor, hipStream_t s) {
+    hipLaunchKernelGGL(owner_offsets_kernel, dim3(1), dim3(1), 0, s, count, world, cursor);
+}
 void launch_bucket_tuples(const OvlSoA& o, uint32_t n_reads, uint32_t world, uint32_t pass, uint32_t* counters,
                           uint2* tuples, hipStream_t s, bool records) {
     if (!o.n) return;

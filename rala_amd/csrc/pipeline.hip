@@ -2166,16 +2166,14 @@ int emit_bucketed(rala_hip_ctx* ctx, uint32_t world, uint64_t* tuples_dev, uint6
     uint32_t* cur = cnt + 64;
     HIPCHECK(hipMemsetAsync(cnt, 0, 2 * 64 * 4, s));
     launch_bucket_tuples(ctx->ovl, (uint32_t)ctx->n_reads, world, 0, cnt, (uint2*)tuples_dev, s, records);
-    uint32_t h[64];
-    HIPCHECK(hipMemcpyAsync(h, cnt, world * 4, hipMemcpyDeviceToHost, s));
-    HIPCHECK(stream_sync(ctx, s));
-    uint32_t off[64];
-    uint32_t acc = 0;
-    for (uint32_t p = 0; p < world; ++p) { off[p] = acc; acc += h[p]; counts[p] = h[p]; }
-    HIPCHECK(hipMemcpyAsync(cur, off, world * 4, hipMemcpyHostToDevice, s));
+    // (the buckets' places from the counts on the device: the host looks once, at the end)
+    launch_owner_offsets(cnt, world, cur, s);
     launch_bucket_tuples(ctx->ovl, (uint32_t)ctx->n_reads, world, 1, cur, (uint2*)tuples_dev, s, records);
+    uint32_t h[64];
+    HIPCHECK(d2h_small(ctx, h, cnt, world * 4, s));
     HIPCHECK(stream_sync(ctx, s));
     HIPCHECK(hipGetLastError());
+    for (uint32_t p = 0; p < world; ++p) counts[p] = h[p];
     return RALA_HIP_OK;
 }
 }  // namespace
