@@ -66,6 +66,9 @@ typedef struct rala_hip_overlaps {
 typedef struct rala_hip_timings {
     float dedupe_ms, bucket_ms, pile_ms, classify_ms, death_ms, finish_ms, tail_host_ms, tr_ms, total_ms;
     uint32_t pile_launches, death_rounds, pile_overflow_reads, pile_position_reads;
+    /* reads whose slope-region / interval lists outgrew the LDS and ran with lists in global memory (initialize; the
+     * sensitive pass adds its own); times an interval pool was grown and the stage repeated */
+    uint32_t pile_unbounded_reads, pool_regrown;
 } rala_hip_timings;
 
 /* ---- context -------------------------------------------------------------- */
@@ -75,7 +78,7 @@ int rala_hip_create(int device, rala_hip_ctx** out);
 void rala_hip_destroy(rala_hip_ctx* ctx);
 const char* rala_hip_last_error(const rala_hip_ctx* ctx);
 /* options: "interval_pool_per_read_x1000" (default 1000 = one pit/hill slot per
- * read on average), "max_lds_read_len" (position-space kernel: reads longer than this use
+ * read on average; a hint - a pool that turns out too small is grown to the counted need and the stage runs again), "max_lds_read_len" (position-space kernel: reads longer than this use
  * the HBM slab path), "use_run_kernel" (default 1; 0 sends every read through the
  * position-space kernel), "use_gpu_tail" (default 1; 0 runs the chimera stage of
  * Graph::preprocess on the host), "use_fixed_buckets" (default 1; 0 always buckets the bounds
@@ -183,8 +186,8 @@ typedef struct rala_hip_device_state {
     const uint16_t* median;
     const uint16_t* p10;
     const uint8_t* alive;
-    const uint8_t* n_pits;
-    const uint8_t* n_hills;
+    const uint32_t* n_pits;     /* 32-bit counts: the reference's lists are vectors (pile.hpp:164-169) */
+    const uint32_t* n_hills;
     const uint32_t* slot;
     const void* pool;
     uint64_t pool_count;

@@ -114,6 +114,10 @@ struct rala_hip_ctx {
     rala_hip::DevBuf<uint64_t> d_pile_off;
     rala_hip::DevBuf<uint16_t> d_pile;
     rala_hip::DevBuf<uint32_t> d_order, d_overflow;
+    // reads whose region / interval lists outgrow the position-space kernels' LDS lists: noted in d_big_list[0], run
+    // again with the lists in d_big_space at growing sizes (those that still do not fit: the other list)
+    rala_hip::DevBuf<uint32_t> d_big_list[2], d_big_space;
+    int64_t debug_big_caps = 0;         // tests: first sizes of the lists in global memory (0: the defaults)
     rala_hip::DevBuf<uint16_t> d_slab;
     std::vector<rala_hip::LaunchClass> classes;
 
@@ -144,10 +148,12 @@ struct rala_hip_ctx {
     // per-read annotation
     rala_hip::DevBuf<uint32_t> d_begin, d_end, d_iv_slot;
     rala_hip::DevBuf<uint16_t> d_median, d_p10;
-    rala_hip::DevBuf<uint8_t> d_alive, d_n_pits, d_n_hills;
+    rala_hip::DevBuf<uint8_t> d_alive;
+    rala_hip::DevBuf<uint32_t> d_n_pits, d_n_hills;
     rala_hip::DevBuf<rala_hip::Interval> d_pool;
     rala_hip::DevBuf<uint32_t> d_small;      // [0] pool_count [1] error [2] changed [3] tr pairs
     uint32_t pool_cap = 0;
+    uint32_t rep_pool_cap = 0;          // repeat hills (sensitive pass); 0: as pool_cap
 
     // pass 2
     rala_hip::DevBuf<uint8_t> d_cls;
@@ -169,7 +175,8 @@ struct rala_hip_ctx {
     uint64_t n_prefiltered = 0;
     std::vector<uint32_t> h_begin, h_end, h_slot;
     std::vector<uint16_t> h_median, h_p10;
-    std::vector<uint8_t> h_alive, h_n_pits, h_n_hills;
+    std::vector<uint8_t> h_alive;
+    std::vector<uint32_t> h_n_pits, h_n_hills;
     std::vector<rala_hip::Interval> h_pool;
     rala_hip::DevBuf<uint32_t> d_overflow_mid, d_overflow_long, d_chain_cnt;      // more overflow lists / chain counters
     // how initialize left the primary bound events (the sensitive pass reads them again):
@@ -193,7 +200,7 @@ struct rala_hip_ctx {
 
     // sensitive pass (repeat hills)
     rala_hip::DevBuf<uint16_t> d_dataset_median;
-    rala_hip::DevBuf<uint8_t> d_n_rep;
+    rala_hip::DevBuf<uint32_t> d_n_rep;
     // sensitive overlaps on the device: columns, transmuted target side, trimmed coordinates, tuples
     rala_hip::DevBuf<uint32_t> d_sens_col[7], d_sens_tb[2], d_sens_c[5];
     rala_hip::DevBuf<uint2> d_sens_tuples, d_sens_part, d_sens_recv;     // as emitted / grouped by owner / received
@@ -202,7 +209,7 @@ struct rala_hip_ctx {
     bool sens_in_device = false;        // option "sensitive_in_device_memory"
     rala_hip::DevBuf<uint32_t> d_rep_slot;
     rala_hip::DevBuf<rala_hip::Interval> d_rep_pool;
-    std::vector<uint8_t> h_n_rep;
+    std::vector<uint32_t> h_n_rep;
     std::vector<uint32_t> h_rep_slot;
     std::vector<rala_hip::Interval> h_rep_pool;
     bool have_repeats = false;
@@ -214,7 +221,8 @@ struct rala_hip_ctx {
     bool marks_on_device = false;         // transitive marks of the device graph not fetched yet
     uint32_t t_n0 = 0, t_n1 = 0, t_rounds = 0, t_n_kept = 0, t_n_nodes = 0, t_n_edges = 0, t_n_alive = 0;
     size_t t_med_tmp = 0;                 // bytes of d_med_tmp
-    rala_hip::DevBuf<uint8_t> d_t_state, d_t_round, d_dirty, d_n_pits0, d_touched;
+    rala_hip::DevBuf<uint8_t> d_t_state, d_t_round, d_dirty, d_touched;
+    rala_hip::DevBuf<uint32_t> d_n_pits0;
     rala_hip::DevBuf<uint16_t> d_cmed;
     rala_hip::DevBuf<uint8_t> d_med_tmp;
     rala_hip::DevBuf<uint32_t> d_cc_flags;
@@ -234,7 +242,8 @@ struct rala_hip_ctx {
     rala_hip::DevBuf<uint8_t> d_tr_marks;
     std::vector<rala_hip::HostOvl> overlaps, internals, scratch_ovl;
     std::vector<rala_hip::EdgePair> scratch_ep;
-    std::vector<uint8_t> scratch_has, scratch_touched, h_n_pits0;
+    std::vector<uint8_t> scratch_has, scratch_touched;
+    std::vector<uint32_t> h_n_pits0;
     std::vector<uint32_t> scratch_u32a, scratch_u32b, scratch_u32c, alive_rank, alive_reads;
     rala_hip::PinnedBuf<uint32_t> p_cc_edges, p_cc_label;
     std::vector<uint32_t> node_read;

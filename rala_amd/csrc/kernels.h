@@ -11,9 +11,13 @@ namespace rala_hip {
 constexpr uint32_t kPadL = 848;
 
 enum : uint32_t {
-    kErrRegionCapacity = 1u,   // more slope regions / raw intervals than the kernel's LDS lists hold
-    kErrPoolCapacity = 2u,     // interval pool exhausted
+    kErrRegionCapacity = 1u,   // more slope regions than the kernel's lists hold
+    kErrPoolCapacity = 2u,     // interval pool exhausted (the pool's counter holds what is needed)
+    kErrRawCapacity = 4u,      // more raw intervals / candidate pairs than the kernel's lists hold
 };
+// Neither is an error of the call: a read that outgrows the LDS lists of the position-space kernels is noted in
+// big_list and runs again with its lists in global memory, grown until it fits; a pool that is too small is grown
+// to the counted size and the stage runs again (the reference keeps all of these in vectors, pile.hpp:164-169).
 
 // one pit / hill / repeat hill of a read
 struct Interval {
@@ -43,8 +47,8 @@ struct PileArgs {
     uint16_t* median;
     uint16_t* p10;
     uint8_t* alive;
-    uint8_t* n_pits;
-    uint8_t* n_hills;
+    uint32_t* n_pits;              // (32-bit counts: the reference's lists are vectors, pile.hpp:164-169)
+    uint32_t* n_hills;
     uint32_t* iv_slot;             // first pool entry of the read (pits, then hills), ~0u if none
     Interval* pool;
     uint32_t* pool_count;
@@ -55,11 +59,17 @@ struct PileArgs {
     const uint32_t* sens_off = nullptr;        // CSR of the sensitive bounds per read
     const uint32_t* sens_ev = nullptr;
     const uint16_t* dataset_median = nullptr;  // mode 2: component median per read
-    uint8_t* n_rep = nullptr;
+    uint32_t* n_rep = nullptr;
     uint32_t* rep_slot = nullptr;
     Interval* rep_pool = nullptr;
     uint32_t* rep_pool_count = nullptr;
     uint32_t rep_pool_cap = 0;
+    // position-space kernel: reads whose lists outgrow the LDS are appended here (null: error bits instead) ...
+    uint32_t* big_list = nullptr;
+    uint32_t* big_count = nullptr;
+    // ... and run again with the lists in global memory: ListSpace::words(..) words per workgroup
+    uint32_t* big_space = nullptr;
+    uint32_t big_cap_reg = 0, big_cap_list = 0, big_cap_raw = 0;
     // first pass: reads with more than kRunEventCap events are listed beforehand
     // (launch_pile_dense_list) and start in the cap-1024 kernel; the cap-512 kernels pass them over
     uint32_t skip_dense = 0;
@@ -67,6 +77,7 @@ struct PileArgs {
 
 uint32_t pile_lds_bytes(uint32_t lw);
 uint32_t pile_lw_for(uint32_t read_len);
+uint64_t pile_big_words(uint32_t cap_reg, uint32_t cap_list, uint32_t cap_raw);    // per workgroup
 void launch_pile_build_annotate(const PileArgs& args, uint32_t grid, bool in_lds, hipStream_t stream);
 
 // run-space kernel (pile_runs_kernel.hip): one wavefront per read; reads with more bound
@@ -109,14 +120,20 @@ struct RepeatArgs {
     uint16_t* median;                  // mode 1 writes, mode 2 reads
     uint16_t* p10;
     const uint16_t* dataset_median;    // mode 2: component median per read
-    uint8_t* n_rep;                    // mode 2 outputs
+    uint32_t* n_rep;                   // mode 2 outputs
     uint32_t* rep_slot;
     Interval* pool;
     uint32_t* pool_count;
     uint32_t pool_cap;
     uint32_t* error;
+    // as in PileArgs (cap_raw also bounds the candidate pairs)
+    uint32_t* big_list = nullptr;
+    uint32_t* big_count = nullptr;
+    uint32_t* big_space = nullptr;
+    uint32_t big_cap_reg = 0, big_cap_list = 0, big_cap_raw = 0;
 };
 uint32_t repeats_lds_bytes(uint32_t lw);
+uint64_t repeats_big_words(uint32_t cap_reg, uint32_t cap_list, uint32_t cap_raw);
 void launch_pile_repeats(const RepeatArgs& args, uint32_t grid, bool in_lds, int mode, hipStream_t stream);
 
 // ---- overlap-side kernels (overlap_kernels.hip) ------------------------------
@@ -137,8 +154,8 @@ struct ReadState {
     const uint32_t* begin;
     const uint32_t* end;
     const uint8_t* alive;
-    const uint8_t* n_pits;
-    const uint8_t* n_hills;
+    const uint32_t* n_pits;
+    const uint32_t* n_hills;
     const uint32_t* iv_slot;
     Interval* pool;
 };
@@ -175,7 +192,7 @@ void launch_sens_tuples(const OvlSoA& o, uint32_t n_reads, const uint32_t* begin
 void launch_sens_trim(const OvlSoA& o, const uint32_t* tb_begin, const uint32_t* tb_end, const uint32_t* begin,
                       const uint32_t* end, const uint8_t* alive, const SensCoords& out, hipStream_t s);
 void launch_sens_bridge(const OvlSoA& o, const SensCoords& sc, const uint32_t* begin, const uint32_t* end,
-                        const uint8_t* alive, const uint8_t* n_rep, const uint32_t* rep_slot, Interval* rep_pool,
+                        const uint8_t* alive, const uint32_t* n_rep, const uint32_t* rep_slot, Interval* rep_pool,
                         hipStream_t s);
 void launch_scatter_tuples(const uint2* tuples, uint64_t n, uint32_t n_reads, uint32_t* cursor, uint32_t* ev,
                            hipStream_t s);
@@ -184,7 +201,7 @@ struct KillList {
     uint32_t* count;            // device counter, zeroed before classify
     uint32_t *ovl, *target, *keeper;
 };
-// per-read records of the second pass: rec = {begin, end, n_pits | n_hills << 8 | alive << 16, pool slot};
+// per-read records of the second pass: rec = {begin, n_hills, n_pits, pool slot};
 // crec = valid region + "chimeric" + "has hills" in 4 bytes (small_records: no read longer than 32767
 // bases) or 8; sure[r] = 0 for the reads that are gone already (sure is all ones on entry)
 size_t compact_record_bytes(bool small_records);
@@ -211,7 +228,7 @@ void launch_survivor_masks(const OvlSoA& o, uint32_t n_reads, const uint8_t* val
                            const uint4* rec, Interval* pool, uint64_t* mask_ov, uint64_t* mask_in, uint32_t* chunk_ov,
                            uint32_t* chunk_in, hipStream_t s);
 // alive[r] = 0 where death[r] is set; fate[r] = "never dies" | "has hills" << 1; *n_alive += the reads that are left
-void launch_apply_death(const uint32_t* death, uint8_t* alive, const uint8_t* n_hills, uint8_t* fate, uint32_t n_reads,
+void launch_apply_death(const uint32_t* death, uint8_t* alive, const uint32_t* n_hills, uint8_t* fate, uint32_t n_reads,
                         uint32_t* n_alive, hipStream_t s);
 
 // survivors gathered into dense arrays (trim re-applied against the pass-1 piles)
@@ -241,9 +258,9 @@ void launch_localize_u8(const uint8_t* global, uint64_t n_local, uint32_t world,
 void launch_pack_median(const uint16_t* median, const uint16_t* p10, uint64_t n_local, uint64_t nl_pad, uint32_t* out, hipStream_t s);
 void launch_unpack_median(const uint32_t* all, uint32_t world, uint64_t nl_pad, uint64_t n_reads, uint16_t* median, uint16_t* p10,
                           hipStream_t s);
-void launch_pack_rep(const uint8_t* n_rep, const uint32_t* rep_slot, uint64_t n_local, uint64_t nl_pad, uint64_t* out, hipStream_t s);
+void launch_pack_rep(const uint32_t* n_rep, const uint32_t* rep_slot, uint64_t n_local, uint64_t nl_pad, uint64_t* out, hipStream_t s);
 void launch_unpack_rep(const uint64_t* all, uint32_t world, uint64_t nl_pad, uint64_t n_reads, const RankOffsets& pool_base,
-                       uint8_t* n_rep, uint32_t* rep_slot, hipStream_t s);
+                       uint32_t* n_rep, uint32_t* rep_slot, hipStream_t s);
 void launch_pool_aux(Interval* pool, uint32_t n, uint32_t* dense, uint32_t mode, hipStream_t s);
 void launch_death_status(const uint32_t* count, uint32_t* status, hipStream_t s);
 void launch_hill_counts(const ReadState& rs, uint32_t n_reads, uint32_t* dense, uint32_t mode, hipStream_t s);
@@ -259,13 +276,14 @@ struct TailList {               // survivors of the second pass: overlaps first,
 };
 struct TailReads {
     uint32_t *begin, *end;
-    uint8_t *alive, *dirty, *n_pits, *n_hills;
-    const uint8_t* n_pits0;     // pit count the pile kernel wrote (hills sit behind those pits)
+    uint8_t *alive, *dirty;
+    uint32_t *n_pits, *n_hills;
+    const uint32_t* n_pits0;     // pit count the pile kernel wrote (hills sit behind those pits)
     const uint32_t* iv_slot;
     Interval* pool;
 };
 // sensitive pass on the device list (sens_kernels.hip)
-void launch_sens_filter(const TailList& L, const uint32_t* begin, const uint32_t* end, const uint8_t* n_rep,
+void launch_sens_filter(const TailList& L, const uint32_t* begin, const uint32_t* end, const uint32_t* n_rep,
                         const uint32_t* rep_slot, const Interval* rep_pool, hipStream_t s);
 void launch_finalize_states(const TailList& L, const uint8_t* alive, hipStream_t s);
 void launch_scatter_component_medians(const uint32_t* alive_reads, const uint8_t* touched, const uint16_t* cmed, uint32_t n_alive,
@@ -290,7 +308,7 @@ hipError_t launch_tail_contain(const TailList& L, const TailReads& R, uint8_t* a
 void launch_count_zero_u8(const uint8_t* x, uint32_t n, uint32_t* out, hipStream_t s);    // *out += #zeros
 // list states (the first n0 items are overlaps, the rest internals), dirty[] = 0, n_pits0[] = n_pits[], base2[0 .. 2 n_reads) =
 // all ones, mark2[0 .. 2 n_reads) = 0, map[0 .. n_reads) = all ones, zero22[0 .. 21] = 0 in one launch
-void launch_tail_init(const TailList& L, uint32_t n0, const TailReads& R, uint8_t* n_pits0, uint32_t n_reads, uint32_t* base2,
+void launch_tail_init(const TailList& L, uint32_t n0, const TailReads& R, uint32_t* n_pits0, uint32_t n_reads, uint32_t* base2,
                       uint8_t* mark2, uint32_t* map, uint32_t* zero22, hipStream_t s);
 // single-pass scans with producer and consumer inside (scan_pass.h); false = out of tile states
 struct ScanSpace;

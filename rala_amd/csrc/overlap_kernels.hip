@@ -346,7 +346,7 @@ __device__ __forceinline__ Coords load_coords(const OvlSoA& o, uint64_t i) {
 
 // ---- second overlap pass (graph.cpp:443-518), static part -----------------------------------
 // Per-read state in two tables:
-//   * rec[r]  = {begin, end, n_pits | n_hills << 8 | alive << 16, first pool slot}, 16 bytes - read only by
+//   * rec[r]  = {begin, n_hills, n_pits, first pool slot}, 16 bytes - read only by
 //               the few overlaps that touch a read with chimeric hills (their span counters);
 //   * crec[r] = what trim / type / the containment rule need of a read - valid region, "has a chimeric
 //               region" (the container guard of graph.cpp:469-480), "has hills" - in ONE word when no read
@@ -396,12 +396,12 @@ __global__ __launch_bounds__(kBlock) void pack_reads_kernel(ReadState rs, uint32
     const bool alive = rs.alive[r] != 0;
     const uint32_t np = rs.n_pits[r], nh = rs.n_hills[r];
     const uint32_t b = rs.begin[r], e = rs.end[r];
-    rec[r] = make_uint4(b, e, np | (nh << 8) | ((uint32_t)alive << 16), rs.iv_slot[r]);
+    rec[r] = make_uint4(b, nh, np, rs.iv_slot[r]);
     crec[r] = CRec<kSmall>::pack(b, e, alive, (np | nh) != 0, nh != 0);
     if (!alive) sure[r] = 0u;
 }
-__device__ __forceinline__ uint32_t rec_pits(const uint4& r) { return r.z & 0xFFu; }
-__device__ __forceinline__ uint32_t rec_hills(const uint4& r) { return (r.z >> 8) & 0xFFu; }
+__device__ __forceinline__ uint32_t rec_pits(const uint4& r) { return r.z; }
+__device__ __forceinline__ uint32_t rec_hills(const uint4& r) { return r.y; }
 
 // A workgroup looks at a chunk of kClassifyChunk consecutive overlaps (8 per thread).
 constexpr uint32_t kClassifyChunk = 2048;
@@ -764,7 +764,7 @@ __global__ __launch_bounds__(kBlock) void survivor_masks_kernel(OvlSoA o, uint32
 
 // the reads that the containment scan deleted; the number of reads that are left
 __global__ __launch_bounds__(kBlock) void apply_death_kernel(const uint32_t* __restrict__ death, uint8_t* alive,
-                                                             const uint8_t* __restrict__ n_hills, uint8_t* __restrict__ fate,
+                                                             const uint32_t* __restrict__ n_hills, uint8_t* __restrict__ fate,
                                                              uint32_t n, uint32_t* n_alive) {
     // (few workgroups, one add each: adds to ONE word cost about 10 ns apiece wherever they come from -
     // one per wavefront of a million reads was 0.18 ms)
@@ -1022,7 +1022,7 @@ void launch_unpack_lists(const uint8_t* blocks, const ListBlocks& lb, const Surv
     const uint32_t gx = (most + kBlock - 1) / kBlock;
     hipLaunchKernelGGL(unpack_lists_kernel, dim3(gx < 1024 ? gx : 1024, lb.world), dim3(kBlock), 0, s, blocks, lb, out);
 }
-void launch_apply_death(const uint32_t* death, uint8_t* alive, const uint8_t* n_hills, uint8_t* fate, uint32_t n_reads,
+void launch_apply_death(const uint32_t* death, uint8_t* alive, const uint32_t* n_hills, uint8_t* fate, uint32_t n_reads,
                         uint32_t* n_alive, hipStream_t s) {
     if (n_reads) {
         const uint32_t blocks = std::min<uint32_t>(256, (n_reads + kBlock - 1) / kBlock);

@@ -137,6 +137,77 @@ struct PadView {
     __device__ uint32_t operator[](uint32_t j) const { return p[j]; }
 };
 
+// Where the slope-region lists and the raw intervals of one read live: in LDS at the sizes nearly every pile
+// needs, or - for the reads that outgrow those (the reference keeps them in vectors, pile.cpp:66, 359, 448) - in a
+// per-workgroup stretch of global memory that the host grows until the read fits.
+struct ListSpace {
+    uint32_t* rfirst;     // 4 lists x cap_reg: first positions of the flag runs (down / up per threshold)
+    uint32_t* rlast;      // 4 lists x cap_reg
+    uint32_t* reg;        // 2 thresholds x (key, last) x cap_list: the lists resolve_and_narrow works on
+    uint32_t* iv;         // 2 kinds x (in first, in second, out first, out second) x cap_raw
+    uint8_t* gone;        // 2 kinds x cap_raw
+    uint32_t cap_reg, cap_list, cap_raw;
+    static __host__ __device__ constexpr uint64_t words(uint32_t cap_reg, uint32_t cap_list, uint32_t cap_raw) {
+        return 8ull * cap_reg + 4ull * cap_list + 8ull * cap_raw + (2ull * cap_raw + 3) / 4;
+    }
+    __device__ void carve(uint32_t* base, uint32_t cr, uint32_t cl, uint32_t cw) {
+        cap_reg = cr; cap_list = cl; cap_raw = cw;
+        rfirst = base;
+        rlast = rfirst + 4 * (size_t)cr;
+        reg = rlast + 4 * (size_t)cr;
+        iv = reg + 4 * (size_t)cl;
+        gone = (uint8_t*)(iv + 8 * (size_t)cw);
+    }
+};
+
+// One item per flagged lane appended in lane order (all lanes of the wavefront call); items beyond cap are
+// counted but not stored.  Returns the new count.
+__device__ __forceinline__ uint32_t wave_append2(bool flag, uint32_t count, uint32_t cap, uint32_t* a, uint32_t va,
+                                                 uint32_t* b, uint32_t vb) {
+    const uint64_t m = __ballot(flag);
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t at = count + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    if (flag && at < cap) { a[at] = va; b[at] = vb; }
+    return count + (uint32_t)__popcll(m);
+}
+
+// intervalMerge (pile.cpp:31-52, geom.h: interval_merge) by a whole wavefront: i in input order; the sweep over
+// j takes 64 intervals at a time - the first one that overlaps the growing i is absorbed, the ones in front of
+// it have been compared with i as it stood when their turn came, the ones behind it are compared again.  The
+// same result as the serial sweep, element for element.  Called by all lanes; returns the new count.
+__device__ uint32_t interval_merge_wave(uint32_t* first, uint32_t* second, uint32_t n, uint8_t* gone, uint32_t* out_first,
+                                        uint32_t* out_second) {
+    const uint32_t lane = threadIdx.x & 63;
+    for (uint32_t j = lane; j < n; j += 64) gone[j] = 0;
+    __threadfence_block();
+    uint32_t m = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (gone[i]) continue;
+        uint32_t F = first[i], S = second[i];
+        for (uint32_t base = 0; base < n; base += 64) {
+            const uint32_t j = base + lane;
+            bool open = j < n && j != i && gone[j < n ? j : 0] == 0;
+            const uint32_t fj = j < n ? first[j] : 0u, sj = j < n ? second[j] : 0u;
+            for (;;) {
+                const uint64_t hit = __ballot(open && F < sj && S > fj);
+                if (!hit) break;
+                const int l0 = __ffsll((unsigned long long)hit) - 1;
+                F = umin(F, (uint32_t)__shfl((int)fj, l0, 64));
+                S = umax(S, (uint32_t)__shfl((int)sj, l0, 64));
+                if ((int)lane == l0) gone[j] = 1;
+                if ((int)lane <= l0) open = false;
+            }
+        }
+        if (lane == 0) {
+            first[i] = F; second[i] = S;
+            out_first[m] = F; out_second[m] = S;
+        }
+        ++m;
+        __threadfence_block();
+    }
+    return m;
+}
+
 
 }  // namespace
 // hist[bin] += 1 for every active lane, one LDS atomic per distinct bin among the lanes of a

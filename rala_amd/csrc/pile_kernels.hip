@@ -29,28 +29,27 @@ namespace {
 
 constexpr int kBlock = 256;
 
-// Scratch words (uint32) behind the three big arrays.
-constexpr uint32_t kMaxRegions = 192;   // per slope list (q)
+// Scratch words (uint32) behind the three big arrays.  The lists of the last phases (ListSpace) at the sizes
+// nearly every pile needs; a read that outgrows them runs again with the lists in global memory.
+constexpr uint32_t kMaxRegions = 192;   // per flag-run list; the two lists of a threshold together while they are resolved
 constexpr uint32_t kMaxRawIv = 64;      // pits / hills before the merge
 constexpr uint32_t SC_TMP = 0;                         // 16 words: scans / reductions (as u64 x 8)
 constexpr uint32_t SC_HIST = SC_TMP + 16;              // 3 x 256 words
 constexpr uint32_t SC_SEL = SC_HIST + 768;             // 8 words
 constexpr uint32_t SC_RCOUNT = SC_SEL + 8;             // 4 words: runs per mask
-constexpr uint32_t SC_RFIRST = SC_RCOUNT + 4;          // 4 x kMaxRegions
-constexpr uint32_t SC_RLAST = SC_RFIRST + 4 * kMaxRegions;
-constexpr uint32_t SC_REG = SC_RLAST + 4 * kMaxRegions;        // 2 lists x (key,last) x kMaxRegions
-constexpr uint32_t SC_IV = SC_REG + 4 * kMaxRegions;           // 2 x (in first,second,out first,second) x kMaxRawIv
-constexpr uint32_t SC_GONE = SC_IV + 8 * kMaxRawIv;            // 2 x kMaxRawIv bytes
-constexpr uint32_t SC_OUT = SC_GONE + (2 * kMaxRawIv) / 4;     // 4 words: n_pits, n_hills, flags
-constexpr uint32_t SC_WORDS = SC_OUT + 4;
+constexpr uint32_t SC_OUT = SC_RCOUNT + 4;             // 8 words: n_hills, n_pits, error bits, pool slot
+constexpr uint32_t SC_LISTS = SC_OUT + 8;
+constexpr uint32_t SC_WORDS = SC_LISTS + (uint32_t)ListSpace::words(kMaxRegions, kMaxRegions, kMaxRawIv);
 
 }  // namespace
 
 uint32_t pile_lds_bytes(uint32_t lw) { return 3u * lw * 2u + SC_WORDS * 4u; }
 uint32_t pile_lw_for(uint32_t n) { return (kPadL + n + 848u + 7u) & ~7u; }
+uint64_t pile_big_words(uint32_t cap_reg, uint32_t cap_list, uint32_t cap_raw) { return ListSpace::words(cap_reg, cap_list, cap_raw); }
 
 // kLds: big arrays in LDS (dynamic shared memory) or in a per-workgroup HBM slab.
-template <bool kLds>
+// kBig: the region lists and raw intervals in global memory (A.big_space), at the sizes the host chose.
+template <bool kLds, bool kBig>
 __global__ __launch_bounds__(kBlock) void pile_build_annotate(PileArgs A) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -68,6 +67,13 @@ __global__ __launch_bounds__(kBlock) void pile_build_annotate(PileArgs A) {
     uint16_t* MA = P + LW;
     uint16_t* MB = MA + LW;
     int32_t* diff = (int32_t*)MA;           // (n + 1) int32 <= 2 * LW uint16
+    ListSpace S;
+    if constexpr (kBig) {
+        S.carve(A.big_space + (size_t)blockIdx.x * ListSpace::words(A.big_cap_reg, A.big_cap_list, A.big_cap_raw), A.big_cap_reg,
+                A.big_cap_list, A.big_cap_raw);
+    } else {
+        S.carve(sc + SC_LISTS, kMaxRegions, kMaxRegions, kMaxRawIv);
+    }
     uint64_t* tmp64 = (uint64_t*)(sc + SC_TMP);
     uint32_t* tmp32 = sc + SC_TMP;
 
@@ -88,7 +94,7 @@ __global__ __launch_bounds__(kBlock) void pile_build_annotate(PileArgs A) {
             uint32_t* P32 = (uint32_t*)P;
             for (uint32_t j = tid; j < LW / 2; j += kBlock) P32[j] = 0;
             for (uint32_t j = tid; j <= n; j += kBlock) diff[j] = 0;
-            if (tid < 4) sc[SC_OUT + tid] = 0;
+            if (tid < 8) sc[SC_OUT + tid] = 0;
         }
         __syncthreads();
 
@@ -296,8 +302,8 @@ __global__ __launch_bounds__(kBlock) void pile_build_annotate(PileArgs A) {
         {
             const int w = wave_id(), l = lane_id();
             const uint64_t* mk = mask + (size_t)w * nw;
-            uint32_t* rf = sc + SC_RFIRST + w * kMaxRegions;
-            uint32_t* rl = sc + SC_RLAST + w * kMaxRegions;
+            uint32_t* rf = S.rfirst + (size_t)w * S.cap_reg;
+            uint32_t* rl = S.rlast + (size_t)w * S.cap_reg;
             uint32_t base_s = 0, base_e = 0;
             for (uint32_t w0 = 0; w0 < nw; w0 += 64) {
                 const uint32_t x = w0 + l;
@@ -315,13 +321,13 @@ __global__ __launch_bounds__(kBlock) void pile_build_annotate(PileArgs A) {
                 while (starts) {
                     const uint32_t bit = __ffsll((unsigned long long)starts) - 1;
                     starts &= starts - 1;
-                    if (ps < kMaxRegions) rf[ps] = x * 64 + bit;
+                    if (ps < S.cap_reg) rf[ps] = x * 64 + bit;
                     ++ps;
                 }
                 while (ends) {
                     const uint32_t bit = __ffsll((unsigned long long)ends) - 1;
                     ends &= ends - 1;
-                    if (pe < kMaxRegions) rl[pe] = x * 64 + bit;
+                    if (pe < S.cap_reg) rl[pe] = x * 64 + bit;
                     ++pe;
                 }
                 base_s += __shfl((int)is, 63, 64);
@@ -329,118 +335,153 @@ __global__ __launch_bounds__(kBlock) void pile_build_annotate(PileArgs A) {
             }
             if (l == 0) sc[SC_RCOUNT + w] = base_s;
         }
+        __threadfence_block();
         __syncthreads();
 
         RALA_STOP(8)
-        // ---- 9. resolve + pits (wave 1) / hills (wave 0), one lane each --------
-        if (tid == 0 || tid == 64) {
-            const int which = tid >> 6;                     // 0: q = 1.3 hills, 1: q = 1.82 pits
+        // ---- 9. wave 0: q = 1.3 -> hills, wave 1: q = 1.82 -> pits --------------------
+        // The regions are resolved by one lane (pile.cpp:131-256 is a serial procedure); pits and hill
+        // candidates are found and merged by the whole wavefront, in the reference's order.
+        if (wave_id() < 2) {
+            const int which = wave_id();                    // 0: q = 1.3 hills, 1: q = 1.82 pits
+            const int l = lane_id();
             const double q = which ? 1.82 : 1.3;
             RegionList R;
-            R.key = sc + SC_REG + which * 2 * kMaxRegions;
-            R.last = R.key + kMaxRegions;
-            R.n = 0; R.cap = kMaxRegions; R.overflow = false;
+            R.key = S.reg + (size_t)which * 2 * S.cap_list;
+            R.last = R.key + S.cap_list;
+            R.n = 0; R.cap = S.cap_list; R.overflow = false;
             const uint32_t nd = sc[SC_RCOUNT + 2 * which], nu = sc[SC_RCOUNT + 2 * which + 1];
-            if (nd + nu > kMaxRegions) R.overflow = true;
-            if (!R.overflow) {
-                const uint32_t* df = sc + SC_RFIRST + (2 * which) * kMaxRegions;
-                const uint32_t* dl = sc + SC_RLAST + (2 * which) * kMaxRegions;
-                const uint32_t* uf = df + kMaxRegions;
-                const uint32_t* ul = dl + kMaxRegions;
+            uint32_t err = 0;
+            if (nd > S.cap_reg || nu > S.cap_reg || nd + nu > S.cap_list) err = kErrRegionCapacity;
+            if (!err && l == 0) {
+                const uint32_t* df = S.rfirst + (size_t)(2 * which) * S.cap_reg;
+                const uint32_t* dl = S.rlast + (size_t)(2 * which) * S.cap_reg;
+                const uint32_t* uf = df + S.cap_reg;
+                const uint32_t* ul = dl + S.cap_reg;
                 for (uint32_t k = 0; k < nd; ++k) rl_push(R, df[k] << 1, dl[k]);
                 for (uint32_t k = 0; k < nu; ++k) rl_push(R, uf[k] << 1 | 1, ul[k]);
                 PadView dv{D};
                 resolve_and_narrow(R, dv, q);
             }
-            uint32_t* ivf = sc + SC_IV + which * 4 * kMaxRawIv;
-            uint32_t* ivs = ivf + kMaxRawIv;
-            uint32_t* of = ivs + kMaxRawIv;
-            uint32_t* os = of + kMaxRawIv;
-            uint8_t* gone = (uint8_t*)(sc + SC_GONE) + which * kMaxRawIv;
+            __threadfence_block();
+            const uint32_t n_reg = (uint32_t)__shfl((int)R.n, 0, 64);
+            if (__shfl((int)R.overflow, 0, 64)) err |= kErrRegionCapacity;
+            uint32_t* ivf = S.iv + (size_t)which * 4 * S.cap_raw;
+            uint32_t* ivs = ivf + S.cap_raw;
+            uint32_t* of = ivs + S.cap_raw;
+            uint32_t* os = of + S.cap_raw;
+            uint8_t* gone = S.gone + (size_t)which * S.cap_raw;
             uint32_t cnt = 0;
-            bool ovf = R.overflow;
-            if (!ovf && R.n) {
+            if (!err && n_reg) {
                 if (which) {
                     // pile.cpp:357-363: adjacent (down, up) -> pit
-                    for (uint32_t i = 0; i + 1 < R.n; ++i) {
-                        if (!(R.key[i] & 1) && (R.key[i + 1] & 1)) {
-                            if (cnt >= kMaxRawIv) { ovf = true; break; }
-                            ivf[cnt] = R.key[i] >> 1;
-                            ivs[cnt] = R.last[i + 1];
-                            ++cnt;
-                        }
+                    for (uint32_t i0 = 0; i0 + 1 < n_reg; i0 += 64) {
+                        const uint32_t i = i0 + l;
+                        const bool in = i + 1 < n_reg;
+                        const uint32_t k0 = in ? R.key[i] : 1u, k1 = in ? R.key[i + 1] : 0u;
+                        const bool pit = in && !(k0 & 1) && (k1 & 1);
+                        cnt = wave_append2(pit, cnt, S.cap_raw, ivf, k0 >> 1, ivs, pit ? R.last[i + 1] : 0u);
                     }
                 } else {
                     // pile.cpp:411-451: every (up, later down) pair
                     const double span = (double)(E - B);
                     const double lo_lim = 0.05 * span + (double)B;
                     const double hi_lim = 0.95 * span + (double)B;
-                    for (uint32_t i = 0; i + 1 < R.n && !ovf; ++i) {
-                        if (!(R.key[i] & 1)) continue;
-                        const uint32_t u_first = R.key[i] >> 1, u_last = R.last[i];
-                        for (uint32_t j = i + 1; j < R.n; ++j) {
-                            if (R.key[j] & 1) continue;
-                            const uint32_t w_first = R.key[j] >> 1, w_last = R.last[j];
-                            if ((double)u_first < lo_lim || (double)w_last > hi_lim ||
-                                (uint32_t)(w_first - u_last) > 840u) {
-                                continue;
+                    for (uint32_t i = 0; i + 1 < n_reg; ++i) {
+                        const uint32_t ki = R.key[i];
+                        if (!(ki & 1)) continue;
+                        const uint32_t u_first = ki >> 1, u_last = R.last[i];
+                        if ((double)u_first < lo_lim) continue;
+                        for (uint32_t j0 = i + 1; j0 < n_reg; j0 += 64) {
+                            const uint32_t j = j0 + l;
+                            bool hill = j < n_reg;
+                            uint32_t w_last = 0;
+                            if (hill) {
+                                const uint32_t kj = R.key[j];
+                                const uint32_t w_first = kj >> 1;
+                                w_last = R.last[j];
+                                hill = !(kj & 1) && !((double)w_last > hi_lim) && !((uint32_t)(w_first - u_last) > 840u);
+                                if (hill) {
+                                    const uint32_t pk = (uint32_t)(1.3 * (double)umax(D[u_last], D[w_first]));
+                                    bool found = false;
+                                    for (uint32_t x = u_last + 1; x < w_first; ++x) {
+                                        if (D[x] > pk) { found = true; break; }
+                                    }
+                                    hill = found;
+                                }
                             }
-                            const uint32_t pk = (uint32_t)(1.3 * (double)umax(D[u_last], D[w_first]));
-                            bool found = false;
-                            for (uint32_t x = u_last + 1; x < w_first; ++x) {
-                                if (D[x] > pk) { found = true; break; }
-                            }
-                            if (!found) continue;
-                            if (cnt >= kMaxRawIv) { ovf = true; break; }
-                            ivf[cnt] = (uint32_t)(u_first - B) > kHillFuzz ? u_first - kHillFuzz : B;
-                            ivs[cnt] = (uint32_t)(E - w_last) > kHillFuzz ? w_last + kHillFuzz : E;
-                            ++cnt;
+                            cnt = wave_append2(hill, cnt, S.cap_raw, ivf, (uint32_t)(u_first - B) > kHillFuzz ? u_first - kHillFuzz : B,
+                                               ivs, (uint32_t)(E - w_last) > kHillFuzz ? w_last + kHillFuzz : E);
                         }
                     }
                 }
-                if (!ovf) cnt = interval_merge(ivf, ivs, cnt, gone, of, os);
+                if (cnt > S.cap_raw) {
+                    err |= kErrRawCapacity;
+                } else {
+                    __threadfence_block();
+                    cnt = interval_merge_wave(ivf, ivs, cnt, gone, of, os);
+                }
             }
-            sc[SC_OUT + which] = ovf ? 0 : cnt;
-            if (ovf) atomicOr(&sc[SC_OUT + 2], 1u);
+            if (l == 0) {
+                sc[SC_OUT + which] = err ? 0 : cnt;
+                if (err) atomicOr(&sc[SC_OUT + 2], err);
+            }
         }
+        __threadfence_block();
         __syncthreads();
 
         RALA_STOP(9)
         // ---- 10. publish ------------------------------------------------------
-        if (tid == 0) {
+        {
             const uint32_t nh = sc[SC_OUT + 0], np = sc[SC_OUT + 1];
-            uint32_t err = sc[SC_OUT + 2] ? kErrRegionCapacity : 0;
-            uint32_t slot = 0xFFFFFFFFu;
-            uint32_t wp = np, wh = nh;
-            if (np > 255 || nh > 255) { err |= kErrRegionCapacity; wp = wh = 0; }
-            if (wp + wh) {
-                slot = atomicAdd(A.pool_count, wp + wh);
-                if (slot + wp + wh > A.pool_cap) {
-                    err |= kErrPoolCapacity;
-                    slot = 0xFFFFFFFFu; wp = wh = 0;
-                } else {
-                    const uint32_t* pf = sc + SC_IV + 4 * kMaxRawIv + 2 * kMaxRawIv;   // pits: merged out
-                    const uint32_t* ps = pf + kMaxRawIv;
-                    const uint32_t* hf = sc + SC_IV + 2 * kMaxRawIv;                   // hills: merged out
-                    const uint32_t* hs = hf + kMaxRawIv;
-                    for (uint32_t k = 0; k < wp; ++k) {
-                        uint32_t mn = 0xFFFFu;
-                        for (uint32_t x = pf[k]; x <= ps[k]; ++x) mn = umin(mn, D[x]);
-                        Interval iv; iv.first = pf[k]; iv.second = ps[k]; iv.aux = mn;
-                        A.pool[slot + k] = iv;
-                    }
-                    for (uint32_t k = 0; k < wh; ++k) {
-                        Interval iv; iv.first = hf[k]; iv.second = hs[k]; iv.aux = 0;
-                        A.pool[slot + wp + k] = iv;
+            const uint32_t lists_err = sc[SC_OUT + 2];
+            if (lists_err && A.big_list) {
+                // the lists of this read do not fit: once more, with (larger) lists in global memory
+                if (tid == 0) {
+                    A.big_list[atomicAdd(A.big_count, 1u)] = r;
+                    if (kBig) atomicOr(A.error, lists_err);      // which of the lists the host has to grow
+                }
+                __syncthreads();
+                continue;
+            }
+            if (tid == 0) {
+                uint32_t slot = 0xFFFFFFFFu;
+                if (!lists_err && np + nh) {
+                    slot = atomicAdd(A.pool_count, np + nh);
+                    if (slot + np + nh > A.pool_cap || slot + np + nh < slot) {
+                        atomicOr(A.error, (uint32_t)kErrPoolCapacity);
+                        slot = 0xFFFFFFFFu;
                     }
                 }
+                sc[SC_OUT + 3] = slot;
+                if (lists_err) atomicOr(A.error, lists_err);
             }
-            A.alive[r] = 1;
-            A.begin[r] = B; A.end[r] = E;
-            A.median[r] = (uint16_t)med; A.p10[r] = (uint16_t)p10;
-            A.n_pits[r] = (uint8_t)wp; A.n_hills[r] = (uint8_t)wh;
-            A.iv_slot[r] = slot;
-            if (err) atomicOr(A.error, err);
+            __syncthreads();
+            const uint32_t slot = sc[SC_OUT + 3];
+            const uint32_t wp = slot == 0xFFFFFFFFu ? 0 : np, wh = slot == 0xFFFFFFFFu ? 0 : nh;
+            {
+                const uint32_t* pf = S.iv + (size_t)4 * S.cap_raw + 2 * S.cap_raw;   // pits: merged out
+                const uint32_t* ps = pf + S.cap_raw;
+                const uint32_t* hf = S.iv + (size_t)2 * S.cap_raw;                   // hills: merged out
+                const uint32_t* hs = hf + S.cap_raw;
+                for (uint32_t k = tid; k < wp; k += kBlock) {
+                    uint32_t mn = 0xFFFFu;
+                    for (uint32_t x = pf[k]; x <= ps[k]; ++x) mn = umin(mn, D[x]);
+                    Interval iv; iv.first = pf[k]; iv.second = ps[k]; iv.aux = mn;
+                    A.pool[slot + k] = iv;
+                }
+                for (uint32_t k = tid; k < wh; k += kBlock) {
+                    Interval iv; iv.first = hf[k]; iv.second = hs[k]; iv.aux = 0;
+                    A.pool[slot + wp + k] = iv;
+                }
+            }
+            if (tid == 0) {
+                A.alive[r] = 1;
+                A.begin[r] = B; A.end[r] = E;
+                A.median[r] = (uint16_t)med; A.p10[r] = (uint16_t)p10;
+                A.n_pits[r] = wp; A.n_hills[r] = wh;
+                A.iv_slot[r] = slot;
+            }
         }
         __syncthreads();
     }
@@ -448,13 +489,20 @@ __global__ __launch_bounds__(kBlock) void pile_build_annotate(PileArgs A) {
 
 void launch_pile_build_annotate(const PileArgs& args, uint32_t grid, bool in_lds, hipStream_t stream) {
     if (grid == 0) return;
+    const bool big = args.big_space != nullptr;
     if (in_lds) {
         const uint32_t bytes = pile_lds_bytes(args.lw);
-        hipFuncSetAttribute((const void*)pile_build_annotate<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)bytes);
-        hipLaunchKernelGGL(pile_build_annotate<true>, dim3(grid), dim3(kBlock), bytes, stream, args);
+        if (big) {
+            hipFuncSetAttribute((const void*)pile_build_annotate<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+            hipLaunchKernelGGL((pile_build_annotate<true, true>), dim3(grid), dim3(kBlock), bytes, stream, args);
+        } else {
+            hipFuncSetAttribute((const void*)pile_build_annotate<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+            hipLaunchKernelGGL((pile_build_annotate<true, false>), dim3(grid), dim3(kBlock), bytes, stream, args);
+        }
+    } else if (big) {
+        hipLaunchKernelGGL((pile_build_annotate<false, true>), dim3(grid), dim3(kBlock), SC_WORDS * 4u, stream, args);
     } else {
-        hipLaunchKernelGGL(pile_build_annotate<false>, dim3(grid), dim3(kBlock), SC_WORDS * 4u, stream, args);
+        hipLaunchKernelGGL((pile_build_annotate<false, false>), dim3(grid), dim3(kBlock), SC_WORDS * 4u, stream, args);
     }
 }
 

@@ -20,27 +20,44 @@ namespace rala_hip {
 namespace {
 
 constexpr int kBlock = 256;
-constexpr uint32_t kMaxRegions = 192;
-constexpr uint32_t kMaxPairs = 256;        // (up, down) candidates that pass the span test
+// the lists of mode 2 at the sizes nearly every pile needs (LDS); a read that outgrows them runs again with the
+// lists in global memory (RepeatArgs::big_space), grown until it fits
+constexpr uint32_t kMaxRegions = 192;      // per flag-run list; twice that while the two lists are resolved
 constexpr uint32_t kMaxRawIv = 64;
 
 constexpr uint32_t SC_TMP = 0;                                 // 16 words
 constexpr uint32_t SC_HIST = SC_TMP + 16;                      // 768 words
 constexpr uint32_t SC_SEL = SC_HIST + 768;                     // 16 words
 constexpr uint32_t SC_RCOUNT = SC_SEL + 16;                    // 2 words (+2 pad)
-constexpr uint32_t SC_RFIRST = SC_RCOUNT + 4;                  // 2 x kMaxRegions
-constexpr uint32_t SC_RLAST = SC_RFIRST + 2 * kMaxRegions;
-constexpr uint32_t SC_REG = SC_RLAST + 2 * kMaxRegions;        // key, last: 2 x 2 * kMaxRegions
-constexpr uint32_t SC_PAIR = SC_REG + 4 * kMaxRegions;         // kMaxPairs
-constexpr uint32_t SC_IV = SC_PAIR + kMaxPairs;                // 4 x kMaxRawIv
-constexpr uint32_t SC_GONE = SC_IV + 4 * kMaxRawIv;            // kMaxRawIv bytes
-constexpr uint32_t SC_WORDS = SC_GONE + kMaxRawIv / 4;
+constexpr uint32_t SC_LISTS = SC_RCOUNT + 4;
+
+// mode 2's lists: flag runs (2 x cap_reg firsts, lasts), the resolved list (key, last: cap_list each), raw hills
+// (in first, in second, out first, out second: cap_raw each), gone bytes
+struct RepLists {
+    uint32_t *rfirst, *rlast, *key, *last, *iv;
+    uint8_t* gone;
+    uint32_t cap_reg, cap_list, cap_raw;
+    static __host__ __device__ constexpr uint64_t words(uint32_t cr, uint32_t cl, uint32_t cw) {
+        return 4ull * cr + 2ull * cl + 4ull * cw + (cw + 3ull) / 4;
+    }
+    __device__ void carve(uint32_t* base, uint32_t cr, uint32_t cl, uint32_t cw) {
+        cap_reg = cr; cap_list = cl; cap_raw = cw;
+        rfirst = base;
+        rlast = rfirst + 2 * (size_t)cr;
+        key = rlast + 2 * (size_t)cr;
+        last = key + cl;
+        iv = last + cl;
+        gone = (uint8_t*)(iv + 4 * (size_t)cw);
+    }
+};
+constexpr uint32_t SC_WORDS = SC_LISTS + (uint32_t)RepLists::words(kMaxRegions, 2 * kMaxRegions, kMaxRawIv);
 
 }  // namespace
 
 uint32_t repeats_lds_bytes(uint32_t lw) { return 3u * lw * 2u + SC_WORDS * 4u; }
+uint64_t repeats_big_words(uint32_t cap_reg, uint32_t cap_list, uint32_t cap_raw) { return RepLists::words(cap_reg, cap_list, cap_raw); }
 
-template <bool kLds, int kMode>
+template <bool kLds, int kMode, bool kBig = false>
 __global__ __launch_bounds__(kBlock) void pile_repeats_kernel(RepeatArgs A) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -58,6 +75,13 @@ __global__ __launch_bounds__(kBlock) void pile_repeats_kernel(RepeatArgs A) {
     uint16_t* MB = MA + LW;
     int32_t* diff = (int32_t*)MA;
     uint32_t* tmp32 = sc + SC_TMP;
+    RepLists S;
+    if constexpr (kBig) {
+        S.carve(A.big_space + (size_t)blockIdx.x * RepLists::words(A.big_cap_reg, A.big_cap_list, A.big_cap_raw), A.big_cap_reg,
+                A.big_cap_list, A.big_cap_raw);
+    } else {
+        S.carve(sc + SC_LISTS, kMaxRegions, 2 * kMaxRegions, kMaxRawIv);
+    }
 
     for (uint32_t item = blockIdx.x; item < A.n_items; item += gridDim.x) {
         const uint32_t r = A.order[item];
@@ -215,8 +239,8 @@ __global__ __launch_bounds__(kBlock) void pile_repeats_kernel(RepeatArgs A) {
             if (wave_id() < 2) {
                 const int w = wave_id(), l = lane_id();
                 const uint64_t* mk = mask + (size_t)w * nw;
-                uint32_t* rf = sc + SC_RFIRST + w * kMaxRegions;
-                uint32_t* rl = sc + SC_RLAST + w * kMaxRegions;
+                uint32_t* rf = S.rfirst + (size_t)w * S.cap_reg;
+                uint32_t* rl = S.rlast + (size_t)w * S.cap_reg;
                 uint32_t base_s = 0, base_e = 0;
                 for (uint32_t w0 = 0; w0 < nw; w0 += 64) {
                     const uint32_t x = w0 + l;
@@ -234,13 +258,13 @@ __global__ __launch_bounds__(kBlock) void pile_repeats_kernel(RepeatArgs A) {
                     while (starts) {
                         const uint32_t bit = __ffsll((unsigned long long)starts) - 1;
                         starts &= starts - 1;
-                        if (ps < kMaxRegions) rf[ps] = x * 64 + bit;
+                        if (ps < S.cap_reg) rf[ps] = x * 64 + bit;
                         ++ps;
                     }
                     while (ends) {
                         const uint32_t bit = __ffsll((unsigned long long)ends) - 1;
                         ends &= ends - 1;
-                        if (pe < kMaxRegions) rl[pe] = x * 64 + bit;
+                        if (pe < S.cap_reg) rl[pe] = x * 64 + bit;
                         ++pe;
                     }
                     base_s += __shfl((int)is, 63, 64);
@@ -248,91 +272,95 @@ __global__ __launch_bounds__(kBlock) void pile_repeats_kernel(RepeatArgs A) {
                 }
                 if (l == 0) sc[SC_RCOUNT + w] = base_s;
             }
+            __threadfence_block();
             __syncthreads();
 
-            // ---- regions resolved on one lane; (up, later down) pairs passing the span test ------
-            uint32_t* key = sc + SC_REG;
-            uint32_t* last = key + 2 * kMaxRegions;
-            uint32_t* pairs = sc + SC_PAIR;
+            // ---- regions resolved on one lane (pile.cpp:131-256 is a serial procedure) -----------------
+            uint32_t* key = S.key;
+            uint32_t* last = S.last;
             uint32_t* sel = sc + SC_SEL;
             // dataset median adjusted by the pile's own statistics (pile.cpp:503-505)
             uint32_t dm = A.dataset_median[r];
             if ((double)A.median[r] > 1.42 * (double)dm) dm = umax(dm, A.p10[r]);
             if (tid == 0) {
                 RegionList R;
-                R.key = key; R.last = last; R.n = 0; R.cap = 2 * kMaxRegions; R.overflow = false;
+                R.key = key; R.last = last; R.n = 0; R.cap = S.cap_list; R.overflow = false;
                 const uint32_t nd = sc[SC_RCOUNT], nu = sc[SC_RCOUNT + 1];
-                uint32_t n_pairs = 0;
-                bool ovf = nd > kMaxRegions || nu > kMaxRegions;
+                bool ovf = nd > S.cap_reg || nu > S.cap_reg;
                 if (!ovf) {
-                    const uint32_t* df = sc + SC_RFIRST;
-                    const uint32_t* dl = sc + SC_RLAST;
-                    const uint32_t* uf = df + kMaxRegions;
-                    const uint32_t* ul = dl + kMaxRegions;
+                    const uint32_t* df = S.rfirst;
+                    const uint32_t* dl = S.rlast;
+                    const uint32_t* uf = df + S.cap_reg;
+                    const uint32_t* ul = dl + S.cap_reg;
                     for (uint32_t k = 0; k < nd; ++k) rl_push(R, df[k] << 1, dl[k]);
                     for (uint32_t k = 0; k < nu; ++k) rl_push(R, uf[k] << 1 | 1, ul[k]);
                     PadView dv{D};
                     resolve_and_narrow(R, dv, 1.42);
                     ovf = R.overflow;
                 }
-                if (!ovf && R.n) {
-                    const double lim = 0.84 * (double)(E - B);
-                    for (uint32_t i = 0; i + 1 < R.n && !ovf; ++i) {
-                        if (!(R.key[i] & 1)) continue;
-                        const uint32_t mid_u = ((R.key[i] >> 1) + R.last[i]) / 2;
-                        for (uint32_t j = i + 1; j < R.n; ++j) {
-                            if (R.key[j] & 1) continue;
-                            const uint32_t mid_w = ((R.key[j] >> 1) + R.last[j]) / 2;
-                            if ((double)(uint32_t)(mid_w - mid_u) > lim) continue;
-                            if (n_pairs >= kMaxPairs) { ovf = true; break; }
-                            pairs[n_pairs++] = i << 16 | j;
-                        }
-                    }
-                }
-                sel[8] = n_pairs;
-                sel[9] = ovf ? 1u : 0u;
+                sel[8] = ovf ? 0u : R.n;
+                sel[9] = ovf ? (uint32_t)kErrRegionCapacity : 0u;
                 sel[10] = 0;        // raw hills
             }
+            __threadfence_block();
             __syncthreads();
-            const uint32_t n_pairs = sel[9] ? 0 : sel[8];
-            uint32_t* ivf = sc + SC_IV;
-            uint32_t* ivs = ivf + kMaxRawIv;
-            uint32_t* of = ivs + kMaxRawIv;
-            uint32_t* os = of + kMaxRawIv;
-            for (uint32_t c = 0; c < n_pairs; ++c) {
-                const uint32_t i = pairs[c] >> 16, j = pairs[c] & 0xFFFFu;
-                const uint32_t u_first = key[i] >> 1, u_last = last[i];
-                const uint32_t w_first = key[j] >> 1, w_last = last[j];
-                const uint32_t peak = (uint32_t)(1.42 * (double)umax(D[u_last], D[w_first]));
-                const uint32_t floor_v = (uint32_t)((double)dm * 1.42);
-                uint32_t valid = 0, found = 0;
-                for (uint32_t x = u_last + 1 + tid; x < w_first; x += kBlock) {
-                    const uint32_t v = D[x];
-                    valid += v > floor_v;
-                    found |= v > peak;
-                }
-                valid = block_reduce<kBlock>(valid, OpAdd(), 0u, tmp32);
-                found = block_reduce<kBlock>(found, OpMax(), 0u, tmp32);
-                if (tid == 0 && found && !((double)valid < 0.9 * (double)(uint32_t)(w_first - u_last))) {
-                    const uint32_t k = sel[10];
-                    if (k >= kMaxRawIv) {
-                        sel[9] = 1;
-                    } else {
-                        ivf[k] = (uint32_t)((double)u_last - 0.336 * (double)(uint32_t)(u_last - u_first));
-                        ivs[k] = (uint32_t)((double)w_first + 0.336 * (double)(uint32_t)(w_last - w_first));
+            // ---- every (up, later down) pair in the reference's order (pile.cpp:515-556); the workgroup walks the
+            // positions between the two regions together
+            const uint32_t n_reg = sel[8];
+            uint32_t* ivf = S.iv;
+            uint32_t* ivs = ivf + S.cap_raw;
+            uint32_t* of = ivs + S.cap_raw;
+            uint32_t* os = of + S.cap_raw;
+            const double lim = 0.84 * (double)(E - B);
+            const uint32_t floor_v = (uint32_t)((double)dm * 1.42);
+            for (uint32_t i = 0; i + 1 < n_reg; ++i) {
+                const uint32_t ki = key[i];
+                if (!(ki & 1)) continue;
+                const uint32_t u_first = ki >> 1, u_last = last[i];
+                const uint32_t mid_u = (u_first + u_last) / 2;
+                for (uint32_t j = i + 1; j < n_reg; ++j) {
+                    const uint32_t kj = key[j];
+                    if (kj & 1) continue;
+                    const uint32_t w_first = kj >> 1, w_last = last[j];
+                    const uint32_t mid_w = (w_first + w_last) / 2;
+                    if ((double)(uint32_t)(mid_w - mid_u) > lim) continue;
+                    const uint32_t peak = (uint32_t)(1.42 * (double)umax(D[u_last], D[w_first]));
+                    uint32_t valid = 0, found = 0;
+                    for (uint32_t x = u_last + 1 + tid; x < w_first; x += kBlock) {
+                        const uint32_t v = D[x];
+                        valid += v > floor_v;
+                        found |= v > peak;
+                    }
+                    valid = block_reduce<kBlock>(valid, OpAdd(), 0u, tmp32);
+                    found = block_reduce<kBlock>(found, OpMax(), 0u, tmp32);
+                    if (tid == 0 && found && !((double)valid < 0.9 * (double)(uint32_t)(w_first - u_last))) {
+                        const uint32_t k = sel[10];
+                        if (k < S.cap_raw) {
+                            ivf[k] = (uint32_t)((double)u_last - 0.336 * (double)(uint32_t)(u_last - u_first));
+                            ivs[k] = (uint32_t)((double)w_first + 0.336 * (double)(uint32_t)(w_last - w_first));
+                        }
                         sel[10] = k + 1;
                     }
                 }
-                __syncthreads();
             }
-            if (tid == 0) {
-                uint32_t err = sel[9] ? kErrRegionCapacity : 0;
-                uint32_t cnt = 0, slot = 0xFFFFFFFFu;
-                if (!err) {
-                    cnt = interval_merge(ivf, ivs, sel[10], (uint8_t*)(sc + SC_GONE), of, os);
-                    if (cnt) {
+            __threadfence_block();
+            __syncthreads();
+            if (wave_id() == 0) {
+                uint32_t err = sel[9];
+                const uint32_t n_raw = sel[10];
+                if (n_raw > S.cap_raw) err |= kErrRawCapacity;
+                uint32_t cnt = 0;
+                if (!err) cnt = interval_merge_wave(ivf, ivs, n_raw, S.gone, of, os);
+                if (tid == 0) {
+                    uint32_t slot = 0xFFFFFFFFu;
+                    if (err && A.big_list) {
+                        // the lists of this read do not fit: once more, with (larger) lists in global memory
+                        A.big_list[atomicAdd(A.big_count, 1u)] = r;
+                        if (!kBig) err = 0;      // (kBig: which of the lists the host has to grow)
+                        cnt = 0;
+                    } else if (cnt) {
                         slot = atomicAdd(A.pool_count, cnt);
-                        if (slot + cnt > A.pool_cap) {
+                        if (slot + cnt > A.pool_cap || slot + cnt < slot) {
                             err |= kErrPoolCapacity;
                             slot = 0xFFFFFFFFu; cnt = 0;
                         } else {
@@ -345,10 +373,10 @@ __global__ __launch_bounds__(kBlock) void pile_repeats_kernel(RepeatArgs A) {
                             }
                         }
                     }
+                    A.n_rep[r] = cnt;
+                    A.rep_slot[r] = slot;
+                    if (err) atomicOr(A.error, err);
                 }
-                A.n_rep[r] = (uint8_t)cnt;
-                A.rep_slot[r] = slot;
-                if (err) atomicOr(A.error, err);
             }
             __syncthreads();
         }
@@ -358,23 +386,23 @@ __global__ __launch_bounds__(kBlock) void pile_repeats_kernel(RepeatArgs A) {
 void launch_pile_repeats(const RepeatArgs& args, uint32_t grid, bool in_lds, int mode, hipStream_t stream) {
     if (grid == 0) return;
     const uint32_t bytes = in_lds ? repeats_lds_bytes(args.lw) : SC_WORDS * 4u;
+    const bool big = mode == 2 && args.big_space != nullptr;
+#define RALA_REPEATS(lds, m, b)                                                                                          \
+    do {                                                                                                                 \
+        if (lds) hipFuncSetAttribute((const void*)pile_repeats_kernel<lds, m, b>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                     (int)bytes);                                                                        \
+        hipLaunchKernelGGL((pile_repeats_kernel<lds, m, b>), dim3(grid), dim3(kBlock), bytes, stream, args);             \
+    } while (0)
     if (in_lds) {
-        if (mode == 1) {
-            hipFuncSetAttribute((const void*)pile_repeats_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)bytes);
-            hipLaunchKernelGGL((pile_repeats_kernel<true, 1>), dim3(grid), dim3(kBlock), bytes, stream, args);
-        } else {
-            hipFuncSetAttribute((const void*)pile_repeats_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)bytes);
-            hipLaunchKernelGGL((pile_repeats_kernel<true, 2>), dim3(grid), dim3(kBlock), bytes, stream, args);
-        }
+        if (mode == 1) RALA_REPEATS(true, 1, false);
+        else if (big) RALA_REPEATS(true, 2, true);
+        else RALA_REPEATS(true, 2, false);
     } else {
-        if (mode == 1) {
-            hipLaunchKernelGGL((pile_repeats_kernel<false, 1>), dim3(grid), dim3(kBlock), bytes, stream, args);
-        } else {
-            hipLaunchKernelGGL((pile_repeats_kernel<false, 2>), dim3(grid), dim3(kBlock), bytes, stream, args);
-        }
+        if (mode == 1) RALA_REPEATS(false, 1, false);
+        else if (big) RALA_REPEATS(false, 2, true);
+        else RALA_REPEATS(false, 2, false);
     }
+#undef RALA_REPEATS
 }
 
 }  // namespace rala_hip

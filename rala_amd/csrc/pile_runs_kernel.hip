@@ -1600,7 +1600,7 @@ __global__ __launch_bounds__(64, kOne ? 7 : kBases > 32768 ? 2 : kBases > 16384 
                         }
                     }
                 }
-                A.n_rep[r] = (uint8_t)cnt;
+                A.n_rep[r] = cnt;
                 A.rep_slot[r] = slot;
             }
         } else if (lane == 0) {
@@ -1635,7 +1635,7 @@ __global__ __launch_bounds__(64, kOne ? 7 : kBases > 32768 ? 2 : kBases > 16384 
             A.alive[r] = 1;
             A.begin[r] = B; A.end[r] = E;
             A.median[r] = (uint16_t)med; A.p10[r] = (uint16_t)p10;
-            A.n_pits[r] = (uint8_t)wp; A.n_hills[r] = (uint8_t)wh;
+            A.n_pits[r] = wp; A.n_hills[r] = wh;
             A.iv_slot[r] = slot;
             if (err) atomicOr(A.error, err);
         }

@@ -94,8 +94,8 @@ int download_read_state(rala_hip_ctx* ctx) {
     HIPCHECK(hipMemcpyAsync(ctx->h_median.data(), ctx->d_median.p, n * 2, hipMemcpyDeviceToHost, s));
     HIPCHECK(hipMemcpyAsync(ctx->h_p10.data(), ctx->d_p10.p, n * 2, hipMemcpyDeviceToHost, s));
     HIPCHECK(hipMemcpyAsync(ctx->h_alive.data(), ctx->d_alive.p, n, hipMemcpyDeviceToHost, s));
-    HIPCHECK(hipMemcpyAsync(ctx->h_n_pits.data(), ctx->d_n_pits.p, n, hipMemcpyDeviceToHost, s));
-    HIPCHECK(hipMemcpyAsync(ctx->h_n_hills.data(), ctx->d_n_hills.p, n, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipMemcpyAsync(ctx->h_n_pits.data(), ctx->d_n_pits.p, n * 4, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipMemcpyAsync(ctx->h_n_hills.data(), ctx->d_n_hills.p, n * 4, hipMemcpyDeviceToHost, s));
     HIPCHECK(hipMemcpyAsync(ctx->h_slot.data(), ctx->d_iv_slot.p, n * 4, hipMemcpyDeviceToHost, s));
     uint32_t small[4];
     HIPCHECK(d2h_small(ctx, small, ctx->d_small.p, sizeof(small), s));
@@ -155,17 +155,24 @@ void build_classes(rala_hip_ctx* ctx, const std::vector<uint32_t>& reads, std::v
 }
 
 // position-space kernel over `reads` (all of them, or the run kernel's overflow)
+// a.big_cap_reg != 0: with the region / interval lists in global memory at those sizes (a.big_space is set here)
 int run_position_kernel(rala_hip_ctx* ctx, PileArgs a, const std::vector<uint32_t>& reads) {
     if (reads.empty()) return RALA_HIP_OK;
     std::vector<uint32_t> order;
     build_classes(ctx, reads, order);
+    HIPCHECK(ctx->d_order.ensure(order.size() + 1));
     HIPCHECK(hipMemcpyAsync(ctx->d_order.p, order.data(), order.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    const bool big = a.big_cap_reg != 0;
+    const uint64_t big_words = big ? pile_big_words(a.big_cap_reg, a.big_cap_list, a.big_cap_raw) : 0;
     for (const LaunchClass& c : ctx->classes) {
         uint32_t grid = c.count;
-        if (!c.in_lds) {
-            grid = std::min<uint32_t>(c.count, 512);
-            HIPCHECK(ctx->d_slab.ensure((size_t)grid * 3 * c.lw));
+        if (!c.in_lds) grid = std::min<uint32_t>(c.count, 512);
+        if (big) {
+            grid = std::min<uint32_t>(grid, 64);
+            HIPCHECK(ctx->d_big_space.ensure((size_t)(big_words * grid)));
+            a.big_space = ctx->d_big_space.p;
         }
+        if (!c.in_lds) HIPCHECK(ctx->d_slab.ensure((size_t)grid * 3 * c.lw));
         a.order = ctx->d_order.p + c.first;
         a.n_items = c.count;
         a.lw = c.lw;
@@ -174,6 +181,72 @@ int run_position_kernel(rala_hip_ctx* ctx, PileArgs a, const std::vector<uint32_
         ++ctx->tm.pile_launches;
     }
     HIPCHECK(stream_sync(ctx, ctx->stream));      // `order` is pageable host memory
+    return RALA_HIP_OK;
+}
+
+// first sizes of the lists in global memory (the position-space kernels' LDS lists hold 192 regions per flag list and 64 raw
+// intervals); the option debug_big_caps = regions << 32 | raw intervals makes tests start lower
+void first_big_caps(const rala_hip_ctx* ctx, uint32_t& cap_reg, uint32_t& cap_list, uint32_t& cap_raw) {
+    cap_reg = 1024; cap_raw = 4096;
+    if (ctx->debug_big_caps) {
+        cap_reg = std::max<uint32_t>(4, (uint32_t)((uint64_t)ctx->debug_big_caps >> 32));
+        cap_raw = std::max<uint32_t>(4, (uint32_t)((uint64_t)ctx->debug_big_caps & 0xFFFFFFFFu));
+    }
+    cap_list = 4 * cap_reg;
+}
+
+// The reads the position-space kernel noted in d_big_list[0] (*count_dev of them): once more, with the region lists and raw
+// intervals in global memory; lists that still do not fit are doubled for the reads concerned until they do (the reference
+// keeps them in vectors, pile.cpp:66, 359, 448).  a: the call's arguments (a.error keeps its pool-capacity bit).
+int run_unbounded_piles(rala_hip_ctx* ctx, PileArgs a, uint32_t count, uint32_t* count_dev) {
+    hipStream_t s = ctx->stream;
+    uint32_t cap_reg, cap_list, cap_raw;
+    first_big_caps(ctx, cap_reg, cap_list, cap_raw);
+    ctx->tm.pile_unbounded_reads += count;
+    int from = 0;
+    while (count) {
+        std::vector<uint32_t> reads(count);
+        HIPCHECK(hipMemcpy(reads.data(), ctx->d_big_list[from].p, (size_t)count * 4, hipMemcpyDeviceToHost));
+        std::sort(reads.begin(), reads.end());
+        HIPCHECK(ctx->d_big_list[from ^ 1].ensure(ctx->n_reads + 1));
+        uint32_t status = 0;
+        HIPCHECK(hipMemcpy(&status, a.error, 4, hipMemcpyDeviceToHost));
+        status &= kErrPoolCapacity;
+        HIPCHECK(hipMemcpyAsync(a.error, &status, 4, hipMemcpyHostToDevice, s));
+        HIPCHECK(hipMemsetAsync(count_dev, 0, 4, s));
+        a.big_list = ctx->d_big_list[from ^ 1].p;
+        a.big_count = count_dev;
+        a.big_cap_reg = cap_reg; a.big_cap_list = cap_list; a.big_cap_raw = cap_raw;
+        a.n_items_dev = nullptr;
+        const int rc = run_position_kernel(ctx, a, reads);
+        if (rc != RALA_HIP_OK) return rc;
+        uint32_t left = 0;
+        HIPCHECK(hipMemcpy(&left, count_dev, 4, hipMemcpyDeviceToHost));
+        HIPCHECK(hipMemcpy(&status, a.error, 4, hipMemcpyDeviceToHost));
+        HIPCHECK(hipGetLastError());
+        if (getenv("RALA_HIP_TRACE")) {
+            fprintf(stderr, "[trace] lists in global memory: %u reads at %u regions / %u raw intervals, %u left (status %u)\n", count, cap_reg,
+                    cap_raw, left, status);
+        }
+        if (left && !(status & (kErrRegionCapacity | kErrRawCapacity))) {
+            return fail(ctx, RALA_HIP_EDEVICE, "position-space kernel: reads left without a reason");
+        }
+        if (status & kErrRegionCapacity) {
+            if (cap_reg > (1u << 26)) return fail(ctx, RALA_HIP_ENOMEM, "slope-region lists beyond 2^26 entries");
+            cap_reg *= 2; cap_list *= 2;
+        }
+        if (status & kErrRawCapacity) {
+            if (cap_raw > (1u << 28)) return fail(ctx, RALA_HIP_ENOMEM, "interval lists beyond 2^28 entries");
+            cap_raw *= 2;
+        }
+        count = left;
+        from ^= 1;
+    }
+    // (the lists' bits are no error of the call any more)
+    uint32_t status = 0;
+    HIPCHECK(hipMemcpy(&status, a.error, 4, hipMemcpyDeviceToHost));
+    status &= kErrPoolCapacity;
+    HIPCHECK(hipMemcpy(a.error, &status, 4, hipMemcpyHostToDevice));
     return RALA_HIP_OK;
 }
 
@@ -249,7 +322,7 @@ bool break_hills(rala_hip_ctx* ctx, uint32_t r, const Interval* hills, uint32_t 
 // Pile::break_over_chimeric_pits (pile.cpp:366-402); a pit is real when some
 // coverage inside it satisfies data*1.84 <= median — monotone in data, so the
 // minimum recorded by the pile kernel decides.  Unreal pits are kept (in place).
-bool break_pits(rala_hip_ctx* ctx, uint32_t r, Interval* pits, uint8_t& n_pits, uint16_t dataset_median) {
+bool break_pits(rala_hip_ctx* ctx, uint32_t r, Interval* pits, uint32_t& n_pits, uint16_t dataset_median) {
     const uint32_t B = ctx->h_begin[r], E = ctx->h_end[r];
     uint32_t b = 0, e = 0, from = B;
     uint32_t w = 0;
@@ -264,7 +337,7 @@ bool break_pits(rala_hip_ctx* ctx, uint32_t r, Interval* pits, uint8_t& n_pits, 
         }
     }
     if ((uint32_t)(E - from) > (uint32_t)(e - b)) { b = from; e = E; }
-    n_pits = (uint8_t)w;
+    n_pits = w;
     return host_shrink(ctx, r, b, e);
 }
 
@@ -363,7 +436,7 @@ int preprocess_chimeras(rala_hip_ctx* ctx) {
         ctx->alive_rank[r] = (uint32_t)ctx->alive_reads.size();
         ctx->alive_reads.push_back((uint32_t)r);
     }
-    const std::vector<uint8_t>& n_pits0 = ctx->h_n_pits0;     // hills sit behind the initial pits
+    const std::vector<uint32_t>& n_pits0 = ctx->h_n_pits0;     // hills sit behind the initial pits
     ctx->h_n_pits0 = ctx->h_n_pits;
     // break over chimeric hills (graph.cpp:704-720)
     for (uint32_t r : ctx->alive_reads) {
@@ -500,20 +573,27 @@ int preprocess_chimeras(rala_hip_ctx* ctx) {
     return RALA_HIP_OK;
 }
 
-// position-space sensitive-pass kernel over `reads`, grouped by LDS image size
-int run_repeats_kernel(rala_hip_ctx* ctx, RepeatArgs a, const std::vector<uint32_t>& reads, int mode) {
-    if (reads.empty()) return RALA_HIP_OK;
+// position-space sensitive-pass kernel over `reads`, grouped by LDS image size.  Mode 2: a read whose region lists or
+// raw hills outgrow the kernel's LDS lists is noted and runs again with the lists in global memory, doubled until the read
+// fits (as run_unbounded_piles).
+int run_repeats_classes(rala_hip_ctx* ctx, RepeatArgs a, const std::vector<uint32_t>& reads, int mode) {
     Trace trc;
     std::vector<uint32_t> order;
     build_classes(ctx, reads, order);
     trc("repeats: classes", reads.size());
+    HIPCHECK(ctx->d_order.ensure(order.size() + 1));
     HIPCHECK(hipMemcpyAsync(ctx->d_order.p, order.data(), order.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    const bool big = mode == 2 && a.big_cap_reg != 0;
+    const uint64_t big_words = big ? repeats_big_words(a.big_cap_reg, a.big_cap_list, a.big_cap_raw) : 0;
     for (const LaunchClass& c : ctx->classes) {
         uint32_t grid = c.count;
-        if (!c.in_lds) {
-            grid = std::min<uint32_t>(c.count, 512);
-            HIPCHECK(ctx->d_slab.ensure((size_t)grid * 3 * c.lw));
+        if (!c.in_lds) grid = std::min<uint32_t>(c.count, 512);
+        if (big) {
+            grid = std::min<uint32_t>(grid, 64);
+            HIPCHECK(ctx->d_big_space.ensure((size_t)(big_words * grid)));
+            a.big_space = ctx->d_big_space.p;
         }
+        if (!c.in_lds) HIPCHECK(ctx->d_slab.ensure((size_t)grid * 3 * c.lw));
         a.order = ctx->d_order.p + c.first;
         a.n_items = c.count;
         a.lw = c.lw;
@@ -523,6 +603,67 @@ int run_repeats_kernel(rala_hip_ctx* ctx, RepeatArgs a, const std::vector<uint32
     HIPCHECK(stream_sync(ctx, ctx->stream));
     HIPCHECK(hipGetLastError());
     trc("repeats: kernels", ctx->classes.size());
+    return RALA_HIP_OK;
+}
+
+int run_repeats_kernel(rala_hip_ctx* ctx, RepeatArgs a, const std::vector<uint32_t>& reads, int mode) {
+    if (reads.empty()) return RALA_HIP_OK;
+    if (mode != 2) return run_repeats_classes(ctx, a, reads, mode);
+    hipStream_t s = ctx->stream;
+    uint32_t* const count_dev = ctx->d_small.p + 8;
+    HIPCHECK(ctx->d_big_list[0].ensure(ctx->n_reads + 1));
+    HIPCHECK(hipMemsetAsync(count_dev, 0, 4, s));
+    a.big_list = ctx->d_big_list[0].p;
+    a.big_count = count_dev;
+    a.big_space = nullptr; a.big_cap_reg = a.big_cap_list = a.big_cap_raw = 0;
+    int rc = run_repeats_classes(ctx, a, reads, 2);
+    if (rc != RALA_HIP_OK) return rc;
+    uint32_t count = 0;
+    HIPCHECK(hipMemcpy(&count, count_dev, 4, hipMemcpyDeviceToHost));
+    uint32_t cap_reg, cap_list, cap_raw;
+    first_big_caps(ctx, cap_reg, cap_list, cap_raw);
+    cap_list = 2 * cap_reg;
+    ctx->tm.pile_unbounded_reads += count;
+    int from = 0;
+    while (count) {
+        std::vector<uint32_t> again(count);
+        HIPCHECK(hipMemcpy(again.data(), ctx->d_big_list[from].p, (size_t)count * 4, hipMemcpyDeviceToHost));
+        std::sort(again.begin(), again.end());
+        HIPCHECK(ctx->d_big_list[from ^ 1].ensure(ctx->n_reads + 1));
+        uint32_t status = 0;
+        HIPCHECK(hipMemcpy(&status, a.error, 4, hipMemcpyDeviceToHost));
+        status &= kErrPoolCapacity;
+        HIPCHECK(hipMemcpyAsync(a.error, &status, 4, hipMemcpyHostToDevice, s));
+        HIPCHECK(hipMemsetAsync(count_dev, 0, 4, s));
+        a.big_list = ctx->d_big_list[from ^ 1].p;
+        a.big_cap_reg = cap_reg; a.big_cap_list = cap_list; a.big_cap_raw = cap_raw;
+        rc = run_repeats_classes(ctx, a, again, 2);
+        if (rc != RALA_HIP_OK) return rc;
+        uint32_t left = 0;
+        HIPCHECK(hipMemcpy(&left, count_dev, 4, hipMemcpyDeviceToHost));
+        HIPCHECK(hipMemcpy(&status, a.error, 4, hipMemcpyDeviceToHost));
+        if (getenv("RALA_HIP_TRACE")) {
+            fprintf(stderr, "[trace] repeat hills, lists in global memory: %u reads at %u regions / %u raw intervals, %u left (status %u)\n",
+                    count, cap_reg, cap_raw, left, status);
+        }
+        if (left && !(status & (kErrRegionCapacity | kErrRawCapacity))) {
+            return fail(ctx, RALA_HIP_EDEVICE, "repeat-hill kernel: reads left without a reason");
+        }
+        if (status & kErrRegionCapacity) {
+            if (cap_reg > (1u << 26)) return fail(ctx, RALA_HIP_ENOMEM, "slope-region lists beyond 2^26 entries");
+            cap_reg *= 2; cap_list *= 2;
+        }
+        if (status & kErrRawCapacity) {
+            if (cap_raw > (1u << 28)) return fail(ctx, RALA_HIP_ENOMEM, "interval lists beyond 2^28 entries");
+            cap_raw *= 2;
+        }
+        count = left;
+        from ^= 1;
+    }
+    uint32_t status = 0;
+    HIPCHECK(hipMemcpy(&status, a.error, 4, hipMemcpyDeviceToHost));
+    status &= kErrPoolCapacity;
+    HIPCHECK(hipMemcpy(a.error, &status, 4, hipMemcpyHostToDevice));
     return RALA_HIP_OK;
 }
 
@@ -661,8 +802,9 @@ int preprocess_repeats(rala_hip_ctx* cs, rala_hip_ctx* cl, Comm* comm, const ral
     HIPCHECK(cs->d_dataset_median.ensure(n));
     HIPCHECK(cs->d_n_rep.ensure(n));
     HIPCHECK(cs->d_rep_slot.ensure(n));
-    HIPCHECK(cs->d_rep_pool.ensure(cs->pool_cap));
-    HIPCHECK(hipMemsetAsync(cs->d_n_rep.p, 0, n, s));
+    cs->rep_pool_cap = std::max(cs->rep_pool_cap, cs->pool_cap);
+    HIPCHECK(cs->d_rep_pool.ensure(cs->rep_pool_cap));
+    HIPCHECK(hipMemsetAsync(cs->d_n_rep.p, 0, n * 4, s));
     HIPCHECK(hipMemsetAsync(cs->d_small.p + 6, 0, 8, s));           // [6] rep pool count [7] error
     HIPCHECK(hipMemsetAsync(cs->d_small.p + 2, 0, 4, s));           // [2] bad sensitive record
     launch_sens_tuples(so, (uint32_t)n, cs->d_begin.p, cs->d_alive.p, cs->d_sens_tb[0].p, cs->d_sens_tb[1].p,
@@ -717,9 +859,10 @@ int preprocess_repeats(rala_hip_ctx* cs, rala_hip_ctx* cl, Comm* comm, const ral
     HIPCHECK(cl->d_dataset_median.ensure(nl));
     HIPCHECK(cl->d_n_rep.ensure(nl));
     HIPCHECK(cl->d_rep_slot.ensure(nl));
-    HIPCHECK(cl->d_rep_pool.ensure(cl->pool_cap));
+    cl->rep_pool_cap = std::max(cl->rep_pool_cap, cl->pool_cap);
+    HIPCHECK(cl->d_rep_pool.ensure(cl->rep_pool_cap));
     if (sharded) {
-        HIPCHECK(hipMemsetAsync(cl->d_n_rep.p, 0, nl, sl));
+        HIPCHECK(hipMemsetAsync(cl->d_n_rep.p, 0, nl * 4, sl));
         HIPCHECK(hipMemsetAsync(cl->d_small.p + 6, 0, 8, sl));
     }
     HIPCHECK(hipMemsetAsync(cl->d_sens_cur.p, 0, (nl + 1) * 4, sl));
@@ -741,7 +884,7 @@ int preprocess_repeats(rala_hip_ctx* cs, rala_hip_ctx* cl, Comm* comm, const ral
     a.ev_off = cl->d_sens_off.p; a.ev = cl->d_sens_ev.p;
     a.begin = cl->d_begin.p; a.end = cl->d_end.p; a.median = cl->d_median.p; a.p10 = cl->d_p10.p;
     a.dataset_median = cl->d_dataset_median.p; a.n_rep = cl->d_n_rep.p; a.rep_slot = cl->d_rep_slot.p;
-    a.pool = cl->d_rep_pool.p; a.pool_count = cl->d_small.p + 6; a.pool_cap = cl->pool_cap;
+    a.pool = cl->d_rep_pool.p; a.pool_count = cl->d_small.p + 6; a.pool_cap = cl->rep_pool_cap;
     a.error = cl->d_small.p + 7;
     a.order = nullptr; a.n_items = 0; a.lw = 0; a.slab = nullptr;
     // the same in run space: the primary events + the sensitive bounds
@@ -755,7 +898,7 @@ int preprocess_repeats(rala_hip_ctx* cs, rala_hip_ctx* cl, Comm* comm, const ral
     pa.error = cl->d_small.p + 7;
     pa.sens_off = cl->d_sens_off.p; pa.sens_ev = cl->d_sens_ev.p;
     pa.dataset_median = cl->d_dataset_median.p; pa.n_rep = cl->d_n_rep.p; pa.rep_slot = cl->d_rep_slot.p;
-    pa.rep_pool = cl->d_rep_pool.p; pa.rep_pool_count = cl->d_small.p + 6; pa.rep_pool_cap = cl->pool_cap;
+    pa.rep_pool = cl->d_rep_pool.p; pa.rep_pool_count = cl->d_small.p + 6; pa.rep_pool_cap = cl->rep_pool_cap;
     // add_layers on top of the coverage + find_median for the targets (graph.cpp:941-969)
     int rc = run_sens_pass(cl, pa, a, targets, 1);
     if (rc != RALA_HIP_OK) { if (cl != cs) cs->err = cl->err; return rc; }
@@ -807,15 +950,28 @@ int preprocess_repeats(rala_hip_ctx* cs, rala_hip_ctx* cl, Comm* comm, const ral
         for (uint32_t q = 0; q < n_alive; ++q) if (cs->p_touched.p[q]) members.push_back(cs->p_alive_reads.p[q]);
     }
     trc("rep: component medians", members.size());
-    if (!sharded) {
-        rc = run_sens_pass(cl, pa, a, members, 2);
-        if (rc != RALA_HIP_OK) return rc;
-    } else {
+    std::vector<uint32_t> mine;
+    if (sharded) {
         launch_localize_u16(cs->d_dataset_median.p, nl, P, me, cl->d_dataset_median.p, sl);
-        std::vector<uint32_t> mine;
         for (uint32_t r : members) if (r % P == me) mine.push_back(r / P);
-        rc = run_sens_pass(cl, pa, a, mine, 2);
-        if (rc != RALA_HIP_OK) { cs->err = cl->err; return rc; }
+    }
+    for (;;) {
+        rc = run_sens_pass(cl, pa, a, sharded ? mine : members, 2);
+        if (rc != RALA_HIP_OK) { if (cl != cs) cs->err = cl->err; return rc; }
+        uint32_t st[2];
+        HIPCHECK(hipMemcpy(st, cl->d_small.p + 6, sizeof(st), hipMemcpyDeviceToHost));
+        if (!(st[1] & kErrPoolCapacity)) break;
+        // more repeat hills than the pool holds: its counter holds what is needed - the pass once more (mode 2 neither
+        // reads nor writes the rows) with a pool of that size
+        const uint64_t need = (uint64_t)st[0] + st[0] / 8 + 1024;
+        if (st[0] <= cl->rep_pool_cap || need > 0xFFFFFFF0ull) return fail(ctx, RALA_HIP_ENOMEM, "repeat-hill pool beyond 2^32 entries");
+        cl->rep_pool_cap = (uint32_t)need;
+        HIPCHECK(cl->d_rep_pool.ensure(cl->rep_pool_cap));
+        a.pool = cl->d_rep_pool.p; a.pool_cap = cl->rep_pool_cap;
+        pa.rep_pool = cl->d_rep_pool.p; pa.rep_pool_cap = cl->rep_pool_cap;
+        HIPCHECK(hipMemsetAsync(cl->d_n_rep.p, 0, nl * 4, sl));
+        HIPCHECK(hipMemsetAsync(cl->d_small.p + 6, 0, 8, sl));
+        ++cl->tm.pool_regrown;
     }
     uint32_t small[8];
     HIPCHECK(hipMemcpy(small, cl->d_small.p, sizeof(small), hipMemcpyDeviceToHost));
@@ -828,10 +984,10 @@ int preprocess_repeats(rala_hip_ctx* cs, rala_hip_ctx* cl, Comm* comm, const ral
         HIPCHECK(d2h_small(cs, &small[7], cs->d_small.p + 7, 4, s));
         HIPCHECK(stream_sync(cs, s));
     }
-    if (small[7] & kErrRegionCapacity) return fail(ctx, RALA_HIP_ECAPACITY, "slope-region list overflow (repeat hills)");
-    if (small[7] & kErrPoolCapacity) return fail(ctx, RALA_HIP_ECAPACITY, "repeat-hill pool exhausted");
+    if (small[7] & (kErrRegionCapacity | kErrRawCapacity)) return fail(ctx, RALA_HIP_EDEVICE, "slope-region list overflow (repeat hills)");
+    if (small[7] & kErrPoolCapacity) return fail(ctx, RALA_HIP_EDEVICE, "repeat-hill pool exhausted");
     if (sharded) {
-        const uint64_t mine = std::min<uint32_t>(small[6], cl->pool_cap);
+        const uint64_t mine = std::min<uint32_t>(small[6], cl->rep_pool_cap);
         std::vector<uint64_t> counts(P);
         if (comm->host_all_gather(&mine, 1, counts.data(), s) != 0) return comm_fail("repeat-hill counts");
         RankOffsets base;
@@ -862,7 +1018,7 @@ int preprocess_repeats(rala_hip_ctx* cs, rala_hip_ctx* cl, Comm* comm, const ral
     HIPCHECK(hipGetLastError());
     trc("rep: bridged hills", n_sens);
     cs->h_n_rep.resize(n); cs->h_rep_slot.resize(n);
-    HIPCHECK(hipMemcpy(cs->h_n_rep.data(), cs->d_n_rep.p, n, hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(cs->h_n_rep.data(), cs->d_n_rep.p, n * 4, hipMemcpyDeviceToHost));
     HIPCHECK(hipMemcpy(cs->h_rep_slot.data(), cs->d_rep_slot.p, n * 4, hipMemcpyDeviceToHost));
     cs->h_rep_pool.resize(n_hills);
     if (n_hills) {
@@ -1702,7 +1858,7 @@ int rala_hip_create(int device, rala_hip_ctx** out) {
     bool ok = hipStreamCreate(&ctx->stream) == hipSuccess && hipStreamCreate(&ctx->side) == hipSuccess &&
               hipStreamCreate(&ctx->aux) == hipSuccess;
     for (auto& e : ctx->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
-    ok = ok && ctx->d_small.ensure(8) == hipSuccess;
+    ok = ok && ctx->d_small.ensure(16) == hipSuccess;
     if (!ok) {                                  // (rala_hip_destroy releases whatever was created)
         rala_hip_destroy(ctx);
         return RALA_HIP_EDEVICE;
@@ -1731,6 +1887,7 @@ const char* rala_hip_last_error(const rala_hip_ctx* ctx) { return ctx ? ctx->err
 int rala_hip_set_option(rala_hip_ctx* ctx, const char* key, int64_t value) {
     if (!ctx || !key) return RALA_HIP_EINVAL;
     if (!strcmp(key, "interval_pool_per_read_x1000")) { ctx->pool_per_read_x1000 = value; return RALA_HIP_OK; }
+    if (!strcmp(key, "debug_big_caps")) { ctx->debug_big_caps = value; return RALA_HIP_OK; }
     if (!strcmp(key, "max_lds_read_len")) { ctx->max_lds_read_len = value; return RALA_HIP_OK; }
     if (!strcmp(key, "debug_pile_stop_after")) { ctx->debug_pile_stop_after = value; return RALA_HIP_OK; }
     if (!strcmp(key, "use_run_kernel")) { ctx->use_run_kernel = value != 0; return RALA_HIP_OK; }
@@ -1881,7 +2038,7 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
     HIPCHECK(hipEventRecord(ctx->ev[0], s));
     // the call's counters and what the bucketing wants cleared: one fill (fill_kernels.hip)
     FillList fills;
-    fills.add(ctx->d_small.p, 0, 8 * 4);
+    fills.add(ctx->d_small.p, 0, 16 * 4);
     // duplicate removal only feeds the second pass (every resolvable overlap adds its bounds,
     // valid or not): it runs on a second stream beside the pile kernels (started when the
     // bucketing is done - beside the bucketing, both reading the same columns while the atomics
@@ -1984,6 +2141,9 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
     a.alive = ctx->d_alive.p; a.n_pits = ctx->d_n_pits.p; a.n_hills = ctx->d_n_hills.p; a.iv_slot = ctx->d_iv_slot.p;
     a.pool = ctx->d_pool.p; a.pool_count = ctx->d_small.p; a.pool_cap = ctx->pool_cap; a.error = ctx->d_small.p + 1;
     a.n_items_dev = nullptr;
+    // (what outgrows the position-space kernel's LDS lists: noted, and dealt with after this call's one look from the host)
+    HIPCHECK(ctx->d_big_list[0].ensure(n_reads + 1));
+    a.big_list = ctx->d_big_list[0].p; a.big_count = ctx->d_small.p + 8;
     if (ctx->use_run_kernel) {
         // Chain without host synchronisation.  Every read starts in the kernel that fits it, known
         // beforehand: by length class (set_reads sorted them) and by event count (listed from the
@@ -2069,10 +2229,22 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
 
     // the per-read results stay on the device; host mirrors are fetched by the first getter
     launch_count_zero_u8(ctx->d_alive.p, n_reads, ctx->d_small.p + 7, s);
-    uint32_t small[8];
+    uint32_t small[16];
     HIPCHECK(d2h_small(ctx, small, ctx->d_small.p, sizeof(small), s));
     HIPCHECK(stream_sync(ctx, s));
-    const uint32_t n_dead = small[7], slot_overflow = fixed ? small[6] : 0;
+    const uint32_t slot_overflow = fixed ? small[6] : 0;
+    if (small[8] && !slot_overflow) {
+        // reads whose region / interval lists outgrew the position-space kernel's LDS lists
+        const int rc_big = run_unbounded_piles(ctx, a, small[8], ctx->d_small.p + 8);
+        if (rc_big != RALA_HIP_OK) return rc_big;
+        HIPCHECK(hipMemsetAsync(ctx->d_small.p + 7, 0, 4, s));
+        launch_count_zero_u8(ctx->d_alive.p, n_reads, ctx->d_small.p + 7, s);
+        const uint32_t noted = small[8];
+        HIPCHECK(d2h_small(ctx, small, ctx->d_small.p, sizeof(small), s));
+        HIPCHECK(stream_sync(ctx, s));
+        small[8] = noted;
+    }
+    const uint32_t n_dead = small[7];
     if (slot_overflow) {
         // some read has more events than a fixed slot holds: once more, through the exact path
         const int64_t keep = ctx->use_fixed_buckets;
@@ -2103,9 +2275,18 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
         ctx->tm.dedupe_ms = forked ? std::max(0.0f, dd - all) : dd;
     }
     HIPCHECK(hipEventElapsedTime(&ctx->tm.pile_ms, ctx->ev[2], ctx->ev[3]));
-    if (small[1] & kErrRegionCapacity) return fail(ctx, RALA_HIP_ECAPACITY, "slope-region list overflow in the pile kernel");
+    if (small[1] & (kErrRegionCapacity | kErrRawCapacity)) return fail(ctx, RALA_HIP_EDEVICE, "slope-region list overflow in the pile kernel");
     if (small[1] & kErrPoolCapacity) {
-        return fail(ctx, RALA_HIP_ECAPACITY, "interval pool exhausted (raise interval_pool_per_read_x1000)");
+        // more pits and hills than the pool holds (interval_pool_per_read_x1000 is a hint): its counter holds what is needed -
+        // once more with a pool of that size (and a little more: the slots of reads that ran twice are not handed back)
+        const uint64_t need = (uint64_t)small[0] + small[0] / 8 + 1024;
+        if (small[0] <= ctx->pool_cap || need > 0xFFFFFFF0ull) return fail(ctx, RALA_HIP_ENOMEM, "interval pool beyond 2^32 entries");
+        ctx->pool_cap = (uint32_t)need;
+        HIPCHECK(ctx->d_pool.ensure(ctx->pool_cap));
+        const uint32_t regrown = ctx->tm.pool_regrown + 1;
+        const int rc_again = rala_hip_initialize(ctx);
+        ctx->tm.pool_regrown = regrown;
+        return rc_again;
     }
     ctx->n_prefiltered = n_dead;
     ctx->ev_ready = true;
@@ -2205,8 +2386,8 @@ int rala_hip_copy_device_state(rala_hip_ctx* ctx, const rala_hip_device_state* d
     HIPCHECK(cp(dst->median, ctx->d_median.p, n * 2));
     HIPCHECK(cp(dst->p10, ctx->d_p10.p, n * 2));
     HIPCHECK(cp(dst->alive, ctx->d_alive.p, n));
-    HIPCHECK(cp(dst->n_pits, ctx->d_n_pits.p, n));
-    HIPCHECK(cp(dst->n_hills, ctx->d_n_hills.p, n));
+    HIPCHECK(cp(dst->n_pits, ctx->d_n_pits.p, n * 4));
+    HIPCHECK(cp(dst->n_hills, ctx->d_n_hills.p, n * 4));
     HIPCHECK(cp(dst->slot, ctx->d_iv_slot.p, n * 4));
     if (dst->pool) {
         if (dst->pool_count < (size_t)ctx->pool_used) return fail(ctx, RALA_HIP_ECAPACITY, "pool buffer too small");
@@ -2244,8 +2425,8 @@ int rala_hip_import_state_device(rala_hip_ctx* ctx, const rala_hip_device_state*
     HIPCHECK(hipMemcpyAsync(ctx->d_median.p, in->median, n * 2, hipMemcpyDeviceToDevice, s));
     HIPCHECK(hipMemcpyAsync(ctx->d_p10.p, in->p10, n * 2, hipMemcpyDeviceToDevice, s));
     HIPCHECK(hipMemcpyAsync(ctx->d_alive.p, in->alive, n, hipMemcpyDeviceToDevice, s));
-    HIPCHECK(hipMemcpyAsync(ctx->d_n_pits.p, in->n_pits, n, hipMemcpyDeviceToDevice, s));
-    HIPCHECK(hipMemcpyAsync(ctx->d_n_hills.p, in->n_hills, n, hipMemcpyDeviceToDevice, s));
+    HIPCHECK(hipMemcpyAsync(ctx->d_n_pits.p, in->n_pits, n * 4, hipMemcpyDeviceToDevice, s));
+    HIPCHECK(hipMemcpyAsync(ctx->d_n_hills.p, in->n_hills, n * 4, hipMemcpyDeviceToDevice, s));
     HIPCHECK(hipMemcpyAsync(ctx->d_iv_slot.p, in->slot, n * 4, hipMemcpyDeviceToDevice, s));
     if (in->pool_count) {
         HIPCHECK(hipMemcpyAsync(ctx->d_pool.p, in->pool, (size_t)in->pool_count * sizeof(Interval), hipMemcpyDeviceToDevice, s));
@@ -2333,13 +2514,13 @@ int rala_hip_import_state(rala_hip_ctx* ctx, const uint8_t* valid, const uint32_
     const uint64_t n = ctx->n_reads;
     ctx->tm = rala_hip_timings();
     ctx->overlaps.clear(); ctx->internals.clear();
-    std::vector<uint8_t> np(n), nh(n);
+    std::vector<uint32_t> np(n), nh(n);
     std::vector<uint32_t> slot(n, 0xFFFFFFFFu);
     std::vector<Interval> pool;
     for (uint64_t r = 0; r < n; ++r) {
         const uint64_t a = pits_off[r + 1] - pits_off[r], b = hills_off[r + 1] - hills_off[r];
-        if (a > 255 || b > 255) return fail(ctx, RALA_HIP_EINVAL, "too many intervals on a read");
-        np[r] = (uint8_t)a; nh[r] = (uint8_t)b;
+        if (a > 0xFFFFFFFFull || b > 0xFFFFFFFFull) return fail(ctx, RALA_HIP_EINVAL, "too many intervals on a read");
+        np[r] = (uint32_t)a; nh[r] = (uint32_t)b;
         if (a + b == 0) continue;
         slot[r] = (uint32_t)pool.size();
         for (uint64_t k = pits_off[r]; k < pits_off[r + 1]; ++k) {
@@ -2363,8 +2544,8 @@ int rala_hip_import_state(rala_hip_ctx* ctx, const uint8_t* valid, const uint32_
     HIPCHECK(hipMemcpy(ctx->d_median.p, median, n * 2, hipMemcpyHostToDevice));
     HIPCHECK(hipMemcpy(ctx->d_p10.p, p10, n * 2, hipMemcpyHostToDevice));
     HIPCHECK(hipMemcpy(ctx->d_alive.p, alive, n, hipMemcpyHostToDevice));
-    HIPCHECK(hipMemcpy(ctx->d_n_pits.p, np.data(), n, hipMemcpyHostToDevice));
-    HIPCHECK(hipMemcpy(ctx->d_n_hills.p, nh.data(), n, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(ctx->d_n_pits.p, np.data(), n * 4, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(ctx->d_n_hills.p, nh.data(), n * 4, hipMemcpyHostToDevice));
     HIPCHECK(hipMemcpy(ctx->d_iv_slot.p, slot.data(), n * 4, hipMemcpyHostToDevice));
     if (used) HIPCHECK(hipMemcpy(ctx->d_pool.p, pool.data(), (size_t)used * sizeof(Interval), hipMemcpyHostToDevice));
     if (ctx->n_ovl) HIPCHECK(hipMemcpy(ctx->d_valid.p, valid, ctx->n_ovl, hipMemcpyHostToDevice));
@@ -2503,9 +2684,10 @@ int rala_hip_find_repetitive_hills(rala_hip_ctx* ctx, uint64_t read, uint32_t be
     HIPCHECK(ctx->d_dataset_median.ensure(n));
     HIPCHECK(ctx->d_n_rep.ensure(n));
     HIPCHECK(ctx->d_rep_slot.ensure(n));
-    HIPCHECK(ctx->d_rep_pool.ensure(ctx->pool_cap));
+    ctx->rep_pool_cap = std::max(ctx->rep_pool_cap, ctx->pool_cap);
+    HIPCHECK(ctx->d_rep_pool.ensure(ctx->rep_pool_cap));
     if (!ctx->have_repeats) {
-        HIPCHECK(hipMemsetAsync(ctx->d_n_rep.p, 0, n, s));
+        HIPCHECK(hipMemsetAsync(ctx->d_n_rep.p, 0, n * 4, s));
         HIPCHECK(hipMemsetAsync(ctx->d_small.p + 6, 0, 8, s));
         ctx->h_n_rep.assign(n, 0); ctx->h_rep_slot.assign(n, 0); ctx->h_rep_pool.clear();
     }
@@ -2522,18 +2704,34 @@ int rala_hip_find_repetitive_hills(rala_hip_ctx* ctx, uint64_t read, uint32_t be
     a.ev_off = ctx->d_ev_off.p; a.ev = ctx->d_ev.p;
     a.begin = ctx->d_begin.p; a.end = ctx->d_end.p; a.median = ctx->d_median.p; a.p10 = ctx->d_p10.p;
     a.dataset_median = ctx->d_dataset_median.p; a.n_rep = ctx->d_n_rep.p; a.rep_slot = ctx->d_rep_slot.p;
-    a.pool = ctx->d_rep_pool.p; a.pool_count = ctx->d_small.p + 6; a.pool_cap = ctx->pool_cap;
+    a.pool = ctx->d_rep_pool.p; a.pool_count = ctx->d_small.p + 6; a.pool_cap = ctx->rep_pool_cap;
     a.error = ctx->d_small.p + 7;
     a.order = nullptr; a.n_items = 0; a.lw = 0; a.slab = nullptr;
     const std::vector<uint32_t> one(1, (uint32_t)read);
-    const int rc = run_repeats_kernel(ctx, a, one, 2);
-    if (rc != RALA_HIP_OK) return rc;
     uint32_t small[8];
-    HIPCHECK(hipMemcpy(small, ctx->d_small.p, sizeof(small), hipMemcpyDeviceToHost));
-    if (small[7] & kErrRegionCapacity) return fail(ctx, RALA_HIP_ECAPACITY, "slope-region list overflow (repeat hills)");
-    if (small[7] & kErrPoolCapacity) return fail(ctx, RALA_HIP_ECAPACITY, "repeat-hill pool exhausted");
+    for (;;) {
+        uint32_t used_before = 0;
+        HIPCHECK(hipMemcpy(&used_before, ctx->d_small.p + 6, 4, hipMemcpyDeviceToHost));
+        const int rc = run_repeats_kernel(ctx, a, one, 2);
+        if (rc != RALA_HIP_OK) return rc;
+        HIPCHECK(hipMemcpy(small, ctx->d_small.p, sizeof(small), hipMemcpyDeviceToHost));
+        if (!(small[7] & kErrPoolCapacity)) break;
+        // the pool (it keeps the hills of earlier calls) is too small for this read's: a larger one, the call once more
+        const uint64_t need = (uint64_t)small[6] + small[6] / 8 + 1024;
+        if (small[6] <= ctx->rep_pool_cap || need > 0xFFFFFFF0ull) return fail(ctx, RALA_HIP_ENOMEM, "repeat-hill pool beyond 2^32 entries");
+        rala_hip::DevBuf<Interval> larger;
+        HIPCHECK(larger.ensure(need));
+        if (used_before) HIPCHECK(hipMemcpy(larger.p, ctx->d_rep_pool.p, (size_t)used_before * sizeof(Interval), hipMemcpyDeviceToDevice));
+        std::swap(larger.p, ctx->d_rep_pool.p);
+        std::swap(larger.n, ctx->d_rep_pool.n);
+        ctx->rep_pool_cap = (uint32_t)need;
+        a.pool = ctx->d_rep_pool.p; a.pool_cap = ctx->rep_pool_cap;
+        const uint32_t reset[2] = {used_before, 0};
+        HIPCHECK(hipMemcpy(ctx->d_small.p + 6, reset, 8, hipMemcpyHostToDevice));
+    }
+    if (small[7] & (kErrRegionCapacity | kErrRawCapacity)) return fail(ctx, RALA_HIP_EDEVICE, "slope-region list overflow (repeat hills)");
     ctx->h_n_rep.resize(n); ctx->h_rep_slot.resize(n);
-    HIPCHECK(hipMemcpy(&ctx->h_n_rep[read], ctx->d_n_rep.p + read, 1, hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(&ctx->h_n_rep[read], ctx->d_n_rep.p + read, 4, hipMemcpyDeviceToHost));
     HIPCHECK(hipMemcpy(&ctx->h_rep_slot[read], ctx->d_rep_slot.p + read, 4, hipMemcpyDeviceToHost));
     ctx->h_rep_pool.resize(small[6]);
     if (small[6]) HIPCHECK(hipMemcpy(ctx->h_rep_pool.data(), ctx->d_rep_pool.p, (size_t)small[6] * sizeof(Interval), hipMemcpyDeviceToHost));

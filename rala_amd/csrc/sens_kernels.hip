@@ -68,7 +68,7 @@ __global__ __launch_bounds__(kBlock) void sens_trim_kernel(OvlSoA o, const uint3
 __global__ __launch_bounds__(kBlock) void sens_bridge_kernel(OvlSoA o, SensCoords sc, const uint32_t* __restrict__ begin,
                                                              const uint32_t* __restrict__ end,
                                                              const uint8_t* __restrict__ alive,
-                                                             const uint8_t* __restrict__ n_rep,
+                                                             const uint32_t* __restrict__ n_rep,
                                                              const uint32_t* __restrict__ rep_slot, Interval* rep_pool) {
     const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= o.n || !sc.state[i]) return;
@@ -115,7 +115,7 @@ __device__ __forceinline__ bool pile_valid_overlap(uint32_t x, uint32_t y, uint3
 // graph.cpp:1045-1051 on the device list: overlaps (not internals) that fail on either side leave
 __global__ __launch_bounds__(kBlock) void sens_filter_kernel(TailList L, const uint32_t* __restrict__ begin,
                                                              const uint32_t* __restrict__ end,
-                                                             const uint8_t* __restrict__ n_rep,
+                                                             const uint32_t* __restrict__ n_rep,
                                                              const uint32_t* __restrict__ rep_slot,
                                                              const Interval* __restrict__ rep_pool) {
     const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
@@ -164,7 +164,7 @@ void launch_sens_trim(const OvlSoA& o, const uint32_t* tb_begin, const uint32_t*
     if (o.n) hipLaunchKernelGGL(sens_trim_kernel, grid_for(o.n), dim3(kBlock), 0, s, o, tb_begin, tb_end, begin, end, alive, out);
 }
 void launch_sens_bridge(const OvlSoA& o, const SensCoords& sc, const uint32_t* begin, const uint32_t* end,
-                        const uint8_t* alive, const uint8_t* n_rep, const uint32_t* rep_slot, Interval* rep_pool,
+                        const uint8_t* alive, const uint32_t* n_rep, const uint32_t* rep_slot, Interval* rep_pool,
                         hipStream_t s) {
     if (o.n) {
         hipLaunchKernelGGL(sens_bridge_kernel, grid_for(o.n), dim3(kBlock), 0, s, o, sc, begin, end, alive, n_rep, rep_slot,
@@ -172,7 +172,7 @@ void launch_sens_bridge(const OvlSoA& o, const SensCoords& sc, const uint32_t* b
     }
 }
 
-void launch_sens_filter(const TailList& L, const uint32_t* begin, const uint32_t* end, const uint8_t* n_rep,
+void launch_sens_filter(const TailList& L, const uint32_t* begin, const uint32_t* end, const uint32_t* n_rep,
                         const uint32_t* rep_slot, const Interval* rep_pool, hipStream_t s) {
     if (L.n) hipLaunchKernelGGL(sens_filter_kernel, grid_for(L.n), dim3(kBlock), 0, s, L, begin, end, n_rep, rep_slot, rep_pool);
 }

@@ -70,21 +70,21 @@ __global__ __launch_bounds__(kBlock) void unpack_median_kernel(const uint32_t* a
     p10[r] = (uint16_t)(w >> 16);
 }
 
-// repeat hills: one 8-byte word per local read, slot << 8 | count
-__global__ __launch_bounds__(kBlock) void pack_rep_kernel(const uint8_t* n_rep, const uint32_t* rep_slot, uint64_t n_local,
+// repeat hills: one 8-byte word per local read, slot << 32 | count
+__global__ __launch_bounds__(kBlock) void pack_rep_kernel(const uint32_t* n_rep, const uint32_t* rep_slot, uint64_t n_local,
                                                           uint64_t nl_pad, uint64_t* out) {
     const uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (j < nl_pad) out[j] = j < n_local && n_rep[j] ? ((uint64_t)rep_slot[j] << 8) | n_rep[j] : 0ull;
+    if (j < nl_pad) out[j] = j < n_local && n_rep[j] ? ((uint64_t)rep_slot[j] << 32) | n_rep[j] : 0ull;
 }
 __global__ __launch_bounds__(kBlock) void unpack_rep_kernel(const uint64_t* all, uint32_t world, uint64_t nl_pad,
-                                                            uint64_t n_reads, RankOffsets pool_base, uint8_t* n_rep,
+                                                            uint64_t n_reads, RankOffsets pool_base, uint32_t* n_rep,
                                                             uint32_t* rep_slot) {
     const uint64_t r = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     if (r >= n_reads) return;
     const uint32_t k = (uint32_t)(r % world);
     const uint64_t w = all[k * nl_pad + r / world];
-    n_rep[r] = (uint8_t)w;
-    rep_slot[r] = (uint32_t)(w >> 8) + pool_base.v[k];
+    n_rep[r] = (uint32_t)w;
+    rep_slot[r] = (uint32_t)(w >> 32) + pool_base.v[k];
 }
 
 // flags of the repeat hills (Interval::aux): mode 0 pool -> dense, mode 1 dense -> pool
@@ -122,11 +122,11 @@ void launch_unpack_median(const uint32_t* all, uint32_t world, uint64_t nl_pad, 
                           hipStream_t s) {
     if (n_reads) hipLaunchKernelGGL(unpack_median_kernel, grid_for(n_reads), dim3(kBlock), 0, s, all, world, nl_pad, n_reads, median, p10);
 }
-void launch_pack_rep(const uint8_t* n_rep, const uint32_t* rep_slot, uint64_t n_local, uint64_t nl_pad, uint64_t* out, hipStream_t s) {
+void launch_pack_rep(const uint32_t* n_rep, const uint32_t* rep_slot, uint64_t n_local, uint64_t nl_pad, uint64_t* out, hipStream_t s) {
     if (nl_pad) hipLaunchKernelGGL(pack_rep_kernel, grid_for(nl_pad), dim3(kBlock), 0, s, n_rep, rep_slot, n_local, nl_pad, out);
 }
 void launch_unpack_rep(const uint64_t* all, uint32_t world, uint64_t nl_pad, uint64_t n_reads, const RankOffsets& pool_base,
-                       uint8_t* n_rep, uint32_t* rep_slot, hipStream_t s) {
+                       uint32_t* n_rep, uint32_t* rep_slot, hipStream_t s) {
     if (n_reads) {
         hipLaunchKernelGGL(unpack_rep_kernel, grid_for(n_reads), dim3(kBlock), 0, s, all, world, nl_pad, n_reads, pool_base, n_rep,
                            rep_slot);

@@ -69,18 +69,19 @@ struct StateLayout {
     __host__ __device__ uint64_t begin() const { return 0; }
     __host__ __device__ uint64_t end() const { return 4 * nl; }
     __host__ __device__ uint64_t slot() const { return 8 * nl; }
-    __host__ __device__ uint64_t median() const { return 12 * nl; }
-    __host__ __device__ uint64_t p10() const { return 14 * nl; }
-    __host__ __device__ uint64_t alive() const { return 16 * nl; }
-    __host__ __device__ uint64_t n_pits() const { return 17 * nl; }
-    __host__ __device__ uint64_t n_hills() const { return 18 * nl; }
-    __host__ __device__ uint64_t bytes() const { return 19 * nl; }
+    __host__ __device__ uint64_t n_pits() const { return 12 * nl; }
+    __host__ __device__ uint64_t n_hills() const { return 16 * nl; }
+    __host__ __device__ uint64_t median() const { return 20 * nl; }
+    __host__ __device__ uint64_t p10() const { return 22 * nl; }
+    __host__ __device__ uint64_t alive() const { return 24 * nl; }
+    __host__ __device__ uint64_t bytes() const { return 25 * nl; }
 };
 
 struct ReadArrays {
     uint32_t *begin, *end, *slot;
     uint16_t *median, *p10;
-    uint8_t *alive, *n_pits, *n_hills;
+    uint8_t* alive;
+    uint32_t *n_pits, *n_hills;
 };
 
 ReadArrays read_arrays(rala_hip_ctx* c) {
@@ -98,8 +99,8 @@ __global__ __launch_bounds__(kBlock) void pack_state_kernel(ReadArrays a, uint64
     ((uint16_t*)(out + L.median()))[j] = in ? a.median[j] : (uint16_t)0;
     ((uint16_t*)(out + L.p10()))[j] = in ? a.p10[j] : (uint16_t)0;
     out[L.alive() + j] = in ? a.alive[j] : (uint8_t)0;
-    out[L.n_pits() + j] = in ? a.n_pits[j] : (uint8_t)0;
-    out[L.n_hills() + j] = in ? a.n_hills[j] : (uint8_t)0;
+    ((uint32_t*)(out + L.n_pits()))[j] = in ? a.n_pits[j] : 0u;
+    ((uint32_t*)(out + L.n_hills()))[j] = in ? a.n_hills[j] : 0u;
 }
 
 struct RankTable {
@@ -122,8 +123,8 @@ __global__ __launch_bounds__(kBlock) void unpack_state_kernel(const uint8_t* all
     a.median[r] = ((const uint16_t*)(in + L.median()))[j];
     a.p10[r] = ((const uint16_t*)(in + L.p10()))[j];
     a.alive[r] = in[L.alive() + j];
-    a.n_pits[r] = in[L.n_pits() + j];
-    a.n_hills[r] = in[L.n_hills() + j];
+    a.n_pits[r] = ((const uint32_t*)(in + L.n_pits()))[j];
+    a.n_hills[r] = ((const uint32_t*)(in + L.n_hills()))[j];
 }
 
 #define MGCHECK(call)                                                                    \

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(kBlock) void break_pits_kernel(TailReads R, const u
         }
     }
     if ((uint32_t)(E - from) > (uint32_t)(e - b)) { b = from; e = E; }
-    R.n_pits[r] = (uint8_t)w;
+    R.n_pits[r] = w;
     if (!dev_shrink(R, r, b, e)) R.alive[r] = 0;
 }
 
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(kBlock) void tail_contain_kill_kernel(TailKillers K
 // start of the tail: list states, nothing dirty, the pit counts the pile kernel wrote (one launch for
 // what used to be a kernel, a fill and a copy)
 __global__ __launch_bounds__(kBlock) void tail_init_kernel(uint8_t* state, uint8_t* round, uint32_t n0, uint32_t m,
-                                                           uint8_t* dirty, uint8_t* n_pits0, const uint8_t* n_pits,
+                                                           uint8_t* dirty, uint32_t* n_pits0, const uint32_t* n_pits,
                                                            uint32_t n_reads, uint32_t* base2, uint8_t* mark2, uint32_t* map, uint32_t* zero22) {
     const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
     if (k < 22) zero22[k] = 0;
@@ -521,7 +521,7 @@ hipError_t launch_tail_contain(const TailList& L, const TailReads& R, uint8_t* a
     hipLaunchKernelGGL(tail_contain_kill_kernel, dim3(128), dim3(kBlock), 0, s, K, L.n, alive);
     return hipGetLastError();
 }
-void launch_tail_init(const TailList& L, uint32_t n0, const TailReads& R, uint8_t* n_pits0, uint32_t n_reads, uint32_t* base2,
+void launch_tail_init(const TailList& L, uint32_t n0, const TailReads& R, uint32_t* n_pits0, uint32_t n_reads, uint32_t* base2,
                       uint8_t* mark2, uint32_t* map, uint32_t* zero22, hipStream_t s) {
     const uint32_t n = std::max<uint32_t>(std::max<uint32_t>(L.n, n_reads), 22u);
     hipLaunchKernelGGL(tail_init_kernel, grid_for(n), dim3(kBlock), 0, s, L.state, L.round, n0, L.n, R.dirty, n_pits0, R.n_pits, n_reads,

@@ -53,7 +53,8 @@ class Timings(ctypes.Structure):
                 ("dedupe_ms", "bucket_ms", "pile_ms", "classify_ms", "death_ms", "finish_ms", "tail_host_ms",
                  "tr_ms", "total_ms")] + [("pile_launches", ctypes.c_uint32), ("death_rounds", ctypes.c_uint32),
                                   ("pile_overflow_reads", ctypes.c_uint32),
-                                  ("pile_position_reads", ctypes.c_uint32)]
+                                  ("pile_position_reads", ctypes.c_uint32),
+                                  ("pile_unbounded_reads", ctypes.c_uint32), ("pool_regrown", ctypes.c_uint32)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -81,7 +81,8 @@ class Dataset:
 
     def __init__(self, n_reads, genome_len, seed, plants=15):
         """plants: bit 0 chimeras, 1 adapters, 2 repeats, 3 stacks (15: SURVEY.md Appendix E); + 16: heavy-tailed read
-        lengths (3 kb + exponential, 2 % of the reads 30 - 90 kb longer) instead of N(10 000, 1 500)"""
+        lengths (3 kb + exponential, 2 % of the reads 30 - 90 kb longer) instead of N(10 000, 1 500); + 32: one read in eighty
+        100 - 400 kb long"""
         L = lib()
         self._h = L.synth_create(n_reads, genome_len, seed, plants)
         self.n_reads = int(L.synth_n_reads(self._h))

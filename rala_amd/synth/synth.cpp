@@ -123,6 +123,10 @@ void generate(Synth& S, uint64_t n_reads, uint64_t genome, uint64_t seed, uint32
             L = 3000 + e * 1000 / 1024;
             if (rng.chance_permille(20)) L += rng.range(30000, 90000);
         }
+        // ultra-long reads (bit 5): one read in eighty 100 - 400 kb.  At a coverage of five to seven such a read meets a
+        // hundred and more others, every step of its shallow pile is a slope region (6 > int(4 * 1.3)): the lists that
+        // the reference keeps in vectors grow with the read's length, not with the coverage.
+        if ((plants & 32) && rng.chance_permille(12)) L = rng.range(100000, 400000);
         if (L < 3000) L = 3000;
         if ((uint64_t)L + 16 > genome) L = (int64_t)genome / 2;
         S.read_len[i] = (uint32_t)L;
@@ -279,7 +283,8 @@ void generate(Synth& S, uint64_t n_reads, uint64_t genome, uint64_t seed, uint32
 
 extern "C" {
 
-// plants: bit0 chimeras, bit1 adapters, bit2 repeats, bit3 stacks (15 = all); bit4: heavy-tailed read lengths
+// plants: bit0 chimeras, bit1 adapters, bit2 repeats, bit3 stacks (15 = all); bit4: heavy-tailed read lengths; bit5: one read
+// in eighty 100 - 400 kb long
 void* synth_create(uint64_t n_reads, uint64_t genome_len, uint64_t seed, uint32_t plants) {
     Synth* s = new Synth;
     generate(*s, n_reads, genome_len, seed, plants);

@@ -4,7 +4,7 @@ import numpy as np
 from oracle.oracle import Oracle
 
 
-def oracle_stages(ds, n_threads=8, ref=False, with_tr=True, n_data=64):
+def oracle_stages(ds, n_threads=8, ref=False, with_tr=True, n_data=64, data_of=()):
     """Run the oracle on a synthetic data set, snapshotting every stage."""
     o = Oracle(ds.read_len, ds.overlaps, n_threads=n_threads, ref=ref)
     st = {}
@@ -22,6 +22,7 @@ def oracle_stages(ds, n_threads=8, ref=False, with_tr=True, n_data=64):
     for key in ("pits0", "hills0"):
         offs = st[key][0]
         pick.update(int(x) for x in np.nonzero(offs[1:] > offs[:-1])[0][:32])
+    pick.update(int(r) for r in data_of)
     st["data0"] = {r: o.pile_data(r) for r in sorted(pick)}
     if rc != 0:
         return st
