@@ -213,6 +213,63 @@ def test_pile_objects_follow_the_reference_method_by_method(n, g, seed):
         hp.close()
 
 
+def test_saw_tooth_pile_objects():
+    """stand-alone Pile objects whose lists outgrow every fixed capacity (tests/sawcase.py): more than 192 slope regions,
+    more than 255 pits / hills, and - with a data set median of 1 - repeat hills from 7 000 candidate pairs (pile.cpp:500-566:
+    every (up, later down) pair); chimeric lists through break_over_*, repeat hills through to_json"""
+    from oracle import oracle as om
+    from oracle.oracle import Oracle
+    from sawcase import SawData
+
+    ds = SawData([("pits", 300, 100, 50), ("hills", 130, 120, 40), ("pits", 120, 3000, 300)])
+    bounds = read_bounds(ds)
+    o = Oracle(ds.read_len, None, ref=om.have_ref())
+    L = _lib()
+    hp = HostPiles(L, ds.read_len)
+    try:
+        for r in ds.targets:
+            part = bounds[r].reshape(-1).copy()
+            o.add_layers(r, part.copy())
+            hp.add_layers(r, part.copy())
+            assert o.find_valid_region(r) and L.hp_find_valid_region(hp.h, r)
+            o.find_median(r); L.hp_find_median(hp.h, r)
+            o.find_chimeric_hills(r); L.hp_find_chimeric_hills(hp.h, r)
+            o.find_chimeric_pits(r); L.hp_find_chimeric_pits(hp.h, r)
+        want = o.piles()
+        n_pits = [len(o.intervals(r, 0)) for r in ds.targets]
+        n_hills = [len(o.intervals(r, 1)) for r in ds.targets]
+        assert n_pits[0] > 255 and n_hills[2] > 100, (n_pits, n_hills)
+        for r in ds.targets:
+            got = hp.get(r)
+            for k in ("begin", "end", "median", "p10"):
+                assert got[k] == int(want[k][r]), (r, k)
+            assert got["has_pit"] == (len(o.intervals(r, 0)) > 0) and got["has_hill"] == (len(o.intervals(r, 1)) > 0), r
+            assert (hp.data(r) == o.pile_data(r)).all(), r
+        n_rep = []
+        for r in ds.targets:
+            for m in (4, 1):
+                o.find_repetitive_hills(r, m)
+                L.hp_find_repetitive_hills(hp.h, r, m)
+                assert hp.to_json(r) == o.to_json(r), (r, m)
+            n_rep.append(len(o.intervals(r, 2)))
+        assert max(n_rep) > 0, n_rep
+        # the pits decide where the reads break (the floor is 4: a median of 8 makes every pit real)
+        for r in ds.targets:
+            bo, bh = o.break_over_chimeric_pits(r, 8), bool(L.hp_break_over_chimeric_pits(hp.h, r, 8))
+            assert bo == bh, r
+            if bo:
+                bo, bh = o.break_over_chimeric_hills(r), bool(L.hp_break_over_chimeric_hills(hp.h, r))
+                assert bo == bh, r
+        want = o.piles()
+        for r in ds.targets:
+            got = hp.get(r)
+            assert got["alive"] == int(want["alive"][r]), r
+            if got["alive"]:
+                assert (got["begin"], got["end"]) == (int(want["begin"][r]), int(want["end"][r])), r
+    finally:
+        hp.close()
+
+
 def test_mhap_record_fields():
     """createOverlap(MHAP) (reference src/overlap.cpp:12-20): ids are 1-based in the file"""
     L = _lib()

@@ -100,3 +100,33 @@ def test_low_coverage_long_reads(hip_ctx_factory, n, g, seed, plants, run_kernel
     ctx.construct()
     parity.check_construct(ctx, st)
     parity.check_tr(ctx, st)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_saw_tooth_piles_sharded(world):
+    """the same piles over several ranks: the owners' lists and pools grow rank by rank, the per-read state travels with
+    32-bit counts"""
+    from test_gpu_sharded import Sharded, check_rank
+
+    ds = SawData(SAW[:3] + [("pits", 300, 100, 50)] * 10, base=Dataset(1000, 200_000, 1))
+    st = parity.oracle_stages(ds, ref=_ref())
+    sh = Sharded(ds, world)
+    try:
+        from rala_amd import hip
+        for r in sh.ranks:                                          # the owners' pools start at the floor: 1 024 slots
+            hip.Context(_borrowed=r.L.rala_hip_mg_owner_context(r.h)).set_option("interval_pool_per_read_x1000", 10)
+            r.set_reads(ds.read_len)
+        n_tr = sh.run()
+        assert sum(r.owner_timings()["pool_regrown"] for r in sh.ranks) >= 1
+        assert sum(r.owner_timings()["pile_unbounded_reads"] for r in sh.ranks) >= 5
+        for r in sh.ranks:
+            check_rank(r.context(), st, n_tr)
+        o = st["oracle"]
+        ctx = sh.ranks[world - 1].context()
+        for kind in (0, 1):
+            offs, pairs, aux = ctx.intervals(kind)
+            want = o.all_intervals(kind)
+            parity.assert_same("intervals%d.offsets" % kind, offs, want[0])
+            parity.assert_same("intervals%d.pairs" % kind, pairs, want[1])
+    finally:
+        sh.close()
