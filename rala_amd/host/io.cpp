@@ -1075,7 +1075,18 @@ bool read_overlaps_streamed(const std::string& path, bool mhap, const NameTable&
     std::vector<char> carry, piece;
     size_t piece_at = 0;
     auto read_text = [&](char* dst, size_t want) -> long {         // bytes, 0 at the end, -1 on a broken file
-        if (!bgzf) return (long)gzread(in, dst, (unsigned)std::min<size_t>(want, (size_t)1 << 20));
+        if (!bgzf) {
+            // (a gzip stream that ends before its trailer - a download cut short - gives a SHORT read, not an error: the
+            // state of the stream says which; plain text read through gzread has no trailer to miss)
+            const int got = gzread(in, dst, (unsigned)std::min<size_t>(want, (size_t)1 << 20));
+            if (got < 0) return -1;
+            if ((size_t)got < std::min<size_t>(want, (size_t)1 << 20)) {
+                int zerr = Z_OK;
+                (void)gzerror(in, &zerr);
+                if (zerr != Z_OK && zerr != Z_STREAM_END) return -1;
+            }
+            return (long)got;
+        }
         size_t have = 0;
         while (have < want) {
             if (piece_at == piece.size()) {
@@ -1135,7 +1146,7 @@ bool read_overlaps_streamed(const std::string& path, bool mhap, const NameTable&
     cv_block.notify_all();
     for (auto& t : parsers) t.join();
     blocks.reset();
-    if (in) gzclose(in);
+    if (in && gzclose(in) != Z_OK) failed = true;              // (Z_BUF_ERROR: the file ended inside the stream)
     if (raw) fclose(raw);
     if (failed) return false;
 
