@@ -26,6 +26,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "kernels.h"
 
@@ -129,9 +130,10 @@ __device__ __forceinline__ void finish_in_lds(uint32_t* lds, const FixedPointLis
     }
 }
 
-// Barrier between the workgroups of a small grid that is resident as a whole.  sync[0] counts arrivals (zero at the
-// launch), `phase` the barriers of this launch.  false: somebody gave up waiting (a workgroup that never got a
-// compute unit) - everybody leaves; the host sees *error.
+// Barrier between the workgroups of a small grid that is USUALLY resident as a whole (nothing guarantees it: ranks that
+// share a device, other tenants, a partitioned device).  sync[0] counts arrivals (zero at the launch), `phase` the barriers
+// of this launch.  false: somebody gave up waiting (a workgroup that never got a compute unit) - everybody leaves, nobody
+// passes this barrier, and the last workgroup to leave does the rounds alone (fixed_point_wide_kernel).
 constexpr uint32_t kWideGroups = 32;
 // (Everything the workgroups tell each other goes through memory-side atomics, stores and loads: what has to be
 // complete before the arrival is this wavefront's own requests - a wait for its counters, not a fence, which on
@@ -145,7 +147,7 @@ __device__ __forceinline__ bool grid_barrier(uint32_t* sync, uint32_t& phase, ui
         uint32_t spins = 0;
         while (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < phase * groups) {
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1u << 23) || __hip_atomic_load(sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+            if (++spins > (1u << 19) || __hip_atomic_load(sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
                 __hip_atomic_store(sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
             }
@@ -158,13 +160,24 @@ __device__ __forceinline__ bool grid_barrier(uint32_t* sync, uint32_t& phase, ui
 // More killers than the LDS holds: X_r in work[r % 4]: round r compares X_(r-1) with X_(r-2), proposes into X_r and
 // resets the targets in the array of X_(r+1) (last read a round ago) - one barrier per round.  sync: eight zeroed
 // words ([0] arrivals, [1] "give up", [4 .. 6] "a value moved" per round % 3).
-__device__ __forceinline__ void finish_wide(const FixedPointList& list, uint32_t* base, uint32_t* w0, uint32_t* w1, uint32_t* w2,
+// kSolo: one workgroup alone (the barrier is the workgroup's own).  false: a barrier gave up, nothing has been written to base.
+template <bool kSolo>
+__device__ __forceinline__ bool finish_wide(const FixedPointList& list, uint32_t* base, uint32_t* w0, uint32_t* w1, uint32_t* w2,
                                             uint32_t* w3, uint32_t* sync, uint32_t* error, uint32_t* rounds_out) {
     const uint32_t n = *list.count;
     constexpr uint32_t kPer = 4;
-    const uint32_t groups = gridDim.x;
+    const uint32_t groups = kSolo ? 1u : gridDim.x;
     const uint32_t stride = groups * kFinishBlock;
-    const uint32_t gtid = blockIdx.x * kFinishBlock + threadIdx.x;
+    const uint32_t gtid = kSolo ? threadIdx.x : blockIdx.x * kFinishBlock + threadIdx.x;
+    auto barrier = [&](uint32_t& phase) -> bool {
+        if constexpr (kSolo) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __syncthreads();
+            return true;
+        } else {
+            return grid_barrier(sync, phase, groups);
+        }
+    };
     uint32_t* const work[4] = {w0, w1, w2, w3};
     uint32_t* const flag = sync + 4;
     uint32_t phase = 0;
@@ -188,7 +201,10 @@ __device__ __forceinline__ void finish_wide(const FixedPointList& list, uint32_t
             for (int w = 0; w < 4; ++w) { st_past_l1(work[w] + et[u], eb[u]); st_past_l1(work[w] + ep[u], bp); }
         }
     }
-    if (!grid_barrier(sync, phase, groups)) { if (gtid == 0) *error = 2u; return; }
+    if (list.debug_give_up && !kSolo && blockIdx.x == 1 && threadIdx.x == 0) {
+        __hip_atomic_store(sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // tests: a workgroup that never arrives
+    }
+    if (!barrier(phase)) return false;
     // (up to 131 072 entries stay in registers over the rounds: one trip to memory less per round)
     const bool resident = n <= kPer * stride;
     if (resident) load(gtid);
@@ -215,11 +231,11 @@ __device__ __forceinline__ void finish_wide(const FixedPointList& list, uint32_t
             __hip_atomic_store(flag + r % 3u, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (gtid == 0) __hip_atomic_store(flag + (r + 1u) % 3u, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (!grid_barrier(sync, phase, groups)) { if (gtid == 0) *error = 2u; return; }
+        if (!barrier(phase)) return false;
         if (r >= 2 && ld_past_l1(flag + r % 3u) == 0) break;     // X_(r-1) = X_(r-2): settled (and X_r is the same again)
         if (r > n + 8u) {                                         // (every round settles at least one read)
             if (gtid == 0) *error = 1u;
-            return;
+            return true;
         }
     }
     const uint32_t* settled = work[(r + 3) & 3];
@@ -229,6 +245,7 @@ __device__ __forceinline__ void finish_wide(const FixedPointList& list, uint32_t
         for (uint32_t u = 0; u < kPer; ++u) base[et[u]] = ld_past_l1(settled + et[u]);
     }
     if (rounds_out && gtid == 0) *rounds_out = r - 1;
+    return true;
 }
 
 // The rounds: a list that fits the LDS is one workgroup's, a longer one the resident workgroups'.  Two kernels, both
@@ -245,7 +262,14 @@ __global__ __launch_bounds__(kFinishBlock) void fixed_point_finish_kernel(FixedP
 __global__ __launch_bounds__(kFinishBlock) void fixed_point_wide_kernel(FixedPointList list, uint32_t* base, uint32_t* w0, uint32_t* w1,
                                                                         uint32_t* w2, uint32_t* w3, uint32_t* sync, uint32_t* error,
                                                                         uint32_t* rounds_out) {
-    if (*list.count > list.lds_limit) finish_wide(list, base, w0, w1, w2, w3, sync, error, rounds_out);
+    if (*list.count <= list.lds_limit) return;
+    if (finish_wide<false>(list, base, w0, w1, w2, w3, sync, error, rounds_out)) return;
+    // The workgroups could not meet (one of them waited 2^19 polls for a compute unit): every workgroup comes by sooner or
+    // later and leaves; the last one to leave does all the rounds alone - slower (C5: 1.1 ms instead of 0.36), never stuck.
+    __shared__ uint32_t last;
+    if (threadIdx.x == 0) last = __hip_atomic_fetch_add(sync + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (last) (void)finish_wide<true>(list, base, w0, w1, w2, w3, sync, error, rounds_out);
 }
 
 }  // namespace
@@ -256,6 +280,7 @@ hipError_t launch_fixed_point_finish(const FixedPointList& list_in, uint32_t* ba
                                      uint32_t* sync8, uint32_t* error, uint32_t* rounds_out, hipStream_t s) {
     FixedPointList list = list_in;
     list.lds_limit = std::min<uint32_t>(list_in.lds_limit, kLdsEntries);
+    if (getenv("RALA_HIP_DEBUG_FP_GIVE_UP")) list.debug_give_up = 1;     // tests: the long lists' workgroups do not meet
     constexpr size_t lds_bytes = 3 * (size_t)kLdsEntries * 4;
     // (every time: the attribute belongs to the function on the CURRENT device, and the ranks of a sharded run are threads
     // of one process on different devices)

@@ -330,12 +330,14 @@ bool launch_pair_offsets_pass(const uint32_t* in0, const uint32_t* in1, uint32_t
 // conditional killers {key, target, keeper} (*count of them, on the device); base: the deaths decided for good (all ones:
 // never), receives the deaths; map: one word per read, all ones, left all ones; pack: fixed_point_pack_words() words of
 // scratch; work: four arrays of as many words as there are reads, uninitialised; sync8: eight zeroed words (one set per
-// call); *error is set when the rounds do not settle (1) or the workgroups of a long list's kernel cannot meet (2);
+// call); *error is set when the rounds do not settle (1) - workgroups of a long list's kernel that cannot meet are no error,
+// the last of them does the rounds alone;
 // *rounds_out (may be null) receives the number of rounds
 struct FixedPointList {
     const uint32_t *key, *target, *keeper;
     const uint32_t* count;
     uint32_t lds_limit = 0xFFFFFFFFu;       // tests: lists longer than this take the long lists' kernel (at most what the LDS holds)
+    uint32_t debug_give_up = 0;             // tests: the long lists' workgroups do not meet (one of them finishes alone)
 };
 size_t fixed_point_pack_words();
 hipError_t launch_fixed_point_finish(const FixedPointList& list, uint32_t* base, uint32_t* map, uint32_t* pack, uint32_t* const work[4],

@@ -1400,8 +1400,7 @@ int gpu_tail_part_b(rala_hip_ctx* ctx) {
                 kc[0], kc[2], kc[1], kc[3], M);
     }
     if (left[1]) {
-        return fail(ctx, RALA_HIP_EDEVICE, left[1] == 1 ? "containment fixed point did not converge"
-                                                        : "containment fixed point: the workgroups could not meet");
+        return fail(ctx, RALA_HIP_EDEVICE, "containment fixed point did not converge");
     }
     const uint32_t n_final = left[0];
     ctx->t_n_kept = totals[0];
@@ -1696,8 +1695,7 @@ int pass2(rala_hip_ctx* ctx, Comm* comm) {
     const uint32_t n_surv[2] = {counts8[6], counts8[7]};
     const uint32_t* counts3 = counts8;
     if (counts3[1]) {
-        return fail(ctx, RALA_HIP_EDEVICE, counts3[1] == 1 ? "containment fixed point did not converge"
-                                                           : "containment fixed point: the workgroups could not meet");
+        return fail(ctx, RALA_HIP_EDEVICE, "containment fixed point did not converge");
     }
     ctx->t_n_alive = counts3[0];            // the reads that survived the second pass (the tail's rank space)
     if (finished_on_device) {

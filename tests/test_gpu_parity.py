@@ -74,11 +74,16 @@ def test_bucketing_variants(hip_ctx_factory, n, g, seed):
 
 
 @pytest.mark.parametrize("n,g,seed", [(3000, 600_000, 21), (5000, 1_000_000, 7), (600, 60_000, 9), (40_000, 8_000_000, 13)])
-@pytest.mark.parametrize("opts", [{"debug_fp_lds_limit": 0}, {"debug_fp_lds_limit": 40}, {"use_round_batches": 0}])
-def test_containment_fixed_point_variants(hip_ctx_factory, n, g, seed, opts):
+@pytest.mark.parametrize("opts", [{"debug_fp_lds_limit": 0}, {"debug_fp_lds_limit": 40}, {"use_round_batches": 0},
+                                  {"debug_fp_lds_limit": 0, "env": "RALA_HIP_DEBUG_FP_GIVE_UP"}])
+def test_containment_fixed_point_variants(hip_ctx_factory, monkeypatch, n, g, seed, opts):
     """The ends of the containment fixed points (second pass, the tail's two scans; fixed_point_kernels.hip): every list
     through the kernel for long lists (resident workgroups, a barrier per round; C5 takes it), a mix of both kernels,
-    and the host's loop of one look per round."""
+    the host's loop of one look per round - and the long lists' kernel when its workgroups cannot meet (nothing
+    guarantees that they are resident together): the last one to leave does the rounds alone."""
+    opts = dict(opts)
+    if "env" in opts:
+        monkeypatch.setenv(opts.pop("env"), "1")
     ds = Dataset(n, g, seed)
     st = parity.oracle_stages(ds)
     ctx = hip_ctx_factory()
