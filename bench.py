@@ -3,18 +3,25 @@
 graph construction + transitive reduction (BASELINE.json metric), synthetic input of the
 named shape resident in HBM before the timed region.
 
-    python bench.py --gpus N --steps K --warmup W [--workload c3|c2|c1|c5]
+    python bench.py --gpus N --steps K --warmup W [--workload c3|c2|c1|c5|c2s|c3s|c5s]
 
 One step = one pass of the whole hot path over the data set: rala_hip_initialize
 (duplicate removal, bound bucketing, pile build + annotation), rala_hip_construct
 (second overlap pass, containment fixed point, preprocess tail, graph build) and
-rala_hip_remove_transitive_edges.  Prints ONE JSON line on rank 0.
+rala_hip_remove_transitive_edges.  Prints ONE JSON line on rank 0.  The workloads c3s / c5s add
+the sensitive second pass (`rala -s`, reference graph.cpp:882-1054) to every step: the sensitive
+overlaps - derived from the piles of an untimed first pass, as the two-run workflow of the
+reference derives them from its `-p` output - lie in HBM like the primary ones.
 
 Several GPUs (reads hash-partitioned, ONE all-to-all of bound tuples; rala_hip_mg_*):
   * bare `python bench.py --gpus N`: the N ranks are host threads of this process, one per
     GPU, over RCCL - what `rala --gpus N` does (rala_amd/host/graph.cpp);
   * under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`: one
     process per GPU; torch carries only the 128-byte RCCL id, the barrier and the clock (gloo).
+The line says which transport carried the ranks ("transport", "rccl_ranks").  A run that was asked
+for RCCL and did not get it ends with a non-zero exit code and no line; `--transport local` (peer
+copies inside one process, several ranks may share a device) is a test of the decomposition that
+has to be asked for by name.
 """
 import argparse
 import ctypes
@@ -37,6 +44,9 @@ WORKLOADS = {
     "c2": "100k reads / 5M overlaps (BASELINE configs[1])",
     "c3": "1M reads / 50M overlaps (BASELINE configs[2])",
     "c5": "4M reads / 300M overlaps (BASELINE configs[4], primary overlaps only)",
+    "c2s": "100k reads / 5M overlaps + the sensitive second pass, -s (BASELINE configs[1] with configs[4]'s second pass)",
+    "c3s": "1M reads / 50M overlaps + the sensitive second pass, -s (BASELINE configs[2] with configs[4]'s second pass)",
+    "c5s": "4M reads / 300M overlaps + the sensitive second pass, -s (BASELINE configs[4])",
 }
 
 
@@ -44,49 +54,56 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(sample_name="c2"):
-    """The CPU path on a bounded sample: one thread AND as many threads as the process may really
-    use, on the SAME sample, one task per pile like the reference's thread pool.  kind "reference":
-    the reference's own rala::Pile / rala::Overlap objects (oracle/_ref, compiled from the
-    reference's pile.cpp / overlap.cpp) under the restated Graph orchestration; kind "port": the
-    flat restatement (oracle/_build) when that library is not there.  Both are test infrastructure
-    used here only as the measured baseline."""
+def cpu_baseline(headline="c3", single="c2"):
+    """The CPU path, timed on this box's host cores: as many threads as the process may really use on the
+    HEADLINE configuration itself (`headline`: the data set `value` is quoted on, or C3 for the C5 workloads), and one
+    thread on a bounded sample (`single`).  One task per pile through a thread pool with the interface of the
+    reference's vendor/thread_pool (graph.cpp:367-377, 387-407; oracle Driver::task_pool).  kind "reference": the
+    reference's own rala::Pile / rala::Overlap objects (oracle/_ref, compiled from the reference's pile.cpp /
+    overlap.cpp) under the restated Graph orchestration; kind "port": the flat restatement (oracle/_build) when that
+    library is not there.  Both are test infrastructure used here only as the measured baseline."""
     from oracle import oracle as ora
     from rala_amd.synth import Dataset
 
     from rala_amd.cpus import effective_cpus
 
     cores = effective_cpus()        # affinity mask cut by the container's CPU quota (16 on the gpurun boxes)
-    ds = Dataset.config(sample_name)
-    n = len(ds.overlaps)
 
-    def once(ref, threads):
+    def once(ds, ref, threads):
         t0 = time.perf_counter()
-        o = ora.Oracle(ds.read_len, ds.overlaps, n_threads=threads, ref=ref)
+        o = ora.Oracle(ds.read_len, ds.overlaps, n_threads=threads, ref=ref, task_pool=True)
         rc = o.construct()
         n_tr = o.remove_transitive_edges() if rc == 0 else 0
-        return time.perf_counter() - t0, n_tr
+        dt = time.perf_counter() - t0
+        del o
+        return dt, n_tr
 
     have_ref = os.path.exists(os.path.join(ROOT, "oracle", "_ref", "liboracle_ref.so"))
     out = {"unit": "overlaps/s", "cores": cores}
-    kind = "port"
-    dt_port, n_tr = once(False, cores)
-    dt = dt_port
-    if have_ref:
-        try:
-            dt_ref, n_tr_ref = once(True, cores)
-            assert n_tr_ref == n_tr
-            kind, dt = "reference", dt_ref
-            out["port_value"] = n / dt_port
-        except Exception as e:          # the library is there but unusable on this box: say so, fall back
-            log("[bench] reference-object baseline failed (%s); using the port" % e)
-    dt1, n_tr1 = once(kind == "reference", 1)
-    assert n_tr1 == n_tr
-    out.update(value=n / dt, kind=kind, value_1_thread=n / dt1,
-               sample="%s synthetic, %d reads / %d overlaps, whole hot path once with %s: %.2f s on %d threads, %.2f s on "
-                      "one thread (same sample), %d transitive pairs" % (
-                          sample_name, ds.n_reads, n, "the reference's Pile / Overlap objects" if kind == "reference"
-                          else "the flat restatement", dt, cores, dt1, n_tr))
+    ds = Dataset.config(headline)
+    n = len(ds.overlaps)
+    kind = "reference" if have_ref else "port"
+    try:
+        dt, n_tr = once(ds, have_ref, cores)
+    except Exception as e:              # the library is there but unusable on this box: say so, fall back
+        if not have_ref:
+            raise
+        log("[bench] reference-object baseline failed (%s); using the port" % e)
+        kind = "port"
+        dt, n_tr = once(ds, False, cores)
+    n_reads = ds.n_reads
+    if single != headline:
+        ds = Dataset.config(single)
+    n1 = len(ds.overlaps)
+    dt1, n_tr1 = once(ds, kind == "reference", 1)
+    if single == headline:
+        assert n_tr1 == n_tr
+    out.update(value=n / dt, kind=kind, value_1_thread=n1 / dt1,
+               sample="%s synthetic (the headline configuration itself), %d reads / %d overlaps, whole hot path once with %s, "
+                      "one task per pile through a thread pool: %.2f s on %d threads, %d transitive pairs; one thread: %s "
+                      "synthetic, %d overlaps in %.2f s" % (
+                          headline, n_reads, n, "the reference's Pile / Overlap objects" if kind == "reference"
+                          else "the flat restatement", dt, cores, n_tr, single, n1, dt1))
     return out
 
 
@@ -161,7 +178,9 @@ def main():
     devices = [int(x) for x in args.devices.split(",") if x.strip() != ""] or list(range(world))
     rccl_failed = None
     if use_threads:
-        have = torch.cuda.device_count()            # (does not initialise the GPU: a child process may still be started)
+        # (no HIP call before the child below is started: where torch has no amdsmi this count goes through
+        # hipGetDeviceCount, which is why the RCCL attempt is a fresh process and not a fork of this one)
+        have = torch.cuda.device_count()
         if len(devices) != world:
             raise SystemExit("bench.py: --devices names %d devices for %d ranks" % (len(devices), world))
         if args.transport == "rccl" and (len(set(devices)) != world or max(devices) >= have):
@@ -170,11 +189,13 @@ def main():
                              % (world, world, have))
         if max(devices) >= have:
             raise SystemExit("bench.py: device %d does not exist (%d visible)" % (max(devices), have))
-        # RCCL with more than one rank has never run on the boxes this was built on (one GPU each).  A bare
-        # `bench.py --gpus N` therefore tries it in a CHILD process first and, should that fail or hang, runs the same
-        # ranks over the in-process transport (peer copies between the devices) - and says so in the line.
+        # RCCL with more than one rank has never run on the boxes this was built on (one GPU each), and a collective that
+        # hangs cannot be interrupted from inside the process: a bare `bench.py --gpus N` runs the RCCL ranks in a CHILD
+        # process with a time limit.  The child's line is this run's line; a child that fails or hangs makes this run
+        # FAIL (exit code 3, no line) - a figure that RCCL did not carry is never printed under this command
+        # (`--transport local` has to be asked for by name).
         try_child = args.transport == "rccl" and "RALA_BENCH_CHILD" not in os.environ and \
-            (world > 1 or os.environ.get("RALA_BENCH_TEST_CHILD") == "1") and os.environ.get("RALA_BENCH_NO_FALLBACK") != "1"
+            (world > 1 or os.environ.get("RALA_BENCH_TEST_CHILD") == "1")
         if try_child:
             import subprocess
             limit = int(os.environ.get("RALA_BENCH_CHILD_TIMEOUT", "900"))
@@ -188,8 +209,10 @@ def main():
                 rccl_failed = "exit code %d" % r.returncode
             except subprocess.TimeoutExpired:
                 rccl_failed = "no result within %d s" % limit
-            log("[bench] the RCCL run failed (%s): the same ranks over the in-process transport" % rccl_failed)
-            args.transport = "local"
+            log("[bench] the RCCL run of %d ranks failed (%s).  No figure is printed: `--transport local` runs the same ranks "
+                "over peer copies inside one process - a test of the decomposition, not the transport that was asked for."
+                % (world, rccl_failed))
+            raise SystemExit(3)
         if os.environ.get("RALA_BENCH_FAKE_RCCL_FAILURE") == "1" and "RALA_BENCH_CHILD" in os.environ and args.transport == "rccl":
             raise SystemExit(3)                     # (tests: the child of the paragraph above fails)
     if not torch.cuda.is_available():
@@ -207,33 +230,85 @@ def main():
     from rala_amd.synth import Dataset
 
     t0 = time.perf_counter()
-    ds = Dataset.config(args.workload)
+    with_sens = args.workload.endswith("s")
+    data_name = args.workload[:-1] if with_sens else args.workload
+    ds = Dataset.config(data_name)
     n_ovl = len(ds.overlaps)
     sum_len = int(ds.read_len.astype(np.int64).sum())
     log("[bench] generated %s: %d reads, %d overlaps in %.1f s" % (args.workload, ds.n_reads, n_ovl,
                                                                     time.perf_counter() - t0))
     mode = "one GPU"
+    transport, rccl_ranks = None, 0             # which transport carried the ranks (None: one context, nothing to carry)
+    sens_info = None
+
+    def sensitive_set(piles):
+        """the sensitive overlaps of the two-run workflow, from the piles an (untimed) first pass leaves"""
+        t1 = time.perf_counter()
+        sens = ds.sensitive(piles["alive"], piles["begin"], piles["end"])
+        targets = np.unique(sens.b_id)
+        info = {"n_sensitive": len(sens), "targets": int(len(targets)),
+                "sum_len_targets": int(ds.read_len[targets].astype(np.int64).sum())}
+        log("[bench] %d sensitive overlaps on %d targets in %.1f s" % (len(sens), len(targets), time.perf_counter() - t1))
+        return sens, info
+
     if use_dist:
         from rala_amd import multi
-        runner = multi.ShardedRunner(ds, rank, world, local_rank)
+        try:
+            runner = multi.ShardedRunner(ds, rank, world, local_rank)
+        except Exception as e:      # noqa: BLE001 - no line without the transport that was asked for
+            log("[bench] rank %d: the RCCL group of %d ranks could not be set up: %s" % (rank, world, e))
+            raise SystemExit(3)
         mode = "one process per GPU (torch.distributed.run), RCCL"
+        transport, rccl_ranks = "rccl", world
+        if with_sens:
+            runner.step()
+            sens, sens_info = sensitive_set(runner.mg.context().piles())
+            cut = [len(sens) * k // world for k in range(world + 1)]
+            share = hip.DeviceOverlaps.from_host(sens.take(slice(cut[rank], cut[rank + 1])), local_rank)
+            runner.mg.context().set_option("sensitive_in_device_memory", 1)
+            def _step():
+                n = runner.mg.run(share)
+                runner._tm = multi.rank_timings(runner.mg)
+                return n
+            runner.step = _step
     elif use_threads:
         from rala_amd import multi
-        runner = multi.ThreadedRunner(ds, world, devices, args.transport)
+        try:
+            runner = multi.ThreadedRunner(ds, world, devices, args.transport)
+        except Exception as e:      # noqa: BLE001
+            log("[bench] the %s group of %d ranks could not be set up: %s" % (args.transport, world, e))
+            sys.stderr.flush()
+            os._exit(3)             # (ranks may be stuck inside the library: no orderly exit)
         mode = "ranks as host threads of one process, %s" % ("RCCL" if args.transport == "rccl" else "in-process transport (peer copies)")
-        if rccl_failed:
-            mode += " - the RCCL run failed: " + rccl_failed
+        transport, rccl_ranks = args.transport, (world if args.transport == "rccl" else 0)
+        if with_sens:
+            runner.step()
+            sens, sens_info = sensitive_set(runner.ranks[0].context().piles())
+            cut = [len(sens) * k // world for k in range(world + 1)]
+            shares = [hip.DeviceOverlaps.from_host(sens.take(slice(cut[k], cut[k + 1])), devices[k]) for k in range(world)]
+            for r in runner.ranks:
+                r.context().set_option("sensitive_in_device_memory", 1)
+            plain = runner.step
+            runner.step = lambda: plain(shares)
     else:
         ctx = hip.Context(local_rank)
         for kv in filter(None, os.environ.get("RALA_BENCH_OPTIONS", "").split(",")):    # diagnostics: key=value,...
             ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
         ctx.set_reads(ds.read_len)
         ctx.set_overlaps(ds.overlaps)          # inputs resident in HBM from here on
+        sens_dev = None
+        if with_sens:
+            ctx.initialize()
+            ctx.construct()
+            sens, sens_info = sensitive_set(ctx.piles())
+            sens_dev = hip.DeviceOverlaps.from_host(sens, local_rank)      # resident in HBM like the primary set
+            ctx.set_option("sensitive_in_device_memory", 1)
+            del sens
 
         class _Single:
             def step(self):
                 ctx.initialize()
-                ctx.construct()
+                ctx.construct(sens_dev)
                 return ctx.remove_transitive_edges()
 
             def timings(self):
@@ -292,11 +367,22 @@ def main():
         except Exception:
             pass
         whole = stage_roofline(stage, n_ovl, sum_len, ds.n_reads, world if sharded else 1)
+        if sens_info is not None:
+            # the sensitive pass adds 32 B per sensitive overlap (ids, coordinates, its target bounds written
+            # and read) and reads and writes the rows of its targets once more
+            sens_info["algorithmic_bytes"] = 32.0 * sens_info["n_sensitive"] + 2.0 * sens_info["sum_len_targets"] * 2.0
+            sens_info["ms"] = stage.get("repeats_ms", 0.0)
+            if sens_info["ms"] > 0:
+                sens_info["achieved_GBs"] = sens_info["algorithmic_bytes"] / (sens_info["ms"] * 1e-3) / 1e9 / (world if sharded else 1)
+                sens_info["frac"] = sens_info["achieved_GBs"] / HBM_PEAK_GBS
+            sens_info["resident"] = "device memory (option sensitive_in_device_memory), uploaded before the timed region"
         out = {
             "metric": "overlaps/sec (pile build + transitive reduction)",
             "value": n_ovl * steps / dt,
             "unit": "overlaps/s",
             "n_gpus": world,
+            "transport": transport,
+            "rccl_ranks": rccl_ranks,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms,
@@ -319,6 +405,8 @@ def main():
                          "stage": whole},
             "stage_ms": stage,
         }
+        if sens_info is not None:
+            out["sensitive_pass"] = sens_info
         if not sharded:
             ctx.close()                 # the end-to-end run creates a context of its own: give the memory back first
         if not args.no_e2e and world == 1 and not sharded:
@@ -328,7 +416,10 @@ def main():
                 log("[bench] end-to-end figure failed: %s" % e)
                 out["end_to_end_from_paf"] = {"error": str(e)}
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline("c2" if args.workload != "c1" else "c1")
+            # the N-thread figure on the configuration `value` is quoted on (C3 for the C5 workloads: what the box's host
+            # memory and a few minutes hold), the one-thread figure on the C2 sample
+            head = {"c1": "c1", "c2": "c2"}.get(data_name, "c3")
+            out["cpu_baseline"] = cpu_baseline(head, "c1" if head == "c1" else "c2")
         print(json.dumps(out), flush=True)
 
     if use_dist or use_threads:

@@ -69,6 +69,7 @@ typedef struct rala_hip_timings {
     /* reads whose slope-region / interval lists outgrew the LDS and ran with lists in global memory (initialize; the
      * sensitive pass adds its own); times an interval pool was grown and the stage repeated */
     uint32_t pile_unbounded_reads, pool_regrown;
+    float repeats_ms;      /* the sensitive pass (Graph::preprocess, repeats: graph.cpp:882-1054), part of tail_host_ms */
 } rala_hip_timings;
 
 /* ---- context -------------------------------------------------------------- */
@@ -231,6 +232,11 @@ int rala_hip_mg_local_group_create(uint32_t world, void** group);
 void rala_hip_mg_local_group_destroy(void* group);
 /* token: the 128-byte id (RALA_HIP_COMM_RCCL) or the group (RALA_HIP_COMM_LOCAL) */
 int rala_hip_mg_create(int device, uint32_t rank, uint32_t world, int transport, const void* token, rala_hip_mg** out);
+/* The same in two steps: the rank's device contexts (NOT collective), then joining the group (collective: ncclCommInitRank).
+ * A launcher creates all contexts first, makes sure every rank has its own, and only then lets them join - a rank that
+ * failed before the collective part would leave the others waiting inside it. */
+int rala_hip_mg_create_contexts(int device, uint32_t rank, uint32_t world, rala_hip_mg** out);
+int rala_hip_mg_join(rala_hip_mg* mg, int transport, const void* token);
 void rala_hip_mg_destroy(rala_hip_mg* mg);
 const char* rala_hip_mg_last_error(const rala_hip_mg* mg);
 /* all read lengths, on every rank (src/graph.cpp:249-264) */

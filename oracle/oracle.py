@@ -29,6 +29,7 @@ def _load(path):
         "ora_backend_name": (ctypes.c_char_p, []),
         "ora_create": (vp, [u32]),
         "ora_destroy": (None, [vp]),
+        "ora_use_task_pool": (None, [vp]),
         "ora_set_reads": (None, [vp, vp, u64]),
         "ora_set_overlaps": (None, [vp, u64] + [vp] * 8),
         "ora_pass1": (None, [vp]),
@@ -101,9 +102,13 @@ def _c(a, dt):
 class Oracle:
     """One run of the restated hot path.  ``ref=True`` uses the real reference objects."""
 
-    def __init__(self, read_len, overlaps=None, n_threads=1, ref=False):
+    def __init__(self, read_len, overlaps=None, n_threads=1, ref=False, task_pool=False):
+        """task_pool: the per-pile fan-out as ONE TASK PER PILE through a thread pool with the interface of the reference's
+        vendor/thread_pool (graph.cpp:367-377, 387-407) - the structure bench.py's cpu_baseline times"""
         self.L = lib(ref)
         self.h = self.L.ora_create(n_threads)
+        if task_pool:
+            self.L.ora_use_task_pool(self.h)
         self.read_len = _c(read_len, np.uint32)
         self.n_reads = int(self.read_len.shape[0])
         self.L.ora_set_reads(self.h, self.read_len.ctypes.data, self.n_reads)

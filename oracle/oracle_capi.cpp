@@ -55,6 +55,13 @@ void* ora_create(uint32_t n_threads) {
     return h;
 }
 
+// one task per pile through a pool of n_threads workers (the reference's thread_pool fan-out, graph.cpp:367-377) instead of
+// the chunked loop
+void ora_use_task_pool(void* p) {
+    Handle* h = (Handle*)p;
+    h->d.task_pool = thread_pool::createThreadPool(h->d.n_threads);
+}
+
 void ora_destroy(void* p) { delete (Handle*)p; }
 
 void ora_set_reads(void* p, const uint32_t* len, uint64_t n) { ((Handle*)p)->d.set_reads(len, n); }

@@ -20,8 +20,16 @@
 #include <algorithm>
 #include <atomic>
 #include <deque>
+#include <future>
+#include <memory>
 #include <thread>
 #include <vector>
+
+// The pool behind the interface of the reference's un-vendored vendor/thread_pool (createThreadPool, submit_task ->
+// std::future): the product's header of that name.  With it the fan-out below has the reference's structure - ONE task
+// per pile, submitted from the main thread, then waited for (graph.cpp:367-377, 387-407) - which is what bench.py's
+// cpu_baseline times (Driver::task_pool); the tests keep the lighter chunked loop.
+#include "../rala_amd/host/thread_pool/thread_pool.hpp"
 
 namespace ora {
 
@@ -47,6 +55,17 @@ inline void parallel_for(uint64_t n, uint32_t n_threads, F fn) {
     for (auto& th : pool) th.join();
 }
 
+// graph.cpp:367-377: a task per item through the pool, futures collected and waited for in order
+template <class F>
+inline void pool_for(uint64_t n, thread_pool::ThreadPool& pool, F fn) {
+    std::vector<std::future<void>> futures;
+    futures.reserve(n);
+    for (uint64_t i = 0; i < n; ++i) {
+        futures.emplace_back(pool.submit_task([&fn](uint64_t k) -> void { fn(k); }, i));
+    }
+    for (const auto& it : futures) it.wait();
+}
+
 // Input overlaps, structure of arrays.  id == 0xFFFFFFFF stands for a name
 // that is not in the sequence file (Overlap::transmute → false,
 // overlap.cpp:44-47,63-66).
@@ -66,6 +85,12 @@ struct Driver {
 
     BK bk;
     uint32_t n_threads;
+    std::unique_ptr<thread_pool::ThreadPool> task_pool;     // set: one task per pile like the reference (bench.py's baseline)
+    template <class F>
+    void parallel_for(uint64_t n, uint32_t, F fn) {
+        if (task_pool) pool_for(n, *task_pool, fn);
+        else ora::parallel_for(n, n_threads, fn);
+    }
     uint64_t n_reads;
     std::vector<uint32_t> read_len;
     OvlInput in;

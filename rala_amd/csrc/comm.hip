@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <mutex>
 
@@ -96,15 +97,19 @@ public:
                 if (reg.comms[k] == this) { reg.comms.erase(reg.comms.begin() + k); break; }
             }
         }
-        if (comm_) (void)(aborted_ ? api_->CommAbort(comm_) : api_->CommDestroy(comm_));
+        // (a peer's abort() has taken the handle away already: ncclCommAbort frees it)
+        const ncclComm_t mine = comm_.exchange(nullptr);
+        if (mine) (void)(aborted_ ? api_->CommAbort(mine) : api_->CommDestroy(mine));
     }
     bool init(const void* id, std::string* err) {
         api_ = rccl_api();
         if (!api_->lib) { *err = api_->err; return false; }
         static_assert(sizeof(ncclUniqueId) == kCommIdBytes, "unique id size");
         memcpy(&uid_, id, sizeof(uid_));
-        const ncclResult_t r = api_->CommInitRank(&comm_, (int)world_, uid_, (int)rank_);
-        if (r != ncclSuccess) { *err = std::string("ncclCommInitRank: ") + api_->GetErrorString(r); comm_ = nullptr; return false; }
+        ncclComm_t made = nullptr;
+        const ncclResult_t r = api_->CommInitRank(&made, (int)world_, uid_, (int)rank_);
+        if (r != ncclSuccess) { *err = std::string("ncclCommInitRank: ") + api_->GetErrorString(r); return false; }
+        comm_ = made;
         RcclRegistry& reg = rccl_registry();
         std::lock_guard<std::mutex> hold(reg.m);
         reg.comms.push_back(this);
@@ -114,23 +119,35 @@ public:
     // Called by a rank that cannot go on.  Its peers inside this process are released from whatever
     // collective they wait in (their calls fail from here on); peers in other processes are the
     // launcher's to end when this process exits with an error.
+    // A peer's handle is taken away (exchanged for null) before it is aborted - ncclCommAbort frees it, and its owner
+    // must neither use nor free it again.  The owner enqueues under call_m_: the abort waits for an enqueue that is under
+    // way, and no call starts on a handle that is gone; an owner that does not come out of its call (the first
+    // collective connects inside ncclGroupEnd and waits for the rank that failed) is aborted all the same after a
+    // moment - releasing a blocked call from another thread is what ncclCommAbort is for.
     void abort() override {
         RcclRegistry& reg = rccl_registry();
         std::lock_guard<std::mutex> hold(reg.m);
         for (RcclComm* c : reg.comms) {
             if (memcmp(&c->uid_, &uid_, sizeof(uid_)) != 0 || c->aborted_.exchange(true)) continue;
-            if (c != this && c->comm_) { (void)api_->CommAbort(c->comm_); c->comm_ = nullptr; }
+            if (c == this) continue;
+            const bool quiet = c->call_m_.try_lock_for(std::chrono::milliseconds(200));
+            const ncclComm_t theirs = c->comm_.exchange(nullptr);
+            if (theirs) (void)api_->CommAbort(theirs);
+            if (quiet) c->call_m_.unlock();
         }
     }
 
     int host_all_gather(const uint64_t* mine, uint32_t n, uint64_t* all, hipStream_t s) override {
         const size_t total = (size_t)world_ * n;
-        if (dead()) return -1;
+        std::unique_lock<std::timed_mutex> call(call_m_);
+        const ncclComm_t comm = live();
+        if (!comm) return -1;
         if (d_small_.ensure(total + n) != hipSuccess || p_small_.ensure(total + n) != hipSuccess) return fail("out of memory");
         uint64_t* h = p_small_.p;                        // [0, n): mine; [n, n + total): all
         memcpy(h, mine, (size_t)n * 8);
         if (hipMemcpyAsync(d_small_.p, h, (size_t)n * 8, hipMemcpyHostToDevice, s) != hipSuccess) return fail("copy");
-        if (!ok(api_->AllGather(d_small_.p, d_small_.p + n, n, ncclUint64, comm_, s), "ncclAllGather")) return -1;
+        if (!ok(api_->AllGather(d_small_.p, d_small_.p + n, n, ncclUint64, comm, s), "ncclAllGather")) return -1;
+        call.unlock();
         if (hipMemcpyAsync(h + n, d_small_.p + n, total * 8, hipMemcpyDeviceToHost, s) != hipSuccess) return fail("copy");
         if (hipStreamSynchronize(s) != hipSuccess) return fail("hipStreamSynchronize");
         memcpy(all, h + n, total * 8);
@@ -140,7 +157,9 @@ public:
     int all_to_all_v(const void* send, const uint64_t* send_counts, void* recv, const uint64_t* recv_counts,
                      size_t elem_bytes, hipStream_t s) override {
         size_t so = 0, ro = 0, self_so = 0, self_ro = 0;
-        if (dead()) return -1;
+        std::unique_lock<std::timed_mutex> call(call_m_);
+        const ncclComm_t comm = live();
+        if (!comm) return -1;
         if (!ok(api_->GroupStart(), "ncclGroupStart")) return -1;
         bool good = true;                               // (a group that was opened is always closed)
         for (uint32_t p = 0; p < world_ && good; ++p) {
@@ -148,8 +167,8 @@ public:
             if (p == rank_) {
                 self_so = so; self_ro = ro;
             } else {
-                if (sb) good = ok(api_->Send((const char*)send + so, sb, ncclUint8, (int)p, comm_, s), "ncclSend");
-                if (rb && good) good = ok(api_->Recv((char*)recv + ro, rb, ncclUint8, (int)p, comm_, s), "ncclRecv");
+                if (sb) good = ok(api_->Send((const char*)send + so, sb, ncclUint8, (int)p, comm, s), "ncclSend");
+                if (rb && good) good = ok(api_->Recv((char*)recv + ro, rb, ncclUint8, (int)p, comm, s), "ncclRecv");
             }
             so += sb; ro += rb;
         }
@@ -163,14 +182,18 @@ public:
 
     int all_gather(const void* send, void* recv, size_t bytes, hipStream_t s) override {
         if (bytes == 0) return 0;
-        if (dead()) return -1;
-        return ok(api_->AllGather(send, recv, bytes, ncclUint8, comm_, s), "ncclAllGather") ? 0 : -1;
+        std::unique_lock<std::timed_mutex> call(call_m_);
+        const ncclComm_t comm = live();
+        if (!comm) return -1;
+        return ok(api_->AllGather(send, recv, bytes, ncclUint8, comm, s), "ncclAllGather") ? 0 : -1;
     }
 
     int all_gather_v(const void* send, void* recv, const uint64_t* counts, size_t elem_bytes, hipStream_t s) override {
         const size_t mine = (size_t)counts[rank_] * elem_bytes;
         size_t ro = 0, self_ro = 0;
-        if (dead()) return -1;
+        std::unique_lock<std::timed_mutex> call(call_m_);
+        const ncclComm_t comm = live();
+        if (!comm) return -1;
         if (!ok(api_->GroupStart(), "ncclGroupStart")) return -1;
         bool good = true;
         for (uint32_t p = 0; p < world_ && good; ++p) {
@@ -178,8 +201,8 @@ public:
             if (p == rank_) {
                 self_ro = ro;
             } else {
-                if (mine) good = ok(api_->Send(send, mine, ncclUint8, (int)p, comm_, s), "ncclSend");
-                if (rb && good) good = ok(api_->Recv((char*)recv + ro, rb, ncclUint8, (int)p, comm_, s), "ncclRecv");
+                if (mine) good = ok(api_->Send(send, mine, ncclUint8, (int)p, comm, s), "ncclSend");
+                if (rb && good) good = ok(api_->Recv((char*)recv + ro, rb, ncclUint8, (int)p, comm, s), "ncclRecv");
             }
             ro += rb;
         }
@@ -193,15 +216,20 @@ public:
 
     int all_reduce_u32(uint32_t* buf, size_t n, ReduceOp op, hipStream_t s) override {
         if (n == 0) return 0;
-        if (dead()) return -1;
+        std::unique_lock<std::timed_mutex> call(call_m_);
+        const ncclComm_t comm = live();
+        if (!comm) return -1;
         const ncclRedOp_t r = op == ReduceOp::kSum ? ncclSum : op == ReduceOp::kMin ? ncclMin : ncclMax;
-        return ok(api_->AllReduce(buf, buf, n, ncclUint32, r, comm_, s), "ncclAllReduce") ? 0 : -1;
+        return ok(api_->AllReduce(buf, buf, n, ncclUint32, r, comm, s), "ncclAllReduce") ? 0 : -1;
     }
 
     int barrier(hipStream_t s) override {
-        if (dead()) return -1;
+        std::unique_lock<std::timed_mutex> call(call_m_);
+        const ncclComm_t comm = live();
+        if (!comm) return -1;
         if (d_small_.ensure(8) != hipSuccess) return fail("out of memory");
-        if (!ok(api_->AllReduce(d_small_.p, d_small_.p, 1, ncclUint64, ncclSum, comm_, s), "ncclAllReduce")) return -1;
+        if (!ok(api_->AllReduce(d_small_.p, d_small_.p, 1, ncclUint64, ncclSum, comm, s), "ncclAllReduce")) return -1;
+        call.unlock();
         return hipStreamSynchronize(s) == hipSuccess ? 0 : fail("hipStreamSynchronize");
     }
 
@@ -212,10 +240,11 @@ private:
         return false;
     }
     int fail(const char* what) { err_ = what; return -1; }
-    bool dead() {
-        if (!aborted_.load() && comm_) return false;
-        err_ = "the group was aborted (a rank failed)";
-        return true;
+    // the handle, or null when the group was aborted (called with call_m_ held)
+    ncclComm_t live() {
+        const ncclComm_t c = aborted_.load() ? nullptr : comm_.load();
+        if (!c) err_ = "the group was aborted (a rank failed)";
+        return c;
     }
     // ncclGroupEnd even when a call inside the group failed: an open group would swallow every later call
     bool close_group(bool good) {
@@ -226,7 +255,8 @@ private:
     }
 
     RcclApi* api_ = nullptr;
-    ncclComm_t comm_ = nullptr;
+    std::atomic<ncclComm_t> comm_{nullptr};
+    std::timed_mutex call_m_;
     ncclUniqueId uid_ = {};
     std::atomic<bool> aborted_{false};
     DevBuf<uint64_t> d_small_;

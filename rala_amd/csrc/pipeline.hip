@@ -1793,7 +1793,8 @@ int rala_hip::repeats_stage(rala_hip_ctx* cs, rala_hip_ctx* cl, Comm* comm, cons
     if (!cl->piles_resident) return fail(cs, RALA_HIP_EINVAL, "the sensitive pass needs the piles on the owner context");
     const double t0 = now_ms();
     const int rc = repeats_after_tail(cs, cl, comm, sens, n_sens);
-    cs->tm.tail_host_ms += (float)(now_ms() - t0);
+    cs->tm.repeats_ms = (float)(now_ms() - t0);
+    cs->tm.tail_host_ms += cs->tm.repeats_ms;
     return rc;
 }
 
@@ -2595,8 +2596,10 @@ int rala_hip_construct(rala_hip_ctx* ctx, const rala_hip_overlaps* sens, uint64_
             // Graph::preprocess(sensitive overlaps) (graph.cpp:882-1054) works on the lists the
             // chimera stage leaves: bring them to the host, annotate repeats (kernels + host
             // orchestration), rebuild the graph from what is left
+            const double t1 = now_ms();
             const int rc6 = repeats_after_tail(ctx, ctx, nullptr, sens, n_sens);
             if (rc6 != RALA_HIP_OK) return rc6;
+            ctx->tm.repeats_ms = (float)(now_ms() - t1);
         }
         ctx->tm.tail_host_ms = (float)(now_ms() - t0);
         ctx->constructed = true;
@@ -2650,8 +2653,10 @@ int rala_hip_construct(rala_hip_ctx* ctx, const rala_hip_overlaps* sens, uint64_
         if (rc4 != RALA_HIP_OK) return rc4;
     }
     if (sens != nullptr && n_sens != 0) {
+        const double t1 = now_ms();
         const int rc3 = preprocess_repeats(ctx, ctx, nullptr, sens, n_sens, false);
         if (rc3 != RALA_HIP_OK) return rc3;
+        ctx->tm.repeats_ms = (float)(now_ms() - t1);
     }
     trc("preprocess total");
     build_graph(ctx);

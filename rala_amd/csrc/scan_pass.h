@@ -7,7 +7,8 @@
 // functor for every item's value, publishes the tile's sum, finds the sum of all tiles in front of it by
 // looking back over their published sums (the "decoupled look-back" of single-pass scans: a tile whose
 // predecessors have published an inclusive prefix stops there), and hands every item its exclusive
-// prefix.  The value is 62 bits wide, so two counters of up to 31 bits can ride in one scan (kept
+// prefix.  The value is 62 bits wide (what is published is masked to that: a functor that overflows cannot touch the status
+// bits), so two counters of up to 31 bits can ride in one scan (kept
 // overlaps and dovetails among them; survivors that go on as overlaps and as internals).
 //
 // State per tile: one 64-bit word {status : 2, value : 62}; the words of a scan must be zero when it
@@ -69,9 +70,9 @@ __global__ __launch_bounds__(kScanBlock) void scan_pass_kernel(uint32_t n, F f, 
         const uint32_t lane = threadIdx.x;
         uint64_t before = 0;
         if (tile == 0) {
-            if (lane == 0) __hip_atomic_store(&state[0], kScanPrefix | tile_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) __hip_atomic_store(&state[0], kScanPrefix | (tile_sum & kScanValueMask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
-            if (lane == 0) __hip_atomic_store(&state[tile], kScanAggregate | tile_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) __hip_atomic_store(&state[tile], kScanAggregate | (tile_sum & kScanValueMask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             int64_t first = (int64_t)tile - 1;       // nearest tile not yet accounted for
             for (;;) {
                 const int64_t t = first - (int64_t)lane;

@@ -177,9 +177,12 @@ int agree_with(rala_hip_mg* mg, int rc, const char* where, uint32_t flag, const 
         }
     }
     for (uint32_t p = 0; p < mg->world; ++p) {
-        if ((all[(size_t)p * (n + 1)] >> 32) != flag) {
-            return mg_fail(mg, RALA_HIP_EINVAL, std::string(where) + ": rank " + std::to_string(p) +
-                                                    " disagrees on whether there are sensitive overlaps");
+        const uint64_t theirs = all[(size_t)p * (n + 1)] >> 32;
+        if (theirs != flag) {
+            // bit 0: a sensitive pass; bit 1: bounds as 8-byte records (option use_bound_records)
+            const char* what = ((theirs ^ flag) & 1) ? " disagrees on whether there are sensitive overlaps"
+                                                     : " disagrees on the format of the bounds (option use_bound_records)";
+            return mg_fail(mg, RALA_HIP_EINVAL, std::string(where) + ": rank " + std::to_string(p) + what);
         }
     }
     mg->verdict_shared = false;
@@ -308,23 +311,44 @@ int rala_hip_mg_local_group_create(uint32_t world, void** group) {
 
 void rala_hip_mg_local_group_destroy(void* group) { destroy_local_group((LocalGroup*)group); }
 
-int rala_hip_mg_create(int device, uint32_t rank, uint32_t world, int transport, const void* token, rala_hip_mg** out) {
+// Two steps, so that callers can make sure every rank has its device before anybody enters the collective part: a rank
+// whose contexts cannot be created never reaches ncclCommInitRank, and the others would wait there for it.
+int rala_hip_mg_create_contexts(int device, uint32_t rank, uint32_t world, rala_hip_mg** out) {
     if (!out) return RALA_HIP_EINVAL;
     *out = nullptr;
-    if (world == 0 || world > 64 || rank >= world || !token) return RALA_HIP_EINVAL;
+    if (world == 0 || world > 64 || rank >= world) return RALA_HIP_EINVAL;
+    if (getenv("RALA_HIP_DEBUG_FAIL_RANK") && (uint32_t)atoi(getenv("RALA_HIP_DEBUG_FAIL_RANK")) == rank) return RALA_HIP_EDEVICE;    // tests
     rala_hip_mg* mg = new rala_hip_mg;
     mg->device = device; mg->rank = rank; mg->world = world;
     int rc = rala_hip_create(device, &mg->cs);
     if (rc == RALA_HIP_OK) rc = rala_hip_create(device, &mg->cl);
-    if (rc == RALA_HIP_OK) {
-        std::string err;
-        if (transport == RALA_HIP_COMM_RCCL) mg->comm = create_rccl_comm(rank, world, token, &err);
-        else if (transport == RALA_HIP_COMM_LOCAL) mg->comm = create_local_comm((LocalGroup*)token, rank, device, &err);
-        if (!mg->comm) {
-            fprintf(stderr, "[rala_hip_mg_create] %s\n", err.empty() ? "unknown transport" : err.c_str());
-            rc = RALA_HIP_EDEVICE;
-        }
+    if (rc != RALA_HIP_OK) { rala_hip_mg_destroy(mg); return rc; }
+    *out = mg;
+    return RALA_HIP_OK;
+}
+
+int rala_hip_mg_join(rala_hip_mg* mg, int transport, const void* token) {
+    if (!mg || !token) return RALA_HIP_EINVAL;
+    if (mg->comm) return mg_fail(mg, RALA_HIP_EINVAL, "the rank has joined a group already");
+    (void)hipSetDevice(mg->device);
+    std::string err;
+    if (transport == RALA_HIP_COMM_RCCL) mg->comm = create_rccl_comm(mg->rank, mg->world, token, &err);
+    else if (transport == RALA_HIP_COMM_LOCAL) mg->comm = create_local_comm((LocalGroup*)token, mg->rank, mg->device, &err);
+    if (!mg->comm) {
+        fprintf(stderr, "[rala_hip_mg_join] %s\n", err.empty() ? "unknown transport" : err.c_str());
+        return mg_fail(mg, RALA_HIP_EDEVICE, err.empty() ? "unknown transport" : err);
     }
+    return RALA_HIP_OK;
+}
+
+int rala_hip_mg_create(int device, uint32_t rank, uint32_t world, int transport, const void* token, rala_hip_mg** out) {
+    if (!out) return RALA_HIP_EINVAL;
+    *out = nullptr;
+    if (!token) return RALA_HIP_EINVAL;
+    rala_hip_mg* mg = nullptr;
+    int rc = rala_hip_mg_create_contexts(device, rank, world, &mg);
+    if (rc != RALA_HIP_OK) return rc;
+    rc = rala_hip_mg_join(mg, transport, token);
     if (rc != RALA_HIP_OK) { rala_hip_mg_destroy(mg); return rc; }
     *out = mg;
     return RALA_HIP_OK;
@@ -425,6 +449,7 @@ int run_all(rala_hip_mg* mg, const rala_hip_overlaps* sens_slice, uint64_t n_sen
 // fails, the rank objects are of no use afterwards.
 int rala_hip_mg_run(rala_hip_mg* mg, const rala_hip_overlaps* sens_slice, uint64_t n_sens, uint32_t* n_pairs) {
     if (!mg || !n_pairs) return RALA_HIP_EINVAL;
+    if (!mg->comm) return mg_fail(mg, RALA_HIP_EINVAL, "the rank has not joined its group (rala_hip_mg_join)");
     if (!mg->have_reads || !mg->have_overlaps) return mg_fail(mg, RALA_HIP_EINVAL, "set reads and overlaps first");
     mg->verdict_shared = false;
     const int rc = run_all(mg, sens_slice, n_sens, n_pairs);

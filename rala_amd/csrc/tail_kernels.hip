@@ -456,20 +456,21 @@ struct OffsetsPass {
     __device__ void total(uint64_t sum) const { out[n] = (uint32_t)sum; }
 };
 
-// two exclusive scans side by side (the second pass' chunk counts of surviving overlaps and internals: both below 2^31);
+// two exclusive scans side by side (the second pass' chunk counts of surviving overlaps and internals): 31 bits each in the
+// scan's 62 - a context holds fewer than 2^30 overlaps (rala_hip_set_overlaps), so neither sum reaches 2^31;
 // out[n] = the sums, which also go to totals[0 .. 1]
 struct PairOffsetsPass {
     const uint32_t *in0, *in1;
     uint32_t *out0, *out1, *totals;
     uint32_t n;
-    __device__ uint64_t value(uint32_t i) const { return (uint64_t)in0[i] | (uint64_t)in1[i] << 32; }
+    __device__ uint64_t value(uint32_t i) const { return (uint64_t)in0[i] | (uint64_t)in1[i] << 31; }
     __device__ void place(uint32_t i, uint64_t, uint64_t before) const {
-        out0[i] = (uint32_t)before;
-        out1[i] = (uint32_t)(before >> 32);
+        out0[i] = (uint32_t)(before & 0x7FFFFFFFull);
+        out1[i] = (uint32_t)(before >> 31);
     }
     __device__ void total(uint64_t sum) const {
-        out0[n] = totals[0] = (uint32_t)sum;
-        out1[n] = totals[1] = (uint32_t)(sum >> 32);
+        out0[n] = totals[0] = (uint32_t)(sum & 0x7FFFFFFFull);
+        out1[n] = totals[1] = (uint32_t)(sum >> 31);
     }
 };
 

@@ -30,6 +30,7 @@ SYMBOLS = (
     "rala_hip_bound_records_fit", "rala_hip_emit_bound_records_bucketed", "rala_hip_set_bound_records",
     "rala_hip_copy_device_state", "rala_hip_layout", "rala_hip_find_repetitive_hills",
     "rala_hip_mg_unique_id", "rala_hip_mg_local_group_create", "rala_hip_mg_local_group_destroy", "rala_hip_mg_create",
+    "rala_hip_mg_create_contexts", "rala_hip_mg_join",
     "rala_hip_mg_destroy", "rala_hip_mg_last_error", "rala_hip_mg_set_reads", "rala_hip_mg_slice_cuts",
     "rala_hip_mg_set_overlaps", "rala_hip_mg_run", "rala_hip_mg_run_threads", "rala_hip_mg_context",
     "rala_hip_mg_owner_context",
@@ -54,7 +55,8 @@ class Timings(ctypes.Structure):
                  "tr_ms", "total_ms")] + [("pile_launches", ctypes.c_uint32), ("death_rounds", ctypes.c_uint32),
                                   ("pile_overflow_reads", ctypes.c_uint32),
                                   ("pile_position_reads", ctypes.c_uint32),
-                                  ("pile_unbounded_reads", ctypes.c_uint32), ("pool_regrown", ctypes.c_uint32)]
+                                  ("pile_unbounded_reads", ctypes.c_uint32), ("pool_regrown", ctypes.c_uint32),
+                                  ("repeats_ms", ctypes.c_float)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -120,6 +122,8 @@ def lib(build=True):
         L.rala_hip_mg_local_group_destroy.argtypes = [vp]
         L.rala_hip_mg_local_group_destroy.restype = None
         L.rala_hip_mg_create.argtypes = [i32, u32, u32, i32, vp, ctypes.POINTER(vp)]
+        L.rala_hip_mg_create_contexts.argtypes = [i32, u32, u32, ctypes.POINTER(vp)]
+        L.rala_hip_mg_join.argtypes = [vp, i32, vp]
         L.rala_hip_mg_destroy.argtypes = [vp]
         L.rala_hip_mg_destroy.restype = None
         L.rala_hip_mg_last_error.argtypes = [vp]
@@ -145,9 +149,39 @@ class RalaHipError(RuntimeError):
         self.code = code
 
 
+class DeviceOverlaps:
+    """overlap columns that lie in device memory (kept alive by the caller, e.g. torch tensors): name -> pointer.
+    Accepted where a sensitive set is (Context.construct, ShardedRank.run, run_ranks) once the context's option
+    sensitive_in_device_memory is 1."""
+
+    def __init__(self, ptrs, n, keep=None):
+        self.ptrs, self.n, self.keep = dict(ptrs), int(n), keep
+
+    def __len__(self):
+        return self.n
+
+    @classmethod
+    def from_host(cls, ov, device):
+        """upload numpy columns to `device` (torch tensors hold the memory)"""
+        import torch
+
+        keep, ptrs = [], {}
+        for name, _ in OverlapsC._fields_:
+            arr = getattr(ov, name)
+            t = torch.from_numpy(arr.view(np.int32) if name != "strand" else arr).to("cuda:%d" % device)
+            keep.append(t)
+            ptrs[name] = t.data_ptr()
+        torch.cuda.synchronize(device)
+        return cls(ptrs, len(ov), keep)
+
+
 def _soa(ov):
-    """OverlapsC over an object with numpy members a_id … strand (kept alive by the caller)."""
+    """OverlapsC over an object with numpy members a_id … strand (kept alive by the caller), or over DeviceOverlaps."""
     c = OverlapsC()
+    if isinstance(ov, DeviceOverlaps):
+        for name, _ in OverlapsC._fields_:
+            setattr(c, name, ov.ptrs[name])
+        return c
     for name, _ in OverlapsC._fields_:
         arr = getattr(ov, name)
         want = np.uint8 if name == "strand" else np.uint32
@@ -400,22 +434,36 @@ def unique_id():
 
 
 class ShardedRank:
-    """One rank of a sharded run (rala_hip_mg_*).  token: 128-byte RCCL id (bytes) or a LocalGroup."""
+    """One rank of a sharded run (rala_hip_mg_*).  token: 128-byte RCCL id (bytes) or a LocalGroup; token None: only the
+    rank's device contexts are created (not collective) and join(token) enters the group later - launchers make sure
+    every rank has its contexts before anybody joins."""
 
-    def __init__(self, device, rank, world, token):
+    def __init__(self, device, rank, world, token=None):
         self.L = lib()
         self.rank, self.world = rank, world
         h = ctypes.c_void_p()
-        if isinstance(token, LocalGroup):
-            self._token = token
-            rc = self.L.rala_hip_mg_create(device, rank, world, COMM_LOCAL, token.h, ctypes.byref(h))
-        else:
-            self._token = ctypes.create_string_buffer(bytes(token), 128)
-            rc = self.L.rala_hip_mg_create(device, rank, world, COMM_RCCL, self._token, ctypes.byref(h))
+        rc = self.L.rala_hip_mg_create_contexts(device, rank, world, ctypes.byref(h))
         if rc != 0:
-            raise RalaHipError(rc, "rala_hip_mg_create failed (device %d, rank %d of %d)" % (device, rank, world))
+            raise RalaHipError(rc, "rala_hip_mg_create_contexts failed (device %d, rank %d of %d)" % (device, rank, world))
         self.h = h
         self._keep = None
+        self._token = None
+        if token is not None:
+            try:
+                self.join(token)
+            except Exception:
+                self.close()
+                raise
+
+    def join(self, token):
+        """collective: every rank of the group calls it (ncclCommInitRank / the in-process rendezvous)"""
+        if isinstance(token, LocalGroup):
+            self._token = token
+            rc = self.L.rala_hip_mg_join(self.h, COMM_LOCAL, token.h)
+        else:
+            self._token = ctypes.create_string_buffer(bytes(token), 128)
+            rc = self.L.rala_hip_mg_join(self.h, COMM_RCCL, self._token)
+        self._check(rc)
 
     def close(self):
         if getattr(self, "h", None):

@@ -2,10 +2,15 @@
 
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
 #include <fstream>
+#include <memory>
+#include <mutex>
 #include <set>
 #include <thread>
 
@@ -102,20 +107,69 @@ void Graph::open_devices() {
         fprintf(stderr, "[rala::Graph::Graph] error: RCCL is not usable (RALA_COMM=local selects the in-process transport)!\n");
         exit(1);
     }
-    // joining a communicator is collective: one host thread per rank
+    // every rank's device contexts first (not collective): nobody enters ncclCommInitRank unless all ranks have theirs -
+    // a rank that failed before it would leave the others waiting inside
     ranks_.assign(n_gpus, nullptr);
     std::vector<int> rc(n_gpus, 0);
-    std::vector<std::thread> th;
-    for (uint32_t k = 0; k < n_gpus; ++k) {
-        th.emplace_back([&, k]() {
-            rc[k] = rala_hip_mg_create(device[k], k, n_gpus, local ? RALA_HIP_COMM_LOCAL : RALA_HIP_COMM_RCCL,
-                                       local ? local_group_ : (const void*)id, &ranks_[k]);
-        });
+    {
+        std::vector<std::thread> th;
+        for (uint32_t k = 0; k < n_gpus; ++k) {
+            th.emplace_back([&, k]() { rc[k] = rala_hip_mg_create_contexts(device[k], k, n_gpus, &ranks_[k]); });
+        }
+        for (auto& t : th) t.join();
     }
-    for (auto& t : th) t.join();
     for (uint32_t k = 0; k < n_gpus; ++k) {
         if (rc[k] != RALA_HIP_OK) {
             fprintf(stderr, "[rala::Graph::Graph] error: device %d (rank %u of %u) is not usable!\n", device[k], k, n_gpus);
+            exit(1);
+        }
+    }
+    // joining a communicator is collective: one host thread per rank.  A join that does not come back cannot be
+    // interrupted from outside; after RALA_JOIN_TIMEOUT seconds (default 300) the run ends with an error instead of
+    // waiting for ever.
+    double limit = 300.0;
+    if (const char* e = getenv("RALA_JOIN_TIMEOUT")) limit = std::max(1.0, atof(e));
+    struct Joined {
+        std::mutex m;
+        std::condition_variable cv;
+        uint32_t done = 0;
+        std::vector<int> rc;
+    };
+    auto joined = std::make_shared<Joined>();            // (outlives this function if a thread is stuck)
+    joined->rc.assign(n_gpus, 0);
+    const void* token = local ? local_group_ : (const void*)id;
+    unsigned char* id_copy = nullptr;
+    if (!local) {                                        // (the id, too)
+        id_copy = new unsigned char[128];
+        memcpy(id_copy, id, 128);
+        token = id_copy;
+    }
+    for (uint32_t k = 0; k < n_gpus; ++k) {
+        rala_hip_mg* mg = ranks_[k];
+        std::thread([joined, mg, k, local, token]() {
+            const int r = rala_hip_mg_join(mg, local ? RALA_HIP_COMM_LOCAL : RALA_HIP_COMM_RCCL, token);
+            std::lock_guard<std::mutex> hold(joined->m);
+            joined->rc[k] = r;
+            ++joined->done;
+            joined->cv.notify_all();
+        }).detach();
+    }
+    {
+        std::unique_lock<std::mutex> hold(joined->m);
+        const bool all = joined->cv.wait_for(hold, std::chrono::duration<double>(limit), [&] { return joined->done == n_gpus; });
+        if (!all) {
+            fprintf(stderr, "[rala::Graph::Graph] error: %u of %u ranks did not join the %s group within %.0f s!\n",
+                    n_gpus - joined->done, n_gpus, local ? "in-process" : "RCCL", limit);
+            fflush(stderr);
+            _exit(1);                                    // (threads are stuck inside the library: no orderly exit)
+        }
+        rc = joined->rc;
+    }
+    delete[] id_copy;
+    for (uint32_t k = 0; k < n_gpus; ++k) {
+        if (rc[k] != RALA_HIP_OK) {
+            fprintf(stderr, "[rala::Graph::Graph] error: rank %u of %u could not join the group (%s)!\n", k, n_gpus,
+                    rala_hip_mg_last_error(ranks_[k]));
             exit(1);
         }
     }

@@ -67,16 +67,27 @@ class ShardedRunner:
         self.cuts = hip.slice_cuts(ov.a_id, world, ov.b_id)
         lo, hi = my_slice(self.cuts, rank)
         err = None
+        self.mg = None
+        # every rank's device contexts first (not collective); only when all ranks have theirs does anybody enter
+        # ncclCommInitRank - a rank that failed before it would leave the others waiting inside
+        try:
+            self.mg = hip.ShardedRank(local_rank, rank, world)
+        except Exception as e:          # noqa: BLE001 - agreed on below, then raised
+            err = e
+        if not all_agree(err is None, group):
+            if self.mg is not None:
+                self.mg.close()
+            raise err if err is not None else RuntimeError("another rank failed to set up its GPU")
         try:
             uid = exchange_id(hip.unique_id, group)
-            self.mg = hip.ShardedRank(local_rank, rank, world, uid)       # collective: ncclCommInitRank
+            self.mg.join(uid)                                            # collective: ncclCommInitRank
             self.mg.set_reads(ds.read_len)
             self._slice = ov.take(slice(lo, hi))
             self.mg.set_overlaps(self._slice, lo)
         except Exception as e:          # noqa: BLE001 - agreed on below, then raised
             err = e
         if not all_agree(err is None, group):
-            raise err if err is not None else RuntimeError("another rank failed to set up its GPU")
+            raise err if err is not None else RuntimeError("another rank failed to join the group")
         self._tm = {}
 
     def step(self):
@@ -114,7 +125,9 @@ class ThreadedRunner:
     call).  transport "local": the in-process transport (peer copies between the devices; also
     several ranks on one device, devices = [0, 0, ...]).  A step is rala_hip_mg_run_threads."""
 
-    def __init__(self, ds, world, devices=None, transport="rccl"):
+    def __init__(self, ds, world, devices=None, transport="rccl", join_timeout=None):
+        import os
+
         from . import hip
 
         self.hip = hip
@@ -136,26 +149,51 @@ class ThreadedRunner:
         self._slices = [None] * world
         errs = [None] * world
 
-        def make(k):
+        def contexts(k):
             try:
-                mg = hip.ShardedRank(devices[k], k, world, token)
-                self.ranks[k] = mg
+                self.ranks[k] = hip.ShardedRank(devices[k], k, world)
+            except Exception as e:      # noqa: BLE001 - reported below, for all ranks together
+                errs[k] = e
+
+        def join(k):
+            try:
+                mg = self.ranks[k]
+                mg.join(token)
                 mg.set_reads(ds.read_len)
                 lo, hi = my_slice(self.cuts, k)
                 self._slices[k] = ov.take(slice(lo, hi))
                 mg.set_overlaps(self._slices[k], lo)
-            except Exception as e:      # noqa: BLE001 - reported below, for all ranks together
+            except Exception as e:      # noqa: BLE001
                 errs[k] = e
 
-        th = [threading.Thread(target=make, args=(k,)) for k in range(world)]
+        def check(what):
+            bad = [(k, e) for k, e in enumerate(errs) if e is not None]
+            if bad:
+                self.close()
+                raise RuntimeError("sharded set-up failed (%s): " % what + "; ".join("rank %d: %s" % (k, e) for k, e in bad))
+
+        # 1. every rank's device contexts (not collective): nobody enters ncclCommInitRank unless all ranks have theirs
+        th = [threading.Thread(target=contexts, args=(k,)) for k in range(world)]
         for t in th:
             t.start()
         for t in th:
             t.join()
-        bad = [(k, e) for k, e in enumerate(errs) if e is not None]
-        if bad:
-            self.close()
-            raise RuntimeError("sharded set-up failed: " + "; ".join("rank %d: %s" % (k, e) for k, e in bad))
+        check("device contexts")
+        # 2. joining is collective; a join that does not come back (RCCL cannot be interrupted from outside) is reported
+        # after a time limit instead of waited for - the stuck threads are daemons and end with the process
+        limit = float(join_timeout if join_timeout is not None else os.environ.get("RALA_JOIN_TIMEOUT", "300"))
+        th = [threading.Thread(target=join, args=(k,), daemon=True) for k in range(world)]
+        for t in th:
+            t.start()
+        import time
+        deadline = time.monotonic() + limit
+        for t in th:
+            t.join(max(0.0, deadline - time.monotonic()))
+        stuck = [k for k, t in enumerate(th) if t.is_alive()]
+        if stuck:
+            self.ranks = []             # (their objects are in use by the stuck threads: not destroyed)
+            raise TimeoutError("sharded set-up: ranks %s did not join the %s group within %.0f s" % (stuck, transport, limit))
+        check("joining the group")
         self._tm = {}
 
     def step(self, sens_slices=None):

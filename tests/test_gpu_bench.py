@@ -57,17 +57,54 @@ def test_bench_end_to_end_figure_is_measured():
     assert e2e["transitive_pairs"] == line["config"]["transitive_pairs"]
 
 
-def test_rccl_attempt_in_a_child_and_the_fallback():
-    """A bare `--gpus N` tries RCCL in a child process first (more than one RCCL rank has never run where this was
-    built); a child that fails sends the same ranks through the in-process transport, and the line says so.  Here with
-    a world of one (RALA_FORCE_SHARDED), the child forced by RALA_BENCH_TEST_CHILD."""
+def test_rccl_attempt_in_a_child_and_no_silent_fallback():
+    """A bare `--gpus N` runs the RCCL ranks in a child process with a time limit (more than one RCCL rank has never run
+    where this was built, and a hung collective cannot be interrupted from inside); the child's line is the run's line, and
+    it names the transport.  A child that fails makes the run FAIL - round 3 printed a figure carried by peer copies
+    instead.  Here with a world of one (RALA_FORCE_SHARDED), the child forced by RALA_BENCH_TEST_CHILD."""
     common = ("--workload", "c1", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-e2e")
     ok = bench(*common, env={"RALA_FORCE_SHARDED": "1", "RALA_BENCH_TEST_CHILD": "1"})
     assert ok.returncode == 0, ok.stderr[-2000:]
     a = json.loads(ok.stdout.strip().splitlines()[-1])
-    assert "RCCL" in a["config"]["ranks"] and "failed" not in a["config"]["ranks"]
+    assert a["transport"] == "rccl" and a["rccl_ranks"] == a["n_gpus"] == 1 and "RCCL" in a["config"]["ranks"]
     bad = bench(*common, env={"RALA_FORCE_SHARDED": "1", "RALA_BENCH_TEST_CHILD": "1", "RALA_BENCH_FAKE_RCCL_FAILURE": "1"})
-    assert bad.returncode == 0, bad.stderr[-2000:]
-    b = json.loads(bad.stdout.strip().splitlines()[-1])
-    assert "in-process transport" in b["config"]["ranks"] and "the RCCL run failed: exit code 3" in b["config"]["ranks"]
+    assert bad.returncode == 3, (bad.returncode, bad.stderr[-2000:])
+    assert not [x for x in bad.stdout.splitlines() if x.startswith("{")]
+    assert "--transport local" in bad.stderr
+    # the in-process transport, asked for by name, says what it is
+    loc = bench(*common, "--transport", "local", env={"RALA_FORCE_SHARDED": "1"})
+    assert loc.returncode == 0, loc.stderr[-2000:]
+    b = json.loads(loc.stdout.strip().splitlines()[-1])
+    assert b["transport"] == "local" and b["rccl_ranks"] == 0
     assert b["config"]["transitive_pairs"] == a["config"]["transitive_pairs"]
+
+
+def test_a_rank_without_a_device_fails_the_set_up_at_once():
+    """every rank's device contexts are created before anybody joins the group (rala_hip_mg_create_contexts / _join): a rank
+    that has no device ends the run with an error instead of leaving the others inside ncclCommInitRank"""
+    import time
+
+    t0 = time.time()
+    res = bench("--gpus", "2", "--transport", "local", "--devices", "0,0", "--workload", "c1", "--steps", "1", "--warmup", "0",
+                "--no-cpu-baseline", "--no-e2e", env={"RALA_HIP_DEBUG_FAIL_RANK": "1"})
+    assert res.returncode == 3, (res.returncode, res.stderr[-2000:])
+    assert "device contexts" in res.stderr and time.time() - t0 < 120
+
+
+def test_sensitive_workload():
+    """c2s: the sensitive second pass inside the timed step, its overlaps resident in HBM; the line carries the pass' own
+    bytes and time; the same over two ranks that share the device"""
+    one = bench("--workload", "c2s", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-e2e")
+    assert one.returncode == 0, one.stderr[-2000:]
+    a = json.loads(one.stdout.strip().splitlines()[-1])
+    sp = a["sensitive_pass"]
+    assert sp["n_sensitive"] > 100_000 and sp["ms"] > 0 and sp["algorithmic_bytes"] > 0 and a["transport"] is None
+    plain = bench("--workload", "c2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-e2e")
+    p = json.loads(plain.stdout.strip().splitlines()[-1])
+    assert a["config"]["transitive_pairs"] != p["config"]["transitive_pairs"]          # the pass drops overlaps
+    two = bench("--gpus", "2", "--transport", "local", "--devices", "0,0", "--workload", "c2s", "--steps", "2", "--warmup", "1",
+                "--no-cpu-baseline", "--no-e2e")
+    assert two.returncode == 0, two.stderr[-2000:]
+    b = json.loads(two.stdout.strip().splitlines()[-1])
+    assert b["config"]["transitive_pairs"] == a["config"]["transitive_pairs"]
+    assert b["sensitive_pass"]["n_sensitive"] == sp["n_sensitive"] and b["sensitive_pass"]["ms"] > 0

@@ -124,7 +124,14 @@ def test_sensitive_pass_vs_oracle(hip_ctx_factory, n, g, seed, gpu_tail, run_ker
     _check_sensitive(hip_ctx_factory, Dataset(n, g, seed), gpu_tail, run_kernel, expect_hills=g >= 100_000)
 
 
-def _check_sensitive(hip_ctx_factory, ds, gpu_tail, run_kernel, expect_hills):
+@pytest.mark.parametrize("gpu_tail", [1, 0])
+def test_sensitive_overlaps_in_device_memory(hip_ctx_factory, gpu_tail):
+    """option sensitive_in_device_memory: the sensitive set handed to rala_hip_construct as device pointers (what
+    bench.py's c3s / c5s workloads do: resident in HBM like the primary set)"""
+    _check_sensitive(hip_ctx_factory, Dataset(5000, 1_000_000, 7), gpu_tail, 1, expect_hills=True, in_device=True)
+
+
+def _check_sensitive(hip_ctx_factory, ds, gpu_tail, run_kernel, expect_hills, in_device=False):
     from oracle.oracle import Oracle
 
     n = ds.n_reads
@@ -150,7 +157,15 @@ def _check_sensitive(hip_ctx_factory, ds, gpu_tail, run_kernel, expect_hills):
     ctx.set_reads(ds.read_len)
     ctx.set_overlaps(ds.overlaps)
     ctx.initialize()
-    ctx.construct(sens)
+    if in_device:
+        from rala_amd import hip
+        ctx.set_option("sensitive_in_device_memory", 1)
+        dev = hip.DeviceOverlaps.from_host(sens, 0)
+        ctx.construct(dev)
+        ctx.initialize()                # (and again: the set is not consumed)
+        ctx.construct(dev)
+    else:
+        ctx.construct(sens)
     offs, pairs, flags = ctx.intervals(2)
     parity.assert_same("rep.offsets", offs, want_rep[0])
     parity.assert_same("rep.pairs", pairs, want_rep[1])
