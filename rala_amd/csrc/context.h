@@ -213,6 +213,8 @@ struct rala_hip_ctx {
     std::vector<uint32_t> h_rep_slot;
     std::vector<rala_hip::Interval> h_rep_pool;
     bool have_repeats = false;
+    bool rep_host_stale = false;        // the hills are on the device, the host vectors above not yet fetched
+    uint32_t n_rep_hills = 0;
 
     // device-resident tail (tail_kernels.hip)
     bool use_gpu_tail = true;

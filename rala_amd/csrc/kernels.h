@@ -286,6 +286,11 @@ struct TailReads {
 void launch_sens_filter(const TailList& L, const uint32_t* begin, const uint32_t* end, const uint32_t* n_rep,
                         const uint32_t* rep_slot, const Interval* rep_pool, hipStream_t s);
 void launch_finalize_states(const TailList& L, const uint8_t* alive, hipStream_t s);
+// the read lists of the sensitive pass, made where the data is (*count zeroed by the caller): reads that received sensitive
+// bounds; alive reads with an overlap (of a sharded run: this rank's, as local ids)
+void launch_list_targets(const uint32_t* off, uint32_t n, uint32_t* list, uint32_t* count, hipStream_t s);
+void launch_list_members(const uint32_t* alive_reads, const uint8_t* touched, uint32_t n_alive, uint32_t world, uint32_t rank,
+                         uint32_t* list, uint32_t* count, hipStream_t s);
 void launch_scatter_component_medians(const uint32_t* alive_reads, const uint8_t* touched, const uint16_t* cmed, uint32_t n_alive,
                                       uint16_t* out, hipStream_t s);
 void launch_break_hills(const TailReads& R, uint32_t n_reads, hipStream_t s);

@@ -116,6 +116,19 @@ void build_classes(rala_hip_ctx* ctx, const std::vector<uint32_t>& reads, std::v
     const int n_lds = (int)(sizeof(kLw) / sizeof(kLw[0]));
     std::vector<std::vector<uint32_t>> bins(n_lds + 1);
     uint32_t max_long = 0;
+    // a handful of reads (what the run-space chain hands on: a dozen at C3): ONE launch at the size of the longest - three
+    // launches of four workgroups each are three times the latency of one
+    int only = -1;
+    if (reads.size() <= 32) {
+        uint32_t top = 0;
+        for (uint32_t r : reads) top = std::max(top, ctx->h_read_len[r]);
+        only = n_lds;
+        if ((int64_t)top <= ctx->max_lds_read_len) {
+            for (int c = 0; c < n_lds; ++c) {
+                if (pile_lw_for(top) <= kLw[c]) { only = c; break; }
+            }
+        }
+    }
     for (uint32_t r : reads) {
         const uint32_t len = ctx->h_read_len[r];
         const uint32_t lw = pile_lw_for(len);
@@ -125,6 +138,7 @@ void build_classes(rala_hip_ctx* ctx, const std::vector<uint32_t>& reads, std::v
                 if (lw <= kLw[c]) { k = c; break; }
             }
         }
+        if (only >= 0) k = only;
         bins[k].push_back(r);
         if (k == n_lds) max_long = std::max(max_long, lw);
     }
@@ -670,19 +684,31 @@ int run_repeats_kernel(rala_hip_ctx* ctx, RepeatArgs a, const std::vector<uint32
 // One mode of the sensitive pass over `reads`: the run-space kernel (cap 512, then 1024) reads the
 // primary bound events where initialize left them plus the sensitive bounds of pa.sens_*; what it
 // hands on goes to the position-space kernel.
-int run_sens_pass(rala_hip_ctx* ctx, PileArgs pa, const RepeatArgs& ra, const std::vector<uint32_t>& reads, int mode) {
-    if (reads.empty()) return RALA_HIP_OK;
-    if (!ctx->use_run_kernel || !ctx->ev_ready) return run_repeats_kernel(ctx, ra, reads, mode);
+// list_dev: the reads (count of them) in ctx->d_sens_list already, or null: `reads` is uploaded there
+int run_sens_pass(rala_hip_ctx* ctx, PileArgs pa, const RepeatArgs& ra, const std::vector<uint32_t>& reads, int mode,
+                  const uint32_t* list_dev = nullptr, uint32_t list_count = 0) {
+    if (list_dev == nullptr && reads.empty()) return RALA_HIP_OK;
+    if (list_dev != nullptr && list_count == 0) return RALA_HIP_OK;
+    if (!ctx->use_run_kernel || !ctx->ev_ready) {
+        if (list_dev == nullptr) return run_repeats_kernel(ctx, ra, reads, mode);
+        std::vector<uint32_t> host(list_count);
+        HIPCHECK(hipMemcpy(host.data(), list_dev, (size_t)list_count * 4, hipMemcpyDeviceToHost));
+        std::sort(host.begin(), host.end());
+        return run_repeats_kernel(ctx, ra, host, mode);
+    }
     hipStream_t s = ctx->stream;
     Trace trc;
-    const uint32_t count = (uint32_t)reads.size();
-    HIPCHECK(ctx->d_sens_list.ensure(count + 1));
+    const uint32_t count = list_dev ? list_count : (uint32_t)reads.size();
     HIPCHECK(ctx->d_overflow.ensure(ctx->n_reads + 1));
     HIPCHECK(ctx->d_overflow_mid.ensure(ctx->n_reads + 1));
     HIPCHECK(ctx->d_chain_cnt.ensure(4));
-    HIPCHECK(hipMemcpyAsync(ctx->d_sens_list.p, reads.data(), (size_t)count * 4, hipMemcpyHostToDevice, s));
+    if (list_dev == nullptr) {
+        HIPCHECK(ctx->d_sens_list.ensure(count + 1));
+        HIPCHECK(hipMemcpyAsync(ctx->d_sens_list.p, reads.data(), (size_t)count * 4, hipMemcpyHostToDevice, s));
+        list_dev = ctx->d_sens_list.p;
+    }
     HIPCHECK(hipMemsetAsync(ctx->d_chain_cnt.p, 0, 16, s));
-    pa.order = ctx->d_sens_list.p;
+    pa.order = list_dev;
     pa.n_items = count;
     pa.n_items_dev = nullptr;
     // cap 512 / 16384 bases -> (list) cap 512 / 32768 bases, if there are such reads -> (list) cap 1024 /
@@ -730,6 +756,21 @@ bool is_valid_overlap(rala_hip_ctx* ctx, uint32_t r, uint32_t x, uint32_t y) {
 }
 
 int materialize_host(rala_hip_ctx* ctx);
+// the repeat hills (sensitive pass) as the host getters want them
+int download_repeat_hills(rala_hip_ctx* ctx) {
+    if (!ctx->rep_host_stale) return RALA_HIP_OK;
+    const uint64_t n = ctx->n_reads;
+    HIPCHECK(hipSetDevice(ctx->device));
+    ctx->h_n_rep.resize(n); ctx->h_rep_slot.resize(n);
+    HIPCHECK(hipMemcpy(ctx->h_n_rep.data(), ctx->d_n_rep.p, n * 4, hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(ctx->h_rep_slot.data(), ctx->d_rep_slot.p, n * 4, hipMemcpyDeviceToHost));
+    ctx->h_rep_pool.resize(ctx->n_rep_hills);
+    if (ctx->n_rep_hills) {
+        HIPCHECK(hipMemcpy(ctx->h_rep_pool.data(), ctx->d_rep_pool.p, (size_t)ctx->n_rep_hills * sizeof(Interval), hipMemcpyDeviceToHost));
+    }
+    ctx->rep_host_stale = false;
+    return RALA_HIP_OK;
+}
 void build_graph(rala_hip_ctx* ctx);
 TailList tail_list(rala_hip_ctx* ctx);
 int tail_components(rala_hip_ctx* ctx, const TailList& L, uint32_t n_alive, bool touched_cleared = false);
@@ -870,14 +911,16 @@ int preprocess_repeats(rala_hip_ctx* cs, rala_hip_ctx* cl, Comm* comm, const ral
     launch_exclusive_scan(cl->d_sens_cur.p, cl->d_sens_off.p, nl, cl->d_scan_ws.p, sl);
     HIPCHECK(hipMemcpyAsync(cl->d_sens_cur.p, cl->d_sens_off.p, nl * 4, hipMemcpyDeviceToDevice, sl));
     launch_scatter_tuples(tuples, n_tuples, (uint32_t)nl, cl->d_sens_cur.p, cl->d_sens_ev.p, sl);
-    // the targets: reads that received bounds
-    std::vector<uint32_t> ev_off(nl + 1);
-    HIPCHECK(hipMemcpyAsync(ev_off.data(), cl->d_sens_off.p, (nl + 1) * 4, hipMemcpyDeviceToHost, sl));
+    // the targets: reads that received bounds - listed where the offsets are, the host learns how many
+    HIPCHECK(cl->d_sens_list.ensure(nl + 1));
+    HIPCHECK(cl->d_chain_cnt.ensure(8));
+    HIPCHECK(hipMemsetAsync(cl->d_chain_cnt.p + 4, 0, 4, sl));
+    launch_list_targets(cl->d_sens_off.p, (uint32_t)nl, cl->d_sens_list.p, cl->d_chain_cnt.p + 4, sl);
+    uint32_t n_targets = 0;
+    HIPCHECK(d2h_small(cl, &n_targets, cl->d_chain_cnt.p + 4, 4, sl));
     HIPCHECK(stream_sync(cl, sl));
     HIPCHECK(hipGetLastError());
-    std::vector<uint32_t> targets;
-    for (uint64_t r = 0; r < nl; ++r) if (ev_off[r + 1] != ev_off[r]) targets.push_back((uint32_t)r);
-    trc("rep: transmute + bucket", targets.size());
+    trc("rep: transmute + bucket", n_targets);
 
     RepeatArgs a;
     a.read_len = cl->d_read_len.p; a.pile_off = cl->d_pile_off.p; a.pile = cl->d_pile.p;
@@ -900,7 +943,7 @@ int preprocess_repeats(rala_hip_ctx* cs, rala_hip_ctx* cl, Comm* comm, const ral
     pa.dataset_median = cl->d_dataset_median.p; pa.n_rep = cl->d_n_rep.p; pa.rep_slot = cl->d_rep_slot.p;
     pa.rep_pool = cl->d_rep_pool.p; pa.rep_pool_count = cl->d_small.p + 6; pa.rep_pool_cap = cl->rep_pool_cap;
     // add_layers on top of the coverage + find_median for the targets (graph.cpp:941-969)
-    int rc = run_sens_pass(cl, pa, a, targets, 1);
+    int rc = run_sens_pass(cl, pa, a, std::vector<uint32_t>(), 1, cl->d_sens_list.p, n_targets);
     if (rc != RALA_HIP_OK) { if (cl != cs) cs->err = cl->err; return rc; }
     if (sharded) {
         // the new medians, everywhere
@@ -915,7 +958,7 @@ int preprocess_repeats(rala_hip_ctx* cs, rala_hip_ctx* cl, Comm* comm, const ral
         HIPCHECK(hipMemcpyAsync(cs->h_p10.data(), cs->d_p10.p, n * 2, hipMemcpyDeviceToHost, s));
         HIPCHECK(stream_sync(cs, s));
     }
-    trc("rep: add_layers + median", targets.size());
+    trc("rep: add_layers + median", n_targets);
     // first trim of the sensitive overlaps (graph.cpp:935-939)
     SensCoords sc;
     for (int k = 0; k < 5; ++k) HIPCHECK(cs->d_sens_c[k].ensure(n_sens));
@@ -926,6 +969,8 @@ int preprocess_repeats(rala_hip_ctx* cs, rala_hip_ctx* cl, Comm* comm, const ral
     trc("rep: first trim", n_sens);
     // component medians over the primary overlaps -> repeat hills (graph.cpp:971-1026)
     std::vector<uint32_t> members;
+    bool members_on_device = false;
+    uint32_t n_members = 0;
     if (!device_lists) {
         std::vector<uint16_t> med;
         rc = component_medians(cs, members, med);
@@ -941,22 +986,25 @@ int preprocess_repeats(rala_hip_ctx* cs, rala_hip_ctx* cl, Comm* comm, const ral
         if (rc != RALA_HIP_OK) return rc;
         HIPCHECK(hipMemsetAsync(cs->d_dataset_median.p, 0, n * 2, s));
         launch_scatter_component_medians(cs->d_alive_reads.p, cs->d_touched.p, cs->d_cmed.p, n_alive, cs->d_dataset_median.p, s);
-        // the members (reads with an overlap), for the launch classes of the hill kernel
-        HIPCHECK(cs->p_alive_reads.ensure(n_alive + 1));
-        HIPCHECK(cs->p_touched.ensure(n_alive + 1));
-        HIPCHECK(hipMemcpyAsync(cs->p_alive_reads.p, cs->d_alive_reads.p, (size_t)n_alive * 4, hipMemcpyDeviceToHost, s));
-        HIPCHECK(hipMemcpyAsync(cs->p_touched.p, cs->d_touched.p, n_alive, hipMemcpyDeviceToHost, s));
+        // the members (reads with an overlap; of a sharded run this rank's, as the owner's local ids) are listed where the
+        // data is; the host learns how many
+        HIPCHECK(cl->d_sens_list.ensure(std::max<uint64_t>(nl, 1) + 1));
+        HIPCHECK(cs->d_chain_cnt.ensure(8));
+        HIPCHECK(hipMemsetAsync(cs->d_chain_cnt.p + 5, 0, 4, s));
+        launch_list_members(cs->d_alive_reads.p, cs->d_touched.p, n_alive, P, me, cl->d_sens_list.p, cs->d_chain_cnt.p + 5, s);
+        HIPCHECK(d2h_small(cs, &n_members, cs->d_chain_cnt.p + 5, 4, s));
         HIPCHECK(stream_sync(cs, s));
-        for (uint32_t q = 0; q < n_alive; ++q) if (cs->p_touched.p[q]) members.push_back(cs->p_alive_reads.p[q]);
+        members_on_device = true;
     }
-    trc("rep: component medians", members.size());
+    trc("rep: component medians", members_on_device ? n_members : members.size());
     std::vector<uint32_t> mine;
     if (sharded) {
         launch_localize_u16(cs->d_dataset_median.p, nl, P, me, cl->d_dataset_median.p, sl);
-        for (uint32_t r : members) if (r % P == me) mine.push_back(r / P);
+        if (!members_on_device) for (uint32_t r : members) if (r % P == me) mine.push_back(r / P);
     }
     for (;;) {
-        rc = run_sens_pass(cl, pa, a, sharded ? mine : members, 2);
+        rc = members_on_device ? run_sens_pass(cl, pa, a, members, 2, cl->d_sens_list.p, n_members)
+                               : run_sens_pass(cl, pa, a, sharded ? mine : members, 2);
         if (rc != RALA_HIP_OK) { if (cl != cs) cs->err = cl->err; return rc; }
         uint32_t st[2];
         HIPCHECK(hipMemcpy(st, cl->d_small.p + 6, sizeof(st), hipMemcpyDeviceToHost));
@@ -1017,13 +1065,12 @@ int preprocess_repeats(rala_hip_ctx* cs, rala_hip_ctx* cl, Comm* comm, const ral
     HIPCHECK(stream_sync(cs, s));
     HIPCHECK(hipGetLastError());
     trc("rep: bridged hills", n_sens);
-    cs->h_n_rep.resize(n); cs->h_rep_slot.resize(n);
-    HIPCHECK(hipMemcpy(cs->h_n_rep.data(), cs->d_n_rep.p, n * 4, hipMemcpyDeviceToHost));
-    HIPCHECK(hipMemcpy(cs->h_rep_slot.data(), cs->d_rep_slot.p, n * 4, hipMemcpyDeviceToHost));
-    cs->h_rep_pool.resize(n_hills);
-    if (n_hills) {
-        HIPCHECK(hipMemcpy(cs->h_rep_pool.data(), cs->d_rep_pool.p, (size_t)n_hills * sizeof(Interval),
-                           hipMemcpyDeviceToHost));
+    // the host's copy of the hills: at once where the host filters the overlaps below, otherwise with the first getter
+    cs->n_rep_hills = n_hills;
+    cs->rep_host_stale = true;
+    if (!device_lists) {
+        const int rcd = download_repeat_hills(cs);
+        if (rcd != RALA_HIP_OK) return rcd;
     }
     trc("rep: download hills", n_hills);
     // overlaps that end inside a bridged edge hill are dropped (graph.cpp:1045-1051)
@@ -1419,6 +1466,10 @@ int gpu_tail_run(rala_hip_ctx* ctx) {
 
 // host mirrors of a device-resident result (lists in the reference's order, graph, read state)
 int materialize_host(rala_hip_ctx* ctx) {
+    if (ctx->have_repeats && ctx->rep_host_stale) {
+        const int rcr = download_repeat_hills(ctx);
+        if (rcr != RALA_HIP_OK) return rcr;
+    }
     if (!ctx->host_stale) return ctx->host_state_fresh ? RALA_HIP_OK : download_read_state(ctx);
     hipStream_t s = ctx->stream;
     int rc = download_read_state(ctx);
@@ -2738,6 +2789,8 @@ int rala_hip_find_repetitive_hills(rala_hip_ctx* ctx, uint64_t read, uint32_t be
     HIPCHECK(hipMemcpy(&ctx->h_rep_slot[read], ctx->d_rep_slot.p + read, 4, hipMemcpyDeviceToHost));
     ctx->h_rep_pool.resize(small[6]);
     if (small[6]) HIPCHECK(hipMemcpy(ctx->h_rep_pool.data(), ctx->d_rep_pool.p, (size_t)small[6] * sizeof(Interval), hipMemcpyDeviceToHost));
+    ctx->n_rep_hills = small[6];
+    ctx->rep_host_stale = false;
     ctx->have_repeats = true;
     return RALA_HIP_OK;
 }

@@ -176,6 +176,41 @@ void launch_sens_filter(const TailList& L, const uint32_t* begin, const uint32_t
                         const uint32_t* rep_slot, const Interval* rep_pool, hipStream_t s) {
     if (L.n) hipLaunchKernelGGL(sens_filter_kernel, grid_for(L.n), dim3(kBlock), 0, s, L, begin, end, n_rep, rep_slot, rep_pool);
 }
+namespace {
+// what a wavefront's flagged lanes append, in lane order, behind one add to the list's counter
+__device__ __forceinline__ void append_flagged(bool flag, uint32_t value, uint32_t* list, uint32_t* count) {
+    const uint64_t m = __ballot(flag);
+    if (m == 0) return;
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(count, (uint32_t)__popcll(m));
+    base = (uint32_t)__shfl((int)base, 0, 64);
+    if (flag) list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = value;
+}
+// the targets of the sensitive overlaps: the reads that received bounds (graph.cpp:941-953 walks the piles with bounds)
+__global__ __launch_bounds__(kBlock) void list_targets_kernel(const uint32_t* __restrict__ off, uint32_t n, uint32_t* list, uint32_t* count) {
+    const uint32_t r = blockIdx.x * kBlock + threadIdx.x;
+    append_flagged(r < n && off[r + 1] != off[r], r, list, count);
+}
+// the members of the components: alive reads with an overlap (graph.cpp:1006-1026); of a sharded run, this rank's (read r
+// lives on rank r % world as its read r / world)
+__global__ __launch_bounds__(kBlock) void list_members_kernel(const uint32_t* __restrict__ alive_reads, const uint8_t* __restrict__ touched,
+                                                              uint32_t n_alive, uint32_t world, uint32_t rank, uint32_t* list,
+                                                              uint32_t* count) {
+    const uint32_t q = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t r = q < n_alive ? alive_reads[q] : 0u;
+    append_flagged(q < n_alive && touched[q] && r % world == rank, r / world, list, count);
+}
+}  // namespace
+
+void launch_list_targets(const uint32_t* off, uint32_t n, uint32_t* list, uint32_t* count, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(list_targets_kernel, grid_for(n), dim3(kBlock), 0, s, off, n, list, count);
+}
+void launch_list_members(const uint32_t* alive_reads, const uint8_t* touched, uint32_t n_alive, uint32_t world, uint32_t rank,
+                         uint32_t* list, uint32_t* count, hipStream_t s) {
+    if (n_alive) hipLaunchKernelGGL(list_members_kernel, grid_for(n_alive), dim3(kBlock), 0, s, alive_reads, touched, n_alive, world, rank, list, count);
+}
+
 void launch_finalize_states(const TailList& L, const uint8_t* alive, hipStream_t s) {
     if (L.n) hipLaunchKernelGGL(finalize_states_kernel, grid_for(L.n), dim3(kBlock), 0, s, L, alive);
 }
