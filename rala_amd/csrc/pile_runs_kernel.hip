@@ -570,8 +570,13 @@ __device__ __forceinline__ void expand_from_bitmap(uint32_t* sm, const uint16_t*
 // vector hoisted that way was spilled and reloaded right behind the row stores: a scratch load, and
 // with it a wait for every one of them.)
 // kBases > 16384: the short layout with a bigger bitmap, for the reads the first kernel handed on.
-template <uint32_t kCap, bool kDiag, int kSens, bool kOne = false, uint32_t kBases = 16384>
-__global__ __launch_bounds__(64, kOne ? 7 : kBases > 32768 ? 2 : kBases > 16384 ? 4 : 5) void pile_runs_kernel(PileArgs A, uint32_t* overflow_list, uint32_t* overflow_count) {
+// kWaves (with kOne): reads per workgroup, one wavefront each.  The wavefronts of a workgroup share nothing - every one has
+// its own stretch of LDS and synchronises with itself only; what they have in common is their place: the rows of
+// neighbouring reads are written from one compute unit (tools/fill_bench4.hip: four rows per workgroup fill at 5.4 TB/s
+// where one row per workgroup fills at 5.0).
+template <uint32_t kCap, bool kDiag, int kSens, bool kOne = false, uint32_t kBases = 16384, uint32_t kWaves = 1>
+__global__ __launch_bounds__(64 * kWaves, kOne ? 7 : kBases > 32768 ? 2 : kBases > 16384 ? 4 : 5) void pile_runs_kernel(PileArgs A, uint32_t* overflow_list, uint32_t* overflow_count) {
+    static_assert(kWaves == 1 || kOne, "several reads per workgroup: the first kernel of a chain only");
     static_assert(kSens == 0 || (kCap <= 1024 && !kDiag), "the sensitive pass runs on the bitmap path");
     static_assert(!kOne || kCap <= 512, "the short layout belongs to the first kernel of a chain");
     static_assert(kBases == 16384 || !kOne, "the bigger bitmap belongs to the chain's second kernel");
@@ -580,7 +585,9 @@ __global__ __launch_bounds__(64, kOne ? 7 : kBases > 32768 ? 2 : kBases > 16384 
     typedef Layout<kCap, kShort, kBases> L;
     typedef typename L::rs_t rs_t;
     constexpr uint32_t kMaxReg = L::kMaxReg, kMaxRaw = L::kMaxRaw;
-    __shared__ __align__(16) uint32_t sm[L::WORDS];
+    __shared__ __align__(16) uint32_t sm_all[kWaves * L::WORDS];
+    const uint32_t wave_in_group = kWaves == 1 ? 0u : (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    uint32_t* sm = sm_all + wave_in_group * L::WORDS;
     uint32_t* ev = sm + L::X;
     rs_t* rs = (rs_t*)(sm + L::RS);
     uint16_t* rv = (uint16_t*)(sm + L::RV);
@@ -600,8 +607,8 @@ __global__ __launch_bounds__(64, kOne ? 7 : kBases > 32768 ? 2 : kBases > 16384 
     // Workgroup i runs on XCD i % 8.  A grid smaller than the number of items (a multiple of 8) gives every
     // XCD one contiguous eighth of the items (tools/fill_bench3.hip: rows written side by side by one XCD
     // stream out at 6.2 TB/s instead of 5.2 TB/s - in a fill kernel; this kernel does not notice).
-    uint32_t item_first = blockIdx.x, item_end = n_items, item_step = gridDim.x;
-    if (kOne && gridDim.x % 8u == 0 && gridDim.x < n_items) {
+    uint32_t item_first = blockIdx.x * kWaves + wave_in_group, item_end = n_items, item_step = gridDim.x * kWaves;
+    if (kOne && kWaves == 1 && gridDim.x % 8u == 0 && gridDim.x < n_items) {
         const uint32_t per = (n_items + 7u) / 8u, xcd = blockIdx.x % 8u;
         item_first = xcd * per + blockIdx.x / 8u;
         item_end = umin(n_items, (xcd + 1u) * per);
@@ -612,7 +619,7 @@ __global__ __launch_bounds__(64, kOne ? 7 : kBases > 32768 ? 2 : kBases > 16384 
         // compiler used to hoist such values out of the loop and keep them in registers for the whole kernel -
         // 96 VGPRs and spills with a loop over items, 70 without one.)
         uint32_t lane;
-        asm volatile("v_mov_b32 %0, %1" : "=v"(lane) : "v"(threadIdx.x));
+        asm volatile("v_mov_b32 %0, %1" : "=v"(lane) : "v"(kWaves == 1 ? threadIdx.x : threadIdx.x & 63u));
         const uint32_t r = A.order ? A.order[item] : item;
         const uint32_t n = A.read_len[r];
         const uint64_t row_off = kSens == 2 ? 0 : A.pile_off[r];
@@ -1669,6 +1676,8 @@ void launch_pile_dense_list(const PileArgs& args, uint32_t n_reads, uint32_t* li
     hipLaunchKernelGGL(pile_dense_list_kernel, dim3((n_reads + 255) / 256), dim3(256), 0, stream, args, n_reads, list, count);
 }
 
+constexpr uint32_t kPileWavesPerGroup = 1;
+
 void launch_pile_runs(const PileArgs& args, uint32_t grid, int tier, uint32_t* overflow_list, uint32_t* overflow_count,
                       hipStream_t stream) {
     if (grid == 0) return;
@@ -1690,8 +1699,14 @@ void launch_pile_runs(const PileArgs& args, uint32_t grid, int tier, uint32_t* o
         // others' work.  The SQ counters' 74 % slot occupancy is not the dispatcher's doing.)
         static const uint32_t persist = getenv("RALA_PILE_PERSIST") ? (uint32_t)atoi(getenv("RALA_PILE_PERSIST")) : 0u;
         const uint32_t g = persist && persist < grid ? persist / 8u * 8u : grid;
+        // reads per workgroup (one wavefront each): RALA_PILE_WAVES = 1, 2 or 4
+        static const uint32_t waves = getenv("RALA_PILE_WAVES") ? (uint32_t)atoi(getenv("RALA_PILE_WAVES")) : kPileWavesPerGroup;
         if (diag) hipLaunchKernelGGL((pile_runs_kernel<kRunEventCap, true, 0, true>), dim3(g), dim3(64), extra_lds, stream,
                                      args, overflow_list, overflow_count);
+        else if (waves == 4 && !persist) hipLaunchKernelGGL((pile_runs_kernel<kRunEventCap, false, 0, true, 16384, 4>), dim3((grid + 3) / 4), dim3(256),
+                                                            extra_lds, stream, args, overflow_list, overflow_count);
+        else if (waves == 2 && !persist) hipLaunchKernelGGL((pile_runs_kernel<kRunEventCap, false, 0, true, 16384, 2>), dim3((grid + 1) / 2), dim3(128),
+                                                            extra_lds, stream, args, overflow_list, overflow_count);
         else hipLaunchKernelGGL((pile_runs_kernel<kRunEventCap, false, 0, true>), dim3(g), dim3(64), extra_lds, stream,
                                 args, overflow_list, overflow_count);
     } else if (tier == 3) {
