@@ -130,6 +130,29 @@ RALA_HD bool ovl_edges(const Coords& c, uint32_t strand, uint32_t type, uint32_t
     return false;
 }
 
+// Pile::break_over_chimeric_pits / _hills (pile.cpp:366-402, 471-498) ask the same question: the read is cut at every
+// interval that lies inside its valid region [B, E) and counts (`cuts(i)`: a pit that is real, a hill that too few overlaps
+// span) - which piece between two cuts is the longest (the first of the longest)?  That piece is the region Pile::shrink
+// is then given.  at(i, first, second) hands out interval i; cuts(i) is asked only about intervals inside the region.
+struct Piece {
+    uint32_t begin, end;
+};
+template <class At, class Cuts>
+RALA_HD Piece longest_piece(uint32_t B, uint32_t E, uint32_t n, At at, Cuts cuts) {
+    Piece best = {0, 0};
+    uint32_t from = B;
+    for (uint32_t i = 0; i < n; ++i) {
+        uint32_t first, second;
+        at(i, first, second);
+        if (B > first || E < second) continue;
+        if (!cuts(i)) continue;
+        if ((uint32_t)(first - from) > (uint32_t)(best.end - best.begin)) { best.begin = from; best.end = first; }
+        from = second;
+    }
+    if ((uint32_t)(E - from) > (uint32_t)(best.end - best.begin)) { best.begin = from; best.end = E; }
+    return best;
+}
+
 // graph.cpp:26-29
 RALA_HD bool comparable(double a, double b, double eps) {
     return (a >= b * (1 - eps) && a <= b * (1 + eps)) || (b >= a * (1 - eps) && b <= a * (1 + eps));

@@ -319,40 +319,28 @@ bool host_shrink(rala_hip_ctx* ctx, uint32_t r, uint32_t b, uint32_t e) {
     return true;
 }
 
-// Pile::break_over_chimeric_hills (pile.cpp:471-498)
+// Pile::break_over_chimeric_hills (pile.cpp:471-498): geom.h longest_piece, as on the device
 bool break_hills(rala_hip_ctx* ctx, uint32_t r, const Interval* hills, uint32_t n) {
-    const uint32_t B = ctx->h_begin[r], E = ctx->h_end[r];
-    uint32_t b = 0, e = 0, from = B;
-    for (uint32_t i = 0; i < n; ++i) {
-        if (B > hills[i].first || E < hills[i].second) continue;
-        if (hills[i].aux > 3) continue;
-        if ((uint32_t)(hills[i].first - from) > (uint32_t)(e - b)) { b = from; e = hills[i].first; }
-        from = hills[i].second;
-    }
-    if ((uint32_t)(E - from) > (uint32_t)(e - b)) { b = from; e = E; }
-    return host_shrink(ctx, r, b, e);
+    const Piece keep = longest_piece(ctx->h_begin[r], ctx->h_end[r], n,
+                                     [&](uint32_t i, uint32_t& f, uint32_t& s) { f = hills[i].first; s = hills[i].second; },
+                                     [&](uint32_t i) { return hills[i].aux <= 3; });
+    return host_shrink(ctx, r, keep.begin, keep.end);
 }
 
 // Pile::break_over_chimeric_pits (pile.cpp:366-402); a pit is real when some
 // coverage inside it satisfies data*1.84 <= median — monotone in data, so the
 // minimum recorded by the pile kernel decides.  Unreal pits are kept (in place).
 bool break_pits(rala_hip_ctx* ctx, uint32_t r, Interval* pits, uint32_t& n_pits, uint16_t dataset_median) {
-    const uint32_t B = ctx->h_begin[r], E = ctx->h_end[r];
-    uint32_t b = 0, e = 0, from = B;
     uint32_t w = 0;
-    for (uint32_t k = 0; k < n_pits; ++k) {
-        const Interval it = pits[k];
-        if (B > it.first || E < it.second) continue;
-        if ((double)it.aux * 1.84 <= (double)dataset_median) {
-            if ((uint32_t)(it.first - from) > (uint32_t)(e - b)) { b = from; e = it.first; }
-            from = it.second;
-        } else {
-            pits[w++] = it;
-        }
-    }
-    if ((uint32_t)(E - from) > (uint32_t)(e - b)) { b = from; e = E; }
+    const Piece keep = longest_piece(ctx->h_begin[r], ctx->h_end[r], n_pits,
+                                     [&](uint32_t k, uint32_t& f, uint32_t& s) { f = pits[k].first; s = pits[k].second; },
+                                     [&](uint32_t k) {
+                                         if ((double)pits[k].aux * 1.84 <= (double)dataset_median) return true;
+                                         pits[w++] = pits[k];
+                                         return false;
+                                     });
     n_pits = w;
-    return host_shrink(ctx, r, b, e);
+    return host_shrink(ctx, r, keep.begin, keep.end);
 }
 
 // per read: the median of the pile medians of its connected component over the current

@@ -42,17 +42,11 @@ __global__ __launch_bounds__(kBlock) void break_hills_kernel(TailReads R, uint32
     const uint32_t r = blockIdx.x * kBlock + threadIdx.x;
     if (r >= n_reads || !R.alive[r] || R.n_hills[r] == 0) return;
     const Interval* hills = R.pool + R.iv_slot[r] + R.n_pits0[r];
-    const uint32_t n = R.n_hills[r];
-    const uint32_t B = R.begin[r], E = R.end[r];
-    uint32_t b = 0, e = 0, from = B;
-    for (uint32_t i = 0; i < n; ++i) {
-        if (B > hills[i].first || E < hills[i].second) continue;
-        if (hills[i].aux > 3) continue;
-        if ((uint32_t)(hills[i].first - from) > (uint32_t)(e - b)) { b = from; e = hills[i].first; }
-        from = hills[i].second;
-    }
-    if ((uint32_t)(E - from) > (uint32_t)(e - b)) { b = from; e = E; }
-    if (!dev_shrink(R, r, b, e)) R.alive[r] = 0;
+    // a hill that more than three overlaps span is no chimera (pile.cpp:480)
+    const Piece keep = longest_piece(R.begin[r], R.end[r], R.n_hills[r],
+                                     [&](uint32_t i, uint32_t& f, uint32_t& s) { f = hills[i].first; s = hills[i].second; },
+                                     [&](uint32_t i) { return hills[i].aux <= 3; });
+    if (!dev_shrink(R, r, keep.begin, keep.end)) R.alive[r] = 0;
     R.n_hills[r] = 0;
 }
 
@@ -70,23 +64,19 @@ __global__ __launch_bounds__(kBlock) void break_pits_kernel(TailReads R, const u
     const uint32_t r = alive_reads[q];
     if (!R.alive[r] || R.n_pits[r] == 0) return;
     Interval* pits = R.pool + R.iv_slot[r];
-    const uint32_t n = R.n_pits[r];
     const double med = (double)comp_median[q];
-    const uint32_t B = R.begin[r], E = R.end[r];
-    uint32_t b = 0, e = 0, from = B, w = 0;
-    for (uint32_t k = 0; k < n; ++k) {
-        const Interval it = pits[k];
-        if (B > it.first || E < it.second) continue;
-        if ((double)it.aux * 1.84 <= med) {
-            if ((uint32_t)(it.first - from) > (uint32_t)(e - b)) { b = from; e = it.first; }
-            from = it.second;
-        } else {
-            pits[w++] = it;
-        }
-    }
-    if ((uint32_t)(E - from) > (uint32_t)(e - b)) { b = from; e = E; }
+    uint32_t w = 0;
+    // a pit is real when some coverage inside it is at most median / 1.84 (pile.cpp:370: its minimum decides); the others
+    // stay on the list, in place
+    const Piece keep = longest_piece(R.begin[r], R.end[r], R.n_pits[r],
+                                     [&](uint32_t k, uint32_t& f, uint32_t& s) { f = pits[k].first; s = pits[k].second; },
+                                     [&](uint32_t k) {
+                                         if ((double)pits[k].aux * 1.84 <= med) return true;
+                                         pits[w++] = pits[k];
+                                         return false;
+                                     });
     R.n_pits[r] = w;
-    if (!dev_shrink(R, r, b, e)) R.alive[r] = 0;
+    if (!dev_shrink(R, r, keep.begin, keep.end)) R.alive[r] = 0;
 }
 
 __device__ __forceinline__ Coords item_coords(const TailList& L, uint32_t k) {

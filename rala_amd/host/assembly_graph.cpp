@@ -195,48 +195,65 @@ uint32_t AssemblyGraph::remove_long_edges() {
     return num_long_edges;
 }
 
-// graph.cpp:1368-1438
-uint32_t AssemblyGraph::remove_tips() {
-    uint32_t num_tip_edges = 0;
-    const size_t n0 = nodes_.size();
-    std::vector<bool> is_visited(n0, false);
-    for (size_t i = 0; i < n0; ++i) {
-        if (!nodes_[i].alive || is_visited[i] || !nodes_[i].is_tip()) continue;
-        bool is_circular = false;
-        uint32_t num_reads = 0;
-        uint32_t end_node = (uint32_t)i;
-        while (!nodes_[end_node].is_junction()) {
-            num_reads += (uint32_t)nodes_[end_node].sequence_ids.size();
-            is_visited[end_node] = true;
-            is_visited[end_node ^ 1u] = true;
-            if (nodes_[end_node].outdegree() == 0 ||
-                nodes_[edges_[nodes_[end_node].suffix_edges[0]].end_node].is_junction()) {
-                break;
-            }
-            end_node = edges_[nodes_[end_node].suffix_edges[0]].end_node;
-            if (end_node == i) { is_circular = true; break; }
-        }
-        if (is_circular || nodes_[end_node].outdegree() == 0 || num_reads > 5) continue;
+// A tip (graph.cpp:1368-1438) is a dead-end chain of at most five reads that hangs off a junction.  Stated here as three
+// questions about one chain: where does the chain that starts at a tip node stop (Chain), is it short and open enough
+// to go, and which edges go with it - the chain's own edges only when every way out of its last node leads into a node that
+// has another way in.
+namespace {
+struct Chain {
+    uint32_t last;          // where the walk stopped
+    uint32_t reads;         // reads of the nodes walked over
+    bool closed;            // came back to its first node
+};
+}  // namespace
 
-        uint32_t num_removed_edges = 0;
-        for (uint32_t e : nodes_[end_node].suffix_edges) {
-            if (nodes_[edges_[e].end_node].indegree() > 1) {
+uint32_t AssemblyGraph::remove_tips() {
+    const size_t n0 = nodes_.size();
+    std::vector<bool> walked(n0, false);
+
+    // follow the only out-edge while neither the node nor its successor branches
+    auto follow = [&](uint32_t first) {
+        Chain c{first, 0, false};
+        for (uint32_t v = first; !nodes_[v].is_junction();) {
+            c.last = v;
+            c.reads += (uint32_t)nodes_[v].sequence_ids.size();
+            walked[v] = walked[v ^ 1u] = true;
+            if (nodes_[v].outdegree() == 0) break;
+            const uint32_t next = edges_[nodes_[v].suffix_edges[0]].end_node;
+            if (nodes_[next].is_junction()) break;
+            if (next == first) { c.closed = true; break; }
+            v = next;
+        }
+        return c;
+    };
+    // the ways out of the chain's end that somebody else also takes
+    auto shared_exits = [&](uint32_t v) {
+        std::vector<uint32_t> out;
+        for (uint32_t e : nodes_[v].suffix_edges) {
+            if (nodes_[edges_[e].end_node].indegree() > 1) out.push_back(e);
+        }
+        return out;
+    };
+
+    uint32_t removed = 0;
+    for (size_t i = 0; i < n0; ++i) {
+        if (!nodes_[i].alive || walked[i] || !nodes_[i].is_tip()) continue;
+        const Chain c = follow((uint32_t)i);
+        if (c.closed || c.reads > 5 || nodes_[c.last].outdegree() == 0) continue;
+        const std::vector<uint32_t> exits = shared_exits(c.last);
+        for (uint32_t e : exits) mark_edge(e);
+        if (exits.size() == nodes_[c.last].suffix_edges.size()) {
+            // nothing holds the chain any more: its own edges go as well
+            for (uint32_t v = (uint32_t)i; v != c.last;) {
+                const uint32_t e = nodes_[v].suffix_edges[0];
                 mark_edge(e);
-                ++num_removed_edges;
+                v = edges_[e].end_node;
             }
         }
-        if (num_removed_edges == nodes_[end_node].suffix_edges.size()) {
-            uint32_t curr = (uint32_t)i;
-            while (curr != end_node) {
-                const uint32_t e = nodes_[curr].suffix_edges[0];
-                mark_edge(e);
-                curr = edges_[e].end_node;
-            }
-        }
-        num_tip_edges += num_removed_edges;
+        removed += (uint32_t)exits.size();
         remove_marked_objects(true);
     }
-    return num_tip_edges;
+    return removed;
 }
 
 uint32_t AssemblyGraph::find_edge(uint32_t src, uint32_t dst) const {
@@ -281,101 +298,105 @@ void AssemblyGraph::find_removable_edges(std::vector<uint32_t>& dst, const std::
     else if (suff < pref) take(suff, pref);
 }
 
-// graph.cpp:1440-1613
+// Bubbles (graph.cpp:1440-1613): from every node with two ways out, a breadth-first search over out-edges (at most
+// 5 Mb away) until some node is reached a second time - the sink; the two ways there are the bubble's sides, and the
+// side with fewer reads loses the edges find_removable_edges lets go.  The search state is one frame that is wiped
+// after every source (only what was touched).
+namespace {
+struct BubbleSearch {
+    std::vector<uint32_t> reach;            // length of the way found to a node
+    std::vector<int64_t> via;               // the node it was first reached from, -1 = not yet
+    std::vector<uint32_t> touched;
+    std::deque<uint32_t> frontier;
+    explicit BubbleSearch(size_t n) : reach(n, 0), via(n, -1) {}
+    void wipe() {
+        for (uint32_t v : touched) { reach[v] = 0; via[v] = -1; }
+        touched.clear();
+        frontier.clear();
+    }
+    // the way from `source` to `node` along the first-reached links
+    std::vector<uint32_t> way(uint32_t source, uint32_t node) const {
+        std::vector<uint32_t> p;
+        for (uint32_t v = node; v != source; v = (uint32_t)via[v]) p.push_back(v);
+        p.push_back(source);
+        std::reverse(p.begin(), p.end());
+        return p;
+    }
+};
+constexpr uint32_t kBubbleReach = 5000000;
+}  // namespace
+
 uint32_t AssemblyGraph::remove_bubbles() {
     const size_t n0 = nodes_.size();
-    std::vector<uint32_t> distance(n0, 0);
-    std::vector<int64_t> predecessor(n0, -1);
-    std::vector<uint32_t> visited;
-    std::deque<uint32_t> queue;
+    BubbleSearch bfs(n0);
 
-    auto extract_path = [&](std::vector<uint32_t>& dst, uint32_t source, uint32_t sink) {
-        uint32_t curr = sink;
-        while (curr != source) {
-            dst.push_back(curr);
-            curr = (uint32_t)predecessor[curr];
-        }
-        dst.push_back(source);
-        std::reverse(dst.begin(), dst.end());
-    };
-    auto inner_junction = [&](const std::vector<uint32_t>& p) {
-        for (size_t i = 1; i + 1 < p.size(); ++i) if (nodes_[p[i]].is_junction()) return true;
-        return false;
-    };
-    auto is_valid_bubble = [&](const std::vector<uint32_t>& path, const std::vector<uint32_t>& other) {
-        if (path.empty() || other.empty()) return false;
-        std::unordered_set<uint32_t> node_set(path.begin(), path.end());
-        node_set.insert(other.begin(), other.end());
-        if (path.size() + other.size() - 2 != node_set.size()) return false;
-        for (uint32_t v : path) if (node_set.count(v ^ 1u)) return false;
-        const uint32_t a = path_length(path), b = path_length(other);
-        if (std::min(a, b) < std::max(a, b) * 0.8) {
-            if (inner_junction(other) || inner_junction(path)) return false;
-        }
-        return true;
-    };
-    auto num_reads = [&](const std::vector<uint32_t>& p) {
-        uint64_t n = 0;
-        for (uint32_t v : p) n += nodes_[v].sequence_ids.size();
-        return n;
-    };
-
-    uint32_t num_bubbles_popped = 0;
-    for (size_t s = 0; s < n0; ++s) {
-        if (!nodes_[s].alive || nodes_[s].outdegree() < 2) continue;
-        const uint32_t source = (uint32_t)s;
-        bool found_sink = false;
-        uint32_t sink = 0, sink_other_predecessor = 0;
-        queue.push_back(source);
-        visited.push_back(source);
-        while (!queue.empty() && !found_sink) {
-            const uint32_t v = queue.front();
-            queue.pop_front();
+    // sink and the second node it was reached from, if the search from `source` closes a bubble
+    auto search = [&](uint32_t source, uint32_t& sink, uint32_t& second) {
+        bfs.frontier.push_back(source);
+        bfs.touched.push_back(source);
+        while (!bfs.frontier.empty()) {
+            const uint32_t v = bfs.frontier.front();
+            bfs.frontier.pop_front();
             for (uint32_t e : nodes_[v].suffix_edges) {
                 const uint32_t w = edges_[e].end_node;
-                if (w == source) continue;                                   // cycle
-                if (distance[v] + edges_[e].length > 5000000) continue;       // out of reach
-                distance[w] = distance[v] + edges_[e].length;
-                visited.push_back(w);
-                queue.push_back(w);
-                if (predecessor[w] != -1) {
-                    sink = w;
-                    sink_other_predecessor = v;
-                    found_sink = true;
-                    break;
-                }
-                predecessor[w] = v;
+                if (w == source || bfs.reach[v] + edges_[e].length > kBubbleReach) continue;     // a cycle; out of reach
+                bfs.reach[w] = bfs.reach[v] + edges_[e].length;
+                bfs.touched.push_back(w);
+                bfs.frontier.push_back(w);
+                if (bfs.via[w] != -1) { sink = w; second = v; return true; }
+                bfs.via[w] = v;
             }
         }
-        if (found_sink) {
-            std::vector<uint32_t> path, other(1, sink);
-            extract_path(path, source, sink);
-            extract_path(other, source, sink_other_predecessor);
-            if (is_valid_bubble(path, other)) {
-                const uint64_t path_reads = num_reads(path), other_reads = num_reads(other);
+        return false;
+    };
+    auto branches_inside = [&](const std::vector<uint32_t>& side) {
+        for (size_t i = 1; i + 1 < side.size(); ++i) if (nodes_[side[i]].is_junction()) return true;
+        return false;
+    };
+    auto reads_on = [&](const std::vector<uint32_t>& side) {
+        uint64_t n = 0;
+        for (uint32_t v : side) n += nodes_[v].sequence_ids.size();
+        return n;
+    };
+    auto alike = [](uint32_t a, uint32_t b) { return std::min(a, b) >= std::max(a, b) * 0.8; };
+    // two sides that share only their ends, no node together with its reverse complement; sides of unlike length
+    // must not branch inside
+    auto sides_make_a_bubble = [&](const std::vector<uint32_t>& one, const std::vector<uint32_t>& two) {
+        if (one.empty() || two.empty()) return false;
+        std::unordered_set<uint32_t> seen(one.begin(), one.end());
+        seen.insert(two.begin(), two.end());
+        if (one.size() + two.size() - 2 != seen.size()) return false;
+        for (uint32_t v : one) if (seen.count(v ^ 1u)) return false;
+        if (!alike(path_length(one), path_length(two)) && (branches_inside(two) || branches_inside(one))) return false;
+        return true;
+    };
+
+    uint32_t popped = 0;
+    for (size_t s0 = 0; s0 < n0; ++s0) {
+        if (!nodes_[s0].alive || nodes_[s0].outdegree() < 2) continue;
+        const uint32_t source = (uint32_t)s0;
+        uint32_t sink = 0, second = 0;
+        if (search(source, sink, second)) {
+            const std::vector<uint32_t> one = bfs.way(source, sink);
+            std::vector<uint32_t> two = bfs.way(source, second);
+            two.push_back(sink);
+            if (sides_make_a_bubble(one, two)) {
+                const bool one_is_heavier = reads_on(one) > reads_on(two);
                 std::vector<uint32_t> doomed;
-                find_removable_edges(doomed, path_reads > other_reads ? other : path);
-                if (doomed.empty()) {
-                    const uint32_t a = path_length(path), b = path_length(other);
-                    if (std::min(a, b) >= std::max(a, b) * 0.8) {
-                        find_removable_edges(doomed, path_reads > other_reads ? path : other);
-                    }
+                find_removable_edges(doomed, one_is_heavier ? two : one);
+                if (doomed.empty() && alike(path_length(one), path_length(two))) {
+                    find_removable_edges(doomed, one_is_heavier ? one : two);
                 }
                 for (uint32_t e : doomed) mark_edge(e);
                 if (!doomed.empty()) {
                     remove_marked_objects(true);
-                    ++num_bubbles_popped;
+                    ++popped;
                 }
             }
         }
-        queue.clear();
-        for (uint32_t v : visited) {
-            distance[v] = 0;
-            predecessor[v] = -1;
-        }
-        visited.clear();
+        bfs.wipe();
     }
-    return num_bubbles_popped;
+    return popped;
 }
 
 // graph.cpp:133-170 (Node constructor for unitigs)

@@ -151,26 +151,22 @@ void Pile::find_chimeric_hills() {
     }
 }
 
-// reference src/pile.cpp:366-402; the kernel recorded the minimum coverage inside each pit
+// reference src/pile.cpp:366-402; the kernel recorded the minimum coverage inside each pit.  Which piece of the read is
+// left: longest_piece (rala_amd/csrc/geom.h), shared with the device's version of this function
 bool Pile::break_over_chimeric_pits(uint16_t dataset_median) {
-    uint32_t begin = 0, end = 0, last_begin = begin_;
-    std::vector<std::pair<uint32_t, uint32_t>> keep;
-    std::vector<uint16_t> keep_min;
-    for (size_t k = 0; k < chimeric_pits_.size(); ++k) {
-        const auto& it = chimeric_pits_[k];
-        if (begin_ > it.first || end_ < it.second) continue;
-        if ((double)chimeric_pit_min_[k] * 1.84 <= (double)dataset_median) {
-            if (it.first - last_begin > end - begin) { begin = last_begin; end = it.first; }
-            last_begin = it.second;
-        } else {
-            keep.push_back(it);
-            keep_min.push_back(chimeric_pit_min_[k]);
-        }
-    }
-    if (end_ - last_begin > end - begin) { begin = last_begin; end = end_; }
-    chimeric_pits_.swap(keep);
-    chimeric_pit_min_.swap(keep_min);
-    return shrink(begin, end);
+    std::vector<std::pair<uint32_t, uint32_t>> unreal;
+    std::vector<uint16_t> unreal_min;
+    const rala_hip::Piece keep = rala_hip::longest_piece(begin_, end_, (uint32_t)chimeric_pits_.size(),
+        [&](uint32_t k, uint32_t& first, uint32_t& second) { first = chimeric_pits_[k].first; second = chimeric_pits_[k].second; },
+        [&](uint32_t k) {
+            if ((double)chimeric_pit_min_[k] * 1.84 <= (double)dataset_median) return true;
+            unreal.push_back(chimeric_pits_[k]);
+            unreal_min.push_back(chimeric_pit_min_[k]);
+            return false;
+        });
+    chimeric_pits_.swap(unreal);
+    chimeric_pit_min_.swap(unreal_min);
+    return shrink(keep.begin, keep.end);
 }
 
 // reference src/pile.cpp:457-469 (begin_ is added to untrimmed coordinates there too)
@@ -183,19 +179,14 @@ void Pile::check_chimeric_hills(const std::unique_ptr<Overlap>& overlap) {
     }
 }
 
-// reference src/pile.cpp:471-498
+// reference src/pile.cpp:471-498: a hill that more than three overlaps span is no chimera
 bool Pile::break_over_chimeric_hills() {
-    uint32_t begin = 0, end = 0, last_begin = begin_;
-    for (size_t i = 0; i < chimeric_hills_.size(); ++i) {
-        if (begin_ > chimeric_hills_[i].first || end_ < chimeric_hills_[i].second) continue;
-        if (chimeric_hill_coverage_[i] > 3) continue;
-        if (chimeric_hills_[i].first - last_begin > end - begin) { begin = last_begin; end = chimeric_hills_[i].first; }
-        last_begin = chimeric_hills_[i].second;
-    }
-    if (end_ - last_begin > end - begin) { begin = last_begin; end = end_; }
+    const rala_hip::Piece keep = rala_hip::longest_piece(begin_, end_, (uint32_t)chimeric_hills_.size(),
+        [&](uint32_t i, uint32_t& first, uint32_t& second) { first = chimeric_hills_[i].first; second = chimeric_hills_[i].second; },
+        [&](uint32_t i) { return chimeric_hill_coverage_[i] <= 3; });
     std::vector<std::pair<uint32_t, uint32_t>>().swap(chimeric_hills_);
     std::vector<uint32_t>().swap(chimeric_hill_coverage_);
-    return shrink(begin, end);
+    return shrink(keep.begin, keep.end);
 }
 
 // reference src/pile.cpp:500-566.  Inside Graph::construct the sensitive pass computes the hills of all
