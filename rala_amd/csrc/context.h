@@ -183,7 +183,7 @@ struct rala_hip_ctx {
     // fixed slots (d_ev_fixed, counts in d_cursor) or the CSR (d_ev_off, d_ev)
     bool ev_ready = false, ev_fixed = false;
     // bounds of the sensitive overlaps by read (CSR), the list of reads of a sensitive-pass launch
-    rala_hip::DevBuf<uint32_t> d_sens_off, d_sens_cur, d_sens_ev, d_sens_list;
+    rala_hip::DevBuf<uint32_t> d_sens_off, d_sens_cur, d_sens_ev, d_sens_list, d_sens_split;
     rala_hip::DevBuf<double> d_layout[4];
     rala_hip::DevBuf<uint32_t> d_layout_adj[2];
     // pinned staging of small device -> host reads (pipeline.hip: d2h_small / stream_sync)

@@ -291,6 +291,23 @@ void launch_finalize_states(const TailList& L, const uint8_t* alive, hipStream_t
 void launch_list_targets(const uint32_t* off, uint32_t n, uint32_t* list, uint32_t* count, hipStream_t s);
 void launch_list_members(const uint32_t* alive_reads, const uint8_t* touched, uint32_t n_alive, uint32_t world, uint32_t rank,
                          uint32_t* list, uint32_t* count, hipStream_t s);
+// The reads of a sensitive-pass list by the kernel that takes them (known beforehand from length and event counts, as in
+// the first pass): class 0 up to 16384 bases and kRunEventCap - 2 events (primary + sensitive), 1 up to 32768 bases and as
+// many events, 2 up to 16384 bases and kRunEventCapMid - 2 events, 3 the rest (position space).  out[c] receives the
+// class' reads, counts[c] (zeroed by the caller) how many.  A hand-over through the kernels' overflow lists costs one add
+// to ONE counter per read: at C5 300 000 of them, 3 ms per kernel.
+struct SensSplitArgs {
+    const uint32_t* read_len;
+    const uint32_t* ev_off;        // primary events: CSR, or
+    const uint32_t* ev_cnt;        // fixed slots (non-null)
+    uint32_t ev_stride;
+    const uint32_t* sens_off;
+    const uint32_t* begin;
+    const uint32_t* end;
+    uint32_t* out[4];
+    uint32_t* counts;
+};
+void launch_sens_split(const uint32_t* list, uint32_t n, const SensSplitArgs& args, hipStream_t s);
 void launch_scatter_component_medians(const uint32_t* alive_reads, const uint8_t* touched, const uint16_t* cmed, uint32_t n_alive,
                                       uint16_t* out, hipStream_t s);
 void launch_break_hills(const TailReads& R, uint32_t n_reads, hipStream_t s);

@@ -672,7 +672,10 @@ int run_repeats_kernel(rala_hip_ctx* ctx, RepeatArgs a, const std::vector<uint32
 // One mode of the sensitive pass over `reads`: the run-space kernel (cap 512, then 1024) reads the
 // primary bound events where initialize left them plus the sensitive bounds of pa.sens_*; what it
 // hands on goes to the position-space kernel.
-// list_dev: the reads (count of them) in ctx->d_sens_list already, or null: `reads` is uploaded there
+// list_dev: the reads (count of them) in ctx->d_sens_list already, or null: `reads` is uploaded there.
+// Every read starts in the kernel that fits it (launch_sens_split: by length and by primary + sensitive event count), as in
+// the first pass; what a kernel still hands on (its region lists) goes down the chain: cap 512 / 16384 bases and cap 512 /
+// 32768 bases -> cap 1024 / 16384 bases -> position space.
 int run_sens_pass(rala_hip_ctx* ctx, PileArgs pa, const RepeatArgs& ra, const std::vector<uint32_t>& reads, int mode,
                   const uint32_t* list_dev = nullptr, uint32_t list_count = 0) {
     if (list_dev == nullptr && reads.empty()) return RALA_HIP_OK;
@@ -689,39 +692,48 @@ int run_sens_pass(rala_hip_ctx* ctx, PileArgs pa, const RepeatArgs& ra, const st
     const uint32_t count = list_dev ? list_count : (uint32_t)reads.size();
     HIPCHECK(ctx->d_overflow.ensure(ctx->n_reads + 1));
     HIPCHECK(ctx->d_overflow_mid.ensure(ctx->n_reads + 1));
-    HIPCHECK(ctx->d_chain_cnt.ensure(4));
+    HIPCHECK(ctx->d_chain_cnt.ensure(16));
     if (list_dev == nullptr) {
         HIPCHECK(ctx->d_sens_list.ensure(count + 1));
         HIPCHECK(hipMemcpyAsync(ctx->d_sens_list.p, reads.data(), (size_t)count * 4, hipMemcpyHostToDevice, s));
         list_dev = ctx->d_sens_list.p;
     }
-    HIPCHECK(hipMemsetAsync(ctx->d_chain_cnt.p, 0, 16, s));
-    pa.order = list_dev;
-    pa.n_items = count;
+    // [0] handed on by the cap-512 kernels, [1] by the cap-1024 kernel, [8 .. 11] the classes' sizes
+    HIPCHECK(hipMemsetAsync(ctx->d_chain_cnt.p, 0, 16 * 4, s));
+    HIPCHECK(ctx->d_sens_split.ensure(4 * ((size_t)count + 1)));
+    SensSplitArgs sp;
+    sp.read_len = pa.read_len; sp.ev_off = pa.ev_off; sp.ev_cnt = pa.ev_cnt; sp.ev_stride = pa.ev_stride;
+    sp.sens_off = pa.sens_off; sp.begin = pa.begin; sp.end = pa.end;
+    for (int c = 0; c < 4; ++c) sp.out[c] = ctx->d_sens_split.p + (size_t)c * ((size_t)count + 1);
+    sp.counts = ctx->d_chain_cnt.p + 8;
+    launch_sens_split(list_dev, count, sp, s);
+    uint32_t cls[4] = {0, 0, 0, 0};
+    HIPCHECK(d2h_small(ctx, cls, ctx->d_chain_cnt.p + 8, 16, s));
+    HIPCHECK(stream_sync(ctx, s));
+    HIPCHECK(hipGetLastError());
+    uint32_t* const handed_512 = ctx->d_overflow.p;            // -> cap 1024
+    uint32_t* const handed_1024 = ctx->d_overflow_mid.p;       // -> position space
     pa.n_items_dev = nullptr;
-    // cap 512 / 16384 bases -> (list) cap 512 / 32768 bases, if there are such reads -> (list) cap 1024 /
-    // 16384 bases -> (list) position space
-    const bool longer = ctx->n_class[0] != ctx->n_reads;
-    uint32_t* first_list = longer ? ctx->d_overflow_long.p : ctx->d_overflow.p;
-    if (longer) HIPCHECK(ctx->d_overflow_long.ensure(ctx->n_reads + 1));
-    first_list = longer ? ctx->d_overflow_long.p : ctx->d_overflow.p;
-    launch_pile_sens(pa, count, 0, mode, first_list, ctx->d_chain_cnt.p + (longer ? 2 : 0), s);
-    if (longer) {
-        pa.order = first_list;
-        pa.n_items_dev = ctx->d_chain_cnt.p + 2;
-        launch_pile_sens(pa, std::min<uint32_t>(count, 16384), 3, mode, ctx->d_overflow.p, ctx->d_chain_cnt.p, s);
-    }
-    pa.order = ctx->d_overflow.p;
-    pa.n_items_dev = ctx->d_chain_cnt.p;
-    launch_pile_sens(pa, std::min<uint32_t>(count, 8192), 1, mode, ctx->d_overflow_mid.p, ctx->d_chain_cnt.p + 1, s);
+    pa.order = sp.out[0]; pa.n_items = cls[0];
+    launch_pile_sens(pa, cls[0], 0, mode, handed_512, ctx->d_chain_cnt.p, s);
+    pa.order = sp.out[1]; pa.n_items = cls[1];
+    launch_pile_sens(pa, std::min<uint32_t>(cls[1], 16384), 3, mode, handed_512, ctx->d_chain_cnt.p, s);
+    pa.order = sp.out[2]; pa.n_items = cls[2];
+    launch_pile_sens(pa, std::min<uint32_t>(cls[2], 8192), 1, mode, handed_1024, ctx->d_chain_cnt.p + 1, s);
+    pa.order = handed_512; pa.n_items = count; pa.n_items_dev = ctx->d_chain_cnt.p;
+    launch_pile_sens(pa, std::min<uint32_t>(count, 2048), 1, mode, handed_1024, ctx->d_chain_cnt.p + 1, s);
     uint32_t cnt[2] = {0, 0};
     HIPCHECK(d2h_small(ctx, cnt, ctx->d_chain_cnt.p, 8, s));
     HIPCHECK(stream_sync(ctx, s));
     HIPCHECK(hipGetLastError());
     trc(mode == 1 ? "sens pass 1: run space" : "sens pass 2: run space", count);
-    if (cnt[1] == 0) return RALA_HIP_OK;
-    std::vector<uint32_t> rest(cnt[1]);
-    HIPCHECK(hipMemcpy(rest.data(), ctx->d_overflow_mid.p, (size_t)cnt[1] * 4, hipMemcpyDeviceToHost));
+    if (getenv("RALA_HIP_TRACE")) {
+        fprintf(stderr, "[trace] sens pass %d: classes %u / %u / %u / %u, handed on %u + %u\n", mode, cls[0], cls[1], cls[2], cls[3], cnt[0], cnt[1]);
+    }
+    if (cnt[1] + cls[3] == 0) return RALA_HIP_OK;
+    std::vector<uint32_t> rest((size_t)cnt[1] + cls[3]);
+    if (cnt[1]) HIPCHECK(hipMemcpy(rest.data(), handed_1024, (size_t)cnt[1] * 4, hipMemcpyDeviceToHost));
+    if (cls[3]) HIPCHECK(hipMemcpy(rest.data() + cnt[1], sp.out[3], (size_t)cls[3] * 4, hipMemcpyDeviceToHost));
     std::sort(rest.begin(), rest.end());
     const int rc = run_repeats_kernel(ctx, ra, rest, mode);
     trc("sens pass: position space", rest.size());
@@ -901,7 +913,7 @@ int preprocess_repeats(rala_hip_ctx* cs, rala_hip_ctx* cl, Comm* comm, const ral
     launch_scatter_tuples(tuples, n_tuples, (uint32_t)nl, cl->d_sens_cur.p, cl->d_sens_ev.p, sl);
     // the targets: reads that received bounds - listed where the offsets are, the host learns how many
     HIPCHECK(cl->d_sens_list.ensure(nl + 1));
-    HIPCHECK(cl->d_chain_cnt.ensure(8));
+    HIPCHECK(cl->d_chain_cnt.ensure(16));
     HIPCHECK(hipMemsetAsync(cl->d_chain_cnt.p + 4, 0, 4, sl));
     launch_list_targets(cl->d_sens_off.p, (uint32_t)nl, cl->d_sens_list.p, cl->d_chain_cnt.p + 4, sl);
     uint32_t n_targets = 0;
@@ -977,7 +989,7 @@ int preprocess_repeats(rala_hip_ctx* cs, rala_hip_ctx* cl, Comm* comm, const ral
         // the members (reads with an overlap; of a sharded run this rank's, as the owner's local ids) are listed where the
         // data is; the host learns how many
         HIPCHECK(cl->d_sens_list.ensure(std::max<uint64_t>(nl, 1) + 1));
-        HIPCHECK(cs->d_chain_cnt.ensure(8));
+        HIPCHECK(cs->d_chain_cnt.ensure(16));
         HIPCHECK(hipMemsetAsync(cs->d_chain_cnt.p + 5, 0, 4, s));
         launch_list_members(cs->d_alive_reads.p, cs->d_touched.p, n_alive, P, me, cl->d_sens_list.p, cs->d_chain_cnt.p + 5, s);
         HIPCHECK(d2h_small(cs, &n_members, cs->d_chain_cnt.p + 5, 4, s));

@@ -201,7 +201,27 @@ __global__ __launch_bounds__(kBlock) void list_members_kernel(const uint32_t* __
     const uint32_t r = q < n_alive ? alive_reads[q] : 0u;
     append_flagged(q < n_alive && touched[q] && r % world == rank, r / world, list, count);
 }
+__global__ __launch_bounds__(kBlock) void sens_split_kernel(const uint32_t* __restrict__ list, uint32_t n, SensSplitArgs A) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    uint32_t cls = 4, r = 0;
+    if (i < n) {
+        r = list[i];
+        const uint32_t len = A.read_len[r];
+        const uint32_t ev = (A.ev_cnt ? umin(A.ev_cnt[r], A.ev_stride) : A.ev_off[r + 1] - A.ev_off[r]) + A.sens_off[r + 1] - A.sens_off[r];
+        const bool region = A.end[r] > A.begin[r];
+        cls = !region ? 3u
+            : len <= 16384u && ev <= kRunEventCap - 2u ? 0u
+            : len <= 32768u && ev <= kRunEventCap - 2u ? 1u
+            : len <= 16384u && ev <= kRunEventCapMid - 2u ? 2u : 3u;
+    }
+#pragma unroll
+    for (uint32_t c = 0; c < 4; ++c) append_flagged(cls == c, r, A.out[c], A.counts + c);
+}
 }  // namespace
+
+void launch_sens_split(const uint32_t* list, uint32_t n, const SensSplitArgs& args, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(sens_split_kernel, grid_for(n), dim3(kBlock), 0, s, list, n, args);
+}
 
 void launch_list_targets(const uint32_t* off, uint32_t n, uint32_t* list, uint32_t* count, hipStream_t s) {
     if (n) hipLaunchKernelGGL(list_targets_kernel, grid_for(n), dim3(kBlock), 0, s, off, n, list, count);
