@@ -118,6 +118,7 @@ struct rala_hip_ctx {
     // again with the lists in d_big_space at growing sizes (those that still do not fit: the other list)
     rala_hip::DevBuf<uint32_t> d_big_list[2], d_big_space;
     int64_t debug_big_caps = 0;         // tests: first sizes of the lists in global memory (0: the defaults)
+    bool debug_force_big = false;       // tests: every read of the position-space kernels runs with its lists in global memory
     rala_hip::DevBuf<uint16_t> d_slab;
     std::vector<rala_hip::LaunchClass> classes;
 

@@ -70,6 +70,7 @@ struct PileArgs {
     // ... and run again with the lists in global memory: ListSpace::words(..) words per workgroup
     uint32_t* big_space = nullptr;
     uint32_t big_cap_reg = 0, big_cap_list = 0, big_cap_raw = 0;
+    uint32_t force_big = 0;        // tests: every read of the position-space kernel takes that way
     // first pass: reads with more than kRunEventCap events are listed beforehand
     // (launch_pile_dense_list) and start in the cap-1024 kernel; the cap-512 kernels pass them over
     uint32_t skip_dense = 0;
@@ -131,6 +132,7 @@ struct RepeatArgs {
     uint32_t* big_count = nullptr;
     uint32_t* big_space = nullptr;
     uint32_t big_cap_reg = 0, big_cap_list = 0, big_cap_raw = 0;
+    uint32_t force_big = 0;
 };
 uint32_t repeats_lds_bytes(uint32_t lw);
 uint64_t repeats_big_words(uint32_t cap_reg, uint32_t cap_list, uint32_t cap_raw);

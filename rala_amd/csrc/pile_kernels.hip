@@ -353,6 +353,7 @@ __global__ __launch_bounds__(kBlock) void pile_build_annotate(PileArgs A) {
             const uint32_t nd = sc[SC_RCOUNT + 2 * which], nu = sc[SC_RCOUNT + 2 * which + 1];
             uint32_t err = 0;
             if (nd > S.cap_reg || nu > S.cap_reg || nd + nu > S.cap_list) err = kErrRegionCapacity;
+            if (!kBig && A.force_big && A.big_list) err = kErrRegionCapacity;      // tests: as if the lists had overflowed
             if (!err && l == 0) {
                 const uint32_t* df = S.rfirst + (size_t)(2 * which) * S.cap_reg;
                 const uint32_t* dl = S.rlast + (size_t)(2 * which) * S.cap_reg;

@@ -286,7 +286,7 @@ __global__ __launch_bounds__(kBlock) void pile_repeats_kernel(RepeatArgs A) {
                 RegionList R;
                 R.key = key; R.last = last; R.n = 0; R.cap = S.cap_list; R.overflow = false;
                 const uint32_t nd = sc[SC_RCOUNT], nu = sc[SC_RCOUNT + 1];
-                bool ovf = nd > S.cap_reg || nu > S.cap_reg;
+                bool ovf = nd > S.cap_reg || nu > S.cap_reg || (!kBig && A.force_big && A.big_list);       // (tests)
                 if (!ovf) {
                     const uint32_t* df = S.rfirst;
                     const uint32_t* dl = S.rlast;

@@ -618,6 +618,7 @@ int run_repeats_kernel(rala_hip_ctx* ctx, RepeatArgs a, const std::vector<uint32
     a.big_list = ctx->d_big_list[0].p;
     a.big_count = count_dev;
     a.big_space = nullptr; a.big_cap_reg = a.big_cap_list = a.big_cap_raw = 0;
+    a.force_big = ctx->debug_force_big ? 1u : 0u;
     int rc = run_repeats_classes(ctx, a, reads, 2);
     if (rc != RALA_HIP_OK) return rc;
     uint32_t count = 0;
@@ -1938,6 +1939,7 @@ int rala_hip_set_option(rala_hip_ctx* ctx, const char* key, int64_t value) {
     if (!ctx || !key) return RALA_HIP_EINVAL;
     if (!strcmp(key, "interval_pool_per_read_x1000")) { ctx->pool_per_read_x1000 = value; return RALA_HIP_OK; }
     if (!strcmp(key, "debug_big_caps")) { ctx->debug_big_caps = value; return RALA_HIP_OK; }
+    if (!strcmp(key, "debug_force_big")) { ctx->debug_force_big = value != 0; return RALA_HIP_OK; }
     if (!strcmp(key, "max_lds_read_len")) { ctx->max_lds_read_len = value; return RALA_HIP_OK; }
     if (!strcmp(key, "debug_pile_stop_after")) { ctx->debug_pile_stop_after = value; return RALA_HIP_OK; }
     if (!strcmp(key, "use_run_kernel")) { ctx->use_run_kernel = value != 0; return RALA_HIP_OK; }
@@ -2194,6 +2196,7 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
     // (what outgrows the position-space kernel's LDS lists: noted, and dealt with after this call's one look from the host)
     HIPCHECK(ctx->d_big_list[0].ensure(n_reads + 1));
     a.big_list = ctx->d_big_list[0].p; a.big_count = ctx->d_small.p + 8;
+    a.force_big = ctx->debug_force_big ? 1u : 0u;
     if (ctx->use_run_kernel) {
         // Chain without host synchronisation.  Every read starts in the kernel that fits it, known
         // beforehand: by length class (set_reads sorted them) and by event count (listed from the

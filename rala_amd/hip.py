@@ -162,17 +162,58 @@ class DeviceOverlaps:
 
     @classmethod
     def from_host(cls, ov, device):
-        """upload numpy columns to `device` (torch tensors hold the memory)"""
-        import torch
-
-        keep, ptrs = [], {}
+        """upload numpy columns to `device` (the HIP runtime directly: hipMalloc / hipMemcpy, freed with the object)"""
+        rt = _hip_runtime()
+        keep, ptrs = _DeviceBlocks(rt), {}
+        _rt_check(rt.hipSetDevice(int(device)), "hipSetDevice")
         for name, _ in OverlapsC._fields_:
-            arr = getattr(ov, name)
-            t = torch.from_numpy(arr.view(np.int32) if name != "strand" else arr).to("cuda:%d" % device)
-            keep.append(t)
-            ptrs[name] = t.data_ptr()
-        torch.cuda.synchronize(device)
+            arr = np.ascontiguousarray(getattr(ov, name))
+            p = ctypes.c_void_p()
+            _rt_check(rt.hipMalloc(ctypes.byref(p), max(1, arr.nbytes)), "hipMalloc")
+            keep.blocks.append(p)
+            if arr.nbytes:
+                _rt_check(rt.hipMemcpy(p, arr.ctypes.data, arr.nbytes, 1), "hipMemcpy")        # hipMemcpyHostToDevice
+            ptrs[name] = p.value
         return cls(ptrs, len(ov), keep)
+
+
+_rt = None
+
+
+def _hip_runtime():
+    global _rt
+    if _rt is None:
+        lib()                           # (librala_hip.so has brought the runtime into the process)
+        for name in ("libamdhip64.so", "libamdhip64.so.7", "libamdhip64.so.6", "/opt/rocm/lib/libamdhip64.so"):
+            try:
+                _rt = ctypes.CDLL(name)
+                break
+            except OSError:
+                continue
+        if _rt is None:
+            raise RalaHipError(-2, "libamdhip64 not found")
+        _rt.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+        _rt.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+        _rt.hipFree.argtypes = [ctypes.c_void_p]
+        _rt.hipSetDevice.argtypes = [ctypes.c_int]
+    return _rt
+
+
+def _rt_check(rc, what):
+    if rc != 0:
+        raise RalaHipError(-2, "%s failed (%d)" % (what, rc))
+
+
+class _DeviceBlocks:
+    def __init__(self, rt):
+        self.rt, self.blocks = rt, []
+
+    def __del__(self):
+        try:
+            for p in self.blocks:
+                self.rt.hipFree(p)
+        except Exception:
+            pass
 
 
 def _soa(ov):

@@ -48,6 +48,18 @@ for case in range(n_cases):
         ctx.set_option("use_side_stream", int(rng.random() < 0.8))
         if rng.random() < 0.4:      # the containment fixed points' long lists' kernel / a mix of both
             ctx.set_option("debug_fp_lds_limit", int(rng.choice([0, 7, 100])))
+        # round 4: the position-space kernels' lists in global memory, from a few entries up (every read that reaches those
+        # kernels); an interval pool that has to grow; the sensitive set handed over as device memory
+        if rng.random() < 0.3:
+            ctx.set_option("debug_force_big", 1)
+            ctx.set_option("debug_big_caps", (int(rng.choice([4, 16, 1024])) << 32) | int(rng.choice([4, 16, 4096])))
+            variant.append("big")
+        if rng.random() < 0.2:
+            ctx.set_option("interval_pool_per_read_x1000", int(rng.choice([1, 50])))
+            variant.append("pool")
+        sens_dev = sens_case and rng.random() < 0.4
+        if sens_dev:
+            ctx.set_option("sensitive_in_device_memory", 1)
         ctx.set_reads(ds.read_len)
         ctx.set_overlaps(ds.overlaps)
         try:
@@ -74,7 +86,11 @@ for case in range(n_cases):
             want_rep, want_ov, want_p = o.all_intervals(2), o.overlap_list(0), o.piles()
             o.build_graph()
             want_tr, want_e = o.remove_transitive_edges(), o.edges()
-            ctx.construct(sens)
+            if sens_dev and len(sens):
+                variant.append("dev")
+                ctx.construct(hip.DeviceOverlaps.from_host(sens, 0))
+            else:
+                ctx.construct(sens)
             offs, pairs, flags = ctx.intervals(2)
             parity.assert_same("rep.offsets", offs, want_rep[0])
             parity.assert_same("rep.pairs", pairs, want_rep[1])
@@ -91,10 +107,9 @@ for case in range(n_cases):
             parity.check_construct(ctx, st)
             parity.check_tr(ctx, st)
         tm = ctx.timings()
-        print("case %d n=%d g=%d cov=%g plants=%d %s: ok (%d overlaps, %d kept, overflow %d, position %d)" % (
+        print("case %d n=%d g=%d cov=%g plants=%d %s: ok (%d overlaps, %d kept, overflow %d, position %d, lists in global memory %d, pool regrown %d)" % (
             seed, n, g, cov, plants, "+".join(variant) or "plain", len(ds.overlaps), len(st["ov"]["src"]),
-            tm["pile_overflow_reads"],
-            tm["pile_position_reads"]), flush=True)
+            tm["pile_overflow_reads"], tm["pile_position_reads"], tm["pile_unbounded_reads"], tm["pool_regrown"]), flush=True)
         ctx.close()
     except AssertionError as e:
         bad += 1
