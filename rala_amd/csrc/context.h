@@ -154,7 +154,8 @@ struct rala_hip_ctx {
     rala_hip::DevBuf<rala_hip::Interval> d_pool;
     rala_hip::DevBuf<uint32_t> d_small;      // [0] pool_count [1] error [2] changed [3] tr pairs
     uint32_t pool_cap = 0;
-    uint32_t rep_pool_cap = 0;          // repeat hills (sensitive pass); 0: as pool_cap
+    uint32_t pool_cap_first = 0;        // what set_reads derived from the option
+    uint32_t rep_pool_cap = 0;          // repeat hills (sensitive pass); starts at pool_cap_first
 
     // pass 2
     rala_hip::DevBuf<uint8_t> d_cls;

@@ -844,7 +844,7 @@ int preprocess_repeats(rala_hip_ctx* cs, rala_hip_ctx* cl, Comm* comm, const ral
     HIPCHECK(cs->d_dataset_median.ensure(n));
     HIPCHECK(cs->d_n_rep.ensure(n));
     HIPCHECK(cs->d_rep_slot.ensure(n));
-    cs->rep_pool_cap = std::max(cs->rep_pool_cap, cs->pool_cap);
+    cs->rep_pool_cap = std::max(cs->rep_pool_cap, cs->pool_cap_first);
     HIPCHECK(cs->d_rep_pool.ensure(cs->rep_pool_cap));
     HIPCHECK(hipMemsetAsync(cs->d_n_rep.p, 0, n * 4, s));
     HIPCHECK(hipMemsetAsync(cs->d_small.p + 6, 0, 8, s));           // [6] rep pool count [7] error
@@ -901,7 +901,7 @@ int preprocess_repeats(rala_hip_ctx* cs, rala_hip_ctx* cl, Comm* comm, const ral
     HIPCHECK(cl->d_dataset_median.ensure(nl));
     HIPCHECK(cl->d_n_rep.ensure(nl));
     HIPCHECK(cl->d_rep_slot.ensure(nl));
-    cl->rep_pool_cap = std::max(cl->rep_pool_cap, cl->pool_cap);
+    cl->rep_pool_cap = std::max(cl->rep_pool_cap, cl->pool_cap_first);
     HIPCHECK(cl->d_rep_pool.ensure(cl->rep_pool_cap));
     if (sharded) {
         HIPCHECK(hipMemsetAsync(cl->d_n_rep.p, 0, nl * 4, sl));
@@ -2022,7 +2022,10 @@ int rala_hip_set_reads(rala_hip_ctx* ctx, const uint32_t* read_len, uint64_t n_r
     ctx->h_begin.resize(n_reads); ctx->h_end.resize(n_reads); ctx->h_median.resize(n_reads);
     ctx->h_p10.resize(n_reads); ctx->h_alive.resize(n_reads); ctx->h_n_pits.resize(n_reads);
     ctx->h_n_hills.resize(n_reads); ctx->h_slot.resize(n_reads);
-    ctx->pool_cap = (uint32_t)std::max<int64_t>(1024, (int64_t)n_reads * ctx->pool_per_read_x1000 / 1000);
+    // (a hint: a pool that turns out too small grows to the counted need; 0 = start at 16 slots, for the tests of that)
+    ctx->pool_cap = (uint32_t)std::max<int64_t>(ctx->pool_per_read_x1000 == 0 ? 16 : 1024, (int64_t)n_reads * ctx->pool_per_read_x1000 / 1000);
+    ctx->pool_cap_first = ctx->pool_cap;        // (the repeat hills' pool starts there too, and grows on its own)
+    ctx->rep_pool_cap = 0;
     HIPCHECK(ctx->d_pool.ensure(ctx->pool_cap));
     ctx->initialized = ctx->constructed = ctx->ev_ready = false;
     return RALA_HIP_OK;
@@ -2741,7 +2744,7 @@ int rala_hip_find_repetitive_hills(rala_hip_ctx* ctx, uint64_t read, uint32_t be
     HIPCHECK(ctx->d_dataset_median.ensure(n));
     HIPCHECK(ctx->d_n_rep.ensure(n));
     HIPCHECK(ctx->d_rep_slot.ensure(n));
-    ctx->rep_pool_cap = std::max(ctx->rep_pool_cap, ctx->pool_cap);
+    ctx->rep_pool_cap = std::max(ctx->rep_pool_cap, ctx->pool_cap_first);
     HIPCHECK(ctx->d_rep_pool.ensure(ctx->rep_pool_cap));
     if (!ctx->have_repeats) {
         HIPCHECK(hipMemsetAsync(ctx->d_n_rep.p, 0, n * 4, s));

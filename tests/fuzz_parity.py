@@ -55,7 +55,7 @@ for case in range(n_cases):
             ctx.set_option("debug_big_caps", (int(rng.choice([4, 16, 1024])) << 32) | int(rng.choice([4, 16, 4096])))
             variant.append("big")
         if rng.random() < 0.2:
-            ctx.set_option("interval_pool_per_read_x1000", int(rng.choice([1, 50])))
+            ctx.set_option("interval_pool_per_read_x1000", int(rng.choice([0, 1, 50])))
             variant.append("pool")
         sens_dev = sens_case and rng.random() < 0.4
         if sens_dev:

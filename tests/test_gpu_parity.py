@@ -124,6 +124,13 @@ def test_sensitive_pass_vs_oracle(hip_ctx_factory, n, g, seed, gpu_tail, run_ker
     _check_sensitive(hip_ctx_factory, Dataset(n, g, seed), gpu_tail, run_kernel, expect_hills=g >= 100_000)
 
 
+@pytest.mark.parametrize("gpu_tail,run_kernel", [(1, 1), (0, 1), (1, 0)])
+def test_sensitive_pass_with_pools_that_grow(hip_ctx_factory, gpu_tail, run_kernel):
+    """both interval pools start at 16 slots (interval_pool_per_read_x1000 = 0): the first pass' pool and the repeat hills'
+    pool are grown to the counted need, the stage / the pass' second mode runs again"""
+    _check_sensitive(hip_ctx_factory, Dataset(6000, 1_600_000, 19), gpu_tail, run_kernel, expect_hills=True, small_pools=True)
+
+
 @pytest.mark.parametrize("gpu_tail", [1, 0])
 def test_sensitive_overlaps_in_device_memory(hip_ctx_factory, gpu_tail):
     """option sensitive_in_device_memory: the sensitive set handed to rala_hip_construct as device pointers (what
@@ -131,7 +138,7 @@ def test_sensitive_overlaps_in_device_memory(hip_ctx_factory, gpu_tail):
     _check_sensitive(hip_ctx_factory, Dataset(5000, 1_000_000, 7), gpu_tail, 1, expect_hills=True, in_device=True)
 
 
-def _check_sensitive(hip_ctx_factory, ds, gpu_tail, run_kernel, expect_hills, in_device=False):
+def _check_sensitive(hip_ctx_factory, ds, gpu_tail, run_kernel, expect_hills, in_device=False, small_pools=False):
     from oracle.oracle import Oracle
 
     n = ds.n_reads
@@ -154,6 +161,8 @@ def _check_sensitive(hip_ctx_factory, ds, gpu_tail, run_kernel, expect_hills, in
     ctx = hip_ctx_factory()
     ctx.set_option("use_gpu_tail", gpu_tail)
     ctx.set_option("use_run_kernel", run_kernel)
+    if small_pools:
+        ctx.set_option("interval_pool_per_read_x1000", 0)
     ctx.set_reads(ds.read_len)
     ctx.set_overlaps(ds.overlaps)
     ctx.initialize()
@@ -166,6 +175,8 @@ def _check_sensitive(hip_ctx_factory, ds, gpu_tail, run_kernel, expect_hills, in
         ctx.construct(dev)
     else:
         ctx.construct(sens)
+    if small_pools:
+        assert len(want_rep[1]) > 16 and ctx.timings()["pool_regrown"] >= 1, (len(want_rep[1]), ctx.timings())
     offs, pairs, flags = ctx.intervals(2)
     parity.assert_same("rep.offsets", offs, want_rep[0])
     parity.assert_same("rep.pairs", pairs, want_rep[1])
