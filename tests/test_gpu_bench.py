@@ -108,3 +108,24 @@ def test_sensitive_workload():
     b = json.loads(two.stdout.strip().splitlines()[-1])
     assert b["config"]["transitive_pairs"] == a["config"]["transitive_pairs"]
     assert b["sensitive_pass"]["n_sensitive"] == sp["n_sensitive"] and b["sensitive_pass"]["ms"] > 0
+
+
+def test_one_process_per_gpu_launch():
+    """the driver's launch for N > 1 (`python -m torch.distributed.run ... bench.py --gpus N`), here with N = 1 and the
+    sharded runner forced: every rank's device contexts first, then the RCCL join (rala_amd/multi.py: ShardedRunner), the
+    step through RCCL - with and without the sensitive pass (its share resident on the rank's device)"""
+    e = dict(os.environ, RALA_FORCE_SHARDED="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        e.pop(k, None)
+    lines = {}
+    for wl in ("c2", "c2s"):
+        res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+                              "127.0.0.1", "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", wl,
+                              "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-e2e"],
+                             stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=e, timeout=600)
+        assert res.returncode == 0, res.stderr[-3000:]
+        lines[wl] = json.loads([x for x in res.stdout.splitlines() if x.startswith("{")][-1])
+    a, b = lines["c2"], lines["c2s"]
+    assert a["transport"] == "rccl" and a["rccl_ranks"] == 1 and a["n_gpus"] == 1 and a["stage_ms"]["exchange_ms"] > 0
+    assert b["sensitive_pass"]["n_sensitive"] > 100_000 and b["sensitive_pass"]["ms"] > 0
+    assert b["config"]["transitive_pairs"] != a["config"]["transitive_pairs"]
