@@ -106,6 +106,30 @@ int rala_hip_set_reads(rala_hip_ctx* ctx, const uint32_t* read_len, uint64_t n_r
  * memory; RALA_HIP_MEM_DEVICE adopts device pointers, which must stay valid. */
 int rala_hip_set_overlaps(rala_hip_ctx* ctx, const rala_hip_overlaps* ovl, uint64_t n, int mem);
 
+/* The same from PAF TEXT, tokenised on the device (uncompressed files).  Replaces bioparser's PAF parser and the two
+ * hash look-ups of Overlap::transmute (src/graph.cpp:328-352, src/overlap.cpp:36-82): `threads` reader threads ship the
+ * file to the device in blocks (pinned staging, copies overlapped with the reads), two kernels count the lines and parse
+ * them - one thread per line: names cut at the first blank and looked up in the name table, numbers as their leading
+ * digits, column 11 as the overlap's length, the strand, Overlap::transmute's length check (check_lengths: the first
+ * record in file order whose length differs from its sequence's is returned in *length_error_read, -1 = none; the
+ * caller prints the reference's message).  The columns stay on the device and are the context's overlaps afterwards.
+ * *irregular != 0: the file is not a plain list of 12-column records (a line with fewer columns, a name of more than a
+ * kilobyte ...) - nothing was set, take the host reader (rala_amd/host/io.cpp), which knows what to do with such files.
+ * The name table: rala::io::NameTable as built on the host (rala_amd/csrc/name_table.h: 32-byte buckets {hash32, id + 1,
+ * length, arena offset, first 16 bytes}, n_buckets a power of two, the names' bytes in `arena`). */
+typedef struct rala_hip_ingest_timings {
+    float ship_ms;          /* file -> device memory (reads and copies overlapped) */
+    float tokenize_ms;      /* count + scan + parse on the device */
+    uint64_t bytes, lines;
+} rala_hip_ingest_timings;
+int rala_hip_set_name_table(rala_hip_ctx* ctx, const void* buckets, uint64_t n_buckets, const char* arena, uint64_t arena_bytes);
+int rala_hip_set_overlaps_from_paf(rala_hip_ctx* ctx, const char* path, int check_lengths, uint32_t threads,
+                                   int64_t* length_error_read, int* irregular);
+int rala_hip_get_ingest_timings(rala_hip_ctx* ctx, rala_hip_ingest_timings* out);
+/* the context's overlap columns, wherever they came from, into host buffers (*n entries each; cols / strand may be NULL to
+ * ask for the count alone): a_id, b_id, a_begin, a_end, b_begin, b_end, length */
+int rala_hip_get_overlap_columns(rala_hip_ctx* ctx, uint64_t* n, uint32_t* const cols[7], uint8_t* strand);
+
 /* ---- stages ---------------------------------------------------------------------- */
 /* Graph::initialize (src/graph.cpp:244-425): duplicate removal (:273-307), bound
  * emission (:311-326), Pile::add_layers for every read (:367-377), then per read

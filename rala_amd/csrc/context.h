@@ -122,6 +122,13 @@ struct rala_hip_ctx {
     rala_hip::DevBuf<uint16_t> d_slab;
     std::vector<rala_hip::LaunchClass> classes;
 
+    // the device tokeniser (ingest.hip): the host's name table as it is, the file's text, the columns it leaves
+    rala_hip::DevBuf<uint8_t> d_name_buckets, d_name_arena, d_paf_text, d_paf_strand;
+    uint64_t n_name_buckets = 0;
+    rala_hip::DevBuf<uint32_t> d_paf_col[7], d_paf_chunk[2];
+    rala_hip::DevBuf<unsigned long long> d_paf_bad;
+    rala_hip_ingest_timings ingest_tm = {};
+
     // overlaps
     uint64_t n_ovl = 0;
     rala_hip::OvlSoA ovl = {};

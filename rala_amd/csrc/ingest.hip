@@ -1,0 +1,238 @@
+// Host side of the device tokeniser (ingest_kernels.hip): the file's text to device memory - reader threads with pinned
+// staging blocks of their own, every block's copy queued behind its read, so that the disk / page cache and PCIe work at the
+// same time - then count, scan, parse, and the columns become the context's overlaps (rala_hip_set_overlaps, device memory).
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <atomic>
+#include <chrono>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "kernels.h"
+#include "name_table.h"
+#include "stages.h"
+
+using namespace rala_hip;
+
+namespace {
+
+constexpr size_t kBlockBytes = 32u << 20;       // one staging block
+constexpr uint32_t kMaxReaders = 8;
+
+// Pinned staging blocks are expensive to make (the pages are locked one by one) and cheap to keep: a pool of the
+// process, two blocks per reader.
+struct StagingPool {
+    std::mutex m;
+    std::vector<void*> free_blocks;
+    ~StagingPool() { for (void* p : free_blocks) (void)hipHostFree(p); }
+    void* take() {
+        {
+            std::lock_guard<std::mutex> hold(m);
+            if (!free_blocks.empty()) { void* p = free_blocks.back(); free_blocks.pop_back(); return p; }
+        }
+        void* p = nullptr;
+        return hipHostMalloc(&p, kBlockBytes, hipHostMallocDefault) == hipSuccess ? p : nullptr;
+    }
+    void give(void* p) {
+        std::lock_guard<std::mutex> hold(m);
+        free_blocks.push_back(p);
+    }
+};
+StagingPool& staging() {
+    static StagingPool pool;
+    return pool;
+}
+
+int ingest_fail(rala_hip_ctx* ctx, int code, const std::string& msg) {
+    ctx->err = msg;
+    return code;
+}
+
+#define INGEST_CHECK(call)                                                                                  \
+    do {                                                                                                    \
+        const hipError_t e_ = (call);                                                                       \
+        if (e_ != hipSuccess) {                                                                             \
+            return ingest_fail(ctx, e_ == hipErrorOutOfMemory ? RALA_HIP_ENOMEM : RALA_HIP_EDEVICE,         \
+                               std::string(#call) + ": " + hipGetErrorString(e_));                          \
+        }                                                                                                   \
+    } while (0)
+
+double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+}  // namespace
+
+extern "C" {
+
+int rala_hip_set_name_table(rala_hip_ctx* ctx, const void* buckets, uint64_t n_buckets, const char* arena, uint64_t arena_bytes) {
+    if (!ctx || !buckets || n_buckets == 0 || (n_buckets & (n_buckets - 1)) != 0 || (!arena && arena_bytes)) return RALA_HIP_EINVAL;
+    INGEST_CHECK(hipSetDevice(ctx->device));
+    INGEST_CHECK(ctx->d_name_buckets.ensure(n_buckets * sizeof(NameBucket)));
+    INGEST_CHECK(ctx->d_name_arena.ensure(arena_bytes + 16));
+    INGEST_CHECK(hipMemcpy(ctx->d_name_buckets.p, buckets, n_buckets * sizeof(NameBucket), hipMemcpyHostToDevice));
+    if (arena_bytes) INGEST_CHECK(hipMemcpy(ctx->d_name_arena.p, arena, arena_bytes, hipMemcpyHostToDevice));
+    ctx->n_name_buckets = n_buckets;
+    return RALA_HIP_OK;
+}
+
+int rala_hip_set_overlaps_from_paf(rala_hip_ctx* ctx, const char* path, int check_lengths, uint32_t threads,
+                                   int64_t* length_error_read, int* irregular) {
+    if (!ctx || !path || !length_error_read || !irregular) return RALA_HIP_EINVAL;
+    *length_error_read = -1;
+    *irregular = 0;
+    if (ctx->n_reads == 0) return ingest_fail(ctx, RALA_HIP_EINVAL, "no reads set");
+    if (ctx->n_name_buckets == 0) return ingest_fail(ctx, RALA_HIP_EINVAL, "no name table set (rala_hip_set_name_table)");
+    INGEST_CHECK(hipSetDevice(ctx->device));
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return ingest_fail(ctx, RALA_HIP_EINVAL, std::string("cannot open ") + path);
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) { close(fd); return ingest_fail(ctx, RALA_HIP_EINVAL, std::string("not a regular file: ") + path); }
+    const uint64_t n = (uint64_t)st.st_size;
+    const uint32_t chunk = paf_chunk_bytes();
+    const uint64_t n_chunks = (n + chunk - 1) / chunk;
+    if (n_chunks >= 0xFFFFFFF0ull) { close(fd); return ingest_fail(ctx, RALA_HIP_EINVAL, "file too large for 32-bit chunk ids"); }
+    const uint64_t cap = n_chunks * chunk + 4096 + 64;
+    hipStream_t s = ctx->stream;
+    const double t0 = now_ms();
+    {
+        const hipError_t e = ctx->d_paf_text.ensure(cap);
+        if (e != hipSuccess) { close(fd); return ingest_fail(ctx, RALA_HIP_ENOMEM, "device memory for the file's text"); }
+    }
+    // what lies behind the text reads as newlines
+    INGEST_CHECK(hipMemsetAsync(ctx->d_paf_text.p + n, '\n', cap - n, s));
+
+    // ---- ship: reader threads, two pinned blocks each, a block's copy queued behind its read ----
+    const uint64_t n_blocks = (n + kBlockBytes - 1) / kBlockBytes;
+    const uint32_t T = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint32_t>(threads ? threads : 1, kMaxReaders), n_blocks));
+    std::atomic<uint64_t> next(0);
+    std::atomic<int> failed(0);
+    std::vector<std::thread> readers;
+    uint8_t* const text = ctx->d_paf_text.p;
+    const int device = ctx->device;
+    for (uint32_t t = 0; t < T && n_blocks; ++t) {
+        readers.emplace_back([&, t]() {
+            (void)t;
+            if (hipSetDevice(device) != hipSuccess) { failed = 1; return; }
+            hipStream_t cs = nullptr;
+            hipEvent_t ev[2] = {nullptr, nullptr};
+            void* blk[2] = {staging().take(), staging().take()};
+            bool ok = blk[0] && blk[1] && hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) == hipSuccess &&
+                      hipEventCreateWithFlags(&ev[0], hipEventDisableTiming) == hipSuccess &&
+                      hipEventCreateWithFlags(&ev[1], hipEventDisableTiming) == hipSuccess;
+            bool busy[2] = {false, false};
+            for (int k = 0; ok && !failed; k ^= 1) {
+                const uint64_t b = next.fetch_add(1);
+                if (b >= n_blocks) break;
+                if (busy[k]) ok = hipEventSynchronize(ev[k]) == hipSuccess;       // the block's last copy has left it
+                const uint64_t off = b * kBlockBytes;
+                const size_t len = (size_t)std::min<uint64_t>(kBlockBytes, n - off);
+                size_t got = 0;
+                while (ok && got < len) {
+                    const ssize_t r = pread(fd, (char*)blk[k] + got, len - got, (off_t)(off + got));
+                    if (r <= 0) { ok = false; break; }
+                    got += (size_t)r;
+                }
+                ok = ok && hipMemcpyAsync(text + off, blk[k], len, hipMemcpyHostToDevice, cs) == hipSuccess &&
+                     hipEventRecord(ev[k], cs) == hipSuccess;
+                busy[k] = ok;
+            }
+            if (cs) ok = (hipStreamSynchronize(cs) == hipSuccess) && ok;
+            if (!ok) failed = 1;
+            for (int k = 0; k < 2; ++k) {
+                if (ev[k]) (void)hipEventDestroy(ev[k]);
+                if (blk[k]) staging().give(blk[k]);
+            }
+            if (cs) (void)hipStreamDestroy(cs);
+        });
+    }
+    for (auto& th : readers) th.join();
+    close(fd);
+    if (failed) return ingest_fail(ctx, RALA_HIP_EDEVICE, std::string("reading / copying ") + path + " failed");
+    INGEST_CHECK(hipStreamSynchronize(s));
+    const double t1 = now_ms();
+
+    // ---- count, scan, parse ----
+    uint32_t n_lines = 0;
+    if (n_chunks) {
+        INGEST_CHECK(ctx->d_paf_chunk[0].ensure(n_chunks + 2));
+        INGEST_CHECK(ctx->d_paf_chunk[1].ensure(n_chunks + 2));
+        INGEST_CHECK(ctx->d_scan_ws.ensure(scan_workspace_bytes(std::max<uint64_t>(std::max<uint64_t>(n_chunks, ctx->n_reads), ctx->n_ovl) + 2)));
+        launch_paf_count(text, n, ctx->d_paf_chunk[0].p, s);
+        launch_exclusive_scan(ctx->d_paf_chunk[0].p, ctx->d_paf_chunk[1].p, n_chunks, ctx->d_scan_ws.p, s);
+        INGEST_CHECK(hipMemcpyAsync(&n_lines, ctx->d_paf_chunk[1].p + n_chunks, 4, hipMemcpyDeviceToHost, s));
+        INGEST_CHECK(hipStreamSynchronize(s));
+    }
+    if ((uint64_t)n_lines >= 0xFFFFFFF0ull / 4) return ingest_fail(ctx, RALA_HIP_EINVAL, "too many overlaps for 32-bit bound offsets");
+    for (int k = 0; k < 7; ++k) INGEST_CHECK(ctx->d_paf_col[k].ensure((size_t)n_lines + 1));
+    INGEST_CHECK(ctx->d_paf_strand.ensure((size_t)n_lines + 1));
+    INGEST_CHECK(ctx->d_paf_bad.ensure(2));
+    unsigned long long bad = ~0ull;
+    uint32_t flags = 0;
+    if (n_lines) {
+        INGEST_CHECK(hipMemsetAsync(ctx->d_paf_bad.p, 0xFF, 8, s));
+        INGEST_CHECK(hipMemsetAsync(ctx->d_paf_bad.p + 1, 0, 8, s));
+        PafColumns out;
+        out.a_id = ctx->d_paf_col[0].p; out.b_id = ctx->d_paf_col[1].p; out.a_begin = ctx->d_paf_col[2].p; out.a_end = ctx->d_paf_col[3].p;
+        out.b_begin = ctx->d_paf_col[4].p; out.b_end = ctx->d_paf_col[5].p; out.length = ctx->d_paf_col[6].p; out.strand = ctx->d_paf_strand.p;
+        launch_paf_parse(text, n, ctx->d_paf_chunk[1].p, ctx->d_name_buckets.p, ctx->n_name_buckets, (const char*)ctx->d_name_arena.p,
+                         ctx->d_read_len.p, (uint32_t)ctx->n_reads, check_lengths != 0, out, (uint32_t*)(ctx->d_paf_bad.p + 1), ctx->d_paf_bad.p, s);
+        unsigned long long back[2] = {0, 0};
+        INGEST_CHECK(hipMemcpyAsync(back, ctx->d_paf_bad.p, 16, hipMemcpyDeviceToHost, s));
+        INGEST_CHECK(hipStreamSynchronize(s));
+        INGEST_CHECK(hipGetLastError());
+        bad = back[0];
+        flags = (uint32_t)back[1];
+    }
+    ctx->d_paf_text.release();                  // (the text is as large as the file: not kept)
+    const double t2 = now_ms();
+    ctx->ingest_tm.ship_ms = (float)(t1 - t0);
+    ctx->ingest_tm.tokenize_ms = (float)(t2 - t1);
+    ctx->ingest_tm.bytes = n;
+    ctx->ingest_tm.lines = n_lines;
+    if (getenv("RALA_HIP_TRACE")) {
+        fprintf(stderr, "[trace] device ingest: %.2f GB of text shipped in %.1f ms by %u readers, %u lines tokenised in %.2f ms (flags %u)\n",
+                n / 1e9, t1 - t0, T, n_lines, t2 - t1, flags);
+    }
+    if (flags) {
+        *irregular = (int)flags;
+        return RALA_HIP_OK;
+    }
+    if (bad != ~0ull) {
+        *length_error_read = (int64_t)(bad & 0xFFFFFFFFull);
+        return RALA_HIP_OK;
+    }
+    rala_hip_overlaps dev;
+    dev.a_id = ctx->d_paf_col[0].p; dev.b_id = ctx->d_paf_col[1].p; dev.a_begin = ctx->d_paf_col[2].p; dev.a_end = ctx->d_paf_col[3].p;
+    dev.b_begin = ctx->d_paf_col[4].p; dev.b_end = ctx->d_paf_col[5].p; dev.length = ctx->d_paf_col[6].p; dev.strand = ctx->d_paf_strand.p;
+    return rala_hip_set_overlaps(ctx, &dev, n_lines, RALA_HIP_MEM_DEVICE);
+}
+
+int rala_hip_get_overlap_columns(rala_hip_ctx* ctx, uint64_t* n, uint32_t* const cols[7], uint8_t* strand) {
+    if (!ctx || !n) return RALA_HIP_EINVAL;
+    if (!ctx->inputs_set || ctx->tuple_mode) return ingest_fail(ctx, RALA_HIP_EINVAL, "no overlaps set");
+    *n = ctx->n_ovl;
+    if (!cols && !strand) return RALA_HIP_OK;
+    INGEST_CHECK(hipSetDevice(ctx->device));
+    const uint32_t* src[7] = {ctx->ovl.a_id, ctx->ovl.b_id, ctx->ovl.a_begin, ctx->ovl.a_end, ctx->ovl.b_begin, ctx->ovl.b_end, ctx->ovl.length};
+    for (int k = 0; cols && k < 7; ++k) {
+        if (cols[k] && ctx->n_ovl) INGEST_CHECK(hipMemcpy(cols[k], src[k], ctx->n_ovl * 4, hipMemcpyDeviceToHost));
+    }
+    if (strand && ctx->n_ovl) INGEST_CHECK(hipMemcpy(strand, ctx->ovl.strand, ctx->n_ovl, hipMemcpyDeviceToHost));
+    return RALA_HIP_OK;
+}
+
+int rala_hip_get_ingest_timings(rala_hip_ctx* ctx, rala_hip_ingest_timings* out) {
+    if (!ctx || !out) return RALA_HIP_EINVAL;
+    *out = ctx->ingest_tm;
+    return RALA_HIP_OK;
+}
+
+}  // extern "C"

@@ -396,6 +396,21 @@ hipError_t launch_bucket_partitioned_records(const uint64_t* records, uint64_t n
                                              uint32_t* part_cursor, uint32_t* group, uint32_t* tiles, uint64_t* rec1, uint64_t* rec2,
                                              uint32_t* ev_off, uint32_t* ev, uint32_t workgroups, FillList& fills, hipStream_t s);
 
+// ---- PAF text -> columns (ingest_kernels.hip) ----------------------------------------------
+struct PafColumns {
+    uint32_t *a_id, *b_id, *a_begin, *a_end, *b_begin, *b_end, *length;
+    uint8_t* strand;
+};
+uint32_t paf_chunk_bytes();
+// text: n bytes, readable (and newlines) up to the next multiple of paf_chunk_bytes() + 4 KB; chunk_lines: one count per chunk
+void launch_paf_count(const uint8_t* text, uint64_t n, uint32_t* chunk_lines, hipStream_t s);
+// chunk_row: the exclusive scan of the counts; flags (zeroed): 1 a line with fewer than 12 columns, 2 more lines in a chunk than
+// records can make, 4 a line whose first eleven columns reach beyond the halo; first_bad (all ones): row << 32 | read of the
+// first record whose length differs from its sequence's
+void launch_paf_parse(const uint8_t* text, uint64_t n, const uint32_t* chunk_row, const void* buckets, uint64_t n_buckets,
+                      const char* arena, const uint32_t* read_len, uint32_t n_reads, bool check_lengths, const PafColumns& out,
+                      uint32_t* flags, unsigned long long* first_bad, hipStream_t s);
+
 // ---- scans (scan_kernels.hip) --------------------------------------------------
 // exclusive prefix sum of n uint32 values; out may alias in; out[n] receives the total
 size_t scan_workspace_bytes(uint64_t n);

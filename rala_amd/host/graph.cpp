@@ -260,6 +260,34 @@ void Graph::initialize() {
     timer("[rala::Graph::initialize] loaded sequences");
     timer();
     name_table_.build(names_);
+    // One GPU, an uncompressed PAF file: the text goes to the device and is tokenised there (rala_hip_set_overlaps_from_paf;
+    // RALA_DEVICE_INGEST=0 keeps the host reader).  A file that tokeniser calls irregular falls through to the host reader,
+    // which knows what to do with lines that are no 12-column records.
+    if (ranks_.empty() && io::has_suffix(overlaps_path_, ".paf") && !(getenv("RALA_DEVICE_INGEST") && atoi(getenv("RALA_DEVICE_INGEST")) == 0)) {
+        check(ctx_, rala_hip_set_reads(ctx_, read_len_.data(), read_len_.size()), "initialize");
+        check(ctx_, rala_hip_set_name_table(ctx_, name_table_.buckets(), name_table_.n_buckets(), name_table_.arena().data(),
+                                            name_table_.arena().size()), "initialize");
+        int64_t bad = -1;
+        int irregular = 0;
+        const int rc = rala_hip_set_overlaps_from_paf(ctx_, overlaps_path_.c_str(), 1, std::max(1u, num_threads_), &bad, &irregular);
+        if (rc == RALA_HIP_EINVAL && !irregular) {
+            // (cannot open: the reference's message)
+            fprintf(stderr, "[rala::Graph::initialize] error: unable to open file %s!\n", overlaps_path_.c_str());
+            exit(1);
+        }
+        check(ctx_, rc, "initialize");
+        if (bad >= 0) {
+            fprintf(stderr, "[rala::Overlap::transmute] error: "
+                "unequal lengths in sequence and overlap file for sequence with id %lu!\n", (uint64_t)bad);
+            exit(1);
+        }
+        if (!irregular) {
+            timer("[rala::Graph::initialize] loaded overlaps");
+            timer();
+            initialize_piles();
+            return;
+        }
+    }
     read_overlaps(overlaps_path_, name_to_id_, name_table_, read_len_, true, num_threads_, overlaps_);
     if (!ranks_.empty()) {
         // every rank gets all read lengths and its slice of the overlaps (cut between runs of
@@ -287,7 +315,12 @@ void Graph::initialize() {
                              overlaps_.length.data(), overlaps_.strand.data()};
     check(ctx_, rala_hip_set_overlaps(ctx_, &soa, overlaps_.size(), RALA_HIP_MEM_HOST), "initialize");
     timer("[rala::Graph::initialize] loaded overlaps");
-    timer();
+    initialize_piles();
+}
+
+// the second half of Graph::initialize (graph.cpp:384-425) once the overlaps are on the device
+void Graph::initialize_piles() {
+    StageTimer timer;
     const int rc = rala_hip_initialize(ctx_);
     timer("[rala::Graph::initialize] prefiltered sequences");
     if (rc == RALA_HIP_EFILTERED) {

@@ -68,6 +68,7 @@ private:
     const Graph& operator=(const Graph&) = delete;
 
     void initialize();
+    void initialize_piles();
     void postprocess();
 
     void open_devices();

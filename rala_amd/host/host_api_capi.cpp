@@ -16,8 +16,10 @@
 #include <unordered_map>
 #include <vector>
 
+#include "io.hpp"
 #include "overlap.hpp"
 #include "pile.hpp"
+#include "rala_hip.h"
 
 namespace {
 
@@ -118,5 +120,59 @@ int hp_overlap_from_mhap(uint64_t a_id, uint64_t b_id, uint32_t a_rc, uint32_t a
     out[0] = o->a_id(); out[1] = o->b_id(); out[2] = o->length(); out[3] = o->orientation();
     return 0;
 }
+
+// ---- the device tokeniser (rala_hip_set_overlaps_from_paf) for tests/test_gpu_ingest.py: the columns it leaves, to be
+// compared with the host readers' (libassembly_graph.so: io_paf_parse).  names: n_reads names separated by '\n'.
+struct PafOnDevice {
+    int rc = 0, irregular = 0;
+    int64_t bad = -1;
+    uint64_t n = 0;
+    std::vector<uint32_t> col[7];
+    std::vector<uint8_t> strand;
+    rala_hip_ingest_timings tm = {};
+};
+
+void* hp_paf_device(const char* path, const char* names, const uint32_t* read_len, uint64_t n_reads, int check_lengths, uint32_t threads) {
+    std::vector<std::string> nm;
+    const char* p = names;
+    for (uint64_t i = 0; i < n_reads; ++i) {
+        const char* e = strchr(p, '\n');
+        nm.emplace_back(p, e ? (size_t)(e - p) : strlen(p));
+        p = e ? e + 1 : p + strlen(p);
+    }
+    rala::io::NameTable table;
+    table.build(nm);
+    auto* out = new PafOnDevice();
+    rala_hip_ctx* ctx = nullptr;
+    out->rc = rala_hip_create(0, &ctx);
+    if (out->rc != RALA_HIP_OK) return out;
+    out->rc = rala_hip_set_reads(ctx, read_len, n_reads);
+    if (out->rc == RALA_HIP_OK) out->rc = rala_hip_set_name_table(ctx, table.buckets(), table.n_buckets(), table.arena().data(), table.arena().size());
+    if (out->rc == RALA_HIP_OK) out->rc = rala_hip_set_overlaps_from_paf(ctx, path, check_lengths, threads, &out->bad, &out->irregular);
+    if (out->rc == RALA_HIP_OK) rala_hip_get_ingest_timings(ctx, &out->tm);
+    if (out->rc == RALA_HIP_OK && !out->irregular && out->bad < 0) {
+        out->rc = rala_hip_get_overlap_columns(ctx, &out->n, nullptr, nullptr);
+        uint32_t* cols[7];
+        for (int k = 0; k < 7; ++k) { out->col[k].resize(out->n); cols[k] = out->col[k].data(); }
+        out->strand.resize(out->n);
+        if (out->rc == RALA_HIP_OK) out->rc = rala_hip_get_overlap_columns(ctx, &out->n, cols, out->strand.data());
+    }
+    rala_hip_destroy(ctx);
+    return out;
+}
+// info[0 .. 5] = return code, irregular flags, first read with a length mismatch (-1 none), records, ship us, tokenise us
+void hp_paf_device_info(void* h, int64_t* info) {
+    const auto* o = (const PafOnDevice*)h;
+    info[0] = o->rc; info[1] = o->irregular; info[2] = o->bad; info[3] = (int64_t)o->n;
+    info[4] = (int64_t)(o->tm.ship_ms * 1000.0f); info[5] = (int64_t)(o->tm.tokenize_ms * 1000.0f);
+}
+void hp_paf_device_copy(void* h, uint32_t* a_id, uint32_t* b_id, uint32_t* a_begin, uint32_t* a_end, uint32_t* b_begin, uint32_t* b_end,
+                        uint32_t* length, uint8_t* strand) {
+    const auto* o = (const PafOnDevice*)h;
+    uint32_t* dst[7] = {a_id, b_id, a_begin, a_end, b_begin, b_end, length};
+    for (int k = 0; k < 7; ++k) memcpy(dst[k], o->col[k].data(), o->n * 4);
+    memcpy(strand, o->strand.data(), o->n);
+}
+void hp_paf_device_free(void* h) { delete (PafOnDevice*)h; }
 
 }  // extern "C"

@@ -191,23 +191,12 @@ namespace io {
 namespace {
 
 inline uint64_t hash_bytes(const char* p, size_t n) {
-    // 8 bytes at a time (names are short: the byte-wise FNV chain cost more than the table probe)
-    uint64_t h = 0x9E3779B97F4A7C15ull ^ (n * 0xFF51AFD7ED558CCDull);
-    while (n >= 8) {
-        uint64_t w;
-        memcpy(&w, p, 8);
-        h = (h ^ w) * 0xC2B2AE3D27D4EB4Full;
-        h ^= h >> 29;
-        p += 8; n -= 8;
-    }
-    if (n) {
+    // (rala_amd/csrc/name_table.h: the device tokeniser computes the same)
+    return rala_hip::name_hash_with((uint64_t)n, [p](uint64_t k, uint64_t m) {
         uint64_t w = 0;
-        memcpy(&w, p, n);
-        h = (h ^ w) * 0xC2B2AE3D27D4EB4Full;
-        h ^= h >> 29;
-    }
-    h *= 0x165667B19E3779F9ull;
-    return h ^ (h >> 32);
+        memcpy(&w, p + k, (size_t)m);
+        return w;
+    });
 }
 
 inline const char* parse_u32(const char* p, const char* e, uint32_t& v) {

@@ -10,6 +10,8 @@
 #include <utility>
 #include <vector>
 
+#include "../csrc/name_table.h"
+
 namespace rala {
 namespace io {
 
@@ -51,14 +53,12 @@ public:
     // id of the name [p, p + n) whose hash is h, or ~0ull
     uint64_t find(const char* p, size_t n, uint64_t h) const;
     uint64_t find(const char* p, size_t n) const { return find(p, n, hash(p, n)); }
+    // the table as it is, for the device tokeniser (rala_hip_set_name_table)
+    const rala_hip::NameBucket* buckets() const { return bucket_; }
+    size_t n_buckets() const { return n_bucket_; }
+    const std::string& arena() const { return arena_; }
 private:
-    struct alignas(32) Bucket {
-        uint32_t hash32;        // high half of the hash
-        uint32_t id1;           // name index + 1, 0 = empty
-        uint32_t len;
-        uint32_t off;           // start of the name in arena_
-        char head[16];          // first min(len, 16) bytes, zero padded
-    };
+    typedef rala_hip::NameBucket Bucket;
     // (2 MiB-aligned block marked for transparent huge pages: a probe of a 64 MB table would
     // otherwise miss the TLB as well as the caches)
     Bucket* bucket_ = nullptr;
