@@ -24,7 +24,7 @@ using namespace rala_hip;
 namespace {
 
 constexpr size_t kBlockBytes = 32u << 20;       // one staging block
-constexpr uint32_t kMaxReaders = 8;
+constexpr uint32_t kMaxReaders = 8;        // (measured at C3: 4 readers 107 ms, 8: 70 - 73 ms, 12 - 16: 85 - 130 ms on the 16 CPUs a box allows)
 
 // Pinned staging blocks are expensive to make (the pages are locked one by one) and cheap to keep: a pool of the
 // process, two blocks per reader.
@@ -153,13 +153,31 @@ int rala_hip_set_overlaps_from_paf(rala_hip_ctx* ctx, const char* path, int chec
             if (cs) (void)hipStreamDestroy(cs);
         });
     }
+    // While the readers work: the device memory the tokeniser will want.  hipMalloc of a few hundred megabytes takes a
+    // millisecond and more, eight columns of them 4 - 9 ms - behind the copies that is free.  The number of records is not
+    // known yet: a record has at least 23 bytes, files in the wild 60 - 150 per line; room for one per 32 bytes is made now
+    // (twice what a synthetic file needs) and the exact count decides later whether that was enough.
+    {
+        const size_t guess = (size_t)(n / 32) + 1024;
+        bool ok = true;
+        for (int k = 0; k < 7 && ok; ++k) ok = ctx->d_paf_col[k].ensure(guess) == hipSuccess;
+        ok = ok && ctx->d_paf_strand.ensure(guess) == hipSuccess && ctx->d_paf_bad.ensure(2) == hipSuccess;
+        if (n_chunks) {
+            ok = ok && ctx->d_paf_chunk[0].ensure(n_chunks + 2) == hipSuccess && ctx->d_paf_chunk[1].ensure(n_chunks + 2) == hipSuccess &&
+                 ctx->d_scan_ws.ensure(scan_workspace_bytes(std::max<uint64_t>(std::max<uint64_t>(n_chunks, ctx->n_reads), ctx->n_ovl) + 2)) == hipSuccess;
+        }
+        if (!ok) failed = 2;
+    }
     for (auto& th : readers) th.join();
     close(fd);
+    if (failed == 2) return ingest_fail(ctx, RALA_HIP_ENOMEM, "device memory for the overlap columns");
     if (failed) return ingest_fail(ctx, RALA_HIP_EDEVICE, std::string("reading / copying ") + path + " failed");
     INGEST_CHECK(hipStreamSynchronize(s));
     const double t1 = now_ms();
 
     // ---- count, scan, parse ----
+    const bool trace = getenv("RALA_HIP_TRACE") != nullptr;
+    double tc = t1, tp0 = t1, tp1 = t1;
     uint32_t n_lines = 0;
     if (n_chunks) {
         INGEST_CHECK(ctx->d_paf_chunk[0].ensure(n_chunks + 2));
@@ -170,6 +188,7 @@ int rala_hip_set_overlaps_from_paf(rala_hip_ctx* ctx, const char* path, int chec
         INGEST_CHECK(hipMemcpyAsync(&n_lines, ctx->d_paf_chunk[1].p + n_chunks, 4, hipMemcpyDeviceToHost, s));
         INGEST_CHECK(hipStreamSynchronize(s));
     }
+    tc = now_ms();
     if ((uint64_t)n_lines >= 0xFFFFFFF0ull / 4) return ingest_fail(ctx, RALA_HIP_EINVAL, "too many overlaps for 32-bit bound offsets");
     for (int k = 0; k < 7; ++k) INGEST_CHECK(ctx->d_paf_col[k].ensure((size_t)n_lines + 1));
     INGEST_CHECK(ctx->d_paf_strand.ensure((size_t)n_lines + 1));
@@ -177,6 +196,7 @@ int rala_hip_set_overlaps_from_paf(rala_hip_ctx* ctx, const char* path, int chec
     unsigned long long bad = ~0ull;
     uint32_t flags = 0;
     if (n_lines) {
+        tp0 = now_ms();
         INGEST_CHECK(hipMemsetAsync(ctx->d_paf_bad.p, 0xFF, 8, s));
         INGEST_CHECK(hipMemsetAsync(ctx->d_paf_bad.p + 1, 0, 8, s));
         PafColumns out;
@@ -190,6 +210,7 @@ int rala_hip_set_overlaps_from_paf(rala_hip_ctx* ctx, const char* path, int chec
         INGEST_CHECK(hipGetLastError());
         bad = back[0];
         flags = (uint32_t)back[1];
+        tp1 = now_ms();
     }
     ctx->d_paf_text.release();                  // (the text is as large as the file: not kept)
     const double t2 = now_ms();
@@ -197,9 +218,10 @@ int rala_hip_set_overlaps_from_paf(rala_hip_ctx* ctx, const char* path, int chec
     ctx->ingest_tm.tokenize_ms = (float)(t2 - t1);
     ctx->ingest_tm.bytes = n;
     ctx->ingest_tm.lines = n_lines;
-    if (getenv("RALA_HIP_TRACE")) {
-        fprintf(stderr, "[trace] device ingest: %.2f GB of text shipped in %.1f ms by %u readers, %u lines tokenised in %.2f ms (flags %u)\n",
-                n / 1e9, t1 - t0, T, n_lines, t2 - t1, flags);
+    if (trace) {
+        fprintf(stderr, "[trace] device ingest: %.2f GB of text shipped in %.1f ms by %u readers, %u lines tokenised in %.2f ms (count + scan %.2f, "
+                "columns' memory %.2f, parse %.2f, the text's memory back %.2f; flags %u)\n",
+                n / 1e9, t1 - t0, T, n_lines, t2 - t1, tc - t1, tp0 - tc, tp1 - tp0, t2 - tp1, flags);
     }
     if (flags) {
         *irregular = (int)flags;
