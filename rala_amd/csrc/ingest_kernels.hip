@@ -84,25 +84,33 @@ struct NameTableDev {
     uint64_t mask;
 };
 
-// rala::io::NameTable::find on the device: the name's bytes come through `at` (LDS or global memory)
-template <class At>
-__device__ __forceinline__ uint32_t find_name(const NameTableDev& T, At at, uint32_t n) {
-    const uint64_t h = name_hash_with((uint64_t)n, [&](uint64_t k, uint64_t m) {
-        uint64_t w = 0;
-        for (uint64_t b = 0; b < m; ++b) w |= (uint64_t)at((uint32_t)(k + b)) << (8 * b);
-        return w;
-    });
+// eight bytes of the window from any byte offset (three aligned words, funnelled): the names are read by the word
+__device__ __forceinline__ uint64_t window8(const uint8_t* win, uint32_t pos) {
+    const uint32_t* w = (const uint32_t*)win + (pos >> 2);
+    const uint32_t a = w[0], b = w[1], c = w[2];
+    const uint32_t sh = (pos & 3u) * 8u;
+    const uint32_t lo = sh ? (a >> sh) | (b << (32u - sh)) : a;
+    const uint32_t hi = sh ? (b >> sh) | (c << (32u - sh)) : b;
+    return (uint64_t)lo | ((uint64_t)hi << 32);
+}
+__device__ __forceinline__ uint64_t low_bytes(uint64_t w, uint32_t m) { return m >= 8 ? w : w & ((1ull << (8u * m)) - 1ull); }
+
+// rala::io::NameTable::find on the device for the name of n bytes at win + pos
+__device__ __forceinline__ uint32_t find_name(const NameTableDev& T, const uint8_t* win, uint32_t pos, uint32_t n) {
+    const uint64_t h = name_hash_with((uint64_t)n, [&](uint64_t k, uint64_t m) { return low_bytes(window8(win, pos + (uint32_t)k), (uint32_t)m); });
     const uint32_t h32 = (uint32_t)(h >> 32);
+    // the name's first 16 bytes, zero padded, as the buckets keep them
+    const uint64_t n0 = low_bytes(window8(win, pos), n), n1 = n > 8 ? low_bytes(window8(win, pos + 8), n - 8) : 0ull;
     for (uint64_t k = h & T.mask;; k = (k + 1) & T.mask) {
-        const NameBucket* b = T.bucket + k;
-        const uint4 head = *(const uint4*)b;                    // hash32, id1, len, off
-        if (head.y == 0) return 0xFFFFFFFFu;
-        if (head.x != h32 || head.z != n) continue;
+        const uint4* b = (const uint4*)(T.bucket + k);
+        const uint4 meta = b[0];                                // hash32, id1, len, off
+        if (meta.y == 0) return 0xFFFFFFFFu;
+        if (meta.x != h32 || meta.z != n) continue;
+        const uint4 head = b[1];
+        if ((((uint64_t)head.y << 32) | head.x) != n0 || (((uint64_t)head.w << 32) | head.z) != n1) continue;
         bool same = true;
-        const uint32_t in_head = n < 16 ? n : 16;
-        for (uint32_t i = 0; i < in_head && same; ++i) same = (uint8_t)b->head[i] == at(i);
-        for (uint32_t i = 16; i < n && same; ++i) same = (uint8_t)T.arena[head.w + i] == at(i);
-        if (same) return head.y - 1u;
+        for (uint32_t i = 16; i < n && same; ++i) same = (uint8_t)T.arena[meta.w + i] == win[pos + i];
+        if (same) return meta.y - 1u;
     }
 }
 
@@ -194,8 +202,8 @@ __global__ __launch_bounds__(kBlock) void paf_parse_kernel(const uint8_t* __rest
         const uint32_t tb = number(tab[6] + 1, tab[7]);
         const uint32_t te = number(tab[7] + 1, tab[8]);
         const uint32_t ol = number(tab[9] + 1, tab[10]);       // column 11: alignment length
-        const uint32_t ia = find_name(names, [&](uint32_t i) { return win[s + i]; }, qn);
-        const uint32_t ib = find_name(names, [&](uint32_t i) { return win[t0 + i]; }, tn);
+        const uint32_t ia = find_name(names, win, s, qn);
+        const uint32_t ib = find_name(names, win, t0, tn);
         const uint32_t row = row0 + li;
         out.a_id[row] = ia; out.b_id[row] = ib;
         out.a_begin[row] = qb; out.a_end[row] = qe;
