@@ -63,9 +63,10 @@ __device__ __forceinline__ uint64_t pack_record(uint32_t b, uint32_t begin, uint
            (uint64_t)(end < kCoordMax ? end : kCoordMax);
 }
 __device__ __forceinline__ uint32_t rec_key(uint64_t r) { return (uint32_t)(r >> 52); }
-__device__ __forceinline__ uint2 rec_events(uint64_t r) {
+// shrink: 15 for the primary overlaps (graph.cpp:317-324), 0 for the sensitive ones (graph.cpp:929-933: no +-15)
+__device__ __forceinline__ uint2 rec_events(uint64_t r, uint32_t shrink) {
     const uint32_t begin = (uint32_t)(r >> kCoordBits) & kCoordMax, end = (uint32_t)r & kCoordMax;
-    return make_uint2((begin + 15u) << 1, ((end - 15u) << 1) | 1u);         // graph.cpp:317-324
+    return make_uint2((begin + shrink) << 1, ((end - shrink) << 1) | 1u);
 }
 
 // lanes are consecutive overlaps; a segment = maximal run of active lanes with equal key.  Returns the
@@ -351,7 +352,7 @@ __global__ __launch_bounds__(1024) void group_event_base_kernel(const uint32_t* 
 __global__ __launch_bounds__(kBlockP) void final_kernel(const uint64_t* __restrict__ rec2, const uint32_t* __restrict__ group_base,
                                                         const uint32_t* __restrict__ pair_base, uint32_t n_reads,
                                                         const uint32_t* __restrict__ acount, uint32_t* __restrict__ ev_off,
-                                                        uint32_t* __restrict__ ev) {
+                                                        uint32_t* __restrict__ ev, uint32_t shrink) {
     extern __shared__ __align__(16) unsigned char s_raw[];
     __shared__ uint32_t tmp[kBlockP / 64 + 1];
     __shared__ uint32_t s_cursor[kGroupReads];          // next free PAIR of every read's row
@@ -388,7 +389,7 @@ __global__ __launch_bounds__(kBlockP) void final_kernel(const uint64_t* __restri
             const uint32_t j = j0 + u * kBlockP + threadIdx.x;
             in[u] = j < hi;
             const uint64_t rec = in[u] ? rec2[j] : 0ull;
-            const uint2 e = rec_events(rec);
+            const uint2 e = rec_events(rec, shrink);
             pair[u] = (uint64_t)e.x | (uint64_t)e.y << 32;
             bin[u] = rec_key(rec) & (kGroupReads - 1u);
         }
@@ -461,7 +462,7 @@ hipError_t count_attribute(size_t lds_count) {
 
 // level 2 and the rows from the level-1 records
 void launch_partition_rest(const PartitionBuffers& B, uint32_t n_reads, const uint32_t* acount, const uint64_t* rec1, uint64_t* rec2,
-                           uint32_t* ev_off, uint32_t* ev, hipStream_t s) {
+                           uint32_t* ev_off, uint32_t* ev, hipStream_t s, uint32_t shrink = 15u) {
     const uint32_t tiles2 = (uint32_t)(B.tile_slots - 4);               // at least as many as the table can hold
     hipLaunchKernelGGL(l2_scatter_kernel, dim3(tiles2), dim3(kBlockP), stage_lds_bytes(kGroupsPerPart), s, rec1,
                        (const uint32_t*)B.tile_part, (const uint32_t*)B.tile_lo, (const uint32_t*)B.tile_hi, (const uint32_t*)B.n_tiles,
@@ -472,7 +473,7 @@ void launch_partition_rest(const PartitionBuffers& B, uint32_t n_reads, const ui
     hipLaunchKernelGGL(group_event_base_kernel, dim3(1), dim3(1024), 0, s, (const uint32_t*)qsum, (const uint32_t*)B.group_base, B.n_groups,
                        pair_base);
     hipLaunchKernelGGL(final_kernel, dim3(B.n_groups), dim3(kBlockP), stage_lds_bytes(kGroupReads), s, (const uint64_t*)rec2,
-                       (const uint32_t*)B.group_base, (const uint32_t*)pair_base, n_reads, acount, ev_off, ev);
+                       (const uint32_t*)B.group_base, (const uint32_t*)pair_base, n_reads, acount, ev_off, ev, shrink);
 }
 }  // namespace
 
@@ -508,7 +509,8 @@ hipError_t launch_bucket_partitioned(const OvlSoA& o, uint32_t n_reads, uint32_t
 // n_reads + 2 zeroed words (cleared here, through `fills`): no query side apart from the records.
 hipError_t launch_bucket_partitioned_records(const uint64_t* records, uint64_t n, uint32_t n_reads, uint32_t* zero_counts,
                                              uint32_t* part_cursor, uint32_t* group, uint32_t* tiles, uint64_t* rec1, uint64_t* rec2,
-                                             uint32_t* ev_off, uint32_t* ev, uint32_t workgroups, FillList& fills, hipStream_t s) {
+                                             uint32_t* ev_off, uint32_t* ev, uint32_t workgroups, FillList& fills, hipStream_t s,
+                                             uint32_t shrink) {
     const PartitionBuffers B(n_reads, n, group, tiles);
     fills.add(zero_counts, 0, (size_t)n_reads * 4);
     fills.add(B.group_count, 0, (size_t)B.group_slots * 4);
@@ -528,7 +530,7 @@ hipError_t launch_bucket_partitioned_records(const uint64_t* records, uint64_t n
         hipLaunchKernelGGL(l1_scatter_records_kernel, dim3(tiles1), dim3(kBlockP), stage_lds_bytes(B.n_part), s, records, n, n_reads,
                            B.n_part, part_cursor, rec1);
     }
-    launch_partition_rest(B, n_reads, zero_counts, rec1, rec2, ev_off, ev, s);
+    launch_partition_rest(B, n_reads, zero_counts, rec1, rec2, ev_off, ev, s, shrink);
     return hipGetLastError();
 }
 

@@ -212,7 +212,8 @@ struct rala_hip_ctx {
     rala_hip::DevBuf<uint32_t> d_n_rep;
     // sensitive overlaps on the device: columns, transmuted target side, trimmed coordinates, tuples
     rala_hip::DevBuf<uint32_t> d_sens_col[7], d_sens_tb[2], d_sens_c[5];
-    rala_hip::DevBuf<uint2> d_sens_tuples, d_sens_part, d_sens_recv;     // as emitted / grouped by owner / received
+    rala_hip::DevBuf<uint2> d_sens_tuples, d_sens_part, d_sens_recv;
+    rala_hip::DevBuf<uint64_t> d_sens_rec;     // one context: the target bounds as 8-byte records     // as emitted / grouped by owner / received
     rala_hip::DevBuf<uint8_t> d_gather[2];     // sharded runs: this rank's block / all ranks' blocks of a gather
     rala_hip::DevBuf<uint8_t> d_sens_strand, d_sens_state;
     bool sens_in_device = false;        // option "sensitive_in_device_memory"

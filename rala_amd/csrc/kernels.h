@@ -191,6 +191,10 @@ void launch_count_tuples(const uint2* tuples, uint64_t n, uint32_t n_reads, uint
 // first trim; dovetails mark the repeat hills they bridge
 void launch_sens_tuples(const OvlSoA& o, uint32_t n_reads, const uint32_t* begin, const uint8_t* alive, uint32_t* tb_begin,
                         uint32_t* tb_end, uint2* tuples, uint32_t* error, hipStream_t s);
+// the same with ONE 8-byte bound record {read : 22, begin : 21, end : 21} per overlap instead of two tuples (the format of the
+// owners' bound records: launch_bucket_partitioned_records takes it); a record of an overlap that is an error names no read
+void launch_sens_records(const OvlSoA& o, uint32_t n_reads, const uint32_t* begin, const uint8_t* alive, uint32_t* tb_begin,
+                         uint32_t* tb_end, uint64_t* records, uint32_t* error, hipStream_t s);
 void launch_sens_trim(const OvlSoA& o, const uint32_t* tb_begin, const uint32_t* tb_end, const uint32_t* begin,
                       const uint32_t* end, const uint8_t* alive, const SensCoords& out, hipStream_t s);
 void launch_sens_bridge(const OvlSoA& o, const SensCoords& sc, const uint32_t* begin, const uint32_t* end,
@@ -392,9 +396,11 @@ hipError_t launch_bucket_partitioned(const OvlSoA& o, uint32_t n_reads, uint32_t
                                      uint32_t* ev_off, uint32_t* ev, uint32_t workgroups, FillList& fills, hipStream_t s);
 // the same from an owner rank's bound records (launch_bucket_tuples(.., records = true)): zero_counts = n_reads + 2 words
 bool partition_path_fits_records(uint32_t n_reads, uint32_t max_read_len, uint64_t n_records);
+// (shrink: what the bounds are drawn in by - 15 for the primary overlaps, graph.cpp:317-324; 0 for the sensitive ones, :929-933)
 hipError_t launch_bucket_partitioned_records(const uint64_t* records, uint64_t n, uint32_t n_reads, uint32_t* zero_counts,
                                              uint32_t* part_cursor, uint32_t* group, uint32_t* tiles, uint64_t* rec1, uint64_t* rec2,
-                                             uint32_t* ev_off, uint32_t* ev, uint32_t workgroups, FillList& fills, hipStream_t s);
+                                             uint32_t* ev_off, uint32_t* ev, uint32_t workgroups, FillList& fills, hipStream_t s,
+                                             uint32_t shrink = 15u);
 
 // ---- PAF text -> columns (ingest_kernels.hip) ----------------------------------------------
 struct PafColumns {

@@ -849,8 +849,19 @@ int preprocess_repeats(rala_hip_ctx* cs, rala_hip_ctx* cl, Comm* comm, const ral
     HIPCHECK(hipMemsetAsync(cs->d_n_rep.p, 0, n * 4, s));
     HIPCHECK(hipMemsetAsync(cs->d_small.p + 6, 0, 8, s));           // [6] rep pool count [7] error
     HIPCHECK(hipMemsetAsync(cs->d_small.p + 2, 0, 4, s));           // [2] bad sensitive record
-    launch_sens_tuples(so, (uint32_t)n, cs->d_begin.p, cs->d_alive.p, cs->d_sens_tb[0].p, cs->d_sens_tb[1].p,
-                       cs->d_sens_tuples.p, cs->d_small.p + 2, s);
+    // One context: the target bounds as ONE 8-byte record per overlap, bucketed by the partitioned path the owners' records
+    // of a sharded run take (bucket_kernels.hip; no +-15 here) - where the set suits that path; two tuples per overlap through
+    // count / scan / scatter otherwise (and in a sharded run, where the tuples travel first)
+    const bool sens_records = !sharded && cl->use_partitioned_buckets && n < (1u << kBoundRecordReadBits) - 1u &&
+                              partition_path_fits_records((uint32_t)nl, cl->max_read_len, 2 * n_sens);
+    if (sens_records) {
+        HIPCHECK(cs->d_sens_rec.ensure(n_sens + 8));
+        launch_sens_records(so, (uint32_t)n, cs->d_begin.p, cs->d_alive.p, cs->d_sens_tb[0].p, cs->d_sens_tb[1].p, cs->d_sens_rec.p,
+                            cs->d_small.p + 2, s);
+    } else {
+        launch_sens_tuples(so, (uint32_t)n, cs->d_begin.p, cs->d_alive.p, cs->d_sens_tb[0].p, cs->d_sens_tb[1].p,
+                           cs->d_sens_tuples.p, cs->d_small.p + 2, s);
+    }
     const uint2* tuples = cs->d_sens_tuples.p;          // what the pile holder buckets: {its read, bound}
     uint64_t n_tuples = 2 * n_sens;
     if (sharded) {
@@ -907,11 +918,25 @@ int preprocess_repeats(rala_hip_ctx* cs, rala_hip_ctx* cl, Comm* comm, const ral
         HIPCHECK(hipMemsetAsync(cl->d_n_rep.p, 0, nl * 4, sl));
         HIPCHECK(hipMemsetAsync(cl->d_small.p + 6, 0, 8, sl));
     }
-    HIPCHECK(hipMemsetAsync(cl->d_sens_cur.p, 0, (nl + 1) * 4, sl));
-    launch_count_tuples(tuples, n_tuples, (uint32_t)nl, cl->d_sens_cur.p, sl);
-    launch_exclusive_scan(cl->d_sens_cur.p, cl->d_sens_off.p, nl, cl->d_scan_ws.p, sl);
-    HIPCHECK(hipMemcpyAsync(cl->d_sens_cur.p, cl->d_sens_off.p, nl * 4, hipMemcpyDeviceToDevice, sl));
-    launch_scatter_tuples(tuples, n_tuples, (uint32_t)nl, cl->d_sens_cur.p, cl->d_sens_ev.p, sl);
+    if (sens_records) {
+        // (the first pass' bucketing buffers have served: the bound events themselves stay where initialize left them)
+        const uint32_t n_reads_l = (uint32_t)nl;
+        HIPCHECK(cl->d_bk_u32[0].ensure(n_reads_l + 2));
+        HIPCHECK(cl->d_bk_part.ensure(partition_count(n_reads_l) + 2));
+        HIPCHECK(cl->d_bk_group.ensure(3 * (size_t)partition_group_slots(n_reads_l)));
+        HIPCHECK(cl->d_bk_tiles.ensure(3 * partition_tile_slots(n_reads_l, n_sens) + 2));
+        for (int k = 0; k < 2; ++k) HIPCHECK(cl->d_bk_rec[k].ensure(partition_records_needed(n_reads_l, n_sens)));
+        FillList fills;
+        HIPCHECK(launch_bucket_partitioned_records(cs->d_sens_rec.p, n_sens, n_reads_l, cl->d_bk_u32[0].p, cl->d_bk_part.p, cl->d_bk_group.p,
+                                                   cl->d_bk_tiles.p, cl->d_bk_rec[0].p, cl->d_bk_rec[1].p, cl->d_sens_off.p, cl->d_sens_ev.p,
+                                                   cl->n_compute_units, fills, sl, 0u));
+    } else {
+        HIPCHECK(hipMemsetAsync(cl->d_sens_cur.p, 0, (nl + 1) * 4, sl));
+        launch_count_tuples(tuples, n_tuples, (uint32_t)nl, cl->d_sens_cur.p, sl);
+        launch_exclusive_scan(cl->d_sens_cur.p, cl->d_sens_off.p, nl, cl->d_scan_ws.p, sl);
+        HIPCHECK(hipMemcpyAsync(cl->d_sens_cur.p, cl->d_sens_off.p, nl * 4, hipMemcpyDeviceToDevice, sl));
+        launch_scatter_tuples(tuples, n_tuples, (uint32_t)nl, cl->d_sens_cur.p, cl->d_sens_ev.p, sl);
+    }
     // the targets: reads that received bounds - listed where the offsets are, the host learns how many
     HIPCHECK(cl->d_sens_list.ensure(nl + 1));
     HIPCHECK(cl->d_chain_cnt.ensure(16));

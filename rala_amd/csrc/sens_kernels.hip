@@ -41,6 +41,31 @@ __global__ __launch_bounds__(kBlock) void sens_tuples_kernel(OvlSoA o, uint32_t 
     *(uint4*)(tuples + 2 * i) = make_uint4(r, x << 1, r, (y << 1) | 1u);
 }
 
+// the same with one bound record {read : 22, begin : 21, end : 21} per overlap for the partitioned bucketing
+__global__ __launch_bounds__(kBlock) void sens_records_kernel(OvlSoA o, uint32_t n_reads, const uint32_t* __restrict__ begin,
+                                                              const uint8_t* __restrict__ alive,
+                                                              uint32_t* __restrict__ tb_begin, uint32_t* __restrict__ tb_end,
+                                                              uint64_t* __restrict__ records, uint32_t* error) {
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= o.n) return;
+    const uint32_t a = o.a_id[i], b = o.b_id[i];
+    uint32_t x = 0, y = 0;
+    uint64_t rec = ~0ull;                          // (names no read)
+    if (a >= n_reads || b >= n_reads) {
+        atomicOr(error, 1u);
+    } else if (!alive[b]) {
+        atomicOr(error, 2u);
+    } else {
+        const uint32_t B = begin[b];
+        x = o.b_begin[i] + B;
+        y = o.b_end[i] + B;
+        constexpr uint32_t kMask = (1u << kBoundRecordCoordBits) - 1u;
+        rec = (uint64_t)b << (2 * kBoundRecordCoordBits) | (uint64_t)(x < kMask ? x : kMask) << kBoundRecordCoordBits | (uint64_t)(y < kMask ? y : kMask);
+    }
+    tb_begin[i] = x; tb_end[i] = y;
+    records[i] = rec;
+}
+
 // first Overlap::trim of every sensitive overlap (graph.cpp:935-939); state 1 = kept
 __global__ __launch_bounds__(kBlock) void sens_trim_kernel(OvlSoA o, const uint32_t* __restrict__ tb_begin,
                                                            const uint32_t* __restrict__ tb_end,
@@ -158,6 +183,10 @@ void launch_sens_tuples(const OvlSoA& o, uint32_t n_reads, const uint32_t* begin
         hipLaunchKernelGGL(sens_tuples_kernel, grid_for(o.n), dim3(kBlock), 0, s, o, n_reads, begin, alive, tb_begin, tb_end,
                            tuples, error);
     }
+}
+void launch_sens_records(const OvlSoA& o, uint32_t n_reads, const uint32_t* begin, const uint8_t* alive, uint32_t* tb_begin,
+                         uint32_t* tb_end, uint64_t* records, uint32_t* error, hipStream_t s) {
+    if (o.n) hipLaunchKernelGGL(sens_records_kernel, grid_for(o.n), dim3(kBlock), 0, s, o, n_reads, begin, alive, tb_begin, tb_end, records, error);
 }
 void launch_sens_trim(const OvlSoA& o, const uint32_t* tb_begin, const uint32_t* tb_end, const uint32_t* begin,
                       const uint32_t* end, const uint8_t* alive, const SensCoords& out, hipStream_t s) {
