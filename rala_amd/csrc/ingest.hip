@@ -31,7 +31,7 @@ constexpr uint32_t kMaxReaders = 8;        // (measured at C3: 4 readers 107 ms,
 struct StagingPool {
     std::mutex m;
     std::vector<void*> free_blocks;
-    ~StagingPool() { for (void* p : free_blocks) (void)hipHostFree(p); }
+    // (never freed: at process exit the runtime may be gone before this object is, and the memory goes with the process)
     void* take() {
         {
             std::lock_guard<std::mutex> hold(m);
