@@ -92,6 +92,8 @@ const char* rala_hip_last_error(const rala_hip_ctx* ctx);
  * target side through fixed slots), "debug_fp_lds_limit" (tests: containment fixed points with more killers than this
  * take the kernel for lists that do not fit the LDS), "use_bound_records" (default 1; sharded runs: 0 ships two bound tuples
  * per overlap side instead of one bound record),
+ * "pile_persistent_grid" (default 0 = one workgroup per read in the first pile kernel; n > 0 = n persistent workgroups,
+ * each looping over its share of the reads with the next read's events requested one read ahead - measured, no gain),
  * "debug_pile_stop_after" (diagnostics: leave the run-space pile kernel after phase k, 99 = all;
  * 100 * m + k: the same without the row stores (m = 1), tools/phase_probe.py) */
 int rala_hip_set_option(rala_hip_ctx* ctx, const char* key, int64_t value);

@@ -95,6 +95,7 @@ struct rala_hip_ctx {
     bool debug_fail_construct = false;          // tests: pass 2 fails on this context
     uint32_t debug_fp_lds_limit = 0xFFFFFFFFu;  // tests: containment fixed points with more killers than this take the long lists' kernel
     bool use_bound_records = true;              // sharded runs: 8-byte bound records instead of two tuples per overlap side where they fit
+    int64_t pile_persistent_grid = -1;          // first pile kernel: persistent workgroups (0 = one per read; -1 = RALA_PILE_PERSIST2 or 0)
     bool use_round_batches = true;              // containment fixed point: several rounds per look at the counter
     rala_hip::DevBuf<uint32_t> d_round_log;     // list sizes after the rounds the host did not look at
 

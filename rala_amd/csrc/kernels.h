@@ -40,6 +40,7 @@ struct PileArgs {
     uint32_t lw;                   // uint16 elements per big array (>= kPadL + len + 848, multiple of 8)
     uint32_t add_to_existing;
     uint32_t stop_after;           // diagnostics: leave the kernel after phase k (99 = run everything)
+    uint32_t persist_grid = 0;     // first kernel of the first pass: > 0 = that many persistent workgroups (option pile_persistent_grid)
     uint16_t* slab;                // HBM scratch, 3 * lw elements per workgroup (long reads only)
     // outputs, indexed by read
     uint32_t* begin;

@@ -1968,6 +1968,7 @@ int rala_hip_set_option(rala_hip_ctx* ctx, const char* key, int64_t value) {
     if (!strcmp(key, "max_lds_read_len")) { ctx->max_lds_read_len = value; return RALA_HIP_OK; }
     if (!strcmp(key, "debug_pile_stop_after")) { ctx->debug_pile_stop_after = value; return RALA_HIP_OK; }
     if (!strcmp(key, "use_run_kernel")) { ctx->use_run_kernel = value != 0; return RALA_HIP_OK; }
+    if (!strcmp(key, "pile_persistent_grid")) { ctx->pile_persistent_grid = std::max<int64_t>(0, value); return RALA_HIP_OK; }
     if (!strcmp(key, "use_round_batches")) { ctx->use_round_batches = value != 0; return RALA_HIP_OK; }
     if (!strcmp(key, "use_bound_records")) { ctx->use_bound_records = value != 0; return RALA_HIP_OK; }
     if (!strcmp(key, "debug_fp_lds_limit")) { ctx->debug_fp_lds_limit = (uint32_t)std::max<int64_t>(0, value); return RALA_HIP_OK; }
@@ -2017,10 +2018,15 @@ int rala_hip_set_reads(rala_hip_ctx* ctx, const uint32_t* read_len, uint64_t n_r
         }
     }
     ctx->h_pile_off.resize(n_reads + 1);
+    // Rows start on 128-byte boundaries (64 elements): a row's first and last cache line are then its own, not shared
+    // with the neighbouring rows, which other wavefronts write at other times.  Round 4, one box, pile kernel at C3:
+    // 16-byte boundaries (rounds 1 - 3: what the 16-byte stores need) 4.26 ms, 128 bytes 4.17, 1 KB 4.18, 4 KB 4.21
+    // (tools/gpurun/r4_rowalign.sh; RALA_PILE_ROW_ALIGN=<elements, a power of two >= 8> for the experiment).
+    static const uint64_t row_align = getenv("RALA_PILE_ROW_ALIGN") ? std::max<uint64_t>(8, (uint64_t)atoll(getenv("RALA_PILE_ROW_ALIGN"))) : 64ull;
     uint64_t off = 0;
     for (uint64_t r = 0; r < n_reads; ++r) {
         ctx->h_pile_off[r] = off;
-        off += ((uint64_t)read_len[r] + 7) & ~7ull;      // rows padded to 16 bytes
+        off += ((uint64_t)read_len[r] + row_align - 1) & ~(row_align - 1);
     }
     ctx->h_pile_off[n_reads] = off;
     ctx->pile_elems = off;
@@ -2120,10 +2126,14 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
     FillList fills;
     fills.add(ctx->d_small.p, 0, 16 * 4);
     // duplicate removal only feeds the second pass (every resolvable overlap adds its bounds,
-    // valid or not): it runs on a second stream beside the pile kernels (started when the
-    // bucketing is done - beside the bucketing, both reading the same columns while the atomics
-    // queue, the two slowed each other: 0.2 - 0.5 ms per C3 step); the main stream joins it after
-    // the pile kernels
+    // valid or not): it runs on a second stream and the main stream joins it after the pile kernels.
+    // Beside WHAT it runs: beside the single-pass bucketing, both reading the same columns while the
+    // atomics queue, the two slowed each other (0.2 - 0.5 ms per C3 step), so it starts when that
+    // bucketing is done, beside the pile kernels.  Those are bound by instruction issue, and what runs
+    // beside them costs them its whole stand-alone time (0.26 ms at C3: pile kernel 4.63 ms with it,
+    // 4.37 without); the partitioned bucketing streams and has issue slots to spare - beside it the
+    // duplicate removal costs 0.14 ms (round 4, tools/gpurun/r4_dedupe_early.sh: step 8.08 -> 7.99 ms).
+    // RALA_DEDUPE_LATE keeps it beside the pile kernels.
     const bool forked = !ctx->tuple_mode && ctx->use_side_stream;
     if (!forked) {
         if (!ctx->tuple_mode) launch_dedupe(ctx->ovl, n_reads, ctx->d_suspect.p, ctx->d_valid.p, s);
@@ -2153,6 +2163,13 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
     const bool partitioned = from_records || (!ctx->tuple_mode && partition_allowed &&
                                               partition_path_fits(n_reads, ctx->max_read_len, ctx->n_ovl));
     bool fixed = !partitioned && ctx->use_run_kernel && ctx->use_fixed_buckets && (uint64_t)n_reads * slot * 4ull <= (64ull << 30);
+    static const bool dedupe_late = getenv("RALA_DEDUPE_LATE") != nullptr;
+    const bool dedupe_early = forked && partitioned && !dedupe_late;
+    if (dedupe_early) {
+        HIPCHECK(hipStreamWaitEvent(ctx->side, ctx->ev[0], 0));
+        launch_dedupe(ctx->ovl, n_reads, ctx->d_suspect.p, ctx->d_valid.p, ctx->side);
+        HIPCHECK(hipEventRecord(ctx->ev[1], ctx->side));
+    }
     if (partitioned) {
         const uint64_t n_rec = from_records ? ctx->n_records : ctx->n_ovl;
         for (int k = 0; k < 3; ++k) HIPCHECK(ctx->d_bk_u32[k].ensure(n_reads + 2));
@@ -2205,7 +2222,7 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
     }
     }
     HIPCHECK(hipEventRecord(ctx->ev[2], s));
-    if (forked) {
+    if (forked && !dedupe_early) {
         HIPCHECK(hipStreamWaitEvent(ctx->side, ctx->ev[2], 0));
         launch_dedupe(ctx->ovl, n_reads, ctx->d_suspect.p, ctx->d_valid.p, ctx->side);
         HIPCHECK(hipEventRecord(ctx->ev[1], ctx->side));
@@ -2217,6 +2234,11 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
     a.ev_cnt = fixed ? ctx->d_cursor.p : nullptr; a.ev_stride = slot;
     a.add_to_existing = 0; a.slab = ctx->d_slab.p;
     a.stop_after = (uint32_t)ctx->debug_pile_stop_after;
+    {
+        static const int64_t env_grid = getenv("RALA_PILE_PERSIST2") ? atoll(getenv("RALA_PILE_PERSIST2")) : 0;
+        const int64_t g = ctx->pile_persistent_grid >= 0 ? ctx->pile_persistent_grid : env_grid;
+        a.persist_grid = (uint32_t)std::min<int64_t>(std::max<int64_t>(0, g), 1 << 24);
+    }
     a.begin = ctx->d_begin.p; a.end = ctx->d_end.p; a.median = ctx->d_median.p; a.p10 = ctx->d_p10.p;
     a.alive = ctx->d_alive.p; a.n_pits = ctx->d_n_pits.p; a.n_hills = ctx->d_n_hills.p; a.iv_slot = ctx->d_iv_slot.p;
     a.pool = ctx->d_pool.p; a.pool_count = ctx->d_small.p; a.pool_cap = ctx->pool_cap; a.error = ctx->d_small.p + 1;
