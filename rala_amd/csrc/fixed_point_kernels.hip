@@ -23,6 +23,7 @@
 // resident together, a barrier between them per round.  What other wavefronts write with atomics is then read past
 // the vector cache, on this device from the memory side: 20 - 30 us per round instead of 2, whatever the list's
 // length (one workgroup alone took 160 us per round for 24 k entries).
+#include <atomic>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -282,12 +283,20 @@ hipError_t launch_fixed_point_finish(const FixedPointList& list_in, uint32_t* ba
     list.lds_limit = std::min<uint32_t>(list_in.lds_limit, kLdsEntries);
     if (getenv("RALA_HIP_DEBUG_FP_GIVE_UP")) list.debug_give_up = 1;     // tests: the long lists' workgroups do not meet
     constexpr size_t lds_bytes = 3 * (size_t)kLdsEntries * 4;
-    // (every time: the attribute belongs to the function on the CURRENT device, and the ranks of a sharded run are threads
-    // of one process on different devices)
+    // (once per DEVICE: the attribute belongs to the function on the current device, and the ranks of a sharded run are
+    // threads of one process on different devices.  Every time, it was part of why the host fell behind the device in
+    // this chain of 4-microsecond kernels: 8 - 19 us of queue idle time in front of each of them)
     {
-        const hipError_t e = hipFuncSetAttribute((const void*)fixed_point_finish_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                 (int)lds_bytes);
+        static std::atomic<uint64_t> set_on{0};
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
         if (e != hipSuccess) return e;
+        const uint64_t bit = 1ull << (dev & 63);
+        if (!(set_on.load(std::memory_order_acquire) & bit)) {
+            e = hipFuncSetAttribute((const void*)fixed_point_finish_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            if (e != hipSuccess) return e;
+            set_on.fetch_or(bit, std::memory_order_release);
+        }
     }
     // (the list's length is on the device: the kernels look at it)
     hipLaunchKernelGGL(fixed_point_assign_kernel, dim3(kPrepGroups), dim3(kPrepBlock), 0, s, list, map);

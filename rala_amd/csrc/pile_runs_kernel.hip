@@ -631,7 +631,9 @@ __global__ __launch_bounds__(64 * kWaves, kOne ? (kPersist ? 8 : 7) : kBases > 3
     }
     // Workgroup i runs on XCD i % 8.  A grid smaller than the number of items (a multiple of 8) gives every
     // XCD one contiguous eighth of the items (tools/fill_bench3.hip: rows written side by side by one XCD
-    // stream out at 6.2 TB/s instead of 5.2 TB/s - in a fill kernel; this kernel does not notice).
+    // stream out at 6.2 TB/s instead of 5.2 TB/s - in a fill kernel; this kernel does not notice.  Round 4, the same
+    // with one workgroup per read - workgroup i takes read (i % 8) * n / 8 + i / 8 - on the build that runs at the
+    // fill kernel's 5.0 TB/s: C3 4.26 against 4.16 ms, C5 17.4 against 17.7, tools/gpurun/r4_xcd.sh; not kept).
     uint32_t item_first = blockIdx.x * kWaves + wave_in_group, item_end = n_items, item_step = gridDim.x * kWaves;
     if (kOne && kWaves == 1 && gridDim.x % 8u == 0 && gridDim.x < n_items) {
         const uint32_t per = (n_items + 7u) / 8u, xcd = blockIdx.x % 8u;
@@ -1869,7 +1871,10 @@ void launch_pile_dense_list(const PileArgs& args, uint32_t n_reads, uint32_t* li
     hipLaunchKernelGGL(pile_dense_list_kernel, dim3((n_reads + 255) / 256), dim3(256), 0, stream, args, n_reads, list, count);
 }
 
-constexpr uint32_t kPileWavesPerGroup = 1;
+// Reads per workgroup in the first kernel (one wavefront each).  Rounds 2 - 3: one (two and four measured no gain: 4.80 /
+// 4.83 against 4.74 ms).  Round 4, once the rows start on cache-line boundaries and nothing else runs beside the kernel: two
+// 4.07 - 4.10 ms, one 4.16, four 4.23 (tools/gpurun/r4_waves2.sh) - two.
+constexpr uint32_t kPileWavesPerGroup = 2;
 
 void launch_pile_runs(const PileArgs& args, uint32_t grid, int tier, uint32_t* overflow_list, uint32_t* overflow_count,
                       hipStream_t stream) {

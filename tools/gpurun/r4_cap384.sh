@@ -1,0 +1,13 @@
+# pile kernel: the first kernel for 384 events per read at eight wavefronts per SIMD (5 056 B of LDS, 63 registers;
+# RALA_PILE_CAP384) against 512 events at seven, one box
+cd $GRAFT_REPO_ROOT
+RALA_PILE_CAP384=1 timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_golden.py -m gpu -x -q 2>&1 | tail -2
+run() { python bench.py --no-cpu-baseline --no-e2e --steps 10 --warmup 2 $1 2>/dev/null | grep '^{' | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('bucket %.3f pile %.3f step %.3f frac %.3f overflow %d tr %d' % (d['stage_ms']['bucket_ms'], d['stage_ms']['pile_ms'], d['ms_per_step'], d['roofline']['frac'], d['stage_ms']['pile_overflow_reads'], d['config']['transitive_pairs']))"; }
+for k in 1 2 3; do
+  echo "512 events, 7 per SIMD : $(run)"
+  echo "384 events, 8 per SIMD : $(RALA_PILE_CAP384=1 run)"
+done
+echo "c5 512 : $(run '--workload c5')"
+echo "c5 384 : $(RALA_PILE_CAP384=1 run '--workload c5')"
