@@ -1871,6 +1871,9 @@ void launch_pile_dense_list(const PileArgs& args, uint32_t n_reads, uint32_t* li
     hipLaunchKernelGGL(pile_dense_list_kernel, dim3((n_reads + 255) / 256), dim3(256), 0, stream, args, n_reads, list, count);
 }
 
+// (An EIGHTH wavefront per SIMD, round 4, timing only - the 384-event instantiation at 5 056 B and 64 registers over the
+// 99.7 % of the C3 reads it can take, the 512-event kernel over the same reads: 4.37 - 4.6 ms against 4.04 - 4.09,
+// tools/gpurun/r4_probe8.sh.  Seven is the kernel's optimum, not a limit worth lifting.)
 // Reads per workgroup in the first kernel (one wavefront each).  Rounds 2 - 3: one (two and four measured no gain: 4.80 /
 // 4.83 against 4.74 ms).  Round 4, once the rows start on cache-line boundaries and nothing else runs beside the kernel: two
 // 4.07 - 4.10 ms, one 4.16, four 4.23 (tools/gpurun/r4_waves2.sh) - two.
