@@ -596,7 +596,7 @@ __device__ __forceinline__ void expand_from_bitmap(uint32_t* sm, const uint16_t*
 // its own stretch of LDS and synchronises with itself only; what they have in common is their place: the rows of
 // neighbouring reads are written from one compute unit (tools/fill_bench4.hip: four rows per workgroup fill at 5.4 TB/s
 // where one row per workgroup fills at 5.0).
-template <uint32_t kCap, bool kDiag, int kSens, bool kOne = false, uint32_t kBases = 16384, uint32_t kWaves = 1, bool kPersist = false>
+template <uint32_t kCap, bool kDiag, int kSens, bool kOne = false, uint32_t kBases = 16384, uint32_t kWaves = 1, bool kPersist = false, bool kPlain = false>
 __global__ __launch_bounds__(64 * kWaves, kOne ? (kPersist ? 8 : 7) : kBases > 32768 ? 2 : kBases > 16384 ? 4 : 5) void pile_runs_kernel(PileArgs A, uint32_t* overflow_list, uint32_t* overflow_count) {
     static_assert(kWaves == 1 || kOne, "several reads per workgroup: the first kernel of a chain only");
     static_assert(!kPersist || (kOne && kSens == 0 && !kDiag && kWaves == 1 && kBases == 16384), "persistent wavefronts: the first kernel of the first pass");
@@ -751,6 +751,17 @@ __global__ __launch_bounds__(64 * kWaves, kOne ? (kPersist ? 8 : 7) : kBases > 3
             cur_ev = A.ev + nx_e0;
             nx_n = nx2_n; nx_off = nx2_off; nx_e0 = nx2_e0; nx_e1 = nx2_e1;
             r_fetch = item + 2u * item_step < item_end ? item + 2u * item_step : item;
+        } else if constexpr (kPlain) {
+            // the reads as they come, their events in the CSR: four loads that do not wait for each other (through the
+            // branches of the general case below they were four round trips in a row)
+            r = item;
+            // (Measured and dropped: the same four values by the scalar unit - s_load_dword / dwordx2 and one wait - 4.6 - 4.8 ms
+            // against 4.0 - 4.1, tools/gpurun/r4_scalar.sh: lines other kernels have just written are not in its cache.)
+            const uint32_t e0 = A.ev_off[r], e1 = A.ev_off[r + 1];
+            n = A.read_len[r];
+            row_off = A.pile_off[r];
+            n_ev_p = e1 - e0;
+            rev = A.ev + e0;
         } else {
             r = A.order ? A.order[item] : item;
             n = A.read_len[r];
@@ -773,6 +784,12 @@ __global__ __launch_bounds__(64 * kWaves, kOne ? (kPersist ? 8 : 7) : kBases > 3
         }
         // the first kernel of the first pass: longer reads start in their own length class's kernel
         // (pipeline.hip), no hand-over through the list
+        if constexpr (kPlain) {
+            // (one test over everything that was loaded: a branch on the length alone would have the offsets' loads wait
+            // behind it)
+            const uint32_t not_mine = (uint32_t)(n > kMaxBases) | (uint32_t)(A.skip_dense != 0 && n_ev > kRunEventCap) | (uint32_t)(row_off == ~0ull);
+            if (not_mine) continue;
+        }
         if (kOne && kSens == 0 && n > kMaxBases) {
             if constexpr (kPersist) rejected = true; else continue;
         }
@@ -1918,6 +1935,9 @@ void launch_pile_runs(const PileArgs& args, uint32_t grid, int tier, uint32_t* o
                                      args, overflow_list, overflow_count);
         else if (waves == 4 && !persist) hipLaunchKernelGGL((pile_runs_kernel<kRunEventCap, false, 0, true, 16384, 4>), dim3((grid + 3) / 4), dim3(256),
                                                             extra_lds, stream, args, overflow_list, overflow_count);
+        else if (waves == 2 && !persist && !args.order && !args.ev_cnt && !getenv("RALA_PILE_NOT_PLAIN"))
+            hipLaunchKernelGGL((pile_runs_kernel<kRunEventCap, false, 0, true, 16384, 2, false, true>), dim3((grid + 1) / 2), dim3(128),
+                               extra_lds, stream, args, overflow_list, overflow_count);
         else if (waves == 2 && !persist) hipLaunchKernelGGL((pile_runs_kernel<kRunEventCap, false, 0, true, 16384, 2>), dim3((grid + 1) / 2), dim3(128),
                                                             extra_lds, stream, args, overflow_list, overflow_count);
         else hipLaunchKernelGGL((pile_runs_kernel<kRunEventCap, false, 0, true>), dim3(g), dim3(64), extra_lds, stream,
