@@ -522,6 +522,9 @@ __device__ __forceinline__ void expand_from_bitmap(uint32_t* sm, const uint16_t*
     auto chunk = [&](uint32_t g0, auto full_tag) {
         constexpr bool kFull = decltype(full_tag)::value;
         const uint32_t voff = lane16 + g0 * 16u;              // the stores' lane offset: once per four groups
+        // (Measured, round 4, no gain: the LDS reads of two groups under way before the first value is looked at instead of
+        // read - wait - combine - store group after group: 4.11 - 4.14 ms either way, tools/gpurun/r4_ahead.sh.  What the
+        // kernel's rate hangs on at a wavefront's start are its round trips to MEMORY - kPlain -, not those to the LDS.)
         uint32_t bits[4], kq[4];
 #pragma unroll
         for (uint32_t u = 0; u < 4; ++u) {
