@@ -216,19 +216,61 @@ __device__ __forceinline__ void append_flagged(bool flag, uint32_t value, uint32
     base = (uint32_t)__shfl((int)base, 0, 64);
     if (flag) list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = value;
 }
+// the same for kListPer items per thread behind ONE add per workgroup (adds to one word cost about 10 ns apiece: a wavefront's
+// add each, list_targets_kernel took 0.70 ms for 4 M reads at C5, list 0.28 M long)
+constexpr uint32_t kListPer = 8;
+__device__ __forceinline__ void append_flagged_block(const bool (&flag)[kListPer], const uint32_t (&value)[kListPer], uint32_t* list,
+                                                     uint32_t* count) {
+    __shared__ uint32_t s_cnt, s_base;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t slot[kListPer];
+#pragma unroll
+    for (uint32_t u = 0; u < kListPer; ++u) {
+        const uint64_t m = __ballot(flag[u]);
+        uint32_t base = 0;
+        if (m) {
+            if (lane == 0) base = atomicAdd(&s_cnt, (uint32_t)__popcll(m));
+            base = (uint32_t)__shfl((int)base, 0, 64);
+        }
+        slot[u] = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) s_base = s_cnt ? atomicAdd(count, s_cnt) : 0u;
+    __syncthreads();
+#pragma unroll
+    for (uint32_t u = 0; u < kListPer; ++u) {
+        if (flag[u]) list[s_base + slot[u]] = value[u];
+    }
+}
 // the targets of the sensitive overlaps: the reads that received bounds (graph.cpp:941-953 walks the piles with bounds)
 __global__ __launch_bounds__(kBlock) void list_targets_kernel(const uint32_t* __restrict__ off, uint32_t n, uint32_t* list, uint32_t* count) {
-    const uint32_t r = blockIdx.x * kBlock + threadIdx.x;
-    append_flagged(r < n && off[r + 1] != off[r], r, list, count);
+    bool flag[kListPer];
+    uint32_t value[kListPer];
+#pragma unroll
+    for (uint32_t u = 0; u < kListPer; ++u) {
+        const uint32_t r = (blockIdx.x * kListPer + u) * kBlock + threadIdx.x;
+        value[u] = r;
+        flag[u] = r < n && off[r + 1] != off[r];
+    }
+    append_flagged_block(flag, value, list, count);
 }
 // the members of the components: alive reads with an overlap (graph.cpp:1006-1026); of a sharded run, this rank's (read r
 // lives on rank r % world as its read r / world)
 __global__ __launch_bounds__(kBlock) void list_members_kernel(const uint32_t* __restrict__ alive_reads, const uint8_t* __restrict__ touched,
                                                               uint32_t n_alive, uint32_t world, uint32_t rank, uint32_t* list,
                                                               uint32_t* count) {
-    const uint32_t q = blockIdx.x * kBlock + threadIdx.x;
-    const uint32_t r = q < n_alive ? alive_reads[q] : 0u;
-    append_flagged(q < n_alive && touched[q] && r % world == rank, r / world, list, count);
+    bool flag[kListPer];
+    uint32_t value[kListPer];
+#pragma unroll
+    for (uint32_t u = 0; u < kListPer; ++u) {
+        const uint32_t q = (blockIdx.x * kListPer + u) * kBlock + threadIdx.x;
+        const uint32_t r = q < n_alive ? alive_reads[q] : 0u;
+        value[u] = r / world;
+        flag[u] = q < n_alive && touched[q] && r % world == rank;
+    }
+    append_flagged_block(flag, value, list, count);
 }
 __global__ __launch_bounds__(kBlock) void sens_split_kernel(const uint32_t* __restrict__ list, uint32_t n, SensSplitArgs A) {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
@@ -253,11 +295,11 @@ void launch_sens_split(const uint32_t* list, uint32_t n, const SensSplitArgs& ar
 }
 
 void launch_list_targets(const uint32_t* off, uint32_t n, uint32_t* list, uint32_t* count, hipStream_t s) {
-    if (n) hipLaunchKernelGGL(list_targets_kernel, grid_for(n), dim3(kBlock), 0, s, off, n, list, count);
+    if (n) hipLaunchKernelGGL(list_targets_kernel, dim3((n + kListPer * kBlock - 1) / (kListPer * kBlock)), dim3(kBlock), 0, s, off, n, list, count);
 }
 void launch_list_members(const uint32_t* alive_reads, const uint8_t* touched, uint32_t n_alive, uint32_t world, uint32_t rank,
                          uint32_t* list, uint32_t* count, hipStream_t s) {
-    if (n_alive) hipLaunchKernelGGL(list_members_kernel, grid_for(n_alive), dim3(kBlock), 0, s, alive_reads, touched, n_alive, world, rank, list, count);
+    if (n_alive) hipLaunchKernelGGL(list_members_kernel, dim3((n_alive + kListPer * kBlock - 1) / (kListPer * kBlock)), dim3(kBlock), 0, s, alive_reads, touched, n_alive, world, rank, list, count);
 }
 
 void launch_finalize_states(const TailList& L, const uint8_t* alive, hipStream_t s) {
