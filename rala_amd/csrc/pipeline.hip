@@ -2022,7 +2022,11 @@ int rala_hip_set_reads(rala_hip_ctx* ctx, const uint32_t* read_len, uint64_t n_r
     // with the neighbouring rows, which other wavefronts write at other times.  Round 4, one box, pile kernel at C3:
     // 16-byte boundaries (rounds 1 - 3: what the 16-byte stores need) 4.26 ms, 128 bytes 4.17, 1 KB 4.18, 4 KB 4.21
     // (tools/gpurun/r4_rowalign.sh; RALA_PILE_ROW_ALIGN=<elements, a power of two >= 8> for the experiment).
-    static const uint64_t row_align = getenv("RALA_PILE_ROW_ALIGN") ? std::max<uint64_t>(8, (uint64_t)atoll(getenv("RALA_PILE_ROW_ALIGN"))) : 64ull;
+    static const uint64_t row_align = [] {
+        uint64_t want = getenv("RALA_PILE_ROW_ALIGN") ? (uint64_t)atoll(getenv("RALA_PILE_ROW_ALIGN")) : 64ull, a = 8;
+        while (a * 2 <= want && a < (1ull << 20)) a *= 2;           // a power of two, 8 elements at least
+        return a;
+    }();
     uint64_t off = 0;
     for (uint64_t r = 0; r < n_reads; ++r) {
         ctx->h_pile_off[r] = off;
