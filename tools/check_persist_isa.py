@@ -79,7 +79,8 @@ def main():
     text = open(sys.argv[1]).read()
     bad, seen = [], 0
     for name, lines in kernels(text):
-        if "ELj16384ELj1ELb1EEEvNS_8PileArgs" not in name:
+        # pile_runs_kernel<kCap, kDiag, kSens, kOne, kBases, kWaves, kPersist = true, ..>
+        if not re.search(r"pile_runs_kernelILj\d+ELb[01]ELi\d+ELb[01]ELj\d+ELj\d+ELb1E", name):
             continue
         seen += 1
         bad += check(name, lines)
