@@ -400,21 +400,32 @@ __global__ __launch_bounds__(kBlockP) void final_kernel(const uint64_t* __restri
 
 // query side: one thread per overlap; the lanes of a wavefront that share the query take their places from
 // ONE atomic (the file is grouped by query).  written[] counts what a read has handed out so far.
+template <uint32_t kQ>
 __global__ __launch_bounds__(256) void query_side_kernel(OvlSoA o, uint32_t n_reads, const uint32_t* __restrict__ ev_off,
                                                          uint32_t* written, uint32_t* __restrict__ ev) {
-    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63;
-    uint32_t a = kInf, b = kInf, begin = 0, end = 0;
-    // (the coordinates with the ids, not behind the add's round trip)
-    if (i < o.n) { a = o.a_id[i]; b = o.b_id[i]; begin = __builtin_nontemporal_load(o.a_begin + i); end = __builtin_nontemporal_load(o.a_end + i); }
-    const bool ok = a < n_reads && b < n_reads;
-    uint32_t leader;
-    const uint32_t seg = segment_of(a, ok, lane, leader);
-    uint32_t base = 0;
-    if (seg) base = ev_off[a] + atomicAdd(&written[a], 2u * seg);
-    base = (uint32_t)__shfl((int)base, (int)leader, 64);
-    if (!ok) return;
-    *(uint2*)(ev + base + 2u * (lane - leader)) = make_uint2((begin + 15u) << 1, ((end - 15u) << 1) | 1u);
+    uint32_t a[kQ], b[kQ], begin[kQ], end[kQ];
+    // (the coordinates with the ids, not behind the add's round trip; kQ overlaps per thread, their loads together)
+#pragma unroll
+    for (uint32_t u = 0; u < kQ; ++u) {
+        const uint64_t i = ((uint64_t)blockIdx.x * kQ + u) * 256 + threadIdx.x;
+        a[u] = kInf; b[u] = kInf; begin[u] = 0; end[u] = 0;
+        if (i < o.n) { a[u] = o.a_id[i]; b[u] = o.b_id[i]; begin[u] = __builtin_nontemporal_load(o.a_begin + i); end[u] = __builtin_nontemporal_load(o.a_end + i); }
+    }
+    uint32_t base[kQ], leader[kQ];
+    bool ok[kQ];
+#pragma unroll
+    for (uint32_t u = 0; u < kQ; ++u) {
+        ok[u] = a[u] < n_reads && b[u] < n_reads;
+        const uint32_t seg = segment_of(a[u], ok[u], lane, leader[u]);
+        base[u] = 0;
+        if (seg) base[u] = ev_off[a[u]] + atomicAdd(&written[a[u]], 2u * seg);
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < kQ; ++u) {
+        const uint32_t at = (uint32_t)__shfl((int)base[u], (int)leader[u], 64);
+        if (ok[u]) *(uint2*)(ev + at + 2u * (lane - leader[u])) = make_uint2((begin[u] + 15u) << 1, ((end[u] - 15u) << 1) | 1u);
+    }
 }
 
 }  // namespace
@@ -501,7 +512,12 @@ hipError_t launch_bucket_partitioned(const OvlSoA& o, uint32_t n_reads, uint32_t
     hipLaunchKernelGGL(l1_scatter_kernel, dim3(tiles1), dim3(kBlockP), stage_lds_bytes(B.n_part), s, o, n_reads, B.n_part, part_cursor, rec1,
                        acount);
     launch_partition_rest(B, n_reads, acount, rec1, rec2, ev_off, ev, s);
-    hipLaunchKernelGGL(query_side_kernel, dim3((uint32_t)((o.n + 255) / 256)), dim3(256), 0, s, o, n_reads, (const uint32_t*)ev_off, written, ev);
+    // (overlaps per thread: two - 1.27 against 1.31 ms for the stage at C3 in two of three alternations, four: the same as one;
+    // RALA_QUERY_PER for the measurement)
+    static const int q_per = getenv("RALA_QUERY_PER") ? atoi(getenv("RALA_QUERY_PER")) : 2;
+    if (q_per == 4) hipLaunchKernelGGL(query_side_kernel<4>, dim3((uint32_t)((o.n + 1023) / 1024)), dim3(256), 0, s, o, n_reads, (const uint32_t*)ev_off, written, ev);
+    else if (q_per == 2) hipLaunchKernelGGL(query_side_kernel<2>, dim3((uint32_t)((o.n + 511) / 512)), dim3(256), 0, s, o, n_reads, (const uint32_t*)ev_off, written, ev);
+    else hipLaunchKernelGGL(query_side_kernel<1>, dim3((uint32_t)((o.n + 255) / 256)), dim3(256), 0, s, o, n_reads, (const uint32_t*)ev_off, written, ev);
     return hipGetLastError();
 }
 
