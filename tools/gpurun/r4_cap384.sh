@@ -1,3 +1,5 @@
+# RECORD of a round-4 measurement: the variant it switches on was removed from the tree after the measurement (results in
+# DESIGN.md section 4, "Round 4"); the script is kept for what it measured and how.
 # pile kernel: the first kernel for 384 events per read at eight wavefronts per SIMD (5 056 B of LDS, 63 registers;
 # RALA_PILE_CAP384) against 512 events at seven, one box
 cd $GRAFT_REPO_ROOT

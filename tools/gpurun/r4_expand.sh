@@ -1,3 +1,5 @@
+# RECORD of a round-4 measurement: the variant it switches on was removed from the tree after the measurement (results in
+# DESIGN.md section 4, "Round 4"); the script is kept for what it measured and how.
 # pile kernel on one box: the kernel's register count alone (variant 5 = variant 1 + a clobber of v71: 72 registers instead of
 # 59, seven wavefronts per SIMD by registers as well as by LDS)
 cd $GRAFT_REPO_ROOT

@@ -1,3 +1,5 @@
+# RECORD of a round-4 measurement: the variant it switches on was removed from the tree after the measurement (results in
+# DESIGN.md section 4, "Round 4"); the script is kept for what it measured and how.
 # TIMING ONLY (the reads with 385 .. 512 events are processed by nobody): what an eighth wavefront per SIMD would bring the
 # first pile kernel if its LDS footprint fell to 5 120 B with the event cap unchanged.  RALA_PILE_PROBE_CAP: the 512-event
 # kernel skips those reads as well (the same work at seven wavefronts); + RALA_PILE_PROBE8: the 384-event instantiation, eight.

@@ -1,3 +1,5 @@
+# RECORD of a round-4 measurement: the variant it switches on was removed from the tree after the measurement (results in
+# DESIGN.md section 4, "Round 4"); the script is kept for what it measured and how.
 # first pile kernel, plain front end: the read's offsets by the scalar unit (RALA_PILE_SCALAR_META) against the vector path
 cd $GRAFT_REPO_ROOT
 RALA_PILE_SCALAR_META=1 timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_golden.py -m gpu -x -q 2>&1 | tail -2
