@@ -162,6 +162,50 @@ def stage_roofline(stage, n_ovl, sum_len, n_reads, ranks):
     return {"algorithmic_bytes": b, "ms": ms, "achieved": ach, "frac": ach / HBM_PEAK_GBS}
 
 
+def measure_traffic(workload):
+    """HBM bytes of the pile kernel chain per step, measured HERE: two child runs of this command (one step, no baselines)
+    under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `WRITE_SIZE` - separate passes, FETCH_SIZE doubled as
+    /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950 (KB units).  None when the profiler is not there or a pass
+    fails: the line then replays profiles/pmc_latest.json and says so."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    py = shutil.which("python3")
+    if not os.path.exists(exe) or not py:
+        return None
+    kb = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="rala_pmc_", dir="/tmp")
+        try:
+            env = dict(os.environ, TMPDIR="/tmp", RALA_BENCH_CHILD="1")
+            # (the program itself behind `--`, nothing that re-executes: the profiler's library is in the process from the start)
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--", py,
+                   os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-e2e", "--no-traffic",
+                   "--workload", workload]
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300, check=True)
+            total, seen = 0.0, False
+            for f in glob.glob(os.path.join(d, "*", "*counter_collection.csv")):
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        name = row.get("Kernel_Name", "")
+                        if row.get("Counter_Name") == counter and ("pile_runs_kernel" in name or "pile_build_annotate" in name):
+                            total += float(row["Counter_Value"])
+                            seen = True
+            if not seen:
+                return None
+            kb[counter] = total
+        except Exception as e:      # noqa: BLE001 - the line stands without it
+            log("[bench] traffic pass %s failed: %s" % (counter, e))
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return (2.0 * kb["FETCH_SIZE"] + kb["WRITE_SIZE"]) * 1024.0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -170,6 +214,8 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("RALA_BENCH_WORKLOAD", "c3"), choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end-from-PAF figure (it writes the data set as text first)")
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="do not measure roofline.traffic here (two one-step child runs under rocprofv3 --pmc); replay profiles/pmc_latest.json")
     ap.add_argument("--transport", default=os.environ.get("RALA_COMM", "rccl"), choices=("rccl", "local"),
                     help="ranks as threads only: RCCL (default) or the in-process transport (peer copies)")
     ap.add_argument("--devices", default=os.environ.get("RALA_GPU_DEVICES", ""),
@@ -422,6 +468,16 @@ def main():
             out["sensitive_pass"] = sens_info
         if not sharded:
             ctx.close()                 # the end-to-end run creates a context of its own: give the memory back first
+        # (the full run only - what the driver launches; the quick runs of tests and measurement scripts pass --no-cpu-baseline -
+        # and not inside a profiler)
+        under_profiler = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)
+        if (not args.no_traffic and not args.no_cpu_baseline and not sharded and world == 1 and not under_profiler and
+                not os.environ.get("RALA_BENCH_CHILD")):
+            measured = measure_traffic(args.workload)
+            if measured is not None:
+                out["roofline"]["traffic"] = measured
+                out["roofline"]["traffic_source"] = ("measured in this run: two one-step child runs of this command under rocprofv3 --kernel-trace "
+                                                     "--pmc FETCH_SIZE / WRITE_SIZE (separate passes; FETCH_SIZE doubled, gfx950), pile kernel chain")
         if not args.no_e2e and world == 1 and not sharded:
             try:
                 out["end_to_end_from_paf"] = end_to_end_from_paf(ds, args.workload)
