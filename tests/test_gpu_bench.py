@@ -129,3 +129,18 @@ def test_one_process_per_gpu_launch():
     assert a["transport"] == "rccl" and a["rccl_ranks"] == 1 and a["n_gpus"] == 1 and a["stage_ms"]["exchange_ms"] > 0
     assert b["sensitive_pass"]["n_sensitive"] > 100_000 and b["sensitive_pass"]["ms"] > 0
     assert b["config"]["transitive_pairs"] != a["config"]["transitive_pairs"]
+
+
+def test_traffic_is_measured_in_the_run():
+    """roofline.traffic of the full bench run: two one-step child runs of bench.py under rocprofv3 --pmc (bench.measure_traffic),
+    the pile kernels' FETCH_SIZE (doubled, gfx950) + WRITE_SIZE.  C2: 100 k reads of 1 Gbase, 5.09 M overlaps - 2.09 GB
+    algorithmic (16 B per overlap + 2 B per base + 40 B per read)."""
+    import shutil
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    assert shutil.which("rocprofv3") or os.path.exists("/opt/rocm/bin/rocprofv3"), "no rocprofv3 on this box"
+    t = bench.measure_traffic("c2")
+    assert t is not None, "the PMC passes failed"
+    assert 1.9e9 < t < 2.8e9, t
