@@ -38,7 +38,9 @@ enum {
     RALA_HIP_EINVAL = -2,     /* bad argument or call order */
     RALA_HIP_ECAPACITY = -3,  /* a fixed-capacity device list overflowed (raise via rala_hip_set_option) */
     RALA_HIP_EFILTERED = -4,  /* "filtered all sequences" (src/graph.cpp:418-421) */
-    RALA_HIP_ENOMEM = -5
+    RALA_HIP_ENOMEM = -5,
+    RALA_HIP_ENOTAFILE = -6,  /* the device tokeniser wants a regular file (a FIFO, a process substitution: take the host reader) */
+    RALA_HIP_ETOOLARGE = -7   /* beyond the device tokeniser's 32-bit chunk / row counts (take the host reader) */
 };
 
 /* rala::OverlapType (src/overlap.hpp:27-33) */
@@ -90,10 +92,10 @@ const char* rala_hip_last_error(const rala_hip_ctx* ctx);
  * "use_round_batches" (default 1: the containment fixed point of the second pass is finished on the device after two
  * rounds; 0 makes the host look at the killer list after every round), "use_partitioned_buckets" (default 1; 0 buckets the
  * target side through fixed slots), "debug_fp_lds_limit" (tests: containment fixed points with more killers than this
- * take the kernel for lists that do not fit the LDS), "use_bound_records" (default 1; sharded runs: 0 ships two bound tuples
- * per overlap side instead of one bound record),
- * "pile_persistent_grid" (default 0 = one workgroup per read in the first pile kernel; n > 0 = n persistent workgroups,
- * each looping over its share of the reads with the next read's events requested one read ahead - measured, no gain),
+ * take the kernel for lists that do not fit the LDS), "use_fused_emit" (default 1; sharded runs: the senders scatter the
+ * bounds once, by (owner, partition of the owner's reads), and the owners start at the second level of the partitioned
+ * bucketing; 0: bounds grouped by owner only, bucketed by the owner from the start), "use_bound_records" (default 1; sharded
+ * runs without the former: 0 ships two bound tuples per overlap side instead of one bound record),
  * "debug_pile_stop_after" (diagnostics: leave the run-space pile kernel after phase k, 99 = all;
  * 100 * m + k: the same without the row stores (m = 1), tools/phase_probe.py) */
 int rala_hip_set_option(rala_hip_ctx* ctx, const char* key, int64_t value);
@@ -128,6 +130,13 @@ int rala_hip_set_name_table(rala_hip_ctx* ctx, const void* buckets, uint64_t n_b
 int rala_hip_set_overlaps_from_paf(rala_hip_ctx* ctx, const char* path, int check_lengths, uint32_t threads,
                                    int64_t* length_error_read, int* irregular);
 int rala_hip_get_ingest_timings(rala_hip_ctx* ctx, rala_hip_ingest_timings* out);
+/* The sensitive overlaps (rala -s; Graph::preprocess, src/graph.cpp:901-939) of an uncompressed PAF file the same way, without
+ * the length check (Overlap::transmute_ has none, src/overlap.cpp:84-114): the lines that start in bytes [lo, hi) of the file
+ * (hi = ~0: to its end; a rank of a sharded run takes a share - any split of the sensitive set will do).  *out receives DEVICE
+ * pointers that stay the context's (valid until the next call): hand them to rala_hip_construct / rala_hip_mg_run with the
+ * option "sensitive_in_device_memory" set.  *irregular != 0: nothing was set, take the host reader. */
+int rala_hip_tokenise_sensitive_paf(rala_hip_ctx* ctx, const char* path, uint64_t lo, uint64_t hi, uint32_t threads,
+                                    rala_hip_overlaps* out, uint64_t* n, int* irregular);
 /* the context's overlap columns, wherever they came from, into host buffers (*n entries each; cols / strand may be NULL to
  * ask for the count alone): a_id, b_id, a_begin, a_end, b_begin, b_end, length */
 int rala_hip_get_overlap_columns(rala_hip_ctx* ctx, uint64_t* n, uint32_t* const cols[7], uint8_t* strand);
@@ -273,6 +282,17 @@ int rala_hip_mg_set_reads(rala_hip_mg* mg, const uint32_t* read_len, uint64_t n_
 int rala_hip_mg_slice_cuts(const uint32_t* a_id, const uint32_t* b_id, uint64_t n, uint32_t world, uint64_t* cuts);
 /* this rank's slice; first = file position of its record 0 */
 int rala_hip_mg_set_overlaps(rala_hip_mg* mg, const rala_hip_overlaps* slice, uint64_t n, uint64_t first, int mem);
+/* The same from PAF TEXT (an uncompressed file), collective: rank k ships bytes [n k / P, n (k + 1) / P) of the file to its own
+ * GPU and tokenises the lines that start there (rala_hip_set_overlaps_from_paf's kernels; the name table and the reads must be
+ * set on rala_hip_mg_context(mg)); the ranks exchange their row counts and the queries at their ends, compute the same cuts
+ * between runs of equal queries (rala_hip_mg_slice_cuts' rule) and move the rows in front of the cuts to the rank that holds
+ * the run's start.  Replaces, for N GPUs, bioparser's parser in front of Graph::initialize (src/graph.cpp:328-382).
+ * *length_error_read, *irregular: as rala_hip_set_overlaps_from_paf (the same values on every rank). */
+int rala_hip_mg_set_overlaps_from_paf(rala_hip_mg* mg, const char* path, int check_lengths, uint32_t threads, int64_t* length_error_read,
+                                      int* irregular);
+/* the rank's slice as it was set: file position of its record 0, records (the columns: rala_hip_get_overlap_columns on
+ * rala_hip_mg_context(mg)) */
+int rala_hip_mg_get_slice(rala_hip_mg* mg, uint64_t* first, uint64_t* n);
 /* Graph::construct + remove_transitive_edges (src/graph.cpp:427-640, :1281-1335); sens_slice = this
  * rank's share of the sensitive overlaps (any contiguous share, n_sens = 0 allowed; NULL on EVERY
  * rank for a run without them - ranks that disagree get RALA_HIP_EINVAL).  A failure of one rank

@@ -292,7 +292,10 @@ __global__ __launch_bounds__(kBlockP) void l1_scatter_records_kernel(const uint6
 }
 
 // ---- level 2: inside every partition, groups of 128 reads; tiles that do not cross a partition -------
-__global__ __launch_bounds__(kBlockP) void l2_scatter_kernel(const uint64_t* __restrict__ rec1, const uint32_t* __restrict__ tile_part,
+// (tile_part's top bit: the tile lies behind rec1b - an owner rank's own block, which stays in its send buffer)
+constexpr uint32_t kTileOtherBase = 0x80000000u;
+__global__ __launch_bounds__(kBlockP) void l2_scatter_kernel(const uint64_t* __restrict__ rec1, const uint64_t* __restrict__ rec1b,
+                                                             const uint32_t* __restrict__ tile_part,
                                                              const uint32_t* __restrict__ tile_lo, const uint32_t* __restrict__ tile_hi,
                                                              const uint32_t* __restrict__ n_tiles, uint32_t* group_cursor,
                                                              uint64_t* __restrict__ rec2) {
@@ -300,7 +303,9 @@ __global__ __launch_bounds__(kBlockP) void l2_scatter_kernel(const uint64_t* __r
     __shared__ uint32_t tmp[kBlockP / 64 + 1];
     if (blockIdx.x >= *n_tiles) return;
     StageLds L(s_raw, kGroupsPerPart);
-    const uint32_t part = tile_part[blockIdx.x], lo = tile_lo[blockIdx.x], hi = tile_hi[blockIdx.x];
+    const uint32_t part_word = tile_part[blockIdx.x], lo = tile_lo[blockIdx.x], hi = tile_hi[blockIdx.x];
+    const uint32_t part = part_word & ~kTileOtherBase;
+    const uint64_t* __restrict__ src = (part_word & kTileOtherBase) ? rec1b : rec1;
     uint64_t rec[kPer];
     uint32_t bin[kPer];
     bool in[kPer];
@@ -308,7 +313,7 @@ __global__ __launch_bounds__(kBlockP) void l2_scatter_kernel(const uint64_t* __r
     for (uint32_t u = 0; u < kPer; ++u) {
         const uint32_t j = lo + u * kBlockP + threadIdx.x;
         in[u] = j < hi;
-        rec[u] = in[u] ? rec1[j] : 0ull;
+        rec[u] = in[u] ? src[j] : 0ull;
         bin[u] = rec_key(rec[u]) >> kGroupShift;
     }
     stage_and_copy(L, kGroupsPerPart, rec, bin, in, group_cursor + part * kGroupsPerPart, rec2, tmp);
@@ -369,7 +374,7 @@ __global__ __launch_bounds__(kBlockP) void final_kernel(const uint64_t* __restri
         // the reads' rows: query-side pairs, then target-side pairs; offsets in events (two per pair)
         const uint32_t r = g * kGroupReads + threadIdx.x;
         const bool mine = threadIdx.x < kGroupReads && r < n_reads;
-        const uint32_t q = mine ? acount[r] : 0u;
+        const uint32_t q = mine && acount ? acount[r] : 0u;
         const uint32_t pairs = mine ? q + s_cnt[threadIdx.x] : 0u;
         uint32_t tot;
         const uint32_t before = pair_base[g] + block_scan_excl<(int)kBlockP>(pairs, OpAdd(), 0u, tmp, tot);
@@ -428,6 +433,166 @@ __global__ __launch_bounds__(256) void query_side_kernel(OvlSoA o, uint32_t n_re
     }
 }
 
+
+// ---- sharded runs: ONE scatter on the sender, by (owner rank, partition of the owner's reads) ------------------------
+// Read r is local read r / P of rank r % P.  A rank used to group the bounds of its slice by owner, ship them, and the
+// owner partitioned what it received from level 1 on (count, l1 scatter): the same records scattered twice, counted
+// twice.  owner = read % P and partition = (read / P) >> 12 are both functions of the read, so the sender scatters once
+// into P * n_part bins (as many as the level-1 bins of one GPU), both sides of every overlap as records
+// {local read & 4095 : 12 | begin : 26 | end : 26}; an owner's block is [header: its groups' record counts][its records,
+// partition by partition].  The owner adds up the headers (the groups' places at level 2, the table of level-2 tiles over
+// the blocks as they lie in the receive buffer - no tile crosses a (sender, partition) segment) and starts at the level-2
+// scatter; no pass over the received records counts anything.
+__global__ __launch_bounds__(kBlockC) void shard_count_kernel(OvlSoA o, uint32_t n_reads, uint32_t world, uint32_t groups,
+                                                              uint32_t n_bins, uint32_t* group_count) {
+    extern __shared__ uint32_t s_hist[];
+    for (uint32_t g = threadIdx.x; g < n_bins; g += kBlockC) s_hist[g] = 0;
+    __syncthreads();
+    constexpr uint32_t kC = kCountPer;
+    const uint64_t last = o.n - 1;
+    for (uint64_t i0 = (uint64_t)blockIdx.x * kBlockC * kC; i0 < o.n; i0 += (uint64_t)gridDim.x * kBlockC * kC) {
+        uint32_t a[kC], b[kC];
+#pragma unroll
+        for (uint32_t u = 0; u < kC; ++u) {
+            const uint64_t i = i0 + u * kBlockC + threadIdx.x;
+            const uint64_t j = i < o.n ? i : last;
+            a[u] = i < o.n ? __builtin_nontemporal_load(o.a_id + j) : kInf;
+            b[u] = __builtin_nontemporal_load(o.b_id + j);
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < kC; ++u) {
+            if (a[u] < n_reads && b[u] < n_reads) {
+                atomicAdd(&s_hist[(a[u] % world) * groups + ((a[u] / world) >> kGroupShift)], 1u);
+                atomicAdd(&s_hist[(b[u] % world) * groups + ((b[u] / world) >> kGroupShift)], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t g = threadIdx.x; g < n_bins; g += kBlockC) {
+        const uint32_t c = s_hist[g];
+        if (c) atomicAdd(&group_count[g], c);
+    }
+}
+
+// The blocks of the send buffer (8-byte words): block p = header (g.header words: the counts of owner p's groups, two per
+// word) + owner p's records; part_cursor[p * n_part + q] = where partition q of owner p starts; send_words[p] = the
+// block's length.  One workgroup.
+__global__ __launch_bounds__(1024) void shard_send_layout_kernel(const uint32_t* __restrict__ group_count, ShardGeometry g,
+                                                                 uint64_t* __restrict__ send, uint32_t* __restrict__ part_cursor,
+                                                                 uint32_t* __restrict__ send_words) {
+    __shared__ uint32_t tmp[1024 / 64 + 1];
+    uint32_t block_start = 0;
+    for (uint32_t p = 0; p < g.world; ++p) {
+        uint32_t* header = (uint32_t*)(send + block_start);
+        uint32_t carry = block_start + g.header;
+        for (uint32_t g0 = 0; g0 < g.groups; g0 += 1024) {
+            const uint32_t k = g0 + threadIdx.x;
+            const uint32_t c = k < g.groups ? group_count[p * g.groups + k] : 0u;
+            uint32_t tot;
+            const uint32_t ex = block_scan_excl<1024>(c, OpAdd(), 0u, tmp, tot);
+            if (k < g.groups) {
+                header[k] = c;
+                if (k % kGroupsPerPart == 0) part_cursor[p * g.n_part + k / kGroupsPerPart] = carry + ex;
+            }
+            carry += tot;
+        }
+        if (threadIdx.x == 0) send_words[p] = carry - block_start;
+        block_start = carry;
+    }
+}
+
+// both sides of kTile / 2 overlaps = kTile records, sorted by (owner, partition) in LDS and copied out bin by bin
+__global__ __launch_bounds__(kBlockP) void shard_l1_scatter_kernel(OvlSoA o, uint32_t n_reads, uint32_t world, uint32_t n_part,
+                                                                   uint32_t* part_cursor, uint64_t* __restrict__ send) {
+    extern __shared__ __align__(16) unsigned char s_raw[];
+    __shared__ uint32_t tmp[kBlockP / 64 + 1];
+    const uint32_t n_bins = world * n_part;
+    StageLds L(s_raw, n_bins);
+    uint64_t rec[kPer];
+    uint32_t bin[kPer];
+    bool in[kPer];
+    const uint64_t last = o.n - 1;
+    static_assert(kPer % 2 == 0, "two records per overlap");
+#pragma unroll
+    for (uint32_t u = 0; u < kPer / 2; ++u) {
+        const uint64_t i = (uint64_t)blockIdx.x * (kTile / 2) + u * kBlockP + threadIdx.x;
+        const uint64_t j = i < o.n ? i : last;
+        const uint32_t a = o.a_id[j], b = o.b_id[j];
+        const bool ok = i < o.n && a < n_reads && b < n_reads;
+        const uint32_t la = a / world, lb = b / world;
+        in[2 * u] = in[2 * u + 1] = ok;
+        rec[2 * u] = pack_record(la, __builtin_nontemporal_load(o.a_begin + j), __builtin_nontemporal_load(o.a_end + j));
+        rec[2 * u + 1] = pack_record(lb, __builtin_nontemporal_load(o.b_begin + j), __builtin_nontemporal_load(o.b_end + j));
+        bin[2 * u] = ok ? (a - la * world) * n_part + (la >> kL1Shift) : 0u;
+        bin[2 * u + 1] = ok ? (b - lb * world) * n_part + (lb >> kL1Shift) : 0u;
+    }
+    stage_and_copy(L, n_bins, rec, bin, in, part_cursor, send, tmp);
+}
+
+// The owner's side.  blocks.off[p]: where rank p's block lies (8-byte words from `base`).  Out: group_base[0 .. groups]
+// and group_cursor = exclusive prefix of the groups' record counts summed over the senders; the table of level-2 tiles -
+// tile t covers words tile_lo[t] .. tile_hi[t] of `base`, all of partition tile_part[t] and of one sender; *n_tiles.
+// pair_pref: world * n_part + 1 words of scratch.  One workgroup.
+__global__ __launch_bounds__(1024) void shard_owner_layout_kernel(const uint64_t* __restrict__ base, const uint64_t* __restrict__ base_self,
+                                                                  ShardBlocks blocks, ShardGeometry g,
+                                                                  uint32_t* __restrict__ group_base, uint32_t* __restrict__ group_cursor,
+                                                                  uint32_t* __restrict__ pair_pref, uint32_t* __restrict__ tile_part,
+                                                                  uint32_t* __restrict__ tile_lo, uint32_t* __restrict__ tile_hi,
+                                                                  uint32_t* n_tiles) {
+    __shared__ uint32_t tmp[1024 / 64 + 1];
+    auto header_of = [&](uint32_t p) { return (const uint32_t*)((p == blocks.self ? base_self : base) + blocks.off[p]); };
+    uint32_t carry = 0;
+    for (uint32_t g0 = 0; g0 < g.groups; g0 += 1024) {
+        const uint32_t k = g0 + threadIdx.x;
+        uint32_t c = 0;
+        if (k < g.groups) {
+            for (uint32_t p = 0; p < g.world; ++p) c += header_of(p)[k];
+        }
+        uint32_t tot;
+        const uint32_t ex = block_scan_excl<1024>(c, OpAdd(), 0u, tmp, tot);
+        if (k < g.groups) { group_base[k] = carry + ex; group_cursor[k] = carry + ex; }
+        carry += tot;
+    }
+    if (threadIdx.x == 0) group_base[g.groups] = carry;
+    // (sender, partition) segments: their lengths, an exclusive prefix over all of them
+    const uint32_t n_pairs = g.world * g.n_part;
+    uint32_t pcarry = 0;
+    for (uint32_t j0 = 0; j0 < n_pairs; j0 += 1024) {
+        const uint32_t j = j0 + threadIdx.x;
+        uint32_t len = 0;
+        if (j < n_pairs) {
+            const uint32_t* header = header_of(j / g.n_part) + (j % g.n_part) * kGroupsPerPart;
+            for (uint32_t k = 0; k < kGroupsPerPart; ++k) len += header[k];
+        }
+        uint32_t tot;
+        const uint32_t ex = block_scan_excl<1024>(len, OpAdd(), 0u, tmp, tot);
+        if (j < n_pairs) pair_pref[j] = pcarry + ex;
+        pcarry += tot;
+    }
+    if (threadIdx.x == 0) pair_pref[n_pairs] = pcarry;
+    __syncthreads();
+    uint32_t tile_carry = 0;
+    for (uint32_t j0 = 0; j0 < n_pairs; j0 += 1024) {
+        const uint32_t j = j0 + threadIdx.x;
+        uint32_t lo = 0, len = 0, tiles = 0;
+        if (j < n_pairs) {
+            const uint32_t p = j / g.n_part;
+            len = pair_pref[j + 1] - pair_pref[j];
+            lo = blocks.off[p] + g.header + (pair_pref[j] - pair_pref[p * g.n_part]);
+            tiles = (len + kTile - 1) / kTile;
+        }
+        uint32_t ttot;
+        const uint32_t tex = block_scan_excl<1024>(tiles, OpAdd(), 0u, tmp, ttot);
+        for (uint32_t k = 0; k < tiles; ++k) {
+            tile_part[tile_carry + tex + k] = (j % g.n_part) | (j / g.n_part == blocks.self ? kTileOtherBase : 0u);
+            tile_lo[tile_carry + tex + k] = lo + k * kTile;
+            tile_hi[tile_carry + tex + k] = umin(lo + len, lo + (k + 1u) * kTile);
+        }
+        tile_carry += ttot;
+    }
+    if (threadIdx.x == 0) *n_tiles = tile_carry;
+}
+
 }  // namespace
 
 uint32_t partition_count(uint32_t n_reads) { return (n_reads + kL1Reads - 1) / kL1Reads; }
@@ -475,7 +640,7 @@ hipError_t count_attribute(size_t lds_count) {
 void launch_partition_rest(const PartitionBuffers& B, uint32_t n_reads, const uint32_t* acount, const uint64_t* rec1, uint64_t* rec2,
                            uint32_t* ev_off, uint32_t* ev, hipStream_t s, uint32_t shrink = 15u) {
     const uint32_t tiles2 = (uint32_t)(B.tile_slots - 4);               // at least as many as the table can hold
-    hipLaunchKernelGGL(l2_scatter_kernel, dim3(tiles2), dim3(kBlockP), stage_lds_bytes(kGroupsPerPart), s, rec1,
+    hipLaunchKernelGGL(l2_scatter_kernel, dim3(tiles2), dim3(kBlockP), stage_lds_bytes(kGroupsPerPart), s, rec1, (const uint64_t*)nullptr,
                        (const uint32_t*)B.tile_part, (const uint32_t*)B.tile_lo, (const uint32_t*)B.tile_hi, (const uint32_t*)B.n_tiles,
                        B.group_cursor, rec2);
     // (the groups' counts and cursors have served: their places take the query-side sums and the groups' first pairs)
@@ -554,5 +719,81 @@ hipError_t launch_bucket_partitioned_records(const uint64_t* records, uint64_t n
 bool partition_path_fits_records(uint32_t n_reads, uint32_t max_read_len, uint64_t n_records) {
     return max_read_len < (1u << kBoundRecordCoordBits) - 32u && partition_path_fits(n_reads, max_read_len, (n_records + 1) / 2);
 }
+
+// ---- sharded runs (kernels above) --------------------------------------------------------------------------------------
+ShardGeometry shard_geometry(uint64_t n_reads, uint32_t world) {
+    ShardGeometry g;
+    g.world = world;
+    const uint64_t most = (n_reads + world - 1) / world;                 // rank 0 owns the most reads
+    g.n_part = (uint32_t)std::max<uint64_t>(1, (most + kL1Reads - 1) / kL1Reads);
+    g.groups = g.n_part * kGroupsPerPart;
+    g.header = g.groups / 2;
+    return g;
+}
+bool shard_path_fits(uint64_t n_reads, uint32_t max_read_len, uint32_t world) {
+    // the same answer on every rank: nothing here depends on a rank's slice
+    if (n_reads == 0 || world == 0 || world > 64 || n_reads >= 0x7FFFFFFFull) return false;
+    const ShardGeometry g = shard_geometry(n_reads, world);
+    return max_read_len < kCoordMax - 32u && (uint64_t)g.world * g.groups * 4u <= 150u * 1024u &&
+           stage_lds_bytes(g.world * g.n_part) <= 60u * 1024u;
+}
+size_t shard_send_words(const ShardGeometry& g, uint64_t n_overlaps) { return 2 * (size_t)n_overlaps + (size_t)g.world * g.header + 64; }
+size_t shard_tile_slots(const ShardGeometry& g, uint64_t n_records) { return (size_t)(n_records / kTile) + (size_t)g.world * g.n_part + 4; }
+
+// group_count: world * groups words (cleared here, through `fills`); part_cursor: world * n_part words; send:
+// shard_send_words(); send_words: world words (the blocks' lengths, for the host)
+hipError_t launch_shard_emit(const OvlSoA& o, uint32_t n_reads, const ShardGeometry& g, uint32_t* group_count, uint32_t* part_cursor,
+                             uint64_t* send, uint32_t* send_words, uint32_t workgroups, FillList& fills, hipStream_t s) {
+    const uint32_t n_bins = g.world * g.groups;
+    fills.add(group_count, 0, (size_t)n_bins * 4);
+    hipError_t e = fills.launch(s);
+    if (e != hipSuccess) return e;
+    const size_t lds_count = (size_t)n_bins * 4;
+    if (lds_count > 64 * 1024) {
+        e = hipFuncSetAttribute((const void*)shard_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_count);
+        if (e != hipSuccess) return e;
+    }
+    if (o.n) {
+        const uint32_t chunks = (uint32_t)((o.n + kBlockC * kCountPer - 1) / (kBlockC * kCountPer));
+        const uint32_t count_groups = (workgroups ? workgroups : 256u) * (2 * lds_count <= 150u * 1024u ? 2u : 1u);
+        hipLaunchKernelGGL(shard_count_kernel, dim3(std::min<uint32_t>(count_groups, chunks)), dim3(kBlockC), lds_count, s, o, n_reads,
+                           g.world, g.groups, n_bins, group_count);
+    }
+    hipLaunchKernelGGL(shard_send_layout_kernel, dim3(1), dim3(1024), 0, s, (const uint32_t*)group_count, g, send, part_cursor, send_words);
+    if (o.n) {
+        const uint32_t tiles1 = (uint32_t)((o.n + kTile / 2 - 1) / (kTile / 2));
+        hipLaunchKernelGGL(shard_l1_scatter_kernel, dim3(tiles1), dim3(kBlockP), stage_lds_bytes(g.world * g.n_part), s, o, n_reads, g.world,
+                           g.n_part, part_cursor, send);
+    }
+    return hipGetLastError();
+}
+
+// The owner: the blocks as they lie behind `base` -> the exact CSR of its n_reads_local reads.  group: 3 *
+// (g.groups + 2) words + g.world * g.n_part + 2 (bases, cursors, the segments' prefix); tiles: 3 * shard_tile_slots() + 2 words;
+// rec2: n_records + 64 records; ev_off: n_reads_local + 2; ev: 2 * n_records + 8.
+hipError_t launch_bucket_from_blocks(const uint64_t* base, const uint64_t* base_self, const ShardBlocks& blocks, const ShardGeometry& g,
+                                     uint32_t n_reads_local,
+                                     uint64_t n_records, uint32_t* group, uint32_t* tiles, uint64_t* rec2, uint32_t* ev_off, uint32_t* ev,
+                                     FillList& fills, hipStream_t s) {
+    hipError_t e = fills.launch(s);
+    if (e != hipSuccess) return e;
+    const uint32_t slots = g.groups + 2;
+    uint32_t *group_base = group, *group_cursor = group + slots, *pair_pref = group + 2 * (size_t)slots;
+    const size_t tile_slots = shard_tile_slots(g, n_records);
+    uint32_t *tile_part = tiles, *tile_lo = tiles + tile_slots, *tile_hi = tiles + 2 * tile_slots, *n_tiles = tiles + 3 * tile_slots;
+    hipLaunchKernelGGL(shard_owner_layout_kernel, dim3(1), dim3(1024), 0, s, base, base_self, blocks, g, group_base, group_cursor, pair_pref, tile_part,
+                       tile_lo, tile_hi, n_tiles);
+    hipLaunchKernelGGL(l2_scatter_kernel, dim3((uint32_t)(tile_slots - 4)), dim3(kBlockP), stage_lds_bytes(kGroupsPerPart), s, base, base_self,
+                       (const uint32_t*)tile_part, (const uint32_t*)tile_lo, (const uint32_t*)tile_hi, (const uint32_t*)n_tiles, group_cursor,
+                       rec2);
+    // (every event is a record's: the groups' first pairs are the groups' first records)
+    const uint32_t n_groups = (n_reads_local + kGroupReads - 1) / kGroupReads;
+    if (n_groups) {
+        hipLaunchKernelGGL(final_kernel, dim3(n_groups), dim3(kBlockP), stage_lds_bytes(kGroupReads), s, (const uint64_t*)rec2,
+                           (const uint32_t*)group_base, (const uint32_t*)group_base, n_reads_local, (const uint32_t*)nullptr, ev_off, ev, 15u);
+    }
+    return hipGetLastError();
+}
+size_t shard_group_words(const ShardGeometry& g) { return 3 * ((size_t)g.groups + 2) + (size_t)g.world * g.n_part + 2; }
 
 }  // namespace rala_hip

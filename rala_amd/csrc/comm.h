@@ -35,9 +35,11 @@ public:
     // rank 0's values, then rank 1's, ...  Blocks until done.
     virtual int host_all_gather(const uint64_t* mine, uint32_t n, uint64_t* all, hipStream_t s) = 0;
     // elements of elem_bytes; send holds the part for rank 0, then rank 1, ... (send_counts[world]);
-    // recv receives the parts from rank 0, 1, ... (recv_counts[world], known from a host exchange)
+    // recv receives the parts from rank 0, 1, ... (recv_counts[world], known from a host exchange).
+    // own_part = false: the rank's part for itself stays where it is - it is neither copied nor given room in recv
+    // (recv_counts[rank] is ignored)
     virtual int all_to_all_v(const void* send, const uint64_t* send_counts, void* recv, const uint64_t* recv_counts,
-                             size_t elem_bytes, hipStream_t s) = 0;
+                             size_t elem_bytes, hipStream_t s, bool own_part = true) = 0;
     // every rank contributes `bytes` bytes; recv = world * bytes
     virtual int all_gather(const void* send, void* recv, size_t bytes, hipStream_t s) = 0;
     // rank k contributes counts[k] elements; recv holds them back to back in rank order

@@ -155,7 +155,7 @@ public:
     }
 
     int all_to_all_v(const void* send, const uint64_t* send_counts, void* recv, const uint64_t* recv_counts,
-                     size_t elem_bytes, hipStream_t s) override {
+                     size_t elem_bytes, hipStream_t s, bool own_part) override {
         size_t so = 0, ro = 0, self_so = 0, self_ro = 0;
         std::unique_lock<std::timed_mutex> call(call_m_);
         const ncclComm_t comm = live();
@@ -163,7 +163,8 @@ public:
         if (!ok(api_->GroupStart(), "ncclGroupStart")) return -1;
         bool good = true;                               // (a group that was opened is always closed)
         for (uint32_t p = 0; p < world_ && good; ++p) {
-            const size_t sb = (size_t)send_counts[p] * elem_bytes, rb = (size_t)recv_counts[p] * elem_bytes;
+            const size_t sb = (size_t)send_counts[p] * elem_bytes;
+            const size_t rb = p == rank_ && !own_part ? 0 : (size_t)recv_counts[p] * elem_bytes;
             if (p == rank_) {
                 self_so = so; self_ro = ro;
             } else {
@@ -173,7 +174,7 @@ public:
             so += sb; ro += rb;
         }
         if (!close_group(good)) return -1;
-        const size_t mine = (size_t)send_counts[rank_] * elem_bytes;
+        const size_t mine = own_part ? (size_t)send_counts[rank_] * elem_bytes : 0;
         if (mine && hipMemcpyAsync((char*)recv + self_ro, (const char*)send + self_so, mine, hipMemcpyDeviceToDevice, s) != hipSuccess) {
             return fail("copy of the own part");
         }
@@ -339,12 +340,13 @@ public:
     }
 
     int all_to_all_v(const void* send, const uint64_t* send_counts, void* recv, const uint64_t* recv_counts,
-                     size_t elem_bytes, hipStream_t s) override {
+                     size_t elem_bytes, hipStream_t s, bool own_part) override {
         publish(send, s);
         g_->counts[rank_].assign(send_counts, send_counts + world_);
         if (!meet()) return -1;
         size_t ro = 0;
         for (uint32_t p = 0; p < world_; ++p) {
+            if (p == rank_ && !own_part) continue;
             size_t so = 0;
             for (uint32_t q = 0; q < rank_; ++q) so += (size_t)g_->counts[p][q] * elem_bytes;
             const size_t bytes = (size_t)g_->counts[p][rank_] * elem_bytes;

@@ -95,7 +95,6 @@ struct rala_hip_ctx {
     bool debug_fail_construct = false;          // tests: pass 2 fails on this context
     uint32_t debug_fp_lds_limit = 0xFFFFFFFFu;  // tests: containment fixed points with more killers than this take the long lists' kernel
     bool use_bound_records = true;              // sharded runs: 8-byte bound records instead of two tuples per overlap side where they fit
-    int64_t pile_persistent_grid = -1;          // first pile kernel: persistent workgroups (0 = one per read; -1 = RALA_PILE_PERSIST2 or 0)
     bool use_round_batches = true;              // containment fixed point: several rounds per look at the counter
     rala_hip::DevBuf<uint32_t> d_round_log;     // list sizes after the rounds the host did not look at
 
@@ -149,6 +148,20 @@ struct rala_hip_ctx {
     rala_hip::DevBuf<uint2> d_tuple;
     rala_hip::DevBuf<uint32_t> d_owner_cnt;
     bool piles_resident = false;
+    // sharded runs, the bounds scattered ONCE on the sender (bucket_kernels.hip, "sharded runs").  A sender: the groups'
+    // counts, the partitions' cursors, the blocks' lengths; duplicate removal runs beside the emit on the side stream and is
+    // joined by the second pass (dedupe_pending).  An owner: its input is the blocks of all senders as they lie in the
+    // runner's buffers (blocks_mode, with tuple_mode).
+    bool use_fused_emit = true;
+    rala_hip::DevBuf<uint32_t> d_shard_group, d_shard_part, d_shard_words, d_shard_tiles;
+    bool dedupe_pending = false;
+    bool lists_pending = false;         // a sharded run's survivor lists are being gathered on the side stream (event ev[3])
+    bool blocks_mode = false;
+    const uint64_t* blocks_base = nullptr;
+    const uint64_t* blocks_base_self = nullptr;
+    rala_hip::ShardBlocks blocks = {};
+    rala_hip::ShardGeometry shard_geom = {};
+    uint64_t n_block_records = 0;
 
     // bound CSR
     rala_hip::DevBuf<uint32_t> d_ev_off, d_cursor, d_ev, d_slot_rank[2], d_ev_fixed;

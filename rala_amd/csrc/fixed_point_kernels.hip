@@ -135,32 +135,49 @@ __device__ __forceinline__ void finish_in_lds(uint32_t* lds, const FixedPointLis
 // share a device, other tenants, a partitioned device).  sync[0] counts arrivals (zero at the launch), `phase` the barriers
 // of this launch.  false: somebody gave up waiting (a workgroup that never got a compute unit) - everybody leaves, nobody
 // passes this barrier, and the last workgroup to leave does the rounds alone (fixed_point_wide_kernel).
+//
+// ONE word decides (with a separate "give up" word one workgroup could see the count complete and pass the
+// last barrier while another one's poll limit ran out a poll earlier - the first wrote its share of base[] and returned,
+// never counted as having left, and nobody ran the rounds alone): giving up is a compare-and-swap that sets the top bit of
+// the arrival count WHILE THE COUNT IS SHORT of this barrier's; a workgroup passes iff it reads a complete count without
+// that bit.  The count only grows, so a barrier that anybody has passed cannot be given up on afterwards, and one that
+// was given up on is passed by nobody: all or nothing.  (A later barrier's giving up can fail a slow workgroup at an
+// earlier one; then the fast ones fail at the later one and everything is redone alone - the last barrier of a launch
+// has no later one.)  give_up_now: tests - this workgroup does not wait at all.
 constexpr uint32_t kWideGroups = 32;
+constexpr uint32_t kGaveUp = 0x80000000u;
 // (Everything the workgroups tell each other goes through memory-side atomics, stores and loads: what has to be
 // complete before the arrival is this wavefront's own requests - a wait for its counters, not a fence, which on
 // this device writes the L2 back and invalidates it: 40 us per round with fences.)
-__device__ __forceinline__ bool grid_barrier(uint32_t* sync, uint32_t& phase, uint32_t groups) {
+__device__ __forceinline__ bool grid_barrier(uint32_t* sync, uint32_t& phase, uint32_t groups, bool give_up_now = false) {
+    __shared__ uint32_t s_passed;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
     ++phase;
     if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        uint32_t spins = 0;
-        while (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < phase * groups) {
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1u << 19) || __hip_atomic_load(sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                __hip_atomic_store(sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
+        const uint32_t target = phase * groups;
+        uint32_t v = __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+        uint32_t spins = give_up_now ? (1u << 19) : 0u;
+        while (!(v & kGaveUp) && v < target) {
+            if (++spins > (1u << 19)) {
+                // give up - unless the count has become complete meanwhile (then v says so and the loop ends with a pass)
+                if (__hip_atomic_compare_exchange_strong(sync, &v, v | kGaveUp, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    v |= kGaveUp;
+                }
+                continue;           // (a failed exchange left the current value in v)
             }
+            __builtin_amdgcn_s_sleep(1);
+            v = __hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        s_passed = (v & kGaveUp) ? 0u : 1u;
     }
     __syncthreads();
-    return ld_past_l1(sync + 1) == 0;
+    return s_passed != 0;
 }
 
 // More killers than the LDS holds: X_r in work[r % 4]: round r compares X_(r-1) with X_(r-2), proposes into X_r and
 // resets the targets in the array of X_(r+1) (last read a round ago) - one barrier per round.  sync: eight zeroed
-// words ([0] arrivals, [1] "give up", [4 .. 6] "a value moved" per round % 3).
+// words ([0] arrivals | "given up" in the top bit, [2] workgroups that have left, [4 .. 6] "a value moved" per round % 3).
 // kSolo: one workgroup alone (the barrier is the workgroup's own).  false: a barrier gave up, nothing has been written to base.
 template <bool kSolo>
 __device__ __forceinline__ bool finish_wide(const FixedPointList& list, uint32_t* base, uint32_t* w0, uint32_t* w1, uint32_t* w2,
@@ -176,7 +193,10 @@ __device__ __forceinline__ bool finish_wide(const FixedPointList& list, uint32_t
             __syncthreads();
             return true;
         } else {
-            return grid_barrier(sync, phase, groups);
+            // (tests, debug_give_up: 1 - workgroup 1 does not wait at the first barrier, so nobody passes it; 2 - it does not
+            // wait at any barrier from the second on: it passes those the others have reached and ends the others for everybody)
+            const bool impatient = blockIdx.x == 1 && (list.debug_give_up == 1 ? phase == 0 : list.debug_give_up == 2 && phase >= 1);
+            return grid_barrier(sync, phase, groups, impatient);
         }
     };
     uint32_t* const work[4] = {w0, w1, w2, w3};
@@ -201,9 +221,6 @@ __device__ __forceinline__ bool finish_wide(const FixedPointList& list, uint32_t
             const uint32_t bp = base[ep[u]];
             for (int w = 0; w < 4; ++w) { st_past_l1(work[w] + et[u], eb[u]); st_past_l1(work[w] + ep[u], bp); }
         }
-    }
-    if (list.debug_give_up && !kSolo && blockIdx.x == 1 && threadIdx.x == 0) {
-        __hip_atomic_store(sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // tests: a workgroup that never arrives
     }
     if (!barrier(phase)) return false;
     // (up to 131 072 entries stay in registers over the rounds: one trip to memory less per round)
@@ -281,7 +298,7 @@ hipError_t launch_fixed_point_finish(const FixedPointList& list_in, uint32_t* ba
                                      uint32_t* sync8, uint32_t* error, uint32_t* rounds_out, hipStream_t s) {
     FixedPointList list = list_in;
     list.lds_limit = std::min<uint32_t>(list_in.lds_limit, kLdsEntries);
-    if (getenv("RALA_HIP_DEBUG_FP_GIVE_UP")) list.debug_give_up = 1;     // tests: the long lists' workgroups do not meet
+    if (const char* g = getenv("RALA_HIP_DEBUG_FP_GIVE_UP")) list.debug_give_up = atoi(g) == 2 ? 2u : 1u;     // tests: the long lists' workgroups do not meet
     constexpr size_t lds_bytes = 3 * (size_t)kLdsEntries * 4;
     // (once per DEVICE: the attribute belongs to the function on the current device, and the ranks of a sharded run are
     // threads of one process on different devices.  Every time, it was part of why the host fell behind the device in

@@ -5,7 +5,11 @@
 // The host readers (rala_amd/host/io.cpp) parse 50 M lines in 330 ms on 16 threads - 88 % of the time from PAF text to the
 // reduced graph; the text itself crosses PCIe in 60 ms, and here 50 M lines are 50 M independent threads.
 //
-// Two passes over the text, which lies in device memory as one buffer (a newline behind its last byte):
+// The text of a RANGE of the file lies in device memory as one buffer: the n bytes whose line starts are this launch's, and
+// behind them up to n_avail bytes for the last lines' first eleven columns (n_avail = n at the end of the file, where a
+// newline stands in; a rank of a sharded run tokenises its byte range of the file this way - round 5).  `first_is_start`:
+// the range's first byte starts a line (it does at the start of the file; elsewhere the byte in front of it says).
+// Two passes over the text:
 //   count   per chunk of 16 KB the lines that START in it (a position whose predecessor is a newline - or the first byte
 //           of the file - and that is no newline itself); an exclusive scan gives every chunk its first row
 //   parse   a workgroup per chunk: the chunk and a halo of 2 KB behind it staged in LDS, the line starts listed in order,
@@ -60,7 +64,8 @@ __device__ __forceinline__ uint64_t line_starts(const uint32_t* w, uint64_t j0, 
     return behind & ~nl & valid;
 }
 
-__global__ __launch_bounds__(kBlock) void paf_count_kernel(const uint8_t* __restrict__ text, uint64_t n, uint32_t* __restrict__ chunk_lines) {
+__global__ __launch_bounds__(kBlock) void paf_count_kernel(const uint8_t* __restrict__ text, uint64_t n, uint32_t first_is_start,
+                                                            uint32_t* __restrict__ chunk_lines) {
     __shared__ uint32_t tmp[kBlock / 64 + 1];
     const uint64_t j0 = (uint64_t)blockIdx.x * kChunk + threadIdx.x * kSeg;
     uint32_t w[16];
@@ -72,7 +77,7 @@ __global__ __launch_bounds__(kBlock) void paf_count_kernel(const uint8_t* __rest
             const uint4 v = p[k];
             w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
         }
-        starts = line_starts(w, j0, n, j0 == 0 || text[j0 - 1] == '\n');
+        starts = line_starts(w, j0, n, j0 == 0 ? first_is_start != 0 : text[j0 - 1] == '\n');
     }
     const uint32_t total = block_reduce<(int)kBlock>((uint32_t)__popcll(starts), OpAdd(), 0u, tmp);
     if (threadIdx.x == 0) chunk_lines[blockIdx.x] = total;
@@ -114,7 +119,8 @@ __device__ __forceinline__ uint32_t find_name(const NameTableDev& T, const uint8
     }
 }
 
-__global__ __launch_bounds__(kBlock) void paf_parse_kernel(const uint8_t* __restrict__ text, uint64_t n, const uint32_t* __restrict__ chunk_row,
+__global__ __launch_bounds__(kBlock) void paf_parse_kernel(const uint8_t* __restrict__ text, uint64_t n, uint64_t n_avail, uint32_t first_is_start,
+                                                            const uint32_t* __restrict__ chunk_row,
                                                            NameTableDev names, const uint32_t* __restrict__ read_len, uint32_t n_reads,
                                                            uint32_t check_lengths, PafColumns out, uint32_t* flags,
                                                            unsigned long long* first_bad) {
@@ -127,11 +133,11 @@ __global__ __launch_bounds__(kBlock) void paf_parse_kernel(const uint8_t* __rest
     for (uint32_t v = tid; v < (kChunk + kHalo) / 16; v += kBlock) {
         const uint64_t j = c0 + (uint64_t)v * 16;
         uint4 x = make_uint4(0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au);
-        if (j + 16 <= n) {
+        if (j + 16 <= n_avail) {
             x = *(const uint4*)(text + j);
-        } else if (j < n) {
+        } else if (j < n_avail) {
             uint8_t b[16];
-            for (uint32_t i = 0; i < 16; ++i) b[i] = j + i < n ? text[j + i] : (uint8_t)'\n';
+            for (uint32_t i = 0; i < 16; ++i) b[i] = j + i < n_avail ? text[j + i] : (uint8_t)'\n';
             x = *(const uint4*)b;
         }
         ((uint4*)win)[v] = x;
@@ -145,7 +151,7 @@ __global__ __launch_bounds__(kBlock) void paf_parse_kernel(const uint8_t* __rest
 #pragma unroll
         for (uint32_t k = 0; k < 16; ++k) ww[k] = w[k];
         const uint64_t j0 = c0 + tid * kSeg;
-        const bool prev_nl = j0 == 0 || (tid == 0 ? text[j0 - 1] == '\n' : win[tid * kSeg - 1] == '\n');
+        const bool prev_nl = j0 == 0 ? first_is_start != 0 : (tid == 0 ? text[j0 - 1] == '\n' : win[tid * kSeg - 1] == '\n');
         starts = line_starts(ww, j0, n, prev_nl);
     }
     uint32_t total;
@@ -224,19 +230,21 @@ __global__ __launch_bounds__(kBlock) void paf_parse_kernel(const uint8_t* __rest
 
 uint32_t paf_chunk_bytes() { return kChunk; }
 
-void launch_paf_count(const uint8_t* text, uint64_t n, uint32_t* chunk_lines, hipStream_t s) {
+uint32_t paf_halo_bytes() { return kHalo + 16; }
+
+void launch_paf_count(const uint8_t* text, uint64_t n, bool first_is_start, uint32_t* chunk_lines, hipStream_t s) {
     const uint32_t chunks = (uint32_t)((n + kChunk - 1) / kChunk);
-    if (chunks) hipLaunchKernelGGL(paf_count_kernel, dim3(chunks), dim3(kBlock), 0, s, text, n, chunk_lines);
+    if (chunks) hipLaunchKernelGGL(paf_count_kernel, dim3(chunks), dim3(kBlock), 0, s, text, n, first_is_start ? 1u : 0u, chunk_lines);
 }
 
-void launch_paf_parse(const uint8_t* text, uint64_t n, const uint32_t* chunk_row, const void* buckets, uint64_t n_buckets,
+void launch_paf_parse(const uint8_t* text, uint64_t n, uint64_t n_avail, bool first_is_start, const uint32_t* chunk_row, const void* buckets, uint64_t n_buckets,
                       const char* arena, const uint32_t* read_len, uint32_t n_reads, bool check_lengths, const PafColumns& out,
                       uint32_t* flags, unsigned long long* first_bad, hipStream_t s) {
     const uint32_t chunks = (uint32_t)((n + kChunk - 1) / kChunk);
     NameTableDev T;
     T.bucket = (const NameBucket*)buckets; T.arena = arena; T.mask = n_buckets - 1;
     if (chunks) {
-        hipLaunchKernelGGL(paf_parse_kernel, dim3(chunks), dim3(kBlock), 0, s, text, n, chunk_row, T, read_len, n_reads,
+        hipLaunchKernelGGL(paf_parse_kernel, dim3(chunks), dim3(kBlock), 0, s, text, n, n_avail, first_is_start ? 1u : 0u, chunk_row, T, read_len, n_reads,
                            check_lengths ? 1u : 0u, out, flags, first_bad);
     }
 }

@@ -40,7 +40,6 @@ struct PileArgs {
     uint32_t lw;                   // uint16 elements per big array (>= kPadL + len + 848, multiple of 8)
     uint32_t add_to_existing;
     uint32_t stop_after;           // diagnostics: leave the kernel after phase k (99 = run everything)
-    uint32_t persist_grid = 0;     // first kernel of the first pass: > 0 = that many persistent workgroups (option pile_persistent_grid)
     uint16_t* slab;                // HBM scratch, 3 * lw elements per workgroup (long reads only)
     // outputs, indexed by read
     uint32_t* begin;
@@ -270,6 +269,11 @@ void launch_unpack_rep(const uint64_t* all, uint32_t world, uint64_t nl_pad, uin
                        uint32_t* n_rep, uint32_t* rep_slot, hipStream_t s);
 void launch_pool_aux(Interval* pool, uint32_t n, uint32_t* dense, uint32_t mode, hipStream_t s);
 void launch_death_status(const uint32_t* count, uint32_t* status, hipStream_t s);
+// a rank's undecided killers padded with inert entries to `each` (block: 3 * each words), and all ranks' blocks back into lists
+void launch_pack_killers(const uint32_t* key, const uint32_t* target, const uint32_t* keeper, const uint32_t* count, uint32_t each,
+                         uint32_t* block, hipStream_t s);
+void launch_unpack_killers(const uint32_t* blocks, uint32_t world, uint32_t each, uint32_t* key, uint32_t* target, uint32_t* keeper,
+                           uint32_t* count, hipStream_t s);
 void launch_hill_counts(const ReadState& rs, uint32_t n_reads, uint32_t* dense, uint32_t mode, hipStream_t s);
 void launch_unpack_lists(const uint8_t* blocks, const ListBlocks& lb, const Survivors& out, hipStream_t s);
 
@@ -403,20 +407,50 @@ hipError_t launch_bucket_partitioned_records(const uint64_t* records, uint64_t n
                                              uint32_t* ev_off, uint32_t* ev, uint32_t workgroups, FillList& fills, hipStream_t s,
                                              uint32_t shrink = 15u);
 
+// ---- sharded runs: the bounds scattered once, on the sender, by (owner rank, partition of the owner's reads) ----------
+// (bucket_kernels.hip) read r = local read r / world of rank r % world; every owner's reads in partitions of 4096 and groups
+// of 128 - as many of each on every owner (what rank 0 needs)
+struct ShardGeometry {
+    uint32_t world;
+    uint32_t n_part;        // partitions per owner
+    uint32_t groups;        // groups per owner = 32 * n_part
+    uint32_t header;        // 8-byte words in front of an owner's records: its groups' record counts (groups / 2)
+};
+struct ShardBlocks {
+    uint32_t off[64];       // where rank p's block lies: 8-byte words from the base the owner is given ...
+    uint32_t self;          // ... except this rank's (the owner's own, never copied): from the second base; 64 = none
+};
+ShardGeometry shard_geometry(uint64_t n_reads, uint32_t world);
+bool shard_path_fits(uint64_t n_reads, uint32_t max_read_len, uint32_t world);         // the same on every rank
+size_t shard_send_words(const ShardGeometry& g, uint64_t n_overlaps);                 // 8-byte words of a sender's buffer
+size_t shard_tile_slots(const ShardGeometry& g, uint64_t n_records);
+size_t shard_group_words(const ShardGeometry& g);
+// sender: block after block - [header][records {local read & 4095 : 12 | begin : 26 | end : 26}, partition by partition];
+// send_words[p] (device) = 8-byte words of block p
+hipError_t launch_shard_emit(const OvlSoA& o, uint32_t n_reads, const ShardGeometry& g, uint32_t* group_count, uint32_t* part_cursor,
+                             uint64_t* send, uint32_t* send_words, uint32_t workgroups, FillList& fills, hipStream_t s);
+// owner: the blocks of all senders -> ev_off[n_reads_local + 1], ev (bounds drawn in by 15, graph.cpp:317-324)
+hipError_t launch_bucket_from_blocks(const uint64_t* base, const uint64_t* base_self, const ShardBlocks& blocks, const ShardGeometry& g, uint32_t n_reads_local,
+                                     uint64_t n_records, uint32_t* group, uint32_t* tiles, uint64_t* rec2, uint32_t* ev_off, uint32_t* ev,
+                                     FillList& fills, hipStream_t s);
+
 // ---- PAF text -> columns (ingest_kernels.hip) ----------------------------------------------
 struct PafColumns {
     uint32_t *a_id, *b_id, *a_begin, *a_end, *b_begin, *b_end, *length;
     uint8_t* strand;
 };
 uint32_t paf_chunk_bytes();
-// text: n bytes, readable (and newlines) up to the next multiple of paf_chunk_bytes() + 4 KB; chunk_lines: one count per chunk
-void launch_paf_count(const uint8_t* text, uint64_t n, uint32_t* chunk_lines, hipStream_t s);
+uint32_t paf_halo_bytes();      // bytes behind a range's last own byte that its last lines' first eleven columns may use
+// text: the n bytes of the file whose line starts belong to this launch, then up to n_avail (>= n) bytes that may be read for
+// the last lines' columns - the buffer itself readable up to the next multiple of paf_chunk_bytes() + 4 KB behind n;
+// first_is_start: byte 0 starts a line (the file's first byte, or the byte behind a newline); chunk_lines: one count per chunk
+void launch_paf_count(const uint8_t* text, uint64_t n, bool first_is_start, uint32_t* chunk_lines, hipStream_t s);
 // chunk_row: the exclusive scan of the counts; flags (zeroed): 1 a line with fewer than 12 columns, 2 more lines in a chunk than
 // records can make, 4 a line whose first eleven columns reach beyond the halo; first_bad (all ones): row << 32 | read of the
 // first record whose length differs from its sequence's
-void launch_paf_parse(const uint8_t* text, uint64_t n, const uint32_t* chunk_row, const void* buckets, uint64_t n_buckets,
-                      const char* arena, const uint32_t* read_len, uint32_t n_reads, bool check_lengths, const PafColumns& out,
-                      uint32_t* flags, unsigned long long* first_bad, hipStream_t s);
+void launch_paf_parse(const uint8_t* text, uint64_t n, uint64_t n_avail, bool first_is_start, const uint32_t* chunk_row, const void* buckets,
+                      uint64_t n_buckets, const char* arena, const uint32_t* read_len, uint32_t n_reads, bool check_lengths,
+                      const PafColumns& out, uint32_t* flags, unsigned long long* first_bad, hipStream_t s);
 
 // ---- scans (scan_kernels.hip) --------------------------------------------------
 // exclusive prefix sum of n uint32 values; out may alias in; out[n] receives the total

@@ -599,10 +599,9 @@ __device__ __forceinline__ void expand_from_bitmap(uint32_t* sm, const uint16_t*
 // its own stretch of LDS and synchronises with itself only; what they have in common is their place: the rows of
 // neighbouring reads are written from one compute unit (tools/fill_bench4.hip: four rows per workgroup fill at 5.4 TB/s
 // where one row per workgroup fills at 5.0).
-template <uint32_t kCap, bool kDiag, int kSens, bool kOne = false, uint32_t kBases = 16384, uint32_t kWaves = 1, bool kPersist = false, bool kPlain = false>
-__global__ __launch_bounds__(64 * kWaves, kOne ? (kPersist ? 8 : 7) : kBases > 32768 ? 2 : kBases > 16384 ? 4 : 5) void pile_runs_kernel(PileArgs A, uint32_t* overflow_list, uint32_t* overflow_count) {
+template <uint32_t kCap, bool kDiag, int kSens, bool kOne = false, uint32_t kBases = 16384, uint32_t kWaves = 1, bool kPlain = false>
+__global__ __launch_bounds__(64 * kWaves, kOne ? 7 : kBases > 32768 ? 2 : kBases > 16384 ? 4 : 5) void pile_runs_kernel(PileArgs A, uint32_t* overflow_list, uint32_t* overflow_count) {
     static_assert(kWaves == 1 || kOne, "several reads per workgroup: the first kernel of a chain only");
-    static_assert(!kPersist || (kOne && kSens == 0 && !kDiag && kWaves == 1 && kBases == 16384), "persistent wavefronts: the first kernel of the first pass");
     static_assert(kSens == 0 || (kCap <= 1024 && !kDiag), "the sensitive pass runs on the bitmap path");
     static_assert(!kOne || kCap <= 512, "the short layout belongs to the first kernel of a chain");
     static_assert(kBases == 16384 || !kOne, "the bigger bitmap belongs to the chain's second kernel");
@@ -611,9 +610,7 @@ __global__ __launch_bounds__(64 * kWaves, kOne ? (kPersist ? 8 : 7) : kBases > 3
     typedef Layout<kCap, kShort, kBases> L;
     typedef typename L::rs_t rs_t;
     constexpr uint32_t kMaxReg = L::kMaxReg, kMaxRaw = L::kMaxRaw;
-    constexpr uint32_t kRecWords = kPersist ? 12 : 0;   // (persistent) the annotations of the item before, until their stores go out
-    static_assert(!kPersist || (L::WORDS + kRecWords) * 4 <= 5632, "seven wavefronts per SIMD");
-    __shared__ __align__(16) uint32_t sm_all[kWaves * L::WORDS + kRecWords];
+    __shared__ __align__(16) uint32_t sm_all[kWaves * L::WORDS];
     const uint32_t wave_in_group = kWaves == 1 ? 0u : (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     uint32_t* sm = sm_all + wave_in_group * L::WORDS;
     uint32_t* ev = sm + L::X;
@@ -644,97 +641,11 @@ __global__ __launch_bounds__(64 * kWaves, kOne ? (kPersist ? 8 : 7) : kBases > 3
         item_end = umin(n_items, (xcd + 1u) * per);
         item_step = gridDim.x / 8u;
     }
-    // kPersist: PERSISTENT wavefronts (round 4) - as many workgroups as the chip holds at once, every one looping over
-    // its share of the reads (XCD-contiguous, above), with the next read's events requested one read ahead.  What a
-    // short-lived wavefront cannot avoid: (i) a slot stands empty between one workgroup's end and the next one's start
-    // (SQ counters: 19 - 23 % of the slot time at C3), (ii) every wavefront starts with two dependent round trips to
-    // memory (offsets, then events), (iii) a wavefront keeps its slot, registers and LDS until its last store has been
-    // acknowledged (s_endpgm waits; + 26 % of a wavefront's life, profiles/r03_c3_pile_store_wait.txt).  A loop over
-    // items alone trades (iii) for something worse (round 3: 6.5 ms against 4.8): loads and stores are counted by ONE
-    // in-order counter, so waiting for the next read's first load is waiting for every row store of the read before.
-    // Here nothing is ever waited for behind a row store:
-    //   * a read's events are requested while the read BEFORE it is between its run phase and its expansion (the
-    //     registers they arrive in are the ones that read's events have just left), and the one `s_waitcnt vmcnt(0)`
-    //     of an item - in front of its first row store - is the wait for them; what else is outstanding there are the
-    //     stores of the item before, issued a whole item earlier;
-    //   * the offsets (length, row, events) of the read after that one come by the same request, five lanes of one
-    //     register, and are taken out of it behind the wait;
-    //   * an item's eight annotation stores would be the youngest stores at the next item's wait: they are parked in
-    //     LDS (`rec`) and go out behind that wait, together with the next item's rows.
-    // The requests are inline assembly: the compiler's wait-count pass must not know them (it would wait for them at
-    // the registers' first use, and with them for every store in front of them).  So it would not know either that the
-    // registers are not valid until the wait - and copies a register whenever it likes.  The requests therefore land
-    // in registers the compiler does not have: the instantiation is compiled for eight wavefronts per SIMD (64 vector
-    // registers; it runs at seven, the LDS allows no more) and the requests use v64 .. v71 by name - seven registers of
-    // events (448; a read with more loads the rest the ordinary way) and one of offsets.  Request, wait and the reads
-    // of those registers are volatile statements: they keep their order.
-    constexpr uint32_t kPre = 7;
-    uint32_t nx_n = 0, nx_e0 = 0, nx_e1 = 0, nx2_n = 0, nx2_e0 = 0, nx2_e1 = 0;
-    uint64_t nx_off = 0, nx2_off = 0;
-    const uint32_t* cur_ev = nullptr;
-    bool rec_pending = false;
-    uint32_t* rec = sm_all + kWaves * L::WORDS;
-#define RALA_REQ_LOAD(R, t)                                                                                             \
-    do {                                                                                                                \
-        const uint32_t off_ = umin((t) * 64u + lane_, last) * 4u;                                                       \
-        asm volatile("global_load_dword v" #R ", %0, %1" : : "v"(off_), "s"(base) : "memory");                          \
-    } while (0)
-#define RALA_REQ_READ(R, x) asm volatile("v_mov_b32 %0, v" #R : "=v"(x))
-#define RALA_REQ_LANE(L_, x) asm volatile("v_readlane_b32 %0, v71, " #L_ : "=s"(x))
-    auto request_events = [&](uint32_t e0, uint32_t e1, uint32_t lane_) {
-        if constexpr (kPersist) {
-            const uint32_t cnt = e1 - e0;
-            const uint32_t last = cnt ? cnt - 1u : 0u;
-            const uint32_t* base = A.ev + e0;
-            asm volatile("" : : : "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71");     // (the kernel's register count)
-            RALA_REQ_LOAD(64, 0); RALA_REQ_LOAD(65, 1); RALA_REQ_LOAD(66, 2); RALA_REQ_LOAD(67, 3);
-            RALA_REQ_LOAD(68, 4); RALA_REQ_LOAD(69, 5); RALA_REQ_LOAD(70, 6);
-        }
-    };
-    auto request_meta = [&](uint32_t rr, uint32_t lane_) {
-        if constexpr (kPersist) {
-            const uint32_t* p = lane_ == 1 ? A.ev_off + rr
-                              : lane_ == 2 ? A.ev_off + rr + 1
-                              : lane_ == 3 ? (const uint32_t*)(A.pile_off + rr)
-                              : lane_ == 4 ? (const uint32_t*)(A.pile_off + rr) + 1 : A.read_len + rr;
-            asm volatile("global_load_dword v71, %0, off" : : "v"(p) : "memory");
-        }
-    };
-    auto wait_requests = [&]() { asm volatile("s_waitcnt vmcnt(0)" : : : "memory"); };
-    auto take_meta = [&]() {
-        if constexpr (kPersist) {
-            uint32_t lo, hi;
-            RALA_REQ_LANE(0, nx2_n); RALA_REQ_LANE(1, nx2_e0); RALA_REQ_LANE(2, nx2_e1); RALA_REQ_LANE(3, lo); RALA_REQ_LANE(4, hi);
-            asm volatile("s_nop 4");                    // (a scalar register written by the vector unit, then an address)
-            nx2_off = (uint64_t)lo | ((uint64_t)hi << 32);
-        }
-    };
-    auto flush_record = [&](uint32_t lane_) {
-        if (lane_ == 0) {
-            const uint4 a = *(const uint4*)rec, b = *(const uint4*)(rec + 4);
-            const uint32_t rr = a.x;
-            A.alive[rr] = 1;
-            A.begin[rr] = a.y; A.end[rr] = a.z;
-            A.median[rr] = (uint16_t)a.w; A.p10[rr] = (uint16_t)(a.w >> 16);
-            A.n_pits[rr] = b.x; A.n_hills[rr] = b.y;
-            A.iv_slot[rr] = b.z;
-        }
-    };
-    if constexpr (kPersist) {
-        if (item_first < item_end) {
-            const uint32_t r2 = item_first + item_step < item_end ? item_first + item_step : item_first;
-            nx_n = A.read_len[item_first];
-            nx_off = A.pile_off[item_first];
-            nx_e0 = A.ev_off[item_first];
-            nx_e1 = A.ev_off[item_first + 1];
-            nx2_n = A.read_len[r2];
-            nx2_off = A.pile_off[r2];
-            nx2_e0 = A.ev_off[r2];
-            nx2_e1 = A.ev_off[r2 + 1];
-            request_events(nx_e0, nx_e1, threadIdx.x);
-            wait_requests();
-        }
-    }
+    // (Round 4 carried a persistent variant of the first kernel here - as many workgroups as the chip holds, the next read's
+    // events requested one read ahead by inline assembly into registers the compiler did not know of, the annotation stores
+    // parked in LDS, so that nothing was ever waited for behind a row store: the same time as one workgroup per read at every
+    // grid size, DESIGN.md section 4.  Removed in round 5: product code that buys nothing and depends on the register
+    // allocator's habits should not stay.)
     for (uint32_t item = item_first; item < item_end; item += item_step) {
         // (The lane id is made opaque once per item: what is derived from it is then no loop invariant.  The
         // compiler used to hoist such values out of the loop and keep them in registers for the whole kernel -
@@ -744,17 +655,7 @@ __global__ __launch_bounds__(64 * kWaves, kOne ? (kPersist ? 8 : 7) : kBases > 3
         uint32_t r, n, n_ev_p;
         uint64_t row_off;
         const uint32_t* __restrict__ rev = nullptr;
-        uint32_t r_fetch = 0;
-        if constexpr (kPersist) {
-            // this item's offsets, the next item's (its events are requested below), and whose to request with them
-            r = item;
-            n = nx_n;
-            row_off = nx_off;
-            n_ev_p = nx_e1 - nx_e0;
-            cur_ev = A.ev + nx_e0;
-            nx_n = nx2_n; nx_off = nx2_off; nx_e0 = nx2_e0; nx_e1 = nx2_e1;
-            r_fetch = item + 2u * item_step < item_end ? item + 2u * item_step : item;
-        } else if constexpr (kPlain) {
+        if constexpr (kPlain) {
             // the reads as they come, their events in the CSR: four loads that do not wait for each other (through the
             // branches of the general case below they were four round trips in a row)
             r = item;
@@ -772,9 +673,6 @@ __global__ __launch_bounds__(64 * kWaves, kOne ? (kPersist ? 8 : 7) : kBases > 3
             n_ev_p = A.ev_cnt ? umin(A.ev_cnt[r], A.ev_stride) : A.ev_off[r + 1] - A.ev_off[r];
             rev = A.ev_cnt ? A.ev + (size_t)r * A.ev_stride : A.ev + A.ev_off[r];
         }
-        // (persistent) a read that is not this kernel's goes through the run phase without events and leaves with
-        // the reads that have no valid region: one request site, above
-        bool rejected = false;
         uint32_t n_ev = n_ev_p;
         const uint32_t* __restrict__ sev = nullptr;
         uint32_t given_b = 0, given_e = 0;
@@ -793,19 +691,12 @@ __global__ __launch_bounds__(64 * kWaves, kOne ? (kPersist ? 8 : 7) : kBases > 3
             const uint32_t not_mine = (uint32_t)(n > kMaxBases) | (uint32_t)(A.skip_dense != 0 && n_ev > kRunEventCap) | (uint32_t)(row_off == ~0ull);
             if (not_mine) continue;
         }
-        if (kOne && kSens == 0 && n > kMaxBases) {
-            if constexpr (kPersist) rejected = true; else continue;
-        }
+        if (kOne && kSens == 0 && n > kMaxBases) continue;
         // (the two region marks of the sensitive pass may add two runs)
-        if (kSens == 0 && kCap <= kRunEventCap && A.skip_dense && n_ev > kRunEventCap) {       // listed beforehand
-            if constexpr (kPersist) rejected = true; else continue;
-        }
-        if (!rejected && (n_ev > (kSens ? kCap - 2 : kCap) || (kSens != 0 && (n > kMaxBases || given_e <= given_b)) || (kShort && n > kMaxBases))) {
+        if (kSens == 0 && kCap <= kRunEventCap && A.skip_dense && n_ev > kRunEventCap) continue;       // listed beforehand
+        if (n_ev > (kSens ? kCap - 2 : kCap) || (kSens != 0 && (n > kMaxBases || given_e <= given_b)) || (kShort && n > kMaxBases)) {
             if (lane == 0) overflow_list[atomicAdd(overflow_count, 1u)] = r;
-            if constexpr (kPersist) rejected = true; else continue;
-        }
-        if constexpr (kPersist) {
-            if (rejected) n_ev = 0;
+            continue;
         }
 
         // ---- 1 + 2. runs (start, value mod 2^16) ---------------------------------------------
@@ -833,27 +724,7 @@ __global__ __launch_bounds__(64 * kWaves, kOne ? (kPersist ? 8 : 7) : kBases > 3
             // a load per predicated block would be waited for one by one
             uint32_t evr[kCap / 64];
             const uint32_t e_last = n_ev ? n_ev - 1 : 0;
-            if constexpr (kPersist) {
-                // requested one item ahead
-                static_assert(kCap / 64 == 8 || !kPersist, "seven registers of events requested ahead, the eighth the ordinary way");
-                RALA_REQ_READ(64, evr[0]); RALA_REQ_READ(65, evr[1]); RALA_REQ_READ(66, evr[2]); RALA_REQ_READ(67, evr[3]);
-                RALA_REQ_READ(68, evr[4]); RALA_REQ_READ(69, evr[5]); RALA_REQ_READ(70, evr[6]);
-                evr[kCap / 64 - 1] = kNone;
-#pragma unroll
-                for (uint32_t t = 0; t < kPre; ++t) {
-                    if (t * 64 + lane >= n_ev) evr[t] = kNone;
-                }
-                // (a read with more events than were requested ahead: the rest the ordinary way - behind the stores
-                // of the item before, which are an item old)
-                if (n_ev > kPre * 64u) {
-#pragma unroll
-                    for (uint32_t t = kPre; t < kCap / 64; ++t) evr[t] = cur_ev[umin(t * 64 + lane, e_last)];
-#pragma unroll
-                    for (uint32_t t = kPre; t < kCap / 64; ++t) {
-                        if (t * 64 + lane >= n_ev) evr[t] = kNone;
-                    }
-                }
-            } else if constexpr (kSens == 0) {
+            if constexpr (kSens == 0) {
 #pragma unroll
                 for (uint32_t t = 0; t < kCap / 64; ++t) evr[t] = rev[umin(t * 64 + lane, e_last)];
 #pragma unroll
@@ -923,11 +794,6 @@ __global__ __launch_bounds__(64 * kWaves, kOne ? (kPersist ? 8 : 7) : kBases > 3
                 }
             }
             if (lane == 0) { rs[0] = 0; rs[R] = n; rs[R + 1] = n; }
-            // (persistent) this read's events have left their registers: the next read's arrive in them
-            if constexpr (kPersist) {
-                request_events(nx_e0, nx_e1, lane);
-                request_meta(r_fetch, lane);
-            }
             if constexpr (kSens != 0) {
                 if ((lane == 1 || lane == 2) && (lane == 1 ? given_b : given_e) < n) {
                     const uint32_t pos = lane == 1 ? given_b : given_e;
@@ -1068,17 +934,13 @@ __global__ __launch_bounds__(64 * kWaves, kOne ? (kPersist ? 8 : 7) : kBases > 3
             kB = len ? sel[0] : 0;
             kE = len ? sel[1] : 0;
         }
-        if (kSens == 0 && (rejected || E - B < kMinRegion)) {
-            if (lane == 0 && !rejected) {
+        if (kSens == 0 && E - B < kMinRegion) {
+            if (lane == 0) {
                 A.alive[r] = 0;
                 A.begin[r] = 0; A.end[r] = 0; A.median[r] = 0; A.p10[r] = 0;
                 A.n_pits[r] = 0; A.n_hills[r] = 0; A.iv_slot[r] = kNone;
             }
             wave_sync();
-            if constexpr (kPersist) {
-                wait_requests();
-                take_meta();
-            }
             continue;
         }
         RUN_STOP(23)
@@ -1146,14 +1008,7 @@ __global__ __launch_bounds__(64 * kWaves, kOne ? (kPersist ? 8 : 7) : kBases > 3
         // pref[w] + popcount(bits up to p) - no searching, and the byte of the bitmap that
         // belongs to a lane's 8 positions says where (if anywhere) the value changes.
         if constexpr (kSens != 2) {
-            if constexpr (kPersist) wait_requests();
-            else __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0), nothing else
-            if constexpr (kPersist) {
-                // the next read's events are there; behind the wait: the annotations of the item before
-                take_meta();
-                if (rec_pending) flush_record(lane);
-                rec_pending = false;
-            }
+            __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0), nothing else
             constexpr uint32_t kSeg = 16384, kBmWords = kSeg / 32;     // (sorted path: segments of the first size)
             uint32_t* bm = sm + L::X;
             uint16_t* pref = (uint16_t*)(bm + kBmWords);
@@ -1842,30 +1697,18 @@ __global__ __launch_bounds__(64 * kWaves, kOne ? (kPersist ? 8 : 7) : kBases > 3
                     }
                 }
             }
-            if constexpr (kPersist) {
-                *(uint4*)rec = make_uint4(r, B, E, (med & 0xFFFFu) | (p10 << 16));
-                *(uint4*)(rec + 4) = make_uint4(wp, wh, slot, 0u);
-            } else {
-                A.alive[r] = 1;
-                A.begin[r] = B; A.end[r] = E;
-                A.median[r] = (uint16_t)med; A.p10[r] = (uint16_t)p10;
-                A.n_pits[r] = wp; A.n_hills[r] = wh;
-                A.iv_slot[r] = slot;
-            }
+            A.alive[r] = 1;
+            A.begin[r] = B; A.end[r] = E;
+            A.median[r] = (uint16_t)med; A.p10[r] = (uint16_t)p10;
+            A.n_pits[r] = wp; A.n_hills[r] = wh;
+            A.iv_slot[r] = slot;
             if (err) atomicOr(A.error, err);
         }
-        if constexpr (kPersist) rec_pending = true;
         }
         wave_sync();
         wave_sync();
     }
-    if constexpr (kPersist) {
-        if (rec_pending) flush_record(threadIdx.x);
-    }
 #undef RUN_STOP
-#undef RALA_REQ_LOAD
-#undef RALA_REQ_READ
-#undef RALA_REQ_LANE
 }
 
 // reads with more events than the cap-512 kernels take: listed straight from the bucket counts, so
@@ -1945,24 +1788,12 @@ void launch_pile_runs(const PileArgs& args, uint32_t grid, int tier, uint32_t* o
         const uint32_t g = persist && persist < grid ? persist / 8u * 8u : grid;
         // reads per workgroup (one wavefront each): RALA_PILE_WAVES = 1, 2 or 4
         static const uint32_t waves = getenv("RALA_PILE_WAVES") ? (uint32_t)atoi(getenv("RALA_PILE_WAVES")) : kPileWavesPerGroup;
-        // persistent wavefronts with the next read's events requested one read ahead (kPersist; option pile_persistent_grid /
-        // RALA_PILE_PERSIST2=<grid>).  Measured and NOT the default (round 4, C3, one box): 7168 workgroups - what the chip holds -
-        // 5.9 ms against 4.65 with one workgroup per read (fixed shares: the wavefronts of a crowded SIMD finish last);
-        // 14336: 5.1, 28672: 4.86, 57344: 4.67, 114688 (nine reads each): 4.57, 229376: 4.64.  With every wait behind a row
-        // store gone, no empty slots and no start-up round trips the kernel takes the SAME time: none of the three bounds it.
-        const uint32_t persist2 = args.persist_grid;
-        if (!diag && persist2 && !args.order && !args.ev_cnt) {
-            const uint32_t g2 = persist2 < grid ? persist2 / 8u * 8u : grid;
-            hipLaunchKernelGGL((pile_runs_kernel<kRunEventCap, false, 0, true, 16384, 1, true>), dim3(g2), dim3(64), extra_lds, stream,
-                               args, overflow_list, overflow_count);
-            return;
-        }
         if (diag) hipLaunchKernelGGL((pile_runs_kernel<kRunEventCap, true, 0, true>), dim3(g), dim3(64), extra_lds, stream,
                                      args, overflow_list, overflow_count);
         else if (waves == 4 && !persist) hipLaunchKernelGGL((pile_runs_kernel<kRunEventCap, false, 0, true, 16384, 4>), dim3((grid + 3) / 4), dim3(256),
                                                             extra_lds, stream, args, overflow_list, overflow_count);
         else if (waves == 2 && !persist && !args.order && !args.ev_cnt && !getenv("RALA_PILE_NOT_PLAIN"))
-            hipLaunchKernelGGL((pile_runs_kernel<kRunEventCap, false, 0, true, 16384, 2, false, true>), dim3((grid + 1) / 2), dim3(128),
+            hipLaunchKernelGGL((pile_runs_kernel<kRunEventCap, false, 0, true, 16384, 2, true>), dim3((grid + 1) / 2), dim3(128),
                                extra_lds, stream, args, overflow_list, overflow_count);
         else if (waves == 2 && !persist) hipLaunchKernelGGL((pile_runs_kernel<kRunEventCap, false, 0, true, 16384, 2>), dim3((grid + 1) / 2), dim3(128),
                                                             extra_lds, stream, args, overflow_list, overflow_count);

@@ -1372,6 +1372,10 @@ int gpu_tail_part_a(rala_hip_ctx* ctx) {
     HIPCHECK(ctx->d_counts.ensure(48));
     uint32_t* dropped = ctx->d_counts.p + 4;                        // one word per round of a batch
     launch_break_hills(R, n_reads, s);
+    if (ctx->lists_pending) {           // (a sharded run's survivor lists, gathered beside the kernels above)
+        HIPCHECK(hipStreamWaitEvent(s, ctx->ev[3], 0));
+        ctx->lists_pending = false;
+    }
     launch_retrim(L, R, 0, 0, dropped, s);
     mark("tail: hills + retrim", M);
 
@@ -1574,6 +1578,10 @@ int pass2(rala_hip_ctx* ctx, Comm* comm) {
         return RALA_HIP_EDEVICE;
     };
 
+    if (ctx->dedupe_pending) {          // (a sharded run's duplicate removal ran beside the emit, on the side stream)
+        HIPCHECK(hipStreamWaitEvent(s, ctx->ev[1], 0));
+        ctx->dedupe_pending = false;
+    }
     // ---- static part ----
     // (a sharded run gathers up to 65 536 undecided killers of ALL ranks on every rank: room for them whatever the slice's size)
     const uint64_t kill_room = comm ? std::max<uint64_t>(N + 1, (1u << 16) + 1) : N + 1;
@@ -1712,27 +1720,19 @@ int pass2(rala_hip_ctx* ctx, Comm* comm) {
             launch_death_lower(klist[cur], lo, s, at_most);
             if (undecided <= kFewKillers && ctx->use_round_batches) unseen = kRoundsPerLook;
         } else if ((uint64_t)undecided * comm->world() <= (1u << 16)) {
-            // few killers left: every rank takes all of them and the rest needs no collective
-            uint64_t mine = 0;
-            {
-                uint32_t c = 0;
-                HIPCHECK(d2h_small(ctx, &c, klist[cur].count, 4, s));
-                HIPCHECK(stream_sync(ctx, s));
-                mine = c;
-            }
-            std::vector<uint64_t> counts(comm->world());
-            if (comm->host_all_gather(&mine, 1, counts.data(), s) != 0) return comm_fail("killer counts");
-            uint64_t total = 0;
-            for (uint64_t c : counts) total += c;
-            uint32_t* src3[3] = {klist[cur].ovl, klist[cur].target, klist[cur].keeper};
-            uint32_t* dst3[3] = {klist[cur ^ 1].ovl, klist[cur ^ 1].target, klist[cur ^ 1].keeper};
+            // few killers left: every rank takes all of them and the rest needs no collective.  `undecided` is the longest
+            // list of any rank, known everywhere: every rank pads its list to that length with inert entries and blocks of one
+            // size are gathered - no exchange of the lists' lengths, no look from the host (rounds 2 - 4: a count to the host,
+            // a host exchange, three gathers of different lengths, a count back to the device and a wait for it)
+            const uint32_t each = undecided;
+            const uint64_t total = (uint64_t)each * comm->world();
             if (total > kill_room) return fail(ctx, RALA_HIP_EDEVICE, "more undecided killers than there is room for");   // (cannot happen: <= 65536)
-            for (int k = 0; k < 3; ++k) {
-                if (comm->all_gather_v(src3[k], dst3[k], counts.data(), 4, s) != 0) return comm_fail("all-gather of the undecided killers");
-            }
-            const uint32_t t32 = (uint32_t)total;
-            HIPCHECK(hipMemcpyAsync(klist[cur ^ 1].count, &t32, 4, hipMemcpyHostToDevice, s));
-            HIPCHECK(stream_sync(ctx, s));                       // t32 is a local
+            HIPCHECK(ctx->d_gather[0].ensure((size_t)each * 12 + 16));
+            HIPCHECK(ctx->d_gather[1].ensure((size_t)total * 12 + 16));
+            launch_pack_killers(klist[cur].ovl, klist[cur].target, klist[cur].keeper, klist[cur].count, each, (uint32_t*)ctx->d_gather[0].p, s);
+            if (comm->all_gather(ctx->d_gather[0].p, ctx->d_gather[1].p, (size_t)each * 12, s) != 0) return comm_fail("all-gather of the undecided killers");
+            launch_unpack_killers((const uint32_t*)ctx->d_gather[1].p, comm->world(), each, klist[cur ^ 1].ovl, klist[cur ^ 1].target,
+                                  klist[cur ^ 1].keeper, klist[cur ^ 1].count, s);
             cur ^= 1;
             gathered = true;
             at_most = total;
@@ -1827,12 +1827,24 @@ int pass2(rala_hip_ctx* ctx, Comm* comm) {
         }
         lb.world = P;
         HIPCHECK(ctx->d_list_block[1].ensure(off + 16));
-        if (comm->all_gather_v(ctx->d_list_block[0].p, ctx->d_list_block[1].p, bytes.data(), 1, s) != 0) return comm_fail("all-gather of the survivors");
         const uint32_t M = (uint32_t)(tot0 + tot1);
         ctx->t_n0 = (uint32_t)tot0; ctx->t_n1 = (uint32_t)tot1;
         for (int f = 0; f < 8; ++f) HIPCHECK(ctx->d_surv_u32[f].ensure(M));
         for (int f = 0; f < 2; ++f) HIPCHECK(ctx->d_surv_u8[f].ensure(M));
-        if (M) launch_unpack_lists(ctx->d_list_block[1].p, lb, tail_view(), s);
+        // The blocks travel on the side stream, beside the first kernels of the tail (list states, ranks of the reads that
+        // are left, the breaks over hills: nothing of that looks at an item); gpu_tail_part_a joins in front of its first
+        // kernel over the items.
+        hipStream_t gs = ctx->use_side_stream ? ctx->side : s;
+        if (gs != s) {
+            HIPCHECK(hipEventRecord(ctx->ev[2], s));
+            HIPCHECK(hipStreamWaitEvent(gs, ctx->ev[2], 0));
+        }
+        if (comm->all_gather_v(ctx->d_list_block[0].p, ctx->d_list_block[1].p, bytes.data(), 1, gs) != 0) return comm_fail("all-gather of the survivors");
+        if (M) launch_unpack_lists(ctx->d_list_block[1].p, lb, tail_view(), gs);
+        if (gs != s) {
+            HIPCHECK(hipEventRecord(ctx->ev[3], gs));
+            ctx->lists_pending = true;
+        }
     }
     HIPCHECK(hipEventRecord(ctx->ev[7], s));
     HIPCHECK(hipGetLastError());
@@ -1885,6 +1897,62 @@ int rala_hip::transitive_stage(rala_hip_ctx* ctx, Comm* comm, uint32_t* n_pairs)
         return rc;
     }
     return rala_hip_remove_transitive_edges(ctx, n_pairs);      // (after the sensitive pass the graph is a host graph)
+}
+
+// A sender of a sharded run: duplicate removal on the side stream (joined by the second pass), the bounds of the slice
+// scattered once by (owner, partition) into `send` (shard_send_words() words); words[p] = 8-byte words of owner p's block.
+int rala_hip::shard_emit(rala_hip_ctx* ctx, const ShardGeometry& g, uint64_t* send, uint64_t* words) {
+    if (!ctx || !send || !words) return RALA_HIP_EINVAL;
+    if (ctx->n_reads == 0) return fail(ctx, RALA_HIP_EINVAL, "no reads set");
+    if (!ctx->inputs_set || ctx->tuple_mode) return fail(ctx, RALA_HIP_EINVAL, "no overlaps set");
+    HIPCHECK(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const uint32_t n_reads = (uint32_t)ctx->n_reads;
+    if (ctx->use_side_stream) {
+        HIPCHECK(hipEventRecord(ctx->ev[0], s));
+        HIPCHECK(hipStreamWaitEvent(ctx->side, ctx->ev[0], 0));
+        launch_dedupe(ctx->ovl, n_reads, ctx->d_suspect.p, ctx->d_valid.p, ctx->side);
+        HIPCHECK(hipEventRecord(ctx->ev[1], ctx->side));
+        ctx->dedupe_pending = true;
+    } else {
+        launch_dedupe(ctx->ovl, n_reads, ctx->d_suspect.p, ctx->d_valid.p, s);
+    }
+    ctx->valid_ready = true;
+    HIPCHECK(ctx->d_shard_group.ensure((size_t)g.world * g.groups + 2));
+    HIPCHECK(ctx->d_shard_part.ensure((size_t)g.world * g.n_part + 2));
+    HIPCHECK(ctx->d_shard_words.ensure(64));
+    FillList fills;
+    HIPCHECK(launch_shard_emit(ctx->ovl, n_reads, g, ctx->d_shard_group.p, ctx->d_shard_part.p, send, ctx->d_shard_words.p,
+                               ctx->n_compute_units, fills, s));
+    uint32_t h[64];
+    HIPCHECK(d2h_small(ctx, h, ctx->d_shard_words.p, g.world * 4, s));
+    HIPCHECK(stream_sync(ctx, s));
+    HIPCHECK(hipGetLastError());
+    for (uint32_t p = 0; p < g.world; ++p) words[p] = h[p];
+    return RALA_HIP_OK;
+}
+
+// An owner of a sharded run: its input is the blocks of all senders where they lie (base: what was received; base_self:
+// the send buffer, for the rank's own block); n_records of them in all.  rala_hip_initialize takes it from there.
+int rala_hip::set_bound_blocks(rala_hip_ctx* ctx, const uint64_t* base, const uint64_t* base_self, const ShardBlocks& blocks,
+                               const ShardGeometry& g, uint64_t n_records) {
+    if (!ctx) return RALA_HIP_EINVAL;
+    if (ctx->n_reads == 0) return fail(ctx, RALA_HIP_EINVAL, "no reads set");
+    if (n_records >= 0x7FFFFFF0ull) return fail(ctx, RALA_HIP_EINVAL, "too many records");
+    HIPCHECK(hipSetDevice(ctx->device));
+    ctx->blocks_base = base; ctx->blocks_base_self = base_self; ctx->blocks = blocks; ctx->shard_geom = g;
+    ctx->n_block_records = n_records;
+    ctx->blocks_mode = true;
+    ctx->records = nullptr; ctx->n_records = 0;
+    ctx->tuples = nullptr; ctx->n_tuples = 2 * n_records;
+    ctx->tuple_mode = true;
+    ctx->inputs_set = true;
+    ctx->n_ovl = 0;
+    ctx->ovl = OvlSoA();
+    HIPCHECK(ctx->d_ev.ensure(2 * n_records + 8));
+    HIPCHECK(ctx->d_scan_ws.ensure(scan_workspace_bytes(std::max<uint64_t>(2 * n_records, ctx->n_reads) + 2)));
+    ctx->initialized = ctx->constructed = ctx->ev_ready = false;
+    return RALA_HIP_OK;
 }
 
 int rala_hip::install_read_state(rala_hip_ctx* ctx, uint64_t pool_count) {
@@ -1968,9 +2036,9 @@ int rala_hip_set_option(rala_hip_ctx* ctx, const char* key, int64_t value) {
     if (!strcmp(key, "max_lds_read_len")) { ctx->max_lds_read_len = value; return RALA_HIP_OK; }
     if (!strcmp(key, "debug_pile_stop_after")) { ctx->debug_pile_stop_after = value; return RALA_HIP_OK; }
     if (!strcmp(key, "use_run_kernel")) { ctx->use_run_kernel = value != 0; return RALA_HIP_OK; }
-    if (!strcmp(key, "pile_persistent_grid")) { ctx->pile_persistent_grid = std::max<int64_t>(0, value); return RALA_HIP_OK; }
     if (!strcmp(key, "use_round_batches")) { ctx->use_round_batches = value != 0; return RALA_HIP_OK; }
     if (!strcmp(key, "use_bound_records")) { ctx->use_bound_records = value != 0; return RALA_HIP_OK; }
+    if (!strcmp(key, "use_fused_emit")) { ctx->use_fused_emit = value != 0; return RALA_HIP_OK; }
     if (!strcmp(key, "debug_fp_lds_limit")) { ctx->debug_fp_lds_limit = (uint32_t)std::max<int64_t>(0, value); return RALA_HIP_OK; }
     if (!strcmp(key, "debug_fail_construct")) { ctx->debug_fail_construct = value != 0; return RALA_HIP_OK; }
     if (!strcmp(key, "use_gpu_tail")) { ctx->use_gpu_tail = value != 0; return RALA_HIP_OK; }
@@ -2098,6 +2166,8 @@ int rala_hip_set_overlaps(rala_hip_ctx* ctx, const rala_hip_overlaps* o, uint64_
     ctx->ovl.n = n;
     ctx->ovl.base = 0;
     ctx->tuple_mode = false;
+    ctx->blocks_mode = false;
+    ctx->dedupe_pending = false;
     ctx->inputs_set = true;
     ctx->valid_ready = false;
     HIPCHECK(ctx->d_valid.ensure(n));
@@ -2164,8 +2234,11 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
         ctx->tuples = ctx->d_tuple.p;
         ctx->n_tuples = 2 * ctx->n_records;
     }
-    const bool partitioned = from_records || (!ctx->tuple_mode && partition_allowed &&
-                                              partition_path_fits(n_reads, ctx->max_read_len, ctx->n_ovl));
+    // (an owner rank's blocks, scattered by partition on the senders: the same path from level 2 on - there is no other
+    // form of that input)
+    const bool from_blocks = ctx->tuple_mode && ctx->blocks_mode;
+    const bool partitioned = from_blocks || from_records || (!ctx->tuple_mode && partition_allowed &&
+                                                             partition_path_fits(n_reads, ctx->max_read_len, ctx->n_ovl));
     bool fixed = !partitioned && ctx->use_run_kernel && ctx->use_fixed_buckets && (uint64_t)n_reads * slot * 4ull <= (64ull << 30);
     static const bool dedupe_late = getenv("RALA_DEDUPE_LATE") != nullptr;
     const bool dedupe_early = forked && partitioned && !dedupe_late;
@@ -2174,7 +2247,14 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
         launch_dedupe(ctx->ovl, n_reads, ctx->d_suspect.p, ctx->d_valid.p, ctx->side);
         HIPCHECK(hipEventRecord(ctx->ev[1], ctx->side));
     }
-    if (partitioned) {
+    if (from_blocks) {
+        const ShardGeometry& g = ctx->shard_geom;
+        HIPCHECK(ctx->d_shard_group.ensure(shard_group_words(g)));
+        HIPCHECK(ctx->d_shard_tiles.ensure(3 * shard_tile_slots(g, ctx->n_block_records) + 2));
+        HIPCHECK(ctx->d_bk_rec[1].ensure((size_t)ctx->n_block_records + 64));
+        HIPCHECK(launch_bucket_from_blocks(ctx->blocks_base, ctx->blocks_base_self, ctx->blocks, g, n_reads, ctx->n_block_records,
+                                           ctx->d_shard_group.p, ctx->d_shard_tiles.p, ctx->d_bk_rec[1].p, ctx->d_ev_off.p, ctx->d_ev.p, fills, s));
+    } else if (partitioned) {
         const uint64_t n_rec = from_records ? ctx->n_records : ctx->n_ovl;
         for (int k = 0; k < 3; ++k) HIPCHECK(ctx->d_bk_u32[k].ensure(n_reads + 2));
         HIPCHECK(ctx->d_bk_part.ensure(partition_count(n_reads) + 2));
@@ -2238,11 +2318,6 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
     a.ev_cnt = fixed ? ctx->d_cursor.p : nullptr; a.ev_stride = slot;
     a.add_to_existing = 0; a.slab = ctx->d_slab.p;
     a.stop_after = (uint32_t)ctx->debug_pile_stop_after;
-    {
-        static const int64_t env_grid = getenv("RALA_PILE_PERSIST2") ? atoll(getenv("RALA_PILE_PERSIST2")) : 0;
-        const int64_t g = ctx->pile_persistent_grid >= 0 ? ctx->pile_persistent_grid : env_grid;
-        a.persist_grid = (uint32_t)std::min<int64_t>(std::max<int64_t>(0, g), 1 << 24);
-    }
     a.begin = ctx->d_begin.p; a.end = ctx->d_end.p; a.median = ctx->d_median.p; a.p10 = ctx->d_p10.p;
     a.alive = ctx->d_alive.p; a.n_pits = ctx->d_n_pits.p; a.n_hills = ctx->d_n_hills.p; a.iv_slot = ctx->d_iv_slot.p;
     a.pool = ctx->d_pool.p; a.pool_count = ctx->d_small.p; a.pool_cap = ctx->pool_cap; a.error = ctx->d_small.p + 1;
@@ -2573,6 +2648,7 @@ int rala_hip_set_bound_tuples(rala_hip_ctx* ctx, const uint64_t* tuples, uint64_
     ctx->n_tuples = n;
     ctx->records = nullptr;
     ctx->n_records = 0;
+    ctx->blocks_mode = false;
     ctx->tuple_mode = true;
     ctx->inputs_set = true;
     ctx->n_ovl = 0;
@@ -2600,6 +2676,7 @@ int rala_hip_set_bound_records(rala_hip_ctx* ctx, const uint64_t* records, uint6
     ctx->n_records = n;
     ctx->tuples = nullptr;
     ctx->n_tuples = 2 * n;              // (what the tuple paths would see)
+    ctx->blocks_mode = false;
     ctx->tuple_mode = true;
     ctx->inputs_set = true;
     ctx->n_ovl = 0;

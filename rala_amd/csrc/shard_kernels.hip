@@ -2,6 +2,8 @@
 // between the global numbering (read r) and an owner's local numbering (read j * P + rank).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "device_utils.h"
 #include "kernels.h"
 
@@ -97,7 +99,41 @@ __global__ __launch_bounds__(kBlock) void pool_aux_kernel(Interval* pool, uint32
 
 inline dim3 grid_for(uint64_t n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); }
 
+// A rank's undecided killers as one block of 3 * each words (key, target, keeper; each = the longest list of any rank, which
+// every rank knows from the status word): entries behind the rank's own are inert - the key "never" proposes nothing.  No
+// exchange of the lists' lengths is needed to gather blocks of one size.
+__global__ __launch_bounds__(kBlock) void pack_killers_kernel(const uint32_t* __restrict__ key, const uint32_t* __restrict__ target,
+                                                              const uint32_t* __restrict__ keeper, const uint32_t* __restrict__ count,
+                                                              uint32_t each, uint32_t* __restrict__ block) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= each) return;
+    const bool mine = i < *count;
+    block[i] = mine ? key[i] : kInf;
+    block[each + i] = mine ? target[i] : 0u;
+    block[2 * each + i] = mine ? keeper[i] : 0u;
+}
+__global__ __launch_bounds__(kBlock) void unpack_killers_kernel(const uint32_t* __restrict__ blocks, uint32_t world, uint32_t each,
+                                                                uint32_t* __restrict__ key, uint32_t* __restrict__ target,
+                                                                uint32_t* __restrict__ keeper, uint32_t* count) {
+    const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
+    if (j == 0) *count = world * each;
+    if (j >= world * each) return;
+    const uint32_t* b = blocks + (size_t)(j / each) * 3 * each;
+    const uint32_t i = j % each;
+    key[j] = b[i]; target[j] = b[each + i]; keeper[j] = b[2 * each + i];
+}
+
 }  // namespace
+
+void launch_pack_killers(const uint32_t* key, const uint32_t* target, const uint32_t* keeper, const uint32_t* count, uint32_t each,
+                         uint32_t* block, hipStream_t s) {
+    if (each) hipLaunchKernelGGL(pack_killers_kernel, grid_for(each), dim3(kBlock), 0, s, key, target, keeper, count, each, block);
+}
+void launch_unpack_killers(const uint32_t* blocks, uint32_t world, uint32_t each, uint32_t* key, uint32_t* target, uint32_t* keeper,
+                           uint32_t* count, hipStream_t s) {
+    hipLaunchKernelGGL(unpack_killers_kernel, grid_for(std::max<uint64_t>(1, (uint64_t)world * each)), dim3(kBlock), 0, s, blocks, world, each,
+                       key, target, keeper, count);
+}
 
 void launch_partition_tuples(const uint2* in, uint64_t n, uint32_t world, uint32_t pass, uint32_t* counters, uint2* out,
                              hipStream_t s) {

@@ -5,9 +5,15 @@
 // on a_id-run boundaries (duplicate removal is per run, reference graph.cpp:346-350); rank k
 // holds slice k and ALL read lengths.  One step (rala_hip_mg_run, collective):
 //
-//   slice   duplicate removal; bound tuples {local read, bound} grouped by owner      O(N / P)
-//   comm    ONE all-to-all(v) of the 8-byte tuples to the read owners
-//   owner   bucket the tuples, build + annotate the piles of the owned reads          O(bases / P)
+//   slice   duplicate removal (beside:) the bounds of both sides of every overlap as 8-byte records
+//           {local read & 4095, begin, end}, scattered ONCE by (owner, partition of 4096 of the owner's
+//           reads) - the first level of the partitioned bucketing done where the overlaps are         O(N / P)
+//   comm    ONE all-to-all(v): an owner's block = its groups' record counts + its records; a rank's own
+//           block stays where it is
+//   owner   second level of the bucketing over the blocks as they lie, rows, then build + annotate the
+//           piles of the owned reads                                                  O(bases / P)
+//           (reads of 2^26 bases and more, or option use_fused_emit = 0: bound records / tuples grouped by
+//           owner, bucketed from the start by the owner - rounds 2 - 4)
 //   comm    all-gather of the per-read state (19 B per read) and the interval pools
 //   slice   classify (trim / type) against the gathered state                         O(N / P)
 //   comm    containment fixed point: bounds all-reduced (min) per round; once few killers are
@@ -23,6 +29,7 @@
 // result, so every getter of rala_hip.h works on it) and `cl` (the owned reads with their piles).
 #include <hip/hip_runtime.h>
 #include <string.h>
+#include <sys/stat.h>
 
 #include <algorithm>
 #include <chrono>
@@ -48,6 +55,7 @@ struct rala_hip_mg {
     DevBuf<uint8_t> d_state_mine, d_state_all;
     DevBuf<uint8_t> d_bytes[2];
     rala_hip_mg_timings tm = {};
+    hipEvent_t ev[8] = {};              // stage boundaries on cs->stream (timings without a wait)
 };
 
 namespace {
@@ -127,6 +135,63 @@ __global__ __launch_bounds__(kBlock) void unpack_state_kernel(const uint8_t* all
     a.n_hills[r] = ((const uint32_t*)(in + L.n_hills()))[j];
 }
 
+
+// ---- a rank's byte range of the PAF file, tokenised on its own GPU (rala_hip_mg_set_overlaps_from_paf) ------------------
+// what the cuts between the ranks' rows need to know of a rank's rows: ends[0] = its first resolved row (query and target
+// known; all ones: none), ends[1] = one behind its last, ends[2] = the first resolved row behind ends[0] whose query differs
+// from that row's (n: none) - where the run that may have begun on the rank before ends
+constexpr uint32_t kNoRow = 0xFFFFFFFFu;
+__global__ __launch_bounds__(kBlock) void run_ends_kernel(const uint32_t* __restrict__ a_id, const uint32_t* __restrict__ b_id, uint32_t n,
+                                                          uint32_t n_reads, uint32_t* ends) {
+    uint32_t lo = kNoRow, hi = 0;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        if (a_id[i] < n_reads && b_id[i] < n_reads) { lo = lo < i ? lo : i; hi = i + 1; }
+    }
+    for (int d = 32; d; d >>= 1) {
+        const uint32_t l2 = (uint32_t)__shfl_xor((int)lo, d, 64), h2 = (uint32_t)__shfl_xor((int)hi, d, 64);
+        lo = lo < l2 ? lo : l2; hi = hi > h2 ? hi : h2;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (lo != kNoRow) atomicMin(&ends[0], lo);
+        if (hi) atomicMax(&ends[1], hi);
+    }
+}
+__global__ __launch_bounds__(kBlock) void head_run_kernel(const uint32_t* __restrict__ a_id, const uint32_t* __restrict__ b_id, uint32_t n,
+                                                          uint32_t n_reads, uint32_t* ends) {
+    const uint32_t first = ends[0];
+    if (first == kNoRow) return;
+    const uint32_t head = a_id[first];
+    uint32_t lo = kNoRow;
+    for (uint32_t i = first + 1 + blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        if (a_id[i] < n_reads && b_id[i] < n_reads && a_id[i] != head) { lo = i; break; }
+    }
+    for (int d = 32; d; d >>= 1) {
+        const uint32_t l2 = (uint32_t)__shfl_xor((int)lo, d, 64);
+        lo = lo < l2 ? lo : l2;
+    }
+    if ((threadIdx.x & 63) == 0 && lo != kNoRow) atomicMin(&ends[2], lo);
+}
+// ends[3], ends[4] = the queries of the first and the last resolved row
+__global__ void run_ends_names_kernel(const uint32_t* __restrict__ a_id, uint32_t* ends) {
+    ends[3] = ends[0] == kNoRow ? kNoRow : a_id[ends[0]];
+    ends[4] = ends[1] == 0 ? kNoRow : a_id[ends[1] - 1];
+}
+
+// a column with room for `need` entries that keeps its first `keep`
+template <class T>
+hipError_t grow_keep(DevBuf<T>& b, size_t keep, size_t need, hipStream_t s) {
+    if (need <= b.n && b.p) return hipSuccess;
+    DevBuf<T> larger;
+    hipError_t e = larger.ensure(need + need / 8);
+    if (e != hipSuccess) return e;
+    if (keep) e = hipMemcpyAsync(larger.p, b.p, keep * sizeof(T), hipMemcpyDeviceToDevice, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return e;
+    std::swap(larger.p, b.p);
+    std::swap(larger.n, b.n);
+    return hipSuccess;
+}
+
 #define MGCHECK(call)                                                                    \
     do {                                                                                 \
         hipError_t e_ = (call);                                                          \
@@ -195,48 +260,82 @@ int run_primary(rala_hip_mg* mg, bool with_sens) {
     Comm* comm = mg->comm;
     const uint32_t P = mg->world;
     hipStream_t s = cs->stream;
-    double t = now_ms();
-    auto lap = [&](float& slot) {
-        (void)hipStreamSynchronize(cs->stream);
-        (void)hipStreamSynchronize(cl->stream);
-        const double u = now_ms();
-        slot = (float)(u - t);
-        t = u;
-    };
+    // Stage boundaries are events on the slice context's stream, read at the end of the run: nobody waits for a stage
+    // to end just to look at the clock.  (Rounds 1 - 4 synchronised both streams after every stage.)
+    int n_marks = 0;
+    auto mark = [&]() { if (n_marks < 8) (void)hipEventRecord(mg->ev[n_marks++], s); };
+    mark();
     std::vector<uint64_t> all;
 
-    // 1. slice: duplicates, owner-grouped bounds - as bound records {local read, begin, end} (8 bytes per overlap side)
-    // where the reads are short and few enough for the format (rala_hip_bound_records_fit: the same answer on every
-    // rank, checked with the status word), as tuples {local read, bound} (two per side) otherwise
-    const bool records = cs->use_bound_records && rala_hip_bound_records_fit(cs, P) != 0;
-    int rc = from_ctx(mg, cs, rala_hip_dedupe(cs), "dedupe");
+    // 1. slice: duplicates, owner-grouped bounds.  Scattered once by (owner, partition) where the reads suit the
+    // partitioned bucketing (shard_path_fits: the same answer on every rank, checked with the status word); otherwise as
+    // bound records {local read, begin, end} (8 bytes per overlap side) where the reads are short and few enough for that
+    // format (rala_hip_bound_records_fit), as tuples {local read, bound} (two per side) in the last resort
+    const bool fused = cs->use_fused_emit && cs->use_bound_records && shard_path_fits(mg->n_reads, cs->max_read_len, P);
+    const bool records = !fused && cs->use_bound_records && rala_hip_bound_records_fit(cs, P) != 0;
+    const ShardGeometry geom = shard_geometry(mg->n_reads, P);
+    int rc = RALA_HIP_OK;
     std::vector<uint64_t> send_counts(P, 0);
-    if (rc == RALA_HIP_OK) {
-        if (mg->d_send.ensure(4 * std::max<uint64_t>(cs->n_ovl, 1) + 8) != hipSuccess) rc = mg_fail(mg, RALA_HIP_ENOMEM, "tuple buffer");
-        else if (records) rc = from_ctx(mg, cs, rala_hip_emit_bound_records_bucketed(cs, P, (uint64_t*)mg->d_send.p, send_counts.data()), "emit records");
-        else rc = from_ctx(mg, cs, rala_hip_emit_bound_tuples_bucketed(cs, P, (uint64_t*)mg->d_send.p, send_counts.data()), "emit tuples");
+    if (fused) {
+        if (mg->d_send.ensure(shard_send_words(geom, cs->n_ovl)) != hipSuccess) rc = mg_fail(mg, RALA_HIP_ENOMEM, "send buffer");
+        else rc = from_ctx(mg, cs, shard_emit(cs, geom, (uint64_t*)mg->d_send.p, send_counts.data()), "emit blocks");
+    } else {
+        rc = from_ctx(mg, cs, rala_hip_dedupe(cs), "dedupe");
+        if (rc == RALA_HIP_OK) {
+            if (mg->d_send.ensure(4 * std::max<uint64_t>(cs->n_ovl, 1) + 8) != hipSuccess) rc = mg_fail(mg, RALA_HIP_ENOMEM, "tuple buffer");
+            else if (records) rc = from_ctx(mg, cs, rala_hip_emit_bound_records_bucketed(cs, P, (uint64_t*)mg->d_send.p, send_counts.data()), "emit records");
+            else rc = from_ctx(mg, cs, rala_hip_emit_bound_tuples_bucketed(cs, P, (uint64_t*)mg->d_send.p, send_counts.data()), "emit tuples");
+        }
     }
     // (the bucket sizes travel with the status: one host exchange)
-    rc = agree_with(mg, rc, "emit", (with_sens ? 1u : 0u) | (records ? 2u : 0u), send_counts.data(), P, all);
+    rc = agree_with(mg, rc, "emit", (with_sens ? 1u : 0u) | (records ? 2u : 0u) | (fused ? 4u : 0u), send_counts.data(), P, all);
     if (rc != RALA_HIP_OK) return rc;
-    lap(mg->tm.emit_ms);
+    mark();
 
-    // 2. ONE all-to-all(v) of 8-byte tuples
+    // 2. ONE all-to-all(v) of 8-byte elements (the own part of the blocks is not moved)
     std::vector<uint64_t> recv_counts(P);
     uint64_t n_recv = 0;
-    for (uint32_t p = 0; p < P; ++p) { recv_counts[p] = all[(size_t)p * (P + 1) + 1 + mg->rank]; n_recv += recv_counts[p]; }
+    for (uint32_t p = 0; p < P; ++p) {
+        recv_counts[p] = all[(size_t)p * (P + 1) + 1 + mg->rank];
+        if (!(fused && p == mg->rank)) n_recv += recv_counts[p];
+    }
     MGCHECK(mg->d_recv.ensure(n_recv + 8));
-    rc = from_comm(mg, comm->all_to_all_v(mg->d_send.p, send_counts.data(), mg->d_recv.p, recv_counts.data(), sizeof(uint2), s),
-                   "all-to-all of the bound tuples");
+    rc = from_comm(mg, comm->all_to_all_v(mg->d_send.p, send_counts.data(), mg->d_recv.p, recv_counts.data(), sizeof(uint2), s, !fused),
+                   "all-to-all of the bounds");
     if (rc != RALA_HIP_OK) return rc;
-    lap(mg->tm.exchange_ms);
+    mark();
     mg->tm.tuples_sent = 0;
     for (uint32_t p = 0; p < P; ++p) if (p != mg->rank) mg->tm.tuples_sent += send_counts[p];
 
-    // 3. owner: piles of the reads this rank owns
-    rc = from_ctx(mg, cl, records ? rala_hip_set_bound_records(cl, (const uint64_t*)mg->d_recv.p, n_recv, RALA_HIP_MEM_DEVICE)
-                                  : rala_hip_set_bound_tuples(cl, (const uint64_t*)mg->d_recv.p, n_recv, RALA_HIP_MEM_DEVICE),
-                  "set tuples");
+    // 3. owner: piles of the reads this rank owns (its stream starts behind the exchange)
+    MGCHECK(hipEventRecord(mg->ev[7], s));
+    MGCHECK(hipStreamWaitEvent(cl->stream, mg->ev[7], 0));
+    if (fused) {
+        ShardBlocks blocks;
+        uint64_t at = 0, mine_at = 0, n_records = 0, words = 0;
+        for (uint32_t p = 0; p < P; ++p) {
+            if (p < mg->rank) mine_at += send_counts[p];
+            blocks.off[p] = (uint32_t)at;
+            if (recv_counts[p] < geom.header) {           // (every block starts with its header)
+                mg->verdict_shared = true;
+                return mg_fail(mg, RALA_HIP_EDEVICE, "a block shorter than its header");
+            }
+            n_records += recv_counts[p] - geom.header;
+            if (p != mg->rank) at += recv_counts[p];
+            words += recv_counts[p];
+        }
+        for (uint32_t p = P; p < 64; ++p) blocks.off[p] = 0;
+        blocks.off[mg->rank] = (uint32_t)mine_at;
+        blocks.self = mg->rank;
+        if (std::max<uint64_t>(at, mine_at + recv_counts[mg->rank]) >= 0xFFFFFFF0ull) {
+            return mg_fail(mg, RALA_HIP_EINVAL, "positions of the bound records must fit 32 bits");
+        }
+        rc = from_ctx(mg, cl, set_bound_blocks(cl, (const uint64_t*)mg->d_recv.p, (const uint64_t*)mg->d_send.p, blocks, geom, n_records), "set blocks");
+    } else {
+        rc = from_ctx(mg, cl, records ? rala_hip_set_bound_records(cl, (const uint64_t*)mg->d_recv.p, n_recv, RALA_HIP_MEM_DEVICE)
+                                      : rala_hip_set_bound_tuples(cl, (const uint64_t*)mg->d_recv.p, n_recv, RALA_HIP_MEM_DEVICE),
+                      "set tuples");
+    }
     if (rc == RALA_HIP_OK) {
         rc = rala_hip_initialize(cl);
         if (rc == RALA_HIP_EFILTERED) rc = RALA_HIP_OK;      // all of ONE rank's reads filtered is not the job's verdict
@@ -246,7 +345,7 @@ int run_primary(rala_hip_mg* mg, bool with_sens) {
     const uint64_t my_pool = rc == RALA_HIP_OK ? cl->pool_used : 0;
     rc = agree_with(mg, rc, "owner initialize", 0, &my_pool, 1, all);
     if (rc != RALA_HIP_OK) return rc;
-    lap(mg->tm.owner_ms);
+    mark();
 
     // 4. all-gather of the per-read state and the interval pools; install in the slice context
     StateLayout L{mg->nl_pad};
@@ -283,14 +382,23 @@ int run_primary(rala_hip_mg* mg, bool with_sens) {
         mg->verdict_shared = true;
         return from_ctx(mg, cs, rc, "initialize");
     }
-    lap(mg->tm.gather_ms);
+    mark();
 
     // 5. second pass .. preprocess tail .. graph, sharded by slice where it is per overlap.  (No status
     // exchange behind it: a rank that fails in there aborts the group, the caller sees to that.)
     rc = from_ctx(mg, cs, construct_stages(cs, comm, with_sens), "construct");
     if (rc != RALA_HIP_OK) return rc;
-    lap(mg->tm.construct_ms);
+    mark();
     return RALA_HIP_OK;
+}
+
+// the stages' times from the events run_primary recorded (after the run's last wait for the stream)
+void read_marks(rala_hip_mg* mg) {
+    float* const slot[5] = {&mg->tm.emit_ms, &mg->tm.exchange_ms, &mg->tm.owner_ms, &mg->tm.gather_ms, &mg->tm.construct_ms};
+    for (int k = 0; k < 5; ++k) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, mg->ev[k], mg->ev[k + 1]) == hipSuccess) *slot[k] = ms;
+    }
 }
 
 }  // namespace
@@ -322,6 +430,7 @@ int rala_hip_mg_create_contexts(int device, uint32_t rank, uint32_t world, rala_
     mg->device = device; mg->rank = rank; mg->world = world;
     int rc = rala_hip_create(device, &mg->cs);
     if (rc == RALA_HIP_OK) rc = rala_hip_create(device, &mg->cl);
+    for (auto& e : mg->ev) if (rc == RALA_HIP_OK && hipEventCreate(&e) != hipSuccess) rc = RALA_HIP_EDEVICE;
     if (rc != RALA_HIP_OK) { rala_hip_mg_destroy(mg); return rc; }
     *out = mg;
     return RALA_HIP_OK;
@@ -359,6 +468,7 @@ void rala_hip_mg_destroy(rala_hip_mg* mg) {
     (void)hipSetDevice(mg->device);
     if (mg->cs) (void)hipStreamSynchronize(mg->cs->stream);
     if (mg->cl) (void)hipStreamSynchronize(mg->cl->stream);
+    for (auto& e : mg->ev) if (e) (void)hipEventDestroy(e);
     delete mg->comm;
     mg->d_send.release(); mg->d_recv.release(); mg->d_state_mine.release(); mg->d_state_all.release();
     if (mg->cl) rala_hip_destroy(mg->cl);
@@ -417,6 +527,142 @@ int rala_hip_mg_slice_cuts(const uint32_t* a_id, const uint32_t* b_id, uint64_t 
     return RALA_HIP_OK;
 }
 
+
+// The overlaps of a sharded run from PAF TEXT, every rank's share tokenised on its own GPU (collective; round 5 - before,
+// `rala --gpus N` parsed the whole file on the host and handed every rank a slice from host memory).  Rank k ships bytes
+// [n k / P, n (k + 1) / P) of the file to its device and tokenises the lines that START there (ingest.hip); the rows of all
+// ranks, in rank order, are the file's records.  A slice must not cut a run of equal queries (duplicate removal is per
+// run, graph.cpp:343-350; rala_hip_mg_slice_cuts): the ranks exchange what the cuts depend on - their row counts, the
+// queries of their first and last resolved rows, where their first run ends - with the status word, every rank computes
+// the same cuts, and the rows in front of a rank's cut (the tail of a run that began on a rank before it, unresolved
+// records in front of the first resolved one) travel to the rank that holds the run's start, column by column.
+// *length_error_read: the first record in file order whose length differs from its sequence's (check_lengths); -1: none.
+// *irregular != 0 (the same on every rank): not a file of 12-column records - nothing was set, take the host reader.
+namespace {
+int ingest_paf(rala_hip_mg* mg, const char* path, int check_lengths, uint32_t threads, int64_t* length_error_read, int* irregular);
+}
+int rala_hip_mg_set_overlaps_from_paf(rala_hip_mg* mg, const char* path, int check_lengths, uint32_t threads, int64_t* length_error_read,
+                                      int* irregular) {
+    if (!mg || !path || !length_error_read || !irregular) return RALA_HIP_EINVAL;
+    *length_error_read = -1;
+    *irregular = 0;
+    if (!mg->comm) return mg_fail(mg, RALA_HIP_EINVAL, "the rank has not joined its group (rala_hip_mg_join)");
+    if (!mg->have_reads) return mg_fail(mg, RALA_HIP_EINVAL, "set the reads first");
+    mg->verdict_shared = false;
+    const int rc = ingest_paf(mg, path, check_lengths, threads, length_error_read, irregular);
+    // (a failure the others do not know of: they must not wait for this rank in the next collective)
+    if (rc != RALA_HIP_OK && !mg->verdict_shared) mg->comm->abort();
+    return rc;
+}
+namespace {
+int ingest_paf(rala_hip_mg* mg, const char* path, int check_lengths, uint32_t threads, int64_t* length_error_read, int* irregular) {
+    rala_hip_ctx* cs = mg->cs;
+    const uint32_t P = mg->world, me = mg->rank;
+    constexpr uint64_t kNone = 0xFFFFFFFFull;
+    int rc = RALA_HIP_OK;
+    mg->have_overlaps = false;
+    if (hipSetDevice(mg->device) != hipSuccess) rc = mg_fail(mg, RALA_HIP_EDEVICE, "hipSetDevice");
+    hipStream_t s = cs->stream;
+    PafTarget T;
+    for (int k = 0; k < 7; ++k) T.col[k] = &cs->d_paf_col[k];
+    T.strand = &cs->d_paf_strand;
+    PafRange R;
+    uint64_t file_n = 0;
+    if (rc == RALA_HIP_OK) {
+        struct stat st;
+        if (stat(path, &st) != 0) rc = mg_fail(mg, RALA_HIP_EINVAL, std::string("cannot open ") + path);
+        else if (!S_ISREG(st.st_mode)) rc = mg_fail(mg, RALA_HIP_ENOTAFILE, std::string("not a regular file: ") + path);
+        else file_n = (uint64_t)st.st_size;
+    }
+    cs->inputs_set = false;
+    cs->n_ovl = 0;
+    if (rc == RALA_HIP_OK) {
+        const uint64_t lo = file_n / P * me + std::min<uint64_t>(me, file_n % P), hi = file_n / P * (me + 1) + std::min<uint64_t>(me + 1, file_n % P);
+        rc = from_ctx(mg, cs, paf_tokenise_range(cs, path, lo, hi, check_lengths != 0, threads, 1u << 16, T, &R), "tokenise");
+    }
+    // what the cuts need of this rank's rows
+    uint32_t ends[5] = {kNoRow, 0, 0, kNoRow, kNoRow};
+    const uint32_t n_mine = (uint32_t)R.n_lines;
+    if (rc == RALA_HIP_OK && R.flags == 0) {
+        DevBuf<uint32_t>& d_ends = cs->d_shard_words;             // (eight words of scratch)
+        hipError_t e = d_ends.ensure(64);
+        ends[2] = n_mine;
+        if (e == hipSuccess) e = hipMemcpyAsync(d_ends.p, ends, sizeof(ends), hipMemcpyHostToDevice, s);
+        if (e == hipSuccess && n_mine) {
+            const uint32_t grid = std::min<uint32_t>((n_mine + kBlock - 1) / kBlock, 2048);
+            hipLaunchKernelGGL(run_ends_kernel, dim3(grid), dim3(kBlock), 0, s, (const uint32_t*)cs->d_paf_col[0].p, (const uint32_t*)cs->d_paf_col[1].p,
+                               n_mine, (uint32_t)mg->n_reads, d_ends.p);
+            hipLaunchKernelGGL(head_run_kernel, dim3(grid), dim3(kBlock), 0, s, (const uint32_t*)cs->d_paf_col[0].p, (const uint32_t*)cs->d_paf_col[1].p,
+                               n_mine, (uint32_t)mg->n_reads, d_ends.p);
+            hipLaunchKernelGGL(run_ends_names_kernel, dim3(1), dim3(1), 0, s, (const uint32_t*)cs->d_paf_col[0].p, d_ends.p);
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(ends, d_ends.p, sizeof(ends), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) rc = mg_fail(mg, RALA_HIP_EDEVICE, std::string("run ends: ") + hipGetErrorString(e));
+    }
+    // one host exchange: {rows, first resolved row, end of the first run, query of the first / last resolved row, tokeniser's
+    // flags, first length error}
+    const uint64_t mine[7] = {n_mine, ends[0] == kNoRow ? n_mine : ends[0], ends[2], ends[3], ends[4], R.flags, R.first_bad};
+    std::vector<uint64_t> all;
+    rc = agree_with(mg, rc, "device ingest", 0, mine, 7, all);
+    if (rc != RALA_HIP_OK) return rc;
+    auto of = [&](uint32_t p, uint32_t f) { return all[(size_t)p * 8 + 1 + f]; };
+    uint32_t flags = 0;
+    for (uint32_t p = 0; p < P; ++p) flags |= (uint32_t)of(p, 5);
+    if (flags) { *irregular = (int)flags; return RALA_HIP_OK; }
+    for (uint32_t p = 0; p < P; ++p) {
+        if (of(p, 6) != ~0ull) { *length_error_read = (int64_t)(of(p, 6) & 0xFFFFFFFFull); return RALA_HIP_OK; }   // (file order: the lowest rank's)
+    }
+    // the cuts: how many of its first rows every rank gives away, to whom, what every rank ends up with
+    std::vector<uint64_t> n_rows(P), move(P, 0), final_rows(P, 0), first_pos(P, 0);
+    std::vector<uint32_t> dest(P, 0);
+    uint64_t X = kNone;
+    uint32_t keeper = 0;                                // the last rank so far that keeps a row (0 while there is none)
+    for (uint32_t p = 0; p < P; ++p) {
+        n_rows[p] = of(p, 0);
+        const uint64_t lead = of(p, 1), head_end = of(p, 2), head_a = of(p, 3), tail_a = of(p, 4);
+        if (p == 0) move[p] = 0;
+        else if (head_a == kNone) move[p] = n_rows[p];                 // nothing resolves: the rows stand behind the record in front of them
+        else if (X != kNone && head_a == X) move[p] = head_end;        // the run goes on: up to its end
+        else move[p] = lead;                                           // a cut never falls on a record that does not resolve
+        dest[p] = keeper;
+        if (n_rows[p] > move[p]) keeper = p;
+        if (tail_a != kNone) X = tail_a;
+    }
+    for (uint32_t p = 0; p < P; ++p) {
+        final_rows[p] += n_rows[p] - move[p];
+        if (move[p]) final_rows[dest[p]] += move[p];
+    }
+    for (uint32_t p = 1; p < P; ++p) first_pos[p] = first_pos[p - 1] + final_rows[p - 1];
+    if (first_pos[P - 1] + final_rows[P - 1] >= 0xFFFFFFF0ull) return mg_fail(mg, RALA_HIP_ETOOLARGE, "file positions must fit 32 bits");
+    // the rows in front of the cuts travel, column by column
+    std::vector<uint64_t> send_counts(P, 0), recv_counts(P, 0);
+    if (move[me]) send_counts[dest[me]] = move[me];
+    uint64_t incoming = 0;
+    for (uint32_t p = 0; p < P; ++p) if (p != me && move[p] && dest[p] == me) { recv_counts[p] = move[p]; incoming += move[p]; }
+    for (int k = 0; k < 7 && rc == RALA_HIP_OK; ++k) {
+        if (grow_keep(cs->d_paf_col[k], n_mine, (size_t)n_mine + incoming + 1, s) != hipSuccess) rc = mg_fail(mg, RALA_HIP_ENOMEM, "overlap columns");
+    }
+    if (rc == RALA_HIP_OK && grow_keep(cs->d_paf_strand, n_mine, (size_t)n_mine + incoming + 1, s) != hipSuccess) rc = mg_fail(mg, RALA_HIP_ENOMEM, "overlap columns");
+    if (rc != RALA_HIP_OK) return rc;                   // (this rank's alone: the caller ends the group)
+    for (int k = 0; k < 7; ++k) {
+        rc = from_comm(mg, mg->comm->all_to_all_v(cs->d_paf_col[k].p, send_counts.data(), cs->d_paf_col[k].p + n_mine, recv_counts.data(), 4, s),
+                       "rows in front of the cuts");
+        if (rc != RALA_HIP_OK) return rc;
+    }
+    rc = from_comm(mg, mg->comm->all_to_all_v(cs->d_paf_strand.p, send_counts.data(), cs->d_paf_strand.p + n_mine, recv_counts.data(), 1, s),
+                   "rows in front of the cuts");
+    if (rc != RALA_HIP_OK) return rc;
+    MGCHECK(hipStreamSynchronize(s));
+    const uint64_t off = move[me];
+    rala_hip_overlaps dev;
+    dev.a_id = cs->d_paf_col[0].p + off; dev.b_id = cs->d_paf_col[1].p + off; dev.a_begin = cs->d_paf_col[2].p + off;
+    dev.a_end = cs->d_paf_col[3].p + off; dev.b_begin = cs->d_paf_col[4].p + off; dev.b_end = cs->d_paf_col[5].p + off;
+    dev.length = cs->d_paf_col[6].p + off; dev.strand = cs->d_paf_strand.p + off;
+    return rala_hip_mg_set_overlaps(mg, &dev, final_rows[me], first_pos[me], RALA_HIP_MEM_DEVICE);
+}
+}  // namespace
+
 namespace {
 
 int run_all(rala_hip_mg* mg, const rala_hip_overlaps* sens_slice, uint64_t n_sens, uint32_t* n_pairs) {
@@ -438,6 +684,7 @@ int run_all(rala_hip_mg* mg, const rala_hip_overlaps* sens_slice, uint64_t n_sen
     if (rc != RALA_HIP_OK) return rc;
     mg->tm.tr_ms = (float)(now_ms() - t1);
     mg->tm.total_ms = (float)(now_ms() - t0);
+    read_marks(mg);
     return RALA_HIP_OK;
 }
 
@@ -474,6 +721,14 @@ int rala_hip_mg_run_threads(rala_hip_mg** ranks, uint32_t n, const rala_hip_over
         if (pairs[k] != pairs[0]) { ranks[0]->err = "ranks disagree on the transitive reduction"; return RALA_HIP_EDEVICE; }
     }
     *n_pairs = pairs[0];
+    return RALA_HIP_OK;
+}
+
+int rala_hip_mg_get_slice(rala_hip_mg* mg, uint64_t* first, uint64_t* n) {
+    if (!mg || !first || !n) return RALA_HIP_EINVAL;
+    if (!mg->have_overlaps) return mg_fail(mg, RALA_HIP_EINVAL, "no overlaps set");
+    *first = mg->cs->ovl.base;
+    *n = mg->cs->n_ovl;
     return RALA_HIP_OK;
 }
 

@@ -32,6 +32,25 @@ int transitive_stage(rala_hip_ctx* ctx, Comm* comm, uint32_t* n_pairs);
 // there too (rala_hip_dedupe).  Counts the filtered reads.
 int install_read_state(rala_hip_ctx* ctx, uint64_t pool_count);
 
+// sharded runs, the bounds scattered once on the sender (bucket_kernels.hip): the sender's and the owner's side
+int shard_emit(rala_hip_ctx* ctx, const ShardGeometry& g, uint64_t* send, uint64_t* words);
+int set_bound_blocks(rala_hip_ctx* ctx, const uint64_t* base, const uint64_t* base_self, const ShardBlocks& blocks, const ShardGeometry& g,
+                     uint64_t n_records);
+
+// the device tokeniser (ingest.hip): the lines that start in bytes [lo, hi) of a PAF file into the target's columns
+struct PafTarget {
+    DevBuf<uint32_t>* col[7];       // a_id, b_id, a_begin, a_end, b_begin, b_end, length
+    DevBuf<uint8_t>* strand;
+};
+struct PafRange {
+    uint64_t n_lines = 0;
+    unsigned long long first_bad = ~0ull;      // row << 32 | read of the first record whose length differs from its sequence's
+    uint32_t flags = 0;                        // != 0: not a file of 12-column records (kernels.h: launch_paf_parse)
+    uint64_t file_bytes = 0;
+};
+int paf_tokenise_range(rala_hip_ctx* ctx, const char* path, uint64_t lo, uint64_t hi, bool check_lengths, uint32_t threads,
+                       size_t extra_rows, const PafTarget& T, PafRange* out);
+
 hipError_t stream_sync(rala_hip_ctx* ctx, hipStream_t s);
 hipError_t d2h_small(rala_hip_ctx* ctx, void* dst, const void* src, size_t bytes, hipStream_t s);
 

@@ -14,7 +14,7 @@ TYPE_X, TYPE_A, TYPE_B, TYPE_AB, TYPE_BA = range(5)
 NO_READ = 0xFFFFFFFF
 MEM_HOST, MEM_DEVICE = 0, 1
 
-ERRORS = {0: "OK", -1: "EDEVICE", -2: "EINVAL", -3: "ECAPACITY", -4: "EFILTERED", -5: "ENOMEM"}
+ERRORS = {0: "OK", -1: "EDEVICE", -2: "EINVAL", -3: "ECAPACITY", -4: "EFILTERED", -5: "ENOMEM", -6: "ENOTAFILE", -7: "ETOOLARGE"}
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "librala_hip.so")
 
@@ -31,7 +31,8 @@ SYMBOLS = (
     "rala_hip_copy_device_state", "rala_hip_layout", "rala_hip_find_repetitive_hills",
     "rala_hip_mg_unique_id", "rala_hip_mg_local_group_create", "rala_hip_mg_local_group_destroy", "rala_hip_mg_create",
     "rala_hip_mg_create_contexts", "rala_hip_mg_join", "rala_hip_set_name_table", "rala_hip_set_overlaps_from_paf",
-    "rala_hip_get_ingest_timings", "rala_hip_get_overlap_columns",
+    "rala_hip_get_ingest_timings", "rala_hip_get_overlap_columns", "rala_hip_tokenise_sensitive_paf",
+    "rala_hip_mg_set_overlaps_from_paf", "rala_hip_mg_get_slice",
     "rala_hip_mg_destroy", "rala_hip_mg_last_error", "rala_hip_mg_set_reads", "rala_hip_mg_slice_cuts",
     "rala_hip_mg_set_overlaps", "rala_hip_mg_run", "rala_hip_mg_run_threads", "rala_hip_mg_context",
     "rala_hip_mg_owner_context",

@@ -8,11 +8,13 @@
  * src/overlap.hpp:27-117).  Built into rala_amd/host/librala_api.so; not part of librala.so.
  */
 
+#include <stdio.h>
 #include <string.h>
 #include <stdint.h>
 
 #include <memory>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -158,6 +160,94 @@ void* hp_paf_device(const char* path, const char* names, const uint32_t* read_le
         if (out->rc == RALA_HIP_OK) out->rc = rala_hip_get_overlap_columns(ctx, &out->n, cols, out->strand.data());
     }
     rala_hip_destroy(ctx);
+    return out;
+}
+// The same over `world` ranks that share device 0 (in-process transport), every rank on a thread of its own: rank k ships and
+// tokenises its byte range of the file, the ranks settle the cuts between runs of equal queries and move the rows in front
+// of them (rala_hip_mg_set_overlaps_from_paf).  The handle holds the slices' columns back to back (which must be the
+// file's records in order); slices[2 k], [2 k + 1] = file position of rank k's first record and its record count.
+// sensitive != 0: the ranks' shares of a sensitive file instead (rala_hip_tokenise_sensitive_paf, no collective, no cuts).
+void* hp_paf_device_ranks(const char* path, const char* names, const uint32_t* read_len, uint64_t n_reads, int check_lengths, uint32_t threads,
+                          uint32_t world, int sensitive, uint64_t* slices) {
+    std::vector<std::string> nm;
+    const char* p = names;
+    for (uint64_t i = 0; i < n_reads; ++i) {
+        const char* e = strchr(p, '\n');
+        nm.emplace_back(p, e ? (size_t)(e - p) : strlen(p));
+        p = e ? e + 1 : p + strlen(p);
+    }
+    rala::io::NameTable table;
+    table.build(nm);
+    auto* out = new PafOnDevice();
+    void* group = nullptr;
+    out->rc = rala_hip_mg_local_group_create(world, &group);
+    if (out->rc != RALA_HIP_OK) return out;
+    std::vector<rala_hip_mg*> ranks(world, nullptr);
+    for (uint32_t k = 0; k < world && out->rc == RALA_HIP_OK; ++k) out->rc = rala_hip_mg_create_contexts(0, k, world, &ranks[k]);
+    std::vector<int> rc(world, RALA_HIP_OK), irregular(world, 0);
+    std::vector<int64_t> bad(world, -1);
+    std::vector<std::vector<uint32_t>> col[7];
+    for (auto& c : col) c.resize(world);
+    std::vector<std::vector<uint8_t>> strand(world);
+    uint64_t file_bytes = 0;
+    if (sensitive) {
+        FILE* f = fopen(path, "rb");
+        if (f) { fseek(f, 0, SEEK_END); file_bytes = (uint64_t)ftell(f); fclose(f); }
+    }
+    if (out->rc == RALA_HIP_OK) {
+        std::vector<std::thread> th;
+        for (uint32_t k = 0; k < world; ++k) {
+            th.emplace_back([&, k]() {
+                rala_hip_mg* mg = ranks[k];
+                int r = rala_hip_mg_join(mg, RALA_HIP_COMM_LOCAL, group);
+                if (r == RALA_HIP_OK) r = rala_hip_mg_set_reads(mg, read_len, n_reads);
+                rala_hip_ctx* cs = rala_hip_mg_context(mg);
+                if (r == RALA_HIP_OK) r = rala_hip_set_name_table(cs, table.buckets(), table.n_buckets(), table.arena().data(), table.arena().size());
+                uint64_t first = 0, n = 0;
+                std::vector<uint32_t> got[7];
+                std::vector<uint8_t> got_strand;
+                if (sensitive) {
+                    rala_hip_overlaps dev = {};
+                    if (r == RALA_HIP_OK) r = rala_hip_tokenise_sensitive_paf(cs, path, file_bytes * k / world, file_bytes * (k + 1) / world, threads, &dev, &n, &irregular[k]);
+                    if (r == RALA_HIP_OK && !irregular[k]) {
+                        // (read back through the context: the columns are plain device memory, adopted as its overlaps)
+                        r = rala_hip_set_overlaps(cs, &dev, n, RALA_HIP_MEM_DEVICE);
+                        uint32_t* dst[7];
+                        for (int c = 0; c < 7; ++c) { got[c].resize(n); dst[c] = got[c].data(); }
+                        got_strand.resize(n);
+                        uint64_t n2 = 0;
+                        if (r == RALA_HIP_OK) r = rala_hip_get_overlap_columns(cs, &n2, dst, got_strand.data());
+                    }
+                } else {
+                    if (r == RALA_HIP_OK) r = rala_hip_mg_set_overlaps_from_paf(mg, path, check_lengths, threads, &bad[k], &irregular[k]);
+                    if (r == RALA_HIP_OK && !irregular[k] && bad[k] < 0) {
+                        r = rala_hip_mg_get_slice(mg, &first, &n);
+                        uint32_t* dst[7];
+                        for (int c = 0; c < 7; ++c) { got[c].resize(n); dst[c] = got[c].data(); }
+                        got_strand.resize(n);
+                        uint64_t n2 = 0;
+                        if (r == RALA_HIP_OK) r = rala_hip_get_overlap_columns(cs, &n2, dst, got_strand.data());
+                        if (r == RALA_HIP_OK && n2 != n) r = RALA_HIP_EDEVICE;
+                    }
+                }
+                slices[2 * k] = first; slices[2 * k + 1] = n;
+                for (int c = 0; c < 7; ++c) col[c][k] = std::move(got[c]);
+                strand[k] = std::move(got_strand);
+                rc[k] = r;
+            });
+        }
+        for (auto& t : th) t.join();
+    }
+    for (uint32_t k = 0; k < world; ++k) {
+        if (rc[k] != RALA_HIP_OK && out->rc == RALA_HIP_OK) { out->rc = rc[k]; fprintf(stderr, "[hp_paf_device_ranks] rank %u: %s\n", k, rala_hip_mg_last_error(ranks[k])); }
+        out->irregular |= irregular[k];
+        if (bad[k] >= 0 && out->bad < 0) out->bad = bad[k];
+        for (int c = 0; c < 7; ++c) out->col[c].insert(out->col[c].end(), col[c][k].begin(), col[c][k].end());
+        out->strand.insert(out->strand.end(), strand[k].begin(), strand[k].end());
+    }
+    out->n = out->strand.size();
+    for (rala_hip_mg* r : ranks) if (r) rala_hip_mg_destroy(r);
+    rala_hip_mg_local_group_destroy(group);
     return out;
 }
 // info[0 .. 5] = return code, irregular flags, first read with a length mismatch (-1 none), records, ship us, tokenise us

@@ -38,9 +38,14 @@ for case in range(n_cases):
         st = parity.oracle_stages(ds, n_threads=effective_cpus())
         sh = Sharded(ds, world)
         opts = {}
-        if rng.random() < 0.3:
+        form = rng.random()              # (default: the bounds scattered once, by (owner, partition), on the senders)
+        if form < 0.15:
+            opts["use_fused_emit"] = 0
             opts["use_bound_records"] = 0
             variant.append("tuples")
+        elif form < 0.35:
+            opts["use_fused_emit"] = 0
+            variant.append("records")
         if rng.random() < 0.4:
             opts["debug_fp_lds_limit"] = int(rng.choice([0, 7, 100]))
             variant.append("limit%d" % opts["debug_fp_lds_limit"])

@@ -110,22 +110,3 @@ int main() {
                                os.path.join(d, "t.cpp")])
         out = subprocess.check_output([exe]).split()
     assert out == [b"999000", b"4"]
-
-
-def test_persistent_pile_kernel_code_object(tmp_path):
-    """The persistent pile kernel requests data by inline assembly into registers the compiler does not have
-    (pile_runs_kernel.hip, kPersist): the generated code is checked - nothing but the kernel's own statements names
-    v64 .. v71, every read of one of them stands behind a wait, 72 registers in all (tools/check_persist_isa.py)."""
-    import subprocess
-    import sys
-
-    from rala_amd import build
-
-    src = os.path.join(ROOT, "rala_amd", "csrc", "pile_runs_kernel.hip")
-    asm = str(tmp_path / "pile_runs_kernel.s")
-    subprocess.run([build.hipcc(), "--offload-arch=gfx950", "--cuda-device-only", "-S", "-O3", "-std=c++17", "-fPIC",
-                    "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.dirname(src), src, "-o", asm],
-                   check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_persist_isa.py"), asm],
-                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-    assert res.returncode == 0, res.stdout

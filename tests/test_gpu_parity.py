@@ -73,39 +73,20 @@ def test_bucketing_variants(hip_ctx_factory, n, g, seed):
         parity.check_initialize(ctx, st, ds)
 
 
-@pytest.mark.parametrize("n,g,seed,cov", [(3000, 600_000, 21, None), (400, 20_000, 5, None), (40_000, 8_000_000, 13, None),
-                                          (2000, 100_000, 17, None)])
-@pytest.mark.parametrize("grid", [8, 64, 1000, 7168, 1 << 20])
-def test_persistent_pile_kernel(hip_ctx_factory, n, g, seed, cov, grid):
-    """The first pile kernel as persistent workgroups (option pile_persistent_grid; pile_runs_kernel<.., kPersist>): every
-    workgroup loops over its share of the reads, the next read's events and the offsets of the one after are requested a
-    read ahead, the annotations go out an item late.  Shares of many reads, of one or two, of none; reads that are not
-    this kernel's (event-dense: (400, 20 000) has 500x coverage; handed on) pass through it without events; reads
-    without a valid region leave before the item's wait."""
-    ds = Dataset(n, g, seed)
-    st = parity.oracle_stages(ds)
-    ctx = hip_ctx_factory()
-    ctx.set_option("pile_persistent_grid", grid)
-    ctx.set_reads(ds.read_len)
-    ctx.set_overlaps(ds.overlaps)
-    ctx.initialize()
-    parity.check_initialize(ctx, st, ds)
-    ctx.construct()
-    parity.check_construct(ctx, st)
-    parity.check_tr(ctx, st)
-
-
 @pytest.mark.parametrize("n,g,seed", [(3000, 600_000, 21), (5000, 1_000_000, 7), (600, 60_000, 9), (40_000, 8_000_000, 13)])
 @pytest.mark.parametrize("opts", [{"debug_fp_lds_limit": 0}, {"debug_fp_lds_limit": 40}, {"use_round_batches": 0},
-                                  {"debug_fp_lds_limit": 0, "env": "RALA_HIP_DEBUG_FP_GIVE_UP"}])
+                                  {"debug_fp_lds_limit": 0, "env": ("RALA_HIP_DEBUG_FP_GIVE_UP", "1")},
+                                  {"debug_fp_lds_limit": 0, "env": ("RALA_HIP_DEBUG_FP_GIVE_UP", "2")}])
 def test_containment_fixed_point_variants(hip_ctx_factory, monkeypatch, n, g, seed, opts):
     """The ends of the containment fixed points (second pass, the tail's two scans; fixed_point_kernels.hip): every list
     through the kernel for long lists (resident workgroups, a barrier per round; C5 takes it), a mix of both kernels,
     the host's loop of one look per round - and the long lists' kernel when its workgroups cannot meet (nothing
-    guarantees that they are resident together): the last one to leave does the rounds alone."""
+    guarantees that they are resident together): the last one to leave does the rounds alone.  "2": one
+    workgroup stops waiting at every barrier behind the first, the last one included (passing and giving
+    up are decided by one word - a barrier is passed by all or by none)."""
     opts = dict(opts)
     if "env" in opts:
-        monkeypatch.setenv(opts.pop("env"), "1")
+        monkeypatch.setenv(*opts.pop("env"))
     ds = Dataset(n, g, seed)
     st = parity.oracle_stages(ds)
     ctx = hip_ctx_factory()

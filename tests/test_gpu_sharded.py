@@ -107,10 +107,14 @@ def test_sharded_run_matches_oracle(sharded_factory, world, n, g, seed):
 
 
 @pytest.mark.parametrize("n,g,seed,factor", [(3000, 600_000, 21, 1), (600, 60_000, 9, 1), (400, 80_000, 5, 230)])
-def test_sharded_run_bound_tuples_instead_of_records(sharded_factory, n, g, seed, factor):
-    """The bounds travel as 8-byte records {local read, begin, end} where the reads are shorter than 2^21 - 32 bases
-    (the default, every other test here); this is the older format - two tuples {local read, bound} per overlap side,
-    bucketed by the owners' single-pass kernel - by option, and by itself for reads of 2.3 M bases."""
+@pytest.mark.parametrize("form", ["tuples", "records"])
+def test_sharded_run_bound_tuples_instead_of_records(sharded_factory, n, g, seed, factor, form):
+    """The default (every other test here): the senders scatter the bounds ONCE, by (owner, partition of the owner's reads),
+    and the owners start at the second level of the partitioned bucketing (round 5; reads shorter than 2^26 - 32 bases).
+    These are the older formats, by option: "records" - 8-byte records {local read, begin, end} grouped by owner only, the
+    owners bucket them from the first level on (rounds 3 - 4; reads shorter than 2^21 - 32 bases); "tuples" - two tuples
+    {local read, bound} per overlap side through the owners' single-pass kernel (round 2) - and what reads of 2.3 M bases
+    take by themselves when the blocks are switched off."""
     from test_gpu_parity import _Scaled
 
     ds = Dataset(n, g, seed)
@@ -119,9 +123,22 @@ def test_sharded_run_bound_tuples_instead_of_records(sharded_factory, n, g, seed
         assert int(ds.read_len.max()) > (1 << 21)
     st = parity.oracle_stages(ds)
     sh = sharded_factory(ds, 3)
-    if factor == 1:
-        for r in sh.ranks:
+    for r in sh.ranks:
+        r.context().set_option("use_fused_emit", 0)
+        if factor == 1 and form == "tuples":
             r.context().set_option("use_bound_records", 0)
+    n_tr = sh.run()
+    for r in sh.ranks:
+        check_rank(r.context(), st, n_tr)
+
+
+def test_sharded_run_long_reads_through_the_blocks(sharded_factory):
+    """reads of 2.3 M bases (beyond the 21 coordinate bits of the older record format) still take the blocks: 26 bits"""
+    from test_gpu_parity import _Scaled
+
+    ds = _Scaled(Dataset(400, 80_000, 5), 230)
+    st = parity.oracle_stages(ds)
+    sh = sharded_factory(ds, 3)
     n_tr = sh.run()
     for r in sh.ranks:
         check_rank(r.context(), st, n_tr)
