@@ -8,8 +8,10 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <algorithm>
 #include <chrono>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "io.hpp"
@@ -89,4 +91,80 @@ extern "C" int rala_e2e_from_paf(const char* paf_path, const uint32_t* read_len,
                                  uint32_t* n_transitive) {
     return rala_e2e_from_paf_with(paf_path, read_len, n_reads, num_threads, 1, ms_parse, ms_upload, ms_device, n_overlaps,
                                   n_transitive, nullptr);
+}
+
+// The same over several ranks (threads of this process, one per device ordinal in `devices`; transport: 0 RCCL, 1 the
+// in-process one, which also lets ranks share a device): every rank ships and tokenises its own byte range of the file on
+// its own GPU (rala_hip_mg_set_overlaps_from_paf), then the sharded step.  ms_ingest: name tables + ship + tokenise + the
+// cuts' exchange (the slowest rank); ms_device: the step (first call).
+extern "C" int rala_e2e_from_paf_ranks(const char* paf_path, const uint32_t* read_len, uint64_t n_reads, uint32_t num_threads, uint32_t world,
+                                       const int* devices, int transport, double* ms_ingest, double* ms_device, uint64_t* n_overlaps,
+                                       uint32_t* n_transitive) {
+    using clock = std::chrono::steady_clock;
+    auto ms = [](clock::time_point a, clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    if (world == 0 || world > 64) return RALA_HIP_EINVAL;
+    std::vector<std::string> names(n_reads);
+    for (uint64_t i = 0; i < n_reads; ++i) names[i] = "r" + std::to_string(i);
+    rala::io::NameTable table;
+    table.build(names);
+    void* group = nullptr;
+    unsigned char id[128] = {0};
+    if (transport == RALA_HIP_COMM_LOCAL) {
+        if (rala_hip_mg_local_group_create(world, &group) != RALA_HIP_OK) return -1;
+    } else if (rala_hip_mg_unique_id(id) != RALA_HIP_OK) {
+        return -1;
+    }
+    std::vector<rala_hip_mg*> ranks(world, nullptr);
+    std::vector<int> rc(world, RALA_HIP_OK);
+    for (uint32_t k = 0; k < world; ++k) rc[k] = rala_hip_mg_create_contexts(devices[k], k, world, &ranks[k]);
+    int bad_rc = RALA_HIP_OK;
+    for (uint32_t k = 0; k < world; ++k) if (rc[k] != RALA_HIP_OK) bad_rc = rc[k];
+    std::vector<uint64_t> rows(world, 0);
+    std::vector<int> irregular(world, 0);
+    std::vector<int64_t> bad(world, -1);
+    auto on_every_rank = [&](auto f) {
+        std::vector<std::thread> th;
+        for (uint32_t k = 0; k < world; ++k) th.emplace_back([&, k]() { rc[k] = f(k); });
+        for (auto& t : th) t.join();
+        for (uint32_t k = 0; k < world; ++k) if (rc[k] != RALA_HIP_OK && bad_rc == RALA_HIP_OK) {
+            bad_rc = rc[k];
+            fprintf(stderr, "[rala_e2e_from_paf_ranks] rank %u: %s\n", k, rala_hip_mg_last_error(ranks[k]));
+        }
+    };
+    if (bad_rc == RALA_HIP_OK) {
+        on_every_rank([&](uint32_t k) {
+            int r = rala_hip_mg_join(ranks[k], transport, transport == RALA_HIP_COMM_LOCAL ? group : (void*)id);
+            if (r == RALA_HIP_OK) r = rala_hip_mg_set_reads(ranks[k], read_len, n_reads);
+            return r;
+        });
+    }
+    const auto t0 = clock::now();
+    if (bad_rc == RALA_HIP_OK) {
+        on_every_rank([&](uint32_t k) {
+            int r = rala_hip_set_name_table(rala_hip_mg_context(ranks[k]), table.buckets(), table.n_buckets(), table.arena().data(), table.arena().size());
+            const int r2 = rala_hip_mg_set_overlaps_from_paf(ranks[k], r == RALA_HIP_OK ? paf_path : "", 1, std::max(1u, num_threads / world), &bad[k],
+                                                             &irregular[k]);
+            if (r == RALA_HIP_OK) r = r2;
+            uint64_t first = 0;
+            if (r == RALA_HIP_OK && !irregular[k] && bad[k] < 0) r = rala_hip_mg_get_slice(ranks[k], &first, &rows[k]);
+            return r;
+        });
+        for (uint32_t k = 0; k < world; ++k) if (bad_rc == RALA_HIP_OK && (irregular[k] || bad[k] >= 0)) bad_rc = -2;
+    }
+    const auto t1 = clock::now();
+    uint32_t pairs = 0;
+    if (bad_rc == RALA_HIP_OK) {
+        bad_rc = rala_hip_mg_run_threads(ranks.data(), world, nullptr, nullptr, &pairs);
+        if (bad_rc != RALA_HIP_OK) {
+            for (uint32_t k = 0; k < world; ++k) fprintf(stderr, "[rala_e2e_from_paf_ranks] rank %u: %s\n", k, rala_hip_mg_last_error(ranks[k]));
+        }
+    }
+    const auto t2 = clock::now();
+    *ms_ingest = ms(t0, t1); *ms_device = ms(t1, t2);
+    *n_overlaps = 0;
+    for (uint64_t r : rows) *n_overlaps += r;
+    *n_transitive = pairs;
+    for (rala_hip_mg* r : ranks) if (r) rala_hip_mg_destroy(r);
+    if (group) rala_hip_mg_local_group_destroy(group);
+    return bad_rc;
 }

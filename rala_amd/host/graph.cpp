@@ -260,10 +260,18 @@ void Graph::initialize() {
     timer("[rala::Graph::initialize] loaded sequences");
     timer();
     name_table_.build(names_);
-    // One GPU, an uncompressed PAF file: the text goes to the device and is tokenised there (rala_hip_set_overlaps_from_paf;
-    // RALA_DEVICE_INGEST=0 keeps the host reader).  A file that tokeniser calls irregular falls through to the host reader,
-    // which knows what to do with lines that are no 12-column records.
-    if (ranks_.empty() && io::has_suffix(overlaps_path_, ".paf") && !(getenv("RALA_DEVICE_INGEST") && atoi(getenv("RALA_DEVICE_INGEST")) == 0)) {
+    // An uncompressed PAF file: the text goes to the device and is tokenised there (rala_hip_set_overlaps_from_paf;
+    // RALA_DEVICE_INGEST=0 keeps the host reader).  A file that tokeniser calls irregular - or cannot take: no regular file,
+    // too large for its 32-bit counts, no room for its text in device memory - falls through to the host reader, which knows
+    // what to do with such files (a FIFO named *.paf used to end with "unable to open file").
+    const bool device_ingest = io::has_suffix(overlaps_path_, ".paf") && !(getenv("RALA_DEVICE_INGEST") && atoi(getenv("RALA_DEVICE_INGEST")) == 0);
+    auto falls_back = [](int rc) { return rc == RALA_HIP_ENOTAFILE || rc == RALA_HIP_ETOOLARGE || rc == RALA_HIP_ENOMEM; };
+    auto length_error = [](int64_t bad) {
+        fprintf(stderr, "[rala::Overlap::transmute] error: "
+            "unequal lengths in sequence and overlap file for sequence with id %lu!\n", (uint64_t)bad);
+        exit(1);
+    };
+    if (ranks_.empty() && device_ingest) {
         check(ctx_, rala_hip_set_reads(ctx_, read_len_.data(), read_len_.size()), "initialize");
         check(ctx_, rala_hip_set_name_table(ctx_, name_table_.buckets(), name_table_.n_buckets(), name_table_.arena().data(),
                                             name_table_.arena().size()), "initialize");
@@ -275,18 +283,62 @@ void Graph::initialize() {
             fprintf(stderr, "[rala::Graph::initialize] error: unable to open file %s!\n", overlaps_path_.c_str());
             exit(1);
         }
-        check(ctx_, rc, "initialize");
-        if (bad >= 0) {
-            fprintf(stderr, "[rala::Overlap::transmute] error: "
-                "unequal lengths in sequence and overlap file for sequence with id %lu!\n", (uint64_t)bad);
-            exit(1);
+        if (!falls_back(rc)) {
+            check(ctx_, rc, "initialize");
+            if (bad >= 0) length_error(bad);
+            if (!irregular) {
+                timer("[rala::Graph::initialize] loaded overlaps");
+                timer();
+                initialize_piles();
+                return;
+            }
         }
-        if (!irregular) {
+    }
+    if (!ranks_.empty() && device_ingest) {
+        // several GPUs: every rank ships and tokenises its own byte range of the file on its own GPU, the ranks settle the
+        // cuts between runs of equal queries among themselves (rala_hip_mg_set_overlaps_from_paf; round 5 - before, the host
+        // parsed the whole file and handed every rank a slice from host memory)
+        const uint32_t P = (uint32_t)ranks_.size();
+        std::vector<int> rc(P, RALA_HIP_OK), irregular(P, 0);
+        std::vector<int64_t> bad(P, -1);
+        std::vector<std::thread> th;
+        for (uint32_t k = 0; k < P; ++k) {
+            th.emplace_back([&, k]() {
+                rala_hip_mg* mg = ranks_[k];
+                int r = rala_hip_mg_set_reads(mg, read_len_.data(), read_len_.size());
+                if (r == RALA_HIP_OK) {
+                    r = rala_hip_set_name_table(rala_hip_mg_context(mg), name_table_.buckets(), name_table_.n_buckets(),
+                                                name_table_.arena().data(), name_table_.arena().size());
+                }
+                // (collective: a rank that failed above still calls it, with nothing to read, so that nobody waits for it)
+                const int r2 = rala_hip_mg_set_overlaps_from_paf(mg, r == RALA_HIP_OK ? overlaps_path_.c_str() : "", 1,
+                                                                 std::max(1u, num_threads_ / P), &bad[k], &irregular[k]);
+                rc[k] = r != RALA_HIP_OK ? r : r2;
+            });
+        }
+        for (auto& t : th) t.join();
+        bool every_rank_ok = true, fall = false;
+        for (uint32_t k = 0; k < P; ++k) {
+            if (rc[k] == RALA_HIP_EINVAL && access(overlaps_path_.c_str(), R_OK) != 0) {
+                fprintf(stderr, "[rala::Graph::initialize] error: unable to open file %s!\n", overlaps_path_.c_str());
+                exit(1);
+            }
+            every_rank_ok = every_rank_ok && rc[k] == RALA_HIP_OK;
+            fall = fall || falls_back(rc[k]) || irregular[k];
+        }
+        if (every_rank_ok && !fall) {
+            for (uint32_t k = 0; k < P; ++k) if (bad[k] >= 0) length_error(bad[k]);
             timer("[rala::Graph::initialize] loaded overlaps");
-            timer();
-            initialize_piles();
             return;
         }
+        if (!fall) {
+            for (uint32_t k = 0; k < P; ++k) {
+                if (rc[k] != RALA_HIP_OK) fprintf(stderr, "[rala::Graph::initialize] error: %s!\n", rala_hip_mg_last_error(ranks_[k]));
+            }
+            exit(1);
+        }
+        // (irregular, or beyond the tokeniser's limits on some rank: the host reader below - the group is intact unless a
+        // rank failed alone, which ends the run at the first collective)
     }
     read_overlaps(overlaps_path_, name_to_id_, name_table_, read_len_, true, num_threads_, overlaps_);
     if (!ranks_.empty()) {
@@ -345,6 +397,10 @@ void Graph::construct(const std::string& sensitive_overlaps_path) {
     io::OverlapColumns s_cols;
     rala_hip_overlaps sens = {};
     uint64_t n_sens = 0;
+    // the sensitive overlaps tokenised on the device(s): every context's share as device pointers
+    bool sens_on_device_ = false;
+    std::vector<rala_hip_overlaps> device_shares_;
+    std::vector<uint64_t> device_share_n_;
     if (!sensitive_overlaps_path.empty()) {
         if (!(io::has_suffix(sensitive_overlaps_path, ".mhap") || io::has_suffix(sensitive_overlaps_path, ".mhap.gz") ||
               io::has_suffix(sensitive_overlaps_path, ".paf") || io::has_suffix(sensitive_overlaps_path, ".paf.gz"))) {
@@ -353,11 +409,53 @@ void Graph::construct(const std::string& sensitive_overlaps_path) {
                 ".mhap, .mhap.gz, .paf, .paf.gz)!\n", sensitive_overlaps_path.c_str());
             exit(1);
         }
-        read_overlaps(sensitive_overlaps_path, name_to_id_, name_table_, read_len_, false, num_threads_, s_cols);
-        sens.a_id = s_cols.a_id.data(); sens.b_id = s_cols.b_id.data(); sens.a_begin = s_cols.a_begin.data();
-        sens.a_end = s_cols.a_end.data(); sens.b_begin = s_cols.b_begin.data(); sens.b_end = s_cols.b_end.data();
-        sens.length = s_cols.length.data(); sens.strand = s_cols.strand.data();
-        n_sens = s_cols.size();
+        // an uncompressed PAF file is tokenised on the device(s) - no length check, Overlap::transmute_ has none (round 5;
+        // RALA_DEVICE_INGEST=0, or a file the tokeniser cannot take: the host reader)
+        const bool device_ingest = io::has_suffix(sensitive_overlaps_path, ".paf") && name_table_.n_buckets() != 0 &&
+                                   !(getenv("RALA_DEVICE_INGEST") && atoi(getenv("RALA_DEVICE_INGEST")) == 0);
+        if (device_ingest) {
+            const uint32_t P = ranks_.empty() ? 1u : (uint32_t)ranks_.size();
+            uint64_t file_bytes = 0;
+            {
+                std::ifstream f(sensitive_overlaps_path, std::ios::binary | std::ios::ate);
+                if (f) file_bytes = (uint64_t)f.tellg();
+            }
+            device_shares_.assign(P, rala_hip_overlaps());
+            device_share_n_.assign(P, 0);
+            std::vector<int> rc(P, RALA_HIP_OK), irregular(P, 0);
+            std::vector<std::thread> th;
+            for (uint32_t k = 0; k < P; ++k) {
+                th.emplace_back([&, k]() {
+                    rala_hip_ctx* c = ranks_.empty() ? ctx_ : rala_hip_mg_context(ranks_[k]);
+                    // (a run that took the host reader for the primary overlaps has set no name table yet)
+                    rc[k] = rala_hip_set_name_table(c, name_table_.buckets(), name_table_.n_buckets(), name_table_.arena().data(),
+                                                    name_table_.arena().size());
+                    if (rc[k] == RALA_HIP_OK) {
+                        rc[k] = rala_hip_tokenise_sensitive_paf(c, sensitive_overlaps_path.c_str(), file_bytes / P * k + std::min<uint64_t>(k, file_bytes % P),
+                                                                file_bytes / P * (k + 1) + std::min<uint64_t>(k + 1, file_bytes % P),
+                                                                std::max(1u, num_threads_ / P), &device_shares_[k], &device_share_n_[k], &irregular[k]);
+                    }
+                });
+            }
+            for (auto& t : th) t.join();
+            sens_on_device_ = true;
+            for (uint32_t k = 0; k < P; ++k) sens_on_device_ = sens_on_device_ && rc[k] == RALA_HIP_OK && !irregular[k];
+            if (sens_on_device_) {
+                for (uint32_t k = 0; k < P; ++k) {
+                    rala_hip_ctx* c = ranks_.empty() ? ctx_ : rala_hip_mg_context(ranks_[k]);
+                    check(c, rala_hip_set_option(c, "sensitive_in_device_memory", 1), "construct");
+                    n_sens += device_share_n_[k];
+                }
+                if (ranks_.empty()) sens = device_shares_[0];
+            }
+        }
+        if (!sens_on_device_) {
+            read_overlaps(sensitive_overlaps_path, name_to_id_, name_table_, read_len_, false, num_threads_, s_cols);
+            sens.a_id = s_cols.a_id.data(); sens.b_id = s_cols.b_id.data(); sens.a_begin = s_cols.a_begin.data();
+            sens.a_end = s_cols.a_end.data(); sens.b_begin = s_cols.b_begin.data(); sens.b_end = s_cols.b_end.data();
+            sens.length = s_cols.length.data(); sens.strand = s_cols.strand.data();
+            n_sens = s_cols.size();
+        }
     }
     if (!ranks_.empty()) {
         // all ranks together: piles on the owners, filtering per slice, tail + graph replicated
@@ -365,13 +463,19 @@ void Graph::construct(const std::string& sensitive_overlaps_path) {
         std::vector<rala_hip_overlaps> shares(P);
         std::vector<uint64_t> n_share(P, 0);
         for (uint32_t k = 0; k < P; ++k) {
+            if (sens_on_device_) {
+                shares[k] = device_shares_[k];
+                n_share[k] = device_share_n_[k];
+                continue;
+            }
             const uint64_t lo = n_sens * k / P, hi = n_sens * (k + 1) / P;
             shares[k] = {sens.a_id + lo, sens.b_id + lo, sens.a_begin + lo, sens.a_end + lo, sens.b_begin + lo,
                          sens.b_end + lo, sens.length + lo, sens.strand + lo};
             n_share[k] = hi - lo;
         }
         uint32_t pairs = 0;
-        const int rc = rala_hip_mg_run_threads(ranks_.data(), P, n_sens ? shares.data() : nullptr, n_sens ? n_share.data() : nullptr,
+        const bool with_sens = !sensitive_overlaps_path.empty() && (n_sens != 0 || sens_on_device_);
+        const int rc = rala_hip_mg_run_threads(ranks_.data(), P, with_sens ? shares.data() : nullptr, with_sens ? n_share.data() : nullptr,
                                                &pairs);
         if (rc == RALA_HIP_EFILTERED) {
             fprintf(stderr, "[rala::Graph::initialize] error: filtered all sequences!\n");

@@ -330,12 +330,19 @@ def test_cli_several_ranks_give_the_single_gpu_result(tmp_path, gpus):
         assert r.returncode == 0, r.stderr.decode()
         return r.stdout, open(prefix + ".csv").read(), open(prefix + ".json").read()
 
+    # (round 5) every rank tokenises its own byte range of the PAF text - and its share of the -s file - on its own GPU;
+    # RALA_DEVICE_INGEST=0: the host readers hand out slices from host memory, as before
+    host_readers = dict(many, RALA_DEVICE_INGEST="0")
     for extra in ([], ["-s", sens_paf]):
         one = run(extra, os.environ, "one%d" % len(extra))
-        more = run(extra + ["--gpus", str(gpus)], many, "many%d" % len(extra))
-        assert one[0] == more[0] and len(one[0]) > 100_000
-        assert one[1] == more[1]
-        assert one[2] == more[2]            # the JSON carries whole coverage vectors: fetched from the owners
+        for env, tag in ((many, "many"), (host_readers, "host")):
+            more = run(extra + ["--gpus", str(gpus)], env, "%s%d" % (tag, len(extra)))
+            assert one[0] == more[0] and len(one[0]) > 100_000
+            assert one[1] == more[1]
+            assert one[2] == more[2]            # the JSON carries whole coverage vectors: fetched from the owners
+        if extra:
+            old = run(extra, dict(os.environ, RALA_DEVICE_INGEST="0"), "onehost")   # one GPU, the -s file through the host reader
+            assert old == one
     a = subprocess.run([exe, "-p", fa, paf], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     b = subprocess.run([exe, "-p", "--gpus", str(gpus), fa, paf], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=many)
     assert a.returncode == 0 and b.returncode == 0 and a.stdout == b.stdout
