@@ -155,6 +155,49 @@ def end_to_end_from_paf(ds, workload):
     return best
 
 
+def from_pinned_host(ds, device, steps=3):
+    """SURVEY 8(d) words the kernel-only figure as "binary SoA already in pinned host memory" - what a Graph that keeps its
+    own parser would hand over.  `value` has the columns in HBM; this member is the same step with
+    the upload in front of it: the eight columns (29 bytes per overlap) from page-locked host memory over PCIe, then
+    initialize + construct + remove_transitive_edges, back to back (the bucketing needs every overlap before its first
+    scatter: what an upload in pieces could hide behind is the duplicate removal and the counting pass, 0.2 of the step's
+    7.7 ms at C3, against 30 ms of transfer - the link is the bound either way)."""
+    import torch
+    from rala_amd import hip
+    from rala_amd.synth import FIELDS
+
+    class _Pinned:
+        pass
+    pinned = _Pinned()
+    keep = []
+    for f in list(FIELDS) + ["strand"]:
+        t = torch.from_numpy(getattr(ds.overlaps, f)).pin_memory()
+        keep.append(t)
+        setattr(pinned, f, t.numpy())
+    pinned.__class__.__len__ = lambda self: len(ds.overlaps)
+    ctx = hip.Context(device)
+    ctx.set_reads(ds.read_len)
+    best = None
+    n_tr = 0
+    for _ in range(steps + 1):                 # (the first call allocates the columns' device memory)
+        t0 = time.perf_counter()
+        ctx.set_overlaps(pinned)
+        t1 = time.perf_counter()
+        ctx.initialize()
+        ctx.construct()
+        n_tr = ctx.remove_transitive_edges()
+        t2 = time.perf_counter()
+        if best is None or t2 - t0 < best[0]:
+            best = (t2 - t0, t1 - t0, t2 - t1)
+    ctx.close()
+    n = len(ds.overlaps)
+    nbytes = 29.0 * n
+    return {"value": n / best[0], "unit": "overlaps/s", "ms_upload": 1e3 * best[1], "ms_step": 1e3 * best[2], "ms_total": 1e3 * best[0],
+            "upload_GBs": nbytes / best[1] / 1e9, "bytes_uploaded": nbytes, "transitive_pairs": int(n_tr),
+            "source": "measured in this run (best of %d): columns in page-locked host memory -> rala_hip_set_overlaps (eight copies over "
+                      "PCIe) -> the step; upload and step back to back" % steps}
+
+
 def end_to_end_from_paf_ranks(ds, world, devices, transport):
     """the same for a sharded run (ranks as threads of this process): every rank ships and tokenises its own byte range of the
     file on its own GPU (rala_hip_mg_set_overlaps_from_paf), then the sharded step - nothing is parsed on the host"""
@@ -521,6 +564,13 @@ def main():
             except Exception as e:      # noqa: BLE001 - the headline figure stands without it
                 log("[bench] end-to-end figure failed: %s" % e)
                 out["end_to_end_from_paf"] = {"error": str(e)}
+        if not args.no_e2e and world == 1 and not sharded and not with_sens:
+            try:
+                out["from_pinned_host"] = from_pinned_host(ds, local_rank)
+                assert out["from_pinned_host"]["transitive_pairs"] == int(n_tr)
+            except Exception as e:      # noqa: BLE001 - the headline figure stands without it
+                log("[bench] host-fed figure failed: %s" % e)
+                out["from_pinned_host"] = {"error": str(e)}
         if not args.no_e2e and world == 1 and not sharded:
             try:
                 out["end_to_end_from_paf"] = end_to_end_from_paf(ds, args.workload)

@@ -117,6 +117,81 @@ __global__ __launch_bounds__(kBlockC) void group_count_kernel(OvlSoA o, uint32_t
     }
 }
 
+// The counting pass AND duplicate removal's first pass in one (round 5).  Both read the two id columns of every overlap;
+// duplicate removal ran beside the bucketing on a second stream and cost it 0.14 ms at C3, its own two kernels moved the
+// ids twice more.  Here a thread takes four CONSECUTIVE overlaps per group (16-byte loads) and, besides the histogram:
+//   * marks the queries that own a run whose targets are not strictly increasing, or a record that does not resolve
+//     (dedupe_mark_kernel's rule, overlap_kernels.hip; the element in front of a thread's four comes from the lane below);
+//   * writes the validity byte that holds for every query that is NOT marked - resolvable and no self overlap
+//     (graph.cpp:273-307 on a run of strictly increasing targets) - four of them as one word;
+//   * sets *any when anybody was marked: dedupe_fix_kernel then goes over the marked queries' overlaps with the full
+//     comparison, and leaves at once otherwise (the usual file).
+// Needs the id columns on 16-byte boundaries (the caller looks).
+__device__ __forceinline__ void load4_ids(const uint32_t* p, uint64_t i0, uint64_t n, uint32_t (&out)[4]) {
+    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+    if (i0 + 4 <= n) {
+        const u32x4_t v = __builtin_nontemporal_load((const u32x4_t*)(p + i0));
+        out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+    } else {
+#pragma unroll
+        for (uint32_t e = 0; e < 4; ++e) out[e] = i0 + e < n ? p[i0 + e] : kInf;
+    }
+}
+constexpr uint32_t kCountVec = 2;               // groups of four overlaps per thread and trip
+__global__ __launch_bounds__(kBlockC) void group_count_dedupe_kernel(OvlSoA o, uint32_t n_reads, uint32_t n_groups, uint32_t* group_count,
+                                                                     uint8_t* __restrict__ suspect, uint8_t* __restrict__ valid, uint32_t* any) {
+    extern __shared__ uint32_t s_hist[];
+    for (uint32_t g = threadIdx.x; g < n_groups; g += kBlockC) s_hist[g] = 0;
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63;
+    bool flagged = false;
+    constexpr uint64_t kTrip = (uint64_t)kBlockC * 4 * kCountVec;
+    for (uint64_t c0 = (uint64_t)blockIdx.x * kTrip; c0 < o.n; c0 += (uint64_t)gridDim.x * kTrip) {
+        uint32_t a[kCountVec][4], b[kCountVec][4];
+#pragma unroll
+        for (uint32_t u = 0; u < kCountVec; ++u) {
+            const uint64_t i0 = c0 + ((uint64_t)u * kBlockC + threadIdx.x) * 4;
+            load4_ids(o.a_id, i0, o.n, a[u]);
+            load4_ids(o.b_id, i0, o.n, b[u]);
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < kCountVec; ++u) {
+            const uint64_t i0 = c0 + ((uint64_t)u * kBlockC + threadIdx.x) * 4;
+            // the overlap in front of this thread's four: the last one of the lane below, or (first lane of a wavefront) from memory
+            uint32_t pa = (uint32_t)__shfl_up((int)a[u][3], 1, 64), pb = (uint32_t)__shfl_up((int)b[u][3], 1, 64);
+            if (lane == 0 && i0 > 0 && i0 < o.n) { pa = o.a_id[i0 - 1]; pb = o.b_id[i0 - 1]; }
+            bool have_prev = i0 > 0;
+            uint32_t word = 0;
+#pragma unroll
+            for (uint32_t e = 0; e < 4; ++e) {
+                const uint32_t x = a[u][e], y = b[u][e];
+                const bool in = i0 + e < o.n;
+                const bool ok = in && x < n_reads && y < n_reads;
+                if (ok) atomicAdd(&s_hist[y >> kGroupShift], 1u);
+                if (in && have_prev) {
+                    const bool pok = pa < n_reads && pb < n_reads;
+                    if (ok && pok) {
+                        if (pa == x && y <= pb) { suspect[x] = 1; flagged = true; }
+                    } else {
+                        // an unresolved record hides the order of its neighbours: flag both queries
+                        if (x < n_reads) { suspect[x] = 1; flagged = true; }
+                        if (pa < n_reads) { suspect[pa] = 1; flagged = true; }
+                    }
+                }
+                if (ok && x != y) word |= 1u << (8 * e);
+                pa = x; pb = y; have_prev = true;
+            }
+            if (i0 + 4 <= o.n) *(uint32_t*)(valid + i0) = word;
+            else for (uint32_t e = 0; e < 4 && i0 + e < o.n; ++e) valid[i0 + e] = (uint8_t)(word >> (8 * e));
+        }
+    }
+    if (__syncthreads_or(flagged ? 1 : 0) && threadIdx.x == 0) *any = 1u;
+    for (uint32_t g = threadIdx.x; g < n_groups; g += kBlockC) {
+        const uint32_t c = s_hist[g];
+        if (c) atomicAdd(&group_count[g], c);
+    }
+}
+
 // From the groups' counts (n_groups of them, padded with empty ones to n_part * kGroupsPerPart): group_base[0 ..
 // n] and group_cursor = exclusive prefix; part_cursor[p] = group_base[p * kGroupsPerPart] (a partition's records
 // lie where its groups' will); the table of level-2 tiles - tile t covers records tile_lo[t] .. tile_hi[t] of
@@ -630,6 +705,7 @@ struct PartitionBuffers {
 hipError_t count_attribute(size_t lds_count) {
     if (lds_count > 64 * 1024) {        // (per launch: the attribute belongs to the function on the current device)
         hipError_t e = hipFuncSetAttribute((const void*)group_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_count);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)group_count_dedupe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_count);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)group_count_records_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_count);
         return e;
     }
@@ -653,14 +729,23 @@ void launch_partition_rest(const PartitionBuffers& B, uint32_t n_reads, const ui
 }
 }  // namespace
 
+bool bucket_count_can_dedupe(const OvlSoA& o, const uint8_t* valid) {
+    return (((uintptr_t)o.a_id | (uintptr_t)o.b_id) & 15u) == 0 && ((uintptr_t)valid & 3u) == 0 && getenv("RALA_DEDUPE_APART") == nullptr;
+}
+
+// dedupe (may be null): the counting pass does duplicate removal's first pass on the way (group_count_dedupe_kernel) -
+// suspect: n_reads bytes, cleared here; valid: the validity bytes; any: a zeroed word; the caller runs launch_dedupe_fix
+// behind this call's counting pass (the event `counted`, recorded here when given)
 hipError_t launch_bucket_partitioned(const OvlSoA& o, uint32_t n_reads, uint32_t* acount, uint32_t* written,
                                      uint32_t* part_cursor, uint32_t* group, uint32_t* tiles, uint64_t* rec1, uint64_t* rec2,
-                                     uint32_t* ev_off, uint32_t* ev, uint32_t workgroups, FillList& fills, hipStream_t s) {
+                                     uint32_t* ev_off, uint32_t* ev, uint32_t workgroups, FillList& fills, hipStream_t s,
+                                     const BucketDedupe* dedupe) {
     const PartitionBuffers B(n_reads, o.n, group, tiles);
     // (with whatever the caller wants cleared at this point)
     fills.add(acount, 0, (size_t)n_reads * 4);
     fills.add(written, 0, (size_t)n_reads * 4);
     fills.add(B.group_count, 0, (size_t)B.group_slots * 4);
+    if (dedupe) fills.add(dedupe->suspect, 0, n_reads);
     hipError_t e = fills.launch(s);
     if (e != hipSuccess) return e;
     const size_t lds_count = (size_t)B.n_part * kGroupsPerPart * 4;
@@ -669,8 +754,17 @@ hipError_t launch_bucket_partitioned(const OvlSoA& o, uint32_t n_reads, uint32_t
     const uint32_t chunks = (uint32_t)((o.n + kBlockC * kCountPer - 1) / (kBlockC * kCountPer));
     // (two workgroups per compute unit where their histograms fit side by side)
     const uint32_t count_groups = (workgroups ? workgroups : 256u) * (2 * lds_count <= 150u * 1024u ? 2u : 1u);
-    hipLaunchKernelGGL(group_count_kernel, dim3(std::min<uint32_t>(count_groups, chunks)), dim3(kBlockC), lds_count, s, o,
-                       n_reads, B.n_part * kGroupsPerPart, B.group_count);
+    if (dedupe) {
+        hipLaunchKernelGGL(group_count_dedupe_kernel, dim3(std::min<uint32_t>(count_groups, chunks)), dim3(kBlockC), lds_count, s, o,
+                           n_reads, B.n_part * kGroupsPerPart, B.group_count, dedupe->suspect, dedupe->valid, dedupe->any);
+        if (dedupe->counted) {
+            e = hipEventRecord(dedupe->counted, s);
+            if (e != hipSuccess) return e;
+        }
+    } else {
+        hipLaunchKernelGGL(group_count_kernel, dim3(std::min<uint32_t>(count_groups, chunks)), dim3(kBlockC), lds_count, s, o,
+                           n_reads, B.n_part * kGroupsPerPart, B.group_count);
+    }
     hipLaunchKernelGGL(layout_kernel, dim3(1), dim3(1024), 0, s, (const uint32_t*)B.group_count, B.n_part, B.group_base, B.group_cursor,
                        part_cursor, B.tile_part, B.tile_lo, B.tile_hi, B.n_tiles);
     const uint32_t tiles1 = (uint32_t)((o.n + kTile - 1) / kTile);

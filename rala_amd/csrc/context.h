@@ -256,7 +256,7 @@ struct rala_hip_ctx {
     rala_hip::DevBuf<uint32_t> d_rank, d_alive_reads, d_t_tmp[2], d_kept_item, d_dovetail, d_epos, d_node_rank,
         d_node_read, d_e[3], d_t_death[2], d_t_work[2], d_t_fin, d_fp_map, d_fp_pack;
     rala_hip::DevBuf<uint8_t> d_t_mark;
-    rala_hip::PinnedBuf<uint32_t> p_alive_reads;
+    rala_hip::PinnedBuf<uint32_t> p_alive_reads, p_sens_rest;
     rala_hip::PinnedBuf<uint8_t> p_touched;
     rala_hip::PinnedBuf<uint16_t> p_cmed;
 

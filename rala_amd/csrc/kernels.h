@@ -318,7 +318,10 @@ struct SensSplitArgs {
     uint32_t* out[4];
     uint32_t* counts;
 };
-void launch_sens_split(const uint32_t* list, uint32_t n, const SensSplitArgs& args, hipStream_t s);
+// (the list's length is on the device: *n_dev, at most `bound`)
+void launch_sens_split(const uint32_t* list, uint32_t bound, const uint32_t* n_dev, const SensSplitArgs& args, hipStream_t s);
+// *status &= ~bits; *zero = 0 (zero may be null)
+void launch_status_clear(uint32_t* status, uint32_t bits, uint32_t* zero, hipStream_t s);
 void launch_scatter_component_medians(const uint32_t* alive_reads, const uint8_t* touched, const uint16_t* cmed, uint32_t n_alive,
                                       uint16_t* out, hipStream_t s);
 void launch_break_hills(const TailReads& R, uint32_t n_reads, hipStream_t s);
@@ -396,9 +399,21 @@ uint32_t partition_group_slots(uint32_t n_reads);
 size_t partition_tile_slots(uint32_t n_reads, uint64_t n_overlaps);
 bool partition_path_fits(uint32_t n_reads, uint32_t max_read_len, uint64_t n_overlaps);
 // bound events of all reads as an exact CSR (ev_off[n_reads + 1], ev); buffer sizes: bucket_kernels.hip
+// dedupe (may be null): the counting pass does duplicate removal's first pass on the way and writes the validity bytes that hold
+// for the unmarked queries; launch_dedupe_fix behind it (`counted` is recorded behind the counting pass) finishes the marked ones
+struct BucketDedupe {
+    uint8_t* suspect;       // n_reads bytes (cleared by the call)
+    uint8_t* valid;         // one byte per overlap
+    uint32_t* any;          // a zeroed word: set when a query was marked
+    hipEvent_t counted;     // may be null
+};
+bool bucket_count_can_dedupe(const OvlSoA& o, const uint8_t* valid);      // (the id columns on 16-byte boundaries)
 hipError_t launch_bucket_partitioned(const OvlSoA& o, uint32_t n_reads, uint32_t* acount, uint32_t* written,
                                      uint32_t* part_cursor, uint32_t* group, uint32_t* tiles, uint64_t* rec1, uint64_t* rec2,
-                                     uint32_t* ev_off, uint32_t* ev, uint32_t workgroups, FillList& fills, hipStream_t s);
+                                     uint32_t* ev_off, uint32_t* ev, uint32_t workgroups, FillList& fills, hipStream_t s,
+                                     const BucketDedupe* dedupe = nullptr);
+// the marked queries' overlaps through the full comparison (a few workgroups that leave at once when *any is 0)
+void launch_dedupe_fix(const OvlSoA& o, uint32_t n_reads, const uint8_t* suspect, const uint32_t* any, uint8_t* valid, hipStream_t s);
 // the same from an owner rank's bound records (launch_bucket_tuples(.., records = true)): zero_counts = n_reads + 2 words
 bool partition_path_fits_records(uint32_t n_reads, uint32_t max_read_len, uint64_t n_records);
 // (shrink: what the bounds are drawn in by - 15 for the primary overlaps, graph.cpp:317-324; 0 for the sensitive ones, :929-933)

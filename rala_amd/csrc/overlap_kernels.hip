@@ -42,19 +42,8 @@ __global__ __launch_bounds__(kBlock) void dedupe_mark_kernel(OvlSoA o, uint32_t 
     }
 }
 
-__global__ __launch_bounds__(kBlock) void dedupe_kernel(OvlSoA o, uint32_t n_reads, const uint8_t* __restrict__ suspect,
-                                                        uint8_t* __restrict__ valid) {
-    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= o.n) return;
-    const uint32_t a = o.a_id[i], b = o.b_id[i];
-    if (a >= n_reads || b >= n_reads || a == b) {
-        valid[i] = 0;
-        return;
-    }
-    if (!suspect[a]) {          // every run of this query has strictly increasing targets
-        valid[i] = 1;
-        return;
-    }
+// the full comparison for overlap i of a marked query (a, b resolve, a != b)
+__device__ __forceinline__ bool dedupe_survives(const OvlSoA& o, uint32_t n_reads, uint64_t i, uint32_t a, uint32_t b) {
     const uint32_t len = o.length[i];
     bool ok = true;
     // neighbours in batches of four: the loads do not depend on the loop exit
@@ -99,7 +88,35 @@ __global__ __launch_bounds__(kBlock) void dedupe_kernel(OvlSoA o, uint32_t n_rea
             }
         }
     }
-    valid[i] = ok ? 1 : 0;
+    return ok;
+}
+
+__global__ __launch_bounds__(kBlock) void dedupe_kernel(OvlSoA o, uint32_t n_reads, const uint8_t* __restrict__ suspect,
+                                                        uint8_t* __restrict__ valid) {
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= o.n) return;
+    const uint32_t a = o.a_id[i], b = o.b_id[i];
+    if (a >= n_reads || b >= n_reads || a == b) {
+        valid[i] = 0;
+        return;
+    }
+    if (!suspect[a]) {          // every run of this query has strictly increasing targets
+        valid[i] = 1;
+        return;
+    }
+    valid[i] = dedupe_survives(o, n_reads, i, a, b) ? 1 : 0;
+}
+
+// behind the counting pass that marked the queries and wrote the validity bytes of everybody else
+// (group_count_dedupe_kernel, bucket_kernels.hip): the marked queries' overlaps; nothing to do in the usual file
+__global__ __launch_bounds__(kBlock) void dedupe_fix_kernel(OvlSoA o, uint32_t n_reads, const uint8_t* __restrict__ suspect,
+                                                            const uint32_t* __restrict__ any, uint8_t* __restrict__ valid) {
+    if (*any == 0) return;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < o.n; i += (uint64_t)gridDim.x * kBlock) {
+        const uint32_t a = o.a_id[i], b = o.b_id[i];
+        if (a >= n_reads || b >= n_reads || a == b || !suspect[a]) continue;
+        valid[i] = dedupe_survives(o, n_reads, i, a, b) ? 1 : 0;
+    }
 }
 
 // Every resolvable overlap (valid or not) contributes two bounds to each of
@@ -429,6 +446,12 @@ __device__ __forceinline__ bool classify_one(const OvlSoA& o, uint64_t i, const 
 // a column value that is read once: a streaming load that should not displace the per-read tables in the L2
 template <class T>
 __device__ __forceinline__ T stream_load(const T* p) { return __builtin_nontemporal_load(p); }
+// four consecutive words of a column (p on a 16-byte boundary)
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void stream_load4(const uint32_t* p, uint32_t (&out)[4]) {
+    const u32x4_t v = __builtin_nontemporal_load((const u32x4_t*)p);
+    out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+}
 
 // trim + type from values that are already in registers (see classify_one)
 template <bool kSmall>
@@ -446,35 +469,68 @@ __device__ __forceinline__ bool classify_loaded(Coords& c, uint32_t strand, cons
 // other (0.9 ms at C3 for 1.5 GB).  Here a thread issues ALL loads of its overlaps that do not depend on
 // data first, unconditionally (columns, at clamped indices), then all record look-ups, and only then
 // computes: two dependent round trips per kPer overlaps instead of four per overlap.
-template <bool kSmall>
+// kVec (round 5): a thread takes FOUR CONSECUTIVE overlaps per group instead of four that lie a workgroup's width apart, so
+// that every column comes by one 16-byte load per lane (and the two byte columns by one word) - eight vector-memory
+// instructions per four overlaps instead of thirty-two.  The kernel moves 26 bytes per overlap and ran at 2 TB/s: what it
+// was short of were not bytes but requests.  Needs the columns on 16-byte boundaries (launch_classify looks; a slice of a
+// sharded run that starts in the middle of its columns takes the other instantiation).
+template <bool kSmall, bool kVec>
 __global__ __launch_bounds__(kBlock) void classify_kernel(OvlSoA o, uint32_t n_reads, const uint8_t* __restrict__ valid,
                                                           const typename CRec<kSmall>::word* __restrict__ crec,
                                                           KillList kl, uint32_t* lo) {
     __shared__ uint32_t s_cnt, s_base;
     constexpr uint32_t kPer = kClassifyChunk / kBlock;
     constexpr uint32_t kHalf = kPer / 2;
+    static_assert(kHalf == 4, "a group is one 16-byte vector of every column");
     const uint32_t lane = threadIdx.x & 63;
     if (threadIdx.x == 0) s_cnt = 0;
     __syncthreads();
     uint32_t slot[kPer], tgt[kPer], kpr[kPer];
     uint32_t any = 0;
     const uint64_t last = o.n - 1;
+    // the overlap a thread's item u is
+    auto item = [&](uint32_t u) -> uint64_t {
+        return kVec ? (uint64_t)blockIdx.x * kClassifyChunk + (u / kHalf) * (kHalf * kBlock) + kHalf * threadIdx.x + u % kHalf
+                    : (uint64_t)blockIdx.x * kClassifyChunk + u * kBlock + threadIdx.x;
+    };
 #pragma unroll
     for (uint32_t h = 0; h < kPer; h += kHalf) {
         uint32_t a[kHalf], b[kHalf], st[kHalf];
         Coords c[kHalf];
         bool ok[kHalf];
         typename CRec<kSmall>::word wa[kHalf], wb[kHalf];
+        bool loaded = false;
+        if constexpr (kVec) {
+            const uint64_t i0 = item(h);
+            if (i0 + kHalf <= o.n) {
+                loaded = true;
+                const uint32_t vw = stream_load((const uint32_t*)(valid + i0)), sw = stream_load((const uint32_t*)(o.strand + i0));
+                uint32_t xa[4], xb[4], xab[4], xae[4], xbb[4], xbe[4];
+                stream_load4(o.a_id + i0, xa); stream_load4(o.b_id + i0, xb);
+                stream_load4(o.a_begin + i0, xab); stream_load4(o.a_end + i0, xae);
+                stream_load4(o.b_begin + i0, xbb); stream_load4(o.b_end + i0, xbe);
 #pragma unroll
-        for (uint32_t v = 0; v < kHalf; ++v) {
-            const uint64_t i = (uint64_t)blockIdx.x * kClassifyChunk + (h + v) * kBlock + threadIdx.x;
-            const uint64_t j = i < o.n ? i : last;
-            ok[v] = i < o.n && stream_load(valid + j);
-            a[v] = stream_load(o.a_id + j); b[v] = stream_load(o.b_id + j);
-            c[v].a_begin = stream_load(o.a_begin + j); c[v].a_end = stream_load(o.a_end + j);
-            c[v].b_begin = stream_load(o.b_begin + j); c[v].b_end = stream_load(o.b_end + j);
-            c[v].length = 0;                        // (Overlap::trim sets it; the file's column is not needed here)
-            st[v] = stream_load(o.strand + j);
+                for (uint32_t v = 0; v < kHalf; ++v) {
+                    ok[v] = ((vw >> (8 * v)) & 0xFFu) != 0;
+                    a[v] = xa[v]; b[v] = xb[v];
+                    c[v].a_begin = xab[v]; c[v].a_end = xae[v]; c[v].b_begin = xbb[v]; c[v].b_end = xbe[v];
+                    c[v].length = 0;
+                    st[v] = (sw >> (8 * v)) & 0xFFu;
+                }
+            }
+        }
+        if (!loaded) {
+#pragma unroll
+            for (uint32_t v = 0; v < kHalf; ++v) {
+                const uint64_t i = item(h + v);
+                const uint64_t j = i < o.n ? i : last;
+                ok[v] = i < o.n && stream_load(valid + j);
+                a[v] = stream_load(o.a_id + j); b[v] = stream_load(o.b_id + j);
+                c[v].a_begin = stream_load(o.a_begin + j); c[v].a_end = stream_load(o.a_end + j);
+                c[v].b_begin = stream_load(o.b_begin + j); c[v].b_end = stream_load(o.b_end + j);
+                c[v].length = 0;                        // (Overlap::trim sets it; the file's column is not needed here)
+                st[v] = stream_load(o.strand + j);
+            }
         }
 #pragma unroll
         for (uint32_t v = 0; v < kHalf; ++v) {
@@ -509,7 +565,7 @@ __global__ __launch_bounds__(kBlock) void classify_kernel(OvlSoA o, uint32_t n_r
 #pragma unroll
     for (uint32_t u = 0; u < kPer; ++u) {
         if (slot[u] == 0xFFFFFFFFu) continue;
-        const uint64_t i = (uint64_t)blockIdx.x * kClassifyChunk + u * kBlock + threadIdx.x;
+        const uint64_t i = item(u);
         const uint32_t w = base + slot[u];
         const uint32_t pos = (uint32_t)(o.base + i) + 1u;  // 1-based position in the whole file (multi-GPU: slices)
         kl.ovl[w] = pos;
@@ -896,6 +952,11 @@ void launch_dedupe(const OvlSoA& o, uint32_t n_reads, uint8_t* suspect, uint8_t*
     hipLaunchKernelGGL(dedupe_mark_kernel, grid_for(o.n), dim3(kBlock), 0, s, o, n_reads, suspect);
     hipLaunchKernelGGL(dedupe_kernel, grid_for(o.n), dim3(kBlock), 0, s, o, n_reads, (const uint8_t*)suspect, valid);
 }
+void launch_dedupe_fix(const OvlSoA& o, uint32_t n_reads, const uint8_t* suspect, const uint32_t* any, uint8_t* valid, hipStream_t s) {
+    if (!o.n) return;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(2048, (o.n + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(dedupe_fix_kernel, dim3(grid), dim3(kBlock), 0, s, o, n_reads, suspect, any, valid);
+}
 void launch_bucket_fixed(const OvlSoA& o, uint32_t n_reads, uint32_t stride, uint32_t* counts, uint32_t* ev_fixed,
                          uint32_t* over, hipStream_t s) {
     if (o.n) {
@@ -971,8 +1032,18 @@ void launch_classify(const OvlSoA& o, uint32_t n_reads, const uint8_t* valid, co
                      const KillList& kl, uint32_t* lo, hipStream_t s) {
     if (!o.n) return;
     const dim3 grid(pass2_chunks(o.n));
-    if (small_records) hipLaunchKernelGGL(classify_kernel<true>, grid, dim3(kBlock), 0, s, o, n_reads, valid, (const uint32_t*)crec, kl, lo);
-    else hipLaunchKernelGGL(classify_kernel<false>, grid, dim3(kBlock), 0, s, o, n_reads, valid, (const uint2*)crec, kl, lo);
+    // (16-byte loads want the columns on 16-byte boundaries: a sharded run's slice may start anywhere in them)
+    const uintptr_t bits = (uintptr_t)o.a_id | (uintptr_t)o.b_id | (uintptr_t)o.a_begin | (uintptr_t)o.a_end | (uintptr_t)o.b_begin |
+                           (uintptr_t)o.b_end | (uintptr_t)o.strand * 4 | (uintptr_t)valid * 4;
+    static const bool no_vec = getenv("RALA_CLASSIFY_NO_VEC") != nullptr;       // (measurements)
+    const bool vec = (bits & 15u) == 0 && !no_vec;
+    if (small_records) {
+        if (vec) hipLaunchKernelGGL((classify_kernel<true, true>), grid, dim3(kBlock), 0, s, o, n_reads, valid, (const uint32_t*)crec, kl, lo);
+        else hipLaunchKernelGGL((classify_kernel<true, false>), grid, dim3(kBlock), 0, s, o, n_reads, valid, (const uint32_t*)crec, kl, lo);
+    } else {
+        if (vec) hipLaunchKernelGGL((classify_kernel<false, true>), grid, dim3(kBlock), 0, s, o, n_reads, valid, (const uint2*)crec, kl, lo);
+        else hipLaunchKernelGGL((classify_kernel<false, false>), grid, dim3(kBlock), 0, s, o, n_reads, valid, (const uint2*)crec, kl, lo);
+    }
 }
 // the list length lives on the device: a grid sized for what the host knows of it strides over it
 // (4096 workgroups that find nothing to do still take 20 us to come and go)

@@ -575,16 +575,17 @@ int preprocess_chimeras(rala_hip_ctx* ctx) {
     return RALA_HIP_OK;
 }
 
-// position-space sensitive-pass kernel over `reads`, grouped by LDS image size.  Mode 2: a read whose region lists or
+// position-space sensitive-pass kernel over `reads`, grouped by LDS image size, on stream st (the main stream, or the aux
+// stream beside a mode's run-space kernels: nothing here waits for another stream).  Mode 2: a read whose region lists or
 // raw hills outgrow the kernel's LDS lists is noted and runs again with the lists in global memory, doubled until the read
 // fits (as run_unbounded_piles).
-int run_repeats_classes(rala_hip_ctx* ctx, RepeatArgs a, const std::vector<uint32_t>& reads, int mode) {
+int run_repeats_classes(rala_hip_ctx* ctx, RepeatArgs a, const std::vector<uint32_t>& reads, int mode, hipStream_t st) {
     Trace trc;
     std::vector<uint32_t> order;
     build_classes(ctx, reads, order);
     trc("repeats: classes", reads.size());
     HIPCHECK(ctx->d_order.ensure(order.size() + 1));
-    HIPCHECK(hipMemcpyAsync(ctx->d_order.p, order.data(), order.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHECK(hipMemcpyAsync(ctx->d_order.p, order.data(), order.size() * 4, hipMemcpyHostToDevice, st));
     const bool big = mode == 2 && a.big_cap_reg != 0;
     const uint64_t big_words = big ? repeats_big_words(a.big_cap_reg, a.big_cap_list, a.big_cap_raw) : 0;
     for (const LaunchClass& c : ctx->classes) {
@@ -600,29 +601,39 @@ int run_repeats_classes(rala_hip_ctx* ctx, RepeatArgs a, const std::vector<uint3
         a.n_items = c.count;
         a.lw = c.lw;
         a.slab = ctx->d_slab.p;
-        launch_pile_repeats(a, grid, c.in_lds, mode, ctx->stream);
+        launch_pile_repeats(a, grid, c.in_lds, mode, st);
     }
-    HIPCHECK(stream_sync(ctx, ctx->stream));
+    HIPCHECK(hipStreamSynchronize(st));              // (`order` is pageable host memory)
     HIPCHECK(hipGetLastError());
     trc("repeats: kernels", ctx->classes.size());
     return RALA_HIP_OK;
 }
 
-int run_repeats_kernel(rala_hip_ctx* ctx, RepeatArgs a, const std::vector<uint32_t>& reads, int mode) {
+int run_repeats_kernel(rala_hip_ctx* ctx, RepeatArgs a, const std::vector<uint32_t>& reads, int mode, hipStream_t st = nullptr) {
     if (reads.empty()) return RALA_HIP_OK;
-    if (mode != 2) return run_repeats_classes(ctx, a, reads, mode);
-    hipStream_t s = ctx->stream;
+    if (st == nullptr) st = ctx->stream;
+    if (mode != 2) return run_repeats_classes(ctx, a, reads, mode, st);
     uint32_t* const count_dev = ctx->d_small.p + 8;
     HIPCHECK(ctx->d_big_list[0].ensure(ctx->n_reads + 1));
-    HIPCHECK(hipMemsetAsync(count_dev, 0, 4, s));
+    HIPCHECK(hipMemsetAsync(count_dev, 0, 4, st));
     a.big_list = ctx->d_big_list[0].p;
     a.big_count = count_dev;
     a.big_space = nullptr; a.big_cap_reg = a.big_cap_list = a.big_cap_raw = 0;
     a.force_big = ctx->debug_force_big ? 1u : 0u;
-    int rc = run_repeats_classes(ctx, a, reads, 2);
+    int rc = run_repeats_classes(ctx, a, reads, 2, st);
     if (rc != RALA_HIP_OK) return rc;
-    uint32_t count = 0;
-    HIPCHECK(hipMemcpy(&count, count_dev, 4, hipMemcpyDeviceToHost));
+    // one look: how many reads were noted, the status word (copies on THIS stream - a blocking copy would wait for the
+    // run-space kernels beside)
+    uint32_t look[2] = {0, 0};                  // [0] status (d_small[7]) [1] noted reads (d_small[8])
+    auto fetch = [&]() -> int {
+        HIPCHECK(hipMemcpyAsync(look, ctx->d_small.p + 7, 8, hipMemcpyDeviceToHost, st));
+        HIPCHECK(hipStreamSynchronize(st));
+        return (int)RALA_HIP_OK;
+    };
+    rc = fetch();
+    if (rc != RALA_HIP_OK) return rc;
+    uint32_t count = look[1];
+    if (count == 0) return RALA_HIP_OK;
     uint32_t cap_reg, cap_list, cap_raw;
     first_big_caps(ctx, cap_reg, cap_list, cap_raw);
     cap_list = 2 * cap_reg;
@@ -630,21 +641,19 @@ int run_repeats_kernel(rala_hip_ctx* ctx, RepeatArgs a, const std::vector<uint32
     int from = 0;
     while (count) {
         std::vector<uint32_t> again(count);
-        HIPCHECK(hipMemcpy(again.data(), ctx->d_big_list[from].p, (size_t)count * 4, hipMemcpyDeviceToHost));
+        HIPCHECK(hipMemcpyAsync(again.data(), ctx->d_big_list[from].p, (size_t)count * 4, hipMemcpyDeviceToHost, st));
+        HIPCHECK(hipStreamSynchronize(st));
         std::sort(again.begin(), again.end());
         HIPCHECK(ctx->d_big_list[from ^ 1].ensure(ctx->n_reads + 1));
-        uint32_t status = 0;
-        HIPCHECK(hipMemcpy(&status, a.error, 4, hipMemcpyDeviceToHost));
-        status &= kErrPoolCapacity;
-        HIPCHECK(hipMemcpyAsync(a.error, &status, 4, hipMemcpyHostToDevice, s));
-        HIPCHECK(hipMemsetAsync(count_dev, 0, 4, s));
+        // (the lists' bits of the status word start every round at zero; other kernels may be setting the pool's bit meanwhile)
+        launch_status_clear(a.error, kErrRegionCapacity | kErrRawCapacity, count_dev, st);
         a.big_list = ctx->d_big_list[from ^ 1].p;
         a.big_cap_reg = cap_reg; a.big_cap_list = cap_list; a.big_cap_raw = cap_raw;
-        rc = run_repeats_classes(ctx, a, again, 2);
+        rc = run_repeats_classes(ctx, a, again, 2, st);
         if (rc != RALA_HIP_OK) return rc;
-        uint32_t left = 0;
-        HIPCHECK(hipMemcpy(&left, count_dev, 4, hipMemcpyDeviceToHost));
-        HIPCHECK(hipMemcpy(&status, a.error, 4, hipMemcpyDeviceToHost));
+        rc = fetch();
+        if (rc != RALA_HIP_OK) return rc;
+        const uint32_t left = look[1], status = look[0];
         if (getenv("RALA_HIP_TRACE")) {
             fprintf(stderr, "[trace] repeat hills, lists in global memory: %u reads at %u regions / %u raw intervals, %u left (status %u)\n",
                     count, cap_reg, cap_raw, left, status);
@@ -663,82 +672,131 @@ int run_repeats_kernel(rala_hip_ctx* ctx, RepeatArgs a, const std::vector<uint32
         count = left;
         from ^= 1;
     }
-    uint32_t status = 0;
-    HIPCHECK(hipMemcpy(&status, a.error, 4, hipMemcpyDeviceToHost));
-    status &= kErrPoolCapacity;
-    HIPCHECK(hipMemcpy(a.error, &status, 4, hipMemcpyHostToDevice));
+    // (the lists' bits are no error of the call any more)
+    launch_status_clear(a.error, kErrRegionCapacity | kErrRawCapacity, nullptr, st);
+    HIPCHECK(hipStreamSynchronize(st));
     return RALA_HIP_OK;
 }
 
-// One mode of the sensitive pass over `reads`: the run-space kernel (cap 512, then 1024) reads the
-// primary bound events where initialize left them plus the sensitive bounds of pa.sens_*; what it
-// hands on goes to the position-space kernel.
-// list_dev: the reads (count of them) in ctx->d_sens_list already, or null: `reads` is uploaded there.
-// Every read starts in the kernel that fits it (launch_sens_split: by length and by primary + sensitive event count), as in
-// the first pass; what a kernel still hands on (its region lists) goes down the chain: cap 512 / 16384 bases and cap 512 /
-// 32768 bases -> cap 1024 / 16384 bases -> position space.
-int run_sens_pass(rala_hip_ctx* ctx, PileArgs pa, const RepeatArgs& ra, const std::vector<uint32_t>& reads, int mode,
-                  const uint32_t* list_dev = nullptr, uint32_t list_count = 0) {
-    if (list_dev == nullptr && reads.empty()) return RALA_HIP_OK;
-    if (list_dev != nullptr && list_count == 0) return RALA_HIP_OK;
-    if (!ctx->use_run_kernel || !ctx->ev_ready) {
-        if (list_dev == nullptr) return run_repeats_kernel(ctx, ra, reads, mode);
-        std::vector<uint32_t> host(list_count);
-        HIPCHECK(hipMemcpy(host.data(), list_dev, (size_t)list_count * 4, hipMemcpyDeviceToHost));
-        std::sort(host.begin(), host.end());
-        return run_repeats_kernel(ctx, ra, host, mode);
-    }
+// One mode of the sensitive pass over the reads of a device list (its length in *count_dev, at most `bound`): every read
+// starts in the kernel that fits it, known beforehand from its length and its primary + sensitive event count
+// (launch_sens_split) - cap 512 / 16384 bases and cap 512 / 32768 bases on the main stream; cap 1024 / 16384 bases and, behind
+// it, the position-space kernel for what fits neither (the event-dense reads: 6 842 of C5's 281 k targets, a third of the
+// pass when they ran behind the others) BESIDE them on the aux stream (round 5).  What a kernel still hands on (its region
+// lists) goes down the chain behind the join: cap 512 -> cap 1024 -> position space; usually nothing.
+// Two looks from the host: the classes' sizes (with whatever the caller has queued on this context: d2h_small), and the
+// hand-over counts at the end - which come with the sixteen words of d_small (the repeat hills' pool counter and the status
+// word among them) in `small16`.  *count_out: the list's length.
+int run_sens_pass(rala_hip_ctx* ctx, PileArgs pa, const RepeatArgs& ra, int mode, const uint32_t* list_dev, uint32_t bound,
+                  const uint32_t* count_dev, uint32_t* count_out, uint32_t* small16) {
+    *count_out = 0;
+    if (bound == 0) return RALA_HIP_OK;
     hipStream_t s = ctx->stream;
     Trace trc;
-    const uint32_t count = list_dev ? list_count : (uint32_t)reads.size();
+    if (!ctx->use_run_kernel || !ctx->ev_ready) {
+        uint32_t count = 0;
+        HIPCHECK(d2h_small(ctx, &count, count_dev, 4, s));
+        HIPCHECK(stream_sync(ctx, s));
+        *count_out = count;
+        std::vector<uint32_t> host(count);
+        if (count) HIPCHECK(hipMemcpy(host.data(), list_dev, (size_t)count * 4, hipMemcpyDeviceToHost));
+        std::sort(host.begin(), host.end());
+        const int rc = run_repeats_kernel(ctx, ra, host, mode);
+        if (rc != RALA_HIP_OK) return rc;
+        HIPCHECK(hipMemcpy(small16, ctx->d_small.p, 64, hipMemcpyDeviceToHost));
+        return RALA_HIP_OK;
+    }
     HIPCHECK(ctx->d_overflow.ensure(ctx->n_reads + 1));
     HIPCHECK(ctx->d_overflow_mid.ensure(ctx->n_reads + 1));
     HIPCHECK(ctx->d_chain_cnt.ensure(16));
-    if (list_dev == nullptr) {
-        HIPCHECK(ctx->d_sens_list.ensure(count + 1));
-        HIPCHECK(hipMemcpyAsync(ctx->d_sens_list.p, reads.data(), (size_t)count * 4, hipMemcpyHostToDevice, s));
-        list_dev = ctx->d_sens_list.p;
-    }
     // [0] handed on by the cap-512 kernels, [1] by the cap-1024 kernel, [8 .. 11] the classes' sizes
-    HIPCHECK(hipMemsetAsync(ctx->d_chain_cnt.p, 0, 16 * 4, s));
-    HIPCHECK(ctx->d_sens_split.ensure(4 * ((size_t)count + 1)));
+    {
+        FillList fills;
+        fills.add(ctx->d_chain_cnt.p, 0, 4 * 4);
+        fills.add(ctx->d_chain_cnt.p + 8, 0, 4 * 4);
+        HIPCHECK(fills.launch(s));
+    }
+    HIPCHECK(ctx->d_sens_split.ensure(4 * ((size_t)bound + 1)));
     SensSplitArgs sp;
     sp.read_len = pa.read_len; sp.ev_off = pa.ev_off; sp.ev_cnt = pa.ev_cnt; sp.ev_stride = pa.ev_stride;
     sp.sens_off = pa.sens_off; sp.begin = pa.begin; sp.end = pa.end;
-    for (int c = 0; c < 4; ++c) sp.out[c] = ctx->d_sens_split.p + (size_t)c * ((size_t)count + 1);
+    for (int c = 0; c < 4; ++c) sp.out[c] = ctx->d_sens_split.p + (size_t)c * ((size_t)bound + 1);
     sp.counts = ctx->d_chain_cnt.p + 8;
-    launch_sens_split(list_dev, count, sp, s);
-    uint32_t cls[4] = {0, 0, 0, 0};
+    launch_sens_split(list_dev, bound, count_dev, sp, s);
+    // look 1: the classes' sizes, the list's length; the first reads of the position-space class ride along
+    constexpr uint32_t kRestAhead = 16384;
+    HIPCHECK(ctx->p_sens_rest.ensure(kRestAhead));
+    uint32_t cls[4] = {0, 0, 0, 0}, count = 0;
     HIPCHECK(d2h_small(ctx, cls, ctx->d_chain_cnt.p + 8, 16, s));
+    HIPCHECK(d2h_small(ctx, &count, count_dev, 4, s));
+    HIPCHECK(hipMemcpyAsync(ctx->p_sens_rest.p, sp.out[3], (size_t)std::min<uint32_t>(bound, kRestAhead) * 4, hipMemcpyDeviceToHost, s));
     HIPCHECK(stream_sync(ctx, s));
     HIPCHECK(hipGetLastError());
+    *count_out = count;
+    if (count == 0) {
+        HIPCHECK(hipMemcpy(small16, ctx->d_small.p, 64, hipMemcpyDeviceToHost));
+        return RALA_HIP_OK;
+    }
     uint32_t* const handed_512 = ctx->d_overflow.p;            // -> cap 1024
     uint32_t* const handed_1024 = ctx->d_overflow_mid.p;       // -> position space
+    // (three streams: the two cap-512 kernels on the main one, the cap-1024 kernel on aux, the position-space kernels - whose
+    // host side waits for its own stream between its steps - on side.  First version of this round: both of the latter on aux,
+    // and the wait for the rest of a long class-3 list was a wait for the cap-1024 kernel: C5 12.4 ms, no gain)
+    hipStream_t aux = ctx->use_side_stream ? ctx->aux : s;
+    hipStream_t pos = ctx->use_side_stream ? ctx->side : s;
+    if (aux != s) {
+        HIPCHECK(hipEventRecord(ctx->ev[8], s));
+        HIPCHECK(hipStreamWaitEvent(aux, ctx->ev[8], 0));
+        HIPCHECK(hipStreamWaitEvent(pos, ctx->ev[8], 0));
+    }
     pa.n_items_dev = nullptr;
     pa.order = sp.out[0]; pa.n_items = cls[0];
     launch_pile_sens(pa, cls[0], 0, mode, handed_512, ctx->d_chain_cnt.p, s);
     pa.order = sp.out[1]; pa.n_items = cls[1];
     launch_pile_sens(pa, std::min<uint32_t>(cls[1], 16384), 3, mode, handed_512, ctx->d_chain_cnt.p, s);
     pa.order = sp.out[2]; pa.n_items = cls[2];
-    launch_pile_sens(pa, std::min<uint32_t>(cls[2], 8192), 1, mode, handed_1024, ctx->d_chain_cnt.p + 1, s);
+    launch_pile_sens(pa, std::min<uint32_t>(cls[2], 8192), 1, mode, handed_1024, ctx->d_chain_cnt.p + 1, aux);
+    if (aux != s) HIPCHECK(hipEventRecord(ctx->ev[9], aux));
+    if (cls[3]) {
+        std::vector<uint32_t> rest(ctx->p_sens_rest.p, ctx->p_sens_rest.p + std::min<uint32_t>(cls[3], kRestAhead));
+        if (cls[3] > kRestAhead) {
+            rest.resize(cls[3]);
+            HIPCHECK(hipMemcpyAsync(rest.data() + kRestAhead, sp.out[3] + kRestAhead, (size_t)(cls[3] - kRestAhead) * 4, hipMemcpyDeviceToHost, pos));
+            HIPCHECK(hipStreamSynchronize(pos));
+        }
+        std::sort(rest.begin(), rest.end());
+        const int rc = run_repeats_kernel(ctx, ra, rest, mode, pos);
+        if (rc != RALA_HIP_OK) return rc;
+        trc("sens pass: position space beside", rest.size());
+    }
+    if (aux != s) {
+        HIPCHECK(hipStreamWaitEvent(s, ctx->ev[9], 0));
+        if (cls[3]) {
+            HIPCHECK(hipEventRecord(ctx->ev[8], pos));
+            HIPCHECK(hipStreamWaitEvent(s, ctx->ev[8], 0));
+        }
+    }
     pa.order = handed_512; pa.n_items = count; pa.n_items_dev = ctx->d_chain_cnt.p;
     launch_pile_sens(pa, std::min<uint32_t>(count, 2048), 1, mode, handed_1024, ctx->d_chain_cnt.p + 1, s);
+    // look 2: what was handed on, and the call's counters
     uint32_t cnt[2] = {0, 0};
     HIPCHECK(d2h_small(ctx, cnt, ctx->d_chain_cnt.p, 8, s));
+    HIPCHECK(d2h_small(ctx, small16, ctx->d_small.p, 64, s));
     HIPCHECK(stream_sync(ctx, s));
     HIPCHECK(hipGetLastError());
     trc(mode == 1 ? "sens pass 1: run space" : "sens pass 2: run space", count);
     if (getenv("RALA_HIP_TRACE")) {
         fprintf(stderr, "[trace] sens pass %d: classes %u / %u / %u / %u, handed on %u + %u\n", mode, cls[0], cls[1], cls[2], cls[3], cnt[0], cnt[1]);
     }
-    if (cnt[1] + cls[3] == 0) return RALA_HIP_OK;
-    std::vector<uint32_t> rest((size_t)cnt[1] + cls[3]);
-    if (cnt[1]) HIPCHECK(hipMemcpy(rest.data(), handed_1024, (size_t)cnt[1] * 4, hipMemcpyDeviceToHost));
-    if (cls[3]) HIPCHECK(hipMemcpy(rest.data() + cnt[1], sp.out[3], (size_t)cls[3] * 4, hipMemcpyDeviceToHost));
+    if (cnt[1] == 0) return RALA_HIP_OK;
+    std::vector<uint32_t> rest((size_t)cnt[1]);
+    HIPCHECK(hipMemcpy(rest.data(), handed_1024, (size_t)cnt[1] * 4, hipMemcpyDeviceToHost));
     std::sort(rest.begin(), rest.end());
     const int rc = run_repeats_kernel(ctx, ra, rest, mode);
     trc("sens pass: position space", rest.size());
-    return rc;
+    if (rc != RALA_HIP_OK) return rc;
+    HIPCHECK(hipMemcpy(small16, ctx->d_small.p, 64, hipMemcpyDeviceToHost));
+    return RALA_HIP_OK;
 }
 
 // Pile::is_valid_overlap (pile.cpp:605-630)
@@ -897,12 +955,21 @@ int preprocess_repeats(rala_hip_ctx* cs, rala_hip_ctx* cl, Comm* comm, const ral
         launch_localize_u32(cs->d_end.p, nl, P, me, cl->d_end.p, sl);
         launch_localize_u8(cs->d_alive.p, nl, P, me, cl->d_alive.p, sl);
     }
+    // (one context: the record check comes back with the first look of the pass below - a record that is an error names no
+    // read, nothing downstream trips over it; a sharded run has waited for its collectives anyway)
     uint32_t bad = 0;
     HIPCHECK(d2h_small(cs, &bad, cs->d_small.p + 2, 4, s));
-    HIPCHECK(stream_sync(cs, s));
-    HIPCHECK(hipGetLastError());
-    if (bad & 1u) return fail(ctx, RALA_HIP_EINVAL, "sensitive overlap names must resolve");
-    if (bad & 2u) return fail(ctx, RALA_HIP_EINVAL, "sensitive overlap targets a read that did not survive");
+    auto check_records = [&]() -> int {
+        if (bad & 1u) return fail(ctx, RALA_HIP_EINVAL, "sensitive overlap names must resolve");
+        if (bad & 2u) return fail(ctx, RALA_HIP_EINVAL, "sensitive overlap targets a read that did not survive");
+        return (int)RALA_HIP_OK;
+    };
+    if (sharded) {
+        HIPCHECK(stream_sync(cs, s));
+        HIPCHECK(hipGetLastError());
+        const int rcb = check_records();
+        if (rcb != RALA_HIP_OK) return rcb;
+    }
     // bucketed by read on the pile holder: count -> scan -> scatter
     // (buffers of their own: the primary bound events stay where initialize left them)
     HIPCHECK(cl->d_sens_ev.ensure(n_tuples + 8));
@@ -943,10 +1010,7 @@ int preprocess_repeats(rala_hip_ctx* cs, rala_hip_ctx* cl, Comm* comm, const ral
     HIPCHECK(hipMemsetAsync(cl->d_chain_cnt.p + 4, 0, 4, sl));
     launch_list_targets(cl->d_sens_off.p, (uint32_t)nl, cl->d_sens_list.p, cl->d_chain_cnt.p + 4, sl);
     uint32_t n_targets = 0;
-    HIPCHECK(d2h_small(cl, &n_targets, cl->d_chain_cnt.p + 4, 4, sl));
-    HIPCHECK(stream_sync(cl, sl));
-    HIPCHECK(hipGetLastError());
-    trc("rep: transmute + bucket", n_targets);
+    uint32_t small[16] = {};
 
     RepeatArgs a;
     a.read_len = cl->d_read_len.p; a.pile_off = cl->d_pile_off.p; a.pile = cl->d_pile.p;
@@ -969,8 +1033,12 @@ int preprocess_repeats(rala_hip_ctx* cs, rala_hip_ctx* cl, Comm* comm, const ral
     pa.dataset_median = cl->d_dataset_median.p; pa.n_rep = cl->d_n_rep.p; pa.rep_slot = cl->d_rep_slot.p;
     pa.rep_pool = cl->d_rep_pool.p; pa.rep_pool_count = cl->d_small.p + 6; pa.rep_pool_cap = cl->rep_pool_cap;
     // add_layers on top of the coverage + find_median for the targets (graph.cpp:941-969)
-    int rc = run_sens_pass(cl, pa, a, std::vector<uint32_t>(), 1, cl->d_sens_list.p, n_targets);
+    int rc = run_sens_pass(cl, pa, a, 1, cl->d_sens_list.p, (uint32_t)nl, cl->d_chain_cnt.p + 4, &n_targets, small);
     if (rc != RALA_HIP_OK) { if (cl != cs) cs->err = cl->err; return rc; }
+    if (!sharded) {
+        const int rcb = check_records();
+        if (rcb != RALA_HIP_OK) return rcb;
+    }
     if (sharded) {
         // the new medians, everywhere
         HIPCHECK(cs->d_gather[0].ensure(nl_pad * 4 + 16));
@@ -1018,22 +1086,29 @@ int preprocess_repeats(rala_hip_ctx* cs, rala_hip_ctx* cl, Comm* comm, const ral
         HIPCHECK(cs->d_chain_cnt.ensure(16));
         HIPCHECK(hipMemsetAsync(cs->d_chain_cnt.p + 5, 0, 4, s));
         launch_list_members(cs->d_alive_reads.p, cs->d_touched.p, n_alive, P, me, cl->d_sens_list.p, cs->d_chain_cnt.p + 5, s);
-        HIPCHECK(d2h_small(cs, &n_members, cs->d_chain_cnt.p + 5, 4, s));
-        HIPCHECK(stream_sync(cs, s));
+        if (sharded) HIPCHECK(stream_sync(cs, s));              // (the owner context's stream goes on from here)
         members_on_device = true;
     }
-    trc("rep: component medians", members_on_device ? n_members : members.size());
     std::vector<uint32_t> mine;
     if (sharded) {
         launch_localize_u16(cs->d_dataset_median.p, nl, P, me, cl->d_dataset_median.p, sl);
         if (!members_on_device) for (uint32_t r : members) if (r % P == me) mine.push_back(r / P);
     }
+    uint32_t member_bound = (uint32_t)nl;
+    if (!members_on_device) {
+        // (host tail: the members were listed on the host)
+        const std::vector<uint32_t>& list = sharded ? mine : members;
+        HIPCHECK(cl->d_sens_list.ensure(std::max<uint64_t>(list.size(), 1) + 1));
+        HIPCHECK(cs->d_chain_cnt.ensure(16));
+        const uint32_t n_list = (uint32_t)list.size();
+        if (n_list) HIPCHECK(hipMemcpy(cl->d_sens_list.p, list.data(), (size_t)n_list * 4, hipMemcpyHostToDevice));
+        HIPCHECK(hipMemcpy(cs->d_chain_cnt.p + 5, &n_list, 4, hipMemcpyHostToDevice));
+        member_bound = n_list;
+    }
     for (;;) {
-        rc = members_on_device ? run_sens_pass(cl, pa, a, members, 2, cl->d_sens_list.p, n_members)
-                               : run_sens_pass(cl, pa, a, sharded ? mine : members, 2);
+        rc = run_sens_pass(cl, pa, a, 2, cl->d_sens_list.p, member_bound, cs->d_chain_cnt.p + 5, &n_members, small);
         if (rc != RALA_HIP_OK) { if (cl != cs) cs->err = cl->err; return rc; }
-        uint32_t st[2];
-        HIPCHECK(hipMemcpy(st, cl->d_small.p + 6, sizeof(st), hipMemcpyDeviceToHost));
+        const uint32_t st[2] = {small[6], small[7]};
         if (!(st[1] & kErrPoolCapacity)) break;
         // more repeat hills than the pool holds: its counter holds what is needed - the pass once more (mode 2 neither
         // reads nor writes the rows) with a pool of that size
@@ -1047,8 +1122,7 @@ int preprocess_repeats(rala_hip_ctx* cs, rala_hip_ctx* cl, Comm* comm, const ral
         HIPCHECK(hipMemsetAsync(cl->d_small.p + 6, 0, 8, sl));
         ++cl->tm.pool_regrown;
     }
-    uint32_t small[8];
-    HIPCHECK(hipMemcpy(small, cl->d_small.p, sizeof(small), hipMemcpyDeviceToHost));
+    trc("rep: component medians + repeat hills", n_members);
     uint32_t n_hills = small[6];
     if (sharded) {
         // capacity errors are everybody's; then the hills of all owners, slots rebased onto the
@@ -1088,8 +1162,10 @@ int preprocess_repeats(rala_hip_ctx* cs, rala_hip_ctx* cl, Comm* comm, const ral
         if (comm->all_reduce_u32(cs->d_t_tmp[0].p, n_hills, ReduceOp::kMax, s) != 0) return comm_fail("all-reduce of the bridged flags");
         launch_pool_aux(cs->d_rep_pool.p, n_hills, cs->d_t_tmp[0].p, 1, s);
     }
-    HIPCHECK(stream_sync(cs, s));
-    HIPCHECK(hipGetLastError());
+    if (sharded || trc.on) {                    // (one context: the next look is the graph's, gpu_tail_part_b)
+        HIPCHECK(stream_sync(cs, s));
+        HIPCHECK(hipGetLastError());
+    }
     trc("rep: bridged hills", n_sens);
     // the host's copy of the hills: at once where the host filters the overlaps below, otherwise with the first getter
     cs->n_rep_hills = n_hills;
@@ -1999,7 +2075,13 @@ int rala_hip_create(int device, rala_hip_ctx** out) {
             ctx->n_compute_units = (uint32_t)prop.multiProcessorCount;
         }
     }
-    bool ok = hipStreamCreate(&ctx->stream) == hipSuccess && hipStreamCreate(&ctx->side) == hipSuccess &&
+    // (the side stream at the highest priority the device offers: what runs there beside a kernel that fills the chip - the
+    // position-space kernels of the sensitive pass, whose workgroups want most of a compute unit's LDS - gets the compute
+    // units as they come free instead of when the other kernel has drained)
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    bool ok = hipStreamCreate(&ctx->stream) == hipSuccess &&
+              hipStreamCreateWithPriority(&ctx->side, hipStreamDefault, prio_greatest) == hipSuccess &&
               hipStreamCreate(&ctx->aux) == hipSuccess;
     for (auto& e : ctx->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
     ok = ok && ctx->d_small.ensure(16) == hipSuccess;
@@ -2242,7 +2324,10 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
     bool fixed = !partitioned && ctx->use_run_kernel && ctx->use_fixed_buckets && (uint64_t)n_reads * slot * 4ull <= (64ull << 30);
     static const bool dedupe_late = getenv("RALA_DEDUPE_LATE") != nullptr;
     const bool dedupe_early = forked && partitioned && !dedupe_late;
-    if (dedupe_early) {
+    // (round 5) ... and inside the bucketing's counting pass where that pass can take it: both read the two id columns of every
+    // overlap, the second stream is left with the marked queries' overlaps - usually none
+    const bool dedupe_counted = dedupe_early && !from_records && !from_blocks && bucket_count_can_dedupe(ctx->ovl, ctx->d_valid.p);
+    if (dedupe_early && !dedupe_counted) {
         HIPCHECK(hipStreamWaitEvent(ctx->side, ctx->ev[0], 0));
         launch_dedupe(ctx->ovl, n_reads, ctx->d_suspect.p, ctx->d_valid.p, ctx->side);
         HIPCHECK(hipEventRecord(ctx->ev[1], ctx->side));
@@ -2266,9 +2351,16 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
                                                        ctx->d_bk_group.p, ctx->d_bk_tiles.p, ctx->d_bk_rec[0].p, ctx->d_bk_rec[1].p,
                                                        ctx->d_ev_off.p, ctx->d_ev.p, ctx->n_compute_units, fills, s));
         } else {
+            const BucketDedupe bd = {ctx->d_suspect.p, ctx->d_valid.p, ctx->d_small.p + 9, ctx->ev[8]};     // ([9]: zeroed with d_small above)
             HIPCHECK(launch_bucket_partitioned(ctx->ovl, n_reads, ctx->d_bk_u32[0].p, ctx->d_bk_u32[2].p,
                                                ctx->d_bk_part.p, ctx->d_bk_group.p, ctx->d_bk_tiles.p, ctx->d_bk_rec[0].p,
-                                               ctx->d_bk_rec[1].p, ctx->d_ev_off.p, ctx->d_ev.p, ctx->n_compute_units, fills, s));
+                                               ctx->d_bk_rec[1].p, ctx->d_ev_off.p, ctx->d_ev.p, ctx->n_compute_units, fills, s,
+                                               dedupe_counted ? &bd : nullptr));
+            if (dedupe_counted) {
+                HIPCHECK(hipStreamWaitEvent(ctx->side, ctx->ev[8], 0));
+                launch_dedupe_fix(ctx->ovl, n_reads, ctx->d_suspect.p, ctx->d_small.p + 9, ctx->d_valid.p, ctx->side);
+                HIPCHECK(hipEventRecord(ctx->ev[1], ctx->side));
+            }
         }
     }
     if (fixed) {

@@ -272,8 +272,11 @@ __global__ __launch_bounds__(kBlock) void list_members_kernel(const uint32_t* __
     }
     append_flagged_block(flag, value, list, count);
 }
-__global__ __launch_bounds__(kBlock) void sens_split_kernel(const uint32_t* __restrict__ list, uint32_t n, SensSplitArgs A) {
+// (n_dev: the list's length, on the device; the grid covers the host's bound of it)
+__global__ __launch_bounds__(kBlock) void sens_split_kernel(const uint32_t* __restrict__ list, const uint32_t* __restrict__ n_dev, uint32_t bound,
+                                                            SensSplitArgs A) {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t n = umin(*n_dev, bound);
     uint32_t cls = 4, r = 0;
     if (i < n) {
         r = list[i];
@@ -290,8 +293,17 @@ __global__ __launch_bounds__(kBlock) void sens_split_kernel(const uint32_t* __re
 }
 }  // namespace
 
-void launch_sens_split(const uint32_t* list, uint32_t n, const SensSplitArgs& args, hipStream_t s) {
-    if (n) hipLaunchKernelGGL(sens_split_kernel, grid_for(n), dim3(kBlock), 0, s, list, n, args);
+void launch_sens_split(const uint32_t* list, uint32_t bound, const uint32_t* n_dev, const SensSplitArgs& args, hipStream_t s) {
+    if (bound) hipLaunchKernelGGL(sens_split_kernel, grid_for(bound), dim3(kBlock), 0, s, list, n_dev, bound, args);
+}
+namespace {
+__global__ void status_clear_kernel(uint32_t* status, uint32_t bits, uint32_t* zero) {
+    atomicAnd(status, ~bits);
+    if (zero) *zero = 0;
+}
+}  // namespace
+void launch_status_clear(uint32_t* status, uint32_t bits, uint32_t* zero, hipStream_t s) {
+    hipLaunchKernelGGL(status_clear_kernel, dim3(1), dim3(1), 0, s, status, bits, zero);
 }
 
 void launch_list_targets(const uint32_t* off, uint32_t n, uint32_t* list, uint32_t* count, hipStream_t s) {
