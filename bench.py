@@ -252,8 +252,16 @@ def measure_traffic(workload):
     import tempfile
 
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
-    py = shutil.which("python3")
-    if not os.path.exists(exe) or not py:
+    # the interpreter that runs this bench, as an ELF binary (a `python3` found on PATH may be a shim script
+    # that execs the real one - an exec hop inside a process the profiler's preloaded library has initialised the GPU in -
+    # or another interpreter altogether)
+    py = os.path.realpath(sys.executable or "")
+    try:
+        with open(py, "rb") as f:
+            is_elf = f.read(4) == b"\x7fELF"
+    except OSError:
+        is_elf = False
+    if not os.path.exists(exe) or not is_elf:
         return None
     kb = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):

@@ -73,6 +73,9 @@ def build_hip(force=False, jobs=None):
     os.makedirs(obj_dir, exist_ok=True)
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
              "-I" + os.path.join(ROOT, "include"), "-I" + d]
+    # (measurement scripts: extra definitions for a variant build, e.g. RALA_HIPCC_FLAGS='-DRALA_ROW_STORE_MOD="sc1"')
+    import shlex
+    flags += shlex.split(os.environ.get("RALA_HIPCC_FLAGS", ""))
     cc = hipcc()
     objs, todo = [], []
     for src in srcs:

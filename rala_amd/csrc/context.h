@@ -49,6 +49,20 @@ struct DevBuf {
         if (e == hipSuccess) n = count;
         return e;
     }
+    // room for `count` elements, the first `keep` kept (a blocking copy when the buffer has to move)
+    hipError_t grow(size_t keep, size_t count) {
+        if (count <= n && p) return hipSuccess;
+        T* q = nullptr;
+        const size_t want = count + count / 4 + 1;
+        hipError_t e = hipMalloc((void**)&q, want * sizeof(T));
+        if (e != hipSuccess) return e;
+        if (keep && p) e = hipMemcpy(q, p, keep * sizeof(T), hipMemcpyDeviceToDevice);
+        if (e != hipSuccess) { (void)hipFree(q); return e; }
+        if (p) (void)hipFree(p);
+        p = q;
+        n = want;
+        return hipSuccess;
+    }
 };
 
 // pinned host staging buffer (fast, truly asynchronous device <-> host copies)
@@ -125,7 +139,9 @@ struct rala_hip_ctx {
     // the device tokeniser (ingest.hip): the host's name table as it is, the file's text, the columns it leaves
     rala_hip::DevBuf<uint8_t> d_name_buckets, d_name_arena, d_paf_text, d_paf_strand;
     uint64_t n_name_buckets = 0;
-    rala_hip::DevBuf<uint32_t> d_paf_col[7], d_paf_chunk[2];
+    rala_hip::DevBuf<uint32_t> d_paf_col[7], d_paf_chunk[2], d_paf_win[7];
+    rala_hip::DevBuf<uint8_t> d_paf_win_strand;
+    int64_t ingest_window_bytes = 0;    // option: the tokeniser's window over the file's text (0: a quarter of the free device memory)
     rala_hip::DevBuf<unsigned long long> d_paf_bad;
     rala_hip_ingest_timings ingest_tm = {};
 

@@ -255,8 +255,55 @@ int rala_hip_set_overlaps_from_paf(rala_hip_ctx* ctx, const char* path, int chec
     for (int k = 0; k < 7; ++k) T.col[k] = &ctx->d_paf_col[k];
     T.strand = &ctx->d_paf_strand;
     PafRange R;
-    const int rc = paf_tokenise_range(ctx, path, 0, ~0ull, check_lengths != 0, threads, 0, T, &R);
-    if (rc != RALA_HIP_OK) return rc;
+    // The file's text goes through device memory in WINDOWS (round 5; before, all of it had to fit at once): at most a
+    // quarter of what is free (option ingest_window_bytes; the reference streams the file in chunks of 1 GiB,
+    // graph.cpp:24, 329-365 - its run carry-over is not needed here, rows are tokenised independently of each other and
+    // a window takes the lines that START in it).  One window - the usual case - tokenises straight into the columns.
+    uint64_t window = (uint64_t)ctx->ingest_window_bytes;
+    if (window == 0 && getenv("RALA_INGEST_WINDOW")) window = (uint64_t)atoll(getenv("RALA_INGEST_WINDOW"));      // (tests)
+    if (window == 0) {
+        size_t free_b = 0, total_b = 0;
+        INGEST_CHECK(hipSetDevice(ctx->device));
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+        window = std::max<uint64_t>(256ull << 20, free_b / 4);
+    }
+    struct stat st_;
+    const uint64_t file_n = stat(path, &st_) == 0 && S_ISREG(st_.st_mode) ? (uint64_t)st_.st_size : 0;
+    if (file_n <= window) {
+        const int rc = paf_tokenise_range(ctx, path, 0, ~0ull, check_lengths != 0, threads, 0, T, &R);
+        if (rc != RALA_HIP_OK) return rc;
+    } else {
+        PafTarget W;
+        for (int k = 0; k < 7; ++k) W.col[k] = &ctx->d_paf_win[k];
+        W.strand = &ctx->d_paf_win_strand;
+        uint64_t rows = 0;
+        float ship = 0, tok = 0;
+        for (uint64_t lo = 0; lo < file_n; lo += window) {
+            PafRange part;
+            const int rc = paf_tokenise_range(ctx, path, lo, lo + window, check_lengths != 0, threads, 0, W, &part);
+            if (rc != RALA_HIP_OK) return rc;
+            ship += ctx->ingest_tm.ship_ms; tok += ctx->ingest_tm.tokenize_ms;
+            R.flags |= part.flags;
+            if (part.flags) break;
+            if (part.first_bad != ~0ull) {          // (windows come in file order: the first one with an offender holds the first offender)
+                R.first_bad = (((part.first_bad >> 32) + rows) << 32) | (part.first_bad & 0xFFFFFFFFull);
+                break;
+            }
+            if (rows + part.n_lines >= 0xFFFFFFF0ull / 4) return ingest_fail(ctx, RALA_HIP_ETOOLARGE, "too many overlaps for 32-bit bound offsets");
+            for (int k = 0; k < 7; ++k) {
+                if (ctx->d_paf_col[k].grow(rows, rows + part.n_lines + 1) != hipSuccess) return ingest_fail(ctx, RALA_HIP_ENOMEM, "device memory for the overlap columns");
+                if (part.n_lines) INGEST_CHECK(hipMemcpy(ctx->d_paf_col[k].p + rows, ctx->d_paf_win[k].p, part.n_lines * 4, hipMemcpyDeviceToDevice));
+            }
+            if (ctx->d_paf_strand.grow(rows, rows + part.n_lines + 1) != hipSuccess) return ingest_fail(ctx, RALA_HIP_ENOMEM, "device memory for the overlap columns");
+            if (part.n_lines) INGEST_CHECK(hipMemcpy(ctx->d_paf_strand.p + rows, ctx->d_paf_win_strand.p, part.n_lines, hipMemcpyDeviceToDevice));
+            rows += part.n_lines;
+        }
+        for (int k = 0; k < 7; ++k) ctx->d_paf_win[k].release();
+        ctx->d_paf_win_strand.release();
+        R.n_lines = rows;
+        ctx->ingest_tm.ship_ms = ship; ctx->ingest_tm.tokenize_ms = tok;
+        ctx->ingest_tm.bytes = file_n; ctx->ingest_tm.lines = rows;
+    }
     if (R.flags) {
         *irregular = (int)R.flags;
         return RALA_HIP_OK;

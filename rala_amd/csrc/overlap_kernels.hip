@@ -699,7 +699,7 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// (Measured, tools/gpurun/r3_probe_masks.sh at C3: the three columns alone stream in 0.11 ms, the two fate
+// (Measured, docs/history/gpurun/r3_probe_masks.sh at C3: the three columns alone stream in 0.11 ms, the two fate
 // bytes add 0.22 ms, the candidates 0.11 ms.  The target's byte is a random access that misses the vector
 // L1; a ONE-bit table "never dies or has hills" in LDS - 125 KB per million reads, one workgroup of 1024
 // threads per compute unit - takes nine look-ups in ten off the memory path and came out at the same

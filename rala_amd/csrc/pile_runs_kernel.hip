@@ -374,6 +374,10 @@ __device__ __forceinline__ uint32_t ffbl_or_minus1(uint32_t v) {
 // compiler prefers a 64-bit address per lane: two more registers per store in flight, and at this
 // kernel's register budget that meant spill reloads inside the store loop - a scratch load is a
 // vector memory operation, and the wait for it is a wait for every row store issued so far.
+// (RALA_ROW_STORE_MOD: cache-policy bits of the row stores, for measurements - "sc1", "sc0 sc1", "nt"; round 5)
+#ifndef RALA_ROW_STORE_MOD
+#define RALA_ROW_STORE_MOD ""
+#endif
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store16(const char* base, uint32_t off, const uint4& v) {
     const u32x4 d = {v.x, v.y, v.z, v.w};
@@ -382,13 +386,13 @@ __device__ __forceinline__ void store16(const char* base, uint32_t off, const ui
     // merge them, it cost 40 %.)
     // (s_nop: a store of more than 8 bytes reads its data registers over the following cycles; the
     // compiler's hazard recogniser keeps vector writes to them away from its own stores, not from this one)
-    asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" : : "v"(off), "v"(d), "s"(base) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, %2 " RALA_ROW_STORE_MOD "\n\ts_nop 1" : : "v"(off), "v"(d), "s"(base) : "memory");
 }
 // (the same with an immediate offset: the lane offset is then a loop constant)
 template <int kImm>
 __device__ __forceinline__ void store16_imm(const char* base, uint32_t off, const uint4& v) {
     const u32x4 d = {v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 1" : : "v"(off), "v"(d), "s"(base), "n"(kImm) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3 " RALA_ROW_STORE_MOD "\n\ts_nop 1" : : "v"(off), "v"(d), "s"(base), "n"(kImm) : "memory");
 }
 
 // kShort: the first kernel of the chain takes only reads of up to 16384 bases (the others go to the
@@ -523,7 +527,7 @@ __device__ __forceinline__ void expand_from_bitmap(uint32_t* sm, const uint16_t*
         constexpr bool kFull = decltype(full_tag)::value;
         const uint32_t voff = lane16 + g0 * 16u;              // the stores' lane offset: once per four groups
         // (Measured, round 4, no gain: the LDS reads of two groups under way before the first value is looked at instead of
-        // read - wait - combine - store group after group: 4.11 - 4.14 ms either way, tools/gpurun/r4_ahead.sh.  What the
+        // read - wait - combine - store group after group: 4.11 - 4.14 ms either way, docs/history/gpurun/r4_ahead.sh.  What the
         // kernel's rate hangs on at a wavefront's start are its round trips to MEMORY - kPlain -, not those to the LDS.)
         uint32_t bits[4], kq[4];
 #pragma unroll
@@ -576,7 +580,7 @@ __device__ __forceinline__ void expand_from_bitmap(uint32_t* sm, const uint16_t*
 }  // namespace
 
 // kDiag: the diagnostic instantiation honours PileArgs::stop_after (per-phase counter runs,
-// tools/gpurun/gpurun_pmc.sh); the product instantiation carries none of those branches.
+// docs/history/gpurun/gpurun_pmc.sh); the product instantiation carries none of those branches.
 //
 // kSens: the second, "sensitive" pass (rala -s; reference graph.cpp:917-1026) in the same run space.
 // The coverage of a read is then the sum over its primary bound events (still in the slots the
@@ -633,7 +637,7 @@ __global__ __launch_bounds__(64 * kWaves, kOne ? 7 : kBases > 32768 ? 2 : kBases
     // XCD one contiguous eighth of the items (tools/fill_bench3.hip: rows written side by side by one XCD
     // stream out at 6.2 TB/s instead of 5.2 TB/s - in a fill kernel; this kernel does not notice.  Round 4, the same
     // with one workgroup per read - workgroup i takes read (i % 8) * n / 8 + i / 8 - on the build that runs at the
-    // fill kernel's 5.0 TB/s: C3 4.26 against 4.16 ms, C5 17.4 against 17.7, tools/gpurun/r4_xcd.sh; not kept).
+    // fill kernel's 5.0 TB/s: C3 4.26 against 4.16 ms, C5 17.4 against 17.7, docs/history/gpurun/r4_xcd.sh; not kept).
     uint32_t item_first = blockIdx.x * kWaves + wave_in_group, item_end = n_items, item_step = gridDim.x * kWaves;
     if (kOne && kWaves == 1 && gridDim.x % 8u == 0 && gridDim.x < n_items) {
         const uint32_t per = (n_items + 7u) / 8u, xcd = blockIdx.x % 8u;
@@ -660,7 +664,7 @@ __global__ __launch_bounds__(64 * kWaves, kOne ? 7 : kBases > 32768 ? 2 : kBases
             // branches of the general case below they were four round trips in a row)
             r = item;
             // (Measured and dropped: the same four values by the scalar unit - s_load_dword / dwordx2 and one wait - 4.6 - 4.8 ms
-            // against 4.0 - 4.1, tools/gpurun/r4_scalar.sh: lines other kernels have just written are not in its cache.)
+            // against 4.0 - 4.1, docs/history/gpurun/r4_scalar.sh: lines other kernels have just written are not in its cache.)
             const uint32_t e0 = A.ev_off[r], e1 = A.ev_off[r + 1];
             n = A.read_len[r];
             row_off = A.pile_off[r];
@@ -1759,10 +1763,10 @@ void launch_pile_dense_list(const PileArgs& args, uint32_t n_reads, uint32_t* li
 
 // (An EIGHTH wavefront per SIMD, round 4, timing only - the 384-event instantiation at 5 056 B and 64 registers over the
 // 99.7 % of the C3 reads it can take, the 512-event kernel over the same reads: 4.37 - 4.6 ms against 4.04 - 4.09,
-// tools/gpurun/r4_probe8.sh.  Seven is the kernel's optimum, not a limit worth lifting.)
+// docs/history/gpurun/r4_probe8.sh.  Seven is the kernel's optimum, not a limit worth lifting.)
 // Reads per workgroup in the first kernel (one wavefront each).  Rounds 2 - 3: one (two and four measured no gain: 4.80 /
 // 4.83 against 4.74 ms).  Round 4, once the rows start on cache-line boundaries and nothing else runs beside the kernel: two
-// 4.07 - 4.10 ms, one 4.16, four 4.23 (tools/gpurun/r4_waves2.sh) - two.
+// 4.07 - 4.10 ms, one 4.16, four 4.23 (docs/history/gpurun/r4_waves2.sh) - two.
 constexpr uint32_t kPileWavesPerGroup = 2;
 
 void launch_pile_runs(const PileArgs& args, uint32_t grid, int tier, uint32_t* overflow_list, uint32_t* overflow_count,

@@ -1420,7 +1420,10 @@ int gpu_tail_part_a(rala_hip_ctx* ctx) {
     HIPCHECK(ctx->d_med_tmp.ensure(ctx->t_med_tmp));
     HIPCHECK(ctx->d_cc_flags.ensure(8));
     (void)big;
-    if ((uint64_t)M * 258ull >= 0xFFFFFFFFull) return fail(ctx, RALA_HIP_EINVAL, "too many surviving overlaps");
+    // (the containment scans order the items by key = items * (1 + round of promotion) + index, 32 bits: checked below with the
+    // rounds this data set took - two to four - and not with the 255 a round counter could hold; before round 5 that was a
+    // limit of 16.6 M surviving overlaps, 2.2 times C5's)
+    if ((uint64_t)M >= 0x7FFFFFF0ull) return fail(ctx, RALA_HIP_ETOOLARGE, "too many surviving overlaps");
     const TailList L = tail_list(ctx);
     const TailReads R = tail_reads(ctx);
     ScanSpace sp;
@@ -1487,6 +1490,9 @@ int gpu_tail_part_a(rala_hip_ctx* ctx) {
         if (!d[batch - 1]) break;
     }
     ctx->t_rounds = rounds;
+    if ((uint64_t)M * ((uint64_t)rounds + 2ull) >= 0xFFFFFFF0ull) {
+        return fail(ctx, RALA_HIP_ETOOLARGE, "too many surviving overlaps for 32-bit list positions");
+    }
 
     // in-order containment removal (graph.cpp:831-877): overlaps (+ promoted), then internals
     {
@@ -1892,7 +1898,7 @@ int pass2(rala_hip_ctx* ctx, Comm* comm) {
         ListBlocks lb;
         uint64_t tot0 = 0, tot1 = 0, off = 0;
         for (uint32_t p = 0; p < P; ++p) { tot0 += all[2 * p]; tot1 += all[2 * p + 1]; }
-        if (tot0 + tot1 >= 0xFFFFFFF0ull / 258) return fail(ctx, RALA_HIP_EINVAL, "too many surviving overlaps");
+        if (tot0 + tot1 >= 0x7FFFFFF0ull) return fail(ctx, RALA_HIP_ETOOLARGE, "too many surviving overlaps");
         uint64_t at0 = 0, at1 = tot0;
         for (uint32_t p = 0; p < P; ++p) {
             const uint64_t mp = all[2 * p] + all[2 * p + 1];
@@ -2121,6 +2127,7 @@ int rala_hip_set_option(rala_hip_ctx* ctx, const char* key, int64_t value) {
     if (!strcmp(key, "use_round_batches")) { ctx->use_round_batches = value != 0; return RALA_HIP_OK; }
     if (!strcmp(key, "use_bound_records")) { ctx->use_bound_records = value != 0; return RALA_HIP_OK; }
     if (!strcmp(key, "use_fused_emit")) { ctx->use_fused_emit = value != 0; return RALA_HIP_OK; }
+    if (!strcmp(key, "ingest_window_bytes")) { ctx->ingest_window_bytes = std::max<int64_t>(0, value); return RALA_HIP_OK; }
     if (!strcmp(key, "debug_fp_lds_limit")) { ctx->debug_fp_lds_limit = (uint32_t)std::max<int64_t>(0, value); return RALA_HIP_OK; }
     if (!strcmp(key, "debug_fail_construct")) { ctx->debug_fail_construct = value != 0; return RALA_HIP_OK; }
     if (!strcmp(key, "use_gpu_tail")) { ctx->use_gpu_tail = value != 0; return RALA_HIP_OK; }
@@ -2171,7 +2178,7 @@ int rala_hip_set_reads(rala_hip_ctx* ctx, const uint32_t* read_len, uint64_t n_r
     // Rows start on 128-byte boundaries (64 elements): a row's first and last cache line are then its own, not shared
     // with the neighbouring rows, which other wavefronts write at other times.  Round 4, one box, pile kernel at C3:
     // 16-byte boundaries (rounds 1 - 3: what the 16-byte stores need) 4.26 ms, 128 bytes 4.17, 1 KB 4.18, 4 KB 4.21
-    // (tools/gpurun/r4_rowalign.sh; RALA_PILE_ROW_ALIGN=<elements, a power of two >= 8> for the experiment).
+    // (docs/history/gpurun/r4_rowalign.sh; RALA_PILE_ROW_ALIGN=<elements, a power of two >= 8> for the experiment).
     static const uint64_t row_align = [] {
         uint64_t want = getenv("RALA_PILE_ROW_ALIGN") ? (uint64_t)atoll(getenv("RALA_PILE_ROW_ALIGN")) : 64ull, a = 8;
         while (a * 2 <= want && a < (1ull << 20)) a *= 2;           // a power of two, 8 elements at least
@@ -2288,7 +2295,7 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
     // bucketing is done, beside the pile kernels.  Those are bound by instruction issue, and what runs
     // beside them costs them its whole stand-alone time (0.26 ms at C3: pile kernel 4.63 ms with it,
     // 4.37 without); the partitioned bucketing streams and has issue slots to spare - beside it the
-    // duplicate removal costs 0.14 ms (round 4, tools/gpurun/r4_dedupe_early.sh: step 8.08 -> 7.99 ms).
+    // duplicate removal costs 0.14 ms (round 4, docs/history/gpurun/r4_dedupe_early.sh: step 8.08 -> 7.99 ms).
     // RALA_DEDUPE_LATE keeps it beside the pile kernels.
     const bool forked = !ctx->tuple_mode && ctx->use_side_stream;
     if (!forked) {

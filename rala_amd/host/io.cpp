@@ -576,7 +576,7 @@ bool read_paf_parallel(const std::string& path, const NameTable& names, const st
     // (RALA_IO_NO_PIN=1: left to the scheduler).  On the two-socket EPYC 9575F boxes 16 threads
     // spread over both sockets (which is what the scheduler does, and what a spread pinning does)
     // parse C3 in 535 - 590 ms; on 16 neighbouring cores of one socket in 320 ms: name table and
-    // columns then live in one NUMA node and two L3 slices (tools/gpurun/r2_ingest_threads.sh).
+    // columns then live in one NUMA node and two L3 slices (docs/history/gpurun/r2_ingest_threads.sh).
     const std::vector<int> cores = getenv("RALA_IO_NO_PIN") ? std::vector<int>() : one_cpu_per_core();
     cpu_set_t before;
     const bool pinned = cores.size() >= n_thr && n_thr > 1 && sched_getaffinity(0, sizeof(before), &before) == 0;

@@ -175,6 +175,36 @@ def test_byte_ranges_with_unresolved_names_long_runs_and_empty_ranks(tmp_path):
     assert got is None and irregular != 0
 
 
+def test_text_through_device_memory_in_windows(tmp_path, monkeypatch):
+    """a file larger than the tokeniser's window (a quarter of the free device memory; here 1 MB and 37 KB by
+    RALA_INGEST_WINDOW): the text goes through device memory window by window - lines across the windows' ends, a window
+    without a line start, the first length error in file order - and the columns are the host reader's (the reference
+    streams the file in chunks of 1 GiB, graph.cpp:24, 329-365)"""
+    ds = Dataset(3000, 600_000, 4)
+    paf = str(tmp_path / "ovl.paf")
+    ds.write_paf(paf)
+    names = ["r%d" % i for i in range(ds.n_reads)]
+    for window in (1 << 20, 37_000):
+        monkeypatch.setenv("RALA_INGEST_WINDOW", str(window))
+        assert os.path.getsize(paf) > 4 * window
+        got, irregular, bad = device_parse(paf, names, ds.read_len, 3)
+        assert irregular == 0 and bad == -1
+        for f in FIELDS:
+            assert (got[f] == getattr(ds.overlaps, f)).all(), f
+        assert (got["strand"] == ds.overlaps.strand).all()
+    # one line longer than several windows; the first record with a wrong length is found in its window
+    names2, lens2 = ["r%d" % i for i in range(5)], [1000, 2000, 3000, 4000, 5000]
+    good = "r0\t1000\t10\t900\t+\tr1\t2000\t5\t895\t800\t890\t255"
+    text = "\n".join([good] * 300 + [good + "\tzz:Z:" + "x" * 200_000] + [good] * 300 + ["r2\t3001\t0\t500\t+\tr1\t2000\t0\t500\t400\t500\t255"] + [good] * 50) + "\n"
+    path = str(tmp_path / "long.paf")
+    open(path, "w").write(text)
+    monkeypatch.setenv("RALA_INGEST_WINDOW", "30000")
+    got, irregular, bad = device_parse(path, names2, lens2, 2)
+    assert got is None and irregular == 0 and bad == 2
+    got, irregular, bad = device_parse(path, names2, lens2, 2, check_lengths=False)
+    assert irregular == 0 and bad == -1 and len(got["a_id"]) == 652
+
+
 def test_sensitive_file_in_shares(tmp_path):
     """rala_hip_tokenise_sensitive_paf: a rank's share of the sensitive file - the lines that start in its byte range -,
     no length check (Overlap::transmute_ has none); all shares together are the host reader's columns"""
