@@ -124,8 +124,12 @@ __global__ __launch_bounds__(kBlockC) void group_count_kernel(OvlSoA o, uint32_t
 //     (dedupe_mark_kernel's rule, overlap_kernels.hip; the element in front of a thread's four comes from the lane below);
 //   * writes the validity byte that holds for every query that is NOT marked - resolvable and no self overlap
 //     (graph.cpp:273-307 on a run of strictly increasing targets) - four of them as one word;
-//   * sets *any when anybody was marked: dedupe_fix_kernel then goes over the marked queries' overlaps with the full
-//     comparison, and leaves at once otherwise (the usual file).
+//   * LISTS where it marked (position, query) - staged per trip in LDS, one add to the list's counter per workgroup and trip:
+//     dedupe_fix_list_kernel (overlap_kernels.hip) then redoes just the runs around those positions with the full
+//     comparison.  (First version of this round: a flag "anybody marked" and a pass over all overlaps behind it - at C3,
+//     where repeats make 1 - 2 % of the queries suspect, that pass ran 0.33 ms beside the first scatter and cost it 0.08.)
+//     A list that outgrows its room (a file whose runs are not sorted by target at all) leaves its counter beyond the
+//     capacity and the pass over all overlaps takes over.
 // Needs the id columns on 16-byte boundaries (the caller looks).
 __device__ __forceinline__ void load4_ids(const uint32_t* p, uint64_t i0, uint64_t n, uint32_t (&out)[4]) {
     typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
@@ -138,13 +142,21 @@ __device__ __forceinline__ void load4_ids(const uint32_t* p, uint64_t i0, uint64
     }
 }
 constexpr uint32_t kCountVec = 2;               // groups of four overlaps per thread and trip
+constexpr uint32_t kFlagStage = 512;            // marks a workgroup stages per trip
 __global__ __launch_bounds__(kBlockC) void group_count_dedupe_kernel(OvlSoA o, uint32_t n_reads, uint32_t n_groups, uint32_t* group_count,
-                                                                     uint8_t* __restrict__ suspect, uint8_t* __restrict__ valid, uint32_t* any) {
+                                                                     uint8_t* __restrict__ suspect, uint8_t* __restrict__ valid, uint32_t* list_pos,
+                                                                     uint32_t* list_query, uint32_t list_cap, uint32_t* list_count) {
     extern __shared__ uint32_t s_hist[];
+    __shared__ uint32_t s_fpos[kFlagStage], s_fq[kFlagStage], s_fcnt, s_fbase;
     for (uint32_t g = threadIdx.x; g < n_groups; g += kBlockC) s_hist[g] = 0;
+    if (threadIdx.x == 0) s_fcnt = 0;
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63;
-    bool flagged = false;
+    auto mark = [&](uint32_t query, uint64_t at) {
+        suspect[query] = 1;
+        const uint32_t slot = atomicAdd(&s_fcnt, 1u);
+        if (slot < kFlagStage) { s_fpos[slot] = (uint32_t)at; s_fq[slot] = query; }
+    };
     constexpr uint64_t kTrip = (uint64_t)kBlockC * 4 * kCountVec;
     for (uint64_t c0 = (uint64_t)blockIdx.x * kTrip; c0 < o.n; c0 += (uint64_t)gridDim.x * kTrip) {
         uint32_t a[kCountVec][4], b[kCountVec][4];
@@ -171,11 +183,11 @@ __global__ __launch_bounds__(kBlockC) void group_count_dedupe_kernel(OvlSoA o, u
                 if (in && have_prev) {
                     const bool pok = pa < n_reads && pb < n_reads;
                     if (ok && pok) {
-                        if (pa == x && y <= pb) { suspect[x] = 1; flagged = true; }
+                        if (pa == x && y <= pb) mark(x, i0 + e);
                     } else {
                         // an unresolved record hides the order of its neighbours: flag both queries
-                        if (x < n_reads) { suspect[x] = 1; flagged = true; }
-                        if (pa < n_reads) { suspect[pa] = 1; flagged = true; }
+                        if (x < n_reads) mark(x, i0 + e);
+                        if (pa < n_reads) mark(pa, i0 + e - 1);
                     }
                 }
                 if (ok && x != y) word |= 1u << (8 * e);
@@ -184,8 +196,24 @@ __global__ __launch_bounds__(kBlockC) void group_count_dedupe_kernel(OvlSoA o, u
             if (i0 + 4 <= o.n) *(uint32_t*)(valid + i0) = word;
             else for (uint32_t e = 0; e < 4 && i0 + e < o.n; ++e) valid[i0 + e] = (uint8_t)(word >> (8 * e));
         }
+        // this trip's marks to the list: one add to its counter (a trip with more marks than the stage holds: the list is
+        // given up - its counter goes beyond its capacity - and the pass over all overlaps will do the work)
+        __syncthreads();
+        const uint32_t staged = s_fcnt;
+        if (staged) {                           // (the same answer in every thread)
+            if (threadIdx.x == 0) s_fbase = atomicAdd(list_count, staged > kFlagStage ? list_cap + 1u : staged);
+            __syncthreads();
+            if (staged <= kFlagStage) {
+                for (uint32_t k = threadIdx.x; k < staged; k += kBlockC) {
+                    const uint32_t at = s_fbase + k;
+                    if (at < list_cap) { list_pos[at] = s_fpos[k]; list_query[at] = s_fq[k]; }
+                }
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) s_fcnt = 0;
+            __syncthreads();
+        }
     }
-    if (__syncthreads_or(flagged ? 1 : 0) && threadIdx.x == 0) *any = 1u;
     for (uint32_t g = threadIdx.x; g < n_groups; g += kBlockC) {
         const uint32_t c = s_hist[g];
         if (c) atomicAdd(&group_count[g], c);
@@ -703,7 +731,7 @@ struct PartitionBuffers {
 };
 
 hipError_t count_attribute(size_t lds_count) {
-    if (lds_count > 64 * 1024) {        // (per launch: the attribute belongs to the function on the current device)
+    if (lds_count + 8192 > 64 * 1024) { // (per launch: the attribute belongs to the function on the current device; 8 KB: the kernels' static LDS)
         hipError_t e = hipFuncSetAttribute((const void*)group_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_count);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)group_count_dedupe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_count);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)group_count_records_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_count);
@@ -734,8 +762,8 @@ bool bucket_count_can_dedupe(const OvlSoA& o, const uint8_t* valid) {
 }
 
 // dedupe (may be null): the counting pass does duplicate removal's first pass on the way (group_count_dedupe_kernel) -
-// suspect: n_reads bytes, cleared here; valid: the validity bytes; any: a zeroed word; the caller runs launch_dedupe_fix
-// behind this call's counting pass (the event `counted`, recorded here when given)
+// suspect: n_reads bytes, cleared here; valid: the validity bytes; list_*: room for list_cap marks and a zeroed counter; the
+// caller runs launch_dedupe_fix behind this call's counting pass (the event `counted`, recorded here when given)
 hipError_t launch_bucket_partitioned(const OvlSoA& o, uint32_t n_reads, uint32_t* acount, uint32_t* written,
                                      uint32_t* part_cursor, uint32_t* group, uint32_t* tiles, uint64_t* rec1, uint64_t* rec2,
                                      uint32_t* ev_off, uint32_t* ev, uint32_t workgroups, FillList& fills, hipStream_t s,
@@ -756,7 +784,8 @@ hipError_t launch_bucket_partitioned(const OvlSoA& o, uint32_t n_reads, uint32_t
     const uint32_t count_groups = (workgroups ? workgroups : 256u) * (2 * lds_count <= 150u * 1024u ? 2u : 1u);
     if (dedupe) {
         hipLaunchKernelGGL(group_count_dedupe_kernel, dim3(std::min<uint32_t>(count_groups, chunks)), dim3(kBlockC), lds_count, s, o,
-                           n_reads, B.n_part * kGroupsPerPart, B.group_count, dedupe->suspect, dedupe->valid, dedupe->any);
+                           n_reads, B.n_part * kGroupsPerPart, B.group_count, dedupe->suspect, dedupe->valid, dedupe->list_pos,
+                           dedupe->list_query, dedupe->list_cap, dedupe->list_count);
         if (dedupe->counted) {
             e = hipEventRecord(dedupe->counted, s);
             if (e != hipSuccess) return e;

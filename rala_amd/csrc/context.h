@@ -151,6 +151,7 @@ struct rala_hip_ctx {
     rala_hip::DevBuf<uint32_t> d_ovl_u32[7];
     rala_hip::DevBuf<uint8_t> d_ovl_strand;
     rala_hip::DevBuf<uint8_t> d_valid, d_suspect;
+    rala_hip::DevBuf<uint32_t> d_dedupe_list;      // where the counting pass marked queries (positions, then queries)
     bool valid_ready = false;
     bool inputs_set = false;            // rala_hip_set_overlaps / _set_bound_tuples was called
 

@@ -404,7 +404,10 @@ bool partition_path_fits(uint32_t n_reads, uint32_t max_read_len, uint64_t n_ove
 struct BucketDedupe {
     uint8_t* suspect;       // n_reads bytes (cleared by the call)
     uint8_t* valid;         // one byte per overlap
-    uint32_t* any;          // a zeroed word: set when a query was marked
+    uint32_t* list_pos;     // where the counting pass marked a query (a run that needs the full comparison): positions ...
+    uint32_t* list_query;   // ... and queries, list_cap of each
+    uint32_t list_cap;
+    uint32_t* list_count;   // a zeroed word: marks listed; beyond list_cap: the list was given up
     hipEvent_t counted;     // may be null
 };
 bool bucket_count_can_dedupe(const OvlSoA& o, const uint8_t* valid);      // (the id columns on 16-byte boundaries)
@@ -412,8 +415,9 @@ hipError_t launch_bucket_partitioned(const OvlSoA& o, uint32_t n_reads, uint32_t
                                      uint32_t* part_cursor, uint32_t* group, uint32_t* tiles, uint64_t* rec1, uint64_t* rec2,
                                      uint32_t* ev_off, uint32_t* ev, uint32_t workgroups, FillList& fills, hipStream_t s,
                                      const BucketDedupe* dedupe = nullptr);
-// the marked queries' overlaps through the full comparison (a few workgroups that leave at once when *any is 0)
-void launch_dedupe_fix(const OvlSoA& o, uint32_t n_reads, const uint8_t* suspect, const uint32_t* any, uint8_t* valid, hipStream_t s);
+// the runs around the listed marks through the full comparison - or, when the list was given up, every overlap of a marked
+// query (two launches; the one that is not needed leaves at once)
+void launch_dedupe_fix(const OvlSoA& o, uint32_t n_reads, const BucketDedupe& d, hipStream_t s);
 // the same from an owner rank's bound records (launch_bucket_tuples(.., records = true)): zero_counts = n_reads + 2 words
 bool partition_path_fits_records(uint32_t n_reads, uint32_t max_read_len, uint64_t n_records);
 // (shrink: what the bounds are drawn in by - 15 for the primary overlaps, graph.cpp:317-324; 0 for the sensitive ones, :929-933)

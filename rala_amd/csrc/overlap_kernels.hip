@@ -107,15 +107,61 @@ __global__ __launch_bounds__(kBlock) void dedupe_kernel(OvlSoA o, uint32_t n_rea
     valid[i] = dedupe_survives(o, n_reads, i, a, b) ? 1 : 0;
 }
 
-// behind the counting pass that marked the queries and wrote the validity bytes of everybody else
-// (group_count_dedupe_kernel, bucket_kernels.hip): the marked queries' overlaps; nothing to do in the usual file
+// behind the counting pass that marked queries and wrote the validity bytes of everybody else
+// (group_count_dedupe_kernel, bucket_kernels.hip).  The list was given up (its counter beyond its capacity): every overlap
+// of a marked query.
 __global__ __launch_bounds__(kBlock) void dedupe_fix_kernel(OvlSoA o, uint32_t n_reads, const uint8_t* __restrict__ suspect,
-                                                            const uint32_t* __restrict__ any, uint8_t* __restrict__ valid) {
-    if (*any == 0) return;
+                                                            const uint32_t* __restrict__ list_count, uint32_t list_cap,
+                                                            uint8_t* __restrict__ valid) {
+    if (*list_count <= list_cap) return;
     for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < o.n; i += (uint64_t)gridDim.x * kBlock) {
         const uint32_t a = o.a_id[i], b = o.b_id[i];
         if (a >= n_reads || b >= n_reads || a == b || !suspect[a]) continue;
         valid[i] = dedupe_survives(o, n_reads, i, a, b) ? 1 : 0;
+    }
+}
+
+// The usual case: a wavefront per listed mark (position i, query a).  The run of query a around position i - records that do
+// not resolve neither start nor end a run (graph.cpp:343-350) - is found by the wavefront, 64 positions at a time to either
+// side; every member of the run then takes the full comparison.  A run with several marks is redone as often: the answers
+// are the same.
+__global__ __launch_bounds__(kBlock) void dedupe_fix_list_kernel(OvlSoA o, uint32_t n_reads, const uint32_t* __restrict__ list_pos,
+                                                                 const uint32_t* __restrict__ list_query,
+                                                                 const uint32_t* __restrict__ list_count, uint32_t list_cap,
+                                                                 uint8_t* __restrict__ valid) {
+    const uint32_t n_list = *list_count;
+    if (n_list == 0 || n_list > list_cap) return;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t n_waves = gridDim.x * (kBlock / 64);
+    for (uint32_t e = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); e < n_list; e += n_waves) {
+        const uint64_t at = list_pos[e];
+        const uint32_t a = list_query[e];
+        auto breaks = [&](uint64_t j) {             // a resolved record of another query
+            const uint32_t aj = o.a_id[j], bj = o.b_id[j];
+            return aj < n_reads && bj < n_reads && aj != a;
+        };
+        uint64_t lo = at, hi = at + 1;              // the run lies within [lo, hi)
+        for (;;) {                                  // to the left: positions lo - 1 - lane
+            if (lo == 0) break;
+            const bool there = lo > lane;
+            const bool stop = !there || breaks(lo - 1 - lane);
+            const uint64_t m = __ballot(stop);
+            if (m) { lo -= (uint32_t)__ffsll((unsigned long long)m) - 1u; break; }
+            lo -= 64;
+        }
+        for (;;) {                                  // to the right: positions hi + lane
+            if (hi >= o.n) break;
+            const bool there = hi + lane < o.n;
+            const bool stop = !there || breaks(hi + lane);
+            const uint64_t m = __ballot(stop);
+            if (m) { hi += (uint32_t)__ffsll((unsigned long long)m) - 1u; break; }
+            hi += 64;
+        }
+        for (uint64_t j = lo + lane; j < hi; j += 64) {
+            const uint32_t aj = o.a_id[j], bj = o.b_id[j];
+            if (aj >= n_reads || bj >= n_reads || aj != a || aj == bj) continue;
+            valid[j] = dedupe_survives(o, n_reads, j, aj, bj) ? 1 : 0;
+        }
     }
 }
 
@@ -952,10 +998,15 @@ void launch_dedupe(const OvlSoA& o, uint32_t n_reads, uint8_t* suspect, uint8_t*
     hipLaunchKernelGGL(dedupe_mark_kernel, grid_for(o.n), dim3(kBlock), 0, s, o, n_reads, suspect);
     hipLaunchKernelGGL(dedupe_kernel, grid_for(o.n), dim3(kBlock), 0, s, o, n_reads, (const uint8_t*)suspect, valid);
 }
-void launch_dedupe_fix(const OvlSoA& o, uint32_t n_reads, const uint8_t* suspect, const uint32_t* any, uint8_t* valid, hipStream_t s) {
+void launch_dedupe_fix(const OvlSoA& o, uint32_t n_reads, const BucketDedupe& d, hipStream_t s) {
     if (!o.n) return;
+    // (the lengths are on the device: both kernels look, the one that is not meant leaves at once)
+    const uint32_t grid_list = (uint32_t)std::min<uint64_t>(4096, ((uint64_t)d.list_cap + kBlock / 64 - 1) / (kBlock / 64));
+    hipLaunchKernelGGL(dedupe_fix_list_kernel, dim3(std::max<uint32_t>(grid_list, 1)), dim3(kBlock), 0, s, o, n_reads, (const uint32_t*)d.list_pos,
+                       (const uint32_t*)d.list_query, (const uint32_t*)d.list_count, d.list_cap, d.valid);
     const uint32_t grid = (uint32_t)std::min<uint64_t>(2048, (o.n + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(dedupe_fix_kernel, dim3(grid), dim3(kBlock), 0, s, o, n_reads, suspect, any, valid);
+    hipLaunchKernelGGL(dedupe_fix_kernel, dim3(grid), dim3(kBlock), 0, s, o, n_reads, (const uint8_t*)d.suspect, (const uint32_t*)d.list_count,
+                       d.list_cap, d.valid);
 }
 void launch_bucket_fixed(const OvlSoA& o, uint32_t n_reads, uint32_t stride, uint32_t* counts, uint32_t* ev_fixed,
                          uint32_t* over, hipStream_t s) {

@@ -2358,14 +2358,17 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
                                                        ctx->d_bk_group.p, ctx->d_bk_tiles.p, ctx->d_bk_rec[0].p, ctx->d_bk_rec[1].p,
                                                        ctx->d_ev_off.p, ctx->d_ev.p, ctx->n_compute_units, fills, s));
         } else {
-            const BucketDedupe bd = {ctx->d_suspect.p, ctx->d_valid.p, ctx->d_small.p + 9, ctx->ev[8]};     // ([9]: zeroed with d_small above)
+            constexpr uint32_t kMarks = 1u << 20;           // (C3: 1 - 2 % of a million queries)
+            if (dedupe_counted) HIPCHECK(ctx->d_dedupe_list.ensure(2 * (size_t)kMarks));
+            const BucketDedupe bd = {ctx->d_suspect.p, ctx->d_valid.p, ctx->d_dedupe_list.p, ctx->d_dedupe_list.p + kMarks, kMarks,
+                                     ctx->d_small.p + 9, ctx->ev[8]};     // ([9]: zeroed with d_small above)
             HIPCHECK(launch_bucket_partitioned(ctx->ovl, n_reads, ctx->d_bk_u32[0].p, ctx->d_bk_u32[2].p,
                                                ctx->d_bk_part.p, ctx->d_bk_group.p, ctx->d_bk_tiles.p, ctx->d_bk_rec[0].p,
                                                ctx->d_bk_rec[1].p, ctx->d_ev_off.p, ctx->d_ev.p, ctx->n_compute_units, fills, s,
                                                dedupe_counted ? &bd : nullptr));
             if (dedupe_counted) {
                 HIPCHECK(hipStreamWaitEvent(ctx->side, ctx->ev[8], 0));
-                launch_dedupe_fix(ctx->ovl, n_reads, ctx->d_suspect.p, ctx->d_small.p + 9, ctx->d_valid.p, ctx->side);
+                launch_dedupe_fix(ctx->ovl, n_reads, bd, ctx->side);
                 HIPCHECK(hipEventRecord(ctx->ev[1], ctx->side));
             }
         }
