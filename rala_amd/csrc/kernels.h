@@ -304,7 +304,8 @@ void launch_list_members(const uint32_t* alive_reads, const uint8_t* touched, ui
                          uint32_t* list, uint32_t* count, hipStream_t s);
 // The reads of a sensitive-pass list by the kernel that takes them (known beforehand from length and event counts, as in
 // the first pass): class 0 up to 16384 bases and kRunEventCap - 2 events (primary + sensitive), 1 up to 32768 bases and as
-// many events, 2 up to 16384 bases and kRunEventCapMid - 2 events, 3 the rest (position space).  out[c] receives the
+// many events, 2 up to 16384 bases and kRunEventCapMid - 2 events, 3 up to 16384 bases and kRunEventCapBig - 2 events (round 5:
+// the event-dense targets, a third of the pass at C5 while they ran in position space), 4 the rest (position space).  out[c] receives the
 // class' reads, counts[c] (zeroed by the caller) how many.  A hand-over through the kernels' overflow lists costs one add
 // to ONE counter per read: at C5 300 000 of them, 3 ms per kernel.
 struct SensSplitArgs {
@@ -315,8 +316,8 @@ struct SensSplitArgs {
     const uint32_t* sens_off;
     const uint32_t* begin;
     const uint32_t* end;
-    uint32_t* out[4];
-    uint32_t* counts;
+    uint32_t* out[5];
+    uint32_t* counts;              // five words
 };
 // (the list's length is on the device: *n_dev, at most `bound`)
 void launch_sens_split(const uint32_t* list, uint32_t bound, const uint32_t* n_dev, const SensSplitArgs& args, hipStream_t s);

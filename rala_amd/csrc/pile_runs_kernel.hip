@@ -410,7 +410,7 @@ struct Layout {
     static constexpr bool kShortLayout = kShort;
     // list capacities: a read that needs more goes to the next kernel of the chain
     // three instantiations: 512 events (almost every read), 1024 (high coverage), 2048 (the rest)
-    static constexpr uint32_t kMaxReg = kShort ? 14 : kCap <= 512 ? 16 : kCap <= 1024 ? 32 : 64;   // regions per (q, kind) list
+    static constexpr uint32_t kMaxReg = kShort ? (kCap <= 512 ? 14 : 28) : kCap <= 512 ? 16 : kCap <= 1024 ? 32 : 64;   // regions per (q, kind) list
     static constexpr uint32_t kMaxRaw = kCap <= 512 ? 8 : kCap <= 1024 ? 16 : 32;    // pits / hills before the merge
     static constexpr uint32_t kArr = kCap + 4;                  // entries per run-indexed array
     static constexpr uint32_t kIdx = kShort ? 128 : kCap <= 512 ? 256 : 512;   // entries of the position -> run index
@@ -421,7 +421,10 @@ struct Layout {
     // X: events (sort) -> bitmap + prefix -> group counts -> histograms -> slope survivors
     static constexpr uint32_t X = 0;
     static constexpr uint32_t kXmin = kCap > kXbitmap ? kCap : kXbitmap;
-    static constexpr uint32_t kX = kSlopeWords > kXmin ? kSlopeWords : kXmin;
+    // (short layout: the region lists - 8 * kMaxReg words and 4 counts - lie inside X behind the slope survivors; at 512 events
+    // the bitmap's size leaves that room anyway)
+    static constexpr uint32_t kXlists = kShort ? kSlopeWords + 8 * kMaxReg + 4 : kSlopeWords;
+    static constexpr uint32_t kX = kXlists > kXmin ? kXlists : kXmin;
     static constexpr uint32_t RS = X + kX;                      // run starts (+ sentinel)
     static constexpr uint32_t RV = RS + (kShort ? kArr / 2 : kArr);   // run values, uint16 (kArr / 2 words)
     static constexpr uint32_t IDX = RV + kArr / 2;              // kIdx uint16
@@ -449,7 +452,7 @@ struct Layout {
     static_assert(kX >= kCap && kX >= kIdx && kX >= 768, "shared region too small");
     static_assert(kIdx / 2 >= 64 && SEL >= XTABLE + 32, "scratch of the expansion: 64 noted groups, 8 masks");
     static_assert(kBases == 16384 || (kShort && (kBases == 32768 || kBases == 65536)), "bitmap sizes in use");
-    static_assert(!kShort || kBases != 16384 || WORDS * 4 <= 5632, "seven wavefronts per SIMD: 28 workgroups in 160 KB, 512-byte granules");
+    static_assert(!kShort || kBases != 16384 || kCap > 512 || WORDS * 4 <= 5632, "seven wavefronts per SIMD: 28 workgroups in 160 KB, 512-byte granules");
     static_assert(!kShort || kBases > 32768 || WORDS * 4 <= 10240, "four wavefronts per SIMD: 16 workgroups in 160 KB");
     static_assert(!kShort || WORDS * 4 <= 16384, "ten workgroups in 160 KB");
 };
@@ -606,10 +609,12 @@ __device__ __forceinline__ void expand_from_bitmap(uint32_t* sm, const uint16_t*
 template <uint32_t kCap, bool kDiag, int kSens, bool kOne = false, uint32_t kBases = 16384, uint32_t kWaves = 1, bool kPlain = false>
 __global__ __launch_bounds__(64 * kWaves, kOne ? 7 : kBases > 32768 ? 2 : kBases > 16384 ? 4 : 5) void pile_runs_kernel(PileArgs A, uint32_t* overflow_list, uint32_t* overflow_count) {
     static_assert(kWaves == 1 || kOne, "several reads per workgroup: the first kernel of a chain only");
-    static_assert(kSens == 0 || (kCap <= 1024 && !kDiag), "the sensitive pass runs on the bitmap path");
+    static_assert(kSens == 0 || !kDiag, "the sensitive pass has no diagnostic instantiation");
     static_assert(!kOne || kCap <= 512, "the short layout belongs to the first kernel of a chain");
     static_assert(kBases == 16384 || !kOne, "the bigger bitmap belongs to the chain's second kernel");
-    constexpr bool kShort = kOne || kBases > 16384;     // reads of up to kBases bases only, 16-bit run starts
+    // (round 5: the sensitive pass's cap-1024 kernels too - their reads have at most 16384 bases; 14 296 -> 9 840 B of LDS, sixteen
+    // workgroups per compute unit instead of eleven, and at C5 this is the kernel nearly every target starts in)
+    constexpr bool kShort = kOne || kBases > 16384 || (kSens != 0 && kCap == 1024);     // reads of up to kBases bases only, 16-bit run starts
     constexpr uint32_t kMaxBases = kBases > 65535 ? 65535 : kBases;     // rs[R] = n in 16 bits
     typedef Layout<kCap, kShort, kBases> L;
     typedef typename L::rs_t rs_t;
@@ -712,7 +717,9 @@ __global__ __launch_bounds__(64 * kWaves, kOne ? 7 : kBases > 32768 ? 2 : kBases
         uint32_t R;
         constexpr uint32_t kBitmapBases = kBases;
         constexpr uint32_t kV = L::kBmWords / 256;      // 16-byte vectors of the bitmap per lane
-        const bool bitmap_path = kShort || (kCap <= 1024 && n <= kBitmapBases);
+        // (the sensitive pass runs on the bitmap path whatever its event cap - its reads have at most kBases bases, and the marks of
+        // the given region go into the bitmap; with 2048 events the events wait in 32 registers)
+        const bool bitmap_path = kShort || ((kCap <= 1024 || kSens != 0) && n <= kBitmapBases);
         if (bitmap_path) {
             uint32_t* bm = sm + L::X;
             uint16_t* pref = (uint16_t*)(bm + kBitmapBases / 32);
@@ -720,7 +727,7 @@ __global__ __launch_bounds__(64 * kWaves, kOne ? 7 : kBases > 32768 ? 2 : kBases
             // borrows from the neighbour (at most kCap events meet at one position)
             // (short layout: in the place of the run values: run k's sum is the 16 bits that rv[k] takes)
             uint32_t* delta = sm + L::DELTA;
-            static_assert(kCap > 1024 || kShort || L::SEL - L::RF >= L::kArr / 2 + 2, "scratch for the per-run sums");
+            static_assert((kCap > 1024 && kSens == 0) || kShort || L::SEL - L::RF >= L::kArr / 2 + 2, "scratch for the per-run sums");
 #pragma unroll
             for (uint32_t j = 0; j < kV; ++j) ((uint4*)bm)[lane + 64 * j] = make_uint4(0, 0, 0, 0);
             for (uint32_t k = lane; 2 * k < n_ev + 5; k += 64) delta[k] = 0x80008000u;
@@ -1836,6 +1843,9 @@ void launch_pile_sens(const PileArgs& args, uint32_t grid, int tier, int mode, u
     } else if (tier == 0) {
         if (mode == 1) RALA_LAUNCH_SENS(kRunEventCap, 1);
         else RALA_LAUNCH_SENS(kRunEventCap, 2);
+    } else if (tier == 2) {
+        if (mode == 1) RALA_LAUNCH_SENS(kRunEventCapBig, 1);
+        else RALA_LAUNCH_SENS(kRunEventCapBig, 2);
     } else {
         if (mode == 1) RALA_LAUNCH_SENS(kRunEventCapMid, 1);
         else RALA_LAUNCH_SENS(kRunEventCapMid, 2);

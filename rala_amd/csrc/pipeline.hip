@@ -709,27 +709,27 @@ int run_sens_pass(rala_hip_ctx* ctx, PileArgs pa, const RepeatArgs& ra, int mode
     HIPCHECK(ctx->d_overflow.ensure(ctx->n_reads + 1));
     HIPCHECK(ctx->d_overflow_mid.ensure(ctx->n_reads + 1));
     HIPCHECK(ctx->d_chain_cnt.ensure(16));
-    // [0] handed on by the cap-512 kernels, [1] by the cap-1024 kernel, [8 .. 11] the classes' sizes
+    // [0] handed on by the cap-512 kernels, [1] by the cap-1024 and cap-2048 kernels, [8 .. 12] the classes' sizes
     {
         FillList fills;
         fills.add(ctx->d_chain_cnt.p, 0, 4 * 4);
-        fills.add(ctx->d_chain_cnt.p + 8, 0, 4 * 4);
+        fills.add(ctx->d_chain_cnt.p + 8, 0, 5 * 4);
         HIPCHECK(fills.launch(s));
     }
-    HIPCHECK(ctx->d_sens_split.ensure(4 * ((size_t)bound + 1)));
+    HIPCHECK(ctx->d_sens_split.ensure(5 * ((size_t)bound + 1)));
     SensSplitArgs sp;
     sp.read_len = pa.read_len; sp.ev_off = pa.ev_off; sp.ev_cnt = pa.ev_cnt; sp.ev_stride = pa.ev_stride;
     sp.sens_off = pa.sens_off; sp.begin = pa.begin; sp.end = pa.end;
-    for (int c = 0; c < 4; ++c) sp.out[c] = ctx->d_sens_split.p + (size_t)c * ((size_t)bound + 1);
+    for (int c = 0; c < 5; ++c) sp.out[c] = ctx->d_sens_split.p + (size_t)c * ((size_t)bound + 1);
     sp.counts = ctx->d_chain_cnt.p + 8;
     launch_sens_split(list_dev, bound, count_dev, sp, s);
     // look 1: the classes' sizes, the list's length; the first reads of the position-space class ride along
     constexpr uint32_t kRestAhead = 16384;
     HIPCHECK(ctx->p_sens_rest.ensure(kRestAhead));
-    uint32_t cls[4] = {0, 0, 0, 0}, count = 0;
-    HIPCHECK(d2h_small(ctx, cls, ctx->d_chain_cnt.p + 8, 16, s));
+    uint32_t cls[5] = {0, 0, 0, 0, 0}, count = 0;
+    HIPCHECK(d2h_small(ctx, cls, ctx->d_chain_cnt.p + 8, 20, s));
     HIPCHECK(d2h_small(ctx, &count, count_dev, 4, s));
-    HIPCHECK(hipMemcpyAsync(ctx->p_sens_rest.p, sp.out[3], (size_t)std::min<uint32_t>(bound, kRestAhead) * 4, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipMemcpyAsync(ctx->p_sens_rest.p, sp.out[4], (size_t)std::min<uint32_t>(bound, kRestAhead) * 4, hipMemcpyDeviceToHost, s));
     HIPCHECK(stream_sync(ctx, s));
     HIPCHECK(hipGetLastError());
     *count_out = count;
@@ -757,11 +757,15 @@ int run_sens_pass(rala_hip_ctx* ctx, PileArgs pa, const RepeatArgs& ra, int mode
     pa.order = sp.out[2]; pa.n_items = cls[2];
     launch_pile_sens(pa, std::min<uint32_t>(cls[2], 8192), 1, mode, handed_1024, ctx->d_chain_cnt.p + 1, aux);
     if (aux != s) HIPCHECK(hipEventRecord(ctx->ev[9], aux));
-    if (cls[3]) {
-        std::vector<uint32_t> rest(ctx->p_sens_rest.p, ctx->p_sens_rest.p + std::min<uint32_t>(cls[3], kRestAhead));
-        if (cls[3] > kRestAhead) {
-            rest.resize(cls[3]);
-            HIPCHECK(hipMemcpyAsync(rest.data() + kRestAhead, sp.out[3] + kRestAhead, (size_t)(cls[3] - kRestAhead) * 4, hipMemcpyDeviceToHost, pos));
+    // (the event-dense reads: run space at 2048 events, one wavefront per SIMD - 6 842 of C5's 281 k targets took as long in
+    // position space as all the others in theirs; what this kernel hands on goes down the chain with the cap-1024 kernel's)
+    pa.order = sp.out[3]; pa.n_items = cls[3];
+    launch_pile_sens(pa, std::min<uint32_t>(cls[3], 4096), 2, mode, handed_1024, ctx->d_chain_cnt.p + 1, pos);
+    if (cls[4]) {
+        std::vector<uint32_t> rest(ctx->p_sens_rest.p, ctx->p_sens_rest.p + std::min<uint32_t>(cls[4], kRestAhead));
+        if (cls[4] > kRestAhead) {
+            rest.resize(cls[4]);
+            HIPCHECK(hipMemcpyAsync(rest.data() + kRestAhead, sp.out[4] + kRestAhead, (size_t)(cls[4] - kRestAhead) * 4, hipMemcpyDeviceToHost, pos));
             HIPCHECK(hipStreamSynchronize(pos));
         }
         std::sort(rest.begin(), rest.end());
@@ -771,7 +775,7 @@ int run_sens_pass(rala_hip_ctx* ctx, PileArgs pa, const RepeatArgs& ra, int mode
     }
     if (aux != s) {
         HIPCHECK(hipStreamWaitEvent(s, ctx->ev[9], 0));
-        if (cls[3]) {
+        if (cls[3] || cls[4]) {
             HIPCHECK(hipEventRecord(ctx->ev[8], pos));
             HIPCHECK(hipStreamWaitEvent(s, ctx->ev[8], 0));
         }
@@ -786,7 +790,7 @@ int run_sens_pass(rala_hip_ctx* ctx, PileArgs pa, const RepeatArgs& ra, int mode
     HIPCHECK(hipGetLastError());
     trc(mode == 1 ? "sens pass 1: run space" : "sens pass 2: run space", count);
     if (getenv("RALA_HIP_TRACE")) {
-        fprintf(stderr, "[trace] sens pass %d: classes %u / %u / %u / %u, handed on %u + %u\n", mode, cls[0], cls[1], cls[2], cls[3], cnt[0], cnt[1]);
+        fprintf(stderr, "[trace] sens pass %d: classes %u / %u / %u / %u / %u, handed on %u + %u\n", mode, cls[0], cls[1], cls[2], cls[3], cls[4], cnt[0], cnt[1]);
     }
     if (cnt[1] == 0) return RALA_HIP_OK;
     std::vector<uint32_t> rest((size_t)cnt[1]);

@@ -277,19 +277,20 @@ __global__ __launch_bounds__(kBlock) void sens_split_kernel(const uint32_t* __re
                                                             SensSplitArgs A) {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     const uint32_t n = umin(*n_dev, bound);
-    uint32_t cls = 4, r = 0;
+    uint32_t cls = 5, r = 0;
     if (i < n) {
         r = list[i];
         const uint32_t len = A.read_len[r];
         const uint32_t ev = (A.ev_cnt ? umin(A.ev_cnt[r], A.ev_stride) : A.ev_off[r + 1] - A.ev_off[r]) + A.sens_off[r + 1] - A.sens_off[r];
         const bool region = A.end[r] > A.begin[r];
-        cls = !region ? 3u
+        cls = !region ? 4u
             : len <= 16384u && ev <= kRunEventCap - 2u ? 0u
             : len <= 32768u && ev <= kRunEventCap - 2u ? 1u
-            : len <= 16384u && ev <= kRunEventCapMid - 2u ? 2u : 3u;
+            : len <= 16384u && ev <= kRunEventCapMid - 2u ? 2u
+            : len <= 16384u && ev <= kRunEventCapBig - 2u ? 3u : 4u;
     }
 #pragma unroll
-    for (uint32_t c = 0; c < 4; ++c) append_flagged(cls == c, r, A.out[c], A.counts + c);
+    for (uint32_t c = 0; c < 5; ++c) append_flagged(cls == c, r, A.out[c], A.counts + c);
 }
 }  // namespace
 
