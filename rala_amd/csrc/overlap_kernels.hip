@@ -490,12 +490,23 @@ __device__ __forceinline__ bool classify_one(const OvlSoA& o, uint64_t i, const 
 // survives is decided once the deaths are known, by the few overlaps whose reads both live
 // (survivor_masks_kernel), which classify themselves again.
 // a column value that is read once: a streaming load that should not displace the per-read tables in the L2
+// (RALA_STREAM_PLAIN: ordinary loads, for measurements)
 template <class T>
-__device__ __forceinline__ T stream_load(const T* p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ T stream_load(const T* p) {
+#ifdef RALA_STREAM_PLAIN
+    return *p;
+#else
+    return __builtin_nontemporal_load(p);
+#endif
+}
 // four consecutive words of a column (p on a 16-byte boundary)
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void stream_load4(const uint32_t* p, uint32_t (&out)[4]) {
+#ifdef RALA_STREAM_PLAIN
+    const u32x4_t v = *(const u32x4_t*)p;
+#else
     const u32x4_t v = __builtin_nontemporal_load((const u32x4_t*)p);
+#endif
     out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
 }
 
@@ -784,7 +795,9 @@ __global__ __launch_bounds__(kBlock) void survivor_masks_kernel(OvlSoA o, uint32
         const uint64_t i = (uint64_t)blockIdx.x * kClassifyChunk + u * kBlock + threadIdx.x;
         const uint64_t j = i < o.n ? i : last;
         ok[u] = i < o.n && stream_load(valid + j);
-        a[u] = stream_load(o.a_id + j); b[u] = stream_load(o.b_id + j);
+        // (ordinary loads: the candidates come back for their ids - 0.430 -> 0.408 ms for this stage at C3, tools/gpurun/r5_stream.sh;
+        // classify_kernel, which does not come back, is 8 % slower with them)
+        a[u] = o.a_id[j]; b[u] = o.b_id[j];
     }
     // The query's death first (the file is grouped by query: neighbouring lanes ask for the same word): an
     // overlap behind its query's death is not live, whatever the target - and most reads die early in their
