@@ -46,7 +46,11 @@ enum {
 /* rala::OverlapType (src/overlap.hpp:27-33) */
 enum { RALA_HIP_TYPE_X = 0, RALA_HIP_TYPE_A = 1, RALA_HIP_TYPE_B = 2, RALA_HIP_TYPE_AB = 3, RALA_HIP_TYPE_BA = 4 };
 
-enum { RALA_HIP_MEM_HOST = 0, RALA_HIP_MEM_DEVICE = 1 };
+/* RALA_HIP_MEM_HOST_ASYNC (rala_hip_set_overlaps only): host memory - page-locked, if the copies are to run beside anything -
+ * that stays valid until the next rala_hip_initialize has returned: the columns are then uploaded by that call, each in front
+ * of the first kernel that reads it, on a stream of their own (ids -> the counting pass; b coordinates -> the first scatter;
+ * a coordinates -> the query side; lengths, strands beside the pile kernels). */
+enum { RALA_HIP_MEM_HOST = 0, RALA_HIP_MEM_DEVICE = 1, RALA_HIP_MEM_HOST_ASYNC = 2 };
 
 typedef struct rala_hip_ctx rala_hip_ctx;
 
@@ -107,7 +111,8 @@ void* rala_hip_stream(rala_hip_ctx* ctx);
 int rala_hip_set_reads(rala_hip_ctx* ctx, const uint32_t* read_len, uint64_t n_reads);
 /* Replaces the overlap stream of both parser passes (src/graph.cpp:328-382, :443-518):
  * parsed once, kept as binary SoA in HBM.  mem = RALA_HIP_MEM_HOST copies from host
- * memory; RALA_HIP_MEM_DEVICE adopts device pointers, which must stay valid. */
+ * memory; RALA_HIP_MEM_DEVICE adopts device pointers, which must stay valid; RALA_HIP_MEM_HOST_ASYNC
+ * leaves the copies to rala_hip_initialize (above). */
 int rala_hip_set_overlaps(rala_hip_ctx* ctx, const rala_hip_overlaps* ovl, uint64_t n, int mem);
 
 /* The same from PAF TEXT, tokenised on the device (uncompressed files).  Replaces bioparser's PAF parser and the two

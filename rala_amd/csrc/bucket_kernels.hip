@@ -780,6 +780,9 @@ hipError_t launch_bucket_partitioned(const OvlSoA& o, uint32_t n_reads, uint32_t
     e = count_attribute(lds_count);
     if (e != hipSuccess) return e;
     const uint32_t chunks = (uint32_t)((o.n + kBlockC * kCountPer - 1) / (kBlockC * kCountPer));
+    auto wait_for = [&](hipEvent_t ev) { return dedupe && ev ? hipStreamWaitEvent(s, ev, 0) : hipSuccess; };
+    e = wait_for(dedupe ? dedupe->ids : nullptr);
+    if (e != hipSuccess) return e;
     // (two workgroups per compute unit where their histograms fit side by side)
     const uint32_t count_groups = (workgroups ? workgroups : 256u) * (2 * lds_count <= 150u * 1024u ? 2u : 1u);
     if (dedupe) {
@@ -797,11 +800,15 @@ hipError_t launch_bucket_partitioned(const OvlSoA& o, uint32_t n_reads, uint32_t
     hipLaunchKernelGGL(layout_kernel, dim3(1), dim3(1024), 0, s, (const uint32_t*)B.group_count, B.n_part, B.group_base, B.group_cursor,
                        part_cursor, B.tile_part, B.tile_lo, B.tile_hi, B.n_tiles);
     const uint32_t tiles1 = (uint32_t)((o.n + kTile - 1) / kTile);
+    e = wait_for(dedupe ? dedupe->b_coords : nullptr);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(l1_scatter_kernel, dim3(tiles1), dim3(kBlockP), stage_lds_bytes(B.n_part), s, o, n_reads, B.n_part, part_cursor, rec1,
                        acount);
     launch_partition_rest(B, n_reads, acount, rec1, rec2, ev_off, ev, s);
     // (overlaps per thread: two - 1.27 against 1.31 ms for the stage at C3 in two of three alternations, four: the same as one;
     // RALA_QUERY_PER for the measurement)
+    e = wait_for(dedupe ? dedupe->a_coords : nullptr);
+    if (e != hipSuccess) return e;
     static const int q_per = getenv("RALA_QUERY_PER") ? atoi(getenv("RALA_QUERY_PER")) : 2;
     if (q_per == 4) hipLaunchKernelGGL(query_side_kernel<4>, dim3((uint32_t)((o.n + 1023) / 1024)), dim3(256), 0, s, o, n_reads, (const uint32_t*)ev_off, written, ev);
     else if (q_per == 2) hipLaunchKernelGGL(query_side_kernel<2>, dim3((uint32_t)((o.n + 511) / 512)), dim3(256), 0, s, o, n_reads, (const uint32_t*)ev_off, written, ev);

@@ -98,6 +98,13 @@ struct rala_hip_ctx {
     bool use_side_stream = true;
     std::string err;
     hipEvent_t ev[12] = {};
+    // RALA_HIP_MEM_HOST_ASYNC: the columns' host addresses until rala_hip_initialize has uploaded them (copy stream; events:
+    // ids, b coordinates, a coordinates, lengths there)
+    hipStream_t copy = nullptr;
+    hipEvent_t ev_up[4] = {};
+    bool upload_pending = false;
+    const uint32_t* up_src[7] = {};
+    const uint8_t* up_strand = nullptr;
 
     // options
     int64_t pool_per_read_x1000 = 1000;

@@ -347,6 +347,7 @@ int rala_hip_get_overlap_columns(rala_hip_ctx* ctx, uint64_t* n, uint32_t* const
     *n = ctx->n_ovl;
     if (!cols && !strand) return RALA_HIP_OK;
     INGEST_CHECK(hipSetDevice(ctx->device));
+    { const int rcu = rala_hip::flush_upload(ctx); if (rcu != RALA_HIP_OK) return rcu; }
     const uint32_t* src[7] = {ctx->ovl.a_id, ctx->ovl.b_id, ctx->ovl.a_begin, ctx->ovl.a_end, ctx->ovl.b_begin, ctx->ovl.b_end, ctx->ovl.length};
     for (int k = 0; cols && k < 7; ++k) {
         if (cols[k] && ctx->n_ovl) INGEST_CHECK(hipMemcpy(cols[k], src[k], ctx->n_ovl * 4, hipMemcpyDeviceToHost));

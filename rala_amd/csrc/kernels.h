@@ -410,6 +410,9 @@ struct BucketDedupe {
     uint32_t list_cap;
     uint32_t* list_count;   // a zeroed word: marks listed; beyond list_cap: the list was given up
     hipEvent_t counted;     // may be null
+    // (may be null) columns that are still on their way (RALA_HIP_MEM_HOST_ASYNC): the stream waits for ids in front of the
+    // counting pass, for b_coords in front of the first scatter, for a_coords in front of the query side
+    hipEvent_t ids = nullptr, b_coords = nullptr, a_coords = nullptr;
 };
 bool bucket_count_can_dedupe(const OvlSoA& o, const uint8_t* valid);      // (the id columns on 16-byte boundaries)
 hipError_t launch_bucket_partitioned(const OvlSoA& o, uint32_t n_reads, uint32_t* acount, uint32_t* written,

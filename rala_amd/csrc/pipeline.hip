@@ -21,6 +21,7 @@
 
 using namespace rala_hip;
 
+
 // Small device -> host reads (counters, flags) go through a pinned staging area: an async copy
 // into pageable memory is staged by the runtime and costs tens of microseconds more, and the
 // tail does a dozen of them per call.  d2h_small queues the copy, stream_sync waits for the
@@ -1987,11 +1988,21 @@ int rala_hip::transitive_stage(rala_hip_ctx* ctx, Comm* comm, uint32_t* n_pairs)
 
 // A sender of a sharded run: duplicate removal on the side stream (joined by the second pass), the bounds of the slice
 // scattered once by (owner, partition) into `send` (shard_send_words() words); words[p] = 8-byte words of owner p's block.
+// RALA_HIP_MEM_HOST_ASYNC columns that rala_hip_initialize has not uploaded yet: now, for a caller that reads them first
+int rala_hip::flush_upload(rala_hip_ctx* ctx) {
+    if (!ctx->upload_pending) return RALA_HIP_OK;
+    for (int k = 0; k < 7; ++k) HIPCHECK(hipMemcpy(ctx->d_ovl_u32[k].p, ctx->up_src[k], (size_t)ctx->n_ovl * 4, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(ctx->d_ovl_strand.p, ctx->up_strand, ctx->n_ovl, hipMemcpyHostToDevice));
+    ctx->upload_pending = false;
+    return RALA_HIP_OK;
+}
+
 int rala_hip::shard_emit(rala_hip_ctx* ctx, const ShardGeometry& g, uint64_t* send, uint64_t* words) {
     if (!ctx || !send || !words) return RALA_HIP_EINVAL;
     if (ctx->n_reads == 0) return fail(ctx, RALA_HIP_EINVAL, "no reads set");
     if (!ctx->inputs_set || ctx->tuple_mode) return fail(ctx, RALA_HIP_EINVAL, "no overlaps set");
     HIPCHECK(hipSetDevice(ctx->device));
+    { const int rcu = flush_upload(ctx); if (rcu != RALA_HIP_OK) return rcu; }
     hipStream_t s = ctx->stream;
     const uint32_t n_reads = (uint32_t)ctx->n_reads;
     if (ctx->use_side_stream) {
@@ -2094,6 +2105,8 @@ int rala_hip_create(int device, rala_hip_ctx** out) {
               hipStreamCreateWithPriority(&ctx->side, hipStreamDefault, prio_greatest) == hipSuccess &&
               hipStreamCreate(&ctx->aux) == hipSuccess;
     for (auto& e : ctx->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
+    ok = ok && hipStreamCreate(&ctx->copy) == hipSuccess;
+    for (auto& e : ctx->ev_up) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
     ok = ok && ctx->d_small.ensure(16) == hipSuccess;
     if (!ok) {                                  // (rala_hip_destroy releases whatever was created)
         rala_hip_destroy(ctx);
@@ -2112,6 +2125,8 @@ void rala_hip_destroy(rala_hip_ctx* ctx) {
     if (ctx->side) (void)hipStreamSynchronize(ctx->side);
     if (ctx->aux) (void)hipStreamSynchronize(ctx->aux);
     for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
+    for (auto& e : ctx->ev_up) if (e) (void)hipEventDestroy(e);
+    if (ctx->copy) (void)hipStreamDestroy(ctx->copy);
     if (ctx->side) (void)hipStreamDestroy(ctx->side);
     if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -2233,6 +2248,8 @@ int rala_hip_set_overlaps(rala_hip_ctx* ctx, const rala_hip_overlaps* o, uint64_
     HIPCHECK(hipSetDevice(ctx->device));
     HIPCHECK(hipStreamSynchronize(ctx->side));          // a failed call may have left work there
     HIPCHECK(hipStreamSynchronize(ctx->aux));
+    HIPCHECK(hipStreamSynchronize(ctx->copy));
+    ctx->upload_pending = false;
     ctx->n_ovl = n;
     const uint32_t* src[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     if (n) {
@@ -2245,14 +2262,19 @@ int rala_hip_set_overlaps(rala_hip_ctx* ctx, const rala_hip_overlaps* o, uint64_
         for (int k = 0; k < 7; ++k) dev[k] = src[k];
         dev_strand = n ? o->strand : nullptr;
     } else {
+        // (RALA_HIP_MEM_HOST_ASYNC: room now, the copies in rala_hip_initialize - upload_columns)
+        const bool later = mem == RALA_HIP_MEM_HOST_ASYNC && n != 0;
         for (int k = 0; k < 7; ++k) {
             HIPCHECK(ctx->d_ovl_u32[k].ensure(n));
-            if (n) HIPCHECK(hipMemcpy(ctx->d_ovl_u32[k].p, src[k], n * 4, hipMemcpyHostToDevice));
+            if (n && !later) HIPCHECK(hipMemcpy(ctx->d_ovl_u32[k].p, src[k], n * 4, hipMemcpyHostToDevice));
             dev[k] = ctx->d_ovl_u32[k].p;
+            ctx->up_src[k] = src[k];
         }
         HIPCHECK(ctx->d_ovl_strand.ensure(n));
-        if (n) HIPCHECK(hipMemcpy(ctx->d_ovl_strand.p, o->strand, n, hipMemcpyHostToDevice));
+        if (n && !later) HIPCHECK(hipMemcpy(ctx->d_ovl_strand.p, o->strand, n, hipMemcpyHostToDevice));
         dev_strand = ctx->d_ovl_strand.p;
+        ctx->up_strand = n ? o->strand : nullptr;
+        ctx->upload_pending = later;
     }
     ctx->ovl.a_id = dev[0]; ctx->ovl.b_id = dev[1]; ctx->ovl.a_begin = dev[2]; ctx->ovl.a_end = dev[3];
     ctx->ovl.b_begin = dev[4]; ctx->ovl.b_end = dev[5]; ctx->ovl.length = dev[6]; ctx->ovl.strand = dev_strand;
@@ -2289,6 +2311,29 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
     HIPCHECK(hipEventRecord(ctx->ev[9], ctx->aux));
     HIPCHECK(hipStreamWaitEvent(s, ctx->ev[9], 0));
     HIPCHECK(hipEventRecord(ctx->ev[0], s));
+    // RALA_HIP_MEM_HOST_ASYNC: the columns leave the host now, in the order the kernels want them; the kernels below wait for
+    // the event of the column they read first (the copy stream is in order: a later event covers the earlier columns)
+    const bool uploading = ctx->upload_pending;
+    if (uploading) {
+        const size_t n4 = (size_t)ctx->n_ovl * 4;
+        auto up = [&](int k) { return hipMemcpyAsync(ctx->d_ovl_u32[k].p, ctx->up_src[k], n4, hipMemcpyHostToDevice, ctx->copy); };
+        // (a failed call may have left kernels that still read the columns: the copies behind them)
+        HIPCHECK(hipStreamWaitEvent(ctx->copy, ctx->ev[0], 0));
+        HIPCHECK(up(0)); HIPCHECK(up(1));
+        HIPCHECK(hipEventRecord(ctx->ev_up[0], ctx->copy));
+        HIPCHECK(up(4)); HIPCHECK(up(5));
+        HIPCHECK(hipEventRecord(ctx->ev_up[1], ctx->copy));
+        HIPCHECK(up(2)); HIPCHECK(up(3));
+        HIPCHECK(hipEventRecord(ctx->ev_up[2], ctx->copy));
+        HIPCHECK(up(6));
+        HIPCHECK(hipMemcpyAsync(ctx->d_ovl_strand.p, ctx->up_strand, ctx->n_ovl, hipMemcpyHostToDevice, ctx->copy));
+        HIPCHECK(hipEventRecord(ctx->ev_up[3], ctx->copy));      // everything
+    }
+    auto wait_for_all_columns = [&]() -> int {
+        HIPCHECK(hipStreamWaitEvent(s, ctx->ev_up[3], 0));
+        HIPCHECK(hipStreamWaitEvent(ctx->side, ctx->ev_up[3], 0));
+        return (int)RALA_HIP_OK;
+    };
     // the call's counters and what the bucketing wants cleared: one fill (fill_kernels.hip)
     FillList fills;
     fills.add(ctx->d_small.p, 0, 16 * 4);
@@ -2302,6 +2347,10 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
     // duplicate removal costs 0.14 ms (round 4, docs/history/gpurun/r4_dedupe_early.sh: step 8.08 -> 7.99 ms).
     // RALA_DEDUPE_LATE keeps it beside the pile kernels.
     const bool forked = !ctx->tuple_mode && ctx->use_side_stream;
+    if (uploading && !forked) {
+        const int rcw = wait_for_all_columns();
+        if (rcw != RALA_HIP_OK) return rcw;
+    }
     if (!forked) {
         if (!ctx->tuple_mode) launch_dedupe(ctx->ovl, n_reads, ctx->d_suspect.p, ctx->d_valid.p, s);
         HIPCHECK(hipEventRecord(ctx->ev[1], s));
@@ -2338,6 +2387,12 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
     // (round 5) ... and inside the bucketing's counting pass where that pass can take it: both read the two id columns of every
     // overlap, the second stream is left with the marked queries' overlaps - usually none
     const bool dedupe_counted = dedupe_early && !from_records && !from_blocks && bucket_count_can_dedupe(ctx->ovl, ctx->d_valid.p);
+    // (columns on their way: only the path below that names what it reads when takes them as they come)
+    const bool fine_upload = uploading && dedupe_counted && partitioned;
+    if (uploading && forked && !fine_upload) {
+        const int rcw = wait_for_all_columns();
+        if (rcw != RALA_HIP_OK) return rcw;
+    }
     if (dedupe_early && !dedupe_counted) {
         HIPCHECK(hipStreamWaitEvent(ctx->side, ctx->ev[0], 0));
         launch_dedupe(ctx->ovl, n_reads, ctx->d_suspect.p, ctx->d_valid.p, ctx->side);
@@ -2364,14 +2419,16 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
         } else {
             constexpr uint32_t kMarks = 1u << 20;           // (C3: 1 - 2 % of a million queries)
             if (dedupe_counted) HIPCHECK(ctx->d_dedupe_list.ensure(2 * (size_t)kMarks));
-            const BucketDedupe bd = {ctx->d_suspect.p, ctx->d_valid.p, ctx->d_dedupe_list.p, ctx->d_dedupe_list.p + kMarks, kMarks,
-                                     ctx->d_small.p + 9, ctx->ev[8]};     // ([9]: zeroed with d_small above)
+            BucketDedupe bd = {ctx->d_suspect.p, ctx->d_valid.p, ctx->d_dedupe_list.p, ctx->d_dedupe_list.p + kMarks, kMarks,
+                               ctx->d_small.p + 9, ctx->ev[8]};     // ([9]: zeroed with d_small above)
+            if (fine_upload) { bd.ids = ctx->ev_up[0]; bd.b_coords = ctx->ev_up[1]; bd.a_coords = ctx->ev_up[2]; }
             HIPCHECK(launch_bucket_partitioned(ctx->ovl, n_reads, ctx->d_bk_u32[0].p, ctx->d_bk_u32[2].p,
                                                ctx->d_bk_part.p, ctx->d_bk_group.p, ctx->d_bk_tiles.p, ctx->d_bk_rec[0].p,
                                                ctx->d_bk_rec[1].p, ctx->d_ev_off.p, ctx->d_ev.p, ctx->n_compute_units, fills, s,
                                                dedupe_counted ? &bd : nullptr));
             if (dedupe_counted) {
                 HIPCHECK(hipStreamWaitEvent(ctx->side, ctx->ev[8], 0));
+                if (fine_upload) HIPCHECK(hipStreamWaitEvent(ctx->side, ctx->ev_up[3], 0));      // (the lengths)
                 launch_dedupe_fix(ctx->ovl, n_reads, bd, ctx->side);
                 HIPCHECK(hipEventRecord(ctx->ev[1], ctx->side));
             }
@@ -2520,6 +2577,11 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
     uint32_t small[16];
     HIPCHECK(d2h_small(ctx, small, ctx->d_small.p, sizeof(small), s));
     HIPCHECK(stream_sync(ctx, s));
+    if (uploading) {
+        // (the host's columns are free from here on)
+        HIPCHECK(hipStreamSynchronize(ctx->copy));
+        ctx->upload_pending = false;
+    }
     const uint32_t slot_overflow = fixed ? small[6] : 0;
     if (small[8] && !slot_overflow) {
         // reads whose region / interval lists outgrew the position-space kernel's LDS lists
@@ -2591,6 +2653,7 @@ int rala_hip_dedupe(rala_hip_ctx* ctx) {
     if (ctx->n_reads == 0) return fail(ctx, RALA_HIP_EINVAL, "no reads set");
     if (!ctx->inputs_set || ctx->tuple_mode) return fail(ctx, RALA_HIP_EINVAL, "no overlaps set");
     HIPCHECK(hipSetDevice(ctx->device));
+    { const int rcu = flush_upload(ctx); if (rcu != RALA_HIP_OK) return rcu; }
     launch_dedupe(ctx->ovl, (uint32_t)ctx->n_reads, ctx->d_suspect.p, ctx->d_valid.p, ctx->stream);
     HIPCHECK(stream_sync(ctx, ctx->stream));
     HIPCHECK(hipGetLastError());
@@ -2602,6 +2665,7 @@ int rala_hip_emit_bound_tuples(rala_hip_ctx* ctx, uint64_t* tuples_dev) {
     if (!ctx || !tuples_dev) return RALA_HIP_EINVAL;
     if (((uintptr_t)tuples_dev & 15u) != 0) return fail(ctx, RALA_HIP_EINVAL, "tuple buffer must be 16-byte aligned");
     HIPCHECK(hipSetDevice(ctx->device));
+    { const int rcu = flush_upload(ctx); if (rcu != RALA_HIP_OK) return rcu; }
     launch_emit_tuples(ctx->ovl, (uint32_t)ctx->n_reads, (uint2*)tuples_dev, ctx->stream);
     HIPCHECK(stream_sync(ctx, ctx->stream));
     HIPCHECK(hipGetLastError());
@@ -2629,6 +2693,7 @@ int emit_bucketed(rala_hip_ctx* ctx, uint32_t world, uint64_t* tuples_dev, uint6
     if (!ctx || !tuples_dev || !counts || world == 0 || world > 64) return RALA_HIP_EINVAL;
     if (((uintptr_t)tuples_dev & 15u) != 0) return fail(ctx, RALA_HIP_EINVAL, "tuple buffer must be 16-byte aligned");
     HIPCHECK(hipSetDevice(ctx->device));
+    { const int rcu = flush_upload(ctx); if (rcu != RALA_HIP_OK) return rcu; }
     hipStream_t s = ctx->stream;
     HIPCHECK(ctx->d_owner_cnt.ensure(2 * 64));
     uint32_t* cnt = ctx->d_owner_cnt.p;

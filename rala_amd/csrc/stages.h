@@ -53,5 +53,6 @@ int paf_tokenise_range(rala_hip_ctx* ctx, const char* path, uint64_t lo, uint64_
 
 hipError_t stream_sync(rala_hip_ctx* ctx, hipStream_t s);
 hipError_t d2h_small(rala_hip_ctx* ctx, void* dst, const void* src, size_t bytes, hipStream_t s);
+int flush_upload(rala_hip_ctx* ctx);       // (pipeline.hip) RALA_HIP_MEM_HOST_ASYNC columns not uploaded yet: now
 
 }  // namespace rala_hip

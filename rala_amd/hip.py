@@ -12,7 +12,7 @@ from . import build as _build
 
 TYPE_X, TYPE_A, TYPE_B, TYPE_AB, TYPE_BA = range(5)
 NO_READ = 0xFFFFFFFF
-MEM_HOST, MEM_DEVICE = 0, 1
+MEM_HOST, MEM_DEVICE, MEM_HOST_ASYNC = 0, 1, 2
 
 ERRORS = {0: "OK", -1: "EDEVICE", -2: "EINVAL", -3: "ECAPACITY", -4: "EFILTERED", -5: "ENOMEM", -6: "ENOTAFILE", -7: "ETOOLARGE"}
 
@@ -280,10 +280,13 @@ class Context:
         self.n_reads = int(rl.shape[0])
         self._check(self.L.rala_hip_set_reads(self.h, rl.ctypes.data, self.n_reads))
 
-    def set_overlaps(self, ov):
+    def set_overlaps(self, ov, later=False):
+        """later: RALA_HIP_MEM_HOST_ASYNC - the columns (page-locked, valid until initialize() has returned) are uploaded by
+        initialize(), beside its first kernels"""
         c = _soa(ov)
         self.n_overlaps = len(ov)
-        self._check(self.L.rala_hip_set_overlaps(self.h, ctypes.byref(c), self.n_overlaps, MEM_HOST))
+        self._keep_columns = ov if later else None
+        self._check(self.L.rala_hip_set_overlaps(self.h, ctypes.byref(c), self.n_overlaps, MEM_HOST_ASYNC if later else MEM_HOST))
 
     def set_overlaps_device(self, ptrs, n):
         """ptrs: dict name -> device pointer (int); the memory must outlive the context's use."""

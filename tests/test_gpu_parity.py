@@ -115,6 +115,62 @@ def test_host_tail_cross_check(hip_ctx_factory, n, g, seed):
     parity.check_tr(ctx, st)
 
 
+def _pinned_columns(ov):
+    """the overlap columns in page-locked host memory (torch is plumbing here: pin_memory), as an object set_overlaps takes"""
+    import torch
+    from rala_amd.synth import FIELDS
+
+    class _Cols:
+        pass
+    cols, keep = _Cols(), []
+    for f in list(FIELDS) + ["strand"]:
+        t = torch.from_numpy(np.ascontiguousarray(getattr(ov, f))).pin_memory()
+        keep.append(t)
+        setattr(cols, f, t.numpy())
+    cols._keep = keep
+    cols.__class__.__len__ = lambda self: len(ov)
+    return cols
+
+
+@pytest.mark.parametrize("side_stream,partitioned", [(1, 1), (0, 1), (1, 0)])
+@pytest.mark.parametrize("n,g,seed", [(5000, 1_000_000, 7), (600, 60_000, 9)])
+def test_columns_uploaded_inside_initialize(hip_ctx_factory, n, g, seed, side_stream, partitioned):
+    """RALA_HIP_MEM_HOST_ASYNC: the host columns leave inside rala_hip_initialize, each in front of the first kernel that reads
+    it (the partitioned bucketing with the counting pass's duplicate removal), or all of them in front of everything (the other
+    paths); twice on one context, the second time over other data - what a failed or finished call left must not be read."""
+    ds = Dataset(n, g, seed)
+    st = parity.oracle_stages(ds)
+    ctx = hip_ctx_factory()
+    ctx.set_option("use_side_stream", side_stream)
+    ctx.set_option("use_partitioned_buckets", partitioned)
+    other = Dataset(n, g, seed + 1)
+    ctx.set_reads(other.read_len)
+    ctx.set_overlaps(_pinned_columns(other.overlaps), later=True)
+    ctx.initialize()
+    ctx.set_reads(ds.read_len)
+    for _ in range(2):
+        ctx.set_overlaps(_pinned_columns(ds.overlaps), later=True)
+        ctx.initialize()
+        parity.check_initialize(ctx, st, ds)
+        ctx.construct()
+        parity.check_construct(ctx, st)
+        parity.check_tr(ctx, st)
+
+
+def test_columns_asked_for_before_initialize_has_uploaded_them(hip_ctx_factory):
+    """RALA_HIP_MEM_HOST_ASYNC followed by a call that reads the columns first (rala_hip_dedupe, the getter): uploaded then"""
+    ds = Dataset(3000, 600_000, 21)
+    st = parity.oracle_stages(ds)
+    ctx = hip_ctx_factory()
+    ctx.set_reads(ds.read_len)
+    ctx.set_overlaps(_pinned_columns(ds.overlaps), later=True)
+    ctx.dedupe()
+    ctx.initialize()
+    parity.check_initialize(ctx, st, ds)
+    ctx.construct()
+    parity.check_construct(ctx, st)
+
+
 @pytest.mark.parametrize("gpu_tail,run_kernel", [(1, 1), (0, 1), (1, 0)])
 @pytest.mark.parametrize("n,g,seed", [(5000, 1_000_000, 7), (6000, 1_600_000, 19),
                                       (600, 60_000, 9),        # ~100x: beyond the 512-event tier
