@@ -50,7 +50,7 @@ out = {"workload": "c3", "kernel": "pile_runs_kernel chain", "fetch_size_kb": fe
        "note": "round 5; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over one bench step; FETCH_SIZE doubled (gfx950, MI355X_MICROARCH.md)"}
 json.dump(out, open("gpurun_out/r05/pmc_latest.json", "w"), indent=1)
 # the bucketing's kernels: bytes moved against the 40 B per overlap = 2.03 GB the stage moves algorithmically
-bk = ["group_count_kernel", "group_count_dedupe_kernel", "dedupe_fix_kernel", "layout_kernel", "l1_scatter_kernel", "l2_scatter_kernel", "group_query_sum_kernel", "group_event_base_kernel",
+bk = ["group_count_kernel", "group_count_dedupe_kernel", "dedupe_fix_kernel", "dedupe_fix_list_kernel", "layout_kernel", "l1_scatter_kernel", "l2_scatter_kernel", "group_query_sum_kernel", "group_event_base_kernel",
       "final_kernel", "query_side_kernel"]
 rows = []
 tot_f = tot_w = 0.0
