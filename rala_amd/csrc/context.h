@@ -102,7 +102,7 @@ struct rala_hip_ctx {
     // ids, b coordinates, a coordinates, lengths there)
     hipStream_t copy = nullptr;
     hipEvent_t ev_up[4] = {};
-    bool upload_pending = false;
+    bool upload_pending = false, upload_queued = false;      // queued: every copy of this call's upload is on the copy stream
     const uint32_t* up_src[7] = {};
     const uint8_t* up_strand = nullptr;
 

@@ -363,6 +363,14 @@ __device__ __forceinline__ uint32_t bitfield_insert(uint32_t mask, uint32_t a, u
     return d;
 }
 
+// a 16-bit value in a 32-bit register whose upper half is nobody's business (no instruction to extend it)
+__device__ __forceinline__ uint32_t low_half_only(uint16_t x) {
+    typedef uint16_t u16x2_t __attribute__((ext_vector_type(2)));
+    u16x2_t t;
+    t.x = x;                                // (t.y stays what it is)
+    return __builtin_bit_cast(uint32_t, t);
+}
+
 // index of the lowest set bit, 0xFFFFFFFF for zero (v_ffbl_b32's own answer: no select around it)
 __device__ __forceinline__ uint32_t ffbl_or_minus1(uint32_t v) {
     uint32_t d;
@@ -545,7 +553,13 @@ __device__ __forceinline__ void expand_from_bitmap(uint32_t* sm, const uint16_t*
             // the value at the group's first place and the next run's (beyond the pile: some LDS word).  (Measured and
             // dropped: both in ONE two-byte aligned 32-bit read - the kernel 4.40 -> 4.85 ms, an LDS word read across
             // its alignment is not one access.)
+            // (the byte selectors below take bytes 0, 1 of each only: no extension of the 16-bit LDS reads - the compiler puts a
+            // v_and behind a zero-extending one)
+#ifdef RALA_EXPAND_EXTEND           // (measurements: the reads zero-extended, as before)
             const uint32_t v0 = rvm1[k], v1 = rvm1[k + 1];
+#else
+            const uint32_t v0 = low_half_only(rvm1[k]), v1 = low_half_only(rvm1[k + 1]);
+#endif
             const uint32_t b7 = (bits[u] >> sh1) & 0x7Fu;                      // run starts at positions 1 .. 7
             const uint32_t gl = 64u * u + lane;
             const bool in = kFull || g0 + gl < nv;

@@ -2294,8 +2294,21 @@ int rala_hip_set_overlaps(rala_hip_ctx* ctx, const rala_hip_overlaps* o, uint64_
     return RALA_HIP_OK;
 }
 
+static int initialize_stages(rala_hip_ctx* ctx);
 int rala_hip_initialize(rala_hip_ctx* ctx) {
     if (!ctx) return RALA_HIP_EINVAL;
+    const int rc = initialize_stages(ctx);
+    // RALA_HIP_MEM_HOST_ASYNC: the host's columns are the caller's again when this call returns - however it returns
+    if (ctx->upload_pending && ctx->copy) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->copy);
+        // (a call that left before it had queued the copies has uploaded nothing: the next reader does, flush_upload)
+        if (ctx->upload_queued) ctx->upload_pending = false;
+    }
+    ctx->upload_queued = false;
+    return rc;
+}
+static int initialize_stages(rala_hip_ctx* ctx) {
     if (ctx->n_reads == 0) return fail(ctx, RALA_HIP_EINVAL, "no reads set");
     if (!ctx->inputs_set) return fail(ctx, RALA_HIP_EINVAL, "no overlaps or bound tuples set");
     HIPCHECK(hipSetDevice(ctx->device));
@@ -2328,6 +2341,7 @@ int rala_hip_initialize(rala_hip_ctx* ctx) {
         HIPCHECK(up(6));
         HIPCHECK(hipMemcpyAsync(ctx->d_ovl_strand.p, ctx->up_strand, ctx->n_ovl, hipMemcpyHostToDevice, ctx->copy));
         HIPCHECK(hipEventRecord(ctx->ev_up[3], ctx->copy));      // everything
+        ctx->upload_queued = true;
     }
     auto wait_for_all_columns = [&]() -> int {
         HIPCHECK(hipStreamWaitEvent(s, ctx->ev_up[3], 0));
