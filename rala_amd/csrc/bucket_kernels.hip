@@ -143,9 +143,13 @@ __device__ __forceinline__ void load4_ids(const uint32_t* p, uint64_t i0, uint64
 }
 constexpr uint32_t kCountVec = 2;               // groups of four overlaps per thread and trip
 constexpr uint32_t kFlagStage = 512;            // marks a workgroup stages per trip
+// kShard: the sender's count of a sharded run (shard_count_kernel's bins: both sides of an overlap, by owner and the owner's
+// group) with the same first pass of duplicate removal on the way; n_groups is then world * groups.
+template <bool kShard>
 __global__ __launch_bounds__(kBlockC) void group_count_dedupe_kernel(OvlSoA o, uint32_t n_reads, uint32_t n_groups, uint32_t* group_count,
                                                                      uint8_t* __restrict__ suspect, uint8_t* __restrict__ valid, uint32_t* list_pos,
-                                                                     uint32_t* list_query, uint32_t list_cap, uint32_t* list_count) {
+                                                                     uint32_t* list_query, uint32_t list_cap, uint32_t* list_count,
+                                                                     uint32_t world, uint32_t groups) {
     extern __shared__ uint32_t s_hist[];
     __shared__ uint32_t s_fpos[kFlagStage], s_fq[kFlagStage], s_fcnt, s_fbase;
     for (uint32_t g = threadIdx.x; g < n_groups; g += kBlockC) s_hist[g] = 0;
@@ -179,7 +183,14 @@ __global__ __launch_bounds__(kBlockC) void group_count_dedupe_kernel(OvlSoA o, u
                 const uint32_t x = a[u][e], y = b[u][e];
                 const bool in = i0 + e < o.n;
                 const bool ok = in && x < n_reads && y < n_reads;
-                if (ok) atomicAdd(&s_hist[y >> kGroupShift], 1u);
+                if (ok) {
+                    if constexpr (kShard) {
+                        atomicAdd(&s_hist[(x % world) * groups + ((x / world) >> kGroupShift)], 1u);
+                        atomicAdd(&s_hist[(y % world) * groups + ((y / world) >> kGroupShift)], 1u);
+                    } else {
+                        atomicAdd(&s_hist[y >> kGroupShift], 1u);
+                    }
+                }
                 if (in && have_prev) {
                     const bool pok = pa < n_reads && pb < n_reads;
                     if (ok && pok) {
@@ -733,7 +744,7 @@ struct PartitionBuffers {
 hipError_t count_attribute(size_t lds_count) {
     if (lds_count + 8192 > 64 * 1024) { // (per launch: the attribute belongs to the function on the current device; 8 KB: the kernels' static LDS)
         hipError_t e = hipFuncSetAttribute((const void*)group_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_count);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)group_count_dedupe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_count);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)group_count_dedupe_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_count);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)group_count_records_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_count);
         return e;
     }
@@ -786,9 +797,9 @@ hipError_t launch_bucket_partitioned(const OvlSoA& o, uint32_t n_reads, uint32_t
     // (two workgroups per compute unit where their histograms fit side by side)
     const uint32_t count_groups = (workgroups ? workgroups : 256u) * (2 * lds_count <= 150u * 1024u ? 2u : 1u);
     if (dedupe) {
-        hipLaunchKernelGGL(group_count_dedupe_kernel, dim3(std::min<uint32_t>(count_groups, chunks)), dim3(kBlockC), lds_count, s, o,
+        hipLaunchKernelGGL(group_count_dedupe_kernel<false>, dim3(std::min<uint32_t>(count_groups, chunks)), dim3(kBlockC), lds_count, s, o,
                            n_reads, B.n_part * kGroupsPerPart, B.group_count, dedupe->suspect, dedupe->valid, dedupe->list_pos,
-                           dedupe->list_query, dedupe->list_cap, dedupe->list_count);
+                           dedupe->list_query, dedupe->list_cap, dedupe->list_count, 1u, 0u);
         if (dedupe->counted) {
             e = hipEventRecord(dedupe->counted, s);
             if (e != hipSuccess) return e;
@@ -873,21 +884,35 @@ size_t shard_tile_slots(const ShardGeometry& g, uint64_t n_records) { return (si
 // group_count: world * groups words (cleared here, through `fills`); part_cursor: world * n_part words; send:
 // shard_send_words(); send_words: world words (the blocks' lengths, for the host)
 hipError_t launch_shard_emit(const OvlSoA& o, uint32_t n_reads, const ShardGeometry& g, uint32_t* group_count, uint32_t* part_cursor,
-                             uint64_t* send, uint32_t* send_words, uint32_t workgroups, FillList& fills, hipStream_t s) {
+                             uint64_t* send, uint32_t* send_words, uint32_t workgroups, FillList& fills, hipStream_t s,
+                             const BucketDedupe* dedupe) {
     const uint32_t n_bins = g.world * g.groups;
     fills.add(group_count, 0, (size_t)n_bins * 4);
+    if (dedupe) fills.add(dedupe->suspect, 0, n_reads);
     hipError_t e = fills.launch(s);
     if (e != hipSuccess) return e;
     const size_t lds_count = (size_t)n_bins * 4;
-    if (lds_count > 64 * 1024) {
+    if (lds_count + 8192 > 64 * 1024) {
         e = hipFuncSetAttribute((const void*)shard_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_count);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)group_count_dedupe_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_count);
         if (e != hipSuccess) return e;
     }
     if (o.n) {
         const uint32_t chunks = (uint32_t)((o.n + kBlockC * kCountPer - 1) / (kBlockC * kCountPer));
         const uint32_t count_groups = (workgroups ? workgroups : 256u) * (2 * lds_count <= 150u * 1024u ? 2u : 1u);
-        hipLaunchKernelGGL(shard_count_kernel, dim3(std::min<uint32_t>(count_groups, chunks)), dim3(kBlockC), lds_count, s, o, n_reads,
-                           g.world, g.groups, n_bins, group_count);
+        if (dedupe) {
+            // (the sender's count with duplicate removal's first pass on the way, as the single GPU's counting pass has it)
+            hipLaunchKernelGGL(group_count_dedupe_kernel<true>, dim3(std::min<uint32_t>(count_groups, chunks)), dim3(kBlockC), lds_count, s, o,
+                               n_reads, n_bins, group_count, dedupe->suspect, dedupe->valid, dedupe->list_pos, dedupe->list_query,
+                               dedupe->list_cap, dedupe->list_count, g.world, g.groups);
+            if (dedupe->counted) {
+                e = hipEventRecord(dedupe->counted, s);
+                if (e != hipSuccess) return e;
+            }
+        } else {
+            hipLaunchKernelGGL(shard_count_kernel, dim3(std::min<uint32_t>(count_groups, chunks)), dim3(kBlockC), lds_count, s, o, n_reads,
+                               g.world, g.groups, n_bins, group_count);
+        }
     }
     hipLaunchKernelGGL(shard_send_layout_kernel, dim3(1), dim3(1024), 0, s, (const uint32_t*)group_count, g, send, part_cursor, send_words);
     if (o.n) {

@@ -451,7 +451,8 @@ size_t shard_group_words(const ShardGeometry& g);
 // sender: block after block - [header][records {local read & 4095 : 12 | begin : 26 | end : 26}, partition by partition];
 // send_words[p] (device) = 8-byte words of block p
 hipError_t launch_shard_emit(const OvlSoA& o, uint32_t n_reads, const ShardGeometry& g, uint32_t* group_count, uint32_t* part_cursor,
-                             uint64_t* send, uint32_t* send_words, uint32_t workgroups, FillList& fills, hipStream_t s);
+                             uint64_t* send, uint32_t* send_words, uint32_t workgroups, FillList& fills, hipStream_t s,
+                             const BucketDedupe* dedupe = nullptr);      // (dedupe: as launch_bucket_partitioned's)
 // owner: the blocks of all senders -> ev_off[n_reads_local + 1], ev (bounds drawn in by 15, graph.cpp:317-324)
 hipError_t launch_bucket_from_blocks(const uint64_t* base, const uint64_t* base_self, const ShardBlocks& blocks, const ShardGeometry& g, uint32_t n_reads_local,
                                      uint64_t n_records, uint32_t* group, uint32_t* tiles, uint64_t* rec2, uint32_t* ev_off, uint32_t* ev,

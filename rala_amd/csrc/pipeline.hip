@@ -2005,7 +2005,18 @@ int rala_hip::shard_emit(rala_hip_ctx* ctx, const ShardGeometry& g, uint64_t* se
     { const int rcu = flush_upload(ctx); if (rcu != RALA_HIP_OK) return rcu; }
     hipStream_t s = ctx->stream;
     const uint32_t n_reads = (uint32_t)ctx->n_reads;
-    if (ctx->use_side_stream) {
+    // duplicate removal: its first pass inside the count where that kernel can take it (the id columns on 16-byte boundaries),
+    // the marked runs' fix on the side stream beside the scatter - as on one GPU (rala_hip_initialize); otherwise the two
+    // kernels of its own beside the whole emit
+    const bool counted = ctx->use_side_stream && bucket_count_can_dedupe(ctx->ovl, ctx->d_valid.p);
+    constexpr uint32_t kMarks = 1u << 20;
+    BucketDedupe bd = {};
+    if (counted) {
+        HIPCHECK(ctx->d_dedupe_list.ensure(2 * (size_t)kMarks + 4));
+        HIPCHECK(hipMemsetAsync(ctx->d_dedupe_list.p + 2 * (size_t)kMarks, 0, 4, s));
+        bd.suspect = ctx->d_suspect.p; bd.valid = ctx->d_valid.p; bd.list_pos = ctx->d_dedupe_list.p; bd.list_query = ctx->d_dedupe_list.p + kMarks;
+        bd.list_cap = kMarks; bd.list_count = ctx->d_dedupe_list.p + 2 * (size_t)kMarks; bd.counted = ctx->ev[0];
+    } else if (ctx->use_side_stream) {
         HIPCHECK(hipEventRecord(ctx->ev[0], s));
         HIPCHECK(hipStreamWaitEvent(ctx->side, ctx->ev[0], 0));
         launch_dedupe(ctx->ovl, n_reads, ctx->d_suspect.p, ctx->d_valid.p, ctx->side);
@@ -2020,7 +2031,13 @@ int rala_hip::shard_emit(rala_hip_ctx* ctx, const ShardGeometry& g, uint64_t* se
     HIPCHECK(ctx->d_shard_words.ensure(64));
     FillList fills;
     HIPCHECK(launch_shard_emit(ctx->ovl, n_reads, g, ctx->d_shard_group.p, ctx->d_shard_part.p, send, ctx->d_shard_words.p,
-                               ctx->n_compute_units, fills, s));
+                               ctx->n_compute_units, fills, s, counted ? &bd : nullptr));
+    if (counted && ctx->n_ovl) {
+        HIPCHECK(hipStreamWaitEvent(ctx->side, ctx->ev[0], 0));
+        launch_dedupe_fix(ctx->ovl, n_reads, bd, ctx->side);
+        HIPCHECK(hipEventRecord(ctx->ev[1], ctx->side));
+        ctx->dedupe_pending = true;
+    }
     uint32_t h[64];
     HIPCHECK(d2h_small(ctx, h, ctx->d_shard_words.p, g.world * 4, s));
     HIPCHECK(stream_sync(ctx, s));
@@ -2105,8 +2122,6 @@ int rala_hip_create(int device, rala_hip_ctx** out) {
               hipStreamCreateWithPriority(&ctx->side, hipStreamDefault, prio_greatest) == hipSuccess &&
               hipStreamCreate(&ctx->aux) == hipSuccess;
     for (auto& e : ctx->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
-    ok = ok && hipStreamCreate(&ctx->copy) == hipSuccess;
-    for (auto& e : ctx->ev_up) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
     ok = ok && ctx->d_small.ensure(16) == hipSuccess;
     if (!ok) {                                  // (rala_hip_destroy releases whatever was created)
         rala_hip_destroy(ctx);
@@ -2248,8 +2263,15 @@ int rala_hip_set_overlaps(rala_hip_ctx* ctx, const rala_hip_overlaps* o, uint64_
     HIPCHECK(hipSetDevice(ctx->device));
     HIPCHECK(hipStreamSynchronize(ctx->side));          // a failed call may have left work there
     HIPCHECK(hipStreamSynchronize(ctx->aux));
-    HIPCHECK(hipStreamSynchronize(ctx->copy));
+    if (ctx->copy) HIPCHECK(hipStreamSynchronize(ctx->copy));
     ctx->upload_pending = false;
+    if (mem == RALA_HIP_MEM_HOST_ASYNC && !ctx->copy) {
+        // (made when first asked for: a process has few hardware queues - four by default - and its streams share them; a
+        // stream that is not used must not push a context's main and aux streams onto one queue.  It did, in the sharded
+        // runner's owner contexts: their small pile kernels ran in front of the big one instead of beside it, +0.13 ms at C3)
+        HIPCHECK(hipStreamCreate(&ctx->copy));
+        for (auto& e : ctx->ev_up) HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
     ctx->n_ovl = n;
     const uint32_t* src[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     if (n) {

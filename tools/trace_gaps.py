@@ -13,7 +13,7 @@ rows = []
 for row in csv.DictReader(open(sys.argv[1])):
     rows.append((int(row["Start_Timestamp"]), int(row["End_Timestamp"]), row["Kernel_Name"]))
 rows.sort()
-starts = [i for i, r in enumerate(rows) if "bucket_fixed_kernel" in r[2] or "group_count_kernel" in r[2] or "group_count_dedupe_kernel" in r[2]]
+starts = [i for i, r in enumerate(rows) if "bucket_fixed_kernel" in r[2] or "group_count_kernel" in r[2] or "group_count_dedupe_kernel" in r[2] or "shard_count_kernel" in r[2]]
 if len(starts) < 2:
     sys.exit("fewer than two steps in the trace")
 a, b = starts[-2], starts[-1]
