@@ -36,8 +36,23 @@ sys.path.insert(0, ROOT)
 # A process has four hardware queues by default and its streams share them; a rank of a sharded run has two contexts with
 # three streams each beside RCCL's, and kernels meant to run beside each other ended up behind each other (the owner's small
 # pile kernels in front of the big one: 0.1 - 0.3 ms per C3 step, tools/gpurun/r5_queues.sh).  The runtime reads this when it
-# starts - before anything imports torch.  (The single-GPU step has four streams and is the same either way.)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# starts - before anything imports torch.  (The single-GPU step has four streams: it stays on the runtime's default, as profiled.)
+def _several_ranks(argv):
+    n = 1
+    for k, a in enumerate(argv):
+        if a == "--gpus" and k + 1 < len(argv):
+            n = argv[k + 1]
+        elif a.startswith("--gpus="):
+            n = a.split("=", 1)[1]
+    try:
+        n = int(n)
+    except ValueError:
+        n = 1
+    return n > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("RALA_FORCE_SHARDED")
+
+
+if _several_ranks(sys.argv[1:]):
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np  # noqa: E402
 
