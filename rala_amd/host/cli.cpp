@@ -170,14 +170,15 @@ int run(const Settings& st) {
 }  // namespace
 
 int main(int argc, char** argv) {
-    // (read by the HIP runtime when it starts: eight hardware queues instead of four - the streams of a rank's two contexts
-    // and RCCL's share them, and with four some kernels meant to run beside each other run behind each other)
-    setenv("GPU_MAX_HW_QUEUES", "8", 0);
     Settings st;
     switch (parse(argc, argv, st)) {
         case Parsed::kDone: return 0;
         case Parsed::kBad: return 1;
         case Parsed::kRun: break;
     }
+    // (read by the HIP runtime when it starts - nothing has touched the device yet: eight hardware queues instead of four for a
+    // run over several GPUs - the streams of a rank's two contexts and RCCL's share them, and with four some kernels meant to run
+    // beside each other run behind each other)
+    if (st.gpus > 1) setenv("GPU_MAX_HW_QUEUES", "8", 0);
     return run(st);
 }
