@@ -623,12 +623,21 @@ __global__ __launch_bounds__(kBlock) void classify_kernel(OvlSoA o, uint32_t n_r
     };
     {
         Half H0, H1;
+#ifdef RALA_CLASSIFY_TWO_TRIPS      // (measurement: everything requested up front)
+        load_half(H0, 0);
+        load_half(H1, kHalf);
+        look_half(H0);
+        look_half(H1);
+        compute_half(H0, 0);
+        compute_half(H1, kHalf);
+#else
         load_half(H0, 0);
         look_half(H0);
         load_half(H1, kHalf);
         compute_half(H0, 0);
         look_half(H1);
         compute_half(H1, kHalf);
+#endif
     }
     __syncthreads();
     if (threadIdx.x == 0) s_base = s_cnt ? atomicAdd(kl.count, s_cnt) : 0u;
