@@ -857,8 +857,9 @@ __global__ __launch_bounds__(kBlock) void survivor_masks_kernel(OvlSoA o, uint32
         const uint32_t u = e >> 6, l = e & 63u;
         const uint64_t i = (uint64_t)blockIdx.x * kClassifyChunk + u * kBlock + wave * 64u + l;
         const uint32_t ia = o.a_id[i], ib = o.b_id[i];
-        const uint32_t da = death[ia], db = death[ib];
         const uint32_t at = (uint32_t)(o.base + i) + 1u;
+#ifdef RALA_CANDIDATES_STEP_BY_STEP     // (measurement: deaths -> records -> coordinates, a round trip each)
+        const uint32_t da = death[ia], db = death[ib];
         if (!(da >= at && db >= at)) continue;
         const bool both = da == kInf && db == kInf;
         CRec<kSmall> ra, rb;
@@ -866,6 +867,21 @@ __global__ __launch_bounds__(kBlock) void survivor_masks_kernel(OvlSoA o, uint32
         Coords c;
         uint32_t st, t, kills;
         if (!classify_one<kSmall>(o, i, ra, rb, c, st, t, kills)) continue;
+#else
+        // (everything a candidate may need behind its ids in ONE round trip - deaths, records, coordinates, strand; the empty asm
+        // keeps the compiler from sinking the loads behind the tests that would make them round trips of their own)
+        uint32_t da = death[ia], db = death[ib];
+        CRec<kSmall> ra, rb;
+        ra.w = crec[ia]; rb.w = crec[ib];
+        Coords c;
+        c.a_begin = o.a_begin[i]; c.a_end = o.a_end[i]; c.b_begin = o.b_begin[i]; c.b_end = o.b_end[i];
+        c.length = 0;
+        uint32_t st = o.strand[i], t = 0, kills = 0;
+        asm volatile("" : "+v"(da), "+v"(db), "+v"(c.a_begin), "+v"(c.a_end), "+v"(c.b_begin), "+v"(c.b_end), "+v"(st));
+        if (!(da >= at && db >= at)) continue;
+        const bool both = da == kInf && db == kInf;
+        if (!classify_loaded<kSmall>(c, st, ra, rb, t, kills)) continue;
+#endif
         if (ra.hills() | rb.hills()) {
             const uint4 xa = rec[ia], xb = rec[ib];
             const uint32_t nha = rec_hills(xa), nhb = rec_hills(xb);
@@ -978,7 +994,16 @@ __global__ __launch_bounds__(kBlock) void gather_kernel(OvlSoA o, const uint64_t
         ra.w = crec[a]; rb.w = crec[b];
         Coords c;
         uint32_t st = 0, t = 0, kills = 0;
+#ifdef RALA_CANDIDATES_STEP_BY_STEP
         (void)classify_one<kSmall>(o, i, ra, rb, c, st, t, kills);
+#else
+        // (the coordinates with the records, not behind them)
+        c.a_begin = o.a_begin[i]; c.a_end = o.a_end[i]; c.b_begin = o.b_begin[i]; c.b_end = o.b_end[i];
+        c.length = 0;
+        st = o.strand[i];
+        asm volatile("" : "+v"(c.a_begin), "+v"(c.a_end), "+v"(c.b_begin), "+v"(c.b_end), "+v"(st));
+        (void)classify_loaded<kSmall>(c, st, ra, rb, t, kills);
+#endif
         out.src[p] = (uint32_t)(o.base + i);
         out.a_id[p] = a; out.b_id[p] = b;
         out.a_begin[p] = c.a_begin; out.a_end[p] = c.a_end;
