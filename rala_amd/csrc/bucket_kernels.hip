@@ -482,7 +482,16 @@ __global__ __launch_bounds__(kBlockP) void final_kernel(const uint64_t* __restri
     if (threadIdx.x < kGroupReads) s_cnt[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t lo = group_base[g], hi = group_base[g + 1];
-    for (uint32_t j = lo + threadIdx.x; j < hi; j += kBlockP) atomicAdd(&s_cnt[rec_key(rec2[j]) & (kGroupReads - 1u)], 1u);
+    // (the counting pass keeps what the first tile below will want - the same records by the same threads: a group's 6 500 records
+    // are two tiles, and the first one need not come from the L2 a second time)
+    uint64_t first[kPer];
+#pragma unroll
+    for (uint32_t u = 0; u < kPer; ++u) {
+        const uint32_t j = lo + u * kBlockP + threadIdx.x;
+        first[u] = j < hi ? rec2[j] : 0ull;
+        if (j < hi) atomicAdd(&s_cnt[rec_key(first[u]) & (kGroupReads - 1u)], 1u);
+    }
+    for (uint32_t j = lo + kTile + threadIdx.x; j < hi; j += kBlockP) atomicAdd(&s_cnt[rec_key(rec2[j]) & (kGroupReads - 1u)], 1u);
     __syncthreads();
     {
         // the reads' rows: query-side pairs, then target-side pairs; offsets in events (two per pair)
@@ -507,7 +516,7 @@ __global__ __launch_bounds__(kBlockP) void final_kernel(const uint64_t* __restri
         for (uint32_t u = 0; u < kPer; ++u) {
             const uint32_t j = j0 + u * kBlockP + threadIdx.x;
             in[u] = j < hi;
-            const uint64_t rec = in[u] ? rec2[j] : 0ull;
+            const uint64_t rec = j0 == lo ? first[u] : in[u] ? rec2[j] : 0ull;
             const uint2 e = rec_events(rec, shrink);
             pair[u] = (uint64_t)e.x | (uint64_t)e.y << 32;
             bin[u] = rec_key(rec) & (kGroupReads - 1u);
