@@ -392,6 +392,51 @@ def test_unordered_runs_duplicates_unresolved(hip_ctx_factory, n, g, seed):
     parity.check_tr(ctx, st)
 
 
+def _queries_in_two_runs(ds, seed):
+    """same overlaps, but one query in twelve has the second half of its run moved to the end of the file: a file that is NOT
+    grouped by query (the reference takes runs as they come: duplicate removal per run, every bound into its pile)"""
+    from rala_amd.synth import Overlaps, FIELDS
+
+    rng = np.random.default_rng(seed)
+    ov = ds.overlaps
+    a = ov.a_id.astype(np.int64)
+    n = len(a)
+    start = np.r_[0, np.nonzero(a[1:] != a[:-1])[0] + 1]
+    end = np.r_[start[1:], n]
+    moved = np.zeros(n, dtype=bool)
+    for s0, e0 in zip(start, end):
+        if e0 - s0 >= 4 and rng.random() < 1.0 / 12:
+            moved[(s0 + e0) // 2:e0] = True
+    idx = np.r_[np.nonzero(~moved)[0], np.nonzero(moved)[0]]
+    assert moved.sum() > 0
+
+    class _D:
+        pass
+    d = _D()
+    d.overlaps = Overlaps(strand=ov.strand[idx].copy(), **{f: getattr(ov, f)[idx].copy() for f in FIELDS})
+    d.read_len = ds.read_len
+    d.n_reads = ds.n_reads
+    return d
+
+
+@pytest.mark.parametrize("partitioned", [1, 0])
+@pytest.mark.parametrize("n,g,seed", [(3000, 600_000, 21), (600, 60_000, 9)])
+def test_queries_in_two_runs(hip_ctx_factory, n, g, seed, partitioned):
+    """a file that is not grouped by query: the bucketing's last kernel may not copy a read's query side from its run of the
+    file (there are two), the pass over all overlaps writes it (and the other bucketing path never looked at runs)"""
+    ds = _queries_in_two_runs(Dataset(n, g, seed), seed)
+    st = parity.oracle_stages(ds)
+    ctx = hip_ctx_factory()
+    ctx.set_option("use_partitioned_buckets", partitioned)
+    ctx.set_reads(ds.read_len)
+    ctx.set_overlaps(ds.overlaps)
+    ctx.initialize()
+    parity.check_initialize(ctx, st, ds)
+    ctx.construct()
+    parity.check_construct(ctx, st)
+    parity.check_tr(ctx, st)
+
+
 def test_degenerate_inputs(hip_ctx_factory):
     from rala_amd import hip
     from rala_amd.synth import Overlaps, FIELDS
