@@ -57,7 +57,7 @@ if _several_ranks(sys.argv[1:]):
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md)
-WRITE_ONLY_GBS = 5100.0 # what a kernel that only writes the same rows reaches (tools/fill_bench.hip)
+ACHIEVABLE_GBS = 6300.0 # what streaming kernels reach of it on this part (MI355X_MICROARCH.md; the builder's own row fills: 5.0 - 6.5 TB/s, profiles/README.md)
 
 WORKLOADS = {
     "c1": "1k reads / 50k overlaps (BASELINE configs[0])",
@@ -322,6 +322,93 @@ def measure_traffic(workload):
     return (2.0 * kb["FETCH_SIZE"] + kb["WRITE_SIZE"]) * 1024.0
 
 
+def broadcast_flag(flag):
+    """rank 0's verdict on every rank (one process per GPU)"""
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32)
+    dist.broadcast(t, src=0)
+    return bool(t.item())
+
+
+RESULT_STAGES = ("valid", "piles2", "ov", "int", "nodes", "edges", "n_overlaps_kept", "n_internals_kept", "n_edges", "n_tr", "rows2", "rows2_sum")
+RESULT_STAGES_SENS = ("valid", "piles3", "ov_sens", "rep", "nodes", "edges", "n_overlaps_kept_sens", "n_repeat_hills", "n_edges", "n_tr", "rows3", "rows3_sum")
+
+
+def _dg(*arrays):
+    """the digest of tests/golden/make_fullsize_digests.py"""
+    import hashlib
+    h = hashlib.sha256()
+    for a in arrays:
+        a = np.ascontiguousarray(a)
+        h.update(str(a.dtype).encode()); h.update(str(a.shape).encode()); h.update(a.tobytes())
+    return h.hexdigest()
+
+
+def replicated_digests(ctx, n_tr, with_sens):
+    """what every rank of a sharded run holds a copy of (and a single context holds once), behind the step's last call: read
+    state, kept overlaps, graph with the transitive marks - as the digests tests/golden/fullsize_*.json keep of the reference
+    objects' results"""
+    out = {"n_tr": int(n_tr)}
+    p = ctx.piles()
+    lists = ("src", "a_begin", "a_end", "b_begin", "b_end", "length", "type")
+    ov = ctx.overlap_list(0)
+    if with_sens:
+        out["piles3"] = _dg(*[p[k] for k in ("begin", "end", "median", "p10", "alive")])
+        offs, pairs, flags = ctx.intervals(2)
+        out["rep"] = _dg(offs.astype(np.uint64), pairs.astype(np.uint32), flags.astype(np.uint8))
+        out["n_repeat_hills"] = int(len(pairs))
+        out["n_overlaps_kept_sens"] = int(len(ov["src"]))
+        out["ov_sens"] = _dg(*[np.asarray(ov[k]).astype(np.uint32) for k in lists])
+    else:
+        out["piles2"] = _dg(p["begin"], p["end"], p["alive"])
+        it = ctx.overlap_list(1)
+        out["n_overlaps_kept"], out["n_internals_kept"] = int(len(ov["src"])), int(len(it["src"]))
+        out["ov"] = _dg(*[np.asarray(ov[k]).astype(np.uint32) for k in lists])
+        out["int"] = _dg(*[np.asarray(it[k]).astype(np.uint32) for k in lists])
+    g = ctx.graph()
+    out["nodes"] = _dg(g["node_read"].astype(np.uint32))
+    out["n_edges"] = int(len(g["src"]))
+    out["edges"] = _dg(g["src"].astype(np.uint32), g["dst"].astype(np.uint32), g["len"].astype(np.uint32), g["marked"].astype(np.uint8))
+    return out
+
+
+def result_check(data_name, with_sens, first, last, valid, row_fnv, row_sum, ranks):
+    """The timed path's RESULT against the committed digests of the reference objects' result on the same synthetic input
+    (tests/golden/fullsize_<workload>[_sens].json, made by tests/golden/make_fullsize_digests.py): `first` / `last` =
+    replicated_digests of rank 0 and of the last rank, `valid` = the validity bytes of all overlaps in file order (the ranks'
+    slices behind each other), row_fnv / row_sum = the checksums of EVERY pile row from their owners, in read order.
+    -> (the line's "result_check" member, ok).  Without a digest file for the workload (C5: no host here holds its reference
+    objects) what is left to check is that the ranks agree."""
+    path = os.path.join("tests", "golden", "fullsize_%s%s.json" % (data_name, "_sens" if with_sens else ""))
+    got = dict(first)
+    got["valid"] = _dg(np.packbits(valid))
+    suffix = "3" if with_sens else "2"
+    got["rows" + suffix] = _dg(row_fnv)
+    got["rows" + suffix + "_sum"] = _dg(row_sum)
+    if os.environ.get("RALA_BENCH_FAKE_WRONG_RESULT") == "1":       # (tests: a result that is not the reference's)
+        got["edges"] = got["edges"][::-1]
+    ranks_agree = all(first[k] == last[k] for k in first)
+    out = {"digests": None, "ranks_checked": ranks, "ranks_agree": ranks_agree, "stages_equal": [], "stages_differ": [], "ok": None}
+    want = None
+    try:
+        with open(os.path.join(ROOT, path)) as f:
+            want = json.load(f)
+    except OSError:
+        pass
+    if want is not None:
+        out["digests"] = path
+        out["backend"] = want.get("backend")
+        for k in (RESULT_STAGES_SENS if with_sens else RESULT_STAGES):
+            if k not in want:
+                continue                    # (a digest file older than the stage)
+            (out["stages_equal"] if got.get(k) == want[k] else out["stages_differ"]).append(k)
+        out["ok"] = bool(ranks_agree and not out["stages_differ"] and len(out["stages_equal"]) >= 8)
+    elif not ranks_agree:
+        out["ok"] = False
+    return out, out["ok"] is not False
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -332,6 +419,8 @@ def main():
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end-from-PAF figure (it writes the data set as text first)")
     ap.add_argument("--no-traffic", action="store_true",
                     help="do not measure roofline.traffic here (two one-step child runs under rocprofv3 --pmc); replay profiles/pmc_latest.json")
+    ap.add_argument("--no-result-check", action="store_true",
+                    help="skip the comparison of the step's result with the committed digests (measurement scripts)")
     ap.add_argument("--transport", default=os.environ.get("RALA_COMM", "rccl"), choices=("rccl", "local"),
                     help="ranks as threads only: RCCL (default) or the in-process transport (peer copies)")
     ap.add_argument("--devices", default=os.environ.get("RALA_GPU_DEVICES", ""),
@@ -516,6 +605,42 @@ def main():
         from rala_amd import multi as _m
         dt = _m.max_over_ranks(dt)
 
+    # ---- the result of the timed path against the committed digests (outside the timed region) ----
+    check, check_ok = None, True
+    if not args.no_result_check:
+        if use_dist:
+            mine = replicated_digests(runner.mg.context(), n_tr, with_sens) if rank in (0, world - 1) else None
+            f, sm, _ = runner.mg.pile_row_digests()
+            box = [None] * world if rank == 0 else None
+            dist.gather_object((mine, runner.mg.context().valid(), f, sm), box, dst=0)
+            if rank == 0:
+                fnv = np.zeros(ds.n_reads, dtype=np.uint64); tot = np.zeros(ds.n_reads, dtype=np.uint64)
+                for k in range(world):
+                    fnv[k::world], tot[k::world] = box[k][2], box[k][3]
+                check, check_ok = result_check(data_name, with_sens, box[0][0], box[world - 1][0], np.concatenate([b[1] for b in box]),
+                                               fnv, tot, [0, world - 1])
+            check_ok = bool(broadcast_flag(check_ok)) if world > 1 else check_ok
+        elif use_threads:
+            first = replicated_digests(runner.ranks[0].context(), n_tr, with_sens)
+            last = replicated_digests(runner.ranks[world - 1].context(), n_tr, with_sens) if world > 1 else first
+            fnv = np.zeros(ds.n_reads, dtype=np.uint64); tot = np.zeros(ds.n_reads, dtype=np.uint64)
+            for k, r in enumerate(runner.ranks):
+                fnv[k::world], tot[k::world], _ = r.pile_row_digests()
+            check, check_ok = result_check(data_name, with_sens, first, last, np.concatenate([r.context().valid() for r in runner.ranks]),
+                                           fnv, tot, [0, world - 1])
+        else:
+            first = replicated_digests(ctx, n_tr, with_sens)
+            fnv, tot, _ = ctx.pile_row_digests()
+            check, check_ok = result_check(data_name, with_sens, first, first, ctx.valid(), fnv, tot, [0])
+        if not check_ok:
+            if rank == 0:
+                log("[bench] RESULT CHECK FAILED: %s" % json.dumps(check))
+                log("[bench] the timed path did not produce the reference's result: no figure is printed")
+            sys.stderr.flush()
+            if use_threads:
+                os._exit(4)
+            raise SystemExit(4)
+
     if rank == 0:
         steps = max(1, args.steps)
         ms = 1000.0 * dt / steps
@@ -575,13 +700,15 @@ def main():
                          "stage_frac": whole["frac"], "stage_achieved": whole["achieved"], "stage_ms": whole["ms"],
                          "stage_algorithmic_bytes": whole["algorithmic_bytes"],
                          "traffic": traffic, "traffic_source": "REPLAYED from profiles/pmc_latest.json (rocprofv3 --pmc passes of an earlier run of this command; not re-measured here)" if traffic is not None else None,
-                         "frac_of_write_only_rate": achieved / WRITE_ONLY_GBS,
+                         "frac_of_achievable": achieved / ACHIEVABLE_GBS, "achievable": ACHIEVABLE_GBS,
                          "algorithmic_bytes": pile_bytes, "kernel_ms": pile_ms,
                          "stage": whole},
             "stage_ms": stage,
         }
         if sens_info is not None:
             out["sensitive_pass"] = sens_info
+        if check is not None:
+            out["result_check"] = check
         if not sharded:
             ctx.close()                 # the end-to-end run creates a context of its own: give the memory back first
         # (the full run only - what the driver launches; the quick runs of tests and measurement scripts pass --no-cpu-baseline -

@@ -100,6 +100,8 @@ const char* rala_hip_last_error(const rala_hip_ctx* ctx);
  * bounds once, by (owner, partition of the owner's reads), and the owners start at the second level of the partitioned
  * bucketing; 0: bounds grouped by owner only, bucketed by the owner from the start), "use_bound_records" (default 1; sharded
  * runs without the former: 0 ships two bound tuples per overlap side instead of one bound record),
+ * "debug_dedupe_list_cap" (tests: the list of the runs duplicate removal's counting pass marks holds this many marks, 0 = the
+ * default 2^20; a list that does not hold them all is given up and the pass over all overlaps does the work),
  * "debug_pile_stop_after" (diagnostics: leave the run-space pile kernel after phase k, 99 = all;
  * 100 * m + k: the same without the row stores (m = 1), tools/phase_probe.py) */
 int rala_hip_set_option(rala_hip_ctx* ctx, const char* key, int64_t value);
@@ -311,6 +313,9 @@ rala_hip_ctx* rala_hip_mg_context(rala_hip_mg* mg);
 /* the context of the reads this rank owns (local read j = read j * P + rank): stage timings of the pile kernels */
 rala_hip_ctx* rala_hip_mg_owner_context(rala_hip_mg* mg);
 int rala_hip_mg_get_pile_data(rala_hip_mg* mg, uint64_t read, uint16_t* data);
+/* rala_hip_get_pile_row_digests (below) of the rows this rank owns: n_owned = the reads r with r % P == rank, entry j = read
+ * j * P + rank, under the final valid regions */
+int rala_hip_mg_get_pile_row_digests(rala_hip_mg* mg, uint64_t* fnv, uint64_t* inside, uint64_t* outside);
 int rala_hip_mg_get_timings(rala_hip_mg* mg, rala_hip_mg_timings* out);
 
 /* Force-directed layout of one connected component, the O(n^2) part of Graph::postprocess
@@ -332,6 +337,13 @@ int rala_hip_get_piles(rala_hip_ctx* ctx, uint32_t* begin, uint32_t* end, uint16
 /* Pile::data() of one read (src/pile.hpp:53): read_len[read] values.  Contents are
  * defined for reads that passed find_valid_region. */
 int rala_hip_get_pile_data(rala_hip_ctx* ctx, uint64_t read, uint16_t* data);
+/* Checksums of EVERY pile row where it lies in device memory (Pile::data() of all reads is 20 GB at 1 M reads: nothing a
+ * caller wants copied), n_reads entries each, any pointer may be NULL: fnv[r] = FNV-1a-64 over the bytes of Pile::data() of
+ * read r (src/pile.hpp:53: uint16 values, low byte first, zero outside the valid region as Pile::shrink leaves them,
+ * src/pile.cpp:311-318) - what rala_hip_get_pile_data would return, hashed on the device; inside[r] = the sum of the row over
+ * [begin, end); outside[r] = the sum of the values STORED outside it (zero right after rala_hip_initialize; later stages narrow a
+ * region without rewriting its row).  A filtered read answers 0 to all three. */
+int rala_hip_get_pile_row_digests(rala_hip_ctx* ctx, uint64_t* fnv, uint64_t* inside, uint64_t* outside);
 /* Pits / hills / repeat hills of all reads as CSR: offsets[n_reads + 1], then pairs
  * (first, second) and one aux word per interval (pit: min coverage inside; hill:
  * spanning-overlap count; repeat hill: bridged flag).  kind: 0 pits, 1 hills, 2 repeat

@@ -45,6 +45,7 @@ def _load(path):
         "ora_get_valid": (None, [vp, vp]),
         "ora_get_piles": (None, [vp] + [vp] * 5),
         "ora_pile_data": (u64, [vp, u64, vp]),
+        "ora_pile_row_digests": (None, [vp, vp, vp]),
         "ora_pile_intervals": (u64, [vp, u64, i32, vp]),
         "ora_pile_hill_counts": (u64, [vp, u64, vp]),
         "ora_pile_repeat_flags": (u64, [vp, u64, vp]),
@@ -188,6 +189,13 @@ class Oracle:
         if n:
             self.L.ora_pile_data(self.h, r, out.ctypes.data)
         return out
+
+    def pile_row_digests(self):
+        """(fnv, sum) over every pile's data_ (FNV-1a-64 of its bytes; 0 for a read without a pile)"""
+        fnv = np.zeros(self.n_reads, dtype=np.uint64)
+        tot = np.zeros(self.n_reads, dtype=np.uint64)
+        self.L.ora_pile_row_digests(self.h, fnv.ctypes.data, tot.ctypes.data)
+        return fnv, tot
 
     def intervals(self, r, kind):
         n = int(self.L.ora_pile_intervals(self.h, r, kind, None))

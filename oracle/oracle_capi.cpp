@@ -124,6 +124,24 @@ uint64_t ora_pile_data(void* p, uint64_t r, uint16_t* out) {
     return v.size();
 }
 
+// Checksums of every pile's data_ as the backend's objects hold it (reference src/pile.hpp:53, a std::vector<uint16_t>): per read the
+// FNV-1a-64 of its bytes and the sum of its values; 0 for a read without a pile.  Either output may be null.
+void ora_pile_row_digests(void* p, uint64_t* fnv, uint64_t* sum) {
+    Drv& d = ((Handle*)p)->d;
+    for (uint64_t r = 0; r < d.n_reads; ++r) {
+        uint64_t h = 0, s = 0;
+        if (d.bk.alive(r)) {
+            const std::vector<uint16_t>& v = d.bk.data(r);
+            const uint8_t* b = (const uint8_t*)v.data();
+            h = 1469598103934665603ull;
+            for (size_t i = 0; i < v.size() * sizeof(uint16_t); ++i) h = (h ^ b[i]) * 1099511628211ull;
+            for (uint16_t x : v) s += x;
+        }
+        if (fnv) fnv[r] = h;
+        if (sum) sum[r] = s;
+    }
+}
+
 // kind: 0 pits, 1 hills, 2 repeat hills.  out may be null (count only).
 uint64_t ora_pile_intervals(void* p, uint64_t r, int kind, uint32_t* out) {
     Drv& d = ((Handle*)p)->d;

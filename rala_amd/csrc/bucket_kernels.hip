@@ -212,7 +212,10 @@ __global__ __launch_bounds__(kBlockC) void group_count_dedupe_kernel(OvlSoA o, u
         __syncthreads();
         const uint32_t staged = s_fcnt;
         if (staged) {                           // (the same answer in every thread)
-            if (threadIdx.x == 0) s_fbase = atomicAdd(list_count, staged > kFlagStage ? list_cap + 1u : staged);
+            // (giving up is a bit that stays - kDedupeListGivenUp, beyond every capacity - not an addition that 4096 such trips
+            // would carry around the 32-bit counter and back below the capacity; what the trips that do fit add stays below
+            // it: at most kFlagStage marks a trip, 2^17 trips in 2^30 overlaps)
+            if (threadIdx.x == 0) s_fbase = staged > kFlagStage ? atomicOr(list_count, kDedupeListGivenUp) : atomicAdd(list_count, staged);
             __syncthreads();
             if (staged <= kFlagStage) {
                 for (uint32_t k = threadIdx.x; k < staged; k += kBlockC) {

@@ -114,6 +114,8 @@ struct rala_hip_ctx {
     std::unique_ptr<rala_hip::HostPool> pool;
     bool use_run_kernel = true;
     bool debug_fail_construct = false;          // tests: pass 2 fails on this context
+    uint32_t debug_pile_variant = 0;            // measurements: PileArgs::variant
+    uint32_t debug_dedupe_list_cap = 0;         // tests: duplicate removal's mark list holds this many marks (0 = 2^20); more: the pass over all overlaps
     uint32_t debug_fp_lds_limit = 0xFFFFFFFFu;  // tests: containment fixed points with more killers than this take the long lists' kernel
     bool use_bound_records = true;              // sharded runs: 8-byte bound records instead of two tuples per overlap side where they fit
     bool use_round_batches = true;              // containment fixed point: several rounds per look at the counter

@@ -74,12 +74,19 @@ struct PileArgs {
     // first pass: reads with more than kRunEventCap events are listed beforehand
     // (launch_pile_dense_list) and start in the cap-1024 kernel; the cap-512 kernels pass them over
     uint32_t skip_dense = 0;
+    uint32_t variant = 0;          // measurements (a library built with -DRALA_PILE_AB): which variant of the first kernel runs
 };
 
 uint32_t pile_lds_bytes(uint32_t lw);
 uint32_t pile_lw_for(uint32_t read_len);
 uint64_t pile_big_words(uint32_t cap_reg, uint32_t cap_list, uint32_t cap_raw);    // per workgroup
 void launch_pile_build_annotate(const PileArgs& args, uint32_t grid, bool in_lds, hipStream_t stream);
+
+// verify_kernels.hip: per row FNV-1a-64 of Pile::data() (zero outside [begin, end)), the row's sum inside and the stored values' sum
+// outside the region; a dead read answers 0 to all three.  Any output may be null.
+void launch_pile_row_digests(const uint16_t* pile, const uint64_t* pile_off, const uint32_t* read_len, const uint32_t* begin,
+                             const uint32_t* end, const uint8_t* alive, uint32_t n_rows, uint64_t* fnv, uint64_t* inside,
+                             uint64_t* outside, hipStream_t stream);
 
 // run-space kernel (pile_runs_kernel.hip): one wavefront per read; reads with more bound
 // events than the instantiation's cap (or, with args.skip_dense, only those whose region lists do
@@ -402,13 +409,14 @@ bool partition_path_fits(uint32_t n_reads, uint32_t max_read_len, uint64_t n_ove
 // bound events of all reads as an exact CSR (ev_off[n_reads + 1], ev); buffer sizes: bucket_kernels.hip
 // dedupe (may be null): the counting pass does duplicate removal's first pass on the way and writes the validity bytes that hold
 // for the unmarked queries; launch_dedupe_fix behind it (`counted` is recorded behind the counting pass) finishes the marked ones
+constexpr uint32_t kDedupeListGivenUp = 0x80000000u;   // (list_cap is at most 2^20)
 struct BucketDedupe {
     uint8_t* suspect;       // n_reads bytes (cleared by the call)
     uint8_t* valid;         // one byte per overlap
     uint32_t* list_pos;     // where the counting pass marked a query (a run that needs the full comparison): positions ...
     uint32_t* list_query;   // ... and queries, list_cap of each
     uint32_t list_cap;
-    uint32_t* list_count;   // a zeroed word: marks listed; beyond list_cap: the list was given up
+    uint32_t* list_count;   // a zeroed word: marks listed; beyond list_cap (a trip that could not stage its marks sets kDedupeListGivenUp): the list was given up
     hipEvent_t counted;     // may be null
     // (may be null) columns that are still on their way (RALA_HIP_MEM_HOST_ASYNC): the stream waits for ids in front of the
     // counting pass, for b_coords in front of the first scatter, for a_coords in front of the query side

@@ -620,7 +620,12 @@ __device__ __forceinline__ void expand_from_bitmap(uint32_t* sm, const uint16_t*
 // its own stretch of LDS and synchronises with itself only; what they have in common is their place: the rows of
 // neighbouring reads are written from one compute unit (tools/fill_bench4.hip: four rows per workgroup fill at 5.4 TB/s
 // where one row per workgroup fills at 5.0).
-template <uint32_t kCap, bool kDiag, int kSens, bool kOne = false, uint32_t kBases = 16384, uint32_t kWaves = 1, bool kPlain = false>
+// kVar: measurement variants of the product instantiation, chosen per launch (PileArgs::variant, option "debug_pile_variant") so
+// that two builds of the kernel are compared INSIDE one process, on the same allocations, step by step - a library built with
+// -DRALA_PILE_AB carries them (round 6: two processes with the same binary differed by 12 % in this kernel's time, two binaries in
+// alternating processes by less).  Bit 0: the loop over the items as it was; bit 1: the events by ordinary loads; bit 2: the
+// arguments fetched where they are first used.
+template <uint32_t kCap, bool kDiag, int kSens, bool kOne = false, uint32_t kBases = 16384, uint32_t kWaves = 1, bool kPlain = false, uint32_t kVar = 0>
 __global__ __launch_bounds__(64 * kWaves, kOne ? 7 : kBases > 32768 ? 2 : kBases > 16384 ? 4 : 5) void pile_runs_kernel(PileArgs A, uint32_t* overflow_list, uint32_t* overflow_count) {
     static_assert(kWaves == 1 || kOne, "several reads per workgroup: the first kernel of a chain only");
     static_assert(kSens == 0 || !kDiag, "the sensitive pass has no diagnostic instantiation");
@@ -628,6 +633,9 @@ __global__ __launch_bounds__(64 * kWaves, kOne ? 7 : kBases > 32768 ? 2 : kBases
     static_assert(kBases == 16384 || !kOne, "the bigger bitmap belongs to the chain's second kernel");
     // (round 5: the sensitive pass's cap-1024 kernels too - their reads have at most 16384 bases; 14 296 -> 9 840 B of LDS, sixteen
     // workgroups per compute unit instead of eleven, and at C5 this is the kernel nearly every target starts in)
+    constexpr bool kSingleItem = kOne && kWaves > 1 && !(kVar & 1u);
+    constexpr bool kSingleItemArgs = kSingleItem && !(kVar & 4u);
+    constexpr bool kBufferEvents = kSens == 0 && !(kVar & 2u);
     constexpr bool kShort = kOne || kBases > 16384 || (kSens != 0 && kCap == 1024);     // reads of up to kBases bases only, 16-bit run starts
     constexpr uint32_t kMaxBases = kBases > 65535 ? 65535 : kBases;     // rs[R] = n in 16 bits
     typedef Layout<kCap, kShort, kBases> L;
@@ -641,7 +649,15 @@ __global__ __launch_bounds__(64 * kWaves, kOne ? 7 : kBases > 32768 ? 2 : kBases
     uint16_t* rv = (uint16_t*)(sm + L::RV);
     uint16_t* idx = (uint16_t*)(sm + L::IDX);
     uint32_t* sel = sm + L::SEL;
-    const uint32_t n_items = A.n_items_dev ? *A.n_items_dev : A.n_items;
+    // (one workgroup per item: launch_pile_runs / launch_pile_sens start these instantiations only without a count in device memory -
+    // one dependent round trip less at every wavefront's start)
+    const uint32_t n_items = kOne ? A.n_items : A.n_items_dev ? *A.n_items_dev : A.n_items;
+    if constexpr (kPlain && kSingleItemArgs) {
+        // Without a loop over the items the compiler fetches every argument where it is first used: six dependent round trips to the
+        // scalar cache in front of the events' loads.  Named here, what a wavefront's first steps need comes in ONE.
+        asm volatile("" : : "s"(A.read_len), "s"(A.pile_off), "s"(A.ev_off), "s"(A.ev), "s"(A.skip_dense), "s"(overflow_list),
+                     "s"(overflow_count), "s"(A.pile), "s"(A.error));
+    }
 
     // diagnostics: 77 = everything but the row stores; 100 + k = leave after phase k, without them
     const uint32_t stop_k = A.stop_after >= 100 ? A.stop_after % 100 : A.stop_after;
@@ -669,7 +685,12 @@ __global__ __launch_bounds__(64 * kWaves, kOne ? 7 : kBases > 32768 ? 2 : kBases
     // parked in LDS, so that nothing was ever waited for behind a row store: the same time as one workgroup per read at every
     // grid size, DESIGN.md section 4.  Removed in round 5: product code that buys nothing and depends on the register
     // allocator's habits should not stay.)
-    for (uint32_t item = item_first; item < item_end; item += item_step) {
+    // (kOne with several reads per workgroup - the product instantiation - is launched with one wavefront per item: said here in a
+    // way the compiler sees, the loop is none, and nothing "loop invariant" - the LDS offsets of a wavefront's stretch, every
+    // pointer of the arguments - is computed in front of it and kept in scalar registers for the whole kernel: round 5's 56
+    // scalar spills = 56 v_writelane at every wavefront's start and a v_readlane wherever one was used, all of them vector
+    // instructions of a kernel that is bound by their issue)
+    for (uint32_t item = item_first; item < item_end; item = kSingleItem ? item_end : item + item_step) {
         // (The lane id is made opaque once per item: what is derived from it is then no loop invariant.  The
         // compiler used to hoist such values out of the loop and keep them in registers for the whole kernel -
         // 96 VGPRs and spills with a loop over items, 70 without one.)
@@ -749,7 +770,16 @@ __global__ __launch_bounds__(64 * kWaves, kOne ? 7 : kBases > 32768 ? 2 : kBases
             // a load per predicated block would be waited for one by one
             uint32_t evr[kCap / 64];
             const uint32_t e_last = n_ev ? n_ev - 1 : 0;
-            if constexpr (kSens == 0) {
+            if constexpr (kBufferEvents) {
+                // (round 6) the events through a buffer descriptor over exactly this read's slots: one lane offset and eight
+                // immediate ones instead of a clamped index and a 64-bit address per load, and nothing to mark behind the last
+                // event (a load beyond the descriptor's size answers 0; the loops below ask the lane's index, not the value) -
+                // 56 vector instructions of a kernel that is bound by their issue became one
+                const __amdgpu_buffer_rsrc_t slots = __builtin_amdgcn_make_buffer_rsrc((void*)rev, 0, (int)(n_ev * 4u), 0x00020000);
+                const int lane4 = (int)(lane * 4u);
+#pragma unroll
+                for (uint32_t t = 0; t < kCap / 64; ++t) evr[t] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(slots, lane4 + (int)(t * 256u), 0, 0);
+            } else if constexpr (kSens == 0) {
 #pragma unroll
                 for (uint32_t t = 0; t < kCap / 64; ++t) evr[t] = rev[umin(t * 64 + lane, e_last)];
 #pragma unroll
@@ -769,7 +799,7 @@ __global__ __launch_bounds__(64 * kWaves, kOne ? 7 : kBases > 32768 ? 2 : kBases
             for (uint32_t t = 0; t < kCap / 64; ++t) {
                 if (t * 64 >= n_ev) break;
                 const uint32_t pos = evr[t] >> 1;
-                if (evr[t] != kNone && pos < n) atomicOr(&bm[pos >> 5], 1u << (pos & 31));
+                if ((kBufferEvents ? t * 64 + lane < n_ev : evr[t] != kNone) && pos < n) atomicOr(&bm[pos >> 5], 1u << (pos & 31));
             }
             if (lane == 0) atomicOr(&bm[0], 1u);             // position 0 always starts a run
             if constexpr (kSens != 0) {
@@ -810,7 +840,7 @@ __global__ __launch_bounds__(64 * kWaves, kOne ? 7 : kBases > 32768 ? 2 : kBases
             for (uint32_t t = 0; t < kCap / 64; ++t) {
                 if (t * 64 >= n_ev) break;
                 const uint32_t pos = evr[t] >> 1;
-                if (evr[t] != kNone && pos < n) {
+                if ((kBufferEvents ? t * 64 + lane < n_ev : evr[t] != kNone) && pos < n) {
                     const uint32_t w = pos >> 5;
                     const uint32_t k = pref[w] + (uint32_t)__popc(bm[w] & ((2u << (pos & 31)) - 1u)) - 1u;
                     rs[k] = pos;
@@ -1817,9 +1847,23 @@ void launch_pile_runs(const PileArgs& args, uint32_t grid, int tier, uint32_t* o
                                      args, overflow_list, overflow_count);
         else if (waves == 4 && !persist) hipLaunchKernelGGL((pile_runs_kernel<kRunEventCap, false, 0, true, 16384, 4>), dim3((grid + 3) / 4), dim3(256),
                                                             extra_lds, stream, args, overflow_list, overflow_count);
-        else if (waves == 2 && !persist && !args.order && !args.ev_cnt && !getenv("RALA_PILE_NOT_PLAIN"))
-            hipLaunchKernelGGL((pile_runs_kernel<kRunEventCap, false, 0, true, 16384, 2, true>), dim3((grid + 1) / 2), dim3(128),
-                               extra_lds, stream, args, overflow_list, overflow_count);
+        else if (waves == 2 && !persist && !args.order && !args.ev_cnt && !getenv("RALA_PILE_NOT_PLAIN")) {
+#define RALA_LAUNCH_PRODUCT(var)                                                                                                  \
+            hipLaunchKernelGGL((pile_runs_kernel<kRunEventCap, false, 0, true, 16384, 2, true, var>), dim3((grid + 1) / 2), dim3(128), \
+                               extra_lds, stream, args, overflow_list, overflow_count)
+#ifdef RALA_PILE_AB
+            switch (args.variant) {
+                case 1: RALA_LAUNCH_PRODUCT(1); break;
+                case 2: RALA_LAUNCH_PRODUCT(2); break;
+                case 3: RALA_LAUNCH_PRODUCT(3); break;
+                case 4: RALA_LAUNCH_PRODUCT(4); break;
+                default: RALA_LAUNCH_PRODUCT(0); break;
+            }
+#else
+            RALA_LAUNCH_PRODUCT(0);
+#endif
+#undef RALA_LAUNCH_PRODUCT
+        }
         else if (waves == 2 && !persist) hipLaunchKernelGGL((pile_runs_kernel<kRunEventCap, false, 0, true, 16384, 2>), dim3((grid + 1) / 2), dim3(128),
                                                             extra_lds, stream, args, overflow_list, overflow_count);
         else hipLaunchKernelGGL((pile_runs_kernel<kRunEventCap, false, 0, true>), dim3(g), dim3(64), extra_lds, stream,

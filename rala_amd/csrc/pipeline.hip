@@ -1940,6 +1940,30 @@ int pass2(rala_hip_ctx* ctx, Comm* comm) {
 
 }  // namespace
 
+// every row of cl where it lies, under the regions that apply (the getters' view: rala_hip_get_pile_data zeroes outside them)
+int rala_hip::pile_row_digests(rala_hip_ctx* ctx, const uint32_t* begin, const uint32_t* end, const uint8_t* alive, uint64_t* fnv,
+                               uint64_t* inside, uint64_t* outside) {
+    const uint64_t n = ctx->n_reads;
+    if (n == 0) return RALA_HIP_OK;
+    HIPCHECK(hipSetDevice(ctx->device));
+    DevBuf<uint32_t> d_be;
+    DevBuf<uint8_t> d_al;
+    DevBuf<uint64_t> d_out;
+    HIPCHECK(d_be.ensure(2 * n)); HIPCHECK(d_al.ensure(n)); HIPCHECK(d_out.ensure(3 * n));
+    HIPCHECK(hipMemcpy(d_be.p, begin, n * 4, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(d_be.p + n, end, n * 4, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(d_al.p, alive, n, hipMemcpyHostToDevice));
+    hipStream_t s = ctx->stream;
+    launch_pile_row_digests(ctx->d_pile.p, ctx->d_pile_off.p, ctx->d_read_len.p, d_be.p, d_be.p + n, d_al.p, (uint32_t)n,
+                            fnv ? d_out.p : nullptr, inside ? d_out.p + n : nullptr, outside ? d_out.p + 2 * n : nullptr, s);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(stream_sync(ctx, s));
+    if (fnv) HIPCHECK(hipMemcpy(fnv, d_out.p, n * 8, hipMemcpyDeviceToHost));
+    if (inside) HIPCHECK(hipMemcpy(inside, d_out.p + n, n * 8, hipMemcpyDeviceToHost));
+    if (outside) HIPCHECK(hipMemcpy(outside, d_out.p + 2 * n, n * 8, hipMemcpyDeviceToHost));
+    return RALA_HIP_OK;
+}
+
 // ---- stage entry points shared with the sharded runner (stages.h) ---------------------------------
 int rala_hip::construct_stages(rala_hip_ctx* ctx, Comm* comm, bool sensitive_pass_follows) {
     if (!ctx) return RALA_HIP_EINVAL;
@@ -2015,7 +2039,7 @@ int rala_hip::shard_emit(rala_hip_ctx* ctx, const ShardGeometry& g, uint64_t* se
         HIPCHECK(ctx->d_dedupe_list.ensure(2 * (size_t)kMarks + 4));
         HIPCHECK(hipMemsetAsync(ctx->d_dedupe_list.p + 2 * (size_t)kMarks, 0, 4, s));
         bd.suspect = ctx->d_suspect.p; bd.valid = ctx->d_valid.p; bd.list_pos = ctx->d_dedupe_list.p; bd.list_query = ctx->d_dedupe_list.p + kMarks;
-        bd.list_cap = kMarks; bd.list_count = ctx->d_dedupe_list.p + 2 * (size_t)kMarks; bd.counted = ctx->ev[0];
+        bd.list_cap = ctx->debug_dedupe_list_cap ? std::min(kMarks, ctx->debug_dedupe_list_cap) : kMarks; bd.list_count = ctx->d_dedupe_list.p + 2 * (size_t)kMarks; bd.counted = ctx->ev[0];
     } else if (ctx->use_side_stream) {
         HIPCHECK(hipEventRecord(ctx->ev[0], s));
         HIPCHECK(hipStreamWaitEvent(ctx->side, ctx->ev[0], 0));
@@ -2162,6 +2186,8 @@ int rala_hip_set_option(rala_hip_ctx* ctx, const char* key, int64_t value) {
     if (!strcmp(key, "use_bound_records")) { ctx->use_bound_records = value != 0; return RALA_HIP_OK; }
     if (!strcmp(key, "use_fused_emit")) { ctx->use_fused_emit = value != 0; return RALA_HIP_OK; }
     if (!strcmp(key, "ingest_window_bytes")) { ctx->ingest_window_bytes = std::max<int64_t>(0, value); return RALA_HIP_OK; }
+    if (!strcmp(key, "debug_pile_variant")) { ctx->debug_pile_variant = (uint32_t)std::max<int64_t>(0, value); return RALA_HIP_OK; }
+    if (!strcmp(key, "debug_dedupe_list_cap")) { ctx->debug_dedupe_list_cap = (uint32_t)std::max<int64_t>(0, value); return RALA_HIP_OK; }
     if (!strcmp(key, "debug_fp_lds_limit")) { ctx->debug_fp_lds_limit = (uint32_t)std::max<int64_t>(0, value); return RALA_HIP_OK; }
     if (!strcmp(key, "debug_fail_construct")) { ctx->debug_fail_construct = value != 0; return RALA_HIP_OK; }
     if (!strcmp(key, "use_gpu_tail")) { ctx->use_gpu_tail = value != 0; return RALA_HIP_OK; }
@@ -2455,7 +2481,8 @@ static int initialize_stages(rala_hip_ctx* ctx) {
         } else {
             constexpr uint32_t kMarks = 1u << 20;           // (C3: 1 - 2 % of a million queries)
             if (dedupe_counted) HIPCHECK(ctx->d_dedupe_list.ensure(2 * (size_t)kMarks));
-            BucketDedupe bd = {ctx->d_suspect.p, ctx->d_valid.p, ctx->d_dedupe_list.p, ctx->d_dedupe_list.p + kMarks, kMarks,
+            BucketDedupe bd = {ctx->d_suspect.p, ctx->d_valid.p, ctx->d_dedupe_list.p, ctx->d_dedupe_list.p + kMarks,
+                               ctx->debug_dedupe_list_cap ? std::min(kMarks, ctx->debug_dedupe_list_cap) : kMarks,
                                ctx->d_small.p + 9, ctx->ev[8]};     // ([9]: zeroed with d_small above)
             if (fine_upload) { bd.ids = ctx->ev_up[0]; bd.b_coords = ctx->ev_up[1]; bd.a_coords = ctx->ev_up[2]; }
             HIPCHECK(launch_bucket_partitioned(ctx->ovl, n_reads, ctx->d_bk_u32[0].p, ctx->d_bk_u32[2].p,
@@ -2517,6 +2544,7 @@ static int initialize_stages(rala_hip_ctx* ctx) {
     a.ev_cnt = fixed ? ctx->d_cursor.p : nullptr; a.ev_stride = slot;
     a.add_to_existing = 0; a.slab = ctx->d_slab.p;
     a.stop_after = (uint32_t)ctx->debug_pile_stop_after;
+    a.variant = ctx->debug_pile_variant;
     a.begin = ctx->d_begin.p; a.end = ctx->d_end.p; a.median = ctx->d_median.p; a.p10 = ctx->d_p10.p;
     a.alive = ctx->d_alive.p; a.n_pits = ctx->d_n_pits.p; a.n_hills = ctx->d_n_hills.p; a.iv_slot = ctx->d_iv_slot.p;
     a.pool = ctx->d_pool.p; a.pool_count = ctx->d_small.p; a.pool_cap = ctx->pool_cap; a.error = ctx->d_small.p + 1;
@@ -3229,6 +3257,15 @@ int rala_hip_get_pile_data(rala_hip_ctx* ctx, uint64_t read, uint16_t* data) {
         for (uint32_t j = E; j < n; ++j) data[j] = 0;
     }
     return RALA_HIP_OK;
+}
+
+int rala_hip_get_pile_row_digests(rala_hip_ctx* ctx, uint64_t* fnv, uint64_t* inside, uint64_t* outside) {
+    if (!ctx) return RALA_HIP_EINVAL;
+    if (!ctx->initialized) return fail(ctx, RALA_HIP_EINVAL, "not initialized");
+    if (!ctx->piles_resident) return fail(ctx, RALA_HIP_EINVAL, "piles live on the owning rank's context");
+    HIPCHECK(hipSetDevice(ctx->device));
+    { const int rcm = materialize_host(ctx); if (rcm != RALA_HIP_OK) return rcm; }
+    return pile_row_digests(ctx, ctx->h_begin.data(), ctx->h_end.data(), ctx->h_alive.data(), fnv, inside, outside);
 }
 
 int rala_hip_get_intervals(rala_hip_ctx* ctx, int kind, uint64_t* offsets, uint32_t* pairs, uint32_t* aux) {

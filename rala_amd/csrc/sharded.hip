@@ -761,6 +761,33 @@ int rala_hip_mg_get_pile_data(rala_hip_mg* mg, uint64_t read, uint16_t* data) {
     return RALA_HIP_OK;
 }
 
+int rala_hip_mg_get_pile_row_digests(rala_hip_mg* mg, uint64_t* fnv, uint64_t* inside, uint64_t* outside) {
+    if (!mg) return RALA_HIP_EINVAL;
+    struct DeviceGuard {
+        int before = -1;
+        DeviceGuard() { if (hipGetDevice(&before) != hipSuccess) before = -1; }
+        ~DeviceGuard() { if (before >= 0) (void)hipSetDevice(before); }
+    } guard;
+    MGCHECK(hipSetDevice(mg->device));
+    // the owner's context keeps the rows (local row j = read j * world + rank); the regions that apply are the final ones of the
+    // replicated state
+    rala_hip_ctx* cl = mg->cl;
+    const uint64_t n_own = cl->n_reads, n = mg->n_reads;
+    std::vector<uint32_t> b(n), e(n), ob(n_own), oe(n_own);
+    std::vector<uint8_t> a(n), oa(n_own);
+    if (n) {
+        MGCHECK(hipMemcpy(b.data(), mg->cs->d_begin.p, n * 4, hipMemcpyDeviceToHost));
+        MGCHECK(hipMemcpy(e.data(), mg->cs->d_end.p, n * 4, hipMemcpyDeviceToHost));
+        MGCHECK(hipMemcpy(a.data(), mg->cs->d_alive.p, n, hipMemcpyDeviceToHost));
+    }
+    for (uint64_t j = 0; j < n_own; ++j) {
+        const uint64_t r = j * mg->world + mg->rank;
+        ob[j] = b[r]; oe[j] = e[r]; oa[j] = a[r];
+    }
+    const int rc = pile_row_digests(cl, ob.data(), oe.data(), oa.data(), fnv, inside, outside);
+    return rc == RALA_HIP_OK ? rc : mg_fail(mg, rc, rala_hip_last_error(cl));
+}
+
 int rala_hip_mg_get_timings(rala_hip_mg* mg, rala_hip_mg_timings* out) {
     if (!mg || !out) return RALA_HIP_EINVAL;
     *out = mg->tm;

@@ -51,6 +51,10 @@ struct PafRange {
 int paf_tokenise_range(rala_hip_ctx* ctx, const char* path, uint64_t lo, uint64_t hi, bool check_lengths, uint32_t threads,
                        size_t extra_rows, const PafTarget& T, PafRange* out);
 
+// checksums of the rows cl holds (verify_kernels.hip) under the regions / liveness given per row (host arrays, cl->n_reads entries)
+int pile_row_digests(rala_hip_ctx* cl, const uint32_t* begin, const uint32_t* end, const uint8_t* alive, uint64_t* fnv, uint64_t* inside,
+                     uint64_t* outside);
+
 hipError_t stream_sync(rala_hip_ctx* ctx, hipStream_t s);
 hipError_t d2h_small(rala_hip_ctx* ctx, void* dst, const void* src, size_t bytes, hipStream_t s);
 int flush_upload(rala_hip_ctx* ctx);       // (pipeline.hip) RALA_HIP_MEM_HOST_ASYNC columns not uploaded yet: now

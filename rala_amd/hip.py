@@ -23,7 +23,7 @@ SYMBOLS = (
     "rala_hip_create", "rala_hip_destroy", "rala_hip_last_error", "rala_hip_set_option", "rala_hip_stream",
     "rala_hip_set_reads", "rala_hip_set_overlaps", "rala_hip_initialize", "rala_hip_construct",
     "rala_hip_remove_transitive_edges", "rala_hip_tr_mark", "rala_hip_get_valid", "rala_hip_get_piles",
-    "rala_hip_get_pile_data", "rala_hip_get_intervals", "rala_hip_get_overlaps", "rala_hip_get_graph_size",
+    "rala_hip_get_pile_data", "rala_hip_get_pile_row_digests", "rala_hip_get_intervals", "rala_hip_get_overlaps", "rala_hip_get_graph_size",
     "rala_hip_get_graph", "rala_hip_get_timings", "rala_hip_get_num_prefiltered",
     "rala_hip_dedupe", "rala_hip_emit_bound_tuples", "rala_hip_set_bound_tuples", "rala_hip_import_state",
     "rala_hip_emit_bound_tuples_bucketed", "rala_hip_get_device_state", "rala_hip_import_state_device",
@@ -36,7 +36,7 @@ SYMBOLS = (
     "rala_hip_mg_destroy", "rala_hip_mg_last_error", "rala_hip_mg_set_reads", "rala_hip_mg_slice_cuts",
     "rala_hip_mg_set_overlaps", "rala_hip_mg_run", "rala_hip_mg_run_threads", "rala_hip_mg_context",
     "rala_hip_mg_owner_context",
-    "rala_hip_mg_get_pile_data", "rala_hip_mg_get_timings",
+    "rala_hip_mg_get_pile_data", "rala_hip_mg_get_pile_row_digests", "rala_hip_mg_get_timings",
 )
 COMM_RCCL, COMM_LOCAL = 0, 1
 
@@ -103,6 +103,7 @@ def lib(build=True):
         L.rala_hip_get_valid.argtypes = [vp, vp]
         L.rala_hip_get_piles.argtypes = [vp, vp, vp, vp, vp, vp]
         L.rala_hip_get_pile_data.argtypes = [vp, u64, vp]
+        L.rala_hip_get_pile_row_digests.argtypes = [vp, vp, vp, vp]
         L.rala_hip_get_intervals.argtypes = [vp, i32, vp, vp, vp]
         L.rala_hip_get_overlaps.argtypes = [vp, i32, ctypes.POINTER(u64), vp, vp, vp, vp, vp, vp, vp]
         L.rala_hip_get_graph_size.argtypes = [vp, ctypes.POINTER(u64), ctypes.POINTER(u64)]
@@ -140,6 +141,7 @@ def lib(build=True):
         L.rala_hip_mg_owner_context.argtypes = [vp]
         L.rala_hip_mg_owner_context.restype = vp
         L.rala_hip_mg_get_pile_data.argtypes = [vp, u64, vp]
+        L.rala_hip_mg_get_pile_row_digests.argtypes = [vp, vp, vp, vp]
         L.rala_hip_mg_get_timings.argtypes = [vp, ctypes.POINTER(MgTimings)]
         _lib = L
     return _lib
@@ -411,6 +413,13 @@ class Context:
         self._check(self.L.rala_hip_get_pile_data(self.h, r, out.ctypes.data))
         return out
 
+    def pile_row_digests(self):
+        """checksums of every pile row, computed where the rows lie: (fnv, inside, outside), uint64 per read -
+        FNV-1a-64 of Pile::data(), the row's sum inside the valid region, the stored values' sum outside it"""
+        out = [np.zeros(self.n_reads, dtype=np.uint64) for _ in range(3)]
+        self._check(self.L.rala_hip_get_pile_row_digests(self.h, *[a.ctypes.data for a in out]))
+        return tuple(out)
+
     def intervals(self, kind):
         """(offsets[n+1] uint64, pairs[k,2] uint32, aux[k] uint32)"""
         offs = np.zeros(self.n_reads + 1, dtype=np.uint64)
@@ -557,6 +566,13 @@ class ShardedRank:
         out = np.zeros(int(self.read_len[r]), dtype=np.uint16)
         self._check(self.L.rala_hip_mg_get_pile_data(self.h, int(r), out.ctypes.data))
         return out
+
+    def pile_row_digests(self):
+        """(fnv, inside, outside) of the rows this rank owns: entry j = read j * world + rank"""
+        n_own = len(range(self.rank, len(self.read_len), self.world))
+        out = [np.zeros(n_own, dtype=np.uint64) for _ in range(3)]
+        self._check(self.L.rala_hip_mg_get_pile_row_digests(self.h, *[a.ctypes.data for a in out]))
+        return tuple(out)
 
     def owner_timings(self):
         """stage timings of the owner context (bucketing and pile kernels over the owned reads)"""

@@ -21,6 +21,7 @@
 #include "io.hpp"
 #include "overlap.hpp"
 #include "pile.hpp"
+#include "sequence.hpp"
 #include "rala_hip.h"
 
 namespace {
@@ -264,5 +265,8 @@ void hp_paf_device_copy(void* h, uint32_t* a_id, uint32_t* b_id, uint32_t* a_beg
     memcpy(strand, o->strand.data(), o->n);
 }
 void hp_paf_device_free(void* h) { delete (PafOnDevice*)h; }
+
+// rala::createSequence (reference src/sequence.cpp:12-25): the length of what it made - it leaves the process on an empty name / data
+uint64_t hp_sequence_length(const char* name, const char* data) { return rala::createSequence(name, data)->data().size(); }
 
 }  // extern "C"

@@ -1,8 +1,17 @@
 #include "sequence.hpp"
 
+#include <stdio.h>
+#include <stdlib.h>
+
 namespace rala {
 
+// (the factory's two fatal checks and their message texts: reference src/sequence.cpp:15-22)
 std::unique_ptr<Sequence> createSequence(const std::string& name, const std::string& data) {
+    const char* missing = name.empty() ? "name" : data.empty() ? "data" : nullptr;
+    if (missing) {
+        fprintf(stderr, "[rala::createSequence] error: empty %s!\n", missing);
+        exit(1);
+    }
     return std::unique_ptr<Sequence>(new Sequence(name, data));
 }
 

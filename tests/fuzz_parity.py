@@ -48,6 +48,9 @@ for case in range(n_cases):
         ctx.set_option("use_side_stream", int(rng.random() < 0.8))
         if rng.random() < 0.4:      # the containment fixed points' long lists' kernel / a mix of both
             ctx.set_option("debug_fp_lds_limit", int(rng.choice([0, 7, 100])))
+        if rng.random() < 0.25:     # duplicate removal: a mark list that overflows (the pass over all overlaps takes over)
+            ctx.set_option("debug_dedupe_list_cap", int(rng.choice([1, 3, 40])))
+            variant.append("marks")
         # round 4: the position-space kernels' lists in global memory, from a few entries up (every read that reaches those
         # kernels); an interval pool that has to grow; the sensitive set handed over as device memory
         if rng.random() < 0.3:

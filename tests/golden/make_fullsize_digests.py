@@ -63,11 +63,19 @@ def main():
     reads = sample_reads(ds.n_reads, p["alive"])
     out["data_reads"] = dg(reads.astype(np.int64))
     out["data0"] = dg(*[np.asarray(o.pile_data(int(r)), dtype=np.uint16) for r in reads])
+    # EVERY pile row (round 6): the vector of per-read FNV-1a-64 over the bytes of data_ of all live reads (0 for a filtered read)
+    # and the vector of the rows' sums - the HIP path computes the same two vectors where the rows lie (rala_hip_get_pile_row_digests)
+    fnv, tot = o.pile_row_digests()
+    out["rows0"] = dg(fnv)
+    out["rows0_sum"] = dg(tot)
     print("[digest] initialize done %.0f s" % (time.time() - t0), file=sys.stderr)
     o.pass2()
     o.preprocess_chimeras()
     p2 = o.piles()
     out["piles2"] = dg(p2["begin"], p2["end"], p2["alive"])
+    fnv, tot = o.pile_row_digests()         # (the chimera stage narrows regions: Pile::shrink zeroes what falls outside)
+    out["rows2"] = dg(fnv)
+    out["rows2_sum"] = dg(tot)
     ov, it = o.overlap_list(0), o.overlap_list(1)
     out["n_overlaps_kept"] = int(len(ov["src"]))
     out["n_internals_kept"] = int(len(it["src"]))
@@ -85,6 +93,9 @@ def main():
         out["n_repeat_hills"] = int(len(rep[1]))
         p3 = o.piles()
         out["piles3"] = dg(*[p3[k] for k in ("begin", "end", "median", "p10", "alive")])
+        fnv, tot = o.pile_row_digests()     # (the targets' rows hold the second add_layers now)
+        out["rows3"] = dg(fnv)
+        out["rows3_sum"] = dg(tot)
         targets = np.unique(sens.b_id)[:SAMPLE]
         out["data3"] = dg(*[np.asarray(o.pile_data(int(r)), dtype=np.uint16) for r in targets])
         ov = o.overlap_list(0)

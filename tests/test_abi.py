@@ -110,3 +110,23 @@ int main() {
                                os.path.join(d, "t.cpp")])
         out = subprocess.check_output([exe]).split()
     assert out == [b"999000", b"4"]
+
+
+def test_create_sequence_keeps_the_reference_fatal_checks():
+    """rala::createSequence leaves the process with the reference's message on an empty name / data (reference
+    src/sequence.cpp:15-22; SURVEY 8(b): error texts kept).  CPU only: the factory touches no device."""
+    import subprocess
+    import sys
+
+    lib = os.path.join(ROOT, "rala_amd", "host", "librala_api.so")
+    from rala_amd import build
+    build.build_host()
+    code = ("import ctypes, sys; L = ctypes.CDLL(%r); L.hp_sequence_length.restype = ctypes.c_uint64; "
+            "L.hp_sequence_length.argtypes = [ctypes.c_char_p, ctypes.c_char_p]; "
+            "print(L.hp_sequence_length(sys.argv[1].encode(), sys.argv[2].encode()))" % lib)
+    ok = subprocess.run([sys.executable, "-c", code, "read1", "ACGT"], capture_output=True, text=True)
+    assert ok.returncode == 0 and ok.stdout.strip() == "4", ok.stderr
+    for name, data, what in (("", "ACGT", "name"), ("read1", "", "data")):
+        res = subprocess.run([sys.executable, "-c", code, name, data], capture_output=True, text=True)
+        assert res.returncode == 1
+        assert "[rala::createSequence] error: empty %s!" % what in res.stderr

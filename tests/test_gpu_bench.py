@@ -37,6 +37,25 @@ def test_bare_bench_runs_one_and_several_ranks():
     assert b["config"]["transitive_pairs"] == a["config"]["transitive_pairs"]
     assert b["config"]["n_overlaps"] == a["config"]["n_overlaps"]
     assert b["stage_ms"]["exchange_ms"] > 0 and b["roofline"]["kernel_ms"] > 0
+    # the step's RESULT against the committed digests of the reference objects' result, in the line (round 6): validity bytes,
+    # read state, kept overlaps, graph with its transitive marks and the checksum of EVERY pile row - rank 0 and the last rank
+    for line, ranks in ((a, [0]), (b, [0, 3])):
+        rc = line["result_check"]
+        assert rc["ok"] is True and rc["digests"] == "tests/golden/fullsize_c2.json" and rc["backend"] == "reference-objects"
+        assert rc["ranks_checked"] == ranks and rc["ranks_agree"] and not rc["stages_differ"]
+        assert set(rc["stages_equal"]) >= {"valid", "piles2", "ov", "int", "nodes", "edges", "n_tr", "rows2", "rows2_sum"}
+    assert "frac_of_achievable" in a["roofline"] and "frac_of_write_only_rate" not in a["roofline"]
+
+
+def test_a_wrong_result_prints_no_figure():
+    """a step whose result differs from the committed digests ends with exit code 4 and no line (RALA_BENCH_FAKE_WRONG_RESULT
+    turns one digest over before the comparison)"""
+    for extra in ((), ("--gpus", "2", "--transport", "local", "--devices", "0,0")):
+        res = bench("--workload", "c2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-e2e", *extra,
+                    env={"RALA_BENCH_FAKE_WRONG_RESULT": "1"})
+        assert res.returncode == 4, (res.returncode, res.stderr[-2000:])
+        assert not [x for x in res.stdout.splitlines() if x.startswith("{")]
+        assert "RESULT CHECK FAILED" in res.stderr and "edges" in res.stderr
 
 
 def test_bench_refuses_more_rccl_ranks_than_devices():
@@ -108,6 +127,10 @@ def test_sensitive_workload():
     b = json.loads(two.stdout.strip().splitlines()[-1])
     assert b["config"]["transitive_pairs"] == a["config"]["transitive_pairs"]
     assert b["sensitive_pass"]["n_sensitive"] == sp["n_sensitive"] and b["sensitive_pass"]["ms"] > 0
+    for line in (a, b):
+        rc = line["result_check"]
+        assert rc["ok"] is True and rc["digests"] == "tests/golden/fullsize_c2_sens.json" and not rc["stages_differ"]
+        assert set(rc["stages_equal"]) >= {"valid", "piles3", "ov_sens", "rep", "nodes", "edges", "n_tr", "rows3"}
 
 
 def test_one_process_per_gpu_launch():
@@ -129,6 +152,8 @@ def test_one_process_per_gpu_launch():
     assert a["transport"] == "rccl" and a["rccl_ranks"] == 1 and a["n_gpus"] == 1 and a["stage_ms"]["exchange_ms"] > 0
     assert b["sensitive_pass"]["n_sensitive"] > 100_000 and b["sensitive_pass"]["ms"] > 0
     assert b["config"]["transitive_pairs"] != a["config"]["transitive_pairs"]
+    assert a["result_check"]["ok"] is True and b["result_check"]["ok"] is True
+    assert a["result_check"]["digests"] == "tests/golden/fullsize_c2.json" and b["result_check"]["digests"] == "tests/golden/fullsize_c2_sens.json"
 
 
 def test_traffic_is_measured_in_the_run():

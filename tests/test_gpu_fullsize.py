@@ -66,9 +66,15 @@ def stage_digests(ctx, with_data=True):
         reads = sample_reads(p["alive"])
         out["data_reads"] = dg(reads.astype(np.int64))
         out["data0"] = dg(*[np.asarray(ctx.pile_data(int(r)), dtype=np.uint16) for r in reads])
+    # EVERY row (round 6): the per-read FNV-1a-64 of Pile::data() and the rows' sums, computed where the rows lie
+    fnv, inside, outside = ctx.pile_row_digests()
+    out["rows0"], out["rows0_sum"] = dg(fnv), dg(inside)
+    assert not outside.any()
     ctx.construct()
     p2 = ctx.piles()
     out["piles2"] = dg(p2["begin"], p2["end"], p2["alive"])
+    fnv, inside, _ = ctx.pile_row_digests()
+    out["rows2"], out["rows2_sum"] = dg(fnv), dg(inside)
     for which, name in ((0, "ov"), (1, "int")):
         lst = ctx.overlap_list(which)
         out["n_%s_kept" % ("overlaps" if which == 0 else "internals")] = int(len(lst["src"]))
@@ -197,6 +203,12 @@ def test_fullsize_sharded_run(wl, world):
                               g["marked"].astype(np.uint8))
             for k, v in got.items():
                 assert v == want[k], "%s sharded over %d ranks: stage %s differs from the oracle" % (wl, world, k)
+        # every row from its owner, under the final regions
+        fnv = np.zeros(ds.n_reads, dtype=np.uint64)
+        tot = np.zeros(ds.n_reads, dtype=np.uint64)
+        for k, r in enumerate(sh.ranks):
+            fnv[k::world], tot[k::world], _ = r.pile_row_digests()
+        assert dg(fnv) == want["rows2"] and dg(tot) == want["rows2_sum"]
         # coverage vectors come from their owners: against a single-context run
         reads = sample_reads(sh.ranks[0].context().piles()["alive"])[:40]
         single = run(lambda: __import__("rala_amd.hip", fromlist=["Context"]).Context(0), ds)
@@ -231,11 +243,12 @@ def test_c5_properties():
             pits, hills = ctx.intervals(0), ctx.intervals(1)
             reads = sample_reads(p["alive"])[:60]
             data = {int(r): np.asarray(ctx.pile_data(int(r)), dtype=np.int64) for r in reads}
+            rows = ctx.pile_row_digests()               # every one of the 4 M rows, hashed and summed where it lies
             ctx.construct()
             n_tr = ctx.remove_transitive_edges()
             g = ctx.graph()
             res = dict(p=p, pits=pits, hills=hills, reads=reads, data=data, n_tr=n_tr, g=g,
-                       ov=ctx.overlap_list(0), tm=ctx.timings())
+                       ov=ctx.overlap_list(0), tm=ctx.timings(), rows=rows)
             if not options:
                 keep = g["marked"] == 0
                 marks, pairs = ctx.tr_mark(len(g["node_read"]), g["src"][keep], g["dst"][keep], g["len"][keep])
@@ -262,6 +275,23 @@ def test_c5_properties():
         assert data[r][:B].sum() == 0 and data[r][E:].sum() == 0
     assert a["n_tr"] > 0 and a["second_tr"] == (0, False)
     assert int(a["g"]["marked"].sum()) == 2 * a["n_tr"]
+    # additivity over ALL 4 M reads (no host holds C5's reference objects): the sum of every row over its valid region, taken
+    # on the device, is the sum of the clipped spans of the read's overlaps (Pile::add_layers' +-15, reference
+    # graph.cpp:311-326: the bounds of every record that resolved, duplicates included); nothing is stored outside the region
+    fnv, inside, outside = a["rows"]
+    assert not outside.any() and not fnv[p["alive"] == 0].any() and fnv[p["alive"] != 0].all()
+    B, E = p["begin"].astype(np.int64), p["end"].astype(np.int64)
+    want = np.zeros(ds.n_reads, dtype=np.float64)
+    step = 1 << 25
+    for lo_i in range(0, len(ov), step):
+        sl = slice(lo_i, min(len(ov), lo_i + step))
+        for side_id, sb, se in ((ov.a_id, ov.a_begin, ov.a_end), (ov.b_id, ov.b_begin, ov.b_end)):
+            ids = side_id[sl].astype(np.int64)
+            lo = np.clip(sb[sl].astype(np.int64) + 15, B[ids], E[ids])
+            hi = np.clip(se[sl].astype(np.int64) - 15, B[ids], E[ids])
+            want += np.bincount(ids, weights=np.maximum(hi - lo, 0).astype(np.float64), minlength=ds.n_reads)
+    alive = p["alive"] != 0
+    assert (inside[alive].astype(np.float64) == want[alive]).all(), int(np.nonzero(alive & (inside.astype(np.float64) != want))[0][0])
 
     def same(x, y, what):
         for k in ("begin", "end", "median", "p10", "alive"):
@@ -270,6 +300,8 @@ def test_c5_properties():
             assert (x[name][0] == y[name][0]).all() and (x[name][1] == y[name][1]).all(), (what, name)
         for r in reads[:20]:
             assert (x["data"][int(r)] == y["data"][int(r)]).all(), (what, int(r))
+        for k in range(3):          # every row: the two pile kernels (and every bucketing path) leave the same 80 GB
+            assert (x["rows"][k] == y["rows"][k]).all(), (what, "rows", k)
         assert x["n_tr"] == y["n_tr"], what
         for k in ("node_read", "src", "dst", "len", "marked"):
             assert (x["g"][k] == y["g"][k]).all(), (what, k)
@@ -499,6 +531,8 @@ def test_fullsize_sensitive_pass_matches_oracle_digests(hip_ctx_factory, wl):
     got["piles3"] = dg(*[p3[k] for k in ("begin", "end", "median", "p10", "alive")])
     targets = np.unique(sens.b_id)[:SAMPLE]
     got["data3"] = dg(*[np.asarray(ctx.pile_data(int(r)), dtype=np.uint16) for r in targets])
+    fnv, inside, _ = ctx.pile_row_digests()           # every row, the targets' with their second add_layers
+    got["rows3"], got["rows3_sum"] = dg(fnv), dg(inside)
     ov = ctx.overlap_list(0)
     got["n_overlaps_kept_sens"] = int(len(ov["src"]))
     got["ov_sens"] = dg(*[np.asarray(ov[k]).astype(np.uint32) for k in

@@ -377,12 +377,57 @@ def _shuffled_with_duplicates(ds, seed):
     return d
 
 
+@pytest.mark.parametrize("list_cap", [0, 5])
 @pytest.mark.parametrize("n,g,seed", [(3000, 600_000, 21), (2000, 1_200_000, 33)])
-def test_unordered_runs_duplicates_unresolved(hip_ctx_factory, n, g, seed):
+def test_unordered_runs_duplicates_unresolved(hip_ctx_factory, n, g, seed, list_cap):
+    """(runs shuffled inside: the counting pass's trips stage more marks than they hold and give the list up - a bit that
+    stays set, advisor round 5; list_cap = 5: a list that overflows by its count)"""
     ds = _shuffled_with_duplicates(Dataset(n, g, seed), seed)
     st = parity.oracle_stages(ds)
     assert st["valid"].sum() < len(st["valid"])                  # duplicates were found
     ctx = hip_ctx_factory()
+    ctx.set_option("debug_dedupe_list_cap", list_cap)
+    ctx.set_reads(ds.read_len)
+    ctx.set_overlaps(ds.overlaps)
+    ctx.initialize()
+    parity.check_initialize(ctx, st, ds)
+    ctx.construct()
+    parity.check_construct(ctx, st)
+    parity.check_tr(ctx, st)
+
+
+def _few_duplicates(ds, seed):
+    """the file as it is (grouped by query), one record in five hundred repeated right behind itself with another length: the
+    counting pass marks a run here and there and lists the marks"""
+    from rala_amd.synth import Overlaps, FIELDS
+
+    rng = np.random.default_rng(seed)
+    ov = ds.overlaps
+    n = len(ov)
+    dup = np.nonzero(rng.random(n) < 0.002)[0]
+    idx = np.sort(np.concatenate([np.arange(n), dup]), kind="stable")
+    kw = {f: getattr(ov, f)[idx].copy() for f in FIELDS}
+    second = np.r_[False, idx[1:] == idx[:-1]]
+    kw["length"][second] += rng.integers(0, 3, size=int(second.sum())).astype(np.uint32)
+
+    class _D:
+        pass
+    d = _D()
+    d.overlaps = Overlaps(strand=ov.strand[idx].copy(), **kw)
+    d.read_len = ds.read_len
+    d.n_reads = ds.n_reads
+    return d
+
+
+@pytest.mark.parametrize("list_cap", [0, 1, 7])
+def test_few_duplicates_mark_list(hip_ctx_factory, list_cap):
+    """duplicate removal inside the bucketing's counting pass: the marked runs redone from the list (list_cap 0 = 2^20 marks), and
+    a list that does not hold its marks given up for the pass over all overlaps"""
+    ds = _few_duplicates(Dataset(3000, 600_000, 21), 5)
+    st = parity.oracle_stages(ds)
+    assert 0 < len(st["valid"]) - st["valid"].sum() < len(st["valid"]) // 100
+    ctx = hip_ctx_factory()
+    ctx.set_option("debug_dedupe_list_cap", list_cap)
     ctx.set_reads(ds.read_len)
     ctx.set_overlaps(ds.overlaps)
     ctx.initialize()

@@ -1,0 +1,41 @@
+"""Measurement: variants of the first pile kernel compared INSIDE one process - the same context, the same allocations, the
+variants alternating step by step (option debug_pile_variant; the library built with RALA_HIPCC_FLAGS=-DRALA_PILE_AB carries them).
+
+    python tools/pile_ab.py [workload] [variants, comma separated] [rounds] [steps per round]
+
+Prints per variant the pile chain's time (HIP events around its launches) of every round, their minimum and median."""
+import os
+import statistics
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from rala_amd import hip
+from rala_amd.synth import Dataset
+
+wl = sys.argv[1] if len(sys.argv) > 1 else "c3"
+variants = [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "0,3").split(",")]
+rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 6
+steps = int(sys.argv[4]) if len(sys.argv) > 4 else 5
+ds = Dataset.config(wl)
+ctx = hip.Context(0)
+ctx.set_reads(ds.read_len)
+ctx.set_overlaps(ds.overlaps)
+for _ in range(2):
+    ctx.initialize()
+per = {v: [] for v in variants}
+for r in range(rounds):
+    order = variants if r % 2 == 0 else variants[::-1]
+    for v in order:
+        ctx.set_option("debug_pile_variant", v)
+        tot = 0.0
+        for _ in range(steps):
+            ctx.initialize()
+            tot += ctx.timings()["pile_ms"]
+        per[v].append(tot / steps)
+ctx.set_option("debug_pile_variant", 0)
+ctx.initialize()
+ctx.construct()
+print("transitive pairs", ctx.remove_transitive_edges())
+for v in variants:
+    x = per[v]
+    print("variant %d: pile min %.3f median %.3f | %s" % (v, min(x), statistics.median(x), " ".join("%.3f" % t for t in x)))
