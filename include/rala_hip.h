@@ -136,6 +136,13 @@ typedef struct rala_hip_ingest_timings {
 int rala_hip_set_name_table(rala_hip_ctx* ctx, const void* buckets, uint64_t n_buckets, const char* arena, uint64_t arena_bytes);
 int rala_hip_set_overlaps_from_paf(rala_hip_ctx* ctx, const char* path, int check_lengths, uint32_t threads,
                                    int64_t* length_error_read, int* irregular);
+/* The same for an uncompressed MHAP file (round 6): bioparser's MhapParser and the MHAP constructor of Overlap
+ * (src/overlap.cpp:12-20) - twelve blank-separated columns "a_id b_id error minmers a_rc a_begin a_end a_length b_rc b_begin
+ * b_end b_length", all numbers: id = the column minus one (ids are counted from 1; one that names no read does not
+ * resolve), length = the longer of the two spans, strand = a_rc != b_rc, the length check of Overlap::transmute on columns
+ * 8 and 12.  No name table is needed.  *irregular as above (fewer than twelve columns, ...). */
+int rala_hip_set_overlaps_from_mhap(rala_hip_ctx* ctx, const char* path, int check_lengths, uint32_t threads,
+                                    int64_t* length_error_read, int* irregular);
 int rala_hip_get_ingest_timings(rala_hip_ctx* ctx, rala_hip_ingest_timings* out);
 /* The sensitive overlaps (rala -s; Graph::preprocess, src/graph.cpp:901-939) of an uncompressed PAF file the same way, without
  * the length check (Overlap::transmute_ has none, src/overlap.cpp:84-114): the lines that start in bytes [lo, hi) of the file

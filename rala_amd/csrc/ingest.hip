@@ -79,7 +79,7 @@ int rala_hip::paf_tokenise_range(rala_hip_ctx* ctx, const char* path, uint64_t l
     if (!ctx || !path || !out) return RALA_HIP_EINVAL;
     *out = PafRange();
     if (ctx->n_reads == 0) return ingest_fail(ctx, RALA_HIP_EINVAL, "no reads set");
-    if (ctx->n_name_buckets == 0) return ingest_fail(ctx, RALA_HIP_EINVAL, "no name table set (rala_hip_set_name_table)");
+    if (ctx->n_name_buckets == 0 && !T.mhap) return ingest_fail(ctx, RALA_HIP_EINVAL, "no name table set (rala_hip_set_name_table)");
     INGEST_CHECK(hipSetDevice(ctx->device));
     struct Fd {                                     // (closed on every way out - ADVICE round 4)
         int fd = -1;
@@ -198,9 +198,9 @@ int rala_hip::paf_tokenise_range(rala_hip_ctx* ctx, const char* path, uint64_t l
         PafColumns cols;
         cols.a_id = T.col[0]->p; cols.b_id = T.col[1]->p; cols.a_begin = T.col[2]->p; cols.a_end = T.col[3]->p;
         cols.b_begin = T.col[4]->p; cols.b_end = T.col[5]->p; cols.length = T.col[6]->p; cols.strand = T.strand->p;
-        launch_paf_parse(text, n, n_avail, first_is_start, ctx->d_paf_chunk[1].p, ctx->d_name_buckets.p, ctx->n_name_buckets,
+        launch_paf_parse(text, n, n_avail, first_is_start, ctx->d_paf_chunk[1].p, ctx->d_name_buckets.p, std::max<uint64_t>(ctx->n_name_buckets, 1),
                          (const char*)ctx->d_name_arena.p, ctx->d_read_len.p, (uint32_t)ctx->n_reads, check_lengths, cols,
-                         (uint32_t*)(ctx->d_paf_bad.p + 1), ctx->d_paf_bad.p, s);
+                         (uint32_t*)(ctx->d_paf_bad.p + 1), ctx->d_paf_bad.p, s, T.mhap);
         unsigned long long back[2] = {0, 0};
         INGEST_CHECK(hipMemcpyAsync(back, ctx->d_paf_bad.p, 16, hipMemcpyDeviceToHost, s));
         INGEST_CHECK(hipStreamSynchronize(s));
@@ -240,8 +240,21 @@ int rala_hip_set_name_table(rala_hip_ctx* ctx, const void* buckets, uint64_t n_b
     return RALA_HIP_OK;
 }
 
+static int set_overlaps_from_text(rala_hip_ctx* ctx, const char* path, bool mhap, int check_lengths, uint32_t threads,
+                                  int64_t* length_error_read, int* irregular);
+
 int rala_hip_set_overlaps_from_paf(rala_hip_ctx* ctx, const char* path, int check_lengths, uint32_t threads,
                                    int64_t* length_error_read, int* irregular) {
+    return set_overlaps_from_text(ctx, path, false, check_lengths, threads, length_error_read, irregular);
+}
+
+int rala_hip_set_overlaps_from_mhap(rala_hip_ctx* ctx, const char* path, int check_lengths, uint32_t threads,
+                                    int64_t* length_error_read, int* irregular) {
+    return set_overlaps_from_text(ctx, path, true, check_lengths, threads, length_error_read, irregular);
+}
+
+static int set_overlaps_from_text(rala_hip_ctx* ctx, const char* path, bool mhap, int check_lengths, uint32_t threads,
+                                  int64_t* length_error_read, int* irregular) {
     if (!ctx || !path || !length_error_read || !irregular) return RALA_HIP_EINVAL;
     *length_error_read = -1;
     *irregular = 0;
@@ -254,6 +267,7 @@ int rala_hip_set_overlaps_from_paf(rala_hip_ctx* ctx, const char* path, int chec
     PafTarget T;
     for (int k = 0; k < 7; ++k) T.col[k] = &ctx->d_paf_col[k];
     T.strand = &ctx->d_paf_strand;
+    T.mhap = mhap;
     PafRange R;
     // The file's text goes through device memory in WINDOWS (round 5; before, all of it had to fit at once): at most a
     // quarter of what is free (option ingest_window_bytes; the reference streams the file in chunks of 1 GiB,
@@ -276,6 +290,7 @@ int rala_hip_set_overlaps_from_paf(rala_hip_ctx* ctx, const char* path, int chec
         PafTarget W;
         for (int k = 0; k < 7; ++k) W.col[k] = &ctx->d_paf_win[k];
         W.strand = &ctx->d_paf_win_strand;
+        W.mhap = mhap;
         uint64_t rows = 0;
         float ship = 0, tok = 0;
         for (uint64_t lo = 0; lo < file_n; lo += window) {

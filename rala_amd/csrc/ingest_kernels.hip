@@ -1,4 +1,4 @@
-// PAF text -> binary overlap columns on the device.
+// PAF (and MHAP) text -> binary overlap columns on the device.
 //
 // Replaces, for an uncompressed PAF file, the tokeniser in front of Graph::initialize (reference src/graph.cpp:328-352:
 // bioparser's PAF parser, one heap Overlap per line, and Overlap::transmute's two hash look-ups, src/overlap.cpp:36-82).
@@ -119,6 +119,11 @@ __device__ __forceinline__ uint32_t find_name(const NameTableDev& T, const uint8
     }
 }
 
+// kMhap: the file is MHAP (reference src/overlap.cpp:12-20; bioparser's MhapParser in front of it): twelve blank-separated columns
+// "a_id b_id error minmers a_rc a_begin a_end a_length b_rc b_begin b_end b_length", all numbers, ids from 1 - no names to look up;
+// id = the column minus one (a value beyond the reads does not resolve), length = the longer of the two spans, strand = a_rc !=
+// b_rc: the columns rala::io::read_overlaps_streamed gives for such a file (parse_mhap_line, io.cpp).  Column 12 ends with the line.
+template <bool kMhap>
 __global__ __launch_bounds__(kBlock) void paf_parse_kernel(const uint8_t* __restrict__ text, uint64_t n, uint64_t n_avail, uint32_t first_is_start,
                                                             const uint32_t* __restrict__ chunk_row,
                                                            NameTableDev names, const uint32_t* __restrict__ read_len, uint32_t n_reads,
@@ -176,8 +181,14 @@ __global__ __launch_bounds__(kBlock) void paf_parse_kernel(const uint8_t* __rest
         while (p < limit && nt < 11) {
             const uint8_t ch = win[p];
             if (ch == '\n') break;
-            if (ch == '\t') tab[nt++] = p;
+            if (ch == (kMhap ? ' ' : '\t')) tab[nt++] = p;
             ++p;
+        }
+        if (kMhap && nt == 11) {
+            // the twelfth column is read up to the line's end: that end (or the thirteenth column's blank) within the window
+            uint32_t q = p;
+            while (q < limit && win[q] != '\n' && win[q] != ' ') ++q;
+            if (q >= limit) { atomicOr(flags, 4u); continue; }
         }
         if (nt < 11) {
             // fewer than 12 columns, or the first eleven reach beyond the halo: the host reader's business
@@ -197,6 +208,35 @@ __global__ __launch_bounds__(kBlock) void paf_parse_kernel(const uint8_t* __rest
             for (uint32_t i = b; i < e; ++i) if (win[i] == ' ') return i;
             return e;
         };
+        if constexpr (kMhap) {
+            auto id_of = [&](uint32_t b, uint32_t e) {            // the column's leading digits as a 64-bit number, minus one (ids from 1)
+                uint64_t x = 0;
+                for (uint32_t i = b; i < e; ++i) {
+                    const uint32_t d = (uint32_t)win[i] - (uint32_t)'0';
+                    if (d > 9u) break;
+                    x = x * 10u + d;
+                }
+                x -= 1;
+                return x < (uint64_t)n_reads ? (uint32_t)x : 0xFFFFFFFFu;
+            };
+            const uint32_t ia = id_of(s, tab[0]), ib = id_of(tab[0] + 1, tab[1]);
+            const uint32_t a_rc = number(tab[3] + 1, tab[4]), ab = number(tab[4] + 1, tab[5]), ae = number(tab[5] + 1, tab[6]);
+            const uint32_t al = number(tab[6] + 1, tab[7]), b_rc = number(tab[7] + 1, tab[8]), bb = number(tab[8] + 1, tab[9]);
+            const uint32_t be = number(tab[9] + 1, tab[10]), bl = number(tab[10] + 1, limit);
+            const uint32_t row = row0 + li;
+            out.a_id[row] = ia; out.b_id[row] = ib;
+            out.a_begin[row] = ab; out.a_end[row] = ae;
+            out.b_begin[row] = bb; out.b_end[row] = be;
+            out.length[row] = (ae - ab) > (be - bb) ? ae - ab : be - bb;           // (no alignment length in the file: the longer span, overlap.cpp:18)
+            out.strand[row] = a_rc == b_rc ? 0 : 1;
+            if (check_lengths) {
+                uint32_t bad = 0xFFFFFFFFu;
+                if (ia != 0xFFFFFFFFu && al != read_len[ia]) bad = ia;
+                else if (ia != 0xFFFFFFFFu && ib != 0xFFFFFFFFu && bl != read_len[ib]) bad = ib;
+                if (bad != 0xFFFFFFFFu) atomicMin(first_bad, ((unsigned long long)row << 32) | bad);
+            }
+            continue;
+        }
         const uint32_t qn = name_end(s, tab[0]) - s;
         const uint32_t ql = number(tab[0] + 1, tab[1]);
         const uint32_t qb = number(tab[1] + 1, tab[2]);
@@ -239,12 +279,15 @@ void launch_paf_count(const uint8_t* text, uint64_t n, bool first_is_start, uint
 
 void launch_paf_parse(const uint8_t* text, uint64_t n, uint64_t n_avail, bool first_is_start, const uint32_t* chunk_row, const void* buckets, uint64_t n_buckets,
                       const char* arena, const uint32_t* read_len, uint32_t n_reads, bool check_lengths, const PafColumns& out,
-                      uint32_t* flags, unsigned long long* first_bad, hipStream_t s) {
+                      uint32_t* flags, unsigned long long* first_bad, hipStream_t s, bool mhap) {
     const uint32_t chunks = (uint32_t)((n + kChunk - 1) / kChunk);
     NameTableDev T;
     T.bucket = (const NameBucket*)buckets; T.arena = arena; T.mask = n_buckets - 1;
-    if (chunks) {
-        hipLaunchKernelGGL(paf_parse_kernel, dim3(chunks), dim3(kBlock), 0, s, text, n, n_avail, first_is_start ? 1u : 0u, chunk_row, T, read_len, n_reads,
+    if (chunks && mhap) {
+        hipLaunchKernelGGL(paf_parse_kernel<true>, dim3(chunks), dim3(kBlock), 0, s, text, n, n_avail, first_is_start ? 1u : 0u, chunk_row, T, read_len, n_reads,
+                           check_lengths ? 1u : 0u, out, flags, first_bad);
+    } else if (chunks) {
+        hipLaunchKernelGGL(paf_parse_kernel<false>, dim3(chunks), dim3(kBlock), 0, s, text, n, n_avail, first_is_start ? 1u : 0u, chunk_row, T, read_len, n_reads,
                            check_lengths ? 1u : 0u, out, flags, first_bad);
     }
 }

@@ -479,10 +479,11 @@ uint32_t paf_halo_bytes();      // bytes behind a range's last own byte that its
 void launch_paf_count(const uint8_t* text, uint64_t n, bool first_is_start, uint32_t* chunk_lines, hipStream_t s);
 // chunk_row: the exclusive scan of the counts; flags (zeroed): 1 a line with fewer than 12 columns, 2 more lines in a chunk than
 // records can make, 4 a line whose first eleven columns reach beyond the halo; first_bad (all ones): row << 32 | read of the
-// first record whose length differs from its sequence's
+// first record whose length differs from its sequence's; mhap: twelve blank-separated numeric columns (reference overlap.cpp:12-20),
+// no name table
 void launch_paf_parse(const uint8_t* text, uint64_t n, uint64_t n_avail, bool first_is_start, const uint32_t* chunk_row, const void* buckets,
                       uint64_t n_buckets, const char* arena, const uint32_t* read_len, uint32_t n_reads, bool check_lengths,
-                      const PafColumns& out, uint32_t* flags, unsigned long long* first_bad, hipStream_t s);
+                      const PafColumns& out, uint32_t* flags, unsigned long long* first_bad, hipStream_t s, bool mhap = false);
 
 // ---- scans (scan_kernels.hip) --------------------------------------------------
 // exclusive prefix sum of n uint32 values; out may alias in; out[n] receives the total

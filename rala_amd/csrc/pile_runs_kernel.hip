@@ -624,7 +624,10 @@ __device__ __forceinline__ void expand_from_bitmap(uint32_t* sm, const uint16_t*
 // that two builds of the kernel are compared INSIDE one process, on the same allocations, step by step - a library built with
 // -DRALA_PILE_AB carries them (round 6: two processes with the same binary differed by 12 % in this kernel's time, two binaries in
 // alternating processes by less).  Bit 0: the loop over the items as it was; bit 1: the events by ordinary loads; bit 2: the
-// arguments fetched where they are first used.
+// arguments fetched where they are first used; bits 3 - 7: that many s_nop at the kernel's start (the code behind them moves by four
+// bytes each: placement); bits 8 - 10: work ADDED behind the expansion, for the sensitivity of the kernel's time to each kind of
+// it - 1: 128 independent vector instructions, 2: 128 scalar ones, 3: 1024 cycles asleep, 4: 32 LDS reads and their wait, 5: 512
+// vector instructions.
 template <uint32_t kCap, bool kDiag, int kSens, bool kOne = false, uint32_t kBases = 16384, uint32_t kWaves = 1, bool kPlain = false, uint32_t kVar = 0>
 __global__ __launch_bounds__(64 * kWaves, kOne ? 7 : kBases > 32768 ? 2 : kBases > 16384 ? 4 : 5) void pile_runs_kernel(PileArgs A, uint32_t* overflow_list, uint32_t* overflow_count) {
     static_assert(kWaves == 1 || kOne, "several reads per workgroup: the first kernel of a chain only");
@@ -633,6 +636,15 @@ __global__ __launch_bounds__(64 * kWaves, kOne ? 7 : kBases > 32768 ? 2 : kBases
     static_assert(kBases == 16384 || !kOne, "the bigger bitmap belongs to the chain's second kernel");
     // (round 5: the sensitive pass's cap-1024 kernels too - their reads have at most 16384 bases; 14 296 -> 9 840 B of LDS, sixteen
     // workgroups per compute unit instead of eleven, and at C5 this is the kernel nearly every target starts in)
+    if constexpr (((kVar >> 3) & 31u) != 0) asm volatile(".rept %0\n\ts_nop 0\n\t.endr" : : "n"((kVar >> 3) & 31u));
+    // bits 11 - 12: something in front of a wavefront's first load - 1: 128 cycles asleep, 2: 64 vector instructions, 3: 512 cycles
+    if constexpr (((kVar >> 11) & 3u) == 1) asm volatile("s_sleep 2");
+    if constexpr (((kVar >> 11) & 3u) == 3) asm volatile("s_sleep 8");
+    if constexpr (((kVar >> 11) & 3u) == 2) {
+        uint32_t d0 = threadIdx.x, d1 = threadIdx.x + 1;
+        asm volatile(".rept 32\n\tv_add_u32 %0, 1, %0\n\tv_add_u32 %1, 1, %1\n\t.endr" : "+v"(d0), "+v"(d1));
+        if (d0 + d1 == 0x7FFFFFFFu && A.n_items == 0xFFFFFFFFu) overflow_list[0] = d0;
+    }
     constexpr bool kSingleItem = kOne && kWaves > 1 && !(kVar & 1u);
     constexpr bool kSingleItemArgs = kSingleItem && !(kVar & 4u);
     constexpr bool kBufferEvents = kSens == 0 && !(kVar & 2u);
@@ -679,6 +691,13 @@ __global__ __launch_bounds__(64 * kWaves, kOne ? 7 : kBases > 32768 ? 2 : kBases
         item_first = xcd * per + blockIdx.x / 8u;
         item_end = umin(n_items, (xcd + 1u) * per);
         item_step = gridDim.x / 8u;
+    }
+    // kVar bit 13: every XCD writes ONE contiguous range of the rows (workgroup i runs on XCD i % 8 and takes the reads
+    // (i % 8) * per + 2 (i / 8) + wavefront; launched with 4 * per workgroups, per = the reads of an XCD, even)
+    if constexpr ((kVar & 8192u) != 0) {
+        const uint32_t per = ((n_items + 15u) / 16u) * 2u, xcd = blockIdx.x & 7u, j = (blockIdx.x >> 3) * kWaves + wave_in_group;
+        item_first = xcd * per + j;
+        item_end = j < per ? umin(n_items, (xcd + 1u) * per) : 0u;
     }
     // (Round 4 carried a persistent variant of the first kernel here - as many workgroups as the chip holds, the next read's
     // events requested one read ahead by inline assembly into registers the compiler did not know of, the annotation stores
@@ -1150,6 +1169,27 @@ __global__ __launch_bounds__(64 * kWaves, kOne ? 7 : kBases > 32768 ? 2 : kBases
             }
         }
         wave_sync();
+        if constexpr (((kVar >> 8) & 7u) != 0) {
+            constexpr uint32_t kKind = (kVar >> 8) & 7u;
+            uint32_t x0 = lane, x1 = lane + 1, x2 = lane + 2, x3 = lane + 3;
+            if constexpr (kKind == 1 || kKind == 5) {
+                asm volatile(".rept %4\n\tv_add_u32 %0, 1, %0\n\tv_add_u32 %1, 1, %1\n\tv_add_u32 %2, 1, %2\n\tv_add_u32 %3, 1, %3\n\t.endr"
+                             : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "n"(kKind == 1 ? 32 : 128));
+            } else if constexpr (kKind == 2) {
+                uint32_t s0 = n, s1 = R, s2 = n_ev, s3 = r;
+                asm volatile(".rept 32\n\ts_add_u32 %0, %0, 1\n\ts_add_u32 %1, %1, 1\n\ts_add_u32 %2, %2, 1\n\ts_add_u32 %3, %3, 1\n\t.endr"
+                             : "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3) : : "scc");
+                x0 += s0 + s1 + s2 + s3;
+            } else if constexpr (kKind == 3) {
+                asm volatile("s_sleep 16" : : : "memory");
+            } else if constexpr (kKind == 4) {
+                uint32_t acc = 0;
+                for (uint32_t t = 0; t < 32; ++t) acc += ((volatile uint32_t*)sm)[(lane + 64u * t) & 511u];
+                x0 += acc;
+            }
+            // (the results must be wanted: a store that never happens)
+            if (x0 + x1 + x2 + x3 == 0x12345u && n == 0xFFFFFFFFu) A.begin[r] = x0;
+        }
 
         RUN_STOP(31)
 
@@ -1849,14 +1889,17 @@ void launch_pile_runs(const PileArgs& args, uint32_t grid, int tier, uint32_t* o
                                                             extra_lds, stream, args, overflow_list, overflow_count);
         else if (waves == 2 && !persist && !args.order && !args.ev_cnt && !getenv("RALA_PILE_NOT_PLAIN")) {
 #define RALA_LAUNCH_PRODUCT(var)                                                                                                  \
-            hipLaunchKernelGGL((pile_runs_kernel<kRunEventCap, false, 0, true, 16384, 2, true, var>), dim3((grid + 1) / 2), dim3(128), \
+            hipLaunchKernelGGL((pile_runs_kernel<kRunEventCap, false, 0, true, 16384, 2, true, var>),                            \
+                               dim3(((var) & 8192u) ? 4u * (((args.n_items + 15u) / 16u) * 2u) : (grid + 1) / 2), dim3(128),    \
                                extra_lds, stream, args, overflow_list, overflow_count)
 #ifdef RALA_PILE_AB
+#ifndef RALA_PILE_AB_CASES          // (-DRALA_PILE_AB_CASES="X(8) X(11)": the variants a measurement build carries beside 0)
+#define RALA_PILE_AB_CASES X(1) X(2) X(3) X(4)
+#endif
             switch (args.variant) {
-                case 1: RALA_LAUNCH_PRODUCT(1); break;
-                case 2: RALA_LAUNCH_PRODUCT(2); break;
-                case 3: RALA_LAUNCH_PRODUCT(3); break;
-                case 4: RALA_LAUNCH_PRODUCT(4); break;
+#define X(v) case v: RALA_LAUNCH_PRODUCT(v); break;
+                RALA_PILE_AB_CASES
+#undef X
                 default: RALA_LAUNCH_PRODUCT(0); break;
             }
 #else

@@ -1039,11 +1039,14 @@ int preprocess_repeats(rala_hip_ctx* cs, rala_hip_ctx* cl, Comm* comm, const ral
     pa.rep_pool = cl->d_rep_pool.p; pa.rep_pool_count = cl->d_small.p + 6; pa.rep_pool_cap = cl->rep_pool_cap;
     // add_layers on top of the coverage + find_median for the targets (graph.cpp:941-969)
     int rc = run_sens_pass(cl, pa, a, 1, cl->d_sens_list.p, (uint32_t)nl, cl->d_chain_cnt.p + 4, &n_targets, small);
-    if (rc != RALA_HIP_OK) { if (cl != cs) cs->err = cl->err; return rc; }
     if (!sharded) {
-        const int rcb = check_records();
+        // (the record check came back with the pass' first look; when the pass itself failed, a record that is an error is the
+        // failure to report - the pass ran over what such records left behind: advisor round 5)
+        const bool looked = rc == RALA_HIP_OK || stream_sync(cs, s) == hipSuccess;
+        const int rcb = looked ? check_records() : (int)RALA_HIP_OK;
         if (rcb != RALA_HIP_OK) return rcb;
     }
+    if (rc != RALA_HIP_OK) { if (cl != cs) cs->err = cl->err; return rc; }
     if (sharded) {
         // the new medians, everywhere
         HIPCHECK(cs->d_gather[0].ensure(nl_pad * 4 + 16));
@@ -2099,6 +2102,7 @@ int rala_hip::install_read_state(rala_hip_ctx* ctx, uint64_t pool_count) {
     if (ctx->n_ovl && !ctx->valid_ready) return fail(ctx, RALA_HIP_EINVAL, "validity bits required (rala_hip_dedupe)");
     if (pool_count > ctx->pool_cap) return fail(ctx, RALA_HIP_ECAPACITY, "interval pool smaller than the installed state");
     HIPCHECK(hipSetDevice(ctx->device));
+    { const int rcu = flush_upload(ctx); if (rcu != RALA_HIP_OK) return rcu; }
     hipStream_t s = ctx->stream;
     ctx->tm = rala_hip_timings();
     ctx->overlaps.clear(); ctx->internals.clear();
@@ -2295,8 +2299,20 @@ int rala_hip_set_overlaps(rala_hip_ctx* ctx, const rala_hip_overlaps* o, uint64_
         // (made when first asked for: a process has few hardware queues - four by default - and its streams share them; a
         // stream that is not used must not push a context's main and aux streams onto one queue.  It did, in the sharded
         // runner's owner contexts: their small pile kernels ran in front of the big one instead of beside it, +0.13 ms at C3)
-        HIPCHECK(hipStreamCreate(&ctx->copy));
-        for (auto& e : ctx->ev_up) HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        // (all or nothing: a stream whose events could not all be made would leave later calls with null events - advisor round 5)
+        hipStream_t made = nullptr;
+        HIPCHECK(hipStreamCreate(&made));
+        hipError_t bad = hipSuccess;
+        for (auto& e : ctx->ev_up) {
+            e = nullptr;
+            if (bad == hipSuccess) bad = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        }
+        if (bad != hipSuccess) {
+            for (auto& e : ctx->ev_up) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+            (void)hipStreamDestroy(made);
+            HIPCHECK(bad);
+        }
+        ctx->copy = made;
     }
     ctx->n_ovl = n;
     const uint32_t* src[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -2827,6 +2843,9 @@ int rala_hip_import_state_device(rala_hip_ctx* ctx, const rala_hip_device_state*
     if (ctx->n_ovl && !in->valid) return fail(ctx, RALA_HIP_EINVAL, "valid bits required");
     if (in->pool_count && !in->pool) return RALA_HIP_EINVAL;
     HIPCHECK(hipSetDevice(ctx->device));
+    // (columns handed over with RALA_HIP_MEM_HOST_ASYNC leave inside rala_hip_initialize; a caller that installs the read state
+    // instead must not find them still on the host - advisor round 5)
+    { const int rcu = flush_upload(ctx); if (rcu != RALA_HIP_OK) return rcu; }
     hipStream_t s = ctx->stream;
     const uint64_t n = ctx->n_reads;
     ctx->tm = rala_hip_timings();
@@ -2991,6 +3010,7 @@ int rala_hip_construct(rala_hip_ctx* ctx, const rala_hip_overlaps* sens, uint64_
     }
     ctx->have_repeats = false;
     HIPCHECK(hipSetDevice(ctx->device));
+    { const int rcu = flush_upload(ctx); if (rcu != RALA_HIP_OK) return rcu; }
     hipStream_t s = ctx->stream;
     const uint32_t n_reads = (uint32_t)ctx->n_reads;
     const uint64_t N = ctx->n_ovl;

@@ -317,7 +317,9 @@ int run_primary(rala_hip_mg* mg, bool with_sens) {
             if (p < mg->rank) mine_at += send_counts[p];
             blocks.off[p] = (uint32_t)at;
             if (recv_counts[p] < geom.header) {           // (every block starts with its header)
-                mg->verdict_shared = true;
+                // (seen by this rank alone - the others' blocks may be whole: the verdict is NOT shared, the caller ends the group
+                // instead of leaving the others waiting for this rank at their next agreement; advisor round 5)
+                mg->verdict_shared = false;
                 return mg_fail(mg, RALA_HIP_EDEVICE, "a block shorter than its header");
             }
             n_records += recv_counts[p] - geom.header;
@@ -634,7 +636,12 @@ int ingest_paf(rala_hip_mg* mg, const char* path, int check_lengths, uint32_t th
         if (move[p]) final_rows[dest[p]] += move[p];
     }
     for (uint32_t p = 1; p < P; ++p) first_pos[p] = first_pos[p - 1] + final_rows[p - 1];
-    if (first_pos[P - 1] + final_rows[P - 1] >= 0xFFFFFFF0ull) return mg_fail(mg, RALA_HIP_ETOOLARGE, "file positions must fit 32 bits");
+    if (first_pos[P - 1] + final_rows[P - 1] >= 0xFFFFFFF0ull) {
+        // (computed from the exchanged counts: the same answer on every rank - a shared verdict, the group stays usable and the host
+        // readers' way into rala_hip_mg_set_overlaps can follow; advisor round 5)
+        mg->verdict_shared = true;
+        return mg_fail(mg, RALA_HIP_ETOOLARGE, "file positions must fit 32 bits");
+    }
     // the rows in front of the cuts travel, column by column
     std::vector<uint64_t> send_counts(P, 0), recv_counts(P, 0);
     if (move[me]) send_counts[dest[me]] = move[me];

@@ -41,6 +41,7 @@ int set_bound_blocks(rala_hip_ctx* ctx, const uint64_t* base, const uint64_t* ba
 struct PafTarget {
     DevBuf<uint32_t>* col[7];       // a_id, b_id, a_begin, a_end, b_begin, b_end, length
     DevBuf<uint8_t>* strand;
+    bool mhap = false;              // the file is MHAP: twelve blank-separated numeric columns, no names
 };
 struct PafRange {
     uint64_t n_lines = 0;

@@ -30,7 +30,7 @@ SYMBOLS = (
     "rala_hip_bound_records_fit", "rala_hip_emit_bound_records_bucketed", "rala_hip_set_bound_records",
     "rala_hip_copy_device_state", "rala_hip_layout", "rala_hip_find_repetitive_hills",
     "rala_hip_mg_unique_id", "rala_hip_mg_local_group_create", "rala_hip_mg_local_group_destroy", "rala_hip_mg_create",
-    "rala_hip_mg_create_contexts", "rala_hip_mg_join", "rala_hip_set_name_table", "rala_hip_set_overlaps_from_paf",
+    "rala_hip_mg_create_contexts", "rala_hip_mg_join", "rala_hip_set_name_table", "rala_hip_set_overlaps_from_paf", "rala_hip_set_overlaps_from_mhap",
     "rala_hip_get_ingest_timings", "rala_hip_get_overlap_columns", "rala_hip_tokenise_sensitive_paf",
     "rala_hip_mg_set_overlaps_from_paf", "rala_hip_mg_get_slice",
     "rala_hip_mg_destroy", "rala_hip_mg_last_error", "rala_hip_mg_set_reads", "rala_hip_mg_slice_cuts",

@@ -264,7 +264,10 @@ void Graph::initialize() {
     // RALA_DEVICE_INGEST=0 keeps the host reader).  A file that tokeniser calls irregular - or cannot take: no regular file,
     // too large for its 32-bit counts, no room for its text in device memory - falls through to the host reader, which knows
     // what to do with such files (a FIFO named *.paf used to end with "unable to open file").
-    const bool device_ingest = io::has_suffix(overlaps_path_, ".paf") && !(getenv("RALA_DEVICE_INGEST") && atoi(getenv("RALA_DEVICE_INGEST")) == 0);
+    // (round 6: an uncompressed MHAP file too - twelve numeric columns, no names to look up; one GPU - several take the host reader)
+    const bool mhap_text = io::has_suffix(overlaps_path_, ".mhap");
+    const bool device_ingest = (io::has_suffix(overlaps_path_, ".paf") || (mhap_text && ranks_.empty())) &&
+                               !(getenv("RALA_DEVICE_INGEST") && atoi(getenv("RALA_DEVICE_INGEST")) == 0);
     auto falls_back = [](int rc) { return rc == RALA_HIP_ENOTAFILE || rc == RALA_HIP_ETOOLARGE || rc == RALA_HIP_ENOMEM; };
     auto length_error = [](int64_t bad) {
         fprintf(stderr, "[rala::Overlap::transmute] error: "
@@ -277,7 +280,8 @@ void Graph::initialize() {
                                             name_table_.arena().size()), "initialize");
         int64_t bad = -1;
         int irregular = 0;
-        const int rc = rala_hip_set_overlaps_from_paf(ctx_, overlaps_path_.c_str(), 1, std::max(1u, num_threads_), &bad, &irregular);
+        const int rc = mhap_text ? rala_hip_set_overlaps_from_mhap(ctx_, overlaps_path_.c_str(), 1, std::max(1u, num_threads_), &bad, &irregular)
+                                 : rala_hip_set_overlaps_from_paf(ctx_, overlaps_path_.c_str(), 1, std::max(1u, num_threads_), &bad, &irregular);
         if (rc == RALA_HIP_EINVAL && !irregular) {
             // (cannot open: the reference's message)
             fprintf(stderr, "[rala::Graph::initialize] error: unable to open file %s!\n", overlaps_path_.c_str());

@@ -135,23 +135,34 @@ struct PafOnDevice {
     rala_hip_ingest_timings tm = {};
 };
 
+static void* text_on_device(const char* path, const char* names, const uint32_t* read_len, uint64_t n_reads, int check_lengths, uint32_t threads, bool mhap);
 void* hp_paf_device(const char* path, const char* names, const uint32_t* read_len, uint64_t n_reads, int check_lengths, uint32_t threads) {
+    return text_on_device(path, names, read_len, n_reads, check_lengths, threads, false);
+}
+// (an MHAP file names its reads by number: no name table)
+void* hp_mhap_device(const char* path, const uint32_t* read_len, uint64_t n_reads, int check_lengths, uint32_t threads) {
+    return text_on_device(path, "", read_len, n_reads, check_lengths, threads, true);
+}
+static void* text_on_device(const char* path, const char* names, const uint32_t* read_len, uint64_t n_reads, int check_lengths, uint32_t threads, bool mhap) {
     std::vector<std::string> nm;
     const char* p = names;
-    for (uint64_t i = 0; i < n_reads; ++i) {
+    for (uint64_t i = 0; i < n_reads && !mhap; ++i) {
         const char* e = strchr(p, '\n');
         nm.emplace_back(p, e ? (size_t)(e - p) : strlen(p));
         p = e ? e + 1 : p + strlen(p);
     }
     rala::io::NameTable table;
-    table.build(nm);
+    if (!mhap) table.build(nm);
     auto* out = new PafOnDevice();
     rala_hip_ctx* ctx = nullptr;
     out->rc = rala_hip_create(0, &ctx);
     if (out->rc != RALA_HIP_OK) return out;
     out->rc = rala_hip_set_reads(ctx, read_len, n_reads);
-    if (out->rc == RALA_HIP_OK) out->rc = rala_hip_set_name_table(ctx, table.buckets(), table.n_buckets(), table.arena().data(), table.arena().size());
-    if (out->rc == RALA_HIP_OK) out->rc = rala_hip_set_overlaps_from_paf(ctx, path, check_lengths, threads, &out->bad, &out->irregular);
+    if (out->rc == RALA_HIP_OK && !mhap) out->rc = rala_hip_set_name_table(ctx, table.buckets(), table.n_buckets(), table.arena().data(), table.arena().size());
+    if (out->rc == RALA_HIP_OK) {
+        out->rc = mhap ? rala_hip_set_overlaps_from_mhap(ctx, path, check_lengths, threads, &out->bad, &out->irregular)
+                       : rala_hip_set_overlaps_from_paf(ctx, path, check_lengths, threads, &out->bad, &out->irregular);
+    }
     if (out->rc == RALA_HIP_OK) rala_hip_get_ingest_timings(ctx, &out->tm);
     if (out->rc == RALA_HIP_OK && !out->irregular && out->bad < 0) {
         out->rc = rala_hip_get_overlap_columns(ctx, &out->n, nullptr, nullptr);

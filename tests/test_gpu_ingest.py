@@ -24,6 +24,8 @@ def _lib():
     L = ctypes.CDLL(os.path.join(ROOT, "rala_amd", "host", "librala_api.so"))
     L.hp_paf_device.restype = ctypes.c_void_p
     L.hp_paf_device.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_uint32]
+    L.hp_mhap_device.restype = ctypes.c_void_p
+    L.hp_mhap_device.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_uint32]
     L.hp_paf_device_info.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     L.hp_paf_device_copy.argtypes = [ctypes.c_void_p] * 9
     L.hp_paf_device_free.argtypes = [ctypes.c_void_p]
@@ -38,6 +40,26 @@ def device_parse(path, names, read_len, threads=4, check_lengths=True):
     L = _lib()
     rl = np.ascontiguousarray(read_len, dtype=np.uint32)
     h = L.hp_paf_device(path.encode(), "\n".join(names).encode(), rl.ctypes.data, len(names), int(check_lengths), threads)
+    try:
+        info = np.zeros(6, dtype=np.int64)
+        L.hp_paf_device_info(h, info.ctypes.data)
+        assert info[0] == 0, info
+        if info[1] or info[2] >= 0:
+            return None, int(info[1]), int(info[2])
+        n = int(info[3])
+        cols = {f: np.zeros(n, dtype=np.uint32) for f in FIELDS}
+        cols["strand"] = np.zeros(n, dtype=np.uint8)
+        L.hp_paf_device_copy(h, *[cols[f].ctypes.data for f in FIELDS], cols["strand"].ctypes.data)
+        return cols, 0, -1
+    finally:
+        L.hp_paf_device_free(h)
+
+
+def device_parse_mhap(path, read_len, threads=4, check_lengths=True):
+    """an MHAP file through the device tokeniser (rala_hip_set_overlaps_from_mhap) -> (columns or None, irregular, length error)"""
+    L = _lib()
+    rl = np.ascontiguousarray(read_len, dtype=np.uint32)
+    h = L.hp_mhap_device(path.encode(), rl.ctypes.data, len(rl), int(check_lengths), threads)
     try:
         info = np.zeros(6, dtype=np.int64)
         L.hp_paf_device_info(h, info.ctypes.data)
@@ -234,6 +256,86 @@ def test_device_tokeniser_matches_host_reader(tmp_path, n, g, seed, threads):
     for f in FIELDS:
         assert (got[f] == getattr(ds.overlaps, f)).all(), f
     assert (got["strand"] == ds.overlaps.strand).all()
+
+
+@pytest.mark.parametrize("threads", [1, 4])
+@pytest.mark.parametrize("n,g,seed", [(3000, 600_000, 4), (20_000, 4_000_000, 8)])
+def test_device_tokeniser_mhap_matches_host_reader(tmp_path, n, g, seed, threads):
+    """an uncompressed MHAP file (twelve blank-separated numeric columns, ids from 1; reference overlap.cpp:12-20) tokenised on
+    the device (round 6) = the host reader's columns: ids minus one, the longer span as the length, strand = a_rc != b_rc"""
+    ds = Dataset(n, g, seed)
+    paf = str(tmp_path / "ovl.paf")
+    ds.write_paf(paf)
+    mhap = str(tmp_path / "ovl.mhap")
+    host._to_mhap(paf, mhap)
+    names = ["r%d" % i for i in range(ds.n_reads)]
+    want, e0 = host.parse(mhap, names, ds.read_len, 2, 3)
+    got, irregular, bad = device_parse_mhap(mhap, ds.read_len, threads)
+    assert e0 == -1 and irregular == 0 and bad == -1
+    for f in want:
+        assert (got[f] == want[f]).all(), f
+    ov = ds.overlaps
+    assert (got["length"] == np.maximum(ov.a_end - ov.a_begin, ov.b_end - ov.b_begin)).all()
+    assert (got["a_id"] == ov.a_id).all() and (got["strand"] == ov.strand).all()
+
+
+def test_device_tokeniser_mhap_awkward_files(tmp_path):
+    """ids that name no read (0, beyond the reads, not a number), a thirteenth column, CR LF, empty lines, no newline at the
+    end; a length that differs from its sequence's (the first offender in file order, Overlap::transmute's rule); a line with
+    fewer than twelve columns is the host reader's business"""
+    lens = [1000 + i for i in range(30)]
+    names = ["r%d" % i for i in range(30)]
+    rng = np.random.default_rng(5)
+    lines = []
+    for k in range(20_000):
+        a, b = int(rng.integers(0, 30)), int(rng.integers(0, 30))
+        ida, idb = str(a + 1), str(b + 1)
+        what = rng.random()
+        if what < 0.02:
+            ida = "0"                                   # 0 - 1 wraps: no read
+        elif what < 0.04:
+            idb = "31"                                  # one beyond the reads
+        elif what < 0.05:
+            ida = "x7"                                  # no digits: 0 - 1
+        elif what < 0.06:
+            idb = "4294967297"                          # 2^32 + 1: not read 0
+        line = "%s %s 0.05 %d %d %d %d %d %d %d %d %d" % (ida, idb, k % 77, k & 1, k % 90, 500 + k % 400, lens[a], (k >> 1) & 1, k % 80,
+                                                         480 + k % 300, lens[b])
+        if what > 0.97:
+            line += " extra column"
+        if what > 0.9 and what < 0.93:
+            line += "\r"
+        lines.append(line)
+        if rng.random() < 0.002:
+            lines.extend([""] * int(rng.integers(1, 4)))
+    path = str(tmp_path / "awkward.mhap")
+    open(path, "w").write("\n".join(lines))             # (no newline at the end)
+    want, e0 = host.parse(path, names, lens, 2, 3)
+    got, irregular, bad = device_parse_mhap(path, lens)
+    assert e0 == -1 and irregular == 0 and bad == -1
+    assert len(got["a_id"]) == 20_000
+    for f in want:
+        assert (got[f] == want[f]).all(), f
+    assert (got["a_id"] == 0xFFFFFFFF).sum() > 300 and (got["b_id"] == 0xFFFFFFFF).sum() > 300
+    # a length error: the target's on one line, the query's on a later one - the first in file order is reported
+    bad_lines = [l for l in lines if l]
+    f = bad_lines[9000].split(" ")
+    f[0], f[1], f[7], f[11] = "3", "5", str(lens[2]), str(lens[4] + 1)
+    bad_lines[9000] = " ".join(f[:12])
+    f = bad_lines[15000].split(" ")
+    f[0], f[7] = "9", str(lens[8] - 1)
+    bad_lines[15000] = " ".join(f[:12])
+    open(path, "w").write("\n".join(bad_lines) + "\n")
+    _, e1 = host.parse(path, names, lens, 2, 3)
+    got, irregular, bad = device_parse_mhap(path, lens)
+    assert got is None and irregular == 0 and bad == e1 == 4
+    got, irregular, bad = device_parse_mhap(path, lens, check_lengths=False)
+    assert irregular == 0 and bad == -1 and len(got["a_id"]) == 20_000
+    # fewer than twelve columns
+    bad_lines[100] = "1 2 0.1 4 0 5 6"
+    open(path, "w").write("\n".join(bad_lines) + "\n")
+    got, irregular, bad = device_parse_mhap(path, lens)
+    assert got is None and irregular != 0
 
 
 def test_minimap2_shaped_paf_and_unknown_names(tmp_path):
