@@ -645,7 +645,8 @@ __global__ __launch_bounds__(64 * kWaves, kOne ? 7 : kBases > 32768 ? 2 : kBases
         asm volatile(".rept 32\n\tv_add_u32 %0, 1, %0\n\tv_add_u32 %1, 1, %1\n\t.endr" : "+v"(d0), "+v"(d1));
         if (d0 + d1 == 0x7FFFFFFFu && A.n_items == 0xFFFFFFFFu) overflow_list[0] = d0;
     }
-    constexpr bool kSingleItem = kOne && kWaves > 1 && !(kVar & 1u);
+    constexpr bool kXcdRanges = kOne && kPlain && !(kVar & 8192u);
+    constexpr bool kSingleItem = kOne && (kWaves > 1 || kPlain) && !(kVar & 1u);
     constexpr bool kSingleItemArgs = kSingleItem && !(kVar & 4u);
     constexpr bool kBufferEvents = kSens == 0 && !(kVar & 2u);
     constexpr bool kShort = kOne || kBases > 16384 || (kSens != 0 && kCap == 1024);     // reads of up to kBases bases only, 16-bit run starts
@@ -692,10 +693,15 @@ __global__ __launch_bounds__(64 * kWaves, kOne ? 7 : kBases > 32768 ? 2 : kBases
         item_end = umin(n_items, (xcd + 1u) * per);
         item_step = gridDim.x / 8u;
     }
-    // kVar bit 13: every XCD writes ONE contiguous range of the rows (workgroup i runs on XCD i % 8 and takes the reads
-    // (i % 8) * per + 2 (i / 8) + wavefront; launched with 4 * per workgroups, per = the reads of an XCD, even)
-    if constexpr ((kVar & 8192u) != 0) {
-        const uint32_t per = ((n_items + 15u) / 16u) * 2u, xcd = blockIdx.x & 7u, j = (blockIdx.x >> 3) * kWaves + wave_in_group;
+    // The product instantiation (round 6): every XCD writes ONE contiguous range of the rows - workgroup i runs on XCD i % 8 and takes
+    // the reads (i % 8) * per + kWaves * (i / 8) + wavefront, per = the reads of an XCD (a multiple of kWaves), 8 * per / kWaves
+    // workgroups.  A kernel that only fills the same rows goes from 5.2 to 6.2 TB/s that way (tools/fill_bench3.hip); this kernel, whose
+    // floor IS that fill rate (4.065 ms = 5.13 TB/s whatever is added to or taken from its instructions - tools/gpurun/r6_ab_inproc.sh),
+    // from 4.07 - 4.3 ms to 3.8 - 3.9 at C3, measured variant against variant inside one process.  Round 4 had
+    // tried the mapping with one read per workgroup on a build that sat above that floor for other reasons and saw nothing.
+    // (kVar bit 13: the reads as launched - workgroup i takes 2 i and 2 i + 1 - for measurements.)
+    if constexpr (kXcdRanges) {
+        const uint32_t per = ((n_items + 8u * kWaves - 1u) / (8u * kWaves)) * kWaves, xcd = blockIdx.x & 7u, j = (blockIdx.x >> 3) * kWaves + wave_in_group;
         item_first = xcd * per + j;
         item_end = j < per ? umin(n_items, (xcd + 1u) * per) : 0u;
     }
@@ -1888,10 +1894,13 @@ void launch_pile_runs(const PileArgs& args, uint32_t grid, int tier, uint32_t* o
         else if (waves == 4 && !persist) hipLaunchKernelGGL((pile_runs_kernel<kRunEventCap, false, 0, true, 16384, 4>), dim3((grid + 3) / 4), dim3(256),
                                                             extra_lds, stream, args, overflow_list, overflow_count);
         else if (waves == 2 && !persist && !args.order && !args.ev_cnt && !getenv("RALA_PILE_NOT_PLAIN")) {
-#define RALA_LAUNCH_PRODUCT(var)                                                                                                  \
-            hipLaunchKernelGGL((pile_runs_kernel<kRunEventCap, false, 0, true, 16384, 2, true, var>),                            \
-                               dim3(((var) & 8192u) ? 4u * (((args.n_items + 15u) / 16u) * 2u) : (grid + 1) / 2), dim3(128),    \
+            // (bit 14 of a variant: four reads per workgroup; bit 15: one)
+#define RALA_LAUNCH_PRODUCT_W(var, w)                                                                                             \
+            hipLaunchKernelGGL((pile_runs_kernel<kRunEventCap, false, 0, true, 16384, w, true, var>),                            \
+                               dim3(((var) & 8192u) ? (grid + w - 1) / w : 8u * ((args.n_items + 8u * w - 1u) / (8u * w))), dim3(64 * w), \
                                extra_lds, stream, args, overflow_list, overflow_count)
+#define RALA_LAUNCH_PRODUCT(var)                                                                                                  \
+            do { if constexpr (((var) & 16384u) != 0) RALA_LAUNCH_PRODUCT_W(var, 4); else if constexpr (((var) & 32768u) != 0) RALA_LAUNCH_PRODUCT_W(var, 1); else RALA_LAUNCH_PRODUCT_W(var, 2); } while (0)
 #ifdef RALA_PILE_AB
 #ifndef RALA_PILE_AB_CASES          // (-DRALA_PILE_AB_CASES="X(8) X(11)": the variants a measurement build carries beside 0)
 #define RALA_PILE_AB_CASES X(1) X(2) X(3) X(4)
@@ -1906,6 +1915,7 @@ void launch_pile_runs(const PileArgs& args, uint32_t grid, int tier, uint32_t* o
             RALA_LAUNCH_PRODUCT(0);
 #endif
 #undef RALA_LAUNCH_PRODUCT
+#undef RALA_LAUNCH_PRODUCT_W
         }
         else if (waves == 2 && !persist) hipLaunchKernelGGL((pile_runs_kernel<kRunEventCap, false, 0, true, 16384, 2>), dim3((grid + 1) / 2), dim3(128),
                                                             extra_lds, stream, args, overflow_list, overflow_count);

@@ -2686,11 +2686,11 @@ static int initialize_stages(rala_hip_ctx* ctx) {
     ctx->host_state_fresh = false;
     ctx->pool_used = std::min(small[0], ctx->pool_cap);
     ctx->tm.pile_overflow_reads = ctx->use_run_kernel ? small[3] + small[4] : 0;      // event-dense + handed on
-    if (getenv("RALA_HIP_TRACE")) {
-        fprintf(stderr, "[trace] buffers: slots %p counts %p piles %p a_id %p b_id %p b_begin %p\n", (void*)ctx->d_ev_fixed.p,
+    if (getenv("RALA_HIP_TRACE") || getenv("RALA_HIP_TRACE_BUFFERS")) {
+        fprintf(stderr, "[trace] buffers: events %p (CSR %p) slots %p counts %p piles %p a_id %p b_id %p b_begin %p\n", (void*)ctx->d_ev.p, (void*)ctx->d_ev_off.p, (void*)ctx->d_ev_fixed.p,
                 (void*)ctx->d_cursor.p, (void*)ctx->d_pile.p, (const void*)ctx->ovl.a_id, (const void*)ctx->ovl.b_id,
                 (const void*)ctx->ovl.b_begin);
-        fprintf(stderr, "[trace] pile chain: %u reads listed as event-dense, %u handed on by the cap-512 kernels, %u on to cap 2048, %u to position space\n",
+        if (getenv("RALA_HIP_TRACE")) fprintf(stderr, "[trace] pile chain: %u reads listed as event-dense, %u handed on by the cap-512 kernels, %u on to cap 2048, %u to position space\n",
                 small[3], small[4], small[2], small[5]);
     }
     ctx->tm.pile_position_reads = ctx->use_run_kernel ? small[5] : n_reads;
