@@ -35,7 +35,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # A process has four hardware queues by default and its streams share them; a rank of a sharded run has two contexts with
 # three streams each beside RCCL's, and kernels meant to run beside each other ended up behind each other (the owner's small
-# pile kernels in front of the big one: 0.1 - 0.3 ms per C3 step, tools/gpurun/r5_queues.sh).  The runtime reads this when it
+# pile kernels in front of the big one: 0.1 - 0.3 ms per C3 step, docs/history/gpurun/r5_queues.sh).  The runtime reads this when it
 # starts - before anything imports torch.  (The single-GPU step has four streams: it stays on the runtime's default, as profiled.)
 def _several_ranks(argv):
     n = 1

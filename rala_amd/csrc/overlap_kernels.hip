@@ -552,7 +552,7 @@ __global__ __launch_bounds__(kBlock) void classify_kernel(OvlSoA o, uint32_t n_r
     };
     // Two halves of four overlaps per thread, software-pipelined (round 5): the second half's columns are requested while the
     // first half's records are on their way - three dependent round trips per wavefront instead of four at six wavefronts per
-    // SIMD instead of seven (77 registers): 0.603 -> 0.577 ms at C3, 4.70 -> 4.67 at C5 (tools/gpurun/r5_classify_pipe.sh).
+    // SIMD instead of seven (77 registers): 0.603 -> 0.577 ms at C3, 4.70 -> 4.67 at C5 (docs/history/gpurun/r5_classify_pipe.sh).
     struct Half {
         uint32_t a[kHalf], b[kHalf], st[kHalf];
         Coords c[kHalf];
@@ -822,7 +822,7 @@ __global__ __launch_bounds__(kBlock) void survivor_masks_kernel(OvlSoA o, uint32
         const uint64_t i = (uint64_t)blockIdx.x * kClassifyChunk + u * kBlock + threadIdx.x;
         const uint64_t j = i < o.n ? i : last;
         ok[u] = i < o.n && stream_load(valid + j);
-        // (ordinary loads: the candidates come back for their ids - 0.430 -> 0.408 ms for this stage at C3, tools/gpurun/r5_stream.sh;
+        // (ordinary loads: the candidates come back for their ids - 0.430 -> 0.408 ms for this stage at C3, docs/history/gpurun/r5_stream.sh;
         // classify_kernel, which does not come back, is 8 % slower with them)
         a[u] = o.a_id[j]; b[u] = o.b_id[j];
     }

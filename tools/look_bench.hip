@@ -1,58 +1,56 @@
-// How long does a "look" from the host cost the device?  A chain of tiny kernels with a look between them:
-//   (a) hipMemcpyAsync of 64 bytes to pinned memory + hipStreamSynchronize (what pipeline.hip's d2h_small / stream_sync do)
-//   (b) a kernel that writes the 64 bytes and a sequence number to host-coherent pinned memory, the host spins on the number
-// Prints microseconds per look (device idle included: wall time of N rounds of kernel + look, minus N kernels back to back).
-// hipcc --offload-arch=gfx950 -O3 tools/look_bench.hip -o /tmp/look_bench && /tmp/look_bench
-// MI355X, round 4: 2.7 us per kernel back to back; (a) 14.8 us per round, (b) 9.5 us - a look costs the device about 12 us
-// either way and spinning on host memory would save 5 of them: not built into the pipeline.
+// Microbenchmark (round 6): what does one "look" from the host cost - a few words produced by a kernel, needed by the host before it
+// launches the next kernel?  (a) hipMemcpyAsync into pinned memory + hipStreamSynchronize (what d2h_small / stream_sync do);
+// (b) the producing side writes the words and then a ticket into host-mapped pinned memory, the host spins on the ticket;
+// (c) as (a) with an event: hipEventRecord + hipEventSynchronize.  Each measured as the time from the launch of a 20 us kernel to the
+// start of the kernel that follows the look (hipEvent timing over N rounds, minus the kernels' own time).
 #include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdint.h>
 #include <chrono>
-#include <cstdint>
-#include <cstdio>
 
-#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
-
-__global__ void work(uint32_t* p) { if (threadIdx.x == 0) p[0] += 1; }
-__global__ void publish(const uint32_t* src, uint32_t* dst, uint32_t words, uint32_t* seq, uint32_t value) {
-    if (threadIdx.x < words) dst[threadIdx.x] = src[threadIdx.x];
-    __threadfence_system();
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(seq, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+__global__ void work(uint32_t* out, uint32_t spin) {
+    uint32_t x = threadIdx.x;
+    for (uint32_t k = 0; k < spin; ++k) x = x * 1664525u + 1013904223u;
+    if (threadIdx.x == 0) out[0] = x | 1u;
 }
-
+__global__ void to_host(const uint32_t* src, volatile uint32_t* dst, uint32_t n, volatile uint32_t* ticket, uint32_t value) {
+    if (threadIdx.x < n) dst[threadIdx.x] = src[threadIdx.x];
+    __threadfence_system();
+    if (threadIdx.x == 0) *ticket = value;
+}
 int main() {
-    uint32_t *d = nullptr, *h = nullptr;
-    CHECK(hipMalloc(&d, 256));
-    CHECK(hipMemset(d, 0, 256));
-    CHECK(hipHostMalloc(&h, 256, hipHostMallocDefault));
-    h[32] = 0;
-    hipStream_t s;
-    CHECK(hipStreamCreate(&s));
+    hipStream_t s; hipStreamCreate(&s);
+    uint32_t* d; hipMalloc(&d, 256);
+    uint32_t* h; hipHostMalloc(&h, 4096, hipHostMallocCoherent | hipHostMallocMapped);
+    uint32_t* hd = nullptr; hipHostGetDevicePointer((void**)&hd, h, 0);
+    volatile uint32_t* ticket = h + 512;
     const int N = 2000;
-    auto now = [] { return std::chrono::steady_clock::now(); };
-    auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
-    for (int rep = 0; rep < 3; ++rep) {
-        auto t0 = now();
-        for (int i = 0; i < N; ++i) hipLaunchKernelGGL(work, dim3(1), dim3(64), 0, s, d);
-        CHECK(hipStreamSynchronize(s));
-        auto t1 = now();
+    const uint32_t spin = 4000;
+    auto run = [&](const char* name, int mode) {
+        hipStreamSynchronize(s);
+        const auto t0 = std::chrono::steady_clock::now();
         for (int i = 0; i < N; ++i) {
-            hipLaunchKernelGGL(work, dim3(1), dim3(64), 0, s, d);
-            CHECK(hipMemcpyAsync(h, d, 64, hipMemcpyDeviceToHost, s));
-            CHECK(hipStreamSynchronize(s));
+            hipLaunchKernelGGL(work, dim3(1), dim3(64), 0, s, d, spin);
+            if (mode == 0) { hipMemcpyAsync(h, d, 16, hipMemcpyDeviceToHost, s); hipStreamSynchronize(s); }
+            else if (mode == 1) {
+                hipLaunchKernelGGL(to_host, dim3(1), dim3(64), 0, s, (const uint32_t*)d, (volatile uint32_t*)hd, 4u, (volatile uint32_t*)(hd + 512), (uint32_t)(i + 1));
+                while (*ticket != (uint32_t)(i + 1)) { __builtin_ia32_pause(); }
+            } else if (mode == 2) {
+                hipStreamSynchronize(s);                    // (no copy at all: the bare wait)
+            } else {
+                hipLaunchKernelGGL(to_host, dim3(1), dim3(64), 0, s, (const uint32_t*)d, (volatile uint32_t*)hd, 4u, (volatile uint32_t*)(hd + 512), (uint32_t)(i + 1));
+                hipStreamSynchronize(s);
+            }
+            if (h[0] == 0xdeadbeef) printf("!");
         }
-        auto t2 = now();
-        volatile uint32_t* seq = h + 32;
-        uint32_t v = *seq;
-        for (int i = 0; i < N; ++i) {
-            hipLaunchKernelGGL(work, dim3(1), dim3(64), 0, s, d);
-            hipLaunchKernelGGL(publish, dim3(1), dim3(64), 0, s, (const uint32_t*)d, h, 16u, (uint32_t*)(h + 32), ++v);
-            while (__atomic_load_n(h + 32, __ATOMIC_ACQUIRE) != v) {}
-        }
-        auto t3 = now();
-        CHECK(hipStreamSynchronize(s));
-        printf("back to back %.2f us per kernel; copy + synchronize %.2f us per round; publish + spin %.2f us per round (value %u)\n",
-               us(t0, t1) / N, us(t1, t2) / N, us(t2, t3) / N, h[0]);
-    }
+        hipStreamSynchronize(s);
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / N;
+        printf("%-64s %7.2f us per round\n", name, us);
+    };
+    run("warm-up", 0);
+    run("work kernel + bare hipStreamSynchronize", 2);
+    run("work kernel + hipMemcpyAsync to pinned + hipStreamSynchronize", 0);
+    run("work kernel + to_host kernel (mapped memory) + spin on ticket", 1);
+    run("work kernel + to_host kernel + hipStreamSynchronize", 3);
     return 0;
 }
