@@ -322,6 +322,22 @@ def measure_traffic(workload):
     return (2.0 * kb["FETCH_SIZE"] + kb["WRITE_SIZE"]) * 1024.0
 
 
+def gather_check_inputs(mine, valid_slice, row_fnv, row_sum, rank, world, n_reads):
+    """one process per GPU: what result_check wants, on rank 0 - the replicated digests of rank 0 and of the last rank, the ranks'
+    validity bytes behind each other (the slices are the file in order), the rows' checksums from their owners back in read order
+    (entry j of rank k = read j * world + k).  Control plane (gloo); the other ranks get None."""
+    import torch.distributed as dist
+    box = [None] * world if rank == 0 else None
+    dist.gather_object((mine, valid_slice, row_fnv, row_sum), box, dst=0)
+    if rank != 0:
+        return None
+    fnv = np.zeros(n_reads, dtype=np.uint64)
+    tot = np.zeros(n_reads, dtype=np.uint64)
+    for k in range(world):
+        fnv[k::world], tot[k::world] = box[k][2], box[k][3]
+    return box[0][0], box[world - 1][0], np.concatenate([b[1] for b in box]), fnv, tot
+
+
 def broadcast_flag(flag):
     """rank 0's verdict on every rank (one process per GPU)"""
     import torch
@@ -611,14 +627,9 @@ def main():
         if use_dist:
             mine = replicated_digests(runner.mg.context(), n_tr, with_sens) if rank in (0, world - 1) else None
             f, sm, _ = runner.mg.pile_row_digests()
-            box = [None] * world if rank == 0 else None
-            dist.gather_object((mine, runner.mg.context().valid(), f, sm), box, dst=0)
+            got = gather_check_inputs(mine, runner.mg.context().valid(), f, sm, rank, world, ds.n_reads)
             if rank == 0:
-                fnv = np.zeros(ds.n_reads, dtype=np.uint64); tot = np.zeros(ds.n_reads, dtype=np.uint64)
-                for k in range(world):
-                    fnv[k::world], tot[k::world] = box[k][2], box[k][3]
-                check, check_ok = result_check(data_name, with_sens, box[0][0], box[world - 1][0], np.concatenate([b[1] for b in box]),
-                                               fnv, tot, [0, world - 1])
+                check, check_ok = result_check(data_name, with_sens, *got, [0, world - 1])
             check_ok = bool(broadcast_flag(check_ok)) if world > 1 else check_ok
         elif use_threads:
             first = replicated_digests(runner.ranks[0].context(), n_tr, with_sens)

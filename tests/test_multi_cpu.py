@@ -101,3 +101,50 @@ def test_slice_cuts_edge_cases():
     a = np.arange(16, dtype=np.uint32)
     assert hip.slice_cuts(a, 4) == [0, 4, 8, 12, 16]
     assert hip.slice_cuts(a, 1) == [0, 16]
+
+
+def _check_worker(rank, world, port, n_reads, q):
+    """bench.py's result check over several processes: every rank hands in its slice of the validity bytes and the checksums of
+    the rows it owns; rank 0 puts them back in file / read order and its verdict reaches everybody"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        valid = (np.arange(1000, dtype=np.uint32) * 7 % 5 != 0).astype(np.uint8)
+        cuts = [1000 * k // world + (k % 2) for k in range(world)] + [1000]
+        cuts[0] = 0
+        fnv = np.arange(n_reads, dtype=np.uint64) * np.uint64(2654435761)
+        tot = np.arange(n_reads, dtype=np.uint64) + np.uint64(11)
+        mine = {"edges": "e", "n_tr": 3, "rank": rank} if rank in (0, world - 1) else None
+        got = bench.gather_check_inputs(mine, valid[cuts[rank]:cuts[rank + 1]], fnv[rank::world], tot[rank::world], rank, world, n_reads)
+        ok = None
+        if rank == 0:
+            first, last, v, f, t = got
+            ok = (first["rank"] == 0 and last["rank"] == world - 1 and (v == valid).all() and (f == fnv).all() and (t == tot).all())
+        else:
+            assert got is None
+        verdict = bench.broadcast_flag(bool(ok))
+        verdict_bad = bench.broadcast_flag(False if rank == 0 else True)       # rank 0's word counts
+        q.put((rank, verdict, verdict_bad))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_reads", [(2, 101), (3, 100)])
+def test_result_check_inputs_over_ranks(world, n_reads):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_check_worker, args=(r, world, port, n_reads, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[0] for r in res] == list(range(world))
+    assert all(r[1] is True and r[2] is False for r in res)
