@@ -387,8 +387,13 @@ __device__ __forceinline__ uint32_t ffbl_or_minus1(uint32_t v) {
 #define RALA_ROW_STORE_MOD ""
 #endif
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+// (kMod, measurements inside one process - bits 16 - 17 of a kernel variant: 1 non-temporal, 2 sc1, 3 sc0 sc1)
+template <int kMod = 0>
 __device__ __forceinline__ void store16(const char* base, uint32_t off, const uint4& v) {
     const u32x4 d = {v.x, v.y, v.z, v.w};
+    if constexpr (kMod == 1) { asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" : : "v"(off), "v"(d), "s"(base) : "memory"); return; }
+    if constexpr (kMod == 2) { asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" : : "v"(off), "v"(d), "s"(base) : "memory"); return; }
+    if constexpr (kMod == 3) { asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1\n\ts_nop 1" : : "v"(off), "v"(d), "s"(base) : "memory"); return; }
     // (Measured and not kept: the `nt` modifier - streaming stores gave 1 % at C3 inside one gpurun call and 3 %
     // more write traffic at the memory; for the bucketing's scattered 8-byte stores, which need the cache to
     // merge them, it cost 40 %.)
@@ -397,9 +402,12 @@ __device__ __forceinline__ void store16(const char* base, uint32_t off, const ui
     asm volatile("global_store_dwordx4 %0, %1, %2 " RALA_ROW_STORE_MOD "\n\ts_nop 1" : : "v"(off), "v"(d), "s"(base) : "memory");
 }
 // (the same with an immediate offset: the lane offset is then a loop constant)
-template <int kImm>
+template <int kImm, int kMod = 0>
 __device__ __forceinline__ void store16_imm(const char* base, uint32_t off, const uint4& v) {
     const u32x4 d = {v.x, v.y, v.z, v.w};
+    if constexpr (kMod == 1) { asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3 nt\n\ts_nop 1" : : "v"(off), "v"(d), "s"(base), "n"(kImm) : "memory"); return; }
+    if constexpr (kMod == 2) { asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3 sc1\n\ts_nop 1" : : "v"(off), "v"(d), "s"(base), "n"(kImm) : "memory"); return; }
+    if constexpr (kMod == 3) { asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3 sc0 sc1\n\ts_nop 1" : : "v"(off), "v"(d), "s"(base), "n"(kImm) : "memory"); return; }
     asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3 " RALA_ROW_STORE_MOD "\n\ts_nop 1" : : "v"(off), "v"(d), "s"(base), "n"(kImm) : "memory");
 }
 
@@ -484,7 +492,7 @@ struct Layout {
 // stored exactly once.  (Before: every changed group went through the list, a walk and a table of
 // finished groups, once per chunk of 256 groups - 700 of the expansion's 900 vector instructions
 // per read.)
-template <class L>
+template <class L, int kMod = 0>
 __device__ __forceinline__ void expand_from_bitmap(uint32_t* sm, const uint16_t* rv, uint16_t* pile, uint64_t row_off,
                                                    uint32_t nv, uint32_t lane, bool store) {
     const uint32_t* bm = sm + L::X;
@@ -528,7 +536,7 @@ __device__ __forceinline__ void expand_from_bitmap(uint32_t* sm, const uint16_t*
                 w2 = bitfield_insert(change_mask(x, 2), f, w2);
                 w3 = bitfield_insert(change_mask(x, 3), f, w3);
             } while (inner);
-            if (store) store16(base, g * 16u, make_uint4(w0, w1, w2, w3));
+            if (store) store16<kMod>(base, g * 16u, make_uint4(w0, w1, w2, w3));
         }
         wave_sync();
         cnt = 0;
@@ -580,10 +588,10 @@ __device__ __forceinline__ void expand_from_bitmap(uint32_t* sm, const uint16_t*
                 cnt += more;
             }
             if (in && !multi && store) {
-                if (u == 0) store16_imm<0>(base, voff, out);
-                else if (u == 1) store16_imm<1024>(base, voff, out);
-                else if (u == 2) store16_imm<2048>(base, voff, out);
-                else store16_imm<3072>(base, voff, out);
+                if (u == 0) store16_imm<0, kMod>(base, voff, out);
+                else if (u == 1) store16_imm<1024, kMod>(base, voff, out);
+                else if (u == 2) store16_imm<2048, kMod>(base, voff, out);
+                else store16_imm<3072, kMod>(base, voff, out);
             }
         }
     };
@@ -627,7 +635,7 @@ __device__ __forceinline__ void expand_from_bitmap(uint32_t* sm, const uint16_t*
 // arguments fetched where they are first used; bits 3 - 7: that many s_nop at the kernel's start (the code behind them moves by four
 // bytes each: placement); bits 8 - 10: work ADDED behind the expansion, for the sensitivity of the kernel's time to each kind of
 // it - 1: 128 independent vector instructions, 2: 128 scalar ones, 3: 1024 cycles asleep, 4: 32 LDS reads and their wait, 5: 512
-// vector instructions.
+// vector instructions; bits 16 - 17: the row stores' cache policy (1 nt, 2 sc1, 3 sc0 sc1).
 template <uint32_t kCap, bool kDiag, int kSens, bool kOne = false, uint32_t kBases = 16384, uint32_t kWaves = 1, bool kPlain = false, uint32_t kVar = 0>
 __global__ __launch_bounds__(64 * kWaves, kOne ? 7 : kBases > 32768 ? 2 : kBases > 16384 ? 4 : 5) void pile_runs_kernel(PileArgs A, uint32_t* overflow_list, uint32_t* overflow_count) {
     static_assert(kWaves == 1 || kOne, "several reads per workgroup: the first kernel of a chain only");
@@ -1100,7 +1108,11 @@ __global__ __launch_bounds__(64 * kWaves, kOne ? 7 : kBases > 32768 ? 2 : kBases
                 // one more bit for the padding behind the last base: run R, value 0
                 if (lane == 0 && n < kBases) atomicOr(&bm[n >> 5], 1u << (n & 31));
                 wave_sync();
-                expand_from_bitmap<L>(sm, rv, A.pile, row_off, nv, lane, row_stores);
+                // (measurements, bits 18 - 19 of a variant: the wavefront's priority raised while it expands / behind the expansion)
+                if constexpr ((kVar >> 18) & 1u) __builtin_amdgcn_s_setprio(2);
+                expand_from_bitmap<L, (int)((kVar >> 16) & 3u)>(sm, rv, A.pile, row_off, nv, lane, row_stores);
+                if constexpr ((kVar >> 18) & 1u) __builtin_amdgcn_s_setprio(0);
+                if constexpr ((kVar >> 19) & 1u) __builtin_amdgcn_s_setprio(2);
                 if (kShort) index_from_bitmap();
             } else
             for (uint32_t s0 = 0; s0 < nv * 8; s0 += kSeg) {       // sorted path: long reads, many events

@@ -100,6 +100,10 @@ for case in range(n_cases):
             hp = ctx.piles()
             for k in ("alive", "begin", "end", "median", "p10"):
                 parity.assert_same("piles." + k, hp[k], want_p[k])
+            want_rows = o.pile_row_digests()                # every row, the targets' with their second add_layers
+            fnv, inside, _ = ctx.pile_row_digests()
+            parity.assert_same("rows3.fnv", fnv, want_rows[0])
+            parity.assert_same("rows3.sum", inside, want_rows[1])
             parity.assert_same("ov.src", ctx.overlap_list(0)["src"], want_ov["src"].astype(np.uint32))
             assert ctx.remove_transitive_edges() == want_tr
             gr = ctx.graph()

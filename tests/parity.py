@@ -15,6 +15,7 @@ def oracle_stages(ds, n_threads=8, ref=False, with_tr=True, n_data=64, data_of=(
     st["pits0"] = o.all_intervals(0)
     st["hills0"] = o.all_intervals(1)
     st["oracle"] = o
+    st["rows0"] = o.pile_row_digests()       # (fnv, sum) of EVERY pile's data_ (round 6)
     # coverage vectors of a sample of live reads and of every read with pits / hills
     alive = np.nonzero(st["piles0"]["alive"])[0]
     rng = np.random.default_rng(0)
@@ -62,6 +63,12 @@ def check_initialize(ctx, st, ds):
         assert_same(key + ".pairs", pairs, st[key][1])
     for r, want in st["data0"].items():
         assert_same("pile_data[%d]" % r, ctx.pile_data(r), want)
+    # every row, hashed and summed where it lies (rala_hip_get_pile_row_digests) against the same vectors from the oracle's objects
+    if "rows0" in st:
+        fnv, inside, outside = ctx.pile_row_digests()
+        assert_same("rows0.fnv", fnv, st["rows0"][0])
+        assert_same("rows0.sum", inside, st["rows0"][1])
+        assert not outside.any(), "values stored outside a valid region right after initialize"
 
 
 def check_construct(ctx, st):
