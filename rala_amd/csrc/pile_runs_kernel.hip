@@ -635,7 +635,9 @@ __device__ __forceinline__ void expand_from_bitmap(uint32_t* sm, const uint16_t*
 // arguments fetched where they are first used; bits 3 - 7: that many s_nop at the kernel's start (the code behind them moves by four
 // bytes each: placement); bits 8 - 10: work ADDED behind the expansion, for the sensitivity of the kernel's time to each kind of
 // it - 1: 128 independent vector instructions, 2: 128 scalar ones, 3: 1024 cycles asleep, 4: 32 LDS reads and their wait, 5: 512
-// vector instructions; bits 16 - 17: the row stores' cache policy (1 nt, 2 sc1, 3 sc0 sc1).
+// vector instructions; bits 16 - 17: the row stores' cache policy (1 nt, 2 sc1, 3 sc0 sc1); bits 18 - 19:
+// the wavefront's priority raised while it expands / behind the expansion; bit 21: the events' loads non-temporal; bit 22: count the
+// workgroups that do not run on XCD blockIdx % 8.
 template <uint32_t kCap, bool kDiag, int kSens, bool kOne = false, uint32_t kBases = 16384, uint32_t kWaves = 1, bool kPlain = false, uint32_t kVar = 0>
 __global__ __launch_bounds__(64 * kWaves, kOne ? 7 : kBases > 32768 ? 2 : kBases > 16384 ? 4 : 5) void pile_runs_kernel(PileArgs A, uint32_t* overflow_list, uint32_t* overflow_count) {
     static_assert(kWaves == 1 || kOne, "several reads per workgroup: the first kernel of a chain only");
@@ -654,6 +656,11 @@ __global__ __launch_bounds__(64 * kWaves, kOne ? 7 : kBases > 32768 ? 2 : kBases
         if (d0 + d1 == 0x7FFFFFFFu && A.n_items == 0xFFFFFFFFu) overflow_list[0] = d0;
     }
     constexpr bool kXcdRanges = kOne && kPlain && !(kVar & 8192u);
+    // The rows' stores stay PLAIN.  Non-temporal ones (kVar bit 16) were measured again on top of the XCD ranges, variant against
+    // variant inside one process: 3.69 - 3.71 ms against 3.82 on two boxes (round 5, with the reads as launched: 4.90 against 4.15 -
+    // there the L2 was what put neighbouring rows' lines together), but 3.86 - 3.88 against 3.90 - 3.93 on a third and 4.26 against
+    // 4.11 in that box's slow state: a gain of 0 - 3 % that turns into a loss of 4 % with the state of the box is not a default.
+    constexpr int kRowStoreMod = (int)((kVar >> 16) & 3u);
     constexpr bool kSingleItem = kOne && (kWaves > 1 || kPlain) && !(kVar & 1u);
     constexpr bool kSingleItemArgs = kSingleItem && !(kVar & 4u);
     constexpr bool kBufferEvents = kSens == 0 && !(kVar & 2u);
@@ -708,6 +715,14 @@ __global__ __launch_bounds__(64 * kWaves, kOne ? 7 : kBases > 32768 ? 2 : kBases
     // from 4.07 - 4.3 ms to 3.8 - 3.9 at C3, measured variant against variant inside one process.  Round 4 had
     // tried the mapping with one read per workgroup on a build that sat above that floor for other reasons and saw nothing.
     // (kVar bit 13: the reads as launched - workgroup i takes 2 i and 2 i + 1 - for measurements.)
+    if constexpr ((kVar >> 22) & 1u) {
+        // (measurement, bit 22 of a variant: does workgroup i really run on XCD i % 8?  HW_REG_XCC_ID = 20, bits 3:0; the count of those
+        // that do not goes to error[11] = the context's d_small[12])
+        // (one workgroup in sixteen notes bit 8 * (blockIdx % 4) + XCC_ID in error[11 + (blockIdx % 8) / 4]: one bit per residue = a
+        // fixed assignment, whatever the numbering)
+        const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u;
+        if (threadIdx.x == 0 && ((blockIdx.x >> 3) & 15u) == 0) atomicOr(A.error + 11 + ((blockIdx.x & 7u) >> 2), 1u << (8u * (blockIdx.x & 3u) + xcc));
+    }
     if constexpr (kXcdRanges) {
         const uint32_t per = ((n_items + 8u * kWaves - 1u) / (8u * kWaves)) * kWaves, xcd = blockIdx.x & 7u, j = (blockIdx.x >> 3) * kWaves + wave_in_group;
         item_first = xcd * per + j;
@@ -811,7 +826,7 @@ __global__ __launch_bounds__(64 * kWaves, kOne ? 7 : kBases > 32768 ? 2 : kBases
                 const __amdgpu_buffer_rsrc_t slots = __builtin_amdgcn_make_buffer_rsrc((void*)rev, 0, (int)(n_ev * 4u), 0x00020000);
                 const int lane4 = (int)(lane * 4u);
 #pragma unroll
-                for (uint32_t t = 0; t < kCap / 64; ++t) evr[t] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(slots, lane4 + (int)(t * 256u), 0, 0);
+                for (uint32_t t = 0; t < kCap / 64; ++t) evr[t] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(slots, lane4 + (int)(t * 256u), 0, (kVar >> 21) & 1u ? 2 : 0);      // (bit 21 of a variant: non-temporal)
             } else if constexpr (kSens == 0) {
 #pragma unroll
                 for (uint32_t t = 0; t < kCap / 64; ++t) evr[t] = rev[umin(t * 64 + lane, e_last)];
@@ -1110,7 +1125,7 @@ __global__ __launch_bounds__(64 * kWaves, kOne ? 7 : kBases > 32768 ? 2 : kBases
                 wave_sync();
                 // (measurements, bits 18 - 19 of a variant: the wavefront's priority raised while it expands / behind the expansion)
                 if constexpr ((kVar >> 18) & 1u) __builtin_amdgcn_s_setprio(2);
-                expand_from_bitmap<L, (int)((kVar >> 16) & 3u)>(sm, rv, A.pile, row_off, nv, lane, row_stores);
+                expand_from_bitmap<L, kRowStoreMod>(sm, rv, A.pile, row_off, nv, lane, row_stores);
                 if constexpr ((kVar >> 18) & 1u) __builtin_amdgcn_s_setprio(0);
                 if constexpr ((kVar >> 19) & 1u) __builtin_amdgcn_s_setprio(2);
                 if (kShort) index_from_bitmap();

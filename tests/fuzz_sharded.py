@@ -64,6 +64,14 @@ for case in range(n_cases):
         n_tr = sh.run()
         for r in sh.ranks:
             check_rank(r.context(), st, n_tr)
+        # every row from its owner, under the final regions (round 6): the oracle's objects hold the same after the chimera stage
+        want_fnv, want_sum = st["oracle"].pile_row_digests()
+        fnv = np.zeros(ds.n_reads, dtype=np.uint64)
+        tot = np.zeros(ds.n_reads, dtype=np.uint64)
+        for k, r in enumerate(sh.ranks):
+            fnv[k::world], tot[k::world], _ = r.pile_row_digests()
+        parity.assert_same("rows2.fnv", fnv, want_fnv)
+        parity.assert_same("rows2.sum", tot, want_sum)
         assert sh.run() == n_tr                 # the same objects once more
         check_rank(sh.ranks[world - 1].context(), st, n_tr)
         print("case %d %s: ok (%d overlaps, %d kept, %d pairs)" % (seed, what, len(ds.overlaps), len(st["ov"]["src"]), n_tr), flush=True)
