@@ -631,13 +631,14 @@ __device__ __forceinline__ void expand_from_bitmap(uint32_t* sm, const uint16_t*
 // kVar: measurement variants of the product instantiation, chosen per launch (PileArgs::variant, option "debug_pile_variant") so
 // that two builds of the kernel are compared INSIDE one process, on the same allocations, step by step - a library built with
 // -DRALA_PILE_AB carries them (round 6: two processes with the same binary differed by 12 % in this kernel's time, two binaries in
-// alternating processes by less).  Bit 0: the loop over the items as it was; bit 1: the events by ordinary loads; bit 2: the
-// arguments fetched where they are first used; bits 3 - 7: that many s_nop at the kernel's start (the code behind them moves by four
-// bytes each: placement); bits 8 - 10: work ADDED behind the expansion, for the sensitivity of the kernel's time to each kind of
-// it - 1: 128 independent vector instructions, 2: 128 scalar ones, 3: 1024 cycles asleep, 4: 32 LDS reads and their wait, 5: 512
-// vector instructions; bits 16 - 17: the row stores' cache policy (1 nt, 2 sc1, 3 sc0 sc1); bits 18 - 19:
-// the wavefront's priority raised while it expands / behind the expansion; bit 21: the events' loads non-temporal; bit 22: count the
-// workgroups that do not run on XCD blockIdx % 8.
+// alternating processes by less).  What is kept are the variants behind profiles/r06_c3_pile_sensitivity.txt: bit 0 the loop over the
+// items as it was, bit 1 the events by ordinary loads, bit 2 the arguments fetched where they are first used (8195 = bits 0, 1, 13 =
+// round 5's kernel); bits 8 - 10 work ADDED behind the expansion, for the sensitivity of the kernel's time to each kind of it - 1: 128
+// independent vector instructions, 2: 128 scalar ones, 3: 1024 cycles asleep, 4: 32 LDS reads and their wait, 5: 512 vector
+// instructions; bit 13 the reads as launched instead of XCD ranges; bits 16 - 17 the row stores' cache policy (1 nt, 2 sc1, 3 sc0 sc1).
+// The others round 6 measured - s_nop pads, sleeps and work in front of the first load, one / four reads per workgroup, priorities,
+// non-temporal event loads, the XCC_ID probe, the expansion's look-ups one group ahead, XCDs taking chunks in turn - are a patch:
+// docs/history/experiments/r6_pile_kernel_variants.patch (their results: docs/history/r6_pile_kernel_notebook.md).
 template <uint32_t kCap, bool kDiag, int kSens, bool kOne = false, uint32_t kBases = 16384, uint32_t kWaves = 1, bool kPlain = false, uint32_t kVar = 0>
 __global__ __launch_bounds__(64 * kWaves, kOne ? 7 : kBases > 32768 ? 2 : kBases > 16384 ? 4 : 5) void pile_runs_kernel(PileArgs A, uint32_t* overflow_list, uint32_t* overflow_count) {
     static_assert(kWaves == 1 || kOne, "several reads per workgroup: the first kernel of a chain only");
@@ -646,22 +647,13 @@ __global__ __launch_bounds__(64 * kWaves, kOne ? 7 : kBases > 32768 ? 2 : kBases
     static_assert(kBases == 16384 || !kOne, "the bigger bitmap belongs to the chain's second kernel");
     // (round 5: the sensitive pass's cap-1024 kernels too - their reads have at most 16384 bases; 14 296 -> 9 840 B of LDS, sixteen
     // workgroups per compute unit instead of eleven, and at C5 this is the kernel nearly every target starts in)
-    if constexpr (((kVar >> 3) & 31u) != 0) asm volatile(".rept %0\n\ts_nop 0\n\t.endr" : : "n"((kVar >> 3) & 31u));
-    // bits 11 - 12: something in front of a wavefront's first load - 1: 128 cycles asleep, 2: 64 vector instructions, 3: 512 cycles
-    if constexpr (((kVar >> 11) & 3u) == 1) asm volatile("s_sleep 2");
-    if constexpr (((kVar >> 11) & 3u) == 3) asm volatile("s_sleep 8");
-    if constexpr (((kVar >> 11) & 3u) == 2) {
-        uint32_t d0 = threadIdx.x, d1 = threadIdx.x + 1;
-        asm volatile(".rept 32\n\tv_add_u32 %0, 1, %0\n\tv_add_u32 %1, 1, %1\n\t.endr" : "+v"(d0), "+v"(d1));
-        if (d0 + d1 == 0x7FFFFFFFu && A.n_items == 0xFFFFFFFFu) overflow_list[0] = d0;
-    }
     constexpr bool kXcdRanges = kOne && kPlain && !(kVar & 8192u);
     // The rows' stores stay PLAIN.  Non-temporal ones (kVar bit 16) were measured again on top of the XCD ranges, variant against
     // variant inside one process: 3.69 - 3.71 ms against 3.82 on two boxes (round 5, with the reads as launched: 4.90 against 4.15 -
     // there the L2 was what put neighbouring rows' lines together), but 3.86 - 3.88 against 3.90 - 3.93 on a third and 4.26 against
     // 4.11 in that box's slow state: a gain of 0 - 3 % that turns into a loss of 4 % with the state of the box is not a default.
     constexpr int kRowStoreMod = (int)((kVar >> 16) & 3u);
-    constexpr bool kSingleItem = kOne && (kWaves > 1 || kPlain) && !(kVar & 1u);
+    constexpr bool kSingleItem = kOne && kWaves > 1 && !(kVar & 1u);
     constexpr bool kSingleItemArgs = kSingleItem && !(kVar & 4u);
     constexpr bool kBufferEvents = kSens == 0 && !(kVar & 2u);
     constexpr bool kShort = kOne || kBases > 16384 || (kSens != 0 && kCap == 1024);     // reads of up to kBases bases only, 16-bit run starts
@@ -715,14 +707,6 @@ __global__ __launch_bounds__(64 * kWaves, kOne ? 7 : kBases > 32768 ? 2 : kBases
     // from 4.07 - 4.3 ms to 3.8 - 3.9 at C3, measured variant against variant inside one process.  Round 4 had
     // tried the mapping with one read per workgroup on a build that sat above that floor for other reasons and saw nothing.
     // (kVar bit 13: the reads as launched - workgroup i takes 2 i and 2 i + 1 - for measurements.)
-    if constexpr ((kVar >> 22) & 1u) {
-        // (measurement, bit 22 of a variant: does workgroup i really run on XCD i % 8?  HW_REG_XCC_ID = 20, bits 3:0; the count of those
-        // that do not goes to error[11] = the context's d_small[12])
-        // (one workgroup in sixteen notes bit 8 * (blockIdx % 4) + XCC_ID in error[11 + (blockIdx % 8) / 4]: one bit per residue = a
-        // fixed assignment, whatever the numbering)
-        const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u;
-        if (threadIdx.x == 0 && ((blockIdx.x >> 3) & 15u) == 0) atomicOr(A.error + 11 + ((blockIdx.x & 7u) >> 2), 1u << (8u * (blockIdx.x & 3u) + xcc));
-    }
     if constexpr (kXcdRanges) {
         const uint32_t per = ((n_items + 8u * kWaves - 1u) / (8u * kWaves)) * kWaves, xcd = blockIdx.x & 7u, j = (blockIdx.x >> 3) * kWaves + wave_in_group;
         item_first = xcd * per + j;
@@ -826,7 +810,7 @@ __global__ __launch_bounds__(64 * kWaves, kOne ? 7 : kBases > 32768 ? 2 : kBases
                 const __amdgpu_buffer_rsrc_t slots = __builtin_amdgcn_make_buffer_rsrc((void*)rev, 0, (int)(n_ev * 4u), 0x00020000);
                 const int lane4 = (int)(lane * 4u);
 #pragma unroll
-                for (uint32_t t = 0; t < kCap / 64; ++t) evr[t] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(slots, lane4 + (int)(t * 256u), 0, (kVar >> 21) & 1u ? 2 : 0);      // (bit 21 of a variant: non-temporal)
+                for (uint32_t t = 0; t < kCap / 64; ++t) evr[t] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(slots, lane4 + (int)(t * 256u), 0, 0);
             } else if constexpr (kSens == 0) {
 #pragma unroll
                 for (uint32_t t = 0; t < kCap / 64; ++t) evr[t] = rev[umin(t * 64 + lane, e_last)];
@@ -1123,11 +1107,7 @@ __global__ __launch_bounds__(64 * kWaves, kOne ? 7 : kBases > 32768 ? 2 : kBases
                 // one more bit for the padding behind the last base: run R, value 0
                 if (lane == 0 && n < kBases) atomicOr(&bm[n >> 5], 1u << (n & 31));
                 wave_sync();
-                // (measurements, bits 18 - 19 of a variant: the wavefront's priority raised while it expands / behind the expansion)
-                if constexpr ((kVar >> 18) & 1u) __builtin_amdgcn_s_setprio(2);
                 expand_from_bitmap<L, kRowStoreMod>(sm, rv, A.pile, row_off, nv, lane, row_stores);
-                if constexpr ((kVar >> 18) & 1u) __builtin_amdgcn_s_setprio(0);
-                if constexpr ((kVar >> 19) & 1u) __builtin_amdgcn_s_setprio(2);
                 if (kShort) index_from_bitmap();
             } else
             for (uint32_t s0 = 0; s0 < nv * 8; s0 += kSeg) {       // sorted path: long reads, many events
@@ -1921,13 +1901,10 @@ void launch_pile_runs(const PileArgs& args, uint32_t grid, int tier, uint32_t* o
         else if (waves == 4 && !persist) hipLaunchKernelGGL((pile_runs_kernel<kRunEventCap, false, 0, true, 16384, 4>), dim3((grid + 3) / 4), dim3(256),
                                                             extra_lds, stream, args, overflow_list, overflow_count);
         else if (waves == 2 && !persist && !args.order && !args.ev_cnt && !getenv("RALA_PILE_NOT_PLAIN")) {
-            // (bit 14 of a variant: four reads per workgroup; bit 15: one)
-#define RALA_LAUNCH_PRODUCT_W(var, w)                                                                                             \
-            hipLaunchKernelGGL((pile_runs_kernel<kRunEventCap, false, 0, true, 16384, w, true, var>),                            \
-                               dim3(((var) & 8192u) ? (grid + w - 1) / w : 8u * ((args.n_items + 8u * w - 1u) / (8u * w))), dim3(64 * w), \
-                               extra_lds, stream, args, overflow_list, overflow_count)
 #define RALA_LAUNCH_PRODUCT(var)                                                                                                  \
-            do { if constexpr (((var) & 16384u) != 0) RALA_LAUNCH_PRODUCT_W(var, 4); else if constexpr (((var) & 32768u) != 0) RALA_LAUNCH_PRODUCT_W(var, 1); else RALA_LAUNCH_PRODUCT_W(var, 2); } while (0)
+            hipLaunchKernelGGL((pile_runs_kernel<kRunEventCap, false, 0, true, 16384, 2, true, var>),                            \
+                               dim3(((var) & 8192u) ? (grid + 1) / 2 : 8u * ((args.n_items + 15u) / 16u)), dim3(128),            \
+                               extra_lds, stream, args, overflow_list, overflow_count)
 #ifdef RALA_PILE_AB
 #ifndef RALA_PILE_AB_CASES          // (-DRALA_PILE_AB_CASES="X(8) X(11)": the variants a measurement build carries beside 0)
 #define RALA_PILE_AB_CASES X(1) X(2) X(3) X(4)
@@ -1942,7 +1919,6 @@ void launch_pile_runs(const PileArgs& args, uint32_t grid, int tier, uint32_t* o
             RALA_LAUNCH_PRODUCT(0);
 #endif
 #undef RALA_LAUNCH_PRODUCT
-#undef RALA_LAUNCH_PRODUCT_W
         }
         else if (waves == 2 && !persist) hipLaunchKernelGGL((pile_runs_kernel<kRunEventCap, false, 0, true, 16384, 2>), dim3((grid + 1) / 2), dim3(128),
                                                             extra_lds, stream, args, overflow_list, overflow_count);

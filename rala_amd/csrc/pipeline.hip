@@ -2694,11 +2694,6 @@ static int initialize_stages(rala_hip_ctx* ctx) {
         if (getenv("RALA_HIP_TRACE")) fprintf(stderr, "[trace] pile chain: %u reads listed as event-dense, %u handed on by the cap-512 kernels, %u on to cap 2048, %u to position space\n",
                 small[3], small[4], small[2], small[5]);
     }
-    if (getenv("RALA_HIP_TRACE_PROBE")) {
-        float ms = 0;
-        (void)hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]);
-        fprintf(stderr, "[probe] variant %u pile chain %.3f ms, XCC ids seen by the workgroups of residue 0 .. 7 (one byte each, a bit per id): %08x %08x\n", ctx->debug_pile_variant, ms, small[12], small[13]);
-    }
     ctx->tm.pile_position_reads = ctx->use_run_kernel ? small[5] : n_reads;
     // dedupe_ms: what duplicate removal adds to the critical path (it runs beside the bucketing
     // and the pile kernels; the main stream joins it after them)

@@ -1,3 +1,5 @@
+# (needs docs/history/experiments/r6_pile_kernel_variants.patch applied - the probe is no product code - and the line that prints
+# d_small[12 .. 13] behind rala_hip_initialize, which went with it)
 # round 6: does workgroup i run on XCD i % 8 - always, or only in a box's fast state?  The first pile kernel counts the workgroups that
 # do not (variant bit 22), several processes, the kernel's time beside the count
 ROOT=$GRAFT_REPO_ROOT
