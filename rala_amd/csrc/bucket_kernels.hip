@@ -43,8 +43,6 @@
 
 namespace rala_hip {
 
-uint32_t g_bucket_xcd = getenv("RALA_BUCKET_XCD") ? (uint32_t)atoi(getenv("RALA_BUCKET_XCD")) : 0u;
-
 namespace {
 
 constexpr uint32_t kInf = 0xFFFFFFFFu;
@@ -85,19 +83,6 @@ __device__ __forceinline__ uint32_t segment_of(uint32_t key, bool active, uint32
     const uint32_t len = after ? (uint32_t)__ffsll((unsigned long long)after) : (64u - lane);
     return head ? len : 0u;
 }
-
-// Workgroup b of a grid runs on XCD b % 8.  With `on`, the n units of work of a kernel (tiles, groups, chunks of the file) are handed
-// out so that every XCD takes ONE contiguous range of them - unit (b % 8) * ceil(n / 8) + b / 8 - instead of every eighth: what an
-// XCD's L2 writes back is then one stream of neighbouring lines, not an eighth of eight (the pile kernel's rows: 4.07 -> 3.85 ms,
-// round 6).  The grid has 8 * ceil(n / 8) workgroups; kInf: nothing for this one.
-__device__ __forceinline__ uint32_t xcd_range_unit(uint32_t b, uint32_t n, uint32_t on) {
-    if (!on) return b < n ? b : kInf;
-    const uint32_t per = (n + 7u) >> 3, unit = (b & 7u) * per + (b >> 3);
-    return (b >> 3) < per && unit < n ? unit : kInf;
-}
-inline uint32_t xcd_range_grid(uint32_t n, uint32_t on) { return on ? 8u * ((n + 7u) / 8u) : n; }
-// which kernels of the bucketing take their units that way: bit 0 the first scatter, 1 the second, 2 the rows' kernel, 3 the query side
-// (option "debug_bucket_xcd"; a process-wide switch - measurements)
 
 // ---- level 1: target >> 12 ------------------------------------------------------------------------
 constexpr uint32_t kBlockC = 1024;
@@ -349,11 +334,9 @@ __device__ __forceinline__ void stage_and_copy(StageLds& L, uint32_t n_bins, con
 
 // + acount[a] = resolvable overlaps of query a (its query-side events / 2)
 __global__ __launch_bounds__(kBlockP) void l1_scatter_kernel(OvlSoA o, uint32_t n_reads, uint32_t n_part, uint32_t* part_cursor,
-                                                             uint64_t* __restrict__ rec1, uint32_t* acount, uint32_t n_tiles, uint32_t xcd) {
+                                                             uint64_t* __restrict__ rec1, uint32_t* acount) {
     extern __shared__ __align__(16) unsigned char s_raw[];
     __shared__ uint32_t tmp[kBlockP / 64 + 1];
-    const uint32_t tile = xcd_range_unit(blockIdx.x, n_tiles, xcd);
-    if (tile == kInf) return;
     StageLds L(s_raw, n_part);
     uint64_t rec[kPer];
     uint32_t bin[kPer];
@@ -362,7 +345,7 @@ __global__ __launch_bounds__(kBlockP) void l1_scatter_kernel(OvlSoA o, uint32_t 
     const uint64_t last = o.n - 1;
 #pragma unroll
     for (uint32_t u = 0; u < kPer; ++u) {
-        const uint64_t i = (uint64_t)tile * kTile + u * kBlockP + threadIdx.x;
+        const uint64_t i = (uint64_t)blockIdx.x * kTile + u * kBlockP + threadIdx.x;
         const uint64_t j = i < o.n ? i : last;
         const uint32_t a = o.a_id[j], b = o.b_id[j];
         in[u] = i < o.n && a < n_reads && b < n_reads;
@@ -432,13 +415,12 @@ __global__ __launch_bounds__(kBlockP) void l2_scatter_kernel(const uint64_t* __r
                                                              const uint32_t* __restrict__ tile_part,
                                                              const uint32_t* __restrict__ tile_lo, const uint32_t* __restrict__ tile_hi,
                                                              const uint32_t* __restrict__ n_tiles, uint32_t* group_cursor,
-                                                             uint64_t* __restrict__ rec2, uint32_t xcd) {
+                                                             uint64_t* __restrict__ rec2) {
     extern __shared__ __align__(16) unsigned char s_raw[];
     __shared__ uint32_t tmp[kBlockP / 64 + 1];
-    const uint32_t tile = xcd_range_unit(blockIdx.x, *n_tiles, xcd);
-    if (tile == kInf) return;
+    if (blockIdx.x >= *n_tiles) return;
     StageLds L(s_raw, kGroupsPerPart);
-    const uint32_t part_word = tile_part[tile], lo = tile_lo[tile], hi = tile_hi[tile];
+    const uint32_t part_word = tile_part[blockIdx.x], lo = tile_lo[blockIdx.x], hi = tile_hi[blockIdx.x];
     const uint32_t part = part_word & ~kTileOtherBase;
     const uint64_t* __restrict__ src = (part_word & kTileOtherBase) ? rec1b : rec1;
     uint64_t rec[kPer];
@@ -492,15 +474,14 @@ __global__ __launch_bounds__(1024) void group_event_base_kernel(const uint32_t* 
 __global__ __launch_bounds__(kBlockP) void final_kernel(const uint64_t* __restrict__ rec2, const uint32_t* __restrict__ group_base,
                                                         const uint32_t* __restrict__ pair_base, uint32_t n_reads,
                                                         const uint32_t* __restrict__ acount, uint32_t* __restrict__ ev_off,
-                                                        uint32_t* __restrict__ ev, uint32_t shrink, uint32_t n_groups, uint32_t xcd) {
+                                                        uint32_t* __restrict__ ev, uint32_t shrink) {
     extern __shared__ __align__(16) unsigned char s_raw[];
     __shared__ uint32_t tmp[kBlockP / 64 + 1];
     __shared__ uint32_t s_cursor[kGroupReads];          // next free PAIR of every read's row
     __shared__ uint32_t s_cnt[kGroupReads];
     static_assert(kGroupReads <= kBlockP, "one thread per read of the group");
     StageLds L(s_raw, kGroupReads);
-    const uint32_t g = xcd_range_unit(blockIdx.x, n_groups, xcd);
-    if (g == kInf) return;
+    const uint32_t g = blockIdx.x;
     if (threadIdx.x < kGroupReads) s_cnt[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t lo = group_base[g], hi = group_base[g + 1];
@@ -552,15 +533,13 @@ __global__ __launch_bounds__(kBlockP) void final_kernel(const uint64_t* __restri
 // ONE atomic (the file is grouped by query).  written[] counts what a read has handed out so far.
 template <uint32_t kQ>
 __global__ __launch_bounds__(256) void query_side_kernel(OvlSoA o, uint32_t n_reads, const uint32_t* __restrict__ ev_off,
-                                                         uint32_t* written, uint32_t* __restrict__ ev, uint32_t n_chunks, uint32_t xcd) {
+                                                         uint32_t* written, uint32_t* __restrict__ ev) {
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t chunk = xcd_range_unit(blockIdx.x, n_chunks, xcd);
-    if (chunk == kInf) return;
     uint32_t a[kQ], b[kQ], begin[kQ], end[kQ];
     // (the coordinates with the ids, not behind the add's round trip; kQ overlaps per thread, their loads together)
 #pragma unroll
     for (uint32_t u = 0; u < kQ; ++u) {
-        const uint64_t i = ((uint64_t)chunk * kQ + u) * 256 + threadIdx.x;
+        const uint64_t i = ((uint64_t)blockIdx.x * kQ + u) * 256 + threadIdx.x;
         a[u] = kInf; b[u] = kInf; begin[u] = 0; end[u] = 0;
         if (i < o.n) { a[u] = o.a_id[i]; b[u] = o.b_id[i]; begin[u] = __builtin_nontemporal_load(o.a_begin + i); end[u] = __builtin_nontemporal_load(o.a_end + i); }
     }
@@ -788,17 +767,16 @@ hipError_t count_attribute(size_t lds_count) {
 void launch_partition_rest(const PartitionBuffers& B, uint32_t n_reads, const uint32_t* acount, const uint64_t* rec1, uint64_t* rec2,
                            uint32_t* ev_off, uint32_t* ev, hipStream_t s, uint32_t shrink = 15u) {
     const uint32_t tiles2 = (uint32_t)(B.tile_slots - 4);               // at least as many as the table can hold
-    const uint32_t x = g_bucket_xcd;
-    hipLaunchKernelGGL(l2_scatter_kernel, dim3(tiles2 + ((x & 2u) ? 8u : 0u)), dim3(kBlockP), stage_lds_bytes(kGroupsPerPart), s, rec1, (const uint64_t*)nullptr,
+    hipLaunchKernelGGL(l2_scatter_kernel, dim3(tiles2), dim3(kBlockP), stage_lds_bytes(kGroupsPerPart), s, rec1, (const uint64_t*)nullptr,
                        (const uint32_t*)B.tile_part, (const uint32_t*)B.tile_lo, (const uint32_t*)B.tile_hi, (const uint32_t*)B.n_tiles,
-                       B.group_cursor, rec2, x & 2u);
+                       B.group_cursor, rec2);
     // (the groups' counts and cursors have served: their places take the query-side sums and the groups' first pairs)
     uint32_t *qsum = B.group_count, *pair_base = B.group_cursor;
     hipLaunchKernelGGL(group_query_sum_kernel, dim3(B.n_groups), dim3(kGroupReads), 0, s, acount, n_reads, qsum);
     hipLaunchKernelGGL(group_event_base_kernel, dim3(1), dim3(1024), 0, s, (const uint32_t*)qsum, (const uint32_t*)B.group_base, B.n_groups,
                        pair_base);
-    hipLaunchKernelGGL(final_kernel, dim3(xcd_range_grid(B.n_groups, x & 4u)), dim3(kBlockP), stage_lds_bytes(kGroupReads), s, (const uint64_t*)rec2,
-                       (const uint32_t*)B.group_base, (const uint32_t*)pair_base, n_reads, acount, ev_off, ev, shrink, B.n_groups, x & 4u);
+    hipLaunchKernelGGL(final_kernel, dim3(B.n_groups), dim3(kBlockP), stage_lds_bytes(kGroupReads), s, (const uint64_t*)rec2,
+                       (const uint32_t*)B.group_base, (const uint32_t*)pair_base, n_reads, acount, ev_off, ev, shrink);
 }
 }  // namespace
 
@@ -847,19 +825,17 @@ hipError_t launch_bucket_partitioned(const OvlSoA& o, uint32_t n_reads, uint32_t
     const uint32_t tiles1 = (uint32_t)((o.n + kTile - 1) / kTile);
     e = wait_for(dedupe ? dedupe->b_coords : nullptr);
     if (e != hipSuccess) return e;
-    const uint32_t x = g_bucket_xcd;
-    hipLaunchKernelGGL(l1_scatter_kernel, dim3(xcd_range_grid(tiles1, x & 1u)), dim3(kBlockP), stage_lds_bytes(B.n_part), s, o, n_reads, B.n_part, part_cursor, rec1,
-                       acount, tiles1, x & 1u);
+    hipLaunchKernelGGL(l1_scatter_kernel, dim3(tiles1), dim3(kBlockP), stage_lds_bytes(B.n_part), s, o, n_reads, B.n_part, part_cursor, rec1,
+                       acount);
     launch_partition_rest(B, n_reads, acount, rec1, rec2, ev_off, ev, s);
     // (overlaps per thread: two - 1.27 against 1.31 ms for the stage at C3 in two of three alternations, four: the same as one;
     // RALA_QUERY_PER for the measurement)
     e = wait_for(dedupe ? dedupe->a_coords : nullptr);
     if (e != hipSuccess) return e;
     static const int q_per = getenv("RALA_QUERY_PER") ? atoi(getenv("RALA_QUERY_PER")) : 2;
-    const uint32_t qc = (uint32_t)((o.n + 256u * (uint32_t)q_per - 1) / (256u * (uint32_t)q_per));
-    if (q_per == 4) hipLaunchKernelGGL(query_side_kernel<4>, dim3(xcd_range_grid(qc, x & 8u)), dim3(256), 0, s, o, n_reads, (const uint32_t*)ev_off, written, ev, qc, x & 8u);
-    else if (q_per == 2) hipLaunchKernelGGL(query_side_kernel<2>, dim3(xcd_range_grid(qc, x & 8u)), dim3(256), 0, s, o, n_reads, (const uint32_t*)ev_off, written, ev, qc, x & 8u);
-    else hipLaunchKernelGGL(query_side_kernel<1>, dim3(xcd_range_grid(qc, x & 8u)), dim3(256), 0, s, o, n_reads, (const uint32_t*)ev_off, written, ev, qc, x & 8u);
+    if (q_per == 4) hipLaunchKernelGGL(query_side_kernel<4>, dim3((uint32_t)((o.n + 1023) / 1024)), dim3(256), 0, s, o, n_reads, (const uint32_t*)ev_off, written, ev);
+    else if (q_per == 2) hipLaunchKernelGGL(query_side_kernel<2>, dim3((uint32_t)((o.n + 511) / 512)), dim3(256), 0, s, o, n_reads, (const uint32_t*)ev_off, written, ev);
+    else hipLaunchKernelGGL(query_side_kernel<1>, dim3((uint32_t)((o.n + 255) / 256)), dim3(256), 0, s, o, n_reads, (const uint32_t*)ev_off, written, ev);
     return hipGetLastError();
 }
 
@@ -976,13 +952,12 @@ hipError_t launch_bucket_from_blocks(const uint64_t* base, const uint64_t* base_
                        tile_lo, tile_hi, n_tiles);
     hipLaunchKernelGGL(l2_scatter_kernel, dim3((uint32_t)(tile_slots - 4)), dim3(kBlockP), stage_lds_bytes(kGroupsPerPart), s, base, base_self,
                        (const uint32_t*)tile_part, (const uint32_t*)tile_lo, (const uint32_t*)tile_hi, (const uint32_t*)n_tiles, group_cursor,
-                       rec2, 0u);
+                       rec2);
     // (every event is a record's: the groups' first pairs are the groups' first records)
     const uint32_t n_groups = (n_reads_local + kGroupReads - 1) / kGroupReads;
     if (n_groups) {
         hipLaunchKernelGGL(final_kernel, dim3(n_groups), dim3(kBlockP), stage_lds_bytes(kGroupReads), s, (const uint64_t*)rec2,
-                           (const uint32_t*)group_base, (const uint32_t*)group_base, n_reads_local, (const uint32_t*)nullptr, ev_off, ev, 15u,
-                           n_groups, 0u);
+                           (const uint32_t*)group_base, (const uint32_t*)group_base, n_reads_local, (const uint32_t*)nullptr, ev_off, ev, 15u);
     }
     return hipGetLastError();
 }

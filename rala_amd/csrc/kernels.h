@@ -422,7 +422,6 @@ struct BucketDedupe {
     // counting pass, for b_coords in front of the first scatter, for a_coords in front of the query side
     hipEvent_t ids = nullptr, b_coords = nullptr, a_coords = nullptr;
 };
-extern uint32_t g_bucket_xcd;        // (bucket_kernels.hip: which of the bucketing's kernels hand their units out in XCD ranges; measurements)
 bool bucket_count_can_dedupe(const OvlSoA& o, const uint8_t* valid);      // (the id columns on 16-byte boundaries)
 hipError_t launch_bucket_partitioned(const OvlSoA& o, uint32_t n_reads, uint32_t* acount, uint32_t* written,
                                      uint32_t* part_cursor, uint32_t* group, uint32_t* tiles, uint64_t* rec1, uint64_t* rec2,
