@@ -49,20 +49,39 @@ constexpr uint32_t kInf = 0xFFFFFFFFu;
 constexpr uint32_t kTile = 4096;                // records per workgroup
 constexpr uint32_t kBlockP = 512;
 constexpr uint32_t kPer = kTile / kBlockP;
-constexpr uint32_t kL1Shift = 12;               // 4096 reads per level-1 partition
+constexpr uint32_t kL1Shift = 12;               // 4096 reads per level-1 partition (a sharded run's owners; one GPU: PartGeom below)
 constexpr uint32_t kL1Reads = 1u << kL1Shift;
 constexpr uint32_t kGroupShift = 7;             // 128 reads per final group
 constexpr uint32_t kGroupReads = 1u << kGroupShift;
 constexpr uint32_t kGroupsPerPart = kL1Reads / kGroupReads;
-constexpr uint32_t kCoordBits = 26;
+constexpr uint32_t kKeyBits = 14;               // the low bits of the read a record keeps: enough for the largest partition
+constexpr uint32_t kCoordBits = 25;
 constexpr uint32_t kCoordMax = (1u << kCoordBits) - 1u;
+static_assert(kKeyBits + 2 * kCoordBits == 64, "a record is 8 bytes");
+
+// One GPU (round 6): the first scatter's bins are partitions of 4096 reads up to a million reads - and of 8192 or 16384 beyond, so
+// that there are never more than 256 of them.  A tile of 4096 records spread over C5's 977 partitions wrote runs of four records
+// (34 bytes); over 245 partitions of 16384 reads it writes whole lines again, and the second scatter takes the two more bits
+// (128 groups per partition instead of 32).  C5's first scatter: 2.45 ms for 6x C3's records where C3 takes 0.31.
+struct PartGeom {
+    uint32_t shift, gpp, n_part;                // reads per partition = 1 << shift; groups per partition; partitions
+};
+}  // namespace
+uint32_t g_part_shift = 0;                      // (option "debug_part_shift", tests and measurements: 12 .. 14; 0 = by the rule)
+namespace {
+inline PartGeom part_geom(uint32_t n_reads) {
+    uint32_t shift = kL1Shift;
+    while (shift < kKeyBits && ((uint64_t)n_reads + (1u << shift) - 1) >> shift > 256) ++shift;
+    if (g_part_shift >= kL1Shift && g_part_shift <= kKeyBits) shift = g_part_shift;
+    return PartGeom{shift, 1u << (shift - kGroupShift), (uint32_t)(((uint64_t)n_reads + (1u << shift) - 1) >> shift)};
+}
 
 __device__ __forceinline__ uint64_t pack_record(uint32_t b, uint32_t begin, uint32_t end) {
-    // coordinates beyond 2^26 lie outside every read this path takes (pipeline.hip) and stay outside
-    return (uint64_t)(b & (kL1Reads - 1u)) << 52 | (uint64_t)(begin < kCoordMax ? begin : kCoordMax) << kCoordBits |
+    // coordinates beyond 2^25 lie outside every read this path takes (partition_path_fits) and stay outside
+    return (uint64_t)(b & ((1u << kKeyBits) - 1u)) << (2 * kCoordBits) | (uint64_t)(begin < kCoordMax ? begin : kCoordMax) << kCoordBits |
            (uint64_t)(end < kCoordMax ? end : kCoordMax);
 }
-__device__ __forceinline__ uint32_t rec_key(uint64_t r) { return (uint32_t)(r >> 52); }
+__device__ __forceinline__ uint32_t rec_key(uint64_t r) { return (uint32_t)(r >> (2 * kCoordBits)); }
 // shrink: 15 for the primary overlaps (graph.cpp:317-324), 0 for the sensitive ones (graph.cpp:929-933: no +-15)
 __device__ __forceinline__ uint2 rec_events(uint64_t r, uint32_t shrink) {
     const uint32_t begin = (uint32_t)(r >> kCoordBits) & kCoordMax, end = (uint32_t)r & kCoordMax;
@@ -238,12 +257,12 @@ __global__ __launch_bounds__(kBlockC) void group_count_dedupe_kernel(OvlSoA o, u
 // n] and group_cursor = exclusive prefix; part_cursor[p] = group_base[p * kGroupsPerPart] (a partition's records
 // lie where its groups' will); the table of level-2 tiles - tile t covers records tile_lo[t] .. tile_hi[t] of
 // partition tile_part[t], *n_tiles of them.  One workgroup.
-__global__ __launch_bounds__(1024) void layout_kernel(const uint32_t* __restrict__ group_count, uint32_t n_part,
+__global__ __launch_bounds__(1024) void layout_kernel(const uint32_t* __restrict__ group_count, uint32_t n_part, uint32_t gpp,
                                                       uint32_t* __restrict__ group_base, uint32_t* __restrict__ group_cursor,
                                                       uint32_t* __restrict__ part_cursor, uint32_t* __restrict__ tile_part,
                                                       uint32_t* __restrict__ tile_lo, uint32_t* __restrict__ tile_hi, uint32_t* n_tiles) {
     __shared__ uint32_t tmp[1024 / 64 + 1];
-    const uint32_t n = n_part * kGroupsPerPart;
+    const uint32_t n = n_part * gpp;
     uint32_t carry = 0;
     for (uint32_t g0 = 0; g0 < n; g0 += 1024) {
         const uint32_t g = g0 + threadIdx.x;
@@ -253,7 +272,7 @@ __global__ __launch_bounds__(1024) void layout_kernel(const uint32_t* __restrict
         if (g < n) {
             group_base[g] = carry + ex;
             group_cursor[g] = carry + ex;
-            if (g % kGroupsPerPart == 0) part_cursor[g / kGroupsPerPart] = carry + ex;
+            if (g % gpp == 0) part_cursor[g / gpp] = carry + ex;
         }
         carry += tot;
     }
@@ -262,8 +281,8 @@ __global__ __launch_bounds__(1024) void layout_kernel(const uint32_t* __restrict
     uint32_t tile_carry = 0;
     for (uint32_t p0 = 0; p0 < n_part; p0 += 1024) {
         const uint32_t p = p0 + threadIdx.x;
-        const uint32_t lo = p < n_part ? group_base[p * kGroupsPerPart] : 0u;
-        const uint32_t hi = p < n_part ? group_base[(p + 1u) * kGroupsPerPart] : 0u;
+        const uint32_t lo = p < n_part ? group_base[p * gpp] : 0u;
+        const uint32_t hi = p < n_part ? group_base[(p + 1u) * gpp] : 0u;
         const uint32_t tiles = (hi - lo + kTile - 1) / kTile;
         uint32_t ttot;
         const uint32_t tex = block_scan_excl<1024>(tiles, OpAdd(), 0u, tmp, ttot);
@@ -333,7 +352,7 @@ __device__ __forceinline__ void stage_and_copy(StageLds& L, uint32_t n_bins, con
 }
 
 // + acount[a] = resolvable overlaps of query a (its query-side events / 2)
-__global__ __launch_bounds__(kBlockP) void l1_scatter_kernel(OvlSoA o, uint32_t n_reads, uint32_t n_part, uint32_t* part_cursor,
+__global__ __launch_bounds__(kBlockP) void l1_scatter_kernel(OvlSoA o, uint32_t n_reads, uint32_t n_part, uint32_t shift, uint32_t* part_cursor,
                                                              uint64_t* __restrict__ rec1, uint32_t* acount) {
     extern __shared__ __align__(16) unsigned char s_raw[];
     __shared__ uint32_t tmp[kBlockP / 64 + 1];
@@ -350,7 +369,7 @@ __global__ __launch_bounds__(kBlockP) void l1_scatter_kernel(OvlSoA o, uint32_t 
         const uint32_t a = o.a_id[j], b = o.b_id[j];
         in[u] = i < o.n && a < n_reads && b < n_reads;
         rec[u] = pack_record(b, o.b_begin[j], o.b_end[j]);
-        bin[u] = in[u] ? b >> kL1Shift : 0u;
+        bin[u] = in[u] ? b >> shift : 0u;
         uint32_t leader;
         const uint32_t seg = segment_of(a, in[u], lane, leader);
         if (seg) atomicAdd(&acount[a], seg);
@@ -388,7 +407,7 @@ __global__ __launch_bounds__(kBlockC) void group_count_records_kernel(const uint
 }
 
 __global__ __launch_bounds__(kBlockP) void l1_scatter_records_kernel(const uint64_t* __restrict__ records, uint64_t n, uint32_t n_reads,
-                                                                     uint32_t n_part, uint32_t* part_cursor, uint64_t* __restrict__ rec1) {
+                                                                     uint32_t n_part, uint32_t shift, uint32_t* part_cursor, uint64_t* __restrict__ rec1) {
     extern __shared__ __align__(16) unsigned char s_raw[];
     __shared__ uint32_t tmp[kBlockP / 64 + 1];
     StageLds L(s_raw, n_part);
@@ -403,7 +422,7 @@ __global__ __launch_bounds__(kBlockP) void l1_scatter_records_kernel(const uint6
         const uint32_t key = bound_record_read(r);
         in[u] = i < n && key < n_reads;
         rec[u] = pack_record(key, (uint32_t)(r >> kBoundRecordCoordBits) & kMask, (uint32_t)r & kMask);
-        bin[u] = in[u] ? key >> kL1Shift : 0u;
+        bin[u] = in[u] ? key >> shift : 0u;
     }
     stage_and_copy(L, n_part, rec, bin, in, part_cursor, rec1, tmp);
 }
@@ -415,11 +434,12 @@ __global__ __launch_bounds__(kBlockP) void l2_scatter_kernel(const uint64_t* __r
                                                              const uint32_t* __restrict__ tile_part,
                                                              const uint32_t* __restrict__ tile_lo, const uint32_t* __restrict__ tile_hi,
                                                              const uint32_t* __restrict__ n_tiles, uint32_t* group_cursor,
-                                                             uint64_t* __restrict__ rec2) {
+                                                             uint64_t* __restrict__ rec2, uint32_t gpp) {
     extern __shared__ __align__(16) unsigned char s_raw[];
     __shared__ uint32_t tmp[kBlockP / 64 + 1];
     if (blockIdx.x >= *n_tiles) return;
-    StageLds L(s_raw, kGroupsPerPart);
+    StageLds L(s_raw, gpp);
+    const uint32_t part_mask = gpp * kGroupReads - 1u;      // (a record keeps 14 bits of its read: those of its partition)
     const uint32_t part_word = tile_part[blockIdx.x], lo = tile_lo[blockIdx.x], hi = tile_hi[blockIdx.x];
     const uint32_t part = part_word & ~kTileOtherBase;
     const uint64_t* __restrict__ src = (part_word & kTileOtherBase) ? rec1b : rec1;
@@ -431,9 +451,9 @@ __global__ __launch_bounds__(kBlockP) void l2_scatter_kernel(const uint64_t* __r
         const uint32_t j = lo + u * kBlockP + threadIdx.x;
         in[u] = j < hi;
         rec[u] = in[u] ? src[j] : 0ull;
-        bin[u] = rec_key(rec[u]) >> kGroupShift;
+        bin[u] = (rec_key(rec[u]) & part_mask) >> kGroupShift;
     }
-    stage_and_copy(L, kGroupsPerPart, rec, bin, in, group_cursor + part * kGroupsPerPart, rec2, tmp);
+    stage_and_copy(L, gpp, rec, bin, in, group_cursor + part * gpp, rec2, tmp);
 }
 
 // ---- final: one workgroup per group of 128 reads -------------------------------------------------------
@@ -721,16 +741,17 @@ __global__ __launch_bounds__(1024) void shard_owner_layout_kernel(const uint64_t
 
 }  // namespace
 
-uint32_t partition_count(uint32_t n_reads) { return (n_reads + kL1Reads - 1) / kL1Reads; }
-uint32_t partition_group_slots(uint32_t n_reads) { return partition_count(n_reads) * kGroupsPerPart + 2; }
+uint32_t partition_count(uint32_t n_reads) { return part_geom(n_reads).n_part; }
+uint32_t partition_group_slots(uint32_t n_reads) { const PartGeom G = part_geom(n_reads); return G.n_part * G.gpp + 2; }
 size_t partition_records_needed(uint32_t, uint64_t n_overlaps) { return (size_t)n_overlaps + 64; }
 size_t partition_tile_slots(uint32_t n_reads, uint64_t n_overlaps) { return (size_t)(n_overlaps / kTile) + partition_count(n_reads) + 4; }
 bool partition_path_fits(uint32_t n_reads, uint32_t max_read_len, uint64_t n_overlaps) {
-    // coordinates in 26 bits; the histogram of all groups in the LDS of one workgroup; level-1 histograms next to
+    // coordinates in 25 bits; the histogram of all groups in the LDS of one workgroup; level-1 histograms next to
     // the staging area; positions in 32 bits; enough overlaps per partition for whole-line copies
     if (n_reads == 0 || n_overlaps == 0) return false;
-    const uint64_t n_part = partition_count(n_reads);
-    return max_read_len < kCoordMax - 32u && n_part * kGroupsPerPart * 4u <= 150u * 1024u &&
+    const PartGeom G = part_geom(n_reads);
+    const uint64_t n_part = G.n_part;
+    return max_read_len < kCoordMax - 32u && n_part * G.gpp * 4u <= 150u * 1024u &&
            stage_lds_bytes((uint32_t)n_part) <= 60u * 1024u && 4ull * n_overlaps < 0xFFFFFFF0ull && n_overlaps / n_part >= 512;
 }
 
@@ -740,11 +761,12 @@ bool partition_path_fits(uint32_t n_reads, uint32_t max_read_len, uint64_t n_ove
 // what the caller has put in.  workgroups: compute units of the device (the counting kernel's persistent workgroups).
 namespace {
 struct PartitionBuffers {
-    uint32_t n_part, n_groups, group_slots;
+    uint32_t n_part, n_groups, group_slots, shift, gpp;
     size_t tile_slots;
     uint32_t *group_count, *group_base, *group_cursor, *tile_part, *tile_lo, *tile_hi, *n_tiles;
     PartitionBuffers(uint32_t n_reads, uint64_t n_records, uint32_t* group, uint32_t* tiles) {
-        n_part = partition_count(n_reads);
+        const PartGeom G = part_geom(n_reads);
+        n_part = G.n_part; shift = G.shift; gpp = G.gpp;
         n_groups = (n_reads + kGroupReads - 1) / kGroupReads;
         group_slots = partition_group_slots(n_reads);
         tile_slots = partition_tile_slots(n_reads, n_records);
@@ -767,9 +789,9 @@ hipError_t count_attribute(size_t lds_count) {
 void launch_partition_rest(const PartitionBuffers& B, uint32_t n_reads, const uint32_t* acount, const uint64_t* rec1, uint64_t* rec2,
                            uint32_t* ev_off, uint32_t* ev, hipStream_t s, uint32_t shrink = 15u) {
     const uint32_t tiles2 = (uint32_t)(B.tile_slots - 4);               // at least as many as the table can hold
-    hipLaunchKernelGGL(l2_scatter_kernel, dim3(tiles2), dim3(kBlockP), stage_lds_bytes(kGroupsPerPart), s, rec1, (const uint64_t*)nullptr,
+    hipLaunchKernelGGL(l2_scatter_kernel, dim3(tiles2), dim3(kBlockP), stage_lds_bytes(B.gpp), s, rec1, (const uint64_t*)nullptr,
                        (const uint32_t*)B.tile_part, (const uint32_t*)B.tile_lo, (const uint32_t*)B.tile_hi, (const uint32_t*)B.n_tiles,
-                       B.group_cursor, rec2);
+                       B.group_cursor, rec2, B.gpp);
     // (the groups' counts and cursors have served: their places take the query-side sums and the groups' first pairs)
     uint32_t *qsum = B.group_count, *pair_base = B.group_cursor;
     hipLaunchKernelGGL(group_query_sum_kernel, dim3(B.n_groups), dim3(kGroupReads), 0, s, acount, n_reads, qsum);
@@ -799,7 +821,7 @@ hipError_t launch_bucket_partitioned(const OvlSoA& o, uint32_t n_reads, uint32_t
     if (dedupe) fills.add(dedupe->suspect, 0, n_reads);
     hipError_t e = fills.launch(s);
     if (e != hipSuccess) return e;
-    const size_t lds_count = (size_t)B.n_part * kGroupsPerPart * 4;
+    const size_t lds_count = (size_t)B.n_part * B.gpp * 4;
     e = count_attribute(lds_count);
     if (e != hipSuccess) return e;
     const uint32_t chunks = (uint32_t)((o.n + kBlockC * kCountPer - 1) / (kBlockC * kCountPer));
@@ -810,7 +832,7 @@ hipError_t launch_bucket_partitioned(const OvlSoA& o, uint32_t n_reads, uint32_t
     const uint32_t count_groups = (workgroups ? workgroups : 256u) * (2 * lds_count <= 150u * 1024u ? 2u : 1u);
     if (dedupe) {
         hipLaunchKernelGGL(group_count_dedupe_kernel<false>, dim3(std::min<uint32_t>(count_groups, chunks)), dim3(kBlockC), lds_count, s, o,
-                           n_reads, B.n_part * kGroupsPerPart, B.group_count, dedupe->suspect, dedupe->valid, dedupe->list_pos,
+                           n_reads, B.n_part * B.gpp, B.group_count, dedupe->suspect, dedupe->valid, dedupe->list_pos,
                            dedupe->list_query, dedupe->list_cap, dedupe->list_count, 1u, 0u);
         if (dedupe->counted) {
             e = hipEventRecord(dedupe->counted, s);
@@ -818,14 +840,14 @@ hipError_t launch_bucket_partitioned(const OvlSoA& o, uint32_t n_reads, uint32_t
         }
     } else {
         hipLaunchKernelGGL(group_count_kernel, dim3(std::min<uint32_t>(count_groups, chunks)), dim3(kBlockC), lds_count, s, o,
-                           n_reads, B.n_part * kGroupsPerPart, B.group_count);
+                           n_reads, B.n_part * B.gpp, B.group_count);
     }
-    hipLaunchKernelGGL(layout_kernel, dim3(1), dim3(1024), 0, s, (const uint32_t*)B.group_count, B.n_part, B.group_base, B.group_cursor,
+    hipLaunchKernelGGL(layout_kernel, dim3(1), dim3(1024), 0, s, (const uint32_t*)B.group_count, B.n_part, B.gpp, B.group_base, B.group_cursor,
                        part_cursor, B.tile_part, B.tile_lo, B.tile_hi, B.n_tiles);
     const uint32_t tiles1 = (uint32_t)((o.n + kTile - 1) / kTile);
     e = wait_for(dedupe ? dedupe->b_coords : nullptr);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(l1_scatter_kernel, dim3(tiles1), dim3(kBlockP), stage_lds_bytes(B.n_part), s, o, n_reads, B.n_part, part_cursor, rec1,
+    hipLaunchKernelGGL(l1_scatter_kernel, dim3(tiles1), dim3(kBlockP), stage_lds_bytes(B.n_part), s, o, n_reads, B.n_part, B.shift, part_cursor, rec1,
                        acount);
     launch_partition_rest(B, n_reads, acount, rec1, rec2, ev_off, ev, s);
     // (overlaps per thread: two - 1.27 against 1.31 ms for the stage at C3 in two of three alternations, four: the same as one;
@@ -850,19 +872,19 @@ hipError_t launch_bucket_partitioned_records(const uint64_t* records, uint64_t n
     fills.add(B.group_count, 0, (size_t)B.group_slots * 4);
     hipError_t e = fills.launch(s);
     if (e != hipSuccess) return e;
-    const size_t lds_count = (size_t)B.n_part * kGroupsPerPart * 4;
+    const size_t lds_count = (size_t)B.n_part * B.gpp * 4;
     e = count_attribute(lds_count);
     if (e != hipSuccess) return e;
     const uint32_t chunks = (uint32_t)((n + kBlockC * kCountPer - 1) / (kBlockC * kCountPer));
     const uint32_t count_groups = (workgroups ? workgroups : 256u) * (2 * lds_count <= 150u * 1024u ? 2u : 1u);
     hipLaunchKernelGGL(group_count_records_kernel, dim3(std::min<uint32_t>(count_groups, std::max<uint32_t>(chunks, 1u))), dim3(kBlockC),
-                       lds_count, s, records, n, n_reads, B.n_part * kGroupsPerPart, B.group_count);
-    hipLaunchKernelGGL(layout_kernel, dim3(1), dim3(1024), 0, s, (const uint32_t*)B.group_count, B.n_part, B.group_base, B.group_cursor,
+                       lds_count, s, records, n, n_reads, B.n_part * B.gpp, B.group_count);
+    hipLaunchKernelGGL(layout_kernel, dim3(1), dim3(1024), 0, s, (const uint32_t*)B.group_count, B.n_part, B.gpp, B.group_base, B.group_cursor,
                        part_cursor, B.tile_part, B.tile_lo, B.tile_hi, B.n_tiles);
     const uint32_t tiles1 = (uint32_t)((n + kTile - 1) / kTile);
     if (tiles1) {
         hipLaunchKernelGGL(l1_scatter_records_kernel, dim3(tiles1), dim3(kBlockP), stage_lds_bytes(B.n_part), s, records, n, n_reads,
-                           B.n_part, part_cursor, rec1);
+                           B.n_part, B.shift, part_cursor, rec1);
     }
     launch_partition_rest(B, n_reads, zero_counts, rec1, rec2, ev_off, ev, s, shrink);
     return hipGetLastError();
@@ -952,7 +974,7 @@ hipError_t launch_bucket_from_blocks(const uint64_t* base, const uint64_t* base_
                        tile_lo, tile_hi, n_tiles);
     hipLaunchKernelGGL(l2_scatter_kernel, dim3((uint32_t)(tile_slots - 4)), dim3(kBlockP), stage_lds_bytes(kGroupsPerPart), s, base, base_self,
                        (const uint32_t*)tile_part, (const uint32_t*)tile_lo, (const uint32_t*)tile_hi, (const uint32_t*)n_tiles, group_cursor,
-                       rec2);
+                       rec2, kGroupsPerPart);
     // (every event is a record's: the groups' first pairs are the groups' first records)
     const uint32_t n_groups = (n_reads_local + kGroupReads - 1) / kGroupReads;
     if (n_groups) {

@@ -422,6 +422,7 @@ struct BucketDedupe {
     // counting pass, for b_coords in front of the first scatter, for a_coords in front of the query side
     hipEvent_t ids = nullptr, b_coords = nullptr, a_coords = nullptr;
 };
+extern uint32_t g_part_shift;        // (bucket_kernels.hip, option "debug_part_shift": reads per first-level partition = 1 << shift, 12 .. 14; 0 = by the rule)
 bool bucket_count_can_dedupe(const OvlSoA& o, const uint8_t* valid);      // (the id columns on 16-byte boundaries)
 hipError_t launch_bucket_partitioned(const OvlSoA& o, uint32_t n_reads, uint32_t* acount, uint32_t* written,
                                      uint32_t* part_cursor, uint32_t* group, uint32_t* tiles, uint64_t* rec1, uint64_t* rec2,

@@ -2190,6 +2190,7 @@ int rala_hip_set_option(rala_hip_ctx* ctx, const char* key, int64_t value) {
     if (!strcmp(key, "use_bound_records")) { ctx->use_bound_records = value != 0; return RALA_HIP_OK; }
     if (!strcmp(key, "use_fused_emit")) { ctx->use_fused_emit = value != 0; return RALA_HIP_OK; }
     if (!strcmp(key, "ingest_window_bytes")) { ctx->ingest_window_bytes = std::max<int64_t>(0, value); return RALA_HIP_OK; }
+    if (!strcmp(key, "debug_part_shift")) { g_part_shift = (uint32_t)std::max<int64_t>(0, value); return RALA_HIP_OK; }
     if (!strcmp(key, "debug_pile_variant")) { ctx->debug_pile_variant = (uint32_t)std::max<int64_t>(0, value); return RALA_HIP_OK; }
     if (!strcmp(key, "debug_dedupe_list_cap")) { ctx->debug_dedupe_list_cap = (uint32_t)std::max<int64_t>(0, value); return RALA_HIP_OK; }
     if (!strcmp(key, "debug_fp_lds_limit")) { ctx->debug_fp_lds_limit = (uint32_t)std::max<int64_t>(0, value); return RALA_HIP_OK; }
@@ -2441,7 +2442,7 @@ static int initialize_stages(rala_hip_ctx* ctx) {
     const uint32_t slot = kRunEventCapBig;
     // Partitioned path (bucket_kernels.hip): the target side through two partitioning passes instead of one
     // memory-side atomic and one partial write per overlap; ends in the exact CSR.  Needs the overlaps
-    // (not tuples), coordinates below 2^26, enough overlaps per partition for the passes to pay, few enough
+    // (not tuples), coordinates below 2^25, enough overlaps per partition for the passes to pay, few enough
     // reads for a histogram of their groups of 128 to fit the LDS (9 M).
     const bool partition_allowed = ctx->use_run_kernel && ctx->use_fixed_buckets && ctx->use_partitioned_buckets;
     // (an owner rank's bound records: the same path from level 1 on, both sides as records; input that does not suit it

@@ -12,7 +12,7 @@
 //           block stays where it is
 //   owner   second level of the bucketing over the blocks as they lie, rows, then build + annotate the
 //           piles of the owned reads                                                  O(bases / P)
-//           (reads of 2^26 bases and more, or option use_fused_emit = 0: bound records / tuples grouped by
+//           (reads of 2^25 bases and more, or option use_fused_emit = 0: bound records / tuples grouped by
 //           owner, bucketed from the start by the owner - rounds 2 - 4)
 //   comm    all-gather of the per-read state (19 B per read) and the interval pools
 //   slice   classify (trim / type) against the gathered state                         O(N / P)

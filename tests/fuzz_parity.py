@@ -48,6 +48,7 @@ for case in range(n_cases):
         ctx.set_option("use_side_stream", int(rng.random() < 0.8))
         if rng.random() < 0.4:      # the containment fixed points' long lists' kernel / a mix of both
             ctx.set_option("debug_fp_lds_limit", int(rng.choice([0, 7, 100])))
+        ctx.set_option("debug_part_shift", int(rng.choice([0, 0, 12, 13, 14])))     # first-level partitions of 4096 / 8192 / 16384 reads
         if rng.random() < 0.25:     # duplicate removal: a mark list that overflows (the pass over all overlaps takes over)
             ctx.set_option("debug_dedupe_list_cap", int(rng.choice([1, 3, 40])))
             variant.append("marks")

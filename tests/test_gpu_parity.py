@@ -73,6 +73,29 @@ def test_bucketing_variants(hip_ctx_factory, n, g, seed):
         parity.check_initialize(ctx, st, ds)
 
 
+@pytest.mark.parametrize("shift", [12, 13, 14])
+@pytest.mark.parametrize("n,g,seed", [(40_000, 8_000_000, 13), (9000, 1_800_000, 4)])
+def test_first_level_partition_sizes(hip_ctx_factory, n, g, seed, shift):
+    """The partitioned bucketing's first-level partitions hold 4096 reads up to a million reads and 8192 / 16384 beyond (never
+    more than 256 partitions - round 6: C5's first scatter wrote runs of four records over 977 of them); here every size on data
+    sets of ten and three partitions of 4096 (option debug_part_shift), every pile row against the oracle's; the sharded owners'
+    level-2 kernels see the same 14-bit record keys (tests/test_gpu_sharded.py, tests/fuzz_sharded.py)"""
+    ds = Dataset(n, g, seed)
+    st = parity.oracle_stages(ds)
+    ctx = hip_ctx_factory()
+    ctx.set_option("debug_part_shift", shift)
+    try:
+        ctx.set_reads(ds.read_len)
+        ctx.set_overlaps(ds.overlaps)
+        ctx.initialize()
+        parity.check_initialize(ctx, st, ds)
+        ctx.construct()
+        parity.check_construct(ctx, st)
+        parity.check_tr(ctx, st)
+    finally:
+        ctx.set_option("debug_part_shift", 0)           # (a process-wide switch)
+
+
 @pytest.mark.parametrize("n,g,seed", [(3000, 600_000, 21), (5000, 1_000_000, 7), (600, 60_000, 9), (40_000, 8_000_000, 13)])
 @pytest.mark.parametrize("opts", [{"debug_fp_lds_limit": 0}, {"debug_fp_lds_limit": 40}, {"use_round_batches": 0},
                                   {"debug_fp_lds_limit": 0, "env": ("RALA_HIP_DEBUG_FP_GIVE_UP", "1")},

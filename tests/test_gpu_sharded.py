@@ -110,7 +110,7 @@ def test_sharded_run_matches_oracle(sharded_factory, world, n, g, seed):
 @pytest.mark.parametrize("form", ["tuples", "records"])
 def test_sharded_run_bound_tuples_instead_of_records(sharded_factory, n, g, seed, factor, form):
     """The default (every other test here): the senders scatter the bounds ONCE, by (owner, partition of the owner's reads),
-    and the owners start at the second level of the partitioned bucketing (round 5; reads shorter than 2^26 - 32 bases).
+    and the owners start at the second level of the partitioned bucketing (round 5; reads shorter than 2^25 - 32 bases).
     These are the older formats, by option: "records" - 8-byte records {local read, begin, end} grouped by owner only, the
     owners bucket them from the first level on (rounds 3 - 4; reads shorter than 2^21 - 32 bases); "tuples" - two tuples
     {local read, bound} per overlap side through the owners' single-pass kernel (round 2) - and what reads of 2.3 M bases
@@ -133,7 +133,7 @@ def test_sharded_run_bound_tuples_instead_of_records(sharded_factory, n, g, seed
 
 
 def test_sharded_run_long_reads_through_the_blocks(sharded_factory):
-    """reads of 2.3 M bases (beyond the 21 coordinate bits of the older record format) still take the blocks: 26 bits"""
+    """reads of 2.3 M bases (beyond the 21 coordinate bits of the older record format) still take the blocks: 25 bits"""
     from test_gpu_parity import _Scaled
 
     ds = _Scaled(Dataset(400, 80_000, 5), 230)
