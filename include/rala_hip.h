@@ -102,6 +102,8 @@ const char* rala_hip_last_error(const rala_hip_ctx* ctx);
  * runs without the former: 0 ships two bound tuples per overlap side instead of one bound record),
  * "debug_part_shift" (tests / measurements, process-wide: the partitioned bucketing's first-level partitions hold 1 << value reads,
  * 12 .. 14; 0 = by the rule - 4096 reads, more where that would make more than 256 partitions),
+ * "debug_ev_events" (tests / measurements: 1 = the partitioned bucketing's row offsets count bound events where 4 n fits 32 bits, as
+ * before round 6; 0, the default: bound pairs - up to 2^31 overlaps per context),
  * "debug_dedupe_list_cap" (tests: the list of the runs duplicate removal's counting pass marks holds this many marks, 0 = the
  * default 2^20; a list that does not hold them all is given up and the pass over all overlaps does the work),
  * "debug_pile_stop_after" (diagnostics: leave the run-space pile kernel after phase k, 99 = all;

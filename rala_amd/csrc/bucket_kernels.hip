@@ -494,7 +494,7 @@ __global__ __launch_bounds__(1024) void group_event_base_kernel(const uint32_t* 
 __global__ __launch_bounds__(kBlockP) void final_kernel(const uint64_t* __restrict__ rec2, const uint32_t* __restrict__ group_base,
                                                         const uint32_t* __restrict__ pair_base, uint32_t n_reads,
                                                         const uint32_t* __restrict__ acount, uint32_t* __restrict__ ev_off,
-                                                        uint32_t* __restrict__ ev, uint32_t shrink) {
+                                                        uint32_t* __restrict__ ev, uint32_t shrink, uint32_t ev_shift) {
     extern __shared__ __align__(16) unsigned char s_raw[];
     __shared__ uint32_t tmp[kBlockP / 64 + 1];
     __shared__ uint32_t s_cursor[kGroupReads];          // next free PAIR of every read's row
@@ -517,7 +517,7 @@ __global__ __launch_bounds__(kBlockP) void final_kernel(const uint64_t* __restri
     for (uint32_t j = lo + kTile + threadIdx.x; j < hi; j += kBlockP) atomicAdd(&s_cnt[rec_key(rec2[j]) & (kGroupReads - 1u)], 1u);
     __syncthreads();
     {
-        // the reads' rows: query-side pairs, then target-side pairs; offsets in events (two per pair)
+        // the reads' rows: query-side pairs, then target-side pairs; offsets in events (two per pair; ev_shift 0) or in pairs (1)
         const uint32_t r = g * kGroupReads + threadIdx.x;
         const bool mine = threadIdx.x < kGroupReads && r < n_reads;
         const uint32_t q = mine && acount ? acount[r] : 0u;
@@ -525,9 +525,9 @@ __global__ __launch_bounds__(kBlockP) void final_kernel(const uint64_t* __restri
         uint32_t tot;
         const uint32_t before = pair_base[g] + block_scan_excl<(int)kBlockP>(pairs, OpAdd(), 0u, tmp, tot);
         if (mine) {
-            ev_off[r] = 2u * before;
+            ev_off[r] = before << (1u - ev_shift);
             s_cursor[threadIdx.x] = before + q;
-            if (r == n_reads - 1u) ev_off[n_reads] = 2u * (before + pairs);
+            if (r == n_reads - 1u) ev_off[n_reads] = (before + pairs) << (1u - ev_shift);
         }
     }
     __syncthreads();
@@ -550,10 +550,11 @@ __global__ __launch_bounds__(kBlockP) void final_kernel(const uint64_t* __restri
 }
 
 // query side: one thread per overlap; the lanes of a wavefront that share the query take their places from
-// ONE atomic (the file is grouped by query).  written[] counts what a read has handed out so far.
+// ONE atomic (the file is grouped by query).  written[] counts what a read has handed out so far - events, like ev_off
+// (ev_shift 0), or pairs like it (1).
 template <uint32_t kQ>
 __global__ __launch_bounds__(256) void query_side_kernel(OvlSoA o, uint32_t n_reads, const uint32_t* __restrict__ ev_off,
-                                                         uint32_t* written, uint32_t* __restrict__ ev) {
+                                                         uint32_t* written, uint32_t* __restrict__ ev, uint32_t ev_shift) {
     const uint32_t lane = threadIdx.x & 63;
     uint32_t a[kQ], b[kQ], begin[kQ], end[kQ];
     // (the coordinates with the ids, not behind the add's round trip; kQ overlaps per thread, their loads together)
@@ -570,12 +571,12 @@ __global__ __launch_bounds__(256) void query_side_kernel(OvlSoA o, uint32_t n_re
         ok[u] = a[u] < n_reads && b[u] < n_reads;
         const uint32_t seg = segment_of(a[u], ok[u], lane, leader[u]);
         base[u] = 0;
-        if (seg) base[u] = ev_off[a[u]] + atomicAdd(&written[a[u]], 2u * seg);
+        if (seg) base[u] = ev_off[a[u]] + atomicAdd(&written[a[u]], (2u >> ev_shift) * seg);
     }
 #pragma unroll
     for (uint32_t u = 0; u < kQ; ++u) {
         const uint32_t at = (uint32_t)__shfl((int)base[u], (int)leader[u], 64);
-        if (ok[u]) *(uint2*)(ev + at + 2u * (lane - leader[u])) = make_uint2((begin[u] + 15u) << 1, ((end[u] - 15u) << 1) | 1u);
+        if (ok[u]) *(uint2*)(ev + ((size_t)at << ev_shift) + 2u * (lane - leader[u])) = make_uint2((begin[u] + 15u) << 1, ((end[u] - 15u) << 1) | 1u);
     }
 }
 
@@ -747,12 +748,12 @@ size_t partition_records_needed(uint32_t, uint64_t n_overlaps) { return (size_t)
 size_t partition_tile_slots(uint32_t n_reads, uint64_t n_overlaps) { return (size_t)(n_overlaps / kTile) + partition_count(n_reads) + 4; }
 bool partition_path_fits(uint32_t n_reads, uint32_t max_read_len, uint64_t n_overlaps) {
     // coordinates in 25 bits; the histogram of all groups in the LDS of one workgroup; level-1 histograms next to
-    // the staging area; positions in 32 bits; enough overlaps per partition for whole-line copies
+    // the staging area; the bound PAIRS' positions (two per overlap) in 32 bits; enough overlaps per partition for whole-line copies
     if (n_reads == 0 || n_overlaps == 0) return false;
     const PartGeom G = part_geom(n_reads);
     const uint64_t n_part = G.n_part;
     return max_read_len < kCoordMax - 32u && n_part * G.gpp * 4u <= 150u * 1024u &&
-           stage_lds_bytes((uint32_t)n_part) <= 60u * 1024u && 4ull * n_overlaps < 0xFFFFFFF0ull && n_overlaps / n_part >= 512;
+           stage_lds_bytes((uint32_t)n_part) <= 60u * 1024u && 2ull * n_overlaps < 0xFFFFFFF0ull && n_overlaps / n_part >= 512;
 }
 
 // Buffers (device): acount, written: n_reads + 2 words each; part_cursor: n_part + 2 words; group: 3 *
@@ -787,7 +788,7 @@ hipError_t count_attribute(size_t lds_count) {
 
 // level 2 and the rows from the level-1 records
 void launch_partition_rest(const PartitionBuffers& B, uint32_t n_reads, const uint32_t* acount, const uint64_t* rec1, uint64_t* rec2,
-                           uint32_t* ev_off, uint32_t* ev, hipStream_t s, uint32_t shrink = 15u) {
+                           uint32_t* ev_off, uint32_t* ev, hipStream_t s, uint32_t ev_shift, uint32_t shrink = 15u) {
     const uint32_t tiles2 = (uint32_t)(B.tile_slots - 4);               // at least as many as the table can hold
     hipLaunchKernelGGL(l2_scatter_kernel, dim3(tiles2), dim3(kBlockP), stage_lds_bytes(B.gpp), s, rec1, (const uint64_t*)nullptr,
                        (const uint32_t*)B.tile_part, (const uint32_t*)B.tile_lo, (const uint32_t*)B.tile_hi, (const uint32_t*)B.n_tiles,
@@ -798,7 +799,7 @@ void launch_partition_rest(const PartitionBuffers& B, uint32_t n_reads, const ui
     hipLaunchKernelGGL(group_event_base_kernel, dim3(1), dim3(1024), 0, s, (const uint32_t*)qsum, (const uint32_t*)B.group_base, B.n_groups,
                        pair_base);
     hipLaunchKernelGGL(final_kernel, dim3(B.n_groups), dim3(kBlockP), stage_lds_bytes(kGroupReads), s, (const uint64_t*)rec2,
-                       (const uint32_t*)B.group_base, (const uint32_t*)pair_base, n_reads, acount, ev_off, ev, shrink);
+                       (const uint32_t*)B.group_base, (const uint32_t*)pair_base, n_reads, acount, ev_off, ev, shrink, ev_shift);
 }
 }  // namespace
 
@@ -812,7 +813,7 @@ bool bucket_count_can_dedupe(const OvlSoA& o, const uint8_t* valid) {
 hipError_t launch_bucket_partitioned(const OvlSoA& o, uint32_t n_reads, uint32_t* acount, uint32_t* written,
                                      uint32_t* part_cursor, uint32_t* group, uint32_t* tiles, uint64_t* rec1, uint64_t* rec2,
                                      uint32_t* ev_off, uint32_t* ev, uint32_t workgroups, FillList& fills, hipStream_t s,
-                                     const BucketDedupe* dedupe) {
+                                     const BucketDedupe* dedupe, uint32_t ev_shift) {
     const PartitionBuffers B(n_reads, o.n, group, tiles);
     // (with whatever the caller wants cleared at this point)
     fills.add(acount, 0, (size_t)n_reads * 4);
@@ -849,15 +850,15 @@ hipError_t launch_bucket_partitioned(const OvlSoA& o, uint32_t n_reads, uint32_t
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(l1_scatter_kernel, dim3(tiles1), dim3(kBlockP), stage_lds_bytes(B.n_part), s, o, n_reads, B.n_part, B.shift, part_cursor, rec1,
                        acount);
-    launch_partition_rest(B, n_reads, acount, rec1, rec2, ev_off, ev, s);
+    launch_partition_rest(B, n_reads, acount, rec1, rec2, ev_off, ev, s, ev_shift);
     // (overlaps per thread: two - 1.27 against 1.31 ms for the stage at C3 in two of three alternations, four: the same as one;
     // RALA_QUERY_PER for the measurement)
     e = wait_for(dedupe ? dedupe->a_coords : nullptr);
     if (e != hipSuccess) return e;
     static const int q_per = getenv("RALA_QUERY_PER") ? atoi(getenv("RALA_QUERY_PER")) : 2;
-    if (q_per == 4) hipLaunchKernelGGL(query_side_kernel<4>, dim3((uint32_t)((o.n + 1023) / 1024)), dim3(256), 0, s, o, n_reads, (const uint32_t*)ev_off, written, ev);
-    else if (q_per == 2) hipLaunchKernelGGL(query_side_kernel<2>, dim3((uint32_t)((o.n + 511) / 512)), dim3(256), 0, s, o, n_reads, (const uint32_t*)ev_off, written, ev);
-    else hipLaunchKernelGGL(query_side_kernel<1>, dim3((uint32_t)((o.n + 255) / 256)), dim3(256), 0, s, o, n_reads, (const uint32_t*)ev_off, written, ev);
+    if (q_per == 4) hipLaunchKernelGGL(query_side_kernel<4>, dim3((uint32_t)((o.n + 1023) / 1024)), dim3(256), 0, s, o, n_reads, (const uint32_t*)ev_off, written, ev, ev_shift);
+    else if (q_per == 2) hipLaunchKernelGGL(query_side_kernel<2>, dim3((uint32_t)((o.n + 511) / 512)), dim3(256), 0, s, o, n_reads, (const uint32_t*)ev_off, written, ev, ev_shift);
+    else hipLaunchKernelGGL(query_side_kernel<1>, dim3((uint32_t)((o.n + 255) / 256)), dim3(256), 0, s, o, n_reads, (const uint32_t*)ev_off, written, ev, ev_shift);
     return hipGetLastError();
 }
 
@@ -866,7 +867,7 @@ hipError_t launch_bucket_partitioned(const OvlSoA& o, uint32_t n_reads, uint32_t
 hipError_t launch_bucket_partitioned_records(const uint64_t* records, uint64_t n, uint32_t n_reads, uint32_t* zero_counts,
                                              uint32_t* part_cursor, uint32_t* group, uint32_t* tiles, uint64_t* rec1, uint64_t* rec2,
                                              uint32_t* ev_off, uint32_t* ev, uint32_t workgroups, FillList& fills, hipStream_t s,
-                                             uint32_t shrink) {
+                                             uint32_t shrink, uint32_t ev_shift) {
     const PartitionBuffers B(n_reads, n, group, tiles);
     fills.add(zero_counts, 0, (size_t)n_reads * 4);
     fills.add(B.group_count, 0, (size_t)B.group_slots * 4);
@@ -886,7 +887,7 @@ hipError_t launch_bucket_partitioned_records(const uint64_t* records, uint64_t n
         hipLaunchKernelGGL(l1_scatter_records_kernel, dim3(tiles1), dim3(kBlockP), stage_lds_bytes(B.n_part), s, records, n, n_reads,
                            B.n_part, B.shift, part_cursor, rec1);
     }
-    launch_partition_rest(B, n_reads, zero_counts, rec1, rec2, ev_off, ev, s, shrink);
+    launch_partition_rest(B, n_reads, zero_counts, rec1, rec2, ev_off, ev, s, ev_shift, shrink);
     return hipGetLastError();
 }
 
@@ -963,7 +964,7 @@ hipError_t launch_shard_emit(const OvlSoA& o, uint32_t n_reads, const ShardGeome
 hipError_t launch_bucket_from_blocks(const uint64_t* base, const uint64_t* base_self, const ShardBlocks& blocks, const ShardGeometry& g,
                                      uint32_t n_reads_local,
                                      uint64_t n_records, uint32_t* group, uint32_t* tiles, uint64_t* rec2, uint32_t* ev_off, uint32_t* ev,
-                                     FillList& fills, hipStream_t s) {
+                                     FillList& fills, hipStream_t s, uint32_t ev_shift) {
     hipError_t e = fills.launch(s);
     if (e != hipSuccess) return e;
     const uint32_t slots = g.groups + 2;
@@ -979,7 +980,7 @@ hipError_t launch_bucket_from_blocks(const uint64_t* base, const uint64_t* base_
     const uint32_t n_groups = (n_reads_local + kGroupReads - 1) / kGroupReads;
     if (n_groups) {
         hipLaunchKernelGGL(final_kernel, dim3(n_groups), dim3(kBlockP), stage_lds_bytes(kGroupReads), s, (const uint64_t*)rec2,
-                           (const uint32_t*)group_base, (const uint32_t*)group_base, n_reads_local, (const uint32_t*)nullptr, ev_off, ev, 15u);
+                           (const uint32_t*)group_base, (const uint32_t*)group_base, n_reads_local, (const uint32_t*)nullptr, ev_off, ev, 15u, ev_shift);
     }
     return hipGetLastError();
 }

@@ -191,6 +191,8 @@ struct rala_hip_ctx {
 
     // bound CSR
     rala_hip::DevBuf<uint32_t> d_ev_off, d_cursor, d_ev, d_slot_rank[2], d_ev_fixed;
+    bool debug_ev_events = false;
+    uint32_t ev_shift = 0;              // units of d_ev_off: 1 << ev_shift events (kernels.h: kBucketPairShift)
     rala_hip::DevBuf<unsigned char> d_scan_ws;
 
     // per-read annotation

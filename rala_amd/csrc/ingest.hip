@@ -186,7 +186,7 @@ int rala_hip::paf_tokenise_range(rala_hip_ctx* ctx, const char* path, uint64_t l
         INGEST_CHECK(hipStreamSynchronize(s));
     }
     tc = now_ms();
-    if ((uint64_t)n_lines >= 0xFFFFFFF0ull / 4) return ingest_fail(ctx, RALA_HIP_ETOOLARGE, "too many overlaps for 32-bit bound offsets");
+    if ((uint64_t)n_lines >= 0xFFFFFFF0ull / 2) return ingest_fail(ctx, RALA_HIP_ETOOLARGE, "too many overlaps for 32-bit bound offsets");
     for (int k = 0; k < 7; ++k) INGEST_CHECK(T.col[k]->ensure((size_t)n_lines + 1 + extra_rows));
     INGEST_CHECK(T.strand->ensure((size_t)n_lines + 1 + extra_rows));
     unsigned long long bad = ~0ull;
@@ -304,7 +304,7 @@ static int set_overlaps_from_text(rala_hip_ctx* ctx, const char* path, bool mhap
                 R.first_bad = (((part.first_bad >> 32) + rows) << 32) | (part.first_bad & 0xFFFFFFFFull);
                 break;
             }
-            if (rows + part.n_lines >= 0xFFFFFFF0ull / 4) return ingest_fail(ctx, RALA_HIP_ETOOLARGE, "too many overlaps for 32-bit bound offsets");
+            if (rows + part.n_lines >= 0xFFFFFFF0ull / 2) return ingest_fail(ctx, RALA_HIP_ETOOLARGE, "too many overlaps for 32-bit bound offsets");
             for (int k = 0; k < 7; ++k) {
                 if (ctx->d_paf_col[k].grow(rows, rows + part.n_lines + 1) != hipSuccess) return ingest_fail(ctx, RALA_HIP_ENOMEM, "device memory for the overlap columns");
                 if (part.n_lines) INGEST_CHECK(hipMemcpy(ctx->d_paf_col[k].p + rows, ctx->d_paf_win[k].p, part.n_lines * 4, hipMemcpyDeviceToDevice));

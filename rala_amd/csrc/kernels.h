@@ -30,10 +30,11 @@ struct PileArgs {
     const uint32_t* read_len;
     const uint64_t* pile_off;      // element offset of each pile row (rows padded to 8 elements)
     uint16_t* pile;                // all piles, row after row
-    const uint32_t* ev_off;        // CSR of bound events per read (n_reads + 1)
+    const uint32_t* ev_off;        // CSR of bound events per read (n_reads + 1), in units of 1 << ev_shift events
     const uint32_t* ev;            // pos << 1 | is_end
     const uint32_t* ev_cnt;        // non-null: fixed slots instead of the CSR - read r has ev_cnt[r] events
     uint32_t ev_stride;            //           at ev + r * ev_stride
+    uint32_t ev_shift = 0;         // 1: ev_off counts bound PAIRS (the partitioned bucketing, round 6: 2^31 overlaps instead of 2^30)
     const uint32_t* order;         // reads of this launch
     uint32_t n_items;
     const uint32_t* n_items_dev;   // when non-null the item count is read from device memory
@@ -317,9 +318,10 @@ void launch_list_members(const uint32_t* alive_reads, const uint8_t* touched, ui
 // to ONE counter per read: at C5 300 000 of them, 3 ms per kernel.
 struct SensSplitArgs {
     const uint32_t* read_len;
-    const uint32_t* ev_off;        // primary events: CSR, or
+    const uint32_t* ev_off;        // primary events: CSR (units of 1 << ev_shift events), or
     const uint32_t* ev_cnt;        // fixed slots (non-null)
     uint32_t ev_stride;
+    uint32_t ev_shift;
     const uint32_t* sens_off;
     const uint32_t* begin;
     const uint32_t* end;
@@ -424,10 +426,14 @@ struct BucketDedupe {
 };
 extern uint32_t g_part_shift;        // (bucket_kernels.hip, option "debug_part_shift": reads per first-level partition = 1 << shift, 12 .. 14; 0 = by the rule)
 bool bucket_count_can_dedupe(const OvlSoA& o, const uint8_t* valid);      // (the id columns on 16-byte boundaries)
+// Units of ev_off (round 6): the partitioned bucketing counts a read's bound PAIRS (an overlap puts one begin and one end on each of
+// its two reads), so 2 n < 2^32 bounds it - 2.1 G overlaps per context instead of the 1.07 G of offsets in events; the readers
+// shift (PileArgs::ev_shift).  The exact CSR and the tuples (single events) keep events.
+constexpr uint32_t kBucketPairShift = 1;
 hipError_t launch_bucket_partitioned(const OvlSoA& o, uint32_t n_reads, uint32_t* acount, uint32_t* written,
                                      uint32_t* part_cursor, uint32_t* group, uint32_t* tiles, uint64_t* rec1, uint64_t* rec2,
                                      uint32_t* ev_off, uint32_t* ev, uint32_t workgroups, FillList& fills, hipStream_t s,
-                                     const BucketDedupe* dedupe = nullptr);
+                                     const BucketDedupe* dedupe = nullptr, uint32_t ev_shift = kBucketPairShift);
 // the runs around the listed marks through the full comparison - or, when the list was given up, every overlap of a marked
 // query (two launches; the one that is not needed leaves at once)
 void launch_dedupe_fix(const OvlSoA& o, uint32_t n_reads, const BucketDedupe& d, hipStream_t s);
@@ -437,7 +443,7 @@ bool partition_path_fits_records(uint32_t n_reads, uint32_t max_read_len, uint64
 hipError_t launch_bucket_partitioned_records(const uint64_t* records, uint64_t n, uint32_t n_reads, uint32_t* zero_counts,
                                              uint32_t* part_cursor, uint32_t* group, uint32_t* tiles, uint64_t* rec1, uint64_t* rec2,
                                              uint32_t* ev_off, uint32_t* ev, uint32_t workgroups, FillList& fills, hipStream_t s,
-                                             uint32_t shrink = 15u);
+                                             uint32_t shrink = 15u, uint32_t ev_shift = kBucketPairShift);
 
 // ---- sharded runs: the bounds scattered once, on the sender, by (owner rank, partition of the owner's reads) ----------
 // (bucket_kernels.hip) read r = local read r / world of rank r % world; every owner's reads in partitions of 4096 and groups
@@ -465,7 +471,7 @@ hipError_t launch_shard_emit(const OvlSoA& o, uint32_t n_reads, const ShardGeome
 // owner: the blocks of all senders -> ev_off[n_reads_local + 1], ev (bounds drawn in by 15, graph.cpp:317-324)
 hipError_t launch_bucket_from_blocks(const uint64_t* base, const uint64_t* base_self, const ShardBlocks& blocks, const ShardGeometry& g, uint32_t n_reads_local,
                                      uint64_t n_records, uint32_t* group, uint32_t* tiles, uint64_t* rec2, uint32_t* ev_off, uint32_t* ev,
-                                     FillList& fills, hipStream_t s);
+                                     FillList& fills, hipStream_t s, uint32_t ev_shift = kBucketPairShift);
 
 // ---- PAF text -> columns (ingest_kernels.hip) ----------------------------------------------
 struct PafColumns {

@@ -101,8 +101,8 @@ __global__ __launch_bounds__(kBlock) void pile_build_annotate(PileArgs A) {
         RALA_STOP(0)
         // ---- 1. bound events -> difference array --------------------------
         {
-            const uint32_t n_ev = A.ev_cnt ? umin(A.ev_cnt[r], A.ev_stride) : A.ev_off[r + 1] - A.ev_off[r];
-            const uint32_t* __restrict__ rev = A.ev_cnt ? A.ev + (size_t)r * A.ev_stride : A.ev + A.ev_off[r];
+            const uint32_t n_ev = A.ev_cnt ? umin(A.ev_cnt[r], A.ev_stride) : (A.ev_off[r + 1] - A.ev_off[r]) << A.ev_shift;
+            const uint32_t* __restrict__ rev = A.ev_cnt ? A.ev + (size_t)r * A.ev_stride : A.ev + ((size_t)A.ev_off[r] << A.ev_shift);
             for (uint32_t k = tid; k < n_ev; k += kBlock) {
                 const uint32_t b = rev[k];
                 const uint32_t pos = b >> 1;

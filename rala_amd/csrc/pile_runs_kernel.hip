@@ -675,7 +675,7 @@ __global__ __launch_bounds__(64 * kWaves, kOne ? 7 : kBases > 32768 ? 2 : kBases
     if constexpr (kPlain && kSingleItemArgs) {
         // Without a loop over the items the compiler fetches every argument where it is first used: six dependent round trips to the
         // scalar cache in front of the events' loads.  Named here, what a wavefront's first steps need comes in ONE.
-        asm volatile("" : : "s"(A.read_len), "s"(A.pile_off), "s"(A.ev_off), "s"(A.ev), "s"(A.skip_dense), "s"(overflow_list),
+        asm volatile("" : : "s"(A.read_len), "s"(A.pile_off), "s"(A.ev_off), "s"(A.ev), "s"(A.ev_shift), "s"(A.skip_dense), "s"(overflow_list),
                      "s"(overflow_count), "s"(A.pile), "s"(A.error));
     }
 
@@ -740,14 +740,14 @@ __global__ __launch_bounds__(64 * kWaves, kOne ? 7 : kBases > 32768 ? 2 : kBases
             const uint32_t e0 = A.ev_off[r], e1 = A.ev_off[r + 1];
             n = A.read_len[r];
             row_off = A.pile_off[r];
-            n_ev_p = e1 - e0;
-            rev = A.ev + e0;
+            n_ev_p = (e1 - e0) << A.ev_shift;
+            rev = A.ev + ((size_t)e0 << A.ev_shift);
         } else {
             r = A.order ? A.order[item] : item;
             n = A.read_len[r];
             row_off = kSens == 2 ? 0 : A.pile_off[r];
-            n_ev_p = A.ev_cnt ? umin(A.ev_cnt[r], A.ev_stride) : A.ev_off[r + 1] - A.ev_off[r];
-            rev = A.ev_cnt ? A.ev + (size_t)r * A.ev_stride : A.ev + A.ev_off[r];
+            n_ev_p = A.ev_cnt ? umin(A.ev_cnt[r], A.ev_stride) : (A.ev_off[r + 1] - A.ev_off[r]) << A.ev_shift;
+            rev = A.ev_cnt ? A.ev + (size_t)r * A.ev_stride : A.ev + ((size_t)A.ev_off[r] << A.ev_shift);
         }
         uint32_t n_ev = n_ev_p;
         const uint32_t* __restrict__ sev = nullptr;
@@ -1836,7 +1836,7 @@ __global__ __launch_bounds__(256) void pile_dense_list_kernel(PileArgs A, uint32
         const uint32_t r = (blockIdx.x * kDenseListPer + u) * 256 + threadIdx.x;
         dense[u] = false;
         if (r < n_reads) {
-            const uint32_t n_ev = A.ev_cnt ? umin(A.ev_cnt[r], A.ev_stride) : A.ev_off[r + 1] - A.ev_off[r];
+            const uint32_t n_ev = A.ev_cnt ? umin(A.ev_cnt[r], A.ev_stride) : (A.ev_off[r + 1] - A.ev_off[r]) << A.ev_shift;
             dense[u] = n_ev > kRunEventCap;
         }
     }

@@ -719,7 +719,7 @@ int run_sens_pass(rala_hip_ctx* ctx, PileArgs pa, const RepeatArgs& ra, int mode
     }
     HIPCHECK(ctx->d_sens_split.ensure(5 * ((size_t)bound + 1)));
     SensSplitArgs sp;
-    sp.read_len = pa.read_len; sp.ev_off = pa.ev_off; sp.ev_cnt = pa.ev_cnt; sp.ev_stride = pa.ev_stride;
+    sp.read_len = pa.read_len; sp.ev_off = pa.ev_off; sp.ev_cnt = pa.ev_cnt; sp.ev_stride = pa.ev_stride; sp.ev_shift = pa.ev_shift;
     sp.sens_off = pa.sens_off; sp.begin = pa.begin; sp.end = pa.end;
     for (int c = 0; c < 5; ++c) sp.out[c] = ctx->d_sens_split.p + (size_t)c * ((size_t)bound + 1);
     sp.counts = ctx->d_chain_cnt.p + 8;
@@ -1001,7 +1001,7 @@ int preprocess_repeats(rala_hip_ctx* cs, rala_hip_ctx* cl, Comm* comm, const ral
         FillList fills;
         HIPCHECK(launch_bucket_partitioned_records(cs->d_sens_rec.p, n_sens, n_reads_l, cl->d_bk_u32[0].p, cl->d_bk_part.p, cl->d_bk_group.p,
                                                    cl->d_bk_tiles.p, cl->d_bk_rec[0].p, cl->d_bk_rec[1].p, cl->d_sens_off.p, cl->d_sens_ev.p,
-                                                   cl->n_compute_units, fills, sl, 0u));
+                                                   cl->n_compute_units, fills, sl, 0u, 0u));       // (the sensitive CSR: in events)
     } else {
         HIPCHECK(hipMemsetAsync(cl->d_sens_cur.p, 0, (nl + 1) * 4, sl));
         launch_count_tuples(tuples, n_tuples, (uint32_t)nl, cl->d_sens_cur.p, sl);
@@ -1030,7 +1030,7 @@ int preprocess_repeats(rala_hip_ctx* cs, rala_hip_ctx* cl, Comm* comm, const ral
     memset(&pa, 0, sizeof(pa));
     pa.read_len = cl->d_read_len.p; pa.pile_off = cl->d_pile_off.p; pa.pile = cl->d_pile.p;
     pa.ev_off = cl->d_ev_off.p; pa.ev = cl->ev_fixed ? cl->d_ev_fixed.p : cl->d_ev.p;
-    pa.ev_cnt = cl->ev_fixed ? cl->d_cursor.p : nullptr; pa.ev_stride = kRunEventCapBig;
+    pa.ev_cnt = cl->ev_fixed ? cl->d_cursor.p : nullptr; pa.ev_stride = kRunEventCapBig; pa.ev_shift = cl->ev_shift;
     pa.stop_after = 99;
     pa.begin = cl->d_begin.p; pa.end = cl->d_end.p; pa.median = cl->d_median.p; pa.p10 = cl->d_p10.p;
     pa.error = cl->d_small.p + 7;
@@ -2190,6 +2190,7 @@ int rala_hip_set_option(rala_hip_ctx* ctx, const char* key, int64_t value) {
     if (!strcmp(key, "use_bound_records")) { ctx->use_bound_records = value != 0; return RALA_HIP_OK; }
     if (!strcmp(key, "use_fused_emit")) { ctx->use_fused_emit = value != 0; return RALA_HIP_OK; }
     if (!strcmp(key, "ingest_window_bytes")) { ctx->ingest_window_bytes = std::max<int64_t>(0, value); return RALA_HIP_OK; }
+    if (!strcmp(key, "debug_ev_events")) { ctx->debug_ev_events = value != 0; return RALA_HIP_OK; }
     if (!strcmp(key, "debug_part_shift")) { g_part_shift = (uint32_t)std::max<int64_t>(0, value); return RALA_HIP_OK; }
     if (!strcmp(key, "debug_pile_variant")) { ctx->debug_pile_variant = (uint32_t)std::max<int64_t>(0, value); return RALA_HIP_OK; }
     if (!strcmp(key, "debug_dedupe_list_cap")) { ctx->debug_dedupe_list_cap = (uint32_t)std::max<int64_t>(0, value); return RALA_HIP_OK; }
@@ -2290,7 +2291,9 @@ int rala_hip_set_reads(rala_hip_ctx* ctx, const uint32_t* read_len, uint64_t n_r
 
 int rala_hip_set_overlaps(rala_hip_ctx* ctx, const rala_hip_overlaps* o, uint64_t n, int mem) {
     if (!ctx || (!o && n)) return RALA_HIP_EINVAL;
-    if (n >= 0xFFFFFFF0ull / 4) return fail(ctx, RALA_HIP_EINVAL, "too many overlaps for 32-bit bound offsets");
+    // (2 n bound pairs in 32 bits - the partitioned bucketing's offsets, kernels.h: kBucketPairShift; the other bucketing paths count
+    // 4 n events and say so in rala_hip_initialize when they meet more)
+    if (n >= 0xFFFFFFF0ull / 2) return fail(ctx, RALA_HIP_EINVAL, "too many overlaps for 32-bit bound offsets");
     HIPCHECK(hipSetDevice(ctx->device));
     HIPCHECK(hipStreamSynchronize(ctx->side));          // a failed call may have left work there
     HIPCHECK(hipStreamSynchronize(ctx->aux));
@@ -2443,8 +2446,9 @@ static int initialize_stages(rala_hip_ctx* ctx) {
     // Partitioned path (bucket_kernels.hip): the target side through two partitioning passes instead of one
     // memory-side atomic and one partial write per overlap; ends in the exact CSR.  Needs the overlaps
     // (not tuples), coordinates below 2^25, enough overlaps per partition for the passes to pay, few enough
-    // reads for a histogram of their groups of 128 to fit the LDS (9 M).
-    const bool partition_allowed = ctx->use_run_kernel && ctx->use_fixed_buckets && ctx->use_partitioned_buckets;
+    // reads for a histogram of their groups of 128 to fit the LDS (4.9 M).
+    // (round 6: whichever pile kernel follows - the position-space kernel reads the rows' offsets in pairs as well)
+    const bool partition_allowed = ctx->use_fixed_buckets && ctx->use_partitioned_buckets;
     // (an owner rank's bound records: the same path from level 1 on, both sides as records; input that does not suit it
     // is turned into tuples)
     const bool from_records = ctx->tuple_mode && ctx->records != nullptr && partition_allowed &&
@@ -2460,6 +2464,12 @@ static int initialize_stages(rala_hip_ctx* ctx) {
     const bool from_blocks = ctx->tuple_mode && ctx->blocks_mode;
     const bool partitioned = from_blocks || from_records || (!ctx->tuple_mode && partition_allowed &&
                                                              partition_path_fits(n_reads, ctx->max_read_len, ctx->n_ovl));
+    if (!partitioned && !ctx->tuple_mode && ctx->n_ovl >= 0xFFFFFFF0ull / 4) {
+        return fail(ctx, RALA_HIP_ETOOLARGE, "2^30 overlaps and more need the partitioned bucketing (its offsets count bound pairs); this input or these options rule it out");
+    }
+    // (the partitioned bucketing's offsets count bound pairs; option debug_ev_events = 1, tests and measurements: events where they fit)
+    const uint64_t n_bounds = from_blocks ? ctx->n_block_records : from_records ? ctx->n_records : 2 * ctx->n_ovl;
+    const uint32_t ev_shift = !partitioned || (ctx->debug_ev_events && 2 * n_bounds < 0xFFFFFFF0ull) ? 0u : kBucketPairShift;
     bool fixed = !partitioned && ctx->use_run_kernel && ctx->use_fixed_buckets && (uint64_t)n_reads * slot * 4ull <= (64ull << 30);
     static const bool dedupe_late = getenv("RALA_DEDUPE_LATE") != nullptr;
     const bool dedupe_early = forked && partitioned && !dedupe_late;
@@ -2483,7 +2493,7 @@ static int initialize_stages(rala_hip_ctx* ctx) {
         HIPCHECK(ctx->d_shard_tiles.ensure(3 * shard_tile_slots(g, ctx->n_block_records) + 2));
         HIPCHECK(ctx->d_bk_rec[1].ensure((size_t)ctx->n_block_records + 64));
         HIPCHECK(launch_bucket_from_blocks(ctx->blocks_base, ctx->blocks_base_self, ctx->blocks, g, n_reads, ctx->n_block_records,
-                                           ctx->d_shard_group.p, ctx->d_shard_tiles.p, ctx->d_bk_rec[1].p, ctx->d_ev_off.p, ctx->d_ev.p, fills, s));
+                                           ctx->d_shard_group.p, ctx->d_shard_tiles.p, ctx->d_bk_rec[1].p, ctx->d_ev_off.p, ctx->d_ev.p, fills, s, ev_shift));
     } else if (partitioned) {
         const uint64_t n_rec = from_records ? ctx->n_records : ctx->n_ovl;
         for (int k = 0; k < 3; ++k) HIPCHECK(ctx->d_bk_u32[k].ensure(n_reads + 2));
@@ -2494,7 +2504,7 @@ static int initialize_stages(rala_hip_ctx* ctx) {
         if (from_records) {
             HIPCHECK(launch_bucket_partitioned_records(ctx->records, ctx->n_records, n_reads, ctx->d_bk_u32[0].p, ctx->d_bk_part.p,
                                                        ctx->d_bk_group.p, ctx->d_bk_tiles.p, ctx->d_bk_rec[0].p, ctx->d_bk_rec[1].p,
-                                                       ctx->d_ev_off.p, ctx->d_ev.p, ctx->n_compute_units, fills, s));
+                                                       ctx->d_ev_off.p, ctx->d_ev.p, ctx->n_compute_units, fills, s, 15u, ev_shift));
         } else {
             constexpr uint32_t kMarks = 1u << 20;           // (C3: 1 - 2 % of a million queries)
             if (dedupe_counted) HIPCHECK(ctx->d_dedupe_list.ensure(2 * (size_t)kMarks));
@@ -2505,7 +2515,7 @@ static int initialize_stages(rala_hip_ctx* ctx) {
             HIPCHECK(launch_bucket_partitioned(ctx->ovl, n_reads, ctx->d_bk_u32[0].p, ctx->d_bk_u32[2].p,
                                                ctx->d_bk_part.p, ctx->d_bk_group.p, ctx->d_bk_tiles.p, ctx->d_bk_rec[0].p,
                                                ctx->d_bk_rec[1].p, ctx->d_ev_off.p, ctx->d_ev.p, ctx->n_compute_units, fills, s,
-                                               dedupe_counted ? &bd : nullptr));
+                                               dedupe_counted ? &bd : nullptr, ev_shift));
             if (dedupe_counted) {
                 HIPCHECK(hipStreamWaitEvent(ctx->side, ctx->ev[8], 0));
                 if (fine_upload) HIPCHECK(hipStreamWaitEvent(ctx->side, ctx->ev_up[3], 0));      // (the lengths)
@@ -2559,6 +2569,8 @@ static int initialize_stages(rala_hip_ctx* ctx) {
     a.read_len = ctx->d_read_len.p; a.pile_off = ctx->d_pile_off.p; a.pile = ctx->d_pile.p;
     a.ev_off = ctx->d_ev_off.p; a.ev = fixed ? ctx->d_ev_fixed.p : ctx->d_ev.p;
     a.ev_cnt = fixed ? ctx->d_cursor.p : nullptr; a.ev_stride = slot;
+    ctx->ev_shift = ev_shift;
+    a.ev_shift = ev_shift;
     a.add_to_existing = 0; a.slab = ctx->d_slab.p;
     a.stop_after = (uint32_t)ctx->debug_pile_stop_after;
     a.variant = ctx->debug_pile_variant;

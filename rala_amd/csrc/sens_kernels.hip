@@ -281,7 +281,7 @@ __global__ __launch_bounds__(kBlock) void sens_split_kernel(const uint32_t* __re
     if (i < n) {
         r = list[i];
         const uint32_t len = A.read_len[r];
-        const uint32_t ev = (A.ev_cnt ? umin(A.ev_cnt[r], A.ev_stride) : A.ev_off[r + 1] - A.ev_off[r]) + A.sens_off[r + 1] - A.sens_off[r];
+        const uint32_t ev = (A.ev_cnt ? umin(A.ev_cnt[r], A.ev_stride) : (A.ev_off[r + 1] - A.ev_off[r]) << A.ev_shift) + A.sens_off[r + 1] - A.sens_off[r];
         const bool region = A.end[r] > A.begin[r];
         cls = !region ? 4u
             : len <= 16384u && ev <= kRunEventCap - 2u ? 0u

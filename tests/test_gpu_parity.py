@@ -96,6 +96,26 @@ def test_first_level_partition_sizes(hip_ctx_factory, n, g, seed, shift):
         ctx.set_option("debug_part_shift", 0)           # (a process-wide switch)
 
 
+@pytest.mark.parametrize("n,g,seed", [(9000, 1_800_000, 4), (600, 60_000, 9)])
+@pytest.mark.parametrize("opts", [{}, {"use_run_kernel": 0}])
+def test_row_offsets_in_events(hip_ctx_factory, n, g, seed, opts):
+    """The partitioned bucketing's row offsets count bound PAIRS since round 6 (2^31 overlaps per context instead of 2^30; every
+    other test runs that way); debug_ev_events = 1 is the old unit - both pile kernels read either (PileArgs::ev_shift)"""
+    ds = Dataset(n, g, seed)
+    st = parity.oracle_stages(ds)
+    ctx = hip_ctx_factory()
+    ctx.set_option("debug_ev_events", 1)
+    for k, v in opts.items():
+        ctx.set_option(k, v)
+    ctx.set_reads(ds.read_len)
+    ctx.set_overlaps(ds.overlaps)
+    ctx.initialize()
+    parity.check_initialize(ctx, st, ds)
+    ctx.construct()
+    parity.check_construct(ctx, st)
+    parity.check_tr(ctx, st)
+
+
 @pytest.mark.parametrize("n,g,seed", [(3000, 600_000, 21), (5000, 1_000_000, 7), (600, 60_000, 9), (40_000, 8_000_000, 13)])
 @pytest.mark.parametrize("opts", [{"debug_fp_lds_limit": 0}, {"debug_fp_lds_limit": 40}, {"use_round_batches": 0},
                                   {"debug_fp_lds_limit": 0, "env": ("RALA_HIP_DEBUG_FP_GIVE_UP", "1")},
