@@ -68,6 +68,7 @@ struct PartGeom {
 };
 }  // namespace
 uint32_t g_part_shift = 0;                      // (option "debug_part_shift", tests and measurements: 12 .. 14; 0 = by the rule)
+uint32_t g_count_window = 0;                    // (option "debug_count_window", tests: groups per counting pass; 0 = what the LDS holds)
 namespace {
 inline PartGeom part_geom(uint32_t n_reads) {
     uint32_t shift = kL1Shift;
@@ -75,6 +76,10 @@ inline PartGeom part_geom(uint32_t n_reads) {
     if (g_part_shift >= kL1Shift && g_part_shift <= kKeyBits) shift = g_part_shift;
     return PartGeom{shift, 1u << (shift - kGroupShift), (uint32_t)(((uint64_t)n_reads + (1u << shift) - 1) >> shift)};
 }
+
+// groups of 128 reads whose counts one counting pass keeps in a workgroup's LDS (4 bytes each in 150 KB: 4.9 M reads)
+constexpr uint32_t kCountWindow = 150u * 1024u / 4u;
+inline uint32_t count_window() { return g_count_window ? g_count_window : kCountWindow; }
 
 __device__ __forceinline__ uint64_t pack_record(uint32_t b, uint32_t begin, uint32_t end) {
     // coordinates beyond 2^25 lie outside every read this path takes (partition_path_fits) and stay outside
@@ -106,7 +111,9 @@ __device__ __forceinline__ uint32_t segment_of(uint32_t key, bool active, uint32
 // ---- level 1: target >> 12 ------------------------------------------------------------------------
 constexpr uint32_t kBlockC = 1024;
 constexpr uint32_t kCountPer = 8;
-__global__ __launch_bounds__(kBlockC) void group_count_kernel(OvlSoA o, uint32_t n_reads, uint32_t n_groups, uint32_t* group_count) {
+// g_lo, n_groups (round 6): the window of groups this launch counts - all of them where their histogram fits a workgroup's LDS
+// (4.9 M reads), otherwise window after window, the ids streamed once per window (count_window)
+__global__ __launch_bounds__(kBlockC) void group_count_kernel(OvlSoA o, uint32_t n_reads, uint32_t g_lo, uint32_t n_groups, uint32_t* group_count) {
     extern __shared__ uint32_t s_hist[];
     for (uint32_t g = threadIdx.x; g < n_groups; g += kBlockC) s_hist[g] = 0;
     __syncthreads();
@@ -126,13 +133,14 @@ __global__ __launch_bounds__(kBlockC) void group_count_kernel(OvlSoA o, uint32_t
         }
 #pragma unroll
         for (uint32_t u = 0; u < kC; ++u) {
-            if (a[u] < n_reads && b[u] < n_reads) atomicAdd(&s_hist[b[u] >> kGroupShift], 1u);
+            const uint32_t g = (b[u] >> kGroupShift) - g_lo;
+            if (a[u] < n_reads && b[u] < n_reads && g < n_groups) atomicAdd(&s_hist[g], 1u);
         }
     }
     __syncthreads();
     for (uint32_t g = threadIdx.x; g < n_groups; g += kBlockC) {
         const uint32_t c = s_hist[g];
-        if (c) atomicAdd(&group_count[g], c);
+        if (c) atomicAdd(&group_count[g_lo + g], c);
     }
 }
 
@@ -207,7 +215,8 @@ __global__ __launch_bounds__(kBlockC) void group_count_dedupe_kernel(OvlSoA o, u
                         atomicAdd(&s_hist[(x % world) * groups + ((x / world) >> kGroupShift)], 1u);
                         atomicAdd(&s_hist[(y % world) * groups + ((y / world) >> kGroupShift)], 1u);
                     } else {
-                        atomicAdd(&s_hist[y >> kGroupShift], 1u);
+                        // (the first window of groups - usually all of them; the windows behind it: group_count_kernel)
+                        if ((y >> kGroupShift) < n_groups) atomicAdd(&s_hist[y >> kGroupShift], 1u);
                     }
                 }
                 if (in && have_prev) {
@@ -382,7 +391,7 @@ __global__ __launch_bounds__(kBlockP) void l1_scatter_kernel(OvlSoA o, uint32_t 
 __device__ __forceinline__ uint32_t bound_record_read(uint64_t r) { return (uint32_t)(r >> (2 * kBoundRecordCoordBits)); }
 
 __global__ __launch_bounds__(kBlockC) void group_count_records_kernel(const uint64_t* __restrict__ records, uint64_t n, uint32_t n_reads,
-                                                                      uint32_t n_groups, uint32_t* group_count) {
+                                                                      uint32_t g_lo, uint32_t n_groups, uint32_t* group_count) {
     extern __shared__ uint32_t s_hist[];
     for (uint32_t g = threadIdx.x; g < n_groups; g += kBlockC) s_hist[g] = 0;
     __syncthreads();
@@ -396,13 +405,14 @@ __global__ __launch_bounds__(kBlockC) void group_count_records_kernel(const uint
         }
 #pragma unroll
         for (uint32_t u = 0; u < kC; ++u) {
-            if (key[u] < n_reads) atomicAdd(&s_hist[key[u] >> kGroupShift], 1u);
+            const uint32_t g = (key[u] >> kGroupShift) - g_lo;
+            if (key[u] < n_reads && g < n_groups) atomicAdd(&s_hist[g], 1u);
         }
     }
     __syncthreads();
     for (uint32_t g = threadIdx.x; g < n_groups; g += kBlockC) {
         const uint32_t c = s_hist[g];
-        if (c) atomicAdd(&group_count[g], c);
+        if (c) atomicAdd(&group_count[g_lo + g], c);
     }
 }
 
@@ -752,7 +762,8 @@ bool partition_path_fits(uint32_t n_reads, uint32_t max_read_len, uint64_t n_ove
     if (n_reads == 0 || n_overlaps == 0) return false;
     const PartGeom G = part_geom(n_reads);
     const uint64_t n_part = G.n_part;
-    return max_read_len < kCoordMax - 32u && n_part * G.gpp * 4u <= 150u * 1024u &&
+    // (round 6: a histogram of all groups that outgrows the LDS is counted in windows - up to eight passes over the ids)
+    return max_read_len < kCoordMax - 32u && n_part * G.gpp <= 8ull * kCountWindow &&
            stage_lds_bytes((uint32_t)n_part) <= 60u * 1024u && 2ull * n_overlaps < 0xFFFFFFF0ull && n_overlaps / n_part >= 512;
 }
 
@@ -822,7 +833,8 @@ hipError_t launch_bucket_partitioned(const OvlSoA& o, uint32_t n_reads, uint32_t
     if (dedupe) fills.add(dedupe->suspect, 0, n_reads);
     hipError_t e = fills.launch(s);
     if (e != hipSuccess) return e;
-    const size_t lds_count = (size_t)B.n_part * B.gpp * 4;
+    const uint32_t all_groups = B.n_part * B.gpp, window = std::min(all_groups, count_window());
+    const size_t lds_count = (size_t)window * 4;
     e = count_attribute(lds_count);
     if (e != hipSuccess) return e;
     const uint32_t chunks = (uint32_t)((o.n + kBlockC * kCountPer - 1) / (kBlockC * kCountPer));
@@ -833,7 +845,7 @@ hipError_t launch_bucket_partitioned(const OvlSoA& o, uint32_t n_reads, uint32_t
     const uint32_t count_groups = (workgroups ? workgroups : 256u) * (2 * lds_count <= 150u * 1024u ? 2u : 1u);
     if (dedupe) {
         hipLaunchKernelGGL(group_count_dedupe_kernel<false>, dim3(std::min<uint32_t>(count_groups, chunks)), dim3(kBlockC), lds_count, s, o,
-                           n_reads, B.n_part * B.gpp, B.group_count, dedupe->suspect, dedupe->valid, dedupe->list_pos,
+                           n_reads, window, B.group_count, dedupe->suspect, dedupe->valid, dedupe->list_pos,
                            dedupe->list_query, dedupe->list_cap, dedupe->list_count, 1u, 0u);
         if (dedupe->counted) {
             e = hipEventRecord(dedupe->counted, s);
@@ -841,7 +853,11 @@ hipError_t launch_bucket_partitioned(const OvlSoA& o, uint32_t n_reads, uint32_t
         }
     } else {
         hipLaunchKernelGGL(group_count_kernel, dim3(std::min<uint32_t>(count_groups, chunks)), dim3(kBlockC), lds_count, s, o,
-                           n_reads, B.n_part * B.gpp, B.group_count);
+                           n_reads, 0u, window, B.group_count);
+    }
+    for (uint32_t g_lo = window; g_lo < all_groups; g_lo += window) {       // (more than 4.9 M reads: the other windows of groups)
+        hipLaunchKernelGGL(group_count_kernel, dim3(std::min<uint32_t>(count_groups, chunks)), dim3(kBlockC), lds_count, s, o,
+                           n_reads, g_lo, std::min(window, all_groups - g_lo), B.group_count);
     }
     hipLaunchKernelGGL(layout_kernel, dim3(1), dim3(1024), 0, s, (const uint32_t*)B.group_count, B.n_part, B.gpp, B.group_base, B.group_cursor,
                        part_cursor, B.tile_part, B.tile_lo, B.tile_hi, B.n_tiles);
@@ -873,13 +889,16 @@ hipError_t launch_bucket_partitioned_records(const uint64_t* records, uint64_t n
     fills.add(B.group_count, 0, (size_t)B.group_slots * 4);
     hipError_t e = fills.launch(s);
     if (e != hipSuccess) return e;
-    const size_t lds_count = (size_t)B.n_part * B.gpp * 4;
+    const uint32_t all_groups = B.n_part * B.gpp, window = std::min(all_groups, count_window());
+    const size_t lds_count = (size_t)window * 4;
     e = count_attribute(lds_count);
     if (e != hipSuccess) return e;
     const uint32_t chunks = (uint32_t)((n + kBlockC * kCountPer - 1) / (kBlockC * kCountPer));
     const uint32_t count_groups = (workgroups ? workgroups : 256u) * (2 * lds_count <= 150u * 1024u ? 2u : 1u);
-    hipLaunchKernelGGL(group_count_records_kernel, dim3(std::min<uint32_t>(count_groups, std::max<uint32_t>(chunks, 1u))), dim3(kBlockC),
-                       lds_count, s, records, n, n_reads, B.n_part * B.gpp, B.group_count);
+    for (uint32_t g_lo = 0; g_lo < all_groups; g_lo += window) {
+        hipLaunchKernelGGL(group_count_records_kernel, dim3(std::min<uint32_t>(count_groups, std::max<uint32_t>(chunks, 1u))), dim3(kBlockC),
+                           lds_count, s, records, n, n_reads, g_lo, std::min(window, all_groups - g_lo), B.group_count);
+    }
     hipLaunchKernelGGL(layout_kernel, dim3(1), dim3(1024), 0, s, (const uint32_t*)B.group_count, B.n_part, B.gpp, B.group_base, B.group_cursor,
                        part_cursor, B.tile_part, B.tile_lo, B.tile_hi, B.n_tiles);
     const uint32_t tiles1 = (uint32_t)((n + kTile - 1) / kTile);

@@ -424,6 +424,7 @@ struct BucketDedupe {
     // counting pass, for b_coords in front of the first scatter, for a_coords in front of the query side
     hipEvent_t ids = nullptr, b_coords = nullptr, a_coords = nullptr;
 };
+extern uint32_t g_count_window;      // (bucket_kernels.hip, option "debug_count_window": groups of 128 reads per counting pass; 0 = what the LDS holds)
 extern uint32_t g_part_shift;        // (bucket_kernels.hip, option "debug_part_shift": reads per first-level partition = 1 << shift, 12 .. 14; 0 = by the rule)
 bool bucket_count_can_dedupe(const OvlSoA& o, const uint8_t* valid);      // (the id columns on 16-byte boundaries)
 // Units of ev_off (round 6): the partitioned bucketing counts a read's bound PAIRS (an overlap puts one begin and one end on each of

@@ -2191,6 +2191,7 @@ int rala_hip_set_option(rala_hip_ctx* ctx, const char* key, int64_t value) {
     if (!strcmp(key, "use_fused_emit")) { ctx->use_fused_emit = value != 0; return RALA_HIP_OK; }
     if (!strcmp(key, "ingest_window_bytes")) { ctx->ingest_window_bytes = std::max<int64_t>(0, value); return RALA_HIP_OK; }
     if (!strcmp(key, "debug_ev_events")) { ctx->debug_ev_events = value != 0; return RALA_HIP_OK; }
+    if (!strcmp(key, "debug_count_window")) { g_count_window = (uint32_t)std::max<int64_t>(0, value); return RALA_HIP_OK; }
     if (!strcmp(key, "debug_part_shift")) { g_part_shift = (uint32_t)std::max<int64_t>(0, value); return RALA_HIP_OK; }
     if (!strcmp(key, "debug_pile_variant")) { ctx->debug_pile_variant = (uint32_t)std::max<int64_t>(0, value); return RALA_HIP_OK; }
     if (!strcmp(key, "debug_dedupe_list_cap")) { ctx->debug_dedupe_list_cap = (uint32_t)std::max<int64_t>(0, value); return RALA_HIP_OK; }

@@ -96,6 +96,33 @@ def test_first_level_partition_sizes(hip_ctx_factory, n, g, seed, shift):
         ctx.set_option("debug_part_shift", 0)           # (a process-wide switch)
 
 
+@pytest.mark.parametrize("n,g,seed,window", [(40_000, 8_000_000, 13, 64), (9000, 1_800_000, 4, 7), (9000, 1_800_000, 4, 1)])
+@pytest.mark.parametrize("sensitive", [False, True])
+def test_counting_pass_in_windows(hip_ctx_factory, n, g, seed, window, sensitive):
+    """The partitioned bucketing's counting pass keeps a histogram of all groups of 128 reads in a workgroup's LDS: 4.9 M reads.
+    Beyond that (round 6) it counts window after window of groups, the ids streamed once per window; here with windows of 64 / 7 /
+    1 groups on sets of 313 and 71 (option debug_count_window), duplicate removal's first pass riding on the first window only;
+    the sensitive pass' records (group_count_records_kernel) the same way"""
+    ds = Dataset(n, g, seed)
+    ctx = hip_ctx_factory()
+    ctx.set_option("debug_count_window", window)
+    try:
+        if sensitive:
+            if n <= 9000:
+                _check_sensitive(hip_ctx_factory, ds, 1, 1, expect_hills=True)
+            return
+        st = parity.oracle_stages(ds)
+        ctx.set_reads(ds.read_len)
+        ctx.set_overlaps(ds.overlaps)
+        ctx.initialize()
+        parity.check_initialize(ctx, st, ds)
+        ctx.construct()
+        parity.check_construct(ctx, st)
+        parity.check_tr(ctx, st)
+    finally:
+        ctx.set_option("debug_count_window", 0)         # (a process-wide switch)
+
+
 @pytest.mark.parametrize("n,g,seed", [(9000, 1_800_000, 4), (600, 60_000, 9)])
 @pytest.mark.parametrize("opts", [{}, {"use_run_kernel": 0}])
 def test_row_offsets_in_events(hip_ctx_factory, n, g, seed, opts):

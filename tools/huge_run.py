@@ -92,6 +92,12 @@ for name in ("pits", "hills"):
 for k in range(3):
     assert (a["rows"][k] == b["rows"][k]).all(), ("rows", k)
 print("[huge] position-space kernel: the same rows and annotations (%.1f ms)" % b["tm"]["total_ms"], flush=True)
+if len(ov) < (1 << 30):          # (the other bucketing paths count events: below 2^30 overlaps they can be compared)
+    c = one(use_partitioned_buckets=0)
+    for k in range(3):
+        assert (a["rows"][k] == c["rows"][k]).all(), ("rows, other bucketing", k)
+    print("[huge] bucketing: partitioned %.2f ms, the single-pass path %.2f ms - the same rows" % (a["tm"]["bucket_ms"], c["tm"]["bucket_ms"]), flush=True)
+    res.update(bucket_ms_partitioned=round(float(a["tm"]["bucket_ms"]), 3), bucket_ms_single_pass=round(float(c["tm"]["bucket_ms"]), 3))
 res.update(n_alive=int(alive.sum()), transitive_pairs=a["n_tr"], nodes=a["nodes"], edges=a["edges"], second_tr_pairs=a["second_tr"][0],
            stage_ms={k: round(float(v), 3) for k, v in a["tm_all"].items()},
            initialize_ms=round(float(a["tm"]["total_ms"]), 2), initialize_ms_position_space=round(float(b["tm"]["total_ms"]), 2),
