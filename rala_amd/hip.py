@@ -82,6 +82,8 @@ def lib(build=True):
         path = LIB_PATH
         if build:
             path = _build.build_hip()
+        if os.environ.get("RALA_HIP_LIB_AB"):        # (measurements: another build of the library, tools/gpurun/r6_build_ab.sh)
+            path = os.environ["RALA_HIP_LIB_AB"]
         if not os.path.exists(path):
             raise RuntimeError("librala_hip.so is missing: run __graft_entry__.build()")
         L = ctypes.CDLL(path)
