@@ -102,6 +102,8 @@ const char* rala_hip_last_error(const rala_hip_ctx* ctx);
  * runs without the former: 0 ships two bound tuples per overlap side instead of one bound record),
  * "debug_part_shift" (tests / measurements, process-wide: the partitioned bucketing's first-level partitions hold 1 << value reads,
  * 12 .. 14; 0 = by the rule - 4096 reads, more where that would make more than 256 partitions),
+ * "pile_chunk_mb" (default 1024: the rows of all piles lie in physical chunks of this many MB mapped side by side into one range -
+ * hipMemCreate / hipMemMap - which the first pile kernel's stores like better than where one hipMalloc puts them; 0 = one hipMalloc),
  * "debug_count_window" (tests, process-wide: the partitioned bucketing counts this many groups of 128 reads per pass over the ids;
  * 0 = what a workgroup's LDS holds, 38 400 - one pass up to 4.9 M reads),
  * "debug_ev_events" (tests / measurements: 1 = the partitioned bucketing's row offsets count bound events where 4 n fits 32 bits, as

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+
 #include <memory>
 #include <string>
 #include <vector>
@@ -35,11 +37,73 @@ template <class T>
 struct DevBuf {
     T* p = nullptr;
     size_t n = 0;
+    // (round 6: the buffer as physical chunks mapped side by side into one reserved range - ensure_chunked; the rows of the piles)
+    std::vector<hipMemGenericAllocationHandle_t> chunks;
+    size_t reserved = 0, chunk_size = 0;
     ~DevBuf() { release(); }
     void release() {
-        if (p) (void)hipFree(p);
+        if (reserved) {
+            (void)hipDeviceSynchronize();       // (hipFree waits for the device's work by itself; unmapping does not)
+            (void)hipMemUnmap(p, reserved);
+            for (auto h : chunks) (void)hipMemRelease(h);
+            // The RANGE is not given back (hipMemAddressFree): the next reservation would be handed the same addresses, and a
+            // kernel of the next context then wrote through translations of the OLD mapping - rows read back as zeros or as another
+            // data set's in 3 runs of 8 of tests/test_gpu_parity.py::test_rows_in_mapped_chunks, none in 8 once no address is ever
+            // mapped twice.  Address space is what leaks (a context's rows, out of 128 TB); when a reservation fails the caller
+            // falls back to hipMalloc.
+            chunks.clear();
+            reserved = 0;
+            chunk_size = 0;
+        } else if (p) {
+            (void)hipFree(p);
+        }
         p = nullptr;
         n = 0;
+    }
+    // chunk_bytes per physical allocation; order 1: chunk i lies at slot (i * stride) mod n_chunks of the range (neighbours in
+    // the range are not neighbours in the order of allocation)
+    hipError_t ensure_chunked(size_t count, size_t chunk_bytes, int order, int device) {
+        if (count <= n && p) return hipSuccess;
+        release();
+        hipMemAllocationProp prop = {};
+        prop.type = hipMemAllocationTypePinned;
+        prop.location.type = hipMemLocationTypeDevice;
+        prop.location.id = device;
+        size_t gran = 0;
+        hipError_t e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended);
+        if (e != hipSuccess) return e;
+        if (gran == 0) gran = 2u << 20;
+        chunk_bytes = (chunk_bytes + gran - 1) / gran * gran;
+        const size_t n_chunks = (count * sizeof(T) + chunk_bytes - 1) / chunk_bytes;
+        const size_t bytes = n_chunks * chunk_bytes;
+        void* base = nullptr;
+        e = hipMemAddressReserve(&base, bytes, 0, nullptr, 0);
+        if (e != hipSuccess) return e;
+        p = (T*)base;
+        reserved = bytes;
+        chunk_size = chunk_bytes;
+        size_t stride = 1;
+        if (order == 1 && n_chunks > 2) {
+            stride = (size_t)((double)n_chunks * 0.6180339887) | 1u;
+            auto gcd = [](size_t a, size_t b) { while (b) { const size_t t = a % b; a = b; b = t; } return a; };
+            while (gcd(stride, n_chunks) != 1) stride += 2;
+        }
+        for (size_t i = 0; i < n_chunks && e == hipSuccess; ++i) {
+            hipMemGenericAllocationHandle_t h;
+            e = hipMemCreate(&h, chunk_bytes, &prop, 0);
+            if (e != hipSuccess) break;
+            chunks.push_back(h);
+            e = hipMemMap((char*)base + ((i * stride) % n_chunks) * chunk_bytes, chunk_bytes, 0, h, 0);
+        }
+        if (e == hipSuccess) {
+            hipMemAccessDesc acc = {};
+            acc.location = prop.location;
+            acc.flags = hipMemAccessFlagsProtReadWrite;
+            e = hipMemSetAccess(base, bytes, &acc, 1);
+        }
+        if (e != hipSuccess) { release(); return e; }
+        n = bytes / sizeof(T);
+        return hipSuccess;
     }
     hipError_t ensure(size_t count) {
         if (count <= n && p) return hipSuccess;
@@ -48,6 +112,19 @@ struct DevBuf {
         hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
         if (e == hipSuccess) n = count;
         return e;
+    }
+    // Elements [first, first + count) to the host, chunk by chunk (every copy inside ONE of the runtime's allocations).
+    hipError_t copy_to_host(void* dst, size_t first, size_t count) const {
+        const char* src = (const char*)(p + first);
+        size_t left = count * sizeof(T);
+        while (left) {
+            size_t take = left;
+            if (chunk_size) take = std::min(left, chunk_size - (size_t)(src - (const char*)p) % chunk_size);
+            const hipError_t e = hipMemcpy(dst, src, take, hipMemcpyDeviceToHost);
+            if (e != hipSuccess) return e;
+            dst = (char*)dst + take; src += take; left -= take;
+        }
+        return hipSuccess;
     }
     // room for `count` elements, the first `keep` kept (a blocking copy when the buffer has to move)
     hipError_t grow(size_t keep, size_t count) {
@@ -191,6 +268,7 @@ struct rala_hip_ctx {
 
     // bound CSR
     rala_hip::DevBuf<uint32_t> d_ev_off, d_cursor, d_ev, d_slot_rank[2], d_ev_fixed;
+    uint32_t pile_chunk_mb = 1024;      // the rows' buffer as physical chunks of this size (0: one hipMalloc) - pipeline.hip
     bool debug_ev_events = false;
     uint32_t ev_shift = 0;              // units of d_ev_off: 1 << ev_shift events (kernels.h: kBucketPairShift)
     rala_hip::DevBuf<unsigned char> d_scan_ws;

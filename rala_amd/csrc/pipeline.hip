@@ -2190,6 +2190,7 @@ int rala_hip_set_option(rala_hip_ctx* ctx, const char* key, int64_t value) {
     if (!strcmp(key, "use_bound_records")) { ctx->use_bound_records = value != 0; return RALA_HIP_OK; }
     if (!strcmp(key, "use_fused_emit")) { ctx->use_fused_emit = value != 0; return RALA_HIP_OK; }
     if (!strcmp(key, "ingest_window_bytes")) { ctx->ingest_window_bytes = std::max<int64_t>(0, value); return RALA_HIP_OK; }
+    if (!strcmp(key, "pile_chunk_mb")) { ctx->pile_chunk_mb = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, 1 << 20)); return RALA_HIP_OK; }
     if (!strcmp(key, "debug_ev_events")) { ctx->debug_ev_events = value != 0; return RALA_HIP_OK; }
     if (!strcmp(key, "debug_count_window")) { g_count_window = (uint32_t)std::max<int64_t>(0, value); return RALA_HIP_OK; }
     if (!strcmp(key, "debug_part_shift")) { g_part_shift = (uint32_t)std::max<int64_t>(0, value); return RALA_HIP_OK; }
@@ -2388,7 +2389,22 @@ static int initialize_stages(rala_hip_ctx* ctx) {
     ctx->initialized = ctx->constructed = ctx->ev_ready = false;
     ctx->tail_on_device = ctx->host_stale = ctx->marks_on_device = false;
 
-    HIPCHECK(ctx->d_pile.ensure(ctx->pile_elems + 8));
+    {
+        // The rows as physical chunks of 1 GB mapped side by side into one range (round 6).  Where the rows lie physically decides
+        // whether the first pile kernel takes 3.8 or 4.3 ms at C3 (five placements inside one process: 3.84 / 4.20 / 4.12 / 4.27 /
+        // 3.81) - its stores, a wavefront per row, 7 000 rows open at a time, are the only access pattern of the path that feels it.
+        // hipMalloc's single block landed anywhere in that range; chunks of 1 GB mapped in order: 3.73 - 3.86 in 25 placements of 25,
+        // the bench line 7.19 - 7.22 ms in five processes against 7.36 - 7.55 alternating with them.
+        // Option pile_chunk_mb (0 = one hipMalloc; RALA_HIP_PILE_CHUNK_ORDER=1, measurements: the chunks permuted).  Falls back
+        // to hipMalloc where the driver refuses the mapping calls.
+        static const char* chunk_order = getenv("RALA_HIP_PILE_CHUNK_ORDER");
+        hipError_t ec = hipErrorNotSupported;
+        if (ctx->pile_chunk_mb > 0 && (ctx->pile_elems + 8) * sizeof(uint16_t) >= ((size_t)ctx->pile_chunk_mb << 20)) {
+            ec = ctx->d_pile.ensure_chunked(ctx->pile_elems + 8, (size_t)ctx->pile_chunk_mb << 20, chunk_order ? atoi(chunk_order) : 0, ctx->device);
+            if (ec != hipSuccess) (void)hipGetLastError();
+        }
+        if (ec != hipSuccess) HIPCHECK(ctx->d_pile.ensure(ctx->pile_elems + 8));
+    }
     // (whatever a failed call may have left on the aux stream ends before the counters are reset)
     HIPCHECK(hipEventRecord(ctx->ev[9], ctx->aux));
     HIPCHECK(hipStreamWaitEvent(s, ctx->ev[9], 0));
@@ -3282,7 +3298,7 @@ int rala_hip_get_pile_data(rala_hip_ctx* ctx, uint64_t read, uint16_t* data) {
     HIPCHECK(hipSetDevice(ctx->device));
     { const int rcm = materialize_host(ctx); if (rcm != RALA_HIP_OK) return rcm; }
     const uint32_t n = ctx->h_read_len[read];
-    HIPCHECK(hipMemcpy(data, ctx->d_pile.p + ctx->h_pile_off[read], (size_t)n * 2, hipMemcpyDeviceToHost));
+    HIPCHECK(ctx->d_pile.copy_to_host(data, ctx->h_pile_off[read], n));
     // Pile::shrink zeroes outside the current valid region (pile.cpp:311-318); the
     // host tail narrows regions after the pile was written
     if (ctx->h_alive[read]) {

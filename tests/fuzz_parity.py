@@ -49,6 +49,7 @@ for case in range(n_cases):
         if rng.random() < 0.4:      # the containment fixed points' long lists' kernel / a mix of both
             ctx.set_option("debug_fp_lds_limit", int(rng.choice([0, 7, 100])))
         ctx.set_option("debug_part_shift", int(rng.choice([0, 0, 12, 13, 14])))     # first-level partitions of 4096 / 8192 / 16384 reads
+        ctx.set_option("pile_chunk_mb", int(rng.choice([1024, 2, 2, 0])))          # the rows in chunks of 2 MB / in one hipMalloc
         ctx.set_option("debug_count_window", int(rng.choice([0, 0, 0, 3, 17])))    # the counting pass in windows of groups (beyond 4.9 M reads)
         ctx.set_option("debug_ev_events", int(rng.random() < 0.3))     # the rows' offsets in events (before round 6) / in pairs
         if rng.random() < 0.25:     # duplicate removal: a mark list that overflows (the pass over all overlaps takes over)

@@ -124,6 +124,26 @@ def test_counting_pass_in_windows(hip_ctx_factory, n, g, seed, window, sensitive
 
 
 @pytest.mark.parametrize("n,g,seed", [(9000, 1_800_000, 4), (600, 60_000, 9)])
+@pytest.mark.parametrize("chunk_mb", [2, 16, 0])
+def test_rows_in_mapped_chunks(hip_ctx_factory, n, g, seed, chunk_mb):
+    """The rows of all piles lie in physical chunks mapped side by side into one range (hipMemCreate / hipMemMap; 1 GB each in the
+    product, where a data set has that much - round 6: the first pile kernel's stores are faster there than where one hipMalloc
+    puts them); here chunks of 2 and 16 MB under sets of 180 and 12 MB of rows, and the single hipMalloc (0); the set given twice,
+    the second time larger (the range is released and mapped again); every row read back (digests, Pile::data() of the samples)"""
+    ctx = hip_ctx_factory()
+    ctx.set_option("pile_chunk_mb", chunk_mb)
+    for d in (Dataset(600, 60_000, seed), Dataset(n, g, seed)):
+        st = parity.oracle_stages(d)
+        ctx.set_reads(d.read_len)
+        ctx.set_overlaps(d.overlaps)
+        ctx.initialize()
+        parity.check_initialize(ctx, st, d)
+        ctx.construct()
+        parity.check_construct(ctx, st)
+        parity.check_tr(ctx, st)
+
+
+@pytest.mark.parametrize("n,g,seed", [(9000, 1_800_000, 4), (600, 60_000, 9)])
 @pytest.mark.parametrize("opts", [{}, {"use_run_kernel": 0}])
 def test_row_offsets_in_events(hip_ctx_factory, n, g, seed, opts):
     """The partitioned bucketing's row offsets count bound PAIRS since round 6 (2^31 overlaps per context instead of 2^30; every
