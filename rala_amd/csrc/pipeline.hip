@@ -2135,6 +2135,7 @@ int rala_hip_create(int device, rala_hip_ctx** out) {
     if (hipSetDevice(device) != hipSuccess) return RALA_HIP_EDEVICE;
     rala_hip_ctx* ctx = new rala_hip_ctx;
     ctx->device = device;
+    if (const char* mb = getenv("RALA_HIP_PILE_CHUNK_MB")) ctx->pile_chunk_mb = (uint32_t)std::max(0, atoi(mb));      // (measurements: the option's default)
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) {

@@ -4,13 +4,13 @@ line() { python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('%s: %.2f ms, pile chain %.3f ms, frac %.3f, bucketing %.3f, check %s' % ('$1', d['ms_per_step'], d['roofline']['kernel_ms'], d['roofline']['frac'], d['stage_ms']['bucket_ms'], d['result_check']['ok']))"; }
-for i in 1 2 3 4 5; do
-  unset RALA_HIP_PILE_CHUNK_MB
+for i in 1 2 3; do
+  export RALA_HIP_PILE_CHUNK_MB=0
   timeout 300 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-e2e 2>/dev/null | line "hipMalloc $i"
   export RALA_HIP_PILE_CHUNK_MB=1024
   timeout 300 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-e2e 2>/dev/null | line "chunks    $i"
 done
-unset RALA_HIP_PILE_CHUNK_MB
-timeout 300 python bench.py --workload c5 --steps 3 --warmup 1 --no-cpu-baseline --no-e2e 2>/dev/null | line "c5 hipMalloc"
+export RALA_HIP_PILE_CHUNK_MB=0
+
 export RALA_HIP_PILE_CHUNK_MB=1024
-timeout 300 python bench.py --workload c5 --steps 3 --warmup 1 --no-cpu-baseline --no-e2e 2>/dev/null | line "c5 chunks"
+
