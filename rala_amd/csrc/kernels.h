@@ -34,6 +34,7 @@ struct PileArgs {
     const uint32_t* ev;            // pos << 1 | is_end
     const uint32_t* ev_cnt;        // non-null: fixed slots instead of the CSR - read r has ev_cnt[r] events
     uint32_t ev_stride;            //           at ev + r * ev_stride
+    uint32_t rows_chunked = 0;     // the rows lie in mapped chunks (pipeline.hip): the first kernel stores them non-temporally
     uint32_t ev_shift = 0;         // 1: ev_off counts bound PAIRS (the partitioned bucketing, round 6: 2^31 overlaps instead of 2^30)
     const uint32_t* order;         // reads of this launch
     uint32_t n_items;

@@ -648,10 +648,12 @@ __global__ __launch_bounds__(64 * kWaves, kOne ? 7 : kBases > 32768 ? 2 : kBases
     // (round 5: the sensitive pass's cap-1024 kernels too - their reads have at most 16384 bases; 14 296 -> 9 840 B of LDS, sixteen
     // workgroups per compute unit instead of eleven, and at C5 this is the kernel nearly every target starts in)
     constexpr bool kXcdRanges = kOne && kPlain && !(kVar & 8192u);
-    // The rows' stores stay PLAIN.  Non-temporal ones (kVar bit 16) were measured again on top of the XCD ranges, variant against
-    // variant inside one process: 3.69 - 3.71 ms against 3.82 on two boxes (round 5, with the reads as launched: 4.90 against 4.15 -
-    // there the L2 was what put neighbouring rows' lines together), but 3.86 - 3.88 against 3.90 - 3.93 on a third and 4.26 against
-    // 4.11 in that box's slow state: a gain of 0 - 3 % that turns into a loss of 4 % with the state of the box is not a default.
+    // The rows' stores (kVar bits 16 - 17): NON-TEMPORAL where the rows lie in mapped chunks (the launch below picks the
+    // instantiation), plain otherwise.  History: with the reads as launched `nt` was 18 % slower (round 5: the L2 was what put
+    // neighbouring rows' lines together); on top of the XCD ranges it was 3 % faster where one hipMalloc had put the rows well
+    // and 4 % slower where it had not (3.70 against 3.82, 4.26 against 4.11) - not a default; with the rows in chunks of 1 GB
+    // (pipeline.hip), where the placement is the good one every time: **3.51 - 3.57 ms against 3.71 - 3.80** in eight processes on
+    // three boxes, C5 15.2 against 16.2 - the default there.
     constexpr int kRowStoreMod = (int)((kVar >> 16) & 3u);
     constexpr bool kSingleItem = kOne && kWaves > 1 && !(kVar & 1u);
     constexpr bool kSingleItemArgs = kSingleItem && !(kVar & 4u);
@@ -1905,18 +1907,24 @@ void launch_pile_runs(const PileArgs& args, uint32_t grid, int tier, uint32_t* o
             hipLaunchKernelGGL((pile_runs_kernel<kRunEventCap, false, 0, true, 16384, 2, true, var>),                            \
                                dim3(((var) & 8192u) ? (grid + 1) / 2 : 8u * ((args.n_items + 15u) / 16u)), dim3(128),            \
                                extra_lds, stream, args, overflow_list, overflow_count)
+            // the product's choice: non-temporal row stores (65536) where the rows lie in mapped chunks, plain ones (0) where one
+            // hipMalloc holds them; debug_pile_variant = 262144 asks for the plain stores whatever holds the rows
+            constexpr uint32_t kNt = 65536u, kForcePlain = 262144u;
+            uint32_t variant = args.variant == 0 && args.rows_chunked ? kNt : args.variant == kForcePlain ? 0u : args.variant;
 #ifdef RALA_PILE_AB
-#ifndef RALA_PILE_AB_CASES          // (-DRALA_PILE_AB_CASES="X(8) X(11)": the variants a measurement build carries beside 0)
+#ifndef RALA_PILE_AB_CASES          // (-DRALA_PILE_AB_CASES="X(8) X(11)": the variants a measurement build carries beside 0 and 65536)
 #define RALA_PILE_AB_CASES X(1) X(2) X(3) X(4)
 #endif
-            switch (args.variant) {
+            switch (variant) {
 #define X(v) case v: RALA_LAUNCH_PRODUCT(v); break;
                 RALA_PILE_AB_CASES
 #undef X
+                case kNt: RALA_LAUNCH_PRODUCT(65536); break;
                 default: RALA_LAUNCH_PRODUCT(0); break;
             }
 #else
-            RALA_LAUNCH_PRODUCT(0);
+            if (variant == kNt) RALA_LAUNCH_PRODUCT(65536);
+            else RALA_LAUNCH_PRODUCT(0);
 #endif
 #undef RALA_LAUNCH_PRODUCT
         }

@@ -2589,6 +2589,7 @@ static int initialize_stages(rala_hip_ctx* ctx) {
     a.ev_cnt = fixed ? ctx->d_cursor.p : nullptr; a.ev_stride = slot;
     ctx->ev_shift = ev_shift;
     a.ev_shift = ev_shift;
+    a.rows_chunked = ctx->d_pile.reserved ? 1u : 0u;
     a.add_to_existing = 0; a.slab = ctx->d_slab.p;
     a.stop_after = (uint32_t)ctx->debug_pile_stop_after;
     a.variant = ctx->debug_pile_variant;

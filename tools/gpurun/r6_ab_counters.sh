@@ -45,7 +45,7 @@ for v in sorted(per):
                            "resident_wavefronts_per_simd": m.get("SQ_WAVE_CYCLES", 0) * 4.0 / 1024.0 / cycles if "SQ_WAVE_CYCLES" in m else None}
     print("variant", v, "ms %.3f" % out[v]["kernel_ms_under_counters"], json.dumps(out[v]["per_read"]))
 json.dump({"workload": "C3 (1 M reads / 50.86 M overlaps / 10.0 Gbase)", "kernel": "pile_runs_kernel<512, false, 0, true, 16384, 2, true, VARIANT>",
-           "variants": "0 = the product instantiation; bit 0 the loop over the items as in round 5 (56 scalar spills), bit 1 the events by ordinary loads, bit 13 the reads as launched instead of XCD ranges: 8195 = round 5's kernel",
+           "variants": "65536 = the product instantiation (non-temporal row stores: what a launch with variant 0 runs where the rows lie in mapped chunks; 0 = the same with plain stores); bit 0 the loop over the items as in round 5 (56 scalar spills), bit 1 the events by ordinary loads, bit 13 the reads as launched instead of XCD ranges: 8195 = round 5's kernel",
            "note": "rocprofv3 --kernel-trace --pmc over tools/pile_ab.py: every variant inside ONE process and one profiler pass per counter group (what differs between processes - the clock state of the box - cancels); per_read = counter / 10^6 reads; SQ_*_CYCLES, SQ_WAIT_*, SQ_ACTIVE_INST_* count quad-cycles summed over wavefronts",
            "builds": out}, open(sys.argv[1], "w"), indent=1)
 PY

@@ -52,7 +52,8 @@ PY
 rm -rf $OUT/fetch $OUT/write
 # the pile kernel's issue model (product instantiation beside round 5's kernel, one process) and its sensitivity to added work
 R6_FLAGS="'-DRALA_PILE_AB_CASES=X(8195)'" bash tools/gpurun/r6_ab_counters.sh 0,8195 gpurun_out/r06/r06_c3_pile_issue_model.json > $OUT/issue_model.log 2>&1
-R6_PROCS=2 R6_ROUNDS=5 R6_STEPS=4 R6_FLAGS="'-DRALA_PILE_AB_CASES=X(256) X(1280) X(512) X(768) X(1024) X(8192) X(8195) X(1) X(2)'" bash tools/gpurun/r6_ab_inproc.sh 0,256,1280,512,768,1024,8192,8195,1,2 > $OUT/r06_c3_pile_sensitivity.txt 2>&1
+# (0 = the product: non-temporal row stores, the rows in mapped chunks; 262144 = plain stores; 65536 + k = the product with work added)
+R6_PROCS=2 R6_ROUNDS=5 R6_STEPS=4 R6_FLAGS="'-DRALA_PILE_AB_CASES=X(65792) X(66816) X(66048) X(66304) X(66560) X(73728) X(8195) X(65537) X(65538)'" bash tools/gpurun/r6_ab_inproc.sh 0,262144,65792,66816,66048,66304,66560,73728,8195,65537,65538 > $OUT/r06_c3_pile_sensitivity.txt 2>&1
 python3 -c "
 import json
 for f in ('r06_c3_bench','r06_c3s_bench','r06_c5_bench_1gpu','r06_c5s_bench_1gpu','r06_c3_bench_sharded_world1','r06_c5_bench_sharded_world1','r06_c3_bench_8ranks_one_gpu'):
