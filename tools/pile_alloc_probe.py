@@ -23,7 +23,10 @@ keep = []
 for c in range(contexts):
     free, total = torch.cuda.mem_get_info()
     ctx = hip.Context(0)
+    import time as _t
+    _t0 = _t.perf_counter()
     ctx.set_reads(ds.read_len)
+    alloc_ms = (_t.perf_counter() - _t0) * 1e3
     ctx.set_overlaps(ds.overlaps)
     ctx.initialize()
     out = []
@@ -36,7 +39,7 @@ for c in range(contexts):
                 t += ctx.timings()["pile_ms"]
             out.append((v, t / steps))
     per = {v: [t for (w, t) in out if w == v] for v in variants}
-    print("context %d (free before: %.1f GB): %s" % (c, free / 1e9, "  ".join("var %d: %s" % (v, " ".join("%.3f" % t for t in per[v])) for v in variants)), flush=True)
+    print("context %d (free before: %.1f GB, set_reads %.0f ms): %s" % (c, free / 1e9, alloc_ms, "  ".join("var %d: %s" % (v, " ".join("%.3f" % t for t in per[v])) for v in variants)), flush=True)
     ctx.close()
     if c % 2 == 0:
         # a block that stays: the next context's buffers land behind it
