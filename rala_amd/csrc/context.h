@@ -77,7 +77,7 @@ struct DevBuf {
         const size_t n_chunks = (count * sizeof(T) + chunk_bytes - 1) / chunk_bytes;
         const size_t bytes = n_chunks * chunk_bytes;
         void* base = nullptr;
-        e = hipMemAddressReserve(&base, bytes, 0, nullptr, 0);
+        e = hipMemAddressReserve(&base, bytes, 0, nullptr, 0);       // (an alignment asked for here is not honoured: 2 MB whatever)
         if (e != hipSuccess) return e;
         p = (T*)base;
         reserved = bytes;
