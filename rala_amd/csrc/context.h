@@ -39,19 +39,23 @@ struct DevBuf {
     size_t n = 0;
     // (round 6: the buffer as physical chunks mapped side by side into one reserved range - ensure_chunked; the rows of the piles)
     std::vector<hipMemGenericAllocationHandle_t> chunks;
+    std::vector<void*> mapped;          // where chunk i is mapped (null: created, not mapped - a call that failed half way)
     size_t reserved = 0, chunk_size = 0;
     ~DevBuf() { release(); }
     void release() {
         if (reserved) {
             (void)hipDeviceSynchronize();       // (hipFree waits for the device's work by itself; unmapping does not)
-            (void)hipMemUnmap(p, reserved);
-            for (auto h : chunks) (void)hipMemRelease(h);
+            for (size_t i = 0; i < chunks.size(); ++i) {
+                if (mapped[i]) (void)hipMemUnmap(mapped[i], chunk_size);
+                (void)hipMemRelease(chunks[i]);
+            }
             // The RANGE is not given back (hipMemAddressFree): the next reservation would be handed the same addresses, and a
             // kernel of the next context then wrote through translations of the OLD mapping - rows read back as zeros or as another
             // data set's in 3 runs of 8 of tests/test_gpu_parity.py::test_rows_in_mapped_chunks, none in 8 once no address is ever
             // mapped twice.  Address space is what leaks (a context's rows, out of 128 TB); when a reservation fails the caller
             // falls back to hipMalloc.
             chunks.clear();
+            mapped.clear();
             reserved = 0;
             chunk_size = 0;
         } else if (p) {
@@ -90,10 +94,16 @@ struct DevBuf {
         }
         for (size_t i = 0; i < n_chunks && e == hipSuccess; ++i) {
             hipMemGenericAllocationHandle_t h;
+            if (const char* f = getenv("RALA_HIP_DEBUG_CHUNK_FAIL")) {          // tests: the mapping fails at chunk k (the caller falls back)
+                if ((size_t)atoll(f) == i) { e = hipErrorOutOfMemory; break; }
+            }
             e = hipMemCreate(&h, chunk_bytes, &prop, 0);
             if (e != hipSuccess) break;
             chunks.push_back(h);
-            e = hipMemMap((char*)base + ((i * stride) % n_chunks) * chunk_bytes, chunk_bytes, 0, h, 0);
+            mapped.push_back(nullptr);
+            void* at = (char*)base + ((i * stride) % n_chunks) * chunk_bytes;
+            e = hipMemMap(at, chunk_bytes, 0, h, 0);
+            if (e == hipSuccess) mapped.back() = at;
         }
         if (e == hipSuccess) {
             hipMemAccessDesc acc = {};

@@ -143,6 +143,29 @@ def test_rows_in_mapped_chunks(hip_ctx_factory, n, g, seed, chunk_mb):
         parity.check_tr(ctx, st)
 
 
+@pytest.mark.parametrize("fail_at", [0, 3])
+def test_rows_chunks_that_cannot_be_mapped(hip_ctx_factory, monkeypatch, fail_at):
+    """the mapping of the rows' chunks fails (at the first chunk; half way): what was created is unmapped and released, the rows
+    come from one hipMalloc and the result is the same; the device's free memory afterwards is what it was"""
+    import torch
+
+    monkeypatch.setenv("RALA_HIP_DEBUG_CHUNK_FAIL", str(fail_at))
+    ds = Dataset(9000, 1_800_000, 4)
+    st = parity.oracle_stages(ds)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    ctx = hip_ctx_factory()
+    ctx.set_option("pile_chunk_mb", 16)
+    ctx.set_reads(ds.read_len)
+    ctx.set_overlaps(ds.overlaps)
+    ctx.initialize()
+    parity.check_initialize(ctx, st, ds)
+    ctx.close()
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert abs(free0 - free1) < (64 << 20), (free0, free1)
+
+
 @pytest.mark.parametrize("n,g,seed", [(9000, 1_800_000, 4), (600, 60_000, 9)])
 @pytest.mark.parametrize("opts", [{}, {"use_run_kernel": 0}])
 def test_row_offsets_in_events(hip_ctx_factory, n, g, seed, opts):
